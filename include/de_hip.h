@@ -1,0 +1,216 @@
+/*
+ * de_hip.h — C ABI of libde_hip.so: MI355X (gfx950) batched expression-tree
+ * evaluation, the drop-in replacement for the hot path of DynamicExpressions.jl
+ * (reference v2.9.2).  Everything crossing this boundary is plain C: pointers,
+ * sizes, enums.  No C++ exception and no abort crosses it; every entry point
+ * returns a de_status_t.  Numeric failure (NaN/Inf) is DATA, reported through
+ * the per-tree `ok` bytes exactly like the reference's `complete` flag
+ * (reference src/Evaluate.jl:258-262), never through the status code.
+ *
+ * Reference interfaces replaced (file:line in /root/reference):
+ *   de_eval            <- eval_tree_array(tree, cX, operators; eval_context)
+ *                         src/Evaluate.jl:279-309 (+ the Bumper whole-tree override
+ *                         _bumper_eval_tree_array(tree,cX,operators,ctx)->(result,ok),
+ *                         ext/DynamicExpressionsBumperExt.jl:11-49, dispatched at
+ *                         src/Evaluate.jl:300-302 — the plug-in precedent this ABI
+ *                         sits behind)
+ *   de_eval_grad       <- eval_grad_tree_array(tree, cX, operators; variable)
+ *                         src/EvaluateDerivative.jl:193-228
+ *   de_eval_diff       <- eval_diff_tree_array(tree, cX, operators, direction)
+ *                         src/EvaluateDerivative.jl:40-53
+ *   de_eval (n_params>0, params/classes set)
+ *                      <- eval_tree_array(ex::ParametricExpression, X, classes, ops)
+ *                         src/ParametricExpression.jl:371-390
+ *   de_opcode_by_name  <- the OperatorEnum function table, src/OperatorEnum.jl:14-49
+ *
+ * Layouts (identical to the reference so Julia arrays pass zero-copy):
+ *   X    : [n_features, N] column-major, feature index fastest; element (f,j) at
+ *          X[f + ldX*j]  (src/Evaluate.jl:251,716-724), ldX >= n_features.
+ *   out  : population output, row `t` (tree t) at out + t*ld_out, N contiguous
+ *          samples (each row is one reference `Vector{T}(N)`).
+ *   grad : per tree an [n_grad, N] column-major matrix (gradient index fastest),
+ *          entry (k,j) at k + n_grad*j  (src/EvaluateDerivative.jl:355-361).
+ *   ok   : one byte per tree, 1 = complete, 0 = a NaN/Inf was met.
+ *
+ * Memory: the CALLER allocates every buffer.  X/out/grad/ok/params/classes may be
+ * device pointers (hipMalloc / AMDGPU.jl ROCArray / torch) — used in place, the
+ * call is asynchronous on the context's stream — or plain host pointers, in
+ * which case the library stages them through its own device scratch and the
+ * call returns after the results are back in host memory.  The library never
+ * frees or retains caller memory.
+ *
+ * Threading: a de_ctx_t owns one device, one stream and scratch; use one context
+ * per calling thread (as the reference is re-entrant and lock-free).
+ * Different contexts may be used concurrently.
+ */
+#ifndef DE_HIP_H
+#define DE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "de_opcodes.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DE_HIP_ABI_VERSION 1
+
+typedef enum de_status {
+    DE_OK = 0,
+    DE_ERR_INVALID_ARG = 1,    /* null pointer, negative size, bad enum          */
+    DE_ERR_BAD_TAPE = 2,       /* tape is not a well-formed post-order tree      */
+    DE_ERR_UNSUPPORTED_OP = 3, /* opcode outside de_opcodes.h / wrong degree     */
+    DE_ERR_HIP = 4,            /* a HIP runtime call failed (see de_last_error)  */
+    DE_ERR_NO_DEVICE = 5,      /* no gfx950 device visible                       */
+    DE_ERR_OUT_OF_RANGE = 6,   /* feature/param/const/class index out of range   */
+    DE_ERR_UNSUPPORTED = 7     /* valid request this build cannot serve          */
+} de_status_t;
+
+typedef enum de_dtype { DE_F32 = 0, DE_F64 = 1 } de_dtype_t;
+
+/* Gradient modes of eval_grad_tree_array (src/EvaluateDerivative.jl:200-210). */
+typedef enum de_grad_mode {
+    DE_GRAD_VARIABLE = 0, /* variable=true : n_grad = n_features(+n_params)           */
+    DE_GRAD_CONSTANT = 1, /* variable=false: n_grad = count_constant_nodes(tree)     */
+    DE_GRAD_BOTH = 2      /* Val(:both)    : features first, then constants (:220)   */
+} de_grad_mode_t;
+
+/* Option bits = the reference's EvalContext knobs that change RESULTS
+ * (src/Evaluate.jl:156-181).  turbo/bumper/buffer are CPU back-end choices
+ * and have no meaning here, except DE_OPT_BUMPER_CHECKS below. */
+enum de_options {
+    /* EvalContext.early_exit (default true).  The GPU never exits early; the bit
+     * selects the FLAG semantics: with it, `ok` is false iff any value the
+     * reference would have tested is non-finite; without it, only constant
+     * folding can clear `ok` (src/Evaluate.jl:305-308,347-354). */
+    DE_OPT_EARLY_EXIT = 1u << 0,
+    /* The reference's fused 2/3-node kernels decide WHICH leaves are validity
+     * tested and where `Inf` is substituted (src/Evaluate.jl:488-691).  They are
+     * on when use_fused=true and the operator count of that degree is <= 15
+     * (OPERATOR_LIMIT_BEFORE_SLOWDOWN, src/Evaluate.jl:14,496,607). */
+    DE_OPT_FUSE_DEG1 = 1u << 1,
+    DE_OPT_FUSE_DEG2 = 1u << 2,
+    /* Flag semantics of the Bumper whole-tree path instead
+     * (ext/DynamicExpressionsBumperExt.jl:25-36,63): constant leaves tested,
+     * feature leaves never tested, every operator result tested, no folding. */
+    DE_OPT_BUMPER_CHECKS = 1u << 3,
+    DE_OPT_DEFAULT = (1u << 0) | (1u << 1) | (1u << 2)
+};
+
+/* One node of a flattened tree.  A tree is the POST-ORDER sequence of its nodes
+ * (children left to right, then the node; traversal order of tree_mapreduce,
+ * src/base.jl:123-158).  This mirrors Node{T,D}'s fields degree/op/feature
+ * (src/Node.jl:74-90) with 0-based indices. */
+typedef struct de_tape_node {
+    uint8_t degree; /* 0 = leaf, 1..3 = operator arity                               */
+    uint8_t op;     /* degree 0: enum de_leaf_kind; degree >= 1: enum de_opcode      */
+    uint16_t arg;   /* leaf: const slot / feature row / param row (0-based); op: 0  */
+} de_tape_node_t;
+
+typedef struct de_ctx de_ctx_t;
+typedef struct de_program de_program_t;
+
+/* ---- library / registry ------------------------------------------------- */
+int de_abi_version(void);
+int de_opcode_table_version(void);
+/* Julia function name + degree -> opcode id, or -1 (=> caller keeps CPU path).
+ * Names are the Julia spellings: "cos", "exp", "+", "-", "*", "/", "^", "max",
+ * "safe_log", "custom_cos", "pow_abs2", "fma", ...; unary minus is ("-", 1). */
+int de_opcode_by_name(const char *name, int degree);
+/* Inverse of the above; NULL if `opcode` is not in the table. */
+const char *de_opcode_name(int opcode);
+int de_opcode_degree(int opcode); /* 1, 2, 3 or -1 */
+const char *de_status_string(int status);
+
+/* ---- context -------------------------------------------------------------- */
+/* `stream` is a hipStream_t to launch on (caller keeps ownership), or NULL to
+ * let the context create its own non-blocking stream. */
+int de_ctx_create(int device, void *stream, de_ctx_t **out_ctx);
+int de_ctx_destroy(de_ctx_t *ctx);
+int de_ctx_synchronize(de_ctx_t *ctx);
+void *de_ctx_stream(de_ctx_t *ctx);
+const char *de_last_error(de_ctx_t *ctx); /* text of the last failure on this ctx */
+
+/* ---- population program --------------------------------------------------- */
+/* Validate and lower a population of `n_trees` tapes into the device program.
+ *   nodes         all tapes concatenated; tree t = nodes[node_offsets[t] ..
+ *                 node_offsets[t+1])
+ *   consts        all constant pools concatenated (dtype elements); tree t's
+ *                 slot i = consts[const_offsets[t] + i]; slots are in
+ *                 depth-first left-to-right leaf order — the row order of the
+ *                 constant gradient (index_constant_nodes,
+ *                 src/NodeUtils.jl:184-201)
+ *   n_features    rows of X; n_params: rows of the parameter matrix (0 for
+ *                 plain Node trees)
+ * Host pointers only (tapes are host data structures).  Nothing is retained. */
+int de_program_create(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes,
+                      const int64_t *node_offsets, int64_t n_trees, const void *consts,
+                      const int64_t *const_offsets, int32_t n_features, int32_t n_params,
+                      uint32_t options, de_program_t **out_program);
+/* Replace all constants (same counts, same order) without re-flattening: the
+ * optimiser inner loop of get/set_scalar_constants (src/NodeUtils.jl:99-143). */
+int de_program_set_consts(de_program_t *prog, const void *consts);
+int de_program_destroy(de_program_t *prog);
+int64_t de_program_n_trees(const de_program_t *prog);
+/* Sum over trees of count_nodes (src/base.jl:271-280): the node-evals unit. */
+int64_t de_program_n_nodes(const de_program_t *prog);
+/* n_grad of tree t in `mode` (src/EvaluateDerivative.jl:204-210). */
+int64_t de_program_n_grad(const de_program_t *prog, int64_t tree, int mode);
+/* Debug/test hook: copy the lowered instruction words of tree t into `words`
+ * (capacity `cap` 32-bit words); returns the number of words, or -status. */
+int64_t de_program_dump(const de_program_t *prog, int64_t tree, uint32_t *words, int64_t cap,
+                        int which);
+
+/* ---- evaluation ------------------------------------------------------------ */
+/* Optional per-call inputs of a parametric population
+ * (src/ParametricExpression.jl:371-390): value of PARAM leaf p at sample j is
+ * params[p + ld_params*(classes[j]-class_base)]. */
+typedef struct de_param_args {
+    const void *params;     /* [n_params, n_classes] column-major, dtype elements */
+    int64_t ld_params;      /* >= n_params                                          */
+    int64_t n_classes;
+    const void *classes;    /* N class ids                                           */
+    int32_t classes_is_i64; /* 0: int32 ids, 1: int64 ids (Julia Vector{Int})        */
+    int32_t class_base;     /* 1 for Julia callers, 0 for C/Python                   */
+} de_param_args_t;
+
+/* out[t*ld_out + j] = tree_t(X[:, j]),  ok[t] as described above.
+ * `pargs` may be NULL when the program has no PARAM leaves. */
+int de_eval(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, int64_t ldX,
+            const de_param_args_t *pargs, void *out, int64_t ld_out, uint8_t *ok);
+
+/* Forward-mode gradient of every tree.  grad holds, for tree t, an
+ * [n_grad_t, N] column-major matrix starting at element grad_offsets[t]
+ * (host array of n_trees entries), or packed back to back when grad_offsets is
+ * NULL.  Row order: VARIABLE: (params,) features; CONSTANT: constant slots;
+ * BOTH: (params,) features, then constant slots.  `out` may be NULL. */
+int de_eval_grad(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, int64_t ldX,
+                 const de_param_args_t *pargs, int mode, void *out, int64_t ld_out, void *grad,
+                 const int64_t *grad_offsets, uint8_t *ok);
+
+/* Single-direction derivative d tree / d x_direction (0-based feature row):
+ * out, dout are [n_trees, N] with row strides ld_out.  `ok` is always 1 as in
+ * the reference (no validity test on this path, src/EvaluateDerivative.jl:68-119). */
+int de_eval_diff(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, int64_t ldX,
+                 int32_t direction, void *out, void *dout, int64_t ld_out, uint8_t *ok);
+
+/* ---- one-shot convenience with the reference's single-tree signature ------- */
+int de_eval_tree_array(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, int64_t n_nodes,
+                       const void *consts, int64_t n_consts, const void *X, int32_t n_features,
+                       int64_t N, uint32_t options, void *out, uint8_t *ok);
+
+/* ---- measurement hooks (bench.py) ------------------------------------------- */
+/* Device time of the kernels launched by the most recent de_eval* call on this
+ * context, measured with hipEvents recorded on the context's stream.  Blocks
+ * until that work has finished. */
+int de_ctx_last_kernel_ms(de_ctx_t *ctx, float *ms);
+/* Name of the dominant kernel symbol of the most recent call (for matching the
+ * rocprofv3 kernel-trace rows). */
+const char *de_ctx_last_kernel_name(de_ctx_t *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DE_HIP_H */
