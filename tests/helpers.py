@@ -1,0 +1,75 @@
+"""Shared test helpers: S-expression -> Node, golden-case decoding, tolerance model."""
+import json
+import os
+
+import numpy as np
+
+import dynamicexpressions_jl_amd as de
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_golden():
+    with open(os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+def operators_of(case):
+    return de.OperatorEnum(binary_operators=case["binary"], unary_operators=case["unary"],
+                           ternary_operators=case.get("ternary", ()))
+
+
+def sexpr_to_node(s, ops, node_type=de.Node):
+    """["op", child...] | ["x", i] | ["p", i] | number  ->  Node (1-based indices)."""
+    if isinstance(s, (int, float)):
+        return node_type(val=float(s))
+    head = s[0]
+    if head == "x" and len(s) == 2 and isinstance(s[1], int):
+        return node_type(feature=s[1])
+    if head == "p" and len(s) == 2 and isinstance(s[1], int):
+        return de.ParametricNode(parameter=s[1])
+    kids = [sexpr_to_node(c, ops, node_type) for c in s[1:]]
+    return node_type(ops.index(head, len(kids)), *kids)
+
+
+def has_param(s):
+    if isinstance(s, (int, float)):
+        return False
+    if s[0] == "p" and len(s) == 2 and isinstance(s[1], int):
+        return True
+    return any(has_param(c) for c in s[1:] if isinstance(c, list))
+
+
+def case_tree(case):
+    ops = operators_of(case)
+    nt = de.ParametricNode if has_param(case["tree"]) else de.Node
+    return sexpr_to_node(case["tree"], ops, nt), ops
+
+
+def case_X(case):
+    dt = np.dtype(case["dtype"])
+    return np.asfortranarray(np.asarray(case["X"], dtype=np.float64).astype(dt))
+
+
+def case_options(case):
+    o = case.get("options", {})
+    early = o.get("early_exit", True)
+    ops = operators_of(case)
+    f1, f2 = ops.fuse_flags(o.get("use_fused", True))
+    bits = (1 if early else 0) | (2 if f1 else 0) | (4 if f2 else 0) | (8 if o.get("bumper") else 0)
+    return bits
+
+
+def check_values(got, case, what="y"):
+    exp = case["expect"]
+    want = np.asarray(exp[what], dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    nonfinite = exp.get("y_nonfinite_idx", []) if what == "y" else []
+    for i in nonfinite:
+        assert not np.isfinite(got[i]), f"{case['name']}: sample {i} should be non-finite"
+    mask = np.ones(want.shape, dtype=bool)
+    for i in nonfinite:
+        mask[i] = False
+    tol = exp.get("atol", 0) + exp.get("rtol", 0) * np.abs(want[mask])
+    err = np.abs(got[mask] - want[mask])
+    assert np.all(err <= tol), f"{case['name']} ({case['cite']}): max err {err.max()} > tol"
