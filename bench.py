@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path of BASELINE.json on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of eval_tree_array over the whole population: every tree of this rank's
+shard evaluated on every sample of X (already resident in HBM).  Workload at N=1 = the
+configuration BASELINE.json's metric is quoted on: 1000 random depth<=15 20-node trees x
+(5 features x 10^7 samples) Float32 (`--workload C2` gives the 10^6-sample config).  With N
+GPUs the population is tree-sharded (weak scaling: 1000 trees per GPU, X replicated, no
+data-path collective; one RCCL all_gather of the per-tree completion flags per step).
+
+Rank 0 prints ONE JSON line: metric node-evals/s (whole job), plus
+  roofline     — the dominant kernel's ALGORITHMIC bytes (24 B per tree-sample: 20 B of X + 4 B
+                 written) / its average launch duration measured with hipEvents on
+                 the launch stream inside the timed region, against 8 TB/s HBM3E;
+  cpu_baseline — the CPU oracle (C restatement of the reference algorithm, 1 thread) timed on
+                 a bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+BYTES_PER_TREE_SAMPLE = 24.0  # (F + 1) * 4 with F = 5   
+
+WORKLOADS = {
+    "headline": dict(n_trees=1000, N=10**7, desc="1000 random depth<=15 20-node trees x (5 x 10^7) Float32"),
+    "C2": dict(n_trees=1000, N=10**6, desc="1000 random depth<=15 20-node trees x (5 x 10^6) Float32"),
+    "tiny": dict(n_trees=64, N=10**5, desc="64 trees x (5 x 10^5) Float32 (plumbing)"),
+}
+
+
+def cpu_baseline(trees, ops, X_host, budget_s=12.0):
+    """Oracle (kind 'port') on a bounded sample: as many whole trees as fit ~budget_s, at
+    N = 10^6 samples (arrays far larger than L2, like the reference at this scale)."""
+    import dynamicexpressions_jl_amd as de
+    from oracle import oracle
+    t0 = time.perf_counter()
+    nodes = 0
+    used = 0
+    for tree in trees:
+        tape, consts = de.flatten(tree, ops, np.float32)
+        oracle.eval_tree_array(tape, consts, X_host)
+        nodes += len(tape)
+        used += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=nodes * X_host.shape[1] / dt, unit="node-evals/s", cores=1, kind="port",
+                sample=f"first {used} trees x {X_host.shape[1]} samples of the same workload, "
+                       f"oracle/libde_oracle.so (C restatement of src/Evaluate.jl, early exit on), "
+                       f"{dt:.1f} s on {os.cpu_count()} host cores available, 1 used")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import dynamicexpressions_jl_amd as de
+    from dynamicexpressions_jl_amd import api, dist as dedist
+
+    wl = WORKLOADS[args.workload]
+    n_per_gpu, N = wl["n_trees"], wl["N"]
+    ops = de.synth.BENCH_OPERATORS
+    # weak scaling: the job's population is n_per_gpu * world trees, round-robin sharded
+    all_trees = de.synth.random_population(n_per_gpu * world, seed=0xDE02)
+    my_ids = dedist.shard_indices(len(all_trees), rank, world)
+    trees = [all_trees[i] for i in my_ids]
+    total_nodes = sum(de.count_nodes(t) for t in all_trees)
+
+    ctx = api.Context(local_rank)
+    pop = api.Population(trees, ops, np.float32, n_features=5, ctx=ctx)
+    g = torch.Generator(device=dev).manual_seed(1)  # same X on every rank (replicated)
+    X = torch.randn((N, 5), generator=g, device=dev, dtype=torch.float32).t()  # [5, N] feature-fastest
+    out = torch.empty((len(trees), N), device=dev, dtype=torch.float32)
+    ok = torch.empty(len(trees), device=dev, dtype=torch.uint8)
+    lib = api.library()
+
+    def step():
+        ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
+        if world > 1:
+            return dedist.gather_flags(ok, len(all_trees), rank, world)
+        return ok
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        flags = step()
+        kernel_ms.append(None)  # filled below from the per-call hipEvents
+        kernel_ms[-1] = ctx.last_kernel_ms() if args.steps <= 64 else None
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = total_nodes * N * args.steps / elapsed
+        kms = [k for k in kernel_ms if k is not None]
+        k_avg_ms = float(np.mean(kms)) if kms else ms_per_step
+        alg_bytes = BYTES_PER_TREE_SAMPLE * len(trees) * N  # per launch (this rank's shard)
+        achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
+        res = {
+            "metric": "node-evals/sec", "value": value, "unit": "node-evals/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl["desc"], "trees_per_gpu": n_per_gpu, "n_samples": N, "n_features": 5,
+                       "nodes_per_tree": 20, "operators": "+ - / * cos exp", "sharding": f"tree-sharded x{world}",
+                       "complete_fraction": float(flags.float().mean().item())},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": ctx.last_kernel_name(), "kernel_ms_avg": k_avg_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if not args.no_cpu_baseline:
+            Ns = min(N, 10**6)
+            Xh = np.asfortranarray(X[:, :Ns].t().contiguous().cpu().numpy().T)
+            res["cpu_baseline"] = cpu_baseline(all_trees, ops, Xh)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

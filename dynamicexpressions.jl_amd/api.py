@@ -1,0 +1,558 @@
+"""Host-side mirror of the reference's evaluation interface on top of the C ABI.
+
+Same names, argument meaning and error behaviour as the reference for this path:
+
+* ``eval_tree_array(tree, cX, operators; eval_context)``  -> ``(out, complete)``
+  (src/Evaluate.jl:279-309)
+* ``eval_grad_tree_array(tree, cX, operators; variable)`` -> ``(out, grad, complete)``
+  (src/EvaluateDerivative.jl:193-228)
+* ``eval_diff_tree_array(tree, cX, operators, direction)``-> ``(out, dout, complete)``
+  (src/EvaluateDerivative.jl:40-53)
+* ``ParametricExpression`` / ``eval_tree_array(ex, X, classes)``
+  (src/ParametricExpression.jl:371-390)
+* ``tree(X, operators)`` sugar with NaN-fill (src/EvaluationHelpers.jl:29-33) = ``Expression``.
+
+plus the population form the MI355X kernels are built for: ``Population(trees, operators)``
+lowers many trees once and evaluates them all in one launch.
+
+All arithmetic happens in ``csrc/libde_hip.so`` (hand-written gfx950 kernels).  There is NO
+CPU fallback: if the library or a GPU is missing, calls raise ``DeviceError``.
+PyTorch is used only as the owner of device memory / streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from .node import Node, count_constant_nodes, flatten_population, max_feature
+from .operators import OperatorEnum
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libde_hip.so")
+
+DE_F32, DE_F64 = 0, 1
+GRAD_VARIABLE, GRAD_CONSTANT, GRAD_BOTH = 0, 1, 2
+OPT_EARLY_EXIT, OPT_FUSE_DEG1, OPT_FUSE_DEG2, OPT_BUMPER_CHECKS = 1, 2, 4, 8
+
+EXPORTS = [
+    "de_abi_version", "de_opcode_table_version", "de_opcode_by_name", "de_opcode_name",
+    "de_opcode_degree", "de_status_string", "de_ctx_create", "de_ctx_destroy",
+    "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create",
+    "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
+    "de_program_n_grad", "de_program_dump", "de_lower_tape", "de_eval", "de_eval_grad", "de_eval_diff",
+    "de_eval_tree_array", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
+]
+
+
+class DeviceError(RuntimeError):
+    """The HIP library/GPU is unavailable or a de_* call failed.  Never swallowed."""
+
+
+class ParamArgs(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("ld_params", C.c_int64), ("n_classes", C.c_int64),
+                ("classes", C.c_void_p), ("classes_is_i64", C.c_int32), ("class_base", C.c_int32)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def library() -> C.CDLL:
+    """Load libde_hip.so (built by ``__graft_entry__.build()`` / ``csrc/build.sh``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DeviceError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise DeviceError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
+    lib.de_abi_version.restype = C.c_int
+    lib.de_opcode_table_version.restype = C.c_int
+    lib.de_opcode_by_name.argtypes = [C.c_char_p, C.c_int]
+    lib.de_opcode_name.restype = C.c_char_p
+    lib.de_opcode_name.argtypes = [C.c_int]
+    lib.de_opcode_degree.argtypes = [C.c_int]
+    lib.de_status_string.restype = C.c_char_p
+    lib.de_status_string.argtypes = [C.c_int]
+    lib.de_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    lib.de_ctx_destroy.argtypes = [vp]
+    lib.de_ctx_synchronize.argtypes = [vp]
+    lib.de_ctx_stream.restype = vp
+    lib.de_ctx_stream.argtypes = [vp]
+    lib.de_last_error.restype = C.c_char_p
+    lib.de_last_error.argtypes = [vp]
+    lib.de_program_create.argtypes = [vp, C.c_int, vp, vp, i64, vp, vp, i32, i32, u32, C.POINTER(vp)]
+    lib.de_program_set_consts.argtypes = [vp, vp]
+    lib.de_program_destroy.argtypes = [vp]
+    lib.de_program_n_trees.restype = i64
+    lib.de_program_n_trees.argtypes = [vp]
+    lib.de_program_n_nodes.restype = i64
+    lib.de_program_n_nodes.argtypes = [vp]
+    lib.de_program_n_grad.restype = i64
+    lib.de_program_n_grad.argtypes = [vp, i64, C.c_int]
+    lib.de_program_dump.restype = i64
+    lib.de_program_dump.argtypes = [vp, i64, vp, i64, C.c_int]
+    lib.de_lower_tape.restype = i64
+    lib.de_lower_tape.argtypes = [C.c_int, vp, i64, vp, i64, i32, i32, u32, vp, i64, vp]
+    lib.de_eval.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), vp, i64, vp]
+    lib.de_eval_grad.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), C.c_int, vp, i64, vp, vp, vp]
+    lib.de_eval_diff.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, i64, vp]
+    lib.de_eval_tree_array.argtypes = [vp, C.c_int, vp, i64, vp, i64, vp, i32, i64, u32, vp, vp]
+    lib.de_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.de_ctx_last_kernel_name.restype = C.c_char_p
+    lib.de_ctx_last_kernel_name.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def _dtype_code(dtype) -> int:
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return DE_F32
+    if dtype == np.float64:
+        return DE_F64
+    # the reference asserts T in (Float32, Float64) for its accelerated back-ends
+    # (src/Evaluate.jl:287-289)
+    raise TypeError(f"MI355X back-end supports Float32/Float64, got {dtype}")
+
+
+@dataclass
+class EvalContext:
+    """``EvalContext(; turbo, bumper, early_exit, buffer, use_fused)`` (src/Evaluate.jl:156-181).
+
+    ``turbo`` (LoopVectorization) and ``buffer`` (ArrayBuffer arena) choose CPU back-end
+    details that have no device meaning and are accepted for signature compatibility;
+    ``bumper=True`` selects the Bumper path's flag semantics."""
+    turbo: bool = False
+    bumper: bool = False
+    early_exit: bool = True
+    buffer: object = None
+    use_fused: bool = True
+
+    def option_bits(self, operators: OperatorEnum) -> int:
+        f1, f2 = operators.fuse_flags(self.use_fused)
+        return ((OPT_EARLY_EXIT if self.early_exit else 0) | (OPT_FUSE_DEG1 if f1 else 0) |
+                (OPT_FUSE_DEG2 if f2 else 0) | (OPT_BUMPER_CHECKS if self.bumper else 0))
+
+
+class Context:
+    """One ``de_ctx_t``: a device + the stream the kernels are launched on.  By default the
+    stream is torch's current stream for that device, so torch ops and de_* calls order
+    naturally."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        lib = library()
+        if stream is None:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    stream = torch.cuda.current_stream(device).cuda_stream
+            except ImportError:  # pragma: no cover
+                stream = None
+        self._h = C.c_void_p()
+        rc = lib.de_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h))
+        if rc != 0:
+            raise DeviceError(f"de_ctx_create(device={device}) failed: {lib.de_status_string(rc).decode()} "
+                              "(no MI355X visible? there is no CPU fallback)")
+        self.device = device
+
+    def check(self, rc: int) -> None:
+        if rc != 0:
+            lib = library()
+            msg = lib.de_last_error(self._h).decode()
+            name = lib.de_status_string(rc).decode()
+            if rc in (1, 2, 6):
+                raise ValueError(f"{name}: {msg}")
+            if rc == 3:
+                from .operators import UnsupportedOperatorError
+                raise UnsupportedOperatorError(f"{name}: {msg}")
+            raise DeviceError(f"{name}: {msg}")
+
+    def synchronize(self) -> None:
+        self.check(library().de_ctx_synchronize(self._h))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float(0)
+        self.check(library().de_ctx_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def last_kernel_name(self) -> str:
+        return library().de_ctx_last_kernel_name(self._h).decode()
+
+    def close(self) -> None:
+        if self._h:
+            library().de_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device: int = 0) -> Context:
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _prep_X(X, dtype):
+    """Return (pointer, F, N, ldX, keepalive, is_torch).  X is [n_features, N]; memory must
+    be feature-fastest (src/Evaluate.jl:251), i.e. Fortran order for numpy / stride (1, F)
+    for torch."""
+    if _is_torch(X):
+        import torch
+        if X.dim() == 1:  # eval_tree_array(tree, cX::AbstractVector) (src/Evaluate.jl:311-315)
+            X = X.reshape(-1, 1)
+        tdt = torch.float32 if np.dtype(dtype) == np.float32 else torch.float64
+        if X.dtype != tdt:
+            X = X.to(tdt)
+        F, N = X.shape
+        if not (X.stride(0) == 1 and (N <= 1 or X.stride(1) >= F)) and X.numel() > 0:
+            X = X.t().contiguous().t()
+        ld = X.stride(1) if N > 1 else max(F, 1)
+        return X.data_ptr(), F, N, ld, X, True
+    X = np.asarray(X)
+    if X.ndim == 1:
+        X = X.reshape(-1, 1)
+    Xf = np.asfortranarray(X, dtype=dtype)
+    F, N = Xf.shape
+    return Xf.ctypes.data, F, N, max(F, 1), Xf, False
+
+
+def lower_tape(tape, consts, n_features: int, n_params: int = 0, options: int = 7, dtype=np.float32):
+    """Host-only: lower one tape, return (instr[n,4] uint32 words, meta dict).  No GPU needed."""
+    lib = library()
+    dtype = np.dtype(dtype)
+    tape = np.ascontiguousarray(tape)
+    consts = np.ascontiguousarray(consts, dtype=dtype)
+    meta = np.zeros(4, dtype=np.int32)
+    cp = consts.ctypes.data if consts.size else None
+    n = lib.de_lower_tape(_dtype_code(dtype), tape.ctypes.data, len(tape), cp, consts.size, n_features,
+                          n_params, options, None, 0, meta.ctypes.data)
+    if n < 0:
+        code = int(-n)
+        name = lib.de_status_string(code).decode()
+        if code == 3:
+            from .operators import UnsupportedOperatorError
+            raise UnsupportedOperatorError(name)
+        raise ValueError(name)
+    w = np.zeros(max(int(n), 1), dtype=np.uint32)
+    lib.de_lower_tape(_dtype_code(dtype), tape.ctypes.data, len(tape), cp, consts.size, n_features,
+                      n_params, options, w.ctypes.data, w.size, meta.ctypes.data)
+    return w[:int(n)].reshape(-1, 4), dict(n_slots=int(meta[0]), host_ok_eval=bool(meta[1]),
+                                           host_ok_grad=bool(meta[2]), uses_params=bool(meta[3]))
+
+
+class Population:
+    """A population of trees lowered once to a device program (``de_program_t``).
+
+    ``eval(X)`` evaluates every tree on every sample in one launch and returns
+    ``(out[n_trees, N], ok[n_trees])``.  numpy in -> numpy out (staged through the
+    library's device scratch, PCIe-inclusive); torch CUDA tensor in -> torch CUDA tensors out
+    (zero-copy, asynchronous on the current stream)."""
+
+    def __init__(self, trees: Sequence[Node], operators: OperatorEnum, dtype=np.float32,
+                 n_features: Optional[int] = None, n_params: int = 0,
+                 eval_context: Optional[EvalContext] = None, ctx: Optional[Context] = None):
+        self.ctx = ctx or default_context()
+        self.dtype = np.dtype(dtype)
+        self.operators = operators
+        self.eval_context = eval_context or EvalContext()
+        self.n_trees = len(trees)
+        nodes, noff, consts, coff = flatten_population(trees, operators, self.dtype)
+        if n_features is None:
+            n_features = max((max_feature(t) for t in trees), default=0)
+        self.n_features, self.n_params = int(n_features), int(n_params)
+        self.n_consts = np.diff(coff).astype(np.int64)
+        self._h = C.c_void_p()
+        lib = library()
+        self.ctx.check(lib.de_program_create(
+            self.ctx._h, _dtype_code(self.dtype), nodes.ctypes.data, noff.ctypes.data, self.n_trees,
+            consts.ctypes.data if len(consts) else None, coff.ctypes.data, self.n_features, self.n_params,
+            self.eval_context.option_bits(operators), C.byref(self._h)))
+        self.n_nodes = int(lib.de_program_n_nodes(self._h))
+
+    # -- constants (optimiser inner loop, src/NodeUtils.jl:99-143) ------------------
+    def set_constants(self, consts: np.ndarray) -> None:
+        consts = np.ascontiguousarray(consts, dtype=self.dtype)
+        if consts.size != int(self.n_consts.sum()):
+            raise ValueError("wrong number of constants")
+        self.ctx.check(library().de_program_set_consts(self._h, consts.ctypes.data if consts.size else None))
+
+    def n_grad(self, tree: int, mode: int) -> int:
+        return int(library().de_program_n_grad(self._h, tree, mode))
+
+    def dump(self, tree: int) -> np.ndarray:
+        """Lowered instruction words of one tree ([n_instr, 4] uint32) — test hook."""
+        lib = library()
+        n = lib.de_program_dump(self._h, tree, None, 0, 0)
+        w = np.zeros(max(int(n), 1), dtype=np.uint32)
+        got = lib.de_program_dump(self._h, tree, w.ctypes.data, w.size, 0)
+        return w[:int(got)].reshape(-1, 4)
+
+    def meta(self, tree: int) -> dict:
+        w = np.zeros(4, dtype=np.uint32)
+        library().de_program_dump(self._h, tree, w.ctypes.data, 4, 1)
+        return dict(n_slots=int(w[0]), host_ok_eval=bool(w[1]), host_ok_grad=bool(w[2]), uses_params=bool(w[3]))
+
+    # -- evaluation -------------------------------------------------------------------
+    def _param_args(self, params, classes, class_base, N, keep):
+        if self.n_params == 0 and params is None:
+            return None
+        if params is None or classes is None:
+            # src/ParametricExpression.jl:357-359
+            raise ValueError("Incorrect call. You must pass the `classes::Vector` argument when calling `eval_tree_array`.")
+        pa = ParamArgs()
+        if _is_torch(params):
+            import torch
+            tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+            params = params.to(tdt)
+            if params.stride(0) != 1 and params.numel() > 0:
+                params = params.t().contiguous().t()
+            P, ncls = params.shape
+            pa.params, pa.ld_params = params.data_ptr(), (params.stride(1) if ncls > 1 else max(P, 1))
+        else:
+            params = np.asfortranarray(params, dtype=self.dtype)
+            P, ncls = params.shape
+            pa.params, pa.ld_params = params.ctypes.data, max(P, 1)
+        if P != self.n_params:
+            raise ValueError("parameter matrix has the wrong number of rows")
+        if _is_torch(classes):
+            import torch
+            if classes.dtype not in (torch.int32, torch.int64):
+                classes = classes.to(torch.int64)
+            classes = classes.contiguous()
+            n_c, mx = classes.numel(), int(classes.max().item()) if classes.numel() else class_base
+            pa.classes, pa.classes_is_i64 = classes.data_ptr(), int(classes.dtype == torch.int64)
+        else:
+            classes = np.ascontiguousarray(classes)
+            if classes.dtype not in (np.int32, np.int64):
+                classes = classes.astype(np.int64)
+            n_c, mx = classes.size, int(classes.max()) if classes.size else class_base
+            pa.classes, pa.classes_is_i64 = classes.ctypes.data, int(classes.dtype == np.int64)
+        # @assert length(classes) == size(X, 2); @assert maximum(classes) <= n_classes  (:378-379)
+        assert n_c == N, "length(classes) == size(X, 2)"
+        assert mx - class_base < ncls, "maximum(classes) <= size(parameters, 2)"
+        pa.n_classes, pa.class_base = ncls, class_base
+        keep.extend([params, classes])
+        return pa
+
+    def eval(self, X, params=None, classes=None, class_base: int = 1):
+        ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        if F < self.n_features:
+            raise ValueError(f"X has {F} features but the trees use feature {self.n_features}")
+        keep = [keep_x]
+        pa = self._param_args(params, classes, class_base, N, keep)
+        lib = library()
+        if is_t:
+            import torch
+            out = torch.empty((self.n_trees, N), dtype=keep_x.dtype, device=keep_x.device)
+            ok = torch.empty(self.n_trees, dtype=torch.uint8, device=keep_x.device)
+            self.ctx.check(lib.de_eval(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None,
+                                       out.data_ptr(), N, ok.data_ptr()))
+            return out, ok.bool()
+        out = np.empty((self.n_trees, N), dtype=self.dtype)
+        ok = np.zeros(self.n_trees, dtype=np.uint8)
+        self.ctx.check(lib.de_eval(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None,
+                                   out.ctypes.data, N, ok.ctypes.data))
+        return out, ok.astype(bool)
+
+    def eval_grad(self, X, variable: Union[bool, str] = False, params=None, classes=None,
+                  class_base: int = 1):
+        """All trees' forward-mode gradients.  Returns (out[n_trees,N], grads, ok) where
+        grads is a list of per-tree [n_grad_t, N] Fortran-ordered arrays (views of one
+        packed buffer)."""
+        mode = _grad_mode(variable)
+        ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        if F < self.n_features:
+            raise ValueError(f"X has {F} features but the trees use feature {self.n_features}")
+        keep = [keep_x]
+        pa = self._param_args(params, classes, class_base, N, keep)
+        lib = library()
+        ng = np.array([self.n_grad(t, mode) for t in range(self.n_trees)], dtype=np.int64)
+        offs = np.zeros(self.n_trees + 1, dtype=np.int64)
+        np.cumsum(ng * N, out=offs[1:])
+        total = int(offs[-1])
+        if is_t:
+            import torch
+            out = torch.empty((self.n_trees, N), dtype=keep_x.dtype, device=keep_x.device)
+            grad = torch.empty(max(total, 1), dtype=keep_x.dtype, device=keep_x.device)
+            ok = torch.empty(self.n_trees, dtype=torch.uint8, device=keep_x.device)
+            self.ctx.check(lib.de_eval_grad(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None, mode,
+                                            out.data_ptr(), N, grad.data_ptr(), offs.ctypes.data, ok.data_ptr()))
+            grads = [grad[offs[t]:offs[t + 1]].view(N, int(ng[t])).t() for t in range(self.n_trees)]
+            return out, grads, ok.bool()
+        out = np.empty((self.n_trees, N), dtype=self.dtype)
+        grad = np.empty(max(total, 1), dtype=self.dtype)
+        ok = np.zeros(self.n_trees, dtype=np.uint8)
+        self.ctx.check(lib.de_eval_grad(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None, mode,
+                                        out.ctypes.data, N, grad.ctypes.data, offs.ctypes.data, ok.ctypes.data))
+        grads = [grad[offs[t]:offs[t + 1]].reshape((int(ng[t]), N), order="F") for t in range(self.n_trees)]
+        return out, grads, ok.astype(bool)
+
+    def eval_diff(self, X, direction: int):
+        """``direction`` is the 1-based feature index, as in the reference."""
+        ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        lib = library()
+        if is_t:
+            import torch
+            out = torch.empty((self.n_trees, N), dtype=keep_x.dtype, device=keep_x.device)
+            dout = torch.empty_like(out)
+            ok = torch.empty(self.n_trees, dtype=torch.uint8, device=keep_x.device)
+            self.ctx.check(lib.de_eval_diff(self.ctx._h, self._h, ptr, N, ldX, direction - 1, out.data_ptr(),
+                                            dout.data_ptr(), N, ok.data_ptr()))
+            return out, dout, ok.bool()
+        out = np.empty((self.n_trees, N), dtype=self.dtype)
+        dout = np.empty_like(out)
+        ok = np.zeros(self.n_trees, dtype=np.uint8)
+        self.ctx.check(lib.de_eval_diff(self.ctx._h, self._h, ptr, N, ldX, direction - 1, out.ctypes.data,
+                                        dout.ctypes.data, N, ok.ctypes.data))
+        return out, dout, ok.astype(bool)
+
+    def close(self) -> None:
+        if self._h:
+            library().de_program_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _grad_mode(variable) -> int:
+    # variable::Union{Bool,Val}: true | false | Val(:both)   (src/EvaluateDerivative.jl:200-202)
+    if variable is True:
+        return GRAD_VARIABLE
+    if variable is False:
+        return GRAD_CONSTANT
+    if variable in ("both", ":both"):
+        return GRAD_BOTH
+    raise ValueError("variable must be True, False or 'both'")
+
+
+def _x_dtype(X, tree_dtype=None):
+    if _is_torch(X):
+        import torch
+        return np.dtype(np.float64 if X.dtype == torch.float64 else np.float32)
+    dt = np.asarray(X).dtype
+    if dt == np.float64:
+        return np.dtype(np.float64)
+    if dt == np.float32:
+        return np.dtype(np.float32)
+    if dt.kind in "iu":
+        return np.dtype(np.float64)
+    raise TypeError(f"MI355X back-end supports Float32/Float64, got {dt}")
+
+
+def eval_tree_array(tree: Node, cX, operators: OperatorEnum, eval_context: Optional[EvalContext] = None,
+                    ctx: Optional[Context] = None):
+    """``eval_tree_array(tree, cX, operators; eval_context) -> (output, complete)``."""
+    if isinstance(tree, ParametricExpression):
+        raise ValueError("Incorrect call. You must pass the `classes::Vector` argument when calling `eval_tree_array`.")
+    F = np.asarray(cX.shape)[0] if not _is_torch(cX) else cX.shape[0]
+    pop = Population([tree], operators, _x_dtype(cX), n_features=int(F), eval_context=eval_context, ctx=ctx)
+    try:
+        out, ok = pop.eval(cX)
+        return out[0], bool(ok[0])
+    finally:
+        pop.close()
+
+
+def eval_grad_tree_array(tree: Node, cX, operators: OperatorEnum, variable: Union[bool, str] = False,
+                         turbo: bool = False, ctx: Optional[Context] = None):
+    """``eval_grad_tree_array(tree, cX, operators; variable) -> (evaluation, gradient, complete)``."""
+    F = cX.shape[0]
+    pop = Population([tree], operators, _x_dtype(cX), n_features=int(F), ctx=ctx)
+    try:
+        out, grads, ok = pop.eval_grad(cX, variable)
+        return out[0], grads[0], bool(ok[0])
+    finally:
+        pop.close()
+
+
+def eval_diff_tree_array(tree: Node, cX, operators: OperatorEnum, direction: int, turbo: bool = False,
+                         ctx: Optional[Context] = None):
+    """``eval_diff_tree_array(tree, cX, operators, direction) -> (evaluation, derivative, complete)``."""
+    F = cX.shape[0]
+    pop = Population([tree], operators, _x_dtype(cX), n_features=int(F), ctx=ctx)
+    try:
+        out, dout, ok = pop.eval_diff(cX, direction)
+        return out[0], dout[0], bool(ok[0])
+    finally:
+        pop.close()
+
+
+class Expression:
+    """``Expression(tree; operators)`` callable sugar (src/Expression.jl:435-520,
+    src/EvaluationHelpers.jl:29-33): ``ex(X)`` returns the output with NaN-fill when
+    incomplete; validates ``max_feature(ex) <= size(X, 1)`` (:401-409)."""
+
+    def __init__(self, tree: Node, operators: OperatorEnum):
+        self.tree, self.operators = tree, operators
+
+    def __call__(self, X, eval_context: Optional[EvalContext] = None):
+        if max_feature(self.tree) > X.shape[0]:
+            raise ValueError("expression references a feature beyond size(X, 1)")
+        out, ok = eval_tree_array(self.tree, X, self.operators, eval_context)
+        if not ok:
+            out[...] = float("nan")  # set_nan!, src/Utils.jl:73-76
+        return out
+
+    def grad(self, X, variable: Union[bool, str] = True):
+        """``ex'(X)`` (src/EvaluationHelpers.jl:56-62): gradient with NaN-fill."""
+        _, g, ok = eval_grad_tree_array(self.tree, X, self.operators, variable)
+        if not ok:
+            g[...] = float("nan")
+        return g
+
+
+class ParametricExpression:
+    """``ParametricExpression(tree; operators, parameters)`` (src/ParametricExpression.jl:83-116)."""
+
+    def __init__(self, tree: Node, operators: OperatorEnum, parameters):
+        self.tree, self.operators = tree, operators
+        self.parameters = np.asfortranarray(parameters)
+
+    def eval_tree_array(self, X, classes, eval_context: Optional[EvalContext] = None,
+                        ctx: Optional[Context] = None):
+        """``eval_tree_array(ex, X, classes) -> (output, complete)``; classes are 1-based."""
+        dt = _x_dtype(X)
+        pop = Population([self.tree], self.operators, dt, n_features=int(X.shape[0]),
+                         n_params=self.parameters.shape[0], eval_context=eval_context, ctx=ctx)
+        try:
+            out, ok = pop.eval(X, self.parameters.astype(dt), classes, class_base=1)
+            return out[0], bool(ok[0])
+        finally:
+            pop.close()
+
+    def __call__(self, X, classes=None, **kw):
+        if classes is None:
+            raise ValueError("Incorrect call. You must pass the `classes::Vector` argument when calling `eval_tree_array`.")
+        out, ok = self.eval_tree_array(X, classes, **kw)
+        if not ok:
+            out[...] = float("nan")
+        return out
+
+    def get_scalar_constants(self):
+        """tree constants then parameters[:] (src/ParametricExpression.jl:258-267)."""
+        from .node import get_scalar_constants
+        cs, refs = get_scalar_constants(self.tree)
+        return np.concatenate([cs, self.parameters.reshape(-1, order="F")]), refs

@@ -1,0 +1,21 @@
+#!/usr/bin/env bash
+# Builds libde_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+# -ffp-contract=off: Julia never contracts a*b+c, so neither may the kernels.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno -Wall -Wno-unused-function"
+mkdir -p _obj
+build_obj() { # src obj extra...
+  local src=$1 obj=$2; shift 2
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ -n "$(find . ../../include -maxdepth 1 \( -name '*.h' \) -newer "$obj" 2>/dev/null | head -1)" ]; then
+    echo "  hipcc $src"
+    $HIPCC $FLAGS "$@" -c "$src" -o "$obj"
+  fi
+}
+build_obj de_lower.cpp _obj/de_lower.o &
+build_obj de_api.cpp _obj/de_api.o &
+build_obj de_kernels.hip _obj/de_kernels.o ${DE_KERNEL_FLAGS:-} &
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libde_hip.so _obj/de_lower.o _obj/de_api.o _obj/de_kernels.o
+echo "built $(pwd)/libde_hip.so"

@@ -1,0 +1,596 @@
+// de_api.cpp — the C ABI of libde_hip.so (include/de_hip.h): contexts, population
+// programs, evaluation entry points.  No exception leaves this file.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/de_hip.h"
+#include "de_kernels.h"
+#include "de_lower.h"
+
+using namespace de;
+
+// ---------------------------------------------------------------------------
+struct DevBuf { // grow-only device scratch
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t st = hipMalloc(&p, n);
+        if (st == hipSuccess) cap = n;
+        return st;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct de_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::string err;
+    const char *last_kernel = "";
+    DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2;
+};
+
+struct de_program {
+    de_ctx *ctx = nullptr;
+    int dtype = DE_F32;
+    uint32_t options = 0;
+    int32_t n_features = 0, n_params = 0;
+    int64_t n_trees = 0, n_nodes = 0;
+    int n_slots = 0;
+    bool uses_params = false;
+    std::vector<Instr> code;            // host copy (patched by set_consts)
+    std::vector<int32_t> code_off;      // n_trees + 1
+    std::vector<int64_t> const_off;     // n_trees + 1
+    std::vector<int32_t> const_instr;   // per const (global index): global instr index
+    std::vector<uint8_t> const_checks;  // per const: CONST_CHECK_* bits
+    std::vector<int32_t> n_consts_tree; // per tree
+    std::vector<uint8_t> host_ok_eval;  // per tree: constant part of the eval flag
+    std::vector<uint8_t> host_ok_grad;  // per tree: all constants finite
+    std::vector<double> consts;         // current constants as double
+    Instr *d_code = nullptr;
+    int32_t *d_code_off = nullptr;
+    // gradient metadata (device), rebuilt per mode on demand
+    int grad_mode_cached = -1;
+    int64_t *d_grad_off = nullptr;
+    int32_t *d_n_grad = nullptr;
+    std::vector<int64_t> h_grad_off;
+    std::vector<int32_t> h_n_grad;
+};
+
+static int fail(de_ctx *c, int code, const char *fmt, ...) {
+    if (c) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        c->err = buf;
+    }
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t st_ = (expr);                                                             \
+        if (st_ != hipSuccess) {                                                             \
+            (void)hipGetLastError();                                                         \
+            return fail((ctx), DE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(st_)); \
+        }                                                                                    \
+    } while (0)
+
+static bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    hipError_t st = hipPointerGetAttributes(&at, p);
+    if (st != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged
+#if defined(hipMemoryTypeArray)
+           || at.type == hipMemoryTypeArray
+#endif
+        ;
+}
+
+// ---------------------------------------------------------------------------
+// registry
+struct OpName { const char *name; int degree; int code; };
+static const OpName kOps[] = {
+    {"neg", 1, DE_U_NEG}, {"-", 1, DE_U_NEG}, {"abs", 1, DE_U_ABS}, {"square", 1, DE_U_SQUARE},
+    {"cube", 1, DE_U_CUBE}, {"relu", 1, DE_U_RELU}, {"sign", 1, DE_U_SIGN}, {"round", 1, DE_U_ROUND},
+    {"floor", 1, DE_U_FLOOR}, {"ceil", 1, DE_U_CEIL}, {"inv", 1, DE_U_INV}, {"sqrt", 1, DE_U_SQRT},
+    {"cbrt", 1, DE_U_CBRT}, {"exp", 1, DE_U_EXP}, {"exp2", 1, DE_U_EXP2}, {"log", 1, DE_U_LOG},
+    {"log2", 1, DE_U_LOG2}, {"log10", 1, DE_U_LOG10}, {"log1p", 1, DE_U_LOG1P}, {"sin", 1, DE_U_SIN},
+    {"cos", 1, DE_U_COS}, {"tan", 1, DE_U_TAN}, {"sinh", 1, DE_U_SINH}, {"cosh", 1, DE_U_COSH},
+    {"tanh", 1, DE_U_TANH}, {"asin", 1, DE_U_ASIN}, {"acos", 1, DE_U_ACOS}, {"atan", 1, DE_U_ATAN},
+    {"asinh", 1, DE_U_ASINH}, {"acosh", 1, DE_U_ACOSH}, {"atanh", 1, DE_U_ATANH},
+    {"safe_log", 1, DE_U_SAFE_LOG}, {"safe_log2", 1, DE_U_SAFE_LOG2}, {"safe_log10", 1, DE_U_SAFE_LOG10},
+    {"safe_log1p", 1, DE_U_SAFE_LOG1P}, {"safe_sqrt", 1, DE_U_SAFE_SQRT},
+    {"safe_acosh", 1, DE_U_SAFE_ACOSH}, {"custom_cos", 1, DE_U_COS2}, {"gamma", 1, DE_U_GAMMA},
+    {"+", 2, DE_B_ADD}, {"add", 2, DE_B_ADD}, {"-", 2, DE_B_SUB}, {"sub", 2, DE_B_SUB},
+    {"*", 2, DE_B_MUL}, {"mult", 2, DE_B_MUL}, {"/", 2, DE_B_DIV}, {"div", 2, DE_B_DIV},
+    {"^", 2, DE_B_POW}, {"pow", 2, DE_B_POW}, {"max", 2, DE_B_MAX}, {"min", 2, DE_B_MIN},
+    {"mod", 2, DE_B_MOD}, {"rem", 2, DE_B_REM}, {"greater", 2, DE_B_GREATER},
+    {"pow_abs2", 2, DE_B_POW_ABS2},
+    {"fma", 3, DE_T_FMA}, {"clamp", 3, DE_T_CLAMP}, {"+", 3, DE_T_ADD3}, {"max", 3, DE_T_MAX3},
+};
+
+extern "C" {
+
+int de_abi_version(void) { return DE_HIP_ABI_VERSION; }
+int de_opcode_table_version(void) { return DE_OPCODE_TABLE_VERSION; }
+
+int de_opcode_by_name(const char *name, int degree) {
+    if (!name) return -1;
+    for (const OpName &o : kOps)
+        if (o.degree == degree && std::strcmp(o.name, name) == 0) return o.code;
+    return -1;
+}
+const char *de_opcode_name(int opcode) {
+    for (const OpName &o : kOps)
+        if (o.code == opcode && !(o.code == DE_U_NEG && o.name[0] == '-')) return o.name;
+    return nullptr;
+}
+int de_opcode_degree(int opcode) {
+    if (opcode >= DE_U_NEG && opcode < DE_U_LAST_) return 1;
+    if (opcode >= DE_B_ADD && opcode < DE_B_LAST_) return 2;
+    if (opcode >= DE_T_FMA && opcode < DE_T_LAST_) return 3;
+    return -1;
+}
+const char *de_status_string(int s) {
+    switch (s) {
+    case DE_OK: return "ok";
+    case DE_ERR_INVALID_ARG: return "invalid argument";
+    case DE_ERR_BAD_TAPE: return "malformed tape";
+    case DE_ERR_UNSUPPORTED_OP: return "unsupported operator";
+    case DE_ERR_HIP: return "HIP runtime error";
+    case DE_ERR_NO_DEVICE: return "no gfx950 device";
+    case DE_ERR_OUT_OF_RANGE: return "index out of range";
+    case DE_ERR_UNSUPPORTED: return "unsupported request";
+    default: return "unknown status";
+    }
+}
+
+// ---------------------------------------------------------------------------
+int de_ctx_create(int device, void *stream, de_ctx_t **out_ctx) {
+    if (!out_ctx) return DE_ERR_INVALID_ARG;
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return DE_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return DE_ERR_INVALID_ARG;
+    de_ctx *c = new (std::nothrow) de_ctx();
+    if (!c) return DE_ERR_HIP;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete c;
+        return DE_ERR_HIP;
+    }
+    if (stream) {
+        c->stream = static_cast<hipStream_t>(stream);
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return DE_ERR_HIP;
+        }
+        c->own_stream = true;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return DE_ERR_HIP;
+    }
+    *out_ctx = c;
+    return DE_OK;
+}
+
+int de_ctx_destroy(de_ctx_t *c) {
+    if (!c) return DE_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2}) b->release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return DE_OK;
+}
+
+int de_ctx_synchronize(de_ctx_t *c) {
+    if (!c) return DE_ERR_INVALID_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DE_OK;
+}
+void *de_ctx_stream(de_ctx_t *c) { return c ? c->stream : nullptr; }
+const char *de_last_error(de_ctx_t *c) { return c ? c->err.c_str() : "null context"; }
+
+int de_ctx_last_kernel_ms(de_ctx_t *c, float *ms) {
+    if (!c || !ms) return DE_ERR_INVALID_ARG;
+    if (!c->timed) return fail(c, DE_ERR_INVALID_ARG, "no timed launch on this context yet");
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return DE_OK;
+}
+const char *de_ctx_last_kernel_name(de_ctx_t *c) { return c ? c->last_kernel : ""; }
+
+// ---------------------------------------------------------------------------
+static void write_imm(Instr &ins, int dtype, double v) {
+    if (dtype == DE_F32) {
+        ins.imm.u32[1] = 0;
+        ins.imm.f32 = (float)v;
+    } else ins.imm.f64 = v;
+}
+static bool finite_in(int dtype, double v) { return dtype == DE_F32 ? std::isfinite((float)v) : std::isfinite(v); }
+
+static void recompute_host_ok(de_program *p) {
+    const bool ee = (p->options & DE_OPT_EARLY_EXIT) != 0;
+    for (int64_t t = 0; t < p->n_trees; t++) {
+        bool ok_eval = true, ok_grad = true;
+        for (int64_t k = p->const_off[t]; k < p->const_off[t + 1]; k++) {
+            const bool fin = finite_in(p->dtype, p->consts[k]);
+            ok_grad = ok_grad && fin;
+            const uint8_t ch = p->const_checks[k];
+            if (!fin && ((ch & CONST_CHECK_ALWAYS) || (ee && (ch & CONST_CHECK_EE)))) ok_eval = false;
+        }
+        p->host_ok_eval[t] = ok_eval;
+        p->host_ok_grad[t] = ok_grad;
+    }
+}
+
+int de_program_create(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, const int64_t *node_offsets,
+                      int64_t n_trees, const void *consts, const int64_t *const_offsets,
+                      int32_t n_features, int32_t n_params, uint32_t options, de_program_t **out_program) {
+    if (!ctx) return DE_ERR_INVALID_ARG;
+    if (!out_program) return fail(ctx, DE_ERR_INVALID_ARG, "out_program is null");
+    *out_program = nullptr;
+    if (dtype != DE_F32 && dtype != DE_F64) return fail(ctx, DE_ERR_INVALID_ARG, "dtype must be DE_F32 or DE_F64");
+    if (n_trees < 0 || n_features < 0 || n_params < 0 || n_features > 65535 || n_params > 65535)
+        return fail(ctx, DE_ERR_INVALID_ARG, "bad sizes");
+    if (n_trees > 0 && (!nodes || !node_offsets || !const_offsets))
+        return fail(ctx, DE_ERR_INVALID_ARG, "null tape pointers");
+    if (n_trees > 0x7fffffff) return fail(ctx, DE_ERR_UNSUPPORTED, "too many trees");
+    std::unique_ptr<de_program> p(new (std::nothrow) de_program());
+    if (!p) return fail(ctx, DE_ERR_HIP, "out of host memory");
+    try {
+        p->ctx = ctx;
+        p->dtype = dtype;
+        p->options = options;
+        p->n_features = n_features;
+        p->n_params = n_params;
+        p->n_trees = n_trees;
+        LowerOptions lo;
+        lo.early_exit = (options & DE_OPT_EARLY_EXIT) != 0;
+        lo.fuse1 = (options & DE_OPT_FUSE_DEG1) != 0;
+        lo.fuse2 = (options & DE_OPT_FUSE_DEG2) != 0;
+        lo.bumper = (options & DE_OPT_BUMPER_CHECKS) != 0;
+        lo.n_features = n_features;
+        lo.n_params = n_params;
+        lo.dtype = dtype;
+        p->code_off.assign((size_t)n_trees + 1, 0);
+        p->const_off.assign((size_t)n_trees + 1, 0);
+        p->n_consts_tree.assign((size_t)n_trees, 0);
+        p->host_ok_eval.assign((size_t)n_trees, 1);
+        p->host_ok_grad.assign((size_t)n_trees, 1);
+        const int64_t total_consts = n_trees ? const_offsets[n_trees] - const_offsets[0] : 0;
+        if (total_consts < 0) return fail(ctx, DE_ERR_INVALID_ARG, "const_offsets not monotone");
+        if (total_consts > 0 && !consts) return fail(ctx, DE_ERR_INVALID_ARG, "consts is null");
+        p->consts.resize((size_t)total_consts);
+        p->const_instr.assign((size_t)total_consts, -1);
+        p->const_checks.assign((size_t)total_consts, 0);
+        TreeProgram tp;
+        std::string why;
+        for (int64_t t = 0; t < n_trees; t++) {
+            const int64_t n0 = node_offsets[t], n1 = node_offsets[t + 1];
+            const int64_t c0 = const_offsets[t], c1 = const_offsets[t + 1];
+            if (n1 < n0 || c1 < c0) return fail(ctx, DE_ERR_INVALID_ARG, "offsets not monotone at tree %lld", (long long)t);
+            int rc = lower_tree(nodes + n0, n1 - n0, c1 - c0, lo, &tp, &why);
+            if (rc != DE_OK) return fail(ctx, rc, "tree %lld: %s", (long long)t, why.c_str());
+            const int64_t cb = c0 - const_offsets[0];
+            p->const_off[(size_t)t] = cb;
+            p->const_off[(size_t)t + 1] = cb + (c1 - c0);
+            p->n_consts_tree[(size_t)t] = (int32_t)(c1 - c0);
+            const int32_t ib = (int32_t)p->code.size();
+            for (int64_t k = 0; k < c1 - c0; k++) {
+                const double v = dtype == DE_F32 ? (double)static_cast<const float *>(consts)[c0 + k]
+                                                 : static_cast<const double *>(consts)[c0 + k];
+                p->consts[(size_t)(cb + k)] = v;
+                p->const_instr[(size_t)(cb + k)] = ib + tp.const_instr[(size_t)k];
+                p->const_checks[(size_t)(cb + k)] = tp.const_checks[(size_t)k];
+                write_imm(tp.code[(size_t)tp.const_instr[(size_t)k]], dtype, v);
+            }
+            p->code.insert(p->code.end(), tp.code.begin(), tp.code.end());
+            p->code_off[(size_t)t + 1] = (int32_t)p->code.size();
+            p->n_slots = std::max(p->n_slots, tp.n_slots);
+            p->uses_params = p->uses_params || tp.uses_params;
+            p->n_nodes += n1 - n0;
+            if (p->code.size() > 0x7fff0000u) return fail(ctx, DE_ERR_UNSUPPORTED, "program too large");
+        }
+        recompute_host_ok(p.get());
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, DE_ERR_HIP, "out of host memory");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t cbytes = std::max<size_t>(p->code.size(), 1) * sizeof(Instr);
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->d_code), cbytes));
+    hipError_t st = hipMalloc(reinterpret_cast<void **>(&p->d_code_off), p->code_off.size() * sizeof(int32_t));
+    if (st != hipSuccess) {
+        (void)hipFree(p->d_code);
+        return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(st));
+    }
+    if (!p->code.empty()) st = hipMemcpy(p->d_code, p->code.data(), p->code.size() * sizeof(Instr), hipMemcpyHostToDevice);
+    if (st == hipSuccess)
+        st = hipMemcpy(p->d_code_off, p->code_off.data(), p->code_off.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (st != hipSuccess) {
+        (void)hipFree(p->d_code);
+        (void)hipFree(p->d_code_off);
+        return fail(ctx, DE_ERR_HIP, "program upload failed: %s", hipGetErrorString(st));
+    }
+    *out_program = p.release();
+    return DE_OK;
+}
+
+int de_program_set_consts(de_program_t *p, const void *consts) {
+    if (!p) return DE_ERR_INVALID_ARG;
+    de_ctx *ctx = p->ctx;
+    if (!consts && !p->consts.empty()) return fail(ctx, DE_ERR_INVALID_ARG, "consts is null");
+    for (size_t k = 0; k < p->consts.size(); k++) {
+        const double v = p->dtype == DE_F32 ? (double)static_cast<const float *>(consts)[k]
+                                            : static_cast<const double *>(consts)[k];
+        p->consts[k] = v;
+        write_imm(p->code[(size_t)p->const_instr[k]], p->dtype, v);
+    }
+    recompute_host_ok(p);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the program may be in use by work already queued on the stream
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (!p->code.empty())
+        HIP_TRY(ctx, hipMemcpy(p->d_code, p->code.data(), p->code.size() * sizeof(Instr), hipMemcpyHostToDevice));
+    return DE_OK;
+}
+
+int de_program_destroy(de_program_t *p) {
+    if (!p) return DE_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->d_code) (void)hipFree(p->d_code);
+    if (p->d_code_off) (void)hipFree(p->d_code_off);
+    if (p->d_grad_off) (void)hipFree(p->d_grad_off);
+    if (p->d_n_grad) (void)hipFree(p->d_n_grad);
+    delete p;
+    return DE_OK;
+}
+
+int64_t de_program_n_trees(const de_program_t *p) { return p ? p->n_trees : -1; }
+int64_t de_program_n_nodes(const de_program_t *p) { return p ? p->n_nodes : -1; }
+int64_t de_program_n_grad(const de_program_t *p, int64_t tree, int mode) {
+    if (!p || tree < 0 || tree >= p->n_trees) return -1;
+    const int64_t nc = p->n_consts_tree[(size_t)tree];
+    const int64_t nv = (int64_t)p->n_features + p->n_params;
+    switch (mode) {
+    case DE_GRAD_VARIABLE: return nv;
+    case DE_GRAD_CONSTANT: return nc;
+    case DE_GRAD_BOTH: return nv + nc;
+    default: return -1;
+    }
+}
+
+int64_t de_program_dump(const de_program_t *p, int64_t tree, uint32_t *words, int64_t cap, int which) {
+    if (!p || tree < 0 || tree >= p->n_trees) return -DE_ERR_INVALID_ARG;
+    if (which == 1) { // metadata: n_slots, host_ok_eval, host_ok_grad, uses_params
+        if (cap < 4) return -DE_ERR_INVALID_ARG;
+        words[0] = (uint32_t)p->n_slots;
+        words[1] = p->host_ok_eval[(size_t)tree];
+        words[2] = p->host_ok_grad[(size_t)tree];
+        words[3] = p->uses_params;
+        return 4;
+    }
+    const int32_t i0 = p->code_off[(size_t)tree], i1 = p->code_off[(size_t)tree + 1];
+    const int64_t nw = (int64_t)(i1 - i0) * 4;
+    if (!words || cap < nw) return nw;
+    std::memcpy(words, p->code.data() + i0, (size_t)nw * 4);
+    return nw;
+}
+
+int64_t de_lower_tape(int dtype, const de_tape_node_t *nodes, int64_t n_nodes, const void *consts,
+                      int64_t n_consts, int32_t n_features, int32_t n_params, uint32_t options, uint32_t *words,
+                      int64_t cap, int32_t *meta) {
+    if (!nodes || (dtype != DE_F32 && dtype != DE_F64) || (n_consts > 0 && !consts)) return -DE_ERR_INVALID_ARG;
+    try {
+        LowerOptions lo;
+        lo.early_exit = (options & DE_OPT_EARLY_EXIT) != 0;
+        lo.fuse1 = (options & DE_OPT_FUSE_DEG1) != 0;
+        lo.fuse2 = (options & DE_OPT_FUSE_DEG2) != 0;
+        lo.bumper = (options & DE_OPT_BUMPER_CHECKS) != 0;
+        lo.n_features = n_features;
+        lo.n_params = n_params;
+        lo.dtype = dtype;
+        TreeProgram tp;
+        std::string why;
+        int rc = lower_tree(nodes, n_nodes, n_consts, lo, &tp, &why);
+        if (rc != DE_OK) return -rc;
+        bool ok_eval = true, ok_grad = true;
+        for (int64_t k = 0; k < n_consts; k++) {
+            const double v = dtype == DE_F32 ? (double)static_cast<const float *>(consts)[k]
+                                             : static_cast<const double *>(consts)[k];
+            write_imm(tp.code[(size_t)tp.const_instr[(size_t)k]], dtype, v);
+            const bool fin = finite_in(dtype, v);
+            ok_grad = ok_grad && fin;
+            const uint8_t ch = tp.const_checks[(size_t)k];
+            if (!fin && ((ch & CONST_CHECK_ALWAYS) || (lo.early_exit && (ch & CONST_CHECK_EE)))) ok_eval = false;
+        }
+        if (meta) {
+            meta[0] = tp.n_slots;
+            meta[1] = ok_eval;
+            meta[2] = ok_grad;
+            meta[3] = tp.uses_params;
+        }
+        const int64_t nw = (int64_t)tp.code.size() * 4;
+        if (!words || cap < nw) return nw;
+        std::memcpy(words, tp.code.data(), (size_t)nw * 4);
+        return nw;
+    } catch (const std::bad_alloc &) {
+        return -DE_ERR_HIP;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Stage a caller buffer: device pointers are used in place; host pointers are
+// copied into context scratch (and copied back by the caller of this helper).
+struct Staged {
+    void *dev = nullptr;
+    bool staged = false;
+};
+static int stage_in(de_ctx *c, DevBuf &buf, const void *user, size_t bytes, Staged *s) {
+    s->dev = const_cast<void *>(user);
+    s->staged = false;
+    if (!user || bytes == 0 || is_device_ptr(user)) return DE_OK;
+    HIP_TRY(c, buf.reserve(bytes));
+    HIP_TRY(c, hipMemcpyAsync(buf.p, user, bytes, hipMemcpyHostToDevice, c->stream));
+    s->dev = buf.p;
+    s->staged = true;
+    return DE_OK;
+}
+static int stage_out(de_ctx *c, DevBuf &buf, void *user, size_t bytes, Staged *s) {
+    s->dev = user;
+    s->staged = false;
+    if (!user || bytes == 0 || is_device_ptr(user)) return DE_OK;
+    HIP_TRY(c, buf.reserve(bytes));
+    s->dev = buf.p;
+    s->staged = true;
+    return DE_OK;
+}
+
+static int check_param_args(de_ctx *c, const de_program *p, const de_param_args_t *pa) {
+    if (!p->uses_params) return DE_OK;
+    if (!pa || !pa->params || !pa->classes)
+        return fail(c, DE_ERR_INVALID_ARG, "program has parameter leaves: params/classes required "
+                                           "(reference: \"You must pass the `classes::Vector` argument\")");
+    if (pa->ld_params < p->n_params || pa->n_classes <= 0) return fail(c, DE_ERR_INVALID_ARG, "bad parameter matrix shape");
+    return DE_OK;
+}
+
+int de_eval(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
+            void *out, int64_t ld_out, uint8_t *ok) {
+    if (!c || !p) return DE_ERR_INVALID_ARG;
+    if (p->ctx != c) return fail(c, DE_ERR_INVALID_ARG, "program belongs to another context");
+    if (N < 0 || !ok || (p->n_trees > 0 && N > 0 && (!X || !out))) return fail(c, DE_ERR_INVALID_ARG, "null buffer");
+    if (ldX < p->n_features || ld_out < N) return fail(c, DE_ERR_INVALID_ARG, "ldX < n_features or ld_out < N");
+    int rc = check_param_args(c, p, pa);
+    if (rc != DE_OK) return rc;
+    if (p->n_trees == 0) return DE_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t es = p->dtype == DE_F32 ? 4 : 8;
+    const bool ok_dev = is_device_ptr(ok);
+    if (N == 0) { // nothing to evaluate: only the constant part of the flag (sum(empty) is finite)
+        if (ok_dev) HIP_TRY(c, hipMemcpyAsync(ok, p->host_ok_eval.data(), (size_t)p->n_trees, hipMemcpyHostToDevice, c->stream));
+        else std::memcpy(ok, p->host_ok_eval.data(), (size_t)p->n_trees);
+        return DE_OK;
+    }
+    int K = 0;
+    if (eval_lds_bytes(p->dtype, p->n_features, p->n_slots, &K) == 0)
+        return fail(c, DE_ERR_UNSUPPORTED, "n_features=%d does not fit the LDS-staged kernel", p->n_features);
+
+    Staged sX, sOut, sOk, sPar, sCls;
+    rc = stage_in(c, c->sX, X, (size_t)ldX * (size_t)N * es, &sX);
+    if (rc) return rc;
+    rc = stage_out(c, c->sOut, out, ((size_t)(p->n_trees - 1) * (size_t)ld_out + (size_t)N) * es, &sOut);
+    if (rc) return rc;
+    // ok[] starts as the host-side (constant) part of the flag; the kernel only clears bytes
+    if (ok_dev) {
+        sOk.dev = ok;
+    } else {
+        HIP_TRY(c, c->sOk.reserve((size_t)p->n_trees));
+        sOk.dev = c->sOk.p;
+        sOk.staged = true;
+    }
+    HIP_TRY(c, hipMemcpyAsync(sOk.dev, p->host_ok_eval.data(), (size_t)p->n_trees, hipMemcpyHostToDevice, c->stream));
+    if (p->uses_params) {
+        rc = stage_in(c, c->sParams, pa->params, (size_t)pa->ld_params * (size_t)pa->n_classes * es, &sPar);
+        if (rc) return rc;
+        rc = stage_in(c, c->sClasses, pa->classes, (size_t)N * (pa->classes_is_i64 ? 8 : 4), &sCls);
+        if (rc) return rc;
+    }
+    EvalArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.code = p->d_code;
+    a.code_off = p->d_code_off;
+    a.n_trees = (int32_t)p->n_trees;
+    a.n_slots = p->n_slots;
+    a.uses_params = p->uses_params;
+    a.X = sX.dev;
+    a.N = N;
+    a.ldX = ldX;
+    a.F = p->n_features;
+    a.out = sOut.dev;
+    a.ld_out = ld_out;
+    a.ok = static_cast<uint8_t *>(sOk.dev);
+    if (p->uses_params) {
+        a.params = sPar.dev;
+        a.ld_params = pa->ld_params;
+        a.classes = sCls.dev;
+        a.classes_is_i64 = pa->classes_is_i64;
+        a.class_base = pa->class_base;
+    }
+    a.early_exit = (p->options & DE_OPT_EARLY_EXIT) != 0;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(c, launch_eval(p->dtype, a, c->stream, &c->last_kernel));
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    if (sOut.staged) {
+        for (int64_t t = 0; t < p->n_trees; t++) // rows may be strided in the caller's buffer
+            HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(out) + (size_t)t * (size_t)ld_out * es,
+                                      static_cast<char *>(sOut.dev) + (size_t)t * (size_t)ld_out * es,
+                                      (size_t)N * es, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (sOk.staged) HIP_TRY(c, hipMemcpyAsync(ok, sOk.dev, (size_t)p->n_trees, hipMemcpyDeviceToHost, c->stream));
+    if (sX.staged || sOut.staged || sOk.staged || sPar.staged || sCls.staged) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DE_OK;
+}
+
+int de_eval_tree_array(de_ctx_t *c, int dtype, const de_tape_node_t *nodes, int64_t n_nodes, const void *consts,
+                       int64_t n_consts, const void *X, int32_t n_features, int64_t N, uint32_t options, void *out,
+                       uint8_t *ok) {
+    if (!c) return DE_ERR_INVALID_ARG;
+    const int64_t noff[2] = {0, n_nodes}, coff[2] = {0, n_consts};
+    de_program_t *p = nullptr;
+    int rc = de_program_create(c, dtype, nodes, noff, 1, consts, coff, n_features, 0, options, &p);
+    if (rc != DE_OK) return rc;
+    rc = de_eval(c, p, X, N, n_features, nullptr, out, N, ok);
+    if (rc == DE_OK) rc = de_ctx_synchronize(c);
+    de_program_destroy(p);
+    return rc;
+}
+
+int de_eval_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
+                 int mode, void *out, int64_t ld_out, void *grad, const int64_t *grad_offsets, uint8_t *ok) {
+    (void)p; (void)X; (void)N; (void)ldX; (void)pa; (void)mode; (void)out; (void)ld_out; (void)grad;
+    (void)grad_offsets; (void)ok;
+    return fail(c, DE_ERR_UNSUPPORTED, "de_eval_grad: not built yet");
+}
+
+int de_eval_diff(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, int32_t direction, void *out,
+                 void *dout, int64_t ld_out, uint8_t *ok) {
+    (void)p; (void)X; (void)N; (void)ldX; (void)direction; (void)out; (void)dout; (void)ld_out; (void)ok;
+    return fail(c, DE_ERR_UNSUPPORTED, "de_eval_diff: not built yet");
+}
+
+} // extern "C"

@@ -1,0 +1,136 @@
+// de_device_ops.h — scalar operator semantics on gfx950 (device side).
+//
+// Same contract as oracle/de_oracle_ops.h (the CPU restatement): Julia Base
+// semantics for every opcode of include/de_opcodes.h; NaN where Julia throws
+// DomainError.  IEEE-exact operators are plain VALU instructions (compiled with
+// -ffp-contract=off so a*b+c is never fused: Julia does not contract);
+// transcendentals are the ROCm device-library (OCML) implementations, which are
+// accurate to 1-2 ulp — inside the 1e-5 (f32) relative tolerance of the path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/de_opcodes.h"
+#include "de_program.h"
+
+namespace de {
+
+template <typename T> struct M; // math traits
+
+template <> struct M<float> {
+    using T = float;
+    static __device__ __forceinline__ T abs(T x) { return fabsf(x); }
+    static __device__ __forceinline__ T sqrt(T x) { return sqrtf(x); }
+    static __device__ __forceinline__ T cbrt(T x) { return cbrtf(x); }
+    static __device__ __forceinline__ T exp(T x) { return expf(x); }
+    static __device__ __forceinline__ T exp2(T x) { return exp2f(x); }
+    static __device__ __forceinline__ T log(T x) { return logf(x); }
+    static __device__ __forceinline__ T log2(T x) { return log2f(x); }
+    static __device__ __forceinline__ T log10(T x) { return log10f(x); }
+    static __device__ __forceinline__ T log1p(T x) { return log1pf(x); }
+    static __device__ __forceinline__ T sin(T x) { return sinf(x); }
+    static __device__ __forceinline__ T cos(T x) { return cosf(x); }
+    static __device__ __forceinline__ T tan(T x) { return tanf(x); }
+    static __device__ __forceinline__ T sinh(T x) { return sinhf(x); }
+    static __device__ __forceinline__ T cosh(T x) { return coshf(x); }
+    static __device__ __forceinline__ T tanh(T x) { return tanhf(x); }
+    static __device__ __forceinline__ T asin(T x) { return asinf(x); }
+    static __device__ __forceinline__ T acos(T x) { return acosf(x); }
+    static __device__ __forceinline__ T atan(T x) { return atanf(x); }
+    static __device__ __forceinline__ T asinh(T x) { return asinhf(x); }
+    static __device__ __forceinline__ T acosh(T x) { return acoshf(x); }
+    static __device__ __forceinline__ T atanh(T x) { return atanhf(x); }
+    static __device__ __forceinline__ T tgamma(T x) { return tgammaf(x); }
+    static __device__ __forceinline__ T pow(T x, T y) { return powf(x, y); }
+    static __device__ __forceinline__ T fmod(T x, T y) { return fmodf(x, y); }
+    static __device__ __forceinline__ T rint(T x) { return rintf(x); }
+    static __device__ __forceinline__ T floor(T x) { return floorf(x); }
+    static __device__ __forceinline__ T ceil(T x) { return ceilf(x); }
+    static __device__ __forceinline__ T trunc(T x) { return truncf(x); }
+    static __device__ __forceinline__ T fma(T x, T y, T z) { return fmaf(x, y, z); }
+    static __device__ __forceinline__ T copysign(T x, T y) { return copysignf(x, y); }
+    static __device__ __forceinline__ T inf() { return __builtin_inff(); }
+    static __device__ __forceinline__ T nan() { return __builtin_nanf(""); }
+    static __device__ __forceinline__ bool isfinite(T x) { return __builtin_isfinite(x); }
+    static __device__ __forceinline__ bool signbit(T x) { return __builtin_signbit(x); }
+};
+
+template <> struct M<double> {
+    using T = double;
+    static __device__ __forceinline__ T abs(T x) { return ::fabs(x); }
+    static __device__ __forceinline__ T sqrt(T x) { return ::sqrt(x); }
+    static __device__ __forceinline__ T cbrt(T x) { return ::cbrt(x); }
+    static __device__ __forceinline__ T exp(T x) { return ::exp(x); }
+    static __device__ __forceinline__ T exp2(T x) { return ::exp2(x); }
+    static __device__ __forceinline__ T log(T x) { return ::log(x); }
+    static __device__ __forceinline__ T log2(T x) { return ::log2(x); }
+    static __device__ __forceinline__ T log10(T x) { return ::log10(x); }
+    static __device__ __forceinline__ T log1p(T x) { return ::log1p(x); }
+    static __device__ __forceinline__ T sin(T x) { return ::sin(x); }
+    static __device__ __forceinline__ T cos(T x) { return ::cos(x); }
+    static __device__ __forceinline__ T tan(T x) { return ::tan(x); }
+    static __device__ __forceinline__ T sinh(T x) { return ::sinh(x); }
+    static __device__ __forceinline__ T cosh(T x) { return ::cosh(x); }
+    static __device__ __forceinline__ T tanh(T x) { return ::tanh(x); }
+    static __device__ __forceinline__ T asin(T x) { return ::asin(x); }
+    static __device__ __forceinline__ T acos(T x) { return ::acos(x); }
+    static __device__ __forceinline__ T atan(T x) { return ::atan(x); }
+    static __device__ __forceinline__ T asinh(T x) { return ::asinh(x); }
+    static __device__ __forceinline__ T acosh(T x) { return ::acosh(x); }
+    static __device__ __forceinline__ T atanh(T x) { return ::atanh(x); }
+    static __device__ __forceinline__ T tgamma(T x) { return ::tgamma(x); }
+    static __device__ __forceinline__ T pow(T x, T y) { return ::pow(x, y); }
+    static __device__ __forceinline__ T fmod(T x, T y) { return ::fmod(x, y); }
+    static __device__ __forceinline__ T rint(T x) { return ::rint(x); }
+    static __device__ __forceinline__ T floor(T x) { return ::floor(x); }
+    static __device__ __forceinline__ T ceil(T x) { return ::ceil(x); }
+    static __device__ __forceinline__ T trunc(T x) { return ::trunc(x); }
+    static __device__ __forceinline__ T fma(T x, T y, T z) { return ::fma(x, y, z); }
+    static __device__ __forceinline__ T copysign(T x, T y) { return ::copysign(x, y); }
+    static __device__ __forceinline__ T inf() { return __builtin_inf(); }
+    static __device__ __forceinline__ T nan() { return __builtin_nan(""); }
+    static __device__ __forceinline__ bool isfinite(T x) { return __builtin_isfinite(x); }
+    static __device__ __forceinline__ bool signbit(T x) { return __builtin_signbit(x); }
+};
+
+// Julia max/min: NaN-propagating, -0 < +0.
+template <typename T> __device__ __forceinline__ T jl_max(T x, T y) {
+    if (x != x) return x;
+    if (y != y) return y;
+    return (y > x || (M<T>::signbit(x) && !M<T>::signbit(y))) ? y : x;
+}
+template <typename T> __device__ __forceinline__ T jl_min(T x, T y) {
+    if (x != x) return x;
+    if (y != y) return y;
+    return (y < x || (M<T>::signbit(y) && !M<T>::signbit(x))) ? y : x;
+}
+template <typename T> __device__ __forceinline__ T jl_mod(T x, T y) { // Base float.jl mod
+    T r = M<T>::fmod(x, y);
+    if (r == T(0)) return M<T>::copysign(r, y);
+    if ((r > T(0)) != (y > T(0))) return r + y;
+    return r;
+}
+template <typename T> __device__ __forceinline__ T jl_sign(T x) {
+    return x > T(0) ? T(1) : (x < T(0) ? T(-1) : x);
+}
+template <typename T> __device__ __forceinline__ T jl_pow_abs2(T x, T y) {
+    T l = M<T>::log(M<T>::abs(x));
+    T m = y * l;
+    return M<T>::exp(m);
+}
+
+// digamma for d gamma / dx (SpecialFunctions.digamma; unpinned)
+template <typename T> __device__ inline T dev_digamma(T x) {
+    T r = T(0);
+    if (x <= T(0)) {
+        if (x == M<T>::floor(x)) return M<T>::nan();
+        const T pi = T(3.14159265358979323846);
+        r = -pi / M<T>::tan(pi * x); // reflection: psi(x) = psi(1-x) - pi*cot(pi*x)
+        x = T(1) - x;
+    }
+    while (x < T(10)) { r -= T(1) / x; x += T(1); }
+    T f = T(1) / (x * x);
+    T t = f * (T(-1.0 / 12) + f * (T(1.0 / 120) + f * (T(-1.0 / 252) + f * (T(1.0 / 240) + f * T(-1.0 / 132)))));
+    return r + M<T>::log(x) - T(0.5) / x + t;
+}
+
+} // namespace de

@@ -1,0 +1,56 @@
+// de_kernels.h — launch interface between the C ABI (de_api.cpp) and the gfx950
+// kernels (de_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/de_hip.h"
+#include "de_program.h"
+
+namespace de {
+
+constexpr int BLOCK = 256; // threads per workgroup = 4 wavefronts of 64
+
+struct EvalArgs {
+    // program
+    const Instr *code;        // device: all trees' instructions
+    const int32_t *code_off;  // device: n_trees+1 offsets into code
+    int32_t n_trees;
+    int32_t n_slots;          // spill slots (max over trees)
+    bool uses_params;
+    // data
+    const void *X;            // device, [F, N] col-major, ld = ldX
+    int64_t N, ldX;
+    int32_t F;
+    void *out;                // device, [n_trees, ld_out]
+    int64_t ld_out;
+    uint8_t *ok;              // device, n_trees bytes, pre-set to 1 by the caller
+    // parametric
+    const void *params;       // device [P, C]
+    int64_t ld_params;
+    const void *classes;      // device, N ids
+    int32_t classes_is_i64, class_base;
+    // flags
+    bool early_exit;
+};
+
+struct GradArgs {
+    EvalArgs e;
+    int32_t mode;             // de_grad_mode
+    int32_t P;                // n_params (rows before the features in VARIABLE/BOTH)
+    void *grad;               // device
+    const int64_t *grad_off;  // device, n_trees element offsets of each tree's [G_t, N] matrix
+    const int32_t *n_grad;    // device, n_trees: G_t
+    int32_t max_grad;         // max G_t
+    int32_t diff_direction;   // >=0: eval_diff mode (single direction, output dout rows)
+};
+
+// Returns hipSuccess or the failing HIP error.  `kernel_name` receives the symbol
+// name of the launched kernel (for matching rocprofv3 kernel-trace rows).
+hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const char **kernel_name);
+hipError_t launch_grad(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name);
+
+// LDS bytes the eval kernel needs for (dtype, F, n_slots); 0 if it cannot fit.
+size_t eval_lds_bytes(int dtype, int F, int n_slots, int *K_out);
+
+} // namespace de

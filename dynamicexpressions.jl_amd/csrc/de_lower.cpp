@@ -1,0 +1,356 @@
+// de_lower.cpp — host lowering of one post-order tape into the accumulator-machine
+// program of de_program.h.
+//
+// Two jobs:
+//  1. ANNOTATE: walk the tree exactly like the reference's recursive dispatch
+//     (reference src/Evaluate.jl:337-364 `_eval_tree_array`, :599-651
+//     `dispatch_deg1_eval`, :488-577 `dispatch_deg2_eval`, :428-487 degree>2) to
+//     decide WHICH values the reference validity-tests, so that the device `ok`
+//     flag is identical to the reference's `complete` flag for the same inputs —
+//     including which feature leaves are (not) tested by the fused 2/3-node
+//     kernels, which constants are value-tested, and where the fused deg1
+//     kernels substitute Inf (:722,737,754,787).
+//  2. CODEGEN: emit accumulator code with Sethi-Ullman child ordering so the
+//     spill stack stays minimal (a leaf never needs a slot).
+#include "de_lower.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace de {
+namespace {
+
+struct LNode {
+    uint8_t degree = 0, op = 0;
+    uint16_t arg = 0;
+    int child[3] = {-1, -1, -1};
+    bool is_const = false;   // is_constant(subtree), src/NodeUtils.jl:73
+    bool chk_leaf = false;   // leaf whose array the reference validity-tests (early_exit)
+    bool inject = false;     // outer op of a fused deg1 kernel
+    bool constfold = false;  // inside a subtree evaluated by dispatch_constant_tree
+    int regs = 0;            // spill slots needed to evaluate into acc
+};
+
+struct Lowerer {
+    const LowerOptions &opt;
+    std::vector<LNode> nodes;
+    TreeProgram *out;
+    int pending_push = -1;
+    int max_slots = 0;
+    std::string *err;
+
+    Lowerer(const LowerOptions &o, TreeProgram *p, std::string *e) : opt(o), out(p), err(e) {}
+
+    bool is_leaf(int i) const { return nodes[i].degree == 0; }
+    bool is_const_leaf(int i) const { return nodes[i].degree == 0 && nodes[i].op == DE_LEAF_CONST; }
+    bool bin_of_leaves(int i) const {
+        return nodes[i].degree == 2 && is_leaf(nodes[i].child[0]) && is_leaf(nodes[i].child[1]);
+    }
+
+    // ---- annotate ---------------------------------------------------------
+    void host_check_ee(int leaf) { // @return_on_nonfinite_val on a constant leaf
+        if (is_const_leaf(leaf)) out->const_checks[nodes[leaf].arg] |= CONST_CHECK_EE;
+    }
+    // `@return_on_nonfinite_array` applied to the result array of child c.
+    void checked_child(int c) {
+        if (!is_leaf(c)) return; // operator results are always tested in early-exit mode
+        if (is_const_leaf(c)) host_check_ee(c);
+        else nodes[c].chk_leaf = true;
+    }
+    void mark_constfold(int i) { // dispatch_constant_tree, src/Evaluate.jl:1002-1067
+        LNode &n = nodes[i];
+        n.constfold = true;
+        if (n.degree == 0) out->const_checks[n.arg] |= CONST_CHECK_ALWAYS;
+        for (int k = 0; k < n.degree; k++) mark_constfold(n.child[k]);
+    }
+    void annotate_bumper(int i) { // ext/DynamicExpressionsBumperExt.jl:25-36,63
+        LNode &n = nodes[i];
+        if (n.degree == 0) { host_check_ee(i); return; }
+        for (int k = 0; k < n.degree; k++) annotate_bumper(n.child[k]);
+    }
+    void annotate(int i) { // == _eval_tree_array(node)
+        LNode &n = nodes[i];
+        if (n.degree == 0) return;
+        if (n.is_const) { mark_constfold(i); return; }
+        if (n.degree == 1) {
+            int c = n.child[0];
+            if (opt.fuse1 && bin_of_leaves(c)) { // deg1_l2_ll0_lr0_eval
+                host_check_ee(nodes[c].child[0]);
+                host_check_ee(nodes[c].child[1]);
+                n.inject = true;
+                return;
+            }
+            if (opt.fuse1 && nodes[c].degree == 1 && is_leaf(nodes[c].child[0])) { // deg1_l1_ll0_eval
+                n.inject = true;
+                return;
+            }
+            annotate(c);
+            checked_child(c);
+            return;
+        }
+        if (n.degree == 2) {
+            int l = n.child[0], r = n.child[1];
+            if (opt.fuse2 && is_leaf(l) && is_leaf(r)) { // deg2_l0_r0_eval
+                host_check_ee(l);
+                host_check_ee(r);
+                return;
+            }
+            if (opt.fuse2 && is_leaf(r)) {
+                if (bin_of_leaves(l)) { // deg2_branch0_eval :left
+                    host_check_ee(nodes[l].child[0]);
+                    host_check_ee(nodes[l].child[1]);
+                    host_check_ee(r);
+                    if (!is_const_leaf(r)) nodes[r].chk_leaf = true; // _fused_binary3 tests x3
+                    return;
+                }
+                annotate(l);
+                checked_child(l);
+                host_check_ee(r); // deg2_r0_eval
+                return;
+            }
+            if (opt.fuse2 && is_leaf(l)) {
+                if (bin_of_leaves(r)) { // deg2_branch0_eval :right
+                    host_check_ee(l);
+                    host_check_ee(nodes[r].child[0]);
+                    host_check_ee(nodes[r].child[1]);
+                    if (!is_const_leaf(l)) nodes[l].chk_leaf = true; // _fused_binary3 tests x1
+                    return;
+                }
+                annotate(r);
+                checked_child(r);
+                host_check_ee(l); // deg2_l0_eval
+                return;
+            }
+            annotate(l);
+            checked_child(l);
+            annotate(r);
+            checked_child(r);
+            return;
+        }
+        for (int k = 0; k < n.degree; k++) { // inner_dispatch_degn_eval
+            annotate(n.child[k]);
+            checked_child(n.child[k]);
+        }
+    }
+
+    // ---- codegen ----------------------------------------------------------
+    void compute_regs(int i) {
+        LNode &n = nodes[i];
+        for (int k = 0; k < n.degree; k++) compute_regs(n.child[k]);
+        if (n.degree == 0) n.regs = 0;
+        else if (n.degree == 1) n.regs = nodes[n.child[0]].regs;
+        else if (n.degree == 2) {
+            int l = n.child[0], r = n.child[1];
+            if (is_leaf(l) && is_leaf(r)) n.regs = 0;
+            else if (is_leaf(l)) n.regs = nodes[r].regs;
+            else if (is_leaf(r)) n.regs = nodes[l].regs;
+            else {
+                int a = nodes[l].regs, b = nodes[r].regs;
+                n.regs = (a == b) ? a + 1 : std::max(a, b);
+            }
+        } else {
+            n.regs = std::max({nodes[n.child[0]].regs, 1 + nodes[n.child[1]].regs,
+                               2 + nodes[n.child[2]].regs});
+        }
+    }
+
+    Instr &emit(uint32_t op) {
+        Instr ins;
+        std::memset(&ins, 0, sizeof ins);
+        ins.hdr = op & H_OP_MASK;
+        if (pending_push >= 0) {
+            ins.hdr |= H_PUSH | ((uint32_t)pending_push << H_PUSH_SHIFT);
+            pending_push = -1;
+        }
+        out->code.push_back(ins);
+        return out->code.back();
+    }
+    // Make leaf `li` the B operand of `ins`.
+    void set_leaf_operand(Instr &ins, int li) {
+        const LNode &lf = nodes[li];
+        if (lf.op == DE_LEAF_CONST) {
+            ins.hdr |= SRC_CONST << H_SRC_SHIFT;
+            ins.feat = (uint32_t)lf.arg << 16;
+            out->const_instr[lf.arg] = (int32_t)(&ins - out->code.data());
+        } else if (lf.op == DE_LEAF_FEATURE) {
+            ins.hdr |= SRC_FEAT << H_SRC_SHIFT;
+            ins.feat = lf.arg;
+            if (lf.chk_leaf) ins.hdr |= H_CHECK_B;
+        } else {
+            ins.hdr |= SRC_PARAM << H_SRC_SHIFT;
+            ins.feat = lf.arg;
+            if (lf.chk_leaf) ins.hdr |= H_CHECK_B;
+            out->uses_params = true;
+        }
+    }
+    static uint32_t swapped(uint32_t op, bool *need_flag) {
+        *need_flag = false;
+        switch (op) {
+        case DE_B_ADD: case DE_B_MUL: case DE_B_MAX: case DE_B_MIN: return op; // commutative
+        case DE_B_SUB: return DOP_RSUB;
+        case DE_B_DIV: return DOP_RDIV;
+        default: *need_flag = true; return op;
+        }
+    }
+    void op_flags(Instr &ins, const LNode &n) {
+        if (n.constfold) ins.hdr |= H_CHECK_ALWAYS;
+        if (n.inject) ins.hdr |= H_INJECT;
+    }
+
+    // Emit code leaving the value of node i in acc; `depth` = occupied spill slots.
+    void gen(int i, int depth) {
+        const LNode n = nodes[i];
+        if (n.degree == 0) {
+            Instr &ins = emit(DOP_LOAD);
+            set_leaf_operand(ins, i);
+            return;
+        }
+        if (n.degree == 1) {
+            int c = n.child[0];
+            if (is_leaf(c)) {
+                Instr &ins = emit(n.op);
+                set_leaf_operand(ins, c);
+                op_flags(ins, n);
+            } else {
+                gen(c, depth);
+                Instr &ins = emit(n.op);
+                ins.hdr |= SRC_ACC << H_SRC_SHIFT;
+                op_flags(ins, n);
+            }
+            return;
+        }
+        if (n.degree == 2) {
+            int l = n.child[0], r = n.child[1];
+            if (is_leaf(r)) {
+                gen(l, depth); // l leaf -> LOAD, else its code
+                Instr &ins = emit(n.op);
+                set_leaf_operand(ins, r);
+                op_flags(ins, n);
+                return;
+            }
+            if (is_leaf(l)) { // acc = r ; result = op(leaf, acc)
+                gen(r, depth);
+                bool flag;
+                Instr &ins = emit(swapped(n.op, &flag));
+                if (flag) ins.hdr |= H_SWAP;
+                set_leaf_operand(ins, l);
+                op_flags(ins, n);
+                return;
+            }
+            max_slots = std::max(max_slots, depth + 1);
+            if (nodes[l].regs > nodes[r].regs) { // left first: result = op(pop=l, acc=r)
+                gen(l, depth);
+                pending_push = depth;
+                gen(r, depth + 1);
+                bool flag;
+                Instr &ins = emit(swapped(n.op, &flag));
+                if (flag) ins.hdr |= H_SWAP;
+                ins.hdr |= (SRC_POP << H_SRC_SHIFT) | ((uint32_t)depth << H_POP_SHIFT);
+                op_flags(ins, n);
+            } else { // right first (also on ties: natural operand order, no swap)
+                gen(r, depth);
+                pending_push = depth;
+                gen(l, depth + 1);
+                Instr &ins = emit(n.op);
+                ins.hdr |= (SRC_POP << H_SRC_SHIFT) | ((uint32_t)depth << H_POP_SHIFT);
+                op_flags(ins, n);
+            }
+            return;
+        }
+        // degree 3: x -> slot depth, y -> slot depth+1, z -> acc ; acc = op(x, y, z)
+        max_slots = std::max(max_slots, depth + 2);
+        gen(n.child[0], depth);
+        pending_push = depth;
+        gen(n.child[1], depth + 1);
+        pending_push = depth + 1;
+        gen(n.child[2], depth + 2);
+        Instr &ins = emit(n.op);
+        ins.hdr |= (SRC_POP << H_SRC_SHIFT) | ((uint32_t)depth << H_POP_SHIFT) |
+                   ((uint32_t)(depth + 1) << H_POPC_SHIFT);
+        op_flags(ins, n);
+    }
+};
+
+} // namespace
+
+int lower_tree(const de_tape_node_t *tape, int64_t n, int64_t n_consts, const LowerOptions &opt,
+               TreeProgram *out, std::string *err) {
+    auto fail = [&](int code, const std::string &msg) {
+        if (err) *err = msg;
+        return code;
+    };
+    if (n <= 0) return fail(DE_ERR_BAD_TAPE, "empty tape");
+    if (n > 65535) return fail(DE_ERR_UNSUPPORTED, "tape longer than 65535 nodes");
+    *out = TreeProgram();
+    out->n_nodes = (int)n;
+    out->n_consts = (int)n_consts;
+    out->const_instr.assign((size_t)n_consts, -1);
+    out->const_checks.assign((size_t)n_consts, 0);
+
+    Lowerer L(opt, out, err);
+    L.nodes.resize((size_t)n);
+    std::vector<int> stack;
+    std::vector<int> depth((size_t)n, 1);
+    stack.reserve((size_t)n);
+    int64_t seen_consts = 0;
+    for (int64_t i = 0; i < n; i++) {
+        LNode &nd = L.nodes[(size_t)i];
+        nd.degree = tape[i].degree;
+        nd.op = tape[i].op;
+        nd.arg = tape[i].arg;
+        if (nd.degree == 0) {
+            if (nd.op == DE_LEAF_CONST) {
+                nd.is_const = true;
+                if (nd.arg >= n_consts) return fail(DE_ERR_OUT_OF_RANGE, "constant slot out of range");
+                if (out->const_instr[nd.arg] == -2)
+                    return fail(DE_ERR_BAD_TAPE, "constant slot referenced twice");
+                out->const_instr[nd.arg] = -2; // seen
+                seen_consts++;
+            } else if (nd.op == DE_LEAF_FEATURE) {
+                if ((int)nd.arg >= opt.n_features) return fail(DE_ERR_OUT_OF_RANGE, "feature index out of range");
+            } else if (nd.op == DE_LEAF_PARAM) {
+                if ((int)nd.arg >= opt.n_params) return fail(DE_ERR_OUT_OF_RANGE, "parameter index out of range");
+            } else return fail(DE_ERR_BAD_TAPE, "unknown leaf kind");
+        } else if (nd.degree <= 3) {
+            int lo = nd.degree == 1 ? DE_U_NEG : (nd.degree == 2 ? DE_B_ADD : DE_T_FMA);
+            int hi = nd.degree == 1 ? DE_U_LAST_ : (nd.degree == 2 ? DE_B_LAST_ : DE_T_LAST_);
+            if (nd.op < lo || nd.op >= hi) return fail(DE_ERR_UNSUPPORTED_OP, "opcode not in table for this degree");
+            if ((int)stack.size() < nd.degree) return fail(DE_ERR_BAD_TAPE, "operator without enough operands");
+            nd.is_const = true;
+            int d = 0;
+            for (int k = nd.degree - 1; k >= 0; k--) {
+                nd.child[k] = stack.back();
+                stack.pop_back();
+                nd.is_const = nd.is_const && L.nodes[(size_t)nd.child[k]].is_const;
+                d = std::max(d, depth[(size_t)nd.child[k]]);
+            }
+            depth[(size_t)i] = d + 1;
+            if (d + 1 > 2048) return fail(DE_ERR_UNSUPPORTED, "tree deeper than 2048");
+        } else return fail(DE_ERR_BAD_TAPE, "degree > 3");
+        stack.push_back((int)i);
+    }
+    if (stack.size() != 1) return fail(DE_ERR_BAD_TAPE, "tape does not reduce to a single root");
+    if (seen_consts != n_consts) return fail(DE_ERR_BAD_TAPE, "constant pool size does not match tape");
+    int root = stack[0];
+
+    if (opt.bumper) {
+        L.annotate_bumper(root);
+    } else {
+        L.annotate(root);
+        L.checked_child(root); // final is_valid_array(result.x), src/Evaluate.jl:305-308
+    }
+    L.compute_regs(root);
+    if (L.nodes[(size_t)root].regs > MAX_SLOTS)
+        return fail(DE_ERR_UNSUPPORTED, "tree needs more than 16 spill slots");
+    out->code.reserve((size_t)n);
+    L.gen(root, 0);
+    // set_leaf_operand stored indices while the vector could still grow: recompute them.
+    for (size_t k = 0; k < out->code.size(); k++) {
+        const Instr &ins = out->code[k];
+        if (((ins.hdr >> H_SRC_SHIFT) & H_SRC_MASK) == SRC_CONST) out->const_instr[ins.feat >> 16] = (int32_t)k;
+    }
+    out->n_slots = L.max_slots;
+    return DE_OK;
+}
+
+} // namespace de

@@ -1,0 +1,42 @@
+// de_lower.h — host lowering: post-order tape -> device program (de_program.h).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/de_hip.h"
+#include "de_program.h"
+
+namespace de {
+
+struct LowerOptions {
+    bool early_exit = true;
+    bool fuse1 = true, fuse2 = true;
+    bool bumper = false;
+    int n_features = 0;
+    int n_params = 0;
+    int dtype = DE_F32;
+};
+
+// How a constant slot takes part in the host-side part of the `ok` flag.
+enum : uint8_t {
+    CONST_CHECK_EE = 1,     // value-tested by the reference when early_exit=true
+    CONST_CHECK_ALWAYS = 2, // leaf of a constant-folded subtree: tested unconditionally
+};
+
+struct TreeProgram {
+    std::vector<Instr> code;
+    std::vector<int32_t> const_instr;  // const slot -> index into `code` holding its immediate
+    std::vector<uint8_t> const_checks; // const slot -> CONST_CHECK_* bits
+    int n_slots = 0;                   // spill slots needed
+    int n_nodes = 0;
+    int n_consts = 0;
+    bool uses_params = false;
+};
+
+// Returns DE_OK or a de_status_t; `err` receives a human-readable reason.
+int lower_tree(const de_tape_node_t *tape, int64_t n_nodes, int64_t n_consts, const LowerOptions &opt,
+               TreeProgram *out, std::string *err);
+
+} // namespace de

@@ -163,6 +163,15 @@ int64_t de_program_n_grad(const de_program_t *prog, int64_t tree, int mode);
 int64_t de_program_dump(const de_program_t *prog, int64_t tree, uint32_t *words, int64_t cap,
                         int which);
 
+/* Host-only hook (makes no HIP call, works without a GPU): lower ONE tape and
+ * return its instruction words (4 x uint32 each, csrc/de_program.h) in `words`
+ * (capacity `cap` words).  meta[4] = {spill slots, host part of the eval flag,
+ * host part of the gradient flag, uses parameters}.  Returns the number of words
+ * or -status.  Used by the CPU unit tests of the lowering. */
+int64_t de_lower_tape(int dtype, const de_tape_node_t *nodes, int64_t n_nodes, const void *consts,
+                      int64_t n_consts, int32_t n_features, int32_t n_params, uint32_t options,
+                      uint32_t *words, int64_t cap, int32_t *meta);
+
 /* ---- evaluation ------------------------------------------------------------ */
 /* Optional per-call inputs of a parametric population
  * (src/ParametricExpression.jl:371-390): value of PARAM leaf p at sample j is

@@ -73,3 +73,24 @@ def check_values(got, case, what="y"):
     tol = exp.get("atol", 0) + exp.get("rtol", 0) * np.abs(want[mask])
     err = np.abs(got[mask] - want[mask])
     assert np.all(err <= tol), f"{case['name']} ({case['cite']}): max err {err.max()} > tol"
+
+
+def value_tolerance(y, y64, dtype):
+    """Per-sample tolerance for comparing two implementations of the same tree in `dtype`.
+
+    north_star: 1e-5 relative for Float32 (1 ulp per operation for Float64).  Transcendental
+    implementations legitimately differ by ~1 ulp per operation and a deep tree amplifies
+    that by its condition number (exp(exp(x)), cancellation ...), so the bound is
+        1e-5*|y|  (f32)  /  1e-12*|y|  (f64)
+      + 64 * |y_T - y_f64|     the oracle's OWN deviation from a wider-precision evaluation of
+                               the same tree on the same inputs = a measured estimate of how much
+                               this sample amplifies one rounding error.
+    Well-conditioned samples (second term ~0) are therefore held to the north-star bound."""
+    y = np.asarray(y)
+    y64 = np.asarray(y64, dtype=np.float64)
+    if np.dtype(dtype) == np.float32:
+        base = 1e-5 * np.abs(y.astype(np.float64)) + 1e-30
+    else:
+        base = 1e-12 * np.abs(y.astype(np.float64)) + 1e-300
+    with np.errstate(invalid="ignore", over="ignore"):
+        return base + 64.0 * np.abs(y.astype(np.float64) - y64)

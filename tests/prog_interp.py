@@ -1,0 +1,113 @@
+"""A numpy model of the device accumulator machine (csrc/de_program.h), used ONLY by the CPU
+unit tests of the host lowering (tests/test_lowering.py): it executes the instruction words
+``de_lower_tape`` returns, so operand order / SWAP / spill slots / check flags can be
+verified against the oracle without a GPU.  It is test infrastructure — the product never
+imports it and it is not a fallback path.
+"""
+import numpy as np
+
+DOP_LOAD, DOP_RSUB, DOP_RDIV = 0xF0, 0xF1, 0xF2
+SRC_ACC, SRC_FEAT, SRC_CONST, SRC_POP, SRC_PARAM = 0, 1, 2, 3, 4
+
+
+def _jlmax(x, y):
+    r = np.where((y > x) | (np.signbit(x) & ~np.signbit(y)), y, x)
+    r = np.where(np.isnan(y), y, r)
+    return np.where(np.isnan(x), x, r)
+
+
+def _jlmin(x, y):
+    r = np.where((y < x) | (np.signbit(y) & ~np.signbit(x)), y, x)
+    r = np.where(np.isnan(y), y, r)
+    return np.where(np.isnan(x), x, r)
+
+
+def _jlmod(x, y):
+    r = np.fmod(x, y)
+    out = np.where((r > 0) != (y > 0), r + y, r)
+    return np.where(r == 0, np.copysign(r, y), out)
+
+
+def _sign(x):
+    return np.where(x > 0, 1, np.where(x < 0, -1, x)).astype(x.dtype)
+
+
+def _nan_where(cond, val):
+    return np.where(cond, np.nan, val).astype(val.dtype)
+
+
+UNARY = {
+    1: lambda x: -x, 2: np.abs, 3: lambda x: x * x, 4: lambda x: (x * x) * x,
+    5: lambda x: np.where(x < 0, 0, x).astype(x.dtype), 6: _sign, 7: np.rint, 8: np.floor, 9: np.ceil,
+    10: lambda x: 1 / x, 11: np.sqrt, 12: np.cbrt, 13: np.exp, 14: np.exp2, 15: np.log, 16: np.log2,
+    17: np.log10, 18: np.log1p, 19: np.sin, 20: np.cos, 21: np.tan, 22: np.sinh, 23: np.cosh,
+    24: np.tanh, 25: np.arcsin, 26: np.arccos, 27: np.arctan, 28: np.arcsinh, 29: np.arccosh,
+    30: np.arctanh,
+    31: lambda x: _nan_where(x <= 0, np.log(np.where(x <= 0, 1, x))),
+    32: lambda x: _nan_where(x <= 0, np.log2(np.where(x <= 0, 1, x))),
+    33: lambda x: _nan_where(x <= 0, np.log10(np.where(x <= 0, 1, x))),
+    34: lambda x: _nan_where(x <= -1, np.log1p(np.where(x <= -1, 0, x))),
+    35: lambda x: _nan_where(x < 0, np.sqrt(np.where(x < 0, 0, x))),
+    36: lambda x: _nan_where(x < 1, np.arccosh(np.where(x < 1, 1, x))),
+    37: lambda x: np.cos(x) * np.cos(x),
+    38: lambda x: np.vectorize(__import__('math').gamma, otypes=[np.float64])(x.astype(np.float64)),
+}
+BINARY = {
+    64: lambda x, y: x + y, 65: lambda x, y: x - y, 66: lambda x, y: x * y, 67: lambda x, y: x / y,
+    68: lambda x, y: np.power(x, y), 69: _jlmax, 70: _jlmin, 71: _jlmod, 72: np.fmod,
+    73: lambda x, y: (x > y).astype(x.dtype), 74: lambda x, y: np.exp(y * np.log(np.abs(x))),
+    DOP_RSUB: lambda x, y: y - x, DOP_RDIV: lambda x, y: y / x,
+}
+TERNARY = {
+    128: lambda x, y, z: x * y + z,  # (fma: single rounding on device; tolerance in the test)
+    129: lambda x, y, z: np.where(x > z, z, np.where(x < y, y, x)),
+    130: lambda x, y, z: (x + y) + z,
+    131: lambda x, y, z: _jlmax(_jlmax(x, y), z),
+}
+
+
+def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True):
+    """Execute instruction words ([n,4] uint32) on X [F, N].  Returns (out, ok)."""
+    dt = X.dtype
+    N = X.shape[1]
+    acc = np.zeros(N, dtype=dt)
+    stack = {}
+    bad = False
+    with np.errstate(all="ignore"):
+        for w in words:
+            hdr, feat = int(w[0]), int(w[1])
+            op, src = hdr & 0xFF, (hdr >> 8) & 7
+            if hdr & (1 << 11):
+                stack[(hdr >> 20) & 15] = acc.copy()
+            if src == SRC_FEAT:
+                b = X[feat & 0xFFFF].copy()
+            elif src == SRC_CONST:
+                imm = np.array([w[2], w[3]], dtype=np.uint32)
+                c = imm[:1].view(np.float32)[0] if dt == np.float32 else imm.view(np.float64)[0]
+                b = np.full(N, c, dtype=dt)
+            elif src == SRC_POP:
+                b = stack[(hdr >> 16) & 15].copy()
+            elif src == SRC_PARAM:
+                b = params[feat & 0xFFFF, classes0].astype(dt)
+            else:
+                b = acc.copy()
+            if early_exit and (hdr & (1 << 12)):
+                bad |= bool(np.any(~np.isfinite(b)))
+            if 128 <= op < DOP_LOAD:
+                c2 = stack[(hdr >> 24) & 15]
+                acc = TERNARY[op](b, c2, acc).astype(dt)
+            else:
+                if hdr & (1 << 15):
+                    acc, b = b, acc
+                if op == DOP_LOAD:
+                    acc = b
+                elif op < 64:
+                    acc = UNARY[op](b).astype(dt)
+                else:
+                    acc = BINARY[op](acc, b).astype(dt)
+                if (not early_exit) and (hdr & (1 << 14)):
+                    acc = np.where(np.isfinite(b), acc, np.inf).astype(dt)
+            check = (op != DOP_LOAD) if early_exit else bool(hdr & (1 << 13))
+            if check:
+                bad |= bool(np.any(~np.isfinite(acc)))
+    return acc, (host_ok and not bad)

@@ -1,0 +1,136 @@
+"""CPU unit tests of the HOST logic: tape flattening, the C lowering (de_lower_tape makes no HIP
+call) and the reference-dispatch annotation that decides the `ok` flag.  The lowered program is
+executed by tests/prog_interp.py (a numpy model of the device machine) and compared with the
+oracle — values AND flags — on the golden cases and on seeded random trees."""
+import numpy as np
+import pytest
+
+import dynamicexpressions_jl_amd as de
+from dynamicexpressions_jl_amd import api
+from helpers import case_X, case_options, case_tree, load_golden, value_tolerance
+from oracle import oracle
+import prog_interp
+
+CASES = [c for c in load_golden() if c["kind"] in ("eval", "flag", "param")]
+
+
+def run_lowered(tree, ops, X, options, params=None, classes=None):
+    dt = X.dtype
+    tape, consts = de.flatten(tree, ops, dt)
+    P = 0 if params is None else params.shape[0]
+    words, meta = api.lower_tape(tape, consts, X.shape[0], P, options, dt)
+    cls0 = None if classes is None else np.asarray(classes) - 1
+    out, ok = prog_interp.run(words, X, bool(options & 1), params, cls0, meta["host_ok_eval"])
+    return out, ok, words, meta, tape, consts
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_lowered_program_matches_oracle_on_golden(case):
+    tree, ops = case_tree(case)
+    X = case_X(case)
+    opts = case_options(case)
+    exp = case["expect"]
+    if case["kind"] == "param":
+        params = np.asarray(exp["params"], dtype=X.dtype)
+        out, ok, *_ = run_lowered(tree, ops, X, opts, params, exp["classes"])
+    else:
+        out, ok, *_ = run_lowered(tree, ops, X, opts)
+    assert ok == exp["ok"], case["name"]
+    if ok and "y" in exp:
+        want = np.asarray(exp["y"], dtype=np.float64)
+        m = np.isfinite(want)
+        tol = max(exp.get("atol", 0), 1e-12) + max(exp.get("rtol", 0), 4e-7 if X.dtype == np.float32 else 1e-14) * np.abs(want[m])
+        assert np.all(np.abs(out[m].astype(np.float64) - want[m]) <= tol)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("options", [7, 1, 6, 0, 9])
+def test_random_trees_values_and_flags(dtype, options):
+    ops = de.OperatorEnum(binary_operators=("+", "-", "/", "*", "max", "pow_abs2"),
+                          unary_operators=("cos", "exp", "safe_log", "neg", "square"))
+    rng = de.synth.Xoshiro256ss(1234 + options)
+    g = np.random.Generator(np.random.PCG64(7))
+    n_bad = 0
+    for it in range(150):
+        tree = de.synth.gen_random_tree_fixed_size(3 + it % 25, ops, 4, rng, dtype)
+        X = np.asfortranarray(g.standard_normal((4, 33)).astype(dtype))
+        if it % 5 == 0:  # non-finite inputs exercise the leaf-test rules
+            X[g.integers(4), g.integers(33)] = [np.inf, -np.inf, np.nan][it % 3]
+        if it % 7 == 0:
+            for n in tree:
+                if n.degree == 0 and n.constant and g.random() < 0.3:
+                    n.val = float("inf")
+        out, ok, words, meta, tape, consts = run_lowered(tree, ops, X, options)
+        y, ok_ref = oracle.eval_tree_array(tape, consts, X, options, elementwise=True)
+        assert ok == ok_ref, (de.string_tree(tree, ops), options)
+        n_bad += not ok
+        if ok:
+            y64, _ = oracle.eval_tree_array(tape, consts.astype(np.float64), X.astype(np.float64), options, True)
+            m = np.isfinite(y)  # (only early_exit=false leaves non-finite samples in an ok tree)
+            assert np.array_equal(np.isfinite(out), m), de.string_tree(tree, ops)
+            tol = value_tolerance(y[m], y64[m], dtype) + (1e-6 if dtype == np.float32 else 0)
+            assert np.all(np.abs(out[m].astype(np.float64) - y[m]) <= tol), de.string_tree(tree, ops)
+        elif not (options & 1):
+            pass
+        # every tree needs few spill slots and never more instructions than nodes
+        assert len(words) <= len(tape) and meta["n_slots"] <= 4
+    assert 5 < n_bad < 140
+
+
+def test_no_early_exit_values_match_oracle_including_inf_injection():
+    """early_exit=false: finite samples keep their values, the fused deg1 kernels write Inf
+    where the inner value is non-finite (src/Evaluate.jl:722,787) — the oracle restates that and
+    the lowered program must reproduce it bit for bit on IEEE-exact operators."""
+    ops = de.OperatorEnum(binary_operators=("+", "-", "*", "/"), unary_operators=("neg", "abs"))
+    x1, x2 = de.Node(feature=1), de.Node(feature=2)
+    X = np.asfortranarray(np.array([[1.0, 0.0, np.inf, 2.0], [0.0, 0.0, 1.0, 4.0]]))
+    trees = [
+        de.Node(1, de.Node(4, x1, x2)),            # neg(x1/x2): deg1_l2_ll0_lr0 -> Inf at 1/0, 0/0
+        de.Node(2, de.Node(1, x1)),                # abs(neg(x1)): deg1_l1_ll0 -> Inf at inf
+        de.Node(1, de.Node(2, de.Node(4, x1, x2))),  # neg(abs(x1/x2)): only the inner pair is fused
+    ]
+    for t in trees:
+        out, ok, words, meta, tape, consts = run_lowered(t, ops, X, 6)
+        y, ok_ref = oracle.eval_tree_array(tape, consts, X, 6)
+        assert ok and ok_ref
+        np.testing.assert_array_equal(out, y)
+
+
+def test_tape_validation_errors():
+    T = de.node.TAPE_DTYPE
+    ok_tape = np.array([(0, 1, 0), (0, 1, 1), (2, 64, 0)], dtype=T)
+    api.lower_tape(ok_tape, [], 2)
+    with pytest.raises(ValueError):  # operator without operands
+        api.lower_tape(np.array([(2, 64, 0)], dtype=T), [], 2)
+    with pytest.raises(ValueError):  # two roots
+        api.lower_tape(np.array([(0, 1, 0), (0, 1, 1)], dtype=T), [], 2)
+    with pytest.raises(ValueError):  # feature out of range
+        api.lower_tape(np.array([(0, 1, 5)], dtype=T), [], 2)
+    with pytest.raises(ValueError):  # constant slot out of range
+        api.lower_tape(np.array([(0, 0, 0)], dtype=T), [], 2)
+    with pytest.raises(de.UnsupportedOperatorError):  # binary opcode used as unary
+        api.lower_tape(np.array([(0, 1, 0), (1, 64, 0)], dtype=T), [], 2)
+    with pytest.raises(de.UnsupportedOperatorError):
+        ops = de.OperatorEnum(unary_operators=("my_custom_op",))
+        de.flatten(de.Node(1, de.Node(feature=1)), ops)
+    with pytest.raises(ValueError):  # get_op: no operators of this degree (src/Evaluate.jl:408-419)
+        de.flatten(de.Node(1, de.Node(feature=1)), de.OperatorEnum(binary_operators=("+",)))
+
+
+def test_deep_and_wide_trees_spill_slots():
+    ops = de.OperatorEnum(binary_operators=("+", "*"), unary_operators=("cos",))
+
+    def full(d):
+        return de.Node(feature=1) if d == 0 else de.Node(1 + d % 2, full(d - 1), full(d - 1))
+
+    t = full(6)  # complete binary tree: Strahler number 7 -> 5 spill slots (leaf pairs need none)
+    X = np.asfortranarray(np.array([[1.5, -0.25, 3.0]]))
+    out, ok, words, meta, tape, consts = run_lowered(t, ops, X, 7)
+    y, _ = oracle.eval_tree_array(tape, consts, X)
+    np.testing.assert_array_equal(out, y)
+    assert meta["n_slots"] == 5
+    chain = de.Node(feature=1)
+    for _ in range(500):
+        chain = de.Node(1, chain)
+    out, ok, words, meta, tape, consts = run_lowered(chain, ops, X, 7)
+    assert meta["n_slots"] == 0 and len(words) == 500
