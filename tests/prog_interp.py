@@ -66,8 +66,13 @@ TERNARY = {
 }
 
 
-def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True):
-    """Execute instruction words ([n,4] uint32) on X [F, N].  Returns (out, ok)."""
+def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noise_eps=0.0, rng=None):
+    """Execute instruction words ([n,4] uint32) on X [F, N].  Returns (out, ok).
+
+    ``noise_eps`` > 0 multiplies every operator result by (1 +- noise_eps) with a random sign
+    per sample (discrete stochastic arithmetic): the spread of the outputs over a few such runs
+    measures how strongly a sample amplifies a one-rounding-error difference between two
+    implementations of the same operator (used for the parity tolerance, helpers.py)."""
     dt = X.dtype
     N = X.shape[1]
     acc = np.zeros(N, dtype=dt)
@@ -107,6 +112,8 @@ def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True):
                     acc = BINARY[op](acc, b).astype(dt)
                 if (not early_exit) and (hdr & (1 << 14)):
                     acc = np.where(np.isfinite(b), acc, np.inf).astype(dt)
+            if noise_eps and op != DOP_LOAD:
+                acc = (acc * (1.0 + noise_eps * rng.choice(np.array([-1.0, 1.0]), size=N))).astype(dt)
             check = (op != DOP_LOAD) if early_exit else bool(hdr & (1 << 13))
             if check:
                 bad |= bool(np.any(~np.isfinite(acc)))

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import dynamicexpressions_jl_amd as de
-from helpers import case_X, case_tree, load_golden, value_tolerance
+from helpers import case_X, case_tree, load_golden, parity_tolerance
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -69,10 +69,9 @@ def compare_population(api, trees, ops, X, dtype, eval_context=None, use_torch=F
         assert bool(ok[t]) == ok_el, f"flag mismatch tree {t}: {de.string_tree(tree, ops)}"
         if ok_el:
             n_ok += 1
-            y64, _ = oracle.eval_tree_array(tape, consts.astype(np.float64), X.astype(np.float64), opts, True)
             m = np.isfinite(y)
             assert np.array_equal(np.isfinite(out[t]), m)
-            tol = value_tolerance(y[m], y64[m], dtype)
+            tol = parity_tolerance(tree, ops, X, dtype, opts)[m]
             err = np.abs(out[t][m].astype(np.float64) - y[m])
             assert np.all(err <= tol), f"value mismatch tree {t}: {de.string_tree(tree, ops)} max err {err.max()}"
             with np.errstate(divide="ignore", invalid="ignore"):
@@ -177,8 +176,7 @@ def test_set_constants_without_reflattening(api):
         y, ok_el = oracle.eval_tree_array(tape, consts, X, elementwise=True)
         assert bool(ok[t]) == ok_el
         if ok_el:
-            y64, _ = oracle.eval_tree_array(tape, consts.astype(np.float64), X.astype(np.float64), elementwise=True)
-            assert np.all(np.abs(out[t] - y) <= value_tolerance(y, y64, np.float32))
+            assert np.all(np.abs(out[t].astype(np.float64) - y) <= parity_tolerance(tree, ops, X, np.float32))
 
 
 def test_full_size_properties_config_C2(api):
