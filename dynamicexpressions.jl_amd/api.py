@@ -153,7 +153,8 @@ class Context:
             try:
                 import torch
                 if torch.cuda.is_available():
-                    stream = torch.cuda.current_stream(device).cuda_stream
+                    # 0 = HIP's null stream (torch's default stream) -> DE_STREAM_NULL
+                    stream = torch.cuda.current_stream(device).cuda_stream or -1
             except ImportError:  # pragma: no cover
                 stream = None
         self._h = C.c_void_p()

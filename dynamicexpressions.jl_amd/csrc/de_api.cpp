@@ -186,7 +186,9 @@ int de_ctx_create(int device, void *stream, de_ctx_t **out_ctx) {
         delete c;
         return DE_ERR_HIP;
     }
-    if (stream) {
+    if (stream == DE_STREAM_NULL) {
+        c->stream = nullptr; // HIP null stream
+    } else if (stream) {
         c->stream = static_cast<hipStream_t>(stream);
     } else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {

@@ -125,8 +125,12 @@ int de_opcode_degree(int opcode); /* 1, 2, 3 or -1 */
 const char *de_status_string(int status);
 
 /* ---- context -------------------------------------------------------------- */
-/* `stream` is a hipStream_t to launch on (caller keeps ownership), or NULL to
- * let the context create its own non-blocking stream. */
+/* `stream` is a hipStream_t to launch on (caller keeps ownership), DE_STREAM_NULL
+ * for HIP's null (legacy default) stream — what torch.cuda.current_stream() is
+ * unless the caller switched streams — or NULL to let the context create and own
+ * a non-blocking stream.  Work is ordered with the caller's other work only if
+ * it is submitted to the same stream. */
+#define DE_STREAM_NULL ((void *)(intptr_t)-1)
 int de_ctx_create(int device, void *stream, de_ctx_t **out_ctx);
 int de_ctx_destroy(de_ctx_t *ctx);
 int de_ctx_synchronize(de_ctx_t *ctx);

