@@ -331,8 +331,10 @@ int de_program_create(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, con
         return fail(ctx, DE_ERR_HIP, "out of host memory");
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t cbytes = std::max<size_t>(p->code.size(), 1) * sizeof(Instr);
+    // one trailing pad instruction: the interpreter prefetches code[pc + 1]
+    const size_t cbytes = (p->code.size() + 1) * sizeof(Instr);
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->d_code), cbytes));
+    HIP_TRY(ctx, hipMemset(p->d_code, 0, cbytes));
     hipError_t st = hipMalloc(reinterpret_cast<void **>(&p->d_code_off), p->code_off.size() * sizeof(int32_t));
     if (st != hipSuccess) {
         (void)hipFree(p->d_code);

@@ -10,10 +10,12 @@
 //    fully coalesced loads and transposed into LDS as xs[f][sample], so a leaf
 //    read is one conflict-free ds_read_b128 per thread (K=4 f32 samples).
 //  * Each tree is a wave-uniform accumulator program (de_program.h): instruction
-//    words come through the scalar cache (s_load_dwordx4), decode and dispatch run
-//    on the scalar unit, the VALU only sees operator arithmetic on K independent
-//    samples per lane.  Intermediates live in registers; only the rare
-//    both-children-are-subtrees case spills one value per sample to LDS.
+//    words are fetched through the SCALAR cache (constant address space ->
+//    s_load_dwordx4, next instruction prefetched while the current one executes),
+//    decode and dispatch run on the scalar unit, the VALU only sees operator
+//    arithmetic on K independent samples per lane.  Intermediates live in
+//    registers; only the rare both-children-are-subtrees case spills one value
+//    per sample to LDS.
 //  * NaN/Inf flag: per-lane predicate, one wavefront ballot per tree, one byte
 //    store per failing wave (no atomics).
 //  * blockIdx -> (tile, chunk) is XCD-aware: all chunks of one X tile run on the
@@ -26,26 +28,39 @@
 
 namespace de {
 
+// Wave-uniform read-only data is addressed through the constant address space so
+// the compiler emits scalar loads (s_load_*) for it.
+#define DE_CONSTANT __attribute__((address_space(4)))
+typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+typedef const DE_CONSTANT U32x4 *ConstU4Ptr;
+typedef const DE_CONSTANT int32_t *ConstI32Ptr;
+
 template <typename T> struct KArgs {
-    const Instr *__restrict__ code;
-    const int32_t *__restrict__ code_off;
-    const T *__restrict__ X;
-    T *__restrict__ out;
-    uint8_t *__restrict__ ok;
-    const T *__restrict__ params;
-    const void *__restrict__ classes;
+    const Instr *code;       // padded with one trailing instruction (prefetch reads pc+1)
+    const int32_t *code_off; // n_trees + 1
+    const T *X;
+    T *out;
+    uint8_t *ok;
+    const T *params;
+    const void *classes;
     int64_t N, ldX, ld_out, ld_params, n_tiles;
     int32_t F, n_trees, trees_per_chunk, n_chunks, n_slots, xstride;
-    int32_t classes_is_i64, class_base, uses_params, vec_store;
+    int32_t classes_is_i64, class_base, vec_store;
 };
 
-template <typename T> __device__ __forceinline__ T imm_of(const Instr &ins);
-template <> __device__ __forceinline__ float imm_of<float>(const Instr &ins) { return ins.imm.f32; }
-template <> __device__ __forceinline__ double imm_of<double>(const Instr &ins) { return ins.imm.f64; }
+template <typename T, int K> struct VecOf;
+template <> struct VecOf<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct VecOf<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+
+template <typename T> __device__ __forceinline__ T imm_of(uint32_t w2, uint32_t w3);
+template <> __device__ __forceinline__ float imm_of<float>(uint32_t w2, uint32_t) { return __uint_as_float(w2); }
+template <> __device__ __forceinline__ double imm_of<double>(uint32_t w2, uint32_t w3) {
+    return __longlong_as_double((long long)(((unsigned long long)w3 << 32) | w2));
+}
 
 #define DE_UNROLL _Pragma("unroll")
 
-// acc = op(b) for every sample
+// acc = f(b) for every sample
 #define U_CASE(OPC, EXPR)                                    \
     case OPC:                                                \
         DE_UNROLL for (int i = 0; i < K; i++) {              \
@@ -53,7 +68,7 @@ template <> __device__ __forceinline__ double imm_of<double>(const Instr &ins) {
             acc[i] = (EXPR);                                 \
         }                                                    \
         break;
-// acc = op(acc, b)
+// acc = f(acc, b)
 #define B_CASE(OPC, EXPR)                                    \
     case OPC:                                                \
         DE_UNROLL for (int i = 0; i < K; i++) {              \
@@ -62,11 +77,11 @@ template <> __device__ __forceinline__ double imm_of<double>(const Instr &ins) {
         }                                                    \
         break;
 
-template <typename T, int K>
-__device__ __forceinline__ void apply_op(uint32_t op, T (&acc)[K], const T (&b)[K]) {
+// Everything that is not on the fast path of the interpreter loop.
+template <typename T, int K, typename V>
+__device__ __forceinline__ void apply_cold_op(uint32_t op, V &acc, const V &b) {
     using m = M<T>;
     switch (op) {
-        U_CASE(DOP_LOAD, x)
         U_CASE(DE_U_NEG, -x)
         U_CASE(DE_U_ABS, m::abs(x))
         U_CASE(DE_U_SQUARE, x * x)
@@ -79,14 +94,12 @@ __device__ __forceinline__ void apply_op(uint32_t op, T (&acc)[K], const T (&b)[
         U_CASE(DE_U_INV, T(1) / x)
         U_CASE(DE_U_SQRT, m::sqrt(x))
         U_CASE(DE_U_CBRT, m::cbrt(x))
-        U_CASE(DE_U_EXP, m::exp(x))
         U_CASE(DE_U_EXP2, m::exp2(x))
         U_CASE(DE_U_LOG, m::log(x))
         U_CASE(DE_U_LOG2, m::log2(x))
         U_CASE(DE_U_LOG10, m::log10(x))
         U_CASE(DE_U_LOG1P, m::log1p(x))
         U_CASE(DE_U_SIN, m::sin(x))
-        U_CASE(DE_U_COS, m::cos(x))
         U_CASE(DE_U_TAN, m::tan(x))
         U_CASE(DE_U_SINH, m::sinh(x))
         U_CASE(DE_U_COSH, m::cosh(x))
@@ -110,26 +123,25 @@ __device__ __forceinline__ void apply_op(uint32_t op, T (&acc)[K], const T (&b)[
         }
         break;
         U_CASE(DE_U_GAMMA, m::tgamma(x))
-        B_CASE(DE_B_ADD, x + y)
-        B_CASE(DE_B_SUB, x - y)
-        B_CASE(DOP_RSUB, y - x)
-        B_CASE(DE_B_MUL, x * y)
-        B_CASE(DE_B_DIV, x / y)
-        B_CASE(DOP_RDIV, y / x)
         B_CASE(DE_B_POW, m::pow(x, y))
+        B_CASE(DOP_RPOW, m::pow(y, x))
         B_CASE(DE_B_MAX, jl_max(x, y))
         B_CASE(DE_B_MIN, jl_min(x, y))
         B_CASE(DE_B_MOD, jl_mod(x, y))
+        B_CASE(DOP_RMOD, jl_mod(y, x))
         B_CASE(DE_B_REM, m::fmod(x, y))
+        B_CASE(DOP_RREM, m::fmod(y, x))
         B_CASE(DE_B_GREATER, x > y ? T(1) : T(0))
+        B_CASE(DOP_RGREATER, y > x ? T(1) : T(0))
         B_CASE(DE_B_POW_ABS2, jl_pow_abs2(x, y))
+        B_CASE(DOP_RPOW_ABS2, jl_pow_abs2(y, x))
     default: break;
     }
 }
 
 // acc = op3(b, c, acc): b, c from spill slots, acc = third argument
-template <typename T, int K>
-__device__ __forceinline__ void apply_op3(uint32_t op, T (&acc)[K], const T (&b)[K], const T (&c)[K]) {
+template <typename T, int K, typename V>
+__device__ __forceinline__ void apply_op3(uint32_t op, V &acc, const V &b, const V &c) {
     using m = M<T>;
     DE_UNROLL for (int i = 0; i < K; i++) {
         const T x = b[i], y = c[i], z = acc[i];
@@ -144,7 +156,7 @@ __device__ __forceinline__ void apply_op3(uint32_t op, T (&acc)[K], const T (&b)
     }
 }
 
-template <typename T, int K> __device__ __forceinline__ bool any_nonfinite(const T (&v)[K]) {
+template <typename T, int K, typename V> __device__ __forceinline__ bool any_nonfinite(const V &v) {
     bool bad = false;
     DE_UNROLL for (int i = 0; i < K; i++) bad |= !M<T>::isfinite(v[i]);
     return bad;
@@ -167,13 +179,16 @@ __device__ __forceinline__ TileMap map_block(uint32_t bid, int32_t n_chunks, int
     return m;
 }
 
-template <typename T, int K, bool EE>
+template <typename T, int K, bool EE, bool PARAMS>
 __global__ void __launch_bounds__(BLOCK) de_eval_tape_kernel(const KArgs<T> a) {
+    typedef typename VecOf<T, K>::type V;
     constexpr int TILE = BLOCK * K;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *__restrict__ xs = reinterpret_cast<T *>(smem_raw);
-    const int xstride = a.xstride;
-    T *__restrict__ stk = xs + (size_t)a.F * xstride;
+    const int xstride = a.xstride; // multiple of K: every row starts 16-byte aligned
+    V *__restrict__ xsv = reinterpret_cast<V *>(smem_raw);
+    V *__restrict__ stkv = reinterpret_cast<V *>(xs + (size_t)a.F * xstride);
+    const int xstride_v = xstride / K;
 
     const TileMap tm = map_block(blockIdx.x, a.n_chunks, a.n_tiles);
     if (!tm.valid) return;
@@ -181,7 +196,7 @@ __global__ void __launch_bounds__(BLOCK) de_eval_tape_kernel(const KArgs<T> a) {
     const int64_t base = tm.tile * TILE;
     const int64_t last = a.N - 1;
 
-    // ---- stage the X tile: coalesced HBM read, transposed LDS write ----------
+    // ---- stage the X tile: coalesced HBM/L2 read, transposed LDS write ----------
     {
         const uint32_t F = (uint32_t)a.F;
         const uint32_t total = (uint32_t)TILE * F;
@@ -202,7 +217,7 @@ __global__ void __launch_bounds__(BLOCK) de_eval_tape_kernel(const KArgs<T> a) {
     }
     const int my = tid * K; // first sample of this thread inside the tile
     int64_t cls[K];
-    if (a.uses_params) {
+    if (PARAMS) {
         DE_UNROLL for (int i = 0; i < K; i++) {
             int64_t jj = base + my + i;
             jj = jj < last ? jj : last;
@@ -210,88 +225,78 @@ __global__ void __launch_bounds__(BLOCK) de_eval_tape_kernel(const KArgs<T> a) {
                                        : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) -
                      a.class_base;
         }
-    } else {
-        DE_UNROLL for (int i = 0; i < K; i++) cls[i] = 0;
     }
     __syncthreads();
 
+    const ConstU4Ptr code = (ConstU4Ptr)(uintptr_t)a.code;
+    const ConstI32Ptr code_off = (ConstI32Ptr)(uintptr_t)a.code_off;
     const int t0 = tm.chunk * a.trees_per_chunk;
     const int t1 = (t0 + a.trees_per_chunk < a.n_trees) ? t0 + a.trees_per_chunk : a.n_trees;
     const bool full = base + TILE <= a.N;
 
+    int pe = code_off[t0];
     for (int tree = t0; tree < t1; ++tree) {
-        int pc = a.code_off[tree];
-        const int pe = a.code_off[tree + 1];
-        T acc[K];
+        int pc = pe;
+        pe = code_off[tree + 1];
+        V acc;
         DE_UNROLL for (int i = 0; i < K; i++) acc[i] = T(0);
         bool bad = false;
+        U32x4 nxt = code[pc]; // scalar load; a tree has at least one instruction
         for (; pc < pe; ++pc) {
-            const Instr ins = a.code[pc]; // wave-uniform: scalar load
-            const uint32_t hdr = ins.hdr;
+            const U32x4 w = nxt;
+            nxt = code[pc + 1]; // prefetch (the code buffer carries one trailing pad instruction)
+            const uint32_t hdr = w.x;
             const uint32_t op = hdr & H_OP_MASK;
             const uint32_t src = (hdr >> H_SRC_SHIFT) & H_SRC_MASK;
-            if (hdr & H_PUSH) {
-                T *__restrict__ s = stk + ((hdr >> H_PUSH_SHIFT) & H_SLOT_MASK) * TILE + my;
-                DE_UNROLL for (int i = 0; i < K; i++) s[i] = acc[i];
-            }
-            T b[K];
-            switch (src) {
-            case SRC_FEAT: {
-                const T *__restrict__ s = xs + (ins.feat & 0xFFFFu) * xstride + my;
-                DE_UNROLL for (int i = 0; i < K; i++) b[i] = s[i];
-                break;
-            }
-            case SRC_CONST: {
-                const T c = imm_of<T>(ins);
+            if (hdr & H_PUSH) stkv[((hdr >> H_PUSH_SHIFT) & H_SLOT_MASK) * BLOCK + tid] = acc;
+            V b;
+            if (src == SRC_FEAT) {
+                b = xsv[(w.y & 0xFFFFu) * xstride_v + tid];
+            } else if (src == SRC_CONST) {
+                const T c = imm_of<T>(w.z, w.w);
                 DE_UNROLL for (int i = 0; i < K; i++) b[i] = c;
-                break;
-            }
-            case SRC_POP: {
-                const T *__restrict__ s = stk + ((hdr >> H_POP_SHIFT) & H_SLOT_MASK) * TILE + my;
-                DE_UNROLL for (int i = 0; i < K; i++) b[i] = s[i];
-                break;
-            }
-            case SRC_PARAM: {
-                const T *__restrict__ s = a.params + (ins.feat & 0xFFFFu);
-                DE_UNROLL for (int i = 0; i < K; i++) b[i] = s[a.ld_params * cls[i]];
-                break;
-            }
-            default: // SRC_ACC
-                DE_UNROLL for (int i = 0; i < K; i++) b[i] = acc[i];
-                break;
-            }
-            if (EE && (hdr & H_CHECK_B)) bad |= any_nonfinite<T, K>(b);
-            if (op >= DE_T_FMA && op < DOP_LOAD) {
-                T c[K];
-                const T *__restrict__ s = stk + ((hdr >> H_POPC_SHIFT) & H_SLOT_MASK) * TILE + my;
-                DE_UNROLL for (int i = 0; i < K; i++) c[i] = s[i];
-                apply_op3<T, K>(op, acc, b, c);
+            } else if (src == SRC_ACC) {
+                b = acc;
+            } else if (src == SRC_POP) {
+                b = stkv[((hdr >> H_POP_SHIFT) & H_SLOT_MASK) * BLOCK + tid];
             } else {
-                if (hdr & H_SWAP) {
-                    DE_UNROLL for (int i = 0; i < K; i++) {
-                        const T t = acc[i];
-                        acc[i] = b[i];
-                        b[i] = t;
-                    }
+                if (PARAMS) {
+                    const T *__restrict__ s = a.params + (w.y & 0xFFFFu);
+                    DE_UNROLL for (int i = 0; i < K; i++) b[i] = s[a.ld_params * cls[i]];
+                } else {
+                    b = acc;
                 }
-                apply_op<T, K>(op, acc, b);
+            }
+            if (EE && (hdr & H_CHECK_B)) bad |= any_nonfinite<T, K, V>(b);
+            // ---- fast path: the operators of the headline workload ----------------
+            if (op == DOP_LOAD) {
+                acc = b;
+            } else {
+                if (op == DE_B_ADD) acc = acc + b;
+                else if (op == DE_B_MUL) acc = acc * b;
+                else if (op == DE_B_SUB) acc = acc - b;
+                else if (op == DOP_RSUB) acc = b - acc;
+                else if (op == DE_B_DIV) acc = acc / b;
+                else if (op == DOP_RDIV) acc = b / acc;
+                else if (op == DE_U_COS) { DE_UNROLL for (int i = 0; i < K; i++) acc[i] = M<T>::cos(b[i]); }
+                else if (op == DE_U_EXP) { DE_UNROLL for (int i = 0; i < K; i++) acc[i] = M<T>::exp(b[i]); }
+                else if (op >= DE_T_FMA && op < DOP_LOAD) {
+                    const V c = stkv[((hdr >> H_POPC_SHIFT) & H_SLOT_MASK) * BLOCK + tid];
+                    apply_op3<T, K, V>(op, acc, b, c);
+                } else {
+                    apply_cold_op<T, K, V>(op, acc, b);
+                }
                 if (!EE && (hdr & H_INJECT)) { // is_valid(x_l) ? op(x_l) : Inf  (src/Evaluate.jl:722)
                     DE_UNROLL for (int i = 0; i < K; i++)
                         if (!M<T>::isfinite(b[i])) acc[i] = M<T>::inf();
                 }
+                if (EE || (hdr & H_CHECK_ALWAYS)) bad |= any_nonfinite<T, K, V>(acc);
             }
-            if (EE ? (op != DOP_LOAD) : ((hdr & H_CHECK_ALWAYS) != 0)) bad |= any_nonfinite<T, K>(acc);
         }
         // ---- store out[tree][base + my .. +K) ---------------------------------
         T *__restrict__ o = a.out + (int64_t)tree * a.ld_out + base + my;
         if (full && a.vec_store) {
-            if constexpr (K * sizeof(T) == 16) {
-                float4 v;
-                __builtin_memcpy(&v, acc, 16);
-                *reinterpret_cast<float4 *>(o) = v;
-            } else {
-                DE_UNROLL for (int i = 0; i < K; i++) o[i] = acc[i];
-            }
+            *reinterpret_cast<V *>(o) = acc;
         } else {
             DE_UNROLL for (int i = 0; i < K; i++)
                 if (base + my + i < a.N) o[i] = acc[i];
@@ -313,6 +318,14 @@ size_t eval_lds_bytes(int dtype, int F, int n_slots, int *K_out) {
 }
 
 static int g_cu_count = 0;
+
+template <typename T> struct KName;
+template <> struct KName<float> { static const char *get(bool ee, bool p) {
+    return ee ? (p ? "de_eval_tape_kernel<float, 4, true, true>" : "de_eval_tape_kernel<float, 4, true, false>")
+              : (p ? "de_eval_tape_kernel<float, 4, false, true>" : "de_eval_tape_kernel<float, 4, false, false>"); } };
+template <> struct KName<double> { static const char *get(bool ee, bool p) {
+    return ee ? (p ? "de_eval_tape_kernel<double, 2, true, true>" : "de_eval_tape_kernel<double, 2, true, false>")
+              : (p ? "de_eval_tape_kernel<double, 2, false, true>" : "de_eval_tape_kernel<double, 2, false, false>"); } };
 
 template <typename T, int K>
 static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const char **kname) {
@@ -336,7 +349,6 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
     a.xstride = TILE + (int)(16 / sizeof(T));
     a.classes_is_i64 = e.classes_is_i64;
     a.class_base = e.class_base;
-    a.uses_params = e.uses_params ? 1 : 0;
     a.vec_store = (reinterpret_cast<uintptr_t>(e.out) % 16 == 0 && (e.ld_out * sizeof(T)) % 16 == 0) ? 1 : 0;
 
     if (g_cu_count == 0) {
@@ -346,11 +358,13 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
             g_cu_count = prop.multiProcessorCount;
         if (g_cu_count <= 0) g_cu_count = 256;
     }
-    // Tree chunking: enough workgroups to fill the chip many times over (tail
-    // quantisation), but chunks long enough to amortise the X-tile staging.
-    const int64_t want_blocks = (int64_t)g_cu_count * 4 * 12;
-    int64_t n_chunks = (want_blocks + a.n_tiles - 1) / a.n_tiles;
-    const int64_t max_chunks = (e.n_trees + 15) / 16; // >= 16 trees per chunk
+    // Tree chunking: chunks of ~64 trees keep workgroups short (fine-grained tail) while
+    // the X-tile staging (one L2 read of the tile per chunk) stays a few percent of the work;
+    // with few sample tiles, split further so the grid still covers the chip several times.
+    int64_t n_chunks = (e.n_trees + 63) / 64;
+    const int64_t want_blocks = (int64_t)g_cu_count * 4 * 8;
+    if (a.n_tiles * n_chunks < want_blocks) n_chunks = (want_blocks + a.n_tiles - 1) / a.n_tiles;
+    const int64_t max_chunks = (e.n_trees + 7) / 8; // >= 8 trees per chunk
     if (n_chunks > max_chunks) n_chunks = max_chunks;
     if (n_chunks < 1) n_chunks = 1;
     a.trees_per_chunk = (int32_t)((e.n_trees + n_chunks - 1) / n_chunks);
@@ -361,10 +375,10 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const size_t lds = ((size_t)a.F * a.xstride + (size_t)a.n_slots * TILE) * sizeof(T);
 
-    auto kern = e.early_exit ? de_eval_tape_kernel<T, K, true> : de_eval_tape_kernel<T, K, false>;
-    if (kname)
-        *kname = sizeof(T) == 4 ? (e.early_exit ? "de_eval_tape_kernel<float, 4, true>" : "de_eval_tape_kernel<float, 4, false>")
-                                : (e.early_exit ? "de_eval_tape_kernel<double, 2, true>" : "de_eval_tape_kernel<double, 2, false>");
+    void (*kern)(const KArgs<T>);
+    if (e.early_exit) kern = e.uses_params ? de_eval_tape_kernel<T, K, true, true> : de_eval_tape_kernel<T, K, true, false>;
+    else kern = e.uses_params ? de_eval_tape_kernel<T, K, false, true> : de_eval_tape_kernel<T, K, false, false>;
+    if (kname) *kname = KName<T>::get(e.early_exit, e.uses_params);
     if (lds > 64 * 1024) {
         hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -189,6 +189,11 @@ struct Lowerer {
         case DE_B_ADD: case DE_B_MUL: case DE_B_MAX: case DE_B_MIN: return op; // commutative
         case DE_B_SUB: return DOP_RSUB;
         case DE_B_DIV: return DOP_RDIV;
+        case DE_B_POW: return DOP_RPOW;
+        case DE_B_MOD: return DOP_RMOD;
+        case DE_B_REM: return DOP_RREM;
+        case DE_B_GREATER: return DOP_RGREATER;
+        case DE_B_POW_ABS2: return DOP_RPOW_ABS2;
         default: *need_flag = true; return op;
         }
     }

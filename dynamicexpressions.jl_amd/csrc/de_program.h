@@ -20,8 +20,14 @@ namespace de {
 // Internal opcodes beyond include/de_opcodes.h (which are used verbatim).
 enum : uint32_t {
     DOP_LOAD = 0xF0, // acc = B
-    DOP_RSUB = 0xF1, // acc = B - acc
-    DOP_RDIV = 0xF2, // acc = B / acc
+    // reversed forms of the non-commutative binary operators: acc = op(B, acc)
+    DOP_RSUB = 0xF1,
+    DOP_RDIV = 0xF2,
+    DOP_RPOW = 0xF3,
+    DOP_RMOD = 0xF4,
+    DOP_RREM = 0xF5,
+    DOP_RGREATER = 0xF6,
+    DOP_RPOW_ABS2 = 0xF7,
 };
 
 // Operand-B kinds (hdr bits 8..10)
@@ -34,7 +40,7 @@ constexpr uint32_t H_PUSH = 1u << 11;         // spill acc to slot PUSH_SLOT bef
 constexpr uint32_t H_CHECK_B = 1u << 12;      // validity-test operand B (a leaf the reference tests)
 constexpr uint32_t H_CHECK_ALWAYS = 1u << 13; // result of a constant-folded subtree: tested even without early_exit
 constexpr uint32_t H_INJECT = 1u << 14;       // reference fused deg1 kernels: non-finite input => Inf
-constexpr uint32_t H_SWAP = 1u << 15;         // binary: op(B, acc)
+constexpr uint32_t H_SWAP = 1u << 15;         // (reserved; reversed operand order is encoded in the opcode)
 constexpr uint32_t H_POP_SHIFT = 16;          // bits 16..19: slot read by SRC_POP
 constexpr uint32_t H_PUSH_SHIFT = 20;         // bits 20..23: slot written by H_PUSH
 constexpr uint32_t H_POPC_SHIFT = 24;         // bits 24..27: second slot of a ternary op

@@ -58,6 +58,8 @@ BINARY = {
     73: lambda x, y: (x > y).astype(x.dtype), 74: lambda x, y: np.exp(y * np.log(np.abs(x))),
     DOP_RSUB: lambda x, y: y - x, DOP_RDIV: lambda x, y: y / x,
 }
+for _r, _f in ((0xF3, 68), (0xF4, 71), (0xF5, 72), (0xF6, 73), (0xF7, 74)):
+    BINARY[_r] = (lambda f: lambda x, y: f(y, x))(BINARY[_f])
 TERNARY = {
     128: lambda x, y, z: x * y + z,  # (fma: single rounding on device; tolerance in the test)
     129: lambda x, y, z: np.where(x > z, z, np.where(x < y, y, x)),
