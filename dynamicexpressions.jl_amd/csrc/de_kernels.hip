@@ -23,6 +23,8 @@
 //  * No MFMA: this is an elementwise map, not a contraction.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "de_device_ops.h"
 #include "de_kernels.h"
 
@@ -48,9 +50,11 @@ template <typename T> struct KArgs {
     int32_t classes_is_i64, class_base, vec_store;
 };
 
-template <typename T, int K> struct VecOf;
-template <> struct VecOf<float, 4> { typedef float type __attribute__((ext_vector_type(4))); };
-template <> struct VecOf<double, 2> { typedef double type __attribute__((ext_vector_type(2))); };
+// A thread owns G groups of VW consecutive samples (VW*sizeof(T) = 16 bytes, one
+// ds_read_b128 / global_store_dwordx4 per group): samples base + g*(BLOCK*VW) + tid*VW + i.
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int W = 4; };
+template <> struct VecOf<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int W = 2; };
 
 template <typename T> __device__ __forceinline__ T imm_of(uint32_t w2, uint32_t w3);
 template <> __device__ __forceinline__ float imm_of<float>(uint32_t w2, uint32_t) { return __uint_as_float(w2); }
@@ -59,28 +63,31 @@ template <> __device__ __forceinline__ double imm_of<double>(uint32_t w2, uint32
 }
 
 #define DE_UNROLL _Pragma("unroll")
+#define FOR_G DE_UNROLL for (int g = 0; g < G; g++)
+#define FOR_I DE_UNROLL for (int i = 0; i < VW; i++)
 
 // acc = f(b) for every sample
 #define U_CASE(OPC, EXPR)                                    \
     case OPC:                                                \
-        DE_UNROLL for (int i = 0; i < K; i++) {              \
-            const T x = b[i];                                \
-            acc[i] = (EXPR);                                 \
+        FOR_G FOR_I {                                        \
+            const T x = b[g][i];                             \
+            acc[g][i] = (EXPR);                              \
         }                                                    \
         break;
 // acc = f(acc, b)
 #define B_CASE(OPC, EXPR)                                    \
     case OPC:                                                \
-        DE_UNROLL for (int i = 0; i < K; i++) {              \
-            const T x = acc[i], y = b[i];                    \
-            acc[i] = (EXPR);                                 \
+        FOR_G FOR_I {                                        \
+            const T x = acc[g][i], y = b[g][i];              \
+            acc[g][i] = (EXPR);                              \
         }                                                    \
         break;
 
 // Everything that is not on the fast path of the interpreter loop.
-template <typename T, int K, typename V>
-__device__ __forceinline__ void apply_cold_op(uint32_t op, V &acc, const V &b) {
+template <typename T, int G, typename V>
+__device__ __forceinline__ void apply_cold_op(uint32_t op, V (&acc)[G], const V (&b)[G]) {
     using m = M<T>;
+    constexpr int VW = VecOf<T>::W;
     switch (op) {
         U_CASE(DE_U_NEG, -x)
         U_CASE(DE_U_ABS, m::abs(x))
@@ -117,9 +124,9 @@ __device__ __forceinline__ void apply_cold_op(uint32_t op, V &acc, const V &b) {
         U_CASE(DE_U_SAFE_SQRT, x < T(0) ? m::nan() : m::sqrt(x))
         U_CASE(DE_U_SAFE_ACOSH, x < T(1) ? m::nan() : m::acosh(x))
     case DE_U_COS2:
-        DE_UNROLL for (int i = 0; i < K; i++) {
-            const T c = m::cos(b[i]);
-            acc[i] = c * c;
+        FOR_G FOR_I {
+            const T c = m::cos(b[g][i]);
+            acc[g][i] = c * c;
         }
         break;
         U_CASE(DE_U_GAMMA, m::tgamma(x))
@@ -140,11 +147,12 @@ __device__ __forceinline__ void apply_cold_op(uint32_t op, V &acc, const V &b) {
 }
 
 // acc = op3(b, c, acc): b, c from spill slots, acc = third argument
-template <typename T, int K, typename V>
-__device__ __forceinline__ void apply_op3(uint32_t op, V &acc, const V &b, const V &c) {
+template <typename T, int G, typename V>
+__device__ __forceinline__ void apply_op3(uint32_t op, V (&acc)[G], const V (&b)[G], const V (&c)[G]) {
     using m = M<T>;
-    DE_UNROLL for (int i = 0; i < K; i++) {
-        const T x = b[i], y = c[i], z = acc[i];
+    constexpr int VW = VecOf<T>::W;
+    FOR_G FOR_I {
+        const T x = b[g][i], y = c[g][i], z = acc[g][i];
         T r;
         switch (op) {
         case DE_T_FMA: r = m::fma(x, y, z); break;
@@ -152,14 +160,16 @@ __device__ __forceinline__ void apply_op3(uint32_t op, V &acc, const V &b, const
         case DE_T_ADD3: r = (x + y) + z; break;
         default: r = jl_max(jl_max(x, y), z); break;
         }
-        acc[i] = r;
+        acc[g][i] = r;
     }
 }
 
-template <typename T, int K, typename V> __device__ __forceinline__ bool any_nonfinite(const V &v) {
-    bool bad = false;
-    DE_UNROLL for (int i = 0; i < K; i++) bad |= !M<T>::isfinite(v[i]);
-    return bad;
+// Validity accumulation without touching the scalar unit: poison = fma(v, 0, poison) stays
+// +0 while every tested value is finite and turns (and stays) NaN at the first Inf/NaN.
+template <typename T, int G, typename V>
+__device__ __forceinline__ void poison_with(T &poison, const V (&v)[G]) {
+    constexpr int VW = VecOf<T>::W;
+    FOR_G FOR_I poison = M<T>::fma(v[g][i], T(0), poison);
 }
 
 // XCD-aware block mapping: hardware dispatches block b to XCD b % 8 (observed, used
@@ -179,16 +189,16 @@ __device__ __forceinline__ TileMap map_block(uint32_t bid, int32_t n_chunks, int
     return m;
 }
 
-template <typename T, int K, bool EE, bool PARAMS>
-__global__ void __launch_bounds__(BLOCK) de_eval_tape_kernel(const KArgs<T> a) {
-    typedef typename VecOf<T, K>::type V;
-    constexpr int TILE = BLOCK * K;
+template <typename T, int G, int BLK, bool EE, bool PARAMS>
+__global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VW = VecOf<T>::W;
+    constexpr int GT = BLK * VW;        // samples per group plane
+    constexpr int TILE = GT * G;        // samples per workgroup
+    constexpr int ROWV = BLK * G + 1;   // LDS row stride in vectors (+1: bank spread for the staging writes)
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    T *__restrict__ xs = reinterpret_cast<T *>(smem_raw);
-    const int xstride = a.xstride; // multiple of K: every row starts 16-byte aligned
-    V *__restrict__ xsv = reinterpret_cast<V *>(smem_raw);
-    V *__restrict__ stkv = reinterpret_cast<V *>(xs + (size_t)a.F * xstride);
-    const int xstride_v = xstride / K;
+    T *__restrict__ rows = reinterpret_cast<T *>(smem_raw);  // rows 0..F-1: X tile; row F+s: spill slot s
+    V *__restrict__ rowsv = reinterpret_cast<V *>(smem_raw);
 
     const TileMap tm = map_block(blockIdx.x, a.n_chunks, a.n_tiles);
     if (!tm.valid) return;
@@ -197,33 +207,33 @@ __global__ void __launch_bounds__(BLOCK) de_eval_tape_kernel(const KArgs<T> a) {
     const int64_t last = a.N - 1;
 
     // ---- stage the X tile: coalesced HBM/L2 read, transposed LDS write ----------
+    // sample j of the tile lives at rows[f*ROWV*VW + j]  (plane g = j / GT, lane = (j % GT) / VW)
     {
         const uint32_t F = (uint32_t)a.F;
         const uint32_t total = (uint32_t)TILE * F;
         if (a.ldX == (int64_t)F && base + TILE <= a.N) {
             const T *__restrict__ src = a.X + base * (int64_t)F; // contiguous TILE*F elements
-            for (uint32_t e = tid; e < total; e += BLOCK) {
+            for (uint32_t e = tid; e < total; e += BLK) {
                 const uint32_t j = e / F, f = e - j * F;
-                xs[f * xstride + j] = src[e];
+                rows[f * (ROWV * VW) + j] = src[e];
             }
         } else { // ragged tail / strided X: clamp to the last real sample
-            for (uint32_t e = tid; e < total; e += BLOCK) {
+            for (uint32_t e = tid; e < total; e += BLK) {
                 const uint32_t j = e / F, f = e - j * F;
                 int64_t jj = base + j;
                 jj = jj < last ? jj : last;
-                xs[f * xstride + j] = a.X[f + a.ldX * jj];
+                rows[f * (ROWV * VW) + j] = a.X[f + a.ldX * jj];
             }
         }
     }
-    const int my = tid * K; // first sample of this thread inside the tile
-    int64_t cls[K];
+    int64_t cls[G][VW];
     if (PARAMS) {
-        DE_UNROLL for (int i = 0; i < K; i++) {
-            int64_t jj = base + my + i;
+        FOR_G FOR_I {
+            int64_t jj = base + g * GT + tid * VW + i;
             jj = jj < last ? jj : last;
-            cls[i] = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
-                                       : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) -
-                     a.class_base;
+            cls[g][i] = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
+                                          : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) -
+                        a.class_base;
         }
     }
     __syncthreads();
@@ -233,14 +243,15 @@ __global__ void __launch_bounds__(BLOCK) de_eval_tape_kernel(const KArgs<T> a) {
     const int t0 = tm.chunk * a.trees_per_chunk;
     const int t1 = (t0 + a.trees_per_chunk < a.n_trees) ? t0 + a.trees_per_chunk : a.n_trees;
     const bool full = base + TILE <= a.N;
+    const int F = a.F;
 
     int pe = code_off[t0];
     for (int tree = t0; tree < t1; ++tree) {
         int pc = pe;
         pe = code_off[tree + 1];
-        V acc;
-        DE_UNROLL for (int i = 0; i < K; i++) acc[i] = T(0);
-        bool bad = false;
+        V acc[G];
+        FOR_G FOR_I acc[g][i] = T(0);
+        T poison = T(0);
         U32x4 nxt = code[pc]; // scalar load; a tree has at least one instruction
         for (; pc < pe; ++pc) {
             const U32x4 w = nxt;
@@ -248,88 +259,94 @@ __global__ void __launch_bounds__(BLOCK) de_eval_tape_kernel(const KArgs<T> a) {
             const uint32_t hdr = w.x;
             const uint32_t op = hdr & H_OP_MASK;
             const uint32_t src = (hdr >> H_SRC_SHIFT) & H_SRC_MASK;
-            if (hdr & H_PUSH) stkv[((hdr >> H_PUSH_SHIFT) & H_SLOT_MASK) * BLOCK + tid] = acc;
-            V b;
-            if (src == SRC_FEAT) {
-                b = xsv[(w.y & 0xFFFFu) * xstride_v + tid];
+            if (hdr & H_PUSH) {
+                V *__restrict__ s = rowsv + (F + ((hdr >> H_PUSH_SHIFT) & H_SLOT_MASK)) * ROWV + tid;
+                FOR_G s[g * BLK] = acc[g];
+            }
+            V b[G];
+            if (src == SRC_ROW) {
+                const V *__restrict__ s = rowsv + (w.y & 0xFFFFu) * ROWV + tid;
+                FOR_G b[g] = s[g * BLK];
             } else if (src == SRC_CONST) {
                 const T c = imm_of<T>(w.z, w.w);
-                DE_UNROLL for (int i = 0; i < K; i++) b[i] = c;
-            } else if (src == SRC_ACC) {
-                b = acc;
-            } else if (src == SRC_POP) {
-                b = stkv[((hdr >> H_POP_SHIFT) & H_SLOT_MASK) * BLOCK + tid];
+                FOR_G FOR_I b[g][i] = c;
+            } else if (PARAMS && src == SRC_PARAM) {
+                const T *__restrict__ s = a.params + (w.y & 0xFFFFu);
+                FOR_G FOR_I b[g][i] = s[a.ld_params * cls[g][i]];
             } else {
-                if (PARAMS) {
-                    const T *__restrict__ s = a.params + (w.y & 0xFFFFu);
-                    DE_UNROLL for (int i = 0; i < K; i++) b[i] = s[a.ld_params * cls[i]];
-                } else {
-                    b = acc;
-                }
+                FOR_G b[g] = acc[g];
             }
-            if (EE && (hdr & H_CHECK_B)) bad |= any_nonfinite<T, K, V>(b);
+            if (EE && (hdr & H_CHECK_B)) poison_with<T, G, V>(poison, b);
             // ---- fast path: the operators of the headline workload ----------------
             if (op == DOP_LOAD) {
-                acc = b;
+                FOR_G acc[g] = b[g];
             } else {
-                if (op == DE_B_ADD) acc = acc + b;
-                else if (op == DE_B_MUL) acc = acc * b;
-                else if (op == DE_B_SUB) acc = acc - b;
-                else if (op == DOP_RSUB) acc = b - acc;
-                else if (op == DE_B_DIV) acc = acc / b;
-                else if (op == DOP_RDIV) acc = b / acc;
-                else if (op == DE_U_COS) { DE_UNROLL for (int i = 0; i < K; i++) acc[i] = M<T>::cos(b[i]); }
-                else if (op == DE_U_EXP) { DE_UNROLL for (int i = 0; i < K; i++) acc[i] = M<T>::exp(b[i]); }
+                if (op == DE_B_ADD) { FOR_G acc[g] = acc[g] + b[g]; }
+                else if (op == DE_B_MUL) { FOR_G acc[g] = acc[g] * b[g]; }
+                else if (op == DE_B_SUB) { FOR_G acc[g] = acc[g] - b[g]; }
+                else if (op == DOP_RSUB) { FOR_G acc[g] = b[g] - acc[g]; }
+                else if (op == DE_B_DIV) { FOR_G acc[g] = acc[g] / b[g]; }
+                else if (op == DOP_RDIV) { FOR_G acc[g] = b[g] / acc[g]; }
+                else if (op == DE_U_COS) { FOR_G FOR_I acc[g][i] = M<T>::cos(b[g][i]); }
+                else if (op == DE_U_EXP) { FOR_G FOR_I acc[g][i] = M<T>::exp(b[g][i]); }
                 else if (op >= DE_T_FMA && op < DOP_LOAD) {
-                    const V c = stkv[((hdr >> H_POPC_SHIFT) & H_SLOT_MASK) * BLOCK + tid];
-                    apply_op3<T, K, V>(op, acc, b, c);
+                    V c[G];
+                    const V *__restrict__ s = rowsv + (F + ((hdr >> H_POPC_SHIFT) & H_SLOT_MASK)) * ROWV + tid;
+                    FOR_G c[g] = s[g * BLK];
+                    apply_op3<T, G, V>(op, acc, b, c);
                 } else {
-                    apply_cold_op<T, K, V>(op, acc, b);
+                    apply_cold_op<T, G, V>(op, acc, b);
                 }
                 if (!EE && (hdr & H_INJECT)) { // is_valid(x_l) ? op(x_l) : Inf  (src/Evaluate.jl:722)
-                    DE_UNROLL for (int i = 0; i < K; i++)
-                        if (!M<T>::isfinite(b[i])) acc[i] = M<T>::inf();
+                    FOR_G FOR_I if (!M<T>::isfinite(b[g][i])) acc[g][i] = M<T>::inf();
                 }
-                if (EE || (hdr & H_CHECK_ALWAYS)) bad |= any_nonfinite<T, K, V>(acc);
+                if (hdr & (EE ? H_CHECK_OUT : H_CHECK_ALWAYS)) poison_with<T, G, V>(poison, acc);
             }
         }
-        // ---- store out[tree][base + my .. +K) ---------------------------------
-        T *__restrict__ o = a.out + (int64_t)tree * a.ld_out + base + my;
+        // ---- store out[tree][...]: one 16-byte store per group, coalesced over the wave
+        T *__restrict__ o = a.out + (int64_t)tree * a.ld_out + base + tid * VW;
         if (full && a.vec_store) {
-            *reinterpret_cast<V *>(o) = acc;
+            FOR_G *reinterpret_cast<V *>(o + g * GT) = acc[g];
         } else {
-            DE_UNROLL for (int i = 0; i < K; i++)
-                if (base + my + i < a.N) o[i] = acc[i];
+            FOR_G FOR_I if (base + g * GT + tid * VW + i < a.N) o[g * GT + i] = acc[g][i];
         }
         // ---- completion flag: one ballot per wave, one byte store per failing wave
-        if (__ballot(bad) != 0ull && (tid & 63) == 0) a.ok[tree] = 0;
+        if (__ballot(poison != poison) != 0ull && (tid & 63) == 0) a.ok[tree] = 0;
     }
 }
 
 // ---------------------------------------------------------------------------
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// Kernel geometry: G groups of 16-byte vectors per thread, BLK threads per workgroup.
+// Defaults chosen on MI355X; DE_EVAL_G / DE_EVAL_BLOCK override
+// them for experiments.
+static void eval_geometry(int dtype, int *G, int *BLK) {
+    *G = env_int("DE_EVAL_G", 1);
+    *BLK = env_int("DE_EVAL_BLOCK", 256);
+    if (*G != 1 && *G != 2) *G = 1;
+    if (*BLK != 128 && *BLK != 256) *BLK = 256;
+    (void)dtype;
+}
+
 size_t eval_lds_bytes(int dtype, int F, int n_slots, int *K_out) {
-    const size_t es = dtype == DE_F32 ? 4 : 8;
-    const int K = dtype == DE_F32 ? 4 : 2;
-    const size_t tile = (size_t)BLOCK * K;
-    const size_t xstride = tile + 16 / es;
-    const size_t bytes = ((size_t)F * xstride + (size_t)n_slots * tile) * es;
-    if (K_out) *K_out = K;
+    int G, BLK;
+    eval_geometry(dtype, &G, &BLK);
+    const size_t rowv = (size_t)BLK * G + 1;
+    const size_t bytes = (size_t)(F + n_slots) * rowv * 16;
+    if (K_out) *K_out = (dtype == DE_F32 ? 4 : 2) * G;
     return bytes <= 160 * 1024 ? bytes : 0;
 }
 
 static int g_cu_count = 0;
 
-template <typename T> struct KName;
-template <> struct KName<float> { static const char *get(bool ee, bool p) {
-    return ee ? (p ? "de_eval_tape_kernel<float, 4, true, true>" : "de_eval_tape_kernel<float, 4, true, false>")
-              : (p ? "de_eval_tape_kernel<float, 4, false, true>" : "de_eval_tape_kernel<float, 4, false, false>"); } };
-template <> struct KName<double> { static const char *get(bool ee, bool p) {
-    return ee ? (p ? "de_eval_tape_kernel<double, 2, true, true>" : "de_eval_tape_kernel<double, 2, true, false>")
-              : (p ? "de_eval_tape_kernel<double, 2, false, true>" : "de_eval_tape_kernel<double, 2, false, false>"); } };
-
-template <typename T, int K>
+template <typename T, int G, int BLK>
 static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const char **kname) {
-    constexpr int TILE = BLOCK * K;
+    constexpr int VW = VecOf<T>::W;
+    constexpr int TILE = BLK * VW * G;
     KArgs<T> a;
     a.code = e.code;
     a.code_off = e.code_off;
@@ -346,7 +363,7 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
     a.F = e.F;
     a.n_trees = e.n_trees;
     a.n_slots = e.n_slots;
-    a.xstride = TILE + (int)(16 / sizeof(T));
+    a.xstride = 0;
     a.classes_is_i64 = e.classes_is_i64;
     a.class_base = e.class_base;
     a.vec_store = (reinterpret_cast<uintptr_t>(e.out) % 16 == 0 && (e.ld_out * sizeof(T)) % 16 == 0) ? 1 : 0;
@@ -373,24 +390,32 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
     const int64_t tile_groups = (a.n_tiles + 7) / 8;
     const int64_t blocks = tile_groups * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)a.F * a.xstride + (size_t)a.n_slots * TILE) * sizeof(T);
+    const size_t lds = (size_t)(a.F + a.n_slots) * ((size_t)BLK * G + 1) * 16;
 
     void (*kern)(const KArgs<T>);
-    if (e.early_exit) kern = e.uses_params ? de_eval_tape_kernel<T, K, true, true> : de_eval_tape_kernel<T, K, true, false>;
-    else kern = e.uses_params ? de_eval_tape_kernel<T, K, false, true> : de_eval_tape_kernel<T, K, false, false>;
-    if (kname) *kname = KName<T>::get(e.early_exit, e.uses_params);
+    if (e.early_exit) kern = e.uses_params ? de_eval_tape_kernel<T, G, BLK, true, true> : de_eval_tape_kernel<T, G, BLK, true, false>;
+    else kern = e.uses_params ? de_eval_tape_kernel<T, G, BLK, false, true> : de_eval_tape_kernel<T, G, BLK, false, false>;
+    if (kname) *kname = "de_eval_tape_kernel";
     if (lds > 64 * 1024) {
         hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (st != hipSuccess) return st;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLOCK), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(BLK), lds, stream, a);
     return hipGetLastError();
 }
 
+template <typename T>
+static hipError_t launch_eval_geo(const EvalArgs &a, hipStream_t stream, const char **kn, int G, int BLK) {
+    if (G == 2) return BLK == 128 ? launch_eval_t<T, 2, 128>(a, stream, kn) : launch_eval_t<T, 2, 256>(a, stream, kn);
+    return BLK == 128 ? launch_eval_t<T, 1, 128>(a, stream, kn) : launch_eval_t<T, 1, 256>(a, stream, kn);
+}
+
 hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const char **kernel_name) {
-    if (dtype == DE_F32) return launch_eval_t<float, 4>(a, stream, kernel_name);
-    return launch_eval_t<double, 2>(a, stream, kernel_name);
+    int G, BLK;
+    eval_geometry(dtype, &G, &BLK);
+    if (dtype == DE_F32) return launch_eval_geo<float>(a, stream, kernel_name, G, BLK);
+    return launch_eval_geo<double>(a, stream, kernel_name, G, BLK);
 }
 
 } // namespace de

@@ -173,7 +173,7 @@ struct Lowerer {
             ins.feat = (uint32_t)lf.arg << 16;
             out->const_instr[lf.arg] = (int32_t)(&ins - out->code.data());
         } else if (lf.op == DE_LEAF_FEATURE) {
-            ins.hdr |= SRC_FEAT << H_SRC_SHIFT;
+            ins.hdr |= SRC_ROW << H_SRC_SHIFT;
             ins.feat = lf.arg;
             if (lf.chk_leaf) ins.hdr |= H_CHECK_B;
         } else {
@@ -183,8 +183,12 @@ struct Lowerer {
             out->uses_params = true;
         }
     }
-    static uint32_t swapped(uint32_t op, bool *need_flag) {
-        *need_flag = false;
+    void set_pop_operand(Instr &ins, int slot) { // spill slot s lives in LDS row F + s
+        ins.hdr |= SRC_ROW << H_SRC_SHIFT;
+        ins.feat = (uint32_t)(opt.n_features + slot);
+    }
+    static uint32_t swapped(uint32_t op, bool *unsupported) {
+        *unsupported = false;
         switch (op) {
         case DE_B_ADD: case DE_B_MUL: case DE_B_MAX: case DE_B_MIN: return op; // commutative
         case DE_B_SUB: return DOP_RSUB;
@@ -194,7 +198,7 @@ struct Lowerer {
         case DE_B_REM: return DOP_RREM;
         case DE_B_GREATER: return DOP_RGREATER;
         case DE_B_POW_ABS2: return DOP_RPOW_ABS2;
-        default: *need_flag = true; return op;
+        default: *unsupported = true; return op;
         }
     }
     void op_flags(Instr &ins, const LNode &n) {
@@ -237,7 +241,6 @@ struct Lowerer {
                 gen(r, depth);
                 bool flag;
                 Instr &ins = emit(swapped(n.op, &flag));
-                if (flag) ins.hdr |= H_SWAP;
                 set_leaf_operand(ins, l);
                 op_flags(ins, n);
                 return;
@@ -249,15 +252,14 @@ struct Lowerer {
                 gen(r, depth + 1);
                 bool flag;
                 Instr &ins = emit(swapped(n.op, &flag));
-                if (flag) ins.hdr |= H_SWAP;
-                ins.hdr |= (SRC_POP << H_SRC_SHIFT) | ((uint32_t)depth << H_POP_SHIFT);
+                set_pop_operand(ins, depth);
                 op_flags(ins, n);
             } else { // right first (also on ties: natural operand order, no swap)
                 gen(r, depth);
                 pending_push = depth;
                 gen(l, depth + 1);
                 Instr &ins = emit(n.op);
-                ins.hdr |= (SRC_POP << H_SRC_SHIFT) | ((uint32_t)depth << H_POP_SHIFT);
+                set_pop_operand(ins, depth);
                 op_flags(ins, n);
             }
             return;
@@ -270,11 +272,67 @@ struct Lowerer {
         pending_push = depth + 1;
         gen(n.child[2], depth + 2);
         Instr &ins = emit(n.op);
-        ins.hdr |= (SRC_POP << H_SRC_SHIFT) | ((uint32_t)depth << H_POP_SHIFT) |
-                   ((uint32_t)(depth + 1) << H_POPC_SHIFT);
+        set_pop_operand(ins, depth);
+        ins.hdr |= (uint32_t)(depth + 1) << H_POPC_SHIFT;
         op_flags(ins, n);
     }
 };
+
+// Does `op` map a non-finite value arriving at the given operand position onto a
+// non-finite result?  (acc_pos: the value is the accumulator / unary input; otherwise it is
+// operand B.)  Conservative: false when unsure.
+bool propagates_nonfinite(uint32_t op, bool acc_pos) {
+    switch (op) {
+    case DE_B_ADD: case DE_B_SUB: case DOP_RSUB: case DE_B_MUL: return true;
+    case DE_B_DIV: return acc_pos;   // acc / B : numerator
+    case DOP_RDIV: return !acc_pos;  // B / acc : numerator is B
+    case DE_U_NEG: case DE_U_ABS: case DE_U_SQUARE: case DE_U_CUBE: case DE_U_ROUND: case DE_U_FLOOR:
+    case DE_U_CEIL: case DE_U_SQRT: case DE_U_CBRT: case DE_U_LOG: case DE_U_LOG2: case DE_U_LOG10:
+    case DE_U_LOG1P: case DE_U_SIN: case DE_U_COS: case DE_U_TAN: case DE_U_SINH: case DE_U_COSH:
+    case DE_U_ASIN: case DE_U_ACOS: case DE_U_ASINH: case DE_U_ACOSH: case DE_U_ATANH:
+    case DE_U_SAFE_LOG: case DE_U_SAFE_LOG2: case DE_U_SAFE_LOG10: case DE_U_SAFE_LOG1P:
+    case DE_U_SAFE_SQRT: case DE_U_SAFE_ACOSH: case DE_U_COS2:
+        return true;
+    default: return false; // exp(-Inf)=0, 1/Inf=0, tanh, atan, max/min, pow, mod, rem, greater, n-ary ...
+    }
+}
+
+// Decide H_CHECK_OUT for every instruction (early-exit flag semantics, see de_program.h).
+void assign_check_out(std::vector<Instr> &code, int n_features) {
+    const size_t n = code.size();
+    for (size_t i = 0; i < n; i++) {
+        Instr &ins = code[i];
+        const uint32_t op = ins.hdr & H_OP_MASK;
+        if (op == DOP_LOAD) continue; // a leaf value, tested only through H_CHECK_B
+        bool need = true;
+        if (i + 1 < n) {
+            const Instr &nx = code[i + 1];
+            if (nx.hdr & H_PUSH) { // value is spilled: consumed later as an LDS row operand
+                const uint32_t row = (uint32_t)n_features + ((nx.hdr >> H_PUSH_SHIFT) & H_SLOT_MASK);
+                for (size_t j = i + 2; j < n; j++) {
+                    const Instr &c = code[j];
+                    const uint32_t cop = c.hdr & H_OP_MASK;
+                    const bool is_row = ((c.hdr >> H_SRC_SHIFT) & H_SRC_MASK) == SRC_ROW;
+                    if (is_row && (c.feat & 0xFFFFu) == row) { // the consumer reads it as operand B
+                        const bool binary = (cop >= DE_B_ADD && cop < DE_T_FMA) || cop >= DOP_RSUB;
+                        need = !(binary && propagates_nonfinite(cop, false));
+                        break;
+                    }
+                    if (cop >= DE_T_FMA && cop < DOP_LOAD &&
+                        (uint32_t)n_features + ((c.hdr >> H_POPC_SHIFT) & H_SLOT_MASK) == row)
+                        break; // second operand of a ternary: keep the test
+                }
+            } else { // consumed by the next instruction through the accumulator
+                const uint32_t nop = nx.hdr & H_OP_MASK;
+                const uint32_t nsrc = (nx.hdr >> H_SRC_SHIFT) & H_SRC_MASK;
+                const bool ternary = nop >= DE_T_FMA && nop < DOP_LOAD;
+                const bool reads_acc = (nop >= DE_B_ADD && nop != DOP_LOAD) || nsrc == SRC_ACC;
+                if (reads_acc && !ternary) need = !propagates_nonfinite(nop, true);
+            }
+        }
+        if (need) ins.hdr |= H_CHECK_OUT;
+    }
+}
 
 } // namespace
 
@@ -354,6 +412,7 @@ int lower_tree(const de_tape_node_t *tape, int64_t n, int64_t n_consts, const Lo
         const Instr &ins = out->code[k];
         if (((ins.hdr >> H_SRC_SHIFT) & H_SRC_MASK) == SRC_CONST) out->const_instr[ins.feat >> 16] = (int32_t)k;
     }
+    assign_check_out(out->code, opt.n_features);
     out->n_slots = L.max_slots;
     return DE_OK;
 }

@@ -30,8 +30,10 @@ enum : uint32_t {
     DOP_RPOW_ABS2 = 0xF7,
 };
 
-// Operand-B kinds (hdr bits 8..10)
-enum : uint32_t { SRC_ACC = 0, SRC_FEAT = 1, SRC_CONST = 2, SRC_POP = 3, SRC_PARAM = 4 };
+// Operand-B kinds (hdr bits 8..10).  SRC_ROW reads an LDS row: rows 0..F-1 are the
+// staged features of X, row F+s is spill slot s (so a leaf and a popped value are the
+// same kind of access to the kernel).
+enum : uint32_t { SRC_ACC = 0, SRC_ROW = 1, SRC_CONST = 2, SRC_PARAM = 4 };
 
 // hdr layout
 constexpr uint32_t H_OP_MASK = 0xFFu;
@@ -40,8 +42,11 @@ constexpr uint32_t H_PUSH = 1u << 11;         // spill acc to slot PUSH_SLOT bef
 constexpr uint32_t H_CHECK_B = 1u << 12;      // validity-test operand B (a leaf the reference tests)
 constexpr uint32_t H_CHECK_ALWAYS = 1u << 13; // result of a constant-folded subtree: tested even without early_exit
 constexpr uint32_t H_INJECT = 1u << 14;       // reference fused deg1 kernels: non-finite input => Inf
-constexpr uint32_t H_SWAP = 1u << 15;         // (reserved; reversed operand order is encoded in the opcode)
-constexpr uint32_t H_POP_SHIFT = 16;          // bits 16..19: slot read by SRC_POP
+// early-exit mode: validity-test the RESULT of this instruction.  Cleared by the lowering when
+// the (single) consumer of the value provably turns a non-finite input into a non-finite,
+// tested output (x+y, x-y, x*y, numerator of x/y, cos, ...): the flag stays exact while most
+// tests disappear from the instruction stream.
+constexpr uint32_t H_CHECK_OUT = 1u << 15;
 constexpr uint32_t H_PUSH_SHIFT = 20;         // bits 20..23: slot written by H_PUSH
 constexpr uint32_t H_POPC_SHIFT = 24;         // bits 24..27: second slot of a ternary op
 constexpr uint32_t H_SLOT_MASK = 0xFu;
@@ -50,7 +55,7 @@ constexpr int MAX_SLOTS = 16;
 // One instruction = 16 bytes = one s_load_dwordx4.
 struct alignas(16) Instr {
     uint32_t hdr;
-    uint32_t feat; // [15:0] feature / parameter row of B; [31:16] gradient row of a CONST operand
+    uint32_t feat; // [15:0] LDS row (SRC_ROW) / parameter row (SRC_PARAM) of B; [31:16] gradient row of a CONST operand
     union {
         float f32;
         double f64;

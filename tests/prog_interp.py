@@ -7,7 +7,7 @@ imports it and it is not a fallback path.
 import numpy as np
 
 DOP_LOAD, DOP_RSUB, DOP_RDIV = 0xF0, 0xF1, 0xF2
-SRC_ACC, SRC_FEAT, SRC_CONST, SRC_POP, SRC_PARAM = 0, 1, 2, 3, 4
+SRC_ACC, SRC_ROW, SRC_CONST, SRC_PARAM = 0, 1, 2, 4
 
 
 def _jlmax(x, y):
@@ -84,16 +84,16 @@ def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noi
         for w in words:
             hdr, feat = int(w[0]), int(w[1])
             op, src = hdr & 0xFF, (hdr >> 8) & 7
+            F = X.shape[0]
             if hdr & (1 << 11):
-                stack[(hdr >> 20) & 15] = acc.copy()
-            if src == SRC_FEAT:
-                b = X[feat & 0xFFFF].copy()
+                stack[F + ((hdr >> 20) & 15)] = acc.copy()
+            if src == SRC_ROW:
+                row = feat & 0xFFFF
+                b = X[row].copy() if row < F else stack[row].copy()
             elif src == SRC_CONST:
                 imm = np.array([w[2], w[3]], dtype=np.uint32)
                 c = imm[:1].view(np.float32)[0] if dt == np.float32 else imm.view(np.float64)[0]
                 b = np.full(N, c, dtype=dt)
-            elif src == SRC_POP:
-                b = stack[(hdr >> 16) & 15].copy()
             elif src == SRC_PARAM:
                 b = params[feat & 0xFFFF, classes0].astype(dt)
             else:
@@ -101,11 +101,9 @@ def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noi
             if early_exit and (hdr & (1 << 12)):
                 bad |= bool(np.any(~np.isfinite(b)))
             if 128 <= op < DOP_LOAD:
-                c2 = stack[(hdr >> 24) & 15]
+                c2 = stack[F + ((hdr >> 24) & 15)]
                 acc = TERNARY[op](b, c2, acc).astype(dt)
             else:
-                if hdr & (1 << 15):
-                    acc, b = b, acc
                 if op == DOP_LOAD:
                     acc = b
                 elif op < 64:
@@ -116,7 +114,7 @@ def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noi
                     acc = np.where(np.isfinite(b), acc, np.inf).astype(dt)
             if noise_eps and op != DOP_LOAD:
                 acc = (acc * (1.0 + noise_eps * rng.choice(np.array([-1.0, 1.0]), size=N))).astype(dt)
-            check = (op != DOP_LOAD) if early_exit else bool(hdr & (1 << 13))
+            check = bool(hdr & (1 << 15)) if early_exit else bool(hdr & (1 << 13))
             if check:
                 bad |= bool(np.any(~np.isfinite(acc)))
     return acc, (host_ok and not bad)
