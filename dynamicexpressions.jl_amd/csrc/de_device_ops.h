@@ -92,6 +92,50 @@ template <> struct M<double> {
     static __device__ __forceinline__ bool signbit(T x) { return __builtin_signbit(x); }
 };
 
+// ---- fast Float32 transcendentals for the hot operators ------------------------
+// OCML's cosf/sinf cost ~125 VALU instructions (both reduction paths are inlined and
+// both polynomials evaluated); cos is >50 % of the VALU work of the headline workload.
+// These versions are ~22 VALU on the fast path and keep <=1.6 ulp (measured against a
+// correctly rounded reference over |x| <= 1e5, tests/test_gpu_ops.py):
+//   k = rint(x*2/pi);  r = x - k*pi/2 with pi/2 = C1+C2+C3 (3 FMAs: the first is exact,
+//   the other two round relative to the already-small r, so r keeps full relative
+//   accuracy next to the zeros of cos/sin);  Cephes minimax sin/cos polynomials on
+//   [-pi/4, pi/4];  quadrant select.  |x| > 1e5 (and Inf) takes the OCML Payne-Hanek
+//   path under a divergent branch; NaN flows through the fast path.
+constexpr float DE_TRIG_FAST_BOUND = 1.0e5f;
+template <bool SIN> __device__ __forceinline__ float fast_trig_f32(float x) {
+    const float t = x * 0x1.45f306p-1f; // 2/pi
+    const float k = __builtin_rintf(t);
+    float r = __builtin_fmaf(-k, 0x1.921fb6p+0f, x);
+    r = __builtin_fmaf(-k, -0x1.777a5cp-25f, r);
+    r = __builtin_fmaf(-k, -0x1.ee59dap-50f, r);
+    const int q = (int)k;
+    const float r2 = r * r;
+    float c = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    c = __builtin_fmaf(r2, c, 4.166664568298827e-2f);
+    c = __builtin_fmaf(r2, c, -0.5f);
+    c = __builtin_fmaf(r2, c, 1.0f);
+    float p = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    p = __builtin_fmaf(r2, p, -1.6666654611e-1f);
+    const float s = __builtin_fmaf(r * r2, p, r);
+    // cos: q=0:c 1:-s 2:-c 3:s      sin: q=0:s 1:c 2:-s 3:-c
+    const float v = (q & 1) ? (SIN ? c : s) : (SIN ? s : c);
+    const unsigned sign = (SIN ? ((unsigned)q << 30) : (((unsigned)q << 30) + 0x40000000u)) & 0x80000000u;
+    return __uint_as_float(__float_as_uint(v) ^ sign);
+}
+// exp(x) = 2^(x*log2(e)): k = rint(x*L), r = x*L - k in two FMAs (hi/lo split of L),
+// hardware v_exp_f32 on r in [-0.5, 0.5], v_ldexp_f32 for the 2^k scaling (gradual
+// underflow and overflow to Inf come from ldexp).  ~10 VALU vs 15; <= 2 ulp.
+__device__ __forceinline__ float fast_exp_f32(float x) {
+    const float xc = __builtin_fminf(__builtin_fmaxf(x, -105.0f), 89.0f);
+    const float k = __builtin_rintf(xc * 0x1.715476p+0f);
+    float r = __builtin_fmaf(xc, 0x1.715476p+0f, -k);
+    r = __builtin_fmaf(xc, 0x1.4ae0c0p-26f, r);
+    const float e = __builtin_amdgcn_exp2f(r);
+    const float y = __builtin_amdgcn_ldexpf(e, (int)k);
+    return x != x ? x : y;
+}
+
 // Julia max/min: NaN-propagating, -0 < +0.
 template <typename T> __device__ __forceinline__ T jl_max(T x, T y) {
     if (x != x) return x;

@@ -101,6 +101,8 @@ __device__ __forceinline__ void apply_cold_op(uint32_t op, V (&acc)[G], const V 
         U_CASE(DE_U_INV, T(1) / x)
         U_CASE(DE_U_SQRT, m::sqrt(x))
         U_CASE(DE_U_CBRT, m::cbrt(x))
+        U_CASE(DE_U_EXP, m::exp(x))
+        U_CASE(DE_U_COS, m::cos(x))
         U_CASE(DE_U_EXP2, m::exp2(x))
         U_CASE(DE_U_LOG, m::log(x))
         U_CASE(DE_U_LOG2, m::log2(x))
@@ -171,6 +173,52 @@ __device__ __forceinline__ void poison_with(T &poison, const V (&v)[G]) {
     constexpr int VW = VecOf<T>::W;
     FOR_G FOR_I poison = M<T>::fma(v[g][i], T(0), poison);
 }
+
+// cos/sin/exp over the G*VW samples of a thread.  Float32 uses the fast versions of
+// de_device_ops.h with ONE divergent fix-up region for out-of-range arguments.
+template <typename T, int G, typename V, bool SIN>
+__device__ __forceinline__ void vec_trig(V (&out)[G], const V (&x)[G]) {
+    constexpr int VW = VecOf<T>::W;
+    if constexpr (sizeof(T) == 4) {
+        bool big = false;
+        V r[G];
+        FOR_G FOR_I {
+            r[g][i] = fast_trig_f32<SIN>(x[g][i]);
+            big |= M<T>::abs(x[g][i]) > DE_TRIG_FAST_BOUND;
+        }
+        if (big) {
+            FOR_G FOR_I if (M<T>::abs(x[g][i]) > DE_TRIG_FAST_BOUND) r[g][i] = SIN ? M<T>::sin(x[g][i]) : M<T>::cos(x[g][i]);
+        }
+        FOR_G out[g] = r[g];
+    } else {
+        V r[G];
+        FOR_G FOR_I r[g][i] = SIN ? M<T>::sin(x[g][i]) : M<T>::cos(x[g][i]);
+        FOR_G out[g] = r[g];
+    }
+}
+template <typename T, int G, typename V>
+__device__ __forceinline__ void vec_exp(V (&out)[G], const V (&x)[G]) {
+    constexpr int VW = VecOf<T>::W;
+    V r[G];
+    if constexpr (sizeof(T) == 4) { FOR_G FOR_I r[g][i] = fast_exp_f32(x[g][i]); }
+    else { FOR_G FOR_I r[g][i] = M<T>::exp(x[g][i]); }
+    FOR_G out[g] = r[g];
+}
+
+// The operators of the headline workload, expanded once per operand source so that a
+// constant operand stays in an SGPR and a unary operator works on acc in place (no
+// v_mov traffic).  IN(g,i) yields operand B of sample (g,i).
+#define DE_FAST_BINARY(IN)                                                               \
+    if (op == DE_B_ADD) { FOR_G FOR_I acc[g][i] = acc[g][i] + IN(g, i); }                \
+    else if (op == DE_B_MUL) { FOR_G FOR_I acc[g][i] = acc[g][i] * IN(g, i); }           \
+    else if (op == DE_B_SUB) { FOR_G FOR_I acc[g][i] = acc[g][i] - IN(g, i); }           \
+    else if (op == DOP_RSUB) { FOR_G FOR_I acc[g][i] = IN(g, i) - acc[g][i]; }           \
+    else if (op == DE_B_DIV) { FOR_G FOR_I acc[g][i] = acc[g][i] / IN(g, i); }           \
+    else if (op == DOP_RDIV) { FOR_G FOR_I acc[g][i] = IN(g, i) / acc[g][i]; }
+#define DE_FAST_UNARY(IN)                                                                \
+    if (op == DE_U_COS) { V x_[G]; FOR_G FOR_I x_[g][i] = IN(g, i); vec_trig<T, G, V, false>(acc, x_); } \
+    else if (op == DE_U_EXP) { V x_[G]; FOR_G FOR_I x_[g][i] = IN(g, i); vec_exp<T, G, V>(acc, x_); }    \
+    else if (op == DE_U_SIN) { V x_[G]; FOR_G FOR_I x_[g][i] = IN(g, i); vec_trig<T, G, V, true>(acc, x_); }
 
 // XCD-aware block mapping: hardware dispatches block b to XCD b % 8 (observed, used
 // for L2 affinity only — correctness never depends on it).  All chunks of a sample
@@ -263,42 +311,56 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
                 V *__restrict__ s = rowsv + (F + ((hdr >> H_PUSH_SHIFT) & H_SLOT_MASK)) * ROWV + tid;
                 FOR_G s[g * BLK] = acc[g];
             }
-            V b[G];
+            V inj[G]; // input of a fused deg1 operator (early_exit=false only)
+            if (!EE && (hdr & H_INJECT)) { FOR_G inj[g] = acc[g]; }
             if (src == SRC_ROW) {
+                V b[G];
                 const V *__restrict__ s = rowsv + (w.y & 0xFFFFu) * ROWV + tid;
                 FOR_G b[g] = s[g * BLK];
-            } else if (src == SRC_CONST) {
-                const T c = imm_of<T>(w.z, w.w);
-                FOR_G FOR_I b[g][i] = c;
-            } else if (PARAMS && src == SRC_PARAM) {
-                const T *__restrict__ s = a.params + (w.y & 0xFFFFu);
-                FOR_G FOR_I b[g][i] = s[a.ld_params * cls[g][i]];
-            } else {
-                FOR_G b[g] = acc[g];
-            }
-            if (EE && (hdr & H_CHECK_B)) poison_with<T, G, V>(poison, b);
-            // ---- fast path: the operators of the headline workload ----------------
-            if (op == DOP_LOAD) {
-                FOR_G acc[g] = b[g];
-            } else {
-                if (op == DE_B_ADD) { FOR_G acc[g] = acc[g] + b[g]; }
-                else if (op == DE_B_MUL) { FOR_G acc[g] = acc[g] * b[g]; }
-                else if (op == DE_B_SUB) { FOR_G acc[g] = acc[g] - b[g]; }
-                else if (op == DOP_RSUB) { FOR_G acc[g] = b[g] - acc[g]; }
-                else if (op == DE_B_DIV) { FOR_G acc[g] = acc[g] / b[g]; }
-                else if (op == DOP_RDIV) { FOR_G acc[g] = b[g] / acc[g]; }
-                else if (op == DE_U_COS) { FOR_G FOR_I acc[g][i] = M<T>::cos(b[g][i]); }
-                else if (op == DE_U_EXP) { FOR_G FOR_I acc[g][i] = M<T>::exp(b[g][i]); }
+                if (EE && (hdr & H_CHECK_B)) poison_with<T, G, V>(poison, b);
+                if (!EE && (hdr & H_INJECT)) { FOR_G inj[g] = b[g]; }
+#define IN_ROW(g, i) b[g][i]
+                if (op == DOP_LOAD) { FOR_G acc[g] = b[g]; }
+                else DE_FAST_BINARY(IN_ROW)
+                else DE_FAST_UNARY(IN_ROW)
                 else if (op >= DE_T_FMA && op < DOP_LOAD) {
                     V c[G];
-                    const V *__restrict__ s = rowsv + (F + ((hdr >> H_POPC_SHIFT) & H_SLOT_MASK)) * ROWV + tid;
-                    FOR_G c[g] = s[g * BLK];
+                    const V *__restrict__ s2 = rowsv + (F + ((hdr >> H_POPC_SHIFT) & H_SLOT_MASK)) * ROWV + tid;
+                    FOR_G c[g] = s2[g * BLK];
                     apply_op3<T, G, V>(op, acc, b, c);
-                } else {
+                } else apply_cold_op<T, G, V>(op, acc, b);
+            } else if (src == SRC_CONST) {
+                const T c = imm_of<T>(w.z, w.w);
+                if (!EE && (hdr & H_INJECT)) { FOR_G FOR_I inj[g][i] = c; }
+#define IN_CONST(g, i) c
+                if (op == DOP_LOAD) { FOR_G FOR_I acc[g][i] = c; }
+                else DE_FAST_BINARY(IN_CONST)
+                else {
+                    V b[G];
+                    FOR_G FOR_I b[g][i] = c;
                     apply_cold_op<T, G, V>(op, acc, b);
                 }
+            } else if (PARAMS && src == SRC_PARAM) {
+                V b[G];
+                const T *__restrict__ s = a.params + (w.y & 0xFFFFu);
+                FOR_G FOR_I b[g][i] = s[a.ld_params * cls[g][i]];
+                if (EE && (hdr & H_CHECK_B)) poison_with<T, G, V>(poison, b);
+                if (!EE && (hdr & H_INJECT)) { FOR_G inj[g] = b[g]; }
+                if (op == DOP_LOAD) { FOR_G acc[g] = b[g]; }
+                else DE_FAST_BINARY(IN_ROW)
+                else apply_cold_op<T, G, V>(op, acc, b);
+            } else { // SRC_ACC: a unary operator applied to the accumulator in place
+#define IN_ACC(g, i) acc[g][i]
+                DE_FAST_UNARY(IN_ACC)
+                else {
+                    V b[G];
+                    FOR_G b[g] = acc[g];
+                    apply_cold_op<T, G, V>(op, acc, b);
+                }
+            }
+            if (op != DOP_LOAD) {
                 if (!EE && (hdr & H_INJECT)) { // is_valid(x_l) ? op(x_l) : Inf  (src/Evaluate.jl:722)
-                    FOR_G FOR_I if (!M<T>::isfinite(b[g][i])) acc[g][i] = M<T>::inf();
+                    FOR_G FOR_I if (!M<T>::isfinite(inj[g][i])) acc[g][i] = M<T>::inf();
                 }
                 if (hdr & (EE ? H_CHECK_OUT : H_CHECK_ALWAYS)) poison_with<T, G, V>(poison, acc);
             }
