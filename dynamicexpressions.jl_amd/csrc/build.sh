@@ -15,7 +15,8 @@ build_obj() { # src obj extra...
 }
 build_obj de_lower.cpp _obj/de_lower.o &
 build_obj de_api.cpp _obj/de_api.o &
+build_obj de_bind.cpp _obj/de_bind.o &
 build_obj de_kernels.hip _obj/de_kernels.o ${DE_KERNEL_FLAGS:-} &
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libde_hip.so _obj/de_lower.o _obj/de_api.o _obj/de_kernels.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libde_hip.so _obj/de_lower.o _obj/de_bind.o _obj/de_api.o _obj/de_kernels.o
 echo "built $(pwd)/libde_hip.so"

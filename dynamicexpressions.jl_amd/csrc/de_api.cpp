@@ -65,7 +65,9 @@ struct de_program {
     std::vector<uint8_t> host_ok_eval;  // per tree: constant part of the eval flag
     std::vector<uint8_t> host_ok_grad;  // per tree: all constants finite
     std::vector<double> consts;         // current constants as double
-    Instr *d_code = nullptr;
+    std::vector<BoundInstr> bcode;      // bound form of `code` (what the eval kernel runs)
+    std::vector<int32_t> bcode_off;     // n_trees + 1
+    BoundInstr *d_code = nullptr;
     int32_t *d_code_off = nullptr;
     // gradient metadata (device), rebuilt per mode on demand
     int grad_mode_cached = -1;
@@ -243,6 +245,17 @@ static void write_imm(Instr &ins, int dtype, double v) {
 }
 static bool finite_in(int dtype, double v) { return dtype == DE_F32 ? std::isfinite((float)v) : std::isfinite(v); }
 
+static void rebind(de_program *p) {
+    const bool ee = (p->options & DE_OPT_EARLY_EXIT) != 0;
+    p->bcode.clear();
+    p->bcode_off.assign((size_t)p->n_trees + 1, 0);
+    for (int64_t t = 0; t < p->n_trees; t++) {
+        const int32_t i0 = p->code_off[(size_t)t], i1 = p->code_off[(size_t)t + 1];
+        bind_tree(p->code.data() + i0, (size_t)(i1 - i0), ee, p->n_features, &p->bcode);
+        p->bcode_off[(size_t)t + 1] = (int32_t)p->bcode.size();
+    }
+}
+
 static void recompute_host_ok(de_program *p) {
     const bool ee = (p->options & DE_OPT_EARLY_EXIT) != 0;
     for (int64_t t = 0; t < p->n_trees; t++) {
@@ -327,22 +340,24 @@ int de_program_create(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, con
             if (p->code.size() > 0x7fff0000u) return fail(ctx, DE_ERR_UNSUPPORTED, "program too large");
         }
         recompute_host_ok(p.get());
+        rebind(p.get());
     } catch (const std::bad_alloc &) {
         return fail(ctx, DE_ERR_HIP, "out of host memory");
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // one trailing pad instruction: the interpreter prefetches code[pc + 1]
-    const size_t cbytes = (p->code.size() + 1) * sizeof(Instr);
+    const size_t cbytes = (p->bcode.size() + 1) * sizeof(BoundInstr);
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->d_code), cbytes));
     HIP_TRY(ctx, hipMemset(p->d_code, 0, cbytes));
-    hipError_t st = hipMalloc(reinterpret_cast<void **>(&p->d_code_off), p->code_off.size() * sizeof(int32_t));
+    hipError_t st = hipMalloc(reinterpret_cast<void **>(&p->d_code_off), p->bcode_off.size() * sizeof(int32_t));
     if (st != hipSuccess) {
         (void)hipFree(p->d_code);
         return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(st));
     }
-    if (!p->code.empty()) st = hipMemcpy(p->d_code, p->code.data(), p->code.size() * sizeof(Instr), hipMemcpyHostToDevice);
+    if (!p->bcode.empty())
+        st = hipMemcpy(p->d_code, p->bcode.data(), p->bcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice);
     if (st == hipSuccess)
-        st = hipMemcpy(p->d_code_off, p->code_off.data(), p->code_off.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        st = hipMemcpy(p->d_code_off, p->bcode_off.data(), p->bcode_off.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (st != hipSuccess) {
         (void)hipFree(p->d_code);
         (void)hipFree(p->d_code_off);
@@ -363,11 +378,16 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
         write_imm(p->code[(size_t)p->const_instr[k]], p->dtype, v);
     }
     recompute_host_ok(p);
+    try {
+        rebind(p); // same shape: only immediates change
+    } catch (const std::bad_alloc &) {
+        return fail(ctx, DE_ERR_HIP, "out of host memory");
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // the program may be in use by work already queued on the stream
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (!p->code.empty())
-        HIP_TRY(ctx, hipMemcpy(p->d_code, p->code.data(), p->code.size() * sizeof(Instr), hipMemcpyHostToDevice));
+    if (!p->bcode.empty())
+        HIP_TRY(ctx, hipMemcpy(p->d_code, p->bcode.data(), p->bcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
     return DE_OK;
 }
 
@@ -406,6 +426,13 @@ int64_t de_program_dump(const de_program_t *p, int64_t tree, uint32_t *words, in
         words[2] = p->host_ok_grad[(size_t)tree];
         words[3] = p->uses_params;
         return 4;
+    }
+    if (which == 2) { // bound instructions (de_bind.h)
+        const int32_t b0 = p->bcode_off[(size_t)tree], b1 = p->bcode_off[(size_t)tree + 1];
+        const int64_t nb = (int64_t)(b1 - b0) * 4;
+        if (!words || cap < nb) return nb;
+        std::memcpy(words, p->bcode.data() + b0, (size_t)nb * 4);
+        return nb;
     }
     const int32_t i0 = p->code_off[(size_t)tree], i1 = p->code_off[(size_t)tree + 1];
     const int64_t nw = (int64_t)(i1 - i0) * 4;

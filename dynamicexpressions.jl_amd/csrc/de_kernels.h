@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/de_hip.h"
+#include "de_bind.h"
 #include "de_program.h"
 
 namespace de {
@@ -13,7 +14,7 @@ constexpr int BLOCK = 256; // threads per workgroup = 4 wavefronts of 64
 
 struct EvalArgs {
     // program
-    const Instr *code;        // device: all trees' instructions
+    const BoundInstr *code;   // device: all trees' BOUND instructions (de_bind.h), +1 pad
     const int32_t *code_off;  // device: n_trees+1 offsets into code
     int32_t n_trees;
     int32_t n_slots;          // spill slots (max over trees)

@@ -25,6 +25,7 @@
 
 #include <cstdlib>
 
+#include "de_bind.h"
 #include "de_device_ops.h"
 #include "de_kernels.h"
 
@@ -38,7 +39,7 @@ typedef const DE_CONSTANT U32x4 *ConstU4Ptr;
 typedef const DE_CONSTANT int32_t *ConstI32Ptr;
 
 template <typename T> struct KArgs {
-    const Instr *code;       // padded with one trailing instruction (prefetch reads pc+1)
+    const BoundInstr *code;  // bound program, padded with one trailing instruction (prefetch reads pc+1)
     const int32_t *code_off; // n_trees + 1
     const T *X;
     T *out;
@@ -83,11 +84,21 @@ template <> __device__ __forceinline__ double imm_of<double>(uint32_t w2, uint32
         }                                                    \
         break;
 
+// The interpreter's inner loop must contain ONLY wave-uniform control flow: one divergent
+// branch anywhere inside it makes LLVM structurize the whole loop and bury the scalar
+// dispatch under "Flow" blocks (the kernel is scalar-issue bound).  Anything
+// with lane-divergent branches (OCML pow/fmod/tgamma/Payne-Hanek ...) therefore lives in
+// __noinline__ functions that take and return register-resident values.
+template <typename T, int G> struct VG { typename VecOf<T>::type v[G]; };
+
 // Everything that is not on the fast path of the interpreter loop.
-template <typename T, int G, typename V>
-__device__ __forceinline__ void apply_cold_op(uint32_t op, V (&acc)[G], const V (&b)[G]) {
+template <typename T, int G>
+__device__ __noinline__ VG<T, G> cold_op(uint32_t op, VG<T, G> accv, VG<T, G> bv) {
     using m = M<T>;
+    typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
+    V (&acc)[G] = accv.v;
+    const V (&b)[G] = bv.v;
     switch (op) {
         U_CASE(DE_U_NEG, -x)
         U_CASE(DE_U_ABS, m::abs(x))
@@ -146,13 +157,18 @@ __device__ __forceinline__ void apply_cold_op(uint32_t op, V (&acc)[G], const V 
         B_CASE(DOP_RPOW_ABS2, jl_pow_abs2(y, x))
     default: break;
     }
+    return accv;
 }
 
 // acc = op3(b, c, acc): b, c from spill slots, acc = third argument
-template <typename T, int G, typename V>
-__device__ __forceinline__ void apply_op3(uint32_t op, V (&acc)[G], const V (&b)[G], const V (&c)[G]) {
+template <typename T, int G>
+__device__ __noinline__ VG<T, G> cold_op3(uint32_t op, VG<T, G> accv, VG<T, G> bv, VG<T, G> cv) {
     using m = M<T>;
+    typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
+    V (&acc)[G] = accv.v;
+    const V (&b)[G] = bv.v;
+    const V (&c)[G] = cv.v;
     FOR_G FOR_I {
         const T x = b[g][i], y = c[g][i], z = acc[g][i];
         T r;
@@ -164,6 +180,7 @@ __device__ __forceinline__ void apply_op3(uint32_t op, V (&acc)[G], const V (&b)
         }
         acc[g][i] = r;
     }
+    return accv;
 }
 
 // Validity accumulation without touching the scalar unit: poison = fma(v, 0, poison) stays
@@ -176,24 +193,38 @@ __device__ __forceinline__ void poison_with(T &poison, const V (&v)[G]) {
 
 // cos/sin/exp over the G*VW samples of a thread.  Float32 uses the fast versions of
 // de_device_ops.h with ONE divergent fix-up region for out-of-range arguments.
+template <int G, bool SIN>
+__device__ __noinline__ VG<float, G> trig_fixup(VG<float, G> r, VG<float, G> x) {
+    DE_UNROLL for (int g = 0; g < G; g++) DE_UNROLL for (int i = 0; i < 4; i++)
+        if (fabsf(x.v[g][i]) > DE_TRIG_FAST_BOUND) r.v[g][i] = SIN ? sinf(x.v[g][i]) : cosf(x.v[g][i]);
+    return r;
+}
+template <int G, bool SIN>
+__device__ __noinline__ VG<double, G> trig_f64(VG<double, G> x) {
+    DE_UNROLL for (int g = 0; g < G; g++) DE_UNROLL for (int i = 0; i < 2; i++)
+        x.v[g][i] = SIN ? ::sin(x.v[g][i]) : ::cos(x.v[g][i]);
+    return x;
+}
 template <typename T, int G, typename V, bool SIN>
 __device__ __forceinline__ void vec_trig(V (&out)[G], const V (&x)[G]) {
     constexpr int VW = VecOf<T>::W;
     if constexpr (sizeof(T) == 4) {
         bool big = false;
-        V r[G];
+        VG<float, G> r, xv;
         FOR_G FOR_I {
-            r[g][i] = fast_trig_f32<SIN>(x[g][i]);
+            r.v[g][i] = fast_trig_f32<SIN>(x[g][i]);
             big |= M<T>::abs(x[g][i]) > DE_TRIG_FAST_BOUND;
         }
-        if (big) {
-            FOR_G FOR_I if (M<T>::abs(x[g][i]) > DE_TRIG_FAST_BOUND) r[g][i] = SIN ? M<T>::sin(x[g][i]) : M<T>::cos(x[g][i]);
+        if (__ballot(big) != 0ull) { // wave-uniform: keeps the interpreter loop free of divergent branches
+            FOR_G xv.v[g] = x[g];
+            r = trig_fixup<G, SIN>(r, xv);
         }
-        FOR_G out[g] = r[g];
+        FOR_G out[g] = r.v[g];
     } else {
-        V r[G];
-        FOR_G FOR_I r[g][i] = SIN ? M<T>::sin(x[g][i]) : M<T>::cos(x[g][i]);
-        FOR_G out[g] = r[g];
+        VG<double, G> xv;
+        FOR_G xv.v[g] = x[g];
+        xv = trig_f64<G, SIN>(xv);
+        FOR_G out[g] = xv.v[g];
     }
 }
 template <typename T, int G, typename V>
@@ -201,24 +232,17 @@ __device__ __forceinline__ void vec_exp(V (&out)[G], const V (&x)[G]) {
     constexpr int VW = VecOf<T>::W;
     V r[G];
     if constexpr (sizeof(T) == 4) { FOR_G FOR_I r[g][i] = fast_exp_f32(x[g][i]); }
-    else { FOR_G FOR_I r[g][i] = M<T>::exp(x[g][i]); }
+    else { FOR_G FOR_I r[g][i] = M<T>::exp(x[g][i]); } // OCML exp (f64) is branch-free
     FOR_G out[g] = r[g];
 }
 
-// The operators of the headline workload, expanded once per operand source so that a
-// constant operand stays in an SGPR and a unary operator works on acc in place (no
-// v_mov traffic).  IN(g,i) yields operand B of sample (g,i).
-#define DE_FAST_BINARY(IN)                                                               \
-    if (op == DE_B_ADD) { FOR_G FOR_I acc[g][i] = acc[g][i] + IN(g, i); }                \
-    else if (op == DE_B_MUL) { FOR_G FOR_I acc[g][i] = acc[g][i] * IN(g, i); }           \
-    else if (op == DE_B_SUB) { FOR_G FOR_I acc[g][i] = acc[g][i] - IN(g, i); }           \
-    else if (op == DOP_RSUB) { FOR_G FOR_I acc[g][i] = IN(g, i) - acc[g][i]; }           \
-    else if (op == DE_B_DIV) { FOR_G FOR_I acc[g][i] = acc[g][i] / IN(g, i); }           \
-    else if (op == DOP_RDIV) { FOR_G FOR_I acc[g][i] = IN(g, i) / acc[g][i]; }
-#define DE_FAST_UNARY(IN)                                                                \
-    if (op == DE_U_COS) { V x_[G]; FOR_G FOR_I x_[g][i] = IN(g, i); vec_trig<T, G, V, false>(acc, x_); } \
-    else if (op == DE_U_EXP) { V x_[G]; FOR_G FOR_I x_[g][i] = IN(g, i); vec_exp<T, G, V>(acc, x_); }    \
-    else if (op == DE_U_SIN) { V x_[G]; FOR_G FOR_I x_[g][i] = IN(g, i); vec_trig<T, G, V, true>(acc, x_); }
+#define COLD_CALL(BV)                                          \
+    {                                                          \
+        VG<T, G> av_, bv_;                                     \
+        FOR_G { av_.v[g] = acc[g]; bv_.v[g] = BV[g]; }         \
+        av_ = cold_op<T, G>(op, av_, bv_);                     \
+        FOR_G acc[g] = av_.v[g];                               \
+    }
 
 // XCD-aware block mapping: hardware dispatches block b to XCD b % 8 (observed, used
 // for L2 affinity only — correctness never depends on it).  All chunks of a sample
@@ -235,6 +259,15 @@ __device__ __forceinline__ TileMap map_block(uint32_t bid, int32_t n_chunks, int
     m.tile = (int64_t)(idx / (uint32_t)n_chunks) * 8 + xcd;
     m.valid = m.tile < n_tiles;
     return m;
+}
+
+template <typename T, int G>
+__device__ __noinline__ void store_ragged(T *o, VG<T, G> v, int64_t remaining, int plane) {
+    constexpr int VW = VecOf<T>::W;
+    FOR_G FOR_I if ((int64_t)g * plane + i < remaining) o[g * plane + i] = v.v[g][i];
+}
+__device__ __noinline__ void flag_incomplete(uint8_t *ok) {
+    if ((threadIdx.x & 63) == 0) *ok = 0;
 }
 
 template <typename T, int G, int BLK, bool EE, bool PARAMS>
@@ -291,7 +324,7 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
     const int t0 = tm.chunk * a.trees_per_chunk;
     const int t1 = (t0 + a.trees_per_chunk < a.n_trees) ? t0 + a.trees_per_chunk : a.n_trees;
     const bool full = base + TILE <= a.N;
-    const int F = a.F;
+
 
     int pe = code_off[t0];
     for (int tree = t0; tree < t1; ++tree) {
@@ -304,65 +337,73 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
         for (; pc < pe; ++pc) {
             const U32x4 w = nxt;
             nxt = code[pc + 1]; // prefetch (the code buffer carries one trailing pad instruction)
-            const uint32_t hdr = w.x;
-            const uint32_t op = hdr & H_OP_MASK;
-            const uint32_t src = (hdr >> H_SRC_SHIFT) & H_SRC_MASK;
-            if (hdr & H_PUSH) {
-                V *__restrict__ s = rowsv + (F + ((hdr >> H_PUSH_SHIFT) & H_SLOT_MASK)) * ROWV + tid;
-                FOR_G s[g * BLK] = acc[g];
-            }
-            V inj[G]; // input of a fused deg1 operator (early_exit=false only)
-            if (!EE && (hdr & H_INJECT)) { FOR_G inj[g] = acc[g]; }
-            if (src == SRC_ROW) {
-                V b[G];
-                const V *__restrict__ s = rowsv + (w.y & 0xFFFFu) * ROWV + tid;
-                FOR_G b[g] = s[g * BLK];
-                if (EE && (hdr & H_CHECK_B)) poison_with<T, G, V>(poison, b);
-                if (!EE && (hdr & H_INJECT)) { FOR_G inj[g] = b[g]; }
-#define IN_ROW(g, i) b[g][i]
-                if (op == DOP_LOAD) { FOR_G acc[g] = b[g]; }
-                else DE_FAST_BINARY(IN_ROW)
-                else DE_FAST_UNARY(IN_ROW)
-                else if (op >= DE_T_FMA && op < DOP_LOAD) {
-                    V c[G];
-                    const V *__restrict__ s2 = rowsv + (F + ((hdr >> H_POPC_SHIFT) & H_SLOT_MASK)) * ROWV + tid;
-                    FOR_G c[g] = s2[g * BLK];
-                    apply_op3<T, G, V>(op, acc, b, c);
-                } else apply_cold_op<T, G, V>(op, acc, b);
-            } else if (src == SRC_CONST) {
-                const T c = imm_of<T>(w.z, w.w);
-                if (!EE && (hdr & H_INJECT)) { FOR_G FOR_I inj[g][i] = c; }
-#define IN_CONST(g, i) c
-                if (op == DOP_LOAD) { FOR_G FOR_I acc[g][i] = c; }
-                else DE_FAST_BINARY(IN_CONST)
-                else {
+            // One flat, wave-uniform switch over the bound handler id (de_bind.h): every case is
+            // straight-line code.  ROW(r) = this thread's vectors of LDS row r.
+#define ROWP(r) (rowsv + (r) * ROWV + tid)
+#define LOAD_ROW(dst, r) { const V *__restrict__ s_ = ROWP(r); FOR_G dst[g] = s_[g * BLK]; }
+#define BIN4(K, EXPR)                                                                                   \
+    case BOP_BIN_BASE + 4 * K + 0: { V b[G]; LOAD_ROW(b, w.y) FOR_G FOR_I { const T x = acc[g][i], y = b[g][i]; acc[g][i] = (EXPR); } } break; \
+    case BOP_BIN_BASE + 4 * K + 1: { V b[G]; LOAD_ROW(b, w.y) FOR_G FOR_I { const T x = acc[g][i], y = b[g][i]; acc[g][i] = (EXPR); } poison_with<T, G, V>(poison, acc); } break; \
+    case BOP_BIN_BASE + 4 * K + 2: { const T y = imm_of<T>(w.z, w.w); FOR_G FOR_I { const T x = acc[g][i]; acc[g][i] = (EXPR); } } break; \
+    case BOP_BIN_BASE + 4 * K + 3: { const T y = imm_of<T>(w.z, w.w); FOR_G FOR_I { const T x = acc[g][i]; acc[g][i] = (EXPR); } poison_with<T, G, V>(poison, acc); } break;
+#define UN4(K, CALL)                                                                                    \
+    case BOP_UN_BASE + 4 * K + 0: { V x_[G]; FOR_G x_[g] = acc[g]; CALL; } break;                      \
+    case BOP_UN_BASE + 4 * K + 1: { V x_[G]; FOR_G x_[g] = acc[g]; CALL; poison_with<T, G, V>(poison, acc); } break; \
+    case BOP_UN_BASE + 4 * K + 2: { V x_[G]; LOAD_ROW(x_, w.y) CALL; } break;                          \
+    case BOP_UN_BASE + 4 * K + 3: { V x_[G]; LOAD_ROW(x_, w.y) CALL; poison_with<T, G, V>(poison, acc); } break;
+            switch (w.x) {
+            case BOP_LOAD_ROW: LOAD_ROW(acc, w.y) break;
+            case BOP_LOAD_CONST: { const T c = imm_of<T>(w.z, w.w); FOR_G FOR_I acc[g][i] = c; } break;
+            case BOP_PUSH: { V *__restrict__ s_ = ROWP(w.y); FOR_G s_[g * BLK] = acc[g]; } break;
+            case BOP_CHECK_ROW: { V b[G]; LOAD_ROW(b, w.y) poison_with<T, G, V>(poison, b); } break;
+            case BOP_CHECK_ACC: poison_with<T, G, V>(poison, acc); break;
+            BIN4(0, x + y)
+            BIN4(1, x - y)
+            BIN4(2, y - x)
+            BIN4(3, x * y)
+            BIN4(4, x / y)
+            BIN4(5, y / x)
+            UN4(0, (vec_trig<T, G, V, false>(acc, x_)))
+            UN4(1, (vec_exp<T, G, V>(acc, x_)))
+            UN4(2, (vec_trig<T, G, V, true>(acc, x_)))
+            case BOP_GEN_ROW: { const uint32_t op = w.y >> 24; V b[G]; LOAD_ROW(b, w.y & 0xFFFFFFu) COLD_CALL(b) } break;
+            case BOP_GEN_CONST: { const uint32_t op = w.y >> 24; V b[G]; const T c = imm_of<T>(w.z, w.w); FOR_G FOR_I b[g][i] = c; COLD_CALL(b) } break;
+            case BOP_GEN_ACC: { const uint32_t op = w.y >> 24; COLD_CALL(acc) } break;
+            case BOP_TERN: {
+                const uint32_t op = w.y >> 24;
+                VG<T, G> av, bv, cv;
+                const V *__restrict__ s1 = ROWP(w.y & 0xFFFFFFu);
+                const V *__restrict__ s2 = ROWP(w.z);
+                FOR_G { av.v[g] = acc[g]; bv.v[g] = s1[g * BLK]; cv.v[g] = s2[g * BLK]; }
+                av = cold_op3<T, G>(op, av, bv, cv);
+                FOR_G acc[g] = av.v[g];
+            } break;
+            case BOP_INJ_ACC: { // is_valid(x_l) ? op(x_l) : Inf   (src/Evaluate.jl:722,787)
+                const uint32_t op = w.y >> 24;
+                V inj[G];
+                FOR_G inj[g] = acc[g];
+                COLD_CALL(inj)
+                FOR_G FOR_I acc[g][i] = M<T>::isfinite(inj[g][i]) ? acc[g][i] : M<T>::inf();
+            } break;
+            case BOP_INJ_ROW: {
+                const uint32_t op = w.y >> 24;
+                V inj[G];
+                LOAD_ROW(inj, w.y & 0xFFFFFFu)
+                COLD_CALL(inj)
+                FOR_G FOR_I acc[g][i] = M<T>::isfinite(inj[g][i]) ? acc[g][i] : M<T>::inf();
+            } break;
+            case BOP_GEN_PARAM:
+                if constexpr (PARAMS) {
+                    const uint32_t op = w.y >> 24;
                     V b[G];
-                    FOR_G FOR_I b[g][i] = c;
-                    apply_cold_op<T, G, V>(op, acc, b);
+                    const T *__restrict__ s_ = a.params + (w.y & 0xFFFFu);
+                    FOR_G FOR_I b[g][i] = s_[a.ld_params * cls[g][i]];
+                    if (EE && (w.y & (1u << 23))) poison_with<T, G, V>(poison, b);
+                    if (op == DOP_LOAD) { FOR_G acc[g] = b[g]; }
+                    else COLD_CALL(b)
                 }
-            } else if (PARAMS && src == SRC_PARAM) {
-                V b[G];
-                const T *__restrict__ s = a.params + (w.y & 0xFFFFu);
-                FOR_G FOR_I b[g][i] = s[a.ld_params * cls[g][i]];
-                if (EE && (hdr & H_CHECK_B)) poison_with<T, G, V>(poison, b);
-                if (!EE && (hdr & H_INJECT)) { FOR_G inj[g] = b[g]; }
-                if (op == DOP_LOAD) { FOR_G acc[g] = b[g]; }
-                else DE_FAST_BINARY(IN_ROW)
-                else apply_cold_op<T, G, V>(op, acc, b);
-            } else { // SRC_ACC: a unary operator applied to the accumulator in place
-#define IN_ACC(g, i) acc[g][i]
-                DE_FAST_UNARY(IN_ACC)
-                else {
-                    V b[G];
-                    FOR_G b[g] = acc[g];
-                    apply_cold_op<T, G, V>(op, acc, b);
-                }
-            }
-            if (op != DOP_LOAD) {
-                if (!EE && (hdr & H_INJECT)) { // is_valid(x_l) ? op(x_l) : Inf  (src/Evaluate.jl:722)
-                    FOR_G FOR_I if (!M<T>::isfinite(inj[g][i])) acc[g][i] = M<T>::inf();
-                }
-                if (hdr & (EE ? H_CHECK_OUT : H_CHECK_ALWAYS)) poison_with<T, G, V>(poison, acc);
+                break;
+            default: break;
             }
         }
         // ---- store out[tree][...]: one 16-byte store per group, coalesced over the wave
@@ -370,10 +411,12 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
         if (full && a.vec_store) {
             FOR_G *reinterpret_cast<V *>(o + g * GT) = acc[g];
         } else {
-            FOR_G FOR_I if (base + g * GT + tid * VW + i < a.N) o[g * GT + i] = acc[g][i];
+            VG<T, G> av;
+            FOR_G av.v[g] = acc[g];
+            store_ragged<T, G>(o, av, a.N - (base + tid * VW), GT);
         }
         // ---- completion flag: one ballot per wave, one byte store per failing wave
-        if (__ballot(poison != poison) != 0ull && (tid & 63) == 0) a.ok[tree] = 0;
+        if (__ballot(poison != poison) != 0ull) flag_incomplete(a.ok + tree);
     }
 }
 
@@ -391,7 +434,7 @@ static void eval_geometry(int dtype, int *G, int *BLK) {
     *BLK = env_int("DE_EVAL_BLOCK", 256);
     if (*G != 1 && *G != 2) *G = 1;
     if (*BLK != 128 && *BLK != 256) *BLK = 256;
-    (void)dtype;
+    if (dtype != DE_F32) { *G = 1; *BLK = 256; }
 }
 
 size_t eval_lds_bytes(int dtype, int F, int n_slots, int *K_out) {
@@ -477,7 +520,7 @@ hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const c
     int G, BLK;
     eval_geometry(dtype, &G, &BLK);
     if (dtype == DE_F32) return launch_eval_geo<float>(a, stream, kernel_name, G, BLK);
-    return launch_eval_geo<double>(a, stream, kernel_name, G, BLK);
+    return launch_eval_t<double, 1, 256>(a, stream, kernel_name);
 }
 
 } // namespace de
