@@ -143,6 +143,12 @@ __device__ __noinline__ VG<T, G> cold_op(uint32_t op, VG<T, G> accv, VG<T, G> bv
         }
         break;
         U_CASE(DE_U_GAMMA, m::tgamma(x))
+        B_CASE(DE_B_ADD, x + y)
+        B_CASE(DE_B_SUB, x - y)
+        B_CASE(DOP_RSUB, y - x)
+        B_CASE(DE_B_MUL, x * y)
+        B_CASE(DE_B_DIV, x / y)
+        B_CASE(DOP_RDIV, y / x)
         B_CASE(DE_B_POW, m::pow(x, y))
         B_CASE(DOP_RPOW, m::pow(y, x))
         B_CASE(DE_B_MAX, jl_max(x, y))
