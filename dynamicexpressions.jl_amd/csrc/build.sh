@@ -17,6 +17,7 @@ build_obj de_lower.cpp _obj/de_lower.o &
 build_obj de_api.cpp _obj/de_api.o &
 build_obj de_bind.cpp _obj/de_bind.o &
 build_obj de_kernels.hip _obj/de_kernels.o ${DE_KERNEL_FLAGS:-} &
+build_obj de_grad_kernels.hip _obj/de_grad_kernels.o &
 wait
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libde_hip.so _obj/de_lower.o _obj/de_bind.o _obj/de_api.o _obj/de_kernels.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libde_hip.so _obj/de_lower.o _obj/de_bind.o _obj/de_api.o _obj/de_kernels.o _obj/de_grad_kernels.o
 echo "built $(pwd)/libde_hip.so"

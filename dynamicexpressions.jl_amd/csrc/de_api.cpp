@@ -45,7 +45,7 @@ struct de_ctx {
     bool timed = false;
     std::string err;
     const char *last_kernel = "";
-    DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2;
+    DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2, sGoff, sNg;
 };
 
 struct de_program {
@@ -69,12 +69,9 @@ struct de_program {
     std::vector<int32_t> bcode_off;     // n_trees + 1
     BoundInstr *d_code = nullptr;
     int32_t *d_code_off = nullptr;
-    // gradient metadata (device), rebuilt per mode on demand
-    int grad_mode_cached = -1;
-    int64_t *d_grad_off = nullptr;
-    int32_t *d_n_grad = nullptr;
-    std::vector<int64_t> h_grad_off;
-    std::vector<int32_t> h_n_grad;
+    Instr *d_gcode = nullptr;           // generic program on the device (gradient kernels), lazily uploaded
+    int32_t *d_gcode_off = nullptr;
+    bool gcode_stale = true;
 };
 
 static int fail(de_ctx *c, int code, const char *fmt, ...) {
@@ -211,7 +208,7 @@ int de_ctx_destroy(de_ctx_t *c) {
     if (!c) return DE_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2}) b->release();
+    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg}) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -378,6 +375,7 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
         write_imm(p->code[(size_t)p->const_instr[k]], p->dtype, v);
     }
     recompute_host_ok(p);
+    p->gcode_stale = true;
     try {
         rebind(p); // same shape: only immediates change
     } catch (const std::bad_alloc &) {
@@ -397,8 +395,8 @@ int de_program_destroy(de_program_t *p) {
     (void)hipStreamSynchronize(p->ctx->stream);
     if (p->d_code) (void)hipFree(p->d_code);
     if (p->d_code_off) (void)hipFree(p->d_code_off);
-    if (p->d_grad_off) (void)hipFree(p->d_grad_off);
-    if (p->d_n_grad) (void)hipFree(p->d_n_grad);
+    if (p->d_gcode) (void)hipFree(p->d_gcode);
+    if (p->d_gcode_off) (void)hipFree(p->d_gcode_off);
     delete p;
     return DE_OK;
 }
@@ -611,17 +609,173 @@ int de_eval_tree_array(de_ctx_t *c, int dtype, const de_tape_node_t *nodes, int6
     return rc;
 }
 
+static int ensure_generic_code(de_ctx *c, de_program *p) {
+    if (!p->d_gcode) {
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gcode), (p->code.size() + 1) * sizeof(Instr)));
+        HIP_TRY(c, hipMemset(p->d_gcode, 0, (p->code.size() + 1) * sizeof(Instr)));
+        p->gcode_stale = true;
+    }
+    if (p->gcode_stale) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!p->code.empty())
+            HIP_TRY(c, hipMemcpy(p->d_gcode, p->code.data(), p->code.size() * sizeof(Instr), hipMemcpyHostToDevice));
+        p->gcode_stale = false;
+    }
+    return DE_OK;
+}
+
+// Shared body of de_eval_grad / de_eval_diff.
+static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
+                     int mode, int diff_direction, void *out, int64_t ld_out, void *grad,
+                     const int64_t *grad_offsets, uint8_t *ok) {
+    if (!c || !p) return DE_ERR_INVALID_ARG;
+    if (p->ctx != c) return fail(c, DE_ERR_INVALID_ARG, "program belongs to another context");
+    const bool diff = diff_direction >= 0;
+    if (N < 0 || !ok || (p->n_trees > 0 && N > 0 && (!X || !grad))) return fail(c, DE_ERR_INVALID_ARG, "null buffer");
+    if (ldX < p->n_features || ((out || diff) && ld_out < N)) return fail(c, DE_ERR_INVALID_ARG, "ldX < n_features or ld_out < N");
+    if (!diff && mode != DE_GRAD_VARIABLE && mode != DE_GRAD_CONSTANT && mode != DE_GRAD_BOTH)
+        return fail(c, DE_ERR_INVALID_ARG, "bad gradient mode");
+    if (diff && diff_direction >= p->n_features) return fail(c, DE_ERR_OUT_OF_RANGE, "direction >= n_features");
+    int rc = check_param_args(c, p, pa);
+    if (rc != DE_OK) return rc;
+    if (p->n_trees == 0) return DE_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t es = p->dtype == DE_F32 ? 4 : 8;
+    const bool ok_dev = is_device_ptr(ok);
+    std::vector<uint8_t> ones;
+    const uint8_t *ok_init = p->host_ok_grad.data();
+    if (diff) { // no validity test on this path: always complete (src/EvaluateDerivative.jl:117)
+        ones.assign((size_t)p->n_trees, 1);
+        ok_init = ones.data();
+    }
+    if (N == 0) {
+        if (ok_dev) {
+            HIP_TRY(c, hipMemcpyAsync(ok, ok_init, (size_t)p->n_trees, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        } else std::memcpy(ok, ok_init, (size_t)p->n_trees);
+        return DE_OK;
+    }
+    // per-tree gradient geometry
+    std::vector<int32_t> ng((size_t)p->n_trees);
+    std::vector<int64_t> goff((size_t)p->n_trees);
+    int64_t span = 0, run = 0;
+    int32_t maxg = 0;
+    for (int64_t t = 0; t < p->n_trees; t++) {
+        const int32_t g = diff ? 1 : (int32_t)de_program_n_grad(p, t, mode);
+        ng[(size_t)t] = g;
+        maxg = std::max(maxg, g);
+        const int64_t off = diff ? t * ld_out : (grad_offsets ? grad_offsets[t] : run);
+        if (off < 0) return fail(c, DE_ERR_INVALID_ARG, "negative gradient offset");
+        goff[(size_t)t] = off;
+        run += (int64_t)g * N;
+        span = std::max(span, off + (int64_t)g * N);
+    }
+    const size_t lds_need = ((size_t)p->n_features + (size_t)p->n_slots * (1 + (size_t)std::min(maxg, 8))) * 260 * es;
+    if (lds_need > 160 * 1024) return fail(c, DE_ERR_UNSUPPORTED, "gradient kernel: LDS footprint too large for this tree shape");
+    rc = ensure_generic_code(c, p);
+    if (rc) return rc;
+
+    Staged sX, sOut, sGrad, sOk, sPar, sCls;
+    rc = stage_in(c, c->sX, X, (size_t)ldX * (size_t)N * es, &sX);
+    if (rc) return rc;
+    if (out) {
+        rc = stage_out(c, c->sOut, out, ((size_t)(p->n_trees - 1) * (size_t)ld_out + (size_t)N) * es, &sOut);
+        if (rc) return rc;
+    }
+    rc = stage_out(c, diff ? c->sOut2 : c->sGrad, grad, (size_t)span * es, &sGrad);
+    if (rc) return rc;
+    if (ok_dev) sOk.dev = ok;
+    else {
+        HIP_TRY(c, c->sOk.reserve((size_t)p->n_trees));
+        sOk.dev = c->sOk.p;
+        sOk.staged = true;
+    }
+    HIP_TRY(c, hipMemcpyAsync(sOk.dev, ok_init, (size_t)p->n_trees, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, c->sGoff.reserve(goff.size() * sizeof(int64_t)));
+    HIP_TRY(c, c->sNg.reserve(ng.size() * sizeof(int32_t)));
+    HIP_TRY(c, hipMemcpyAsync(c->sGoff.p, goff.data(), goff.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->sNg.p, ng.data(), ng.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if (p->uses_params) {
+        rc = stage_in(c, c->sParams, pa->params, (size_t)pa->ld_params * (size_t)pa->n_classes * es, &sPar);
+        if (rc) return rc;
+        rc = stage_in(c, c->sClasses, pa->classes, (size_t)N * (pa->classes_is_i64 ? 8 : 4), &sCls);
+        if (rc) return rc;
+    }
+    // the pageable host vectors above must outlive their async copies
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+
+    GradArgs g;
+    std::memset(&g, 0, sizeof g);
+    g.generic_code = p->d_gcode;
+    g.e.code_off = nullptr;
+    g.e.n_trees = (int32_t)p->n_trees;
+    g.e.n_slots = p->n_slots;
+    g.e.uses_params = p->uses_params;
+    g.e.X = sX.dev;
+    g.e.N = N;
+    g.e.ldX = ldX;
+    g.e.F = p->n_features;
+    g.e.out = out ? sOut.dev : nullptr;
+    g.e.ld_out = ld_out;
+    g.e.ok = static_cast<uint8_t *>(sOk.dev);
+    if (p->uses_params) {
+        g.e.params = sPar.dev;
+        g.e.ld_params = pa->ld_params;
+        g.e.classes = sCls.dev;
+        g.e.classes_is_i64 = pa->classes_is_i64;
+        g.e.class_base = pa->class_base;
+    }
+    g.mode = diff ? DE_GRAD_VARIABLE : mode;
+    g.P = p->n_params;
+    g.grad = sGrad.dev;
+    g.grad_off = static_cast<const int64_t *>(c->sGoff.p);
+    g.n_grad = static_cast<const int32_t *>(c->sNg.p);
+    g.max_grad = maxg;
+    g.diff_direction = diff ? diff_direction : -1;
+    // generic code offsets = code_off (the bound program has its own): upload once per program
+    if (!p->d_gcode_off) {
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gcode_off), p->code_off.size() * sizeof(int32_t)));
+        HIP_TRY(c, hipMemcpy(p->d_gcode_off, p->code_off.data(), p->code_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    g.e.code_off = p->d_gcode_off;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(c, launch_grad(p->dtype, g, c->stream, &c->last_kernel));
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    if (out && sOut.staged)
+        for (int64_t t = 0; t < p->n_trees; t++)
+            HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(out) + (size_t)t * (size_t)ld_out * es,
+                                      static_cast<char *>(sOut.dev) + (size_t)t * (size_t)ld_out * es, (size_t)N * es,
+                                      hipMemcpyDeviceToHost, c->stream));
+    if (sGrad.staged) {
+        if (diff) {
+            for (int64_t t = 0; t < p->n_trees; t++)
+                HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(grad) + (size_t)t * (size_t)ld_out * es,
+                                          static_cast<char *>(sGrad.dev) + (size_t)t * (size_t)ld_out * es, (size_t)N * es,
+                                          hipMemcpyDeviceToHost, c->stream));
+        } else {
+            for (int64_t t = 0; t < p->n_trees; t++)
+                if (ng[(size_t)t] > 0)
+                    HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(grad) + (size_t)goff[(size_t)t] * es,
+                                              static_cast<char *>(sGrad.dev) + (size_t)goff[(size_t)t] * es,
+                                              (size_t)ng[(size_t)t] * (size_t)N * es, hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    if (sOk.staged) HIP_TRY(c, hipMemcpyAsync(ok, sOk.dev, (size_t)p->n_trees, hipMemcpyDeviceToHost, c->stream));
+    if (sX.staged || sOut.staged || sGrad.staged || sOk.staged || sPar.staged || sCls.staged) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DE_OK;
+}
+
 int de_eval_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
                  int mode, void *out, int64_t ld_out, void *grad, const int64_t *grad_offsets, uint8_t *ok) {
-    (void)p; (void)X; (void)N; (void)ldX; (void)pa; (void)mode; (void)out; (void)ld_out; (void)grad;
-    (void)grad_offsets; (void)ok;
-    return fail(c, DE_ERR_UNSUPPORTED, "de_eval_grad: not built yet");
+    return grad_impl(c, p, X, N, ldX, pa, mode, -1, out, ld_out, grad, grad_offsets, ok);
 }
 
 int de_eval_diff(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, int32_t direction, void *out,
                  void *dout, int64_t ld_out, uint8_t *ok) {
-    (void)p; (void)X; (void)N; (void)ldX; (void)direction; (void)out; (void)dout; (void)ld_out; (void)ok;
-    return fail(c, DE_ERR_UNSUPPORTED, "de_eval_diff: not built yet");
+    if (direction < 0) return fail(c, DE_ERR_INVALID_ARG, "direction < 0");
+    if (p && p->uses_params) return fail(c, DE_ERR_UNSUPPORTED, "eval_diff on parametric trees");
+    return grad_impl(c, p, X, N, ldX, nullptr, DE_GRAD_VARIABLE, direction, out, ld_out, dout, nullptr, ok);
 }
 
 } // extern "C"

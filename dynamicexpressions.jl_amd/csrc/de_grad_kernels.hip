@@ -1,0 +1,420 @@
+// de_grad_kernels.hip — forward-mode gradient of a population of trees on gfx950.
+// Replaces the reference's src/EvaluateDerivative.jl: eval_grad_tree_array (:193-243),
+// grad_degn_eval (:340-365), grad_deg0_eval (:367-404) and eval_diff_tree_array (:40-168).
+//
+// Every sample carries a dual number (x, d[0..GC)) through the same accumulator program the
+// eval kernel runs (de_program.h, generic form).  GC = the window of gradient components a
+// launch handles; wider gradients (constant mode with many constants, :both mode) are covered by
+// several windows (blockIdx.y), each recomputing x — the alternative, (1+n_grad) live values
+// per spill slot, would wreck occupancy.  Semantics follow the reference exactly:
+//   * d[k] = g1*d1[k] + g2*d2[k] with dense arithmetic, leaf gradients materialised as 0/1
+//     (so an infinite partial times a zero seed is NaN, as in grad_degn_eval);
+//   * after EVERY node (leaves included) x and all d[k] are validity-tested (:239-242);
+//   * eval_diff (single direction) performs NO validity test (:99-119).
+// Partial derivatives restate ChainRules' scalar rules (same table as oracle/de_oracle_ops.h).
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "de_device_ops.h"
+#include "de_kernels.h"
+
+namespace de {
+
+#define DE_CONSTANT __attribute__((address_space(4)))
+typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+typedef const DE_CONSTANT U32x4 *ConstU4Ptr;
+typedef const DE_CONSTANT int32_t *ConstI32Ptr;
+typedef const DE_CONSTANT int64_t *ConstI64Ptr;
+#define DE_UNROLL _Pragma("unroll")
+
+template <typename T> struct GArgs {
+    const Instr *code;       // GENERIC program, padded with one trailing instruction
+    const int32_t *code_off; // n_trees + 1
+    const T *X;
+    T *out;                  // may be null
+    T *grad;
+    const int64_t *grad_off; // n_trees element offsets
+    const int32_t *n_grad;   // n_trees
+    uint8_t *ok;
+    const T *params;
+    const void *classes;
+    int64_t N, ldX, ld_out, ld_params, n_tiles;
+    int32_t F, P, n_trees, trees_per_chunk, n_chunks, n_slots, mode;
+    int32_t classes_is_i64, class_base, uses_params, check;
+    int32_t diff_g0; // >= 0: eval_diff mode — single component diff_g0, dense [n_trees, ld_out] output
+};
+
+template <typename T> __device__ __forceinline__ T gimm(uint32_t w2, uint32_t w3);
+template <> __device__ __forceinline__ float gimm<float>(uint32_t w2, uint32_t) { return __uint_as_float(w2); }
+template <> __device__ __forceinline__ double gimm<double>(uint32_t w2, uint32_t w3) {
+    return __longlong_as_double((long long)(((unsigned long long)w3 << 32) | w2));
+}
+
+// value + partial of a unary operator; Zygote `nothing` -> 0 (ext/DynamicExpressionsZygoteExt.jl:12-15)
+template <typename T> struct UG { T y, g; };
+template <typename T> __device__ __noinline__ UG<T> unary_vg(uint32_t op, T x) {
+    using m = M<T>;
+    UG<T> r;
+    const T LN2 = T(0.693147180559945309417232121458176568), LN10 = T(2.302585092994045684017991454684364208);
+    switch (op) {
+    case DE_U_NEG: r.y = -x; r.g = T(-1); break;
+    case DE_U_ABS: r.y = m::abs(x); r.g = jl_sign(x); break;
+    case DE_U_SQUARE: r.y = x * x; r.g = x + x; break;
+    case DE_U_CUBE: r.y = (x * x) * x; r.g = (T(3) * x) * x; break;
+    case DE_U_RELU: r.y = x < T(0) ? T(0) : x; r.g = x < T(0) ? T(0) : T(1); break;
+    case DE_U_SIGN: r.y = jl_sign(x); r.g = T(0); break;
+    case DE_U_ROUND: r.y = m::rint(x); r.g = T(0); break;
+    case DE_U_FLOOR: r.y = m::floor(x); r.g = T(0); break;
+    case DE_U_CEIL: r.y = m::ceil(x); r.g = T(0); break;
+    case DE_U_INV: r.y = T(1) / x; r.g = -(r.y * r.y); break;
+    case DE_U_SQRT: r.y = m::sqrt(x); r.g = T(1) / (T(2) * r.y); break;
+    case DE_U_CBRT: r.y = m::cbrt(x); r.g = T(1) / (T(3) * (r.y * r.y)); break;
+    case DE_U_EXP: r.y = m::exp(x); r.g = r.y; break;
+    case DE_U_EXP2: r.y = m::exp2(x); r.g = r.y * LN2; break;
+    case DE_U_LOG: r.y = m::log(x); r.g = T(1) / x; break;
+    case DE_U_LOG2: r.y = m::log2(x); r.g = (T(1) / x) / LN2; break;
+    case DE_U_LOG10: r.y = m::log10(x); r.g = (T(1) / x) / LN10; break;
+    case DE_U_LOG1P: r.y = m::log1p(x); r.g = T(1) / (x + T(1)); break;
+    case DE_U_SIN: r.y = m::sin(x); r.g = m::cos(x); break;
+    case DE_U_COS: r.y = m::cos(x); r.g = -m::sin(x); break;
+    case DE_U_TAN: r.y = m::tan(x); r.g = T(1) + r.y * r.y; break;
+    case DE_U_SINH: r.y = m::sinh(x); r.g = m::cosh(x); break;
+    case DE_U_COSH: r.y = m::cosh(x); r.g = m::sinh(x); break;
+    case DE_U_TANH: r.y = m::tanh(x); r.g = T(1) - r.y * r.y; break;
+    case DE_U_ASIN: r.y = m::asin(x); r.g = T(1) / m::sqrt(T(1) - x * x); break;
+    case DE_U_ACOS: r.y = m::acos(x); r.g = -(T(1) / m::sqrt(T(1) - x * x)); break;
+    case DE_U_ATAN: r.y = m::atan(x); r.g = T(1) / (T(1) + x * x); break;
+    case DE_U_ASINH: r.y = m::asinh(x); r.g = T(1) / m::sqrt(x * x + T(1)); break;
+    case DE_U_ACOSH: r.y = m::acosh(x); r.g = T(1) / (m::sqrt(x - T(1)) * m::sqrt(x + T(1))); break;
+    case DE_U_ATANH: r.y = m::atanh(x); r.g = T(1) / (T(1) - x * x); break;
+    case DE_U_SAFE_LOG: r.y = x <= T(0) ? m::nan() : m::log(x); r.g = x <= T(0) ? T(0) : T(1) / x; break;
+    case DE_U_SAFE_LOG2: r.y = x <= T(0) ? m::nan() : m::log2(x); r.g = x <= T(0) ? T(0) : (T(1) / x) / LN2; break;
+    case DE_U_SAFE_LOG10: r.y = x <= T(0) ? m::nan() : m::log10(x); r.g = x <= T(0) ? T(0) : (T(1) / x) / LN10; break;
+    case DE_U_SAFE_LOG1P: r.y = x <= T(-1) ? m::nan() : m::log1p(x); r.g = x <= T(-1) ? T(0) : T(1) / (x + T(1)); break;
+    case DE_U_SAFE_SQRT:
+        if (x < T(0)) { r.y = m::nan(); r.g = T(0); } else { r.y = m::sqrt(x); r.g = T(1) / (T(2) * r.y); }
+        break;
+    case DE_U_SAFE_ACOSH:
+        r.y = x < T(1) ? m::nan() : m::acosh(x);
+        r.g = x < T(1) ? T(0) : T(1) / (m::sqrt(x - T(1)) * m::sqrt(x + T(1)));
+        break;
+    case DE_U_COS2: { const T c = m::cos(x), s = m::sin(x); r.y = c * c; r.g = (T(2) * c) * (-s); } break;
+    case DE_U_GAMMA: r.y = m::tgamma(x); r.g = r.y * dev_digamma(x); break;
+    default: r.y = m::nan(); r.g = m::nan(); break;
+    }
+    return r;
+}
+
+// value + both partials of op(x, y) (x = first/left argument)
+template <typename T> struct BG { T v, gx, gy; };
+template <typename T> __device__ __noinline__ BG<T> binary_vg(uint32_t op, T x, T y) {
+    using m = M<T>;
+    BG<T> r;
+    switch (op) {
+    case DE_B_ADD: r.v = x + y; r.gx = T(1); r.gy = T(1); break;
+    case DE_B_SUB: r.v = x - y; r.gx = T(1); r.gy = T(-1); break;
+    case DE_B_MUL: r.v = x * y; r.gx = y; r.gy = x; break;
+    case DE_B_DIV: r.v = x / y; r.gx = T(1) / y; r.gy = -(r.v / y); break;
+    case DE_B_POW: { // ChainRules _pow_grad_x / _pow_grad_p (real case)
+        r.v = m::pow(x, y);
+        if (x != T(0) || y < T(0)) r.gx = (!m::isfinite(x) && x == x && y == T(1)) ? T(1) : (r.v * y) / x;
+        else if (y == T(1)) r.gx = T(1);
+        else if (y == T(0) || y > T(1)) r.gx = T(0);
+        else r.gx = m::inf();
+        if (x != T(0)) r.gy = r.v * m::log(m::abs(x));
+        else if (y > T(0)) r.gy = T(0);
+        else r.gy = m::nan();
+    } break;
+    case DE_B_MAX: { const bool gt = x > y; r.v = jl_max(x, y); r.gx = gt ? T(1) : T(0); r.gy = gt ? T(0) : T(1); } break;
+    case DE_B_MIN: { const bool gt = x > y; r.v = jl_min(x, y); r.gx = gt ? T(0) : T(1); r.gy = gt ? T(1) : T(0); } break;
+    case DE_B_MOD: {
+        r.v = jl_mod(x, y);
+        const T u = x / y;
+        const bool isint = (u == m::floor(u)) && m::isfinite(u);
+        r.gx = isint ? m::nan() : T(1);
+        r.gy = isint ? m::nan() : -m::floor(u);
+    } break;
+    case DE_B_REM: {
+        r.v = m::fmod(x, y);
+        const T u = x / y;
+        const bool isint = (u == m::floor(u)) && m::isfinite(u);
+        r.gx = isint ? m::nan() : T(1);
+        r.gy = isint ? m::nan() : -m::trunc(u);
+    } break;
+    case DE_B_GREATER: r.v = x > y ? T(1) : T(0); r.gx = T(0); r.gy = T(0); break;
+    case DE_B_POW_ABS2: {
+        const T a = m::abs(x), l = m::log(a), mm = y * l;
+        r.v = m::exp(mm);
+        r.gx = ((r.v * y) * (T(1) / a)) * jl_sign(x);
+        r.gy = r.v * l;
+    } break;
+    default: r.v = r.gx = r.gy = m::nan(); break;
+    }
+    return r;
+}
+
+template <typename T> struct TG { T v, g0, g1, g2; };
+template <typename T> __device__ __noinline__ TG<T> ternary_vg(uint32_t op, T x, T y, T z) {
+    using m = M<T>;
+    TG<T> r;
+    switch (op) {
+    case DE_T_FMA: r.v = m::fma(x, y, z); r.g0 = y; r.g1 = x; r.g2 = T(1); break;
+    case DE_T_CLAMP:
+        r.v = x > z ? z : (x < y ? y : x);
+        r.g0 = (x > z || x < y) ? T(0) : T(1);
+        r.g1 = (x > z) ? T(0) : (x < y ? T(1) : T(0));
+        r.g2 = (x > z) ? T(1) : T(0);
+        break;
+    case DE_T_ADD3: r.v = (x + y) + z; r.g0 = r.g1 = r.g2 = T(1); break;
+    default: {
+        const T mx = jl_max(x, y);
+        const bool gt1 = x > y, gt2 = mx > z;
+        r.v = jl_max(mx, z);
+        r.g0 = (gt2 && gt1) ? T(1) : T(0);
+        r.g1 = (gt2 && !gt1) ? T(1) : T(0);
+        r.g2 = gt2 ? T(0) : T(1);
+    } break;
+    }
+    return r;
+}
+
+struct GTileMap { int64_t tile; int32_t chunk; bool valid; };
+__device__ __forceinline__ GTileMap gmap_block(uint32_t bid, int32_t n_chunks, int64_t n_tiles) {
+    const uint32_t xcd = bid & 7u, idx = bid >> 3;
+    GTileMap m;
+    m.chunk = (int32_t)(idx % (uint32_t)n_chunks);
+    m.tile = (int64_t)(idx / (uint32_t)n_chunks) * 8 + xcd;
+    m.valid = m.tile < n_tiles;
+    return m;
+}
+
+__device__ __noinline__ void gflag_incomplete(uint8_t *ok) {
+    if ((threadIdx.x & 63) == 0) *ok = 0;
+}
+
+constexpr int GBLK = 256;
+
+// One sample per thread; LDS rows of GBLK(+4) elements: rows [0,F) = X tile, then each spill
+// slot s owns 1+GC rows (x, d[0..GC)).
+template <typename T, int GC>
+__global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
+    constexpr int RS = GBLK + 4; // row stride (elements)
+    extern __shared__ __align__(16) unsigned char gsmem[];
+    T *__restrict__ rows = reinterpret_cast<T *>(gsmem);
+
+    const GTileMap tm = gmap_block(blockIdx.x, a.n_chunks, a.n_tiles);
+    if (!tm.valid) return;
+    const int tid = threadIdx.x;
+    const int64_t base = tm.tile * GBLK;
+    const int64_t last = a.N - 1;
+    const int g0 = a.diff_g0 >= 0 ? a.diff_g0 : (int)blockIdx.y * GC; // first gradient component of this window
+    const int F = a.F, P = a.P;
+
+    {
+        const uint32_t Fu = (uint32_t)F;
+        const uint32_t total = (uint32_t)GBLK * Fu;
+        for (uint32_t e = tid; e < total; e += GBLK) {
+            const uint32_t j = e / Fu, f = e - j * Fu;
+            int64_t jj = base + j;
+            jj = jj < last ? jj : last;
+            rows[f * RS + j] = a.X[f + a.ldX * jj];
+        }
+    }
+    int64_t jj0 = base + tid;
+    const bool live = jj0 < a.N;
+    jj0 = jj0 < last ? jj0 : last;
+    int64_t cls = 0;
+    if (a.uses_params)
+        cls = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj0]
+                                : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj0]) - a.class_base;
+    __syncthreads();
+
+    const ConstU4Ptr code = (ConstU4Ptr)(uintptr_t)a.code;
+    const ConstI32Ptr code_off = (ConstI32Ptr)(uintptr_t)a.code_off;
+    const ConstI32Ptr n_grad = (ConstI32Ptr)(uintptr_t)a.n_grad;
+    const ConstI64Ptr grad_off = (ConstI64Ptr)(uintptr_t)a.grad_off;
+    const int t0 = tm.chunk * a.trees_per_chunk;
+    const int t1 = (t0 + a.trees_per_chunk < a.n_trees) ? t0 + a.trees_per_chunk : a.n_trees;
+    T *__restrict__ stk = rows + (size_t)F * RS;
+
+    for (int tree = t0; tree < t1; ++tree) {
+        const int G = a.diff_g0 >= 0 ? 1 : n_grad[tree];
+        if (a.diff_g0 < 0 && g0 >= G && g0 > 0) continue; // window without a component of this tree (window 0 always runs: x, flag)
+        int pc = code_off[tree];
+        const int pe = code_off[tree + 1];
+        T x = T(0), d[GC];
+        DE_UNROLL for (int k = 0; k < GC; k++) d[k] = T(0);
+        T poison = T(0);
+        U32x4 nxt = code[pc];
+        for (; pc < pe; ++pc) {
+            const U32x4 w = nxt;
+            nxt = code[pc + 1];
+            const uint32_t hdr = w.x;
+            const uint32_t op = hdr & H_OP_MASK;
+            const uint32_t src = (hdr >> H_SRC_SHIFT) & H_SRC_MASK;
+            const uint32_t row = w.y & 0xFFFFu;
+            if (hdr & H_PUSH) {
+                T *__restrict__ s = stk + ((hdr >> H_PUSH_SHIFT) & H_SLOT_MASK) * (1 + GC) * RS + tid;
+                s[0] = x;
+                DE_UNROLL for (int k = 0; k < GC; k++) s[(1 + k) * RS] = d[k];
+            }
+            // ---- operand B: value xb and its gradient (db for a popped value, a one-hot seed for a leaf)
+            T xb = T(0), db[GC];
+            int seed = -1; // window-local one-hot index of a leaf operand
+            bool b_is_leaf = true;
+            if (src == SRC_ROW) {
+                if ((int)row < F) {
+                    xb = rows[row * RS + tid];
+                    if (a.mode != DE_GRAD_CONSTANT) seed = P + (int)row - g0;
+                } else {
+                    const T *__restrict__ s = stk + ((int)row - F) * (1 + GC) * RS + tid;
+                    xb = s[0];
+                    DE_UNROLL for (int k = 0; k < GC; k++) db[k] = s[(1 + k) * RS];
+                    b_is_leaf = false;
+                }
+            } else if (src == SRC_CONST) {
+                xb = gimm<T>(w.z, w.w);
+                if (a.mode == DE_GRAD_CONSTANT) seed = (int)(w.y >> 16) - g0;
+                else if (a.mode == DE_GRAD_BOTH) seed = P + F + (int)(w.y >> 16) - g0;
+            } else if (src == SRC_PARAM) {
+                xb = a.params[row + a.ld_params * cls];
+                if (a.mode != DE_GRAD_CONSTANT) seed = (int)row - g0;
+            }
+            if (b_is_leaf && src != SRC_ACC) {
+                DE_UNROLL for (int k = 0; k < GC; k++) db[k] = (k == seed) ? T(1) : T(0);
+                if (a.check) poison = M<T>::fma(xb, T(0), poison); // the leaf node itself is tested (:239-242)
+            }
+            // ---- apply
+            if (op == DOP_LOAD) {
+                x = xb;
+                DE_UNROLL for (int k = 0; k < GC; k++) d[k] = db[k];
+            } else if (op < DE_B_ADD) { // unary: input is acc (SRC_ACC) or the leaf
+                const T xin = src == SRC_ACC ? x : xb;
+                const UG<T> r = unary_vg<T>(op, xin);
+                x = r.y;
+                if (src == SRC_ACC) { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.g * d[k]; }
+                else { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.g * db[k]; }
+            } else if (op >= DE_T_FMA && op < DOP_LOAD) { // op3(B, C, acc)
+                const T *__restrict__ s = stk + ((hdr >> H_POPC_SHIFT) & H_SLOT_MASK) * (1 + GC) * RS + tid;
+                const T xc = s[0];
+                const TG<T> r = ternary_vg<T>(op, xb, xc, x);
+                x = r.v;
+                DE_UNROLL for (int k = 0; k < GC; k++) d[k] = (r.g0 * db[k] + r.g1 * s[(1 + k) * RS]) + r.g2 * d[k];
+            } else { // binary; reversed opcodes mean op(B, acc)
+                uint32_t fop = op;
+                bool rev = false;
+                switch (op) {
+                case DOP_RSUB: fop = DE_B_SUB; rev = true; break;
+                case DOP_RDIV: fop = DE_B_DIV; rev = true; break;
+                case DOP_RPOW: fop = DE_B_POW; rev = true; break;
+                case DOP_RMOD: fop = DE_B_MOD; rev = true; break;
+                case DOP_RREM: fop = DE_B_REM; rev = true; break;
+                case DOP_RGREATER: fop = DE_B_GREATER; rev = true; break;
+                case DOP_RPOW_ABS2: fop = DE_B_POW_ABS2; rev = true; break;
+                default: break;
+                }
+                const BG<T> r = rev ? binary_vg<T>(fop, xb, x) : binary_vg<T>(fop, x, xb);
+                x = r.v;
+                if (rev) { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.gx * db[k] + r.gy * d[k]; }
+                else { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.gx * d[k] + r.gy * db[k]; }
+            }
+            if (a.check) {
+                poison = M<T>::fma(x, T(0), poison);
+                DE_UNROLL for (int k = 0; k < GC; k++) poison = M<T>::fma(d[k], T(0), poison);
+            }
+        }
+        if (live) {
+            if (a.diff_g0 >= 0) {
+                if (a.out) a.out[(int64_t)tree * a.ld_out + base + tid] = x;
+                a.grad[(int64_t)tree * a.ld_out + base + tid] = d[0];
+            } else {
+                if (a.out && g0 == 0) a.out[(int64_t)tree * a.ld_out + base + tid] = x;
+                T *__restrict__ gp = a.grad + grad_off[tree] + (int64_t)G * (base + tid) + g0;
+                DE_UNROLL for (int k = 0; k < GC; k++)
+                    if (g0 + k < G) gp[k] = d[k];
+            }
+        }
+        if (a.check && __ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree);
+    }
+}
+
+static int g_gcu = 0;
+
+template <typename T, int GC>
+static hipError_t launch_grad_t(const GradArgs &ga, int windows, hipStream_t stream) {
+    const EvalArgs &e = ga.e;
+    GArgs<T> a;
+    a.code = nullptr;
+    a.code_off = e.code_off;
+    a.X = static_cast<const T *>(e.X);
+    a.out = static_cast<T *>(e.out);
+    a.grad = static_cast<T *>(ga.grad);
+    a.grad_off = ga.grad_off;
+    a.n_grad = ga.n_grad;
+    a.ok = e.ok;
+    a.params = static_cast<const T *>(e.params);
+    a.classes = e.classes;
+    a.N = e.N;
+    a.ldX = e.ldX;
+    a.ld_out = e.ld_out;
+    a.ld_params = e.ld_params;
+    a.n_tiles = (e.N + GBLK - 1) / GBLK;
+    a.F = e.F;
+    a.P = ga.P;
+    a.n_trees = e.n_trees;
+    a.n_slots = e.n_slots;
+    a.mode = ga.mode;
+    a.classes_is_i64 = e.classes_is_i64;
+    a.class_base = e.class_base;
+    a.uses_params = e.uses_params ? 1 : 0;
+    a.check = ga.diff_direction >= 0 ? 0 : 1;
+    a.diff_g0 = ga.diff_direction >= 0 ? ga.P + ga.diff_direction : -1;
+    a.code = ga.generic_code;
+    if (g_gcu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_gcu = prop.multiProcessorCount;
+        if (g_gcu <= 0) g_gcu = 256;
+    }
+    int64_t n_chunks = (e.n_trees + 31) / 32;
+    const int64_t want_blocks = (int64_t)g_gcu * 4 * 8;
+    if (a.n_tiles * n_chunks * windows < want_blocks) n_chunks = (want_blocks + a.n_tiles * windows - 1) / (a.n_tiles * windows);
+    const int64_t max_chunks = (e.n_trees + 3) / 4;
+    if (n_chunks > max_chunks) n_chunks = max_chunks;
+    if (n_chunks < 1) n_chunks = 1;
+    a.trees_per_chunk = (int32_t)((e.n_trees + n_chunks - 1) / n_chunks);
+    a.n_chunks = (int32_t)((e.n_trees + a.trees_per_chunk - 1) / a.trees_per_chunk);
+    const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
+    if (blocks <= 0 || blocks > 0x7fffffffLL || windows > 65535) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(a.F + (size_t)a.n_slots * (1 + GC)) * (GBLK + 4) * sizeof(T);
+    auto kern = de_grad_tape_kernel<T, GC>;
+    if (lds > 64 * 1024) {
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (st != hipSuccess) return st;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)windows), dim3(GBLK), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <typename T> static hipError_t launch_grad_dt(const GradArgs &ga, hipStream_t stream) {
+    const int maxg = ga.max_grad < 1 ? 1 : ga.max_grad;
+    // smallest window that covers the widest gradient in one pass, else windows of 8
+    if (maxg <= 1) return launch_grad_t<T, 1>(ga, 1, stream);
+    if (maxg <= 2) return launch_grad_t<T, 2>(ga, 1, stream);
+    if (maxg <= 3) return launch_grad_t<T, 3>(ga, 1, stream);
+    if (maxg <= 4) return launch_grad_t<T, 4>(ga, 1, stream);
+    if (maxg <= 5) return launch_grad_t<T, 5>(ga, 1, stream);
+    if (maxg <= 6) return launch_grad_t<T, 6>(ga, 1, stream);
+    return launch_grad_t<T, 8>(ga, (maxg + 7) / 8, stream);
+}
+
+hipError_t launch_grad(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name) {
+    if (kernel_name) *kernel_name = "de_grad_tape_kernel";
+    if (a.diff_direction >= 0) return dtype == DE_F32 ? launch_grad_t<float, 1>(a, 1, stream) : launch_grad_t<double, 1>(a, 1, stream);
+    if (dtype == DE_F32) return launch_grad_dt<float>(a, stream);
+    return launch_grad_dt<double>(a, stream);
+}
+
+} // namespace de

@@ -36,7 +36,8 @@ struct EvalArgs {
 };
 
 struct GradArgs {
-    EvalArgs e;
+    EvalArgs e;               // e.code is unused: the gradient kernel runs the GENERIC program
+    const Instr *generic_code; // device, +1 pad
     int32_t mode;             // de_grad_mode
     int32_t P;                // n_params (rows before the features in VARIABLE/BOTH)
     void *grad;               // device

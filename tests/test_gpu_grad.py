@@ -1,0 +1,185 @@
+"""GPU parity tests of eval_grad_tree_array / eval_diff_tree_array (and the parametric path)
+through the C ABI vs the CPU oracle.  Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+import dynamicexpressions_jl_amd as de
+from helpers import case_X, case_tree, load_golden
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+GCASES = [c for c in load_golden() if c["kind"] == "grad"]
+MODES = {"variable": (True, oracle.GRAD_VARIABLE), "constant": (False, oracle.GRAD_CONSTANT),
+         "both": ("both", oracle.GRAD_BOTH)}
+
+
+@pytest.fixture(scope="module")
+def api():
+    from dynamicexpressions_jl_amd import api as _api
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    _api.library()
+    return _api
+
+
+@pytest.mark.parametrize("case", GCASES, ids=[c["name"] for c in GCASES])
+def test_golden_gradients_on_gpu(case, api):
+    tree, ops = case_tree(case)
+    X = case_X(case)
+    exp = case["expect"]
+    variable, omode = MODES[exp["mode"]]
+    y, g, ok = api.eval_grad_tree_array(tree, X, ops, variable=variable)
+    assert ok == exp["ok"], f"{case['name']} ({case['cite']})"
+    if not ok:
+        return
+    tol = lambda want: max(exp.get("atol", 0), 1e-30) + max(exp.get("rtol", 0), 2e-13) * np.abs(want)  # noqa: E731
+    if "y" in exp:
+        want = np.asarray(exp["y"])
+        assert np.all(np.abs(y - want) <= tol(want))
+    if "grad" in exp:
+        want = np.asarray(exp["grad"])
+        assert g.shape == want.shape
+        assert np.all(np.abs(g - want) <= tol(want)), case["name"]
+    for row, vals in exp.get("grad_rows", {}).items():
+        want = np.asarray(vals)
+        assert np.all(np.abs(g[int(row)] - want) <= tol(want))
+    if exp["mode"] == "variable":  # eval_diff_tree_array per feature == gradient row (test_derivatives.jl:84-92)
+        for f in range(X.shape[0]):
+            y2, d, okd = api.eval_diff_tree_array(tree, X, ops, f + 1)
+            assert okd
+            np.testing.assert_array_equal(d, g[f])
+            np.testing.assert_array_equal(y2, y)
+
+
+def grad_compare(api, trees, ops, X, dtype, mode_name, exact=False):
+    variable, omode = MODES[mode_name]
+    pop = api.Population(trees, ops, dtype, n_features=X.shape[0])
+    out, grads, ok = pop.eval_grad(X, variable)
+    n_ok = 0
+    n_ent = n_pass = 0
+    for t, tree in enumerate(trees):
+        tape, consts = de.flatten(tree, ops, dtype)
+        y, g, ok_el = oracle.eval_grad_tree_array(tape, consts, X, omode, elementwise=True)
+        assert bool(ok[t]) == ok_el, f"flag mismatch tree {t} [{mode_name}]: {de.string_tree(tree, ops)}"
+        assert grads[t].shape == g.shape
+        if not ok_el:
+            continue
+        n_ok += 1
+        if exact:
+            ui = np.uint32 if dtype == np.float32 else np.uint64
+            np.testing.assert_array_equal(out[t].view(ui), y.view(ui), err_msg=de.string_tree(tree, ops))
+            np.testing.assert_array_equal(np.ascontiguousarray(grads[t]).view(ui), np.ascontiguousarray(g).view(ui),
+                                          err_msg=de.string_tree(tree, ops))
+            continue
+        y64, g64, _ = oracle.eval_grad_tree_array(tape, consts.astype(np.float64), X.astype(np.float64), omode, True)
+        rel = 1e-4 if dtype == np.float32 else 1e-11
+        scale = np.max(np.abs(g64), axis=1, keepdims=True) if g.size else 0
+        tol = rel * np.abs(g64) + 128 * np.abs(g.astype(np.float64) - g64) + 1e-7 * rel * 1e4 * scale + 1e-300
+        okm = np.abs(grads[t].astype(np.float64) - g) <= tol
+        n_ent += okm.size
+        n_pass += int(okm.sum())
+        tolx = rel * np.abs(y64) + 128 * np.abs(y.astype(np.float64) - y64) + 1e-300
+        assert np.mean(np.abs(out[t].astype(np.float64) - y) <= tolx) > 0.99
+    pop.close()
+    if not exact and n_ent:
+        assert n_pass / n_ent > 0.995, f"only {n_pass}/{n_ent} gradient entries within tolerance [{mode_name}]"
+    return n_ok
+
+
+@pytest.mark.parametrize("mode", ["variable", "constant", "both"])
+def test_exact_operator_gradients_bit_identical(api, mode):
+    """+ - * / square neg abs: every partial is IEEE-exact, the accumulation order is the
+    reference's (g1*d1 + g2*d2): the whole Jacobian must match the oracle bit for bit."""
+    ops = de.OperatorEnum(binary_operators=("+", "-", "/", "*"), unary_operators=("neg", "square", "abs"))
+    rng = de.synth.Xoshiro256ss(17)
+    for dtype in (np.float32, np.float64):
+        trees = [de.synth.gen_random_tree_fixed_size(3 + i % 26, ops, 4, rng, dtype) for i in range(80)]
+        X = de.synth.random_X(4, 777, seed=12, dtype=dtype)
+        assert grad_compare(api, trees, ops, X, dtype, mode, exact=True) > 10
+
+
+@pytest.mark.parametrize("mode", ["variable", "constant", "both"])
+@pytest.mark.parametrize("N", [1, 300, 2049])
+def test_random_population_gradients_vs_oracle(api, mode, N):
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(120, seed=0xDE03)
+    X = de.synth.random_X(5, N, seed=6)
+    assert grad_compare(api, trees, ops, X, np.float32, mode) > 5
+
+
+def test_wide_operator_gradients_f64(api):
+    ops = de.OperatorEnum(binary_operators=("+", "-", "/", "*", "max", "min", "pow_abs2", "^"),
+                          unary_operators=("cos", "exp", "safe_log", "neg", "square", "cube", "abs", "tanh", "sin",
+                                           "safe_sqrt", "relu", "atan", "custom_cos"))
+    rng = de.synth.Xoshiro256ss(23)
+    trees = [de.synth.gen_random_tree_fixed_size(4 + i % 18, ops, 3, rng, np.float64) for i in range(100)]
+    X = de.synth.random_X(3, 500, seed=8, dtype=np.float64)
+    for mode in ("variable", "both"):
+        grad_compare(api, trees, ops, X, np.float64, mode)
+
+
+def test_many_constants_use_several_windows(api):
+    """A tree with 19 constants: constant-mode gradient is computed in three 8-wide windows."""
+    ops = de.OperatorEnum(binary_operators=("+", "*"), unary_operators=("cos",))
+    t = de.Node(feature=1)
+    for i in range(19):
+        t = de.Node(1 + i % 2, t, de.Node(val=0.5 + 0.1 * i))
+    t2 = de.Node(1, de.Node(1, t.copy()), de.Node(feature=2))
+    X = de.synth.random_X(2, 1000, seed=2, dtype=np.float64)
+    grad_compare(api, [t, t2, de.Node(feature=2)], ops, X, np.float64, "constant", exact=False)
+    grad_compare(api, [t, t2, de.Node(val=2.0)], ops, X, np.float64, "both", exact=False)
+    # + and * only: exact
+    ops2 = de.OperatorEnum(binary_operators=("+", "*"))
+    t3 = de.Node(feature=1)
+    for i in range(19):
+        t3 = de.Node(1 + i % 2, t3, de.Node(val=0.5 + 0.1 * i))
+    grad_compare(api, [t3], ops2, X, np.float64, "constant", exact=True)
+
+
+def test_parametric_eval_and_constant_gradient_config_C5_shape(api):
+    """BASELINE config 5 in miniature: ParametricNode trees, P=8 per-class parameters, eval and
+    the constant-mode gradient, against the reference's own reduction (gather params above X,
+    re-index leaves — src/ParametricExpression.jl:381-389) run through the oracle."""
+    ops = de.synth.BENCH_OPERATORS
+    P, F, C, N = 8, 5, 16, 1500
+    trees = de.synth.random_population(60, seed=0xDE05, nfeatures=F, node_type=de.ParametricNode, nparams=P)
+    g = np.random.Generator(np.random.PCG64(5))
+    params = np.asfortranarray(g.standard_normal((P, C)).astype(np.float32))
+    classes = g.integers(1, C + 1, N).astype(np.int64)
+    X = de.synth.random_X(F, N, seed=7)
+    pop = api.Population(trees, ops, np.float32, n_features=F, n_params=P)
+    out, ok = pop.eval(X, params, classes)
+    outg, grads, okg = pop.eval_grad(X, False, params, classes)
+    outb, gradsb, okb = pop.eval_grad(X, "both", params, classes)
+    n_ok = 0
+    for t, tree in enumerate(trees):
+        tape, consts = de.flatten(tree, ops, np.float32)
+        y, ok_el = oracle.eval_tree_array_parametric(tape, consts, X, params, classes.astype(np.int32), 1, elementwise=True)
+        assert bool(ok[t]) == ok_el, de.string_tree(tree, ops)
+        t2, PX = oracle.parametric_to_plain(tape, X, params, classes)
+        yg, gg, okg_el = oracle.eval_grad_tree_array(t2, consts, PX, oracle.GRAD_CONSTANT, elementwise=True)
+        yb, gb, okb_el = oracle.eval_grad_tree_array(t2, consts, PX, oracle.GRAD_BOTH, elementwise=True)
+        assert bool(okg[t]) == okg_el and bool(okb[t]) == okb_el
+        assert gradsb[t].shape == (P + F + len(consts), N)
+        if ok_el:
+            n_ok += 1
+            assert np.mean(np.abs(out[t] - y) <= 1e-5 * np.abs(y) + 1e-30) > 0.98
+        if okg_el and gg.size:
+            sc = np.max(np.abs(gg)) + 1e-30
+            assert np.mean(np.abs(grads[t] - gg) <= 1e-4 * np.abs(gg) + 1e-6 * sc) > 0.98
+        if okb_el:
+            sc = np.max(np.abs(gb)) + 1e-30
+            assert np.mean(np.abs(gradsb[t] - gb) <= 1e-4 * np.abs(gb) + 1e-6 * sc) > 0.98
+    assert n_ok > 5
+    with pytest.raises(ValueError):  # "You must pass the `classes::Vector` argument"
+        pop.eval(X)
+
+
+def test_diff_has_no_validity_test(api):
+    ops = de.OperatorEnum(binary_operators=("+", "/"), unary_operators=("cos",))
+    tree = de.Node(2, de.Node(feature=1), de.Node(val=0.0))  # x1 / 0
+    X = de.synth.random_X(1, 50, seed=1, dtype=np.float64)
+    y, d, ok = api.eval_diff_tree_array(tree, X, ops, 1)
+    assert ok and np.all(np.isinf(y)) and np.all(np.isinf(d))
+    _, _, okg = api.eval_grad_tree_array(tree, X, ops, variable=True)
+    assert not okg
