@@ -12,9 +12,14 @@ GPUs the population is tree-sharded (weak scaling: 1000 trees per GPU, X replica
 data-path collective; one RCCL all_gather of the per-tree completion flags per step).
 
 Rank 0 prints ONE JSON line: metric node-evals/s (whole job), plus
-  roofline     — the dominant kernel's ALGORITHMIC bytes (24 B per tree-sample: 20 B of X + 4 B
-                 written) / its average launch duration measured with hipEvents on
-                 the launch stream inside the timed region, against 8 TB/s HBM3E;
+  roofline     — the dominant kernel's ALGORITHMIC bytes / its average launch duration measured
+                 with hipEvents on the launch stream inside the timed region, against 8 TB/s HBM3E.
+                 The kernel stages each X tile once per chunk of K_eff trees, so per SURVEY.md §8d
+                 the algorithmic figure is F*s/K_eff + s bytes per tree-sample (4.3 B at K_eff=63),
+                 NOT the 24 B of a one-tree-per-pass design; `traffic` is the rocprofv3 PMC
+                 measurement of the same launch (profiles/), and `single_tree_equivalent` restates
+                 the rate in the north-star's 24 B/tree-sample accounting.  After X reuse the path
+                 is issue-bound (VALU + scalar), not HBM-bound: see DESIGN.md §Roofline.
   cpu_baseline — the CPU oracle (C restatement of the reference algorithm, 1 thread) timed on
                  a bounded sample of the same workload on this box's host cores.
 """
@@ -31,11 +36,14 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-BYTES_PER_TREE_SAMPLE = 24.0  # (F + 1) * 4 with F = 5   
+F_FEATURES, ELEM = 5, 4
+BYTES_PER_TREE_SAMPLE_SINGLE = (F_FEATURES + 1) * ELEM  # 24 B: one tree per pass over X
 
 WORKLOADS = {
     "headline": dict(n_trees=1000, N=10**7, desc="1000 random depth<=15 20-node trees x (5 x 10^7) Float32"),
     "C2": dict(n_trees=1000, N=10**6, desc="1000 random depth<=15 20-node trees x (5 x 10^6) Float32"),
+    "C3": dict(n_trees=1000, N=10**6, grad=True,
+               desc="1000 random depth<=15 20-node trees x (5 x 10^6) Float32, eval_grad_tree_array(variable=true)"),
     "tiny": dict(n_trees=64, N=10**5, desc="64 trees x (5 x 10^5) Float32 (plumbing)"),
 }
 
@@ -103,9 +111,15 @@ def main():
     out = torch.empty((len(trees), N), device=dev, dtype=torch.float32)
     ok = torch.empty(len(trees), device=dev, dtype=torch.uint8)
     lib = api.library()
+    is_grad = bool(wl.get("grad"))
+    grad = torch.empty(len(trees) * 5 * N, device=dev, dtype=torch.float32) if is_grad else None
 
     def step():
-        ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
+        if is_grad:
+            ctx.check(lib.de_eval_grad(ctx._h, pop._h, X.data_ptr(), N, 5, None, 0, out.data_ptr(), N,
+                                       grad.data_ptr(), None, ok.data_ptr()))
+        else:
+            ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
         if world > 1:
             return dedist.gather_flags(ok, len(all_trees), rank, world)
         return ok
@@ -136,8 +150,21 @@ def main():
         value = total_nodes * N * args.steps / elapsed
         kms = [k for k in kernel_ms if k is not None]
         k_avg_ms = float(np.mean(kms)) if kms else ms_per_step
-        alg_bytes = BYTES_PER_TREE_SAMPLE * len(trees) * N  # per launch (this rank's shard)
+        plan = pop.plan(N)
+        units = len(trees) * N  # tree-samples per launch (this rank's shard)
+        if is_grad:  # one tree per X pass, writes x + 5 gradient rows: (F + 1 + F)*s  
+            k_eff, b_unit = 1, float((2 * F_FEATURES + 1) * ELEM)
+        else:  # X tile staged once per chunk of trees
+            k_eff = plan["trees_per_chunk"]
+            b_unit = F_FEATURES * ELEM / k_eff + ELEM
+        alg_bytes = b_unit * units
         achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
+        single = BYTES_PER_TREE_SAMPLE_SINGLE * units / (k_avg_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(prof):  # measured by tools/profile_round.sh with rocprofv3 --pmc (separate passes)
+            with open(prof) as fh:
+                traffic = json.load(fh).get(args.workload, {}).get("hbm_bytes_per_launch")
         res = {
             "metric": "node-evals/sec", "value": value, "unit": "node-evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -147,9 +174,14 @@ def main():
                        "nodes_per_tree": 20, "operators": "+ - / * cos exp", "sharding": f"tree-sharded x{world}",
                        "complete_fraction": float(flags.float().mean().item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": ctx.last_kernel_name(), "kernel_ms_avg": k_avg_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_bytes_per_tree_sample": b_unit, "k_eff_trees_per_x_tile": k_eff,
+                         "single_tree_equivalent": {"bytes_per_tree_sample": BYTES_PER_TREE_SAMPLE_SINGLE,
+                                                    "achieved": single, "frac": single / HBM_PEAK_GBS},
+                         "note": "X tile reused by k_eff trees from LDS: HBM traffic ~= the output; the kernel is "
+                                 "VALU/scalar-issue bound (DESIGN.md §Roofline)"},
         }
         if not args.no_cpu_baseline:
             Ns = min(N, 10**6)

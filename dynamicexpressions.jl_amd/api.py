@@ -44,7 +44,7 @@ EXPORTS = [
     "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create",
     "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
     "de_program_n_grad", "de_program_dump", "de_lower_tape", "de_eval", "de_eval_grad", "de_eval_diff",
-    "de_eval_tree_array", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
+    "de_eval_tree_array", "de_eval_plan", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
 ]
 
 
@@ -105,6 +105,7 @@ def library() -> C.CDLL:
     lib.de_eval_grad.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), C.c_int, vp, i64, vp, vp, vp]
     lib.de_eval_diff.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, i64, vp]
     lib.de_eval_tree_array.argtypes = [vp, C.c_int, vp, i64, vp, i64, vp, i32, i64, u32, vp, vp]
+    lib.de_eval_plan.argtypes = [vp, i64, vp]
     lib.de_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.de_ctx_last_kernel_name.restype = C.c_char_p
     lib.de_ctx_last_kernel_name.argtypes = [vp]
@@ -295,6 +296,12 @@ class Population:
         if consts.size != int(self.n_consts.sum()):
             raise ValueError("wrong number of constants")
         self.ctx.check(library().de_program_set_consts(self._h, consts.ctypes.data if consts.size else None))
+
+    def plan(self, N: int) -> dict:
+        """Launch plan of ``eval`` for N samples (tile size, tree chunks, trees per chunk)."""
+        pl = np.zeros(3, dtype=np.int32)
+        self.ctx.check(library().de_eval_plan(self._h, N, pl.ctypes.data))
+        return dict(tile=int(pl[0]), n_chunks=int(pl[1]), trees_per_chunk=int(pl[2]))
 
     def n_grad(self, tree: int, mode: int) -> int:
         return int(library().de_program_n_grad(self._h, tree, mode))

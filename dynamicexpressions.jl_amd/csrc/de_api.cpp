@@ -415,6 +415,12 @@ int64_t de_program_n_grad(const de_program_t *p, int64_t tree, int mode) {
     }
 }
 
+int de_eval_plan(const de_program_t *p, int64_t N, int32_t *plan) {
+    if (!p || !plan || N < 0) return DE_ERR_INVALID_ARG;
+    eval_plan(p->dtype, p->n_trees, N, &plan[0], &plan[1], &plan[2]);
+    return DE_OK;
+}
+
 int64_t de_program_dump(const de_program_t *p, int64_t tree, uint32_t *words, int64_t cap, int which) {
     if (!p || tree < 0 || tree >= p->n_trees) return -DE_ERR_INVALID_ARG;
     if (which == 1) { // metadata: n_slots, host_ok_eval, host_ok_grad, uses_params

@@ -52,6 +52,9 @@ struct GradArgs {
 hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const char **kernel_name);
 hipError_t launch_grad(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name);
 
+// Launch plan of the eval kernel for (n_trees, N): samples per workgroup tile, tree chunks.
+void eval_plan(int dtype, int64_t n_trees, int64_t N, int32_t *tile, int32_t *n_chunks, int32_t *trees_per_chunk);
+
 // LDS bytes the eval kernel needs for (dtype, F, n_slots); 0 if it cannot fit.
 size_t eval_lds_bytes(int dtype, int F, int n_slots, int *K_out);
 

@@ -452,7 +452,34 @@ size_t eval_lds_bytes(int dtype, int F, int n_slots, int *K_out) {
     return bytes <= 160 * 1024 ? bytes : 0;
 }
 
+static void eval_geometry(int dtype, int *G, int *BLK);
 static int g_cu_count = 0;
+
+static int cu_count() {
+    return g_cu_count;
+}
+
+// Tree chunking: chunks of ~64 trees keep workgroups short (fine-grained tail) while the
+// X-tile staging (one L2 read of the tile per chunk) stays a few percent of the work; with few
+// sample tiles, split further so the grid still covers the chip several times.
+static void plan_chunks(int64_t n_trees, int64_t n_tiles, int32_t *n_chunks_out, int32_t *tpc_out) {
+    int64_t n_chunks = (n_trees + 63) / 64;
+    const int64_t want_blocks = (int64_t)cu_count() * 4 * 8;
+    if (n_tiles * n_chunks < want_blocks) n_chunks = (want_blocks + n_tiles - 1) / n_tiles;
+    const int64_t max_chunks = (n_trees + 7) / 8; // >= 8 trees per chunk
+    if (n_chunks > max_chunks) n_chunks = max_chunks;
+    if (n_chunks < 1) n_chunks = 1;
+    const int64_t tpc = (n_trees + n_chunks - 1) / n_chunks;
+    *tpc_out = (int32_t)tpc;
+    *n_chunks_out = (int32_t)((n_trees + tpc - 1) / tpc);
+}
+
+void eval_plan(int dtype, int64_t n_trees, int64_t N, int32_t *tile, int32_t *n_chunks, int32_t *trees_per_chunk) {
+    int G, BLK;
+    eval_geometry(dtype, &G, &BLK);
+    *tile = BLK * G * (dtype == DE_F32 ? 4 : 2);
+    plan_chunks(n_trees, (N + *tile - 1) / *tile, n_chunks, trees_per_chunk);
+}
 
 template <typename T, int G, int BLK>
 static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const char **kname) {
@@ -479,24 +506,10 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
     a.class_base = e.class_base;
     a.vec_store = (reinterpret_cast<uintptr_t>(e.out) % 16 == 0 && (e.ld_out * sizeof(T)) % 16 == 0) ? 1 : 0;
 
-    if (g_cu_count == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            g_cu_count = prop.multiProcessorCount;
-        if (g_cu_count <= 0) g_cu_count = 256;
-    }
-    // Tree chunking: chunks of ~64 trees keep workgroups short (fine-grained tail) while
-    // the X-tile staging (one L2 read of the tile per chunk) stays a few percent of the work;
-    // with few sample tiles, split further so the grid still covers the chip several times.
-    int64_t n_chunks = (e.n_trees + 63) / 64;
-    const int64_t want_blocks = (int64_t)g_cu_count * 4 * 8;
-    if (a.n_tiles * n_chunks < want_blocks) n_chunks = (want_blocks + a.n_tiles - 1) / a.n_tiles;
-    const int64_t max_chunks = (e.n_trees + 7) / 8; // >= 8 trees per chunk
-    if (n_chunks > max_chunks) n_chunks = max_chunks;
-    if (n_chunks < 1) n_chunks = 1;
-    a.trees_per_chunk = (int32_t)((e.n_trees + n_chunks - 1) / n_chunks);
-    a.n_chunks = (int32_t)((e.n_trees + a.trees_per_chunk - 1) / a.trees_per_chunk);
+    int32_t tpc, nch;
+    plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc);
+    a.trees_per_chunk = tpc;
+    a.n_chunks = nch;
 
     const int64_t tile_groups = (a.n_tiles + 7) / 8;
     const int64_t blocks = tile_groups * 8 * a.n_chunks;

@@ -215,6 +215,10 @@ int de_eval_tree_array(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, in
                        int64_t N, uint32_t options, void *out, uint8_t *ok);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------- */
+/* Launch plan de_eval would use for N samples: plan[0] = samples per workgroup tile,
+ * plan[1] = tree chunks, plan[2] = trees per chunk (the trees that share one staged X
+ * tile: the K_eff of the algorithmic-bytes formula). */
+int de_eval_plan(const de_program_t *prog, int64_t N, int32_t *plan);
 /* Device time of the kernels launched by the most recent de_eval* call on this
  * context, measured with hipEvents recorded on the context's stream.  Blocks
  * until that work has finished. */
