@@ -1,0 +1,222 @@
+# DynamicExpressionsHIPExt.jl — the reference-side binding of libde_hip.so.
+#
+# This is the Julia half of the boundary (SURVEY.md §8b, INTEGRATION.md): it stays entirely on
+# the host, keeps the reference's Node / OperatorEnum / EvalContext API, flattens a tree into
+# the post-order tape of include/de_hip.h and `ccall`s the C ABI.  It mirrors, line for line,
+# what the Python twin (dynamicexpressions.jl_amd/node.py + api.py) does; the Python twin is the
+# one exercised by the test-suite because the build image has no Julia.
+#
+# Plug-in point: exactly the precedent of the Bumper whole-tree override
+#   ext/DynamicExpressionsBumperExt.jl:11-49   _bumper_eval_tree_array(tree, cX, operators, ctx)
+#   src/ExtensionInterface.jl:60-64            bumper_eval_tree_array stub
+#   src/Evaluate.jl:300-302                    `if bumper isa Val{true} return bumper_eval_tree_array(...)`
+# A maintainer adds the analogous stub `hip_eval_tree_array` (INTEGRATION.md §3) and this file
+# as a package extension keyed on a weak dependency that provides the shared library.
+module DynamicExpressionsHIPExt
+
+using DynamicExpressions:
+    AbstractExpressionNode, Node, OperatorEnum, EvalContext, get_child, get_children,
+    count_constant_nodes
+import DynamicExpressions.ExtensionInterfaceModule: is_extension_loaded
+
+const LIBDE = get(ENV, "DE_HIP_LIB", "libde_hip")
+
+# ---- de_hip.h mirrors ---------------------------------------------------------------------
+struct TapeNode            # de_tape_node_t
+    degree::UInt8
+    op::UInt8
+    arg::UInt16
+end
+const DE_OK = Cint(0)
+const DE_ERR_UNSUPPORTED_OP = Cint(3)
+const DE_LEAF_CONST, DE_LEAF_FEATURE, DE_LEAF_PARAM = UInt8(0), UInt8(1), UInt8(2)
+const DE_F32, DE_F64 = Cint(0), Cint(1)
+const DE_OPT_EARLY_EXIT, DE_OPT_FUSE_DEG1, DE_OPT_FUSE_DEG2, DE_OPT_BUMPER_CHECKS =
+    UInt32(1), UInt32(2), UInt32(4), UInt32(8)
+const OPERATOR_LIMIT_BEFORE_SLOWDOWN = 15   # src/Evaluate.jl:14
+dtype_code(::Type{Float32}) = DE_F32
+dtype_code(::Type{Float64}) = DE_F64
+
+struct UnsupportedOperator <: Exception
+    f::Any
+    degree::Int
+end
+
+# ---- OperatorEnum -> opcode table (by function NAME; the C table is authoritative) -----------
+"""Opcode of every operator of `operators`, per degree; throws `UnsupportedOperator` for a
+function the device table does not know (the caller then keeps the CPU path)."""
+function opcode_table(operators::OperatorEnum)
+    return ntuple(length(operators.ops)) do d
+        map(operators.ops[d]) do f
+            name = String(nameof(f))
+            code = ccall((:de_opcode_by_name, LIBDE), Cint, (Cstring, Cint), name, d)
+            code < 0 && throw(UnsupportedOperator(f, d))
+            UInt8(code)
+        end
+    end
+end
+
+"""EvalContext knobs that change RESULTS -> de_options bits (src/Evaluate.jl:156-181,496,607)."""
+function option_bits(operators::OperatorEnum, ctx::EvalContext)
+    nops(d) = d <= length(operators.ops) ? length(operators.ops[d]) : 0
+    fused = ctx.use_fused isa Val{true}
+    bits = UInt32(0)
+    ctx.early_exit isa Val{true} && (bits |= DE_OPT_EARLY_EXIT)
+    fused && nops(1) <= OPERATOR_LIMIT_BEFORE_SLOWDOWN && (bits |= DE_OPT_FUSE_DEG1)
+    fused && nops(2) <= OPERATOR_LIMIT_BEFORE_SLOWDOWN && (bits |= DE_OPT_FUSE_DEG2)
+    ctx.bumper isa Val{true} && (bits |= DE_OPT_BUMPER_CHECKS)
+    return bits
+end
+
+# ---- flattening: post-order tape + constant pool (depth-first, left to right) ---------------
+function flatten!(
+    nodes::Vector{TapeNode}, consts::Vector{T}, tree::AbstractExpressionNode{T}, optable
+) where {T}
+    if tree.degree == 0
+        if tree.constant
+            push!(consts, tree.val)
+            push!(nodes, TapeNode(0x00, DE_LEAF_CONST, UInt16(length(consts) - 1)))
+        elseif hasproperty(tree, :is_parameter) && tree.is_parameter   # ParametricNode
+            push!(nodes, TapeNode(0x00, DE_LEAF_PARAM, UInt16(tree.parameter - 1)))
+        else
+            push!(nodes, TapeNode(0x00, DE_LEAF_FEATURE, UInt16(tree.feature - 1)))
+        end
+    else
+        d = Int(tree.degree)
+        for c in get_children(tree, d)
+            flatten!(nodes, consts, c, optable)
+        end
+        push!(nodes, TapeNode(UInt8(d), optable[d][tree.op], 0x0000))
+    end
+    return nothing
+end
+
+# ---- context: one de_ctx_t per Julia task/thread --------------------------------------------
+mutable struct HIPContext
+    handle::Ptr{Cvoid}
+end
+function HIPContext(device::Integer=0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:de_ctx_create, LIBDE), Cint, (Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, h)
+    rc == DE_OK || error("de_ctx_create failed: ", unsafe_string(ccall((:de_status_string, LIBDE), Cstring, (Cint,), rc)))
+    ctx = HIPContext(h[])
+    finalizer(c -> ccall((:de_ctx_destroy, LIBDE), Cint, (Ptr{Cvoid},), c.handle), ctx)
+    return ctx
+end
+const CONTEXTS = Dict{Int,HIPContext}()
+const CONTEXTS_LOCK = ReentrantLock()
+function task_context()
+    tid = Threads.threadid()
+    lock(CONTEXTS_LOCK) do
+        get!(() -> HIPContext(0), CONTEXTS, tid)
+    end
+end
+check(ctx::HIPContext, rc::Cint) =
+    rc == DE_OK || error(unsafe_string(ccall((:de_last_error, LIBDE), Cstring, (Ptr{Cvoid},), ctx.handle)))
+
+# ---- the whole-tree override (signature of _bumper_eval_tree_array) --------------------------
+"""
+    _hip_eval_tree_array(tree, cX, operators, eval_context) -> (result::Vector{T}, ok::Bool)
+
+Drop-in for `eval_tree_array`'s body: same `(output, complete)` tuple, `cX` is the reference's
+`[n_features, n_rows]` column-major matrix and is passed zero-copy.  Falls back to the CPU path
+(returns `nothing`) when an operator has no device opcode.
+"""
+function _hip_eval_tree_array(
+    tree::AbstractExpressionNode{T}, cX::AbstractMatrix{T}, operators::OperatorEnum,
+    eval_context::EvalContext,
+) where {T<:Union{Float32,Float64}}
+    optable = try
+        opcode_table(operators)
+    catch e
+        e isa UnsupportedOperator || rethrow()
+        return nothing                       # caller continues on the reference CPU path
+    end
+    nodes, consts = TapeNode[], T[]
+    flatten!(nodes, consts, tree, optable)
+    F, N = size(cX)
+    X = cX isa Matrix{T} ? cX : Matrix{T}(cX)  # strided views are copied; Matrix is zero-copy
+    out = Vector{T}(undef, N)
+    ok = Ref{UInt8}(0)
+    ctx = task_context()
+    rc = GC.@preserve nodes consts X out ccall(
+        (:de_eval_tree_array, LIBDE), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{TapeNode}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int32, Int64, UInt32,
+         Ptr{Cvoid}, Ref{UInt8}),
+        ctx.handle, dtype_code(T), nodes, length(nodes), consts, length(consts), X, F, N,
+        option_bits(operators, eval_context), out, ok)
+    check(ctx, rc)
+    return (out, ok[] != 0x00)
+end
+
+# ---- population form: lower many trees once, evaluate in one launch -------------------------
+mutable struct HIPPopulation{T}
+    ctx::HIPContext
+    handle::Ptr{Cvoid}
+    n_trees::Int
+    n_features::Int
+end
+function HIPPopulation(
+    trees::AbstractVector{<:AbstractExpressionNode{T}}, operators::OperatorEnum, n_features::Integer;
+    eval_context::EvalContext=EvalContext(), n_params::Integer=0,
+) where {T<:Union{Float32,Float64}}
+    optable = opcode_table(operators)
+    nodes, consts = TapeNode[], T[]
+    node_off, const_off = Int64[0], Int64[0]
+    for t in trees
+        flatten!(nodes, consts, t, optable)
+        push!(node_off, length(nodes)); push!(const_off, length(consts))
+    end
+    ctx = task_context()
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = GC.@preserve nodes consts node_off const_off ccall(
+        (:de_program_create, LIBDE), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{TapeNode}, Ptr{Int64}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int32, Int32, UInt32,
+         Ref{Ptr{Cvoid}}),
+        ctx.handle, dtype_code(T), nodes, node_off, length(trees), consts, const_off, n_features,
+        n_params, option_bits(operators, eval_context), h)
+    check(ctx, rc)
+    pop = HIPPopulation{T}(ctx, h[], length(trees), n_features)
+    finalizer(p -> ccall((:de_program_destroy, LIBDE), Cint, (Ptr{Cvoid},), p.handle), pop)
+    return pop
+end
+
+"""`(out::Matrix{T}(N × n_trees), ok::Vector{Bool})`; column t is `eval_tree_array(trees[t], X)`."""
+function eval_population(pop::HIPPopulation{T}, X::Matrix{T}) where {T}
+    F, N = size(X)
+    @assert F >= pop.n_features
+    out = Matrix{T}(undef, N, pop.n_trees)          # row t of the C layout = column t here
+    ok = Vector{UInt8}(undef, pop.n_trees)
+    rc = GC.@preserve X out ok ccall(
+        (:de_eval, LIBDE), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{UInt8}),
+        pop.ctx.handle, pop.handle, X, N, F, C_NULL, out, N, ok)
+    check(pop.ctx, rc)
+    return out, ok .!= 0x00
+end
+
+"""Forward-mode gradient of one tree: `(evaluation, gradient(n_grad × N), complete)` like
+`eval_grad_tree_array(tree, cX, operators; variable)` (src/EvaluateDerivative.jl:193-228)."""
+function _hip_eval_grad_tree_array(
+    tree::AbstractExpressionNode{T}, cX::Matrix{T}, operators::OperatorEnum; variable=Val(false)
+) where {T<:Union{Float32,Float64}}
+    mode = variable isa Val{true} || variable === true ? Cint(0) :
+           variable isa Val{:both} ? Cint(2) : Cint(1)
+    F, N = size(cX)
+    pop = HIPPopulation([tree], operators, F)
+    ng = ccall((:de_program_n_grad, LIBDE), Int64, (Ptr{Cvoid}, Int64, Cint), pop.handle, 0, mode)
+    out = Vector{T}(undef, N)
+    grad = Matrix{T}(undef, ng, N)
+    ok = Ref{UInt8}(0)
+    rc = GC.@preserve cX out grad ccall(
+        (:de_eval_grad, LIBDE), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid},
+         Ptr{Int64}, Ref{UInt8}),
+        pop.ctx.handle, pop.handle, cX, N, F, C_NULL, mode, out, N, grad, C_NULL, ok)
+    check(pop.ctx, rc)
+    return (out, grad, ok[] != 0x00)
+end
+
+is_extension_loaded(::Val{:HIP}) = true
+
+end # module
