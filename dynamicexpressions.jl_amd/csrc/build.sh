@@ -2,6 +2,7 @@
 # Builds libde_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
 # -ffp-contract=off: Julia never contracts a*b+c, so neither may the kernels.
 set -euo pipefail
+fail=0
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno -Wall -Wno-unused-function"

@@ -65,7 +65,11 @@ struct de_program {
     std::vector<uint8_t> host_ok_eval;  // per tree: constant part of the eval flag
     std::vector<uint8_t> host_ok_grad;  // per tree: all constants finite
     std::vector<double> consts;         // current constants as double
-    std::vector<BoundInstr> bcode;      // bound form of `code` (what the eval kernel runs)
+    std::vector<BoundInstr> bcode;      // bound form of `code` (handler ids)
+    std::vector<BoundInstr> tcode;      // threaded form: handler address offsets + LDS byte offsets
+    bool threaded = false;
+    uint64_t handler_base = 0;
+    uint32_t param_handler_off = 0;
     std::vector<int32_t> bcode_off;     // n_trees + 1
     BoundInstr *d_code = nullptr;
     int32_t *d_code_off = nullptr;
@@ -253,6 +257,38 @@ static void rebind(de_program *p) {
     }
 }
 
+// Threaded-code form of the bound program (de_kernels.hip, de_eval_threaded_kernel): word 0 =
+// handler address - handler_base, word 1 = LDS byte offset of the operand row | aux << 24.
+static int make_threaded(de_ctx *c, de_program *p) {
+    p->threaded = false;
+    if (!eval_uses_threaded()) return DE_OK;
+    if ((int64_t)p->n_features + p->n_slots > 4000) return DE_OK; // row offsets must fit 24 bits
+    uint64_t table[BOP_COUNT];
+    hipError_t st = eval_handler_table(p->dtype, table);
+    if (st != hipSuccess) return fail(c, DE_ERR_HIP, "handler table: %s", hipGetErrorString(st));
+    uint64_t base = table[0];
+    for (int i = 0; i < (int)BOP_COUNT; i++) base = std::min(base, table[i]);
+    for (int i = 0; i < (int)BOP_COUNT; i++)
+        if (table[i] - base > 0xFFFFFFFFull) return DE_OK; // cannot encode: keep the switch kernel
+    const uint32_t row_bytes = 257 * 16;
+    p->tcode.resize(p->bcode.size());
+    for (size_t i = 0; i < p->bcode.size(); i++) {
+        const BoundInstr &b = p->bcode[i];
+        BoundInstr t = b;
+        t.bop = (uint32_t)(table[b.bop] - base);
+        if (b.bop != BOP_GEN_PARAM) {
+            const uint32_t row = b.arg & 0xFFFFFFu, aux = b.arg >> 24;
+            t.arg = (row * row_bytes) | (aux << 24);
+            if (b.bop == BOP_TERN) t.lo = (b.lo - row) * row_bytes; // byte distance row B -> row C (mod 2^32)
+        }
+        p->tcode[i] = t;
+    }
+    p->handler_base = base;
+    p->param_handler_off = (uint32_t)(table[BOP_GEN_PARAM] - base);
+    p->threaded = true;
+    return DE_OK;
+}
+
 static void recompute_host_ok(de_program *p) {
     const bool ee = (p->options & DE_OPT_EARLY_EXIT) != 0;
     for (int64_t t = 0; t < p->n_trees; t++) {
@@ -342,6 +378,11 @@ int de_program_create(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, con
         return fail(ctx, DE_ERR_HIP, "out of host memory");
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        int rc = DE_OK;
+        try { rc = make_threaded(ctx, p.get()); } catch (const std::bad_alloc &) { rc = fail(ctx, DE_ERR_HIP, "out of host memory"); }
+        if (rc != DE_OK) return rc;
+    }
     // one trailing pad instruction: the interpreter prefetches code[pc + 1]
     const size_t cbytes = (p->bcode.size() + 1) * sizeof(BoundInstr);
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->d_code), cbytes));
@@ -352,7 +393,8 @@ int de_program_create(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, con
         return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(st));
     }
     if (!p->bcode.empty())
-        st = hipMemcpy(p->d_code, p->bcode.data(), p->bcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice);
+        st = hipMemcpy(p->d_code, (p->threaded ? p->tcode : p->bcode).data(), p->bcode.size() * sizeof(BoundInstr),
+                       hipMemcpyHostToDevice);
     if (st == hipSuccess)
         st = hipMemcpy(p->d_code_off, p->bcode_off.data(), p->bcode_off.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     if (st != hipSuccess) {
@@ -382,10 +424,16 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
         return fail(ctx, DE_ERR_HIP, "out of host memory");
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (p->threaded) {
+        int rc = DE_OK;
+        try { rc = make_threaded(ctx, p); } catch (const std::bad_alloc &) { rc = fail(ctx, DE_ERR_HIP, "out of host memory"); }
+        if (rc != DE_OK) return rc;
+    }
     // the program may be in use by work already queued on the stream
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!p->bcode.empty())
-        HIP_TRY(ctx, hipMemcpy(p->d_code, p->bcode.data(), p->bcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(p->d_code, (p->threaded ? p->tcode : p->bcode).data(),
+                               p->bcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
     return DE_OK;
 }
 
@@ -586,6 +634,9 @@ int de_eval(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX,
         a.class_base = pa->class_base;
     }
     a.early_exit = (p->options & DE_OPT_EARLY_EXIT) != 0;
+    a.threaded = p->threaded;
+    a.handler_base = p->handler_base;
+    a.param_handler_off = p->param_handler_off;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, launch_eval(p->dtype, a, c->stream, &c->last_kernel));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));

@@ -33,6 +33,11 @@ struct EvalArgs {
     int32_t classes_is_i64, class_base;
     // flags
     bool early_exit;
+    // threaded-code variant: `code` holds handler OFFSETS (relative to handler_base) in word 0 and
+    // LDS byte offsets in the low 24 bits of word 1
+    bool threaded;
+    uint64_t handler_base;
+    uint32_t param_handler_off;
 };
 
 struct GradArgs {
@@ -51,6 +56,10 @@ struct GradArgs {
 // name of the launched kernel (for matching rocprofv3 kernel-trace rows).
 hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const char **kernel_name);
 hipError_t launch_grad(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name);
+
+// Threaded-code eval kernel: addresses of the BOP_COUNT device handlers (cached per process).
+hipError_t eval_handler_table(int dtype, uint64_t *table);
+bool eval_uses_threaded();
 
 // Launch plan of the eval kernel for (n_trees, N): samples per workgroup tile, tree chunks.
 void eval_plan(int dtype, int64_t n_trees, int64_t N, int32_t *tile, int32_t *n_chunks, int32_t *trees_per_chunk);

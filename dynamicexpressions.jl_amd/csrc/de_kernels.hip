@@ -426,6 +426,213 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
     }
 }
 
+// ===========================================================================
+// Threaded-code variant: every bound handler is its own function and the interpreter loop is
+// {prefetch, handler address = base + offset, s_swappc}.  The flat switch above costs ~37
+// scalar+branch instructions per interpreted instruction (LLVM lowers a switch to a compare
+// tree and then structurizes it); an indirect call costs ~20, and each handler is compiled
+// as clean straight-line code.  Handler addresses are taken on the device
+// (de_fill_handlers), read back once per process, and bound into the instruction stream as
+// 32-bit offsets by the host (de_api.cpp).  G = 1, 256 threads per workgroup.
+template <typename T> struct HState {
+    typename VecOf<T>::type acc;
+    T poison;
+};
+#define HARGS HState<T> st, uint32_t la, uint32_t lo, uint32_t hi, uint32_t aux
+#define LDSP(T, addr) (reinterpret_cast<__attribute__((address_space(3))) typename VecOf<T>::type *>((uintptr_t)(addr)))
+template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, uint32_t, uint32_t, uint32_t);
+
+template <typename T> __device__ __forceinline__ void hpoison(T &poison, const typename VecOf<T>::type &v) {
+    DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) poison = M<T>::fma(v[i], T(0), poison);
+}
+template <typename T> __device__ __noinline__ HState<T> h_load_row(HARGS) { st.acc = *LDSP(T, la); return st; }
+template <typename T> __device__ __noinline__ HState<T> h_load_const(HARGS) {
+    const T c = imm_of<T>(lo, hi);
+    DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = c;
+    return st;
+}
+template <typename T> __device__ __noinline__ HState<T> h_push(HARGS) { *LDSP(T, la) = st.acc; return st; }
+template <typename T> __device__ __noinline__ HState<T> h_check_row(HARGS) {
+    const typename VecOf<T>::type v = *LDSP(T, la);
+    hpoison<T>(st.poison, v);
+    return st;
+}
+template <typename T> __device__ __noinline__ HState<T> h_check_acc(HARGS) { hpoison<T>(st.poison, st.acc); return st; }
+
+// K: 0 ADD 1 SUB 2 RSUB 3 MUL 4 DIV 5 RDIV;  VAR bit0 = validity-test the result, bit1 = constant operand
+template <typename T, int K, int VAR> __device__ __noinline__ HState<T> h_bin(HARGS) {
+    typedef typename VecOf<T>::type V;
+    V b;
+    if constexpr (VAR & 2) { const T c = imm_of<T>(lo, hi); DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) b[i] = c; }
+    else b = *LDSP(T, la);
+    if constexpr (K == 0) st.acc = st.acc + b;
+    else if constexpr (K == 1) st.acc = st.acc - b;
+    else if constexpr (K == 2) st.acc = b - st.acc;
+    else if constexpr (K == 3) st.acc = st.acc * b;
+    else if constexpr (K == 4) st.acc = st.acc / b;
+    else st.acc = b / st.acc;
+    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
+    return st;
+}
+// K: 0 COS 1 EXP 2 SIN;  VAR bit0 = test the result, bit1 = operand is an LDS row (else acc)
+template <typename T, int K, int VAR> __device__ __noinline__ HState<T> h_un(HARGS) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VW = VecOf<T>::W;
+    V x = st.acc;
+    if constexpr (VAR & 2) x = *LDSP(T, la);
+    V r;
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (K == 1) { DE_UNROLL for (int i = 0; i < VW; i++) r[i] = fast_exp_f32(x[i]); }
+        else {
+            bool big = false;
+            DE_UNROLL for (int i = 0; i < VW; i++) { r[i] = fast_trig_f32<K == 2>(x[i]); big |= fabsf(x[i]) > DE_TRIG_FAST_BOUND; }
+            if (__ballot(big) != 0ull) {
+                DE_UNROLL for (int i = 0; i < VW; i++)
+                    if (fabsf(x[i]) > DE_TRIG_FAST_BOUND) r[i] = K == 2 ? sinf(x[i]) : cosf(x[i]);
+            }
+        }
+    } else {
+        DE_UNROLL for (int i = 0; i < VW; i++) r[i] = K == 0 ? M<T>::cos(x[i]) : (K == 1 ? M<T>::exp(x[i]) : M<T>::sin(x[i]));
+    }
+    st.acc = r;
+    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
+    return st;
+}
+// generic handlers: de_opcode in aux.  SRC: 0 row, 1 const, 2 acc.  INJ: Inf-injection of the fused deg1 kernels.
+template <typename T, int SRC, bool INJ> __device__ __noinline__ HState<T> h_gen(HARGS) {
+    typedef typename VecOf<T>::type V;
+    VG<T, 1> a, b;
+    a.v[0] = st.acc;
+    if constexpr (SRC == 0) b.v[0] = *LDSP(T, la);
+    else if constexpr (SRC == 1) { const T c = imm_of<T>(lo, hi); DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) b.v[0][i] = c; }
+    else b.v[0] = st.acc;
+    const V in = b.v[0];
+    a = cold_op<T, 1>(aux, a, b);
+    st.acc = a.v[0];
+    if constexpr (INJ) { DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = M<T>::isfinite(in[i]) ? st.acc[i] : M<T>::inf(); }
+    return st;
+}
+template <typename T> __device__ __noinline__ HState<T> h_tern(HARGS) { // acc = op3(row la, row lo, acc)
+    VG<T, 1> a, b, c;
+    a.v[0] = st.acc;
+    b.v[0] = *LDSP(T, la);
+    c.v[0] = *LDSP(T, la + lo); // lo = byte distance from row B to row C
+    a = cold_op3<T, 1>(aux, a, b, c);
+    st.acc = a.v[0];
+    return st;
+}
+template <typename T> __device__ __noinline__ HState<T> h_nop(HARGS) { return st; }
+
+template <typename T> __global__ void de_fill_handlers(uint64_t *t) {
+#define HB(K) t[BOP_BIN_BASE + 4 * K + 0] = (uint64_t)&h_bin<T, K, 0>; t[BOP_BIN_BASE + 4 * K + 1] = (uint64_t)&h_bin<T, K, 1>; \
+              t[BOP_BIN_BASE + 4 * K + 2] = (uint64_t)&h_bin<T, K, 2>; t[BOP_BIN_BASE + 4 * K + 3] = (uint64_t)&h_bin<T, K, 3>;
+#define HU(K) t[BOP_UN_BASE + 4 * K + 0] = (uint64_t)&h_un<T, K, 0>; t[BOP_UN_BASE + 4 * K + 1] = (uint64_t)&h_un<T, K, 1>; \
+              t[BOP_UN_BASE + 4 * K + 2] = (uint64_t)&h_un<T, K, 2>; t[BOP_UN_BASE + 4 * K + 3] = (uint64_t)&h_un<T, K, 3>;
+    t[BOP_LOAD_ROW] = (uint64_t)&h_load_row<T>;
+    t[BOP_LOAD_CONST] = (uint64_t)&h_load_const<T>;
+    t[BOP_PUSH] = (uint64_t)&h_push<T>;
+    t[BOP_CHECK_ROW] = (uint64_t)&h_check_row<T>;
+    t[BOP_CHECK_ACC] = (uint64_t)&h_check_acc<T>;
+    HB(0) HB(1) HB(2) HB(3) HB(4) HB(5)
+    HU(0) HU(1) HU(2)
+    t[BOP_GEN_ROW] = (uint64_t)&h_gen<T, 0, false>;
+    t[BOP_GEN_CONST] = (uint64_t)&h_gen<T, 1, false>;
+    t[BOP_GEN_ACC] = (uint64_t)&h_gen<T, 2, false>;
+    t[BOP_GEN_PARAM] = (uint64_t)&h_nop<T>; // parameter operands are resolved in the interpreter loop
+    t[BOP_TERN] = (uint64_t)&h_tern<T>;
+    t[BOP_INJ_ACC] = (uint64_t)&h_gen<T, 2, true>;
+    t[BOP_INJ_ROW] = (uint64_t)&h_gen<T, 0, true>;
+#undef HB
+#undef HU
+}
+
+template <typename T, bool PARAMS>
+__global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a, const uint64_t hbase, const uint32_t param_off) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VW = VecOf<T>::W;
+    constexpr int BLK = 256, TILE = BLK * VW, ROWV = BLK + 1;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T *__restrict__ rows = reinterpret_cast<T *>(smem_raw);
+
+    const TileMap tm = map_block(blockIdx.x, a.n_chunks, a.n_tiles);
+    if (!tm.valid) return;
+    const int tid = threadIdx.x;
+    const int64_t base = tm.tile * TILE;
+    const int64_t last = a.N - 1;
+    {
+        const uint32_t F = (uint32_t)a.F;
+        const uint32_t total = (uint32_t)TILE * F;
+        if (a.ldX == (int64_t)F && base + TILE <= a.N) {
+            const T *__restrict__ src = a.X + base * (int64_t)F;
+            for (uint32_t e = tid; e < total; e += BLK) {
+                const uint32_t j = e / F, f = e - j * F;
+                rows[f * (ROWV * VW) + j] = src[e];
+            }
+        } else {
+            for (uint32_t e = tid; e < total; e += BLK) {
+                const uint32_t j = e / F, f = e - j * F;
+                int64_t jj = base + j;
+                jj = jj < last ? jj : last;
+                rows[f * (ROWV * VW) + j] = a.X[f + a.ldX * jj];
+            }
+        }
+    }
+    int64_t cls[VW];
+    if (PARAMS) {
+        DE_UNROLL for (int i = 0; i < VW; i++) {
+            int64_t jj = base + tid * VW + i;
+            jj = jj < last ? jj : last;
+            cls[i] = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
+                                       : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base;
+        }
+    }
+    __syncthreads();
+
+    const ConstU4Ptr code = (ConstU4Ptr)(uintptr_t)a.code;
+    const ConstI32Ptr code_off = (ConstI32Ptr)(uintptr_t)a.code_off;
+    const int t0 = tm.chunk * a.trees_per_chunk;
+    const int t1 = (t0 + a.trees_per_chunk < a.n_trees) ? t0 + a.trees_per_chunk : a.n_trees;
+    const bool full = base + TILE <= a.N;
+    // LDS byte address of this thread's vector in row 0 (the dynamic LDS segment starts at 0)
+    // (the low 32 bits of a flat pointer into LDS are the LDS byte offset)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw + tid * 16;
+
+    int pe = code_off[t0];
+    for (int tree = t0; tree < t1; ++tree) {
+        int pc = pe;
+        pe = code_off[tree + 1];
+        HState<T> st;
+        DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
+        st.poison = T(0);
+        U32x4 nxt = code[pc];
+        for (; pc < pe; ++pc) {
+            const U32x4 w = nxt;
+            nxt = code[pc + 1];
+            if (PARAMS && w.x == param_off) { // operand = params[row, class]: needs kernel arguments
+                const uint32_t op = w.y >> 24;
+                VG<T, 1> av, bv;
+                const T *__restrict__ s_ = a.params + (w.y & 0xFFFFu);
+                DE_UNROLL for (int i = 0; i < VW; i++) bv.v[0][i] = s_[a.ld_params * cls[i]];
+                if (w.y & (1u << 23)) hpoison<T>(st.poison, bv.v[0]);
+                if (op == DOP_LOAD) st.acc = bv.v[0];
+                else { av.v[0] = st.acc; av = cold_op<T, 1>(op, av, bv); st.acc = av.v[0]; }
+                continue;
+            }
+            const HandlerFn<T> fn = reinterpret_cast<HandlerFn<T>>(hbase + w.x);
+            st = fn(st, lds0 + (w.y & 0xFFFFFFu), w.z, w.w, w.y >> 24);
+        }
+        T *__restrict__ o = a.out + (int64_t)tree * a.ld_out + base + tid * VW;
+        if (full && a.vec_store) {
+            *reinterpret_cast<V *>(o) = st.acc;
+        } else {
+            VG<T, 1> av;
+            av.v[0] = st.acc;
+            store_ragged<T, 1>(o, av, a.N - (base + tid * VW), TILE);
+        }
+        if (__ballot(st.poison != st.poison) != 0ull) flag_incomplete(a.ok + tree);
+    }
+}
+
 // ---------------------------------------------------------------------------
 static int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
@@ -535,7 +742,75 @@ static hipError_t launch_eval_geo(const EvalArgs &a, hipStream_t stream, const c
     return BLK == 128 ? launch_eval_t<T, 1, 128>(a, stream, kn) : launch_eval_t<T, 1, 256>(a, stream, kn);
 }
 
+// ---- threaded variant: handler table + launch ---------------------------------------------
+template <typename T> static hipError_t fetch_handlers(uint64_t *host_table) {
+    uint64_t *d = nullptr;
+    hipError_t st = hipMalloc(reinterpret_cast<void **>(&d), BOP_COUNT * sizeof(uint64_t));
+    if (st != hipSuccess) return st;
+    hipLaunchKernelGGL(de_fill_handlers<T>, dim3(1), dim3(1), 0, 0, d);
+    st = hipMemcpy(host_table, d, BOP_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return st;
+}
+
+hipError_t eval_handler_table(int dtype, uint64_t *table) {
+    static uint64_t cache[2][BOP_COUNT];
+    static bool have[2] = {false, false};
+    const int k = dtype == DE_F32 ? 0 : 1;
+    if (!have[k]) {
+        hipError_t st = k == 0 ? fetch_handlers<float>(cache[k]) : fetch_handlers<double>(cache[k]);
+        if (st != hipSuccess) return st;
+        have[k] = true;
+    }
+    for (int i = 0; i < (int)BOP_COUNT; i++) table[i] = cache[k][i];
+    return hipSuccess;
+}
+
+bool eval_uses_threaded() { return env_int("DE_EVAL_THREADED", 1) != 0 && env_int("DE_EVAL_G", 1) == 1 && env_int("DE_EVAL_BLOCK", 256) == 256; }
+
+template <typename T>
+static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const char **kname) {
+    constexpr int VW = VecOf<T>::W;
+    constexpr int TILE = 256 * VW;
+    KArgs<T> a;
+    a.code = e.code;
+    a.code_off = e.code_off;
+    a.X = static_cast<const T *>(e.X);
+    a.out = static_cast<T *>(e.out);
+    a.ok = e.ok;
+    a.params = static_cast<const T *>(e.params);
+    a.classes = e.classes;
+    a.N = e.N;
+    a.ldX = e.ldX;
+    a.ld_out = e.ld_out;
+    a.ld_params = e.ld_params;
+    a.n_tiles = (e.N + TILE - 1) / TILE;
+    a.F = e.F;
+    a.n_trees = e.n_trees;
+    a.n_slots = e.n_slots;
+    a.xstride = 0;
+    a.classes_is_i64 = e.classes_is_i64;
+    a.class_base = e.class_base;
+    a.vec_store = (reinterpret_cast<uintptr_t>(e.out) % 16 == 0 && (e.ld_out * sizeof(T)) % 16 == 0) ? 1 : 0;
+    int32_t tpc, nch;
+    plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc);
+    a.trees_per_chunk = tpc;
+    a.n_chunks = nch;
+    const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(a.F + a.n_slots) * 257 * 16;
+    void (*kern)(const KArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_eval_threaded_kernel<T, true> : de_eval_threaded_kernel<T, false>;
+    if (kname) *kname = "de_eval_threaded_kernel";
+    if (lds > 64 * 1024) {
+        hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (st != hipSuccess) return st;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a, e.handler_base, e.param_handler_off);
+    return hipGetLastError();
+}
+
 hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const char **kernel_name) {
+    if (a.threaded) return dtype == DE_F32 ? launch_threaded_t<float>(a, stream, kernel_name) : launch_threaded_t<double>(a, stream, kernel_name);
     int G, BLK;
     eval_geometry(dtype, &G, &BLK);
     if (dtype == DE_F32) return launch_eval_geo<float>(a, stream, kernel_name, G, BLK);
