@@ -266,9 +266,8 @@ static int make_threaded(de_ctx *c, de_program *p) {
     uint64_t table[BOP_COUNT];
     hipError_t st = eval_handler_table(p->dtype, table);
     if (st != hipSuccess) return fail(c, DE_ERR_HIP, "handler table: %s", hipGetErrorString(st));
-    // table[i] = handler address | call class (low two bits; code is at least 4-byte aligned)
-    uint64_t base = table[0] & ~3ull;
-    for (int i = 0; i < (int)BOP_COUNT; i++) base = std::min<uint64_t>(base, table[i] & ~3ull);
+    uint64_t base = table[0];
+    for (int i = 0; i < (int)BOP_COUNT; i++) base = std::min<uint64_t>(base, table[i]);
     for (int i = 0; i < (int)BOP_COUNT; i++)
         if (table[i] - base > 0xFFFFFFFFull) return DE_OK; // cannot encode: keep the switch kernel
     const uint32_t row_bytes = 257 * 16;

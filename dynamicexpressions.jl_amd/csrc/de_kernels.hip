@@ -438,60 +438,62 @@ template <typename T> struct HState {
     typename VecOf<T>::type acc;
     T poison;
 };
-// Four call classes (low two bits of the bound handler offset) so that a call marshals only
-// what its handler reads — argument moves are VALU instructions and the kernel is VALU-bound:
-//   0 ROW  : (st, la)        la = LDS byte address of this thread's vector of the operand row
-//   1 CONST: (st, c)         c  = the immediate
-//   2 ACC  : (st)
-//   3 GEN  : (st, la, lo, hi, aux)   generic / cold handlers (de_opcode in aux)
-enum : uint32_t { HC_ROW = 0, HC_CONST = 1, HC_ACC = 2, HC_GEN = 3 };
+// ONE call signature for every handler (several call sites with different signatures make the
+// compiler shuffle the returned state through a dozen v_movs per call):
+//   st  : accumulator + validity poison, in and out, stays in v0..v4 across calls
+//   la  : (LDS byte address of this thread's vector of the operand row) | aux << 24, aux = the
+//         de_opcode for the generic handlers and 0 for the hot ones (which use `la` unmasked)
+//   imm : the immediate's bits (uint32 for Float32, uint64 for Float64); for BOP_TERN the byte
+//         distance from operand row B to row C
+// = 2 VALU argument moves per call for Float32.
+template <typename T> struct ImmBits;
+template <> struct ImmBits<float> { typedef uint32_t type; };
+template <> struct ImmBits<double> { typedef uint64_t type; };
+template <typename T> __device__ __forceinline__ T imm_from(typename ImmBits<T>::type b);
+template <> __device__ __forceinline__ float imm_from<float>(uint32_t b) { return __uint_as_float(b); }
+template <> __device__ __forceinline__ double imm_from<double>(uint64_t b) { return __longlong_as_double((long long)b); }
+#define HARGS HState<T> st, uint32_t la, typename ImmBits<T>::type imm
 #define LDSP(T, addr) (reinterpret_cast<__attribute__((address_space(3))) typename VecOf<T>::type *>((uintptr_t)(addr)))
-template <typename T> using HRowFn = HState<T> (*)(HState<T>, uint32_t);
-template <typename T> using HConstFn = HState<T> (*)(HState<T>, T);
-template <typename T> using HAccFn = HState<T> (*)(HState<T>);
-template <typename T> using HGenFn = HState<T> (*)(HState<T>, uint32_t, uint32_t, uint32_t, uint32_t);
+template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, typename ImmBits<T>::type);
 
 template <typename T> __device__ __forceinline__ void hpoison(T &poison, const typename VecOf<T>::type &v) {
     DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) poison = M<T>::fma(v[i], T(0), poison);
 }
-template <typename T> __device__ __noinline__ HState<T> h_load_row(HState<T> st, uint32_t la) { st.acc = *LDSP(T, la); return st; }
-template <typename T> __device__ __noinline__ HState<T> h_load_const(HState<T> st, T c) {
+template <typename T> __device__ __noinline__ HState<T> h_load_row(HARGS) { st.acc = *LDSP(T, la); return st; }
+template <typename T> __device__ __noinline__ HState<T> h_load_const(HARGS) {
+    const T c = imm_from<T>(imm);
     DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = c;
     return st;
 }
-template <typename T> __device__ __noinline__ HState<T> h_push(HState<T> st, uint32_t la) { *LDSP(T, la) = st.acc; return st; }
-template <typename T> __device__ __noinline__ HState<T> h_check_row(HState<T> st, uint32_t la) {
+template <typename T> __device__ __noinline__ HState<T> h_push(HARGS) { *LDSP(T, la) = st.acc; return st; }
+template <typename T> __device__ __noinline__ HState<T> h_check_row(HARGS) {
     const typename VecOf<T>::type v = *LDSP(T, la);
     hpoison<T>(st.poison, v);
     return st;
 }
-template <typename T> __device__ __noinline__ HState<T> h_check_acc(HState<T> st) { hpoison<T>(st.poison, st.acc); return st; }
+template <typename T> __device__ __noinline__ HState<T> h_check_acc(HARGS) { hpoison<T>(st.poison, st.acc); return st; }
 
-// K: 0 ADD 1 SUB 2 RSUB 3 MUL 4 DIV 5 RDIV;  CHK = validity-test the result
-template <typename T, int K, bool CHK>
-__device__ __forceinline__ HState<T> bin_body(HState<T> st, const typename VecOf<T>::type b) {
+// K: 0 ADD 1 SUB 2 RSUB 3 MUL 4 DIV 5 RDIV;  VAR bit0 = validity-test the result, bit1 = constant operand
+template <typename T, int K, int VAR> __device__ __noinline__ HState<T> h_bin(HARGS) {
+    typedef typename VecOf<T>::type V;
+    V b;
+    if constexpr (VAR & 2) { const T c = imm_from<T>(imm); DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) b[i] = c; }
+    else b = *LDSP(T, la);
     if constexpr (K == 0) st.acc = st.acc + b;
     else if constexpr (K == 1) st.acc = st.acc - b;
     else if constexpr (K == 2) st.acc = b - st.acc;
     else if constexpr (K == 3) st.acc = st.acc * b;
     else if constexpr (K == 4) st.acc = st.acc / b;
     else st.acc = b / st.acc;
-    if constexpr (CHK) hpoison<T>(st.poison, st.acc);
+    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
     return st;
 }
-template <typename T, int K, bool CHK> __device__ __noinline__ HState<T> h_bin_row(HState<T> st, uint32_t la) {
-    return bin_body<T, K, CHK>(st, *LDSP(T, la));
-}
-template <typename T, int K, bool CHK> __device__ __noinline__ HState<T> h_bin_const(HState<T> st, T c) {
-    typename VecOf<T>::type b;
-    DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) b[i] = c;
-    return bin_body<T, K, CHK>(st, b);
-}
-// K: 0 COS 1 EXP 2 SIN
-template <typename T, int K, bool CHK>
-__device__ __forceinline__ HState<T> un_body(HState<T> st, const typename VecOf<T>::type x) {
+// K: 0 COS 1 EXP 2 SIN;  VAR bit0 = test the result, bit1 = operand is an LDS row (else acc)
+template <typename T, int K, int VAR> __device__ __noinline__ HState<T> h_un(HARGS) {
     typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
+    V x = st.acc;
+    if constexpr (VAR & 2) x = *LDSP(T, la);
     V r;
     if constexpr (sizeof(T) == 4) {
         if constexpr (K == 1) { DE_UNROLL for (int i = 0; i < VW; i++) r[i] = fast_exp_f32(x[i]); }
@@ -507,21 +509,17 @@ __device__ __forceinline__ HState<T> un_body(HState<T> st, const typename VecOf<
         DE_UNROLL for (int i = 0; i < VW; i++) r[i] = K == 0 ? M<T>::cos(x[i]) : (K == 1 ? M<T>::exp(x[i]) : M<T>::sin(x[i]));
     }
     st.acc = r;
-    if constexpr (CHK) hpoison<T>(st.poison, st.acc);
+    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
     return st;
 }
-template <typename T, int K, bool CHK> __device__ __noinline__ HState<T> h_un_acc(HState<T> st) { return un_body<T, K, CHK>(st, st.acc); }
-template <typename T, int K, bool CHK> __device__ __noinline__ HState<T> h_un_row(HState<T> st, uint32_t la) {
-    return un_body<T, K, CHK>(st, *LDSP(T, la));
-}
-// generic handlers: de_opcode in aux.  SRC: 0 row, 1 const, 2 acc.  INJ: Inf-injection of the fused deg1 kernels.
-template <typename T, int SRC, bool INJ>
-__device__ __noinline__ HState<T> h_gen(HState<T> st, uint32_t la, uint32_t lo, uint32_t hi, uint32_t aux) {
+// generic handlers: de_opcode in la[31:24].  SRC: 0 row, 1 const, 2 acc.  INJ: Inf-injection of the fused deg1 kernels.
+template <typename T, int SRC, bool INJ> __device__ __noinline__ HState<T> h_gen(HARGS) {
     typedef typename VecOf<T>::type V;
+    const uint32_t aux = la >> 24;
     VG<T, 1> a, b;
     a.v[0] = st.acc;
-    if constexpr (SRC == 0) b.v[0] = *LDSP(T, la);
-    else if constexpr (SRC == 1) { const T c = imm_of<T>(lo, hi); DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) b.v[0][i] = c; }
+    if constexpr (SRC == 0) b.v[0] = *LDSP(T, la & 0xFFFFFFu);
+    else if constexpr (SRC == 1) { const T c = imm_from<T>(imm); DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) b.v[0][i] = c; }
     else b.v[0] = st.acc;
     const V in = b.v[0];
     a = cold_op<T, 1>(aux, a, b);
@@ -529,41 +527,39 @@ __device__ __noinline__ HState<T> h_gen(HState<T> st, uint32_t la, uint32_t lo, 
     if constexpr (INJ) { DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = M<T>::isfinite(in[i]) ? st.acc[i] : M<T>::inf(); }
     return st;
 }
-template <typename T>
-__device__ __noinline__ HState<T> h_tern(HState<T> st, uint32_t la, uint32_t lo, uint32_t hi, uint32_t aux) { // acc = op3(row la, row la+lo, acc)
+template <typename T> __device__ __noinline__ HState<T> h_tern(HARGS) { // acc = op3(row B, row C, acc)
+    const uint32_t aux = la >> 24, lb = la & 0xFFFFFFu;
     VG<T, 1> a, b, c;
     a.v[0] = st.acc;
-    b.v[0] = *LDSP(T, la);
-    c.v[0] = *LDSP(T, la + lo); // lo = byte distance from row B to row C
+    b.v[0] = *LDSP(T, lb);
+    c.v[0] = *LDSP(T, lb + (uint32_t)imm); // imm = byte distance from row B to row C
     a = cold_op3<T, 1>(aux, a, b, c);
     st.acc = a.v[0];
     return st;
 }
-template <typename T> __device__ __noinline__ HState<T> h_nop(HState<T> st) { return st; }
+template <typename T> __device__ __noinline__ HState<T> h_nop(HARGS) { return st; }
 
 template <typename T> __global__ void de_fill_handlers(uint64_t *t) {
-#define ADDR(f, cls) ((uint64_t)(f) | (uint64_t)(cls))
-#define HB(K) t[BOP_BIN_BASE + 4 * K + 0] = ADDR((&h_bin_row<T, K, false>), HC_ROW); t[BOP_BIN_BASE + 4 * K + 1] = ADDR((&h_bin_row<T, K, true>), HC_ROW); \
-              t[BOP_BIN_BASE + 4 * K + 2] = ADDR((&h_bin_const<T, K, false>), HC_CONST); t[BOP_BIN_BASE + 4 * K + 3] = ADDR((&h_bin_const<T, K, true>), HC_CONST);
-#define HU(K) t[BOP_UN_BASE + 4 * K + 0] = ADDR((&h_un_acc<T, K, false>), HC_ACC); t[BOP_UN_BASE + 4 * K + 1] = ADDR((&h_un_acc<T, K, true>), HC_ACC); \
-              t[BOP_UN_BASE + 4 * K + 2] = ADDR((&h_un_row<T, K, false>), HC_ROW); t[BOP_UN_BASE + 4 * K + 3] = ADDR((&h_un_row<T, K, true>), HC_ROW);
-    t[BOP_LOAD_ROW] = ADDR(&h_load_row<T>, HC_ROW);
-    t[BOP_LOAD_CONST] = ADDR(&h_load_const<T>, HC_CONST);
-    t[BOP_PUSH] = ADDR(&h_push<T>, HC_ROW);
-    t[BOP_CHECK_ROW] = ADDR(&h_check_row<T>, HC_ROW);
-    t[BOP_CHECK_ACC] = ADDR(&h_check_acc<T>, HC_ACC);
+#define HB(K) t[BOP_BIN_BASE + 4 * K + 0] = (uint64_t)&h_bin<T, K, 0>; t[BOP_BIN_BASE + 4 * K + 1] = (uint64_t)&h_bin<T, K, 1>; \
+              t[BOP_BIN_BASE + 4 * K + 2] = (uint64_t)&h_bin<T, K, 2>; t[BOP_BIN_BASE + 4 * K + 3] = (uint64_t)&h_bin<T, K, 3>;
+#define HU(K) t[BOP_UN_BASE + 4 * K + 0] = (uint64_t)&h_un<T, K, 0>; t[BOP_UN_BASE + 4 * K + 1] = (uint64_t)&h_un<T, K, 1>; \
+              t[BOP_UN_BASE + 4 * K + 2] = (uint64_t)&h_un<T, K, 2>; t[BOP_UN_BASE + 4 * K + 3] = (uint64_t)&h_un<T, K, 3>;
+    t[BOP_LOAD_ROW] = (uint64_t)&h_load_row<T>;
+    t[BOP_LOAD_CONST] = (uint64_t)&h_load_const<T>;
+    t[BOP_PUSH] = (uint64_t)&h_push<T>;
+    t[BOP_CHECK_ROW] = (uint64_t)&h_check_row<T>;
+    t[BOP_CHECK_ACC] = (uint64_t)&h_check_acc<T>;
     HB(0) HB(1) HB(2) HB(3) HB(4) HB(5)
     HU(0) HU(1) HU(2)
-    t[BOP_GEN_ROW] = ADDR((&h_gen<T, 0, false>), HC_GEN);
-    t[BOP_GEN_CONST] = ADDR((&h_gen<T, 1, false>), HC_GEN);
-    t[BOP_GEN_ACC] = ADDR((&h_gen<T, 2, false>), HC_GEN);
-    t[BOP_GEN_PARAM] = ADDR(&h_nop<T>, HC_ACC); // parameter operands are resolved in the interpreter loop
-    t[BOP_TERN] = ADDR(&h_tern<T>, HC_GEN);
-    t[BOP_INJ_ACC] = ADDR((&h_gen<T, 2, true>), HC_GEN);
-    t[BOP_INJ_ROW] = ADDR((&h_gen<T, 0, true>), HC_GEN);
+    t[BOP_GEN_ROW] = (uint64_t)&h_gen<T, 0, false>;
+    t[BOP_GEN_CONST] = (uint64_t)&h_gen<T, 1, false>;
+    t[BOP_GEN_ACC] = (uint64_t)&h_gen<T, 2, false>;
+    t[BOP_GEN_PARAM] = (uint64_t)&h_nop<T>; // parameter operands are resolved in the interpreter loop
+    t[BOP_TERN] = (uint64_t)&h_tern<T>;
+    t[BOP_INJ_ACC] = (uint64_t)&h_gen<T, 2, true>;
+    t[BOP_INJ_ROW] = (uint64_t)&h_gen<T, 0, true>;
 #undef HB
 #undef HU
-#undef ADDR
 }
 
 template <typename T, bool PARAMS>
@@ -638,12 +634,11 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
                 else { av.v[0] = st.acc; av = cold_op<T, 1>(op, av, bv); st.acc = av.v[0]; }
                 continue;
             }
-            const uint64_t fa = hbase + (w.x & ~3u);
-            const uint32_t cls_ = w.x & 3u;
-            if (cls_ == HC_ROW) st = reinterpret_cast<HRowFn<T>>(fa)(st, lds0 + (w.y & 0xFFFFFFu));
-            else if (cls_ == HC_CONST) st = reinterpret_cast<HConstFn<T>>(fa)(st, imm_of<T>(w.z, w.w));
-            else if (cls_ == HC_ACC) st = reinterpret_cast<HAccFn<T>>(fa)(st);
-            else st = reinterpret_cast<HGenFn<T>>(fa)(st, lds0 + (w.y & 0xFFFFFFu), w.z, w.w, w.y >> 24);
+            const HandlerFn<T> fn = reinterpret_cast<HandlerFn<T>>(hbase + w.x);
+            typename ImmBits<T>::type imm;
+            if constexpr (sizeof(T) == 4) imm = w.z;
+            else imm = ((uint64_t)w.w << 32) | w.z;
+            st = fn(st, lds0 + w.y, imm); // w.y = row byte offset | aux << 24 (no carry: LDS < 2^18 bytes)
         }
         T *__restrict__ o = a.out + (int64_t)tree * a.ld_out + base + tid * VW;
         if (full && a.vec_store) {
