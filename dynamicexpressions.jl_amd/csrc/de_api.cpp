@@ -65,7 +65,19 @@ struct de_program {
     std::vector<uint8_t> host_ok_eval;  // per tree: constant part of the eval flag
     std::vector<uint8_t> host_ok_grad;  // per tree: all constants finite
     std::vector<double> consts;         // current constants as double
-    std::vector<BoundInstr> bcode;      // bound form of `code` (handler ids)
+    // Constant folding on the device (LowerOptions.fold): the eval path runs `fcode`, in which every
+    // maximal constant subtree is one constant operand; the subtrees themselves form the `aux`
+    // population, evaluated once per constant update by the same kernels (N = 1).
+    bool folded = false;
+    std::vector<Instr> fcode;
+    std::vector<int32_t> fcode_off;
+    std::vector<int32_t> fconst_instr;  // per constant: index into fcode, or < 0 if folded away
+    struct Fold { int32_t tree, instr; };
+    std::vector<Fold> folds;            // aux tree j -> (owning tree, fcode instruction holding its value)
+    std::vector<int64_t> aux_const_src; // aux constant k = consts[aux_const_src[k]]
+    de_program *aux = nullptr;
+    std::vector<uint8_t> fold_ok;
+    std::vector<BoundInstr> bcode;      // bound form of the eval program (handler ids)
     std::vector<BoundInstr> tcode;      // threaded form: handler address offsets + LDS byte offsets
     bool threaded = false;
     uint64_t handler_base = 0;
@@ -250,9 +262,11 @@ static void rebind(de_program *p) {
     const bool ee = (p->options & DE_OPT_EARLY_EXIT) != 0;
     p->bcode.clear();
     p->bcode_off.assign((size_t)p->n_trees + 1, 0);
+    const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
+    const std::vector<int32_t> &off = p->folded ? p->fcode_off : p->code_off;
     for (int64_t t = 0; t < p->n_trees; t++) {
-        const int32_t i0 = p->code_off[(size_t)t], i1 = p->code_off[(size_t)t + 1];
-        bind_tree(p->code.data() + i0, (size_t)(i1 - i0), ee, p->n_features, &p->bcode);
+        const int32_t i0 = off[(size_t)t], i1 = off[(size_t)t + 1];
+        bind_tree(src.data() + i0, (size_t)(i1 - i0), ee, p->n_features, &p->bcode);
         p->bcode_off[(size_t)t + 1] = (int32_t)p->bcode.size();
     }
 }
@@ -302,11 +316,54 @@ static void recompute_host_ok(de_program *p) {
         p->host_ok_eval[t] = ok_eval;
         p->host_ok_grad[t] = ok_grad;
     }
+    // a constant subtree that evaluates to a non-finite value clears the flag — with the flag
+    // semantics of the program's own options (dispatch_constant_tree tests unconditionally,
+    // the Bumper path only under early_exit): that is exactly what `aux` was lowered with
+    for (size_t j = 0; j < p->folds.size() && j < p->fold_ok.size(); j++)
+        if (!p->fold_ok[j]) p->host_ok_eval[(size_t)p->folds[j].tree] = 0;
 }
+
+static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, const int64_t *node_offsets,
+                       int64_t n_trees, const void *consts, const int64_t *const_offsets, int32_t n_features,
+                       int32_t n_params, uint32_t options, bool allow_fold, de_program_t **out_program);
+
+// (Re-)evaluate the folded constant subtrees on the device and patch their values into fcode.
+static int refresh_folds(de_ctx *c, de_program *p) {
+    if (!p->folded) return DE_OK;
+    const size_t es = p->dtype == DE_F32 ? 4 : 8;
+    const size_t na = p->folds.size();
+    std::vector<unsigned char> ac(std::max<size_t>(p->aux_const_src.size(), 1) * es);
+    for (size_t k = 0; k < p->aux_const_src.size(); k++) {
+        const double v = p->consts[(size_t)p->aux_const_src[k]];
+        if (p->dtype == DE_F32) reinterpret_cast<float *>(ac.data())[k] = (float)v;
+        else reinterpret_cast<double *>(ac.data())[k] = v;
+    }
+    int rc = de_program_set_consts(p->aux, ac.data());
+    if (rc != DE_OK) return fail(c, rc, "constant folding: %s", p->aux->ctx->err.c_str());
+    std::vector<unsigned char> X(std::max<size_t>((size_t)p->n_features, 1) * es, 0), out(na * es);
+    p->fold_ok.assign(na, 0);
+    rc = de_eval(c, p->aux, X.data(), 1, std::max<int64_t>(p->n_features, 1), nullptr, out.data(), 1, p->fold_ok.data());
+    if (rc != DE_OK) return rc;
+    for (size_t j = 0; j < na; j++) {
+        const double v = p->dtype == DE_F32 ? (double)reinterpret_cast<float *>(out.data())[j]
+                                            : reinterpret_cast<double *>(out.data())[j];
+        write_imm(p->fcode[(size_t)p->folds[j].instr], p->dtype, v);
+    }
+    return DE_OK;
+}
+
 
 int de_program_create(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, const int64_t *node_offsets,
                       int64_t n_trees, const void *consts, const int64_t *const_offsets,
                       int32_t n_features, int32_t n_params, uint32_t options, de_program_t **out_program) {
+    const char *nf = getenv("DE_NO_FOLD");
+    return create_impl(ctx, dtype, nodes, node_offsets, n_trees, consts, const_offsets, n_features, n_params, options,
+                       !(nf && *nf == '1'), out_program);
+}
+
+static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, const int64_t *node_offsets,
+                       int64_t n_trees, const void *consts, const int64_t *const_offsets, int32_t n_features,
+                       int32_t n_params, uint32_t options, bool allow_fold, de_program_t **out_program) {
     if (!ctx) return DE_ERR_INVALID_ARG;
     if (!out_program) return fail(ctx, DE_ERR_INVALID_ARG, "out_program is null");
     *out_program = nullptr;
@@ -372,6 +429,60 @@ int de_program_create(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, con
             p->n_nodes += n1 - n0;
             if (p->code.size() > 0x7fff0000u) return fail(ctx, DE_ERR_UNSUPPORTED, "program too large");
         }
+        // ---- folded lowering of the eval program + the auxiliary population of constant subtrees
+        if (allow_fold) {
+            lo.fold = true;
+            std::vector<de_tape_node_t> anodes;
+            std::vector<int64_t> anoff{0}, acoff{0};
+            p->fcode_off.assign((size_t)n_trees + 1, 0);
+            p->fconst_instr.assign((size_t)total_consts, -1);
+            for (int64_t t = 0; t < n_trees; t++) {
+                const int64_t n0 = node_offsets[t], n1 = node_offsets[t + 1];
+                const int64_t c0 = const_offsets[t], c1 = const_offsets[t + 1];
+                int rc = lower_tree(nodes + n0, n1 - n0, c1 - c0, lo, &tp, &why);
+                if (rc != DE_OK) return fail(ctx, rc, "tree %lld (folded): %s", (long long)t, why.c_str());
+                const int64_t cb = c0 - const_offsets[0];
+                const int32_t ib = (int32_t)p->fcode.size();
+                for (int64_t k = 0; k < c1 - c0; k++) {
+                    const int32_t ci = tp.const_instr[(size_t)k];
+                    if (ci < 0) continue; // constant lives inside a folded subtree
+                    p->fconst_instr[(size_t)(cb + k)] = ib + ci;
+                    write_imm(tp.code[(size_t)ci], dtype, p->consts[(size_t)(cb + k)]);
+                }
+                for (size_t f = 0; f < tp.folds.size(); f++) {
+                    const FoldSpan &sp = tp.folds[f];
+                    p->folds.push_back({(int32_t)t, ib + tp.const_instr[(size_t)(c1 - c0) + f]});
+                    for (int32_t q = sp.node_begin; q < sp.node_end; q++) {
+                        de_tape_node_t nd = nodes[n0 + q];
+                        if (nd.degree == 0 && nd.op == DE_LEAF_CONST) nd.arg = (uint16_t)(nd.arg - sp.const_begin);
+                        anodes.push_back(nd);
+                    }
+                    for (int32_t q = sp.const_begin; q < sp.const_end; q++) p->aux_const_src.push_back(cb + q);
+                    anoff.push_back((int64_t)anodes.size());
+                    acoff.push_back((int64_t)p->aux_const_src.size());
+                }
+                p->fcode.insert(p->fcode.end(), tp.code.begin(), tp.code.end());
+                p->fcode_off[(size_t)t + 1] = (int32_t)p->fcode.size();
+            }
+            if (!p->folds.empty()) {
+                const size_t es = dtype == DE_F32 ? 4 : 8;
+                std::vector<unsigned char> ac(std::max<size_t>(p->aux_const_src.size(), 1) * es, 0);
+                for (size_t k = 0; k < p->aux_const_src.size(); k++) {
+                    const double v = p->consts[(size_t)p->aux_const_src[k]];
+                    if (dtype == DE_F32) reinterpret_cast<float *>(ac.data())[k] = (float)v;
+                    else reinterpret_cast<double *>(ac.data())[k] = v;
+                }
+                int rc = create_impl(ctx, dtype, anodes.data(), anoff.data(), (int64_t)p->folds.size(), ac.data(),
+                                     acoff.data(), n_features, 0, options, false, &p->aux);
+                if (rc != DE_OK) return rc;
+                p->folded = true;
+                rc = refresh_folds(ctx, p.get());
+                if (rc != DE_OK) return rc;
+            } else {
+                p->fcode.clear();
+                p->fcode_off.clear();
+            }
+        }
         recompute_host_ok(p.get());
         rebind(p.get());
     } catch (const std::bad_alloc &) {
@@ -415,6 +526,12 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
                                             : static_cast<const double *>(consts)[k];
         p->consts[k] = v;
         write_imm(p->code[(size_t)p->const_instr[k]], p->dtype, v);
+        if (p->folded && p->fconst_instr[k] >= 0) write_imm(p->fcode[(size_t)p->fconst_instr[k]], p->dtype, v);
+    }
+    if (p->folded) {
+        int rc = DE_OK;
+        try { rc = refresh_folds(ctx, p); } catch (const std::bad_alloc &) { rc = fail(ctx, DE_ERR_HIP, "out of host memory"); }
+        if (rc != DE_OK) return rc;
     }
     recompute_host_ok(p);
     p->gcode_stale = true;
@@ -443,6 +560,7 @@ int de_program_destroy(de_program_t *p) {
     (void)hipStreamSynchronize(p->ctx->stream);
     if (p->d_code) (void)hipFree(p->d_code);
     if (p->d_code_off) (void)hipFree(p->d_code_off);
+    if (p->aux) de_program_destroy(p->aux);
     if (p->d_gcode) (void)hipFree(p->d_gcode);
     if (p->d_gcode_off) (void)hipFree(p->d_gcode_off);
     delete p;

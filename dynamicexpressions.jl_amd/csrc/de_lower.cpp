@@ -28,6 +28,9 @@ struct LNode {
     bool chk_leaf = false;   // leaf whose array the reference validity-tests (early_exit)
     bool inject = false;     // outer op of a fused deg1 kernel
     bool constfold = false;  // inside a subtree evaluated by dispatch_constant_tree
+    int fold_slot = -1;      // >= 0: maximal constant subtree replaced by extended constant slot
+    int first = 0;           // index of the first tape node of this subtree (post-order slice [first, i])
+    int cfirst = 0, ccount = 0; // constant slots owned by the subtree
     int regs = 0;            // spill slots needed to evaluate into acc
 };
 
@@ -42,6 +45,8 @@ struct Lowerer {
     Lowerer(const LowerOptions &o, TreeProgram *p, std::string *e) : opt(o), out(p), err(e) {}
 
     bool is_leaf(int i) const { return nodes[i].degree == 0; }
+    // codegen view: a folded constant subtree is an operand, like a leaf
+    bool is_opnd(int i) const { return nodes[i].degree == 0 || nodes[i].fold_slot >= 0; }
     bool is_const_leaf(int i) const { return nodes[i].degree == 0 && nodes[i].op == DE_LEAF_CONST; }
     bool bin_of_leaves(int i) const {
         return nodes[i].degree == 2 && is_leaf(nodes[i].child[0]) && is_leaf(nodes[i].child[1]);
@@ -136,14 +141,15 @@ struct Lowerer {
     // ---- codegen ----------------------------------------------------------
     void compute_regs(int i) {
         LNode &n = nodes[i];
+        if (n.fold_slot >= 0) { n.regs = 0; return; }
         for (int k = 0; k < n.degree; k++) compute_regs(n.child[k]);
         if (n.degree == 0) n.regs = 0;
         else if (n.degree == 1) n.regs = nodes[n.child[0]].regs;
         else if (n.degree == 2) {
             int l = n.child[0], r = n.child[1];
-            if (is_leaf(l) && is_leaf(r)) n.regs = 0;
-            else if (is_leaf(l)) n.regs = nodes[r].regs;
-            else if (is_leaf(r)) n.regs = nodes[l].regs;
+            if (is_opnd(l) && is_opnd(r)) n.regs = 0;
+            else if (is_opnd(l)) n.regs = nodes[r].regs;
+            else if (is_opnd(r)) n.regs = nodes[l].regs;
             else {
                 int a = nodes[l].regs, b = nodes[r].regs;
                 n.regs = (a == b) ? a + 1 : std::max(a, b);
@@ -168,6 +174,11 @@ struct Lowerer {
     // Make leaf `li` the B operand of `ins`.
     void set_leaf_operand(Instr &ins, int li) {
         const LNode &lf = nodes[li];
+        if (lf.fold_slot >= 0) { // folded constant subtree: extended constant slot, value patched by the caller
+            ins.hdr |= SRC_CONST << H_SRC_SHIFT;
+            ins.feat = (uint32_t)lf.fold_slot << 16;
+            return;
+        }
         if (lf.op == DE_LEAF_CONST) {
             ins.hdr |= SRC_CONST << H_SRC_SHIFT;
             ins.feat = (uint32_t)lf.arg << 16;
@@ -209,14 +220,14 @@ struct Lowerer {
     // Emit code leaving the value of node i in acc; `depth` = occupied spill slots.
     void gen(int i, int depth) {
         const LNode n = nodes[i];
-        if (n.degree == 0) {
+        if (n.degree == 0 || n.fold_slot >= 0) {
             Instr &ins = emit(DOP_LOAD);
             set_leaf_operand(ins, i);
             return;
         }
         if (n.degree == 1) {
             int c = n.child[0];
-            if (is_leaf(c)) {
+            if (is_opnd(c)) {
                 Instr &ins = emit(n.op);
                 set_leaf_operand(ins, c);
                 op_flags(ins, n);
@@ -230,14 +241,14 @@ struct Lowerer {
         }
         if (n.degree == 2) {
             int l = n.child[0], r = n.child[1];
-            if (is_leaf(r)) {
+            if (is_opnd(r)) {
                 gen(l, depth); // l leaf -> LOAD, else its code
                 Instr &ins = emit(n.op);
                 set_leaf_operand(ins, r);
                 op_flags(ins, n);
                 return;
             }
-            if (is_leaf(l)) { // acc = r ; result = op(leaf, acc)
+            if (is_opnd(l)) { // acc = r ; result = op(leaf, acc)
                 gen(r, depth);
                 bool flag;
                 Instr &ins = emit(swapped(n.op, &flag));
@@ -361,9 +372,12 @@ int lower_tree(const de_tape_node_t *tape, int64_t n, int64_t n_consts, const Lo
         nd.degree = tape[i].degree;
         nd.op = tape[i].op;
         nd.arg = tape[i].arg;
+        nd.first = (int)i;
         if (nd.degree == 0) {
             if (nd.op == DE_LEAF_CONST) {
                 nd.is_const = true;
+                nd.cfirst = nd.arg;
+                nd.ccount = 1;
                 if (nd.arg >= n_consts) return fail(DE_ERR_OUT_OF_RANGE, "constant slot out of range");
                 if (out->const_instr[nd.arg] == -2)
                     return fail(DE_ERR_BAD_TAPE, "constant slot referenced twice");
@@ -384,8 +398,14 @@ int lower_tree(const de_tape_node_t *tape, int64_t n, int64_t n_consts, const Lo
             for (int k = nd.degree - 1; k >= 0; k--) {
                 nd.child[k] = stack.back();
                 stack.pop_back();
-                nd.is_const = nd.is_const && L.nodes[(size_t)nd.child[k]].is_const;
+                const LNode &ch = L.nodes[(size_t)nd.child[k]];
+                nd.is_const = nd.is_const && ch.is_const;
                 d = std::max(d, depth[(size_t)nd.child[k]]);
+                nd.first = std::min(nd.first, ch.first);
+                if (ch.ccount) {
+                    nd.cfirst = nd.ccount ? std::min(nd.cfirst, ch.cfirst) : ch.cfirst;
+                    nd.ccount += ch.ccount;
+                }
             }
             depth[(size_t)i] = d + 1;
             if (d + 1 > 2048) return fail(DE_ERR_UNSUPPORTED, "tree deeper than 2048");
@@ -402,6 +422,24 @@ int lower_tree(const de_tape_node_t *tape, int64_t n, int64_t n_consts, const Lo
         L.annotate(root);
         L.checked_child(root); // final is_valid_array(result.x), src/Evaluate.jl:305-308
     }
+    if (opt.fold) { // maximal constant subtrees with at least one operator
+        std::vector<int> todo{root};
+        while (!todo.empty()) {
+            const int i = todo.back();
+            todo.pop_back();
+            LNode &nd = L.nodes[(size_t)i];
+            if (nd.degree == 0) continue;
+            if (nd.is_const) {
+                nd.fold_slot = (int)n_consts + (int)out->folds.size();
+                if (nd.fold_slot > 65535) return fail(DE_ERR_UNSUPPORTED, "too many constants");
+                out->folds.push_back(FoldSpan{nd.first, (int32_t)i + 1, nd.cfirst, nd.cfirst + nd.ccount});
+            } else {
+                for (int k = 0; k < nd.degree; k++) todo.push_back(nd.child[k]);
+            }
+        }
+    }
+    // slots n_consts .. n_consts+folds-1 are the folded subtrees' values
+    out->const_instr.resize((size_t)n_consts + out->folds.size(), -1);
     L.compute_regs(root);
     if (L.nodes[(size_t)root].regs > MAX_SLOTS)
         return fail(DE_ERR_UNSUPPORTED, "tree needs more than 16 spill slots");

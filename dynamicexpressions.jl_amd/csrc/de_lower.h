@@ -17,6 +17,11 @@ struct LowerOptions {
     int n_features = 0;
     int n_params = 0;
     int dtype = DE_F32;
+    // Replace every maximal constant subtree (>= 1 operator) by a constant operand whose value
+    // the caller computes ON THE DEVICE (same operator code as everywhere else) before the first
+    // launch — the reference folds the same subtrees on the host, dispatch_constant_tree,
+    // src/Evaluate.jl:347-354,1002-1067.  Flag annotation still follows the ORIGINAL tree.
+    bool fold = false;
 };
 
 // How a constant slot takes part in the host-side part of the `ok` flag.
@@ -25,7 +30,14 @@ enum : uint8_t {
     CONST_CHECK_ALWAYS = 2, // leaf of a constant-folded subtree: tested unconditionally
 };
 
+// A folded constant subtree: the post-order tape slice [node_begin, node_end) and the constant
+// slots [const_begin, const_end) it owns; its value lives in extended constant slot n_consts + k.
+struct FoldSpan {
+    int32_t node_begin, node_end, const_begin, const_end;
+};
+
 struct TreeProgram {
+    std::vector<FoldSpan> folds;       // only with LowerOptions.fold
     std::vector<Instr> code;
     std::vector<int32_t> const_instr;  // const slot -> index into `code` holding its immediate
     std::vector<uint8_t> const_checks; // const slot -> CONST_CHECK_* bits
