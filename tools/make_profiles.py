@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/profiles_<tag>/ (tools/profile_round.sh) into the committed profiles/ files.
+usage: python tools/make_profiles.py <tag> <round-prefix>   e.g.  r1b r1"""
+import csv, json, os, shutil, sys
+tag, pre = sys.argv[1], sys.argv[2]
+src = f"gpurun_out/profiles_{tag}"
+os.makedirs("profiles", exist_ok=True)
+
+def kstats(path, out):
+    rows = list(csv.DictReader(open(path)))
+    with open(out, "w") as fh:
+        w = csv.DictWriter(fh, fieldnames=rows[0].keys()); w.writeheader()
+        for r in rows[:6]:
+            r = dict(r); r["Name"] = r["Name"][:140]; w.writerow(r)
+    return [r for r in rows if "de::" in r["Name"]]
+
+k = kstats(f"{src}/stats/eval_kernel_stats.csv", f"profiles/{pre}_headline_kernel_stats.csv")
+g = kstats(f"{src}/stats_C3/grad_kernel_stats.csv", f"profiles/{pre}_C3_grad_kernel_stats.csv")
+
+def pmc(path, name, out):
+    rows = [r for r in csv.DictReader(open(path)) if "de::" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    with open(out, "w") as fh:
+        f = ["Kernel_Name", "Counter_Name", "Counter_Value", "Grid_Size", "Workgroup_Size", "VGPR_Count", "SGPR_Count", "LDS_Block_Size"]
+        w = csv.DictWriter(fh, fieldnames=f); w.writeheader()
+        for r in rows: w.writerow({q: r[q] for q in f})
+    vals = [float(r["Counter_Value"]) for r in rows]
+    return sum(vals) / len(vals), len(vals), rows[0]["Kernel_Name"]
+
+fetch, n1, kn = pmc(f"{src}/pmc_fetch/eval_counter_collection.csv", "FETCH_SIZE", f"profiles/{pre}_pmc_fetch.csv")
+write, n2, _ = pmc(f"{src}/pmc_write/eval_counter_collection.csv", "WRITE_SIZE", f"profiles/{pre}_pmc_write.csv")
+summ = {"headline": {
+    "kernel": kn, "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
+    "fetch_correction": "x2: on gfx950 rocprofv3 FETCH_SIZE tallies 64 B per 128-B request of a wide coalesced read "
+                        "(MI355X_MICROARCH.md §HBM); WRITE_SIZE equals the 40.0 GB output exactly, i.e. needs no correction",
+    "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "launches_averaged": min(n1, n2),
+    "avg_kernel_us_rocprof": float(k[0]["AverageNs"]) / 1e3,
+    "source": f"tools/profile_round.sh {tag}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+              "`python bench.py --steps 2 --warmup 1` (headline workload); kernel time from `rocprofv3 --kernel-trace --stats`"}}
+json.dump(summ, open("profiles/pmc_summary.json", "w"), indent=1)
+print(json.dumps(summ, indent=1))
+print("eval kernel avg us:", k[0]["AverageNs"], " grad:", g[0]["AverageNs"])
+for f in ("bench_r1_headline.json", "bench_r1_C2.json", "bench_r1_C3.json"):
+    if os.path.exists(f"gpurun_out/{f}"):
+        shutil.copy(f"gpurun_out/{f}", f"profiles/{pre}_" + f.replace("bench_r1_", "bench_"))
