@@ -17,8 +17,20 @@ def kstats(path, out):
 k = kstats(f"{src}/stats/eval_kernel_stats.csv", f"profiles/{pre}_headline_kernel_stats.csv")
 g = kstats(f"{src}/stats_C3/grad_kernel_stats.csv", f"profiles/{pre}_C3_grad_kernel_stats.csv")
 
+def big_launches(trace, needle):
+    """Durations (us) of the full-size launches of the kernel whose name contains `needle` (the one-sample
+    constant-folding launch of the same kernel and the handler-table kernel are excluded by grid size)."""
+    rows = [r for r in csv.DictReader(open(trace)) if needle in r["Kernel_Name"]]
+    gmax = max(int(r["Grid_Size"]) for r in rows)
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if int(r["Grid_Size"]) == gmax]
+    return d, gmax
+ev, gmax = big_launches(f"{src}/stats/eval_kernel_trace.csv", "de_eval_")
+gr, _ = big_launches(f"{src}/stats_C3/grad_kernel_trace.csv", "de_grad_")
+
 def pmc(path, name, out):
-    rows = [r for r in csv.DictReader(open(path)) if "de::" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    rows = [r for r in csv.DictReader(open(path)) if "de_eval_" in r["Kernel_Name"] and r["Counter_Name"] == name]
+    gm = max(int(r["Grid_Size"]) for r in rows)
+    rows = [r for r in rows if int(r["Grid_Size"]) == gm]  # full-size launches only
     with open(out, "w") as fh:
         f = ["Kernel_Name", "Counter_Name", "Counter_Value", "Grid_Size", "Workgroup_Size", "VGPR_Count", "SGPR_Count", "LDS_Block_Size"]
         w = csv.DictWriter(fh, fieldnames=f); w.writeheader()
@@ -33,12 +45,13 @@ summ = {"headline": {
     "fetch_correction": "x2: on gfx950 rocprofv3 FETCH_SIZE tallies 64 B per 128-B request of a wide coalesced read "
                         "(MI355X_MICROARCH.md §HBM); WRITE_SIZE equals the 40.0 GB output exactly, i.e. needs no correction",
     "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "launches_averaged": min(n1, n2),
-    "avg_kernel_us_rocprof": float(k[0]["AverageNs"]) / 1e3,
+    "avg_kernel_us_rocprof": sum(ev) / len(ev), "kernel_launches_in_trace": len(ev), "grid_size": gmax,
+    "grad_C3_avg_kernel_us_rocprof": sum(gr) / len(gr),
     "source": f"tools/profile_round.sh {tag}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
               "`python bench.py --steps 2 --warmup 1` (headline workload); kernel time from `rocprofv3 --kernel-trace --stats`"}}
 json.dump(summ, open("profiles/pmc_summary.json", "w"), indent=1)
 print(json.dumps(summ, indent=1))
-print("eval kernel avg us:", k[0]["AverageNs"], " grad:", g[0]["AverageNs"])
+print("eval kernel avg us:", sum(ev) / len(ev), " grad:", sum(gr) / len(gr))
 for f in ("bench_r1_headline.json", "bench_r1_C2.json", "bench_r1_C3.json"):
     if os.path.exists(f"gpurun_out/{f}"):
         shutil.copy(f"gpurun_out/{f}", f"profiles/{pre}_" + f.replace("bench_r1_", "bench_"))
