@@ -21,8 +21,8 @@ def big_launches(trace, needle):
     """Durations (us) of the full-size launches of the kernel whose name contains `needle` (the one-sample
     constant-folding launch of the same kernel and the handler-table kernel are excluded by grid size)."""
     rows = [r for r in csv.DictReader(open(trace)) if needle in r["Kernel_Name"]]
-    gmax = max(int(r["Grid_Size"]) for r in rows)
-    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if int(r["Grid_Size"]) == gmax]
+    gmax = max(int(r["Grid_Size_X"]) for r in rows)
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if int(r["Grid_Size_X"]) == gmax]
     return d, gmax
 ev, gmax = big_launches(f"{src}/stats/eval_kernel_trace.csv", "de_eval_")
 gr, _ = big_launches(f"{src}/stats_C3/grad_kernel_trace.csv", "de_grad_")
