@@ -80,6 +80,7 @@ struct de_program {
     std::vector<BoundInstr> bcode;      // bound form of the eval program (handler ids)
     std::vector<BoundInstr> tcode;      // threaded form: handler address offsets + LDS byte offsets
     bool threaded = false;
+    bool direct = false;                // X too wide for the LDS tile (decided at creation)
     uint64_t handler_base = 0;
     uint32_t param_handler_off = 0;
     std::vector<int32_t> bcode_off;     // n_trees + 1
@@ -275,7 +276,9 @@ static void rebind(de_program *p) {
 // handler address - handler_base, word 1 = LDS byte offset of the operand row | aux << 24.
 static int make_threaded(de_ctx *c, de_program *p) {
     p->threaded = false;
-    if (!eval_uses_threaded()) return DE_OK;
+    // the LDS-staged kernels need (n_features + n_slots) rows of 4112 B; wider X uses the direct variant
+    p->direct = ((size_t)p->n_features + (size_t)p->n_slots) * 257 * 16 > 150 * 1024;
+    if (p->direct || !eval_uses_threaded()) return DE_OK;
     if ((int64_t)p->n_features + p->n_slots > 4000) return DE_OK; // row offsets must fit 24 bits
     uint64_t table[BOP_COUNT];
     hipError_t st = eval_handler_table(p->dtype, table);
@@ -541,7 +544,7 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
         return fail(ctx, DE_ERR_HIP, "out of host memory");
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (p->threaded) {
+    {
         int rc = DE_OK;
         try { rc = make_threaded(ctx, p); } catch (const std::bad_alloc &) { rc = fail(ctx, DE_ERR_HIP, "out of host memory"); }
         if (rc != DE_OK) return rc;
@@ -706,9 +709,7 @@ int de_eval(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX,
         else std::memcpy(ok, p->host_ok_eval.data(), (size_t)p->n_trees);
         return DE_OK;
     }
-    int K = 0;
-    if (eval_lds_bytes(p->dtype, p->n_features, p->n_slots, &K) == 0)
-        return fail(c, DE_ERR_UNSUPPORTED, "n_features=%d does not fit the LDS-staged kernel", p->n_features);
+    const bool direct = p->direct;
 
     Staged sX, sOut, sOk, sPar, sCls;
     rc = stage_in(c, c->sX, X, (size_t)ldX * (size_t)N * es, &sX);
@@ -752,7 +753,8 @@ int de_eval(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX,
         a.class_base = pa->class_base;
     }
     a.early_exit = (p->options & DE_OPT_EARLY_EXIT) != 0;
-    a.threaded = p->threaded;
+    a.threaded = p->threaded && !direct;
+    a.direct = direct;
     a.handler_base = p->handler_base;
     a.param_handler_off = p->param_handler_off;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));

@@ -36,6 +36,7 @@ struct EvalArgs {
     // threaded-code variant: `code` holds handler OFFSETS (relative to handler_base) in word 0 and
     // LDS byte offsets in the low 24 bits of word 1
     bool threaded;
+    bool direct; // feature matrix too wide for the LDS tile: gather features from global memory (flat-switch kernel)
     uint64_t handler_base;
     uint32_t param_handler_off;
 };

@@ -276,7 +276,9 @@ __device__ __noinline__ void flag_incomplete(uint8_t *ok) {
     if ((threadIdx.x & 63) == 0) *ok = 0;
 }
 
-template <typename T, int G, int BLK, bool EE, bool PARAMS>
+// DIRECT = true: wide feature matrices whose X tile does not fit in LDS — feature operands are
+// gathered from global memory (L1/L2 absorb the re-reads), LDS holds only the spill rows.
+template <typename T, int G, int BLK, bool EE, bool PARAMS, bool DIRECT = false>
 __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
     typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
@@ -295,7 +297,7 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
 
     // ---- stage the X tile: coalesced HBM/L2 read, transposed LDS write ----------
     // sample j of the tile lives at rows[f*ROWV*VW + j]  (plane g = j / GT, lane = (j % GT) / VW)
-    {
+    if (!DIRECT) {
         const uint32_t F = (uint32_t)a.F;
         const uint32_t total = (uint32_t)TILE * F;
         if (a.ldX == (int64_t)F && base + TILE <= a.N) {
@@ -345,8 +347,20 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
             nxt = code[pc + 1]; // prefetch (the code buffer carries one trailing pad instruction)
             // One flat, wave-uniform switch over the bound handler id (de_bind.h): every case is
             // straight-line code.  ROW(r) = this thread's vectors of LDS row r.
-#define ROWP(r) (rowsv + (r) * ROWV + tid)
-#define LOAD_ROW(dst, r) { const V *__restrict__ s_ = ROWP(r); FOR_G dst[g] = s_[g * BLK]; }
+#define ROWP(r) (rowsv + ((r) - (DIRECT ? (uint32_t)a.F : 0u)) * ROWV + tid)
+#define LOAD_ROW(dst, r)                                                                              \
+    {                                                                                                 \
+        if (DIRECT && (r) < (uint32_t)a.F) {                                                          \
+            FOR_G FOR_I {                                                                             \
+                int64_t jj_ = base + g * GT + tid * VW + i;                                           \
+                jj_ = jj_ < last ? jj_ : last;                                                        \
+                dst[g][i] = a.X[(r) + a.ldX * jj_];                                                   \
+            }                                                                                         \
+        } else {                                                                                      \
+            const V *__restrict__ s_ = ROWP(r);                                                       \
+            FOR_G dst[g] = s_[g * BLK];                                                               \
+        }                                                                                             \
+    }
 #define BIN4(K, EXPR)                                                                                   \
     case BOP_BIN_BASE + 4 * K + 0: { V b[G]; LOAD_ROW(b, w.y) FOR_G FOR_I { const T x = acc[g][i], y = b[g][i]; acc[g][i] = (EXPR); } } break; \
     case BOP_BIN_BASE + 4 * K + 1: { V b[G]; LOAD_ROW(b, w.y) FOR_G FOR_I { const T x = acc[g][i], y = b[g][i]; acc[g][i] = (EXPR); } poison_with<T, G, V>(poison, acc); } break; \
@@ -740,12 +754,19 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
     const int64_t tile_groups = (a.n_tiles + 7) / 8;
     const int64_t blocks = tile_groups * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(a.F + a.n_slots) * ((size_t)BLK * G + 1) * 16;
-
     void (*kern)(const KArgs<T>);
     if (e.early_exit) kern = e.uses_params ? de_eval_tape_kernel<T, G, BLK, true, true> : de_eval_tape_kernel<T, G, BLK, true, false>;
     else kern = e.uses_params ? de_eval_tape_kernel<T, G, BLK, false, true> : de_eval_tape_kernel<T, G, BLK, false, false>;
     if (kname) *kname = "de_eval_tape_kernel";
+    size_t lds = (size_t)(a.F + a.n_slots) * ((size_t)BLK * G + 1) * 16;
+    if constexpr (G == 1 && BLK == 256) {
+        if (e.direct) {
+            kern = e.early_exit ? (e.uses_params ? de_eval_tape_kernel<T, 1, 256, true, true, true> : de_eval_tape_kernel<T, 1, 256, true, false, true>)
+                                : (e.uses_params ? de_eval_tape_kernel<T, 1, 256, false, true, true> : de_eval_tape_kernel<T, 1, 256, false, false, true>);
+            lds = (size_t)(a.n_slots > 0 ? a.n_slots : 1) * 257 * 16;
+            if (kname) *kname = "de_eval_tape_kernel<direct>";
+        }
+    }
     if (lds > 64 * 1024) {
         hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -829,6 +850,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
 }
 
 hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const char **kernel_name) {
+    if (a.direct) return dtype == DE_F32 ? launch_eval_t<float, 1, 256>(a, stream, kernel_name) : launch_eval_t<double, 1, 256>(a, stream, kernel_name);
     if (a.threaded) return dtype == DE_F32 ? launch_threaded_t<float>(a, stream, kernel_name) : launch_threaded_t<double>(a, stream, kernel_name);
     int G, BLK;
     eval_geometry(dtype, &G, &BLK);

@@ -218,3 +218,54 @@ def test_full_size_properties_config_C2(api):
     assert torch.equal(ok, ok2)
     assert torch.equal(torch.nan_to_num(out[complete]).double().sum(1), torch.nan_to_num(out2[complete]).double().sum(1))
     assert 100 < int(okc.sum()) < 1000
+
+
+def test_wide_feature_matrix_uses_direct_path(api):
+    """F = 200 features does not fit the LDS tile: the direct variant gathers features from
+    global memory; results must still match the oracle (and be bit-exact for exact operators)."""
+    F = 200
+    ops = de.OperatorEnum(binary_operators=("+", "-", "/", "*"), unary_operators=("cos", "exp", "neg"))
+    rng = de.synth.Xoshiro256ss(41)
+    trees = [de.synth.gen_random_tree_fixed_size(3 + i % 25, ops, F, rng, np.float32) for i in range(60)]
+    X = de.synth.random_X(F, 1500, seed=13)
+    compare_population(api, trees, ops, X, np.float32, min_ok=5)
+    ops2 = de.OperatorEnum(binary_operators=("+", "-", "*"), unary_operators=("neg", "abs"))
+    trees2 = [de.synth.gen_random_tree_fixed_size(3 + i % 25, ops2, F, rng, np.float64) for i in range(40)]
+    X64 = de.synth.random_X(F, 700, seed=14, dtype=np.float64)
+    pop = api.Population(trees2, ops2, np.float64, n_features=F)
+    out, ok = pop.eval(X64)
+    assert pop.ctx.last_kernel_name().endswith("<direct>")
+    for t, tree in enumerate(trees2):
+        tape, consts = de.flatten(tree, ops2, np.float64)
+        y, okr = oracle.eval_tree_array(tape, consts, X64, elementwise=True)
+        assert bool(ok[t]) == okr
+        if okr:
+            np.testing.assert_array_equal(out[t], y)
+
+
+def test_abi_error_paths_on_device(api):
+    """Misuse returns status codes + messages, never crashes."""
+    import ctypes as C
+    lib = api.library()
+    ctx = api.default_context()
+    T = de.node.TAPE_DTYPE
+    bad = np.array([(2, 64, 0)], dtype=T)  # operator without operands
+    off = np.array([0, 1], dtype=np.int64)
+    coff = np.zeros(2, dtype=np.int64)
+    h = C.c_void_p()
+    rc = lib.de_program_create(ctx._h, 0, bad.ctypes.data, off.ctypes.data, 1, None, coff.ctypes.data, 2, 0, 7, C.byref(h))
+    assert rc == 2 and b"tree 0" in lib.de_last_error(ctx._h)
+    unk = np.array([(0, 1, 0), (1, 250, 0)], dtype=T)  # opcode outside the table
+    off2 = np.array([0, 2], dtype=np.int64)
+    rc = lib.de_program_create(ctx._h, 0, unk.ctypes.data, off2.ctypes.data, 1, None, coff.ctypes.data, 2, 0, 7, C.byref(h))
+    assert rc == 3
+    rc = lib.de_program_create(ctx._h, 5, unk.ctypes.data, off2.ctypes.data, 1, None, coff.ctypes.data, 2, 0, 7, C.byref(h))
+    assert rc == 1  # bad dtype
+    pop = api.Population([de.Node(feature=2)], de.synth.BENCH_OPERATORS, np.float32, n_features=2)
+    ok = np.zeros(1, np.uint8)
+    out = np.zeros(4, np.float32)
+    X = np.zeros((2, 4), np.float32, order="F")
+    assert lib.de_eval(ctx._h, pop._h, X.ctypes.data, 4, 1, None, out.ctypes.data, 4, ok.ctypes.data) == 1  # ldX < F
+    assert lib.de_eval(ctx._h, pop._h, X.ctypes.data, 4, 2, None, out.ctypes.data, 3, ok.ctypes.data) == 1  # ld_out < N
+    assert lib.de_eval(ctx._h, pop._h, None, 4, 2, None, out.ctypes.data, 4, ok.ctypes.data) == 1  # null X
+    assert lib.de_eval(ctx._h, pop._h, X.ctypes.data, 4, 2, None, out.ctypes.data, 4, ok.ctypes.data) == 0
