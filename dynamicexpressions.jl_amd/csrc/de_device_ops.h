@@ -123,6 +123,29 @@ template <bool SIN> __device__ __forceinline__ float fast_trig_f32(float x) {
     const unsigned sign = (SIN ? ((unsigned)q << 30) : (((unsigned)q << 30) + 0x40000000u)) & 0x80000000u;
     return __uint_as_float(__float_as_uint(v) ^ sign);
 }
+// sin and cos of the same argument (value + derivative of cos/sin in the gradient kernel):
+// one reduction, both polynomials, two quadrant selects.  Same accuracy as fast_trig_f32.
+__device__ __forceinline__ void fast_sincos_f32(float x, float *sn, float *cs) {
+    const float t = x * 0x1.45f306p-1f;
+    const float k = __builtin_rintf(t);
+    float r = __builtin_fmaf(-k, 0x1.921fb6p+0f, x);
+    r = __builtin_fmaf(-k, -0x1.777a5cp-25f, r);
+    r = __builtin_fmaf(-k, -0x1.ee59dap-50f, r);
+    const int q = (int)k;
+    const float r2 = r * r;
+    float c = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    c = __builtin_fmaf(r2, c, 4.166664568298827e-2f);
+    c = __builtin_fmaf(r2, c, -0.5f);
+    c = __builtin_fmaf(r2, c, 1.0f);
+    float p = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    p = __builtin_fmaf(r2, p, -1.6666654611e-1f);
+    const float s = __builtin_fmaf(r * r2, p, r);
+    const bool odd = q & 1;
+    const unsigned ssign = ((unsigned)q << 30) & 0x80000000u;                 // sin: negative in quadrants 2,3
+    const unsigned csign = (((unsigned)q << 30) + 0x40000000u) & 0x80000000u; // cos: negative in quadrants 1,2
+    *sn = __uint_as_float(__float_as_uint(odd ? c : s) ^ ssign);
+    *cs = __uint_as_float(__float_as_uint(odd ? s : c) ^ csign);
+}
 // exp(x) = 2^(x*log2(e)): k = rint(x*L), r = x*L - k in two FMAs (hi/lo split of L),
 // hardware v_exp_f32 on r in [-0.5, 0.5], v_ldexp_f32 for the 2^k scaling (gradual
 // underflow and overflow to Inf come from ldexp).  ~10 VALU vs 15; <= 2 ulp.

@@ -291,7 +291,17 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
                 DE_UNROLL for (int k = 0; k < GC; k++) d[k] = db[k];
             } else if (op < DE_B_ADD) { // unary: input is acc (SRC_ACC) or the leaf
                 const T xin = src == SRC_ACC ? x : xb;
-                const UG<T> r = unary_vg<T>(op, xin);
+                UG<T> r;
+                if (sizeof(T) == 4 && (op == DE_U_COS || op == DE_U_SIN || op == DE_U_EXP)) {
+                    // hot operators inline (fast Float32 versions, de_device_ops.h); huge |x| -> OCML path
+                    if (op == DE_U_EXP) { r.y = (T)fast_exp_f32((float)xin); r.g = r.y; }
+                    else if (__ballot(M<T>::abs(xin) > T(DE_TRIG_FAST_BOUND)) != 0ull) r = unary_vg<T>(op, xin);
+                    else {
+                        float sn, cs;
+                        fast_sincos_f32((float)xin, &sn, &cs);
+                        if (op == DE_U_COS) { r.y = (T)cs; r.g = (T)-sn; } else { r.y = (T)sn; r.g = (T)cs; }
+                    }
+                } else r = unary_vg<T>(op, xin);
                 x = r.y;
                 if (src == SRC_ACC) { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.g * d[k]; }
                 else { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.g * db[k]; }
@@ -314,15 +324,27 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
                 case DOP_RPOW_ABS2: fop = DE_B_POW_ABS2; rev = true; break;
                 default: break;
                 }
-                const BG<T> r = rev ? binary_vg<T>(fop, xb, x) : binary_vg<T>(fop, x, xb);
+                const T lx = rev ? xb : x, ly = rev ? x : xb;
+                BG<T> r;
+                if (fop == DE_B_ADD) { r.v = lx + ly; r.gx = T(1); r.gy = T(1); }
+                else if (fop == DE_B_SUB) { r.v = lx - ly; r.gx = T(1); r.gy = T(-1); }
+                else if (fop == DE_B_MUL) { r.v = lx * ly; r.gx = ly; r.gy = lx; }
+                else if (fop == DE_B_DIV) { r.v = lx / ly; r.gx = T(1) / ly; r.gy = -(r.v / ly); }
+                else r = binary_vg<T>(fop, lx, ly);
                 x = r.v;
                 if (rev) { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.gx * db[k] + r.gy * d[k]; }
                 else { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.gx * d[k] + r.gy * db[k]; }
             }
-            if (a.check) {
-                poison = M<T>::fma(x, T(0), poison);
-                DE_UNROLL for (int k = 0; k < GC; k++) poison = M<T>::fma(d[k], T(0), poison);
-            }
+            // Validity (src/EvaluateDerivative.jl:239-242 tests x and dx after EVERY node).  Exact
+            // elision: x needs a test only where the lowering kept H_CHECK_OUT (the consumer would
+            // not propagate a non-finite x, de_lower.cpp); a non-finite d[k] ALWAYS survives to the
+            // root because every update is linear in it (g*Inf, Inf+c, NaN*g stay non-finite), so
+            // the gradient is tested once, below.
+            if (a.check && op != DOP_LOAD && (hdr & H_CHECK_OUT)) poison = M<T>::fma(x, T(0), poison);
+        }
+        if (a.check) {
+            poison = M<T>::fma(x, T(0), poison);
+            DE_UNROLL for (int k = 0; k < GC; k++) poison = M<T>::fma(d[k], T(0), poison);
         }
         if (live) {
             if (a.diff_g0 >= 0) {
