@@ -361,209 +361,6 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Vector variant: each thread owns VW consecutive samples (one 16-byte vector: 4 x f32 / 2 x f64),
-// so the scalar decode of an instruction is amortised over 4x the samples, and the (rare) spill
-// slots live in REGISTERS (up to 3; deeper trees use the scalar-per-thread kernel above) so LDS
-// only holds the X tile and occupancy stays high.
-template <typename T> struct GVec;
-template <> struct GVec<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int W = 4; };
-template <> struct GVec<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int W = 2; };
-constexpr int GV_MAX_SLOTS = 3;
-
-template <typename T, int GC>
-__global__ void __launch_bounds__(GBLK) de_grad_vec_kernel(const GArgs<T> a) {
-    typedef typename GVec<T>::type V;
-    constexpr int VW = GVec<T>::W;
-    constexpr int TILE = GBLK * VW, ROWV = GBLK + 1;
-    extern __shared__ __align__(16) unsigned char gsmem[];
-    T *__restrict__ rows = reinterpret_cast<T *>(gsmem);
-    const V *__restrict__ rowsv = reinterpret_cast<const V *>(gsmem);
-
-    const GTileMap tm = gmap_block(blockIdx.x, a.n_chunks, a.n_tiles);
-    if (!tm.valid) return;
-    const int tid = threadIdx.x;
-    const int64_t base = tm.tile * TILE;
-    const int64_t last = a.N - 1;
-    const int g0 = a.diff_g0 >= 0 ? a.diff_g0 : (int)blockIdx.y * GC;
-    const int F = a.F, P = a.P;
-    {
-        const uint32_t Fu = (uint32_t)F;
-        const uint32_t total = (uint32_t)TILE * Fu;
-        for (uint32_t e = tid; e < total; e += GBLK) {
-            const uint32_t j = e / Fu, f = e - j * Fu;
-            int64_t jj = base + j;
-            jj = jj < last ? jj : last;
-            rows[f * (ROWV * VW) + j] = a.X[f + a.ldX * jj];
-        }
-    }
-    int64_t cls[VW];
-    DE_UNROLL for (int i = 0; i < VW; i++) cls[i] = 0;
-    if (a.uses_params) {
-        DE_UNROLL for (int i = 0; i < VW; i++) {
-            int64_t jj = base + tid * VW + i;
-            jj = jj < last ? jj : last;
-            cls[i] = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
-                                       : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base;
-        }
-    }
-    __syncthreads();
-
-    const ConstU4Ptr code = (ConstU4Ptr)(uintptr_t)a.code;
-    const ConstI32Ptr code_off = (ConstI32Ptr)(uintptr_t)a.code_off;
-    const ConstI32Ptr n_grad = (ConstI32Ptr)(uintptr_t)a.n_grad;
-    const ConstI64Ptr grad_off = (ConstI64Ptr)(uintptr_t)a.grad_off;
-    const int t0 = tm.chunk * a.trees_per_chunk;
-    const int t1 = (t0 + a.trees_per_chunk < a.n_trees) ? t0 + a.trees_per_chunk : a.n_trees;
-
-    for (int tree = t0; tree < t1; ++tree) {
-        const int G = a.diff_g0 >= 0 ? 1 : n_grad[tree];
-        if (a.diff_g0 < 0 && g0 >= G && g0 > 0) continue;
-        int pc = code_off[tree];
-        const int pe = code_off[tree + 1];
-        V x, d[GC];
-        V sx[GV_MAX_SLOTS], sd[GV_MAX_SLOTS][GC]; // register spill slots
-        DE_UNROLL for (int i = 0; i < VW; i++) x[i] = T(0);
-        DE_UNROLL for (int k = 0; k < GC; k++) d[k] = x;
-        DE_UNROLL for (int s = 0; s < GV_MAX_SLOTS; s++) { sx[s] = x; DE_UNROLL for (int k = 0; k < GC; k++) sd[s][k] = x; }
-        T poison = T(0);
-        U32x4 nxt = code[pc];
-        for (; pc < pe; ++pc) {
-            const U32x4 w = nxt;
-            nxt = code[pc + 1];
-            const uint32_t hdr = w.x;
-            const uint32_t op = hdr & H_OP_MASK;
-            const uint32_t src = (hdr >> H_SRC_SHIFT) & H_SRC_MASK;
-            const uint32_t row = w.y & 0xFFFFu;
-            if (hdr & H_PUSH) {
-                const uint32_t sl = (hdr >> H_PUSH_SHIFT) & H_SLOT_MASK;
-                DE_UNROLL for (int s = 0; s < GV_MAX_SLOTS; s++)
-                    if (sl == (uint32_t)s) { sx[s] = x; DE_UNROLL for (int k = 0; k < GC; k++) sd[s][k] = d[k]; }
-            }
-            // ---- operand B
-            V xb, db[GC];
-            DE_UNROLL for (int i = 0; i < VW; i++) xb[i] = T(0);
-            DE_UNROLL for (int k = 0; k < GC; k++) db[k] = xb;
-            int seed = -1;
-            bool b_is_leaf = true;
-            if (src == SRC_ROW) {
-                if ((int)row < F) {
-                    xb = rowsv[row * ROWV + tid];
-                    if (a.mode != DE_GRAD_CONSTANT) seed = P + (int)row - g0;
-                } else {
-                    const uint32_t sl = row - (uint32_t)F;
-                    DE_UNROLL for (int s = 0; s < GV_MAX_SLOTS; s++)
-                        if (sl == (uint32_t)s) { xb = sx[s]; DE_UNROLL for (int k = 0; k < GC; k++) db[k] = sd[s][k]; }
-                    b_is_leaf = false;
-                }
-            } else if (src == SRC_CONST) {
-                const T c = gimm<T>(w.z, w.w);
-                DE_UNROLL for (int i = 0; i < VW; i++) xb[i] = c;
-                if (a.mode == DE_GRAD_CONSTANT) seed = (int)(w.y >> 16) - g0;
-                else if (a.mode == DE_GRAD_BOTH) seed = P + F + (int)(w.y >> 16) - g0;
-            } else if (src == SRC_PARAM) {
-                DE_UNROLL for (int i = 0; i < VW; i++) xb[i] = a.params[row + a.ld_params * cls[i]];
-                if (a.mode != DE_GRAD_CONSTANT) seed = (int)row - g0;
-            }
-            const bool leafb = b_is_leaf && src != SRC_ACC;
-            if (leafb) {
-                DE_UNROLL for (int k = 0; k < GC; k++) {
-                    const T oh = (k == seed) ? T(1) : T(0); // wave-uniform: stays in an SGPR
-                    DE_UNROLL for (int i = 0; i < VW; i++) db[k][i] = oh;
-                }
-                if (a.check) { DE_UNROLL for (int i = 0; i < VW; i++) poison = M<T>::fma(xb[i], T(0), poison); }
-            }
-            // ---- apply
-            if (op == DOP_LOAD) {
-                x = xb;
-                DE_UNROLL for (int k = 0; k < GC; k++) d[k] = db[k];
-            } else if (op < DE_B_ADD) {
-                const V xin = src == SRC_ACC ? x : xb;
-                V y, g;
-                if (sizeof(T) == 4 && (op == DE_U_COS || op == DE_U_SIN || op == DE_U_EXP)) {
-                    if (op == DE_U_EXP) { DE_UNROLL for (int i = 0; i < VW; i++) { y[i] = (T)fast_exp_f32((float)xin[i]); g[i] = y[i]; } }
-                    else {
-                        bool big = false;
-                        DE_UNROLL for (int i = 0; i < VW; i++) big |= M<T>::abs(xin[i]) > T(DE_TRIG_FAST_BOUND);
-                        if (__ballot(big) != 0ull) {
-                            DE_UNROLL for (int i = 0; i < VW; i++) { const UG<T> r = unary_vg<T>(op, xin[i]); y[i] = r.y; g[i] = r.g; }
-                        } else {
-                            DE_UNROLL for (int i = 0; i < VW; i++) {
-                                float sn, cs;
-                                fast_sincos_f32((float)xin[i], &sn, &cs);
-                                if (op == DE_U_COS) { y[i] = (T)cs; g[i] = (T)-sn; } else { y[i] = (T)sn; g[i] = (T)cs; }
-                            }
-                        }
-                    }
-                } else {
-                    DE_UNROLL for (int i = 0; i < VW; i++) { const UG<T> r = unary_vg<T>(op, xin[i]); y[i] = r.y; g[i] = r.g; }
-                }
-                x = y;
-                if (src == SRC_ACC) { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = g * d[k]; }
-                else { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = g * db[k]; }
-            } else if (op >= DE_T_FMA && op < DOP_LOAD) {
-                const uint32_t sl = (hdr >> H_POPC_SHIFT) & H_SLOT_MASK;
-                V xc = x, dc[GC];
-                DE_UNROLL for (int k = 0; k < GC; k++) dc[k] = x;
-                DE_UNROLL for (int s = 0; s < GV_MAX_SLOTS; s++)
-                    if (sl == (uint32_t)s) { xc = sx[s]; DE_UNROLL for (int k = 0; k < GC; k++) dc[k] = sd[s][k]; }
-                V v, q0, q1, q2;
-                DE_UNROLL for (int i = 0; i < VW; i++) {
-                    const TG<T> r = ternary_vg<T>(op, xb[i], xc[i], x[i]);
-                    v[i] = r.v; q0[i] = r.g0; q1[i] = r.g1; q2[i] = r.g2;
-                }
-                x = v;
-                DE_UNROLL for (int k = 0; k < GC; k++) d[k] = (q0 * db[k] + q1 * dc[k]) + q2 * d[k];
-            } else {
-                uint32_t fop = op;
-                bool rev = false;
-                switch (op) {
-                case DOP_RSUB: fop = DE_B_SUB; rev = true; break;
-                case DOP_RDIV: fop = DE_B_DIV; rev = true; break;
-                case DOP_RPOW: fop = DE_B_POW; rev = true; break;
-                case DOP_RMOD: fop = DE_B_MOD; rev = true; break;
-                case DOP_RREM: fop = DE_B_REM; rev = true; break;
-                case DOP_RGREATER: fop = DE_B_GREATER; rev = true; break;
-                case DOP_RPOW_ABS2: fop = DE_B_POW_ABS2; rev = true; break;
-                default: break;
-                }
-                const V lx = rev ? xb : x, ly = rev ? x : xb;
-                V v, gx, gy;
-                if (fop == DE_B_ADD) { v = lx + ly; DE_UNROLL for (int i = 0; i < VW; i++) { gx[i] = T(1); gy[i] = T(1); } }
-                else if (fop == DE_B_SUB) { v = lx - ly; DE_UNROLL for (int i = 0; i < VW; i++) { gx[i] = T(1); gy[i] = T(-1); } }
-                else if (fop == DE_B_MUL) { v = lx * ly; gx = ly; gy = lx; }
-                else if (fop == DE_B_DIV) { v = lx / ly; DE_UNROLL for (int i = 0; i < VW; i++) { gx[i] = T(1) / ly[i]; gy[i] = -(v[i] / ly[i]); } }
-                else {
-                    DE_UNROLL for (int i = 0; i < VW; i++) { const BG<T> r = binary_vg<T>(fop, lx[i], ly[i]); v[i] = r.v; gx[i] = r.gx; gy[i] = r.gy; }
-                }
-                x = v;
-                if (rev) { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = gx * db[k] + gy * d[k]; }
-                else { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = gx * d[k] + gy * db[k]; }
-            }
-            if (a.check && op != DOP_LOAD && (hdr & H_CHECK_OUT)) { DE_UNROLL for (int i = 0; i < VW; i++) poison = M<T>::fma(x[i], T(0), poison); }
-        }
-        if (a.check) {
-            DE_UNROLL for (int i = 0; i < VW; i++) poison = M<T>::fma(x[i], T(0), poison);
-            DE_UNROLL for (int k = 0; k < GC; k++) DE_UNROLL for (int i = 0; i < VW; i++) poison = M<T>::fma(d[k][i], T(0), poison);
-        }
-        DE_UNROLL for (int i = 0; i < VW; i++) {
-            const int64_t j = base + tid * VW + i;
-            if (j < a.N) {
-                if (a.diff_g0 >= 0) {
-                    if (a.out) a.out[(int64_t)tree * a.ld_out + j] = x[i];
-                    a.grad[(int64_t)tree * a.ld_out + j] = d[0][i];
-                } else {
-                    if (a.out && g0 == 0) a.out[(int64_t)tree * a.ld_out + j] = x[i];
-                    T *__restrict__ gp = a.grad + grad_off[tree] + (int64_t)G * j + g0;
-                    DE_UNROLL for (int k = 0; k < GC; k++)
-                        if (g0 + k < G) gp[k] = d[k][i];
-                }
-            }
-        }
-        if (a.check && __ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree);
-    }
-}
-
 static int g_gcu = 0;
 
 template <typename T, int GC>
@@ -585,17 +382,6 @@ static hipError_t launch_grad_t(const GradArgs &ga, int windows, hipStream_t str
     a.ld_out = e.ld_out;
     a.ld_params = e.ld_params;
     a.n_tiles = (e.N + GBLK - 1) / GBLK;
-    a.n_slots = e.n_slots;
-    const bool vec = a.n_slots <= GV_MAX_SLOTS && getenv("DE_GRAD_SCALAR") == nullptr &&
-                     (size_t)e.F * (GBLK + 1) * 16 <= 150 * 1024;
-    size_t lds = (size_t)(e.F + (size_t)a.n_slots * (1 + GC)) * (GBLK + 4) * sizeof(T);
-    void (*kern)(const GArgs<T>) = de_grad_tape_kernel<T, GC>;
-    if (vec) {
-        constexpr int VW = GVec<T>::W;
-        kern = de_grad_vec_kernel<T, GC>;
-        lds = (size_t)(e.F > 0 ? e.F : 1) * (GBLK + 1) * 16;
-        a.n_tiles = (e.N + GBLK * VW - 1) / (GBLK * VW);
-    }
     a.F = e.F;
     a.P = ga.P;
     a.n_trees = e.n_trees;
@@ -623,6 +409,8 @@ static hipError_t launch_grad_t(const GradArgs &ga, int windows, hipStream_t str
     a.n_chunks = (int32_t)((e.n_trees + a.trees_per_chunk - 1) / a.trees_per_chunk);
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL || windows > 65535) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(a.F + (size_t)a.n_slots * (1 + GC)) * (GBLK + 4) * sizeof(T);
+    auto kern = de_grad_tape_kernel<T, GC>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return hipErrorInvalidValue;
         hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
