@@ -86,8 +86,10 @@ struct de_program {
     std::vector<int32_t> bcode_off;     // n_trees + 1
     BoundInstr *d_code = nullptr;
     int32_t *d_code_off = nullptr;
-    Instr *d_gcode = nullptr;           // generic program on the device (gradient kernels), lazily uploaded
+    BoundInstr *d_gcode = nullptr;      // bound UNFOLDED program on the device (gradient kernels), lazily uploaded
     int32_t *d_gcode_off = nullptr;
+    std::vector<BoundInstr> gbcode;
+    std::vector<int32_t> gbcode_off;
     bool gcode_stale = true;
 };
 
@@ -293,7 +295,9 @@ static int make_threaded(de_ctx *c, de_program *p) {
         const BoundInstr &b = p->bcode[i];
         BoundInstr t = b;
         t.bop = (uint32_t)(table[b.bop] - base);
-        if (b.bop != BOP_GEN_PARAM) {
+        if (bop_is_const_source(b.bop)) {
+            t.arg = b.arg & 0xFF000000u; // constant ordinal is only for the gradient kernel
+        } else if (b.bop != BOP_GEN_PARAM) {
             const uint32_t row = b.arg & 0xFFFFFFu, aux = b.arg >> 24;
             t.arg = (row * row_bytes) | (aux << 24);
             if (b.bop == BOP_TERN) t.lo = (b.lo - row) * row_bytes; // byte distance row B -> row C (mod 2^32)
@@ -787,15 +791,28 @@ int de_eval_tree_array(de_ctx_t *c, int dtype, const de_tape_node_t *nodes, int6
 }
 
 static int ensure_generic_code(de_ctx *c, de_program *p) {
+    if (p->gcode_stale || !p->d_gcode) {
+        // gradients flow through constant subtrees, so this is the UNFOLDED program; every value the
+        // reference tests is tested (ee binding) whatever the eval options were
+        p->gbcode.clear();
+        p->gbcode_off.assign((size_t)p->n_trees + 1, 0);
+        for (int64_t t = 0; t < p->n_trees; t++) {
+            const int32_t i0 = p->code_off[(size_t)t], i1 = p->code_off[(size_t)t + 1];
+            bind_tree(p->code.data() + i0, (size_t)(i1 - i0), true, p->n_features, &p->gbcode);
+            p->gbcode_off[(size_t)t + 1] = (int32_t)p->gbcode.size();
+        }
+    }
     if (!p->d_gcode) {
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gcode), (p->code.size() + 1) * sizeof(Instr)));
-        HIP_TRY(c, hipMemset(p->d_gcode, 0, (p->code.size() + 1) * sizeof(Instr)));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gcode), (p->gbcode.size() + 1) * sizeof(BoundInstr)));
+        HIP_TRY(c, hipMemset(p->d_gcode, 0, (p->gbcode.size() + 1) * sizeof(BoundInstr)));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gcode_off), p->gbcode_off.size() * sizeof(int32_t)));
+        HIP_TRY(c, hipMemcpy(p->d_gcode_off, p->gbcode_off.data(), p->gbcode_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         p->gcode_stale = true;
     }
     if (p->gcode_stale) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (!p->code.empty())
-            HIP_TRY(c, hipMemcpy(p->d_gcode, p->code.data(), p->code.size() * sizeof(Instr), hipMemcpyHostToDevice));
+        if (!p->gbcode.empty())
+            HIP_TRY(c, hipMemcpy(p->d_gcode, p->gbcode.data(), p->gbcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
         p->gcode_stale = false;
     }
     return DE_OK;
@@ -909,11 +926,6 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
     g.n_grad = static_cast<const int32_t *>(c->sNg.p);
     g.max_grad = maxg;
     g.diff_direction = diff ? diff_direction : -1;
-    // generic code offsets = code_off (the bound program has its own): upload once per program
-    if (!p->d_gcode_off) {
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gcode_off), p->code_off.size() * sizeof(int32_t)));
-        HIP_TRY(c, hipMemcpy(p->d_gcode_off, p->code_off.data(), p->code_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    }
     g.e.code_off = p->d_gcode_off;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, launch_grad(p->dtype, g, c->stream, &c->last_kernel));

@@ -52,7 +52,7 @@ void bind_tree(const Instr *code, size_t n, bool ee, int n_features, std::vector
         bool check_done = false;
         if (op == DOP_LOAD) {
             if (src == SRC_ROW) out->push_back(mk(BOP_LOAD_ROW, row));
-            else if (src == SRC_CONST) out->push_back(mk(BOP_LOAD_CONST, 0, lo, hi));
+            else if (src == SRC_CONST) out->push_back(mk(BOP_LOAD_CONST, ins.feat >> 16, lo, hi)); // arg = constant ordinal (gradient seed)
             else out->push_back(mk(BOP_GEN_PARAM, row | (check_b ? 1u << 23 : 0u) | (DOP_LOAD << 24)));
         } else if (op >= DE_T_FMA && op < DOP_LOAD) {
             out->push_back(mk(BOP_TERN, row | (op << 24), (uint32_t)n_features + ((hdr >> H_POPC_SHIFT) & H_SLOT_MASK)));
@@ -63,7 +63,8 @@ void bind_tree(const Instr *code, size_t n, bool ee, int n_features, std::vector
         } else {
             const int kb = hot_binary_index(op), ku = hot_unary_index(op);
             if (kb >= 0 && (src == SRC_ROW || src == SRC_CONST)) {
-                out->push_back(mk(BOP_BIN_BASE + 4 * kb + (src == SRC_CONST ? 2 : 0) + (check_out ? 1 : 0), row, lo, hi));
+                out->push_back(mk(BOP_BIN_BASE + 4 * kb + (src == SRC_CONST ? 2 : 0) + (check_out ? 1 : 0),
+                                  src == SRC_CONST ? (ins.feat >> 16) : row, lo, hi));
                 check_done = true;
             } else if (ku >= 0 && (src == SRC_ACC || src == SRC_ROW)) {
                 out->push_back(mk(BOP_UN_BASE + 4 * ku + (src == SRC_ROW ? 2 : 0) + (check_out ? 1 : 0), row));
@@ -71,7 +72,7 @@ void bind_tree(const Instr *code, size_t n, bool ee, int n_features, std::vector
             } else if (src == SRC_ROW) {
                 out->push_back(mk(BOP_GEN_ROW, row | (op << 24)));
             } else if (src == SRC_CONST) {
-                out->push_back(mk(BOP_GEN_CONST, op << 24, lo, hi));
+                out->push_back(mk(BOP_GEN_CONST, ((ins.feat >> 16) & 0xFFFFu) | (op << 24), lo, hi));
             } else {
                 out->push_back(mk(BOP_GEN_ACC, op << 24));
             }

@@ -43,10 +43,16 @@ enum BoundOp : uint32_t {
 
 struct alignas(16) BoundInstr {
     uint32_t bop;
-    uint32_t arg; // [23:0] LDS row index / parameter row; [31:24] de_opcode for generic handlers
+    uint32_t arg; // [23:0] LDS row index / parameter row / constant ordinal (constant operands); [31:24] de_opcode for generic handlers
     uint32_t lo, hi; // immediate bits (f32: lo; f64: lo,hi); BOP_TERN: lo = second row
 };
 static_assert(sizeof(BoundInstr) == 16, "BoundInstr must be 16 bytes");
+
+// True for handlers whose operand is an inline constant (arg = constant ordinal, not an LDS row).
+inline bool bop_is_const_source(uint32_t bop) {
+    if (bop == BOP_LOAD_CONST || bop == BOP_GEN_CONST) return true;
+    return bop >= BOP_BIN_BASE && bop < BOP_BIN_END && ((bop - BOP_BIN_BASE) & 2);
+}
 
 // Append the bound form of `code` (one tree) to `out`.
 void bind_tree(const Instr *code, size_t n, bool early_exit, int n_features, std::vector<BoundInstr> *out);

@@ -29,7 +29,7 @@ typedef const DE_CONSTANT int64_t *ConstI64Ptr;
 #define DE_UNROLL _Pragma("unroll")
 
 template <typename T> struct GArgs {
-    const Instr *code;       // GENERIC program, padded with one trailing instruction
+    const BoundInstr *code;  // BOUND form of the UNFOLDED program (de_bind.h, ee binding), +1 pad
     const int32_t *code_off; // n_trees + 1
     const T *X;
     T *out;                  // may be null
@@ -238,6 +238,11 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
     const int t1 = (t0 + a.trees_per_chunk < a.n_trees) ? t0 + a.trees_per_chunk : a.n_trees;
     T *__restrict__ stk = rows + (size_t)F * RS;
 
+    // window-local seed of a leaf = its gradient row - g0 (or < 0: no gradient in this mode/window)
+    const int feat_seed0 = a.mode != DE_GRAD_CONSTANT ? P - g0 : -0x40000000;
+    const int param_seed0 = a.mode != DE_GRAD_CONSTANT ? -g0 : -0x40000000;
+    const int const_seed0 = a.mode == DE_GRAD_CONSTANT ? -g0 : (a.mode == DE_GRAD_BOTH ? P + F - g0 : -0x40000000);
+
     for (int tree = t0; tree < t1; ++tree) {
         const int G = a.diff_g0 >= 0 ? 1 : n_grad[tree];
         if (a.diff_g0 < 0 && g0 >= G && g0 > 0) continue; // window without a component of this tree (window 0 always runs: x, flag)
@@ -250,98 +255,132 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
         for (; pc < pe; ++pc) {
             const U32x4 w = nxt;
             nxt = code[pc + 1];
-            const uint32_t hdr = w.x;
-            const uint32_t op = hdr & H_OP_MASK;
-            const uint32_t src = (hdr >> H_SRC_SHIFT) & H_SRC_MASK;
-            const uint32_t row = w.y & 0xFFFFu;
-            if (hdr & H_PUSH) {
-                T *__restrict__ s = stk + ((hdr >> H_PUSH_SHIFT) & H_SLOT_MASK) * (1 + GC) * RS + tid;
-                s[0] = x;
-                DE_UNROLL for (int k = 0; k < GC; k++) s[(1 + k) * RS] = d[k];
-            }
-            // ---- operand B: value xb and its gradient (db for a popped value, a one-hot seed for a leaf)
-            T xb = T(0), db[GC];
-            int seed = -1; // window-local one-hot index of a leaf operand
-            bool b_is_leaf = true;
-            if (src == SRC_ROW) {
-                if ((int)row < F) {
-                    xb = rows[row * RS + tid];
-                    if (a.mode != DE_GRAD_CONSTANT) seed = P + (int)row - g0;
-                } else {
-                    const T *__restrict__ s = stk + ((int)row - F) * (1 + GC) * RS + tid;
-                    xb = s[0];
-                    DE_UNROLL for (int k = 0; k < GC; k++) db[k] = s[(1 + k) * RS];
-                    b_is_leaf = false;
-                }
-            } else if (src == SRC_CONST) {
-                xb = gimm<T>(w.z, w.w);
-                if (a.mode == DE_GRAD_CONSTANT) seed = (int)(w.y >> 16) - g0;
-                else if (a.mode == DE_GRAD_BOTH) seed = P + F + (int)(w.y >> 16) - g0;
-            } else if (src == SRC_PARAM) {
-                xb = a.params[row + a.ld_params * cls];
-                if (a.mode != DE_GRAD_CONSTANT) seed = (int)row - g0;
-            }
-            if (b_is_leaf && src != SRC_ACC) {
-                DE_UNROLL for (int k = 0; k < GC; k++) db[k] = (k == seed) ? T(1) : T(0);
-                if (a.check) poison = M<T>::fma(xb, T(0), poison); // the leaf node itself is tested (:239-242)
-            }
-            // ---- apply
-            if (op == DOP_LOAD) {
-                x = xb;
-                DE_UNROLL for (int k = 0; k < GC; k++) d[k] = db[k];
-            } else if (op < DE_B_ADD) { // unary: input is acc (SRC_ACC) or the leaf
-                const T xin = src == SRC_ACC ? x : xb;
-                UG<T> r;
-                if (sizeof(T) == 4 && (op == DE_U_COS || op == DE_U_SIN || op == DE_U_EXP)) {
-                    // hot operators inline (fast Float32 versions, de_device_ops.h); huge |x| -> OCML path
-                    if (op == DE_U_EXP) { r.y = (T)fast_exp_f32((float)xin); r.g = r.y; }
-                    else if (__ballot(M<T>::abs(xin) > T(DE_TRIG_FAST_BOUND)) != 0ull) r = unary_vg<T>(op, xin);
-                    else {
-                        float sn, cs;
-                        fast_sincos_f32((float)xin, &sn, &cs);
-                        if (op == DE_U_COS) { r.y = (T)cs; r.g = (T)-sn; } else { r.y = (T)sn; r.g = (T)cs; }
-                    }
-                } else r = unary_vg<T>(op, xin);
-                x = r.y;
-                if (src == SRC_ACC) { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.g * d[k]; }
-                else { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.g * db[k]; }
-            } else if (op >= DE_T_FMA && op < DOP_LOAD) { // op3(B, C, acc)
-                const T *__restrict__ s = stk + ((hdr >> H_POPC_SHIFT) & H_SLOT_MASK) * (1 + GC) * RS + tid;
-                const T xc = s[0];
-                const TG<T> r = ternary_vg<T>(op, xb, xc, x);
+            // One flat wave-uniform switch over the bound handler id (de_bind.h); the operand is a LEAF
+            // row (< F: one-hot seed), a spill ROW (>= F: a popped dual number) or a constant (seed).
+#define G_SLOT(r) (stk + ((r) - (uint32_t)F) * (1 + GC) * RS + tid)
+#define G_LEAF_ROW(r) { xb = rows[(r) * RS + tid]; seed = (int)(r) + feat_seed0; if (a.check) poison = M<T>::fma(xb, T(0), poison); }
+#define G_ROW_OPERAND(r)                                                                           \
+    T xb, db[GC];                                                                                  \
+    if ((r) < (uint32_t)F) {                                                                       \
+        int seed;                                                                                  \
+        G_LEAF_ROW(r)                                                                              \
+        DE_UNROLL for (int k = 0; k < GC; k++) db[k] = (k == seed) ? T(1) : T(0);                  \
+    } else {                                                                                       \
+        const T *__restrict__ s_ = G_SLOT(r);                                                      \
+        xb = s_[0];                                                                                \
+        DE_UNROLL for (int k = 0; k < GC; k++) db[k] = s_[(1 + k) * RS];                           \
+    }
+#define G_CONST_OPERAND()                                                                          \
+    const T xb = gimm<T>(w.z, w.w);                                                                \
+    T db[GC];                                                                                      \
+    { const int seed = (int)(w.y & 0xFFFFu) + const_seed0;                                         \
+      DE_UNROLL for (int k = 0; k < GC; k++) db[k] = (k == seed) ? T(1) : T(0); }
+#define G_CHK() if (a.check) poison = M<T>::fma(x, T(0), poison);
+            // binary hot ops: value v and partials (gl, gr) w.r.t. (left, right); REV: left = operand
+#define G_BIN_APPLY(K)                                                                             \
+    {                                                                                              \
+        constexpr bool REV = (K == 2 || K == 5);                                                   \
+        const T lx = REV ? xb : x, ly = REV ? x : xb;                                              \
+        T v, gl, gr;                                                                               \
+        if (K == 0) { v = lx + ly; gl = T(1); gr = T(1); }                                         \
+        else if (K == 1 || K == 2) { v = lx - ly; gl = T(1); gr = T(-1); }                         \
+        else if (K == 3) { v = lx * ly; gl = ly; gr = lx; }                                        \
+        else { v = lx / ly; gl = T(1) / ly; gr = -(v / ly); }                                      \
+        x = v;                                                                                     \
+        if (REV) { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = gl * db[k] + gr * d[k]; }         \
+        else { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = gl * d[k] + gr * db[k]; }             \
+    }
+#define G_BIN4(K)                                                                                  \
+    case BOP_BIN_BASE + 4 * K + 0: { G_ROW_OPERAND(w.y) G_BIN_APPLY(K) } break;                    \
+    case BOP_BIN_BASE + 4 * K + 1: { G_ROW_OPERAND(w.y) G_BIN_APPLY(K) G_CHK() } break;            \
+    case BOP_BIN_BASE + 4 * K + 2: { G_CONST_OPERAND() G_BIN_APPLY(K) } break;                     \
+    case BOP_BIN_BASE + 4 * K + 3: { G_CONST_OPERAND() G_BIN_APPLY(K) G_CHK() } break;
+            // unary hot ops (K: 0 cos, 1 exp, 2 sin) on xin with incoming gradient din[]
+#define G_UN_APPLY(K, XIN, DIN)                                                                    \
+    {                                                                                              \
+        const T xin_ = (XIN);                                                                      \
+        UG<T> r;                                                                                   \
+        if (sizeof(T) == 4) {                                                                      \
+            if (K == 1) { r.y = (T)fast_exp_f32((float)xin_); r.g = r.y; }                         \
+            else if (__ballot(M<T>::abs(xin_) > T(DE_TRIG_FAST_BOUND)) != 0ull) r = unary_vg<T>(K == 0 ? DE_U_COS : DE_U_SIN, xin_); \
+            else {                                                                                 \
+                float sn, cs;                                                                      \
+                fast_sincos_f32((float)xin_, &sn, &cs);                                            \
+                if (K == 0) { r.y = (T)cs; r.g = (T)-sn; } else { r.y = (T)sn; r.g = (T)cs; }      \
+            }                                                                                      \
+        } else r = unary_vg<T>(K == 0 ? DE_U_COS : (K == 1 ? DE_U_EXP : DE_U_SIN), xin_);          \
+        x = r.y;                                                                                   \
+        DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.g * DIN[k];                                \
+    }
+#define G_UN4(K)                                                                                   \
+    case BOP_UN_BASE + 4 * K + 0: G_UN_APPLY(K, x, d) break;                                       \
+    case BOP_UN_BASE + 4 * K + 1: G_UN_APPLY(K, x, d) G_CHK() break;                               \
+    case BOP_UN_BASE + 4 * K + 2: { G_ROW_OPERAND(w.y) G_UN_APPLY(K, xb, db) } break;              \
+    case BOP_UN_BASE + 4 * K + 3: { G_ROW_OPERAND(w.y) G_UN_APPLY(K, xb, db) G_CHK() } break;
+            // generic (cold) operators through the noinline value+partials functions
+#define G_GEN_APPLY(OP, SRC_IS_ACC)                                                                \
+    {                                                                                              \
+        const uint32_t op_ = (OP);                                                                 \
+        if (op_ < DE_B_ADD) {                                                                      \
+            const UG<T> r = unary_vg<T>(op_, SRC_IS_ACC ? x : xb);                                 \
+            x = r.y;                                                                               \
+            if (SRC_IS_ACC) { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.g * d[k]; }          \
+            else { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.g * db[k]; }                    \
+        } else {                                                                                   \
+            uint32_t fop = op_;                                                                    \
+            bool rev = false;                                                                      \
+            switch (op_) {                                                                         \
+            case DOP_RSUB: fop = DE_B_SUB; rev = true; break;                                      \
+            case DOP_RDIV: fop = DE_B_DIV; rev = true; break;                                      \
+            case DOP_RPOW: fop = DE_B_POW; rev = true; break;                                      \
+            case DOP_RMOD: fop = DE_B_MOD; rev = true; break;                                      \
+            case DOP_RREM: fop = DE_B_REM; rev = true; break;                                      \
+            case DOP_RGREATER: fop = DE_B_GREATER; rev = true; break;                              \
+            case DOP_RPOW_ABS2: fop = DE_B_POW_ABS2; rev = true; break;                            \
+            default: break;                                                                        \
+            }                                                                                      \
+            const BG<T> r = rev ? binary_vg<T>(fop, xb, x) : binary_vg<T>(fop, x, xb);             \
+            x = r.v;                                                                               \
+            if (rev) { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.gx * db[k] + r.gy * d[k]; } \
+            else { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.gx * d[k] + r.gy * db[k]; }     \
+        }                                                                                          \
+    }
+            switch (w.x) {
+            case BOP_LOAD_ROW: { G_ROW_OPERAND(w.y) x = xb; DE_UNROLL for (int k = 0; k < GC; k++) d[k] = db[k]; } break;
+            case BOP_LOAD_CONST: { G_CONST_OPERAND() x = xb; DE_UNROLL for (int k = 0; k < GC; k++) d[k] = db[k]; } break;
+            case BOP_PUSH: {
+                T *__restrict__ s_ = G_SLOT(w.y);
+                s_[0] = x;
+                DE_UNROLL for (int k = 0; k < GC; k++) s_[(1 + k) * RS] = d[k];
+            } break;
+            case BOP_CHECK_ROW: break; // every leaf operand is tested where it is read (G_LEAF_ROW)
+            case BOP_CHECK_ACC: G_CHK() break;
+            G_BIN4(0) G_BIN4(1) G_BIN4(2) G_BIN4(3) G_BIN4(4) G_BIN4(5)
+            G_UN4(0) G_UN4(1) G_UN4(2)
+            case BOP_GEN_ROW: { G_ROW_OPERAND(w.y & 0xFFFFFFu) G_GEN_APPLY(w.y >> 24, false) } break;
+            case BOP_GEN_CONST: { G_CONST_OPERAND() G_GEN_APPLY(w.y >> 24, false) } break;
+            case BOP_GEN_ACC: { const T xb = x; T db[GC]; DE_UNROLL for (int k = 0; k < GC; k++) db[k] = d[k]; G_GEN_APPLY(w.y >> 24, true) } break;
+            case BOP_GEN_PARAM: {
+                const uint32_t prow = w.y & 0xFFFFu, op_ = w.y >> 24;
+                const T xb = a.params[prow + a.ld_params * cls];
+                if (a.check) poison = M<T>::fma(xb, T(0), poison);
+                T db[GC];
+                { const int seed = (int)prow + param_seed0; DE_UNROLL for (int k = 0; k < GC; k++) db[k] = (k == seed) ? T(1) : T(0); }
+                if (op_ == DOP_LOAD) { x = xb; DE_UNROLL for (int k = 0; k < GC; k++) d[k] = db[k]; }
+                else G_GEN_APPLY(op_, false)
+            } break;
+            case BOP_TERN: { // acc = op3(row B, row C, acc)
+                const T *__restrict__ sb = G_SLOT(w.y & 0xFFFFFFu);
+                const T *__restrict__ sc = G_SLOT(w.z);
+                const TG<T> r = ternary_vg<T>(w.y >> 24, sb[0], sc[0], x);
                 x = r.v;
-                DE_UNROLL for (int k = 0; k < GC; k++) d[k] = (r.g0 * db[k] + r.g1 * s[(1 + k) * RS]) + r.g2 * d[k];
-            } else { // binary; reversed opcodes mean op(B, acc)
-                uint32_t fop = op;
-                bool rev = false;
-                switch (op) {
-                case DOP_RSUB: fop = DE_B_SUB; rev = true; break;
-                case DOP_RDIV: fop = DE_B_DIV; rev = true; break;
-                case DOP_RPOW: fop = DE_B_POW; rev = true; break;
-                case DOP_RMOD: fop = DE_B_MOD; rev = true; break;
-                case DOP_RREM: fop = DE_B_REM; rev = true; break;
-                case DOP_RGREATER: fop = DE_B_GREATER; rev = true; break;
-                case DOP_RPOW_ABS2: fop = DE_B_POW_ABS2; rev = true; break;
-                default: break;
-                }
-                const T lx = rev ? xb : x, ly = rev ? x : xb;
-                BG<T> r;
-                if (fop == DE_B_ADD) { r.v = lx + ly; r.gx = T(1); r.gy = T(1); }
-                else if (fop == DE_B_SUB) { r.v = lx - ly; r.gx = T(1); r.gy = T(-1); }
-                else if (fop == DE_B_MUL) { r.v = lx * ly; r.gx = ly; r.gy = lx; }
-                else if (fop == DE_B_DIV) { r.v = lx / ly; r.gx = T(1) / ly; r.gy = -(r.v / ly); }
-                else r = binary_vg<T>(fop, lx, ly);
-                x = r.v;
-                if (rev) { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.gx * db[k] + r.gy * d[k]; }
-                else { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.gx * d[k] + r.gy * db[k]; }
+                DE_UNROLL for (int k = 0; k < GC; k++) d[k] = (r.g0 * sb[(1 + k) * RS] + r.g1 * sc[(1 + k) * RS]) + r.g2 * d[k];
+            } break;
+            default: break;
             }
-            // Validity (src/EvaluateDerivative.jl:239-242 tests x and dx after EVERY node).  Exact
-            // elision: x needs a test only where the lowering kept H_CHECK_OUT (the consumer would
-            // not propagate a non-finite x, de_lower.cpp); a non-finite d[k] ALWAYS survives to the
-            // root because every update is linear in it (g*Inf, Inf+c, NaN*g stay non-finite), so
-            // the gradient is tested once, below.
-            if (a.check && op != DOP_LOAD && (hdr & H_CHECK_OUT)) poison = M<T>::fma(x, T(0), poison);
         }
+        // a non-finite d[k] always survives to the root (every update is linear in it), so the gradient
+        // is validity-tested once, here; x was tested where the lowering kept a test (H_CHECK_OUT)
         if (a.check) {
             poison = M<T>::fma(x, T(0), poison);
             DE_UNROLL for (int k = 0; k < GC; k++) poison = M<T>::fma(d[k], T(0), poison);

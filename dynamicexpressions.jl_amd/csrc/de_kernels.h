@@ -42,8 +42,8 @@ struct EvalArgs {
 };
 
 struct GradArgs {
-    EvalArgs e;               // e.code is unused: the gradient kernel runs the GENERIC program
-    const Instr *generic_code; // device, +1 pad
+    EvalArgs e;               // e.code is unused: the gradient kernel runs the bound UNFOLDED program
+    const BoundInstr *generic_code; // device, +1 pad (bound form of the unfolded generic program)
     int32_t mode;             // de_grad_mode
     int32_t P;                // n_params (rows before the features in VARIABLE/BOTH)
     void *grad;               // device
