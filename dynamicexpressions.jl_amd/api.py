@@ -69,6 +69,13 @@ def library() -> C.CDLL:
         raise DeviceError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)")
     try:
+        # torch ships its own libamdhip64; import it FIRST so that the process has exactly one HIP
+        # runtime (two runtimes in one process do not see the device).  Without torch (e.g. the Julia
+        # shim) libde_hip.so simply uses /opt/rocm's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # pragma: no cover
+            pass
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise DeviceError(f"cannot load {LIB_PATH}: {e}") from e
