@@ -320,16 +320,16 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
             // generic (cold) operators through the noinline value+partials functions
 #define G_GEN_APPLY(OP, SRC_IS_ACC)                                                                \
     {                                                                                              \
-        const uint32_t op_ = (OP);                                                                 \
-        if (op_ < DE_B_ADD) {                                                                      \
-            const UG<T> r = unary_vg<T>(op_, SRC_IS_ACC ? x : xb);                                 \
+        const uint32_t gop_ = (OP);                                                                 \
+        if (gop_ < DE_B_ADD) {                                                                      \
+            const UG<T> r = unary_vg<T>(gop_, SRC_IS_ACC ? x : xb);                                 \
             x = r.y;                                                                               \
             if (SRC_IS_ACC) { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.g * d[k]; }          \
             else { DE_UNROLL for (int k = 0; k < GC; k++) d[k] = r.g * db[k]; }                    \
         } else {                                                                                   \
-            uint32_t fop = op_;                                                                    \
+            uint32_t fop = gop_;                                                                    \
             bool rev = false;                                                                      \
-            switch (op_) {                                                                         \
+            switch (gop_) {                                                                         \
             case DOP_RSUB: fop = DE_B_SUB; rev = true; break;                                      \
             case DOP_RDIV: fop = DE_B_DIV; rev = true; break;                                      \
             case DOP_RPOW: fop = DE_B_POW; rev = true; break;                                      \

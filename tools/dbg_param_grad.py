@@ -24,3 +24,17 @@ for t, tree in enumerate(trees):
             print(t, okm.mean(), de.string_tree(tree, ops)[:150], "rows bad:", np.unique(bad[:,0]), "n_c", len(consts))
             k, j = bad[0]
             print("  sample", j, "gpu", grads[t][k, j], "ref", gg[k, j], "y gpu", outg[t][j], "ref", yg[j])
+print("---- single-tree populations")
+for t in (52, 55, 10):
+    p1 = api.Population([trees[t]], ops, np.float32, n_features=F, n_params=P)
+    o1, g1, k1 = p1.eval_grad(X, False, params, classes)
+    tape, consts = de.flatten(trees[t], ops, np.float32)
+    t2, PX = oracle.parametric_to_plain(tape, X, params, classes)
+    yg, gg, _ = oracle.eval_grad_tree_array(t2, consts, PX, oracle.GRAD_CONSTANT, elementwise=True)
+    print(t, "alone: y max err", np.nanmax(np.abs(o1[0]-yg)), "in-pop: ", np.nanmax(np.abs(outg[t]-yg)))
+    w = p1.dump(0)
+    print("  n_instr", len(w))
+import ctypes as C
+for t in (51, 52):
+    n = api.library().de_program_dump(pop._h, t, None, 0, 0)
+    print("tree", t, "generic words", n, "n_consts", pop.n_consts[t], "cum consts", pop.n_consts[:t].sum())
