@@ -269,3 +269,49 @@ def test_abi_error_paths_on_device(api):
     assert lib.de_eval(ctx._h, pop._h, X.ctypes.data, 4, 2, None, out.ctypes.data, 3, ok.ctypes.data) == 1  # ld_out < N
     assert lib.de_eval(ctx._h, pop._h, None, 4, 2, None, out.ctypes.data, 4, ok.ctypes.data) == 1  # null X
     assert lib.de_eval(ctx._h, pop._h, X.ctypes.data, 4, 2, None, out.ctypes.data, 4, ok.ctypes.data) == 0
+
+
+def test_strided_buffers_through_the_c_abi(api):
+    """ldX > n_features (a view into a wider matrix) and ld_out > N, host pointers, raw C ABI."""
+    import ctypes as C
+    lib = api.library()
+    ctx = api.default_context()
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(8, seed=5)
+    pop = api.Population(trees, ops, np.float32, n_features=5)
+    N, ldX, ld_out = 1300, 9, 1400
+    g = np.random.Generator(np.random.PCG64(1))
+    big = g.standard_normal((N, ldX)).astype(np.float32)  # row j = sample j, first 5 entries are the features
+    out = np.full((8, ld_out), -7.0, np.float32)
+    ok = np.zeros(8, np.uint8)
+    assert lib.de_eval(ctx._h, pop._h, big.ctypes.data, N, ldX, None, out.ctypes.data, ld_out, ok.ctypes.data) == 0
+    X = np.asfortranarray(big[:, :5].T)
+    ref, okr = pop.eval(X)
+    np.testing.assert_array_equal(out[:, :N], ref)
+    assert np.all(out[:, N:] == -7.0)  # padding untouched
+    np.testing.assert_array_equal(ok.astype(bool), okr)
+
+
+def test_two_contexts_from_two_threads(api):
+    """One de_ctx_t per calling thread: concurrent evaluation gives the same
+    results as sequential evaluation."""
+    import threading
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(50, seed=9)
+    X = de.synth.random_X(5, 20000, seed=4)
+    ref, okr = api.Population(trees, ops, np.float32, n_features=5).eval(X)
+    results = {}
+
+    def work(i):
+        ctx = api.Context(0, stream=None)
+        pop = api.Population(trees, ops, np.float32, n_features=5, ctx=ctx)
+        for _ in range(3):
+            results[i] = pop.eval(X)
+        pop.close()
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(2):
+        np.testing.assert_array_equal(results[i][0][okr], ref[okr])
+        np.testing.assert_array_equal(results[i][1], okr)

@@ -189,3 +189,49 @@ def test_diff_has_no_validity_test(api):
     np.testing.assert_array_equal(np.isnan(d), np.isnan(do))  # (1/0)*1 + (-(Inf/0))*0 = NaN
     _, _, okg = api.eval_grad_tree_array(tree, X, ops, variable=True)
     assert not okg
+
+
+def test_random_population_diff_vs_oracle(api):
+    """eval_diff_tree_array on a random population: every direction equals the matching row of
+    the variable-mode Jacobian bit for bit (same arithmetic), and matches the oracle."""
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(40, seed=77)
+    X = de.synth.random_X(5, 900, seed=3)
+    pop = api.Population(trees, ops, np.float32, n_features=5)
+    _, grads, _ = pop.eval_grad(X, True)
+    for direction in (1, 3, 5):
+        out, dout, ok = pop.eval_diff(X, direction)
+        assert ok.all()
+        for t, tree in enumerate(trees):
+            np.testing.assert_array_equal(dout[t], grads[t][direction - 1])
+            tape, consts = de.flatten(tree, ops, np.float32)
+            yo, do, _ = oracle.eval_diff_tree_array(tape, consts, X, direction - 1)
+            m = np.isfinite(do) & np.isfinite(yo)
+            if m.any():
+                scale = np.max(np.abs(do[m])) + 1e-30
+                assert np.mean(np.abs(dout[t][m] - do[m]) <= 1e-4 * np.abs(do[m]) + 1e-6 * scale) > 0.97
+
+
+def test_full_size_gradient_properties_config_C3(api):
+    """BASELINE config 3 at full size (1000 trees x 10^6, variable=true): the head of every
+    Jacobian equals a separate small launch; flags are the AND over a 4-way sample split."""
+    import torch
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(1000, seed=0xDE02)
+    N = 10**6
+    g = torch.Generator(device="cuda").manual_seed(1)
+    Xd = torch.randn((N, 5), generator=g, device="cuda", dtype=torch.float32).t()
+    pop = api.Population(trees, ops, np.float32, n_features=5)
+    out, grads, ok = pop.eval_grad(Xd, True)
+    out_h, grads_h, ok_h = pop.eval_grad(Xd[:, :1536], True)
+    torch.cuda.synchronize()
+    for t in range(0, 1000, 37):
+        if bool(ok[t]):
+            assert torch.equal(grads[t][:, :1536], grads_h[t])
+            assert torch.equal(out[t, :1536], out_h[t])
+    parts = []
+    for i in range(4):
+        sl = Xd[:, i * (N // 4):(i + 1) * (N // 4)].t().contiguous().t()
+        parts.append(pop.eval_grad(sl, True)[2])
+    assert torch.equal(ok, parts[0] & parts[1] & parts[2] & parts[3])
+    assert 50 < int(ok.sum()) < 1000
