@@ -448,9 +448,13 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
 // as clean straight-line code.  Handler addresses are taken on the device
 // (de_fill_handlers), read back once per process, and bound into the instruction stream as
 // 32-bit offsets by the host (de_api.cpp).  G = 1, 256 threads per workgroup.
+// The validity poison is accumulated two lanes wide for Float32 so that one v_pk_fma_f32 tests two
+// samples (2 VALU per tested vector instead of 4).
+template <typename T> struct PoisonOf { typedef T type; };
+template <> struct PoisonOf<float> { typedef float type __attribute__((ext_vector_type(2))); };
 template <typename T> struct HState {
     typename VecOf<T>::type acc;
-    T poison;
+    typename PoisonOf<T>::type poison;
 };
 // ONE call signature for every handler (several call sites with different signatures make the
 // compiler shuffle the returned state through a dozen v_movs per call):
@@ -470,9 +474,21 @@ template <> __device__ __forceinline__ double imm_from<double>(uint64_t b) { ret
 #define LDSP(T, addr) (reinterpret_cast<__attribute__((address_space(3))) typename VecOf<T>::type *>((uintptr_t)(addr)))
 template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, typename ImmBits<T>::type);
 
-template <typename T> __device__ __forceinline__ void hpoison(T &poison, const typename VecOf<T>::type &v) {
-    DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) poison = M<T>::fma(v[i], T(0), poison);
+__device__ __forceinline__ void hpoison_impl(PoisonOf<float>::type &poison, const VecOf<float>::type &v) {
+    typedef PoisonOf<float>::type P2;
+    const P2 z = {0.0f, 0.0f};
+    poison = __builtin_elementwise_fma(P2{v[0], v[1]}, z, poison);
+    poison = __builtin_elementwise_fma(P2{v[2], v[3]}, z, poison);
 }
+__device__ __forceinline__ void hpoison_impl(double &poison, const VecOf<double>::type &v) {
+    poison = ::fma(v[0], 0.0, poison);
+    poison = ::fma(v[1], 0.0, poison);
+}
+template <typename T> __device__ __forceinline__ void hpoison(typename PoisonOf<T>::type &poison, const typename VecOf<T>::type &v) {
+    hpoison_impl(poison, v);
+}
+__device__ __forceinline__ bool poison_set(const PoisonOf<float>::type &p) { return (p[0] != p[0]) | (p[1] != p[1]); }
+__device__ __forceinline__ bool poison_set(const double &p) { return p != p; }
 template <typename T> __device__ __noinline__ HState<T> h_load_row(HARGS) { st.acc = *LDSP(T, la); return st; }
 template <typename T> __device__ __noinline__ HState<T> h_load_const(HARGS) {
     const T c = imm_from<T>(imm);
@@ -633,7 +649,7 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
         pe = code_off[tree + 1];
         HState<T> st;
         DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
-        st.poison = T(0);
+        st.poison = typename PoisonOf<T>::type{};
         U32x4 nxt = code[pc];
         for (; pc < pe; ++pc) {
             const U32x4 w = nxt;
@@ -662,7 +678,7 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
             av.v[0] = st.acc;
             store_ragged<T, 1>(o, av, a.N - (base + tid * VW), TILE);
         }
-        if (__ballot(st.poison != st.poison) != 0ull) flag_incomplete(a.ok + tree);
+        if (__ballot(poison_set(st.poison)) != 0ull) flag_incomplete(a.ok + tree);
     }
 }
 
