@@ -183,7 +183,7 @@ def main():
                          "note": "X tile reused by k_eff trees from LDS: HBM traffic ~= the output; the kernel is "
                                  "VALU/scalar-issue bound (DESIGN.md §Roofline)"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0)
             Ns = min(N, 10**6)
             Xh = np.asfortranarray(X[:, :Ns].t().contiguous().cpu().numpy().T)
             res["cpu_baseline"] = cpu_baseline(all_trees, ops, Xh)
