@@ -44,6 +44,8 @@ WORKLOADS = {
     "C2": dict(n_trees=1000, N=10**6, desc="1000 random depth<=15 20-node trees x (5 x 10^6) Float32"),
     "C3": dict(n_trees=1000, N=10**6, grad=True,
                desc="1000 random depth<=15 20-node trees x (5 x 10^6) Float32, eval_grad_tree_array(variable=true)"),
+    "loss": dict(n_trees=1000, N=10**7, loss=True,
+                 desc="1000 random depth<=15 20-node trees x (5 x 10^7) Float32, fused sum(abs2, tree(X) .- y)"),
     "tiny": dict(n_trees=64, N=10**5, desc="64 trees x (5 x 10^5) Float32 (plumbing)"),
 }
 
@@ -108,16 +110,23 @@ def main():
     pop = api.Population(trees, ops, np.float32, n_features=5, ctx=ctx)
     g = torch.Generator(device=dev).manual_seed(1)  # same X on every rank (replicated)
     X = torch.randn((N, 5), generator=g, device=dev, dtype=torch.float32).t()  # [5, N] feature-fastest
-    out = torch.empty((len(trees), N), device=dev, dtype=torch.float32)
+    out = None if wl.get("loss") else torch.empty((len(trees), N), device=dev, dtype=torch.float32)
     ok = torch.empty(len(trees), device=dev, dtype=torch.uint8)
     lib = api.library()
     is_grad = bool(wl.get("grad"))
+    is_loss = bool(wl.get("loss"))
+    if is_loss:
+        yv = torch.randn(N, generator=g, device=dev, dtype=torch.float32)
+        lossv = torch.empty(len(trees), device=dev, dtype=torch.float32)
     grad = torch.empty(len(trees) * 5 * N, device=dev, dtype=torch.float32) if is_grad else None
 
     def step():
         if is_grad:
             ctx.check(lib.de_eval_grad(ctx._h, pop._h, X.data_ptr(), N, 5, None, 0, out.data_ptr(), N,
                                        grad.data_ptr(), None, ok.data_ptr()))
+        elif is_loss:
+            ctx.check(lib.de_eval_loss(ctx._h, pop._h, X.data_ptr(), N, 5, None, yv.data_ptr(), None, 0,
+                                       lossv.data_ptr(), ok.data_ptr()))
         else:
             ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
         if world > 1:
@@ -154,6 +163,9 @@ def main():
         units = len(trees) * N  # tree-samples per launch (this rank's shard)
         if is_grad:  # one tree per X pass, writes x + 5 gradient rows: (F + 1 + F)*s  
             k_eff, b_unit = 1, float((2 * F_FEATURES + 1) * ELEM)
+        elif is_loss:  # X (+ y) tile staged once per chunk of trees, nothing written but the partial sums
+            k_eff = plan["trees_per_chunk"]
+            b_unit = (F_FEATURES + 1) * ELEM / k_eff + 4 * ELEM / plan["tile"]
         else:  # X tile staged once per chunk of trees
             k_eff = plan["trees_per_chunk"]
             b_unit = F_FEATURES * ELEM / k_eff + ELEM

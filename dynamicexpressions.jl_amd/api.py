@@ -43,7 +43,7 @@ EXPORTS = [
     "de_opcode_degree", "de_status_string", "de_ctx_create", "de_ctx_destroy",
     "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create",
     "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
-    "de_program_n_grad", "de_program_dump", "de_lower_tape", "de_eval", "de_eval_grad", "de_eval_diff",
+    "de_program_n_grad", "de_program_dump", "de_lower_tape", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss",
     "de_eval_tree_array", "de_eval_plan", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
 ]
 
@@ -109,6 +109,7 @@ def library() -> C.CDLL:
     lib.de_lower_tape.restype = i64
     lib.de_lower_tape.argtypes = [C.c_int, vp, i64, vp, i64, i32, i32, u32, vp, i64, vp]
     lib.de_eval.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), vp, i64, vp]
+    lib.de_eval_loss.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), vp, vp, C.c_int32, vp, vp]
     lib.de_eval_grad.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), C.c_int, vp, i64, vp, vp, vp]
     lib.de_eval_diff.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, i64, vp]
     lib.de_eval_tree_array.argtypes = [vp, C.c_int, vp, i64, vp, i64, vp, i32, i64, u32, vp, vp]
@@ -386,6 +387,49 @@ class Population:
         ok = np.zeros(self.n_trees, dtype=np.uint8)
         self.ctx.check(lib.de_eval(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None,
                                    out.ctypes.data, N, ok.ctypes.data))
+        return out, ok.astype(bool)
+
+    def eval_loss(self, X, y, weights=None, loss: str = "L2", params=None, classes=None, class_base: int = 1):
+        """Fused ``sum_j w_j * l(tree_t(X[:, j]) - y[j])`` for every tree (l = abs2 for "L2", abs for
+        "L1") without materialising the [n_trees, N] output: what the reference's optimisation
+        consumers compute right after eval_tree_array (``sum(abs2, tree(X, operators) .- y)``,
+        test/test_optim.jl:95,99).  Returns (loss[n_trees], ok[n_trees]); loss is NaN where not ok."""
+        kind = {"L2": 0, "L1": 1}[loss]
+        ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        if F < self.n_features:
+            raise ValueError(f"X has {F} features but the trees use feature {self.n_features}")
+        keep = [keep_x]
+        pa = self._param_args(params, classes, class_base, N, keep)
+        lib = library()
+
+        def vec(v, name):
+            if v is None:
+                return None
+            if is_t:
+                import torch
+                v = torch.as_tensor(v, dtype=keep_x.dtype, device=keep_x.device).contiguous()
+                if v.numel() != N:
+                    raise ValueError(f"{name} must have {N} entries")
+                keep.append(v)
+                return v.data_ptr()
+            v = np.ascontiguousarray(v, dtype=self.dtype)
+            if v.size != N:
+                raise ValueError(f"{name} must have {N} entries")
+            keep.append(v)
+            return v.ctypes.data
+
+        yp, wp = vec(y, "y"), vec(weights, "weights")
+        if is_t:
+            import torch
+            out = torch.empty(self.n_trees, dtype=keep_x.dtype, device=keep_x.device)
+            ok = torch.empty(self.n_trees, dtype=torch.uint8, device=keep_x.device)
+            self.ctx.check(lib.de_eval_loss(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None,
+                                            yp, wp, kind, out.data_ptr(), ok.data_ptr()))
+            return out, ok.bool()
+        out = np.empty(self.n_trees, dtype=self.dtype)
+        ok = np.zeros(self.n_trees, dtype=np.uint8)
+        self.ctx.check(lib.de_eval_loss(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None,
+                                        yp, wp, kind, out.ctypes.data, ok.ctypes.data))
         return out, ok.astype(bool)
 
     def eval_grad(self, X, variable: Union[bool, str] = False, params=None, classes=None,

@@ -45,7 +45,7 @@ struct de_ctx {
     bool timed = false;
     std::string err;
     const char *last_kernel = "";
-    DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2, sGoff, sNg;
+    DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2, sGoff, sNg, sY, sW, sLoss, sPartial, sSeg;
 };
 
 struct de_program {
@@ -227,7 +227,7 @@ int de_ctx_destroy(de_ctx_t *c) {
     if (!c) return DE_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg}) b->release();
+    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg}) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -696,12 +696,38 @@ static int check_param_args(de_ctx *c, const de_program *p, const de_param_args_
     return DE_OK;
 }
 
+struct LossReq {
+    const void *y, *w;
+    int32_t kind;
+    void *loss;
+};
+
+static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
+                     void *out, int64_t ld_out, uint8_t *ok, const LossReq *lr);
+
 int de_eval(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
             void *out, int64_t ld_out, uint8_t *ok) {
     if (!c || !p) return DE_ERR_INVALID_ARG;
-    if (p->ctx != c) return fail(c, DE_ERR_INVALID_ARG, "program belongs to another context");
     if (N < 0 || !ok || (p->n_trees > 0 && N > 0 && (!X || !out))) return fail(c, DE_ERR_INVALID_ARG, "null buffer");
-    if (ldX < p->n_features || ld_out < N) return fail(c, DE_ERR_INVALID_ARG, "ldX < n_features or ld_out < N");
+    if (ld_out < N) return fail(c, DE_ERR_INVALID_ARG, "ld_out < N");
+    return eval_impl(c, p, X, N, ldX, pa, out, ld_out, ok, nullptr);
+}
+
+int de_eval_loss(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
+                 const void *y, const void *w, int32_t loss_kind, void *loss, uint8_t *ok) {
+    if (!c || !p) return DE_ERR_INVALID_ARG;
+    if (N < 0 || !ok || (p->n_trees > 0 && (!loss || (N > 0 && (!X || !y))))) return fail(c, DE_ERR_INVALID_ARG, "null buffer");
+    if (loss_kind != DE_LOSS_L2 && loss_kind != DE_LOSS_L1) return fail(c, DE_ERR_INVALID_ARG, "unknown loss_kind %d", loss_kind);
+    if (p->direct || !p->threaded)
+        return fail(c, DE_ERR_UNSUPPORTED, "de_eval_loss needs the LDS-tiled kernel (feature matrix too wide for this build)");
+    const LossReq lr{y, w, loss_kind, loss};
+    return eval_impl(c, p, X, N, ldX, pa, nullptr, N, ok, &lr);
+}
+
+static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
+                     void *out, int64_t ld_out, uint8_t *ok, const LossReq *lr) {
+    if (p->ctx != c) return fail(c, DE_ERR_INVALID_ARG, "program belongs to another context");
+    if (ldX < p->n_features) return fail(c, DE_ERR_INVALID_ARG, "ldX < n_features");
     int rc = check_param_args(c, p, pa);
     if (rc != DE_OK) return rc;
     if (p->n_trees == 0) return DE_OK;
@@ -711,15 +737,50 @@ int de_eval(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX,
     if (N == 0) { // nothing to evaluate: only the constant part of the flag (sum(empty) is finite)
         if (ok_dev) HIP_TRY(c, hipMemcpyAsync(ok, p->host_ok_eval.data(), (size_t)p->n_trees, hipMemcpyHostToDevice, c->stream));
         else std::memcpy(ok, p->host_ok_eval.data(), (size_t)p->n_trees);
+        if (lr) { // empty sum = 0; NaN where a constant already failed the flag
+            std::vector<unsigned char> z((size_t)p->n_trees * es);
+            for (int64_t t = 0; t < p->n_trees; t++) {
+                const double v = p->host_ok_eval[(size_t)t] ? 0.0 : std::nan("");
+                if (p->dtype == DE_F32) reinterpret_cast<float *>(z.data())[t] = (float)v;
+                else reinterpret_cast<double *>(z.data())[t] = v;
+            }
+            if (is_device_ptr(lr->loss)) {
+                HIP_TRY(c, hipMemcpyAsync(lr->loss, z.data(), z.size(), hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+            } else std::memcpy(lr->loss, z.data(), z.size());
+        }
         return DE_OK;
     }
     const bool direct = p->direct;
 
-    Staged sX, sOut, sOk, sPar, sCls;
+    Staged sX, sOut, sOk, sPar, sCls, sY, sW, sLoss;
+    LossArgs la;
+    std::memset(&la, 0, sizeof la);
     rc = stage_in(c, c->sX, X, (size_t)ldX * (size_t)N * es, &sX);
     if (rc) return rc;
-    rc = stage_out(c, c->sOut, out, ((size_t)(p->n_trees - 1) * (size_t)ld_out + (size_t)N) * es, &sOut);
-    if (rc) return rc;
+    if (lr) {
+        rc = stage_in(c, c->sY, lr->y, (size_t)N * es, &sY);
+        if (rc) return rc;
+        if (lr->w) {
+            rc = stage_in(c, c->sW, lr->w, (size_t)N * es, &sW);
+            if (rc) return rc;
+        }
+        rc = stage_out(c, c->sLoss, lr->loss, (size_t)p->n_trees * es, &sLoss);
+        if (rc) return rc;
+        size_t pb = 0, sb = 0;
+        loss_scratch_bytes(p->dtype, p->n_trees, N, &pb, &sb);
+        HIP_TRY(c, c->sPartial.reserve(pb));
+        HIP_TRY(c, c->sSeg.reserve(sb));
+        la.y = sY.dev;
+        la.w = lr->w ? sW.dev : nullptr;
+        la.kind = lr->kind;
+        la.partial = c->sPartial.p;
+        la.seg_sum = c->sSeg.p;
+        la.loss = sLoss.dev;
+    } else {
+        rc = stage_out(c, c->sOut, out, ((size_t)(p->n_trees - 1) * (size_t)ld_out + (size_t)N) * es, &sOut);
+        if (rc) return rc;
+    }
     // ok[] starts as the host-side (constant) part of the flag; the kernel only clears bytes
     if (ok_dev) {
         sOk.dev = ok;
@@ -761,10 +822,12 @@ int de_eval(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX,
     a.direct = direct;
     a.handler_base = p->handler_base;
     a.param_handler_off = p->param_handler_off;
+    a.loss = lr ? &la : nullptr;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, launch_eval(p->dtype, a, c->stream, &c->last_kernel));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
+    if (sLoss.staged) HIP_TRY(c, hipMemcpyAsync(lr->loss, sLoss.dev, (size_t)p->n_trees * es, hipMemcpyDeviceToHost, c->stream));
     if (sOut.staged) {
         for (int64_t t = 0; t < p->n_trees; t++) // rows may be strided in the caller's buffer
             HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(out) + (size_t)t * (size_t)ld_out * es,
@@ -772,7 +835,8 @@ int de_eval(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX,
                                       (size_t)N * es, hipMemcpyDeviceToHost, c->stream));
     }
     if (sOk.staged) HIP_TRY(c, hipMemcpyAsync(ok, sOk.dev, (size_t)p->n_trees, hipMemcpyDeviceToHost, c->stream));
-    if (sX.staged || sOut.staged || sOk.staged || sPar.staged || sCls.staged) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (sX.staged || sOut.staged || sOk.staged || sPar.staged || sCls.staged || sY.staged || sW.staged || sLoss.staged)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DE_OK;
 }
 

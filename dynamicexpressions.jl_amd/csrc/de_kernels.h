@@ -12,6 +12,17 @@ namespace de {
 
 constexpr int BLOCK = 256; // threads per workgroup = 4 wavefronts of 64
 
+// Fused loss epilogue of the threaded eval kernel (de_eval_loss): instead of storing out[t][j] the
+// kernel reduces sum_j w_j * l(out[t][j] - y[j]) per tree (per-wave partials + two fixed-order passes).
+struct LossArgs {
+    const void *y;    // device, N
+    const void *w;    // device, N, or null (= 1)
+    int32_t kind;     // de_loss_kind
+    void *partial;    // device scratch, loss_scratch_bytes().partial
+    void *seg_sum;    // device scratch (double), loss_scratch_bytes().seg
+    void *loss;       // device, n_trees values of the program's dtype
+};
+
 struct EvalArgs {
     // program
     const BoundInstr *code;   // device: all trees' BOUND instructions (de_bind.h), +1 pad
@@ -39,6 +50,7 @@ struct EvalArgs {
     bool direct; // feature matrix too wide for the LDS tile: gather features from global memory (flat-switch kernel)
     uint64_t handler_base;
     uint32_t param_handler_off;
+    const LossArgs *loss; // non-null: fused loss instead of the output store (threaded kernel only)
 };
 
 struct GradArgs {
@@ -64,6 +76,9 @@ bool eval_uses_threaded();
 
 // Launch plan of the eval kernel for (n_trees, N): samples per workgroup tile, tree chunks.
 void eval_plan(int dtype, int64_t n_trees, int64_t N, int32_t *tile, int32_t *n_chunks, int32_t *trees_per_chunk);
+
+// Scratch the fused-loss reduction needs for (dtype, n_trees, N).
+void loss_scratch_bytes(int dtype, int64_t n_trees, int64_t N, size_t *partial_bytes, size_t *seg_bytes);
 
 // LDS bytes the eval kernel needs for (dtype, F, n_slots); 0 if it cannot fit.
 size_t eval_lds_bytes(int dtype, int F, int n_slots, int *K_out);

@@ -49,6 +49,11 @@ template <typename T> struct KArgs {
     int64_t N, ldX, ld_out, ld_params, n_tiles;
     int32_t F, n_trees, trees_per_chunk, n_chunks, n_slots, xstride;
     int32_t classes_is_i64, class_base, vec_store;
+    // fused loss (de_eval_loss): residual target, optional weights, per-wave partial sums
+    const T *y;
+    const T *w;
+    T *partial; // [n_tiles][n_trees][4 waves]
+    int32_t loss_kind;
 };
 
 // A thread owns G groups of VW consecutive samples (VW*sizeof(T) = 16 bytes, one
@@ -592,7 +597,29 @@ template <typename T> __global__ void de_fill_handlers(uint64_t *t) {
 #undef HU
 }
 
-template <typename T, bool PARAMS>
+// Sum over the 64 lanes of a wavefront; the total is valid in lane 63.  Float32: DPP row
+// operations fused into the adds (no LDS traffic); Float64: cross-lane shuffles.
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+#define DE_DPP_ADD(CTRL, ROWMASK)                                                                          \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+    DE_DPP_ADD(0x111, 0xf) // row_shr:1
+    DE_DPP_ADD(0x112, 0xf) // row_shr:2
+    DE_DPP_ADD(0x114, 0xf) // row_shr:4   (bound_ctrl off + old = 0: lanes without a source add 0)
+    DE_DPP_ADD(0x118, 0xf) // row_shr:8   -> lane 15 of every row holds the row sum
+    DE_DPP_ADD(0x142, 0xa) // row_bcast:15 into rows 1 and 3
+    DE_DPP_ADD(0x143, 0xc) // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+#undef DE_DPP_ADD
+    return v;
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+    DE_UNROLL for (int m = 1; m < 64; m <<= 1) {
+        const double o = __shfl_up(v, m, 64);
+        if ((int)(threadIdx.x & 63) >= m) v += o;
+    }
+    return v;
+}
+
+template <typename T, bool PARAMS, bool LOSS = false>
 __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a, const uint64_t hbase, const uint32_t param_off) {
     typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
@@ -642,6 +669,17 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
     // LDS byte address of this thread's vector in row 0 (the dynamic LDS segment starts at 0)
     // (the low 32 bits of a flat pointer into LDS are the LDS byte offset)
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw + tid * 16;
+    // fused loss: this thread's residual targets and weights stay in registers for every tree of
+    // the chunk; samples past N get weight 0 (their X columns are clamped copies of the last one)
+    V yv, wv;
+    if constexpr (LOSS) {
+        DE_UNROLL for (int i = 0; i < VW; i++) {
+            const int64_t j = base + tid * VW + i;
+            const int64_t jj = j < last ? j : last;
+            yv[i] = a.y[jj];
+            wv[i] = j <= last ? (a.w ? a.w[jj] : T(1)) : T(0);
+        }
+    }
 
     int pe = code_off[t0];
     for (int tree = t0; tree < t1; ++tree) {
@@ -670,16 +708,54 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
             else imm = ((uint64_t)w.w << 32) | w.z;
             st = fn(st, lds0 + w.y, imm); // w.y = row byte offset | aux << 24 (no carry: LDS < 2^18 bytes)
         }
-        T *__restrict__ o = a.out + (int64_t)tree * a.ld_out + base + tid * VW;
-        if (full && a.vec_store) {
-            *reinterpret_cast<V *>(o) = st.acc;
+        if constexpr (LOSS) {
+            // sum_j w_j * l(out_j - y_j) over this wave's 64*VW samples -> one partial per (tile, tree, wave)
+            T s = T(0);
+            DE_UNROLL for (int i = 0; i < VW; i++) {
+                const T e = st.acc[i] - yv[i];
+                const T l = a.loss_kind == DE_LOSS_L1 ? M<T>::abs(e) : e * e;
+                s += wv[i] != T(0) ? wv[i] * l : T(0); // weight 0 really excludes the sample (0 * Inf would be NaN)
+            }
+            s = wave_sum_to_lane63(s);
+            if ((tid & 63) == 63) a.partial[((int64_t)tm.tile * a.n_trees + tree) * 4 + (tid >> 6)] = s;
         } else {
-            VG<T, 1> av;
-            av.v[0] = st.acc;
-            store_ragged<T, 1>(o, av, a.N - (base + tid * VW), TILE);
+            T *__restrict__ o = a.out + (int64_t)tree * a.ld_out + base + tid * VW;
+            if (full && a.vec_store) {
+                *reinterpret_cast<V *>(o) = st.acc;
+            } else {
+                VG<T, 1> av;
+                av.v[0] = st.acc;
+                store_ragged<T, 1>(o, av, a.N - (base + tid * VW), TILE);
+            }
         }
         if (__ballot(poison_set(st.poison)) != 0ull) flag_incomplete(a.ok + tree);
     }
+}
+
+// ---- fused loss, passes 2 and 3: deterministic fixed-order reduction of the per-wave partials.
+// Pass 2: thread = one (tree, wave) column, block row = one segment of tiles; coalesced reads.
+template <typename T>
+__global__ void __launch_bounds__(256) de_loss_reduce_tiles_kernel(const T *__restrict__ partial, int64_t n_cols, int64_t n_tiles,
+                                                                  int64_t tiles_per_seg, double *__restrict__ seg_sum) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= n_cols) return;
+    const int64_t r0 = (int64_t)blockIdx.y * tiles_per_seg;
+    const int64_t r1 = r0 + tiles_per_seg < n_tiles ? r0 + tiles_per_seg : n_tiles;
+    double s = 0.0;
+    for (int64_t r = r0; r < r1; ++r) s += (double)partial[r * n_cols + col];
+    seg_sum[(int64_t)blockIdx.y * n_cols + col] = s;
+}
+// Pass 3: thread = one tree; NaN where the evaluation was incomplete (what `tree(X)` NaN-fills to,
+// src/EvaluationHelpers.jl:29-33, gives any sum-type loss).
+template <typename T>
+__global__ void __launch_bounds__(256) de_loss_finish_kernel(const double *__restrict__ seg_sum, int64_t n_trees, int32_t n_segs,
+                                                            const uint8_t *__restrict__ ok, T *__restrict__ loss) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_trees) return;
+    double s = 0.0;
+    for (int32_t g = 0; g < n_segs; ++g)
+        for (int w = 0; w < 4; ++w) s += seg_sum[((int64_t)g * n_trees + t) * 4 + w];
+    loss[t] = ok[t] ? (T)s : M<T>::nan();
 }
 
 // ---------------------------------------------------------------------------
@@ -824,6 +900,8 @@ hipError_t eval_handler_table(int dtype, uint64_t *table) {
 
 bool eval_uses_threaded() { return env_int("DE_EVAL_THREADED", 1) != 0 && env_int("DE_EVAL_G", 1) == 1 && env_int("DE_EVAL_BLOCK", 256) == 256; }
 
+int32_t loss_segments(int64_t n_tiles);
+
 template <typename T>
 static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const char **kname) {
     constexpr int VW = VecOf<T>::W;
@@ -856,13 +934,40 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const size_t lds = (size_t)(a.F + a.n_slots) * 257 * 16;
     void (*kern)(const KArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_eval_threaded_kernel<T, true> : de_eval_threaded_kernel<T, false>;
+    a.y = a.w = nullptr;
+    a.partial = nullptr;
+    a.loss_kind = 0;
+    if (e.loss) {
+        kern = e.uses_params ? de_eval_threaded_kernel<T, true, true> : de_eval_threaded_kernel<T, false, true>;
+        a.y = static_cast<const T *>(e.loss->y);
+        a.w = static_cast<const T *>(e.loss->w);
+        a.partial = static_cast<T *>(e.loss->partial);
+        a.loss_kind = e.loss->kind;
+    }
     if (kname) *kname = "de_eval_threaded_kernel";
     if (lds > 64 * 1024) {
         hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (st != hipSuccess) return st;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a, e.handler_base, e.param_handler_off);
+    hipError_t st = hipGetLastError();
+    if (st != hipSuccess || !e.loss) return st;
+    const int64_t n_cols = (int64_t)e.n_trees * 4;
+    const int32_t n_segs = loss_segments(a.n_tiles);
+    const int64_t tps = (a.n_tiles + n_segs - 1) / n_segs;
+    hipLaunchKernelGGL(de_loss_reduce_tiles_kernel<T>, dim3((unsigned)((n_cols + 255) / 256), (unsigned)n_segs), dim3(256), 0, stream,
+                       a.partial, n_cols, a.n_tiles, tps, static_cast<double *>(e.loss->seg_sum));
+    hipLaunchKernelGGL(de_loss_finish_kernel<T>, dim3((unsigned)((e.n_trees + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<const double *>(e.loss->seg_sum), (int64_t)e.n_trees, n_segs, e.ok, static_cast<T *>(e.loss->loss));
     return hipGetLastError();
+}
+
+int32_t loss_segments(int64_t n_tiles) { return (int32_t)(n_tiles < 64 ? (n_tiles < 1 ? 1 : n_tiles) : 64); }
+void loss_scratch_bytes(int dtype, int64_t n_trees, int64_t N, size_t *partial_bytes, size_t *seg_bytes) {
+    const int64_t tile = 256 * (dtype == DE_F32 ? 4 : 2);
+    const int64_t n_tiles = (N + tile - 1) / tile;
+    *partial_bytes = (size_t)n_tiles * (size_t)n_trees * 4 * (dtype == DE_F32 ? 4 : 8);
+    *seg_bytes = (size_t)loss_segments(n_tiles) * (size_t)n_trees * 4 * sizeof(double);
 }
 
 hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const char **kernel_name) {

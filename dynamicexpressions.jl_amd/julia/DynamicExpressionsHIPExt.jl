@@ -195,6 +195,30 @@ function eval_population(pop::HIPPopulation{T}, X::Matrix{T}) where {T}
     return out, ok .!= 0x00
 end
 
+"""
+    eval_population_loss(pop, X, y; weights=nothing, loss=:L2) -> (loss::Vector{T}, ok)
+
+`sum(abs2, trees[t](X) .- y)` (test/test_optim.jl:95,99) for every tree, reduced on the device:
+the `N × n_trees` output matrix is never written.  `loss[t]` is NaN where `ok[t]` is false.
+"""
+function eval_population_loss(
+    pop::HIPPopulation{T}, X::Matrix{T}, y::Vector{T}; weights::Union{Nothing,Vector{T}}=nothing,
+    loss::Symbol=:L2,
+) where {T}
+    F, N = size(X)
+    @assert F >= pop.n_features && length(y) == N
+    out = Vector{T}(undef, pop.n_trees)
+    ok = Vector{UInt8}(undef, pop.n_trees)
+    w = weights === nothing ? C_NULL : pointer(weights)
+    rc = GC.@preserve X y weights out ok ccall(
+        (:de_eval_loss, LIBDE), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32,
+         Ptr{Cvoid}, Ptr{UInt8}),
+        pop.ctx.handle, pop.handle, X, N, F, C_NULL, y, w, loss === :L1 ? 1 : 0, out, ok)
+    check(pop.ctx, rc)
+    return out, ok .!= 0x00
+end
+
 """Forward-mode gradient of one tree: `(evaluation, gradient(n_grad × N), complete)` like
 `eval_grad_tree_array(tree, cX, operators; variable)` (src/EvaluateDerivative.jl:193-228)."""
 function _hip_eval_grad_tree_array(

@@ -209,6 +209,21 @@ int de_eval_grad(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, in
 int de_eval_diff(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, int64_t ldX,
                  int32_t direction, void *out, void *dout, int64_t ld_out, uint8_t *ok);
 
+/* ---- fused loss (the consumer either side of the path) --------
+ * loss[t] = sum_j w_j * l(tree_t(X[:, j]) - y[j]),  l = abs2 (DE_LOSS_L2) or abs (DE_LOSS_L1);
+ * w == NULL means w_j = 1; w_j == 0 excludes sample j.  This is what every consumer of
+ * eval_tree_array in the reference's optimisation loop computes right after the call —
+ * `sum(abs2, tree(X, operators) .- y)` (test/test_optim.jl:95,99), the objective handed to Optim
+ * (ext/DynamicExpressionsOptimExt.jl:86-126) — fused into the evaluation so that the
+ * [n_trees, N] output never goes to HBM.  loss[t] is NaN where ok[t] == 0 (the callable sugar
+ * NaN-fills incomplete evaluations, src/EvaluationHelpers.jl:29-33).  The reduction order is
+ * fixed (per-wavefront partials, then two fixed-order passes in double), so results are
+ * reproducible run to run.  `loss` holds n_trees values of the program's dtype. */
+typedef enum de_loss_kind { DE_LOSS_L2 = 0, DE_LOSS_L1 = 1 } de_loss_kind_t;
+int de_eval_loss(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, int64_t ldX,
+                 const de_param_args_t *pargs, const void *y, const void *w, int32_t loss_kind,
+                 void *loss, uint8_t *ok);
+
 /* ---- one-shot convenience with the reference's single-tree signature ------- */
 int de_eval_tree_array(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, int64_t n_nodes,
                        const void *consts, int64_t n_consts, const void *X, int32_t n_features,
