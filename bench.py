@@ -46,6 +46,9 @@ WORKLOADS = {
                desc="1000 random depth<=15 20-node trees x (5 x 10^6) Float32, eval_grad_tree_array(variable=true)"),
     "loss": dict(n_trees=1000, N=10**7, loss=True,
                  desc="1000 random depth<=15 20-node trees x (5 x 10^7) Float32, fused sum(abs2, tree(X) .- y)"),
+    "lossgrad": dict(n_trees=1000, N=10**6, lossgrad=True,
+                     desc="1000 random depth<=15 20-node trees x (5 x 10^6) Float32, fused loss + d loss/d constants "
+                          "(optimiser callback, test/test_optim.jl:42-51)"),
     "tiny": dict(n_trees=64, N=10**5, desc="64 trees x (5 x 10^5) Float32 (plumbing)"),
 }
 
@@ -110,12 +113,16 @@ def main():
     pop = api.Population(trees, ops, np.float32, n_features=5, ctx=ctx)
     g = torch.Generator(device=dev).manual_seed(1)  # same X on every rank (replicated)
     X = torch.randn((N, 5), generator=g, device=dev, dtype=torch.float32).t()  # [5, N] feature-fastest
-    out = None if wl.get("loss") else torch.empty((len(trees), N), device=dev, dtype=torch.float32)
+    out = None if (wl.get("loss") or wl.get("lossgrad")) else torch.empty((len(trees), N), device=dev, dtype=torch.float32)
     ok = torch.empty(len(trees), device=dev, dtype=torch.uint8)
     lib = api.library()
     is_grad = bool(wl.get("grad"))
     is_loss = bool(wl.get("loss"))
-    if is_loss:
+    is_lossgrad = bool(wl.get("lossgrad"))
+    if is_lossgrad:
+        n_const = sum(pop.n_grad(t, 1) for t in range(len(trees)))
+        dlossv = torch.empty(max(n_const, 1), device=dev, dtype=torch.float32)
+    if is_loss or is_lossgrad:
         yv = torch.randn(N, generator=g, device=dev, dtype=torch.float32)
         lossv = torch.empty(len(trees), device=dev, dtype=torch.float32)
     grad = torch.empty(len(trees) * 5 * N, device=dev, dtype=torch.float32) if is_grad else None
@@ -124,6 +131,9 @@ def main():
         if is_grad:
             ctx.check(lib.de_eval_grad(ctx._h, pop._h, X.data_ptr(), N, 5, None, 0, out.data_ptr(), N,
                                        grad.data_ptr(), None, ok.data_ptr()))
+        elif is_lossgrad:
+            ctx.check(lib.de_eval_loss_grad(ctx._h, pop._h, X.data_ptr(), N, 5, None, 1, yv.data_ptr(), None, 0,
+                                            lossv.data_ptr(), dlossv.data_ptr(), None, ok.data_ptr()))
         elif is_loss:
             ctx.check(lib.de_eval_loss(ctx._h, pop._h, X.data_ptr(), N, 5, None, yv.data_ptr(), None, 0,
                                        lossv.data_ptr(), ok.data_ptr()))
@@ -163,6 +173,9 @@ def main():
         units = len(trees) * N  # tree-samples per launch (this rank's shard)
         if is_grad:  # one tree per X pass, writes x + 5 gradient rows: (F + 1 + F)*s  
             k_eff, b_unit = 1, float((2 * F_FEATURES + 1) * ELEM)
+        elif is_lossgrad:  # X (+ y) tile staged once per chunk of 32 trees; (1 + n_const) partials per wave
+            k_eff = 32
+            b_unit = (F_FEATURES + 1) * ELEM / k_eff + (1 + n_const / len(trees)) * 4 * ELEM / 256
         elif is_loss:  # X (+ y) tile staged once per chunk of trees, nothing written but the partial sums
             k_eff = plan["trees_per_chunk"]
             b_unit = (F_FEATURES + 1) * ELEM / k_eff + 4 * ELEM / plan["tile"]

@@ -43,7 +43,7 @@ EXPORTS = [
     "de_opcode_degree", "de_status_string", "de_ctx_create", "de_ctx_destroy",
     "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create",
     "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
-    "de_program_n_grad", "de_program_dump", "de_lower_tape", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss",
+    "de_program_n_grad", "de_program_dump", "de_lower_tape", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad",
     "de_eval_tree_array", "de_eval_plan", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
 ]
 
@@ -110,6 +110,7 @@ def library() -> C.CDLL:
     lib.de_lower_tape.argtypes = [C.c_int, vp, i64, vp, i64, i32, i32, u32, vp, i64, vp]
     lib.de_eval.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), vp, i64, vp]
     lib.de_eval_loss.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), vp, vp, C.c_int32, vp, vp]
+    lib.de_eval_loss_grad.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), C.c_int, vp, vp, C.c_int32, vp, vp, vp, vp]
     lib.de_eval_grad.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), C.c_int, vp, i64, vp, vp, vp]
     lib.de_eval_diff.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, i64, vp]
     lib.de_eval_tree_array.argtypes = [vp, C.c_int, vp, i64, vp, i64, vp, i32, i64, u32, vp, vp]
@@ -431,6 +432,59 @@ class Population:
         self.ctx.check(lib.de_eval_loss(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None,
                                         yp, wp, kind, out.ctypes.data, ok.ctypes.data))
         return out, ok.astype(bool)
+
+    def eval_loss_grad(self, X, y, weights=None, loss: str = "L2", variable: Union[bool, str] = False,
+                       params=None, classes=None, class_base: int = 1):
+        """Fused loss and its gradient w.r.t. the rows ``variable`` selects (default: the constants) —
+        the body of the reference's optimiser callback (test/test_optim.jl:42-51: ``G[i] = sum_j
+        2(yhat_j - y_j) * dyhat_dconstants[i, j]``) without the [n_grad, N] Jacobian.  ``loss="pullback"``
+        treats ``y`` as the cotangent dY of the ChainRules pullback (src/ChainRules.jl:56-77).
+        Returns (loss[n_trees], [dloss_t[n_grad_t] per tree], ok)."""
+        kind = {"L2": 0, "L1": 1, "pullback": 2}[loss]
+        mode = _grad_mode(variable)
+        ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        if F < self.n_features:
+            raise ValueError(f"X has {F} features but the trees use feature {self.n_features}")
+        keep = [keep_x]
+        pa = self._param_args(params, classes, class_base, N, keep)
+        lib = library()
+        ng = np.array([self.n_grad(t, mode) for t in range(self.n_trees)], dtype=np.int64)
+        offs = np.zeros(self.n_trees + 1, dtype=np.int64)
+        np.cumsum(ng, out=offs[1:])
+        total = max(int(offs[-1]), 1)
+
+        def vec(v, name):
+            if v is None:
+                return None
+            if is_t:
+                import torch
+                v = torch.as_tensor(v, dtype=keep_x.dtype, device=keep_x.device).contiguous()
+                n = v.numel()
+                p_ = v.data_ptr()
+            else:
+                v = np.ascontiguousarray(v, dtype=self.dtype)
+                n = v.size
+                p_ = v.ctypes.data
+            if n != N:
+                raise ValueError(f"{name} must have {N} entries")
+            keep.append(v)
+            return p_
+
+        yp, wp = vec(y, "y"), vec(weights, "weights")
+        if is_t:
+            import torch
+            lo = torch.empty(self.n_trees, dtype=keep_x.dtype, device=keep_x.device)
+            dl = torch.empty(total, dtype=keep_x.dtype, device=keep_x.device)
+            ok = torch.empty(self.n_trees, dtype=torch.uint8, device=keep_x.device)
+            self.ctx.check(lib.de_eval_loss_grad(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None, mode,
+                                                 yp, wp, kind, lo.data_ptr(), dl.data_ptr(), offs.ctypes.data, ok.data_ptr()))
+            return lo, [dl[offs[t]:offs[t + 1]] for t in range(self.n_trees)], ok.bool()
+        lo = np.empty(self.n_trees, dtype=self.dtype)
+        dl = np.empty(total, dtype=self.dtype)
+        ok = np.zeros(self.n_trees, dtype=np.uint8)
+        self.ctx.check(lib.de_eval_loss_grad(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None, mode,
+                                             yp, wp, kind, lo.ctypes.data, dl.ctypes.data, offs.ctypes.data, ok.ctypes.data))
+        return lo, [dl[offs[t]:offs[t + 1]] for t in range(self.n_trees)], ok.astype(bool)
 
     def eval_grad(self, X, variable: Union[bool, str] = False, params=None, classes=None,
                   class_base: int = 1):

@@ -45,7 +45,7 @@ struct de_ctx {
     bool timed = false;
     std::string err;
     const char *last_kernel = "";
-    DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2, sGoff, sNg, sY, sW, sLoss, sPartial, sSeg;
+    DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2, sGoff, sNg, sY, sW, sLoss, sPartial, sSeg, sDloss, sColOff, sDoff;
 };
 
 struct de_program {
@@ -227,7 +227,7 @@ int de_ctx_destroy(de_ctx_t *c) {
     if (!c) return DE_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg}) b->release();
+    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff}) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1016,6 +1016,160 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
     }
     if (sOk.staged) HIP_TRY(c, hipMemcpyAsync(ok, sOk.dev, (size_t)p->n_trees, hipMemcpyDeviceToHost, c->stream));
     if (sX.staged || sOut.staged || sGrad.staged || sOk.staged || sPar.staged || sCls.staged) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DE_OK;
+}
+
+int de_eval_loss_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
+                      int mode, const void *y, const void *w, int32_t loss_kind, void *loss, void *dloss,
+                      const int64_t *dloss_offsets, uint8_t *ok) {
+    if (!c || !p) return DE_ERR_INVALID_ARG;
+    if (p->ctx != c) return fail(c, DE_ERR_INVALID_ARG, "program belongs to another context");
+    if (N < 0 || !ok || (p->n_trees > 0 && (!dloss || (N > 0 && (!X || !y))))) return fail(c, DE_ERR_INVALID_ARG, "null buffer");
+    if (ldX < p->n_features) return fail(c, DE_ERR_INVALID_ARG, "ldX < n_features");
+    if (mode != DE_GRAD_VARIABLE && mode != DE_GRAD_CONSTANT && mode != DE_GRAD_BOTH) return fail(c, DE_ERR_INVALID_ARG, "bad gradient mode");
+    if (loss_kind != DE_LOSS_L2 && loss_kind != DE_LOSS_L1 && loss_kind != DE_LOSS_PULLBACK)
+        return fail(c, DE_ERR_INVALID_ARG, "unknown loss_kind %d", loss_kind);
+    int rc = check_param_args(c, p, pa);
+    if (rc != DE_OK) return rc;
+    if (p->n_trees == 0) return DE_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t es = p->dtype == DE_F32 ? 4 : 8;
+    // per-tree geometry: tree t owns reduction columns col_off[t] (loss) .. col_off[t] + n_grad[t]
+    std::vector<int32_t> ng((size_t)p->n_trees);
+    std::vector<int64_t> coloff((size_t)p->n_trees + 1, 0), doff((size_t)p->n_trees);
+    int64_t span = 0, run = 0;
+    int32_t maxg = 0;
+    for (int64_t t = 0; t < p->n_trees; t++) {
+        const int32_t g = (int32_t)de_program_n_grad(p, t, mode);
+        ng[(size_t)t] = g;
+        maxg = std::max(maxg, g);
+        const int64_t off = dloss_offsets ? dloss_offsets[t] : run;
+        if (off < 0) return fail(c, DE_ERR_INVALID_ARG, "negative dloss offset");
+        doff[(size_t)t] = off;
+        run += g;
+        span = std::max(span, off + g);
+        coloff[(size_t)t + 1] = coloff[(size_t)t] + 1 + g;
+    }
+    const int64_t n_cols = coloff[(size_t)p->n_trees];
+    const bool ok_dev = is_device_ptr(ok);
+    if (N == 0) { // empty sums: 0, or NaN where a constant already fails the flag
+        std::vector<unsigned char> zl((size_t)p->n_trees * es), zd((size_t)std::max<int64_t>(span, 1) * es);
+        auto put = [&](unsigned char *b, int64_t i, double v) {
+            if (p->dtype == DE_F32) reinterpret_cast<float *>(b)[i] = (float)v;
+            else reinterpret_cast<double *>(b)[i] = v;
+        };
+        for (int64_t t = 0; t < p->n_trees; t++) {
+            const double v = p->host_ok_grad[(size_t)t] ? 0.0 : std::nan("");
+            put(zl.data(), t, v);
+            for (int32_t k = 0; k < ng[(size_t)t]; k++) put(zd.data(), doff[(size_t)t] + k, v);
+        }
+        for (int64_t t = 0; t < p->n_trees; t++) // only the entries each tree owns are written
+            if (ng[(size_t)t] > 0)
+                HIP_TRY(c, hipMemcpy(static_cast<char *>(dloss) + (size_t)doff[(size_t)t] * es, zd.data() + (size_t)doff[(size_t)t] * es,
+                                     (size_t)ng[(size_t)t] * es, hipMemcpyDefault));
+        if (loss) HIP_TRY(c, hipMemcpy(loss, zl.data(), zl.size(), hipMemcpyDefault));
+        HIP_TRY(c, hipMemcpy(ok, p->host_ok_grad.data(), (size_t)p->n_trees, hipMemcpyDefault));
+        return DE_OK;
+    }
+    const size_t lds_need = ((size_t)p->n_features + (size_t)p->n_slots * (1 + (size_t)std::min(maxg, 8))) * 260 * es;
+    if (lds_need > 160 * 1024) return fail(c, DE_ERR_UNSUPPORTED, "gradient kernel: LDS footprint too large for this tree shape");
+    rc = ensure_generic_code(c, p);
+    if (rc) return rc;
+
+    Staged sX, sY, sW, sLoss, sDl, sOk, sPar, sCls;
+    rc = stage_in(c, c->sX, X, (size_t)ldX * (size_t)N * es, &sX);
+    if (rc) return rc;
+    rc = stage_in(c, c->sY, y, (size_t)N * es, &sY);
+    if (rc) return rc;
+    if (w) {
+        rc = stage_in(c, c->sW, w, (size_t)N * es, &sW);
+        if (rc) return rc;
+    }
+    if (loss) {
+        rc = stage_out(c, c->sLoss, loss, (size_t)p->n_trees * es, &sLoss);
+        if (rc) return rc;
+    }
+    rc = stage_out(c, c->sDloss, dloss, (size_t)std::max<int64_t>(span, 1) * es, &sDl);
+    if (rc) return rc;
+    if (ok_dev) sOk.dev = ok;
+    else {
+        HIP_TRY(c, c->sOk.reserve((size_t)p->n_trees));
+        sOk.dev = c->sOk.p;
+        sOk.staged = true;
+    }
+    const int64_t n_tiles = (N + 255) / 256;
+    HIP_TRY(c, c->sPartial.reserve((size_t)n_tiles * (size_t)n_cols * 4 * es));
+    HIP_TRY(c, c->sSeg.reserve((size_t)loss_segments(n_tiles) * (size_t)n_cols * 4 * sizeof(double)));
+    HIP_TRY(c, c->sNg.reserve(ng.size() * sizeof(int32_t)));
+    HIP_TRY(c, c->sColOff.reserve(coloff.size() * sizeof(int64_t)));
+    HIP_TRY(c, c->sDoff.reserve(doff.size() * sizeof(int64_t)));
+    HIP_TRY(c, hipMemcpyAsync(sOk.dev, p->host_ok_grad.data(), (size_t)p->n_trees, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->sNg.p, ng.data(), ng.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->sColOff.p, coloff.data(), coloff.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->sDoff.p, doff.data(), doff.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    if (p->uses_params) {
+        rc = stage_in(c, c->sParams, pa->params, (size_t)pa->ld_params * (size_t)pa->n_classes * es, &sPar);
+        if (rc) return rc;
+        rc = stage_in(c, c->sClasses, pa->classes, (size_t)N * (pa->classes_is_i64 ? 8 : 4), &sCls);
+        if (rc) return rc;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // the pageable host vectors above must outlive their async copies
+
+    LossArgs la;
+    std::memset(&la, 0, sizeof la);
+    la.y = sY.dev;
+    la.w = w ? sW.dev : nullptr;
+    la.kind = loss_kind;
+    la.partial = c->sPartial.p;
+    la.seg_sum = c->sSeg.p;
+    la.loss = loss ? sLoss.dev : nullptr;
+    GradArgs g;
+    std::memset(&g, 0, sizeof g);
+    g.generic_code = p->d_gcode;
+    g.e.code_off = p->d_gcode_off;
+    g.e.n_trees = (int32_t)p->n_trees;
+    g.e.n_slots = p->n_slots;
+    g.e.uses_params = p->uses_params;
+    g.e.X = sX.dev;
+    g.e.N = N;
+    g.e.ldX = ldX;
+    g.e.F = p->n_features;
+    g.e.out = nullptr;
+    g.e.ld_out = N;
+    g.e.ok = static_cast<uint8_t *>(sOk.dev);
+    if (p->uses_params) {
+        g.e.params = sPar.dev;
+        g.e.ld_params = pa->ld_params;
+        g.e.classes = sCls.dev;
+        g.e.classes_is_i64 = pa->classes_is_i64;
+        g.e.class_base = pa->class_base;
+    }
+    g.mode = mode;
+    g.P = p->n_params;
+    g.grad = nullptr;
+    g.grad_off = nullptr;
+    g.n_grad = static_cast<const int32_t *>(c->sNg.p);
+    g.max_grad = maxg;
+    g.diff_direction = -1;
+    g.loss = &la;
+    g.col_off = static_cast<const int64_t *>(c->sColOff.p);
+    g.n_cols = n_cols;
+    g.dloss = sDl.dev;
+    g.dloss_off = static_cast<const int64_t *>(c->sDoff.p);
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(c, launch_grad(p->dtype, g, c->stream, &c->last_kernel));
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    if (sLoss.staged) HIP_TRY(c, hipMemcpyAsync(loss, sLoss.dev, (size_t)p->n_trees * es, hipMemcpyDeviceToHost, c->stream));
+    if (sDl.staged)
+        for (int64_t t = 0; t < p->n_trees; t++)
+            if (ng[(size_t)t] > 0)
+                HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(dloss) + (size_t)doff[(size_t)t] * es,
+                                          static_cast<char *>(sDl.dev) + (size_t)doff[(size_t)t] * es, (size_t)ng[(size_t)t] * es,
+                                          hipMemcpyDeviceToHost, c->stream));
+    if (sOk.staged) HIP_TRY(c, hipMemcpyAsync(ok, sOk.dev, (size_t)p->n_trees, hipMemcpyDeviceToHost, c->stream));
+    if (sX.staged || sY.staged || sW.staged || sLoss.staged || sDl.staged || sOk.staged || sPar.staged || sCls.staged)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DE_OK;
 }
 

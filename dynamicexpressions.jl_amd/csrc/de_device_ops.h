@@ -200,4 +200,27 @@ template <typename T> __device__ inline T dev_digamma(T x) {
     return r + M<T>::log(x) - T(0.5) / x + t;
 }
 
+// Sum over the 64 lanes of a wavefront; the total is valid in lane 63.  Float32: DPP row
+// operations fused into the adds (no LDS traffic); Float64: cross-lane shuffles.
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+#define DE_DPP_ADD(CTRL, ROWMASK)                                                                          \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+    DE_DPP_ADD(0x111, 0xf) // row_shr:1
+    DE_DPP_ADD(0x112, 0xf) // row_shr:2
+    DE_DPP_ADD(0x114, 0xf) // row_shr:4   (bound_ctrl off + old = 0: lanes without a source add 0)
+    DE_DPP_ADD(0x118, 0xf) // row_shr:8   -> lane 15 of every row holds the row sum
+    DE_DPP_ADD(0x142, 0xa) // row_bcast:15 into rows 1 and 3
+    DE_DPP_ADD(0x143, 0xc) // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+#undef DE_DPP_ADD
+    return v;
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+    _Pragma("unroll") for (int m = 1; m < 64; m <<= 1) {
+        const double o = __shfl_up(v, m, 64);
+        if ((int)(threadIdx.x & 63) >= m) v += o;
+    }
+    return v;
+}
+
+
 } // namespace de

@@ -43,6 +43,13 @@ template <typename T> struct GArgs {
     int32_t F, P, n_trees, trees_per_chunk, n_chunks, n_slots, mode;
     int32_t classes_is_i64, class_base, uses_params, check;
     int32_t diff_g0; // >= 0: eval_diff mode — single component diff_g0, dense [n_trees, ld_out] output
+    // fused loss + pullback (de_eval_loss_grad): instead of storing x and d[k] the kernel reduces
+    //   sum_j w_j l(x_j - y_j)   and   sum_j w_j l'(x_j - y_j) d_k[j]   per wavefront
+    int32_t loss_mode;       // 0 = off, 1 + de_loss_kind otherwise
+    const T *y;
+    const T *w;              // may be null
+    T *partial;              // [n_tiles][n_cols][4 waves]; tree t owns columns col_off[t] .. col_off[t] + n_grad[t] (loss first)
+    const int64_t *col_off;  // n_trees + 1
 };
 
 template <typename T> __device__ __forceinline__ T gimm(uint32_t w2, uint32_t w3);
@@ -228,10 +235,16 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
     if (a.uses_params)
         cls = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj0]
                                 : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj0]) - a.class_base;
+    T yv = T(0), wv = T(0);
+    if (a.loss_mode) {
+        yv = a.y[jj0];
+        wv = live ? (a.w ? a.w[jj0] : T(1)) : T(0);
+    }
     __syncthreads();
 
     const ConstU4Ptr code = (ConstU4Ptr)(uintptr_t)a.code;
     const ConstI32Ptr code_off = (ConstI32Ptr)(uintptr_t)a.code_off;
+    const ConstI64Ptr col_off = (ConstI64Ptr)(uintptr_t)a.col_off;
     const ConstI32Ptr n_grad = (ConstI32Ptr)(uintptr_t)a.n_grad;
     const ConstI64Ptr grad_off = (ConstI64Ptr)(uintptr_t)a.grad_off;
     const int t0 = tm.chunk * a.trees_per_chunk;
@@ -385,7 +398,27 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
             poison = M<T>::fma(x, T(0), poison);
             DE_UNROLL for (int k = 0; k < GC; k++) poison = M<T>::fma(d[k], T(0), poison);
         }
-        if (live) {
+        if (a.loss_mode) {
+            const T e = x - yv;
+            T lp; // w * l'(e)
+            T l;  // w * l(e)
+            if (a.loss_mode == 1 + DE_LOSS_L2) { l = wv * (e * e); lp = wv * (T(2) * e); }
+            else if (a.loss_mode == 1 + DE_LOSS_L1) { l = wv * M<T>::abs(e); lp = wv * jl_sign(e); }
+            else { l = wv * (x * yv); lp = wv * yv; } // DE_LOSS_PULLBACK: y holds the cotangent dY
+            if (wv == T(0)) { l = T(0); lp = T(0); }  // weight 0 (and samples past N) really excludes the sample
+            const int64_t n_cols = col_off[a.n_trees];
+            T *__restrict__ pp = a.partial + ((int64_t)tm.tile * n_cols + col_off[tree]) * 4 + (tid >> 6);
+            if (g0 == 0) {
+                const T s = wave_sum_to_lane63(l);
+                if ((tid & 63) == 63) pp[0] = s;
+            }
+            DE_UNROLL for (int k = 0; k < GC; k++) {
+                if (g0 + k < G) { // wave-uniform
+                    const T s = wave_sum_to_lane63(wv == T(0) ? T(0) : lp * d[k]);
+                    if ((tid & 63) == 63) pp[(int64_t)(1 + g0 + k) * 4] = s;
+                }
+            }
+        } else if (live) {
             if (a.diff_g0 >= 0) {
                 if (a.out) a.out[(int64_t)tree * a.ld_out + base + tid] = x;
                 a.grad[(int64_t)tree * a.ld_out + base + tid] = d[0];
@@ -397,6 +430,29 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
             }
         }
         if (a.check && __ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree);
+    }
+}
+
+// Pass 3 of the fused loss+pullback reduction: thread = one tree; fixed summation order.  NaN where
+// the evaluation was incomplete (src/ChainRules.jl:62-64 `dX_constants_dY .= NaN`).
+template <typename T>
+__global__ void __launch_bounds__(256) de_loss_grad_finish_kernel(const double *__restrict__ seg_sum, int64_t n_trees, int64_t n_cols,
+                                                                 int32_t n_segs, const int64_t *__restrict__ col_off,
+                                                                 const int32_t *__restrict__ n_grad, const uint8_t *__restrict__ ok,
+                                                                 T *__restrict__ loss, T *__restrict__ dloss,
+                                                                 const int64_t *__restrict__ dloss_off) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_trees) return;
+    const int64_t c0 = col_off[t];
+    const int G = n_grad[t];
+    const bool good = ok[t] != 0;
+    for (int c = 0; c <= G; ++c) {
+        double s = 0.0;
+        for (int32_t g = 0; g < n_segs; ++g)
+            for (int w = 0; w < 4; ++w) s += seg_sum[((int64_t)g * n_cols + c0 + c) * 4 + w];
+        const T v = good ? (T)s : M<T>::nan();
+        if (c == 0) { if (loss) loss[t] = v; }
+        else dloss[dloss_off[t] + c - 1] = v;
     }
 }
 
@@ -432,6 +488,17 @@ static hipError_t launch_grad_t(const GradArgs &ga, int windows, hipStream_t str
     a.check = ga.diff_direction >= 0 ? 0 : 1;
     a.diff_g0 = ga.diff_direction >= 0 ? ga.P + ga.diff_direction : -1;
     a.code = ga.generic_code;
+    a.loss_mode = 0;
+    a.y = a.w = nullptr;
+    a.partial = nullptr;
+    a.col_off = nullptr;
+    if (ga.loss) {
+        a.loss_mode = 1 + ga.loss->kind;
+        a.y = static_cast<const T *>(ga.loss->y);
+        a.w = static_cast<const T *>(ga.loss->w);
+        a.partial = static_cast<T *>(ga.loss->partial);
+        a.col_off = ga.col_off;
+    }
     if (g_gcu == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -456,6 +523,15 @@ static hipError_t launch_grad_t(const GradArgs &ga, int windows, hipStream_t str
         if (st != hipSuccess) return st;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)windows), dim3(GBLK), lds, stream, a);
+    hipError_t st = hipGetLastError();
+    if (st != hipSuccess || !ga.loss) return st;
+    // passes 2 and 3 of the deterministic reduction (pass 2 is shared with de_eval_loss)
+    int32_t n_segs = 1;
+    st = launch_loss_reduce_tiles(sizeof(T) == 4 ? DE_F32 : DE_F64, a.partial, ga.n_cols * 4, a.n_tiles, ga.loss->seg_sum, &n_segs, stream);
+    if (st != hipSuccess) return st;
+    hipLaunchKernelGGL(de_loss_grad_finish_kernel<T>, dim3((unsigned)((e.n_trees + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<const double *>(ga.loss->seg_sum), (int64_t)e.n_trees, ga.n_cols, n_segs, ga.col_off, ga.n_grad,
+                       e.ok, static_cast<T *>(ga.loss->loss), static_cast<T *>(ga.dloss), ga.dloss_off);
     return hipGetLastError();
 }
 

@@ -63,6 +63,12 @@ struct GradArgs {
     const int32_t *n_grad;    // device, n_trees: G_t
     int32_t max_grad;         // max G_t
     int32_t diff_direction;   // >=0: eval_diff mode (single direction, output dout rows)
+    // fused loss + pullback (de_eval_loss_grad): loss->partial is [n_tiles(256 samples)][n_cols][4]
+    const LossArgs *loss;
+    const int64_t *col_off;   // device, n_trees + 1: tree t owns columns col_off[t] .. +n_grad[t] (loss first)
+    int64_t n_cols;           // = col_off[n_trees]
+    void *dloss;              // device: tree t's n_grad[t] reduced gradient entries at dloss_off[t]
+    const int64_t *dloss_off; // device, n_trees
 };
 
 // Returns hipSuccess or the failing HIP error.  `kernel_name` receives the symbol
@@ -79,6 +85,12 @@ void eval_plan(int dtype, int64_t n_trees, int64_t N, int32_t *tile, int32_t *n_
 
 // Scratch the fused-loss reduction needs for (dtype, n_trees, N).
 void loss_scratch_bytes(int dtype, int64_t n_trees, int64_t N, size_t *partial_bytes, size_t *seg_bytes);
+
+// Pass 2 of the fused-loss reductions: seg_sum[seg][col] = sum over the tiles of a segment of
+// partial[tile][col] (fixed order, double).  n_cols counts (column, wave) pairs.
+hipError_t launch_loss_reduce_tiles(int dtype, const void *partial, int64_t n_cols, int64_t n_tiles, void *seg_sum,
+                                    int32_t *n_segs, hipStream_t stream);
+int32_t loss_segments(int64_t n_tiles);
 
 // LDS bytes the eval kernel needs for (dtype, F, n_slots); 0 if it cannot fit.
 size_t eval_lds_bytes(int dtype, int F, int n_slots, int *K_out);

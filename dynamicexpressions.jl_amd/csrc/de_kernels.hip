@@ -597,28 +597,6 @@ template <typename T> __global__ void de_fill_handlers(uint64_t *t) {
 #undef HU
 }
 
-// Sum over the 64 lanes of a wavefront; the total is valid in lane 63.  Float32: DPP row
-// operations fused into the adds (no LDS traffic); Float64: cross-lane shuffles.
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-#define DE_DPP_ADD(CTRL, ROWMASK)                                                                          \
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
-    DE_DPP_ADD(0x111, 0xf) // row_shr:1
-    DE_DPP_ADD(0x112, 0xf) // row_shr:2
-    DE_DPP_ADD(0x114, 0xf) // row_shr:4   (bound_ctrl off + old = 0: lanes without a source add 0)
-    DE_DPP_ADD(0x118, 0xf) // row_shr:8   -> lane 15 of every row holds the row sum
-    DE_DPP_ADD(0x142, 0xa) // row_bcast:15 into rows 1 and 3
-    DE_DPP_ADD(0x143, 0xc) // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
-#undef DE_DPP_ADD
-    return v;
-}
-__device__ __forceinline__ double wave_sum_to_lane63(double v) {
-    DE_UNROLL for (int m = 1; m < 64; m <<= 1) {
-        const double o = __shfl_up(v, m, 64);
-        if ((int)(threadIdx.x & 63) >= m) v += o;
-    }
-    return v;
-}
-
 template <typename T, bool PARAMS, bool LOSS = false>
 __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a, const uint64_t hbase, const uint32_t param_off) {
     typedef typename VecOf<T>::type V;
@@ -900,8 +878,6 @@ hipError_t eval_handler_table(int dtype, uint64_t *table) {
 
 bool eval_uses_threaded() { return env_int("DE_EVAL_THREADED", 1) != 0 && env_int("DE_EVAL_G", 1) == 1 && env_int("DE_EVAL_BLOCK", 256) == 256; }
 
-int32_t loss_segments(int64_t n_tiles);
-
 template <typename T>
 static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const char **kname) {
     constexpr int VW = VecOf<T>::W;
@@ -952,13 +928,26 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a, e.handler_base, e.param_handler_off);
     hipError_t st = hipGetLastError();
     if (st != hipSuccess || !e.loss) return st;
-    const int64_t n_cols = (int64_t)e.n_trees * 4;
-    const int32_t n_segs = loss_segments(a.n_tiles);
-    const int64_t tps = (a.n_tiles + n_segs - 1) / n_segs;
-    hipLaunchKernelGGL(de_loss_reduce_tiles_kernel<T>, dim3((unsigned)((n_cols + 255) / 256), (unsigned)n_segs), dim3(256), 0, stream,
-                       a.partial, n_cols, a.n_tiles, tps, static_cast<double *>(e.loss->seg_sum));
+    int32_t n_segs = 1;
+    st = launch_loss_reduce_tiles(sizeof(T) == 4 ? DE_F32 : DE_F64, a.partial, (int64_t)e.n_trees * 4, a.n_tiles, e.loss->seg_sum, &n_segs, stream);
+    if (st != hipSuccess) return st;
     hipLaunchKernelGGL(de_loss_finish_kernel<T>, dim3((unsigned)((e.n_trees + 255) / 256)), dim3(256), 0, stream,
                        static_cast<const double *>(e.loss->seg_sum), (int64_t)e.n_trees, n_segs, e.ok, static_cast<T *>(e.loss->loss));
+    return hipGetLastError();
+}
+
+hipError_t launch_loss_reduce_tiles(int dtype, const void *partial, int64_t n_cols, int64_t n_tiles, void *seg_sum,
+                                    int32_t *n_segs_out, hipStream_t stream) {
+    const int32_t n_segs = loss_segments(n_tiles);
+    const int64_t tps = (n_tiles + n_segs - 1) / n_segs;
+    const dim3 grid((unsigned)((n_cols + 255) / 256), (unsigned)n_segs);
+    if (dtype == DE_F32)
+        hipLaunchKernelGGL(de_loss_reduce_tiles_kernel<float>, grid, dim3(256), 0, stream, static_cast<const float *>(partial), n_cols,
+                           n_tiles, tps, static_cast<double *>(seg_sum));
+    else
+        hipLaunchKernelGGL(de_loss_reduce_tiles_kernel<double>, grid, dim3(256), 0, stream, static_cast<const double *>(partial), n_cols,
+                           n_tiles, tps, static_cast<double *>(seg_sum));
+    *n_segs_out = n_segs;
     return hipGetLastError();
 }
 

@@ -219,6 +219,40 @@ function eval_population_loss(
     return out, ok .!= 0x00
 end
 
+"""
+    eval_population_loss_grad(pop, X, y; weights=nothing, loss=:L2, variable=Val(false))
+        -> (loss::Vector{T}, dloss::Vector{Vector{T}}, ok)
+
+The optimiser callback of test/test_optim.jl:42-51 for a whole population in one launch:
+`dloss[t][i] = sum_j 2 (ŷ_j - y_j) * dŷ_dconstants[i, j]` without the `n_grad × N` Jacobian.
+`loss=:pullback` treats `y` as the cotangent `dY` of the ChainRules pullback
+(src/ChainRules.jl:56-77) and returns its `dtree` gradient.
+"""
+function eval_population_loss_grad(
+    pop::HIPPopulation{T}, X::Matrix{T}, y::Vector{T}; weights::Union{Nothing,Vector{T}}=nothing,
+    loss::Symbol=:L2, variable=Val(false),
+) where {T}
+    mode = variable isa Val{true} || variable === true ? Cint(0) :
+           variable isa Val{:both} ? Cint(2) : Cint(1)
+    F, N = size(X)
+    @assert F >= pop.n_features && length(y) == N
+    ng = [ccall((:de_program_n_grad, LIBDE), Int64, (Ptr{Cvoid}, Int64, Cint), pop.handle, t - 1, mode)
+          for t in 1:pop.n_trees]
+    offs = Int64[0; cumsum(ng)]
+    lossv = Vector{T}(undef, pop.n_trees)
+    dl = Vector{T}(undef, max(offs[end], 1))
+    ok = Vector{UInt8}(undef, pop.n_trees)
+    w = weights === nothing ? C_NULL : pointer(weights)
+    kind = loss === :L1 ? 1 : loss === :pullback ? 2 : 0
+    rc = GC.@preserve X y weights lossv dl offs ok ccall(
+        (:de_eval_loss_grad, LIBDE), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int32,
+         Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{UInt8}),
+        pop.ctx.handle, pop.handle, X, N, F, C_NULL, mode, y, w, kind, lossv, dl, offs, ok)
+    check(pop.ctx, rc)
+    return lossv, [dl[(offs[t] + 1):offs[t + 1]] for t in 1:pop.n_trees], ok .!= 0x00
+end
+
 """Forward-mode gradient of one tree: `(evaluation, gradient(n_grad × N), complete)` like
 `eval_grad_tree_array(tree, cX, operators; variable)` (src/EvaluateDerivative.jl:193-228)."""
 function _hip_eval_grad_tree_array(

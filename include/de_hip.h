@@ -219,10 +219,30 @@ int de_eval_diff(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, in
  * NaN-fills incomplete evaluations, src/EvaluationHelpers.jl:29-33).  The reduction order is
  * fixed (per-wavefront partials, then two fixed-order passes in double), so results are
  * reproducible run to run.  `loss` holds n_trees values of the program's dtype. */
-typedef enum de_loss_kind { DE_LOSS_L2 = 0, DE_LOSS_L1 = 1 } de_loss_kind_t;
+typedef enum de_loss_kind {
+    DE_LOSS_L2 = 0,      /* l(e) = e^2,  l'(e) = 2e                                              */
+    DE_LOSS_L1 = 1,      /* l(e) = |e|,  l'(e) = sign(e)                                         */
+    DE_LOSS_PULLBACK = 2 /* de_eval_loss_grad only: `y` holds a cotangent dY (see there)         */
+} de_loss_kind_t;
 int de_eval_loss(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, int64_t ldX,
                  const de_param_args_t *pargs, const void *y, const void *w, int32_t loss_kind,
                  void *loss, uint8_t *ok);
+
+/* Fused loss + its gradient (the pullback of the reduction through eval_grad_tree_array):
+ *   loss[t]              = sum_j w_j * l(tree_t(x_j) - y_j)
+ *   dloss[off_t + k]     = sum_j w_j * l'(tree_t(x_j) - y_j) * d tree_t(x_j) / d theta_k
+ * theta = the gradient rows of `mode` (same order as de_eval_grad).  This is the body of the
+ * optimiser callback g!/fg! — `dresult_dy = 2 (yhat - y); G[i] = sum_j dresult_dy[j] * dyhat_dconstants[i, j]`
+ * (test/test_optim.jl:42-51,83-96) — and, with DE_LOSS_PULLBACK (`y` = the incoming cotangent dY,
+ * l' = dY_j, loss[t] = sum_j w_j dY_j tree_t(x_j)), the `dtree` of the ChainRules pullback
+ * (`sum(j -> dconstants_dY[:, j] * dY[j])`, src/ChainRules.jl:56-77) — without materialising the
+ * [n_grad, N] Jacobian.  Entries are NaN where ok[t] == 0 (src/ChainRules.jl:62-64).
+ * `dloss_offsets` = element offset of each tree's n_grad(t, mode) entries (NULL: packed back to
+ * back); `loss` may be NULL.  Same fixed-order reduction as de_eval_loss. */
+int de_eval_loss_grad(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, int64_t ldX,
+                      const de_param_args_t *pargs, int mode, const void *y, const void *w,
+                      int32_t loss_kind, void *loss, void *dloss, const int64_t *dloss_offsets,
+                      uint8_t *ok);
 
 /* ---- one-shot convenience with the reference's single-tree signature ------- */
 int de_eval_tree_array(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, int64_t n_nodes,

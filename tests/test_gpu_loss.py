@@ -185,3 +185,147 @@ def test_fused_loss_empty_and_error_paths(api):
     rc = lib.de_eval_loss(pop.ctx._h, pop._h, X.ctypes.data, 10, 5, None, yb.ctypes.data, None, 7, lossb.ctypes.data, okb.ctypes.data)
     assert rc == 1 and b"loss_kind" in lib.de_last_error(pop.ctx._h)
     pop.close()
+
+
+# ---- fused loss + gradient (de_eval_loss_grad) -------------------------------------------------
+MODES = {"variable": (True, oracle.GRAD_VARIABLE), "constant": (False, oracle.GRAD_CONSTANT),
+         "both": ("both", oracle.GRAD_BOTH)}
+
+
+def ref_loss_grad(out64, g64, y, w, kind):
+    """(loss, dloss[k], abs-sum of the gradient terms) from a materialised evaluation + Jacobian."""
+    y = y.astype(np.float64)
+    ww = np.ones_like(y) if w is None else w.astype(np.float64)
+    if kind == "pullback":
+        l, lp = out64 * y, y
+    else:
+        e = out64 - y
+        l, lp = (e * e, 2 * e) if kind == "L2" else (np.abs(e), np.sign(e))
+    keep = ww != 0
+    terms = (ww * lp)[None, keep] * g64[:, keep]
+    return (ww * l)[keep].sum(), terms.sum(axis=1), np.abs(terms).sum(axis=1)
+
+
+def check_loss_grads(api, trees, ops, X, y, w, kind, dtype, mode_name, oracle_exact=False, min_ok=1, **pkw):
+    variable, omode = MODES[mode_name]
+    pop = api.Population(trees, ops, dtype, n_features=X.shape[0], n_params=pkw.pop("n_params", 0))
+    loss, dls, ok = pop.eval_loss_grad(X, y, weights=w, loss=kind, variable=variable, **pkw)
+    out, grads, ok_g = pop.eval_grad(X, variable, **pkw)
+    assert np.array_equal(ok, ok_g)
+    eps = np.finfo(dtype).eps
+    fmax = np.finfo(dtype).max
+    tiny = float(np.finfo(dtype).tiny) * X.shape[1]  # terms below the normal range flush/round
+    n_ok = 0
+    for t, tree in enumerate(trees):
+        assert dls[t].shape == (grads[t].shape[0],)
+        if not ok[t]:
+            assert np.isnan(loss[t]) and np.all(np.isnan(dls[t]))  # src/ChainRules.jl:62-64
+            continue
+        srcs = [(out[t].astype(np.float64), np.asarray(grads[t], dtype=np.float64))]
+        if oracle_exact:  # IEEE-exact operators: the oracle's Jacobian is bit-identical, so it is a second anchor
+            tape, consts = de.flatten(tree, ops, dtype)
+            yo, go, ok_o = oracle.eval_grad_tree_array(tape, consts, X, omode, elementwise=True)
+            assert ok_o
+            srcs.append((yo.astype(np.float64), go.astype(np.float64)))
+        for o64, g64 in srcs:
+            want_l, want_g, mag = ref_loss_grad(o64, g64, y, w, kind)
+            if not np.all(np.isfinite(want_g)) or max(abs(want_l), mag.max(initial=0)) > 0.05 * fmax:
+                continue  # a term overflows T
+            assert abs(float(loss[t]) - want_l) <= 64 * eps * abs(want_l) + 64 * eps * np.abs(o64 * y).sum() * (kind == "pullback") + tiny
+            err = np.abs(dls[t].astype(np.float64) - want_g)
+            assert np.all(err <= 64 * eps * mag + tiny), (t, mode_name, de.string_tree(tree, ops), dls[t], want_g)
+        n_ok += 1
+    assert n_ok >= min_ok
+    pop.close()
+    return n_ok
+
+
+@pytest.mark.parametrize("mode", ["constant", "variable", "both"])
+@pytest.mark.parametrize("kind", ["L2", "L1", "pullback"])
+def test_fused_loss_grad_exact_operators_vs_oracle(api, mode, kind):
+    ops = de.OperatorEnum(binary_operators=("+", "-", "/", "*"), unary_operators=("neg", "square", "abs"))
+    rng = de.synth.Xoshiro256ss(17)
+    for dtype in (np.float32, np.float64):
+        trees = [de.synth.gen_random_tree_fixed_size(3 + i % 26, ops, 4, rng, dtype) for i in range(60)]
+        N = 777
+        X = de.synth.random_X(4, N, seed=12, dtype=dtype)
+        g = np.random.Generator(np.random.PCG64(2))
+        y = g.standard_normal(N).astype(dtype)
+        w = g.uniform(0, 2, N).astype(dtype)
+        w[::5] = 0
+        check_loss_grads(api, trees, ops, X, y, w, kind, dtype, mode, oracle_exact=True, min_ok=10)
+
+
+@pytest.mark.parametrize("N", [1, 300, 2049])
+def test_fused_loss_grad_random_population(api, N):
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(120, seed=0xDE03)
+    X = de.synth.random_X(5, N, seed=6)
+    y = np.sin(np.arange(N)).astype(np.float32)
+    for mode in ("constant", "variable", "both"):
+        check_loss_grads(api, trees, ops, X, y, None, "L2", np.float32, mode, min_ok=5)
+
+
+def test_fused_loss_grad_many_constants_use_several_windows(api):
+    ops = de.OperatorEnum(binary_operators=("+", "*"))
+    t = de.Node(feature=1)
+    for i in range(19):
+        t = de.Node(1 + i % 2, t, de.Node(val=0.5 + 0.1 * i))
+    X = de.synth.random_X(2, 1000, seed=2, dtype=np.float64)
+    y = np.cos(np.arange(1000.0))
+    for mode in ("constant", "both"):
+        check_loss_grads(api, [t, de.Node(feature=2), t.copy()], ops, X, y, None, "L2", np.float64, mode,
+                         oracle_exact=True, min_ok=3)
+
+
+def test_fused_loss_grad_parametric_and_device_tensors(api):
+    import torch
+    ops = de.OperatorEnum(binary_operators=("+", "*", "-"), unary_operators=("cos", "exp"))
+    rng = de.synth.Xoshiro256ss(21)
+    trees = [de.synth.gen_random_tree_fixed_size(9 + i % 8, ops, 2, rng, np.float32, de.ParametricNode, 2)
+             for i in range(40)]
+    N, P, Cn = 1500, 2, 4
+    g = np.random.Generator(np.random.PCG64(5))
+    X = np.asfortranarray(g.standard_normal((2, N)).astype(np.float32))
+    params = np.asfortranarray(g.standard_normal((P, Cn)).astype(np.float32))
+    classes = g.integers(1, Cn + 1, N)
+    y = g.standard_normal(N).astype(np.float32)
+    for mode in ("constant", "variable"):
+        check_loss_grads(api, trees, ops, X, y, None, "L2", np.float32, mode, min_ok=5, n_params=P,
+                         params=params, classes=classes)
+    # device tensors, repeatability, and the optimiser identity: loss from loss_grad == loss from eval_loss
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(100, seed=3)
+    pop = api.Population(trees, ops, np.float32, n_features=5)
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    Nd = 200_003
+    Xd = torch.randn((Nd, 5), generator=gen, device="cuda").t()
+    yd = torch.randn(Nd, generator=gen, device="cuda")
+    l1, d1, ok1 = pop.eval_loss_grad(Xd, yd)
+    l2, d2, ok2 = pop.eval_loss_grad(Xd, yd)
+    torch.cuda.synchronize()
+    assert torch.equal(ok1, ok2) and torch.equal(l1[ok1], l2[ok1])
+    for a, b, k in zip(d1, d2, ok1.tolist()):
+        if k:
+            assert torch.equal(a, b)
+    out, grads, okg = pop.eval_grad(Xd, False)
+    for t in torch.nonzero(ok1).flatten().tolist()[:20]:
+        want = (2 * (out[t].double() - yd.double())[None, :] * grads[t].double()).sum(dim=1)
+        mag = (2 * (out[t].double() - yd.double())[None, :] * grads[t].double()).abs().sum(dim=1)
+        assert bool(((d1[t].double() - want).abs() <= 64 * 1.2e-7 * mag + 1e-30).all())
+    pop.close()
+
+
+def test_fused_loss_grad_empty_and_error_paths(api):
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(5, seed=1)
+    pop = api.Population(trees, ops, np.float32, n_features=5)
+    loss, dls, ok = pop.eval_loss_grad(np.zeros((5, 0), np.float32), np.zeros(0, np.float32))
+    assert np.array_equal(loss, np.zeros(5, np.float32)) and ok.all()
+    assert all(np.array_equal(d, np.zeros_like(d)) for d in dls)
+    X = de.synth.random_X(5, 10, seed=1)
+    with pytest.raises(ValueError):
+        pop.eval_loss_grad(X, np.zeros(9, np.float32))
+    with pytest.raises(KeyError):
+        pop.eval_loss(X, np.zeros(10, np.float32), loss="pullback")  # value-only entry point has no cotangent mode
+    pop.close()
