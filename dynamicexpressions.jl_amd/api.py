@@ -43,7 +43,7 @@ EXPORTS = [
     "de_opcode_degree", "de_status_string", "de_ctx_create", "de_ctx_destroy",
     "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create",
     "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
-    "de_program_n_grad", "de_program_dump", "de_lower_tape", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad",
+    "de_program_n_grad", "de_program_dump", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad",
     "de_eval_tree_array", "de_eval_plan", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
 ]
 
@@ -108,6 +108,8 @@ def library() -> C.CDLL:
     lib.de_program_dump.argtypes = [vp, i64, vp, i64, C.c_int]
     lib.de_lower_tape.restype = i64
     lib.de_lower_tape.argtypes = [C.c_int, vp, i64, vp, i64, i32, i32, u32, vp, i64, vp]
+    lib.de_lower_tape_stage.restype = i64
+    lib.de_lower_tape_stage.argtypes = [C.c_int, vp, i64, vp, i64, i32, i32, u32, C.c_int, vp, i64]
     lib.de_eval.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), vp, i64, vp]
     lib.de_eval_loss.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), vp, vp, C.c_int32, vp, vp]
     lib.de_eval_loss_grad.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), C.c_int, vp, vp, C.c_int32, vp, vp, vp, vp]
@@ -268,6 +270,23 @@ def lower_tape(tape, consts, n_features: int, n_params: int = 0, options: int = 
                       n_params, options, w.ctypes.data, w.size, meta.ctypes.data)
     return w[:int(n)].reshape(-1, 4), dict(n_slots=int(meta[0]), host_ok_eval=bool(meta[1]),
                                            host_ok_grad=bool(meta[2]), uses_params=bool(meta[3]))
+
+
+def lower_tape_stage(tape, consts, n_features: int, stage: int, n_params: int = 0, options: int = 7,
+                     dtype=np.float32) -> np.ndarray:
+    """Host-only: the bound (stage 2) or fused (stage 3) instruction words of one tape, [n, 4] uint32."""
+    lib = library()
+    dtype = np.dtype(dtype)
+    tape = np.ascontiguousarray(tape)
+    consts = np.ascontiguousarray(consts, dtype=dtype)
+    cp = consts.ctypes.data if consts.size else None
+    args = (_dtype_code(dtype), tape.ctypes.data, len(tape), cp, consts.size, n_features, n_params, options, stage)
+    n = lib.de_lower_tape_stage(*args, None, 0)
+    if n < 0:
+        raise ValueError(lib.de_status_string(int(-n)).decode())
+    w = np.zeros(max(int(n), 1), dtype=np.uint32)
+    lib.de_lower_tape_stage(*args, w.ctypes.data, w.size)
+    return w[:int(n)].reshape(-1, 4)
 
 
 class Population:

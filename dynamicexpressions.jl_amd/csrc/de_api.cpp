@@ -79,6 +79,8 @@ struct de_program {
     std::vector<uint8_t> fold_ok;
     std::vector<BoundInstr> bcode;      // bound form of the eval program (handler ids)
     std::vector<BoundInstr> tcode;      // threaded form: handler address offsets + LDS byte offsets
+    std::vector<BoundInstr> fbcode;     // fused (superinstruction) form the threaded code is made from
+    std::vector<int32_t> tcode_off;     // n_trees + 1 offsets into tcode / fbcode
     bool threaded = false;
     bool direct = false;                // X too wide for the LDS tile (decided at creation)
     uint64_t handler_base = 0;
@@ -282,25 +284,38 @@ static int make_threaded(de_ctx *c, de_program *p) {
     p->direct = ((size_t)p->n_features + (size_t)p->n_slots) * 257 * 16 > 150 * 1024;
     if (p->direct || !eval_uses_threaded()) return DE_OK;
     if ((int64_t)p->n_features + p->n_slots > 4000) return DE_OK; // row offsets must fit 24 bits
-    uint64_t table[BOP_COUNT];
+    uint64_t table[TOP_COUNT];
     hipError_t st = eval_handler_table(p->dtype, table);
     if (st != hipSuccess) return fail(c, DE_ERR_HIP, "handler table: %s", hipGetErrorString(st));
     uint64_t base = table[0];
-    for (int i = 0; i < (int)BOP_COUNT; i++) base = std::min<uint64_t>(base, table[i]);
-    for (int i = 0; i < (int)BOP_COUNT; i++)
+    for (int i = 0; i < (int)TOP_COUNT; i++) base = std::min<uint64_t>(base, table[i]);
+    for (int i = 0; i < (int)TOP_COUNT; i++)
         if (table[i] - base > 0xFFFFFFFFull) return DE_OK; // cannot encode: keep the switch kernel
     const uint32_t row_bytes = 257 * 16;
-    p->tcode.resize(p->bcode.size());
-    for (size_t i = 0; i < p->bcode.size(); i++) {
-        const BoundInstr &b = p->bcode[i];
+    // superinstructions (de_bind.h): fewer dispatches for the same arithmetic
+    const char *nf = getenv("DE_NO_FUSE");
+    const bool fuse = !(nf && *nf == '1');
+    p->fbcode.clear();
+    p->tcode_off.assign((size_t)p->n_trees + 1, 0);
+    for (int64_t t = 0; t < p->n_trees; t++) {
+        const int32_t b0 = p->bcode_off[(size_t)t], b1 = p->bcode_off[(size_t)t + 1];
+        if (fuse) fuse_tree(p->bcode.data() + b0, (size_t)(b1 - b0), &p->fbcode);
+        else p->fbcode.insert(p->fbcode.end(), p->bcode.begin() + b0, p->bcode.begin() + b1);
+        p->tcode_off[(size_t)t + 1] = (int32_t)p->fbcode.size();
+    }
+    p->tcode.resize(p->fbcode.size());
+    for (size_t i = 0; i < p->fbcode.size(); i++) {
+        const BoundInstr &b = p->fbcode[i];
         BoundInstr t = b;
         t.bop = (uint32_t)(table[b.bop] - base);
-        if (bop_is_const_source(b.bop)) {
+        if (b.bop < BOP_COUNT && bop_is_const_source(b.bop)) {
             t.arg = b.arg & 0xFF000000u; // constant ordinal is only for the gradient kernel
         } else if (b.bop != BOP_GEN_PARAM) {
             const uint32_t row = b.arg & 0xFFFFFFu, aux = b.arg >> 24;
             t.arg = (row * row_bytes) | (aux << 24);
             if (b.bop == BOP_TERN) t.lo = (b.lo - row) * row_bytes; // byte distance row B -> row C (mod 2^32)
+            if (b.bop >= TOP_BIN2_BASE && b.bop < TOP_COUNT && !(((b.bop - TOP_BIN2_BASE) >> 2) & 1))
+                t.lo = (uint32_t)((int32_t)b.lo * (int32_t)row_bytes); // row-row: byte distance row A -> row B
         }
         p->tcode[i] = t;
     }
@@ -502,7 +517,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         if (rc != DE_OK) return rc;
     }
     // one trailing pad instruction: the interpreter prefetches code[pc + 1]
-    const size_t cbytes = (p->bcode.size() + 1) * sizeof(BoundInstr);
+    const size_t cbytes = (p->bcode.size() + 1) * sizeof(BoundInstr); // the fused form is never longer
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->d_code), cbytes));
     HIP_TRY(ctx, hipMemset(p->d_code, 0, cbytes));
     hipError_t st = hipMalloc(reinterpret_cast<void **>(&p->d_code_off), p->bcode_off.size() * sizeof(int32_t));
@@ -511,10 +526,11 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(st));
     }
     if (!p->bcode.empty())
-        st = hipMemcpy(p->d_code, (p->threaded ? p->tcode : p->bcode).data(), p->bcode.size() * sizeof(BoundInstr),
-                       hipMemcpyHostToDevice);
+        st = hipMemcpy(p->d_code, (p->threaded ? p->tcode : p->bcode).data(),
+                       (p->threaded ? p->tcode : p->bcode).size() * sizeof(BoundInstr), hipMemcpyHostToDevice);
     if (st == hipSuccess)
-        st = hipMemcpy(p->d_code_off, p->bcode_off.data(), p->bcode_off.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+        st = hipMemcpy(p->d_code_off, (p->threaded ? p->tcode_off : p->bcode_off).data(), p->bcode_off.size() * sizeof(int32_t),
+                       hipMemcpyHostToDevice);
     if (st != hipSuccess) {
         (void)hipFree(p->d_code);
         (void)hipFree(p->d_code_off);
@@ -557,7 +573,7 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!p->bcode.empty())
         HIP_TRY(ctx, hipMemcpy(p->d_code, (p->threaded ? p->tcode : p->bcode).data(),
-                               p->bcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
+                               (p->threaded ? p->tcode : p->bcode).size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
     return DE_OK;
 }
 
@@ -611,6 +627,14 @@ int64_t de_program_dump(const de_program_t *p, int64_t tree, uint32_t *words, in
         std::memcpy(words, p->bcode.data() + b0, (size_t)nb * 4);
         return nb;
     }
+    if (which == 3) { // fused (superinstruction) form of the threaded kernel; empty when that kernel is not in use
+        if (!p->threaded) return 0;
+        const int32_t b0 = p->tcode_off[(size_t)tree], b1 = p->tcode_off[(size_t)tree + 1];
+        const int64_t nb = (int64_t)(b1 - b0) * 4;
+        if (!words || cap < nb) return nb;
+        std::memcpy(words, p->fbcode.data() + b0, (size_t)nb * 4);
+        return nb;
+    }
     const int32_t i0 = p->code_off[(size_t)tree], i1 = p->code_off[(size_t)tree + 1];
     const int64_t nw = (int64_t)(i1 - i0) * 4;
     if (!words || cap < nw) return nw;
@@ -655,6 +679,30 @@ int64_t de_lower_tape(int dtype, const de_tape_node_t *nodes, int64_t n_nodes, c
         if (!words || cap < nw) return nw;
         std::memcpy(words, tp.code.data(), (size_t)nw * 4);
         return nw;
+    } catch (const std::bad_alloc &) {
+        return -DE_ERR_HIP;
+    }
+}
+
+int64_t de_lower_tape_stage(int dtype, const de_tape_node_t *nodes, int64_t n_nodes, const void *consts,
+                            int64_t n_consts, int32_t n_features, int32_t n_params, uint32_t options, int stage,
+                            uint32_t *words, int64_t cap) {
+    if (stage != 2 && stage != 3) return -DE_ERR_INVALID_ARG;
+    std::vector<uint32_t> g;
+    int64_t nw = de_lower_tape(dtype, nodes, n_nodes, consts, n_consts, n_features, n_params, options, nullptr, 0, nullptr);
+    if (nw < 0) return nw;
+    try {
+        g.resize((size_t)nw);
+        nw = de_lower_tape(dtype, nodes, n_nodes, consts, n_consts, n_features, n_params, options, g.data(), nw, nullptr);
+        if (nw < 0) return nw;
+        std::vector<BoundInstr> b, f;
+        bind_tree(reinterpret_cast<const Instr *>(g.data()), (size_t)nw / 4, (options & DE_OPT_EARLY_EXIT) != 0, n_features, &b);
+        if (stage == 3) fuse_tree(b.data(), b.size(), &f);
+        const std::vector<BoundInstr> &o = stage == 3 ? f : b;
+        const int64_t n = (int64_t)o.size() * 4;
+        if (!words || cap < n) return n;
+        std::memcpy(words, o.data(), (size_t)n * 4);
+        return n;
     } catch (const std::bad_alloc &) {
         return -DE_ERR_HIP;
     }

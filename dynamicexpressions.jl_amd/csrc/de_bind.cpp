@@ -81,4 +81,135 @@ void bind_tree(const Instr *code, size_t n, bool ee, int n_features, std::vector
     }
 }
 
+// ---- superinstruction pass ---------------------------------------------------------------------
+namespace {
+struct HotBin { int k; bool cst, out; };
+bool hot_bin_of(const BoundInstr &b, HotBin *h) {
+    if (b.bop < BOP_BIN_BASE || b.bop >= BOP_BIN_END) return false;
+    const uint32_t v = b.bop - BOP_BIN_BASE;
+    h->k = (int)(v >> 2);
+    h->cst = (v & 2) != 0;
+    h->out = (v & 1) != 0;
+    return true;
+}
+// acc = x op b  ->  the same value written as  b' op' x'  with the operands swapped
+int mirrored(int k) {
+    switch (k) {
+    case 1: return 2; // SUB  -> RSUB
+    case 2: return 1;
+    case 4: return 5; // DIV  -> RDIV
+    case 5: return 4;
+    default: return k; // ADD, MUL
+    }
+}
+bool delta_ok(uint32_t a, uint32_t b) {
+    const int64_t d = (int64_t)b - (int64_t)a;
+    return d >= -127 && d <= 127;
+}
+uint32_t with_delta(uint32_t rowA, bool push, uint32_t push_row) {
+    const int32_t d = push ? (int32_t)push_row - (int32_t)rowA : 0;
+    return (rowA & 0xFFFFFFu) | ((uint32_t)(d & 0xFF) << 24);
+}
+} // namespace
+
+bool top_is_const_source(uint32_t top) {
+    if (top < BOP_COUNT) return bop_is_const_source(top);
+    return top == TOP_LOADCONST_PUSH; // TOP_BIN2 row-const keeps row A in arg
+}
+
+void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out) {
+    size_t i = 0;
+    while (i < n) {
+        size_t j = i;
+        bool push = false, chk = false;
+        uint32_t push_row = 0, chk_row = 0;
+        if (b[j].bop == BOP_PUSH) { push = true; push_row = b[j].arg & 0xFFFFFFu; j++; }
+        if (j < n && b[j].bop == BOP_CHECK_ROW) { chk = true; chk_row = b[j].arg & 0xFFFFFFu; j++; }
+        if (j < n && (push || chk)) {
+            const BoundInstr &m = b[j];
+            const uint32_t row = m.arg & 0xFFFFFFu;
+            HotBin hb;
+            if (m.bop == BOP_LOAD_ROW && (!chk || chk_row == row) && (!push || delta_ok(row, push_row))) {
+                if (!chk && j + 1 < n && hot_bin_of(b[j + 1], &hb) && (hb.cst || delta_ok(row, b[j + 1].arg & 0xFFFFFFu))) {
+                    const BoundInstr &nb = b[j + 1];
+                    BoundInstr f = nb;
+                    f.bop = top_bin2(hb.k, hb.cst, hb.out, push);
+                    f.arg = with_delta(row, push, push_row);
+                    if (!hb.cst) { f.lo = (uint32_t)((int32_t)(nb.arg & 0xFFFFFFu) - (int32_t)row); f.hi = 0; }
+                    out->push_back(f);
+                    i = j + 2;
+                    continue;
+                }
+                BoundInstr f = m;
+                f.bop = top_loadrow(push, chk);
+                f.arg = with_delta(row, push, push_row);
+                out->push_back(f);
+                i = j + 1;
+                continue;
+            }
+            if (m.bop == BOP_LOAD_CONST && push && !chk) {
+                if (j + 1 < n && hot_bin_of(b[j + 1], &hb) && !hb.cst && delta_ok(b[j + 1].arg & 0xFFFFFFu, push_row)) {
+                    const uint32_t rowA = b[j + 1].arg & 0xFFFFFFu;
+                    BoundInstr f = m; // keeps the constant's bits
+                    f.bop = top_bin2(mirrored(hb.k), true, hb.out, true);
+                    f.arg = with_delta(rowA, true, push_row);
+                    out->push_back(f);
+                    i = j + 2;
+                    continue;
+                }
+                BoundInstr f = m;
+                f.bop = TOP_LOADCONST_PUSH;
+                f.arg = push_row;
+                out->push_back(f);
+                i = j + 1;
+                continue;
+            }
+            if (m.bop >= BOP_UN_BASE && m.bop < BOP_UN_END && ((m.bop - BOP_UN_BASE) & 2) && (!chk || chk_row == row) &&
+                (!push || delta_ok(row, push_row))) {
+                const uint32_t v = m.bop - BOP_UN_BASE;
+                BoundInstr f = m;
+                f.bop = top_unrow((int)(v >> 2), (v & 1) != 0, push, chk);
+                f.arg = with_delta(row, push, push_row);
+                out->push_back(f);
+                i = j + 1;
+                continue;
+            }
+            if (!push && chk && hot_bin_of(m, &hb) && !hb.cst && chk_row == row) {
+                BoundInstr f = m;
+                f.bop = top_binrowc(hb.k, hb.out);
+                f.arg = row;
+                out->push_back(f);
+                i = j + 1;
+                continue;
+            }
+        } else if (j < n) { // no PUSH / CHECK_ROW prefix: LOAD + BIN pairs
+            const BoundInstr &m = b[j];
+            HotBin hb;
+            if (j + 1 < n && hot_bin_of(b[j + 1], &hb)) {
+                const BoundInstr &nb = b[j + 1];
+                if (m.bop == BOP_LOAD_ROW && (hb.cst || delta_ok(m.arg & 0xFFFFFFu, nb.arg & 0xFFFFFFu))) {
+                    const uint32_t row = m.arg & 0xFFFFFFu;
+                    BoundInstr f = nb;
+                    f.bop = top_bin2(hb.k, hb.cst, hb.out, false);
+                    f.arg = row;
+                    if (!hb.cst) { f.lo = (uint32_t)((int32_t)(nb.arg & 0xFFFFFFu) - (int32_t)row); f.hi = 0; }
+                    out->push_back(f);
+                    i = j + 2;
+                    continue;
+                }
+                if (m.bop == BOP_LOAD_CONST && !hb.cst) {
+                    BoundInstr f = m;
+                    f.bop = top_bin2(mirrored(hb.k), true, hb.out, false);
+                    f.arg = nb.arg & 0xFFFFFFu;
+                    out->push_back(f);
+                    i = j + 2;
+                    continue;
+                }
+            }
+        }
+        out->push_back(b[i]); // unfused: same id as the bound form
+        i++;
+    }
+}
+
 } // namespace de

@@ -54,6 +54,39 @@ inline bool bop_is_const_source(uint32_t bop) {
     return bop >= BOP_BIN_BASE && bop < BOP_BIN_END && ((bop - BOP_BIN_BASE) & 2);
 }
 
+// ---- third stage (threaded kernel only): superinstructions -----------------------------------
+// On the bench population 12 % of the bound dispatches are PUSH, 8 % CHECK_ROW and 13 % LOAD_*;
+// a dispatch costs ~24 scalar + 3 vector instructions whatever it does, and the kernel is
+// co-limited by scalar issue and VALU.  fuse_tree() folds
+//   [PUSH s] [CHECK_ROW r] LOAD_ROW r                    -> TOP_LOADROW   (push, chk)
+//   [PUSH s] LOAD_CONST c                                -> TOP_LOADCONST_PUSH
+//   [PUSH s] [CHECK_ROW r] UN(row r)                     -> TOP_UNROW     (k, out-check, push, chk)
+//   CHECK_ROW r; BIN(row r)                              -> TOP_BINROWC   (k, out-check)
+//   [PUSH s] LOAD_ROW a; BIN(row b | const c)            -> TOP_BIN2      (k, const?, out-check, push)
+//   [PUSH s] LOAD_CONST c; BIN(row a)                    -> TOP_BIN2 with the operator mirrored
+// into one dispatch each; everything else keeps its BoundOp id (ids < BOP_COUNT are shared).
+// Encoding of a fused instruction (BoundInstr fields):
+//   arg[23:0]  = row A (the LDS row operand)             arg[31:24] = int8 (push row - row A), 0 if no push
+//   lo, hi     = the constant's bits, or for TOP_BIN2 row-row: lo = (row B - row A) as int32
+//   TOP_LOADCONST_PUSH: arg = the push row itself.
+enum ThreadedOp : uint32_t {
+    TOP_LOADROW_BASE = BOP_COUNT,                 // + 2*push + chk                         (4)
+    TOP_LOADCONST_PUSH = TOP_LOADROW_BASE + 4,    //                                        (1)
+    TOP_UNROW_BASE = TOP_LOADCONST_PUSH + 1,      // + ((k*2 + out)*2 + push)*2 + chk       (24)
+    TOP_BINROWC_BASE = TOP_UNROW_BASE + 24,       // + k*2 + out                            (12)
+    TOP_BIN2_BASE = TOP_BINROWC_BASE + 12,        // + ((k*2 + const)*2 + out)*2 + push     (48)
+    TOP_COUNT = TOP_BIN2_BASE + 48
+};
+constexpr uint32_t top_loadrow(bool push, bool chk) { return TOP_LOADROW_BASE + 2 * push + chk; }
+constexpr uint32_t top_unrow(int k, bool out, bool push, bool chk) { return TOP_UNROW_BASE + ((k * 2 + out) * 2 + push) * 2 + chk; }
+constexpr uint32_t top_binrowc(int k, bool out) { return TOP_BINROWC_BASE + k * 2 + out; }
+constexpr uint32_t top_bin2(int k, bool cst, bool out, bool push) { return TOP_BIN2_BASE + ((k * 2 + cst) * 2 + out) * 2 + push; }
+
+// Fused form of one tree's bound instructions (appended to `out`).
+void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out);
+// True when the fused instruction's operand is an inline constant (arg carries no operand row).
+bool top_is_const_source(uint32_t top);
+
 // Append the bound form of `code` (one tree) to `out`.
 void bind_tree(const Instr *code, size_t n, bool early_exit, int n_features, std::vector<BoundInstr> *out);
 

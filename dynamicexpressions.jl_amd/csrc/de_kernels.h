@@ -76,7 +76,7 @@ struct GradArgs {
 hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const char **kernel_name);
 hipError_t launch_grad(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name);
 
-// Threaded-code eval kernel: addresses of the BOP_COUNT device handlers (cached per process).
+// Threaded-code eval kernel: addresses of the TOP_COUNT device handlers (cached per process).
 hipError_t eval_handler_table(int dtype, uint64_t *table);
 bool eval_uses_threaded();
 

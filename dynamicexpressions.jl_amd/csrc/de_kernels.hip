@@ -508,27 +508,25 @@ template <typename T> __device__ __noinline__ HState<T> h_check_row(HARGS) {
 }
 template <typename T> __device__ __noinline__ HState<T> h_check_acc(HARGS) { hpoison<T>(st.poison, st.acc); return st; }
 
-// K: 0 ADD 1 SUB 2 RSUB 3 MUL 4 DIV 5 RDIV;  VAR bit0 = validity-test the result, bit1 = constant operand
-template <typename T, int K, int VAR> __device__ __noinline__ HState<T> h_bin(HARGS) {
-    typedef typename VecOf<T>::type V;
-    V b;
-    if constexpr (VAR & 2) { const T c = imm_from<T>(imm); DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) b[i] = c; }
-    else b = *LDSP(T, la);
-    if constexpr (K == 0) st.acc = st.acc + b;
-    else if constexpr (K == 1) st.acc = st.acc - b;
-    else if constexpr (K == 2) st.acc = b - st.acc;
-    else if constexpr (K == 3) st.acc = st.acc * b;
-    else if constexpr (K == 4) st.acc = st.acc / b;
-    else st.acc = b / st.acc;
-    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
-    return st;
+// K: 0 ADD 1 SUB 2 RSUB 3 MUL 4 DIV 5 RDIV  —  x op b (R*: b op x)
+template <typename T, int K> __device__ __forceinline__ typename VecOf<T>::type bin_apply(typename VecOf<T>::type x, typename VecOf<T>::type b) {
+    if constexpr (K == 0) return x + b;
+    else if constexpr (K == 1) return x - b;
+    else if constexpr (K == 2) return b - x;
+    else if constexpr (K == 3) return x * b;
+    else if constexpr (K == 4) return x / b;
+    else return b / x;
 }
-// K: 0 COS 1 EXP 2 SIN;  VAR bit0 = test the result, bit1 = operand is an LDS row (else acc)
-template <typename T, int K, int VAR> __device__ __noinline__ HState<T> h_un(HARGS) {
+template <typename T> __device__ __forceinline__ typename VecOf<T>::type splat(typename ImmBits<T>::type imm) {
+    typename VecOf<T>::type b;
+    const T c = imm_from<T>(imm);
+    DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) b[i] = c;
+    return b;
+}
+// K: 0 COS 1 EXP 2 SIN
+template <typename T, int K> __device__ __forceinline__ typename VecOf<T>::type un_apply(typename VecOf<T>::type x) {
     typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
-    V x = st.acc;
-    if constexpr (VAR & 2) x = *LDSP(T, la);
     V r;
     if constexpr (sizeof(T) == 4) {
         if constexpr (K == 1) { DE_UNROLL for (int i = 0; i < VW; i++) r[i] = fast_exp_f32(x[i]); }
@@ -543,8 +541,69 @@ template <typename T, int K, int VAR> __device__ __noinline__ HState<T> h_un(HAR
     } else {
         DE_UNROLL for (int i = 0; i < VW; i++) r[i] = K == 0 ? M<T>::cos(x[i]) : (K == 1 ? M<T>::exp(x[i]) : M<T>::sin(x[i]));
     }
-    st.acc = r;
+    return r;
+}
+// VAR bit0 = validity-test the result, bit1 = constant operand
+template <typename T, int K, int VAR> __device__ __noinline__ HState<T> h_bin(HARGS) {
+    typedef typename VecOf<T>::type V;
+    V b;
+    if constexpr (VAR & 2) b = splat<T>(imm);
+    else b = *LDSP(T, la);
+    st.acc = bin_apply<T, K>(st.acc, b);
     if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
+    return st;
+}
+// VAR bit0 = test the result, bit1 = operand is an LDS row (else acc)
+template <typename T, int K, int VAR> __device__ __noinline__ HState<T> h_un(HARGS) {
+    typedef typename VecOf<T>::type V;
+    V x = st.acc;
+    if constexpr (VAR & 2) x = *LDSP(T, la);
+    st.acc = un_apply<T, K>(x);
+    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
+    return st;
+}
+// ---- superinstructions (de_bind.h, fuse_tree): la = LDS address of row A | int8 (push row - row A) << 24
+#define DE_ROW_BYTES (257 * 16)
+__device__ __forceinline__ uint32_t row_a(uint32_t la) { return la & 0xFFFFFFu; }
+__device__ __forceinline__ uint32_t push_addr(uint32_t la) { return (la & 0xFFFFFFu) + (uint32_t)(((int32_t)la >> 24) * DE_ROW_BYTES); }
+template <typename T, bool PUSH, bool CHK> __device__ __noinline__ HState<T> h_loadrow_f(HARGS) {
+    if constexpr (PUSH) *LDSP(T, push_addr(la)) = st.acc;
+    const typename VecOf<T>::type v = *LDSP(T, PUSH ? row_a(la) : la);
+    if constexpr (CHK) hpoison<T>(st.poison, v);
+    st.acc = v;
+    return st;
+}
+template <typename T> __device__ __noinline__ HState<T> h_loadconst_push(HARGS) {
+    *LDSP(T, la) = st.acc;
+    st.acc = splat<T>(imm);
+    return st;
+}
+template <typename T, int K, bool OUT, bool PUSH, bool CHK> __device__ __noinline__ HState<T> h_unrow_f(HARGS) {
+    if constexpr (PUSH) *LDSP(T, push_addr(la)) = st.acc;
+    const typename VecOf<T>::type x = *LDSP(T, PUSH ? row_a(la) : la);
+    if constexpr (CHK) hpoison<T>(st.poison, x);
+    st.acc = un_apply<T, K>(x);
+    if constexpr (OUT) hpoison<T>(st.poison, st.acc);
+    return st;
+}
+template <typename T, int K, bool OUT> __device__ __noinline__ HState<T> h_binrowc(HARGS) { // operand row tested, then acc = acc op row
+    const typename VecOf<T>::type b = *LDSP(T, la);
+    hpoison<T>(st.poison, b);
+    st.acc = bin_apply<T, K>(st.acc, b);
+    if constexpr (OUT) hpoison<T>(st.poison, st.acc);
+    return st;
+}
+// acc = row A op (row B | constant); row B's byte distance from row A travels in the immediate
+template <typename T, int K, bool CST, bool OUT, bool PUSH> __device__ __noinline__ HState<T> h_bin2(HARGS) {
+    typedef typename VecOf<T>::type V;
+    if constexpr (PUSH) *LDSP(T, push_addr(la)) = st.acc;
+    const uint32_t a = PUSH ? row_a(la) : la;
+    const V x = *LDSP(T, a);
+    V b;
+    if constexpr (CST) b = splat<T>(imm);
+    else b = *LDSP(T, a + (uint32_t)imm);
+    st.acc = bin_apply<T, K>(x, b);
+    if constexpr (OUT) hpoison<T>(st.poison, st.acc);
     return st;
 }
 // generic handlers: de_opcode in la[31:24].  SRC: 0 row, 1 const, 2 acc.  INJ: Inf-injection of the fused deg1 kernels.
@@ -595,6 +654,25 @@ template <typename T> __global__ void de_fill_handlers(uint64_t *t) {
     t[BOP_INJ_ROW] = (uint64_t)&h_gen<T, 0, true>;
 #undef HB
 #undef HU
+    // superinstructions
+    t[top_loadrow(false, false)] = (uint64_t)&h_load_row<T>;
+    t[top_loadrow(false, true)] = (uint64_t)&h_loadrow_f<T, false, true>;
+    t[top_loadrow(true, false)] = (uint64_t)&h_loadrow_f<T, true, false>;
+    t[top_loadrow(true, true)] = (uint64_t)&h_loadrow_f<T, true, true>;
+    t[TOP_LOADCONST_PUSH] = (uint64_t)&h_loadconst_push<T>;
+#define TU1(K, O, P) t[top_unrow(K, O, P, false)] = (uint64_t)&h_unrow_f<T, K, O, P, false>; t[top_unrow(K, O, P, true)] = (uint64_t)&h_unrow_f<T, K, O, P, true>;
+#define TU(K) TU1(K, false, false) TU1(K, false, true) TU1(K, true, false) TU1(K, true, true)
+    TU(0) TU(1) TU(2)
+#define TBC(K) t[top_binrowc(K, false)] = (uint64_t)&h_binrowc<T, K, false>; t[top_binrowc(K, true)] = (uint64_t)&h_binrowc<T, K, true>;
+    TBC(0) TBC(1) TBC(2) TBC(3) TBC(4) TBC(5)
+#define TB1(K, C, O) t[top_bin2(K, C, O, false)] = (uint64_t)&h_bin2<T, K, C, O, false>; t[top_bin2(K, C, O, true)] = (uint64_t)&h_bin2<T, K, C, O, true>;
+#define TB(K) TB1(K, false, false) TB1(K, false, true) TB1(K, true, false) TB1(K, true, true)
+    TB(0) TB(1) TB(2) TB(3) TB(4) TB(5)
+#undef TU1
+#undef TU
+#undef TBC
+#undef TB1
+#undef TB
 }
 
 template <typename T, bool PARAMS, bool LOSS = false>
@@ -855,16 +933,16 @@ static hipError_t launch_eval_geo(const EvalArgs &a, hipStream_t stream, const c
 // ---- threaded variant: handler table + launch ---------------------------------------------
 template <typename T> static hipError_t fetch_handlers(uint64_t *host_table) {
     uint64_t *d = nullptr;
-    hipError_t st = hipMalloc(reinterpret_cast<void **>(&d), BOP_COUNT * sizeof(uint64_t));
+    hipError_t st = hipMalloc(reinterpret_cast<void **>(&d), TOP_COUNT * sizeof(uint64_t));
     if (st != hipSuccess) return st;
     hipLaunchKernelGGL(de_fill_handlers<T>, dim3(1), dim3(1), 0, 0, d);
-    st = hipMemcpy(host_table, d, BOP_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    st = hipMemcpy(host_table, d, TOP_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     return st;
 }
 
 hipError_t eval_handler_table(int dtype, uint64_t *table) {
-    static uint64_t cache[2][BOP_COUNT];
+    static uint64_t cache[2][TOP_COUNT];
     static bool have[2] = {false, false};
     const int k = dtype == DE_F32 ? 0 : 1;
     if (!have[k]) {
@@ -872,7 +950,7 @@ hipError_t eval_handler_table(int dtype, uint64_t *table) {
         if (st != hipSuccess) return st;
         have[k] = true;
     }
-    for (int i = 0; i < (int)BOP_COUNT; i++) table[i] = cache[k][i];
+    for (int i = 0; i < (int)TOP_COUNT; i++) table[i] = cache[k][i];
     return hipSuccess;
 }
 
@@ -908,7 +986,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.n_chunks = nch;
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(a.F + a.n_slots) * 257 * 16;
+    const size_t lds = (size_t)(a.F + a.n_slots + env_int("DE_EXTRA_LDS_ROWS", 0)) * 257 * 16;
     void (*kern)(const KArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_eval_threaded_kernel<T, true> : de_eval_threaded_kernel<T, false>;
     a.y = a.w = nullptr;
     a.partial = nullptr;

@@ -163,7 +163,9 @@ int64_t de_program_n_nodes(const de_program_t *prog);
 /* n_grad of tree t in `mode` (src/EvaluateDerivative.jl:204-210). */
 int64_t de_program_n_grad(const de_program_t *prog, int64_t tree, int mode);
 /* Debug/test hook: copy the lowered instruction words of tree t into `words`
- * (capacity `cap` 32-bit words); returns the number of words, or -status. */
+ * (capacity `cap` 32-bit words); returns the number of words, or -status.
+ * which: 0 generic program, 1 metadata, 2 bound program, 3 fused (superinstruction)
+ * program of the threaded eval kernel (0 words when that kernel is not in use). */
 int64_t de_program_dump(const de_program_t *prog, int64_t tree, uint32_t *words, int64_t cap,
                         int which);
 
@@ -175,6 +177,12 @@ int64_t de_program_dump(const de_program_t *prog, int64_t tree, uint32_t *words,
 int64_t de_lower_tape(int dtype, const de_tape_node_t *nodes, int64_t n_nodes, const void *consts,
                       int64_t n_consts, int32_t n_features, int32_t n_params, uint32_t options,
                       uint32_t *words, int64_t cap, int32_t *meta);
+/* Same, for the later host stages of the eval program: stage 2 = bound instructions
+ * (csrc/de_bind.h), stage 3 = fused superinstructions of the threaded kernel.  Host-only. */
+int64_t de_lower_tape_stage(int dtype, const de_tape_node_t *nodes, int64_t n_nodes,
+                            const void *consts, int64_t n_consts, int32_t n_features,
+                            int32_t n_params, uint32_t options, int stage, uint32_t *words,
+                            int64_t cap);
 
 /* ---- evaluation ------------------------------------------------------------ */
 /* Optional per-call inputs of a parametric population
