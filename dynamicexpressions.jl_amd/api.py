@@ -32,7 +32,8 @@ from .node import Node, count_constant_nodes, flatten_population, max_feature
 from .operators import OperatorEnum
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libde_hip.so")
+# DE_HIP_LIB (the variable the Julia shim reads too) selects another build of the same library
+LIB_PATH = os.environ.get("DE_HIP_LIB") or os.path.join(_HERE, "csrc", "libde_hip.so")
 
 DE_F32, DE_F64 = 0, 1
 GRAD_VARIABLE, GRAD_CONSTANT, GRAD_BOTH = 0, 1, 2

@@ -94,34 +94,81 @@ template <> struct M<double> {
 
 // ---- fast Float32 transcendentals for the hot operators ------------------------
 // OCML's cosf/sinf cost ~125 VALU instructions (both reduction paths are inlined and
-// both polynomials evaluated); cos is >50 % of the VALU work of the headline workload.
-// These versions are ~22 VALU on the fast path and keep <=1.6 ulp (measured against a
-// correctly rounded reference over |x| <= 1e5, tests/test_gpu_ops.py):
-//   k = rint(x*2/pi);  r = x - k*pi/2 with pi/2 = C1+C2+C3 (3 FMAs: the first is exact,
-//   the other two round relative to the already-small r, so r keeps full relative
-//   accuracy next to the zeros of cos/sin);  Cephes minimax sin/cos polynomials on
-//   [-pi/4, pi/4];  quadrant select.  |x| > 1e5 (and Inf) takes the OCML Payne-Hanek
-//   path under a divergent branch; NaN flows through the fast path.
+// both polynomials evaluated); cos is the largest single share of the VALU work of the headline
+// workload.  One odd polynomial serves both functions:
+//   sin(x) = (-1)^n sin(r),  r = x - n*pi,          n = rint(x/pi)
+//   cos(x) = (-1)^n sin(r),  r = x - (n - 1/2)*pi,  n = rint(x/pi + 1/2)
+// so r lies in [-pi/2, pi/2] and is SMALL next to the zeros of either function.  pi = P1+P2+P3
+// (3 FMAs: the first is exact — (n - 1/2)*P1 has its last bit at 2^-23 and |r| < 2 — the other
+// two round relative to the already-small r, which keeps full relative accuracy at the zeros).
+// n comes from the 1.5*2^23 magic add (packable; its low mantissa bit is the parity of n, i.e.
+// the sign flip).  sin(r) = r + r^3 Q(r^2), Q = degree-4 minimax of the relative error on
+// |r| <= pi/2 + 0.02 (2.8e-11).  11 VALU per element (6.5 when two elements share v_pk_* ops)
+// instead of 20 (+3 for the exact-extremum select below); <= 2.0 ulp over |x| <= 1e5 (measured:
+// tests/test_gpu_ops.py).  |x| > 1e5 and
+// Inf take the OCML Payne-Hanek path under a divergent branch; NaN flows through the fast path.
 constexpr float DE_TRIG_FAST_BOUND = 1.0e5f;
+#define DE_TRIG_INV_PI 0x1.45f306p-2f
+#define DE_TRIG_MAGIC 12582912.0f
+#define DE_TRIG_P1 0x1.921fb6p+1f
+#define DE_TRIG_P2 -0x1.777a5cp-24f
+#define DE_TRIG_P3 -0x1.ee59dap-49f
+#define DE_TRIG_S0 -0x1.555556p-3f
+#define DE_TRIG_S1 0x1.11110cp-7f
+#define DE_TRIG_S2 -0x1.a017aep-13f
+#define DE_TRIG_S3 0x1.716ac4p-19f
+#define DE_TRIG_S4 -0x1.99e5cap-26f
+// Within 2^-12 of +-pi/2 the correctly rounded sine IS +-1 (1 - d^2/2 with d^2/2 <= 2^-25): return it
+// exactly, so that cos(0) == 1, cos(2k*pi) == 1, sin(pi/2 + k*pi) == +-1 hold bit for bit (the
+// polynomial's 2-ulp worst case sits exactly there, where r + r^3 Q cancels from 1.57 to 1).
+__device__ __forceinline__ float trig_extremum_fix(float r, float s) {
+    const float one = __uint_as_float((__float_as_uint(r) & 0x80000000u) | 0x3f800000u);
+    // two-sided: for |x| near 1e5 the rounding of x/pi can leave |r| up to 0.006 beyond pi/2
+    return __builtin_fabsf(__builtin_fabsf(r) - 0x1.921fb6p+0f) < 0x1.fep-13f ? one : s;
+}
 template <bool SIN> __device__ __forceinline__ float fast_trig_f32(float x) {
-    const float t = x * 0x1.45f306p-1f; // 2/pi
-    const float k = __builtin_rintf(t);
-    float r = __builtin_fmaf(-k, 0x1.921fb6p+0f, x);
-    r = __builtin_fmaf(-k, -0x1.777a5cp-25f, r);
-    r = __builtin_fmaf(-k, -0x1.ee59dap-50f, r);
-    const int q = (int)k;
-    const float r2 = r * r;
-    float c = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    c = __builtin_fmaf(r2, c, 4.166664568298827e-2f);
-    c = __builtin_fmaf(r2, c, -0.5f);
-    c = __builtin_fmaf(r2, c, 1.0f);
-    float p = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    p = __builtin_fmaf(r2, p, -1.6666654611e-1f);
-    const float s = __builtin_fmaf(r * r2, p, r);
-    // cos: q=0:c 1:-s 2:-c 3:s      sin: q=0:s 1:c 2:-s 3:-c
-    const float v = (q & 1) ? (SIN ? c : s) : (SIN ? s : c);
-    const unsigned sign = (SIN ? ((unsigned)q << 30) : (((unsigned)q << 30) + 0x40000000u)) & 0x80000000u;
-    return __uint_as_float(__float_as_uint(v) ^ sign);
+    const float t = SIN ? x * DE_TRIG_INV_PI : __builtin_fmaf(x, DE_TRIG_INV_PI, 0.5f);
+    const float kk = t + DE_TRIG_MAGIC;
+    const float n = kk - DE_TRIG_MAGIC;
+    const float m = SIN ? n : n - 0.5f;
+    float r = __builtin_fmaf(-m, DE_TRIG_P1, x);
+    r = __builtin_fmaf(-m, DE_TRIG_P2, r);
+    r = __builtin_fmaf(-m, DE_TRIG_P3, r);
+    const float z = r * r;
+    float p = __builtin_fmaf(z, DE_TRIG_S4, DE_TRIG_S3);
+    p = __builtin_fmaf(z, p, DE_TRIG_S2);
+    p = __builtin_fmaf(z, p, DE_TRIG_S1);
+    p = __builtin_fmaf(z, p, DE_TRIG_S0);
+    float s = __builtin_fmaf(r * z, p, r);
+#ifndef DE_TRIG_NO_EXTREMUM_FIX
+    s = trig_extremum_fix(r, s);
+#endif
+    return __uint_as_float(__float_as_uint(s) ^ (__float_as_uint(kk) << 31));
+}
+// Two elements at a time: every multiply/add/fma is one v_pk_*_f32.
+typedef float DeF2 __attribute__((ext_vector_type(2)));
+typedef unsigned DeU2 __attribute__((ext_vector_type(2)));
+#define DE_F2(c) (DeF2{(c), (c)})
+template <bool SIN> __device__ __forceinline__ DeF2 fast_trig_f32x2(DeF2 x) {
+    const DeF2 t = SIN ? x * DE_F2(DE_TRIG_INV_PI) : __builtin_elementwise_fma(x, DE_F2(DE_TRIG_INV_PI), DE_F2(0.5f));
+    const DeF2 kk = t + DE_F2(DE_TRIG_MAGIC);
+    const DeF2 n = kk - DE_F2(DE_TRIG_MAGIC);
+    const DeF2 m = SIN ? n : n - DE_F2(0.5f);
+    DeF2 r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P1), x);
+    r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P2), r);
+    r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P3), r);
+    const DeF2 z = r * r;
+    DeF2 p = __builtin_elementwise_fma(z, DE_F2(DE_TRIG_S4), DE_F2(DE_TRIG_S3));
+    p = __builtin_elementwise_fma(z, p, DE_F2(DE_TRIG_S2));
+    p = __builtin_elementwise_fma(z, p, DE_F2(DE_TRIG_S1));
+    p = __builtin_elementwise_fma(z, p, DE_F2(DE_TRIG_S0));
+    DeF2 s = __builtin_elementwise_fma(r * z, p, r);
+#ifndef DE_TRIG_NO_EXTREMUM_FIX
+    s[0] = trig_extremum_fix(r[0], s[0]);
+    s[1] = trig_extremum_fix(r[1], s[1]);
+#endif
+    const DeU2 bits = __builtin_bit_cast(DeU2, s) ^ (__builtin_bit_cast(DeU2, kk) << 31);
+    return __builtin_bit_cast(DeF2, bits);
 }
 // sin and cos of the same argument (value + derivative of cos/sin in the gradient kernel):
 // one reduction, both polynomials, two quadrant selects.  Same accuracy as fast_trig_f32.
@@ -157,6 +204,22 @@ __device__ __forceinline__ float fast_exp_f32(float x) {
     const float e = __builtin_amdgcn_exp2f(r);
     const float y = __builtin_amdgcn_ldexpf(e, (int)k);
     return x != x ? x : y;
+}
+
+// Two elements at a time (v_pk_mul/v_pk_fma for the reduction; exp2/ldexp/rint stay per element).
+__device__ __forceinline__ DeF2 fast_exp_f32x2(DeF2 x) {
+    // med3 also absorbs NaN (patched back in at the end), so no separate canonicalisation
+    const DeF2 xc = {__builtin_amdgcn_fmed3f(x[0], -105.0f, 89.0f), __builtin_amdgcn_fmed3f(x[1], -105.0f, 89.0f)};
+    const DeF2 t = xc * DE_F2(0x1.715476p+0f);
+    const DeF2 k = {__builtin_rintf(t[0]), __builtin_rintf(t[1])};
+    DeF2 r = __builtin_elementwise_fma(xc, DE_F2(0x1.715476p+0f), -k);
+    r = __builtin_elementwise_fma(xc, DE_F2(0x1.4ae0c0p-26f), r);
+    DeF2 y;
+    y[0] = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(r[0]), (int)k[0]);
+    y[1] = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(r[1]), (int)k[1]);
+    y[0] = x[0] != x[0] ? x[0] : y[0];
+    y[1] = x[1] != x[1] ? x[1] : y[1];
+    return y;
 }
 
 // Julia max/min: NaN-propagating, -0 < +0.

@@ -529,11 +529,16 @@ template <typename T, int K> __device__ __forceinline__ typename VecOf<T>::type 
     constexpr int VW = VecOf<T>::W;
     V r;
     if constexpr (sizeof(T) == 4) {
-        if constexpr (K == 1) { DE_UNROLL for (int i = 0; i < VW; i++) r[i] = fast_exp_f32(x[i]); }
-        else {
-            bool big = false;
-            DE_UNROLL for (int i = 0; i < VW; i++) { r[i] = fast_trig_f32<K == 2>(x[i]); big |= fabsf(x[i]) > DE_TRIG_FAST_BOUND; }
-            if (__ballot(big) != 0ull) {
+        const DeF2 lo = {x[0], x[1]}, hi = {x[2], x[3]};
+        if constexpr (K == 1) {
+            const DeF2 a = fast_exp_f32x2(lo), b = fast_exp_f32x2(hi);
+            r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
+        } else {
+            const DeF2 a = fast_trig_f32x2<K == 2>(lo), b = fast_trig_f32x2<K == 2>(hi);
+            r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
+            // max ignores NaN (which the fast path already propagates); Inf and |x| > 1e5 take the slow path
+            const float mx = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+            if (__ballot(mx > DE_TRIG_FAST_BOUND) != 0ull) { // inline: a call here would turn every handler into a non-leaf function
                 DE_UNROLL for (int i = 0; i < VW; i++)
                     if (fabsf(x[i]) > DE_TRIG_FAST_BOUND) r[i] = K == 2 ? sinf(x[i]) : cosf(x[i]);
             }
