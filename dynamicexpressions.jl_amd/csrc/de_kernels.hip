@@ -508,14 +508,52 @@ template <typename T> __device__ __noinline__ HState<T> h_check_row(HARGS) {
 }
 template <typename T> __device__ __noinline__ HState<T> h_check_acc(HARGS) { hpoison<T>(st.poison, st.acc); return st; }
 
+// Correctly rounded Float32 division, 4 samples.  The compiler's expansion of `/` is
+//   v_div_scale x2, v_rcp, 6 dependent FMA/MUL (Newton + two residual corrections), v_div_fmas, v_div_fixup
+// per ELEMENT (11 instructions, none packed): division is 1.6 of the ~9.4 dispatches of a bench tree
+// and a quarter of the VALU time.  When every numerator and denominator of the wavefront lies in
+// [2^-40, 2^40] the scale/fixup steps are the identity (v_div_scale only rescales for exponent
+// differences >= 96, denormals, or tiny numerators), so the SAME arithmetic sequence is run two
+// elements per v_pk_fma_f32 without them — bit-identical results, 38 issue slots instead of 56.
+// Anything else in the wave (zeros, Inf, huge/tiny values; NaN is transparent to max/min and
+// propagates through the FMAs) takes the generic expansion, under a wave-uniform branch.
+__device__ __forceinline__ VecOf<float>::type div_apply(VecOf<float>::type a, VecOf<float>::type b) {
+    typedef VecOf<float>::type V;
+    float hi = fmaxf(fmaxf(fabsf(a[0]), fabsf(b[0])), fabsf(a[1]));
+    hi = fmaxf(fmaxf(hi, fabsf(b[1])), fabsf(a[2]));
+    hi = fmaxf(fmaxf(hi, fabsf(b[2])), fabsf(a[3]));
+    hi = fmaxf(hi, fabsf(b[3]));
+    float lo = fminf(fminf(fabsf(a[0]), fabsf(b[0])), fabsf(a[1]));
+    lo = fminf(fminf(lo, fabsf(b[1])), fabsf(a[2]));
+    lo = fminf(fminf(lo, fabsf(b[2])), fabsf(a[3]));
+    lo = fminf(lo, fabsf(b[3]));
+    const bool safe = (hi < 0x1p+40f) & (lo > 0x1p-40f); // all-NaN compares false: generic path
+    if (__ballot(!safe) != 0ull) return a / b;
+    V q;
+    DE_UNROLL for (int h = 0; h < 2; h++) {
+        const DeF2 n = {a[2 * h], a[2 * h + 1]}, d = {b[2 * h], b[2 * h + 1]};
+        DeF2 y = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const DeF2 e = __builtin_elementwise_fma(-d, y, DE_F2(1.0f));
+        y = __builtin_elementwise_fma(e, y, y);
+        DeF2 t = n * y;
+        DeF2 r = __builtin_elementwise_fma(-d, t, n);
+        t = __builtin_elementwise_fma(r, y, t);
+        r = __builtin_elementwise_fma(-d, t, n);
+        t = __builtin_elementwise_fma(r, y, t);
+        q[2 * h] = t[0];
+        q[2 * h + 1] = t[1];
+    }
+    return q;
+}
+__device__ __forceinline__ VecOf<double>::type div_apply(VecOf<double>::type a, VecOf<double>::type b) { return a / b; }
 // K: 0 ADD 1 SUB 2 RSUB 3 MUL 4 DIV 5 RDIV  —  x op b (R*: b op x)
 template <typename T, int K> __device__ __forceinline__ typename VecOf<T>::type bin_apply(typename VecOf<T>::type x, typename VecOf<T>::type b) {
     if constexpr (K == 0) return x + b;
     else if constexpr (K == 1) return x - b;
     else if constexpr (K == 2) return b - x;
     else if constexpr (K == 3) return x * b;
-    else if constexpr (K == 4) return x / b;
-    else return b / x;
+    else if constexpr (K == 4) return div_apply(x, b);
+    else return div_apply(b, x);
 }
 template <typename T> __device__ __forceinline__ typename VecOf<T>::type splat(typename ImmBits<T>::type imm) {
     typename VecOf<T>::type b;

@@ -101,3 +101,34 @@ def test_fast_exp_within_two_ulp_and_edges(api):
                                eval_context=api.EvalContext(early_exit=False))
     assert o[0] == 0 and o[1] == 0 and np.isposinf(o[2]) and np.isposinf(o[3]) and np.isposinf(o[4]) and o[5] == 0
     assert np.isnan(o[6])
+
+
+def test_division_fast_path_is_bit_identical_to_ieee(api):
+    """The packed Newton division (csrc/de_kernels.hip div_apply) must equal the correctly rounded
+    quotient bit for bit: in-range operands (fast path), and waves that mix in zeros, Inf, NaN,
+    denormals and huge/tiny values (generic path), for all lowered forms x/y, c/x, x/c."""
+    ops = de.OperatorEnum(binary_operators=("/",))
+    g = np.random.Generator(np.random.PCG64(11))
+    N = 1 << 20
+    mags = [(-1, 1), (-12, 12), (-38, 38), (-45, 38)]
+    for lo, hi in mags:
+        a = (10.0 ** g.uniform(lo, hi, N) * g.choice([-1, 1], N)).astype(np.float32)
+        b = (10.0 ** g.uniform(lo, hi, N) * g.choice([-1, 1], N)).astype(np.float32)
+        if lo < -20:  # sprinkle specials into some waves
+            idx = g.integers(0, N, 2000)
+            a[idx[:500]] = 0.0; a[idx[500:700]] = -0.0; b[idx[700:900]] = 0.0
+            a[idx[900:1100]] = np.inf; b[idx[1100:1300]] = -np.inf; a[idx[1300:1500]] = np.nan
+            b[idx[1500:1700]] = np.float32(1e-42); a[idx[1700:2000]] = np.float32(-3e-41)
+        X = np.asfortranarray(np.stack([a, b]))
+        ec = api.EvalContext(early_exit=False)
+        with np.errstate(all="ignore"):
+            want = a / b
+            forms = [(de.Node(1, de.Node(feature=1), de.Node(feature=2)), want),
+                     (de.Node(1, de.Node(val=1.5), de.Node(feature=2)), np.float32(1.5) / b),
+                     (de.Node(1, de.Node(feature=1), de.Node(val=-3.0)), a / np.float32(-3.0)),
+                     (de.Node(1, de.Node(1, de.Node(feature=1), de.Node(feature=2)), de.Node(feature=2)), (a / b) / b)]
+        for tree, w in forms:
+            out, _ = api.eval_tree_array(tree, X, ops, eval_context=ec)
+            nan = np.isnan(w)
+            assert np.array_equal(np.isnan(out), nan)
+            np.testing.assert_array_equal(out[~nan].view(np.uint32), w[~nan].view(np.uint32))
