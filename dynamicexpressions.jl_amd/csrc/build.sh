@@ -22,10 +22,11 @@ build_obj de_bind.cpp _obj/de_bind.o &
 # device IR (irpatch.py: the interpreter's indirect handler calls need none of the implicit kernel inputs).
 # DE_NO_IRPATCH=1 builds it the plain way.
 LLVM=${LLVM:-/opt/rocm/lib/llvm/bin}
-build_kernels() {
-  local src=de_kernels.hip obj=_obj/de_kernels.o tmp=_obj/irp
+build_kernels() { # src obj [extra flags...]
+  local src=$1 obj=$2 tmp=_obj/irp_$(basename $2 .o); shift 2
+  local DE_KERNEL_FLAGS="${DE_KERNEL_FLAGS:-} $*"
   if [ -f "$obj" ] && [ ! "$src" -nt "$obj" ] && [ ! irpatch.py -nt "$obj" ] && [ -z "$(find . ../../include -maxdepth 1 -name '*.h' -newer "$obj" 2>/dev/null | head -1)" ]; then return 0; fi
-  echo "  hipcc $src (device IR -> irpatch -> gfx950 code object -> host object)"
+  echo "  hipcc $src $* (device IR -> irpatch -> gfx950 code object -> host object)"
   rm -f "$obj"; mkdir -p $tmp
   if [ "${DE_NO_IRPATCH:-0}" = 1 ]; then $HIPCC $FLAGS ${DE_KERNEL_FLAGS:-} -c $src -o $obj; return; fi
   $HIPCC $FLAGS ${DE_KERNEL_FLAGS:-} --cuda-device-only -emit-llvm -S $src -o $tmp/k.ll
@@ -36,9 +37,17 @@ build_kernels() {
       -input=/dev/null -input=$tmp/k.out -output=$tmp/k.hipfb
   $HIPCC $FLAGS ${DE_KERNEL_FLAGS:-} --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang $tmp/k.hipfb -c $src -o $obj
 }
-build_kernels &
+build_kernels de_kernels.hip _obj/de_kernels.o &
+# the threaded gradient kernel: one module per (element type, window width), see de_grad_threaded.hip
+GT_OBJS=""
+for spec in f:float:1 f:float:2 f:float:3 f:float:4 f:float:5 f:float:6 f:float:8 d:double:1 d:double:2 d:double:3 d:double:4 d:double:5; do
+  IFS=: read tag ty gc <<< "$spec"
+  GT_OBJS="$GT_OBJS _obj/de_gt_$tag$gc.o"
+  while [ "$(jobs -r | wc -l)" -ge "${DE_BUILD_JOBS:-8}" ]; do sleep 0.2; done
+  build_kernels de_grad_threaded.hip _obj/de_gt_$tag$gc.o -DDE_GT_T=$ty -DDE_GT_TAG=$tag -DDE_GT_GC=$gc &
+done
 build_obj de_grad_kernels.hip _obj/de_grad_kernels.o &
 wait
-for o in _obj/de_lower.o _obj/de_bind.o _obj/de_api.o _obj/de_kernels.o _obj/de_grad_kernels.o; do [ -f $o ] || { echo "missing $o"; exit 1; }; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libde_hip.so _obj/de_lower.o _obj/de_bind.o _obj/de_api.o _obj/de_kernels.o _obj/de_grad_kernels.o
+for o in _obj/de_lower.o _obj/de_bind.o _obj/de_api.o _obj/de_kernels.o _obj/de_grad_kernels.o $GT_OBJS; do [ -f $o ] || { echo "missing $o"; exit 1; }; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libde_hip.so _obj/de_lower.o _obj/de_bind.o _obj/de_api.o _obj/de_kernels.o _obj/de_grad_kernels.o $GT_OBJS
 echo "built $(pwd)/libde_hip.so"

@@ -93,6 +93,15 @@ struct de_program {
     std::vector<BoundInstr> gbcode;
     std::vector<int32_t> gbcode_off;
     bool gcode_stale = true;
+    // threaded form of the gradient program for one (mode, window width): de_grad_threaded.hip
+    std::vector<BoundInstr> gtcode;
+    std::vector<int32_t> gtcode_off;
+    BoundInstr *d_gtcode = nullptr;
+    int32_t *d_gtcode_off = nullptr;
+    int gt_mode = -1, gt_gc = -1;
+    bool gt_valid = false;
+    uint64_t gt_handler_base = 0;
+    uint32_t gt_param_off = 0;
 };
 
 static int fail(de_ctx *c, int code, const char *fmt, ...) {
@@ -586,6 +595,8 @@ int de_program_destroy(de_program_t *p) {
     if (p->aux) de_program_destroy(p->aux);
     if (p->d_gcode) (void)hipFree(p->d_gcode);
     if (p->d_gcode_off) (void)hipFree(p->d_gcode_off);
+    if (p->d_gtcode) (void)hipFree(p->d_gtcode);
+    if (p->d_gtcode_off) (void)hipFree(p->d_gtcode_off);
     delete p;
     return DE_OK;
 }
@@ -907,6 +918,7 @@ static int ensure_generic_code(de_ctx *c, de_program *p) {
         // gradients flow through constant subtrees, so this is the UNFOLDED program; every value the
         // reference tests is tested (ee binding) whatever the eval options were
         p->gbcode.clear();
+        p->gt_valid = false;
         p->gbcode_off.assign((size_t)p->n_trees + 1, 0);
         for (int64_t t = 0; t < p->n_trees; t++) {
             const int32_t i0 = p->code_off[(size_t)t], i1 = p->code_off[(size_t)t + 1];
@@ -927,6 +939,112 @@ static int ensure_generic_code(de_ctx *c, de_program *p) {
             HIP_TRY(c, hipMemcpy(p->d_gcode, p->gbcode.data(), p->gbcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
         p->gcode_stale = false;
     }
+    return DE_OK;
+}
+
+// Threaded form of the gradient program (de_grad_threaded.hip) for (mode, window width of max_grad).
+// Fills g->threaded_code & co. when the program can be expressed in it; otherwise leaves them null and
+// the flat-switch kernel runs.  Call after ensure_generic_code().
+static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, int max_grad, GradArgs *g) {
+    g->threaded_code = nullptr;
+    const char *env = getenv("DE_GRAD_THREADED");
+    if (env && *env == '0') return DE_OK;
+    if (max_grad > 240) return DE_OK; // gradient rows travel in 8 bits
+    const int GC = grad_window(max_grad);
+    // Float64 states wider than 16 dwords are passed through scratch memory by the calling convention
+    if (p->dtype == DE_F64 && GC > 5) return DE_OK;
+    const int F = p->n_features, P = p->n_params;
+    if (!(p->gt_valid && p->gt_mode == mode && p->gt_gc == GC)) {
+        uint64_t table[GOP_COUNT];
+        hipError_t st = grad_handler_table(p->dtype, GC, table);
+        if (st != hipSuccess) return fail(c, DE_ERR_HIP, "gradient handler table: %s", hipGetErrorString(st));
+        uint64_t base = table[0];
+        for (int i = 0; i < (int)GOP_COUNT; i++) base = std::min<uint64_t>(base, table[i]);
+        for (int i = 0; i < (int)GOP_COUNT; i++)
+            if (table[i] - base > 0xFFFFFFFFull) return DE_OK;
+        const uint32_t RB = (uint32_t)(260 * (p->dtype == DE_F32 ? 4 : 8)); // row bytes: (GBLK + 4) elements
+        if (((uint64_t)F + (uint64_t)p->n_slots * (1 + GC)) * RB >= (1u << 24)) return DE_OK;
+        auto slot_off = [&](uint32_t row) { return (uint32_t)((F + (row - (uint32_t)F) * (1 + GC)) * RB); };
+        auto leaf_seed = [&](uint32_t f) -> uint32_t { return mode != DE_GRAD_CONSTANT ? (uint32_t)P + f : 0xFFu; };
+        auto const_seed = [&](uint32_t ord) -> uint32_t {
+            return mode == DE_GRAD_CONSTANT ? ord : (mode == DE_GRAD_BOTH ? (uint32_t)(P + F) + ord : 0xFFu);
+        };
+        p->gtcode.clear();
+        p->gtcode_off.assign((size_t)p->n_trees + 1, 0);
+        bool ok = true;
+        for (int64_t t = 0; t < p->n_trees && ok; t++) {
+            for (int32_t i = p->gbcode_off[(size_t)t]; i < p->gbcode_off[(size_t)t + 1] && ok; i++) {
+                const BoundInstr &b = p->gbcode[(size_t)i];
+                const uint32_t row = b.arg & 0xFFFFFFu, aux = b.arg >> 24;
+                BoundInstr o = b;
+                uint32_t gop = GOP_COUNT;
+                auto row_operand = [&](uint32_t leaf_op, uint32_t slot_op) { // sets gop and o.arg for a row operand
+                    if (row < (uint32_t)F) {
+                        const uint32_t sd = leaf_seed(row);
+                        if (sd != 0xFFu && sd >= 0xF0u) ok = false;
+                        gop = leaf_op;
+                        o.arg = (row * RB) | (sd << 24);
+                    } else {
+                        gop = slot_op;
+                        o.arg = slot_off(row);
+                    }
+                };
+                auto const_operand = [&](uint32_t ord, uint32_t low) {
+                    const uint32_t sd = const_seed(ord);
+                    if (sd != 0xFFu && sd >= 0xF0u) ok = false;
+                    o.arg = low | (sd << 24);
+                };
+                if (b.bop == BOP_CHECK_ROW) continue; // leaf operands are tested where they are read
+                if (b.bop == BOP_LOAD_ROW) row_operand(GOP_LOAD_LEAF, GOP_LOAD_SLOT);
+                else if (b.bop == BOP_LOAD_CONST) { gop = GOP_LOAD_CONST; const_operand(b.arg & 0xFFFFu, 0); }
+                else if (b.bop == BOP_PUSH) { gop = GOP_PUSH; o.arg = slot_off(row); }
+                else if (b.bop == BOP_CHECK_ACC) { gop = GOP_CHECK_ACC; o.arg = 0; }
+                else if (b.bop >= BOP_BIN_BASE && b.bop < BOP_BIN_END) {
+                    const uint32_t v = b.bop - BOP_BIN_BASE;
+                    const int k = (int)(v >> 2);
+                    const bool chk = v & 1;
+                    if (v & 2) { gop = gop_bin(k, 2, chk); const_operand(b.arg & 0xFFFFu, 0); }
+                    else row_operand(gop_bin(k, 0, chk), gop_bin(k, 1, chk));
+                } else if (b.bop >= BOP_UN_BASE && b.bop < BOP_UN_END) {
+                    const uint32_t v = b.bop - BOP_UN_BASE;
+                    const int k = (int)(v >> 2);
+                    const bool chk = v & 1;
+                    if (v & 2) row_operand(gop_un(k, 0, chk), gop_un(k, 1, chk));
+                    else { gop = gop_un(k, 3, chk); o.arg = 0; }
+                } else if (b.bop == BOP_GEN_ROW) { row_operand(GOP_GEN_LEAF, GOP_GEN_SLOT); o.lo = aux; o.hi = 0; }
+                else if (b.bop == BOP_GEN_CONST) { gop = GOP_GEN_CONST; const_operand(b.arg & 0xFFFFu, aux << 16); }
+                else if (b.bop == BOP_GEN_ACC) { gop = GOP_GEN_ACC; o.arg = 0; o.lo = aux; o.hi = 0; }
+                else if (b.bop == BOP_GEN_PARAM) { gop = GOP_PARAM; o.arg = b.arg; }
+                else if (b.bop == BOP_TERN) {
+                    if (row < (uint32_t)F || b.lo < (uint32_t)F) ok = false; // both operands are spilled duals
+                    else { gop = GOP_TERN; o.arg = slot_off(row) | (aux << 24); o.lo = slot_off(b.lo) - slot_off(row); o.hi = 0; }
+                } else ok = false; // INJ_*: only bound with early_exit=false, never for gradients
+                if (!ok) break;
+                o.bop = (uint32_t)(table[gop] - base);
+                p->gtcode.push_back(o);
+            }
+            p->gtcode_off[(size_t)t + 1] = (int32_t)p->gtcode.size();
+        }
+        if (!ok) return DE_OK;
+        if (!p->d_gtcode) {
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode), (p->gbcode.size() + 1) * sizeof(BoundInstr)));
+            HIP_TRY(c, hipMemset(p->d_gtcode, 0, (p->gbcode.size() + 1) * sizeof(BoundInstr)));
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode_off), p->gtcode_off.size() * sizeof(int32_t)));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); // the previous form may be in use by queued work
+        if (!p->gtcode.empty())
+            HIP_TRY(c, hipMemcpy(p->d_gtcode, p->gtcode.data(), p->gtcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(p->d_gtcode_off, p->gtcode_off.data(), p->gtcode_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        p->gt_handler_base = base;
+        p->gt_param_off = (uint32_t)(table[GOP_PARAM] - base);
+        p->gt_mode = mode;
+        p->gt_gc = GC;
+        p->gt_valid = true;
+    }
+    g->threaded_code = p->d_gtcode;
+    g->e.code_off = p->d_gtcode_off;
+    g->handler_base = p->gt_handler_base;
+    g->param_handler_off = p->gt_param_off;
     return DE_OK;
 }
 
@@ -1039,6 +1157,10 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
     g.max_grad = maxg;
     g.diff_direction = diff ? diff_direction : -1;
     g.e.code_off = p->d_gcode_off;
+    if (!diff) {
+        rc = ensure_grad_threaded(c, p, mode, maxg, &g);
+        if (rc) return rc;
+    }
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, launch_grad(p->dtype, g, c->stream, &c->last_kernel));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -1204,6 +1326,8 @@ int de_eval_loss_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, in
     g.n_cols = n_cols;
     g.dloss = sDl.dev;
     g.dloss_off = static_cast<const int64_t *>(c->sDoff.p);
+    rc = ensure_grad_threaded(c, p, mode, maxg, &g);
+    if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, launch_grad(p->dtype, g, c->stream, &c->last_kernel));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));

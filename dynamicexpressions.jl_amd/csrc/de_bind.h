@@ -82,6 +82,28 @@ constexpr uint32_t top_unrow(int k, bool out, bool push, bool chk) { return TOP_
 constexpr uint32_t top_binrowc(int k, bool out) { return TOP_BINROWC_BASE + k * 2 + out; }
 constexpr uint32_t top_bin2(int k, bool cst, bool out, bool push) { return TOP_BIN2_BASE + ((k * 2 + cst) * 2 + out) * 2 + push; }
 
+// ---- handler ids of the threaded GRADIENT kernel (de_grad_threaded.hip) ----------------------------
+// Operand kinds are resolved on the host: LEAF = feature row (one-hot seed), SLOT = spilled dual
+// number, CONST = inline constant (seed by ordinal), ACC.
+enum GradOp : uint32_t {
+    GOP_LOAD_LEAF = 0,
+    GOP_LOAD_SLOT,
+    GOP_LOAD_CONST,
+    GOP_PUSH,
+    GOP_CHECK_ACC,
+    GOP_BIN_BASE,                     // + (k*3 + src)*2 + chk,  src: 0 LEAF 1 SLOT 2 CONST   (36)
+    GOP_UN_BASE = GOP_BIN_BASE + 36,  // + (k*3 + src)*2 + chk,  src: 0 LEAF 1 SLOT 2 ACC     (18)
+    GOP_GEN_LEAF = GOP_UN_BASE + 18,
+    GOP_GEN_SLOT,
+    GOP_GEN_CONST,
+    GOP_GEN_ACC,
+    GOP_PARAM,
+    GOP_TERN,
+    GOP_COUNT
+};
+constexpr uint32_t gop_bin(int k, int src, bool chk) { return GOP_BIN_BASE + (k * 3 + src) * 2 + chk; }
+constexpr uint32_t gop_un(int k, int src, bool chk) { return GOP_UN_BASE + (k * 3 + (src == 3 ? 2 : src)) * 2 + chk; } // src 3 = ACC
+
 // Fused form of one tree's bound instructions (appended to `out`).
 void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out);
 // True when the fused instruction's operand is an inline constant (arg carries no operand row).

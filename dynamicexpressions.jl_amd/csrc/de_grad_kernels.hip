@@ -12,195 +12,10 @@
 //   * after EVERY node (leaves included) x and all d[k] are validity-tested (:239-242);
 //   * eval_diff (single direction) performs NO validity test (:99-119).
 // Partial derivatives restate ChainRules' scalar rules (same table as oracle/de_oracle_ops.h).
-#include <hip/hip_runtime.h>
-
-#include <cstdlib>
-
-#include "de_device_ops.h"
-#include "de_kernels.h"
+#include "de_grad_common.h"
 
 namespace de {
 
-#define DE_CONSTANT __attribute__((address_space(4)))
-typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
-typedef const DE_CONSTANT U32x4 *ConstU4Ptr;
-typedef const DE_CONSTANT int32_t *ConstI32Ptr;
-typedef const DE_CONSTANT int64_t *ConstI64Ptr;
-#define DE_UNROLL _Pragma("unroll")
-
-template <typename T> struct GArgs {
-    const BoundInstr *code;  // BOUND form of the UNFOLDED program (de_bind.h, ee binding), +1 pad
-    const int32_t *code_off; // n_trees + 1
-    const T *X;
-    T *out;                  // may be null
-    T *grad;
-    const int64_t *grad_off; // n_trees element offsets
-    const int32_t *n_grad;   // n_trees
-    uint8_t *ok;
-    const T *params;
-    const void *classes;
-    int64_t N, ldX, ld_out, ld_params, n_tiles;
-    int32_t F, P, n_trees, trees_per_chunk, n_chunks, n_slots, mode;
-    int32_t classes_is_i64, class_base, uses_params, check;
-    int32_t diff_g0; // >= 0: eval_diff mode — single component diff_g0, dense [n_trees, ld_out] output
-    // fused loss + pullback (de_eval_loss_grad): instead of storing x and d[k] the kernel reduces
-    //   sum_j w_j l(x_j - y_j)   and   sum_j w_j l'(x_j - y_j) d_k[j]   per wavefront
-    int32_t loss_mode;       // 0 = off, 1 + de_loss_kind otherwise
-    const T *y;
-    const T *w;              // may be null
-    T *partial;              // [n_tiles][n_cols][4 waves]; tree t owns columns col_off[t] .. col_off[t] + n_grad[t] (loss first)
-    const int64_t *col_off;  // n_trees + 1
-};
-
-template <typename T> __device__ __forceinline__ T gimm(uint32_t w2, uint32_t w3);
-template <> __device__ __forceinline__ float gimm<float>(uint32_t w2, uint32_t) { return __uint_as_float(w2); }
-template <> __device__ __forceinline__ double gimm<double>(uint32_t w2, uint32_t w3) {
-    return __longlong_as_double((long long)(((unsigned long long)w3 << 32) | w2));
-}
-
-// value + partial of a unary operator; Zygote `nothing` -> 0 (ext/DynamicExpressionsZygoteExt.jl:12-15)
-template <typename T> struct UG { T y, g; };
-template <typename T> __device__ __noinline__ UG<T> unary_vg(uint32_t op, T x) {
-    using m = M<T>;
-    UG<T> r;
-    const T LN2 = T(0.693147180559945309417232121458176568), LN10 = T(2.302585092994045684017991454684364208);
-    switch (op) {
-    case DE_U_NEG: r.y = -x; r.g = T(-1); break;
-    case DE_U_ABS: r.y = m::abs(x); r.g = jl_sign(x); break;
-    case DE_U_SQUARE: r.y = x * x; r.g = x + x; break;
-    case DE_U_CUBE: r.y = (x * x) * x; r.g = (T(3) * x) * x; break;
-    case DE_U_RELU: r.y = x < T(0) ? T(0) : x; r.g = x < T(0) ? T(0) : T(1); break;
-    case DE_U_SIGN: r.y = jl_sign(x); r.g = T(0); break;
-    case DE_U_ROUND: r.y = m::rint(x); r.g = T(0); break;
-    case DE_U_FLOOR: r.y = m::floor(x); r.g = T(0); break;
-    case DE_U_CEIL: r.y = m::ceil(x); r.g = T(0); break;
-    case DE_U_INV: r.y = T(1) / x; r.g = -(r.y * r.y); break;
-    case DE_U_SQRT: r.y = m::sqrt(x); r.g = T(1) / (T(2) * r.y); break;
-    case DE_U_CBRT: r.y = m::cbrt(x); r.g = T(1) / (T(3) * (r.y * r.y)); break;
-    case DE_U_EXP: r.y = m::exp(x); r.g = r.y; break;
-    case DE_U_EXP2: r.y = m::exp2(x); r.g = r.y * LN2; break;
-    case DE_U_LOG: r.y = m::log(x); r.g = T(1) / x; break;
-    case DE_U_LOG2: r.y = m::log2(x); r.g = (T(1) / x) / LN2; break;
-    case DE_U_LOG10: r.y = m::log10(x); r.g = (T(1) / x) / LN10; break;
-    case DE_U_LOG1P: r.y = m::log1p(x); r.g = T(1) / (x + T(1)); break;
-    case DE_U_SIN: r.y = m::sin(x); r.g = m::cos(x); break;
-    case DE_U_COS: r.y = m::cos(x); r.g = -m::sin(x); break;
-    case DE_U_TAN: r.y = m::tan(x); r.g = T(1) + r.y * r.y; break;
-    case DE_U_SINH: r.y = m::sinh(x); r.g = m::cosh(x); break;
-    case DE_U_COSH: r.y = m::cosh(x); r.g = m::sinh(x); break;
-    case DE_U_TANH: r.y = m::tanh(x); r.g = T(1) - r.y * r.y; break;
-    case DE_U_ASIN: r.y = m::asin(x); r.g = T(1) / m::sqrt(T(1) - x * x); break;
-    case DE_U_ACOS: r.y = m::acos(x); r.g = -(T(1) / m::sqrt(T(1) - x * x)); break;
-    case DE_U_ATAN: r.y = m::atan(x); r.g = T(1) / (T(1) + x * x); break;
-    case DE_U_ASINH: r.y = m::asinh(x); r.g = T(1) / m::sqrt(x * x + T(1)); break;
-    case DE_U_ACOSH: r.y = m::acosh(x); r.g = T(1) / (m::sqrt(x - T(1)) * m::sqrt(x + T(1))); break;
-    case DE_U_ATANH: r.y = m::atanh(x); r.g = T(1) / (T(1) - x * x); break;
-    case DE_U_SAFE_LOG: r.y = x <= T(0) ? m::nan() : m::log(x); r.g = x <= T(0) ? T(0) : T(1) / x; break;
-    case DE_U_SAFE_LOG2: r.y = x <= T(0) ? m::nan() : m::log2(x); r.g = x <= T(0) ? T(0) : (T(1) / x) / LN2; break;
-    case DE_U_SAFE_LOG10: r.y = x <= T(0) ? m::nan() : m::log10(x); r.g = x <= T(0) ? T(0) : (T(1) / x) / LN10; break;
-    case DE_U_SAFE_LOG1P: r.y = x <= T(-1) ? m::nan() : m::log1p(x); r.g = x <= T(-1) ? T(0) : T(1) / (x + T(1)); break;
-    case DE_U_SAFE_SQRT:
-        if (x < T(0)) { r.y = m::nan(); r.g = T(0); } else { r.y = m::sqrt(x); r.g = T(1) / (T(2) * r.y); }
-        break;
-    case DE_U_SAFE_ACOSH:
-        r.y = x < T(1) ? m::nan() : m::acosh(x);
-        r.g = x < T(1) ? T(0) : T(1) / (m::sqrt(x - T(1)) * m::sqrt(x + T(1)));
-        break;
-    case DE_U_COS2: { const T c = m::cos(x), s = m::sin(x); r.y = c * c; r.g = (T(2) * c) * (-s); } break;
-    case DE_U_GAMMA: r.y = m::tgamma(x); r.g = r.y * dev_digamma(x); break;
-    default: r.y = m::nan(); r.g = m::nan(); break;
-    }
-    return r;
-}
-
-// value + both partials of op(x, y) (x = first/left argument)
-template <typename T> struct BG { T v, gx, gy; };
-template <typename T> __device__ __noinline__ BG<T> binary_vg(uint32_t op, T x, T y) {
-    using m = M<T>;
-    BG<T> r;
-    switch (op) {
-    case DE_B_ADD: r.v = x + y; r.gx = T(1); r.gy = T(1); break;
-    case DE_B_SUB: r.v = x - y; r.gx = T(1); r.gy = T(-1); break;
-    case DE_B_MUL: r.v = x * y; r.gx = y; r.gy = x; break;
-    case DE_B_DIV: r.v = x / y; r.gx = T(1) / y; r.gy = -(r.v / y); break;
-    case DE_B_POW: { // ChainRules _pow_grad_x / _pow_grad_p (real case)
-        r.v = m::pow(x, y);
-        if (x != T(0) || y < T(0)) r.gx = (!m::isfinite(x) && x == x && y == T(1)) ? T(1) : (r.v * y) / x;
-        else if (y == T(1)) r.gx = T(1);
-        else if (y == T(0) || y > T(1)) r.gx = T(0);
-        else r.gx = m::inf();
-        if (x != T(0)) r.gy = r.v * m::log(m::abs(x));
-        else if (y > T(0)) r.gy = T(0);
-        else r.gy = m::nan();
-    } break;
-    case DE_B_MAX: { const bool gt = x > y; r.v = jl_max(x, y); r.gx = gt ? T(1) : T(0); r.gy = gt ? T(0) : T(1); } break;
-    case DE_B_MIN: { const bool gt = x > y; r.v = jl_min(x, y); r.gx = gt ? T(0) : T(1); r.gy = gt ? T(1) : T(0); } break;
-    case DE_B_MOD: {
-        r.v = jl_mod(x, y);
-        const T u = x / y;
-        const bool isint = (u == m::floor(u)) && m::isfinite(u);
-        r.gx = isint ? m::nan() : T(1);
-        r.gy = isint ? m::nan() : -m::floor(u);
-    } break;
-    case DE_B_REM: {
-        r.v = m::fmod(x, y);
-        const T u = x / y;
-        const bool isint = (u == m::floor(u)) && m::isfinite(u);
-        r.gx = isint ? m::nan() : T(1);
-        r.gy = isint ? m::nan() : -m::trunc(u);
-    } break;
-    case DE_B_GREATER: r.v = x > y ? T(1) : T(0); r.gx = T(0); r.gy = T(0); break;
-    case DE_B_POW_ABS2: {
-        const T a = m::abs(x), l = m::log(a), mm = y * l;
-        r.v = m::exp(mm);
-        r.gx = ((r.v * y) * (T(1) / a)) * jl_sign(x);
-        r.gy = r.v * l;
-    } break;
-    default: r.v = r.gx = r.gy = m::nan(); break;
-    }
-    return r;
-}
-
-template <typename T> struct TG { T v, g0, g1, g2; };
-template <typename T> __device__ __noinline__ TG<T> ternary_vg(uint32_t op, T x, T y, T z) {
-    using m = M<T>;
-    TG<T> r;
-    switch (op) {
-    case DE_T_FMA: r.v = m::fma(x, y, z); r.g0 = y; r.g1 = x; r.g2 = T(1); break;
-    case DE_T_CLAMP:
-        r.v = x > z ? z : (x < y ? y : x);
-        r.g0 = (x > z || x < y) ? T(0) : T(1);
-        r.g1 = (x > z) ? T(0) : (x < y ? T(1) : T(0));
-        r.g2 = (x > z) ? T(1) : T(0);
-        break;
-    case DE_T_ADD3: r.v = (x + y) + z; r.g0 = r.g1 = r.g2 = T(1); break;
-    default: {
-        const T mx = jl_max(x, y);
-        const bool gt1 = x > y, gt2 = mx > z;
-        r.v = jl_max(mx, z);
-        r.g0 = (gt2 && gt1) ? T(1) : T(0);
-        r.g1 = (gt2 && !gt1) ? T(1) : T(0);
-        r.g2 = gt2 ? T(0) : T(1);
-    } break;
-    }
-    return r;
-}
-
-struct GTileMap { int64_t tile; int32_t chunk; bool valid; };
-__device__ __forceinline__ GTileMap gmap_block(uint32_t bid, int32_t n_chunks, int64_t n_tiles) {
-    const uint32_t xcd = bid & 7u, idx = bid >> 3;
-    GTileMap m;
-    m.chunk = (int32_t)(idx % (uint32_t)n_chunks);
-    m.tile = (int64_t)(idx / (uint32_t)n_chunks) * 8 + xcd;
-    m.valid = m.tile < n_tiles;
-    return m;
-}
-
-__device__ __noinline__ void gflag_incomplete(uint8_t *ok) {
-    if ((threadIdx.x & 63) == 0) *ok = 0;
-}
-
-constexpr int GBLK = 256;
 
 // One sample per thread; LDS rows of GBLK(+4) elements: rows [0,F) = X tile, then each spill
 // slot s owns 1+GC rows (x, d[0..GC)).
@@ -525,14 +340,27 @@ static hipError_t launch_grad_t(const GradArgs &ga, int windows, hipStream_t str
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)windows), dim3(GBLK), lds, stream, a);
     hipError_t st = hipGetLastError();
     if (st != hipSuccess || !ga.loss) return st;
-    // passes 2 and 3 of the deterministic reduction (pass 2 is shared with de_eval_loss)
+    return launch_loss_grad_finish(sizeof(T) == 4 ? DE_F32 : DE_F64, ga, a.n_tiles, stream);
+}
+
+// passes 2 and 3 of the deterministic loss-gradient reduction (pass 2 is shared with de_eval_loss)
+template <typename T> static hipError_t loss_grad_finish_t(const GradArgs &ga, int64_t n_tiles, hipStream_t stream) {
     int32_t n_segs = 1;
-    st = launch_loss_reduce_tiles(sizeof(T) == 4 ? DE_F32 : DE_F64, a.partial, ga.n_cols * 4, a.n_tiles, ga.loss->seg_sum, &n_segs, stream);
+    hipError_t st = launch_loss_reduce_tiles(sizeof(T) == 4 ? DE_F32 : DE_F64, ga.loss->partial, ga.n_cols * 4, n_tiles, ga.loss->seg_sum,
+                                             &n_segs, stream);
     if (st != hipSuccess) return st;
-    hipLaunchKernelGGL(de_loss_grad_finish_kernel<T>, dim3((unsigned)((e.n_trees + 255) / 256)), dim3(256), 0, stream,
-                       static_cast<const double *>(ga.loss->seg_sum), (int64_t)e.n_trees, ga.n_cols, n_segs, ga.col_off, ga.n_grad,
-                       e.ok, static_cast<T *>(ga.loss->loss), static_cast<T *>(ga.dloss), ga.dloss_off);
+    hipLaunchKernelGGL(de_loss_grad_finish_kernel<T>, dim3((unsigned)((ga.e.n_trees + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<const double *>(ga.loss->seg_sum), (int64_t)ga.e.n_trees, ga.n_cols, n_segs, ga.col_off, ga.n_grad,
+                       ga.e.ok, static_cast<T *>(ga.loss->loss), static_cast<T *>(ga.dloss), ga.dloss_off);
     return hipGetLastError();
+}
+hipError_t launch_loss_grad_finish(int dtype, const GradArgs &ga, int64_t n_tiles, hipStream_t stream) {
+    return dtype == DE_F32 ? loss_grad_finish_t<float>(ga, n_tiles, stream) : loss_grad_finish_t<double>(ga, n_tiles, stream);
+}
+
+int grad_window(int max_grad) {
+    const int m = max_grad < 1 ? 1 : max_grad;
+    return m <= 6 ? m : 8; // smallest window that covers the widest gradient in one pass, else windows of 8
 }
 
 template <typename T> static hipError_t launch_grad_dt(const GradArgs &ga, hipStream_t stream) {
@@ -547,7 +375,41 @@ template <typename T> static hipError_t launch_grad_dt(const GradArgs &ga, hipSt
     return launch_grad_t<T, 8>(ga, (maxg + 7) / 8, stream);
 }
 
+// ---- threaded variant: one module per (type, window) — de_grad_threaded.hip ---------------------------
+#define DE_GT_DECL(TAG, GC)                                                     \
+    hipError_t grad_thr_fetch_##TAG##GC(uint64_t *host_table);                  \
+    hipError_t grad_thr_launch_##TAG##GC(const GradArgs &ga, int windows, hipStream_t stream);
+#define DE_GT_ALL(X) X(f, 1) X(f, 2) X(f, 3) X(f, 4) X(f, 5) X(f, 6) X(f, 8) X(d, 1) X(d, 2) X(d, 3) X(d, 4) X(d, 5)
+DE_GT_ALL(DE_GT_DECL)
+
+hipError_t grad_handler_table(int dtype, int GC, uint64_t *table) {
+    static uint64_t cache[2][9][GOP_COUNT];
+    static bool have[2][9] = {};
+    const int k = dtype == DE_F32 ? 0 : 1;
+    if (GC < 1 || GC > 8 || GC == 7 || (k == 1 && GC > 5)) return hipErrorInvalidValue;
+    if (!have[k][GC]) {
+        hipError_t st = hipErrorInvalidValue;
+#define DE_GT_FETCH(TAG, G) if (k == (#TAG[0] == 'f' ? 0 : 1) && GC == G) st = grad_thr_fetch_##TAG##G(cache[k][GC]);
+        DE_GT_ALL(DE_GT_FETCH)
+        if (st != hipSuccess) return st;
+        have[k][GC] = true;
+    }
+    for (int i = 0; i < (int)GOP_COUNT; i++) table[i] = cache[k][GC][i];
+    return hipSuccess;
+}
+
+hipError_t launch_grad_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name) {
+    if (kernel_name) *kernel_name = "de_grad_threaded_kernel";
+    const int maxg = a.max_grad < 1 ? 1 : a.max_grad;
+    const int GC = grad_window(maxg), windows = GC == 8 ? (maxg + 7) / 8 : 1;
+    const int k = dtype == DE_F32 ? 0 : 1;
+#define DE_GT_LAUNCH(TAG, G) if (k == (#TAG[0] == 'f' ? 0 : 1) && GC == G) return grad_thr_launch_##TAG##G(a, windows, stream);
+    DE_GT_ALL(DE_GT_LAUNCH)
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_grad(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name) {
+    if (a.threaded_code && a.diff_direction < 0) return launch_grad_threaded(dtype, a, stream, kernel_name);
     if (kernel_name) *kernel_name = "de_grad_tape_kernel";
     if (a.diff_direction >= 0) return dtype == DE_F32 ? launch_grad_t<float, 1>(a, 1, stream) : launch_grad_t<double, 1>(a, 1, stream);
     if (dtype == DE_F32) return launch_grad_dt<float>(a, stream);

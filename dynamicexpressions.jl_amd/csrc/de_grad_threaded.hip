@@ -1,0 +1,401 @@
+// de_grad_threaded.hip — forward-mode gradient kernel, threaded-code variant (gfx950).
+// Same semantics as de_grad_tape_kernel (de_grad_kernels.hip; reference src/EvaluateDerivative.jl:
+// eval_grad_tree_array :193-243, grad_degn_eval :340-365, grad_deg0_eval :367-404): every sample
+// carries a dual number (x, d[0..GC)) through the bound UNFOLDED program.  The flat switch of that
+// kernel costs ~37 scalar instructions per interpreted instruction and a gradient wave holds ONE
+// sample per lane, so scalar issue — not the dual arithmetic — was its limit.  Here every
+// (operator, operand kind, check) combination is its own leaf function, reached by one indirect
+// call (14 scalar + 2 vector instructions with csrc/irpatch.py); operand kinds are resolved on the
+// host (leaf row / spill slot / constant), so handlers are straight-line code.
+//
+// Instruction word (16 B, built by de_api.cpp make_grad_threaded from the bound program):
+//   x = handler address - handler base
+//   y = LDS byte offset of the operand (leaf row or spill slot base) | aux << 24
+//         aux = gradient row seeded by a leaf/constant operand (0xFF: none in this mode);
+//         for GOP_GEN_CONST y[23:16] = de_opcode (no LDS operand), for GOP_TERN aux = de_opcode
+//   z,w = constant bits | de_opcode (generic row/acc handlers) | byte distance slot B -> slot C (TERN)
+// The window offset g0 travels in the state (a uniform VGPR that never moves): seed = aux - g0.
+//
+// ONE translation unit (= one code object module) per (element type, window width): for an indirect call
+// LLVM sizes the kernel's register file for the most expensive address-taken function of the MODULE,
+// so with every instantiation in one module the Float32 GC=5 kernel was allocated the 104 VGPRs of the
+// Float64 GC=8 handlers (4 waves/SIMD instead of 8).  build.sh compiles this file with
+// -DDE_GT_T=float|double -DDE_GT_TAG=f|d -DDE_GT_GC=1..6,8; de_grad_kernels.hip dispatches.
+#include "de_grad_common.h"
+
+#ifndef DE_GT_T
+#error "compile with -DDE_GT_T=<float|double> -DDE_GT_TAG=<f|d> -DDE_GT_GC=<n>"
+#endif
+
+namespace de {
+
+template <typename T> struct GImm;
+template <> struct GImm<float> { typedef uint32_t type; };
+template <> struct GImm<double> { typedef uint64_t type; };
+template <typename T> __device__ __forceinline__ T gimm_from(typename GImm<T>::type b);
+template <> __device__ __forceinline__ float gimm_from<float>(uint32_t b) { return __uint_as_float(b); }
+template <> __device__ __forceinline__ double gimm_from<double>(uint64_t b) { return __longlong_as_double((long long)b); }
+
+template <typename T, int GC> struct GState {
+    T x;
+    T d[GC];
+    T poison;
+    uint32_t g0;
+};
+template <typename T, int GC> struct GDual {
+    T x;
+    T d[GC];
+};
+#define GHARGS GState<T, GC> st, uint32_t la, typename GImm<T>::type imm
+template <typename T, int GC> using GHandlerFn = GState<T, GC> (*)(GState<T, GC>, uint32_t, typename GImm<T>::type);
+#define GLDS(T, addr) (reinterpret_cast<__attribute__((address_space(3))) T *>((uintptr_t)(addr)))
+template <typename T> constexpr uint32_t grow_bytes() { return (uint32_t)((GBLK + 4) * sizeof(T)); }
+
+// operand kinds
+enum { GS_LEAF = 0, GS_SLOT = 1, GS_CONST = 2, GS_ACC = 3 };
+
+template <typename T, int GC, int SRC> __device__ __forceinline__ GDual<T, GC> goperand(GState<T, GC> &st, uint32_t la, typename GImm<T>::type imm) {
+    GDual<T, GC> b;
+    if constexpr (SRC == GS_SLOT) {
+        b.x = *GLDS(T, la);
+        DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = *GLDS(T, la + (1 + k) * grow_bytes<T>());
+    } else if constexpr (SRC == GS_ACC) {
+        b.x = st.x;
+        DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = st.d[k];
+    } else {
+        if constexpr (SRC == GS_LEAF) {
+            b.x = *GLDS(T, la & 0xFFFFFFu);
+            st.poison = M<T>::fma(b.x, T(0), st.poison); // every leaf operand is tested where it is read (:239-242)
+        } else b.x = gimm_from<T>(imm);
+        const int seed = (int)(la >> 24) - (int)st.g0;
+        DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = (k == seed) ? T(1) : T(0);
+    }
+    return b;
+}
+
+template <typename T, int GC, int SRC> __device__ __noinline__ GState<T, GC> g_load(GHARGS) {
+    const GDual<T, GC> b = goperand<T, GC, SRC>(st, la, imm);
+    st.x = b.x;
+    DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = b.d[k];
+    return st;
+}
+template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_push(GHARGS) {
+    *GLDS(T, la) = st.x;
+    DE_UNROLL for (int k = 0; k < GC; k++) *GLDS(T, la + (1 + k) * grow_bytes<T>()) = st.d[k];
+    return st;
+}
+template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_check_acc(GHARGS) {
+    st.poison = M<T>::fma(st.x, T(0), st.poison);
+    return st;
+}
+template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_nop(GHARGS) { return st; }
+
+// binary hot ops: value v and partials (gl, gr) w.r.t. (left, right); K 2/5 (RSUB/RDIV): left = operand.
+// The formulas (and their operation order) are the oracle's / the switch kernel's: d = gl*dl + gr*dr dense.
+template <typename T, int GC, int K, int SRC, bool CHK> __device__ __noinline__ GState<T, GC> g_bin(GHARGS) {
+    const GDual<T, GC> b = goperand<T, GC, SRC>(st, la, imm);
+    constexpr bool REV = (K == 2 || K == 5);
+    const T lx = REV ? b.x : st.x, ly = REV ? st.x : b.x;
+    T v, gl, gr;
+    if constexpr (K == 0) { v = lx + ly; gl = T(1); gr = T(1); }
+    else if constexpr (K == 1 || K == 2) { v = lx - ly; gl = T(1); gr = T(-1); }
+    else if constexpr (K == 3) { v = lx * ly; gl = ly; gr = lx; }
+    else { v = lx / ly; gl = T(1) / ly; gr = -(v / ly); }
+    st.x = v;
+    if constexpr (REV) { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = gl * b.d[k] + gr * st.d[k]; }
+    else { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = gl * st.d[k] + gr * b.d[k]; }
+    if constexpr (CHK) st.poison = M<T>::fma(st.x, T(0), st.poison);
+    return st;
+}
+// unary hot ops (K: 0 cos, 1 exp, 2 sin)
+template <typename T, int GC, int K, int SRC, bool CHK> __device__ __noinline__ GState<T, GC> g_un(GHARGS) {
+    const GDual<T, GC> b = goperand<T, GC, SRC>(st, la, imm);
+    UG<T> r;
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (K == 1) { r.y = (T)fast_exp_f32((float)b.x); r.g = r.y; }
+        else if (__ballot(M<T>::abs(b.x) > T(DE_TRIG_FAST_BOUND)) != 0ull) {
+            // inline OCML (a call would make this handler a non-leaf function)
+            const float sn = sinf((float)b.x), cs = cosf((float)b.x);
+            if constexpr (K == 0) { r.y = (T)cs; r.g = (T)-sn; } else { r.y = (T)sn; r.g = (T)cs; }
+        } else {
+            float sn, cs;
+            fast_sincos_f32((float)b.x, &sn, &cs);
+            if constexpr (K == 0) { r.y = (T)cs; r.g = (T)-sn; } else { r.y = (T)sn; r.g = (T)cs; }
+        }
+    } else {
+        if constexpr (K == 0) { r.y = M<T>::cos(b.x); r.g = -M<T>::sin(b.x); }
+        else if constexpr (K == 1) { r.y = M<T>::exp(b.x); r.g = r.y; }
+        else { r.y = M<T>::sin(b.x); r.g = M<T>::cos(b.x); }
+    }
+    st.x = r.y;
+    DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = r.g * b.d[k];
+    if constexpr (CHK) st.poison = M<T>::fma(st.x, T(0), st.poison);
+    return st;
+}
+// generic (cold) operators through the noinline value+partials functions of de_grad_common.h
+template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_gen_apply(GState<T, GC> st, uint32_t gop, GDual<T, GC> b) {
+    if (gop < DE_B_ADD) {
+        const UG<T> r = unary_vg<T>(gop, b.x);
+        st.x = r.y;
+        DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = r.g * b.d[k];
+    } else {
+        uint32_t fop = gop;
+        bool rev = false;
+        switch (gop) {
+        case DOP_RSUB: fop = DE_B_SUB; rev = true; break;
+        case DOP_RDIV: fop = DE_B_DIV; rev = true; break;
+        case DOP_RPOW: fop = DE_B_POW; rev = true; break;
+        case DOP_RMOD: fop = DE_B_MOD; rev = true; break;
+        case DOP_RREM: fop = DE_B_REM; rev = true; break;
+        case DOP_RGREATER: fop = DE_B_GREATER; rev = true; break;
+        case DOP_RPOW_ABS2: fop = DE_B_POW_ABS2; rev = true; break;
+        default: break;
+        }
+        const BG<T> r = rev ? binary_vg<T>(fop, b.x, st.x) : binary_vg<T>(fop, st.x, b.x);
+        st.x = r.v;
+        if (rev) { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = r.gx * b.d[k] + r.gy * st.d[k]; }
+        else { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = r.gx * st.d[k] + r.gy * b.d[k]; }
+    }
+    return st;
+}
+template <typename T, int GC, int SRC> __device__ __noinline__ GState<T, GC> g_gen(GHARGS) {
+    uint32_t gop;
+    if constexpr (SRC == GS_CONST) gop = (la >> 16) & 0xFFu; // no LDS operand: the opcode rides in la[23:16] (lds0 < 2^16)
+    else gop = (uint32_t)imm;
+    const GDual<T, GC> b = goperand<T, GC, SRC>(st, la, imm);
+    return g_gen_apply<T, GC>(st, gop, b);
+}
+template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_tern(GHARGS) { // acc = op3(slot B, slot C, acc)
+    const uint32_t lb = la & 0xFFFFFFu, lc = lb + (uint32_t)imm;
+    const TG<T> r = ternary_vg<T>(la >> 24, *GLDS(T, lb), *GLDS(T, lc), st.x);
+    st.x = r.v;
+    DE_UNROLL for (int k = 0; k < GC; k++)
+        st.d[k] = (r.g0 * *GLDS(T, lb + (1 + k) * grow_bytes<T>()) + r.g1 * *GLDS(T, lc + (1 + k) * grow_bytes<T>())) + r.g2 * st.d[k];
+    return st;
+}
+
+template <typename T, int GC> __global__ void de_grad_fill_handlers(uint64_t *t) {
+    t[GOP_LOAD_LEAF] = (uint64_t)&g_load<T, GC, GS_LEAF>;
+    t[GOP_LOAD_SLOT] = (uint64_t)&g_load<T, GC, GS_SLOT>;
+    t[GOP_LOAD_CONST] = (uint64_t)&g_load<T, GC, GS_CONST>;
+    t[GOP_PUSH] = (uint64_t)&g_push<T, GC>;
+    t[GOP_CHECK_ACC] = (uint64_t)&g_check_acc<T, GC>;
+#define GB1(K, S) t[gop_bin(K, S, false)] = (uint64_t)&g_bin<T, GC, K, S, false>; t[gop_bin(K, S, true)] = (uint64_t)&g_bin<T, GC, K, S, true>;
+#define GB(K) GB1(K, GS_LEAF) GB1(K, GS_SLOT) GB1(K, GS_CONST)
+    GB(0) GB(1) GB(2) GB(3) GB(4) GB(5)
+#define GU1(K, S) t[gop_un(K, S, false)] = (uint64_t)&g_un<T, GC, K, S, false>; t[gop_un(K, S, true)] = (uint64_t)&g_un<T, GC, K, S, true>;
+#define GU(K) GU1(K, GS_LEAF) GU1(K, GS_SLOT) GU1(K, GS_ACC)
+    GU(0) GU(1) GU(2)
+#undef GB1
+#undef GB
+#undef GU1
+#undef GU
+    t[GOP_GEN_LEAF] = (uint64_t)&g_gen<T, GC, GS_LEAF>;
+    t[GOP_GEN_SLOT] = (uint64_t)&g_gen<T, GC, GS_SLOT>;
+    t[GOP_GEN_CONST] = (uint64_t)&g_gen<T, GC, GS_CONST>;
+    t[GOP_GEN_ACC] = (uint64_t)&g_gen<T, GC, GS_ACC>;
+    t[GOP_PARAM] = (uint64_t)&g_nop<T, GC>; // parameter operands are resolved in the interpreter loop
+    t[GOP_TERN] = (uint64_t)&g_tern<T, GC>;
+}
+
+// One sample per thread; LDS rows of GBLK(+4) elements: rows [0,F) = X tile, then each spill
+// slot s owns 1+GC rows (x, d[0..GC)) — the layout of de_grad_tape_kernel.
+template <typename T, int GC, bool PARAMS>
+__global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a, const uint64_t hbase, const uint32_t param_off) {
+    constexpr int RS = GBLK + 4;
+    extern __shared__ __align__(16) unsigned char gtsmem[];
+    T *__restrict__ rows = reinterpret_cast<T *>(gtsmem);
+
+    const GTileMap tm = gmap_block(blockIdx.x, a.n_chunks, a.n_tiles);
+    if (!tm.valid) return;
+    const int tid = threadIdx.x;
+    const int64_t base = tm.tile * GBLK;
+    const int64_t last = a.N - 1;
+    const int g0 = (int)blockIdx.y * GC; // first gradient component of this window
+    const int F = a.F;
+    {
+        const uint32_t Fu = (uint32_t)F;
+        const uint32_t total = (uint32_t)GBLK * Fu;
+        for (uint32_t e = tid; e < total; e += GBLK) {
+            const uint32_t j = e / Fu, f = e - j * Fu;
+            int64_t jj = base + j;
+            jj = jj < last ? jj : last;
+            rows[f * RS + j] = a.X[f + a.ldX * jj];
+        }
+    }
+    int64_t jj0 = base + tid;
+    const bool live = jj0 < a.N;
+    jj0 = jj0 < last ? jj0 : last;
+    int64_t cls = 0;
+    if (PARAMS)
+        cls = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj0]
+                                : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj0]) - a.class_base;
+    T yv = T(0), wv = T(0);
+    if (a.loss_mode) {
+        yv = a.y[jj0];
+        wv = live ? (a.w ? a.w[jj0] : T(1)) : T(0);
+    }
+    __syncthreads();
+
+    const ConstU4Ptr code = (ConstU4Ptr)(uintptr_t)a.code;
+    const ConstI32Ptr code_off = (ConstI32Ptr)(uintptr_t)a.code_off;
+    const ConstI64Ptr col_off = (ConstI64Ptr)(uintptr_t)a.col_off;
+    const ConstI32Ptr n_grad = (ConstI32Ptr)(uintptr_t)a.n_grad;
+    const ConstI64Ptr grad_off = (ConstI64Ptr)(uintptr_t)a.grad_off;
+    const int t0 = tm.chunk * a.trees_per_chunk;
+    const int t1 = (t0 + a.trees_per_chunk < a.n_trees) ? t0 + a.trees_per_chunk : a.n_trees;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)gtsmem + tid * (uint32_t)sizeof(T);
+    const int param_seed0 = a.mode != DE_GRAD_CONSTANT ? -g0 : -0x40000000;
+
+    for (int tree = t0; tree < t1; ++tree) {
+        const int G = n_grad[tree];
+        if (g0 >= G && g0 > 0) continue; // window without a component of this tree (window 0 always runs: x, flag)
+        int pc = code_off[tree];
+        const int pe = code_off[tree + 1];
+        GState<T, GC> st;
+        st.x = T(0);
+        DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = T(0);
+        st.poison = T(0);
+        st.g0 = (uint32_t)g0;
+        U32x4 nxt = code[pc];
+        for (; pc < pe; ++pc) {
+            const U32x4 w = nxt;
+            nxt = code[pc + 1];
+            if (PARAMS && w.x == param_off) { // operand = params[row, class]: needs kernel arguments
+                const uint32_t prow = w.y & 0xFFFFu, op = w.y >> 24;
+                GDual<T, GC> b;
+                b.x = a.params[prow + a.ld_params * cls];
+                st.poison = M<T>::fma(b.x, T(0), st.poison);
+                const int seed = (int)prow + param_seed0;
+                DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = (k == seed) ? T(1) : T(0);
+                if (op == DOP_LOAD) { st.x = b.x; DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = b.d[k]; }
+                else st = g_gen_apply<T, GC>(st, op, b);
+                continue;
+            }
+            const GHandlerFn<T, GC> fn = reinterpret_cast<GHandlerFn<T, GC>>(hbase + w.x);
+            typename GImm<T>::type imm;
+            if constexpr (sizeof(T) == 4) imm = w.z;
+            else imm = ((uint64_t)w.w << 32) | w.z;
+            st = fn(st, lds0 + w.y, imm);
+        }
+        // a non-finite d[k] always survives to the root (every update is linear in it), so the gradient
+        // is validity-tested once, here; x was tested where the lowering kept a test (H_CHECK_OUT)
+        T poison = M<T>::fma(st.x, T(0), st.poison);
+        DE_UNROLL for (int k = 0; k < GC; k++) poison = M<T>::fma(st.d[k], T(0), poison);
+        if (a.loss_mode) {
+            const T e = st.x - yv;
+            T lp, l;
+            if (a.loss_mode == 1 + DE_LOSS_L2) { l = wv * (e * e); lp = wv * (T(2) * e); }
+            else if (a.loss_mode == 1 + DE_LOSS_L1) { l = wv * M<T>::abs(e); lp = wv * jl_sign(e); }
+            else { l = wv * (st.x * yv); lp = wv * yv; } // DE_LOSS_PULLBACK: y holds the cotangent dY
+            if (wv == T(0)) { l = T(0); lp = T(0); }
+            const int64_t n_cols = col_off[a.n_trees];
+            T *__restrict__ pp = a.partial + ((int64_t)tm.tile * n_cols + col_off[tree]) * 4 + (tid >> 6);
+            if (g0 == 0) {
+                const T s = wave_sum_to_lane63(l);
+                if ((tid & 63) == 63) pp[0] = s;
+            }
+            DE_UNROLL for (int k = 0; k < GC; k++) {
+                if (g0 + k < G) { // wave-uniform
+                    const T s = wave_sum_to_lane63(wv == T(0) ? T(0) : lp * st.d[k]);
+                    if ((tid & 63) == 63) pp[(int64_t)(1 + g0 + k) * 4] = s;
+                }
+            }
+        } else if (live) {
+            if (a.out && g0 == 0) a.out[(int64_t)tree * a.ld_out + base + tid] = st.x;
+            T *__restrict__ gp = a.grad + grad_off[tree] + (int64_t)G * (base + tid) + g0;
+            DE_UNROLL for (int k = 0; k < GC; k++)
+                if (g0 + k < G) gp[k] = st.d[k];
+        }
+        if (__ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree);
+    }
+}
+
+// ---- host side: entry points of this (type, window) module -----------------------------------------
+#define DE_GT_CAT2(a, b, c) a##b##c
+#define DE_GT_CAT(a, b, c) DE_GT_CAT2(a, b, c)
+#define DE_GT_NAME(prefix) DE_GT_CAT(prefix, DE_GT_TAG, DE_GT_GC)
+
+hipError_t DE_GT_NAME(grad_thr_fetch_)(uint64_t *host_table) {
+    uint64_t *d = nullptr;
+    hipError_t st = hipMalloc(reinterpret_cast<void **>(&d), GOP_COUNT * sizeof(uint64_t));
+    if (st != hipSuccess) return st;
+    hipLaunchKernelGGL((de_grad_fill_handlers<DE_GT_T, DE_GT_GC>), dim3(1), dim3(1), 0, 0, d);
+    st = hipMemcpy(host_table, d, GOP_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    return st;
+}
+
+hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int windows, hipStream_t stream) {
+    typedef DE_GT_T T;
+    constexpr int GC = DE_GT_GC;
+    static int gt_gcu = 0;
+    const EvalArgs &e = ga.e;
+    GArgs<T> a;
+    a.code = ga.threaded_code;
+    a.code_off = e.code_off;
+    a.X = static_cast<const T *>(e.X);
+    a.out = static_cast<T *>(e.out);
+    a.grad = static_cast<T *>(ga.grad);
+    a.grad_off = ga.grad_off;
+    a.n_grad = ga.n_grad;
+    a.ok = e.ok;
+    a.params = static_cast<const T *>(e.params);
+    a.classes = e.classes;
+    a.N = e.N;
+    a.ldX = e.ldX;
+    a.ld_out = e.ld_out;
+    a.ld_params = e.ld_params;
+    a.n_tiles = (e.N + GBLK - 1) / GBLK;
+    a.F = e.F;
+    a.P = ga.P;
+    a.n_trees = e.n_trees;
+    a.n_slots = e.n_slots;
+    a.mode = ga.mode;
+    a.classes_is_i64 = e.classes_is_i64;
+    a.class_base = e.class_base;
+    a.uses_params = e.uses_params ? 1 : 0;
+    a.check = 1;
+    a.diff_g0 = -1;
+    a.loss_mode = 0;
+    a.y = a.w = nullptr;
+    a.partial = nullptr;
+    a.col_off = nullptr;
+    if (ga.loss) {
+        a.loss_mode = 1 + ga.loss->kind;
+        a.y = static_cast<const T *>(ga.loss->y);
+        a.w = static_cast<const T *>(ga.loss->w);
+        a.partial = static_cast<T *>(ga.loss->partial);
+        a.col_off = ga.col_off;
+    }
+    if (gt_gcu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) gt_gcu = prop.multiProcessorCount;
+        if (gt_gcu <= 0) gt_gcu = 256;
+    }
+    int64_t n_chunks = (e.n_trees + 31) / 32;
+    const int64_t want_blocks = (int64_t)gt_gcu * 4 * 8;
+    if (a.n_tiles * n_chunks * windows < want_blocks) n_chunks = (want_blocks + a.n_tiles * windows - 1) / (a.n_tiles * windows);
+    const int64_t max_chunks = (e.n_trees + 3) / 4;
+    if (n_chunks > max_chunks) n_chunks = max_chunks;
+    if (n_chunks < 1) n_chunks = 1;
+    a.trees_per_chunk = (int32_t)((e.n_trees + n_chunks - 1) / n_chunks);
+    a.n_chunks = (int32_t)((e.n_trees + a.trees_per_chunk - 1) / a.trees_per_chunk);
+    const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
+    if (blocks <= 0 || blocks > 0x7fffffffLL || windows > 65535) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(a.F + (size_t)a.n_slots * (1 + GC)) * (GBLK + 4) * sizeof(T);
+    void (*kern)(const GArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_grad_threaded_kernel<T, GC, true> : de_grad_threaded_kernel<T, GC, false>;
+    if (lds > 64 * 1024) {
+        if (lds > 160 * 1024) return hipErrorInvalidValue;
+        hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (st != hipSuccess) return st;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)windows), dim3(GBLK), lds, stream, a, ga.handler_base, ga.param_handler_off);
+    hipError_t st = hipGetLastError();
+    if (st != hipSuccess || !ga.loss) return st;
+    return launch_loss_grad_finish(sizeof(T) == 4 ? DE_F32 : DE_F64, ga, a.n_tiles, stream);
+}
+
+
+} // namespace de

@@ -69,12 +69,23 @@ struct GradArgs {
     int64_t n_cols;           // = col_off[n_trees]
     void *dloss;              // device: tree t's n_grad[t] reduced gradient entries at dloss_off[t]
     const int64_t *dloss_off; // device, n_trees
+    // threaded-code variant (de_grad_threaded.hip): non-null = use it; code built for grad_window(max_grad)
+    const BoundInstr *threaded_code;
+    uint64_t handler_base;
+    uint32_t param_handler_off;
 };
 
 // Returns hipSuccess or the failing HIP error.  `kernel_name` receives the symbol
 // name of the launched kernel (for matching rocprofv3 kernel-trace rows).
 hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const char **kernel_name);
 hipError_t launch_grad(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name);
+
+// Threaded gradient kernel: window width used for a population whose widest gradient has max_grad rows,
+// handler addresses for (dtype, window), launch; pass 2+3 of the fused loss-gradient reduction.
+int grad_window(int max_grad);
+hipError_t grad_handler_table(int dtype, int GC, uint64_t *table); // GOP_COUNT entries
+hipError_t launch_grad_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name);
+hipError_t launch_loss_grad_finish(int dtype, const GradArgs &ga, int64_t n_tiles, hipStream_t stream);
 
 // Threaded-code eval kernel: addresses of the TOP_COUNT device handlers (cached per process).
 hipError_t eval_handler_table(int dtype, uint64_t *table);
