@@ -98,10 +98,11 @@ struct de_program {
     std::vector<int32_t> gtcode_off;
     BoundInstr *d_gtcode = nullptr;
     int32_t *d_gtcode_off = nullptr;
-    int gt_mode = -1, gt_gc = -1;
+    int32_t *d_gt_ids = nullptr;        // tree indices grouped by bucket
+    int gt_mode = -1;
     bool gt_valid = false;
-    uint64_t gt_handler_base = 0;
-    uint32_t gt_param_off = 0;
+    int gt_n_buckets = 0;
+    GradArgs::Bucket gt_buckets[8];
 };
 
 static int fail(de_ctx *c, int code, const char *fmt, ...) {
@@ -597,6 +598,7 @@ int de_program_destroy(de_program_t *p) {
     if (p->d_gcode_off) (void)hipFree(p->d_gcode_off);
     if (p->d_gtcode) (void)hipFree(p->d_gtcode);
     if (p->d_gtcode_off) (void)hipFree(p->d_gtcode_off);
+    if (p->d_gt_ids) (void)hipFree(p->d_gt_ids);
     delete p;
     return DE_OK;
 }
@@ -942,29 +944,45 @@ static int ensure_generic_code(de_ctx *c, de_program *p) {
     return DE_OK;
 }
 
-// Threaded form of the gradient program (de_grad_threaded.hip) for (mode, window width of max_grad).
-// Fills g->threaded_code & co. when the program can be expressed in it; otherwise leaves them null and
-// the flat-switch kernel runs.  Call after ensure_generic_code().
-static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, int max_grad, GradArgs *g) {
+// Threaded form of the gradient program (de_grad_threaded.hip) for `mode`.  Trees are grouped into
+// buckets by gradient width n_grad(t, mode): widths 1..6 and 7-8 each run in the module built for that
+// window (every seed is known here and compiled into the handler choice), wider trees in windows of 8
+// with run-time seeds.  Fills g->threaded_code & co. when the program can be expressed this way; otherwise
+// leaves them null and the flat-switch kernel runs.  Call after ensure_generic_code().
+static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::vector<int32_t> &ng, GradArgs *g) {
     g->threaded_code = nullptr;
+    g->n_buckets = 0;
     const char *env = getenv("DE_GRAD_THREADED");
     if (env && *env == '0') return DE_OK;
-    if (max_grad > 240) return DE_OK; // gradient rows travel in 8 bits
-    const int GC = grad_window(max_grad);
-    // Float64 states wider than 16 dwords are passed through scratch memory by the calling convention
-    if (p->dtype == DE_F64 && GC > 5) return DE_OK;
     const int F = p->n_features, P = p->n_params;
-    if (!(p->gt_valid && p->gt_mode == mode && p->gt_gc == GC)) {
-        uint64_t table[GOP_COUNT];
-        hipError_t st = grad_handler_table(p->dtype, GC, table);
-        if (st != hipSuccess) return fail(c, DE_ERR_HIP, "gradient handler table: %s", hipGetErrorString(st));
-        uint64_t base = table[0];
-        for (int i = 0; i < (int)GOP_COUNT; i++) base = std::min<uint64_t>(base, table[i]);
-        for (int i = 0; i < (int)GOP_COUNT; i++)
-            if (table[i] - base > 0xFFFFFFFFull) return DE_OK;
+    if (!(p->gt_valid && p->gt_mode == mode)) {
+        // bucket of a tree: index 0..6 = single window of width 1,2,3,4,5,6,8; 7 = several windows of 8
+        static const int WIDTH[8] = {1, 2, 3, 4, 5, 6, 8, 8};
+        auto bucket_of = [](int32_t G) { return G <= 6 ? (G < 1 ? 0 : G - 1) : (G <= 8 ? 6 : 7); };
+        int32_t count[8] = {0}, maxg[8] = {0};
+        for (int64_t t = 0; t < p->n_trees; t++) {
+            const int32_t G = ng[(size_t)t];
+            if (G > 240) return DE_OK; // gradient rows travel in 8 bits
+            const int b = bucket_of(G);
+            // Float64 states wider than 16 dwords are passed through scratch memory by the calling convention
+            if (p->dtype == DE_F64 && WIDTH[b] > 5) return DE_OK;
+            count[b]++;
+            maxg[b] = std::max(maxg[b], G);
+        }
         const uint32_t RB = (uint32_t)(260 * (p->dtype == DE_F32 ? 4 : 8)); // row bytes: (GBLK + 4) elements
-        if (((uint64_t)F + (uint64_t)p->n_slots * (1 + GC)) * RB >= (1u << 24)) return DE_OK;
-        auto slot_off = [&](uint32_t row) { return (uint32_t)((F + (row - (uint32_t)F) * (1 + GC)) * RB); };
+        uint64_t tables[8][GOP_MAX], bases[8] = {0};
+        for (int b = 0; b < 8; b++) {
+            if (!count[b]) continue;
+            const int GC = WIDTH[b];
+            if (((uint64_t)F + (uint64_t)p->n_slots * (1 + GC)) * RB >= (1u << 24)) return DE_OK;
+            hipError_t st = grad_handler_table(p->dtype, GC, tables[b]);
+            if (st != hipSuccess) return fail(c, DE_ERR_HIP, "gradient handler table: %s", hipGetErrorString(st));
+            uint64_t base = tables[b][0];
+            for (int i = 0; i < (int)gop_count(GC); i++) base = std::min<uint64_t>(base, tables[b][i]);
+            for (int i = 0; i < (int)gop_count(GC); i++)
+                if (tables[b][i] - base > 0xFFFFFFFFull) return DE_OK;
+            bases[b] = base;
+        }
         auto leaf_seed = [&](uint32_t f) -> uint32_t { return mode != DE_GRAD_CONSTANT ? (uint32_t)P + f : 0xFFu; };
         auto const_seed = [&](uint32_t ord) -> uint32_t {
             return mode == DE_GRAD_CONSTANT ? ord : (mode == DE_GRAD_BOTH ? (uint32_t)(P + F) + ord : 0xFFu);
@@ -973,51 +991,61 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, int max_grad
         p->gtcode_off.assign((size_t)p->n_trees + 1, 0);
         bool ok = true;
         for (int64_t t = 0; t < p->n_trees && ok; t++) {
+            const int bkt = bucket_of(ng[(size_t)t]);
+            const int GC = WIDTH[bkt];
+            const bool one_window = bkt != 7; // then g0 = 0 and every seed is known here
+            const uint64_t *table = tables[bkt];
+            const uint64_t base = bases[bkt];
+            auto slot_off = [&](uint32_t row) { return (uint32_t)((F + (row - (uint32_t)F) * (1 + GC)) * RB); };
+            // seed variant of a handler (de_bind.h): 0 run-time, 1 none, 2 + k
+            auto seed_variant = [&](uint32_t sd) -> int { return !one_window ? 0 : (sd == 0xFFu ? 1 : (sd < (uint32_t)GC ? 2 + (int)sd : 0)); };
             for (int32_t i = p->gbcode_off[(size_t)t]; i < p->gbcode_off[(size_t)t + 1] && ok; i++) {
                 const BoundInstr &b = p->gbcode[(size_t)i];
                 const uint32_t row = b.arg & 0xFFFFFFu, aux = b.arg >> 24;
                 BoundInstr o = b;
-                uint32_t gop = GOP_COUNT;
-                auto row_operand = [&](uint32_t leaf_op, uint32_t slot_op) { // sets gop and o.arg for a row operand
+                int src = GSRC_ACC, sv = 0;
+                auto row_operand = [&](bool rt = false) { // sets src, sv and o.arg for a row operand (rt: handler reads the seed at run time)
                     if (row < (uint32_t)F) {
                         const uint32_t sd = leaf_seed(row);
                         if (sd != 0xFFu && sd >= 0xF0u) ok = false;
-                        gop = leaf_op;
-                        o.arg = (row * RB) | (sd << 24);
+                        src = GSRC_LEAF;
+                        sv = rt ? 0 : seed_variant(sd);
+                        o.arg = (row * RB) | (sv == 0 ? sd << 24 : 0u); // known seeds are compiled into the handler
                     } else {
-                        gop = slot_op;
+                        src = GSRC_SLOT;
                         o.arg = slot_off(row);
                     }
                 };
-                auto const_operand = [&](uint32_t ord, uint32_t low) {
+                auto const_operand = [&](uint32_t ord, uint32_t low, bool rt = false) {
                     const uint32_t sd = const_seed(ord);
                     if (sd != 0xFFu && sd >= 0xF0u) ok = false;
-                    o.arg = low | (sd << 24);
+                    src = GSRC_CONST;
+                    sv = rt ? 0 : seed_variant(sd);
+                    o.arg = low | (sv == 0 ? sd << 24 : 0u);
                 };
+                uint32_t gop = 0;
                 if (b.bop == BOP_CHECK_ROW) continue; // leaf operands are tested where they are read
-                if (b.bop == BOP_LOAD_ROW) row_operand(GOP_LOAD_LEAF, GOP_LOAD_SLOT);
-                else if (b.bop == BOP_LOAD_CONST) { gop = GOP_LOAD_CONST; const_operand(b.arg & 0xFFFFu, 0); }
-                else if (b.bop == BOP_PUSH) { gop = GOP_PUSH; o.arg = slot_off(row); }
-                else if (b.bop == BOP_CHECK_ACC) { gop = GOP_CHECK_ACC; o.arg = 0; }
+                if (b.bop == BOP_LOAD_ROW) { row_operand(); gop = gop_load(GC, src, sv); }
+                else if (b.bop == BOP_LOAD_CONST) { const_operand(b.arg & 0xFFFFu, 0); gop = gop_load(GC, src, sv); }
+                else if (b.bop == BOP_PUSH) { gop = gop_push(GC); o.arg = slot_off(row); }
+                else if (b.bop == BOP_CHECK_ACC) { gop = gop_check_acc(GC); o.arg = 0; }
                 else if (b.bop >= BOP_BIN_BASE && b.bop < BOP_BIN_END) {
                     const uint32_t v = b.bop - BOP_BIN_BASE;
-                    const int k = (int)(v >> 2);
-                    const bool chk = v & 1;
-                    if (v & 2) { gop = gop_bin(k, 2, chk); const_operand(b.arg & 0xFFFFu, 0); }
-                    else row_operand(gop_bin(k, 0, chk), gop_bin(k, 1, chk));
+                    if (v & 2) const_operand(b.arg & 0xFFFFu, 0);
+                    else row_operand();
+                    gop = gop_bin(GC, (int)(v >> 2), src, sv, (v & 1) != 0);
                 } else if (b.bop >= BOP_UN_BASE && b.bop < BOP_UN_END) {
                     const uint32_t v = b.bop - BOP_UN_BASE;
-                    const int k = (int)(v >> 2);
-                    const bool chk = v & 1;
-                    if (v & 2) row_operand(gop_un(k, 0, chk), gop_un(k, 1, chk));
-                    else { gop = gop_un(k, 3, chk); o.arg = 0; }
-                } else if (b.bop == BOP_GEN_ROW) { row_operand(GOP_GEN_LEAF, GOP_GEN_SLOT); o.lo = aux; o.hi = 0; }
-                else if (b.bop == BOP_GEN_CONST) { gop = GOP_GEN_CONST; const_operand(b.arg & 0xFFFFu, aux << 16); }
-                else if (b.bop == BOP_GEN_ACC) { gop = GOP_GEN_ACC; o.arg = 0; o.lo = aux; o.hi = 0; }
-                else if (b.bop == BOP_GEN_PARAM) { gop = GOP_PARAM; o.arg = b.arg; }
+                    if (v & 2) row_operand();
+                    else o.arg = 0;
+                    gop = gop_un(GC, (int)(v >> 2), src, sv, (v & 1) != 0);
+                } else if (b.bop == BOP_GEN_ROW) { row_operand(true); gop = gop_gen(GC, src); o.lo = aux; o.hi = 0; }
+                else if (b.bop == BOP_GEN_CONST) { const_operand(b.arg & 0xFFFFu, aux << 16, true); gop = gop_gen(GC, GSRC_CONST); }
+                else if (b.bop == BOP_GEN_ACC) { gop = gop_gen(GC, GSRC_ACC); o.arg = 0; o.lo = aux; o.hi = 0; }
+                else if (b.bop == BOP_GEN_PARAM) { gop = gop_param(GC); o.arg = b.arg; }
                 else if (b.bop == BOP_TERN) {
                     if (row < (uint32_t)F || b.lo < (uint32_t)F) ok = false; // both operands are spilled duals
-                    else { gop = GOP_TERN; o.arg = slot_off(row) | (aux << 24); o.lo = slot_off(b.lo) - slot_off(row); o.hi = 0; }
+                    else { gop = gop_tern(GC); o.arg = slot_off(row) | (aux << 24); o.lo = slot_off(b.lo) - slot_off(row); o.hi = 0; }
                 } else ok = false; // INJ_*: only bound with early_exit=false, never for gradients
                 if (!ok) break;
                 o.bop = (uint32_t)(table[gop] - base);
@@ -1026,25 +1054,44 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, int max_grad
             p->gtcode_off[(size_t)t + 1] = (int32_t)p->gtcode.size();
         }
         if (!ok) return DE_OK;
+        std::vector<int32_t> ids((size_t)p->n_trees);
+        int32_t start[8], run = 0;
+        for (int b = 0; b < 8; b++) { start[b] = run; run += count[b]; }
+        {
+            int32_t fill[8];
+            for (int b = 0; b < 8; b++) fill[b] = start[b];
+            for (int64_t t = 0; t < p->n_trees; t++) ids[(size_t)fill[bucket_of(ng[(size_t)t])]++] = (int32_t)t;
+        }
         if (!p->d_gtcode) {
             HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode), (p->gbcode.size() + 1) * sizeof(BoundInstr)));
             HIP_TRY(c, hipMemset(p->d_gtcode, 0, (p->gbcode.size() + 1) * sizeof(BoundInstr)));
             HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode_off), p->gtcode_off.size() * sizeof(int32_t)));
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gt_ids), std::max<size_t>(ids.size(), 1) * sizeof(int32_t)));
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream)); // the previous form may be in use by queued work
         if (!p->gtcode.empty())
             HIP_TRY(c, hipMemcpy(p->d_gtcode, p->gtcode.data(), p->gtcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(p->d_gtcode_off, p->gtcode_off.data(), p->gtcode_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        p->gt_handler_base = base;
-        p->gt_param_off = (uint32_t)(table[GOP_PARAM] - base);
+        if (!ids.empty()) HIP_TRY(c, hipMemcpy(p->d_gt_ids, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        p->gt_n_buckets = 0;
+        for (int b = 0; b < 8; b++) {
+            if (!count[b]) continue;
+            GradArgs::Bucket &bk = p->gt_buckets[p->gt_n_buckets++];
+            bk.GC = WIDTH[b];
+            bk.windows = b == 7 ? (maxg[b] + 7) / 8 : 1;
+            bk.max_grad = maxg[b];
+            bk.ids = p->d_gt_ids + start[b];
+            bk.n = count[b];
+            bk.handler_base = bases[b];
+            bk.param_handler_off = (uint32_t)(tables[b][gop_param(WIDTH[b])] - bases[b]);
+        }
         p->gt_mode = mode;
-        p->gt_gc = GC;
         p->gt_valid = true;
     }
     g->threaded_code = p->d_gtcode;
     g->e.code_off = p->d_gtcode_off;
-    g->handler_base = p->gt_handler_base;
-    g->param_handler_off = p->gt_param_off;
+    g->n_buckets = p->gt_n_buckets;
+    for (int b = 0; b < p->gt_n_buckets; b++) g->buckets[b] = p->gt_buckets[b];
     return DE_OK;
 }
 
@@ -1158,7 +1205,7 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
     g.diff_direction = diff ? diff_direction : -1;
     g.e.code_off = p->d_gcode_off;
     if (!diff) {
-        rc = ensure_grad_threaded(c, p, mode, maxg, &g);
+        rc = ensure_grad_threaded(c, p, mode, ng, &g);
         if (rc) return rc;
     }
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -1326,7 +1373,7 @@ int de_eval_loss_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, in
     g.n_cols = n_cols;
     g.dloss = sDl.dev;
     g.dloss_off = static_cast<const int64_t *>(c->sDoff.p);
-    rc = ensure_grad_threaded(c, p, mode, maxg, &g);
+    rc = ensure_grad_threaded(c, p, mode, ng, &g);
     if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, launch_grad(p->dtype, g, c->stream, &c->last_kernel));

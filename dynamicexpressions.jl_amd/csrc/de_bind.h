@@ -83,26 +83,35 @@ constexpr uint32_t top_binrowc(int k, bool out) { return TOP_BINROWC_BASE + k * 
 constexpr uint32_t top_bin2(int k, bool cst, bool out, bool push) { return TOP_BIN2_BASE + ((k * 2 + cst) * 2 + out) * 2 + push; }
 
 // ---- handler ids of the threaded GRADIENT kernel (de_grad_threaded.hip) ----------------------------
-// Operand kinds are resolved on the host: LEAF = feature row (one-hot seed), SLOT = spilled dual
-// number, CONST = inline constant (seed by ordinal), ACC.
-enum GradOp : uint32_t {
-    GOP_LOAD_LEAF = 0,
-    GOP_LOAD_SLOT,
-    GOP_LOAD_CONST,
-    GOP_PUSH,
-    GOP_CHECK_ACC,
-    GOP_BIN_BASE,                     // + (k*3 + src)*2 + chk,  src: 0 LEAF 1 SLOT 2 CONST   (36)
-    GOP_UN_BASE = GOP_BIN_BASE + 36,  // + (k*3 + src)*2 + chk,  src: 0 LEAF 1 SLOT 2 ACC     (18)
-    GOP_GEN_LEAF = GOP_UN_BASE + 18,
-    GOP_GEN_SLOT,
-    GOP_GEN_CONST,
-    GOP_GEN_ACC,
-    GOP_PARAM,
-    GOP_TERN,
-    GOP_COUNT
-};
-constexpr uint32_t gop_bin(int k, int src, bool chk) { return GOP_BIN_BASE + (k * 3 + src) * 2 + chk; }
-constexpr uint32_t gop_un(int k, int src, bool chk) { return GOP_UN_BASE + (k * 3 + (src == 3 ? 2 : src)) * 2 + chk; } // src 3 = ACC
+// Operand kinds are resolved on the host: LEAF = feature row, SLOT = spilled dual number, CONST = inline
+// constant, ACC.  LEAF and CONST operands seed ONE gradient component (or none in this mode); with a
+// single window that component is known on the host, so those handlers exist once per seed
+// ("seed variant" sv = 0: read the row at run time (several windows), 1: no gradient, 2 + k: row k):
+// the dense  g1*d1[k] + g2*d2[k]  then needs no one-hot materialisation.  Window width GC gives
+// NS = GC + 2 seed variants; ids depend on GC (one module per GC anyway).
+constexpr int GOP_MAX = 400; // >= gop_count(8)
+enum { GSRC_LEAF = 0, GSRC_SLOT = 1, GSRC_CONST = 2, GSRC_ACC = 3 };
+constexpr uint32_t gop_ns(int GC) { return (uint32_t)GC + 2; }
+constexpr uint32_t gop_load(int GC, int src, int sv) { // LEAF: [0,NS)  SLOT: NS  CONST: NS+1+sv
+    return src == GSRC_LEAF ? (uint32_t)sv : (src == GSRC_SLOT ? gop_ns(GC) : gop_ns(GC) + 1 + (uint32_t)sv);
+}
+constexpr uint32_t gop_push(int GC) { return 2 * gop_ns(GC) + 1; }
+constexpr uint32_t gop_check_acc(int GC) { return gop_push(GC) + 1; }
+constexpr uint32_t gop_bin_base(int GC) { return gop_check_acc(GC) + 1; }
+constexpr uint32_t gop_bin(int GC, int k, int src, int sv, bool chk) { // 6 K x 2 chk x (LEAF NS + SLOT + CONST NS)
+    return gop_bin_base(GC) + (uint32_t)(k * 2 + chk) * (2 * gop_ns(GC) + 1) + gop_load(GC, src, sv);
+}
+constexpr uint32_t gop_un_base(int GC) { return gop_bin_base(GC) + 12 * (2 * gop_ns(GC) + 1); }
+constexpr uint32_t gop_un(int GC, int k, int src, int sv, bool chk) { // 3 K x 2 chk x (LEAF NS + SLOT + ACC)
+    return gop_un_base(GC) + (uint32_t)(k * 2 + chk) * (gop_ns(GC) + 2) +
+           (src == GSRC_LEAF ? (uint32_t)sv : (src == GSRC_SLOT ? gop_ns(GC) : gop_ns(GC) + 1));
+}
+constexpr uint32_t gop_gen_base(int GC) { return gop_un_base(GC) + 6 * (gop_ns(GC) + 2); }
+constexpr uint32_t gop_gen(int GC, int src) { return gop_gen_base(GC) + (uint32_t)src; } // LEAF, SLOT, CONST, ACC (run-time seeds)
+constexpr uint32_t gop_param(int GC) { return gop_gen_base(GC) + 4; }
+constexpr uint32_t gop_tern(int GC) { return gop_gen_base(GC) + 5; }
+constexpr uint32_t gop_count(int GC) { return gop_gen_base(GC) + 6; }
+static_assert(gop_count(8) <= GOP_MAX, "GOP_MAX too small");
 
 // Fused form of one tree's bound instructions (appended to `out`).
 void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out);

@@ -40,6 +40,8 @@ template <typename T> struct GArgs {
     const T *w;              // may be null
     T *partial;              // [n_tiles][n_cols][4 waves]; tree t owns columns col_off[t] .. col_off[t] + n_grad[t] (loss first)
     const int64_t *col_off;  // n_trees + 1
+    const int32_t *tree_ids; // threaded kernel: the n_trees trees this launch evaluates (null = 0..n_trees-1)
+    int32_t n_all_trees;     // trees of the program (col_off has n_all_trees + 1 entries)
 };
 
 template <typename T> __device__ __forceinline__ T gimm(uint32_t w2, uint32_t w3);

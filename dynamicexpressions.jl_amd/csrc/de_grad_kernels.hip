@@ -303,6 +303,8 @@ static hipError_t launch_grad_t(const GradArgs &ga, int windows, hipStream_t str
     a.check = ga.diff_direction >= 0 ? 0 : 1;
     a.diff_g0 = ga.diff_direction >= 0 ? ga.P + ga.diff_direction : -1;
     a.code = ga.generic_code;
+    a.tree_ids = nullptr;
+    a.n_all_trees = e.n_trees;
     a.loss_mode = 0;
     a.y = a.w = nullptr;
     a.partial = nullptr;
@@ -378,12 +380,12 @@ template <typename T> static hipError_t launch_grad_dt(const GradArgs &ga, hipSt
 // ---- threaded variant: one module per (type, window) — de_grad_threaded.hip ---------------------------
 #define DE_GT_DECL(TAG, GC)                                                     \
     hipError_t grad_thr_fetch_##TAG##GC(uint64_t *host_table);                  \
-    hipError_t grad_thr_launch_##TAG##GC(const GradArgs &ga, int windows, hipStream_t stream);
+    hipError_t grad_thr_launch_##TAG##GC(const GradArgs &ga, int bucket, hipStream_t stream);
 #define DE_GT_ALL(X) X(f, 1) X(f, 2) X(f, 3) X(f, 4) X(f, 5) X(f, 6) X(f, 8) X(d, 1) X(d, 2) X(d, 3) X(d, 4) X(d, 5)
 DE_GT_ALL(DE_GT_DECL)
 
 hipError_t grad_handler_table(int dtype, int GC, uint64_t *table) {
-    static uint64_t cache[2][9][GOP_COUNT];
+    static uint64_t cache[2][9][GOP_MAX];
     static bool have[2][9] = {};
     const int k = dtype == DE_F32 ? 0 : 1;
     if (GC < 1 || GC > 8 || GC == 7 || (k == 1 && GC > 5)) return hipErrorInvalidValue;
@@ -394,18 +396,23 @@ hipError_t grad_handler_table(int dtype, int GC, uint64_t *table) {
         if (st != hipSuccess) return st;
         have[k][GC] = true;
     }
-    for (int i = 0; i < (int)GOP_COUNT; i++) table[i] = cache[k][GC][i];
+    for (int i = 0; i < (int)gop_count(GC); i++) table[i] = cache[k][GC][i];
     return hipSuccess;
 }
 
 hipError_t launch_grad_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name) {
     if (kernel_name) *kernel_name = "de_grad_threaded_kernel";
-    const int maxg = a.max_grad < 1 ? 1 : a.max_grad;
-    const int GC = grad_window(maxg), windows = GC == 8 ? (maxg + 7) / 8 : 1;
     const int k = dtype == DE_F32 ? 0 : 1;
-#define DE_GT_LAUNCH(TAG, G) if (k == (#TAG[0] == 'f' ? 0 : 1) && GC == G) return grad_thr_launch_##TAG##G(a, windows, stream);
-    DE_GT_ALL(DE_GT_LAUNCH)
-    return hipErrorInvalidValue;
+    for (int b = 0; b < a.n_buckets; b++) {
+        const GradArgs::Bucket &bk = a.buckets[b];
+        if (bk.n <= 0) continue;
+        hipError_t st = hipErrorInvalidValue;
+#define DE_GT_LAUNCH(TAG, G) if (k == (#TAG[0] == 'f' ? 0 : 1) && bk.GC == G) st = grad_thr_launch_##TAG##G(a, b, stream);
+        DE_GT_ALL(DE_GT_LAUNCH)
+        if (st != hipSuccess) return st;
+    }
+    if (!a.loss) return hipSuccess;
+    return launch_loss_grad_finish(dtype, a, (a.e.N + GBLK - 1) / GBLK, stream);
 }
 
 hipError_t launch_grad(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name) {

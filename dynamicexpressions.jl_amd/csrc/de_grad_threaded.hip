@@ -51,11 +51,20 @@ template <typename T, int GC> using GHandlerFn = GState<T, GC> (*)(GState<T, GC>
 #define GLDS(T, addr) (reinterpret_cast<__attribute__((address_space(3))) T *>((uintptr_t)(addr)))
 template <typename T> constexpr uint32_t grow_bytes() { return (uint32_t)((GBLK + 4) * sizeof(T)); }
 
-// operand kinds
-enum { GS_LEAF = 0, GS_SLOT = 1, GS_CONST = 2, GS_ACC = 3 };
+// operand kinds (de_bind.h GSRC_*)
+enum { GS_LEAF = GSRC_LEAF, GS_SLOT = GSRC_SLOT, GS_CONST = GSRC_CONST, GS_ACC = GSRC_ACC };
 
-template <typename T, int GC, int SRC> __device__ __forceinline__ GDual<T, GC> goperand(GState<T, GC> &st, uint32_t la, typename GImm<T>::type imm) {
-    GDual<T, GC> b;
+// An operand: value + how its gradient is represented.  SV (seed variant, de_bind.h): 0 = the one-hot
+// row index is read at run time (aux - g0), 1 = no gradient component in this window, 2 + k = component k.
+// For LEAF/CONST operands with SV >= 1 the one-hot vector is never materialised: the reference's dense
+//   g * db[k]   is   g * 1 = g  for k = seed  and  g * 0  elsewhere  (g * 0 is still computed once: it is NaN
+// for an infinite partial and carries the sign of zero, exactly as in grad_degn_eval :340-365).
+template <typename T, int GC, int SRC, int SV> struct GOperand {
+    T x;
+    T d[GC]; // only meaningful for SLOT/ACC operands and run-time seeds
+};
+template <typename T, int GC, int SRC, int SV> __device__ __forceinline__ GOperand<T, GC, SRC, SV> goperand(GState<T, GC> &st, uint32_t la, typename GImm<T>::type imm) {
+    GOperand<T, GC, SRC, SV> b;
     if constexpr (SRC == GS_SLOT) {
         b.x = *GLDS(T, la);
         DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = *GLDS(T, la + (1 + k) * grow_bytes<T>());
@@ -64,19 +73,31 @@ template <typename T, int GC, int SRC> __device__ __forceinline__ GDual<T, GC> g
         DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = st.d[k];
     } else {
         if constexpr (SRC == GS_LEAF) {
-            b.x = *GLDS(T, la & 0xFFFFFFu);
+            b.x = *GLDS(T, SV == 0 ? (la & 0xFFFFFFu) : la); // host leaves aux = 0 for known seeds
             st.poison = M<T>::fma(b.x, T(0), st.poison); // every leaf operand is tested where it is read (:239-242)
         } else b.x = gimm_from<T>(imm);
-        const int seed = (int)(la >> 24) - (int)st.g0;
-        DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = (k == seed) ? T(1) : T(0);
+        if constexpr (SV == 0) {
+            const int seed = (int)(la >> 24) - (int)st.g0;
+            DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = (k == seed) ? T(1) : T(0);
+        }
     }
     return b;
 }
+// g * db[k]
+template <typename T, int GC, int SRC, int SV> __device__ __forceinline__ void gscale(T g, const GOperand<T, GC, SRC, SV> &b, T (&out)[GC]) {
+    if constexpr ((SRC == GS_LEAF || SRC == GS_CONST) && SV >= 1) {
+        const T z = g * T(0);
+        DE_UNROLL for (int k = 0; k < GC; k++) out[k] = (k == SV - 2) ? g : z; // g * 1 == g bit for bit
+    } else {
+        DE_UNROLL for (int k = 0; k < GC; k++) out[k] = g * b.d[k];
+    }
+}
 
-template <typename T, int GC, int SRC> __device__ __noinline__ GState<T, GC> g_load(GHARGS) {
-    const GDual<T, GC> b = goperand<T, GC, SRC>(st, la, imm);
+template <typename T, int GC, int SRC, int SV> __device__ __noinline__ GState<T, GC> g_load(GHARGS) {
+    const GOperand<T, GC, SRC, SV> b = goperand<T, GC, SRC, SV>(st, la, imm);
     st.x = b.x;
-    DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = b.d[k];
+    if constexpr ((SRC == GS_LEAF || SRC == GS_CONST) && SV >= 1) { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = (k == SV - 2) ? T(1) : T(0); }
+    else { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = b.d[k]; }
     return st;
 }
 template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_push(GHARGS) {
@@ -92,8 +113,8 @@ template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_nop(GHARGS
 
 // binary hot ops: value v and partials (gl, gr) w.r.t. (left, right); K 2/5 (RSUB/RDIV): left = operand.
 // The formulas (and their operation order) are the oracle's / the switch kernel's: d = gl*dl + gr*dr dense.
-template <typename T, int GC, int K, int SRC, bool CHK> __device__ __noinline__ GState<T, GC> g_bin(GHARGS) {
-    const GDual<T, GC> b = goperand<T, GC, SRC>(st, la, imm);
+template <typename T, int GC, int K, int SRC, int SV, bool CHK> __device__ __noinline__ GState<T, GC> g_bin(GHARGS) {
+    const GOperand<T, GC, SRC, SV> b = goperand<T, GC, SRC, SV>(st, la, imm);
     constexpr bool REV = (K == 2 || K == 5);
     const T lx = REV ? b.x : st.x, ly = REV ? st.x : b.x;
     T v, gl, gr;
@@ -102,14 +123,16 @@ template <typename T, int GC, int K, int SRC, bool CHK> __device__ __noinline__ 
     else if constexpr (K == 3) { v = lx * ly; gl = ly; gr = lx; }
     else { v = lx / ly; gl = T(1) / ly; gr = -(v / ly); }
     st.x = v;
-    if constexpr (REV) { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = gl * b.d[k] + gr * st.d[k]; }
-    else { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = gl * st.d[k] + gr * b.d[k]; }
+    T sb[GC];
+    gscale<T, GC, SRC, SV>(REV ? gl : gr, b, sb); // the operand's term
+    if constexpr (REV) { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = sb[k] + gr * st.d[k]; }
+    else { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = gl * st.d[k] + sb[k]; }
     if constexpr (CHK) st.poison = M<T>::fma(st.x, T(0), st.poison);
     return st;
 }
 // unary hot ops (K: 0 cos, 1 exp, 2 sin)
-template <typename T, int GC, int K, int SRC, bool CHK> __device__ __noinline__ GState<T, GC> g_un(GHARGS) {
-    const GDual<T, GC> b = goperand<T, GC, SRC>(st, la, imm);
+template <typename T, int GC, int K, int SRC, int SV, bool CHK> __device__ __noinline__ GState<T, GC> g_un(GHARGS) {
+    const GOperand<T, GC, SRC, SV> b = goperand<T, GC, SRC, SV>(st, la, imm);
     UG<T> r;
     if constexpr (sizeof(T) == 4) {
         if constexpr (K == 1) { r.y = (T)fast_exp_f32((float)b.x); r.g = r.y; }
@@ -128,7 +151,7 @@ template <typename T, int GC, int K, int SRC, bool CHK> __device__ __noinline__ 
         else { r.y = M<T>::sin(b.x); r.g = M<T>::cos(b.x); }
     }
     st.x = r.y;
-    DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = r.g * b.d[k];
+    gscale<T, GC, SRC, SV>(r.g, b, st.d);
     if constexpr (CHK) st.poison = M<T>::fma(st.x, T(0), st.poison);
     return st;
 }
@@ -162,7 +185,10 @@ template <typename T, int GC, int SRC> __device__ __noinline__ GState<T, GC> g_g
     uint32_t gop;
     if constexpr (SRC == GS_CONST) gop = (la >> 16) & 0xFFu; // no LDS operand: the opcode rides in la[23:16] (lds0 < 2^16)
     else gop = (uint32_t)imm;
-    const GDual<T, GC> b = goperand<T, GC, SRC>(st, la, imm);
+    const GOperand<T, GC, SRC, 0> o = goperand<T, GC, SRC, 0>(st, la, imm);
+    GDual<T, GC> b;
+    b.x = o.x;
+    DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = o.d[k];
     return g_gen_apply<T, GC>(st, gop, b);
 }
 template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_tern(GHARGS) { // acc = op3(slot B, slot C, acc)
@@ -174,28 +200,42 @@ template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_tern(GHARG
     return st;
 }
 
-template <typename T, int GC> __global__ void de_grad_fill_handlers(uint64_t *t) {
-    t[GOP_LOAD_LEAF] = (uint64_t)&g_load<T, GC, GS_LEAF>;
-    t[GOP_LOAD_SLOT] = (uint64_t)&g_load<T, GC, GS_SLOT>;
-    t[GOP_LOAD_CONST] = (uint64_t)&g_load<T, GC, GS_CONST>;
-    t[GOP_PUSH] = (uint64_t)&g_push<T, GC>;
-    t[GOP_CHECK_ACC] = (uint64_t)&g_check_acc<T, GC>;
-#define GB1(K, S) t[gop_bin(K, S, false)] = (uint64_t)&g_bin<T, GC, K, S, false>; t[gop_bin(K, S, true)] = (uint64_t)&g_bin<T, GC, K, S, true>;
-#define GB(K) GB1(K, GS_LEAF) GB1(K, GS_SLOT) GB1(K, GS_CONST)
-    GB(0) GB(1) GB(2) GB(3) GB(4) GB(5)
-#define GU1(K, S) t[gop_un(K, S, false)] = (uint64_t)&g_un<T, GC, K, S, false>; t[gop_un(K, S, true)] = (uint64_t)&g_un<T, GC, K, S, true>;
-#define GU(K) GU1(K, GS_LEAF) GU1(K, GS_SLOT) GU1(K, GS_ACC)
-    GU(0) GU(1) GU(2)
+// handler table: seed variants enumerated at compile time
+template <typename T, int GC, int SV> __device__ __forceinline__ void fill_seeded(uint64_t *t) {
+    if constexpr (SV < GC + 2) {
+        t[gop_load(GC, GS_LEAF, SV)] = (uint64_t)&g_load<T, GC, GS_LEAF, SV>;
+        t[gop_load(GC, GS_CONST, SV)] = (uint64_t)&g_load<T, GC, GS_CONST, SV>;
+#define GB1(K) t[gop_bin(GC, K, GS_LEAF, SV, false)] = (uint64_t)&g_bin<T, GC, K, GS_LEAF, SV, false>; \
+               t[gop_bin(GC, K, GS_LEAF, SV, true)] = (uint64_t)&g_bin<T, GC, K, GS_LEAF, SV, true>;    \
+               t[gop_bin(GC, K, GS_CONST, SV, false)] = (uint64_t)&g_bin<T, GC, K, GS_CONST, SV, false>; \
+               t[gop_bin(GC, K, GS_CONST, SV, true)] = (uint64_t)&g_bin<T, GC, K, GS_CONST, SV, true>;
+        GB1(0) GB1(1) GB1(2) GB1(3) GB1(4) GB1(5)
 #undef GB1
-#undef GB
+#define GU1(K) t[gop_un(GC, K, GS_LEAF, SV, false)] = (uint64_t)&g_un<T, GC, K, GS_LEAF, SV, false>; \
+               t[gop_un(GC, K, GS_LEAF, SV, true)] = (uint64_t)&g_un<T, GC, K, GS_LEAF, SV, true>;
+        GU1(0) GU1(1) GU1(2)
 #undef GU1
-#undef GU
-    t[GOP_GEN_LEAF] = (uint64_t)&g_gen<T, GC, GS_LEAF>;
-    t[GOP_GEN_SLOT] = (uint64_t)&g_gen<T, GC, GS_SLOT>;
-    t[GOP_GEN_CONST] = (uint64_t)&g_gen<T, GC, GS_CONST>;
-    t[GOP_GEN_ACC] = (uint64_t)&g_gen<T, GC, GS_ACC>;
-    t[GOP_PARAM] = (uint64_t)&g_nop<T, GC>; // parameter operands are resolved in the interpreter loop
-    t[GOP_TERN] = (uint64_t)&g_tern<T, GC>;
+        fill_seeded<T, GC, SV + 1>(t);
+    }
+}
+template <typename T, int GC> __global__ void de_grad_fill_handlers(uint64_t *t) {
+    fill_seeded<T, GC, 0>(t);
+    t[gop_load(GC, GS_SLOT, 0)] = (uint64_t)&g_load<T, GC, GS_SLOT, 0>;
+    t[gop_push(GC)] = (uint64_t)&g_push<T, GC>;
+    t[gop_check_acc(GC)] = (uint64_t)&g_check_acc<T, GC>;
+#define GB2(K) t[gop_bin(GC, K, GS_SLOT, 0, false)] = (uint64_t)&g_bin<T, GC, K, GS_SLOT, 0, false>; \
+               t[gop_bin(GC, K, GS_SLOT, 0, true)] = (uint64_t)&g_bin<T, GC, K, GS_SLOT, 0, true>;
+    GB2(0) GB2(1) GB2(2) GB2(3) GB2(4) GB2(5)
+#undef GB2
+#define GU2(K, S) t[gop_un(GC, K, S, 0, false)] = (uint64_t)&g_un<T, GC, K, S, 0, false>; t[gop_un(GC, K, S, 0, true)] = (uint64_t)&g_un<T, GC, K, S, 0, true>;
+    GU2(0, GS_SLOT) GU2(1, GS_SLOT) GU2(2, GS_SLOT) GU2(0, GS_ACC) GU2(1, GS_ACC) GU2(2, GS_ACC)
+#undef GU2
+    t[gop_gen(GC, GS_LEAF)] = (uint64_t)&g_gen<T, GC, GS_LEAF>;
+    t[gop_gen(GC, GS_SLOT)] = (uint64_t)&g_gen<T, GC, GS_SLOT>;
+    t[gop_gen(GC, GS_CONST)] = (uint64_t)&g_gen<T, GC, GS_CONST>;
+    t[gop_gen(GC, GS_ACC)] = (uint64_t)&g_gen<T, GC, GS_ACC>;
+    t[gop_param(GC)] = (uint64_t)&g_nop<T, GC>; // parameter operands are resolved in the interpreter loop
+    t[gop_tern(GC)] = (uint64_t)&g_tern<T, GC>;
 }
 
 // One sample per thread; LDS rows of GBLK(+4) elements: rows [0,F) = X tile, then each spill
@@ -247,7 +287,9 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
     const uint32_t lds0 = (uint32_t)(uintptr_t)gtsmem + tid * (uint32_t)sizeof(T);
     const int param_seed0 = a.mode != DE_GRAD_CONSTANT ? -g0 : -0x40000000;
 
-    for (int tree = t0; tree < t1; ++tree) {
+    const ConstI32Ptr tree_ids = (ConstI32Ptr)(uintptr_t)a.tree_ids;
+    for (int ti = t0; ti < t1; ++ti) {
+        const int tree = tree_ids[ti];
         const int G = n_grad[tree];
         if (g0 >= G && g0 > 0) continue; // window without a component of this tree (window 0 always runs: x, flag)
         int pc = code_off[tree];
@@ -289,7 +331,7 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
             else if (a.loss_mode == 1 + DE_LOSS_L1) { l = wv * M<T>::abs(e); lp = wv * jl_sign(e); }
             else { l = wv * (st.x * yv); lp = wv * yv; } // DE_LOSS_PULLBACK: y holds the cotangent dY
             if (wv == T(0)) { l = T(0); lp = T(0); }
-            const int64_t n_cols = col_off[a.n_trees];
+            const int64_t n_cols = col_off[a.n_all_trees];
             T *__restrict__ pp = a.partial + ((int64_t)tm.tile * n_cols + col_off[tree]) * 4 + (tid >> 6);
             if (g0 == 0) {
                 const T s = wave_sum_to_lane63(l);
@@ -318,15 +360,17 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
 
 hipError_t DE_GT_NAME(grad_thr_fetch_)(uint64_t *host_table) {
     uint64_t *d = nullptr;
-    hipError_t st = hipMalloc(reinterpret_cast<void **>(&d), GOP_COUNT * sizeof(uint64_t));
+    hipError_t st = hipMalloc(reinterpret_cast<void **>(&d), GOP_MAX * sizeof(uint64_t));
     if (st != hipSuccess) return st;
     hipLaunchKernelGGL((de_grad_fill_handlers<DE_GT_T, DE_GT_GC>), dim3(1), dim3(1), 0, 0, d);
-    st = hipMemcpy(host_table, d, GOP_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    st = hipMemcpy(host_table, d, gop_count(DE_GT_GC) * sizeof(uint64_t), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     return st;
 }
 
-hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int windows, hipStream_t stream) {
+hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStream_t stream) {
+    const GradArgs::Bucket &bk = ga.buckets[bucket];
+    const int windows = bk.windows;
     typedef DE_GT_T T;
     constexpr int GC = DE_GT_GC;
     static int gt_gcu = 0;
@@ -349,7 +393,9 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int windows, hipStre
     a.n_tiles = (e.N + GBLK - 1) / GBLK;
     a.F = e.F;
     a.P = ga.P;
-    a.n_trees = e.n_trees;
+    a.n_trees = bk.n;
+    a.n_all_trees = e.n_trees;
+    a.tree_ids = bk.ids;
     a.n_slots = e.n_slots;
     a.mode = ga.mode;
     a.classes_is_i64 = e.classes_is_i64;
@@ -374,14 +420,14 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int windows, hipStre
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) gt_gcu = prop.multiProcessorCount;
         if (gt_gcu <= 0) gt_gcu = 256;
     }
-    int64_t n_chunks = (e.n_trees + 31) / 32;
+    int64_t n_chunks = (bk.n + 31) / 32;
     const int64_t want_blocks = (int64_t)gt_gcu * 4 * 8;
     if (a.n_tiles * n_chunks * windows < want_blocks) n_chunks = (want_blocks + a.n_tiles * windows - 1) / (a.n_tiles * windows);
-    const int64_t max_chunks = (e.n_trees + 3) / 4;
+    const int64_t max_chunks = (bk.n + 3) / 4;
     if (n_chunks > max_chunks) n_chunks = max_chunks;
     if (n_chunks < 1) n_chunks = 1;
-    a.trees_per_chunk = (int32_t)((e.n_trees + n_chunks - 1) / n_chunks);
-    a.n_chunks = (int32_t)((e.n_trees + a.trees_per_chunk - 1) / a.trees_per_chunk);
+    a.trees_per_chunk = (int32_t)((bk.n + n_chunks - 1) / n_chunks);
+    a.n_chunks = (int32_t)((bk.n + a.trees_per_chunk - 1) / a.trees_per_chunk);
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL || windows > 65535) return hipErrorInvalidValue;
     const size_t lds = (size_t)(a.F + (size_t)a.n_slots * (1 + GC)) * (GBLK + 4) * sizeof(T);
@@ -391,10 +437,8 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int windows, hipStre
         hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (st != hipSuccess) return st;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)windows), dim3(GBLK), lds, stream, a, ga.handler_base, ga.param_handler_off);
-    hipError_t st = hipGetLastError();
-    if (st != hipSuccess || !ga.loss) return st;
-    return launch_loss_grad_finish(sizeof(T) == 4 ? DE_F32 : DE_F64, ga, a.n_tiles, stream);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)windows), dim3(GBLK), lds, stream, a, bk.handler_base, bk.param_handler_off);
+    return hipGetLastError(); // the loss reduction passes run once, after the last bucket (de_grad_kernels.hip)
 }
 
 

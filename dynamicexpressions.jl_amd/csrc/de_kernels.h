@@ -69,10 +69,17 @@ struct GradArgs {
     int64_t n_cols;           // = col_off[n_trees]
     void *dloss;              // device: tree t's n_grad[t] reduced gradient entries at dloss_off[t]
     const int64_t *dloss_off; // device, n_trees
-    // threaded-code variant (de_grad_threaded.hip): non-null = use it; code built for grad_window(max_grad)
+    // threaded-code variant (de_grad_threaded.hip): non-null = use it.  Trees are grouped into buckets by
+    // gradient width; each bucket is one launch of the module built for its window width.
     const BoundInstr *threaded_code;
-    uint64_t handler_base;
-    uint32_t param_handler_off;
+    int32_t n_buckets;
+    struct Bucket {
+        int32_t GC, windows, max_grad; // module (window width), windows per tree, widest gradient in the bucket
+        const int32_t *ids;            // device: tree indices of the bucket
+        int32_t n;
+        uint64_t handler_base;
+        uint32_t param_handler_off;
+    } buckets[8];
 };
 
 // Returns hipSuccess or the failing HIP error.  `kernel_name` receives the symbol
@@ -83,7 +90,7 @@ hipError_t launch_grad(int dtype, const GradArgs &a, hipStream_t stream, const c
 // Threaded gradient kernel: window width used for a population whose widest gradient has max_grad rows,
 // handler addresses for (dtype, window), launch; pass 2+3 of the fused loss-gradient reduction.
 int grad_window(int max_grad);
-hipError_t grad_handler_table(int dtype, int GC, uint64_t *table); // GOP_COUNT entries
+hipError_t grad_handler_table(int dtype, int GC, uint64_t *table); // GOP_MAX entries, gop_count(GC) used
 hipError_t launch_grad_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name);
 hipError_t launch_loss_grad_finish(int dtype, const GradArgs &ga, int64_t n_tiles, hipStream_t stream);
 
