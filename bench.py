@@ -49,30 +49,44 @@ WORKLOADS = {
     "lossgrad": dict(n_trees=1000, N=10**6, lossgrad=True,
                      desc="1000 random depth<=15 20-node trees x (5 x 10^6) Float32, fused loss + d loss/d constants "
                           "(optimiser callback, test/test_optim.jl:42-51)"),
+    "C5": dict(n_trees=1000, N=10**6, parametric=True,
+               desc="1000 random 20-node ParametricNode trees (8 parameters x 16 classes), 5 x 10^6 Float32: "
+                    "eval_tree_array + eval_grad_tree_array(variable=false) per step"),
     "tiny": dict(n_trees=64, N=10**5, desc="64 trees x (5 x 10^5) Float32 (plumbing)"),
 }
 
 
-def cpu_baseline(trees, ops, X_host, budget_s=12.0):
-    """Oracle (kind 'port') on a bounded sample: as many whole trees as fit ~budget_s, at
-    N = 10^6 samples (arrays far larger than L2, like the reference at this scale)."""
+def cpu_baseline(trees, ops, X_host, budget_s=12.0, threads=None):
+    """Oracle (kind 'port') on a bounded sample of the same workload: whole trees at N = 10^6 samples
+    (arrays far larger than L2, like the reference at this scale) for ~budget_s, on `threads` host
+    threads — the reference evaluates one tree per call single-threaded, a population is
+    parallelised over trees by its callers, which is what the thread pool does (ctypes releases the
+    GIL inside the C call).  `cores` = threads actually used."""
+    from concurrent.futures import ThreadPoolExecutor
     import dynamicexpressions_jl_amd as de
     from oracle import oracle
-    t0 = time.perf_counter()
-    nodes = 0
-    used = 0
-    for tree in trees:
-        tape, consts = de.flatten(tree, ops, np.float32)
+    threads = threads or max(1, min(64, (os.cpu_count() or 1) // 2))
+    tapes = [de.flatten(t, ops, np.float32) for t in trees]
+    oracle.eval_tree_array(tapes[0][0], tapes[0][1], X_host[:, :1000])  # load the library outside the timed region
+    deadline = [0.0]
+    done = []
+
+    def work(i):
+        if time.perf_counter() > deadline[0]:
+            return
+        tape, consts = tapes[i]
         oracle.eval_tree_array(tape, consts, X_host)
-        nodes += len(tape)
-        used += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
+        done.append(len(tape))
+
+    t0 = time.perf_counter()
+    deadline[0] = t0 + budget_s
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(work, range(len(tapes))))
     dt = time.perf_counter() - t0
-    return dict(value=nodes * X_host.shape[1] / dt, unit="node-evals/s", cores=1, kind="port",
-                sample=f"first {used} trees x {X_host.shape[1]} samples of the same workload, "
-                       f"oracle/libde_oracle.so (C restatement of src/Evaluate.jl, early exit on), "
-                       f"{dt:.1f} s on {os.cpu_count()} host cores available, 1 used")
+    return dict(value=sum(done) * X_host.shape[1] / dt, unit="node-evals/s", cores=threads, kind="port",
+                sample=f"{len(done)} trees x {X_host.shape[1]} samples of the same workload, "
+                       f"oracle/libde_oracle.so (C restatement of src/Evaluate.jl, early exit on), one tree per task on "
+                       f"{threads} threads, {dt:.1f} s; {os.cpu_count()} host cores available")
 
 
 def main():
@@ -104,13 +118,17 @@ def main():
     n_per_gpu, N = wl["n_trees"], wl["N"]
     ops = de.synth.BENCH_OPERATORS
     # weak scaling: the job's population is n_per_gpu * world trees, round-robin sharded
-    all_trees = de.synth.random_population(n_per_gpu * world, seed=0xDE02)
+    is_param = bool(wl.get("parametric"))
+    if is_param:
+        all_trees = de.synth.random_population(n_per_gpu * world, seed=0xDE05, node_type=de.ParametricNode, nparams=8)
+    else:
+        all_trees = de.synth.random_population(n_per_gpu * world, seed=0xDE02)
     my_ids = dedist.shard_indices(len(all_trees), rank, world)
     trees = [all_trees[i] for i in my_ids]
     total_nodes = sum(de.count_nodes(t) for t in all_trees)
 
     ctx = api.Context(local_rank)
-    pop = api.Population(trees, ops, np.float32, n_features=5, ctx=ctx)
+    pop = api.Population(trees, ops, np.float32, n_features=5, n_params=8 if is_param else 0, ctx=ctx)
     g = torch.Generator(device=dev).manual_seed(1)  # same X on every rank (replicated)
     X = torch.randn((N, 5), generator=g, device=dev, dtype=torch.float32).t()  # [5, N] feature-fastest
     out = None if (wl.get("loss") or wl.get("lossgrad")) else torch.empty((len(trees), N), device=dev, dtype=torch.float32)
@@ -127,8 +145,26 @@ def main():
         lossv = torch.empty(len(trees), device=dev, dtype=torch.float32)
     grad = torch.empty(len(trees) * 5 * N, device=dev, dtype=torch.float32) if is_grad else None
 
+    if is_param:
+        n_cls = 16
+        params = torch.randn((n_cls, 8), generator=g, device=dev, dtype=torch.float32)  # [P=8, C] column-major
+        classes = torch.randint(1, n_cls + 1, (N,), generator=g, device=dev, dtype=torch.int32)
+        pa = api.ParamArgs()
+        pa.params, pa.ld_params, pa.n_classes = params.data_ptr(), 8, n_cls
+        pa.classes, pa.classes_is_i64, pa.class_base = classes.data_ptr(), 0, 1
+        import ctypes
+        pa_ref = ctypes.byref(pa)
+        ng_c = np.array([pop.n_grad(t, 1) for t in range(len(trees))], dtype=np.int64)
+        goffs = np.zeros(len(trees), dtype=np.int64)
+        np.cumsum(ng_c[:-1] * N, out=goffs[1:])
+        gradc = torch.empty(max(int((ng_c * N).sum()), 1), device=dev, dtype=torch.float32)
+
     def step():
-        if is_grad:
+        if is_param:
+            ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, 5, pa_ref, out.data_ptr(), N, ok.data_ptr()))
+            ctx.check(lib.de_eval_grad(ctx._h, pop._h, X.data_ptr(), N, 5, pa_ref, 1, None, N, gradc.data_ptr(),
+                                       goffs.ctypes.data, ok.data_ptr()))
+        elif is_grad:
             ctx.check(lib.de_eval_grad(ctx._h, pop._h, X.data_ptr(), N, 5, None, 0, out.data_ptr(), N,
                                        grad.data_ptr(), None, ok.data_ptr()))
         elif is_lossgrad:
@@ -171,7 +207,11 @@ def main():
         k_avg_ms = float(np.mean(kms)) if kms else ms_per_step
         plan = pop.plan(N)
         units = len(trees) * N  # tree-samples per launch (this rank's shard)
-        if is_grad:  # one tree per X pass, writes x + 5 gradient rows: (F + 1 + F)*s  
+        if is_param:  # eval (X tile per chunk + output) + constant-mode Jacobian rows; priced on the whole step
+            k_eff = plan["trees_per_chunk"]
+            k_avg_ms = ms_per_step
+            b_unit = (F_FEATURES * ELEM / k_eff + ELEM) + (F_FEATURES * ELEM / 32 + float(ng_c.mean()) * ELEM)
+        elif is_grad:  # one tree per X pass, writes x + 5 gradient rows: (F + 1 + F)*s  
             k_eff, b_unit = 1, float((2 * F_FEATURES + 1) * ELEM)
         elif is_lossgrad:  # X (+ y) tile staged once per chunk of 32 trees; (1 + n_const) partials per wave
             k_eff = 32
@@ -208,7 +248,7 @@ def main():
                          "note": "X tile reused by k_eff trees from LDS: HBM traffic ~= the output; the kernel is "
                                  "VALU/scalar-issue bound (DESIGN.md §Roofline)"},
         }
-        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (rank 0)
+        if not args.no_cpu_baseline and world == 1 and not is_param:  # reported at N=1 only (rank 0)
             Ns = min(N, 10**6)
             Xh = np.asfortranarray(X[:, :Ns].t().contiguous().cpu().numpy().T)
             res["cpu_baseline"] = cpu_baseline(all_trees, ops, Xh)
