@@ -54,6 +54,9 @@ template <typename T> struct KArgs {
     const T *w;
     T *partial; // [n_tiles][n_trees][4 waves]
     int32_t loss_kind;
+    // vectorised staging of the X tile (threaded kernel): X 16-byte aligned with ldX == F
+    int32_t x_vec;
+    uint32_t f_magic; // ceil(2^32 / F) for F > 1 (e / F == umulhi(e, f_magic) while e * F < 2^32), 0 for F == 1
 };
 
 // A thread owns G groups of VW consecutive samples (VW*sizeof(T) = 16 bytes, one
@@ -734,7 +737,30 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
     {
         const uint32_t F = (uint32_t)a.F;
         const uint32_t total = (uint32_t)TILE * F;
-        if (a.ldX == (int64_t)F && base + TILE <= a.N) {
+        if (a.x_vec && base + TILE <= a.N) {
+            // The tile is TILE*F contiguous elements = exactly F 16-byte vectors per thread.  Up to 8 vector
+            // loads are issued before the first LDS write (few trees per chunk = HBM-bound: memory-level
+            // parallelism is what counts there); (sample, feature) of an element by a host-computed
+            // reciprocal instead of a run-time division.
+            const V *__restrict__ src = reinterpret_cast<const V *>(a.X + base * (int64_t)F);
+            for (uint32_t i0 = 0; i0 < F; i0 += 8) {
+                V buf[8];
+                DE_UNROLL for (uint32_t u = 0; u < 8; u++)
+                    if (i0 + u < F) buf[u] = src[tid + (i0 + u) * BLK];
+                DE_UNROLL for (uint32_t u = 0; u < 8; u++) {
+                    if (i0 + u < F) {
+                        const uint32_t e = (tid + (i0 + u) * BLK) * VW;
+                        uint32_t j = a.f_magic ? __umulhi(e, a.f_magic) : e;
+                        uint32_t f = e - j * F;
+                        DE_UNROLL for (int c = 0; c < VW; c++) {
+                            rows[f * (ROWV * VW) + j] = buf[u][c];
+                            ++f;
+                            if (f == F) { f = 0; ++j; }
+                        }
+                    }
+                }
+            }
+        } else if (a.ldX == (int64_t)F && base + TILE <= a.N) {
             const T *__restrict__ src = a.X + base * (int64_t)F;
             for (uint32_t e = tid; e < total; e += BLK) {
                 const uint32_t j = e / F, f = e - j * F;
@@ -1023,6 +1049,10 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.classes_is_i64 = e.classes_is_i64;
     a.class_base = e.class_base;
     a.vec_store = (reinterpret_cast<uintptr_t>(e.out) % 16 == 0 && (e.ld_out * sizeof(T)) % 16 == 0) ? 1 : 0;
+    a.x_vec = (e.F >= 1 && e.ldX == e.F && reinterpret_cast<uintptr_t>(e.X) % 16 == 0 && (int64_t)TILE * e.F < 0x10000000LL) ? 1 : 0;
+    a.f_magic = e.F > 1 ? (uint32_t)((0x100000000ull + (uint64_t)e.F - 1) / (uint64_t)e.F) : 0u;
+    a.x_vec = 0;
+    a.f_magic = 0;
     int32_t tpc, nch;
     plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc);
     a.trees_per_chunk = tpc;
