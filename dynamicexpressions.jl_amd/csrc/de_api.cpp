@@ -72,7 +72,7 @@ struct de_program {
     std::vector<Instr> fcode;
     std::vector<int32_t> fcode_off;
     std::vector<int32_t> fconst_instr;  // per constant: index into fcode, or < 0 if folded away
-    struct Fold { int32_t tree, instr; };
+    struct Fold { int32_t tree, instr; bool tested_always; };
     std::vector<Fold> folds;            // aux tree j -> (owning tree, fcode instruction holding its value)
     std::vector<int64_t> aux_const_src; // aux constant k = consts[aux_const_src[k]]
     de_program *aux = nullptr;
@@ -351,8 +351,10 @@ static void recompute_host_ok(de_program *p) {
     // a constant subtree that evaluates to a non-finite value clears the flag — with the flag
     // semantics of the program's own options (dispatch_constant_tree tests unconditionally,
     // the Bumper path only under early_exit): that is exactly what `aux` was lowered with
+    // — except for a subtree the reference never hands to dispatch_constant_tree (inner branch of a fused
+    // 3-node kernel): its non-finite value is only noticed by the early-exit tests
     for (size_t j = 0; j < p->folds.size() && j < p->fold_ok.size(); j++)
-        if (!p->fold_ok[j]) p->host_ok_eval[(size_t)p->folds[j].tree] = 0;
+        if (!p->fold_ok[j] && (p->folds[j].tested_always || ee)) p->host_ok_eval[(size_t)p->folds[j].tree] = 0;
 }
 
 static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, const int64_t *node_offsets,
@@ -483,7 +485,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                 }
                 for (size_t f = 0; f < tp.folds.size(); f++) {
                     const FoldSpan &sp = tp.folds[f];
-                    p->folds.push_back({(int32_t)t, ib + tp.const_instr[(size_t)(c1 - c0) + f]});
+                    p->folds.push_back({(int32_t)t, ib + tp.const_instr[(size_t)(c1 - c0) + f], sp.tested_always});
                     for (int32_t q = sp.node_begin; q < sp.node_end; q++) {
                         de_tape_node_t nd = nodes[n0 + q];
                         if (nd.degree == 0 && nd.op == DE_LEAF_CONST) nd.arg = (uint16_t)(nd.arg - sp.const_begin);

@@ -432,7 +432,7 @@ int lower_tree(const de_tape_node_t *tape, int64_t n, int64_t n_consts, const Lo
             if (nd.is_const) {
                 nd.fold_slot = (int)n_consts + (int)out->folds.size();
                 if (nd.fold_slot > 65535) return fail(DE_ERR_UNSUPPORTED, "too many constants");
-                out->folds.push_back(FoldSpan{nd.first, (int32_t)i + 1, nd.cfirst, nd.cfirst + nd.ccount});
+                out->folds.push_back(FoldSpan{nd.first, (int32_t)i + 1, nd.cfirst, nd.cfirst + nd.ccount, nd.constfold});
             } else {
                 for (int k = 0; k < nd.degree; k++) todo.push_back(nd.child[k]);
             }

@@ -34,6 +34,11 @@ enum : uint8_t {
 // slots [const_begin, const_end) it owns; its value lives in extended constant slot n_consts + k.
 struct FoldSpan {
     int32_t node_begin, node_end, const_begin, const_end;
+    // true: the reference evaluates this subtree with dispatch_constant_tree (reached through
+    // _eval_tree_array), whose validity test is unconditional; false: the subtree is the inner branch of a
+    // fused 3-node kernel (deg2_branch0_eval, src/Evaluate.jl:795-871) or on the Bumper path — a non-finite
+    // value only clears the flag under early_exit
+    bool tested_always;
 };
 
 struct TreeProgram {

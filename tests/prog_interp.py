@@ -71,7 +71,7 @@ TERNARY = {
 def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noise_eps=0.0, rng=None):
     """Execute instruction words ([n,4] uint32) on X [F, N].  Returns (out, ok).
 
-    ``noise_eps`` > 0 multiplies every operator result by (1 +- noise_eps) with a random sign
+    ``noise_eps`` > 0 multiplies every operator result by (1 +- u*noise_eps), u uniform in [1/4, 1], with a random sign
     per sample (discrete stochastic arithmetic): the spread of the outputs over a few such runs
     measures how strongly a sample amplifies a one-rounding-error difference between two
     implementations of the same operator (used for the parity tolerance, helpers.py)."""
@@ -113,7 +113,16 @@ def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noi
                 if (not early_exit) and (hdr & (1 << 14)):
                     acc = np.where(np.isfinite(b), acc, np.inf).astype(dt)
             if noise_eps and op != DOP_LOAD:
-                acc = (acc * (1.0 + noise_eps * rng.choice(np.array([-1.0, 1.0]), size=N))).astype(dt)
+                # random sign AND magnitude in [1/4, 1] of noise_eps: a fixed step can land on a period of the
+                # function downstream (1.05e8 * 2^-23 = 12.55 ~ 4*pi hid a chaotic cos(exp(x)) sample)
+                step = rng.choice(np.array([-1.0, 1.0]), size=N) * rng.uniform(0.25, 1.0, size=N)
+                acc = (acc * (1.0 + noise_eps * step)).astype(dt)
+                if op in (74, 0xF7):  # pow_abs2 = exp(y * log|x|) is three roundings; exp amplifies the inner two by |m|
+                    with np.errstate(all="ignore"):
+                        m = np.abs(np.log(np.abs(acc.astype(np.float64))))
+                    m = np.where(np.isfinite(m), m, 0.0)
+                    step2 = rng.choice(np.array([-1.0, 1.0]), size=N) * rng.uniform(0.25, 1.0, size=N)
+                    acc = (acc * (1.0 + noise_eps * 2.0 * m * step2)).astype(dt)
             check = bool(hdr & (1 << 15)) if early_exit else bool(hdr & (1 << 13))
             if check:
                 bad |= bool(np.any(~np.isfinite(acc)))
