@@ -7,9 +7,9 @@ from dynamicexpressions_jl_amd import api
 from oracle import oracle
 from helpers import parity_tolerance
 seed0 = int(sys.argv[1])
-ops_wide = de.OperatorEnum(binary_operators=("+", "-", "/", "*", "max", "min", "pow_abs2", "^", "mod", "rem", "greater"),
+ops_wide = de.OperatorEnum(binary_operators=("+", "-", "/", "*", "max", "min", "pow_abs2", "^"),
                            unary_operators=("cos", "exp", "safe_log", "neg", "square", "cube", "abs", "tanh", "sin",
-                                            "safe_sqrt", "relu", "sign", "round", "atan"))
+                                            "safe_sqrt", "atan", "relu"))
 ops_hot = de.synth.BENCH_OPERATORS
 
 def subtrees(t):
@@ -52,7 +52,7 @@ for rep in range(6):
                             flag = "" if (yo[0] == yg[0] or (np.isnan(yo[0]) and np.isnan(yg[0]))) else "   <-- differs"
                             print("   ", de.string_tree(st, ops)[:70], "gpu", repr(yg[0]), "oracle", repr(yo[0]), flag)
                         found += 1
-                        if found >= 3: sys.exit(0)
+                        if found >= 1: sys.exit(0)
                         continue
                     if not ok_el or not ok[t]:
                         continue
@@ -73,6 +73,6 @@ for rep in range(6):
                             flag = "" if (yo[0] == yg[0] or (np.isnan(yo[0]) and np.isnan(yg[0]))) else "   <-- differs"
                             print("   ", de.string_tree(st, ops)[:70], "gpu", repr(yg[0]), "oracle", repr(yo[0]), flag)
                         found += 1
-                        if found >= 3: sys.exit(0)
+                        if found >= 1: sys.exit(0)
                 pop.close()
 print("no mismatch")
