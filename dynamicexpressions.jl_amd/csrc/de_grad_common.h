@@ -180,8 +180,16 @@ template <typename T> __device__ __noinline__ TG<T> ternary_vg(uint32_t op, T x,
 
 struct GTileMap { int64_t tile; int32_t chunk; bool valid; };
 __device__ __forceinline__ GTileMap gmap_block(uint32_t bid, int32_t n_chunks, int64_t n_tiles) {
-    const uint32_t xcd = bid & 7u, idx = bid >> 3;
     GTileMap m;
+    if (n_tiles < 64) {
+        // few sample tiles (the many-trees x few-rows shape): X fits in every L2 anyway, and the XCD-aware
+        // order below would put all work of tile t on XCD t mod 8 (one eighth of the chip for a single tile)
+        m.tile = (int64_t)(bid % (uint32_t)n_tiles);
+        m.chunk = (int32_t)(bid / (uint32_t)n_tiles);
+        m.valid = m.chunk < n_chunks;
+        return m;
+    }
+    const uint32_t xcd = bid & 7u, idx = bid >> 3;
     m.chunk = (int32_t)(idx % (uint32_t)n_chunks);
     m.tile = (int64_t)(idx / (uint32_t)n_chunks) * 8 + xcd;
     m.valid = m.tile < n_tiles;

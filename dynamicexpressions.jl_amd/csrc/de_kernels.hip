@@ -267,8 +267,16 @@ struct TileMap {
     bool valid;
 };
 __device__ __forceinline__ TileMap map_block(uint32_t bid, int32_t n_chunks, int64_t n_tiles) {
-    const uint32_t xcd = bid & 7u, idx = bid >> 3;
     TileMap m;
+    if (n_tiles < 64) {
+        // few sample tiles (the many-trees x few-rows shape): X fits in every L2 anyway, and the XCD-aware
+        // order below would put all work of tile t on XCD t mod 8 (one eighth of the chip for a single tile)
+        m.tile = (int64_t)(bid % (uint32_t)n_tiles);
+        m.chunk = (int32_t)(bid / (uint32_t)n_tiles);
+        m.valid = m.chunk < n_chunks;
+        return m;
+    }
+    const uint32_t xcd = bid & 7u, idx = bid >> 3;
     m.chunk = (int32_t)(idx % (uint32_t)n_chunks);
     m.tile = (int64_t)(idx / (uint32_t)n_chunks) * 8 + xcd;
     m.valid = m.tile < n_tiles;
@@ -913,7 +921,15 @@ static void eval_geometry(int dtype, int *G, int *BLK);
 static int g_cu_count = 0;
 
 static int cu_count() {
-    return g_cu_count;
+    if (g_cu_count == 0) {
+        const int forced = env_int("DE_CU_COUNT", 0); // experiments: < 0 disables the small-grid re-split
+        if (forced != 0) { g_cu_count = forced; return forced < 0 ? 0 : forced; }
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) g_cu_count = prop.multiProcessorCount;
+        if (g_cu_count <= 0) g_cu_count = 256; // MI355X
+    }
+    return g_cu_count < 0 ? 0 : g_cu_count;
 }
 
 // Tree chunking: chunks of ~64 trees keep workgroups short (fine-grained tail) while the
