@@ -9,6 +9,8 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/de_hip.h"
@@ -163,6 +165,28 @@ static const OpName kOps[] = {
     {"fma", 3, DE_T_FMA}, {"clamp", 3, DE_T_CLAMP}, {"+", 3, DE_T_ADD3}, {"max", 3, DE_T_MAX3},
 };
 
+// Host-side lowering is ~3 us per tree and per pass; populations of 10^4..10^5 trees are re-created every
+// generation by a search loop, so the per-tree passes run on a few host threads.
+template <class F> static void parallel_for_trees(int64_t n, F f) {
+    unsigned hw = std::thread::hardware_concurrency();
+    const char *env = getenv("DE_HOST_THREADS");
+    unsigned nt = env && *env ? (unsigned)atoi(env) : std::min(hw ? hw : 1u, 16u);
+    if ((int64_t)nt > n / 256) nt = (unsigned)(n / 256);
+    if (nt <= 1) {
+        for (int64_t i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    const int64_t per = (n + nt - 1) / nt;
+    for (unsigned k = 0; k < nt; k++) {
+        const int64_t b = (int64_t)k * per, e = std::min<int64_t>(n, b + per);
+        if (b >= e) break;
+        th.emplace_back([=] { for (int64_t i = b; i < e; i++) f(i); });
+    }
+    for (auto &t : th) t.join();
+}
+
 extern "C" {
 
 int de_abi_version(void) { return DE_HIP_ABI_VERSION; }
@@ -285,6 +309,7 @@ static void rebind(de_program *p) {
         p->bcode_off[(size_t)t + 1] = (int32_t)p->bcode.size();
     }
 }
+// (bind_tree / fuse_tree are ~0.3 us per tree: not worth threads)
 
 // Threaded-code form of the bound program (de_kernels.hip, de_eval_threaded_kernel): word 0 =
 // handler address - handler_base, word 1 = LDS byte offset of the operand row | aux << 24.
@@ -435,14 +460,32 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         p->consts.resize((size_t)total_consts);
         p->const_instr.assign((size_t)total_consts, -1);
         p->const_checks.assign((size_t)total_consts, 0);
-        TreeProgram tp;
-        std::string why;
+        for (int64_t t = 0; t < n_trees; t++)
+            if (node_offsets[t + 1] < node_offsets[t] || const_offsets[t + 1] < const_offsets[t])
+                return fail(ctx, DE_ERR_INVALID_ARG, "offsets not monotone at tree %lld", (long long)t);
+        // both lowerings of every tree (plain, and with constant subtrees folded), on host threads
+        struct Lowered { TreeProgram plain, folded; int rc = DE_OK, rcf = DE_OK; std::string why; };
+        std::vector<Lowered> low((size_t)n_trees);
+        {
+            LowerOptions lof = lo;
+            lof.fold = true;
+            std::atomic<bool> oom{false};
+            parallel_for_trees(n_trees, [&](int64_t t) {
+                Lowered &L = low[(size_t)t];
+                const int64_t n0 = node_offsets[t], c0 = const_offsets[t];
+                try {
+                    L.rc = lower_tree(nodes + n0, node_offsets[t + 1] - n0, const_offsets[t + 1] - c0, lo, &L.plain, &L.why);
+                    if (L.rc == DE_OK && allow_fold)
+                        L.rcf = lower_tree(nodes + n0, node_offsets[t + 1] - n0, const_offsets[t + 1] - c0, lof, &L.folded, &L.why);
+                } catch (const std::bad_alloc &) { oom = true; }
+            });
+            if (oom) return fail(ctx, DE_ERR_HIP, "out of host memory");
+        }
         for (int64_t t = 0; t < n_trees; t++) {
             const int64_t n0 = node_offsets[t], n1 = node_offsets[t + 1];
             const int64_t c0 = const_offsets[t], c1 = const_offsets[t + 1];
-            if (n1 < n0 || c1 < c0) return fail(ctx, DE_ERR_INVALID_ARG, "offsets not monotone at tree %lld", (long long)t);
-            int rc = lower_tree(nodes + n0, n1 - n0, c1 - c0, lo, &tp, &why);
-            if (rc != DE_OK) return fail(ctx, rc, "tree %lld: %s", (long long)t, why.c_str());
+            TreeProgram &tp = low[(size_t)t].plain;
+            if (low[(size_t)t].rc != DE_OK) return fail(ctx, low[(size_t)t].rc, "tree %lld: %s", (long long)t, low[(size_t)t].why.c_str());
             const int64_t cb = c0 - const_offsets[0];
             p->const_off[(size_t)t] = cb;
             p->const_off[(size_t)t + 1] = cb + (c1 - c0);
@@ -473,8 +516,10 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
             for (int64_t t = 0; t < n_trees; t++) {
                 const int64_t n0 = node_offsets[t], n1 = node_offsets[t + 1];
                 const int64_t c0 = const_offsets[t], c1 = const_offsets[t + 1];
-                int rc = lower_tree(nodes + n0, n1 - n0, c1 - c0, lo, &tp, &why);
-                if (rc != DE_OK) return fail(ctx, rc, "tree %lld (folded): %s", (long long)t, why.c_str());
+                TreeProgram &tp = low[(size_t)t].folded;
+                if (low[(size_t)t].rcf != DE_OK)
+                    return fail(ctx, low[(size_t)t].rcf, "tree %lld (folded): %s", (long long)t, low[(size_t)t].why.c_str());
+                (void)n1;
                 const int64_t cb = c0 - const_offsets[0];
                 const int32_t ib = (int32_t)p->fcode.size();
                 for (int64_t k = 0; k < c1 - c0; k++) {
@@ -892,10 +937,13 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
     c->timed = true;
     if (sLoss.staged) HIP_TRY(c, hipMemcpyAsync(lr->loss, sLoss.dev, (size_t)p->n_trees * es, hipMemcpyDeviceToHost, c->stream));
     if (sOut.staged) {
-        for (int64_t t = 0; t < p->n_trees; t++) // rows may be strided in the caller's buffer
-            HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(out) + (size_t)t * (size_t)ld_out * es,
-                                      static_cast<char *>(sOut.dev) + (size_t)t * (size_t)ld_out * es,
-                                      (size_t)N * es, hipMemcpyDeviceToHost, c->stream));
+        if (ld_out == N) // one block (the constant-folding population is 10^3..10^5 one-sample rows)
+            HIP_TRY(c, hipMemcpyAsync(out, sOut.dev, (size_t)p->n_trees * (size_t)N * es, hipMemcpyDeviceToHost, c->stream));
+        else
+            for (int64_t t = 0; t < p->n_trees; t++) // rows are strided in the caller's buffer
+                HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(out) + (size_t)t * (size_t)ld_out * es,
+                                          static_cast<char *>(sOut.dev) + (size_t)t * (size_t)ld_out * es,
+                                          (size_t)N * es, hipMemcpyDeviceToHost, c->stream));
     }
     if (sOk.staged) HIP_TRY(c, hipMemcpyAsync(ok, sOk.dev, (size_t)p->n_trees, hipMemcpyDeviceToHost, c->stream));
     if (sX.staged || sOut.staged || sOk.staged || sPar.staged || sCls.staged || sY.staged || sW.staged || sLoss.staged)
