@@ -335,6 +335,14 @@ class Population:
     def n_grad(self, tree: int, mode: int) -> int:
         return int(library().de_program_n_grad(self._h, tree, mode))
 
+    def _n_grad_all(self, mode: int) -> np.ndarray:
+        """n_grad of every tree in ``mode`` (cached: it depends on the tree shapes only)."""
+        cache = self.__dict__.setdefault("_ng_cache", {})
+        if mode not in cache:
+            lib = library()
+            cache[mode] = np.array([lib.de_program_n_grad(self._h, t, mode) for t in range(self.n_trees)], dtype=np.int64)
+        return cache[mode]
+
     def dump(self, tree: int) -> np.ndarray:
         """Lowered instruction words of one tree ([n_instr, 4] uint32) — test hook."""
         lib = library()
@@ -468,7 +476,7 @@ class Population:
         keep = [keep_x]
         pa = self._param_args(params, classes, class_base, N, keep)
         lib = library()
-        ng = np.array([self.n_grad(t, mode) for t in range(self.n_trees)], dtype=np.int64)
+        ng = self._n_grad_all(mode)
         offs = np.zeros(self.n_trees + 1, dtype=np.int64)
         np.cumsum(ng, out=offs[1:])
         total = max(int(offs[-1]), 1)
@@ -498,13 +506,13 @@ class Population:
             ok = torch.empty(self.n_trees, dtype=torch.uint8, device=keep_x.device)
             self.ctx.check(lib.de_eval_loss_grad(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None, mode,
                                                  yp, wp, kind, lo.data_ptr(), dl.data_ptr(), offs.ctypes.data, ok.data_ptr()))
-            return lo, [dl[offs[t]:offs[t + 1]] for t in range(self.n_trees)], ok.bool()
+            return lo, list(torch.split(dl[:int(offs[-1])], ng.tolist())), ok.bool()
         lo = np.empty(self.n_trees, dtype=self.dtype)
         dl = np.empty(total, dtype=self.dtype)
         ok = np.zeros(self.n_trees, dtype=np.uint8)
         self.ctx.check(lib.de_eval_loss_grad(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None, mode,
                                              yp, wp, kind, lo.ctypes.data, dl.ctypes.data, offs.ctypes.data, ok.ctypes.data))
-        return lo, [dl[offs[t]:offs[t + 1]] for t in range(self.n_trees)], ok.astype(bool)
+        return lo, np.split(dl[:int(offs[-1])], offs[1:-1]), ok.astype(bool)
 
     def eval_grad(self, X, variable: Union[bool, str] = False, params=None, classes=None,
                   class_base: int = 1):
@@ -518,7 +526,7 @@ class Population:
         keep = [keep_x]
         pa = self._param_args(params, classes, class_base, N, keep)
         lib = library()
-        ng = np.array([self.n_grad(t, mode) for t in range(self.n_trees)], dtype=np.int64)
+        ng = self._n_grad_all(mode)
         offs = np.zeros(self.n_trees + 1, dtype=np.int64)
         np.cumsum(ng * N, out=offs[1:])
         total = int(offs[-1])

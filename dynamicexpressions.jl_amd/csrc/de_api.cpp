@@ -101,6 +101,10 @@ struct de_program {
     BoundInstr *d_gtcode = nullptr;
     int32_t *d_gtcode_off = nullptr;
     int32_t *d_gt_ids = nullptr;        // tree indices grouped by bucket
+    // immediate sites (set_consts patches constants in place): for a generic instruction with a constant
+    // operand, the index of the instruction carrying its bits in bcode / tcode (eval source program) and in
+    // gbcode / gtcode (unfolded program); -1 elsewhere.  Empty = not available (full rebuild instead).
+    std::vector<int32_t> bsite, tsite, gbsite, gtsite_of_gb;
     int gt_mode = -1;
     bool gt_valid = false;
     int gt_n_buckets = 0;
@@ -185,6 +189,27 @@ template <class F> static void parallel_for_trees(int64_t n, F f) {
         th.emplace_back([=] { for (int64_t i = b; i < e; i++) f(i); });
     }
     for (auto &t : th) t.join();
+}
+
+// Pair the constant-carrying instructions of a generic program with those of a derived (bound / fused)
+// stream, tree by tree, in program order.  Returns false if the counts disagree (never expected).
+template <class Derived, class Pred>
+static bool match_const_sites(const std::vector<Instr> &src, const std::vector<int32_t> &src_off, const std::vector<Derived> &dst,
+                              const std::vector<int32_t> &dst_off, int64_t n_trees, Pred carries, std::vector<int32_t> *site) {
+    site->assign(src.size(), -1);
+    for (int64_t t = 0; t < n_trees; t++) {
+        int32_t j = dst_off[(size_t)t];
+        const int32_t j1 = dst_off[(size_t)t + 1];
+        for (int32_t i = src_off[(size_t)t]; i < src_off[(size_t)t + 1]; i++) {
+            if (((src[(size_t)i].hdr >> H_SRC_SHIFT) & H_SRC_MASK) != SRC_CONST) continue;
+            while (j < j1 && !carries(dst[(size_t)j])) j++;
+            if (j >= j1) { site->clear(); return false; }
+            (*site)[(size_t)i] = j++;
+        }
+        while (j < j1 && !carries(dst[(size_t)j])) j++;
+        if (j != j1) { site->clear(); return false; }
+    }
+    return true;
 }
 
 extern "C" {
@@ -308,6 +333,8 @@ static void rebind(de_program *p) {
         bind_tree(src.data() + i0, (size_t)(i1 - i0), ee, p->n_features, &p->bcode);
         p->bcode_off[(size_t)t + 1] = (int32_t)p->bcode.size();
     }
+    match_const_sites(src, off, p->bcode, p->bcode_off, p->n_trees, [](const BoundInstr &b) { return bop_is_const_source(b.bop); }, &p->bsite);
+    p->tsite.clear();
 }
 // (bind_tree / fuse_tree are ~0.3 us per tree: not worth threads)
 
@@ -353,6 +380,11 @@ static int make_threaded(de_ctx *c, de_program *p) {
                 t.lo = (uint32_t)((int32_t)b.lo * (int32_t)row_bytes); // row-row: byte distance row A -> row B
         }
         p->tcode[i] = t;
+    }
+    {
+        const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
+        const std::vector<int32_t> &off = p->folded ? p->fcode_off : p->code_off;
+        match_const_sites(src, off, p->fbcode, p->tcode_off, p->n_trees, [](const BoundInstr &b) { return top_carries_const(b.bop); }, &p->tsite);
     }
     p->handler_base = base;
     p->param_handler_off = (uint32_t)(table[BOP_GEN_PARAM] - base);
@@ -614,13 +646,55 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
         if (rc != DE_OK) return rc;
     }
     recompute_host_ok(p);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // Same tree shapes, new immediates: patch the bits where they live (the optimiser calls this once per
+    // step — re-binding 10^4 trees costs milliseconds, the kernel it feeds a few hundred microseconds).
+    const char *nopatch = getenv("DE_NO_CONST_PATCH");
+    if (!(nopatch && *nopatch == '1') && p->threaded && !p->tsite.empty() && !p->bsite.empty()) {
+        const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
+        for (size_t i = 0; i < src.size(); i++) {
+            const int32_t bj = p->bsite[i], tj = p->tsite[i];
+            if (bj < 0) continue;
+            p->bcode[(size_t)bj].lo = src[i].imm.u32[0];
+            p->bcode[(size_t)bj].hi = src[i].imm.u32[1];
+            p->tcode[(size_t)tj].lo = src[i].imm.u32[0];
+            p->tcode[(size_t)tj].hi = src[i].imm.u32[1];
+        }
+        const bool gpatch = p->d_gcode && !p->gcode_stale && !p->gbsite.empty();
+        if (gpatch) {
+            const bool tpatch = p->gt_valid && !p->gtsite_of_gb.empty();
+            for (size_t i = 0; i < p->code.size(); i++) {
+                const int32_t gj = p->gbsite[i];
+                if (gj < 0) continue;
+                p->gbcode[(size_t)gj].lo = p->code[i].imm.u32[0];
+                p->gbcode[(size_t)gj].hi = p->code[i].imm.u32[1];
+                if (tpatch) {
+                    const int32_t tj = p->gtsite_of_gb[(size_t)gj];
+                    p->gtcode[(size_t)tj].lo = p->code[i].imm.u32[0];
+                    p->gtcode[(size_t)tj].hi = p->code[i].imm.u32[1];
+                }
+            }
+            if (!tpatch) p->gt_valid = false;
+        } else {
+            p->gcode_stale = true;
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // the program may be in use by work already queued
+        if (!p->tcode.empty())
+            HIP_TRY(ctx, hipMemcpy(p->d_code, p->tcode.data(), p->tcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
+        if (gpatch) {
+            if (!p->gbcode.empty())
+                HIP_TRY(ctx, hipMemcpy(p->d_gcode, p->gbcode.data(), p->gbcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
+            if (p->gt_valid && !p->gtcode.empty())
+                HIP_TRY(ctx, hipMemcpy(p->d_gtcode, p->gtcode.data(), p->gtcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
+        }
+        return DE_OK;
+    }
     p->gcode_stale = true;
     try {
         rebind(p); // same shape: only immediates change
     } catch (const std::bad_alloc &) {
         return fail(ctx, DE_ERR_HIP, "out of host memory");
     }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     {
         int rc = DE_OK;
         try { rc = make_threaded(ctx, p); } catch (const std::bad_alloc &) { rc = fail(ctx, DE_ERR_HIP, "out of host memory"); }
@@ -977,6 +1051,9 @@ static int ensure_generic_code(de_ctx *c, de_program *p) {
             bind_tree(p->code.data() + i0, (size_t)(i1 - i0), true, p->n_features, &p->gbcode);
             p->gbcode_off[(size_t)t + 1] = (int32_t)p->gbcode.size();
         }
+        match_const_sites(p->code, p->code_off, p->gbcode, p->gbcode_off, p->n_trees,
+                          [](const BoundInstr &b) { return bop_is_const_source(b.bop); }, &p->gbsite);
+        p->gtsite_of_gb.clear();
     }
     if (!p->d_gcode) {
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gcode), (p->gbcode.size() + 1) * sizeof(BoundInstr)));
@@ -1039,6 +1116,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         };
         p->gtcode.clear();
         p->gtcode_off.assign((size_t)p->n_trees + 1, 0);
+        p->gtsite_of_gb.assign(p->gbcode.size(), -1);
         bool ok = true;
         for (int64_t t = 0; t < p->n_trees && ok; t++) {
             const int bkt = bucket_of(ng[(size_t)t]);
@@ -1099,11 +1177,12 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                 } else ok = false; // INJ_*: only bound with early_exit=false, never for gradients
                 if (!ok) break;
                 o.bop = (uint32_t)(table[gop] - base);
+                p->gtsite_of_gb[(size_t)i] = (int32_t)p->gtcode.size();
                 p->gtcode.push_back(o);
             }
             p->gtcode_off[(size_t)t + 1] = (int32_t)p->gtcode.size();
         }
-        if (!ok) return DE_OK;
+        if (!ok) { p->gtsite_of_gb.clear(); return DE_OK; }
         std::vector<int32_t> ids((size_t)p->n_trees);
         int32_t start[8], run = 0;
         for (int b = 0; b < 8; b++) { start[b] = run; run += count[b]; }

@@ -113,6 +113,16 @@ constexpr uint32_t gop_tern(int GC) { return gop_gen_base(GC) + 5; }
 constexpr uint32_t gop_count(int GC) { return gop_gen_base(GC) + 6; }
 static_assert(gop_count(8) <= GOP_MAX, "GOP_MAX too small");
 
+// True when a (bound or fused) instruction carries a constant's bits in lo/hi.  Every generic
+// instruction with a constant operand becomes exactly one such instruction, in program order, in the
+// bound and in the fused stream — which is how de_program_set_consts patches immediates in place.
+inline bool top_carries_const(uint32_t top) {
+    if (top < BOP_COUNT) return bop_is_const_source(top);
+    if (top == TOP_LOADCONST_PUSH) return true;
+    if (top >= TOP_BIN2_BASE && top < TOP_COUNT) return (((top - TOP_BIN2_BASE) >> 2) & 1u) != 0;
+    return false;
+}
+
 // Fused form of one tree's bound instructions (appended to `out`).
 void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out);
 // True when the fused instruction's operand is an inline constant (arg carries no operand row).

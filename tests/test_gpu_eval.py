@@ -350,3 +350,66 @@ def test_constant_inner_branch_of_a_fused_kernel_is_not_constant_folded_for_the_
     _, ok = pop.eval(X)
     assert list(ok) == [True, True, False]
     pop.close()
+
+
+def test_set_constants_patches_every_derived_program_in_place(api):
+    """de_program_set_consts rewrites immediates inside the bound / fused / gradient instruction streams
+    (no re-lowering).  After several updates every entry point must be bit-identical to a population
+    created from scratch with the same constants — including folded constant subtrees, fused
+    two-operand forms, and the gradient programs built before the update."""
+    ops = de.OperatorEnum(binary_operators=("+", "-", "/", "*", "max"), unary_operators=("cos", "exp", "square", "safe_log"))
+    rng = de.synth.Xoshiro256ss(31)
+    trees = [de.synth.gen_random_tree_fixed_size(2 + i % 28, ops, 3, rng, np.float32) for i in range(300)]
+    X = de.synth.random_X(3, 700, seed=9)
+    y = np.cos(np.arange(700)).astype(np.float32)
+    pop = api.Population(trees, ops, np.float32, n_features=3)
+    pop.eval(X); pop.eval_grad(X, False); pop.eval_grad(X, "both"); pop.eval_loss_grad(X, y)  # build every derived program first
+    g = np.random.Generator(np.random.PCG64(1))
+    n_const = int(pop.n_consts.sum())
+
+    def bits(a):
+        return np.ascontiguousarray(np.asarray(a, dtype=np.float32)).view(np.uint32)
+
+    def same(a, b):  # NaN payloads/signs are not contractual
+        a, b = np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)
+        assert a.shape == b.shape
+        m = ~(np.isnan(a) & np.isnan(b))
+        np.testing.assert_array_equal(bits(a)[m], bits(b)[m])
+
+    def assign(n, it):  # constants in depth-first leaf order = the order of set_constants
+        if n.degree == 0:
+            if n.constant:
+                n.val = float(next(it))
+            return
+        for ch in n.children[:n.degree]:
+            assign(ch, it)
+
+    for step in range(3):
+        new = g.standard_normal(n_const).astype(np.float32)
+        if step == 2:
+            new[::17] = np.float32(np.inf)  # flags through the constant path too
+        pop.set_constants(new)
+        it = iter(new.tolist())
+        fresh = [t.copy() for t in trees]
+        for c in fresh:
+            assign(c, it)
+        ref = api.Population(fresh, ops, np.float32, n_features=3)
+        oa, ka = pop.eval(X); ob, kb = ref.eval(X)
+        assert np.array_equal(ka, kb) and ka.any()
+        same(oa[ka], ob[kb])
+        for variable in (False, "both"):
+            oa, ga, ka = pop.eval_grad(X, variable); ob, gb, kb = ref.eval_grad(X, variable)
+            assert np.array_equal(ka, kb)
+            same(oa[ka], ob[kb])
+            for t in np.nonzero(ka)[0]:
+                same(ga[t], gb[t])
+        la, da, ka = pop.eval_loss_grad(X, y); lb, db, kb = ref.eval_loss_grad(X, y)
+        assert np.array_equal(ka, kb)
+        same(la[ka], lb[kb])
+        for t in np.nonzero(ka)[0]:
+            same(da[t], db[t])
+        la, ka = pop.eval_loss(X, y); lb, kb = ref.eval_loss(X, y)
+        assert np.array_equal(ka, kb)
+        same(la[ka], lb[kb])
+        ref.close()
+    pop.close()
