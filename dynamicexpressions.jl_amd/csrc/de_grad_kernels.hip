@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
         // is validity-tested once, here; x was tested where the lowering kept a test (H_CHECK_OUT)
         if (a.check) {
             poison = M<T>::fma(x, T(0), poison);
-            DE_UNROLL for (int k = 0; k < GC; k++) poison = M<T>::fma(d[k], T(0), poison);
+            DE_UNROLL for (int k = 0; k < GC; k++) poison = M<T>::fma(g0 + k < G ? d[k] : T(0), T(0), poison); // real rows only
         }
         if (a.loss_mode) {
             const T e = x - yv;

@@ -323,7 +323,10 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
         // a non-finite d[k] always survives to the root (every update is linear in it), so the gradient
         // is validity-tested once, here; x was tested where the lowering kept a test (H_CHECK_OUT)
         T poison = M<T>::fma(st.x, T(0), st.poison);
-        DE_UNROLL for (int k = 0; k < GC; k++) poison = M<T>::fma(st.d[k], T(0), poison);
+        // only the components this tree really has: a window is as wide as its bucket, and a column beyond
+        // n_grad (the lone column of a tree without constants in constant mode) holds g*0 terms that are NaN
+        // for an infinite partial although the reference's gradient matrix has no such row
+        DE_UNROLL for (int k = 0; k < GC; k++) poison = M<T>::fma(g0 + k < G ? st.d[k] : T(0), T(0), poison);
         if (a.loss_mode) {
             const T e = st.x - yv;
             T lp, l;

@@ -235,3 +235,26 @@ def test_full_size_gradient_properties_config_C3(api):
         parts.append(pop.eval_grad(sl, True)[2])
     assert torch.equal(ok, parts[0] & parts[1] & parts[2] & parts[3])
     assert 50 < int(ok.sum()) < 1000
+
+
+def test_gradient_flag_ignores_columns_the_tree_does_not_have(api):
+    """A tree without constants has a 0-row gradient in constant mode: an infinite partial (d safe_sqrt / dx at 0)
+    must not clear `complete` through the window's unused column (found by tools/fuzz_grad.py)."""
+    ops = de.OperatorEnum(binary_operators=("max", "+"), unary_operators=("safe_sqrt", "relu", "square"))
+    t0 = de.Node(1, de.Node(1, de.Node(2, de.Node(feature=2))), de.Node(3, de.Node(feature=1)))  # max(safe_sqrt(relu(x2)), square(x1))
+    t1 = de.Node(2, t0.copy(), de.Node(val=0.5))  # same + one constant: the partial now meets a real column
+    for dtype in (np.float32, np.float64):
+        X = de.synth.random_X(2, 300, seed=3, dtype=dtype)  # x2 < 0 for about half of the samples
+        pop = api.Population([t0, t1], ops, dtype, n_features=2)
+        for mode_name in ("constant", "variable", "both"):
+            variable, omode = MODES[mode_name]
+            out, grads, ok = pop.eval_grad(X, variable)
+            for t, tree in enumerate((t0, t1)):
+                tape, consts = de.flatten(tree, ops, dtype)
+                _, g, ok_ref = oracle.eval_grad_tree_array(tape, consts, X, omode, elementwise=True)
+                assert bool(ok[t]) == ok_ref, (dtype.__name__, mode_name, t)
+                assert grads[t].shape == g.shape
+        assert pop.n_grad(0, 1) == 0
+        out, grads, ok = pop.eval_grad(X, False)
+        assert bool(ok[0])
+        pop.close()
