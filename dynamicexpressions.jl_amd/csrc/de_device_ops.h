@@ -149,10 +149,13 @@ template <bool SIN> __device__ __forceinline__ float fast_trig_f32(float x) {
 typedef float DeF2 __attribute__((ext_vector_type(2)));
 typedef unsigned DeU2 __attribute__((ext_vector_type(2)));
 #define DE_F2(c) (DeF2{(c), (c)})
-template <bool SIN> __device__ __forceinline__ DeF2 fast_trig_f32x2(DeF2 x) {
+// The two-element core: reduced argument r, its square z, sin(r) and the magic-add word (parity of n).
+struct DeTrig2 { DeF2 r, z, s, kk; };
+template <bool SIN> __device__ __forceinline__ DeTrig2 fast_trig_core_f32x2(DeF2 x) {
+    DeTrig2 o;
     const DeF2 t = SIN ? x * DE_F2(DE_TRIG_INV_PI) : __builtin_elementwise_fma(x, DE_F2(DE_TRIG_INV_PI), DE_F2(0.5f));
-    const DeF2 kk = t + DE_F2(DE_TRIG_MAGIC);
-    const DeF2 n = kk - DE_F2(DE_TRIG_MAGIC);
+    o.kk = t + DE_F2(DE_TRIG_MAGIC);
+    const DeF2 n = o.kk - DE_F2(DE_TRIG_MAGIC);
     const DeF2 m = SIN ? n : n - DE_F2(0.5f);
     DeF2 r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P1), x);
     r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P2), r);
@@ -162,13 +165,42 @@ template <bool SIN> __device__ __forceinline__ DeF2 fast_trig_f32x2(DeF2 x) {
     p = __builtin_elementwise_fma(z, p, DE_F2(DE_TRIG_S2));
     p = __builtin_elementwise_fma(z, p, DE_F2(DE_TRIG_S1));
     p = __builtin_elementwise_fma(z, p, DE_F2(DE_TRIG_S0));
-    DeF2 s = __builtin_elementwise_fma(r * z, p, r);
-#ifndef DE_TRIG_NO_EXTREMUM_FIX
-    s[0] = trig_extremum_fix(r[0], s[0]);
-    s[1] = trig_extremum_fix(r[1], s[1]);
-#endif
+    o.r = r;
+    o.z = z;
+    o.s = __builtin_elementwise_fma(r * z, p, r);
+    return o;
+}
+__device__ __forceinline__ DeF2 fast_trig_sign_f32x2(DeF2 s, DeF2 kk) {
     const DeU2 bits = __builtin_bit_cast(DeU2, s) ^ (__builtin_bit_cast(DeU2, kk) << 31);
     return __builtin_bit_cast(DeF2, bits);
+}
+// Stand-alone two-element version (per-element extremum select).
+template <bool SIN> __device__ __forceinline__ DeF2 fast_trig_f32x2(DeF2 x) {
+    DeTrig2 o = fast_trig_core_f32x2<SIN>(x);
+#ifndef DE_TRIG_NO_EXTREMUM_FIX
+    o.s[0] = trig_extremum_fix(o.r[0], o.s[0]);
+    o.s[1] = trig_extremum_fix(o.r[1], o.s[1]);
+#endif
+    return fast_trig_sign_f32x2(o.s, o.kk);
+}
+// Four elements with a wave-uniform short cut for the extremum select: |r| within 2^-12 of pi/2 means
+// r^2 within ~7.7e-4 of pi^2/4; the test on the already computed r^2 costs 1.5 VALU per element and the
+// select itself (4 per element) runs only in the ~4 % of wavefronts where some lane is that close.
+template <bool SIN> __device__ __forceinline__ void fast_trig_f32x4(const float (&x)[4], float (&y)[4]) {
+    DeTrig2 a = fast_trig_core_f32x2<SIN>(DeF2{x[0], x[1]}), b = fast_trig_core_f32x2<SIN>(DeF2{x[2], x[3]});
+#ifndef DE_TRIG_NO_EXTREMUM_FIX
+    const DeF2 da = a.z - DE_F2(0x1.3bd3ccp+1f), db = b.z - DE_F2(0x1.3bd3ccp+1f); // pi^2/4
+    const bool near = (__builtin_fabsf(da[0]) < 8.0e-4f) | (__builtin_fabsf(da[1]) < 8.0e-4f) |
+                      (__builtin_fabsf(db[0]) < 8.0e-4f) | (__builtin_fabsf(db[1]) < 8.0e-4f);
+    if (__ballot(near) != 0ull) {
+        a.s[0] = trig_extremum_fix(a.r[0], a.s[0]);
+        a.s[1] = trig_extremum_fix(a.r[1], a.s[1]);
+        b.s[0] = trig_extremum_fix(b.r[0], b.s[0]);
+        b.s[1] = trig_extremum_fix(b.r[1], b.s[1]);
+    }
+#endif
+    const DeF2 ya = fast_trig_sign_f32x2(a.s, a.kk), yb = fast_trig_sign_f32x2(b.s, b.kk);
+    y[0] = ya[0]; y[1] = ya[1]; y[2] = yb[0]; y[3] = yb[1];
 }
 // sin and cos of the same argument (value + derivative of cos/sin in the gradient kernel):
 // one reduction, both polynomials, two quadrant selects.  Same accuracy as fast_trig_f32.

@@ -583,8 +583,11 @@ template <typename T, int K> __device__ __forceinline__ typename VecOf<T>::type 
             const DeF2 a = fast_exp_f32x2(lo), b = fast_exp_f32x2(hi);
             r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
         } else {
-            const DeF2 a = fast_trig_f32x2<K == 2>(lo), b = fast_trig_f32x2<K == 2>(hi);
-            r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
+            (void)lo; (void)hi;
+            const float xi[4] = {x[0], x[1], x[2], x[3]};
+            float yo[4];
+            fast_trig_f32x4<K == 2>(xi, yo);
+            r[0] = yo[0]; r[1] = yo[1]; r[2] = yo[2]; r[3] = yo[3];
             // max ignores NaN (which the fast path already propagates); Inf and |x| > 1e5 take the slow path
             const float mx = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
             if (__ballot(mx > DE_TRIG_FAST_BOUND) != 0ull) { // inline: a call here would turn every handler into a non-leaf function

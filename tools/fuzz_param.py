@@ -1,0 +1,54 @@
+"""Differential fuzz of the ParametricExpression path (eval, gradients, fused loss) — flags must equal the
+oracle's (reference reduction: gather parameters above X, src/ParametricExpression.jl:381-389)."""
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+import dynamicexpressions_jl_amd as de
+from dynamicexpressions_jl_amd import api
+from oracle import oracle
+from helpers import parity_tolerance
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+ops_wide = de.OperatorEnum(binary_operators=("+", "-", "/", "*", "max", "pow_abs2"),
+                           unary_operators=("cos", "exp", "safe_log", "square", "abs", "tanh", "safe_sqrt"))
+bad = 0
+for rep in range(4):
+    rng = de.synth.Xoshiro256ss(seed0 * 77 + rep)
+    for ops in (de.synth.BENCH_OPERATORS, ops_wide):
+        for dtype in (np.float32, np.float64):
+            P, F = 1 + rep % 3 * 3, 2 + rep
+            trees = [de.synth.gen_random_tree_fixed_size(1 + (i * 3 + rep) % 27, ops, F, rng, dtype, de.ParametricNode, P) for i in range(200)]
+            g = np.random.Generator(np.random.PCG64(seed0 * 10 + rep))
+            N, C = int(g.integers(1, 1300)), int(g.integers(1, 9))
+            X = np.asfortranarray(g.standard_normal((F, N)).astype(dtype))
+            params = np.asfortranarray((g.standard_normal((P, C)) * 2).astype(dtype))
+            classes = g.integers(1, C + 1, N).astype(np.int64)
+            for ec in (api.EvalContext(), api.EvalContext(early_exit=False), api.EvalContext(use_fused=False)):
+                opts = ec.option_bits(ops)
+                pop = api.Population(trees, ops, dtype, n_features=F, n_params=P, eval_context=ec)
+                out, ok = pop.eval(X, params, classes)
+                grads = {m: pop.eval_grad(X, v, params, classes) for m, v in (("constant", False), ("both", "both"), ("variable", True))}
+                for t, tree in enumerate(trees):
+                    tape, consts = de.flatten(tree, ops, dtype)
+                    y, ok_el = oracle.eval_tree_array_parametric(tape, consts, X, params, classes.astype(np.int32), 1, opts, elementwise=True)
+                    if bool(ok[t]) != ok_el:
+                        print("EVAL FLAG", dtype.__name__, opts, de.string_tree(tree, ops)[:140], bool(ok[t]), ok_el); bad += 1; continue
+                    if ok_el:
+                        tol = parity_tolerance(tree, ops, X, dtype, opts, params, classes - 1)
+                        m = np.isfinite(y) & np.isfinite(out[t])
+                        if np.any(np.abs(out[t][m].astype(np.float64) - y[m]) > tol[m]):
+                            print("EVAL VALUE", dtype.__name__, opts, de.string_tree(tree, ops)[:140]); bad += 1
+                    t2, PX = oracle.parametric_to_plain(tape, X, params, classes)
+                    for m_, om in (("constant", oracle.GRAD_CONSTANT), ("both", oracle.GRAD_BOTH), ("variable", oracle.GRAD_VARIABLE)):
+                        yg, gg, okg = oracle.eval_grad_tree_array(t2, consts, PX, om, elementwise=True)
+                        og, gr, okk = grads[m_]
+                        if bool(okk[t]) != okg:
+                            print("GRAD FLAG", m_, dtype.__name__, de.string_tree(tree, ops)[:140], bool(okk[t]), okg); bad += 1
+                        elif okg and gg.size:
+                            if gr[t].shape != gg.shape:
+                                print("GRAD SHAPE", m_, gr[t].shape, gg.shape); bad += 1; continue
+                            rel = np.abs(np.asarray(gr[t], dtype=np.float64) - gg) / (np.abs(gg) + 1e-30)
+                            if np.median(rel) > (1e-3 if dtype == np.float32 else 1e-9):
+                                print("GRAD VALUE", m_, dtype.__name__, de.string_tree(tree, ops)[:140], np.median(rel)); bad += 1
+                pop.close()
+            print("done", rep, dtype.__name__, P, F, N, C, flush=True)
+print("param fuzz finished, findings:", bad)
