@@ -240,17 +240,17 @@ __device__ __forceinline__ float fast_exp_f32(float x) {
 
 // Two elements at a time (v_pk_mul/v_pk_fma for the reduction; exp2/ldexp/rint stay per element).
 __device__ __forceinline__ DeF2 fast_exp_f32x2(DeF2 x) {
-    // med3 also absorbs NaN (patched back in at the end), so no separate canonicalisation
-    const DeF2 xc = {__builtin_amdgcn_fmed3f(x[0], -105.0f, 89.0f), __builtin_amdgcn_fmed3f(x[1], -105.0f, 89.0f)};
-    const DeF2 t = xc * DE_F2(0x1.715476p+0f);
-    const DeF2 k = {__builtin_rintf(t[0]), __builtin_rintf(t[1])};
-    DeF2 r = __builtin_elementwise_fma(xc, DE_F2(0x1.715476p+0f), -k);
-    r = __builtin_elementwise_fma(xc, DE_F2(0x1.4ae0c0p-26f), r);
+    // Only the integer part k is clamped (to the ldexp range): x itself stays as it is, so NaN flows through
+    // the FMAs, +-Inf and huge arguments give r = +-Inf / far outside [-1/2, 1/2] exactly where the result is
+    // Inf or 0 anyway, and no NaN fix-up select is needed (2 VALU per element less than clamping x).
+    const DeF2 t = x * DE_F2(0x1.715476p+0f);
+    const DeF2 k = {__builtin_amdgcn_fmed3f(__builtin_rintf(t[0]), -152.0f, 130.0f),
+                    __builtin_amdgcn_fmed3f(__builtin_rintf(t[1]), -152.0f, 130.0f)};
+    DeF2 r = __builtin_elementwise_fma(x, DE_F2(0x1.715476p+0f), -k);
+    r = __builtin_elementwise_fma(x, DE_F2(0x1.4ae0c0p-26f), r);
     DeF2 y;
     y[0] = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(r[0]), (int)k[0]);
     y[1] = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(r[1]), (int)k[1]);
-    y[0] = x[0] != x[0] ? x[0] : y[0];
-    y[1] = x[1] != x[1] ? x[1] : y[1];
     return y;
 }
 
