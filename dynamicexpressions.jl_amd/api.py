@@ -384,16 +384,19 @@ class Population:
                 classes = classes.to(torch.int64)
             classes = classes.contiguous()
             n_c, mx = classes.numel(), int(classes.max().item()) if classes.numel() else class_base
+            mn = int(classes.min().item()) if classes.numel() else class_base
             pa.classes, pa.classes_is_i64 = classes.data_ptr(), int(classes.dtype == torch.int64)
         else:
             classes = np.ascontiguousarray(classes)
             if classes.dtype not in (np.int32, np.int64):
                 classes = classes.astype(np.int64)
             n_c, mx = classes.size, int(classes.max()) if classes.size else class_base
+            mn = int(classes.min()) if classes.size else class_base
             pa.classes, pa.classes_is_i64 = classes.ctypes.data, int(classes.dtype == np.int64)
         # @assert length(classes) == size(X, 2); @assert maximum(classes) <= n_classes  (:378-379)
         assert n_c == N, "length(classes) == size(X, 2)"
         assert mx - class_base < ncls, "maximum(classes) <= size(parameters, 2)"
+        assert mn >= class_base, "class ids start at class_base"
         pa.n_classes, pa.class_base = ncls, class_base
         keep.extend([params, classes])
         return pa

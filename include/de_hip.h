@@ -187,7 +187,10 @@ int64_t de_lower_tape_stage(int dtype, const de_tape_node_t *nodes, int64_t n_no
 /* ---- evaluation ------------------------------------------------------------ */
 /* Optional per-call inputs of a parametric population
  * (src/ParametricExpression.jl:371-390): value of PARAM leaf p at sample j is
- * params[p + ld_params*(classes[j]-class_base)]. */
+ * params[p + ld_params*(classes[j]-class_base)].  Every class id must lie in
+ * [class_base, class_base + n_classes): the reference asserts this on the host
+ * (`@assert maximum(classes) <= size(parameters, 2)`, :378-379) and so must the caller's shim —
+ * the kernels index `params` with the ids as given. */
 typedef struct de_param_args {
     const void *params;     /* [n_params, n_classes] column-major, dtype elements */
     int64_t ld_params;      /* >= n_params                                          */
