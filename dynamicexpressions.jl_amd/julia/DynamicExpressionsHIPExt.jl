@@ -195,6 +195,41 @@ function eval_population(pop::HIPPopulation{T}, X::Matrix{T}) where {T}
     return out, ok .!= 0x00
 end
 
+struct ParamArgs            # de_param_args_t
+    params::Ptr{Cvoid}
+    ld_params::Int64
+    n_classes::Int64
+    classes::Ptr{Cvoid}
+    classes_is_i64::Int32
+    class_base::Int32
+end
+
+"""
+    eval_population(pop, X, parameters, classes) -> (out, ok)
+
+ParametricExpression form (src/ParametricExpression.jl:371-390): `parameters` is the `P × C` matrix,
+`classes::Vector{Int}` the 1-based class of every column of `X`; the `P × N` gather the reference
+materialises is done on the fly in the kernel.  The range assertions of the reference (:378-379) are
+repeated here because the library trusts the ids.
+"""
+function eval_population(
+    pop::HIPPopulation{T}, X::Matrix{T}, parameters::Matrix{T}, classes::Vector{Int}
+) where {T}
+    F, N = size(X)
+    @assert length(classes) == N
+    @assert isempty(classes) || (minimum(classes) >= 1 && maximum(classes) <= size(parameters, 2))
+    out = Matrix{T}(undef, N, pop.n_trees)
+    ok = Vector{UInt8}(undef, pop.n_trees)
+    rc = GC.@preserve X parameters classes out ok begin
+        pa = Ref(ParamArgs(pointer(parameters), size(parameters, 1), size(parameters, 2), pointer(classes), 1, 1))
+        ccall((:de_eval, LIBDE), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ref{ParamArgs}, Ptr{Cvoid}, Int64, Ptr{UInt8}),
+            pop.ctx.handle, pop.handle, X, N, F, pa, out, N, ok)
+    end
+    check(pop.ctx, rc)
+    return out, ok .!= 0x00
+end
+
 """
     eval_population_loss(pop, X, y; weights=nothing, loss=:L2) -> (loss::Vector{T}, ok)
 
