@@ -174,15 +174,6 @@ __device__ __forceinline__ DeF2 fast_trig_sign_f32x2(DeF2 s, DeF2 kk) {
     const DeU2 bits = __builtin_bit_cast(DeU2, s) ^ (__builtin_bit_cast(DeU2, kk) << 31);
     return __builtin_bit_cast(DeF2, bits);
 }
-// Stand-alone two-element version (per-element extremum select).
-template <bool SIN> __device__ __forceinline__ DeF2 fast_trig_f32x2(DeF2 x) {
-    DeTrig2 o = fast_trig_core_f32x2<SIN>(x);
-#ifndef DE_TRIG_NO_EXTREMUM_FIX
-    o.s[0] = trig_extremum_fix(o.r[0], o.s[0]);
-    o.s[1] = trig_extremum_fix(o.r[1], o.s[1]);
-#endif
-    return fast_trig_sign_f32x2(o.s, o.kk);
-}
 // Four elements with a wave-uniform short cut for the extremum select: |r| within 2^-12 of pi/2 means
 // r^2 within ~7.7e-4 of pi^2/4; the test on the already computed r^2 costs 1.5 VALU per element and the
 // select itself (4 per element) runs only in the ~4 % of wavefronts where some lane is that close.

@@ -578,12 +578,10 @@ template <typename T, int K> __device__ __forceinline__ typename VecOf<T>::type 
     constexpr int VW = VecOf<T>::W;
     V r;
     if constexpr (sizeof(T) == 4) {
-        const DeF2 lo = {x[0], x[1]}, hi = {x[2], x[3]};
         if constexpr (K == 1) {
-            const DeF2 a = fast_exp_f32x2(lo), b = fast_exp_f32x2(hi);
+            const DeF2 a = fast_exp_f32x2(DeF2{x[0], x[1]}), b = fast_exp_f32x2(DeF2{x[2], x[3]});
             r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
         } else {
-            (void)lo; (void)hi;
             const float xi[4] = {x[0], x[1], x[2], x[3]};
             float yo[4];
             fast_trig_f32x4<K == 2>(xi, yo);
