@@ -1,0 +1,62 @@
+"""CPU test of csrc/irpatch.py (the build-time IR pass that marks the interpreter's indirect handler calls as
+needing no implicit kernel inputs): attributes are added to the indirect calls only, and only those that
+EVERY possible callee already carries."""
+import importlib.util
+import os
+import re
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SPEC = importlib.util.spec_from_file_location(
+    "irpatch", os.path.join(HERE, "..", "dynamicexpressions.jl_amd", "csrc", "irpatch.py"))
+irpatch = importlib.util.module_from_spec(SPEC)
+SPEC.loader.exec_module(irpatch)
+
+IR = '''
+%"struct.de::HState" = type { <4 x float>, <2 x float>, [8 x i8] }
+define internal %"struct.de::HState" @h_a(<4 x float> %0, i32 %1) #0 {
+  ret %"struct.de::HState" undef
+}
+define internal %"struct.de::HState" @h_b(<4 x float> %0, i32 %1) #1 {
+  ret %"struct.de::HState" undef
+}
+define void @other(i32 %x) #2 {
+  ret void
+}
+define protected amdgpu_kernel void @kern(ptr %fn) #2 {
+  %r = tail call %"struct.de::HState" %fn(<4 x float> zeroinitializer, i32 0) #3
+  %d = tail call %"struct.de::HState" @h_a(<4 x float> zeroinitializer, i32 0) #3
+  ret void
+}
+attributes #0 = { nounwind "amdgpu-no-dispatch-ptr" "amdgpu-no-queue-ptr" "amdgpu-no-workitem-id-x" }
+attributes #1 = { nounwind "amdgpu-no-dispatch-ptr" "amdgpu-no-workitem-id-x" }
+attributes #2 = { nounwind }
+attributes #3 = { convergent nounwind }
+'''
+
+
+def test_only_indirect_handler_calls_get_the_attributes_all_callees_share(tmp_path):
+    src, dst = tmp_path / "k.ll", tmp_path / "k2.ll"
+    src.write_text(IR)
+    irpatch.main(str(src), str(dst))
+    out = dst.read_text()
+    ind = re.search(r'%r = tail call [^\n]* %fn\([^\n]*\) #(\d+)', out)
+    direct = re.search(r'%d = tail call [^\n]* @h_a\([^\n]*\) #(\d+)', out)
+    assert ind and direct
+    assert direct.group(1) == "3"  # the direct call keeps its group
+    new_group = re.search(r'^attributes #%s = \{(.*)\}$' % ind.group(1), out, re.M).group(1)
+    assert ind.group(1) != "3" and "convergent" in new_group
+    assert '"amdgpu-no-dispatch-ptr"' in new_group and '"amdgpu-no-workitem-id-x"' in new_group
+    assert '"amdgpu-no-queue-ptr"' not in new_group  # h_b does not carry it
+    assert '"amdgpu-no-implicitarg-ptr"' not in new_group  # nobody carries it
+
+
+def test_refuses_a_module_without_handlers_or_without_indirect_calls(tmp_path):
+    src, dst = tmp_path / "k.ll", tmp_path / "k2.ll"
+    src.write_text("define void @f() #0 {\n  ret void\n}\nattributes #0 = { nounwind }\n")
+    with pytest.raises(SystemExit):
+        irpatch.main(str(src), str(dst))
+    src.write_text(IR.replace('%r = tail call %"struct.de::HState" %fn(<4 x float> zeroinitializer, i32 0) #3\n', ''))
+    with pytest.raises(SystemExit):
+        irpatch.main(str(src), str(dst))
