@@ -101,6 +101,7 @@ struct de_program {
     BoundInstr *d_gtcode = nullptr;
     int32_t *d_gtcode_off = nullptr;
     int32_t *d_gt_ids = nullptr;        // tree indices grouped by bucket
+    uint8_t *d_ok_eval = nullptr;       // device copy of host_ok_eval (initial value of the flags of every eval call)
     // immediate sites (set_consts patches constants in place): for a generic instruction with a constant
     // operand, the index of the instruction carrying its bits in bcode / tcode (eval source program) and in
     // gbcode / gtcode (unfolded program); -1 elsewhere.  Empty = not available (full rebuild instead).
@@ -418,6 +419,16 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                        int64_t n_trees, const void *consts, const int64_t *const_offsets, int32_t n_features,
                        int32_t n_params, uint32_t options, bool allow_fold, de_program_t **out_program);
 
+// Device copy of the host part of the eval flag: every de_eval starts from it with one device-to-device copy
+// (a pageable host-to-device copy per call costs ~10 us, a fifth of a small-population call).
+static int upload_ok_eval(de_ctx *c, de_program *p) {
+    if (p->n_trees == 0) return DE_OK;
+    if (!p->d_ok_eval) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_ok_eval), (size_t)p->n_trees));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(p->d_ok_eval, p->host_ok_eval.data(), (size_t)p->n_trees, hipMemcpyHostToDevice));
+    return DE_OK;
+}
+
 // (Re-)evaluate the folded constant subtrees on the device and patch their values into fcode.
 static int refresh_folds(de_ctx *c, de_program *p) {
     if (!p->folded) return DE_OK;
@@ -625,6 +636,10 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         (void)hipFree(p->d_code_off);
         return fail(ctx, DE_ERR_HIP, "program upload failed: %s", hipGetErrorString(st));
     }
+    {
+        const int rc = upload_ok_eval(ctx, p.get());
+        if (rc != DE_OK) return rc; // (~de_program is not run on this path: the process is out of device memory anyway)
+    }
     *out_program = p.release();
     return DE_OK;
 }
@@ -647,6 +662,10 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
     }
     recompute_host_ok(p);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    {
+        const int rc = upload_ok_eval(ctx, p);
+        if (rc != DE_OK) return rc;
+    }
     // Same tree shapes, new immediates: patch the bits where they live (the optimiser calls this once per
     // step — re-binding 10^4 trees costs milliseconds, the kernel it feeds a few hundred microseconds).
     const char *nopatch = getenv("DE_NO_CONST_PATCH");
@@ -720,6 +739,7 @@ int de_program_destroy(de_program_t *p) {
     if (p->d_gtcode) (void)hipFree(p->d_gtcode);
     if (p->d_gtcode_off) (void)hipFree(p->d_gtcode_off);
     if (p->d_gt_ids) (void)hipFree(p->d_gt_ids);
+    if (p->d_ok_eval) (void)hipFree(p->d_ok_eval);
     delete p;
     return DE_OK;
 }
@@ -971,7 +991,8 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
         sOk.dev = c->sOk.p;
         sOk.staged = true;
     }
-    HIP_TRY(c, hipMemcpyAsync(sOk.dev, p->host_ok_eval.data(), (size_t)p->n_trees, hipMemcpyHostToDevice, c->stream));
+    if (p->d_ok_eval) HIP_TRY(c, hipMemcpyAsync(sOk.dev, p->d_ok_eval, (size_t)p->n_trees, hipMemcpyDeviceToDevice, c->stream));
+    else HIP_TRY(c, hipMemcpyAsync(sOk.dev, p->host_ok_eval.data(), (size_t)p->n_trees, hipMemcpyHostToDevice, c->stream));
     if (p->uses_params) {
         rc = stage_in(c, c->sParams, pa->params, (size_t)pa->ld_params * (size_t)pa->n_classes * es, &sPar);
         if (rc) return rc;
