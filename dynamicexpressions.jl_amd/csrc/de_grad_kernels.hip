@@ -130,11 +130,15 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
         UG<T> r;                                                                                   \
         if (sizeof(T) == 4) {                                                                      \
             if (K == 1) { r.y = (T)fast_exp_f32((float)xin_); r.g = r.y; }                         \
-            else if (__ballot(M<T>::abs(xin_) > T(DE_TRIG_FAST_BOUND)) != 0ull) r = unary_vg<T>(K == 0 ? DE_U_COS : DE_U_SIN, xin_); \
             else {                                                                                 \
                 float sn, cs;                                                                      \
                 fast_sincos_f32((float)xin_, &sn, &cs);                                            \
                 if (K == 0) { r.y = (T)cs; r.g = (T)-sn; } else { r.y = (T)sn; r.g = (T)cs; }      \
+                /* per ELEMENT: a sample's value must not depend on its wave neighbours */         \
+                if (__ballot(M<T>::abs(xin_) > T(DE_TRIG_FAST_BOUND)) != 0ull) {                   \
+                    const UG<T> slow = unary_vg<T>(K == 0 ? DE_U_COS : DE_U_SIN, xin_);            \
+                    if (M<T>::abs(xin_) > T(DE_TRIG_FAST_BOUND)) r = slow;                         \
+                }                                                                                  \
             }                                                                                      \
         } else r = unary_vg<T>(K == 0 ? DE_U_COS : (K == 1 ? DE_U_EXP : DE_U_SIN), xin_);          \
         x = r.y;                                                                                   \

@@ -136,14 +136,18 @@ template <typename T, int GC, int K, int SRC, int SV, bool CHK> __device__ __noi
     UG<T> r;
     if constexpr (sizeof(T) == 4) {
         if constexpr (K == 1) { r.y = (T)fast_exp_f32((float)b.x); r.g = r.y; }
-        else if (__ballot(M<T>::abs(b.x) > T(DE_TRIG_FAST_BOUND)) != 0ull) {
-            // inline OCML (a call would make this handler a non-leaf function)
-            const float sn = sinf((float)b.x), cs = cosf((float)b.x);
-            if constexpr (K == 0) { r.y = (T)cs; r.g = (T)-sn; } else { r.y = (T)sn; r.g = (T)cs; }
-        } else {
+        else {
             float sn, cs;
             fast_sincos_f32((float)b.x, &sn, &cs);
             if constexpr (K == 0) { r.y = (T)cs; r.g = (T)-sn; } else { r.y = (T)sn; r.g = (T)cs; }
+            // |x| > 1e5: OCML's full-range functions, per ELEMENT — a sample's value must not depend on its wave
+            // neighbours (inline: a call would make this handler a non-leaf function)
+            if (__ballot(M<T>::abs(b.x) > T(DE_TRIG_FAST_BOUND)) != 0ull) {
+                if (M<T>::abs(b.x) > T(DE_TRIG_FAST_BOUND)) {
+                    const float sn2 = sinf((float)b.x), cs2 = cosf((float)b.x);
+                    if constexpr (K == 0) { r.y = (T)cs2; r.g = (T)-sn2; } else { r.y = (T)sn2; r.g = (T)cs2; }
+                }
+            }
         }
     } else {
         if constexpr (K == 0) { r.y = M<T>::cos(b.x); r.g = -M<T>::sin(b.x); }
