@@ -33,12 +33,14 @@ def gather_flags(local_ok, n_trees: int, rank: int, world: int):
     if world == 1:
         return local_ok
     per = (n_trees + world - 1) // world  # padded shard length so all_gather shapes match
-    buf = torch.ones(per, dtype=torch.uint8, device=local_ok.device)
-    buf[: local_ok.numel()] = local_ok.to(torch.uint8)
-    gathered = torch.empty(world * per, dtype=torch.uint8, device=local_ok.device)
+    # gloo (CPU tests, and the 1-GPU dry run of bench.py's multi-rank path) gathers host tensors
+    dev = local_ok.device if dist.get_backend() != "gloo" else torch.device("cpu")
+    buf = torch.ones(per, dtype=torch.uint8, device=dev)
+    buf[: local_ok.numel()] = local_ok.to(torch.uint8).to(dev)
+    gathered = torch.empty(world * per, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(gathered, buf)
     # rank r holds trees r, r+world, ...: entry [r, i] is tree r + i*world
-    return gathered.view(world, per).t().reshape(-1)[:n_trees]
+    return gathered.view(world, per).t().reshape(-1)[:n_trees].to(local_ok.device)
 
 
 def scatter_population(trees, rank: int, world: int):
