@@ -40,11 +40,13 @@ build_kernels() { # src obj [extra flags...]
 build_kernels de_kernels.hip _obj/de_kernels.o &
 # the threaded gradient kernel: one module per (element type, window width), see de_grad_threaded.hip
 GT_OBJS=""
-for spec in f:float:1 f:float:2 f:float:3 f:float:4 f:float:5 f:float:6 f:float:8 d:double:1 d:double:2 d:double:3 d:double:4 d:double:5; do
-  IFS=: read tag ty gc <<< "$spec"
-  GT_OBJS="$GT_OBJS _obj/de_gt_$tag$gc.o"
+for spec in f:float:1:1 f:float:2:1 f:float:3:1 f:float:4:1 f:float:5:1 f:float:6:1 f:float:8:1 \
+            f:float:1:2 f:float:2:2 f:float:3:2 f:float:4:2 f:float:5:2 f:float:6:2 \
+            d:double:1:1 d:double:2:1 d:double:3:1 d:double:4:1 d:double:5:1; do  # = DE_GT_ALL in de_grad_kernels.hip
+  IFS=: read tag ty gc vs <<< "$spec"
+  GT_OBJS="$GT_OBJS _obj/de_gt_$tag${gc}v$vs.o"
   while [ "$(jobs -r | wc -l)" -ge "${DE_BUILD_JOBS:-8}" ]; do sleep 0.2; done
-  build_kernels de_grad_threaded.hip _obj/de_gt_$tag$gc.o -DDE_GT_T=$ty -DDE_GT_TAG=$tag -DDE_GT_GC=$gc &
+  build_kernels de_grad_threaded.hip _obj/de_gt_$tag${gc}v$vs.o -DDE_GT_T=$ty -DDE_GT_TAG=$tag -DDE_GT_GC=$gc -DDE_GT_VS=$vs &
 done
 build_obj de_grad_kernels.hip _obj/de_grad_kernels.o &
 wait

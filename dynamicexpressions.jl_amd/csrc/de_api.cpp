@@ -9,6 +9,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <array>
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -109,7 +110,7 @@ struct de_program {
     int gt_mode = -1;
     bool gt_valid = false;
     int gt_n_buckets = 0;
-    GradArgs::Bucket gt_buckets[8];
+    GradArgs::Bucket gt_buckets[16];
 };
 
 static int fail(de_ctx *c, int code, const char *fmt, ...) {
@@ -1104,26 +1105,54 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
     if (env && *env == '0') return DE_OK;
     const int F = p->n_features, P = p->n_params;
     if (!(p->gt_valid && p->gt_mode == mode)) {
-        // bucket of a tree: index 0..6 = single window of width 1,2,3,4,5,6,8; 7 = several windows of 8
+        // bucket of a tree: (width index 0..6 = single window of width 1,2,3,4,5,6,8; 7 = several windows of 8)
+        // x (samples per lane - 1).  The two-sample modules exist for Float32 windows <= 6; their rows are
+        // twice as long, so they only pay while a workgroup's LDS stays small: trees with <= 1 spill slot.
         static const int WIDTH[8] = {1, 2, 3, 4, 5, 6, 8, 8};
-        auto bucket_of = [](int32_t G) { return G <= 6 ? (G < 1 ? 0 : G - 1) : (G <= 8 ? 6 : 7); };
-        int32_t count[8] = {0}, maxg[8] = {0};
+        constexpr int NB = 16;
+        const char *env2 = getenv("DE_GRAD_VS2_SLOTS"); // widest spill need that still runs two samples per lane
+        const int vs2_slots = env2 ? atoi(env2) : 1;
+        std::vector<int32_t> tslots((size_t)p->n_trees, 0); // spill slots of each tree (rows >= F the code names)
+        for (int64_t t = 0; t < p->n_trees; t++) {
+            int32_t need = 0;
+            for (int32_t i = p->gbcode_off[(size_t)t]; i < p->gbcode_off[(size_t)t + 1]; i++) {
+                const BoundInstr &b = p->gbcode[(size_t)i];
+                const uint32_t row = b.arg & 0xFFFFFFu;
+                const bool names_row = b.bop == BOP_PUSH || b.bop == BOP_LOAD_ROW || b.bop == BOP_GEN_ROW || b.bop == BOP_TERN ||
+                                       (b.bop >= BOP_BIN_BASE && b.bop < BOP_BIN_END && !((b.bop - BOP_BIN_BASE) & 2)) ||
+                                       (b.bop >= BOP_UN_BASE && b.bop < BOP_UN_END && ((b.bop - BOP_UN_BASE) & 2));
+                if (names_row && row >= (uint32_t)F) need = std::max(need, (int32_t)(row - (uint32_t)F) + 1);
+                if (b.bop == BOP_TERN && b.lo >= (uint32_t)F) need = std::max(need, (int32_t)(b.lo - (uint32_t)F) + 1);
+            }
+            tslots[(size_t)t] = need;
+        }
+        auto bucket_of = [&](int64_t t) {
+            const int32_t G = ng[(size_t)t];
+            const int w = G <= 6 ? (G < 1 ? 0 : G - 1) : (G <= 8 ? 6 : 7);
+            const bool two = p->dtype == DE_F32 && w <= 5 && tslots[(size_t)t] <= vs2_slots && grad_threaded_has(p->dtype, WIDTH[w], 2);
+            return w + (two ? 8 : 0);
+        };
+        int32_t count[NB] = {0}, maxg[NB] = {0}, slots[NB] = {0};
         for (int64_t t = 0; t < p->n_trees; t++) {
             const int32_t G = ng[(size_t)t];
             if (G > 240) return DE_OK; // gradient rows travel in 8 bits
-            const int b = bucket_of(G);
+            const int b = bucket_of(t);
             // Float64 states wider than 16 dwords are passed through scratch memory by the calling convention
-            if (p->dtype == DE_F64 && WIDTH[b] > 5) return DE_OK;
+            if (!grad_threaded_has(p->dtype, WIDTH[b & 7], 1 + (b >> 3))) return DE_OK;
             count[b]++;
             maxg[b] = std::max(maxg[b], G);
+            slots[b] = std::max(slots[b], tslots[(size_t)t]);
         }
-        const uint32_t RB = (uint32_t)(260 * (p->dtype == DE_F32 ? 4 : 8)); // row bytes: (GBLK + 4) elements
-        uint64_t tables[8][GOP_MAX], bases[8] = {0};
-        for (int b = 0; b < 8; b++) {
+        const uint32_t es32 = p->dtype == DE_F32 ? 4u : 8u;
+        std::vector<std::array<uint64_t, GOP_MAX>> tables(NB);
+        uint64_t bases[NB] = {0};
+        for (int b = 0; b < NB; b++) {
             if (!count[b]) continue;
-            const int GC = WIDTH[b];
-            if (((uint64_t)F + (uint64_t)p->n_slots * (1 + GC)) * RB >= (1u << 24)) return DE_OK;
-            hipError_t st = grad_handler_table(p->dtype, GC, tables[b]);
+            const int GC = WIDTH[b & 7], VS = 1 + (b >> 3);
+            const uint64_t RBb = 64ull * VS * es32; // one wave's row
+            const uint64_t rows = (uint64_t)F + std::max<uint64_t>((uint64_t)slots[b] * (1 + GC), (uint64_t)GC);
+            if (4 * rows * RBb > 160 * 1024) return DE_OK; // four waves' rows must fit the CU's LDS
+            hipError_t st = grad_handler_table(p->dtype, GC, VS, tables[b].data());
             if (st != hipSuccess) return fail(c, DE_ERR_HIP, "gradient handler table: %s", hipGetErrorString(st));
             uint64_t base = tables[b][0];
             for (int i = 0; i < (int)gop_count(GC); i++) base = std::min<uint64_t>(base, tables[b][i]);
@@ -1140,10 +1169,11 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         p->gtsite_of_gb.assign(p->gbcode.size(), -1);
         bool ok = true;
         for (int64_t t = 0; t < p->n_trees && ok; t++) {
-            const int bkt = bucket_of(ng[(size_t)t]);
-            const int GC = WIDTH[bkt];
-            const bool one_window = bkt != 7; // then g0 = 0 and every seed is known here
-            const uint64_t *table = tables[bkt];
+            const int bkt = bucket_of(t);
+            const int GC = WIDTH[bkt & 7];
+            const uint32_t RB = 64u * (uint32_t)(1 + (bkt >> 3)) * es32; // bytes of one wave's row
+            const bool one_window = (bkt & 7) != 7; // then g0 = 0 and every seed is known here
+            const uint64_t *table = tables[bkt].data();
             const uint64_t base = bases[bkt];
             auto slot_off = [&](uint32_t row) { return (uint32_t)((F + (row - (uint32_t)F) * (1 + GC)) * RB); };
             // seed variant of a handler (de_bind.h): 0 run-time, 1 none, 2 + k
@@ -1205,12 +1235,12 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         }
         if (!ok) { p->gtsite_of_gb.clear(); return DE_OK; }
         std::vector<int32_t> ids((size_t)p->n_trees);
-        int32_t start[8], run = 0;
-        for (int b = 0; b < 8; b++) { start[b] = run; run += count[b]; }
+        int32_t start[NB], run = 0;
+        for (int b = 0; b < NB; b++) { start[b] = run; run += count[b]; }
         {
-            int32_t fill[8];
-            for (int b = 0; b < 8; b++) fill[b] = start[b];
-            for (int64_t t = 0; t < p->n_trees; t++) ids[(size_t)fill[bucket_of(ng[(size_t)t])]++] = (int32_t)t;
+            int32_t fill[NB];
+            for (int b = 0; b < NB; b++) fill[b] = start[b];
+            for (int64_t t = 0; t < p->n_trees; t++) ids[(size_t)fill[bucket_of(t)]++] = (int32_t)t;
         }
         if (!p->d_gtcode) {
             HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode), (p->gbcode.size() + 1) * sizeof(BoundInstr)));
@@ -1224,16 +1254,18 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         HIP_TRY(c, hipMemcpy(p->d_gtcode_off, p->gtcode_off.data(), p->gtcode_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         if (!ids.empty()) HIP_TRY(c, hipMemcpy(p->d_gt_ids, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         p->gt_n_buckets = 0;
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < NB; b++) {
             if (!count[b]) continue;
             GradArgs::Bucket &bk = p->gt_buckets[p->gt_n_buckets++];
-            bk.GC = WIDTH[b];
-            bk.windows = b == 7 ? (maxg[b] + 7) / 8 : 1;
+            bk.GC = WIDTH[b & 7];
+            bk.VS = 1 + (b >> 3);
+            bk.windows = (b & 7) == 7 ? (maxg[b] + 7) / 8 : 1;
             bk.max_grad = maxg[b];
+            bk.n_slots = slots[b];
             bk.ids = p->d_gt_ids + start[b];
             bk.n = count[b];
             bk.handler_base = bases[b];
-            bk.param_handler_off = (uint32_t)(tables[b][gop_param(WIDTH[b])] - bases[b]);
+            bk.param_handler_off = (uint32_t)(tables[b][gop_param(WIDTH[b & 7])] - bases[b]);
         }
         p->gt_mode = mode;
         p->gt_valid = true;

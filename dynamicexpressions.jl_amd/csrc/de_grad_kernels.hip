@@ -381,37 +381,56 @@ template <typename T> static hipError_t launch_grad_dt(const GradArgs &ga, hipSt
     return launch_grad_t<T, 8>(ga, (maxg + 7) / 8, stream);
 }
 
-// ---- threaded variant: one module per (type, window) — de_grad_threaded.hip ---------------------------
-#define DE_GT_DECL(TAG, GC)                                                     \
-    hipError_t grad_thr_fetch_##TAG##GC(uint64_t *host_table);                  \
-    hipError_t grad_thr_launch_##TAG##GC(const GradArgs &ga, int bucket, hipStream_t stream);
-#define DE_GT_ALL(X) X(f, 1) X(f, 2) X(f, 3) X(f, 4) X(f, 5) X(f, 6) X(f, 8) X(d, 1) X(d, 2) X(d, 3) X(d, 4) X(d, 5)
+// ---- threaded variant: one module per (type, window, samples per lane) — de_grad_threaded.hip ----------
+#define DE_GT_DECL(TAG, GC, V)                                                       \
+    hipError_t grad_thr_fetch_##TAG##GC##v##V(uint64_t *host_table);                  \
+    hipError_t grad_thr_launch_##TAG##GC##v##V(const GradArgs &ga, int bucket, hipStream_t stream);
+// must agree with build.sh
+#define DE_GT_ALL(X)                                                                                     \
+    X(f, 1, 1) X(f, 2, 1) X(f, 3, 1) X(f, 4, 1) X(f, 5, 1) X(f, 6, 1) X(f, 8, 1)                          \
+    X(f, 1, 2) X(f, 2, 2) X(f, 3, 2) X(f, 4, 2) X(f, 5, 2) X(f, 6, 2)                                     \
+    X(d, 1, 1) X(d, 2, 1) X(d, 3, 1) X(d, 4, 1) X(d, 5, 1)
 DE_GT_ALL(DE_GT_DECL)
 
-hipError_t grad_handler_table(int dtype, int GC, uint64_t *table) {
-    static uint64_t cache[2][9][GOP_MAX];
-    static bool have[2][9] = {};
+bool grad_threaded_has(int dtype, int GC, int VS) {
+    if (GC < 1 || GC > 8 || GC == 7) return false;
+    if (dtype == DE_F32) return VS == 1 || (VS == 2 && GC <= 6);
+    return VS == 1 && GC <= 5; // Float64 states wider than 16 dwords would be passed through scratch memory
+}
+
+hipError_t grad_handler_table(int dtype, int GC, int VS, uint64_t *table) {
+    static uint64_t cache[2][9][3][GOP_MAX];
+    static bool have[2][9][3] = {};
     const int k = dtype == DE_F32 ? 0 : 1;
-    if (GC < 1 || GC > 8 || GC == 7 || (k == 1 && GC > 5)) return hipErrorInvalidValue;
-    if (!have[k][GC]) {
+    if (!grad_threaded_has(dtype, GC, VS)) return hipErrorInvalidValue;
+    if (!have[k][GC][VS]) {
         hipError_t st = hipErrorInvalidValue;
-#define DE_GT_FETCH(TAG, G) if (k == (#TAG[0] == 'f' ? 0 : 1) && GC == G) st = grad_thr_fetch_##TAG##G(cache[k][GC]);
+#define DE_GT_FETCH(TAG, G, V) if (k == (#TAG[0] == 'f' ? 0 : 1) && GC == G && VS == V) st = grad_thr_fetch_##TAG##G##v##V(cache[k][GC][VS]);
         DE_GT_ALL(DE_GT_FETCH)
         if (st != hipSuccess) return st;
-        have[k][GC] = true;
+        have[k][GC][VS] = true;
     }
-    for (int i = 0; i < (int)gop_count(GC); i++) table[i] = cache[k][GC][i];
+    for (int i = 0; i < (int)gop_count(GC); i++) table[i] = cache[k][GC][VS][i];
     return hipSuccess;
 }
 
 hipError_t launch_grad_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name) {
     if (kernel_name) *kernel_name = "de_grad_threaded_kernel";
     const int k = dtype == DE_F32 ? 0 : 1;
+    if (a.loss) { // two-sample modules use 512-sample tiles: the 256-sample tile slots they never write must read as 0
+        bool wide = false;
+        for (int b = 0; b < a.n_buckets; b++) wide = wide || (a.buckets[b].n > 0 && a.buckets[b].VS > 1);
+        if (wide) {
+            const size_t bytes = (size_t)((a.e.N + GBLK - 1) / GBLK) * (size_t)a.n_cols * 4 * (dtype == DE_F32 ? 4 : 8);
+            hipError_t st = hipMemsetAsync(a.loss->partial, 0, bytes, stream);
+            if (st != hipSuccess) return st;
+        }
+    }
     for (int b = 0; b < a.n_buckets; b++) {
         const GradArgs::Bucket &bk = a.buckets[b];
         if (bk.n <= 0) continue;
         hipError_t st = hipErrorInvalidValue;
-#define DE_GT_LAUNCH(TAG, G) if (k == (#TAG[0] == 'f' ? 0 : 1) && bk.GC == G) st = grad_thr_launch_##TAG##G(a, b, stream);
+#define DE_GT_LAUNCH(TAG, G, V) if (k == (#TAG[0] == 'f' ? 0 : 1) && bk.GC == G && bk.VS == V) st = grad_thr_launch_##TAG##G##v##V(a, b, stream);
         DE_GT_ALL(DE_GT_LAUNCH)
         if (st != hipSuccess) return st;
     }

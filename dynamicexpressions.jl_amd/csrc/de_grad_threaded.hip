@@ -20,14 +20,35 @@
 // LLVM sizes the kernel's register file for the most expensive address-taken function of the MODULE,
 // so with every instantiation in one module the Float32 GC=5 kernel was allocated the 104 VGPRs of the
 // Float64 GC=8 handlers (4 waves/SIMD instead of 8).  build.sh compiles this file with
-// -DDE_GT_T=float|double -DDE_GT_TAG=f|d -DDE_GT_GC=1..6,8; de_grad_kernels.hip dispatches.
+// -DDE_GT_T=float|double -DDE_GT_TAG=f|d -DDE_GT_GC=1..6,8 -DDE_GT_VS=1|2; de_grad_kernels.hip dispatches.
+//
+// Samples per lane (DE_GT_VS): Float32 windows of <= 6 rows also exist in a variant that carries TWO
+// consecutive samples per lane as float2 — the dense dual update  g1*d1[k] + g2*d2[k]  is all multiplies and
+// adds, which gfx950 issues two per lane per instruction (v_pk_mul_f32 / v_pk_add_f32), and a dispatch is
+// amortised over twice the samples.  It doubles the LDS rows, so the host uses it for the trees that need at
+// most one spill slot (11 rows x 512 B x 4 waves = 22.5 KB: 7 workgroups per CU); with two slots (34.8 KB: 4
+// workgroups) the lost occupancy costs more than the packed arithmetic saves (measured).  The state must stay
+// within the 16 dwords the calling convention passes in registers (2*(1 + GC) + poison + g0).
+#include <algorithm>
+
 #include "de_grad_common.h"
 
 #ifndef DE_GT_T
-#error "compile with -DDE_GT_T=<float|double> -DDE_GT_TAG=<f|d> -DDE_GT_GC=<n>"
+#error "compile with -DDE_GT_T=<float|double> -DDE_GT_TAG=<f|d> -DDE_GT_GC=<n> -DDE_GT_VS=<1|2>"
+#endif
+#ifndef DE_GT_VS
+#define DE_GT_VS 1
 #endif
 
 namespace de {
+
+#define DE_GT_CAT4(a, b, c, d, e) a##b##c##d##e
+#define DE_GT_CAT5(a, b, c, d, e) DE_GT_CAT4(a, b, c, d, e)
+#define DE_GT_NAME(prefix) DE_GT_CAT5(prefix, DE_GT_TAG, DE_GT_GC, v, DE_GT_VS)
+// Every module instantiates the SAME templates with different DE_GT_VS: their host-side kernel stubs are
+// linkonce symbols the linker would merge across modules (launching some other module's kernel), so each
+// module's templates live in a namespace of their own.
+namespace DE_GT_NAME(gtm_) {
 
 template <typename T> struct GImm;
 template <> struct GImm<float> { typedef uint32_t type; };
@@ -36,20 +57,34 @@ template <typename T> __device__ __forceinline__ T gimm_from(typename GImm<T>::t
 template <> __device__ __forceinline__ float gimm_from<float>(uint32_t b) { return __uint_as_float(b); }
 template <> __device__ __forceinline__ double gimm_from<double>(uint64_t b) { return __longlong_as_double((long long)b); }
 
+constexpr int VS = DE_GT_VS; // samples per lane
+template <typename T> struct LaneVec { typedef T type __attribute__((ext_vector_type(DE_GT_VS))); };
+#define LV(T) typename LaneVec<T>::type
+template <typename T> __device__ __forceinline__ LV(T) lv_splat(T c) {
+    LV(T) v;
+    DE_UNROLL for (int i = 0; i < VS; i++) v[i] = c;
+    return v;
+}
 template <typename T, int GC> struct GState {
-    T x;
-    T d[GC];
-    T poison;
+    LV(T) x;
+    LV(T) d[GC];
+    T poison; // one per lane: fma-accumulated over its samples
     uint32_t g0;
 };
 template <typename T, int GC> struct GDual {
-    T x;
-    T d[GC];
+    LV(T) x;
+    LV(T) d[GC];
 };
 #define GHARGS GState<T, GC> st, uint32_t la, typename GImm<T>::type imm
 template <typename T, int GC> using GHandlerFn = GState<T, GC> (*)(GState<T, GC>, uint32_t, typename GImm<T>::type);
-#define GLDS(T, addr) (reinterpret_cast<__attribute__((address_space(3))) T *>((uintptr_t)(addr)))
-template <typename T> constexpr uint32_t grow_bytes() { return (uint32_t)((GBLK + 4) * sizeof(T)); }
+#define GLDS(T, addr) (reinterpret_cast<__attribute__((address_space(3))) LV(T) *>((uintptr_t)(addr)))
+// LDS is laid out wave-major: wave w owns rows [w*R, (w+1)*R), a row = the 64*VS samples of that wave
+// (512 B for Float32 x 2) — everything a wave touches is private to it and contiguous, which the epilogue
+// uses to turn the [samples, G] gradient block into coalesced 16-byte stores.
+template <typename T> constexpr uint32_t grow_bytes() { return (uint32_t)(64 * VS * sizeof(T)); }
+template <typename T> __device__ __forceinline__ void gpoison(T &poison, LV(T) v) {
+    DE_UNROLL for (int i = 0; i < VS; i++) poison = M<T>::fma(v[i], T(0), poison);
+}
 
 // operand kinds (de_bind.h GSRC_*)
 enum { GS_LEAF = GSRC_LEAF, GS_SLOT = GSRC_SLOT, GS_CONST = GSRC_CONST, GS_ACC = GSRC_ACC };
@@ -60,8 +95,8 @@ enum { GS_LEAF = GSRC_LEAF, GS_SLOT = GSRC_SLOT, GS_CONST = GSRC_CONST, GS_ACC =
 //   g * db[k]   is   g * 1 = g  for k = seed  and  g * 0  elsewhere  (g * 0 is still computed once: it is NaN
 // for an infinite partial and carries the sign of zero, exactly as in grad_degn_eval :340-365).
 template <typename T, int GC, int SRC, int SV> struct GOperand {
-    T x;
-    T d[GC]; // only meaningful for SLOT/ACC operands and run-time seeds
+    LV(T) x;
+    LV(T) d[GC]; // only meaningful for SLOT/ACC operands and run-time seeds
 };
 template <typename T, int GC, int SRC, int SV> __device__ __forceinline__ GOperand<T, GC, SRC, SV> goperand(GState<T, GC> &st, uint32_t la, typename GImm<T>::type imm) {
     GOperand<T, GC, SRC, SV> b;
@@ -74,19 +109,19 @@ template <typename T, int GC, int SRC, int SV> __device__ __forceinline__ GOpera
     } else {
         if constexpr (SRC == GS_LEAF) {
             b.x = *GLDS(T, SV == 0 ? (la & 0xFFFFFFu) : la); // host leaves aux = 0 for known seeds
-            st.poison = M<T>::fma(b.x, T(0), st.poison); // every leaf operand is tested where it is read (:239-242)
-        } else b.x = gimm_from<T>(imm);
+            gpoison<T>(st.poison, b.x); // every leaf operand is tested where it is read (:239-242)
+        } else b.x = lv_splat<T>(gimm_from<T>(imm));
         if constexpr (SV == 0) {
-            const int seed = (int)(la >> 24) - (int)st.g0;
-            DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = (k == seed) ? T(1) : T(0);
+            const int seed = (int)(la >> 24) - (int)(st.g0 & 0xFFFFu);
+            DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = lv_splat<T>((k == seed) ? T(1) : T(0));
         }
     }
     return b;
 }
 // g * db[k]
-template <typename T, int GC, int SRC, int SV> __device__ __forceinline__ void gscale(T g, const GOperand<T, GC, SRC, SV> &b, T (&out)[GC]) {
+template <typename T, int GC, int SRC, int SV> __device__ __forceinline__ void gscale(LV(T) g, const GOperand<T, GC, SRC, SV> &b, LV(T) (&out)[GC]) {
     if constexpr ((SRC == GS_LEAF || SRC == GS_CONST) && SV >= 1) {
-        const T z = g * T(0);
+        const LV(T) z = g * lv_splat<T>(T(0));
         DE_UNROLL for (int k = 0; k < GC; k++) out[k] = (k == SV - 2) ? g : z; // g * 1 == g bit for bit
     } else {
         DE_UNROLL for (int k = 0; k < GC; k++) out[k] = g * b.d[k];
@@ -96,7 +131,7 @@ template <typename T, int GC, int SRC, int SV> __device__ __forceinline__ void g
 template <typename T, int GC, int SRC, int SV> __device__ __noinline__ GState<T, GC> g_load(GHARGS) {
     const GOperand<T, GC, SRC, SV> b = goperand<T, GC, SRC, SV>(st, la, imm);
     st.x = b.x;
-    if constexpr ((SRC == GS_LEAF || SRC == GS_CONST) && SV >= 1) { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = (k == SV - 2) ? T(1) : T(0); }
+    if constexpr ((SRC == GS_LEAF || SRC == GS_CONST) && SV >= 1) { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = lv_splat<T>((k == SV - 2) ? T(1) : T(0)); }
     else { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = b.d[k]; }
     return st;
 }
@@ -106,7 +141,7 @@ template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_push(GHARG
     return st;
 }
 template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_check_acc(GHARGS) {
-    st.poison = M<T>::fma(st.x, T(0), st.poison);
+    gpoison<T>(st.poison, st.x);
     return st;
 }
 template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_nop(GHARGS) { return st; }
@@ -116,55 +151,67 @@ template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_nop(GHARGS
 template <typename T, int GC, int K, int SRC, int SV, bool CHK> __device__ __noinline__ GState<T, GC> g_bin(GHARGS) {
     const GOperand<T, GC, SRC, SV> b = goperand<T, GC, SRC, SV>(st, la, imm);
     constexpr bool REV = (K == 2 || K == 5);
-    const T lx = REV ? b.x : st.x, ly = REV ? st.x : b.x;
-    T v, gl, gr;
-    if constexpr (K == 0) { v = lx + ly; gl = T(1); gr = T(1); }
-    else if constexpr (K == 1 || K == 2) { v = lx - ly; gl = T(1); gr = T(-1); }
+    const LV(T) lx = REV ? b.x : st.x, ly = REV ? st.x : b.x;
+    LV(T) v, gl, gr;
+    if constexpr (K == 0) { v = lx + ly; gl = lv_splat<T>(T(1)); gr = lv_splat<T>(T(1)); }
+    else if constexpr (K == 1 || K == 2) { v = lx - ly; gl = lv_splat<T>(T(1)); gr = lv_splat<T>(T(-1)); }
     else if constexpr (K == 3) { v = lx * ly; gl = ly; gr = lx; }
-    else { v = lx / ly; gl = T(1) / ly; gr = -(v / ly); }
+    else { v = lx / ly; gl = lv_splat<T>(T(1)) / ly; gr = -(v / ly); }
     st.x = v;
-    T sb[GC];
+    LV(T) sb[GC];
     gscale<T, GC, SRC, SV>(REV ? gl : gr, b, sb); // the operand's term
     if constexpr (REV) { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = sb[k] + gr * st.d[k]; }
     else { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = gl * st.d[k] + sb[k]; }
-    if constexpr (CHK) st.poison = M<T>::fma(st.x, T(0), st.poison);
+    if constexpr (CHK) gpoison<T>(st.poison, st.x);
     return st;
 }
 // unary hot ops (K: 0 cos, 1 exp, 2 sin)
 template <typename T, int GC, int K, int SRC, int SV, bool CHK> __device__ __noinline__ GState<T, GC> g_un(GHARGS) {
     const GOperand<T, GC, SRC, SV> b = goperand<T, GC, SRC, SV>(st, la, imm);
-    UG<T> r;
+    LV(T) y, g;
     if constexpr (sizeof(T) == 4) {
-        if constexpr (K == 1) { r.y = (T)fast_exp_f32((float)b.x); r.g = r.y; }
+        if constexpr (K == 1) { DE_UNROLL for (int i = 0; i < VS; i++) { y[i] = (T)fast_exp_f32((float)b.x[i]); g[i] = y[i]; } }
         else {
-            float sn, cs;
-            fast_sincos_f32((float)b.x, &sn, &cs);
-            if constexpr (K == 0) { r.y = (T)cs; r.g = (T)-sn; } else { r.y = (T)sn; r.g = (T)cs; }
+            bool big = false;
+            DE_UNROLL for (int i = 0; i < VS; i++) {
+                float sn, cs;
+                fast_sincos_f32((float)b.x[i], &sn, &cs);
+                if constexpr (K == 0) { y[i] = (T)cs; g[i] = (T)-sn; } else { y[i] = (T)sn; g[i] = (T)cs; }
+                big |= M<T>::abs(b.x[i]) > T(DE_TRIG_FAST_BOUND);
+            }
             // |x| > 1e5: OCML's full-range functions, per ELEMENT — a sample's value must not depend on its wave
             // neighbours (inline: a call would make this handler a non-leaf function)
-            if (__ballot(M<T>::abs(b.x) > T(DE_TRIG_FAST_BOUND)) != 0ull) {
-                if (M<T>::abs(b.x) > T(DE_TRIG_FAST_BOUND)) {
-                    const float sn2 = sinf((float)b.x), cs2 = cosf((float)b.x);
-                    if constexpr (K == 0) { r.y = (T)cs2; r.g = (T)-sn2; } else { r.y = (T)sn2; r.g = (T)cs2; }
+            if (__ballot(big) != 0ull) {
+                DE_UNROLL for (int i = 0; i < VS; i++) {
+                    if (M<T>::abs(b.x[i]) > T(DE_TRIG_FAST_BOUND)) {
+                        const float sn = sinf((float)b.x[i]), cs = cosf((float)b.x[i]);
+                        if constexpr (K == 0) { y[i] = (T)cs; g[i] = (T)-sn; } else { y[i] = (T)sn; g[i] = (T)cs; }
+                    }
                 }
             }
         }
     } else {
-        if constexpr (K == 0) { r.y = M<T>::cos(b.x); r.g = -M<T>::sin(b.x); }
-        else if constexpr (K == 1) { r.y = M<T>::exp(b.x); r.g = r.y; }
-        else { r.y = M<T>::sin(b.x); r.g = M<T>::cos(b.x); }
+        DE_UNROLL for (int i = 0; i < VS; i++) {
+            if constexpr (K == 0) { y[i] = M<T>::cos(b.x[i]); g[i] = -M<T>::sin(b.x[i]); }
+            else if constexpr (K == 1) { y[i] = M<T>::exp(b.x[i]); g[i] = y[i]; }
+            else { y[i] = M<T>::sin(b.x[i]); g[i] = M<T>::cos(b.x[i]); }
+        }
     }
-    st.x = r.y;
-    gscale<T, GC, SRC, SV>(r.g, b, st.d);
-    if constexpr (CHK) st.poison = M<T>::fma(st.x, T(0), st.poison);
+    st.x = y;
+    gscale<T, GC, SRC, SV>(g, b, st.d);
+    if constexpr (CHK) gpoison<T>(st.poison, st.x);
     return st;
 }
 // generic (cold) operators through the noinline value+partials functions of de_grad_common.h
 template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_gen_apply(GState<T, GC> st, uint32_t gop, GDual<T, GC> b) {
     if (gop < DE_B_ADD) {
-        const UG<T> r = unary_vg<T>(gop, b.x);
-        st.x = r.y;
-        DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = r.g * b.d[k];
+        LV(T) g;
+        DE_UNROLL for (int i = 0; i < VS; i++) {
+            const UG<T> r = unary_vg<T>(gop, b.x[i]);
+            st.x[i] = r.y;
+            g[i] = r.g;
+        }
+        DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = g * b.d[k];
     } else {
         uint32_t fop = gop;
         bool rev = false;
@@ -178,16 +225,21 @@ template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_gen_apply(
         case DOP_RPOW_ABS2: fop = DE_B_POW_ABS2; rev = true; break;
         default: break;
         }
-        const BG<T> r = rev ? binary_vg<T>(fop, b.x, st.x) : binary_vg<T>(fop, st.x, b.x);
-        st.x = r.v;
-        if (rev) { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = r.gx * b.d[k] + r.gy * st.d[k]; }
-        else { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = r.gx * st.d[k] + r.gy * b.d[k]; }
+        LV(T) gx, gy;
+        DE_UNROLL for (int i = 0; i < VS; i++) {
+            const BG<T> r = rev ? binary_vg<T>(fop, b.x[i], st.x[i]) : binary_vg<T>(fop, st.x[i], b.x[i]);
+            st.x[i] = r.v;
+            gx[i] = r.gx;
+            gy[i] = r.gy;
+        }
+        if (rev) { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = gx * b.d[k] + gy * st.d[k]; }
+        else { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = gx * st.d[k] + gy * b.d[k]; }
     }
     return st;
 }
 template <typename T, int GC, int SRC> __device__ __noinline__ GState<T, GC> g_gen(GHARGS) {
     uint32_t gop;
-    if constexpr (SRC == GS_CONST) gop = (la >> 16) & 0xFFu; // no LDS operand: the opcode rides in la[23:16] (lds0 < 2^16)
+    if constexpr (SRC == GS_CONST) gop = ((la - (st.g0 & 0xFFFF0000u)) >> 16) & 0xFFu; // no LDS operand: the opcode rides in la[23:16] above the lane's LDS base, whose upper half st.g0 carries
     else gop = (uint32_t)imm;
     const GOperand<T, GC, SRC, 0> o = goperand<T, GC, SRC, 0>(st, la, imm);
     GDual<T, GC> b;
@@ -197,10 +249,15 @@ template <typename T, int GC, int SRC> __device__ __noinline__ GState<T, GC> g_g
 }
 template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_tern(GHARGS) { // acc = op3(slot B, slot C, acc)
     const uint32_t lb = la & 0xFFFFFFu, lc = lb + (uint32_t)imm;
-    const TG<T> r = ternary_vg<T>(la >> 24, *GLDS(T, lb), *GLDS(T, lc), st.x);
-    st.x = r.v;
+    const LV(T) xb = *GLDS(T, lb), xc = *GLDS(T, lc);
+    LV(T) g0, g1, g2;
+    DE_UNROLL for (int i = 0; i < VS; i++) {
+        const TG<T> r = ternary_vg<T>(la >> 24, xb[i], xc[i], st.x[i]);
+        st.x[i] = r.v;
+        g0[i] = r.g0; g1[i] = r.g1; g2[i] = r.g2;
+    }
     DE_UNROLL for (int k = 0; k < GC; k++)
-        st.d[k] = (r.g0 * *GLDS(T, lb + (1 + k) * grow_bytes<T>()) + r.g1 * *GLDS(T, lc + (1 + k) * grow_bytes<T>())) + r.g2 * st.d[k];
+        st.d[k] = (g0 * *GLDS(T, lb + (1 + k) * grow_bytes<T>()) + g1 * *GLDS(T, lc + (1 + k) * grow_bytes<T>())) + g2 * st.d[k];
     return st;
 }
 
@@ -242,53 +299,139 @@ template <typename T, int GC> __global__ void de_grad_fill_handlers(uint64_t *t)
     t[gop_tern(GC)] = (uint64_t)&g_tern<T, GC>;
 }
 
-// One sample per thread; LDS rows of GBLK(+4) elements: rows [0,F) = X tile, then each spill
-// slot s owns 1+GC rows (x, d[0..GC)) — the layout of de_grad_tape_kernel.
+// End of a tree: store (or reduce) the wave's results.  Out of line on purpose, and fed with plain values
+// (taking the address of the kernel-argument struct would make every load from it look divergent): nothing
+// of the epilogue stays live in VGPRs across the handler calls of the interpreter loop.
+template <typename T, int GC>
+__device__ __noinline__ void g_epilogue_loss(GState<T, GC> st, const T *y, const T *w, T *pp, int64_t N, int loss_mode, int G, int g0, int64_t tile) {
+    constexpr int TILE = GBLK * VS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t base = tile * TILE, last = N - 1;
+    T l = T(0);
+    LV(T) lp, wv;
+    DE_UNROLL for (int i = 0; i < VS; i++) {
+        const int64_t j = base + (int64_t)tid * VS + i;
+        const int64_t jj = j < last ? j : last;
+        const T yv = y[jj];
+        wv[i] = j <= last ? (w ? w[jj] : T(1)) : T(0);
+        const T e = st.x[i] - yv;
+        T li;
+        if (loss_mode == 1 + DE_LOSS_L2) { li = wv[i] * (e * e); lp[i] = wv[i] * (T(2) * e); }
+        else if (loss_mode == 1 + DE_LOSS_L1) { li = wv[i] * M<T>::abs(e); lp[i] = wv[i] * jl_sign(e); }
+        else { li = wv[i] * (st.x[i] * yv); lp[i] = wv[i] * yv; } // DE_LOSS_PULLBACK: y holds the cotangent dY
+        if (wv[i] == T(0)) { li = T(0); lp[i] = T(0); } // weight 0 (and samples past N) really excludes the sample
+        l += li;
+    }
+    pp += wave; // pp = partial sums of this (tile, tree): [1 + n_grad][4 waves]
+    if (g0 == 0) {
+        const T s = wave_sum_to_lane63(l);
+        if (lane == 63) pp[0] = s;
+    }
+    DE_UNROLL for (int k = 0; k < GC; k++) {
+        if (g0 + k < G) { // wave-uniform
+            T c = T(0);
+            DE_UNROLL for (int i = 0; i < VS; i++) c += wv[i] == T(0) ? T(0) : lp[i] * st.d[k][i];
+            const T s = wave_sum_to_lane63(c);
+            if (lane == 63) pp[(int64_t)(1 + g0 + k) * 4] = s;
+        }
+    }
+}
+template <typename T, int GC>
+__device__ __noinline__ void g_epilogue_store(GState<T, GC> st, T *out_row, T *grad_tree, int64_t N, int G, int g0, int64_t tile, uint32_t stage0) {
+    constexpr int TILE = GBLK * VS, WSAMP = 64 * VS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t base = tile * TILE, last = N - 1;
+    if (G <= GC) {
+        // One window: the wave's gradient block — WSAMP samples x G rows, gradient index fastest
+        // (src/EvaluateDerivative.jl:355-361) — is WSAMP*G contiguous elements in memory.  Transpose it
+        // through the wave's (now idle) slot rows and write it with 16-byte stores; per-lane stores
+        // would each touch 4 of every 4*G*VS bytes.
+        DE_UNROLL for (int i = 0; i < VS; i++) {
+            const int64_t j = base + (int64_t)tid * VS + i;
+            if (j <= last && out_row) out_row[j] = st.x[i];
+        }
+        const int64_t j0 = base + (int64_t)wave * WSAMP;         // first sample of this wave
+        const int64_t n_valid = N - j0 < WSAMP ? N - j0 : WSAMP; // samples of this wave inside N (may be <= 0)
+        if (G > 0 && n_valid > 0) {
+            DE_UNROLL for (int i = 0; i < VS; i++)
+                DE_UNROLL for (int k = 0; k < GC; k++)
+                    if (k < G) *reinterpret_cast<__attribute__((address_space(3))) T *>((uintptr_t)(stage0 + (uint32_t)(((lane * VS + i) * G + k) * sizeof(T)))) = st.d[k][i];
+            __builtin_amdgcn_wave_barrier(); // LDS is in order within a wave; this only pins the compiler
+            constexpr int PER16 = 16 / (int)sizeof(T);
+            T *__restrict__ gdst = grad_tree + (int64_t)G * j0;
+            const int total = (int)n_valid * G; // elements to write
+            const bool aligned = (reinterpret_cast<uintptr_t>(gdst) & 15) == 0;
+            for (int e = lane * PER16; e < total; e += 64 * PER16) {
+                typedef T V16 __attribute__((ext_vector_type(PER16)));
+                const V16 v = *reinterpret_cast<__attribute__((address_space(3))) V16 *>((uintptr_t)(stage0 + (uint32_t)(e * sizeof(T))));
+                if (aligned && e + PER16 <= total) *reinterpret_cast<V16 *>(gdst + e) = v;
+                else { DE_UNROLL for (int q = 0; q < PER16; q++) if (e + q < total) gdst[e + q] = v[q]; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else { // several windows: every window owns a few rows of the block — direct stores
+        DE_UNROLL for (int i = 0; i < VS; i++) {
+            const int64_t j = base + (int64_t)tid * VS + i;
+            if (j <= last) {
+                if (out_row && g0 == 0) out_row[j] = st.x[i];
+                T *__restrict__ gp = grad_tree + (int64_t)G * j + g0;
+                DE_UNROLL for (int k = 0; k < GC; k++)
+                    if (g0 + k < G) gp[k] = st.d[k][i];
+            }
+        }
+    }
+}
+
+// VS consecutive samples per thread; wave-major LDS: per wave, rows [0,F) = its slice of the X tile, then each
+// spill slot s owns 1+GC rows (x, d[0..GC)); at least GC rows follow the X rows (output staging).
 template <typename T, int GC, bool PARAMS>
 __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a, const uint64_t hbase, const uint32_t param_off) {
-    constexpr int RS = GBLK + 4;
+    constexpr int TILE = GBLK * VS, WSAMP = 64 * VS; // samples per workgroup / per wave
     extern __shared__ __align__(16) unsigned char gtsmem[];
     T *__restrict__ rows = reinterpret_cast<T *>(gtsmem);
 
     const GTileMap tm = gmap_block(blockIdx.x, a.n_chunks, a.n_tiles);
     if (!tm.valid) return;
     const int tid = threadIdx.x;
-    const int64_t base = tm.tile * GBLK;
+    const int64_t base = tm.tile * TILE;
     const int64_t last = a.N - 1;
     const int g0 = (int)blockIdx.y * GC; // first gradient component of this window
     const int F = a.F;
+    const int slot_rows = a.n_slots * (1 + GC) > GC ? a.n_slots * (1 + GC) : GC;
+    const int R = F + slot_rows; // rows per wave
     {
         const uint32_t Fu = (uint32_t)F;
-        const uint32_t total = (uint32_t)GBLK * Fu;
+        const uint32_t total = (uint32_t)TILE * Fu;
         for (uint32_t e = tid; e < total; e += GBLK) {
             const uint32_t j = e / Fu, f = e - j * Fu;
             int64_t jj = base + j;
             jj = jj < last ? jj : last;
-            rows[f * RS + j] = a.X[f + a.ldX * jj];
+            rows[((j / WSAMP) * (uint32_t)R + f) * WSAMP + (j % WSAMP)] = a.X[f + a.ldX * jj];
         }
     }
-    int64_t jj0 = base + tid;
-    const bool live = jj0 < a.N;
-    jj0 = jj0 < last ? jj0 : last;
-    int64_t cls = 0;
-    if (PARAMS)
-        cls = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj0]
-                                : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj0]) - a.class_base;
-    T yv = T(0), wv = T(0);
-    if (a.loss_mode) {
-        yv = a.y[jj0];
-        wv = live ? (a.w ? a.w[jj0] : T(1)) : T(0);
+    // this thread's samples: base + tid*VS + i
+    int64_t cls[VS];
+    DE_UNROLL for (int i = 0; i < VS; i++) {
+        cls[i] = 0;
+        if (PARAMS) {
+            const int64_t j = base + (int64_t)tid * VS + i;
+            const int64_t jj = j < last ? j : last;
+            cls[i] = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
+                                       : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base;
+        }
     }
     __syncthreads();
 
     const ConstU4Ptr code = (ConstU4Ptr)(uintptr_t)a.code;
     const ConstI32Ptr code_off = (ConstI32Ptr)(uintptr_t)a.code_off;
     const ConstI64Ptr col_off = (ConstI64Ptr)(uintptr_t)a.col_off;
-    const ConstI32Ptr n_grad = (ConstI32Ptr)(uintptr_t)a.n_grad;
     const ConstI64Ptr grad_off = (ConstI64Ptr)(uintptr_t)a.grad_off;
+    const ConstI32Ptr n_grad = (ConstI32Ptr)(uintptr_t)a.n_grad;
     const int t0 = tm.chunk * a.trees_per_chunk;
     const int t1 = (t0 + a.trees_per_chunk < a.n_trees) ? t0 + a.trees_per_chunk : a.n_trees;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)gtsmem + tid * (uint32_t)sizeof(T);
+    const uint32_t wave_base = (uint32_t)(uintptr_t)gtsmem + (uint32_t)((tid >> 6) * R) * grow_bytes<T>();
+    const uint32_t lds0 = wave_base + (uint32_t)(tid & 63) * (uint32_t)(VS * sizeof(T));
+    const uint32_t stage0 = wave_base + (uint32_t)F * grow_bytes<T>(); // the wave's slot area, free between trees
     const int param_seed0 = a.mode != DE_GRAD_CONSTANT ? -g0 : -0x40000000;
 
     const ConstI32Ptr tree_ids = (ConstI32Ptr)(uintptr_t)a.tree_ids;
@@ -299,10 +442,10 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
         int pc = code_off[tree];
         const int pe = code_off[tree + 1];
         GState<T, GC> st;
-        st.x = T(0);
-        DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = T(0);
+        st.x = lv_splat<T>(T(0));
+        DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = lv_splat<T>(T(0));
         st.poison = T(0);
-        st.g0 = (uint32_t)g0;
+        st.g0 = (uint32_t)g0 | (lds0 & 0xFFFF0000u); // window offset (< 2^16) | upper half of the lane's LDS base (g_gen)
         U32x4 nxt = code[pc];
         for (; pc < pe; ++pc) {
             const U32x4 w = nxt;
@@ -310,10 +453,10 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
             if (PARAMS && w.x == param_off) { // operand = params[row, class]: needs kernel arguments
                 const uint32_t prow = w.y & 0xFFFFu, op = w.y >> 24;
                 GDual<T, GC> b;
-                b.x = a.params[prow + a.ld_params * cls];
-                st.poison = M<T>::fma(b.x, T(0), st.poison);
+                DE_UNROLL for (int i = 0; i < VS; i++) b.x[i] = a.params[prow + a.ld_params * cls[i]];
+                gpoison<T>(st.poison, b.x);
                 const int seed = (int)prow + param_seed0;
-                DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = (k == seed) ? T(1) : T(0);
+                DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = lv_splat<T>((k == seed) ? T(1) : T(0));
                 if (op == DOP_LOAD) { st.x = b.x; DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = b.d[k]; }
                 else st = g_gen_apply<T, GC>(st, op, b);
                 continue;
@@ -326,46 +469,27 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
         }
         // a non-finite d[k] always survives to the root (every update is linear in it), so the gradient
         // is validity-tested once, here; x was tested where the lowering kept a test (H_CHECK_OUT)
-        T poison = M<T>::fma(st.x, T(0), st.poison);
+        T poison = st.poison;
+        gpoison<T>(poison, st.x);
         // only the components this tree really has: a window is as wide as its bucket, and a column beyond
         // n_grad (the lone column of a tree without constants in constant mode) holds g*0 terms that are NaN
         // for an infinite partial although the reference's gradient matrix has no such row
-        DE_UNROLL for (int k = 0; k < GC; k++) poison = M<T>::fma(g0 + k < G ? st.d[k] : T(0), T(0), poison);
+        DE_UNROLL for (int k = 0; k < GC; k++) gpoison<T>(poison, g0 + k < G ? st.d[k] : lv_splat<T>(T(0)));
         if (a.loss_mode) {
-            const T e = st.x - yv;
-            T lp, l;
-            if (a.loss_mode == 1 + DE_LOSS_L2) { l = wv * (e * e); lp = wv * (T(2) * e); }
-            else if (a.loss_mode == 1 + DE_LOSS_L1) { l = wv * M<T>::abs(e); lp = wv * jl_sign(e); }
-            else { l = wv * (st.x * yv); lp = wv * yv; } // DE_LOSS_PULLBACK: y holds the cotangent dY
-            if (wv == T(0)) { l = T(0); lp = T(0); }
             const int64_t n_cols = col_off[a.n_all_trees];
-            T *__restrict__ pp = a.partial + ((int64_t)tm.tile * n_cols + col_off[tree]) * 4 + (tid >> 6);
-            if (g0 == 0) {
-                const T s = wave_sum_to_lane63(l);
-                if ((tid & 63) == 63) pp[0] = s;
-            }
-            DE_UNROLL for (int k = 0; k < GC; k++) {
-                if (g0 + k < G) { // wave-uniform
-                    const T s = wave_sum_to_lane63(wv == T(0) ? T(0) : lp * st.d[k]);
-                    if ((tid & 63) == 63) pp[(int64_t)(1 + g0 + k) * 4] = s;
-                }
-            }
-        } else if (live) {
-            if (a.out && g0 == 0) a.out[(int64_t)tree * a.ld_out + base + tid] = st.x;
-            T *__restrict__ gp = a.grad + grad_off[tree] + (int64_t)G * (base + tid) + g0;
-            DE_UNROLL for (int k = 0; k < GC; k++)
-                if (g0 + k < G) gp[k] = st.d[k];
+            g_epilogue_loss<T, GC>(st, a.y, a.w, a.partial + ((int64_t)tm.tile * n_cols + col_off[tree]) * 4, a.N, a.loss_mode, G, g0, (int64_t)tm.tile);
+        } else {
+            g_epilogue_store<T, GC>(st, a.out ? a.out + (int64_t)tree * a.ld_out : nullptr, a.grad + grad_off[tree], a.N, G, g0, (int64_t)tm.tile, stage0);
         }
         if (__ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree);
     }
 }
 
 // ---- host side: entry points of this (type, window) module -----------------------------------------
-#define DE_GT_CAT2(a, b, c) a##b##c
-#define DE_GT_CAT(a, b, c) DE_GT_CAT2(a, b, c)
-#define DE_GT_NAME(prefix) DE_GT_CAT(prefix, DE_GT_TAG, DE_GT_GC)
+} // module namespace
 
 hipError_t DE_GT_NAME(grad_thr_fetch_)(uint64_t *host_table) {
+    using namespace DE_GT_NAME(gtm_);
     uint64_t *d = nullptr;
     hipError_t st = hipMalloc(reinterpret_cast<void **>(&d), GOP_MAX * sizeof(uint64_t));
     if (st != hipSuccess) return st;
@@ -376,6 +500,7 @@ hipError_t DE_GT_NAME(grad_thr_fetch_)(uint64_t *host_table) {
 }
 
 hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStream_t stream) {
+    using namespace DE_GT_NAME(gtm_);
     const GradArgs::Bucket &bk = ga.buckets[bucket];
     const int windows = bk.windows;
     typedef DE_GT_T T;
@@ -397,13 +522,13 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStrea
     a.ldX = e.ldX;
     a.ld_out = e.ld_out;
     a.ld_params = e.ld_params;
-    a.n_tiles = (e.N + GBLK - 1) / GBLK;
+    a.n_tiles = (e.N + GBLK * VS - 1) / (GBLK * VS);
     a.F = e.F;
     a.P = ga.P;
     a.n_trees = bk.n;
     a.n_all_trees = e.n_trees;
     a.tree_ids = bk.ids;
-    a.n_slots = e.n_slots;
+    a.n_slots = bk.n_slots; // spill slots the trees of this bucket need
     a.mode = ga.mode;
     a.classes_is_i64 = e.classes_is_i64;
     a.class_base = e.class_base;
@@ -437,7 +562,8 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStrea
     a.n_chunks = (int32_t)((bk.n + a.trees_per_chunk - 1) / a.trees_per_chunk);
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL || windows > 65535) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(a.F + (size_t)a.n_slots * (1 + GC)) * (GBLK + 4) * sizeof(T);
+    const size_t slot_rows = std::max<size_t>((size_t)a.n_slots * (1 + GC), (size_t)GC);
+    const size_t lds = 4 * ((size_t)a.F + slot_rows) * 64 * VS * sizeof(T); // 4 waves x rows x one wave's samples
     void (*kern)(const GArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_grad_threaded_kernel<T, GC, true> : de_grad_threaded_kernel<T, GC, false>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return hipErrorInvalidValue;

@@ -74,12 +74,14 @@ struct GradArgs {
     const BoundInstr *threaded_code;
     int32_t n_buckets;
     struct Bucket {
-        int32_t GC, windows, max_grad; // module (window width), windows per tree, widest gradient in the bucket
+        int32_t GC, VS;                // module: window width, samples per lane
+        int32_t windows, max_grad;     // windows per tree, widest gradient in the bucket
+        int32_t n_slots;               // spill slots the trees of the bucket need (LDS rows of the launch)
         const int32_t *ids;            // device: tree indices of the bucket
         int32_t n;
         uint64_t handler_base;
         uint32_t param_handler_off;
-    } buckets[8];
+    } buckets[16];
 };
 
 // Returns hipSuccess or the failing HIP error.  `kernel_name` receives the symbol
@@ -90,7 +92,8 @@ hipError_t launch_grad(int dtype, const GradArgs &a, hipStream_t stream, const c
 // Threaded gradient kernel: window width used for a population whose widest gradient has max_grad rows,
 // handler addresses for (dtype, window), launch; pass 2+3 of the fused loss-gradient reduction.
 int grad_window(int max_grad);
-hipError_t grad_handler_table(int dtype, int GC, uint64_t *table); // GOP_MAX entries, gop_count(GC) used
+hipError_t grad_handler_table(int dtype, int GC, int VS, uint64_t *table); // GOP_MAX entries, gop_count(GC) used
+bool grad_threaded_has(int dtype, int GC, int VS);                            // is there a module for (type, window, samples per lane)?
 hipError_t launch_grad_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name);
 hipError_t launch_loss_grad_finish(int dtype, const GradArgs &ga, int64_t n_tiles, hipStream_t stream);
 

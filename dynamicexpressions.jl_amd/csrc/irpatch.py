@@ -23,7 +23,7 @@ NO_ATTRS = ["amdgpu-no-dispatch-ptr", "amdgpu-no-queue-ptr", "amdgpu-no-implicit
             "amdgpu-no-lds-kernel-id", "amdgpu-no-hostcall-ptr", "amdgpu-no-heap-ptr", "amdgpu-no-default-queue",
             "amdgpu-no-completion-action", "amdgpu-no-multigrid-sync-arg", "amdgpu-no-flat-scratch-init",
             "amdgpu-no-cluster-id-x", "amdgpu-no-cluster-id-y", "amdgpu-no-cluster-id-z"]
-HSTATE = r'%"struct\.de::[HG]State(?:\.\d+)?"'
+HSTATE = r'%"struct\.de::(?:\w+::)?[HG]State(?:\.\d+)?"'
 
 
 def main(src, dst):
