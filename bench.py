@@ -52,6 +52,11 @@ WORKLOADS = {
     "C5": dict(n_trees=1000, N=10**6, parametric=True,
                desc="1000 random 20-node ParametricNode trees (8 parameters x 16 classes), 5 x 10^6 Float32: "
                     "eval_tree_array + eval_grad_tree_array(variable=false) per step"),
+    "C5pb": dict(n_trees=1000, N=10**6, parametric=True, by_class=True,
+                 desc="1000 random 20-node ParametricNode trees (8 parameters x 16 classes, samples grouped by class), "
+                      "5 x 10^6 Float32: eval_tree_array + the :both-mode pullback (dY = randn) with the parameter rows "
+                      "reduced by class, fused (SURVEY.md §8d C5; src/ChainRules.jl:56-77, "
+                      "test/test_parametric_expression.jl:326-372)"),
     "tiny": dict(n_trees=64, N=10**5, desc="64 trees x (5 x 10^5) Float32 (plumbing)"),
 }
 
@@ -157,6 +162,16 @@ def main():
         n_cls = 16
         params = torch.randn((n_cls, 8), generator=g, device=dev, dtype=torch.float32)  # [P=8, C] column-major
         classes = torch.randint(1, n_cls + 1, (N,), generator=g, device=dev, dtype=torch.int32)
+        by_class = bool(wl.get("by_class"))
+        if by_class:  # the dataset is ordered by class once (classes belong to the dataset)
+            classes = torch.sort(classes).values
+            starts = np.zeros(n_cls + 1, dtype=np.int64)
+            np.cumsum(torch.bincount(classes.long() - 1, minlength=n_cls).cpu().numpy(), out=starts[1:])
+            dY = torch.randn(N, generator=g, device=dev, dtype=torch.float32)
+            ng_b = np.array([pop.n_grad(t, 2) for t in range(len(trees))], dtype=np.int64)
+            lossv = torch.empty(len(trees), device=dev, dtype=torch.float32)
+            dlossv = torch.empty(max(int(ng_b.sum()), 1), device=dev, dtype=torch.float32)
+            dparv = torch.empty((len(trees), n_cls, 8), device=dev, dtype=torch.float32)
         pa = api.ParamArgs()
         pa.params, pa.ld_params, pa.n_classes = params.data_ptr(), 8, n_cls
         pa.classes, pa.classes_is_i64, pa.class_base = classes.data_ptr(), 0, 1
@@ -165,13 +180,18 @@ def main():
         ng_c = np.array([pop.n_grad(t, 1) for t in range(len(trees))], dtype=np.int64)
         goffs = np.zeros(len(trees), dtype=np.int64)
         np.cumsum(ng_c[:-1] * N, out=goffs[1:])
-        gradc = torch.empty(max(int((ng_c * N).sum()), 1), device=dev, dtype=torch.float32)
+        gradc = None if wl.get("by_class") else torch.empty(max(int((ng_c * N).sum()), 1), device=dev, dtype=torch.float32)
 
     def step():
         if is_param:
             ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, 5, pa_ref, out.data_ptr(), N, ok.data_ptr()))
-            ctx.check(lib.de_eval_grad(ctx._h, pop._h, X.data_ptr(), N, 5, pa_ref, 1, None, N, gradc.data_ptr(),
-                                       goffs.ctypes.data, ok.data_ptr()))
+            if by_class:
+                ctx.check(lib.de_eval_loss_grad_by_class(ctx._h, pop._h, X.data_ptr(), N, 5, pa_ref, 2, dY.data_ptr(), None, 2,
+                                                         starts.ctypes.data, lossv.data_ptr(), dlossv.data_ptr(), None,
+                                                         dparv.data_ptr(), ok.data_ptr()))
+            else:
+                ctx.check(lib.de_eval_grad(ctx._h, pop._h, X.data_ptr(), N, 5, pa_ref, 1, None, N, gradc.data_ptr(),
+                                           goffs.ctypes.data, ok.data_ptr()))
         elif is_grad:
             ctx.check(lib.de_eval_grad(ctx._h, pop._h, X.data_ptr(), N, 5, None, 0, out.data_ptr(), N,
                                        grad.data_ptr(), None, ok.data_ptr()))
@@ -219,6 +239,9 @@ def main():
             k_eff = plan["trees_per_chunk"]
             k_avg_ms = ms_per_step
             b_unit = (F_FEATURES * ELEM / k_eff + ELEM) + (F_FEATURES * ELEM / 32 + float(ng_c.mean()) * ELEM)
+            if by_class:  # eval as above; pullback: X + class id + dY tile per chunk of 32 trees, (1 + n_grad) partials per wave
+                b_unit = ((F_FEATURES * ELEM + 4) / k_eff + ELEM) + ((F_FEATURES * ELEM + 4 + ELEM) / 32
+                                                                     + (1 + float(ng_b.mean())) * 4 * ELEM / 256)
         elif is_grad:  # one tree per X pass, writes x + 5 gradient rows: (F + 1 + F)*s  
             k_eff, b_unit = 1, float((2 * F_FEATURES + 1) * ELEM)
         elif is_lossgrad:  # X (+ y) tile staged once per chunk of 32 trees; (1 + n_const) partials per wave

@@ -44,7 +44,7 @@ EXPORTS = [
     "de_opcode_degree", "de_status_string", "de_ctx_create", "de_ctx_destroy",
     "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create",
     "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
-    "de_program_n_grad", "de_program_dump", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad",
+    "de_program_n_grad", "de_program_dump", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad", "de_eval_loss_grad_by_class",
     "de_eval_tree_array", "de_eval_plan", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
 ]
 
@@ -114,6 +114,7 @@ def library() -> C.CDLL:
     lib.de_eval.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), vp, i64, vp]
     lib.de_eval_loss.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), vp, vp, C.c_int32, vp, vp]
     lib.de_eval_loss_grad.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), C.c_int, vp, vp, C.c_int32, vp, vp, vp, vp]
+    lib.de_eval_loss_grad_by_class.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), C.c_int, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp]
     lib.de_eval_grad.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), C.c_int, vp, i64, vp, vp, vp]
     lib.de_eval_diff.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, i64, vp]
     lib.de_eval_tree_array.argtypes = [vp, C.c_int, vp, i64, vp, i64, vp, i32, i64, u32, vp, vp]
@@ -516,6 +517,86 @@ class Population:
         self.ctx.check(lib.de_eval_loss_grad(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None, mode,
                                              yp, wp, kind, lo.ctypes.data, dl.ctypes.data, offs.ctypes.data, ok.ctypes.data))
         return lo, np.split(dl[:int(offs[-1])], offs[1:-1]), ok.astype(bool)
+
+    def eval_loss_grad_by_class(self, X, y, params, classes, weights=None, loss: str = "L2",
+                                variable: Union[bool, str] = "both", class_base: int = 1, grouped: bool = False):
+        """Fused loss + gradient of a parametric population with the parameter rows reduced by class:
+        returns (loss[n_trees], [dloss_t], dparams[n_trees, n_params, n_classes], ok) where
+        ``dparams[t]`` is the gradient w.r.t. the parameter MATRIX — Zygote's
+        ``grad.metadata._data.parameters`` (test/test_parametric_expression.jl:326-372).
+        The library reduces class by class over sample ranges, so the samples are ordered by class
+        first (a stable sort, done here unless ``grouped=True`` says the caller already did: classes are
+        part of the dataset, so a search loop orders it once)."""
+        kind = {"L2": 0, "L1": 1, "pullback": 2}[loss]
+        mode = _grad_mode(variable)
+        is_t = _is_torch(X)
+        if is_t:
+            import torch
+            classes = torch.as_tensor(classes, device=X.device)
+            if not grouped:
+                order = torch.argsort(classes, stable=True)
+                X, classes = X[:, order], classes[order]  # _prep_X makes the column gather feature-fastest again
+                y = torch.as_tensor(y, device=X.device)[order]
+                weights = None if weights is None else torch.as_tensor(weights, device=X.device)[order]
+            counts = torch.bincount((classes - class_base).to(torch.int64), minlength=params.shape[1]).cpu().numpy()
+        else:
+            classes = np.asarray(classes)
+            if not grouped:
+                order = np.argsort(classes, kind="stable")
+                X, classes = np.asfortranarray(np.asarray(X)[:, order]), classes[order]
+                y = np.asarray(y)[order]
+                weights = None if weights is None else np.asarray(weights)[order]
+            counts = np.bincount((classes - class_base).astype(np.int64), minlength=params.shape[1])
+        ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        if F < self.n_features:
+            raise ValueError(f"X has {F} features but the trees use feature {self.n_features}")
+        keep = [keep_x]
+        pa = self._param_args(params, classes, class_base, N, keep)
+        if pa is None:
+            raise ValueError("not a parametric population")
+        n_cls = int(pa.n_classes)
+        starts = np.zeros(n_cls + 1, dtype=np.int64)
+        np.cumsum(counts[:n_cls], out=starts[1:])
+        lib = library()
+        ng = self._n_grad_all(mode)
+        offs = np.zeros(self.n_trees + 1, dtype=np.int64)
+        np.cumsum(ng, out=offs[1:])
+        total = max(int(offs[-1]), 1)
+        P = self.n_params
+
+        def vec(v, name):
+            if v is None:
+                return None
+            if is_t:
+                import torch
+                v = torch.as_tensor(v, dtype=keep_x.dtype, device=keep_x.device).contiguous()
+                n, p_ = v.numel(), v.data_ptr()
+            else:
+                v = np.ascontiguousarray(v, dtype=self.dtype)
+                n, p_ = v.size, v.ctypes.data
+            if n != N:
+                raise ValueError(f"{name} must have {N} entries")
+            keep.append(v)
+            return p_
+
+        yp, wp = vec(y, "y"), vec(weights, "weights")
+        if is_t:
+            import torch
+            kw = dict(dtype=keep_x.dtype, device=keep_x.device)
+            lo, dl = torch.empty(self.n_trees, **kw), torch.empty(total, **kw)
+            dp = torch.empty((self.n_trees, n_cls, P), **kw)
+            ok = torch.empty(self.n_trees, dtype=torch.uint8, device=keep_x.device)
+            self.ctx.check(lib.de_eval_loss_grad_by_class(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa), mode, yp, wp, kind,
+                                                          starts.ctypes.data, lo.data_ptr(), dl.data_ptr(), offs.ctypes.data,
+                                                          dp.data_ptr(), ok.data_ptr()))
+            return lo, list(torch.split(dl[:int(offs[-1])], ng.tolist())), dp.transpose(1, 2), ok.bool()
+        lo, dl = np.empty(self.n_trees, dtype=self.dtype), np.empty(total, dtype=self.dtype)
+        dp = np.empty((self.n_trees, n_cls, P), dtype=self.dtype)
+        ok = np.zeros(self.n_trees, dtype=np.uint8)
+        self.ctx.check(lib.de_eval_loss_grad_by_class(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa), mode, yp, wp, kind,
+                                                      starts.ctypes.data, lo.ctypes.data, dl.ctypes.data, offs.ctypes.data,
+                                                      dp.ctypes.data, ok.ctypes.data))
+        return lo, np.split(dl[:int(offs[-1])], offs[1:-1]), dp.transpose(0, 2, 1), ok.astype(bool)
 
     def eval_grad(self, X, variable: Union[bool, str] = False, params=None, classes=None,
                   class_base: int = 1):

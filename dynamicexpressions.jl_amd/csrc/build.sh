@@ -48,6 +48,12 @@ for spec in f:float:1:1 f:float:2:1 f:float:3:1 f:float:4:1 f:float:5:1 f:float:
   while [ "$(jobs -r | wc -l)" -ge "${DE_BUILD_JOBS:-8}" ]; do sleep 0.2; done
   build_kernels de_grad_threaded.hip _obj/de_gt_$tag${gc}v$vs.o -DDE_GT_T=$ty -DDE_GT_TAG=$tag -DDE_GT_GC=$gc -DDE_GT_VS=$vs &
 done
+for spec in f:float d:double; do  # the reverse-accumulation kernel: one module per element type
+  IFS=: read tag ty <<< "$spec"
+  GT_OBJS="$GT_OBJS _obj/de_rt_$tag.o"
+  while [ "$(jobs -r | wc -l)" -ge "${DE_BUILD_JOBS:-8}" ]; do sleep 0.2; done
+  build_kernels de_rev_threaded.hip _obj/de_rt_$tag.o -DDE_RT_T=$ty -DDE_RT_TAG=$tag &
+done
 build_obj de_grad_kernels.hip _obj/de_grad_kernels.o &
 wait
 for o in _obj/de_lower.o _obj/de_bind.o _obj/de_api.o _obj/de_kernels.o _obj/de_grad_kernels.o $GT_OBJS; do [ -f $o ] || { echo "missing $o"; exit 1; }; done

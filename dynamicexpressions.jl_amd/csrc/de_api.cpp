@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <new>
 #include <string>
@@ -49,6 +50,8 @@ struct de_ctx {
     std::string err;
     const char *last_kernel = "";
     DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2, sGoff, sNg, sY, sW, sLoss, sPartial, sSeg, sDloss, sColOff, sDoff;
+    DevBuf sBcLoss, sBcDloss, sBcOk, sBcNg, sBcDoff, sBcOut; // de_eval_loss_grad_by_class
+    int nested = 0; // > 0 inside a call made of several inner calls: those do not touch the timing events
 };
 
 struct de_program {
@@ -107,10 +110,19 @@ struct de_program {
     // operand, the index of the instruction carrying its bits in bcode / tcode (eval source program) and in
     // gbcode / gtcode (unfolded program); -1 elsewhere.  Empty = not available (full rebuild instead).
     std::vector<int32_t> bsite, tsite, gbsite, gtsite_of_gb;
+    // reverse-accumulation form (de_rev_threaded.hip) for one gradient mode
+    std::vector<BoundInstr> rtcode;
+    std::vector<int32_t> rtcode_off, rtcode_mid, rtsite_of_gb;
+    BoundInstr *d_rtcode = nullptr;
+    int32_t *d_rtcode_off = nullptr, *d_rtcode_mid = nullptr, *d_rt_ids = nullptr;
+    int rt_mode = -1, rt_rows = 0, rt_stage_cols = 0;
+    bool rt_valid = false;
+    uint64_t rt_handler_base = 0;
+    uint32_t rt_param_off = 0;
     int gt_mode = -1;
     bool gt_valid = false;
     int gt_n_buckets = 0;
-    GradArgs::Bucket gt_buckets[16];
+    GradArgs::Bucket gt_buckets[24];
 };
 
 static int fail(de_ctx *c, int code, const char *fmt, ...) {
@@ -290,7 +302,7 @@ int de_ctx_destroy(de_ctx_t *c) {
     if (!c) return DE_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff}) b->release();
+    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff, &c->sBcLoss, &c->sBcDloss, &c->sBcOk, &c->sBcNg, &c->sBcDoff, &c->sBcOut}) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -695,6 +707,15 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
                 }
             }
             if (!tpatch) p->gt_valid = false;
+            if (p->rt_valid && !p->rtsite_of_gb.empty()) {
+                for (size_t i = 0; i < p->code.size(); i++) {
+                    const int32_t gj = p->gbsite[i];
+                    const int32_t rj = gj < 0 ? -1 : p->rtsite_of_gb[(size_t)gj];
+                    if (rj < 0) continue;
+                    p->rtcode[(size_t)rj].lo = p->code[i].imm.u32[0];
+                    p->rtcode[(size_t)rj].hi = p->code[i].imm.u32[1];
+                }
+            } else p->rt_valid = false;
         } else {
             p->gcode_stale = true;
         }
@@ -706,6 +727,8 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
                 HIP_TRY(ctx, hipMemcpy(p->d_gcode, p->gbcode.data(), p->gbcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
             if (p->gt_valid && !p->gtcode.empty())
                 HIP_TRY(ctx, hipMemcpy(p->d_gtcode, p->gtcode.data(), p->gtcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
+            if (p->rt_valid && !p->rtcode.empty())
+                HIP_TRY(ctx, hipMemcpy(p->d_rtcode, p->rtcode.data(), p->rtcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
         }
         return DE_OK;
     }
@@ -740,6 +763,8 @@ int de_program_destroy(de_program_t *p) {
     if (p->d_gtcode) (void)hipFree(p->d_gtcode);
     if (p->d_gtcode_off) (void)hipFree(p->d_gtcode_off);
     if (p->d_gt_ids) (void)hipFree(p->d_gt_ids);
+    for (void *q : {(void *)p->d_rtcode, (void *)p->d_rtcode_off, (void *)p->d_rtcode_mid, (void *)p->d_rt_ids})
+        if (q) (void)hipFree(q);
     if (p->d_ok_eval) (void)hipFree(p->d_ok_eval);
     delete p;
     return DE_OK;
@@ -1067,6 +1092,7 @@ static int ensure_generic_code(de_ctx *c, de_program *p) {
         // reference tests is tested (ee binding) whatever the eval options were
         p->gbcode.clear();
         p->gt_valid = false;
+        p->rt_valid = false;
         p->gbcode_off.assign((size_t)p->n_trees + 1, 0);
         for (int64_t t = 0; t < p->n_trees; t++) {
             const int32_t i0 = p->code_off[(size_t)t], i1 = p->code_off[(size_t)t + 1];
@@ -1108,8 +1134,10 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         // bucket of a tree: (width index 0..6 = single window of width 1,2,3,4,5,6,8; 7 = several windows of 8)
         // x (samples per lane - 1).  The two-sample modules exist for Float32 windows <= 6; their rows are
         // twice as long, so they only pay while a workgroup's LDS stays small: trees with <= 1 spill slot.
-        static const int WIDTH[8] = {1, 2, 3, 4, 5, 6, 8, 8};
-        constexpr int NB = 16;
+        // width index 0..6 = single window of width 1,2,3,4,5,6,8; 7,8,9 = several windows of 8,5,6 (the
+        // narrowest module that covers the gradient in ceil(G/8) windows: 9-10 rows -> 2x5, 11-12 -> 2x6, 17-18 -> 3x6)
+        static const int WIDTH[10] = {1, 2, 3, 4, 5, 6, 8, 8, 5, 6};
+        constexpr int NW = 10, NB = 2 * NW;
         const char *env2 = getenv("DE_GRAD_VS2_SLOTS"); // widest spill need that still runs two samples per lane
         const int vs2_slots = env2 ? atoi(env2) : 1;
         std::vector<int32_t> tslots((size_t)p->n_trees, 0); // spill slots of each tree (rows >= F the code names)
@@ -1128,9 +1156,16 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         }
         auto bucket_of = [&](int64_t t) {
             const int32_t G = ng[(size_t)t];
-            const int w = G <= 6 ? (G < 1 ? 0 : G - 1) : (G <= 8 ? 6 : 7);
-            const bool two = p->dtype == DE_F32 && w <= 5 && tslots[(size_t)t] <= vs2_slots && grad_threaded_has(p->dtype, WIDTH[w], 2);
-            return w + (two ? 8 : 0);
+            int w;
+            if (G <= 6) w = G < 1 ? 0 : G - 1;
+            else if (G <= 8) w = 6;
+            else {
+                const int windows = (G + 7) / 8, per = (G + windows - 1) / windows;
+                w = per <= 5 ? 8 : (per <= 6 ? 9 : 7);
+                if (!grad_threaded_has(p->dtype, WIDTH[w], 1)) w = 7;
+            }
+            const bool two = p->dtype == DE_F32 && WIDTH[w] <= 6 && tslots[(size_t)t] <= vs2_slots && grad_threaded_has(p->dtype, WIDTH[w], 2);
+            return w + (two ? NW : 0);
         };
         int32_t count[NB] = {0}, maxg[NB] = {0}, slots[NB] = {0};
         for (int64_t t = 0; t < p->n_trees; t++) {
@@ -1138,7 +1173,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             if (G > 240) return DE_OK; // gradient rows travel in 8 bits
             const int b = bucket_of(t);
             // Float64 states wider than 16 dwords are passed through scratch memory by the calling convention
-            if (!grad_threaded_has(p->dtype, WIDTH[b & 7], 1 + (b >> 3))) return DE_OK;
+            if (!grad_threaded_has(p->dtype, WIDTH[b % NW], 1 + b / NW)) return DE_OK;
             count[b]++;
             maxg[b] = std::max(maxg[b], G);
             slots[b] = std::max(slots[b], tslots[(size_t)t]);
@@ -1148,7 +1183,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         uint64_t bases[NB] = {0};
         for (int b = 0; b < NB; b++) {
             if (!count[b]) continue;
-            const int GC = WIDTH[b & 7], VS = 1 + (b >> 3);
+            const int GC = WIDTH[b % NW], VS = 1 + b / NW;
             const uint64_t RBb = 64ull * VS * es32; // one wave's row
             const uint64_t rows = (uint64_t)F + std::max<uint64_t>((uint64_t)slots[b] * (1 + GC), (uint64_t)GC);
             if (4 * rows * RBb > 160 * 1024) return DE_OK; // four waves' rows must fit the CU's LDS
@@ -1170,9 +1205,9 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         bool ok = true;
         for (int64_t t = 0; t < p->n_trees && ok; t++) {
             const int bkt = bucket_of(t);
-            const int GC = WIDTH[bkt & 7];
-            const uint32_t RB = 64u * (uint32_t)(1 + (bkt >> 3)) * es32; // bytes of one wave's row
-            const bool one_window = (bkt & 7) != 7; // then g0 = 0 and every seed is known here
+            const int GC = WIDTH[bkt % NW];
+            const uint32_t RB = 64u * (uint32_t)(1 + bkt / NW) * es32; // bytes of one wave's row
+            const bool one_window = bkt % NW < 7; // then g0 = 0 and every seed is known here
             const uint64_t *table = tables[bkt].data();
             const uint64_t base = bases[bkt];
             auto slot_off = [&](uint32_t row) { return (uint32_t)((F + (row - (uint32_t)F) * (1 + GC)) * RB); };
@@ -1257,15 +1292,15 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         for (int b = 0; b < NB; b++) {
             if (!count[b]) continue;
             GradArgs::Bucket &bk = p->gt_buckets[p->gt_n_buckets++];
-            bk.GC = WIDTH[b & 7];
-            bk.VS = 1 + (b >> 3);
-            bk.windows = (b & 7) == 7 ? (maxg[b] + 7) / 8 : 1;
+            bk.GC = WIDTH[b % NW];
+            bk.VS = 1 + b / NW;
+            bk.windows = b % NW >= 7 ? (maxg[b] + bk.GC - 1) / bk.GC : 1;
             bk.max_grad = maxg[b];
             bk.n_slots = slots[b];
             bk.ids = p->d_gt_ids + start[b];
             bk.n = count[b];
             bk.handler_base = bases[b];
-            bk.param_handler_off = (uint32_t)(tables[b][gop_param(WIDTH[b & 7])] - bases[b]);
+            bk.param_handler_off = (uint32_t)(tables[b][gop_param(WIDTH[b % NW])] - bases[b]);
         }
         p->gt_mode = mode;
         p->gt_valid = true;
@@ -1274,6 +1309,236 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
     g->e.code_off = p->d_gtcode_off;
     g->n_buckets = p->gt_n_buckets;
     for (int b = 0; b < p->gt_n_buckets; b++) g->buckets[b] = p->gt_buckets[b];
+    return DE_OK;
+}
+
+// Reverse-accumulation form of the gradient program (de_rev_threaded.hip) for `mode`: per tree the forward
+// instructions (every operator also stores its partials in LDS rows of its own), then the backward instructions
+// in execution order.  Fills g->rev_* when the program can be expressed this way (otherwise leaves rev_code
+// null and the forward-dual kernels run).  Call after ensure_generic_code().
+static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) {
+    g->rev_code = nullptr;
+    // Reverse accumulation costs two sweeps whatever the number of gradient rows; forward duals cost one sweep
+    // of (1 + rows) values (and one sweep per window of 8 rows).  Measured break-even on MI355X: ~8 rows per tree
+    // (20-node trees: 3.5 rows 12.3 ms forward / 19.8 ms reverse; 17 rows 80 ms / 46 ms).  DE_LOSS_GRAD_REVERSE=1|0 forces.
+    const char *env = getenv("DE_LOSS_GRAD_REVERSE");
+    if (env && *env == '0') return DE_OK;
+    if (!(env && *env == '1')) {
+        int64_t total = 0;
+        for (int64_t t = 0; t < p->n_trees; t++) total += de_program_n_grad(p, t, mode);
+        if (total < 8 * p->n_trees) return DE_OK;
+    }
+    const int F = p->n_features, P = p->n_params;
+    if (!(p->rt_valid && p->rt_mode == mode)) {
+        const uint32_t es32 = p->dtype == DE_F32 ? 4u : 8u, RB = 64u * es32;
+        const uint32_t PR0 = (uint32_t)F + (uint32_t)p->n_slots; // first partial row
+        uint64_t table[ROP_COUNT];
+        hipError_t hst = rev_handler_table(p->dtype, table);
+        if (hst != hipSuccess) return fail(c, DE_ERR_HIP, "reverse handler table: %s", hipGetErrorString(hst));
+        uint64_t base = table[0];
+        for (int i = 0; i < (int)ROP_COUNT; i++) base = std::min<uint64_t>(base, table[i]);
+        for (int i = 0; i < (int)ROP_COUNT; i++)
+            if (table[i] - base > 0xFFFFFFFFull) return DE_OK;
+        constexpr uint32_t NONE = 0xFFFFFFFFu, ACC = 0x80000000u;
+        auto leaf_col = [&](uint32_t f) -> uint32_t { return mode != DE_GRAD_CONSTANT ? (1u + (uint32_t)P + f) | ACC : NONE; };
+        auto param_col = [&](uint32_t r) -> uint32_t { return mode != DE_GRAD_CONSTANT ? (1u + r) | ACC : NONE; };
+        auto const_col = [&](uint32_t ord) -> uint32_t {
+            return mode == DE_GRAD_CONSTANT ? 1u + ord : (mode == DE_GRAD_BOTH ? 1u + (uint32_t)(P + F) + ord : NONE);
+        };
+        p->rtcode.clear();
+        p->rtcode_off.assign((size_t)p->n_trees + 1, 0);
+        p->rtcode_mid.assign((size_t)p->n_trees, 0);
+        p->rtsite_of_gb.assign(p->gbcode.size(), -1);
+        uint32_t max_prows = 0;
+        bool ok = true;
+        std::vector<BoundInstr> rv;
+        std::vector<uint8_t> rv_col; // rv[k] carries a gradient column word in .lo
+        std::map<uint32_t, std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> occ; // column -> (leaves, (seen, row))
+        auto mk = [&](uint32_t rop, uint32_t y, uint32_t z, uint32_t w) {
+            BoundInstr o;
+            o.bop = (uint32_t)(table[rop] - base);
+            o.arg = y;
+            o.lo = z;
+            o.hi = w;
+            return o;
+        };
+        for (int64_t t = 0; t < p->n_trees && ok; t++) {
+            uint32_t n_prows = 0;
+            rv.clear();
+            rv_col.clear();
+            auto alloc = [&](uint32_t n) { const uint32_t r = (PR0 + n_prows) * RB; n_prows += n; return r; };
+            auto F_ = [&](const BoundInstr &o) { p->rtcode.push_back(o); };
+            auto R_ = [&](const BoundInstr &o, bool has_col = false) { rv.push_back(o); rv_col.push_back(has_col ? 1 : 0); }; // pushed in forward order, reversed below
+            // backward of "acc' = op(acc, operand)" whose partial rows (d/d acc, d/d operand) start at pr
+            auto back_binary = [&](int pk, uint32_t pr, bool slot, uint32_t slot_byte, uint32_t col) {
+                if (slot) R_(mk(rop_rbin(pk, 0), pk == 0 ? pr : 0, slot_byte, 0));
+                else if (col != NONE) R_(mk(rop_rbin(pk, 1), pk == 0 ? pr : 0, col, 0), true);
+                else if (pk == 0) R_(mk(ROP_R_UN, pr, 0, 0));
+                else if (pk == 3) R_(mk(ROP_R_NEG, 0, 0, 0));
+            };
+            // backward of "acc' = f(leaf)": first the unary partial, then the leaf's row — pushed in reverse
+            auto back_unary_leaf = [&](uint32_t pr, uint32_t col) {
+                if (col != NONE) R_(mk(ROP_R_LEAF, 0, col, 0), true);
+                R_(mk(ROP_R_UN, pr, 0, 0));
+            };
+            for (int32_t i = p->gbcode_off[(size_t)t]; i < p->gbcode_off[(size_t)t + 1] && ok; i++) {
+                const BoundInstr &b = p->gbcode[(size_t)i];
+                const uint32_t row = b.arg & 0xFFFFFFu, aux = b.arg >> 24, ord = b.arg & 0xFFFFu;
+                const bool is_leaf = row < (uint32_t)F;
+                if (b.bop == BOP_CHECK_ROW) continue; // leaf operands are tested where they are read
+                if (b.bop == BOP_LOAD_ROW) {
+                    if (!is_leaf) { ok = false; break; }
+                    F_(mk(rop_load(RSRC_LEAF), row * RB, 0, 0));
+                    if (leaf_col(row) != NONE) R_(mk(ROP_R_LEAF, 0, leaf_col(row), 0), true);
+                } else if (b.bop == BOP_LOAD_CONST) {
+                    p->rtsite_of_gb[(size_t)i] = (int32_t)p->rtcode.size();
+                    F_(mk(rop_load(RSRC_CONST), 0, b.lo, b.hi));
+                    if (const_col(ord) != NONE) R_(mk(ROP_R_LEAF, 0, const_col(ord), 0), true);
+                } else if (b.bop == BOP_PUSH) {
+                    F_(mk(ROP_PUSH, row * RB, 0, 0));
+                    R_(mk(ROP_R_POP, row * RB, 0, 0));
+                } else if (b.bop == BOP_CHECK_ACC) {
+                    F_(mk(ROP_CHECK, 0, 0, 0));
+                } else if (b.bop >= BOP_BIN_BASE && b.bop < BOP_BIN_END) {
+                    const uint32_t v = b.bop - BOP_BIN_BASE;
+                    const int k = (int)(v >> 2);
+                    const bool cst = (v & 2) != 0, chk = (v & 1) != 0;
+                    const uint32_t pr = k >= 3 ? alloc(2) : 0;
+                    const int pk = k == 0 ? 1 : (k == 1 ? 2 : (k == 2 ? 3 : 0));
+                    if (cst) {
+                        p->rtsite_of_gb[(size_t)i] = (int32_t)p->rtcode.size();
+                        F_(mk(rop_bin(k, RSRC_CONST, chk), pr, b.lo, b.hi));
+                        back_binary(pk, pr, false, 0, const_col(ord));
+                    } else {
+                        F_(mk(rop_bin(k, is_leaf ? RSRC_LEAF : RSRC_SLOT, chk), row * RB, pr, 0));
+                        back_binary(pk, pr, !is_leaf, row * RB, is_leaf ? leaf_col(row) : NONE);
+                    }
+                } else if (b.bop >= BOP_UN_BASE && b.bop < BOP_UN_END) {
+                    const uint32_t v = b.bop - BOP_UN_BASE;
+                    const int k = (int)(v >> 2);
+                    const bool from_row = (v & 2) != 0, chk = (v & 1) != 0;
+                    const uint32_t pr = alloc(1);
+                    if (from_row) {
+                        if (!is_leaf) { ok = false; break; }
+                        F_(mk(rop_un(k, RSRC_LEAF, chk), row * RB, pr, 0));
+                        back_unary_leaf(pr, leaf_col(row));
+                    } else {
+                        F_(mk(rop_un(k, RSRC_ACC, chk), pr, 0, 0));
+                        R_(mk(ROP_R_UN, pr, 0, 0));
+                    }
+                } else if (b.bop == BOP_GEN_ROW) {
+                    const bool unary = aux < (uint32_t)DE_B_ADD;
+                    const uint32_t pr = alloc(unary ? 1 : 2);
+                    if (unary && !is_leaf) { ok = false; break; }
+                    F_(mk(rop_gen(is_leaf ? RSRC_LEAF : RSRC_SLOT), row * RB, pr | (aux << 24), 0));
+                    if (unary) back_unary_leaf(pr, leaf_col(row));
+                    else back_binary(0, pr, !is_leaf, row * RB, is_leaf ? leaf_col(row) : NONE);
+                } else if (b.bop == BOP_GEN_CONST) {
+                    const bool unary = aux < (uint32_t)DE_B_ADD;
+                    const uint32_t pr = alloc(unary ? 1 : 2);
+                    p->rtsite_of_gb[(size_t)i] = (int32_t)p->rtcode.size();
+                    F_(mk(rop_gen(RSRC_CONST), pr | (aux << 24), b.lo, b.hi));
+                    if (unary) back_unary_leaf(pr, const_col(ord));
+                    else back_binary(0, pr, false, 0, const_col(ord));
+                } else if (b.bop == BOP_GEN_ACC) {
+                    const uint32_t pr = alloc(1);
+                    F_(mk(rop_gen(RSRC_ACC), pr | (aux << 24), 0, 0));
+                    R_(mk(ROP_R_UN, pr, 0, 0));
+                } else if (b.bop == BOP_GEN_PARAM) {
+                    const uint32_t prm = b.arg & 0xFFFFu;
+                    if (aux == (uint32_t)DOP_LOAD) {
+                        F_(mk(ROP_PARAM, prm | (aux << 24), 0, 0));
+                        if (param_col(prm) != NONE) R_(mk(ROP_R_LEAF, 0, param_col(prm), 0), true);
+                    } else {
+                        const bool unary = aux < (uint32_t)DE_B_ADD;
+                        const uint32_t pr = alloc(unary ? 1 : 2);
+                        F_(mk(ROP_PARAM, prm | (aux << 24), pr, 0));
+                        if (unary) back_unary_leaf(pr, param_col(prm));
+                        else back_binary(0, pr, false, 0, param_col(prm));
+                    }
+                } else if (b.bop == BOP_TERN) {
+                    if (is_leaf || b.lo < (uint32_t)F || row > 0xFFFFu || b.lo > 0xFFFFu) { ok = false; break; }
+                    const uint32_t pr = alloc(3);
+                    F_(mk(ROP_TERN, pr | (aux << 24), row | (b.lo << 16), 0));
+                    R_(mk(ROP_R_TERN, pr, row | (b.lo << 16), 0));
+                } else ok = false; // INJ_*: only bound with early_exit=false, never for gradients
+            }
+            if (!ok) break;
+            p->rtcode_mid[(size_t)t] = (int32_t)p->rtcode.size();
+            // Gradient rows several leaves share (features, parameters): the leaves' contributions are added per
+            // SAMPLE in an LDS row and reduced once, at the last of them — paths that cancel within a sample then
+            // cancel before the reduction, as they do in the forward Jacobian.
+            // column word: [15:0] column, [29:16] accumulation row, [31:30] 0 reduce now, 1 first, 2 middle, 3 last
+            occ.clear();
+            for (size_t k = 0; k < rv.size(); k++)
+                if (rv_col[k] && (rv[k].lo & ACC)) occ[rv[k].lo & 0xFFFFu].first++;
+            uint32_t n_acc = 0;
+            for (size_t k = rv.size(); k-- > 0;) { // execution order
+                BoundInstr o = rv[k];
+                if (rv_col[k]) {
+                    const uint32_t col = o.lo & 0xFFFFu;
+                    if ((o.lo & 0x7FFFFFFFu) > 0xFFFFu) { ok = false; break; }
+                    uint32_t word = col;
+                    if (o.lo & ACC) {
+                        auto &oc = occ[col];
+                        if (oc.first > 1) {
+                            if (oc.second.first == 0) oc.second.second = n_acc++;
+                            const uint32_t nth = ++oc.second.first;
+                            const uint32_t md = nth == 1 ? 1u : (nth == oc.first ? 3u : 2u);
+                            word = col | ((PR0 + n_prows + oc.second.second) << 16) | (md << 30);
+                        }
+                    }
+                    o.lo = word;
+                }
+                p->rtcode.push_back(o);
+            }
+            if (!ok) break;
+            if (PR0 + n_prows + n_acc > 0x3FFFu) { ok = false; break; }
+            p->rtcode_off[(size_t)t + 1] = (int32_t)p->rtcode.size();
+            max_prows = std::max(max_prows, n_prows + n_acc);
+        }
+        // per-wave staging of the column sums: one LDS row, or the widest tree's columns
+        int64_t stage_cols = 64;
+        for (int64_t t = 0; t < p->n_trees; t++) stage_cols = std::max<int64_t>(stage_cols, 1 + de_program_n_grad(p, t, mode));
+        const uint64_t stage_rows = ((uint64_t)stage_cols * es32 + RB - 1) / RB;
+        const uint64_t rows = (uint64_t)PR0 + max_prows + stage_rows;
+        if (!ok || 4 * rows * RB > 160 * 1024 || rows * RB >= (1u << 24)) { p->rtsite_of_gb.clear(); return DE_OK; }
+        std::vector<int32_t> ids((size_t)p->n_trees);
+        for (int64_t t = 0; t < p->n_trees; t++) ids[(size_t)t] = (int32_t)t;
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); // the previous form may be in use by queued work
+        if (p->d_rtcode) { // sizes depend on the mode
+            (void)hipFree(p->d_rtcode);
+            p->d_rtcode = nullptr;
+        }
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_rtcode), (p->rtcode.size() + 1) * sizeof(BoundInstr)));
+        HIP_TRY(c, hipMemset(p->d_rtcode, 0, (p->rtcode.size() + 1) * sizeof(BoundInstr)));
+        if (!p->d_rtcode_off) {
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_rtcode_off), p->rtcode_off.size() * sizeof(int32_t)));
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_rtcode_mid), std::max<size_t>(p->rtcode_mid.size(), 1) * sizeof(int32_t)));
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_rt_ids), std::max<size_t>(ids.size(), 1) * sizeof(int32_t)));
+        }
+        if (!p->rtcode.empty())
+            HIP_TRY(c, hipMemcpy(p->d_rtcode, p->rtcode.data(), p->rtcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(p->d_rtcode_off, p->rtcode_off.data(), p->rtcode_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (!ids.empty()) {
+            HIP_TRY(c, hipMemcpy(p->d_rtcode_mid, p->rtcode_mid.data(), p->rtcode_mid.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(p->d_rt_ids, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        p->rt_rows = (int)rows;
+        p->rt_stage_cols = (int)stage_cols;
+        p->rt_handler_base = base;
+        p->rt_param_off = (uint32_t)(table[ROP_PARAM] - base);
+        p->rt_mode = mode;
+        p->rt_valid = true;
+    }
+    g->rev_code = p->d_rtcode;
+    g->rev_code_off = p->d_rtcode_off;
+    g->rev_code_mid = p->d_rtcode_mid;
+    g->rev_ids = p->d_rt_ids;
+    g->rev_rows = p->rt_rows;
+    g->rev_stage_cols = p->rt_stage_cols;
+    g->rev_handler_base = p->rt_handler_base;
+    g->rev_param_off = p->rt_param_off;
     return DE_OK;
 }
 
@@ -1470,8 +1735,6 @@ int de_eval_loss_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, in
         HIP_TRY(c, hipMemcpy(ok, p->host_ok_grad.data(), (size_t)p->n_trees, hipMemcpyDefault));
         return DE_OK;
     }
-    const size_t lds_need = ((size_t)p->n_features + (size_t)p->n_slots * (1 + (size_t)std::min(maxg, 8))) * 260 * es;
-    if (lds_need > 160 * 1024) return fail(c, DE_ERR_UNSUPPORTED, "gradient kernel: LDS footprint too large for this tree shape");
     rc = ensure_generic_code(c, p);
     if (rc) return rc;
 
@@ -1555,11 +1818,18 @@ int de_eval_loss_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, in
     g.n_cols = n_cols;
     g.dloss = sDl.dev;
     g.dloss_off = static_cast<const int64_t *>(c->sDoff.p);
-    rc = ensure_grad_threaded(c, p, mode, ng, &g);
+    rc = ensure_rev_threaded(c, p, mode, &g);
     if (rc) return rc;
-    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(c, launch_grad(p->dtype, g, c->stream, &c->last_kernel));
-    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    if (!g.rev_code) {
+        const size_t lds_need = ((size_t)p->n_features + (size_t)p->n_slots * (1 + (size_t)std::min(maxg, 8))) * 260 * es;
+        if (lds_need > 160 * 1024) return fail(c, DE_ERR_UNSUPPORTED, "gradient kernel: LDS footprint too large for this tree shape");
+        rc = ensure_grad_threaded(c, p, mode, ng, &g);
+        if (rc) return rc;
+    }
+    if (!c->nested) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (g.rev_code) HIP_TRY(c, launch_rev_threaded(p->dtype, g, c->stream, &c->last_kernel));
+    else HIP_TRY(c, launch_grad(p->dtype, g, c->stream, &c->last_kernel));
+    if (!c->nested) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     if (sLoss.staged) HIP_TRY(c, hipMemcpyAsync(loss, sLoss.dev, (size_t)p->n_trees * es, hipMemcpyDeviceToHost, c->stream));
     if (sDl.staged)
@@ -1571,6 +1841,107 @@ int de_eval_loss_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, in
     if (sOk.staged) HIP_TRY(c, hipMemcpyAsync(ok, sOk.dev, (size_t)p->n_trees, hipMemcpyDeviceToHost, c->stream));
     if (sX.staged || sY.staged || sW.staged || sLoss.staged || sDl.staged || sOk.staged || sPar.staged || sCls.staged)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DE_OK;
+}
+
+int de_eval_loss_grad_by_class(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX,
+                               const de_param_args_t *pa, int mode, const void *y, const void *w, int32_t loss_kind,
+                               const int64_t *class_starts, void *loss, void *dloss, const int64_t *dloss_offsets,
+                               void *dparams, uint8_t *ok) {
+    if (!c || !p) return DE_ERR_INVALID_ARG;
+    if (p->ctx != c) return fail(c, DE_ERR_INVALID_ARG, "program belongs to another context");
+    if (p->n_params <= 0 || !pa) return fail(c, DE_ERR_INVALID_ARG, "not a parametric population (n_params = 0 or no parameter arguments)");
+    if (mode != DE_GRAD_VARIABLE && mode != DE_GRAD_BOTH)
+        return fail(c, DE_ERR_INVALID_ARG, "by-class reduction needs a mode with parameter rows (DE_GRAD_VARIABLE / DE_GRAD_BOTH)");
+    if (!pa->params || !pa->classes || pa->ld_params < p->n_params || pa->n_classes <= 0)
+        return fail(c, DE_ERR_INVALID_ARG, "bad parameter arguments");
+    if (N < 0 || !ok || !class_starts || (p->n_trees > 0 && (!dloss || !dparams))) return fail(c, DE_ERR_INVALID_ARG, "null buffer");
+    const int64_t C = pa->n_classes;
+    if (class_starts[0] != 0 || class_starts[C] != N) return fail(c, DE_ERR_INVALID_ARG, "class_starts must run from 0 to N");
+    for (int64_t k = 0; k < C; k++)
+        if (class_starts[k + 1] < class_starts[k]) return fail(c, DE_ERR_INVALID_ARG, "class_starts must be non-decreasing");
+    if (p->n_trees == 0) return DE_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t es = p->dtype == DE_F32 ? 4 : 8;
+    const int P = p->n_params;
+    std::vector<int32_t> ng((size_t)p->n_trees);
+    std::vector<int64_t> doff((size_t)p->n_trees);
+    int64_t span = 0, run = 0;
+    for (int64_t t = 0; t < p->n_trees; t++) {
+        const int32_t g = (int32_t)de_program_n_grad(p, t, mode);
+        ng[(size_t)t] = g;
+        const int64_t off = dloss_offsets ? dloss_offsets[t] : run;
+        if (off < 0) return fail(c, DE_ERR_INVALID_ARG, "negative dloss offset");
+        doff[(size_t)t] = off;
+        run += g;
+        span = std::max(span, off + g);
+    }
+    span = std::max<int64_t>(span, 1);
+    HIP_TRY(c, c->sBcLoss.reserve((size_t)C * (size_t)p->n_trees * es));
+    HIP_TRY(c, c->sBcDloss.reserve((size_t)C * (size_t)span * es));
+    HIP_TRY(c, c->sBcOk.reserve((size_t)C * (size_t)p->n_trees));
+    HIP_TRY(c, c->sBcNg.reserve(ng.size() * sizeof(int32_t)));
+    HIP_TRY(c, c->sBcDoff.reserve(doff.size() * sizeof(int64_t)));
+    HIP_TRY(c, hipMemcpyAsync(c->sBcNg.p, ng.data(), ng.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->sBcDoff.p, doff.data(), doff.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    // dloss entries no tree owns (caller-chosen offsets) are never read by the combine pass
+    HIP_TRY(c, hipMemsetAsync(c->sBcDloss.p, 0, (size_t)C * (size_t)span * es, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    c->nested++;
+    int rc = DE_OK;
+    const size_t cls_es = pa->classes_is_i64 ? 8 : 4;
+    for (int64_t k = 0; k < C && rc == DE_OK; k++) {
+        const int64_t j0 = class_starts[k], n = class_starts[k + 1] - j0;
+        de_param_args_t sub = *pa;
+        sub.classes = static_cast<const char *>(pa->classes) + (size_t)j0 * cls_es;
+        rc = de_eval_loss_grad(c, p, static_cast<const char *>(X) + (size_t)j0 * (size_t)ldX * es, n, ldX, &sub, mode,
+                               y ? static_cast<const char *>(y) + (size_t)j0 * es : nullptr,
+                               w ? static_cast<const char *>(w) + (size_t)j0 * es : nullptr, loss_kind,
+                               static_cast<char *>(c->sBcLoss.p) + (size_t)k * (size_t)p->n_trees * es,
+                               static_cast<char *>(c->sBcDloss.p) + (size_t)k * (size_t)span * es, dloss_offsets,
+                               static_cast<uint8_t *>(c->sBcOk.p) + (size_t)k * (size_t)p->n_trees);
+    }
+    c->nested--;
+    if (rc != DE_OK) return rc;
+    Staged sLoss, sDl, sDp, sOk;
+    if (loss) {
+        rc = stage_out(c, c->sLoss, loss, (size_t)p->n_trees * es, &sLoss);
+        if (rc) return rc;
+    }
+    rc = stage_out(c, c->sDloss, dloss, (size_t)span * es, &sDl);
+    if (rc) return rc;
+    const size_t dp_bytes = (size_t)p->n_trees * (size_t)C * (size_t)P * es;
+    rc = stage_out(c, c->sBcOut, dparams, dp_bytes, &sDp);
+    if (rc) return rc;
+    rc = stage_out(c, c->sOk, ok, (size_t)p->n_trees, &sOk);
+    if (rc) return rc;
+    ByClassArgs a;
+    a.loss_c = c->sBcLoss.p;
+    a.dloss_c = c->sBcDloss.p;
+    a.ok_c = static_cast<const uint8_t *>(c->sBcOk.p);
+    a.n_classes = (int32_t)C;
+    a.n_params = P;
+    a.n_trees = p->n_trees;
+    a.span = span;
+    a.n_grad = static_cast<const int32_t *>(c->sBcNg.p);
+    a.dloss_off = static_cast<const int64_t *>(c->sBcDoff.p);
+    a.loss = loss ? sLoss.dev : nullptr;
+    a.dloss = sDl.dev;
+    a.dparams = sDp.dev;
+    a.ok = static_cast<uint8_t *>(sOk.dev);
+    HIP_TRY(c, launch_by_class_combine(p->dtype, a, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    if (sLoss.staged) HIP_TRY(c, hipMemcpyAsync(loss, sLoss.dev, (size_t)p->n_trees * es, hipMemcpyDeviceToHost, c->stream));
+    if (sDl.staged)
+        for (int64_t t = 0; t < p->n_trees; t++)
+            if (ng[(size_t)t] > 0)
+                HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(dloss) + (size_t)doff[(size_t)t] * es,
+                                          static_cast<char *>(sDl.dev) + (size_t)doff[(size_t)t] * es, (size_t)ng[(size_t)t] * es,
+                                          hipMemcpyDeviceToHost, c->stream));
+    if (sDp.staged) HIP_TRY(c, hipMemcpyAsync(dparams, sDp.dev, dp_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (sOk.staged) HIP_TRY(c, hipMemcpyAsync(ok, sOk.dev, (size_t)p->n_trees, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // ng/doff (pageable) were copied asynchronously
     return DE_OK;
 }
 

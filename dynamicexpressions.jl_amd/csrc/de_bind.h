@@ -41,6 +41,32 @@ enum BoundOp : uint32_t {
     BOP_COUNT
 };
 
+// Handler ids of the reverse-accumulation kernel (de_rev_threaded.hip).  Operand kinds RSRC_*; hot binary
+// K = 0 ADD, 1 SUB, 2 RSUB, 3 MUL, 4 DIV, 5 RDIV; hot unary K = 0 cos, 1 exp, 2 sin.
+enum { RSRC_LEAF = 0, RSRC_SLOT = 1, RSRC_CONST = 2, RSRC_ACC = 3 };
+enum RevOp : uint32_t {
+    ROP_LOAD_BASE = 0,                 // + src (LEAF, SLOT, CONST)
+    ROP_PUSH = 3,
+    ROP_CHECK = 4,
+    ROP_BIN_BASE = 5,                  // + ((K*3 + src)*2 + checked)
+    ROP_UN_BASE = ROP_BIN_BASE + 36,   // + ((K*2 + (src == LEAF))*2 + checked)
+    ROP_GEN_BASE = ROP_UN_BASE + 12,   // + src (LEAF, SLOT, CONST, ACC)
+    ROP_TERN = ROP_GEN_BASE + 4,
+    ROP_PARAM,
+    ROP_R_UN,                          // backward: adjoint *= partial
+    ROP_R_NEG,
+    ROP_R_POP,
+    ROP_R_LEAF,
+    ROP_R_BIN_BASE,                    // + PK*2 + OK   (PK: 0 partial rows, 1 ADD, 2 SUB, 3 RSUB; OK: 0 slot, 1 column)
+    ROP_R_TERN = ROP_R_BIN_BASE + 8,
+    ROP_COUNT
+};
+constexpr uint32_t rop_load(int src) { return ROP_LOAD_BASE + (uint32_t)src; }
+constexpr uint32_t rop_bin(int k, int src, bool chk) { return ROP_BIN_BASE + (uint32_t)((k * 3 + src) * 2 + (chk ? 1 : 0)); }
+constexpr uint32_t rop_un(int k, int src, bool chk) { return ROP_UN_BASE + (uint32_t)((k * 2 + (src == RSRC_LEAF ? 1 : 0)) * 2 + (chk ? 1 : 0)); }
+constexpr uint32_t rop_gen(int src) { return ROP_GEN_BASE + (uint32_t)src; }
+constexpr uint32_t rop_rbin(int pk, int ok) { return ROP_R_BIN_BASE + (uint32_t)(pk * 2 + ok); }
+
 struct alignas(16) BoundInstr {
     uint32_t bop;
     uint32_t arg; // [23:0] LDS row index / parameter row / constant ordinal (constant operands); [31:24] de_opcode for generic handlers

@@ -381,6 +381,42 @@ template <typename T> static hipError_t launch_grad_dt(const GradArgs &ga, hipSt
     return launch_grad_t<T, 8>(ga, (maxg + 7) / 8, stream);
 }
 
+// ---- de_eval_loss_grad_by_class: fold the per-class passes into the outputs ---------------------------
+// One thread per tree; classes are added in index order, in double: reproducible.
+template <typename T>
+__global__ void __launch_bounds__(256) de_by_class_combine_kernel(const ByClassArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.n_trees) return;
+    const T *loss_c = static_cast<const T *>(a.loss_c), *dloss_c = static_cast<const T *>(a.dloss_c);
+    T *dloss = static_cast<T *>(a.dloss), *dparams = static_cast<T *>(a.dparams);
+    const int C = a.n_classes, P = a.n_params, G = a.n_grad[t];
+    const int64_t off = a.dloss_off[t];
+    bool ok = true;
+    for (int c = 0; c < C; c++) ok = ok && a.ok_c[(int64_t)c * a.n_trees + t] != 0;
+    a.ok[t] = ok ? 1 : 0;
+    const T nan = T(__builtin_nan(""));
+    if (a.loss) {
+        double s = 0.0;
+        for (int c = 0; c < C; c++) s += (double)loss_c[(int64_t)c * a.n_trees + t];
+        static_cast<T *>(a.loss)[t] = ok ? (T)s : nan; // incomplete evaluations are NaN-filled (src/EvaluationHelpers.jl:29-33)
+    }
+    for (int k = 0; k < G; k++) {
+        double s = 0.0;
+        for (int c = 0; c < C; c++) {
+            const T v = dloss_c[(int64_t)c * a.span + off + k];
+            s += (double)v;
+            if (k < P) dparams[((int64_t)t * C + c) * P + k] = ok ? v : nan;
+        }
+        dloss[off + k] = ok ? (T)s : nan;
+    }
+}
+hipError_t launch_by_class_combine(int dtype, const ByClassArgs &a, hipStream_t stream) {
+    const dim3 grid((unsigned)((a.n_trees + 255) / 256));
+    if (dtype == DE_F32) hipLaunchKernelGGL(de_by_class_combine_kernel<float>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(de_by_class_combine_kernel<double>, grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 // ---- threaded variant: one module per (type, window, samples per lane) — de_grad_threaded.hip ----------
 #define DE_GT_DECL(TAG, GC, V)                                                       \
     hipError_t grad_thr_fetch_##TAG##GC##v##V(uint64_t *host_table);                  \
@@ -436,6 +472,31 @@ hipError_t launch_grad_threaded(int dtype, const GradArgs &a, hipStream_t stream
     }
     if (!a.loss) return hipSuccess;
     return launch_loss_grad_finish(dtype, a, (a.e.N + GBLK - 1) / GBLK, stream);
+}
+
+// ---- reverse accumulation: one module per element type (de_rev_threaded.hip) --------------------------
+hipError_t rev_thr_fetch_f(uint64_t *host_table);
+hipError_t rev_thr_fetch_d(uint64_t *host_table);
+hipError_t rev_thr_launch_f(const GradArgs &ga, hipStream_t stream);
+hipError_t rev_thr_launch_d(const GradArgs &ga, hipStream_t stream);
+hipError_t rev_handler_table(int dtype, uint64_t *table) {
+    static uint64_t cache[2][ROP_COUNT];
+    static bool have[2] = {false, false};
+    const int k = dtype == DE_F32 ? 0 : 1;
+    if (!have[k]) {
+        const hipError_t st = k == 0 ? rev_thr_fetch_f(cache[k]) : rev_thr_fetch_d(cache[k]);
+        if (st != hipSuccess) return st;
+        have[k] = true;
+    }
+    for (int i = 0; i < (int)ROP_COUNT; i++) table[i] = cache[k][i];
+    return hipSuccess;
+}
+hipError_t launch_rev_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name) {
+    if (kernel_name) *kernel_name = "de_rev_threaded_kernel";
+    const int64_t n_tiles = (a.e.N + GBLK - 1) / GBLK;
+    const hipError_t st = dtype == DE_F32 ? rev_thr_launch_f(a, stream) : rev_thr_launch_d(a, stream);
+    if (st != hipSuccess) return st;
+    return launch_loss_grad_finish(dtype, a, n_tiles, stream);
 }
 
 hipError_t launch_grad(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name) {

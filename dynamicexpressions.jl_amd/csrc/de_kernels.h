@@ -72,6 +72,15 @@ struct GradArgs {
     // threaded-code variant (de_grad_threaded.hip): non-null = use it.  Trees are grouped into buckets by
     // gradient width; each bucket is one launch of the module built for its window width.
     const BoundInstr *threaded_code;
+    // reverse accumulation (de_rev_threaded.hip; fused loss + gradient only): forward + backward instruction
+    // stream per tree, null = not available
+    const BoundInstr *rev_code;
+    const int32_t *rev_code_off, *rev_code_mid; // n_trees + 1 / n_trees
+    const int32_t *rev_ids;                     // device: evaluation order of the trees
+    int32_t rev_rows;                           // LDS rows per wave (staging included)
+    int32_t rev_stage_cols;                     // column sums a wave stages in LDS between two writes
+    uint64_t rev_handler_base;
+    uint32_t rev_param_off;
     int32_t n_buckets;
     struct Bucket {
         int32_t GC, VS;                // module: window width, samples per lane
@@ -81,7 +90,7 @@ struct GradArgs {
         int32_t n;
         uint64_t handler_base;
         uint32_t param_handler_off;
-    } buckets[16];
+    } buckets[24];
 };
 
 // Returns hipSuccess or the failing HIP error.  `kernel_name` receives the symbol
@@ -93,9 +102,23 @@ hipError_t launch_grad(int dtype, const GradArgs &a, hipStream_t stream, const c
 // handler addresses for (dtype, window), launch; pass 2+3 of the fused loss-gradient reduction.
 int grad_window(int max_grad);
 hipError_t grad_handler_table(int dtype, int GC, int VS, uint64_t *table); // GOP_MAX entries, gop_count(GC) used
-bool grad_threaded_has(int dtype, int GC, int VS);                            // is there a module for (type, window, samples per lane)?
+bool grad_threaded_has(int dtype, int GC, int VS);
+hipError_t rev_handler_table(int dtype, uint64_t *table); // ROP_COUNT entries
+hipError_t launch_rev_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name);                            // is there a module for (type, window, samples per lane)?
 hipError_t launch_grad_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name);
 hipError_t launch_loss_grad_finish(int dtype, const GradArgs &ga, int64_t n_tiles, hipStream_t stream);
+// de_eval_loss_grad_by_class: per-class results ([C][n_trees] losses and flags, [C][span] gradients) -> outputs
+struct ByClassArgs {
+    const void *loss_c, *dloss_c;
+    const uint8_t *ok_c;
+    int32_t n_classes, n_params;
+    int64_t n_trees, span;
+    const int32_t *n_grad;   // device
+    const int64_t *dloss_off; // device
+    void *loss, *dloss, *dparams; // loss may be null
+    uint8_t *ok;
+};
+hipError_t launch_by_class_combine(int dtype, const ByClassArgs &a, hipStream_t stream);
 
 // Threaded-code eval kernel: addresses of the TOP_COUNT device handlers (cached per process).
 hipError_t eval_handler_table(int dtype, uint64_t *table);

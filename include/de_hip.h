@@ -255,6 +255,26 @@ int de_eval_loss_grad(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t 
                       int32_t loss_kind, void *loss, void *dloss, const int64_t *dloss_offsets,
                       uint8_t *ok);
 
+/* Fused loss + gradient of a PARAMETRIC population with the parameter rows reduced BY CLASS:
+ *   dparams[(t*n_classes + c)*n_params + p] = sum_{j : class_j = c} w_j l'(e_j) d tree_t(x_j) / d params[p, c]
+ * i.e. the gradient w.r.t. the [n_params, n_classes] parameter matrix of tree t (column-major, like
+ * `params`) — what Zygote returns for `ex.metadata.parameters` when it differentiates through the
+ * reference's gather `parameters[i, classes[j]]` (src/ParametricExpression.jl:381-389; known answer
+ * test/test_parametric_expression.jl:326-372; the optimiser's combined vector is
+ * vcat(constants, parameters[:]), :260-265).  `mode` is DE_GRAD_VARIABLE or DE_GRAD_BOTH (the modes
+ * that have parameter rows); loss / dloss / ok are exactly de_eval_loss_grad's (the parameter rows of
+ * dloss hold the sum over all classes).
+ *
+ * The samples must be GROUPED BY CLASS: class_starts[c] .. class_starts[c+1] (host array of
+ * n_classes + 1 sample offsets, class_starts[0] = 0, class_starts[n_classes] = N) holds the samples
+ * whose class id is class_base + c.  Classes are part of the dataset, so the shim orders the dataset
+ * once (api.py / the Julia extension do).  The call runs one fused pass per class over its sample
+ * range — a segmented, fixed-order (reproducible) reduction instead of a scatter with atomics. */
+int de_eval_loss_grad_by_class(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, int64_t ldX,
+                               const de_param_args_t *pargs, int mode, const void *y, const void *w,
+                               int32_t loss_kind, const int64_t *class_starts, void *loss, void *dloss,
+                               const int64_t *dloss_offsets, void *dparams, uint8_t *ok);
+
 /* ---- one-shot convenience with the reference's single-tree signature ------- */
 int de_eval_tree_array(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, int64_t n_nodes,
                        const void *consts, int64_t n_consts, const void *X, int32_t n_features,

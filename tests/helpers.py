@@ -130,3 +130,77 @@ def parity_tolerance(tree, ops, X, dtype, options=7, params=None, classes0=None,
         tol = base + 8.0 * spread
         chaotic = ~np.isfinite(clean) | ~(spread <= 1e-3 * np.abs(clean) + (1e-30 if dtype == np.float32 else 1e-290))
         return np.where(chaotic, np.inf, tol)
+
+
+def path_abs_jacobian(tree, ops, X, mode, params=None, classes=None, class_base=1):
+    """[n_grad, N] float64: for every gradient row the sum over the root-to-leaf paths of |product of the partials|
+    — the conditioning of a gradient entry however the products and sums are associated (forward duals add the
+    paths of a sample in tree order, reverse accumulation leaf by leaf).  Equals |Jacobian| when no two paths of
+    a row cancel.  Rows as de_eval_grad: mode "variable": (params,) features; "constant": constants; "both":
+    (params,) features, constants.  Returns None for an operator without an entry in the small table below."""
+    X = np.asarray(X, dtype=np.float64)
+    F, N = X.shape
+    P = 0 if params is None else np.asarray(params).shape[0]
+    consts = [n for n in _leaves_in_order(tree) if n.constant]
+    n_c = len(consts)
+    ord_of = {id(n): k for k, n in enumerate(consts)}
+    G = {"variable": P + F, "constant": n_c, "both": P + F + n_c}[mode]
+
+    def row_of(n):
+        if getattr(n, "is_parameter", False):
+            return None if mode == "constant" else n.parameter - 1
+        if n.constant:
+            return None if mode == "variable" else (ord_of[id(n)] if mode == "constant" else P + F + ord_of[id(n)])
+        return None if mode == "constant" else P + n.feature - 1
+
+    def rec(n):
+        if n.degree == 0:
+            if getattr(n, "is_parameter", False):
+                v = np.asarray(params, dtype=np.float64)[n.parameter - 1, np.asarray(classes) - class_base]
+            elif n.constant:
+                v = np.full(N, n.val)
+            else:
+                v = X[n.feature - 1]
+            d = np.zeros((G, N))
+            r = row_of(n)
+            if r is not None:
+                d[r] = 1.0
+            return v, d
+        name = ops.ops[n.degree - 1][n.op - 1]
+        kids = [rec(c) for c in n.children]
+        if kids[0] is None or (n.degree == 2 and kids[1] is None):
+            return None
+        with np.errstate(all="ignore"):
+            if n.degree == 1:
+                x, dx = kids[0]
+                tab = {"cos": (np.cos, lambda x: -np.sin(x)), "sin": (np.sin, np.cos), "exp": (np.exp, np.exp),
+                       "neg": (np.negative, lambda x: -np.ones_like(x)), "square": (np.square, lambda x: 2 * x),
+                       "abs": (np.abs, np.sign), "cube": (lambda x: x ** 3, lambda x: 3 * x * x)}
+                if name not in tab:
+                    return None
+                f, g = tab[name]
+                return f(x), np.abs(g(x))[None, :] * dx
+            if n.degree == 2:
+                (x, dx), (y, dy) = kids
+                if name == "+":
+                    return x + y, dx + dy
+                if name in ("-", "sub"):
+                    return x - y, dx + dy
+                if name == "*":
+                    return x * y, np.abs(y)[None, :] * dx + np.abs(x)[None, :] * dy
+                if name == "/":
+                    return x / y, np.abs(1 / y)[None, :] * dx + np.abs(x / (y * y))[None, :] * dy
+            return None
+
+    out = rec(tree)
+    return None if out is None else out[1]
+
+
+def _leaves_in_order(tree):
+    """Leaves depth-first, left to right (the order of constant ordinals, src/NodeUtils.jl:184-201)."""
+    if tree.degree == 0:
+        return [tree]
+    res = []
+    for c in tree.children:
+        res.extend(_leaves_in_order(c))
+    return res

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import dynamicexpressions_jl_amd as de
-from helpers import parity_tolerance
+from helpers import parity_tolerance, path_abs_jacobian
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -188,12 +188,23 @@ def test_fused_loss_empty_and_error_paths(api):
 
 
 # ---- fused loss + gradient (de_eval_loss_grad) -------------------------------------------------
+@pytest.fixture(params=["forward", "reverse"], autouse=True)
+def accumulation(request, monkeypatch):
+    """Every fused loss+gradient test runs with both kernels: forward duals (de_grad_threaded.hip) and reverse
+    accumulation (de_rev_threaded.hip); the library picks by gradient width unless DE_LOSS_GRAD_REVERSE says."""
+    monkeypatch.setenv("DE_LOSS_GRAD_REVERSE", "1" if request.param == "reverse" else "0")
+    return request.param
+
+
 MODES = {"variable": (True, oracle.GRAD_VARIABLE), "constant": (False, oracle.GRAD_CONSTANT),
          "both": ("both", oracle.GRAD_BOTH)}
 
 
-def ref_loss_grad(out64, g64, y, w, kind):
-    """(loss, dloss[k], abs-sum of the gradient terms) from a materialised evaluation + Jacobian."""
+def ref_loss_grad(out64, g64, y, w, kind, gabs=None):
+    """(loss, dloss[k], magnitude of the gradient terms) from a materialised evaluation + Jacobian.  The
+    magnitude is sum_j |lp_j| * gabs[k, j]: with gabs = the path-absolute Jacobian (helpers.path_abs_jacobian)
+    it bounds the rounding of ANY association of the per-sample products and sums — forward duals and reverse
+    accumulation differ exactly there, e.g. d/dx (x * (c / x)) is rounding noise in both, but different noise."""
     y = y.astype(np.float64)
     ww = np.ones_like(y) if w is None else w.astype(np.float64)
     if kind == "pullback":
@@ -203,7 +214,11 @@ def ref_loss_grad(out64, g64, y, w, kind):
         l, lp = (e * e, 2 * e) if kind == "L2" else (np.abs(e), np.sign(e))
     keep = ww != 0
     terms = (ww * lp)[None, keep] * g64[:, keep]
-    return (ww * l)[keep].sum(), terms.sum(axis=1), np.abs(terms).sum(axis=1)
+    mag = np.abs(terms).sum(axis=1)
+    if gabs is not None:
+        with np.errstate(all="ignore"):
+            mag = np.maximum(mag, np.nan_to_num((np.abs(ww * lp)[None, keep] * gabs[:, keep]).sum(axis=1), nan=np.inf, posinf=np.inf))
+    return (ww * l)[keep].sum(), terms.sum(axis=1), mag
 
 
 def check_loss_grads(api, trees, ops, X, y, w, kind, dtype, mode_name, oracle_exact=False, min_ok=1, **pkw):
@@ -227,8 +242,9 @@ def check_loss_grads(api, trees, ops, X, y, w, kind, dtype, mode_name, oracle_ex
             yo, go, ok_o = oracle.eval_grad_tree_array(tape, consts, X, omode, elementwise=True)
             assert ok_o
             srcs.append((yo.astype(np.float64), go.astype(np.float64)))
+        gabs = path_abs_jacobian(tree, ops, X, mode_name, pkw.get("params"), pkw.get("classes"), pkw.get("class_base", 1))
         for o64, g64 in srcs:
-            want_l, want_g, mag = ref_loss_grad(o64, g64, y, w, kind)
+            want_l, want_g, mag = ref_loss_grad(o64, g64, y, w, kind, gabs)
             if not np.all(np.isfinite(want_g)) or max(abs(want_l), mag.max(initial=0)) > 0.05 * fmax:
                 continue  # a term overflows T
             assert abs(float(loss[t]) - want_l) <= 64 * eps * abs(want_l) + 64 * eps * np.abs(o64 * y).sum() * (kind == "pullback") + tiny
@@ -314,6 +330,123 @@ def test_fused_loss_grad_parametric_and_device_tensors(api):
         mag = (2 * (out[t].double() - yd.double())[None, :] * grads[t].double()).abs().sum(dim=1)
         assert bool(((d1[t].double() - want).abs() <= 64 * 1.2e-7 * mag + 1e-30).all())
     pop.close()
+
+
+# ---- parameter gradients reduced by class (de_eval_loss_grad_by_class) -----------------------------
+def test_parameter_gradient_by_class_reference_known_answer(api):
+    """test/test_parametric_expression.jl:321-372: ex = x*x - cos(2.5*y) + p1, params [0.1 0.2], loss
+    sum(abs2, ex(X, classes) - y_true): the gradient w.r.t. the constant and w.r.t. the parameter MATRIX equal
+    the closed form (there: Zygote through the hand-written prediction).  X / classes are re-drawn with our
+    PRNG (MersenneTwister streams are not reproducible here); the assertion is the reference's."""
+    from helpers import sexpr_to_node
+    ops = de.OperatorEnum(binary_operators=("+", "*", "-"), unary_operators=("cos",))
+    tree = sexpr_to_node(["+", ["-", ["*", ["x", 1], ["x", 1]], ["cos", ["*", 2.5, ["x", 2]]]], ["p", 1]], ops,
+                         de.ParametricNode)
+    g = np.random.Generator(np.random.PCG64(0))
+    for N in (32, 1000):
+        X = np.asfortranarray(g.random((2, N)))
+        classes = g.integers(1, 3, N)
+        true_params, init = np.array([[0.5, 2.0]]), np.array([[0.1, 0.2]])
+        y = X[0] * X[0] - np.cos(2.6 * X[1]) + true_params[0, classes - 1]
+        pred = X[0] * X[0] - np.cos(2.5 * X[1]) + init[0, classes - 1]
+        e = pred - y
+        true_val = (e * e).sum()
+        true_dc = (2 * e * np.sin(2.5 * X[1]) * X[1]).sum()
+        true_dp = np.array([[(2 * e)[classes == 1].sum(), (2 * e)[classes == 2].sum()]])
+        pop = api.Population([tree], ops, np.float64, n_features=2, n_params=1)
+        loss, dls, dp, ok = pop.eval_loss_grad_by_class(X, y, init, classes, variable="both")
+        assert ok[0] and dp.shape == (1, 1, 2)
+        np.testing.assert_allclose(loss[0], true_val, rtol=1e-12)
+        # rows of :both on a parametric tree: parameters, features, constants
+        np.testing.assert_allclose(dls[0][3], true_dc, rtol=1e-10)
+        np.testing.assert_allclose(dp[0], true_dp, rtol=1e-10)
+        np.testing.assert_allclose(dls[0][0], true_dp.sum(), rtol=1e-10)  # the dloss row is the sum over classes
+        pop.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["L2", "pullback"])
+def test_parameter_gradient_by_class_matches_scatter_of_jacobian(api, dtype, kind):
+    """dparams[t][p, c] == sum over the samples of class c of l'(e_j) * Jacobian row p — the scatter-add the
+    reference's AD performs through `parameters[i, classes[j]]` (src/ParametricExpression.jl:381-384); classes
+    arrive unordered (the wrapper groups them), some classes are empty, weights exclude samples."""
+    ops = de.OperatorEnum(binary_operators=("+", "*", "-", "/"), unary_operators=("cos", "exp"))
+    rng = de.synth.Xoshiro256ss(33)
+    P, Cn, N = 3, 7, 2500
+    trees = [de.synth.gen_random_tree_fixed_size(7 + i % 12, ops, 2, rng, dtype, de.ParametricNode, P) for i in range(60)]
+    g = np.random.Generator(np.random.PCG64(9))
+    X = np.asfortranarray(g.standard_normal((2, N)).astype(dtype))
+    params = np.asfortranarray(g.standard_normal((P, Cn)).astype(dtype))
+    classes = g.choice([1, 2, 4, 5, 7], N)  # classes 3 and 6 have no sample
+    y = g.standard_normal(N).astype(dtype)
+    w = (g.random(N) > 0.2).astype(dtype) * g.random(N).astype(dtype)
+    pop = api.Population(trees, ops, dtype, n_features=2, n_params=P)
+    for variable in (True, "both"):
+        loss, dls, dp, ok = pop.eval_loss_grad_by_class(X, y, params, classes, weights=w, loss=kind, variable=variable)
+        loss1, dls1, ok1 = pop.eval_loss_grad(X, y, weights=w, loss=kind, variable=variable, params=params, classes=classes)
+        out, grads, okg = pop.eval_grad(X, variable, params=params, classes=classes)
+        assert np.array_equal(ok, okg) and np.array_equal(ok, ok1) and ok.sum() > 10
+        assert dp.shape == (len(trees), P, Cn)
+        eps, fmax = np.finfo(dtype).eps, float(np.finfo(dtype).max)
+        for t in range(len(trees)):
+            if not ok[t]:
+                assert np.isnan(loss[t]) and np.isnan(dls[t]).all() and np.isnan(dp[t]).all()
+                continue
+            o64, g64 = out[t].astype(np.float64), np.asarray(grads[t], dtype=np.float64)
+            lp = y.astype(np.float64) if kind == "pullback" else 2 * (o64 - y)
+            terms = (w.astype(np.float64) * lp)[None, :] * g64
+            gabs = path_abs_jacobian(trees[t], ops, X, "variable" if variable is True else "both", params, classes)
+            aterms = np.abs(terms) if gabs is None else np.maximum(np.abs(terms), np.nan_to_num(
+                np.abs(w.astype(np.float64) * lp)[None, :] * gabs, nan=np.inf))  # conditioning under any association
+            for c in range(Cn):
+                sel = classes == c + 1
+                want, mag = terms[:P, sel].sum(axis=1), aterms[:P, sel].sum(axis=1)
+                big = mag > 0.25 * fmax  # a sum beyond the range of the type may be +-Inf
+                assert np.all((np.abs(dp[t][:, c] - want) <= 64 * eps * mag + 1e-300) | big), (t, c)
+                if not sel.any():
+                    assert np.all(dp[t][:, c] == 0)
+            want, mag = terms.sum(axis=1), aterms.sum(axis=1)
+            assert np.all((np.abs(dls[t] - want) <= 64 * eps * mag + 1e-300) | (mag > 0.25 * fmax))
+            assert loss[t] == loss1[t] or abs(loss[t] - loss1[t]) <= 64 * eps * abs(loss1[t]) + 1e-300 or kind == "pullback"
+    # run-to-run reproducible (fixed-order reduction), and grouped=True input gives the same bits
+    a = pop.eval_loss_grad_by_class(X, y, params, classes, weights=w, loss=kind)
+    order = np.argsort(classes, kind="stable")
+    b = pop.eval_loss_grad_by_class(np.asfortranarray(X[:, order]), y[order], params, classes[order], weights=w[order],
+                                    loss=kind, grouped=True)
+    assert np.array_equal(a[2], b[2], equal_nan=True) and np.array_equal(a[0], b[0], equal_nan=True)
+    pop.close()
+
+
+def test_parameter_gradient_by_class_device_tensors_and_errors(api):
+    import torch
+    trees = de.synth.random_population(50, seed=0xDE05, node_type=de.ParametricNode, nparams=8)
+    ops = de.synth.BENCH_OPERATORS
+    pop = api.Population(trees, ops, np.float32, n_features=5, n_params=8)
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    N, Cn = 50_001, 16
+    Xd = torch.randn((N, 5), generator=gen, device="cuda").t()
+    dY = torch.randn(N, generator=gen, device="cuda")
+    params = torch.randn((Cn, 8), generator=gen, device="cuda").t()
+    classes = torch.randint(1, Cn + 1, (N,), generator=gen, device="cuda", dtype=torch.int32)
+    loss, dls, dp, ok = pop.eval_loss_grad_by_class(Xd, dY, params, classes, loss="pullback")
+    torch.cuda.synchronize()
+    assert dp.shape == (50, 8, Cn) and ok.sum().item() > 5
+    out, grads, okg = pop.eval_grad(Xd, "both", params=params, classes=classes)
+    assert torch.equal(ok, okg)
+    for t in torch.nonzero(ok).flatten().tolist()[:10]:
+        terms = dY.double()[None, :] * grads[t][:8].double()
+        for c in (0, 7, 15):
+            sel = classes == c + 1
+            want, mag = terms[:, sel].sum(dim=1), terms[:, sel].abs().sum(dim=1)
+            assert bool(((dp[t][:, c].double() - want).abs() <= 64 * 1.2e-7 * mag + 1e-30).all())
+    # misuse: constant mode has no parameter rows; a plain population has no parameters
+    with pytest.raises(ValueError):
+        pop.eval_loss_grad_by_class(Xd, dY, params, classes, variable=False)
+    pop.close()
+    plain = api.Population(de.synth.random_population(3, seed=1), ops, np.float32, n_features=5)
+    with pytest.raises(ValueError):
+        plain.eval_loss_grad_by_class(Xd, dY, params, classes)
+    plain.close()
 
 
 def test_fused_loss_grad_empty_and_error_paths(api):
