@@ -288,6 +288,56 @@ function eval_population_loss_grad(
     return lossv, [dl[(offs[t] + 1):offs[t + 1]] for t in 1:pop.n_trees], ok .!= 0x00
 end
 
+"""
+    eval_population_loss_grad_by_class(pop, X, y, parameters, classes; weights=nothing, loss=:L2, variable=Val(:both))
+        -> (loss, dloss::Vector{Vector{T}}, dparameters::Vector{Matrix{T}}, ok)
+
+Parametric population: the fused loss gradient with the parameter rows reduced BY CLASS —
+`dparameters[t]` is the gradient w.r.t. the `n_params × n_classes` parameter matrix, i.e. Zygote's
+`grad.metadata._data.parameters` (test/test_parametric_expression.jl:326-372; the optimiser vector is
+`vcat(constants, parameters[:])`, src/ParametricExpression.jl:260-265).  The library reduces class by
+class over sample ranges, so the samples are ordered by class here (`sortperm`, stable); a search loop
+that keeps its dataset ordered passes `grouped=true`.
+"""
+function eval_population_loss_grad_by_class(
+    pop::HIPPopulation{T}, X::Matrix{T}, y::Vector{T}, parameters::Matrix{T}, classes::Vector{Int64};
+    weights::Union{Nothing,Vector{T}}=nothing, loss::Symbol=:L2, variable=Val(:both), grouped::Bool=false,
+) where {T}
+    mode = variable isa Val{true} || variable === true ? Cint(0) : Cint(2)
+    F, N = size(X)
+    P, C = size(parameters)
+    @assert F >= pop.n_features && length(y) == N && length(classes) == N
+    @assert maximum(classes; init=1) <= C   # src/ParametricExpression.jl:378-379
+    if !grouped
+        perm = sortperm(classes; alg=MergeSort)
+        X, y, classes = X[:, perm], y[perm], classes[perm]
+        weights = weights === nothing ? nothing : weights[perm]
+    end
+    starts = zeros(Int64, C + 1)
+    for c in classes
+        starts[c + 1] += 1
+    end
+    cumsum!(starts, starts)
+    ng = [ccall((:de_program_n_grad, LIBDE), Int64, (Ptr{Cvoid}, Int64, Cint), pop.handle, t - 1, mode)
+          for t in 1:pop.n_trees]
+    offs = Int64[0; cumsum(ng)]
+    lossv = Vector{T}(undef, pop.n_trees)
+    dl = Vector{T}(undef, max(offs[end], 1))
+    dp = Array{T,3}(undef, P, C, pop.n_trees)
+    ok = Vector{UInt8}(undef, pop.n_trees)
+    w = weights === nothing ? C_NULL : pointer(weights)
+    kind = loss === :L1 ? 1 : loss === :pullback ? 2 : 0
+    pa = Ref(ParamArgs(pointer(parameters), P, C, pointer(classes), 1, 1))
+    rc = GC.@preserve X y weights parameters classes starts lossv dl dp offs ok ccall(
+        (:de_eval_loss_grad_by_class, LIBDE), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ref{ParamArgs}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int32,
+         Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{Cvoid}, Ptr{UInt8}),
+        pop.ctx.handle, pop.handle, X, N, F, pa, mode, y, w, kind, starts, lossv, dl, offs, dp, ok)
+    check(pop.ctx, rc)
+    return lossv, [dl[(offs[t] + 1):offs[t + 1]] for t in 1:pop.n_trees], [dp[:, :, t] for t in 1:pop.n_trees],
+           ok .!= 0x00
+end
+
 """Forward-mode gradient of one tree: `(evaluation, gradient(n_grad × N), complete)` like
 `eval_grad_tree_array(tree, cX, operators; variable)` (src/EvaluateDerivative.jl:193-228)."""
 function _hip_eval_grad_tree_array(

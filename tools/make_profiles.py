@@ -25,7 +25,14 @@ def big_launches(trace, needle):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if int(r["Grid_Size_X"]) == gmax]
     return d, gmax
 ev, gmax = big_launches(f"{src}/stats/eval_kernel_trace.csv", "de_eval_")
-gr, _ = big_launches(f"{src}/stats_C3/grad_kernel_trace.csv", "de_grad_")
+def per_step(trace, needle):
+    """The gradient runs as one launch per width/samples-per-lane bucket: time of ALL full-size launches per step."""
+    rows = [r for r in csv.DictReader(open(trace)) if needle in r["Kernel_Name"] and int(r["Grid_Size_X"]) > 256 * 64]
+    gmax = max(int(r["Grid_Size_X"]) for r in rows)
+    steps = sum(1 for r in rows if int(r["Grid_Size_X"]) == gmax)
+    total = sum((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows)
+    return [total / steps] * steps
+gr = per_step(f"{src}/stats_C3/grad_kernel_trace.csv", "de_grad_")
 
 def pmc(path, name, out):
     rows = [r for r in csv.DictReader(open(path)) if "de_eval_" in r["Kernel_Name"] and r["Counter_Name"] == name]
@@ -52,6 +59,7 @@ summ = {"headline": {
 json.dump(summ, open("profiles/pmc_summary.json", "w"), indent=1)
 print(json.dumps(summ, indent=1))
 print("eval kernel avg us:", sum(ev) / len(ev), " grad:", sum(gr) / len(gr))
-for f in ("bench_r1_headline.json", "bench_r1_C2.json", "bench_r1_C3.json"):
+for f in ("bench_r1_headline.json", "bench_r1_C2.json", "bench_r1_C3.json", "bench_r1_loss.json", "bench_r1_lossgrad.json",
+          "bench_r1_C5.json", "bench_r1_C5pb.json"):
     if os.path.exists(f"gpurun_out/{f}"):
         shutil.copy(f"gpurun_out/{f}", f"profiles/{pre}_" + f.replace("bench_r1_", "bench_"))
