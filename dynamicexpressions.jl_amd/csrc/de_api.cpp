@@ -120,7 +120,7 @@ struct de_program {
     uint64_t rt_handler_base = 0;
     uint32_t rt_param_off = 0;
     int gt_mode = -1;
-    bool gt_valid = false;
+    bool gt_valid = false, gt_wide = false;
     int gt_n_buckets = 0;
     GradArgs::Bucket gt_buckets[24];
 };
@@ -1124,13 +1124,17 @@ static int ensure_generic_code(de_ctx *c, de_program *p) {
 // window (every seed is known here and compiled into the handler choice), wider trees in windows of 8
 // with run-time seeds.  Fills g->threaded_code & co. when the program can be expressed this way; otherwise
 // leaves them null and the flat-switch kernel runs.  Call after ensure_generic_code().
-static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::vector<int32_t> &ng, GradArgs *g) {
+static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::vector<int32_t> &ng, int64_t N, GradArgs *g) {
     g->threaded_code = nullptr;
     g->n_buckets = 0;
     const char *env = getenv("DE_GRAD_THREADED");
     if (env && *env == '0') return DE_OK;
     const int F = p->n_features, P = p->n_params;
-    if (!(p->gt_valid && p->gt_mode == mode)) {
+    // Two samples per lane double the buckets (launches) and the tile: they pay from ~10^5 samples on (10^4 trees x
+    // 10^3 rows: 0.55 ms with them, 0.35 ms without; 10^3 trees x 10^6 rows: 12.1 against 13.4 ms)
+    const char *envn = getenv("DE_GRAD_VS2_MIN_N");
+    const bool wide = N >= (envn ? atoll(envn) : 65536);
+    if (!(p->gt_valid && p->gt_mode == mode && p->gt_wide == wide)) {
         // bucket of a tree: (width index 0..6 = single window of width 1,2,3,4,5,6,8; 7 = several windows of 8)
         // x (samples per lane - 1).  The two-sample modules exist for Float32 windows <= 6; their rows are
         // twice as long, so they only pay while a workgroup's LDS stays small: trees with <= 1 spill slot.
@@ -1164,7 +1168,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                 w = per <= 5 ? 8 : (per <= 6 ? 9 : 7);
                 if (!grad_threaded_has(p->dtype, WIDTH[w], 1)) w = 7;
             }
-            const bool two = p->dtype == DE_F32 && WIDTH[w] <= 6 && tslots[(size_t)t] <= vs2_slots && grad_threaded_has(p->dtype, WIDTH[w], 2);
+            const bool two = wide && p->dtype == DE_F32 && WIDTH[w] <= 6 && tslots[(size_t)t] <= vs2_slots && grad_threaded_has(p->dtype, WIDTH[w], 2);
             return w + (two ? NW : 0);
         };
         int32_t count[NB] = {0}, maxg[NB] = {0}, slots[NB] = {0};
@@ -1303,6 +1307,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             bk.param_handler_off = (uint32_t)(tables[b][gop_param(WIDTH[b % NW])] - bases[b]);
         }
         p->gt_mode = mode;
+        p->gt_wide = wide;
         p->gt_valid = true;
     }
     g->threaded_code = p->d_gtcode;
@@ -1652,7 +1657,7 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
     g.diff_direction = diff ? diff_direction : -1;
     g.e.code_off = p->d_gcode_off;
     if (!diff) {
-        rc = ensure_grad_threaded(c, p, mode, ng, &g);
+        rc = ensure_grad_threaded(c, p, mode, ng, N, &g);
         if (rc) return rc;
     }
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -1823,7 +1828,7 @@ int de_eval_loss_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, in
     if (!g.rev_code) {
         const size_t lds_need = ((size_t)p->n_features + (size_t)p->n_slots * (1 + (size_t)std::min(maxg, 8))) * 260 * es;
         if (lds_need > 160 * 1024) return fail(c, DE_ERR_UNSUPPORTED, "gradient kernel: LDS footprint too large for this tree shape");
-        rc = ensure_grad_threaded(c, p, mode, ng, &g);
+        rc = ensure_grad_threaded(c, p, mode, ng, N, &g);
         if (rc) return rc;
     }
     if (!c->nested) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));

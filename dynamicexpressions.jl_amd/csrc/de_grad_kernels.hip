@@ -252,27 +252,31 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
     }
 }
 
-// Pass 3 of the fused loss+pullback reduction: thread = one tree; fixed summation order.  NaN where
-// the evaluation was incomplete (src/ChainRules.jl:62-64 `dX_constants_dY .= NaN`).
+// Pass 3 of the fused loss+pullback reduction: thread = one reduction column (a tree's loss or one of its
+// gradient rows; the owner is found by bisection in col_off); fixed summation order.  NaN where the evaluation
+// was incomplete (src/ChainRules.jl:62-64 `dX_constants_dY .= NaN`).
 template <typename T>
 __global__ void __launch_bounds__(256) de_loss_grad_finish_kernel(const double *__restrict__ seg_sum, int64_t n_trees, int64_t n_cols,
                                                                  int32_t n_segs, const int64_t *__restrict__ col_off,
                                                                  const int32_t *__restrict__ n_grad, const uint8_t *__restrict__ ok,
                                                                  T *__restrict__ loss, T *__restrict__ dloss,
                                                                  const int64_t *__restrict__ dloss_off) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_trees) return;
-    const int64_t c0 = col_off[t];
-    const int G = n_grad[t];
-    const bool good = ok[t] != 0;
-    for (int c = 0; c <= G; ++c) {
-        double s = 0.0;
-        for (int32_t g = 0; g < n_segs; ++g)
-            for (int w = 0; w < 4; ++w) s += seg_sum[((int64_t)g * n_cols + c0 + c) * 4 + w];
-        const T v = good ? (T)s : M<T>::nan();
-        if (c == 0) { if (loss) loss[t] = v; }
-        else dloss[dloss_off[t] + c - 1] = v;
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= n_cols) return;
+    int64_t lo = 0, hi = n_trees; // col_off[lo] <= col < col_off[hi]
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (col_off[mid] <= col) lo = mid;
+        else hi = mid;
     }
+    const int64_t t = lo;
+    const int c = (int)(col - col_off[t]);
+    double s = 0.0;
+    for (int32_t g = 0; g < n_segs; ++g)
+        for (int w = 0; w < 4; ++w) s += seg_sum[((int64_t)g * n_cols + col) * 4 + w];
+    const T v = ok[t] != 0 ? (T)s : M<T>::nan();
+    if (c == 0) { if (loss) loss[t] = v; }
+    else dloss[dloss_off[t] + c - 1] = v;
 }
 
 static int g_gcu = 0;
@@ -355,7 +359,7 @@ template <typename T> static hipError_t loss_grad_finish_t(const GradArgs &ga, i
     hipError_t st = launch_loss_reduce_tiles(sizeof(T) == 4 ? DE_F32 : DE_F64, ga.loss->partial, ga.n_cols * 4, n_tiles, ga.loss->seg_sum,
                                              &n_segs, stream);
     if (st != hipSuccess) return st;
-    hipLaunchKernelGGL(de_loss_grad_finish_kernel<T>, dim3((unsigned)((ga.e.n_trees + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(de_loss_grad_finish_kernel<T>, dim3((unsigned)((ga.n_cols + 255) / 256)), dim3(256), 0, stream,
                        static_cast<const double *>(ga.loss->seg_sum), (int64_t)ga.e.n_trees, ga.n_cols, n_segs, ga.col_off, ga.n_grad,
                        ga.e.ok, static_cast<T *>(ga.loss->loss), static_cast<T *>(ga.dloss), ga.dloss_off);
     return hipGetLastError();

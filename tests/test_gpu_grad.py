@@ -51,6 +51,14 @@ def test_golden_gradients_on_gpu(case, api):
             np.testing.assert_array_equal(y2, y)
 
 
+@pytest.fixture(params=["1-per-lane", "2-per-lane"], autouse=True)
+def samples_per_lane(request, monkeypatch):
+    """The threaded gradient modules exist with one and with two samples per lane (Float32, windows <= 6, trees with
+    <= 1 spill slot); the library uses the latter from 65536 samples on — the tests force each."""
+    monkeypatch.setenv("DE_GRAD_VS2_MIN_N", "0" if request.param == "2-per-lane" else "1000000000000")
+    return request.param
+
+
 def grad_compare(api, trees, ops, X, dtype, mode_name, exact=False):
     variable, omode = MODES[mode_name]
     pop = api.Population(trees, ops, dtype, n_features=X.shape[0])

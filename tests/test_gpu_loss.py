@@ -188,11 +188,13 @@ def test_fused_loss_empty_and_error_paths(api):
 
 
 # ---- fused loss + gradient (de_eval_loss_grad) -------------------------------------------------
-@pytest.fixture(params=["forward", "reverse"], autouse=True)
+@pytest.fixture(params=["forward", "forward-2-per-lane", "reverse"], autouse=True)
 def accumulation(request, monkeypatch):
-    """Every fused loss+gradient test runs with both kernels: forward duals (de_grad_threaded.hip) and reverse
-    accumulation (de_rev_threaded.hip); the library picks by gradient width unless DE_LOSS_GRAD_REVERSE says."""
+    """Every fused loss+gradient test runs with all kernels: forward duals (de_grad_threaded.hip) with one sample per
+    lane and with the two-samples-per-lane modules (which the library only uses from 65536 samples on), and reverse
+    accumulation (de_rev_threaded.hip; picked by gradient width unless DE_LOSS_GRAD_REVERSE says)."""
     monkeypatch.setenv("DE_LOSS_GRAD_REVERSE", "1" if request.param == "reverse" else "0")
+    monkeypatch.setenv("DE_GRAD_VS2_MIN_N", "0" if request.param == "forward-2-per-lane" else "1000000000000")
     return request.param
 
 
