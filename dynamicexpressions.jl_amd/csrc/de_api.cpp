@@ -115,7 +115,8 @@ struct de_program {
     std::vector<int32_t> rtcode_off, rtcode_mid, rtsite_of_gb;
     BoundInstr *d_rtcode = nullptr;
     int32_t *d_rtcode_off = nullptr, *d_rtcode_mid = nullptr, *d_rt_ids = nullptr;
-    int rt_mode = -1, rt_rows = 0, rt_stage_cols = 0;
+    int rt_mode = -1, rt_stage_cols = 0, rt_n_groups = 0;
+    GradArgs::RevGroup rt_groups[8];
     bool rt_valid = false;
     uint64_t rt_handler_base = 0;
     uint32_t rt_param_off = 0;
@@ -1356,6 +1357,8 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
         p->rtsite_of_gb.assign(p->gbcode.size(), -1);
         uint32_t max_prows = 0;
         bool ok = true;
+        std::vector<int> row_hist; // trees by partial + accumulation rows (DE_DEBUG_ROWS=1 prints it)
+        std::vector<uint32_t> need((size_t)p->n_trees, 0);
         std::vector<BoundInstr> rv;
         std::vector<uint8_t> rv_col; // rv[k] carries a gradient column word in .lo
         std::map<uint32_t, std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> occ; // column -> (leaves, (seen, row))
@@ -1501,15 +1504,49 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
             if (PR0 + n_prows + n_acc > 0x3FFFu) { ok = false; break; }
             p->rtcode_off[(size_t)t + 1] = (int32_t)p->rtcode.size();
             max_prows = std::max(max_prows, n_prows + n_acc);
+            need[(size_t)t] = n_prows + n_acc;
+            if (row_hist.size() <= n_prows + n_acc) row_hist.resize(n_prows + n_acc + 1, 0);
+            row_hist[n_prows + n_acc]++;
+        }
+        if (getenv("DE_DEBUG_ROWS")) {
+            fprintf(stderr, "rev rows: PR0=%u;", PR0);
+            for (size_t r = 0; r < row_hist.size(); r++) if (row_hist[r]) fprintf(stderr, " %zu:%d", r, row_hist[r]);
+            fprintf(stderr, "\n");
         }
         // per-wave staging of the column sums: one LDS row, or the widest tree's columns
         int64_t stage_cols = 64;
         for (int64_t t = 0; t < p->n_trees; t++) stage_cols = std::max<int64_t>(stage_cols, 1 + de_program_n_grad(p, t, mode));
         const uint64_t stage_rows = ((uint64_t)stage_cols * es32 + RB - 1) / RB;
-        const uint64_t rows = (uint64_t)PR0 + max_prows + stage_rows;
+        const char *envx = getenv("DE_REV_EXTRA_ROWS"); // occupancy experiments: pad the LDS allocation
+        const uint64_t extra_rows = envx ? (uint64_t)atoi(envx) : 0;
+        const uint64_t rows = (uint64_t)PR0 + max_prows + stage_rows + extra_rows;
         if (!ok || 4 * rows * RB > 160 * 1024 || rows * RB >= (1u << 24)) { p->rtsite_of_gb.clear(); return DE_OK; }
+        // The kernel is latency-bound and its occupancy is set by the LDS rows of the neediest tree of a launch
+        // (5 -> 4 workgroups per CU: +17 % time): trees are grouped by the number of workgroups per CU their own
+        // need allows and every group is a launch of its own (small groups join the next needier one).
+        auto wgs_of = [&](uint32_t nd) { return (int)std::min<uint64_t>(8, (160 * 1024) / (4 * ((uint64_t)PR0 + nd + stage_rows + extra_rows) * RB)); };
         std::vector<int32_t> ids((size_t)p->n_trees);
         for (int64_t t = 0; t < p->n_trees; t++) ids[(size_t)t] = (int32_t)t;
+        std::stable_sort(ids.begin(), ids.end(), [&](int32_t x, int32_t y) { return need[(size_t)x] < need[(size_t)y]; });
+        p->rt_n_groups = 0;
+        const char *envg = getenv("DE_REV_GROUPS");
+        const bool grouping = !(envg && *envg == '0');
+        for (int64_t k = 0; k < p->n_trees;) {
+            int64_t e = k;
+            const int w = wgs_of(need[(size_t)ids[(size_t)k]]);
+            while (e < p->n_trees && grouping && wgs_of(need[(size_t)ids[(size_t)e]]) == w) e++;
+            if (!grouping) e = p->n_trees;
+            // a group too small to fill the chip, or the last slot: extend to the end / absorb into the next group
+            if (p->rt_n_groups == 7) e = p->n_trees;
+            while (e < p->n_trees && e - k < std::max<int64_t>(64, p->n_trees / 16)) e++;
+            if (p->n_trees - e < std::max<int64_t>(64, p->n_trees / 16)) e = p->n_trees;
+            GradArgs::RevGroup &gr = p->rt_groups[p->rt_n_groups++];
+            gr.first = (int32_t)k;
+            gr.n = (int32_t)(e - k);
+            gr.rows = (int32_t)(PR0 + need[(size_t)ids[(size_t)e - 1]] + stage_rows + extra_rows);
+            std::sort(ids.begin() + k, ids.begin() + e); // tree order inside a group: adjacent trees share staging batches
+            k = e;
+        }
         HIP_TRY(c, hipStreamSynchronize(c->stream)); // the previous form may be in use by queued work
         if (p->d_rtcode) { // sizes depend on the mode
             (void)hipFree(p->d_rtcode);
@@ -1529,7 +1566,6 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
             HIP_TRY(c, hipMemcpy(p->d_rtcode_mid, p->rtcode_mid.data(), p->rtcode_mid.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             HIP_TRY(c, hipMemcpy(p->d_rt_ids, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         }
-        p->rt_rows = (int)rows;
         p->rt_stage_cols = (int)stage_cols;
         p->rt_handler_base = base;
         p->rt_param_off = (uint32_t)(table[ROP_PARAM] - base);
@@ -1540,7 +1576,8 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
     g->rev_code_off = p->d_rtcode_off;
     g->rev_code_mid = p->d_rtcode_mid;
     g->rev_ids = p->d_rt_ids;
-    g->rev_rows = p->rt_rows;
+    g->rev_n_groups = p->rt_n_groups;
+    for (int k = 0; k < p->rt_n_groups; k++) g->rev_groups[k] = p->rt_groups[k];
     g->rev_stage_cols = p->rt_stage_cols;
     g->rev_handler_base = p->rt_handler_base;
     g->rev_param_off = p->rt_param_off;

@@ -481,8 +481,8 @@ hipError_t launch_grad_threaded(int dtype, const GradArgs &a, hipStream_t stream
 // ---- reverse accumulation: one module per element type (de_rev_threaded.hip) --------------------------
 hipError_t rev_thr_fetch_f(uint64_t *host_table);
 hipError_t rev_thr_fetch_d(uint64_t *host_table);
-hipError_t rev_thr_launch_f(const GradArgs &ga, hipStream_t stream);
-hipError_t rev_thr_launch_d(const GradArgs &ga, hipStream_t stream);
+hipError_t rev_thr_launch_f(const GradArgs &ga, int group, hipStream_t stream);
+hipError_t rev_thr_launch_d(const GradArgs &ga, int group, hipStream_t stream);
 hipError_t rev_handler_table(int dtype, uint64_t *table) {
     static uint64_t cache[2][ROP_COUNT];
     static bool have[2] = {false, false};
@@ -498,8 +498,10 @@ hipError_t rev_handler_table(int dtype, uint64_t *table) {
 hipError_t launch_rev_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name) {
     if (kernel_name) *kernel_name = "de_rev_threaded_kernel";
     const int64_t n_tiles = (a.e.N + GBLK - 1) / GBLK;
-    const hipError_t st = dtype == DE_F32 ? rev_thr_launch_f(a, stream) : rev_thr_launch_d(a, stream);
-    if (st != hipSuccess) return st;
+    for (int k = 0; k < a.rev_n_groups; k++) { // one launch per LDS-need group of trees
+        const hipError_t st = dtype == DE_F32 ? rev_thr_launch_f(a, k, stream) : rev_thr_launch_d(a, k, stream);
+        if (st != hipSuccess) return st;
+    }
     return launch_loss_grad_finish(dtype, a, n_tiles, stream);
 }
 

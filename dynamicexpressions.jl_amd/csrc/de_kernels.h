@@ -76,8 +76,9 @@ struct GradArgs {
     // stream per tree, null = not available
     const BoundInstr *rev_code;
     const int32_t *rev_code_off, *rev_code_mid; // n_trees + 1 / n_trees
-    const int32_t *rev_ids;                     // device: evaluation order of the trees
-    int32_t rev_rows;                           // LDS rows per wave (staging included)
+    const int32_t *rev_ids;                     // device: the trees grouped by LDS need (rev_groups)
+    int32_t rev_n_groups;
+    struct RevGroup { int32_t first, n, rows; } rev_groups[8]; // ids[first .. first+n), LDS rows per wave (staging included)
     int32_t rev_stage_cols;                     // column sums a wave stages in LDS between two writes
     uint64_t rev_handler_base;
     uint32_t rev_param_off;

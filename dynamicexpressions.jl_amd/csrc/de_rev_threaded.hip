@@ -279,7 +279,9 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
     T *__restrict__ rows = reinterpret_cast<T *>(rtsmem);
     const GTileMap tm = gmap_block(blockIdx.x, a.n_chunks, a.n_tiles);
     if (!tm.valid) return;
-    const int tid = threadIdx.x, wave = tid >> 6;
+    // few per-lane values may live across the handler calls: they sit in callee-saved VGPRs, which the ABI hands out
+    // in blocks of 8 at v40, v56, v72, v88 — a fourth block costs a fifth of the occupancy
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t base = tm.tile * GBLK, last = a.N - 1;
     const int F = a.F, R = a.rev_rows; // rows per wave
     {
@@ -292,9 +294,9 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
         }
     }
     const int64_t j = base + tid, jj = j < last ? j : last;
-    int64_t cls = 0;
+    uint32_t poff = 0; // element offset of the sample's parameter column
     if (PARAMS)
-        cls = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj] : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base;
+        poff = (uint32_t)(a.ld_params * ((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj] : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base));
     const T yv = a.y[jj];
     const T wv = j <= last ? (a.w ? a.w[jj] : T(1)) : T(0);
     __syncthreads();
@@ -307,18 +309,19 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
     const ConstI32Ptr tree_ids = (ConstI32Ptr)(uintptr_t)a.tree_ids;
     const int t0 = tm.chunk * a.trees_per_chunk;
     const int t1 = (t0 + a.trees_per_chunk < a.n_trees) ? t0 + a.trees_per_chunk : a.n_trees;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)rtsmem + (uint32_t)(wave * R) * rrow_bytes<T>() + (uint32_t)(tid & 63) * (uint32_t)sizeof(T);
+    GState<T> st;
+    st.lds0 = (uint32_t)(uintptr_t)rtsmem + (uint32_t)(wave * R) * rrow_bytes<T>() + (uint32_t)(tid & 63) * (uint32_t)sizeof(T);
     const int64_t n_cols = col_off[a.n_all_trees];
 
     // per-wave staging of the column sums: [stage_cols] elements after the wave's rows
     const int SC = a.rev_stage_cols;
     const uint32_t stage0 = (uint32_t)(uintptr_t)rtsmem + (uint32_t)(wave * R + (R - a.rev_stage_rows)) * rrow_bytes<T>();
-    const int lane = tid & 63;
+#define RT_LANE() ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
     int64_t stage_col0 = 0; // global column of stage[0]
     int staged = 0;         // columns staged so far
     auto flush = [&]() {
         T *dst = a.partial + ((int64_t)tm.tile * n_cols + stage_col0) * 4 + wave;
-        for (int i = lane; i < staged; i += 64) dst[(int64_t)i * 4] = *RLDS(T, stage0 + (uint32_t)i * (uint32_t)sizeof(T));
+        for (int i = RT_LANE(); i < staged; i += 64) dst[(int64_t)i * 4] = *RLDS(T, stage0 + (uint32_t)i * (uint32_t)sizeof(T));
         staged = 0;
     };
     for (int ti = t0; ti < t1; ++ti) {
@@ -327,13 +330,11 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
         const int nc = 1 + n_grad[tree];
         if (staged > 0 && (c0 != stage_col0 + staged || staged + nc > SC)) flush();
         if (staged == 0) stage_col0 = c0;
-        for (int i = lane; i < nc; i += 64) *RLDS(T, stage0 + (uint32_t)(staged + i) * (uint32_t)sizeof(T)) = T(0); // rows no leaf touches are 0
-        GState<T> st;
+        for (int i = RT_LANE(); i < nc; i += 64) *RLDS(T, stage0 + (uint32_t)(staged + i) * (uint32_t)sizeof(T)) = T(0); // rows no leaf touches are 0
         st.x = T(0);
         st.lp = T(0);
         st.vpoison = T(0);
         st.gpoison = T(0);
-        st.lds0 = lds0;
         st.stage = stage0 + (uint32_t)staged * (uint32_t)sizeof(T);
         staged += nc;
         int pc = code_off[tree];
@@ -344,17 +345,17 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
             nxt = code[pc + 1];
             if (PARAMS && w.x == param_off) { // operand = params[row, class]: y = row | op << 24, z = partial row
                 const uint32_t prow = w.y & 0xFFFFu, op = w.y >> 24;
-                const T b = a.params[prow + a.ld_params * cls];
+                const T b = a.params[prow + poff];
                 rpoison<T>(st.vpoison, b);
                 if (op == DOP_LOAD) st.x = b;
-                else st = r_gen_apply<T>(st, op, b, lds0 + w.z);
+                else st = r_gen_apply<T>(st, op, b, st.lds0 + w.z);
                 continue;
             }
             const RHandlerFn<T> fn = reinterpret_cast<RHandlerFn<T>>(hbase + w.x);
             typename RImm<T>::type imm;
             if constexpr (sizeof(T) == 4) imm = w.z;
             else imm = ((uint64_t)w.w << 32) | w.z;
-            st = fn(st, lds0 + w.y, imm);
+            st = fn(st, st.lds0 + w.y, imm);
         }
         rpoison<T>(st.vpoison, st.x);
         { // loss term and the seed of the backward sweep
@@ -365,7 +366,7 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
             else { l = wv * (st.x * yv); lp = wv * yv; } // DE_LOSS_PULLBACK: y holds the cotangent dY
             if (wv == T(0)) { l = T(0); lp = T(0); }
             const T s = wave_sum_to_lane63(l);
-            if (lane == 63) *RLDS(T, st.stage) = s;
+            if (RT_LANE() == 63) *RLDS(T, st.stage) = s;
             st.lp = lp;
             st.x = T(1);
         }
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
             typename RImm<T>::type imm;
             if constexpr (sizeof(T) == 4) imm = w.z;
             else imm = ((uint64_t)w.w << 32) | w.z;
-            st = fn(st, lds0 + w.y, imm);
+            st = fn(st, st.lds0 + w.y, imm);
         }
         const bool bad = (st.vpoison != st.vpoison) || (nc > 1 && st.gpoison != st.gpoison);
         if (__ballot(bad) != 0ull) gflag_incomplete(a.ok + tree);
@@ -397,17 +398,19 @@ hipError_t DE_RT_NAME(rev_thr_fetch_)(uint64_t *host_table) {
     return st;
 }
 
-hipError_t DE_RT_NAME(rev_thr_launch_)(const GradArgs &ga, hipStream_t stream) {
+hipError_t DE_RT_NAME(rev_thr_launch_)(const GradArgs &ga, int group, hipStream_t stream) {
     using namespace DE_RT_NAME(rtm_);
     typedef DE_RT_T T;
     static int rt_gcu = 0;
     const EvalArgs &e = ga.e;
+    const GradArgs::RevGroup &grp = ga.rev_groups[group];
+    if (grp.n <= 0) return hipSuccess;
     GArgs<T> a;
     std::memset(&a, 0, sizeof a);
     a.code = ga.rev_code;
     a.code_off = ga.rev_code_off;
     a.rev_mid = ga.rev_code_mid;
-    a.rev_rows = ga.rev_rows;
+    a.rev_rows = grp.rows;
     a.rev_stage_cols = ga.rev_stage_cols;
     a.rev_stage_rows = (int32_t)(((size_t)ga.rev_stage_cols * sizeof(T) + 64 * sizeof(T) - 1) / (64 * sizeof(T)));
     a.X = static_cast<const T *>(e.X);
@@ -421,9 +424,9 @@ hipError_t DE_RT_NAME(rev_thr_launch_)(const GradArgs &ga, hipStream_t stream) {
     a.n_tiles = (e.N + GBLK - 1) / GBLK;
     a.F = e.F;
     a.P = ga.P;
-    a.n_trees = e.n_trees;
+    a.n_trees = grp.n;
     a.n_all_trees = e.n_trees;
-    a.tree_ids = ga.rev_ids;
+    a.tree_ids = ga.rev_ids + grp.first;
     a.n_slots = e.n_slots;
     a.mode = ga.mode;
     a.classes_is_i64 = e.classes_is_i64;
@@ -442,14 +445,14 @@ hipError_t DE_RT_NAME(rev_thr_launch_)(const GradArgs &ga, hipStream_t stream) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) rt_gcu = prop.multiProcessorCount;
         if (rt_gcu <= 0) rt_gcu = 256;
     }
-    int64_t n_chunks = (e.n_trees + 31) / 32;
+    int64_t n_chunks = (grp.n + 31) / 32;
     const int64_t want_blocks = (int64_t)rt_gcu * 4 * 8;
     if (a.n_tiles * n_chunks < want_blocks) n_chunks = (want_blocks + a.n_tiles - 1) / a.n_tiles;
-    const int64_t max_chunks = (e.n_trees + 3) / 4;
+    const int64_t max_chunks = (grp.n + 3) / 4;
     if (n_chunks > max_chunks) n_chunks = max_chunks;
     if (n_chunks < 1) n_chunks = 1;
-    a.trees_per_chunk = (int32_t)((e.n_trees + n_chunks - 1) / n_chunks);
-    a.n_chunks = (int32_t)((e.n_trees + a.trees_per_chunk - 1) / a.trees_per_chunk);
+    a.trees_per_chunk = (int32_t)((grp.n + n_chunks - 1) / n_chunks);
+    a.n_chunks = (int32_t)((grp.n + a.trees_per_chunk - 1) / a.trees_per_chunk);
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const size_t lds = 4 * (size_t)a.rev_rows * 64 * sizeof(T);
