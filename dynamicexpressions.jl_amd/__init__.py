@@ -11,12 +11,13 @@ from .node import (  # noqa: F401
     Node, ParametricNode, count_nodes, count_depth, count_constant_nodes, flatten,
     flatten_population, get_scalar_constants, set_scalar_constants, string_tree, postorder,
 )
+from .simplify import simplify_tree, combine_operators  # noqa: F401
 from . import synth  # noqa: F401
 
 __all__ = [
     "OperatorEnum", "UnsupportedOperatorError", "Node", "ParametricNode", "count_nodes",
     "count_depth", "count_constant_nodes", "flatten", "flatten_population",
-    "get_scalar_constants", "set_scalar_constants", "string_tree", "synth",
+    "get_scalar_constants", "set_scalar_constants", "string_tree", "simplify_tree", "combine_operators", "synth",
 ]
 
 
