@@ -1043,6 +1043,7 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
     if (p->uses_params) {
         a.params = sPar.dev;
         a.ld_params = pa->ld_params;
+        a.n_classes = pa->n_classes;
         a.classes = sCls.dev;
         a.classes_is_i64 = pa->classes_is_i64;
         a.class_base = pa->class_base;
@@ -1681,6 +1682,7 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
     if (p->uses_params) {
         g.e.params = sPar.dev;
         g.e.ld_params = pa->ld_params;
+        g.e.n_classes = pa->n_classes;
         g.e.classes = sCls.dev;
         g.e.classes_is_i64 = pa->classes_is_i64;
         g.e.class_base = pa->class_base;
@@ -1844,6 +1846,7 @@ int de_eval_loss_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, in
     if (p->uses_params) {
         g.e.params = sPar.dev;
         g.e.ld_params = pa->ld_params;
+        g.e.n_classes = pa->n_classes;
         g.e.classes = sCls.dev;
         g.e.classes_is_i64 = pa->classes_is_i64;
         g.e.class_base = pa->class_base;

@@ -42,11 +42,15 @@ template <typename T> struct GArgs {
     const int64_t *col_off;  // n_trees + 1
     const int32_t *tree_ids; // threaded kernel: the n_trees trees this launch evaluates (null = 0..n_trees-1)
     int32_t n_all_trees;     // trees of the program (col_off has n_all_trees + 1 entries)
+    // threaded kernels: a parameter table of <= GPTAB_MAX elements is copied to LDS behind the rows
+    int32_t ptab_elems;      // ld_params * n_classes, or 0: read the table from global memory
+    uint32_t ptab_offset;    // LDS byte offset of the copy
     const int32_t *rev_mid;  // de_rev_threaded.hip: first backward instruction of every tree
     int32_t rev_rows;        // ... and LDS rows per wave (X + slots + partial rows + staging)
     int32_t rev_stage_cols, rev_stage_rows; // per-wave staging of the column sums (elements / rows)
 };
 
+constexpr int GPTAB_MAX = 2048;
 template <typename T> __device__ __forceinline__ T gimm(uint32_t w2, uint32_t w3);
 template <> __device__ __forceinline__ float gimm<float>(uint32_t w2, uint32_t) { return __uint_as_float(w2); }
 template <> __device__ __forceinline__ double gimm<double>(uint32_t w2, uint32_t w3) {

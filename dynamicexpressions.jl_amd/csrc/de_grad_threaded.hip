@@ -410,15 +410,19 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
         }
     }
     // this thread's samples: base + tid*VS + i
-    int64_t cls[VS];
+    uint32_t cls[VS]; // element offset of the sample's parameter column
     DE_UNROLL for (int i = 0; i < VS; i++) {
         cls[i] = 0;
         if (PARAMS) {
             const int64_t j = base + (int64_t)tid * VS + i;
             const int64_t jj = j < last ? j : last;
-            cls[i] = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
-                                       : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base;
+            cls[i] = (uint32_t)(a.ld_params * ((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
+                                                                 : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base));
         }
+    }
+    if (PARAMS) { // a small parameter table is gathered from LDS inside the loop, not from global memory
+        T *__restrict__ ptab = reinterpret_cast<T *>(gtsmem + a.ptab_offset);
+        for (int e = tid; e < a.ptab_elems; e += GBLK) ptab[e] = a.params[e];
     }
     __syncthreads();
 
@@ -453,7 +457,13 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
             if (PARAMS && w.x == param_off) { // operand = params[row, class]: needs kernel arguments
                 const uint32_t prow = w.y & 0xFFFFu, op = w.y >> 24;
                 GDual<T, GC> b;
-                DE_UNROLL for (int i = 0; i < VS; i++) b.x[i] = a.params[prow + a.ld_params * cls[i]];
+                if (a.ptab_elems) {
+                    const uint32_t t0_ = (uint32_t)(uintptr_t)gtsmem + a.ptab_offset + prow * (uint32_t)sizeof(T);
+                    DE_UNROLL for (int i = 0; i < VS; i++)
+                        b.x[i] = *reinterpret_cast<__attribute__((address_space(3))) T *>((uintptr_t)(t0_ + cls[i] * (uint32_t)sizeof(T)));
+                } else {
+                    DE_UNROLL for (int i = 0; i < VS; i++) b.x[i] = a.params[prow + cls[i]];
+                }
                 gpoison<T>(st.poison, b.x);
                 const int seed = (int)prow + param_seed0;
                 DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = lv_splat<T>((k == seed) ? T(1) : T(0));
@@ -563,7 +573,13 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStrea
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL || windows > 65535) return hipErrorInvalidValue;
     const size_t slot_rows = std::max<size_t>((size_t)a.n_slots * (1 + GC), (size_t)GC);
-    const size_t lds = 4 * ((size_t)a.F + slot_rows) * 64 * VS * sizeof(T); // 4 waves x rows x one wave's samples
+    size_t lds = 4 * ((size_t)a.F + slot_rows) * 64 * VS * sizeof(T); // 4 waves x rows x one wave's samples
+    a.ptab_elems = 0;
+    a.ptab_offset = (uint32_t)lds;
+    if (e.uses_params && e.ld_params * e.n_classes <= GPTAB_MAX) {
+        a.ptab_elems = (int32_t)(e.ld_params * e.n_classes);
+        lds += (size_t)a.ptab_elems * sizeof(T);
+    }
     void (*kern)(const GArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_grad_threaded_kernel<T, GC, true> : de_grad_threaded_kernel<T, GC, false>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return hipErrorInvalidValue;

@@ -40,6 +40,7 @@ struct EvalArgs {
     // parametric
     const void *params;       // device [P, C]
     int64_t ld_params;
+    int64_t n_classes;        // columns of params (a small table is staged in LDS)
     const void *classes;      // device, N ids
     int32_t classes_is_i64, class_base;
     // flags

@@ -57,7 +57,11 @@ template <typename T> struct KArgs {
     // vectorised staging of the X tile (threaded kernel): X 16-byte aligned with ldX == F
     int32_t x_vec;
     uint32_t f_magic; // ceil(2^32 / F) for F > 1 (e / F == umulhi(e, f_magic) while e * F < 2^32), 0 for F == 1
+    // parametric populations: a parameter table of <= PTAB_MAX elements is copied to LDS behind the rows (threaded kernel)
+    int32_t ptab_elems;   // ld_params * n_classes, or 0: read the table from global memory
+    uint32_t ptab_offset; // LDS byte offset of the copy
 };
+constexpr int PTAB_MAX = 2048;
 
 // A thread owns G groups of VW consecutive samples (VW*sizeof(T) = 16 bytes, one
 // ds_read_b128 / global_store_dwordx4 per group): samples base + g*(BLOCK*VW) + tid*VW + i.
@@ -784,14 +788,18 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
             }
         }
     }
-    int64_t cls[VW];
+    int64_t cls[VW]; // element offset of the sample's parameter column
     if (PARAMS) {
         DE_UNROLL for (int i = 0; i < VW; i++) {
             int64_t jj = base + tid * VW + i;
             jj = jj < last ? jj : last;
-            cls[i] = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
-                                       : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base;
+            cls[i] = a.ld_params * ((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
+                                                      : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base);
         }
+        // a small table ([P, C] with few classes) is read once per workgroup; the interpreter then gathers from LDS
+        // (a global load inside the loop costs a full memory round trip per parameter leaf)
+        T *__restrict__ ptab = reinterpret_cast<T *>(smem_raw + a.ptab_offset);
+        for (int e = tid; e < a.ptab_elems; e += BLK) ptab[e] = a.params[e];
     }
     __syncthreads();
 
@@ -829,11 +837,25 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
             if (PARAMS && w.x == param_off) { // operand = params[row, class]: needs kernel arguments
                 const uint32_t op = w.y >> 24;
                 VG<T, 1> av, bv;
-                const T *__restrict__ s_ = a.params + (w.y & 0xFFFFu);
-                DE_UNROLL for (int i = 0; i < VW; i++) bv.v[0][i] = s_[a.ld_params * cls[i]];
+                if (a.ptab_elems) {
+                    const uint32_t t0_ = (uint32_t)(uintptr_t)smem_raw + a.ptab_offset + (w.y & 0xFFFFu) * (uint32_t)sizeof(T);
+                    DE_UNROLL for (int i = 0; i < VW; i++)
+                        bv.v[0][i] = *reinterpret_cast<__attribute__((address_space(3))) T *>((uintptr_t)(t0_ + (uint32_t)cls[i] * (uint32_t)sizeof(T)));
+                } else {
+                    const T *__restrict__ s_ = a.params + (w.y & 0xFFFFu);
+                    DE_UNROLL for (int i = 0; i < VW; i++) bv.v[0][i] = s_[cls[i]];
+                }
                 if (w.y & (1u << 23)) hpoison<T>(st.poison, bv.v[0]);
-                if (op == DOP_LOAD) st.acc = bv.v[0];
-                else { av.v[0] = st.acc; av = cold_op<T, 1>(op, av, bv); st.acc = av.v[0]; }
+                switch (op) { // the hot binary operators inline (same arithmetic as their handlers); the rest through the generic switch
+                case DOP_LOAD: st.acc = bv.v[0]; break;
+                case DE_B_ADD: st.acc = bin_apply<T, 0>(st.acc, bv.v[0]); break;
+                case DE_B_SUB: st.acc = bin_apply<T, 1>(st.acc, bv.v[0]); break;
+                case DOP_RSUB: st.acc = bin_apply<T, 2>(st.acc, bv.v[0]); break;
+                case DE_B_MUL: st.acc = bin_apply<T, 3>(st.acc, bv.v[0]); break;
+                case DE_B_DIV: st.acc = bin_apply<T, 4>(st.acc, bv.v[0]); break;
+                case DOP_RDIV: st.acc = bin_apply<T, 5>(st.acc, bv.v[0]); break;
+                default: av.v[0] = st.acc; av = cold_op<T, 1>(op, av, bv); st.acc = av.v[0]; break;
+                }
                 continue;
             }
             const HandlerFn<T> fn = reinterpret_cast<HandlerFn<T>>(hbase + w.x);
@@ -960,6 +982,8 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
     constexpr int VW = VecOf<T>::W;
     constexpr int TILE = BLK * VW * G;
     KArgs<T> a;
+    a.ptab_elems = 0;
+    a.ptab_offset = 0;
     a.code = e.code;
     a.code_off = e.code_off;
     a.X = static_cast<const T *>(e.X);
@@ -1047,6 +1071,8 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     constexpr int VW = VecOf<T>::W;
     constexpr int TILE = 256 * VW;
     KArgs<T> a;
+    a.ptab_elems = 0;
+    a.ptab_offset = 0;
     a.code = e.code;
     a.code_off = e.code_off;
     a.X = static_cast<const T *>(e.X);
@@ -1076,7 +1102,13 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.n_chunks = nch;
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(a.F + a.n_slots + env_int("DE_EXTRA_LDS_ROWS", 0)) * 257 * 16;
+    size_t lds = (size_t)(a.F + a.n_slots + env_int("DE_EXTRA_LDS_ROWS", 0)) * 257 * 16;
+    a.ptab_elems = 0;
+    a.ptab_offset = (uint32_t)lds;
+    if (e.uses_params && e.ld_params * e.n_classes <= PTAB_MAX && env_int("DE_PARAM_LDS", 1)) {
+        a.ptab_elems = (int32_t)(e.ld_params * e.n_classes);
+        lds += (size_t)a.ptab_elems * sizeof(T);
+    }
     void (*kern)(const KArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_eval_threaded_kernel<T, true> : de_eval_threaded_kernel<T, false>;
     a.y = a.w = nullptr;
     a.partial = nullptr;

@@ -297,6 +297,10 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
     uint32_t poff = 0; // element offset of the sample's parameter column
     if (PARAMS)
         poff = (uint32_t)(a.ld_params * ((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj] : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base));
+    if (PARAMS) { // a small parameter table is gathered from LDS inside the loop, not from global memory
+        T *__restrict__ ptab = reinterpret_cast<T *>(rtsmem + a.ptab_offset);
+        for (int e = tid; e < a.ptab_elems; e += GBLK) ptab[e] = a.params[e];
+    }
     const T yv = a.y[jj];
     const T wv = j <= last ? (a.w ? a.w[jj] : T(1)) : T(0);
     __syncthreads();
@@ -345,7 +349,8 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
             nxt = code[pc + 1];
             if (PARAMS && w.x == param_off) { // operand = params[row, class]: y = row | op << 24, z = partial row
                 const uint32_t prow = w.y & 0xFFFFu, op = w.y >> 24;
-                const T b = a.params[prow + poff];
+                const T b = a.ptab_elems ? *RLDS(T, (uint32_t)(uintptr_t)rtsmem + a.ptab_offset + (prow + poff) * (uint32_t)sizeof(T))
+                                         : a.params[prow + poff];
                 rpoison<T>(st.vpoison, b);
                 if (op == DOP_LOAD) st.x = b;
                 else st = r_gen_apply<T>(st, op, b, st.lds0 + w.z);
@@ -455,7 +460,12 @@ hipError_t DE_RT_NAME(rev_thr_launch_)(const GradArgs &ga, int group, hipStream_
     a.n_chunks = (int32_t)((grp.n + a.trees_per_chunk - 1) / a.trees_per_chunk);
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    const size_t lds = 4 * (size_t)a.rev_rows * 64 * sizeof(T);
+    size_t lds = 4 * (size_t)a.rev_rows * 64 * sizeof(T);
+    a.ptab_offset = (uint32_t)lds;
+    if (e.uses_params && e.ld_params * e.n_classes <= GPTAB_MAX) {
+        a.ptab_elems = (int32_t)(e.ld_params * e.n_classes);
+        lds += (size_t)a.ptab_elems * sizeof(T);
+    }
     void (*kern)(const GArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_rev_threaded_kernel<T, true> : de_rev_threaded_kernel<T, false>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return hipErrorInvalidValue;
