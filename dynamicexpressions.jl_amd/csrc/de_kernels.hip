@@ -788,13 +788,13 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
             }
         }
     }
-    int64_t cls[VW]; // element offset of the sample's parameter column
+    uint32_t cls[VW]; // element offset of the sample's parameter column (the table has < 2^32 elements)
     if (PARAMS) {
         DE_UNROLL for (int i = 0; i < VW; i++) {
             int64_t jj = base + tid * VW + i;
             jj = jj < last ? jj : last;
-            cls[i] = a.ld_params * ((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
-                                                      : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base);
+            cls[i] = (uint32_t)(a.ld_params * ((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
+                                                                 : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base));
         }
         // a small table ([P, C] with few classes) is read once per workgroup; the interpreter then gathers from LDS
         // (a global load inside the loop costs a full memory round trip per parameter leaf)
@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
                 if (a.ptab_elems) {
                     const uint32_t t0_ = (uint32_t)(uintptr_t)smem_raw + a.ptab_offset + (w.y & 0xFFFFu) * (uint32_t)sizeof(T);
                     DE_UNROLL for (int i = 0; i < VW; i++)
-                        bv.v[0][i] = *reinterpret_cast<__attribute__((address_space(3))) T *>((uintptr_t)(t0_ + (uint32_t)cls[i] * (uint32_t)sizeof(T)));
+                        bv.v[0][i] = *reinterpret_cast<__attribute__((address_space(3))) T *>((uintptr_t)(t0_ + cls[i] * (uint32_t)sizeof(T)));
                 } else {
                     const T *__restrict__ s_ = a.params + (w.y & 0xFFFFu);
                     DE_UNROLL for (int i = 0; i < VW; i++) bv.v[0][i] = s_[cls[i]];
