@@ -2,6 +2,7 @@
 // programs, evaluation entry points.  No exception leaves this file.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -110,6 +111,12 @@ struct de_program {
     // operand, the index of the instruction carrying its bits in bcode / tcode (eval source program) and in
     // gbcode / gtcode (unfolded program); -1 elsewhere.  Empty = not available (full rebuild instead).
     std::vector<int32_t> bsite, tsite, gbsite, gtsite_of_gb;
+    // compact forms for de_program_set_consts (rebuilt when site_gen moves): only the instructions that carry an immediate
+    struct EvalSite { int32_t src, b, t; };          // source instruction (fcode/code), bcode index, tcode index
+    struct GradSite { int32_t src, gb, gt, rt; };   // code instruction, gbcode index, gtcode / rtcode index or -1
+    std::vector<EvalSite> eval_sites;
+    std::vector<GradSite> grad_sites;
+    uint64_t site_gen = 1, lists_gen = 0;
     // reverse-accumulation form (de_rev_threaded.hip) for one gradient mode
     std::vector<BoundInstr> rtcode;
     std::vector<int32_t> rtcode_off, rtcode_mid, rtsite_of_gb;
@@ -350,6 +357,7 @@ static void rebind(de_program *p) {
     }
     match_const_sites(src, off, p->bcode, p->bcode_off, p->n_trees, [](const BoundInstr &b) { return bop_is_const_source(b.bop); }, &p->bsite);
     p->tsite.clear();
+    p->site_gen++;
 }
 // (bind_tree / fuse_tree are ~0.3 us per tree: not worth threads)
 
@@ -400,6 +408,7 @@ static int make_threaded(de_ctx *c, de_program *p) {
         const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
         const std::vector<int32_t> &off = p->folded ? p->fcode_off : p->code_off;
         match_const_sites(src, off, p->fbcode, p->tcode_off, p->n_trees, [](const BoundInstr &b) { return top_carries_const(b.bop); }, &p->tsite);
+        p->site_gen++;
     }
     p->handler_base = base;
     p->param_handler_off = (uint32_t)(table[BOP_GEN_PARAM] - base);
@@ -662,6 +671,10 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
     if (!p) return DE_ERR_INVALID_ARG;
     de_ctx *ctx = p->ctx;
     if (!consts && !p->consts.empty()) return fail(ctx, DE_ERR_INVALID_ARG, "consts is null");
+    const bool timing = getenv("DE_DEBUG_TIMING") != nullptr; // stderr: microseconds per phase
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+    const auto t0 = now();
     for (size_t k = 0; k < p->consts.size(); k++) {
         const double v = p->dtype == DE_F32 ? (double)static_cast<const float *>(consts)[k]
                                             : static_cast<const double *>(consts)[k];
@@ -669,57 +682,69 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
         write_imm(p->code[(size_t)p->const_instr[k]], p->dtype, v);
         if (p->folded && p->fconst_instr[k] >= 0) write_imm(p->fcode[(size_t)p->fconst_instr[k]], p->dtype, v);
     }
+    const auto t1 = now();
     if (p->folded) {
         int rc = DE_OK;
         try { rc = refresh_folds(ctx, p); } catch (const std::bad_alloc &) { rc = fail(ctx, DE_ERR_HIP, "out of host memory"); }
         if (rc != DE_OK) return rc;
     }
+    const auto t2 = now();
     recompute_host_ok(p);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     {
         const int rc = upload_ok_eval(ctx, p);
         if (rc != DE_OK) return rc;
     }
+    const auto t3 = now();
     // Same tree shapes, new immediates: patch the bits where they live (the optimiser calls this once per
     // step — re-binding 10^4 trees costs milliseconds, the kernel it feeds a few hundred microseconds).
     const char *nopatch = getenv("DE_NO_CONST_PATCH");
     if (!(nopatch && *nopatch == '1') && p->threaded && !p->tsite.empty() && !p->bsite.empty()) {
         const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
-        for (size_t i = 0; i < src.size(); i++) {
-            const int32_t bj = p->bsite[i], tj = p->tsite[i];
-            if (bj < 0) continue;
-            p->bcode[(size_t)bj].lo = src[i].imm.u32[0];
-            p->bcode[(size_t)bj].hi = src[i].imm.u32[1];
-            p->tcode[(size_t)tj].lo = src[i].imm.u32[0];
-            p->tcode[(size_t)tj].hi = src[i].imm.u32[1];
-        }
         const bool gpatch = p->d_gcode && !p->gcode_stale && !p->gbsite.empty();
+        const bool tpatch = gpatch && p->gt_valid && !p->gtsite_of_gb.empty();
+        const bool rpatch = gpatch && p->rt_valid && !p->rtsite_of_gb.empty();
+        if (p->lists_gen != p->site_gen) { // one pass over all instructions, then only the immediates are visited
+            p->eval_sites.clear();
+            p->grad_sites.clear();
+            for (size_t i = 0; i < src.size(); i++)
+                if (p->bsite[i] >= 0) p->eval_sites.push_back({(int32_t)i, p->bsite[i], p->tsite[i]});
+            if (!p->gbsite.empty())
+                for (size_t i = 0; i < p->code.size(); i++) {
+                    const int32_t gj = p->gbsite[i];
+                    if (gj < 0) continue;
+                    p->grad_sites.push_back({(int32_t)i, gj, p->gtsite_of_gb.empty() ? -1 : p->gtsite_of_gb[(size_t)gj],
+                                             p->rtsite_of_gb.empty() ? -1 : p->rtsite_of_gb[(size_t)gj]});
+                }
+            p->lists_gen = p->site_gen;
+        }
+        for (const de_program::EvalSite &e : p->eval_sites) {
+            const uint32_t lo = src[(size_t)e.src].imm.u32[0], hi = src[(size_t)e.src].imm.u32[1];
+            p->bcode[(size_t)e.b].lo = lo;
+            p->bcode[(size_t)e.b].hi = hi;
+            p->tcode[(size_t)e.t].lo = lo;
+            p->tcode[(size_t)e.t].hi = hi;
+        }
         if (gpatch) {
-            const bool tpatch = p->gt_valid && !p->gtsite_of_gb.empty();
-            for (size_t i = 0; i < p->code.size(); i++) {
-                const int32_t gj = p->gbsite[i];
-                if (gj < 0) continue;
-                p->gbcode[(size_t)gj].lo = p->code[i].imm.u32[0];
-                p->gbcode[(size_t)gj].hi = p->code[i].imm.u32[1];
-                if (tpatch) {
-                    const int32_t tj = p->gtsite_of_gb[(size_t)gj];
-                    p->gtcode[(size_t)tj].lo = p->code[i].imm.u32[0];
-                    p->gtcode[(size_t)tj].hi = p->code[i].imm.u32[1];
+            for (const de_program::GradSite &g : p->grad_sites) {
+                const uint32_t lo = p->code[(size_t)g.src].imm.u32[0], hi = p->code[(size_t)g.src].imm.u32[1];
+                p->gbcode[(size_t)g.gb].lo = lo;
+                p->gbcode[(size_t)g.gb].hi = hi;
+                if (tpatch && g.gt >= 0) {
+                    p->gtcode[(size_t)g.gt].lo = lo;
+                    p->gtcode[(size_t)g.gt].hi = hi;
+                }
+                if (rpatch && g.rt >= 0) {
+                    p->rtcode[(size_t)g.rt].lo = lo;
+                    p->rtcode[(size_t)g.rt].hi = hi;
                 }
             }
             if (!tpatch) p->gt_valid = false;
-            if (p->rt_valid && !p->rtsite_of_gb.empty()) {
-                for (size_t i = 0; i < p->code.size(); i++) {
-                    const int32_t gj = p->gbsite[i];
-                    const int32_t rj = gj < 0 ? -1 : p->rtsite_of_gb[(size_t)gj];
-                    if (rj < 0) continue;
-                    p->rtcode[(size_t)rj].lo = p->code[i].imm.u32[0];
-                    p->rtcode[(size_t)rj].hi = p->code[i].imm.u32[1];
-                }
-            } else p->rt_valid = false;
+            if (!rpatch) p->rt_valid = false;
         } else {
             p->gcode_stale = true;
         }
+        const auto t4 = now();
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // the program may be in use by work already queued
         if (!p->tcode.empty())
             HIP_TRY(ctx, hipMemcpy(p->d_code, p->tcode.data(), p->tcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
@@ -731,6 +756,9 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
             if (p->rt_valid && !p->rtcode.empty())
                 HIP_TRY(ctx, hipMemcpy(p->d_rtcode, p->rtcode.data(), p->rtcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
         }
+        if (timing)
+            fprintf(stderr, "set_consts us: write %ld, refresh_folds %ld, flags %ld, patch %ld, upload %ld\n", us(t0, t1), us(t1, t2), us(t2, t3),
+                    us(t3, t4), us(t4, now()));
         return DE_OK;
     }
     p->gcode_stale = true;
@@ -1104,6 +1132,7 @@ static int ensure_generic_code(de_ctx *c, de_program *p) {
         match_const_sites(p->code, p->code_off, p->gbcode, p->gbcode_off, p->n_trees,
                           [](const BoundInstr &b) { return bop_is_const_source(b.bop); }, &p->gbsite);
         p->gtsite_of_gb.clear();
+        p->site_gen++;
     }
     if (!p->d_gcode) {
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gcode), (p->gbcode.size() + 1) * sizeof(BoundInstr)));
@@ -1208,6 +1237,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         p->gtcode.clear();
         p->gtcode_off.assign((size_t)p->n_trees + 1, 0);
         p->gtsite_of_gb.assign(p->gbcode.size(), -1);
+        p->site_gen++;
         bool ok = true;
         for (int64_t t = 0; t < p->n_trees && ok; t++) {
             const int bkt = bucket_of(t);
@@ -1274,7 +1304,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             }
             p->gtcode_off[(size_t)t + 1] = (int32_t)p->gtcode.size();
         }
-        if (!ok) { p->gtsite_of_gb.clear(); return DE_OK; }
+        if (!ok) { p->gtsite_of_gb.clear(); p->site_gen++; return DE_OK; }
         std::vector<int32_t> ids((size_t)p->n_trees);
         int32_t start[NB], run = 0;
         for (int b = 0; b < NB; b++) { start[b] = run; run += count[b]; }
@@ -1356,6 +1386,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
         p->rtcode_off.assign((size_t)p->n_trees + 1, 0);
         p->rtcode_mid.assign((size_t)p->n_trees, 0);
         p->rtsite_of_gb.assign(p->gbcode.size(), -1);
+        p->site_gen++;
         uint32_t max_prows = 0;
         bool ok = true;
         std::vector<int> row_hist; // trees by partial + accumulation rows (DE_DEBUG_ROWS=1 prints it)
@@ -1521,7 +1552,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
         const char *envx = getenv("DE_REV_EXTRA_ROWS"); // occupancy experiments: pad the LDS allocation
         const uint64_t extra_rows = envx ? (uint64_t)atoi(envx) : 0;
         const uint64_t rows = (uint64_t)PR0 + max_prows + stage_rows + extra_rows;
-        if (!ok || 4 * rows * RB > 160 * 1024 || rows * RB >= (1u << 24)) { p->rtsite_of_gb.clear(); return DE_OK; }
+        if (!ok || 4 * rows * RB > 160 * 1024 || rows * RB >= (1u << 24)) { p->rtsite_of_gb.clear(); p->site_gen++; return DE_OK; }
         // The kernel is latency-bound and its occupancy is set by the LDS rows of the neediest tree of a launch
         // (5 -> 4 workgroups per CU: +17 % time): trees are grouped by the number of workgroups per CU their own
         // need allows and every group is a launch of its own (small groups join the next needier one).
