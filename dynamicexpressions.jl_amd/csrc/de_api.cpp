@@ -1963,9 +1963,15 @@ int de_eval_loss_grad_by_class(de_ctx_t *c, de_program_t *p, const void *X, int6
     // dloss entries no tree owns (caller-chosen offsets) are never read by the combine pass
     HIP_TRY(c, hipMemsetAsync(c->sBcDloss.p, 0, (size_t)C * (size_t)span * es, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    c->nested++;
+    struct Nest { // inner calls leave the timing events alone; restored on every exit path
+        de_ctx *c;
+        explicit Nest(de_ctx *c_) : c(c_) { c->nested++; }
+        ~Nest() { c->nested--; }
+    };
     int rc = DE_OK;
     const size_t cls_es = pa->classes_is_i64 ? 8 : 4;
+    {
+    Nest nest(c);
     for (int64_t k = 0; k < C && rc == DE_OK; k++) {
         const int64_t j0 = class_starts[k], n = class_starts[k + 1] - j0;
         de_param_args_t sub = *pa;
@@ -1977,7 +1983,7 @@ int de_eval_loss_grad_by_class(de_ctx_t *c, de_program_t *p, const void *X, int6
                                static_cast<char *>(c->sBcDloss.p) + (size_t)k * (size_t)span * es, dloss_offsets,
                                static_cast<uint8_t *>(c->sBcOk.p) + (size_t)k * (size_t)p->n_trees);
     }
-    c->nested--;
+    }
     if (rc != DE_OK) return rc;
     Staged sLoss, sDl, sDp, sOk;
     if (loss) {
