@@ -13,6 +13,7 @@
 //   * eval_diff (single direction) performs NO validity test (:99-119).
 // Partial derivatives restate ChainRules' scalar rules (same table as oracle/de_oracle_ops.h).
 #include "de_grad_common.h"
+#include <mutex>
 
 namespace de {
 
@@ -441,6 +442,8 @@ bool grad_threaded_has(int dtype, int GC, int VS) {
 hipError_t grad_handler_table(int dtype, int GC, int VS, uint64_t *table) {
     static uint64_t cache[2][9][3][GOP_MAX];
     static bool have[2][9][3] = {};
+    static std::mutex mu; // contexts on several host threads may ask at once
+    const std::lock_guard<std::mutex> lock(mu);
     const int k = dtype == DE_F32 ? 0 : 1;
     if (!grad_threaded_has(dtype, GC, VS)) return hipErrorInvalidValue;
     if (!have[k][GC][VS]) {
@@ -486,6 +489,8 @@ hipError_t rev_thr_launch_d(const GradArgs &ga, int group, hipStream_t stream);
 hipError_t rev_handler_table(int dtype, uint64_t *table) {
     static uint64_t cache[2][ROP_COUNT];
     static bool have[2] = {false, false};
+    static std::mutex mu; // contexts on several host threads may ask at once
+    const std::lock_guard<std::mutex> lock(mu);
     const int k = dtype == DE_F32 ? 0 : 1;
     if (!have[k]) {
         const hipError_t st = k == 0 ? rev_thr_fetch_f(cache[k]) : rev_thr_fetch_d(cache[k]);

@@ -22,6 +22,7 @@
 //    same XCD, so the tile is fetched from HBM once and re-served by that XCD's L2.
 //  * No MFMA: this is an elementwise map, not a contraction.
 #include <hip/hip_runtime.h>
+#include <mutex>
 
 #include <cstdlib>
 
@@ -1054,6 +1055,8 @@ template <typename T> static hipError_t fetch_handlers(uint64_t *host_table) {
 hipError_t eval_handler_table(int dtype, uint64_t *table) {
     static uint64_t cache[2][TOP_COUNT];
     static bool have[2] = {false, false};
+    static std::mutex mu; // contexts on several host threads may ask at once
+    const std::lock_guard<std::mutex> lock(mu);
     const int k = dtype == DE_F32 ? 0 : 1;
     if (!have[k]) {
         hipError_t st = k == 0 ? fetch_handlers<float>(cache[k]) : fetch_handlers<double>(cache[k]);
