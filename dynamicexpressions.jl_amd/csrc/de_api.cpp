@@ -1161,6 +1161,9 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
     const char *env = getenv("DE_GRAD_THREADED");
     if (env && *env == '0') return DE_OK;
     const int F = p->n_features, P = p->n_params;
+    // Parameter leaves are LDS rows of their own: the kernel gathers params[:, class] into P rows behind the X rows when it
+    // stages a tile (the reference's formulation, src/ParametricExpression.jl:381-389), so every hot handler serves them.
+    const int FE = F + (p->uses_params ? P : 0);
     // Two samples per lane double the buckets (launches) and the tile: they pay from ~10^5 samples on (10^4 trees x
     // 10^3 rows: 0.55 ms with them, 0.35 ms without; 10^3 trees x 10^6 rows: 12.1 against 13.4 ms)
     const char *envn = getenv("DE_GRAD_VS2_MIN_N");
@@ -1220,7 +1223,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             if (!count[b]) continue;
             const int GC = WIDTH[b % NW], VS = 1 + b / NW;
             const uint64_t RBb = 64ull * VS * es32; // one wave's row
-            const uint64_t rows = (uint64_t)F + std::max<uint64_t>((uint64_t)slots[b] * (1 + GC), (uint64_t)GC);
+            const uint64_t rows = (uint64_t)FE + std::max<uint64_t>((uint64_t)slots[b] * (1 + GC), (uint64_t)GC);
             if (4 * rows * RBb > 160 * 1024) return DE_OK; // four waves' rows must fit the CU's LDS
             hipError_t st = grad_handler_table(p->dtype, GC, VS, tables[b].data());
             if (st != hipSuccess) return fail(c, DE_ERR_HIP, "gradient handler table: %s", hipGetErrorString(st));
@@ -1246,7 +1249,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             const bool one_window = bkt % NW < 7; // then g0 = 0 and every seed is known here
             const uint64_t *table = tables[bkt].data();
             const uint64_t base = bases[bkt];
-            auto slot_off = [&](uint32_t row) { return (uint32_t)((F + (row - (uint32_t)F) * (1 + GC)) * RB); };
+            auto slot_off = [&](uint32_t row) { return (uint32_t)((FE + (row - (uint32_t)F) * (1 + GC)) * RB); };
             // seed variant of a handler (de_bind.h): 0 run-time, 1 none, 2 + k
             auto seed_variant = [&](uint32_t sd) -> int { return !one_window ? 0 : (sd == 0xFFu ? 1 : (sd < (uint32_t)GC ? 2 + (int)sd : 0)); };
             for (int32_t i = p->gbcode_off[(size_t)t]; i < p->gbcode_off[(size_t)t + 1] && ok; i++) {
@@ -1273,6 +1276,13 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                     sv = rt ? 0 : seed_variant(sd);
                     o.arg = low | (sv == 0 ? sd << 24 : 0u);
                 };
+                auto param_operand = [&](uint32_t prm, bool rt = false) { // parameter row prm = LDS row F + prm, seed = its gradient row
+                    const uint32_t sd = mode != DE_GRAD_CONSTANT ? prm : 0xFFu;
+                    if (sd != 0xFFu && sd >= 0xF0u) ok = false;
+                    src = GSRC_LEAF;
+                    sv = rt ? 0 : seed_variant(sd);
+                    o.arg = (((uint32_t)F + prm) * RB) | (sv == 0 ? sd << 24 : 0u);
+                };
                 uint32_t gop = 0;
                 if (b.bop == BOP_CHECK_ROW) continue; // leaf operands are tested where they are read
                 if (b.bop == BOP_LOAD_ROW) { row_operand(); gop = gop_load(GC, src, sv); }
@@ -1292,7 +1302,27 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                 } else if (b.bop == BOP_GEN_ROW) { row_operand(true); gop = gop_gen(GC, src); o.lo = aux; o.hi = 0; }
                 else if (b.bop == BOP_GEN_CONST) { const_operand(b.arg & 0xFFFFu, aux << 16, true); gop = gop_gen(GC, GSRC_CONST); }
                 else if (b.bop == BOP_GEN_ACC) { gop = gop_gen(GC, GSRC_ACC); o.arg = 0; o.lo = aux; o.hi = 0; }
-                else if (b.bop == BOP_GEN_PARAM) { gop = gop_param(GC); o.arg = b.arg; }
+                else if (b.bop == BOP_GEN_PARAM) { // operand = parameter row (b.arg & 0xFFFF), operator aux: the leaf-operand handlers
+                    const uint32_t prm = b.arg & 0xFFFFu;
+                    int k = -1, ku = -1;
+                    switch (aux) {
+                    case DE_B_ADD: k = 0; break;
+                    case DE_B_SUB: k = 1; break;
+                    case DOP_RSUB: k = 2; break;
+                    case DE_B_MUL: k = 3; break;
+                    case DE_B_DIV: k = 4; break;
+                    case DOP_RDIV: k = 5; break;
+                    case DE_U_COS: ku = 0; break;
+                    case DE_U_EXP: ku = 1; break;
+                    case DE_U_SIN: ku = 2; break;
+                    default: break;
+                    }
+                    o.lo = o.hi = 0;
+                    if (aux == (uint32_t)DOP_LOAD) { param_operand(prm); gop = gop_load(GC, src, sv); }
+                    else if (k >= 0) { param_operand(prm); gop = gop_bin(GC, k, src, sv, false); }
+                    else if (ku >= 0) { param_operand(prm); gop = gop_un(GC, ku, src, sv, false); }
+                    else { param_operand(prm, true); gop = gop_gen(GC, GSRC_LEAF); o.lo = aux; }
+                }
                 else if (b.bop == BOP_TERN) {
                     if (row < (uint32_t)F || b.lo < (uint32_t)F) ok = false; // both operands are spilled duals
                     else { gop = gop_tern(GC); o.arg = slot_off(row) | (aux << 24); o.lo = slot_off(b.lo) - slot_off(row); o.hi = 0; }
@@ -1368,7 +1398,9 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
     const int F = p->n_features, P = p->n_params;
     if (!(p->rt_valid && p->rt_mode == mode)) {
         const uint32_t es32 = p->dtype == DE_F32 ? 4u : 8u, RB = 64u * es32;
-        const uint32_t PR0 = (uint32_t)F + (uint32_t)p->n_slots; // first partial row
+        // parameter leaves are LDS rows F .. F+P (gathered by class when the kernel stages a tile), slots follow
+        const uint32_t FE = (uint32_t)F + (p->uses_params ? (uint32_t)P : 0u);
+        const uint32_t PR0 = FE + (uint32_t)p->n_slots; // first partial row
         uint64_t table[ROP_COUNT];
         hipError_t hst = rev_handler_table(p->dtype, table);
         if (hst != hipSuccess) return fail(c, DE_ERR_HIP, "reverse handler table: %s", hipGetErrorString(hst));
@@ -1382,6 +1414,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
         auto const_col = [&](uint32_t ord) -> uint32_t {
             return mode == DE_GRAD_CONSTANT ? 1u + ord : (mode == DE_GRAD_BOTH ? 1u + (uint32_t)(P + F) + ord : NONE);
         };
+        auto rowb = [&](uint32_t row) { return (row < (uint32_t)F ? row : row + (FE - (uint32_t)F)) * RB; }; // LDS byte offset of a bound row
         p->rtcode.clear();
         p->rtcode_off.assign((size_t)p->n_trees + 1, 0);
         p->rtcode_mid.assign((size_t)p->n_trees, 0);
@@ -1428,15 +1461,15 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                 if (b.bop == BOP_CHECK_ROW) continue; // leaf operands are tested where they are read
                 if (b.bop == BOP_LOAD_ROW) {
                     if (!is_leaf) { ok = false; break; }
-                    F_(mk(rop_load(RSRC_LEAF), row * RB, 0, 0));
+                    F_(mk(rop_load(RSRC_LEAF), rowb(row), 0, 0));
                     if (leaf_col(row) != NONE) R_(mk(ROP_R_LEAF, 0, leaf_col(row), 0), true);
                 } else if (b.bop == BOP_LOAD_CONST) {
                     p->rtsite_of_gb[(size_t)i] = (int32_t)p->rtcode.size();
                     F_(mk(rop_load(RSRC_CONST), 0, b.lo, b.hi));
                     if (const_col(ord) != NONE) R_(mk(ROP_R_LEAF, 0, const_col(ord), 0), true);
                 } else if (b.bop == BOP_PUSH) {
-                    F_(mk(ROP_PUSH, row * RB, 0, 0));
-                    R_(mk(ROP_R_POP, row * RB, 0, 0));
+                    F_(mk(ROP_PUSH, rowb(row), 0, 0));
+                    R_(mk(ROP_R_POP, rowb(row), 0, 0));
                 } else if (b.bop == BOP_CHECK_ACC) {
                     F_(mk(ROP_CHECK, 0, 0, 0));
                 } else if (b.bop >= BOP_BIN_BASE && b.bop < BOP_BIN_END) {
@@ -1450,8 +1483,8 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                         F_(mk(rop_bin(k, RSRC_CONST, chk), pr, b.lo, b.hi));
                         back_binary(pk, pr, false, 0, const_col(ord));
                     } else {
-                        F_(mk(rop_bin(k, is_leaf ? RSRC_LEAF : RSRC_SLOT, chk), row * RB, pr, 0));
-                        back_binary(pk, pr, !is_leaf, row * RB, is_leaf ? leaf_col(row) : NONE);
+                        F_(mk(rop_bin(k, is_leaf ? RSRC_LEAF : RSRC_SLOT, chk), rowb(row), pr, 0));
+                        back_binary(pk, pr, !is_leaf, rowb(row), is_leaf ? leaf_col(row) : NONE);
                     }
                 } else if (b.bop >= BOP_UN_BASE && b.bop < BOP_UN_END) {
                     const uint32_t v = b.bop - BOP_UN_BASE;
@@ -1460,7 +1493,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     const uint32_t pr = alloc(1);
                     if (from_row) {
                         if (!is_leaf) { ok = false; break; }
-                        F_(mk(rop_un(k, RSRC_LEAF, chk), row * RB, pr, 0));
+                        F_(mk(rop_un(k, RSRC_LEAF, chk), rowb(row), pr, 0));
                         back_unary_leaf(pr, leaf_col(row));
                     } else {
                         F_(mk(rop_un(k, RSRC_ACC, chk), pr, 0, 0));
@@ -1470,9 +1503,9 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     const bool unary = aux < (uint32_t)DE_B_ADD;
                     const uint32_t pr = alloc(unary ? 1 : 2);
                     if (unary && !is_leaf) { ok = false; break; }
-                    F_(mk(rop_gen(is_leaf ? RSRC_LEAF : RSRC_SLOT), row * RB, pr | (aux << 24), 0));
+                    F_(mk(rop_gen(is_leaf ? RSRC_LEAF : RSRC_SLOT), rowb(row), pr | (aux << 24), 0));
                     if (unary) back_unary_leaf(pr, leaf_col(row));
-                    else back_binary(0, pr, !is_leaf, row * RB, is_leaf ? leaf_col(row) : NONE);
+                    else back_binary(0, pr, !is_leaf, rowb(row), is_leaf ? leaf_col(row) : NONE);
                 } else if (b.bop == BOP_GEN_CONST) {
                     const bool unary = aux < (uint32_t)DE_B_ADD;
                     const uint32_t pr = alloc(unary ? 1 : 2);
@@ -1484,23 +1517,46 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     const uint32_t pr = alloc(1);
                     F_(mk(rop_gen(RSRC_ACC), pr | (aux << 24), 0, 0));
                     R_(mk(ROP_R_UN, pr, 0, 0));
-                } else if (b.bop == BOP_GEN_PARAM) {
-                    const uint32_t prm = b.arg & 0xFFFFu;
+                } else if (b.bop == BOP_GEN_PARAM) { // operand = parameter row prm = LDS leaf row F + prm
+                    const uint32_t prm = b.arg & 0xFFFFu, prow = ((uint32_t)F + prm) * RB;
+                    int k = -1, ku = -1;
+                    switch (aux) {
+                    case DE_B_ADD: k = 0; break;
+                    case DE_B_SUB: k = 1; break;
+                    case DOP_RSUB: k = 2; break;
+                    case DE_B_MUL: k = 3; break;
+                    case DE_B_DIV: k = 4; break;
+                    case DOP_RDIV: k = 5; break;
+                    case DE_U_COS: ku = 0; break;
+                    case DE_U_EXP: ku = 1; break;
+                    case DE_U_SIN: ku = 2; break;
+                    default: break;
+                    }
                     if (aux == (uint32_t)DOP_LOAD) {
-                        F_(mk(ROP_PARAM, prm | (aux << 24), 0, 0));
+                        F_(mk(rop_load(RSRC_LEAF), prow, 0, 0));
                         if (param_col(prm) != NONE) R_(mk(ROP_R_LEAF, 0, param_col(prm), 0), true);
+                    } else if (k >= 0) {
+                        const uint32_t pr = k >= 3 ? alloc(2) : 0;
+                        F_(mk(rop_bin(k, RSRC_LEAF, false), prow, pr, 0));
+                        back_binary(k == 0 ? 1 : (k == 1 ? 2 : (k == 2 ? 3 : 0)), pr, false, 0, param_col(prm));
+                    } else if (ku >= 0) {
+                        const uint32_t pr = alloc(1);
+                        F_(mk(rop_un(ku, RSRC_LEAF, false), prow, pr, 0));
+                        back_unary_leaf(pr, param_col(prm));
                     } else {
                         const bool unary = aux < (uint32_t)DE_B_ADD;
                         const uint32_t pr = alloc(unary ? 1 : 2);
-                        F_(mk(ROP_PARAM, prm | (aux << 24), pr, 0));
+                        F_(mk(rop_gen(RSRC_LEAF), prow, pr | (aux << 24), 0));
                         if (unary) back_unary_leaf(pr, param_col(prm));
                         else back_binary(0, pr, false, 0, param_col(prm));
                     }
                 } else if (b.bop == BOP_TERN) {
                     if (is_leaf || b.lo < (uint32_t)F || row > 0xFFFFu || b.lo > 0xFFFFu) { ok = false; break; }
                     const uint32_t pr = alloc(3);
-                    F_(mk(ROP_TERN, pr | (aux << 24), row | (b.lo << 16), 0));
-                    R_(mk(ROP_R_TERN, pr, row | (b.lo << 16), 0));
+                    const uint32_t rb_ = row + (FE - (uint32_t)F), rc_ = b.lo + (FE - (uint32_t)F);
+                    if (rb_ > 0xFFFFu || rc_ > 0xFFFFu) { ok = false; break; }
+                    F_(mk(ROP_TERN, pr | (aux << 24), rb_ | (rc_ << 16), 0));
+                    R_(mk(ROP_R_TERN, pr, rb_ | (rc_ << 16), 0));
                 } else ok = false; // INJ_*: only bound with early_exit=false, never for gradients
             }
             if (!ok) break;

@@ -31,6 +31,7 @@ template <typename T> struct GArgs {
     const void *classes;
     int64_t N, ldX, ld_out, ld_params, n_tiles;
     int32_t F, P, n_trees, trees_per_chunk, n_chunks, n_slots, mode;
+    int32_t FX; // threaded kernels: rows of X; F - FX further leaf rows hold the parameters gathered by class (0 elsewhere)
     int32_t classes_is_i64, class_base, uses_params, check;
     int32_t diff_g0; // >= 0: eval_diff mode — single component diff_g0, dense [n_trees, ld_out] output
     // fused loss + pullback (de_eval_loss_grad): instead of storing x and d[k] the kernel reduces

@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
     const int slot_rows = a.n_slots * (1 + GC) > GC ? a.n_slots * (1 + GC) : GC;
     const int R = F + slot_rows; // rows per wave
     {
-        const uint32_t Fu = (uint32_t)F;
+        const uint32_t Fu = (uint32_t)a.FX;
         const uint32_t total = (uint32_t)TILE * Fu;
         for (uint32_t e = tid; e < total; e += GBLK) {
             const uint32_t j = e / Fu, f = e - j * Fu;
@@ -409,20 +409,15 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
             rows[((j / WSAMP) * (uint32_t)R + f) * WSAMP + (j % WSAMP)] = a.X[f + a.ldX * jj];
         }
     }
-    // this thread's samples: base + tid*VS + i
-    uint32_t cls[VS]; // element offset of the sample's parameter column
-    DE_UNROLL for (int i = 0; i < VS; i++) {
-        cls[i] = 0;
-        if (PARAMS) {
-            const int64_t j = base + (int64_t)tid * VS + i;
-            const int64_t jj = j < last ? j : last;
-            cls[i] = (uint32_t)(a.ld_params * ((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
-                                                                 : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base));
+    if (PARAMS) { // rows FX .. F: params[:, class of the sample] (src/ParametricExpression.jl:381-389), read through the caches
+        const uint32_t Pu = (uint32_t)(F - a.FX), total = (uint32_t)TILE * Pu;
+        for (uint32_t e = tid; e < total; e += GBLK) {
+            const uint32_t j = e / Pu, q = e - j * Pu;
+            int64_t jj = base + j;
+            jj = jj < last ? jj : last;
+            const int64_t cl = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj] : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base;
+            rows[((j / WSAMP) * (uint32_t)R + (uint32_t)a.FX + q) * WSAMP + (j % WSAMP)] = a.params[q + a.ld_params * cl];
         }
-    }
-    if (PARAMS) { // a small parameter table is gathered from LDS inside the loop, not from global memory
-        T *__restrict__ ptab = reinterpret_cast<T *>(gtsmem + a.ptab_offset);
-        for (int e = tid; e < a.ptab_elems; e += GBLK) ptab[e] = a.params[e];
     }
     __syncthreads();
 
@@ -436,7 +431,6 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
     const uint32_t wave_base = (uint32_t)(uintptr_t)gtsmem + (uint32_t)((tid >> 6) * R) * grow_bytes<T>();
     const uint32_t lds0 = wave_base + (uint32_t)(tid & 63) * (uint32_t)(VS * sizeof(T));
     const uint32_t stage0 = wave_base + (uint32_t)F * grow_bytes<T>(); // the wave's slot area, free between trees
-    const int param_seed0 = a.mode != DE_GRAD_CONSTANT ? -g0 : -0x40000000;
 
     const ConstI32Ptr tree_ids = (ConstI32Ptr)(uintptr_t)a.tree_ids;
     for (int ti = t0; ti < t1; ++ti) {
@@ -454,23 +448,6 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
         for (; pc < pe; ++pc) {
             const U32x4 w = nxt;
             nxt = code[pc + 1];
-            if (PARAMS && w.x == param_off) { // operand = params[row, class]: needs kernel arguments
-                const uint32_t prow = w.y & 0xFFFFu, op = w.y >> 24;
-                GDual<T, GC> b;
-                if (a.ptab_elems) {
-                    const uint32_t t0_ = (uint32_t)(uintptr_t)gtsmem + a.ptab_offset + prow * (uint32_t)sizeof(T);
-                    DE_UNROLL for (int i = 0; i < VS; i++)
-                        b.x[i] = *reinterpret_cast<__attribute__((address_space(3))) T *>((uintptr_t)(t0_ + cls[i] * (uint32_t)sizeof(T)));
-                } else {
-                    DE_UNROLL for (int i = 0; i < VS; i++) b.x[i] = a.params[prow + cls[i]];
-                }
-                gpoison<T>(st.poison, b.x);
-                const int seed = (int)prow + param_seed0;
-                DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = lv_splat<T>((k == seed) ? T(1) : T(0));
-                if (op == DOP_LOAD) { st.x = b.x; DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = b.d[k]; }
-                else st = g_gen_apply<T, GC>(st, op, b);
-                continue;
-            }
             const GHandlerFn<T, GC> fn = reinterpret_cast<GHandlerFn<T, GC>>(hbase + w.x);
             typename GImm<T>::type imm;
             if constexpr (sizeof(T) == 4) imm = w.z;
@@ -533,7 +510,8 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStrea
     a.ld_out = e.ld_out;
     a.ld_params = e.ld_params;
     a.n_tiles = (e.N + GBLK * VS - 1) / (GBLK * VS);
-    a.F = e.F;
+    a.FX = e.F;
+    a.F = e.F + (e.uses_params ? ga.P : 0); // leaf rows: X, then the parameters gathered by class
     a.P = ga.P;
     a.n_trees = bk.n;
     a.n_all_trees = e.n_trees;
@@ -573,13 +551,7 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStrea
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL || windows > 65535) return hipErrorInvalidValue;
     const size_t slot_rows = std::max<size_t>((size_t)a.n_slots * (1 + GC), (size_t)GC);
-    size_t lds = 4 * ((size_t)a.F + slot_rows) * 64 * VS * sizeof(T); // 4 waves x rows x one wave's samples
-    a.ptab_elems = 0;
-    a.ptab_offset = (uint32_t)lds;
-    if (e.uses_params && e.ld_params * e.n_classes <= GPTAB_MAX) {
-        a.ptab_elems = (int32_t)(e.ld_params * e.n_classes);
-        lds += (size_t)a.ptab_elems * sizeof(T);
-    }
+    const size_t lds = 4 * ((size_t)a.F + slot_rows) * 64 * VS * sizeof(T); // 4 waves x rows x one wave's samples
     void (*kern)(const GArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_grad_threaded_kernel<T, GC, true> : de_grad_threaded_kernel<T, GC, false>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return hipErrorInvalidValue;

@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
     const int64_t base = tm.tile * GBLK, last = a.N - 1;
     const int F = a.F, R = a.rev_rows; // rows per wave
     {
-        const uint32_t Fu = (uint32_t)F, total = (uint32_t)GBLK * Fu;
+        const uint32_t Fu = (uint32_t)a.FX, total = (uint32_t)GBLK * Fu;
         for (uint32_t e = tid; e < total; e += GBLK) {
             const uint32_t j = e / Fu, f = e - j * Fu;
             int64_t jj = base + j;
@@ -293,14 +293,17 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
             rows[((j >> 6) * (uint32_t)R + f) * 64 + (j & 63)] = a.X[f + a.ldX * jj];
         }
     }
-    const int64_t j = base + tid, jj = j < last ? j : last;
-    uint32_t poff = 0; // element offset of the sample's parameter column
-    if (PARAMS)
-        poff = (uint32_t)(a.ld_params * ((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj] : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base));
-    if (PARAMS) { // a small parameter table is gathered from LDS inside the loop, not from global memory
-        T *__restrict__ ptab = reinterpret_cast<T *>(rtsmem + a.ptab_offset);
-        for (int e = tid; e < a.ptab_elems; e += GBLK) ptab[e] = a.params[e];
+    if (PARAMS) { // rows FX .. F: params[:, class of the sample] (src/ParametricExpression.jl:381-389), read through the caches
+        const uint32_t Pu = (uint32_t)(F - a.FX), total = (uint32_t)GBLK * Pu;
+        for (uint32_t e = tid; e < total; e += GBLK) {
+            const uint32_t j = e / Pu, q = e - j * Pu;
+            int64_t jj = base + j;
+            jj = jj < last ? jj : last;
+            const int64_t cl = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj] : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base;
+            rows[((j >> 6) * (uint32_t)R + (uint32_t)a.FX + q) * 64 + (j & 63)] = a.params[q + a.ld_params * cl];
+        }
     }
+    const int64_t j = base + tid, jj = j < last ? j : last;
     const T yv = a.y[jj];
     const T wv = j <= last ? (a.w ? a.w[jj] : T(1)) : T(0);
     __syncthreads();
@@ -347,15 +350,6 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
         for (; pc < pm; ++pc) { // forward sweep
             const U32x4 w = nxt;
             nxt = code[pc + 1];
-            if (PARAMS && w.x == param_off) { // operand = params[row, class]: y = row | op << 24, z = partial row
-                const uint32_t prow = w.y & 0xFFFFu, op = w.y >> 24;
-                const T b = a.ptab_elems ? *RLDS(T, (uint32_t)(uintptr_t)rtsmem + a.ptab_offset + (prow + poff) * (uint32_t)sizeof(T))
-                                         : a.params[prow + poff];
-                rpoison<T>(st.vpoison, b);
-                if (op == DOP_LOAD) st.x = b;
-                else st = r_gen_apply<T>(st, op, b, st.lds0 + w.z);
-                continue;
-            }
             const RHandlerFn<T> fn = reinterpret_cast<RHandlerFn<T>>(hbase + w.x);
             typename RImm<T>::type imm;
             if constexpr (sizeof(T) == 4) imm = w.z;
@@ -427,7 +421,8 @@ hipError_t DE_RT_NAME(rev_thr_launch_)(const GradArgs &ga, int group, hipStream_
     a.ldX = e.ldX;
     a.ld_params = e.ld_params;
     a.n_tiles = (e.N + GBLK - 1) / GBLK;
-    a.F = e.F;
+    a.FX = e.F;
+    a.F = e.F + (e.uses_params ? ga.P : 0); // leaf rows: X, then the parameters gathered by class
     a.P = ga.P;
     a.n_trees = grp.n;
     a.n_all_trees = e.n_trees;
@@ -460,12 +455,7 @@ hipError_t DE_RT_NAME(rev_thr_launch_)(const GradArgs &ga, int group, hipStream_
     a.n_chunks = (int32_t)((grp.n + a.trees_per_chunk - 1) / a.trees_per_chunk);
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    size_t lds = 4 * (size_t)a.rev_rows * 64 * sizeof(T);
-    a.ptab_offset = (uint32_t)lds;
-    if (e.uses_params && e.ld_params * e.n_classes <= GPTAB_MAX) {
-        a.ptab_elems = (int32_t)(e.ld_params * e.n_classes);
-        lds += (size_t)a.ptab_elems * sizeof(T);
-    }
+    const size_t lds = 4 * (size_t)a.rev_rows * 64 * sizeof(T);
     void (*kern)(const GArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_rev_threaded_kernel<T, true> : de_rev_threaded_kernel<T, false>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return hipErrorInvalidValue;
