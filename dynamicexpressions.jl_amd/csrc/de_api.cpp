@@ -51,7 +51,7 @@ struct de_ctx {
     std::string err;
     const char *last_kernel = "";
     DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2, sGoff, sNg, sY, sW, sLoss, sPartial, sSeg, sDloss, sColOff, sDoff;
-    DevBuf sBcLoss, sBcDloss, sBcOk, sBcNg, sBcDoff, sBcOut; // de_eval_loss_grad_by_class
+    DevBuf sBcLoss, sBcDloss, sBcOk, sBcNg, sBcDoff, sBcOut, sBcTiles; // de_eval_loss_grad_by_class
     int nested = 0; // > 0 inside a call made of several inner calls: those do not touch the timing events
 };
 
@@ -310,7 +310,7 @@ int de_ctx_destroy(de_ctx_t *c) {
     if (!c) return DE_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff, &c->sBcLoss, &c->sBcDloss, &c->sBcOk, &c->sBcNg, &c->sBcDoff, &c->sBcOut}) b->release();
+    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff, &c->sBcLoss, &c->sBcDloss, &c->sBcOk, &c->sBcNg, &c->sBcDoff, &c->sBcOut, &c->sBcTiles}) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1814,9 +1814,26 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
     return DE_OK;
 }
 
+// By-class reduction in ONE pass (de_eval_loss_grad_by_class): class-aligned tiles, then one pair of finish passes per
+// class into loss_c / dloss_c ([C][n_trees] and [C][span], device).  Only the reverse kernel takes a tile table:
+// `done` stays false when the population runs forward duals and the caller falls back to one call per class.
+struct ByClassPlan {
+    const int64_t *class_starts;
+    int64_t C, span;
+    void *loss_c, *dloss_c;
+    bool done;
+};
+static int loss_grad_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
+                          int mode, const void *y, const void *w, int32_t loss_kind, void *loss, void *dloss,
+                          const int64_t *dloss_offsets, uint8_t *ok, ByClassPlan *plan);
 int de_eval_loss_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
                       int mode, const void *y, const void *w, int32_t loss_kind, void *loss, void *dloss,
                       const int64_t *dloss_offsets, uint8_t *ok) {
+    return loss_grad_impl(c, p, X, N, ldX, pa, mode, y, w, loss_kind, loss, dloss, dloss_offsets, ok, nullptr);
+}
+static int loss_grad_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
+                          int mode, const void *y, const void *w, int32_t loss_kind, void *loss, void *dloss,
+                          const int64_t *dloss_offsets, uint8_t *ok, ByClassPlan *plan) {
     if (!c || !p) return DE_ERR_INVALID_ARG;
     if (p->ctx != c) return fail(c, DE_ERR_INVALID_ARG, "program belongs to another context");
     if (N < 0 || !ok || (p->n_trees > 0 && (!dloss || (N > 0 && (!X || !y))))) return fail(c, DE_ERR_INVALID_ARG, "null buffer");
@@ -1890,7 +1907,20 @@ int de_eval_loss_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, in
         sOk.dev = c->sOk.p;
         sOk.staged = true;
     }
-    const int64_t n_tiles = (N + 255) / 256;
+    int64_t n_tiles = (N + 255) / 256;
+    std::vector<int64_t> tile_range, class_tile0; // by-class: (first, last) sample of every class-aligned tile; first tile of every class
+    if (plan) {
+        class_tile0.assign((size_t)plan->C + 1, 0);
+        for (int64_t k = 0; k < plan->C; k++) {
+            const int64_t j0 = plan->class_starts[k], j1 = plan->class_starts[k + 1];
+            for (int64_t b = j0; b < j1; b += 256) {
+                tile_range.push_back(b);
+                tile_range.push_back(j1 - 1);
+            }
+            class_tile0[(size_t)k + 1] = (int64_t)(tile_range.size() / 2);
+        }
+        n_tiles = (int64_t)(tile_range.size() / 2);
+    }
     HIP_TRY(c, c->sPartial.reserve((size_t)n_tiles * (size_t)n_cols * 4 * es));
     HIP_TRY(c, c->sSeg.reserve((size_t)loss_segments(n_tiles) * (size_t)n_cols * 4 * sizeof(double)));
     HIP_TRY(c, c->sNg.reserve(ng.size() * sizeof(int32_t)));
@@ -1952,6 +1982,15 @@ int de_eval_loss_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, in
     g.dloss_off = static_cast<const int64_t *>(c->sDoff.p);
     rc = ensure_rev_threaded(c, p, mode, &g);
     if (rc) return rc;
+    if (plan && !g.rev_code) return DE_OK; // forward duals: the caller runs one call per class (plan->done stays false)
+    if (plan) {
+        HIP_TRY(c, c->sBcTiles.reserve(std::max<size_t>(tile_range.size(), 2) * sizeof(int64_t)));
+        if (!tile_range.empty())
+            HIP_TRY(c, hipMemcpyAsync(c->sBcTiles.p, tile_range.data(), tile_range.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); // tile_range is pageable
+        g.rev_tile_range = static_cast<const int64_t *>(c->sBcTiles.p);
+        g.rev_n_tiles = n_tiles;
+    }
     if (!g.rev_code) {
         const size_t lds_need = ((size_t)p->n_features + (size_t)p->n_slots * (1 + (size_t)std::min(maxg, 8))) * 260 * es;
         if (lds_need > 160 * 1024) return fail(c, DE_ERR_UNSUPPORTED, "gradient kernel: LDS footprint too large for this tree shape");
@@ -1961,6 +2000,13 @@ int de_eval_loss_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, in
     if (!c->nested) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     if (g.rev_code) HIP_TRY(c, launch_rev_threaded(p->dtype, g, c->stream, &c->last_kernel));
     else HIP_TRY(c, launch_grad(p->dtype, g, c->stream, &c->last_kernel));
+    if (plan) { // one pair of finish passes per class over its own tiles
+        for (int64_t k = 0; k < plan->C; k++)
+            HIP_TRY(c, launch_loss_grad_finish_range(p->dtype, g, class_tile0[(size_t)k], class_tile0[(size_t)k + 1] - class_tile0[(size_t)k],
+                                                     static_cast<char *>(plan->loss_c) + (size_t)k * (size_t)p->n_trees * es,
+                                                     static_cast<char *>(plan->dloss_c) + (size_t)k * (size_t)plan->span * es, c->stream));
+        plan->done = true;
+    }
     if (!c->nested) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     if (sLoss.staged) HIP_TRY(c, hipMemcpyAsync(loss, sLoss.dev, (size_t)p->n_trees * es, hipMemcpyDeviceToHost, c->stream));
@@ -2019,6 +2065,19 @@ int de_eval_loss_grad_by_class(de_ctx_t *c, de_program_t *p, const void *X, int6
     // dloss entries no tree owns (caller-chosen offsets) are never read by the combine pass
     HIP_TRY(c, hipMemsetAsync(c->sBcDloss.p, 0, (size_t)C * (size_t)span * es, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    ByClassPlan plan{class_starts, C, span, c->sBcLoss.p, c->sBcDloss.p, false};
+    bool shared_ok = false; // one pass: a single flag array instead of one per class
+    {
+        const char *env1 = getenv("DE_BY_CLASS_ONE_PASS");
+        if (!(env1 && *env1 == '0') && N > 0) {
+            c->nested++;
+            const int rc1 = loss_grad_impl(c, p, X, N, ldX, pa, mode, y, w, loss_kind, c->sBcLoss.p, c->sBcDloss.p, dloss_offsets,
+                                           static_cast<uint8_t *>(c->sBcOk.p), &plan);
+            c->nested--;
+            if (rc1 != DE_OK) return rc1;
+            shared_ok = plan.done;
+        }
+    }
     struct Nest { // inner calls leave the timing events alone; restored on every exit path
         de_ctx *c;
         explicit Nest(de_ctx *c_) : c(c_) { c->nested++; }
@@ -2028,7 +2087,7 @@ int de_eval_loss_grad_by_class(de_ctx_t *c, de_program_t *p, const void *X, int6
     const size_t cls_es = pa->classes_is_i64 ? 8 : 4;
     {
     Nest nest(c);
-    for (int64_t k = 0; k < C && rc == DE_OK; k++) {
+    for (int64_t k = 0; k < C && rc == DE_OK && !plan.done; k++) {
         const int64_t j0 = class_starts[k], n = class_starts[k + 1] - j0;
         de_param_args_t sub = *pa;
         sub.classes = static_cast<const char *>(pa->classes) + (size_t)j0 * cls_es;
@@ -2058,6 +2117,7 @@ int de_eval_loss_grad_by_class(de_ctx_t *c, de_program_t *p, const void *X, int6
     a.dloss_c = c->sBcDloss.p;
     a.ok_c = static_cast<const uint8_t *>(c->sBcOk.p);
     a.n_classes = (int32_t)C;
+    a.ok_stride = shared_ok ? 0 : p->n_trees;
     a.n_params = P;
     a.n_trees = p->n_trees;
     a.span = span;

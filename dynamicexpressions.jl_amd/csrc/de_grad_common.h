@@ -46,6 +46,7 @@ template <typename T> struct GArgs {
     // threaded kernels: a parameter table of <= GPTAB_MAX elements is copied to LDS behind the rows
     int32_t ptab_elems;      // ld_params * n_classes, or 0: read the table from global memory
     uint32_t ptab_offset;    // LDS byte offset of the copy
+    const int64_t *tile_range; // de_rev_threaded.hip, by-class reduction: (first sample, last sample) of every tile, or null
     const int32_t *rev_mid;  // de_rev_threaded.hip: first backward instruction of every tree
     int32_t rev_rows;        // ... and LDS rows per wave (X + slots + partial rows + staging)
     int32_t rev_stage_cols, rev_stage_rows; // per-wave staging of the column sums (elements / rows)

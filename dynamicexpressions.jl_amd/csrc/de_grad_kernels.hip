@@ -365,6 +365,15 @@ template <typename T> static hipError_t loss_grad_finish_t(const GradArgs &ga, i
                        ga.e.ok, static_cast<T *>(ga.loss->loss), static_cast<T *>(ga.dloss), ga.dloss_off);
     return hipGetLastError();
 }
+hipError_t launch_loss_grad_finish_range(int dtype, const GradArgs &ga, int64_t tile0, int64_t n_tiles, void *loss, void *dloss, hipStream_t stream) {
+    LossArgs la = *ga.loss;
+    GradArgs g = ga;
+    la.partial = static_cast<char *>(la.partial) + (size_t)tile0 * (size_t)ga.n_cols * 4 * (dtype == DE_F32 ? 4 : 8);
+    la.loss = loss;
+    g.loss = &la;
+    g.dloss = dloss;
+    return dtype == DE_F32 ? loss_grad_finish_t<float>(g, n_tiles, stream) : loss_grad_finish_t<double>(g, n_tiles, stream);
+}
 hipError_t launch_loss_grad_finish(int dtype, const GradArgs &ga, int64_t n_tiles, hipStream_t stream) {
     return dtype == DE_F32 ? loss_grad_finish_t<float>(ga, n_tiles, stream) : loss_grad_finish_t<double>(ga, n_tiles, stream);
 }
@@ -397,7 +406,7 @@ __global__ void __launch_bounds__(256) de_by_class_combine_kernel(const ByClassA
     const int C = a.n_classes, P = a.n_params, G = a.n_grad[t];
     const int64_t off = a.dloss_off[t];
     bool ok = true;
-    for (int c = 0; c < C; c++) ok = ok && a.ok_c[(int64_t)c * a.n_trees + t] != 0;
+    for (int c = 0; c < C; c++) ok = ok && a.ok_c[(int64_t)c * a.ok_stride + t] != 0;
     a.ok[t] = ok ? 1 : 0;
     const T nan = T(__builtin_nan(""));
     if (a.loss) {
@@ -507,6 +516,7 @@ hipError_t launch_rev_threaded(int dtype, const GradArgs &a, hipStream_t stream,
         const hipError_t st = dtype == DE_F32 ? rev_thr_launch_f(a, k, stream) : rev_thr_launch_d(a, k, stream);
         if (st != hipSuccess) return st;
     }
+    if (a.rev_tile_range) return hipSuccess; // by-class: the caller reduces every class's tile range itself
     return launch_loss_grad_finish(dtype, a, n_tiles, stream);
 }
 

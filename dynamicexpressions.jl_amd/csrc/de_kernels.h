@@ -79,6 +79,8 @@ struct GradArgs {
     const int32_t *rev_code_off, *rev_code_mid; // n_trees + 1 / n_trees
     const int32_t *rev_ids;                     // device: the trees grouped by LDS need (rev_groups)
     int32_t rev_n_groups;
+    const int64_t *rev_tile_range; // by-class reduction: device (first, last) sample of each class-aligned tile; null = regular tiles
+    int64_t rev_n_tiles;           // ... and their number (the caller runs the finish passes per class)
     struct RevGroup { int32_t first, n, rows; } rev_groups[8]; // ids[first .. first+n), LDS rows per wave (staging included)
     int32_t rev_stage_cols;                     // column sums a wave stages in LDS between two writes
     uint64_t rev_handler_base;
@@ -109,11 +111,14 @@ hipError_t rev_handler_table(int dtype, uint64_t *table); // ROP_COUNT entries
 hipError_t launch_rev_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name);                            // is there a module for (type, window, samples per lane)?
 hipError_t launch_grad_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name);
 hipError_t launch_loss_grad_finish(int dtype, const GradArgs &ga, int64_t n_tiles, hipStream_t stream);
+// the same over tiles [tile0, tile0 + n_tiles) only, results to loss / dloss (by-class reduction: one call per class)
+hipError_t launch_loss_grad_finish_range(int dtype, const GradArgs &ga, int64_t tile0, int64_t n_tiles, void *loss, void *dloss, hipStream_t stream);
 // de_eval_loss_grad_by_class: per-class results ([C][n_trees] losses and flags, [C][span] gradients) -> outputs
 struct ByClassArgs {
     const void *loss_c, *dloss_c;
     const uint8_t *ok_c;
     int32_t n_classes, n_params;
+    int64_t ok_stride;       // n_trees: one flag array per class; 0: one shared array (single-pass reduction)
     int64_t n_trees, span;
     const int32_t *n_grad;   // device
     const int64_t *dloss_off; // device

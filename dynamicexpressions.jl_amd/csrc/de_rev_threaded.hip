@@ -282,7 +282,11 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
     // few per-lane values may live across the handler calls: they sit in callee-saved VGPRs, which the ABI hands out
     // in blocks of 8 at v40, v56, v72, v88 — a fourth block costs a fifth of the occupancy
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t base = tm.tile * GBLK, last = a.N - 1;
+    // regular tiling, or class-aligned tiles of a by-class reduction: a tile never straddles two classes, samples past
+    // the end of its class are clamped copies with weight 0 like the samples past N
+    const ConstI64Ptr tile_range = (ConstI64Ptr)(uintptr_t)a.tile_range;
+    const int64_t base = a.tile_range ? tile_range[2 * tm.tile] : tm.tile * GBLK;
+    const int64_t last = a.tile_range ? tile_range[2 * tm.tile + 1] : a.N - 1;
     const int F = a.F, R = a.rev_rows; // rows per wave
     {
         const uint32_t Fu = (uint32_t)a.FX, total = (uint32_t)GBLK * Fu;
@@ -420,7 +424,8 @@ hipError_t DE_RT_NAME(rev_thr_launch_)(const GradArgs &ga, int group, hipStream_
     a.N = e.N;
     a.ldX = e.ldX;
     a.ld_params = e.ld_params;
-    a.n_tiles = (e.N + GBLK - 1) / GBLK;
+    a.n_tiles = ga.rev_tile_range ? ga.rev_n_tiles : (e.N + GBLK - 1) / GBLK;
+    a.tile_range = ga.rev_tile_range;
     a.FX = e.F;
     a.F = e.F + (e.uses_params ? ga.P : 0); // leaf rows: X, then the parameters gathered by class
     a.P = ga.P;

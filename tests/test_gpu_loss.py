@@ -368,7 +368,7 @@ def test_parameter_gradient_by_class_reference_known_answer(api):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("kind", ["L2", "pullback"])
-def test_parameter_gradient_by_class_matches_scatter_of_jacobian(api, dtype, kind):
+def test_parameter_gradient_by_class_matches_scatter_of_jacobian(api, dtype, kind, monkeypatch):
     """dparams[t][p, c] == sum over the samples of class c of l'(e_j) * Jacobian row p — the scatter-add the
     reference's AD performs through `parameters[i, classes[j]]` (src/ParametricExpression.jl:381-384); classes
     arrive unordered (the wrapper groups them), some classes are empty, weights exclude samples."""
@@ -416,6 +416,11 @@ def test_parameter_gradient_by_class_matches_scatter_of_jacobian(api, dtype, kin
     b = pop.eval_loss_grad_by_class(np.asfortranarray(X[:, order]), y[order], params, classes[order], weights=w[order],
                                     loss=kind, grouped=True)
     assert np.array_equal(a[2], b[2], equal_nan=True) and np.array_equal(a[0], b[0], equal_nan=True)
+    # one pass over class-aligned tiles (reverse kernel) == one call per class: same tiles, same reduction order
+    monkeypatch.setenv("DE_BY_CLASS_ONE_PASS", "0")
+    c2 = pop.eval_loss_grad_by_class(X, y, params, classes, weights=w, loss=kind)
+    assert np.array_equal(a[2], c2[2], equal_nan=True) and np.array_equal(a[0], c2[0], equal_nan=True)
+    assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(a[1], c2[1])) and np.array_equal(a[3], c2[3])
     pop.close()
 
 
