@@ -424,6 +424,39 @@ def test_parameter_gradient_by_class_matches_scatter_of_jacobian(api, dtype, kin
     pop.close()
 
 
+def test_parameter_gradient_by_class_edge_cases(api):
+    """One class (the by-class matrix is the shared row), no samples (zeros), int64 class ids, L1 loss, Float64."""
+    ops = de.OperatorEnum(binary_operators=("+", "*", "-"), unary_operators=("cos",))
+    rng = de.synth.Xoshiro256ss(8)
+    P = 2
+    trees = [de.synth.gen_random_tree_fixed_size(5 + i % 9, ops, 3, rng, np.float64, de.ParametricNode, P) for i in range(24)]
+    g = np.random.Generator(np.random.PCG64(3))
+    N = 700
+    X = np.asfortranarray(g.standard_normal((3, N)))
+    y = g.standard_normal(N)
+    pop = api.Population(trees, ops, np.float64, n_features=3, n_params=P)
+    # a single class: dparams[:, 0] is the parameter rows of the plain fused gradient
+    params1 = np.asfortranarray(g.standard_normal((P, 1)))
+    ones = np.ones(N, dtype=np.int64)
+    loss, dls, dp, ok = pop.eval_loss_grad_by_class(X, y, params1, ones, loss="L1", variable=True)
+    loss1, dls1, ok1 = pop.eval_loss_grad(X, y, loss="L1", variable=True, params=params1, classes=ones)
+    assert np.array_equal(ok, ok1) and ok.sum() > 10 and dp.shape == (24, P, 1)
+    for t in np.nonzero(ok)[0]:
+        np.testing.assert_allclose(dp[t][:, 0], dls1[t][:P], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(dls[t], dls1[t], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(loss[t], loss1[t], rtol=1e-13)
+    # int64 ids with a base of 0, three classes of which the middle one is empty
+    params3 = np.asfortranarray(g.standard_normal((P, 3)))
+    cls = np.where(g.random(N) < 0.5, 0, 2).astype(np.int64)
+    a = pop.eval_loss_grad_by_class(X, y, params3, cls, class_base=0)
+    b = pop.eval_loss_grad_by_class(X, y, params3, cls.astype(np.int32), class_base=0)
+    assert np.array_equal(a[2], b[2], equal_nan=True) and np.all(a[2][a[3]][:, :, 1] == 0)
+    # no samples at all
+    l0, d0, p0, k0 = pop.eval_loss_grad_by_class(np.zeros((3, 0)), np.zeros(0), params3, np.zeros(0, dtype=np.int64), class_base=0)
+    assert k0.all() and np.all(l0 == 0) and np.all(p0 == 0) and all(np.all(d == 0) for d in d0)
+    pop.close()
+
+
 def test_parameter_gradient_by_class_device_tensors_and_errors(api):
     import torch
     trees = de.synth.random_population(50, seed=0xDE05, node_type=de.ParametricNode, nparams=8)
