@@ -1164,6 +1164,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
     // Parameter leaves are LDS rows of their own: the kernel gathers params[:, class] into P rows behind the X rows when it
     // stages a tile (the reference's formulation, src/ParametricExpression.jl:381-389), so every hot handler serves them.
     const int FE = F + (p->uses_params ? P : 0);
+    const bool hot_const_unary = !getenv("DE_NO_CONST_UNARY_HOT"); // cos/exp/sin of a constant leaf through the hot handlers
     // Two samples per lane double the buckets (launches) and the tile: they pay from ~10^5 samples on (10^4 trees x
     // 10^3 rows: 0.55 ms with them, 0.35 ms without; 10^3 trees x 10^6 rows: 12.1 against 13.4 ms)
     const char *envn = getenv("DE_GRAD_VS2_MIN_N");
@@ -1300,6 +1301,21 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                     else o.arg = 0;
                     gop = gop_un(GC, (int)(v >> 2), src, sv, (v & 1) != 0);
                 } else if (b.bop == BOP_GEN_ROW) { row_operand(true); gop = gop_gen(GC, src); o.lo = aux; o.hi = 0; }
+                else if (b.bop == BOP_GEN_CONST && hot_const_unary && (aux == (uint32_t)DE_U_COS || aux == (uint32_t)DE_U_EXP || aux == (uint32_t)DE_U_SIN)) {
+                    // cos / exp / sin of a constant leaf (common: half the leaves are constants and the gradient program
+                    // is not folded): load the constant, then the hot unary handler on the accumulator — not the generic
+                    // handler (out-of-line operator switch, OCML functions, scratch traffic of its spills)
+                    const_operand(b.arg & 0xFFFFu, 0);
+                    o.bop = (uint32_t)(table[gop_load(GC, src, sv)] - base);
+                    p->gtsite_of_gb[(size_t)i] = (int32_t)p->gtcode.size();
+                    p->gtcode.push_back(o);
+                    BoundInstr u = b;
+                    u.arg = 0;
+                    u.lo = u.hi = 0;
+                    u.bop = (uint32_t)(table[gop_un(GC, aux == (uint32_t)DE_U_COS ? 0 : (aux == (uint32_t)DE_U_EXP ? 1 : 2), GSRC_ACC, 0, false)] - base);
+                    p->gtcode.push_back(u);
+                    continue;
+                }
                 else if (b.bop == BOP_GEN_CONST) { const_operand(b.arg & 0xFFFFu, aux << 16, true); gop = gop_gen(GC, GSRC_CONST); }
                 else if (b.bop == BOP_GEN_ACC) { gop = gop_gen(GC, GSRC_ACC); o.arg = 0; o.lo = aux; o.hi = 0; }
                 else if (b.bop == BOP_GEN_PARAM) { // operand = parameter row (b.arg & 0xFFFF), operator aux: the leaf-operand handlers
@@ -1344,8 +1360,9 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             for (int64_t t = 0; t < p->n_trees; t++) ids[(size_t)fill[bucket_of(t)]++] = (int32_t)t;
         }
         if (!p->d_gtcode) {
-            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode), (p->gbcode.size() + 1) * sizeof(BoundInstr)));
-            HIP_TRY(c, hipMemset(p->d_gtcode, 0, (p->gbcode.size() + 1) * sizeof(BoundInstr)));
+            // a unary operator on a constant leaf becomes two instructions: at most twice the bound program
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode), (2 * p->gbcode.size() + 1) * sizeof(BoundInstr)));
+            HIP_TRY(c, hipMemset(p->d_gtcode, 0, (2 * p->gbcode.size() + 1) * sizeof(BoundInstr)));
             HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode_off), p->gtcode_off.size() * sizeof(int32_t)));
             HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gt_ids), std::max<size_t>(ids.size(), 1) * sizeof(int32_t)));
         }
@@ -1400,6 +1417,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
         const uint32_t es32 = p->dtype == DE_F32 ? 4u : 8u, RB = 64u * es32;
         // parameter leaves are LDS rows F .. F+P (gathered by class when the kernel stages a tile), slots follow
         const uint32_t FE = (uint32_t)F + (p->uses_params ? (uint32_t)P : 0u);
+        const bool hot_const_unary = !getenv("DE_NO_CONST_UNARY_HOT");
         const uint32_t PR0 = FE + (uint32_t)p->n_slots; // first partial row
         uint64_t table[ROP_COUNT];
         hipError_t hst = rev_handler_table(p->dtype, table);
@@ -1506,6 +1524,13 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     F_(mk(rop_gen(is_leaf ? RSRC_LEAF : RSRC_SLOT), rowb(row), pr | (aux << 24), 0));
                     if (unary) back_unary_leaf(pr, leaf_col(row));
                     else back_binary(0, pr, !is_leaf, rowb(row), is_leaf ? leaf_col(row) : NONE);
+                } else if (b.bop == BOP_GEN_CONST && hot_const_unary && (aux == (uint32_t)DE_U_COS || aux == (uint32_t)DE_U_EXP || aux == (uint32_t)DE_U_SIN)) {
+                    // cos / exp / sin of a constant leaf: load + hot unary handler instead of the generic one
+                    const uint32_t pr = alloc(1);
+                    p->rtsite_of_gb[(size_t)i] = (int32_t)p->rtcode.size();
+                    F_(mk(rop_load(RSRC_CONST), 0, b.lo, b.hi));
+                    F_(mk(rop_un(aux == (uint32_t)DE_U_COS ? 0 : (aux == (uint32_t)DE_U_EXP ? 1 : 2), RSRC_ACC, false), pr, 0, 0));
+                    back_unary_leaf(pr, const_col(ord));
                 } else if (b.bop == BOP_GEN_CONST) {
                     const bool unary = aux < (uint32_t)DE_B_ADD;
                     const uint32_t pr = alloc(unary ? 1 : 2);

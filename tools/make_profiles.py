@@ -56,6 +56,20 @@ summ = {"headline": {
     "grad_C3_avg_kernel_us_rocprof": sum(gr) / len(gr),
     "source": f"tools/profile_round.sh {tag}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
               "`python bench.py --steps 2 --warmup 1` (headline workload); kernel time from `rocprofv3 --kernel-trace --stats`"}}
+def pmc_per_step(path, name, needle, steps):
+    """Counter summed over ALL full-size launches of the kernels containing `needle`, per step (the gradient runs one
+    launch per bucket)."""
+    rows = [r for r in csv.DictReader(open(path)) if needle in r["Kernel_Name"] and r["Counter_Name"] == name and int(r["Grid_Size"]) > 256 * 64]
+    return sum(float(r["Counter_Value"]) for r in rows) / steps, len(rows)
+fc3, wc3 = f"{src}/pmc_fetch_C3/grad_counter_collection.csv", f"{src}/pmc_write_C3/grad_counter_collection.csv"
+if os.path.exists(fc3) and os.path.exists(wc3):
+    steps = 3  # bench.py --steps 2 --warmup 1
+    f3, nf = pmc_per_step(fc3, "FETCH_SIZE", "de_grad_", steps)
+    w3, nw = pmc_per_step(wc3, "WRITE_SIZE", "de_grad_", steps)
+    summ["C3"] = {"kernel": "de_grad_threaded_kernel (all bucket launches of a step)", "FETCH_SIZE_KiB_per_step": f3,
+                  "WRITE_SIZE_KiB_per_step": w3, "hbm_bytes_per_launch": (2 * f3 + w3) * 1024, "launches_counted": min(nf, nw),
+                  "fetch_correction": "x2, as for the headline",
+                  "source": f"tools/profile_round.sh {tag}: separate --pmc FETCH_SIZE / WRITE_SIZE passes over `python bench.py --workload C3 --steps 2 --warmup 1`"}
 json.dump(summ, open("profiles/pmc_summary.json", "w"), indent=1)
 print(json.dumps(summ, indent=1))
 print("eval kernel avg us:", sum(ev) / len(ev), " grad:", sum(gr) / len(gr))

@@ -10,4 +10,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o eval -- pyth
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o eval -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o eval -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_C3 -o grad -- python $R/bench.py --workload C3 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_C3_under_rocprof.json 2>>$O/stats.log
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_C3 -o grad -- python $R/bench.py --workload C3 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_C3 -o grad -- python $R/bench.py --workload C3 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 find $O -name "*.csv" | head -20
