@@ -855,6 +855,9 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
                 case DE_B_MUL: st.acc = bin_apply<T, 3>(st.acc, bv.v[0]); break;
                 case DE_B_DIV: st.acc = bin_apply<T, 4>(st.acc, bv.v[0]); break;
                 case DOP_RDIV: st.acc = bin_apply<T, 5>(st.acc, bv.v[0]); break;
+                case DE_U_COS: st.acc = un_apply<T, 0>(bv.v[0]); break; // unary operator on a parameter leaf
+                case DE_U_EXP: st.acc = un_apply<T, 1>(bv.v[0]); break;
+                case DE_U_SIN: st.acc = un_apply<T, 2>(bv.v[0]); break;
                 default: av.v[0] = st.acc; av = cold_op<T, 1>(op, av, bv); st.acc = av.v[0]; break;
                 }
                 continue;
