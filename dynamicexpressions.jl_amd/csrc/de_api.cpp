@@ -1172,13 +1172,13 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
     if (!(p->gt_valid && p->gt_mode == mode && p->gt_wide == wide)) {
         // bucket of a tree: (width index 0..6 = single window of width 1,2,3,4,5,6,8; 7 = several windows of 8)
         // x (samples per lane - 1).  The two-sample modules exist for Float32 windows <= 6; their rows are
-        // twice as long, so they only pay while a workgroup's LDS stays small: trees with <= 1 spill slot.
+        // twice as long, so they only pay while a workgroup's LDS stays small: at most DE_GRAD_VS2_ROWS (15) rows per wave.
         // width index 0..6 = single window of width 1,2,3,4,5,6,8; 7,8,9 = several windows of 8,5,6 (the
         // narrowest module that covers the gradient in ceil(G/8) windows: 9-10 rows -> 2x5, 11-12 -> 2x6, 17-18 -> 3x6)
         static const int WIDTH[10] = {1, 2, 3, 4, 5, 6, 8, 8, 5, 6};
         constexpr int NW = 10, NB = 2 * NW;
-        const char *env2 = getenv("DE_GRAD_VS2_SLOTS"); // widest spill need that still runs two samples per lane
-        const int vs2_slots = env2 ? atoi(env2) : 1;
+        const char *env2 = getenv("DE_GRAD_VS2_ROWS"); // most LDS rows per wave (X + parameters + slots) that still run two samples per lane
+        const int vs2_rows = env2 ? atoi(env2) : 15;    // 15 rows x 512 B x 4 waves = 30.7 KB: 5 workgroups per CU
         std::vector<int32_t> tslots((size_t)p->n_trees, 0); // spill slots of each tree (rows >= F the code names)
         for (int64_t t = 0; t < p->n_trees; t++) {
             int32_t need = 0;
@@ -1203,7 +1203,8 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                 w = per <= 5 ? 8 : (per <= 6 ? 9 : 7);
                 if (!grad_threaded_has(p->dtype, WIDTH[w], 1)) w = 7;
             }
-            const bool two = wide && p->dtype == DE_F32 && WIDTH[w] <= 6 && tslots[(size_t)t] <= vs2_slots && grad_threaded_has(p->dtype, WIDTH[w], 2);
+            const int rows2 = FE + std::max(tslots[(size_t)t] * (1 + WIDTH[w]), WIDTH[w]);
+            const bool two = wide && p->dtype == DE_F32 && WIDTH[w] <= 6 && rows2 <= vs2_rows && grad_threaded_has(p->dtype, WIDTH[w], 2);
             return w + (two ? NW : 0);
         };
         int32_t count[NB] = {0}, maxg[NB] = {0}, slots[NB] = {0};
