@@ -1405,7 +1405,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
     g->rev_code = nullptr;
     // Reverse accumulation costs two sweeps whatever the number of gradient rows; forward duals cost one sweep
     // of (1 + rows) values (and one sweep per window of 8 rows).  Measured break-even on MI355X: ~8 rows per tree
-    // (20-node trees: 3.5 rows 12.3 ms forward / 19.8 ms reverse; 17 rows 80 ms / 46 ms).  DE_LOSS_GRAD_REVERSE=1|0 forces.
+    // (20-node trees: 3.5 rows 9.6 ms forward / 17.2 ms reverse; 17 rows 44.6 ms / 30.2 ms).  DE_LOSS_GRAD_REVERSE=1|0 forces.
     const char *env = getenv("DE_LOSS_GRAD_REVERSE");
     if (env && *env == '0') return DE_OK;
     if (!(env && *env == '1')) {
