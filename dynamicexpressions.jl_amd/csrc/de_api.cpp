@@ -1164,7 +1164,11 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
     // Parameter leaves are LDS rows of their own: the kernel gathers params[:, class] into P rows behind the X rows when it
     // stages a tile (the reference's formulation, src/ParametricExpression.jl:381-389), so every hot handler serves them.
     const int FE = F + (p->uses_params ? P : 0);
-    const bool hot_const_unary = !getenv("DE_NO_CONST_UNARY_HOT"); // cos/exp/sin of a constant leaf through the hot handlers
+    const bool hot_const_unary = !getenv("DE_NO_CONST_UNARY_HOT"); // unary operators outside the binder's hot set through hot handlers
+    auto gun_of = [&](uint32_t op) { // hot unary index of a de_opcode (de_bind.h), or -1
+        return hot_const_unary ? gun_index((int)op, DE_U_COS, DE_U_EXP, DE_U_SIN, DE_U_NEG, DE_U_SQUARE, DE_U_CUBE, DE_U_ABS, DE_U_LOG, DE_U_SAFE_LOG,
+                                           DE_U_SQRT, DE_U_SAFE_SQRT, DE_U_TANH, DE_U_RELU) : -1;
+    };
     // Two samples per lane double the buckets (launches) and the tile: they pay from ~10^5 samples on (10^4 trees x
     // 10^3 rows: 0.55 ms with them, 0.35 ms without; 10^3 trees x 10^6 rows: 12.1 against 13.4 ms)
     const char *envn = getenv("DE_GRAD_VS2_MIN_N");
@@ -1301,8 +1305,9 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                     if (v & 2) row_operand();
                     else o.arg = 0;
                     gop = gop_un(GC, (int)(v >> 2), src, sv, (v & 1) != 0);
-                } else if (b.bop == BOP_GEN_ROW) { row_operand(true); gop = gop_gen(GC, src); o.lo = aux; o.hi = 0; }
-                else if (b.bop == BOP_GEN_CONST && hot_const_unary && (aux == (uint32_t)DE_U_COS || aux == (uint32_t)DE_U_EXP || aux == (uint32_t)DE_U_SIN)) {
+                } else if (b.bop == BOP_GEN_ROW && gun_of(aux) >= 0) { row_operand(); gop = gop_un(GC, gun_of(aux), src, sv, false); o.lo = o.hi = 0; }
+                else if (b.bop == BOP_GEN_ROW) { row_operand(true); gop = gop_gen(GC, src); o.lo = aux; o.hi = 0; }
+                else if (b.bop == BOP_GEN_CONST && gun_of(aux) >= 0) {
                     // cos / exp / sin of a constant leaf (common: half the leaves are constants and the gradient program
                     // is not folded): load the constant, then the hot unary handler on the accumulator — not the generic
                     // handler (out-of-line operator switch, OCML functions, scratch traffic of its spills)
@@ -1313,11 +1318,12 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                     BoundInstr u = b;
                     u.arg = 0;
                     u.lo = u.hi = 0;
-                    u.bop = (uint32_t)(table[gop_un(GC, aux == (uint32_t)DE_U_COS ? 0 : (aux == (uint32_t)DE_U_EXP ? 1 : 2), GSRC_ACC, 0, false)] - base);
+                    u.bop = (uint32_t)(table[gop_un(GC, gun_of(aux), GSRC_ACC, 0, false)] - base);
                     p->gtcode.push_back(u);
                     continue;
                 }
                 else if (b.bop == BOP_GEN_CONST) { const_operand(b.arg & 0xFFFFu, aux << 16, true); gop = gop_gen(GC, GSRC_CONST); }
+                else if (b.bop == BOP_GEN_ACC && gun_of(aux) >= 0) { gop = gop_un(GC, gun_of(aux), GSRC_ACC, 0, false); o.arg = 0; o.lo = o.hi = 0; }
                 else if (b.bop == BOP_GEN_ACC) { gop = gop_gen(GC, GSRC_ACC); o.arg = 0; o.lo = aux; o.hi = 0; }
                 else if (b.bop == BOP_GEN_PARAM) { // operand = parameter row (b.arg & 0xFFFF), operator aux: the leaf-operand handlers
                     const uint32_t prm = b.arg & 0xFFFFu;
@@ -1329,10 +1335,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                     case DE_B_MUL: k = 3; break;
                     case DE_B_DIV: k = 4; break;
                     case DOP_RDIV: k = 5; break;
-                    case DE_U_COS: ku = 0; break;
-                    case DE_U_EXP: ku = 1; break;
-                    case DE_U_SIN: ku = 2; break;
-                    default: break;
+                    default: ku = gun_of(aux); break;
                     }
                     o.lo = o.hi = 0;
                     if (aux == (uint32_t)DOP_LOAD) { param_operand(prm); gop = gop_load(GC, src, sv); }
@@ -1419,6 +1422,10 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
         // parameter leaves are LDS rows F .. F+P (gathered by class when the kernel stages a tile), slots follow
         const uint32_t FE = (uint32_t)F + (p->uses_params ? (uint32_t)P : 0u);
         const bool hot_const_unary = !getenv("DE_NO_CONST_UNARY_HOT");
+        auto gun_of = [&](uint32_t op) { // hot unary index of a de_opcode (de_bind.h), or -1
+            return hot_const_unary ? gun_index((int)op, DE_U_COS, DE_U_EXP, DE_U_SIN, DE_U_NEG, DE_U_SQUARE, DE_U_CUBE, DE_U_ABS, DE_U_LOG, DE_U_SAFE_LOG,
+                                               DE_U_SQRT, DE_U_SAFE_SQRT, DE_U_TANH, DE_U_RELU) : -1;
+        };
         const uint32_t PR0 = FE + (uint32_t)p->n_slots; // first partial row
         uint64_t table[ROP_COUNT];
         hipError_t hst = rev_handler_table(p->dtype, table);
@@ -1518,6 +1525,10 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                         F_(mk(rop_un(k, RSRC_ACC, chk), pr, 0, 0));
                         R_(mk(ROP_R_UN, pr, 0, 0));
                     }
+                } else if (b.bop == BOP_GEN_ROW && gun_of(aux) >= 0 && is_leaf) {
+                    const uint32_t pr = alloc(1);
+                    F_(mk(rop_un(gun_of(aux), RSRC_LEAF, false), rowb(row), pr, 0));
+                    back_unary_leaf(pr, leaf_col(row));
                 } else if (b.bop == BOP_GEN_ROW) {
                     const bool unary = aux < (uint32_t)DE_B_ADD;
                     const uint32_t pr = alloc(unary ? 1 : 2);
@@ -1525,12 +1536,12 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     F_(mk(rop_gen(is_leaf ? RSRC_LEAF : RSRC_SLOT), rowb(row), pr | (aux << 24), 0));
                     if (unary) back_unary_leaf(pr, leaf_col(row));
                     else back_binary(0, pr, !is_leaf, rowb(row), is_leaf ? leaf_col(row) : NONE);
-                } else if (b.bop == BOP_GEN_CONST && hot_const_unary && (aux == (uint32_t)DE_U_COS || aux == (uint32_t)DE_U_EXP || aux == (uint32_t)DE_U_SIN)) {
+                } else if (b.bop == BOP_GEN_CONST && gun_of(aux) >= 0) {
                     // cos / exp / sin of a constant leaf: load + hot unary handler instead of the generic one
                     const uint32_t pr = alloc(1);
                     p->rtsite_of_gb[(size_t)i] = (int32_t)p->rtcode.size();
                     F_(mk(rop_load(RSRC_CONST), 0, b.lo, b.hi));
-                    F_(mk(rop_un(aux == (uint32_t)DE_U_COS ? 0 : (aux == (uint32_t)DE_U_EXP ? 1 : 2), RSRC_ACC, false), pr, 0, 0));
+                    F_(mk(rop_un(gun_of(aux), RSRC_ACC, false), pr, 0, 0));
                     back_unary_leaf(pr, const_col(ord));
                 } else if (b.bop == BOP_GEN_CONST) {
                     const bool unary = aux < (uint32_t)DE_B_ADD;
@@ -1539,6 +1550,10 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     F_(mk(rop_gen(RSRC_CONST), pr | (aux << 24), b.lo, b.hi));
                     if (unary) back_unary_leaf(pr, const_col(ord));
                     else back_binary(0, pr, false, 0, const_col(ord));
+                } else if (b.bop == BOP_GEN_ACC && gun_of(aux) >= 0) {
+                    const uint32_t pr = alloc(1);
+                    F_(mk(rop_un(gun_of(aux), RSRC_ACC, false), pr, 0, 0));
+                    R_(mk(ROP_R_UN, pr, 0, 0));
                 } else if (b.bop == BOP_GEN_ACC) {
                     const uint32_t pr = alloc(1);
                     F_(mk(rop_gen(RSRC_ACC), pr | (aux << 24), 0, 0));
@@ -1553,10 +1568,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     case DE_B_MUL: k = 3; break;
                     case DE_B_DIV: k = 4; break;
                     case DOP_RDIV: k = 5; break;
-                    case DE_U_COS: ku = 0; break;
-                    case DE_U_EXP: ku = 1; break;
-                    case DE_U_SIN: ku = 2; break;
-                    default: break;
+                    default: ku = gun_of(aux); break;
                     }
                     if (aux == (uint32_t)DOP_LOAD) {
                         F_(mk(rop_load(RSRC_LEAF), prow, 0, 0));

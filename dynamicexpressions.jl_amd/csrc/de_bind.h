@@ -49,8 +49,8 @@ enum RevOp : uint32_t {
     ROP_PUSH = 3,
     ROP_CHECK = 4,
     ROP_BIN_BASE = 5,                  // + ((K*3 + src)*2 + checked)
-    ROP_UN_BASE = ROP_BIN_BASE + 36,   // + ((K*2 + (src == LEAF))*2 + checked)
-    ROP_GEN_BASE = ROP_UN_BASE + 12,   // + src (LEAF, SLOT, CONST, ACC)
+    ROP_UN_BASE = ROP_BIN_BASE + 36,   // + ((K*2 + (src == LEAF))*2 + checked),  K < GUN_K (13)
+    ROP_GEN_BASE = ROP_UN_BASE + 52,   // + src (LEAF, SLOT, CONST, ACC)
     ROP_TERN = ROP_GEN_BASE + 4,
     ROP_PARAM,
     ROP_R_UN,                          // backward: adjoint *= partial
@@ -115,7 +115,16 @@ constexpr uint32_t top_bin2(int k, bool cst, bool out, bool push) { return TOP_B
 // ("seed variant" sv = 0: read the row at run time (several windows), 1: no gradient, 2 + k: row k):
 // the dense  g1*d1[k] + g2*d2[k]  then needs no one-hot materialisation.  Window width GC gives
 // NS = GC + 2 seed variants; ids depend on GC (one module per GC anyway).
-constexpr int GOP_MAX = 400; // >= gop_count(8)
+constexpr int GOP_MAX = 640; // >= gop_count(8)
+// hot unary operators of the gradient kernels: cos exp sin | neg square cube abs log safe_log sqrt safe_sqrt tanh relu
+constexpr int GUN_K = 13;
+static_assert(ROP_GEN_BASE - ROP_UN_BASE == 4 * GUN_K, "RevOp layout and GUN_K disagree");
+// de_opcode -> hot unary index, or -1 (de_opcodes.h values are passed in: this header stays free of that include)
+constexpr int gun_index(int op, int u_cos, int u_exp, int u_sin, int u_neg, int u_square, int u_cube, int u_abs, int u_log,
+                        int u_safe_log, int u_sqrt, int u_safe_sqrt, int u_tanh, int u_relu) {
+    return op == u_cos ? 0 : op == u_exp ? 1 : op == u_sin ? 2 : op == u_neg ? 3 : op == u_square ? 4 : op == u_cube ? 5 : op == u_abs ? 6 :
+           op == u_log ? 7 : op == u_safe_log ? 8 : op == u_sqrt ? 9 : op == u_safe_sqrt ? 10 : op == u_tanh ? 11 : op == u_relu ? 12 : -1;
+}
 enum { GSRC_LEAF = 0, GSRC_SLOT = 1, GSRC_CONST = 2, GSRC_ACC = 3 };
 constexpr uint32_t gop_ns(int GC) { return (uint32_t)GC + 2; }
 constexpr uint32_t gop_load(int GC, int src, int sv) { // LEAF: [0,NS)  SLOT: NS  CONST: NS+1+sv
@@ -128,11 +137,11 @@ constexpr uint32_t gop_bin(int GC, int k, int src, int sv, bool chk) { // 6 K x 
     return gop_bin_base(GC) + (uint32_t)(k * 2 + chk) * (2 * gop_ns(GC) + 1) + gop_load(GC, src, sv);
 }
 constexpr uint32_t gop_un_base(int GC) { return gop_bin_base(GC) + 12 * (2 * gop_ns(GC) + 1); }
-constexpr uint32_t gop_un(int GC, int k, int src, int sv, bool chk) { // 3 K x 2 chk x (LEAF NS + SLOT + ACC)
+constexpr uint32_t gop_un(int GC, int k, int src, int sv, bool chk) { // GUN_K x 2 chk x (LEAF NS + SLOT + ACC)
     return gop_un_base(GC) + (uint32_t)(k * 2 + chk) * (gop_ns(GC) + 2) +
            (src == GSRC_LEAF ? (uint32_t)sv : (src == GSRC_SLOT ? gop_ns(GC) : gop_ns(GC) + 1));
 }
-constexpr uint32_t gop_gen_base(int GC) { return gop_un_base(GC) + 6 * (gop_ns(GC) + 2); }
+constexpr uint32_t gop_gen_base(int GC) { return gop_un_base(GC) + 2 * GUN_K * (gop_ns(GC) + 2); }
 constexpr uint32_t gop_gen(int GC, int src) { return gop_gen_base(GC) + (uint32_t)src; } // LEAF, SLOT, CONST, ACC (run-time seeds)
 constexpr uint32_t gop_param(int GC) { return gop_gen_base(GC) + 4; }
 constexpr uint32_t gop_tern(int GC) { return gop_gen_base(GC) + 5; }

@@ -114,6 +114,24 @@ template <typename T> __device__ __noinline__ UG<T> unary_vg(uint32_t op, T x) {
     return r;
 }
 
+// Value and derivative of the cheap unary operators, inline: the same expressions as unary_vg (de_grad_common.h), so a tree
+// gives the same bits whichever handler serves it.  K: 3 neg 4 square 5 cube 6 abs 7 log 8 safe_log 9 sqrt 10 safe_sqrt 11 tanh 12 relu
+template <typename T, int K> __device__ __forceinline__ UG<T> gun_inline(T x) {
+    using m = M<T>;
+    UG<T> r;
+    if constexpr (K == 3) { r.y = -x; r.g = T(-1); }
+    else if constexpr (K == 4) { r.y = x * x; r.g = x + x; }
+    else if constexpr (K == 5) { r.y = (x * x) * x; r.g = (T(3) * x) * x; }
+    else if constexpr (K == 6) { r.y = m::abs(x); r.g = jl_sign(x); }
+    else if constexpr (K == 7) { r.y = m::log(x); r.g = T(1) / x; }
+    else if constexpr (K == 8) { r.y = x <= T(0) ? m::nan() : m::log(x); r.g = x <= T(0) ? T(0) : T(1) / x; }
+    else if constexpr (K == 9) { r.y = m::sqrt(x); r.g = T(1) / (T(2) * r.y); }
+    else if constexpr (K == 10) {
+        if (x < T(0)) { r.y = m::nan(); r.g = T(0); } else { r.y = m::sqrt(x); r.g = T(1) / (T(2) * r.y); }
+    } else if constexpr (K == 11) { r.y = m::tanh(x); r.g = T(1) - r.y * r.y; }
+    else { r.y = x < T(0) ? T(0) : x; r.g = x < T(0) ? T(0) : T(1); }
+    return r;
+}
 // value + both partials of op(x, y) (x = first/left argument)
 template <typename T> struct BG { T v, gx, gy; };
 template <typename T> __device__ __noinline__ BG<T> binary_vg(uint32_t op, T x, T y) {

@@ -165,11 +165,17 @@ template <typename T, int GC, int K, int SRC, int SV, bool CHK> __device__ __noi
     if constexpr (CHK) gpoison<T>(st.poison, st.x);
     return st;
 }
-// unary hot ops (K: 0 cos, 1 exp, 2 sin)
+// unary hot ops (K: 0 cos, 1 exp, 2 sin, 3.. see gun_inline)
 template <typename T, int GC, int K, int SRC, int SV, bool CHK> __device__ __noinline__ GState<T, GC> g_un(GHARGS) {
     const GOperand<T, GC, SRC, SV> b = goperand<T, GC, SRC, SV>(st, la, imm);
     LV(T) y, g;
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (K >= 3) {
+        DE_UNROLL for (int i = 0; i < VS; i++) {
+            const UG<T> r = gun_inline<T, K>(b.x[i]);
+            y[i] = r.y;
+            g[i] = r.g;
+        }
+    } else if constexpr (sizeof(T) == 4) {
         if constexpr (K == 1) { DE_UNROLL for (int i = 0; i < VS; i++) { y[i] = (T)fast_exp_f32((float)b.x[i]); g[i] = y[i]; } }
         else {
             bool big = false;
@@ -274,7 +280,7 @@ template <typename T, int GC, int SV> __device__ __forceinline__ void fill_seede
 #undef GB1
 #define GU1(K) t[gop_un(GC, K, GS_LEAF, SV, false)] = (uint64_t)&g_un<T, GC, K, GS_LEAF, SV, false>; \
                t[gop_un(GC, K, GS_LEAF, SV, true)] = (uint64_t)&g_un<T, GC, K, GS_LEAF, SV, true>;
-        GU1(0) GU1(1) GU1(2)
+        GU1(0) GU1(1) GU1(2) GU1(3) GU1(4) GU1(5) GU1(6) GU1(7) GU1(8) GU1(9) GU1(10) GU1(11) GU1(12)
 #undef GU1
         fill_seeded<T, GC, SV + 1>(t);
     }
@@ -289,7 +295,9 @@ template <typename T, int GC> __global__ void de_grad_fill_handlers(uint64_t *t)
     GB2(0) GB2(1) GB2(2) GB2(3) GB2(4) GB2(5)
 #undef GB2
 #define GU2(K, S) t[gop_un(GC, K, S, 0, false)] = (uint64_t)&g_un<T, GC, K, S, 0, false>; t[gop_un(GC, K, S, 0, true)] = (uint64_t)&g_un<T, GC, K, S, 0, true>;
-    GU2(0, GS_SLOT) GU2(1, GS_SLOT) GU2(2, GS_SLOT) GU2(0, GS_ACC) GU2(1, GS_ACC) GU2(2, GS_ACC)
+#define GU3(K) GU2(K, GS_SLOT) GU2(K, GS_ACC)
+    GU3(0) GU3(1) GU3(2) GU3(3) GU3(4) GU3(5) GU3(6) GU3(7) GU3(8) GU3(9) GU3(10) GU3(11) GU3(12)
+#undef GU3
 #undef GU2
     t[gop_gen(GC, GS_LEAF)] = (uint64_t)&g_gen<T, GC, GS_LEAF>;
     t[gop_gen(GC, GS_SLOT)] = (uint64_t)&g_gen<T, GC, GS_SLOT>;

@@ -112,11 +112,15 @@ template <typename T, int K, int SRC, bool CHK> __device__ __noinline__ GState<T
     if constexpr (CHK) rpoison<T>(st.vpoison, st.x);
     return st;
 }
-// unary hot ops (K: 0 cos, 1 exp, 2 sin); SRC = RS_ACC or RS_LEAF (fused leaf load)
+// unary hot ops (K: 0 cos, 1 exp, 2 sin, 3.. gun_inline); SRC = RS_ACC or RS_LEAF (fused leaf load)
 template <typename T, int K, int SRC, bool CHK> __device__ __noinline__ GState<T> f_un(RHARGS) {
     const T b = roperand<T, SRC>(st, la, imm);
     T y, g;
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (K >= 3) { // the cheap unary operators, same expressions as the generic table (gun_inline, de_grad_common.h)
+        const UG<T> r = gun_inline<T, K>(b);
+        y = r.y;
+        g = r.g;
+    } else if constexpr (sizeof(T) == 4) {
         if constexpr (K == 1) { y = (T)fast_exp_f32((float)b); g = y; }
         else {
             float sn, cs;
@@ -255,7 +259,7 @@ template <typename T> __global__ void de_rev_fill_handlers(uint64_t *t) {
     RB1(0) RB1(1) RB1(2) RB1(3) RB1(4) RB1(5)
 #define RU2(K, S) t[rop_un(K, S, false)] = (uint64_t)&f_un<T, K, S, false>; t[rop_un(K, S, true)] = (uint64_t)&f_un<T, K, S, true>;
 #define RU1(K) RU2(K, RS_ACC) RU2(K, RS_LEAF)
-    RU1(0) RU1(1) RU1(2)
+    RU1(0) RU1(1) RU1(2) RU1(3) RU1(4) RU1(5) RU1(6) RU1(7) RU1(8) RU1(9) RU1(10) RU1(11) RU1(12)
     t[rop_gen(RS_LEAF)] = (uint64_t)&f_gen<T, RS_LEAF>;
     t[rop_gen(RS_SLOT)] = (uint64_t)&f_gen<T, RS_SLOT>;
     t[rop_gen(RS_CONST)] = (uint64_t)&f_gen<T, RS_CONST>;
