@@ -352,7 +352,7 @@ def test_constant_inner_branch_of_a_fused_kernel_is_not_constant_folded_for_the_
     pop.close()
 
 
-def test_set_constants_patches_every_derived_program_in_place(api):
+def test_set_constants_patches_every_derived_program_in_place(api, monkeypatch):
     """de_program_set_consts rewrites immediates inside the bound / fused / gradient instruction streams
     (no re-lowering).  After several updates every entry point must be bit-identical to a population
     created from scratch with the same constants — including folded constant subtrees, fused
@@ -364,6 +364,9 @@ def test_set_constants_patches_every_derived_program_in_place(api):
     y = np.cos(np.arange(700)).astype(np.float32)
     pop = api.Population(trees, ops, np.float32, n_features=3)
     pop.eval(X); pop.eval_grad(X, False); pop.eval_grad(X, "both"); pop.eval_loss_grad(X, y)  # build every derived program first
+    monkeypatch.setenv("DE_LOSS_GRAD_REVERSE", "1")  # ... the reverse-accumulation program too
+    pop.eval_loss_grad(X, y)
+    monkeypatch.delenv("DE_LOSS_GRAD_REVERSE")
     g = np.random.Generator(np.random.PCG64(1))
     n_const = int(pop.n_consts.sum())
 
@@ -411,5 +414,12 @@ def test_set_constants_patches_every_derived_program_in_place(api):
         la, ka = pop.eval_loss(X, y); lb, kb = ref.eval_loss(X, y)
         assert np.array_equal(ka, kb)
         same(la[ka], lb[kb])
+        monkeypatch.setenv("DE_LOSS_GRAD_REVERSE", "1")  # patched reverse program == reverse program built from scratch
+        la, da, ka = pop.eval_loss_grad(X, y); lb, db, kb = ref.eval_loss_grad(X, y)
+        monkeypatch.delenv("DE_LOSS_GRAD_REVERSE")
+        assert np.array_equal(ka, kb)
+        same(la[ka], lb[kb])
+        for t in np.nonzero(ka)[0]:
+            same(da[t], db[t])
         ref.close()
     pop.close()
