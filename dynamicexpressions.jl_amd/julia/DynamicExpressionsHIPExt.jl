@@ -255,6 +255,20 @@ function eval_population_loss(
 end
 
 """
+    set_population_constants!(pop, constants::Vector{T})
+
+New constants for the trees of `pop`, same shapes: `constants` = the trees' `get_scalar_constants` vectors
+(src/NodeUtils.jl:99-143: depth-first leaf order) back to back.  Nothing is re-flattened or re-lowered — the
+immediates are patched inside the device programs (`de_program_set_consts`), which is what an optimiser
+loop (`ext/DynamicExpressionsOptimExt.jl:182-224`) calls between `eval_population_loss_grad` evaluations.
+"""
+function set_population_constants!(pop::HIPPopulation{T}, constants::Vector{T}) where {T}
+    rc = GC.@preserve constants ccall((:de_program_set_consts, LIBDE), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), pop.handle, constants)
+    check(pop.ctx, rc)
+    return pop
+end
+
+"""
     eval_population_loss_grad(pop, X, y; weights=nothing, loss=:L2, variable=Val(false))
         -> (loss::Vector{T}, dloss::Vector{Vector{T}}, ok)
 
