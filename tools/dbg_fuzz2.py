@@ -7,6 +7,7 @@ from dynamicexpressions_jl_amd import api
 from oracle import oracle
 from helpers import parity_tolerance
 seed0 = int(sys.argv[1])
+HOT = len(sys.argv) > 2 and sys.argv[2] == "hot"  # reproduce tools/fuzz_hot.py instead of tools/fuzz_gpu.py
 ops_wide = de.OperatorEnum(binary_operators=("+", "-", "/", "*", "max", "min", "pow_abs2", "^"),
                            unary_operators=("cos", "exp", "safe_log", "neg", "square", "cube", "abs", "tanh", "sin",
                                             "safe_sqrt", "atan", "relu"))
@@ -19,16 +20,22 @@ def subtrees(t):
     return out
 
 found = 0
-for rep in range(6):
-    rng = de.synth.Xoshiro256ss(seed0 * 1000 + rep)
-    for ops, F in ((ops_hot, 5), (ops_wide, 3), (ops_hot, 2)):
+for rep in range(5 if HOT else 6):
+    rng = de.synth.Xoshiro256ss(seed0 * 31 + rep if HOT else seed0 * 1000 + rep)
+    for ops, F in (((ops_hot, 1 + (seed0 + rep) % 7),) if HOT else ((ops_hot, 5), (ops_wide, 3), (ops_hot, 2))):
         for dtype in (np.float32, np.float64):
-            trees = [de.synth.gen_random_tree_fixed_size(1 + (i * 7 + rep) % 33, ops, F, rng, dtype) for i in range(400)]
-            g = np.random.Generator(np.random.PCG64(seed0 + rep))
-            N = int(g.integers(1, 1500))
-            X = np.asfortranarray((g.standard_normal((F, N)) * g.choice([0.1, 1, 10])).astype(dtype))
-            if rep % 2:
-                X[0, N // 2] = np.inf
+            if HOT:
+                trees = [de.synth.gen_random_tree_fixed_size(1 + (i * 3 + rep) % 40, ops, F, rng, dtype) for i in range(300)]
+                g = np.random.Generator(np.random.PCG64(seed0 * 7 + rep))
+                N = int(g.choice([1, 2, 63, 64, 65, 1023, 1024, 1025, 2047, 3000, 5121]))
+                X = np.asfortranarray((g.standard_normal((F, N)) * g.choice([0.5, 1, 3])).astype(dtype))
+            else:
+                trees = [de.synth.gen_random_tree_fixed_size(1 + (i * 7 + rep) % 33, ops, F, rng, dtype) for i in range(400)]
+                g = np.random.Generator(np.random.PCG64(seed0 + rep))
+                N = int(g.integers(1, 1500))
+                X = np.asfortranarray((g.standard_normal((F, N)) * g.choice([0.1, 1, 10])).astype(dtype))
+                if rep % 2:
+                    X[0, N // 2] = np.inf
             for ec in (api.EvalContext(), api.EvalContext(early_exit=False), api.EvalContext(use_fused=False), api.EvalContext(bumper=True)):
                 opts = ec.option_bits(ops)
                 pop = api.Population(trees, ops, dtype, n_features=F, eval_context=ec)
