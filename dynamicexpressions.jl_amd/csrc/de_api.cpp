@@ -1305,8 +1305,13 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                     if (v & 2) row_operand();
                     else o.arg = 0;
                     gop = gop_un(GC, (int)(v >> 2), src, sv, (v & 1) != 0);
+                } else if (b.bop == BOP_GEN_ROW && hot_const_unary && (aux == (uint32_t)DE_B_MAX || aux == (uint32_t)DE_B_MIN)) {
+                    row_operand(); gop = gop_bin(GC, aux == (uint32_t)DE_B_MAX ? 6 : 7, src, sv, false); o.lo = o.hi = 0;
                 } else if (b.bop == BOP_GEN_ROW && gun_of(aux) >= 0) { row_operand(); gop = gop_un(GC, gun_of(aux), src, sv, false); o.lo = o.hi = 0; }
                 else if (b.bop == BOP_GEN_ROW) { row_operand(true); gop = gop_gen(GC, src); o.lo = aux; o.hi = 0; }
+                else if (b.bop == BOP_GEN_CONST && hot_const_unary && (aux == (uint32_t)DE_B_MAX || aux == (uint32_t)DE_B_MIN)) {
+                    const_operand(b.arg & 0xFFFFu, 0); gop = gop_bin(GC, aux == (uint32_t)DE_B_MAX ? 6 : 7, src, sv, false);
+                }
                 else if (b.bop == BOP_GEN_CONST && gun_of(aux) >= 0) {
                     // cos / exp / sin of a constant leaf (common: half the leaves are constants and the gradient program
                     // is not folded): load the constant, then the hot unary handler on the accumulator — not the generic
@@ -1335,6 +1340,8 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                     case DE_B_MUL: k = 3; break;
                     case DE_B_DIV: k = 4; break;
                     case DOP_RDIV: k = 5; break;
+                    case DE_B_MAX: k = hot_const_unary ? 6 : -1; break;
+                    case DE_B_MIN: k = hot_const_unary ? 7 : -1; break;
                     default: ku = gun_of(aux); break;
                     }
                     o.lo = o.hi = 0;
@@ -1525,6 +1532,10 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                         F_(mk(rop_un(k, RSRC_ACC, chk), pr, 0, 0));
                         R_(mk(ROP_R_UN, pr, 0, 0));
                     }
+                } else if (b.bop == BOP_GEN_ROW && hot_const_unary && (aux == (uint32_t)DE_B_MAX || aux == (uint32_t)DE_B_MIN)) {
+                    const uint32_t pr = alloc(2);
+                    F_(mk(rop_bin(aux == (uint32_t)DE_B_MAX ? 6 : 7, is_leaf ? RSRC_LEAF : RSRC_SLOT, false), rowb(row), pr, 0));
+                    back_binary(0, pr, !is_leaf, rowb(row), is_leaf ? leaf_col(row) : NONE);
                 } else if (b.bop == BOP_GEN_ROW && gun_of(aux) >= 0 && is_leaf) {
                     const uint32_t pr = alloc(1);
                     F_(mk(rop_un(gun_of(aux), RSRC_LEAF, false), rowb(row), pr, 0));
@@ -1536,6 +1547,11 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     F_(mk(rop_gen(is_leaf ? RSRC_LEAF : RSRC_SLOT), rowb(row), pr | (aux << 24), 0));
                     if (unary) back_unary_leaf(pr, leaf_col(row));
                     else back_binary(0, pr, !is_leaf, rowb(row), is_leaf ? leaf_col(row) : NONE);
+                } else if (b.bop == BOP_GEN_CONST && hot_const_unary && (aux == (uint32_t)DE_B_MAX || aux == (uint32_t)DE_B_MIN)) {
+                    const uint32_t pr = alloc(2);
+                    p->rtsite_of_gb[(size_t)i] = (int32_t)p->rtcode.size();
+                    F_(mk(rop_bin(aux == (uint32_t)DE_B_MAX ? 6 : 7, RSRC_CONST, false), pr, b.lo, b.hi));
+                    back_binary(0, pr, false, 0, const_col(ord));
                 } else if (b.bop == BOP_GEN_CONST && gun_of(aux) >= 0) {
                     // cos / exp / sin of a constant leaf: load + hot unary handler instead of the generic one
                     const uint32_t pr = alloc(1);
@@ -1568,6 +1584,8 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     case DE_B_MUL: k = 3; break;
                     case DE_B_DIV: k = 4; break;
                     case DOP_RDIV: k = 5; break;
+                    case DE_B_MAX: k = hot_const_unary ? 6 : -1; break;
+                    case DE_B_MIN: k = hot_const_unary ? 7 : -1; break;
                     default: ku = gun_of(aux); break;
                     }
                     if (aux == (uint32_t)DOP_LOAD) {

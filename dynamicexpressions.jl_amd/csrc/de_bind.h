@@ -48,8 +48,8 @@ enum RevOp : uint32_t {
     ROP_LOAD_BASE = 0,                 // + src (LEAF, SLOT, CONST)
     ROP_PUSH = 3,
     ROP_CHECK = 4,
-    ROP_BIN_BASE = 5,                  // + ((K*3 + src)*2 + checked)
-    ROP_UN_BASE = ROP_BIN_BASE + 36,   // + ((K*2 + (src == LEAF))*2 + checked),  K < GUN_K (13)
+    ROP_BIN_BASE = 5,                  // + ((K*3 + src)*2 + checked),  K < GBIN_K (8)
+    ROP_UN_BASE = ROP_BIN_BASE + 48,   // + ((K*2 + (src == LEAF))*2 + checked),  K < GUN_K (13)
     ROP_GEN_BASE = ROP_UN_BASE + 52,   // + src (LEAF, SLOT, CONST, ACC)
     ROP_TERN = ROP_GEN_BASE + 4,
     ROP_PARAM,
@@ -115,10 +115,13 @@ constexpr uint32_t top_bin2(int k, bool cst, bool out, bool push) { return TOP_B
 // ("seed variant" sv = 0: read the row at run time (several windows), 1: no gradient, 2 + k: row k):
 // the dense  g1*d1[k] + g2*d2[k]  then needs no one-hot materialisation.  Window width GC gives
 // NS = GC + 2 seed variants; ids depend on GC (one module per GC anyway).
-constexpr int GOP_MAX = 640; // >= gop_count(8)
+constexpr int GOP_MAX = 720; // >= gop_count(8)
+// hot binary operators of the gradient kernels: ADD SUB RSUB MUL DIV RDIV | MAX MIN  (the lowering treats max/min as commutative)
+constexpr int GBIN_K = 8;
 // hot unary operators of the gradient kernels: cos exp sin | neg square cube abs log safe_log sqrt safe_sqrt tanh relu
 constexpr int GUN_K = 13;
 static_assert(ROP_GEN_BASE - ROP_UN_BASE == 4 * GUN_K, "RevOp layout and GUN_K disagree");
+static_assert(ROP_UN_BASE - ROP_BIN_BASE == 6 * GBIN_K, "RevOp layout and GBIN_K disagree");
 // de_opcode -> hot unary index, or -1 (de_opcodes.h values are passed in: this header stays free of that include)
 constexpr int gun_index(int op, int u_cos, int u_exp, int u_sin, int u_neg, int u_square, int u_cube, int u_abs, int u_log,
                         int u_safe_log, int u_sqrt, int u_safe_sqrt, int u_tanh, int u_relu) {
@@ -133,10 +136,10 @@ constexpr uint32_t gop_load(int GC, int src, int sv) { // LEAF: [0,NS)  SLOT: NS
 constexpr uint32_t gop_push(int GC) { return 2 * gop_ns(GC) + 1; }
 constexpr uint32_t gop_check_acc(int GC) { return gop_push(GC) + 1; }
 constexpr uint32_t gop_bin_base(int GC) { return gop_check_acc(GC) + 1; }
-constexpr uint32_t gop_bin(int GC, int k, int src, int sv, bool chk) { // 6 K x 2 chk x (LEAF NS + SLOT + CONST NS)
+constexpr uint32_t gop_bin(int GC, int k, int src, int sv, bool chk) { // GBIN_K x 2 chk x (LEAF NS + SLOT + CONST NS)
     return gop_bin_base(GC) + (uint32_t)(k * 2 + chk) * (2 * gop_ns(GC) + 1) + gop_load(GC, src, sv);
 }
-constexpr uint32_t gop_un_base(int GC) { return gop_bin_base(GC) + 12 * (2 * gop_ns(GC) + 1); }
+constexpr uint32_t gop_un_base(int GC) { return gop_bin_base(GC) + 2 * GBIN_K * (2 * gop_ns(GC) + 1); }
 constexpr uint32_t gop_un(int GC, int k, int src, int sv, bool chk) { // GUN_K x 2 chk x (LEAF NS + SLOT + ACC)
     return gop_un_base(GC) + (uint32_t)(k * 2 + chk) * (gop_ns(GC) + 2) +
            (src == GSRC_LEAF ? (uint32_t)sv : (src == GSRC_SLOT ? gop_ns(GC) : gop_ns(GC) + 1));

@@ -156,6 +156,14 @@ template <typename T, int GC, int K, int SRC, int SV, bool CHK> __device__ __noi
     if constexpr (K == 0) { v = lx + ly; gl = lv_splat<T>(T(1)); gr = lv_splat<T>(T(1)); }
     else if constexpr (K == 1 || K == 2) { v = lx - ly; gl = lv_splat<T>(T(1)); gr = lv_splat<T>(T(-1)); }
     else if constexpr (K == 3) { v = lx * ly; gl = ly; gr = lx; }
+    else if constexpr (K == 6 || K == 7) { // max / min: the expressions of binary_vg (ties: the second argument takes the gradient of max)
+        DE_UNROLL for (int i = 0; i < VS; i++) {
+            const bool gt = lx[i] > ly[i];
+            v[i] = K == 6 ? jl_max(lx[i], ly[i]) : jl_min(lx[i], ly[i]);
+            gl[i] = (K == 6) == gt ? T(1) : T(0);
+            gr[i] = (K == 6) == gt ? T(0) : T(1);
+        }
+    }
     else { v = lx / ly; gl = lv_splat<T>(T(1)) / ly; gr = -(v / ly); }
     st.x = v;
     LV(T) sb[GC];
@@ -276,7 +284,7 @@ template <typename T, int GC, int SV> __device__ __forceinline__ void fill_seede
                t[gop_bin(GC, K, GS_LEAF, SV, true)] = (uint64_t)&g_bin<T, GC, K, GS_LEAF, SV, true>;    \
                t[gop_bin(GC, K, GS_CONST, SV, false)] = (uint64_t)&g_bin<T, GC, K, GS_CONST, SV, false>; \
                t[gop_bin(GC, K, GS_CONST, SV, true)] = (uint64_t)&g_bin<T, GC, K, GS_CONST, SV, true>;
-        GB1(0) GB1(1) GB1(2) GB1(3) GB1(4) GB1(5)
+        GB1(0) GB1(1) GB1(2) GB1(3) GB1(4) GB1(5) GB1(6) GB1(7)
 #undef GB1
 #define GU1(K) t[gop_un(GC, K, GS_LEAF, SV, false)] = (uint64_t)&g_un<T, GC, K, GS_LEAF, SV, false>; \
                t[gop_un(GC, K, GS_LEAF, SV, true)] = (uint64_t)&g_un<T, GC, K, GS_LEAF, SV, true>;
@@ -292,7 +300,7 @@ template <typename T, int GC> __global__ void de_grad_fill_handlers(uint64_t *t)
     t[gop_check_acc(GC)] = (uint64_t)&g_check_acc<T, GC>;
 #define GB2(K) t[gop_bin(GC, K, GS_SLOT, 0, false)] = (uint64_t)&g_bin<T, GC, K, GS_SLOT, 0, false>; \
                t[gop_bin(GC, K, GS_SLOT, 0, true)] = (uint64_t)&g_bin<T, GC, K, GS_SLOT, 0, true>;
-    GB2(0) GB2(1) GB2(2) GB2(3) GB2(4) GB2(5)
+    GB2(0) GB2(1) GB2(2) GB2(3) GB2(4) GB2(5) GB2(6) GB2(7)
 #undef GB2
 #define GU2(K, S) t[gop_un(GC, K, S, 0, false)] = (uint64_t)&g_un<T, GC, K, S, 0, false>; t[gop_un(GC, K, S, 0, true)] = (uint64_t)&g_un<T, GC, K, S, 0, true>;
 #define GU3(K) GU2(K, GS_SLOT) GU2(K, GS_ACC)

@@ -100,6 +100,12 @@ template <typename T, int K, int SRC, bool CHK> __device__ __noinline__ GState<T
     else {
         T v, gl, gr;
         if constexpr (K == 3) { v = lx * ly; gl = ly; gr = lx; }
+        else if constexpr (K == 6 || K == 7) { // max / min (binary_vg's expressions)
+            const bool gt = lx > ly;
+            v = K == 6 ? jl_max(lx, ly) : jl_min(lx, ly);
+            gl = (K == 6) == gt ? T(1) : T(0);
+            gr = (K == 6) == gt ? T(0) : T(1);
+        }
         else { v = lx / ly; gl = T(1) / ly; gr = -(v * gl); }
         const uint32_t pr = rprow<T, SRC>(st, la, imm);
         const T ga = REV ? gr : gl, gb = REV ? gl : gr;
@@ -256,7 +262,7 @@ template <typename T> __global__ void de_rev_fill_handlers(uint64_t *t) {
     t[ROP_CHECK] = (uint64_t)&f_check<T>;
 #define RB2(K, S) t[rop_bin(K, S, false)] = (uint64_t)&f_bin<T, K, S, false>; t[rop_bin(K, S, true)] = (uint64_t)&f_bin<T, K, S, true>;
 #define RB1(K) RB2(K, RS_LEAF) RB2(K, RS_SLOT) RB2(K, RS_CONST)
-    RB1(0) RB1(1) RB1(2) RB1(3) RB1(4) RB1(5)
+    RB1(0) RB1(1) RB1(2) RB1(3) RB1(4) RB1(5) RB1(6) RB1(7)
 #define RU2(K, S) t[rop_un(K, S, false)] = (uint64_t)&f_un<T, K, S, false>; t[rop_un(K, S, true)] = (uint64_t)&f_un<T, K, S, true>;
 #define RU1(K) RU2(K, RS_ACC) RU2(K, RS_LEAF)
     RU1(0) RU1(1) RU1(2) RU1(3) RU1(4) RU1(5) RU1(6) RU1(7) RU1(8) RU1(9) RU1(10) RU1(11) RU1(12)
