@@ -369,13 +369,14 @@ static int make_threaded(de_ctx *c, de_program *p) {
     p->direct = ((size_t)p->n_features + (size_t)p->n_slots) * 257 * 16 > 150 * 1024;
     if (p->direct || !eval_uses_threaded()) return DE_OK;
     if ((int64_t)p->n_features + p->n_slots > 4000) return DE_OK; // row offsets must fit 24 bits
-    uint64_t table[TOP_COUNT];
+    uint64_t table[TOPX_COUNT];
     hipError_t st = eval_handler_table(p->dtype, table);
     if (st != hipSuccess) return fail(c, DE_ERR_HIP, "handler table: %s", hipGetErrorString(st));
     uint64_t base = table[0];
-    for (int i = 0; i < (int)TOP_COUNT; i++) base = std::min<uint64_t>(base, table[i]);
-    for (int i = 0; i < (int)TOP_COUNT; i++)
+    for (int i = 0; i < (int)TOPX_COUNT; i++) base = std::min<uint64_t>(base, table[i]);
+    for (int i = 0; i < (int)TOPX_COUNT; i++)
         if (table[i] - base > 0xFFFFFFFFull) return DE_OK; // cannot encode: keep the switch kernel
+    const bool hot_unary = !getenv("DE_NO_CONST_UNARY_HOT"); // unary operators outside the binder's hot set: their own handlers
     const uint32_t row_bytes = 257 * 16;
     // superinstructions (de_bind.h): fewer dispatches for the same arithmetic
     const char *nf = getenv("DE_NO_FUSE");
@@ -393,6 +394,11 @@ static int make_threaded(de_ctx *c, de_program *p) {
         const BoundInstr &b = p->fbcode[i];
         BoundInstr t = b;
         t.bop = (uint32_t)(table[b.bop] - base);
+        if (hot_unary && (b.bop == BOP_GEN_ROW || b.bop == BOP_GEN_ACC)) {
+            const int k = gun_index((int)(b.arg >> 24), DE_U_COS, DE_U_EXP, DE_U_SIN, DE_U_NEG, DE_U_SQUARE, DE_U_CUBE, DE_U_ABS, DE_U_LOG, DE_U_SAFE_LOG,
+                                    DE_U_SQRT, DE_U_SAFE_SQRT, DE_U_TANH, DE_U_RELU);
+            if (k >= 3) t.bop = (uint32_t)(table[TOPX_UN_BASE + (uint32_t)(k - 3) * 2 + (b.bop == BOP_GEN_ACC ? 1 : 0)] - base);
+        }
         if (b.bop < BOP_COUNT && bop_is_const_source(b.bop)) {
             t.arg = b.arg & 0xFF000000u; // constant ordinal is only for the gradient kernel
         } else if (b.bop != BOP_GEN_PARAM) {

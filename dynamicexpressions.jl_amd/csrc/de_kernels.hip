@@ -681,6 +681,29 @@ template <typename T, int SRC, bool INJ> __device__ __noinline__ HState<T> h_gen
     if constexpr (INJ) { DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = M<T>::isfinite(in[i]) ? st.acc[i] : M<T>::inf(); }
     return st;
 }
+// Unary operators outside the binder's hot set, without the detour through the generic switch (cold_op): K = gun_index
+// (de_bind.h) 3 neg 4 square 5 cube 6 abs 7 log 8 safe_log 9 sqrt 10 safe_sqrt 11 tanh 12 relu — cold_op's expressions.
+template <typename T, int K, int SRC> __device__ __noinline__ HState<T> h_un2(HARGS) { // SRC 0: row, 1: accumulator
+    using m = M<T>;
+    typename VecOf<T>::type x = st.acc;
+    if constexpr (SRC == 0) x = *LDSP(T, la & 0xFFFFFFu);
+    DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) {
+        const T v = x[i];
+        T r;
+        if constexpr (K == 3) r = -v;
+        else if constexpr (K == 4) r = v * v;
+        else if constexpr (K == 5) r = (v * v) * v;
+        else if constexpr (K == 6) r = m::abs(v);
+        else if constexpr (K == 7) r = m::log(v);
+        else if constexpr (K == 8) r = v <= T(0) ? m::nan() : m::log(v);
+        else if constexpr (K == 9) r = m::sqrt(v);
+        else if constexpr (K == 10) r = v < T(0) ? m::nan() : m::sqrt(v);
+        else if constexpr (K == 11) r = m::tanh(v);
+        else r = v < T(0) ? T(0) : v;
+        st.acc[i] = r;
+    }
+    return st;
+}
 template <typename T> __device__ __noinline__ HState<T> h_tern(HARGS) { // acc = op3(row B, row C, acc)
     const uint32_t aux = la >> 24, lb = la & 0xFFFFFFu;
     VG<T, 1> a, b, c;
@@ -712,6 +735,9 @@ template <typename T> __global__ void de_fill_handlers(uint64_t *t) {
     t[BOP_TERN] = (uint64_t)&h_tern<T>;
     t[BOP_INJ_ACC] = (uint64_t)&h_gen<T, 2, true>;
     t[BOP_INJ_ROW] = (uint64_t)&h_gen<T, 0, true>;
+#define HX(K) t[TOPX_UN_BASE + (K - 3) * 2] = (uint64_t)&h_un2<T, K, 0>; t[TOPX_UN_BASE + (K - 3) * 2 + 1] = (uint64_t)&h_un2<T, K, 1>;
+    HX(3) HX(4) HX(5) HX(6) HX(7) HX(8) HX(9) HX(10) HX(11) HX(12)
+#undef HX
 #undef HB
 #undef HU
     // superinstructions
@@ -1047,16 +1073,16 @@ static hipError_t launch_eval_geo(const EvalArgs &a, hipStream_t stream, const c
 // ---- threaded variant: handler table + launch ---------------------------------------------
 template <typename T> static hipError_t fetch_handlers(uint64_t *host_table) {
     uint64_t *d = nullptr;
-    hipError_t st = hipMalloc(reinterpret_cast<void **>(&d), TOP_COUNT * sizeof(uint64_t));
+    hipError_t st = hipMalloc(reinterpret_cast<void **>(&d), TOPX_COUNT * sizeof(uint64_t));
     if (st != hipSuccess) return st;
     hipLaunchKernelGGL(de_fill_handlers<T>, dim3(1), dim3(1), 0, 0, d);
-    st = hipMemcpy(host_table, d, TOP_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    st = hipMemcpy(host_table, d, TOPX_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     return st;
 }
 
 hipError_t eval_handler_table(int dtype, uint64_t *table) {
-    static uint64_t cache[2][TOP_COUNT];
+    static uint64_t cache[2][TOPX_COUNT];
     static bool have[2] = {false, false};
     static std::mutex mu; // contexts on several host threads may ask at once
     const std::lock_guard<std::mutex> lock(mu);
@@ -1066,7 +1092,7 @@ hipError_t eval_handler_table(int dtype, uint64_t *table) {
         if (st != hipSuccess) return st;
         have[k] = true;
     }
-    for (int i = 0; i < (int)TOP_COUNT; i++) table[i] = cache[k][i];
+    for (int i = 0; i < (int)TOPX_COUNT; i++) table[i] = cache[k][i];
     return hipSuccess;
 }
 
