@@ -399,6 +399,8 @@ static int make_threaded(de_ctx *c, de_program *p) {
                                     DE_U_SQRT, DE_U_SAFE_SQRT, DE_U_TANH, DE_U_RELU);
             if (k >= 3) t.bop = (uint32_t)(table[TOPX_UN_BASE + (uint32_t)(k - 3) * 2 + (b.bop == BOP_GEN_ACC ? 1 : 0)] - base);
         }
+        if (hot_unary && (b.bop == BOP_GEN_ROW || b.bop == BOP_GEN_CONST) && ((b.arg >> 24) == (uint32_t)DE_B_MAX || (b.arg >> 24) == (uint32_t)DE_B_MIN))
+            t.bop = (uint32_t)(table[TOPX_BIN_BASE + ((b.arg >> 24) == (uint32_t)DE_B_MAX ? 0u : 2u) + (b.bop == BOP_GEN_CONST ? 1u : 0u)] - base);
         if (b.bop < BOP_COUNT && bop_is_const_source(b.bop)) {
             t.arg = b.arg & 0xFF000000u; // constant ordinal is only for the gradient kernel
         } else if (b.bop != BOP_GEN_PARAM) {

@@ -155,7 +155,8 @@ static_assert(gop_count(8) <= GOP_MAX, "GOP_MAX too small");
 // (GUN_K - 3 of them: neg .. relu, the list of gun_index) on a row or on the accumulator.  Chosen when the
 // threaded code is made (de_api.cpp make_threaded) instead of the generic handler; ids follow TOP_COUNT.
 constexpr uint32_t TOPX_UN_BASE = TOP_COUNT;                 // + (k - 3) * 2 + (src == ACC)
-constexpr uint32_t TOPX_COUNT = TOPX_UN_BASE + 2 * (GUN_K - 3);
+constexpr uint32_t TOPX_BIN_BASE = TOPX_UN_BASE + 2 * (GUN_K - 3); // max / min: + (k - 6) * 2 + (src == CONST)
+constexpr uint32_t TOPX_COUNT = TOPX_BIN_BASE + 4;
 
 // True when a (bound or fused) instruction carries a constant's bits in lo/hi.  Every generic
 // instruction with a constant operand becomes exactly one such instruction, in program order, in the

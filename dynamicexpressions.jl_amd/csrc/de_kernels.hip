@@ -704,6 +704,14 @@ template <typename T, int K, int SRC> __device__ __noinline__ HState<T> h_un2(HA
     }
     return st;
 }
+// acc = max(acc, b) / min(acc, b) (K 6 / 7; cold_op's expressions) with b = a row (SRC 0) or a constant (SRC 1)
+template <typename T, int K, int SRC> __device__ __noinline__ HState<T> h_bin2(HARGS) {
+    typename VecOf<T>::type b;
+    if constexpr (SRC == 0) b = *LDSP(T, la & 0xFFFFFFu);
+    else { const T c = imm_from<T>(imm); DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) b[i] = c; }
+    DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = K == 6 ? jl_max(st.acc[i], b[i]) : jl_min(st.acc[i], b[i]);
+    return st;
+}
 template <typename T> __device__ __noinline__ HState<T> h_tern(HARGS) { // acc = op3(row B, row C, acc)
     const uint32_t aux = la >> 24, lb = la & 0xFFFFFFu;
     VG<T, 1> a, b, c;
@@ -738,6 +746,8 @@ template <typename T> __global__ void de_fill_handlers(uint64_t *t) {
 #define HX(K) t[TOPX_UN_BASE + (K - 3) * 2] = (uint64_t)&h_un2<T, K, 0>; t[TOPX_UN_BASE + (K - 3) * 2 + 1] = (uint64_t)&h_un2<T, K, 1>;
     HX(3) HX(4) HX(5) HX(6) HX(7) HX(8) HX(9) HX(10) HX(11) HX(12)
 #undef HX
+    t[TOPX_BIN_BASE + 0] = (uint64_t)&h_bin2<T, 6, 0>; t[TOPX_BIN_BASE + 1] = (uint64_t)&h_bin2<T, 6, 1>;
+    t[TOPX_BIN_BASE + 2] = (uint64_t)&h_bin2<T, 7, 0>; t[TOPX_BIN_BASE + 3] = (uint64_t)&h_bin2<T, 7, 1>;
 #undef HB
 #undef HU
     // superinstructions
