@@ -423,3 +423,40 @@ def test_set_constants_patches_every_derived_program_in_place(api, monkeypatch):
             same(da[t], db[t])
         ref.close()
     pop.close()
+
+
+def test_eval_handlers_of_more_unary_operators_and_max_min(api, monkeypatch):
+    """`neg square cube abs log safe_log sqrt safe_sqrt tanh relu` and max/min have eval handlers of their own (DESIGN
+    §4.1); they must give the bits of the generic handler (same expressions), and the oracle's bits for the exact ones."""
+    from helpers import sexpr_to_node
+    una = ("neg", "square", "cube", "abs", "log", "safe_log", "sqrt", "safe_sqrt", "tanh", "relu")
+    ops = de.OperatorEnum(binary_operators=("+", "*", "max", "min"), unary_operators=una)
+    for dtype in (np.float32, np.float64):
+        X = np.asfortranarray(de.synth.random_X(3, 3000, seed=4, dtype=dtype))
+        trees = []
+        for u in una:
+            trees += [sexpr_to_node(f, ops) for f in (
+                [u, ["x", 1]], [u, ["+", ["x", 1], ["*", ["x", 2], 0.5]]],
+                ["*", [u, ["+", ["x", 1], 1.5]], [u, ["*", ["x", 3], ["x", 2]]]],
+                ["max", [u, ["x", 2]], ["min", [u, ["x", 1]], 0.75]], ["min", ["max", ["x", 3], -0.25], [u, ["x", 3]]])]
+        for ec in (api.EvalContext(), api.EvalContext(early_exit=False)):
+            pop = api.Population(trees, ops, dtype, n_features=3, eval_context=ec)
+            a, ka = pop.eval(X)
+            pop.close()
+            monkeypatch.setenv("DE_NO_CONST_UNARY_HOT", "1")
+            pop = api.Population(trees, ops, dtype, n_features=3, eval_context=ec)
+            b, kb = pop.eval(X)
+            pop.close()
+            monkeypatch.delenv("DE_NO_CONST_UNARY_HOT")
+            assert np.array_equal(ka, kb)
+            ui = np.uint32 if dtype == np.float32 else np.uint64
+            m = ~(np.isnan(a) & np.isnan(b))
+            np.testing.assert_array_equal(a.view(ui)[m], b.view(ui)[m])
+        for t, tree in enumerate(trees):  # IEEE-exact operators: the oracle's bits
+            if (t // 5) in (0, 1, 2, 3, 9):  # neg square cube abs relu
+                tape, consts = de.flatten(tree, ops, dtype)
+                y, ok = oracle.eval_tree_array(tape, consts, X)
+                o, k = api.eval_tree_array(tree, X, ops)
+                assert k == ok
+                if ok:
+                    np.testing.assert_array_equal(o.view(ui), y.view(ui))

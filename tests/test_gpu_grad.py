@@ -126,6 +126,66 @@ def test_wide_operator_gradients_f64(api):
         grad_compare(api, trees, ops, X, np.float64, mode)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_every_hot_unary_and_max_min_on_every_operand_kind(api, dtype):
+    """The gradient kernels serve `neg square cube abs log safe_log sqrt safe_sqrt tanh relu` (and max/min) with hot
+    handlers of their own instead of the generic one: each operator applied to a feature row, a
+    constant leaf, the accumulator, a spilled subtree and (parametric) a parameter row must give the oracle's
+    Jacobian — bit for bit for the IEEE-exact ones — in all three modes, and the same bits as the generic handler."""
+    from helpers import sexpr_to_node
+    una = ("neg", "square", "cube", "abs", "log", "safe_log", "sqrt", "safe_sqrt", "tanh", "relu", "cos", "exp", "sin")
+    ops = de.OperatorEnum(binary_operators=("+", "*", "max", "min"), unary_operators=una)
+    exact_ops = {"neg", "square", "cube", "abs", "relu"}
+    X = np.asfortranarray(np.abs(de.synth.random_X(3, 300, seed=4, dtype=dtype)) + dtype(0.25))  # positive: log / sqrt defined
+    import os
+    for u in una:
+        forms = [
+            [u, ["x", 1]],                                             # feature row
+            [u, 1.75],                                                 # constant leaf
+            [u, ["+", ["x", 1], ["*", ["x", 2], 0.5]]],                # accumulator
+            ["*", [u, ["+", ["x", 1], 1.5]], [u, ["*", ["x", 3], ["x", 2]]]],  # a spilled subtree on one side
+            ["max", [u, ["x", 2]], ["min", [u, 0.75], ["x", 3]]],      # max / min with rows, constants, slots
+        ]
+        trees = [sexpr_to_node(f, ops) for f in forms]
+        for mode in ("variable", "constant", "both"):
+            assert grad_compare(api, trees, ops, X, dtype, mode, exact=u in exact_ops) == len(trees), (u, mode)
+        # same bits as the generic handler
+        variable, _ = MODES["both"]
+        pop = api.Population(trees, ops, dtype, n_features=3)
+        a = pop.eval_grad(X, variable)
+        pop.close()
+        os.environ["DE_NO_CONST_UNARY_HOT"] = "1"
+        try:
+            pop = api.Population(trees, ops, dtype, n_features=3)
+            b = pop.eval_grad(X, variable)
+            pop.close()
+        finally:
+            del os.environ["DE_NO_CONST_UNARY_HOT"]
+        if u in exact_ops or u in ("log", "safe_log", "sqrt", "safe_sqrt", "tanh"):  # same library functions on both paths
+            for t in range(len(trees)):
+                np.testing.assert_array_equal(np.asarray(a[1][t]), np.asarray(b[1][t]), err_msg=f"{u} tree {t}")
+                np.testing.assert_array_equal(a[0][t], b[0][t])
+    # parameter rows
+    pops = de.OperatorEnum(binary_operators=("+", "*", "max", "min"), unary_operators=("square", "tanh", "safe_log", "cos"))
+    ptrees = [sexpr_to_node(f, pops, de.ParametricNode) for f in (
+        ["square", ["p", 1]], ["tanh", ["p", 2]], ["max", ["x", 1], ["p", 1]], ["*", ["safe_log", ["p", 2]], ["min", ["p", 1], ["x", 2]]],
+        ["+", ["cos", ["p", 1]], ["square", ["*", ["p", 2], ["x", 3]]]])]
+    g = np.random.Generator(np.random.PCG64(2))
+    params = np.asfortranarray(np.abs(g.standard_normal((2, 3))).astype(dtype) + dtype(0.5))
+    classes = g.integers(1, 4, X.shape[1])
+    pop = api.Population(ptrees, pops, dtype, n_features=3, n_params=2)
+    for variable, om in ((True, oracle.GRAD_VARIABLE), ("both", oracle.GRAD_BOTH)):
+        out, grads, ok = pop.eval_grad(X, variable, params=params, classes=classes)
+        for t, tree in enumerate(ptrees):
+            tape, consts = de.flatten(tree, pops, dtype)
+            t2, PX = oracle.parametric_to_plain(tape, X, params, classes)
+            y, gg, ok_o = oracle.eval_grad_tree_array(t2, consts, PX, om, elementwise=True)
+            assert bool(ok[t]) == ok_o
+            np.testing.assert_allclose(out[t], y, rtol=2e-6 if dtype == np.float32 else 1e-13)
+            np.testing.assert_allclose(np.asarray(grads[t]), gg, rtol=1e-5 if dtype == np.float32 else 1e-12, atol=1e-6 if dtype == np.float32 else 1e-14)
+    pop.close()
+
+
 def test_many_constants_use_several_windows(api):
     """A tree with 19 constants: constant-mode gradient is computed in three 8-wide windows."""
     ops = de.OperatorEnum(binary_operators=("+", "*"), unary_operators=("cos",))
