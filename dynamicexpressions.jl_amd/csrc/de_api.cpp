@@ -1206,6 +1206,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
     // stages a tile (the reference's formulation, src/ParametricExpression.jl:381-389), so every hot handler serves them.
     const int FE = F + (p->uses_params ? P : 0);
     const bool hot_const_unary = !getenv("DE_NO_CONST_UNARY_HOT"); // unary operators outside the binder's hot set through hot handlers
+    const bool fuse_push = !getenv("DE_NO_GRAD_PUSHLOAD");         // PUSH + LOAD pairs as one instruction
     auto gun_of = [&](uint32_t op) { // hot unary index of a de_opcode (de_bind.h), or -1
         return hot_const_unary ? gun_index((int)op, DE_U_COS, DE_U_EXP, DE_U_SIN, DE_U_NEG, DE_U_SQUARE, DE_U_CUBE, DE_U_ABS, DE_U_LOG, DE_U_SAFE_LOG,
                                            DE_U_SQRT, DE_U_SAFE_SQRT, DE_U_TANH, DE_U_RELU) : -1;
@@ -1344,6 +1345,32 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                 if (b.bop == BOP_CHECK_ROW) continue; // leaf operands are tested where they are read
                 if (b.bop == BOP_LOAD_ROW) { row_operand(); gop = gop_load(GC, src, sv); }
                 else if (b.bop == BOP_LOAD_CONST) { const_operand(b.arg & 0xFFFFu, 0); gop = gop_load(GC, src, sv); }
+                else if (b.bop == BOP_PUSH && fuse_push && i + 1 < p->gbcode_off[(size_t)t + 1] &&
+                         (p->gbcode[(size_t)i + 1].bop == BOP_LOAD_CONST ||
+                          (p->gbcode[(size_t)i + 1].bop == BOP_LOAD_ROW && (p->gbcode[(size_t)i + 1].arg & 0xFFFFFFu) < (uint32_t)F))) {
+                    // PUSH followed by the LOAD that starts the next subtree: one dispatch (g_pushload)
+                    const BoundInstr &b2 = p->gbcode[(size_t)i + 1];
+                    const uint32_t slot = slot_off(row);
+                    if (b2.bop == BOP_LOAD_CONST) {
+                        const_operand(b2.arg & 0xFFFFu, slot);
+                        o.lo = b2.lo;
+                        o.hi = b2.hi;
+                        p->gtsite_of_gb[(size_t)i + 1] = (int32_t)out.size(); // the constant lives in the fused instruction
+                    } else {
+                        const uint32_t row2 = b2.arg & 0xFFFFFFu, sd = leaf_seed(row2);
+                        if (sd != 0xFFu && sd >= 0xF0u) ok = false;
+                        src = GSRC_LEAF;
+                        sv = seed_variant(sd);
+                        o.arg = (row2 * RB) | (sv == 0 ? sd << 24 : 0u);
+                        o.lo = slot - row2 * RB; // byte distance row -> slot
+                        o.hi = 0;
+                    }
+                    if (!ok) break;
+                    o.bop = (uint32_t)(table[gop_pushload(GC, src, sv)] - base);
+                    out.push_back(o);
+                    i++; // the LOAD is part of this instruction
+                    continue;
+                }
                 else if (b.bop == BOP_PUSH) { gop = gop_push(GC); o.arg = slot_off(row); }
                 else if (b.bop == BOP_CHECK_ACC) { gop = gop_check_acc(GC); o.arg = 0; }
                 else if (b.bop >= BOP_BIN_BASE && b.bop < BOP_BIN_END) {

@@ -115,7 +115,7 @@ constexpr uint32_t top_bin2(int k, bool cst, bool out, bool push) { return TOP_B
 // ("seed variant" sv = 0: read the row at run time (several windows), 1: no gradient, 2 + k: row k):
 // the dense  g1*d1[k] + g2*d2[k]  then needs no one-hot materialisation.  Window width GC gives
 // NS = GC + 2 seed variants; ids depend on GC (one module per GC anyway).
-constexpr int GOP_MAX = 720; // >= gop_count(8)
+constexpr int GOP_MAX = 760; // >= gop_count(8)
 // hot binary operators of the gradient kernels: ADD SUB RSUB MUL DIV RDIV | MAX MIN  (the lowering treats max/min as commutative)
 constexpr int GBIN_K = 8;
 // hot unary operators of the gradient kernels: cos exp sin | neg square cube abs log safe_log sqrt safe_sqrt tanh relu
@@ -148,7 +148,10 @@ constexpr uint32_t gop_gen_base(int GC) { return gop_un_base(GC) + 2 * GUN_K * (
 constexpr uint32_t gop_gen(int GC, int src) { return gop_gen_base(GC) + (uint32_t)src; } // LEAF, SLOT, CONST, ACC (run-time seeds)
 constexpr uint32_t gop_param(int GC) { return gop_gen_base(GC) + 4; }
 constexpr uint32_t gop_tern(int GC) { return gop_gen_base(GC) + 5; }
-constexpr uint32_t gop_count(int GC) { return gop_gen_base(GC) + 6; }
+// spill the accumulator to a slot, then load a leaf row / a constant: one dispatch for the PUSH + LOAD pair that starts every
+// right-hand subtree (LEAF: NS seed variants, then CONST: NS)
+constexpr uint32_t gop_pushload(int GC, int src, int sv) { return gop_gen_base(GC) + 6 + (src == GSRC_LEAF ? 0u : gop_ns(GC)) + (uint32_t)sv; }
+constexpr uint32_t gop_count(int GC) { return gop_gen_base(GC) + 6 + 2 * gop_ns(GC); }
 static_assert(gop_count(8) <= GOP_MAX, "GOP_MAX too small");
 
 // Handlers the threaded EVAL kernel has beyond the fused set: unary operators outside the binder's hot set

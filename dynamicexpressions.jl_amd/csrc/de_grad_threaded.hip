@@ -140,6 +140,19 @@ template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_push(GHARG
     DE_UNROLL for (int k = 0; k < GC; k++) *GLDS(T, la + (1 + k) * grow_bytes<T>()) = st.d[k];
     return st;
 }
+// PUSH + LOAD in one dispatch.  LEAF: la = the row (| run-time seed << 24), imm = byte distance from the row to the slot;
+// CONST: la = the slot (| run-time seed << 24), imm = the constant.
+template <typename T, int GC, int SRC, int SV> __device__ __noinline__ GState<T, GC> g_pushload(GHARGS) {
+    uint32_t slot = la & 0xFFFFFFu;
+    if constexpr (SRC == GS_LEAF) slot += (uint32_t)imm;
+    *GLDS(T, slot) = st.x;
+    DE_UNROLL for (int k = 0; k < GC; k++) *GLDS(T, slot + (1 + k) * grow_bytes<T>()) = st.d[k];
+    const GOperand<T, GC, SRC, SV> b = goperand<T, GC, SRC, SV>(st, la, imm);
+    st.x = b.x;
+    if constexpr (SV >= 1) { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = lv_splat<T>((k == SV - 2) ? T(1) : T(0)); }
+    else { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = b.d[k]; }
+    return st;
+}
 template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_check_acc(GHARGS) {
     gpoison<T>(st.poison, st.x);
     return st;
@@ -280,6 +293,8 @@ template <typename T, int GC, int SV> __device__ __forceinline__ void fill_seede
     if constexpr (SV < GC + 2) {
         t[gop_load(GC, GS_LEAF, SV)] = (uint64_t)&g_load<T, GC, GS_LEAF, SV>;
         t[gop_load(GC, GS_CONST, SV)] = (uint64_t)&g_load<T, GC, GS_CONST, SV>;
+        t[gop_pushload(GC, GS_LEAF, SV)] = (uint64_t)&g_pushload<T, GC, GS_LEAF, SV>;
+        t[gop_pushload(GC, GS_CONST, SV)] = (uint64_t)&g_pushload<T, GC, GS_CONST, SV>;
 #define GB1(K) t[gop_bin(GC, K, GS_LEAF, SV, false)] = (uint64_t)&g_bin<T, GC, K, GS_LEAF, SV, false>; \
                t[gop_bin(GC, K, GS_LEAF, SV, true)] = (uint64_t)&g_bin<T, GC, K, GS_LEAF, SV, true>;    \
                t[gop_bin(GC, K, GS_CONST, SV, false)] = (uint64_t)&g_bin<T, GC, K, GS_CONST, SV, false>; \
