@@ -460,3 +460,25 @@ def test_eval_handlers_of_more_unary_operators_and_max_min(api, monkeypatch):
                 assert k == ok
                 if ok:
                     np.testing.assert_array_equal(o.view(ui), y.view(ui))
+
+
+def test_shared_subtrees_evaluate_like_their_expansion(api):
+    """GraphNode-style sharing (src/Node.jl:138-166): the reference evaluates a shared node once per parent, so a DAG
+    and its deep copy give the same bits; the constant of the shared node owns one gradient row per occurrence (the
+    reference's shared `NodeIndex` row is their sum)."""
+    ops = de.OperatorEnum(binary_operators=("+", "*"), unary_operators=("cos",))
+    s = de.Node(1, de.Node(2, de.Node(feature=1), de.Node(val=0.75)))
+    dag = de.Node(1, s, de.Node(2, s, s))
+    tree = dag.copy()
+    X = np.asfortranarray(np.linspace(-2, 2, 257, dtype=np.float64)[None, :])
+    ya, oka = api.eval_tree_array(dag, X, ops)
+    yb, okb = api.eval_tree_array(tree, X, ops)
+    assert oka and okb
+    np.testing.assert_array_equal(ya, yb)
+    c, sn = np.cos(X[0] * 0.75), np.sin(X[0] * 0.75)
+    np.testing.assert_allclose(ya, c + c * c, rtol=1e-14)
+    _, ga, oka = api.eval_grad_tree_array(dag, X, ops, variable=False)
+    _, gb, okb = api.eval_grad_tree_array(tree, X, ops, variable=False)
+    assert oka and okb and ga.shape == (3, X.shape[1])
+    np.testing.assert_array_equal(ga, gb)
+    np.testing.assert_allclose(ga.sum(axis=0), -sn * X[0] * (1 + 2 * c), rtol=1e-12, atol=1e-14)

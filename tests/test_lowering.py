@@ -226,3 +226,25 @@ def test_fused_program_is_a_regrouping_of_the_bound_program(options):
         n_fused += len(fused)
     if options == 7:
         assert n_fused < 0.85 * n_bound  # the pass pays: > 15 % fewer dispatches on random trees
+
+
+def test_shared_subtrees_are_evaluated_like_their_expansion():
+    """A GraphNode-style DAG (the same node object under two parents, src/Node.jl:138-166): the reference's
+    `_eval_tree_array` ignores sharing and evaluates the shared node once per parent, so the
+    flattener expands it; tape, constants and values equal those of the deep copy (`copy_node(...; break_sharing)`)."""
+    ops = de.OperatorEnum(binary_operators=("+", "*"), unary_operators=("cos",))
+    s = de.Node(1, de.Node(2, de.Node(feature=1), de.Node(val=0.75)))  # cos(x1 * 0.75)
+    dag = de.Node(1, s, de.Node(2, s, s))                               # s + s * s
+    tree = dag.copy()                                                   # sharing broken
+    assert tree.children[0] is not tree.children[1].children[0]
+    assert de.node.count_nodes(dag) == de.node.count_nodes(tree) == 14
+    assert de.node.count_constant_nodes(dag) == 3
+    tape_d, c_d = de.flatten(dag, ops, np.float64)
+    tape_t, c_t = de.flatten(tree, ops, np.float64)
+    np.testing.assert_array_equal(tape_d, tape_t)
+    np.testing.assert_array_equal(c_d, c_t)
+    X = np.asfortranarray(np.linspace(-2, 2, 33, dtype=np.float64)[None, :])
+    y, ok = oracle.eval_tree_array(tape_d, c_d, X)
+    c = np.cos(X[0] * 0.75)
+    assert ok
+    np.testing.assert_allclose(y, c + c * c, rtol=1e-15)
