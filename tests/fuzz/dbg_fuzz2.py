@@ -1,4 +1,4 @@
-"""Reproduce tools/fuzz_gpu.py and, at the first value mismatch, print the sample and every subtree's value."""
+"""Reproduce tests/fuzz/fuzz_gpu.py and, at the first value mismatch, print the sample and every subtree's value."""
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
@@ -7,7 +7,7 @@ from dynamicexpressions_jl_amd import api
 from oracle import oracle
 from helpers import parity_tolerance
 seed0 = int(sys.argv[1])
-HOT = len(sys.argv) > 2 and sys.argv[2] == "hot"  # reproduce tools/fuzz_hot.py instead of tools/fuzz_gpu.py
+HOT = len(sys.argv) > 2 and sys.argv[2] == "hot"  # reproduce tests/fuzz/fuzz_hot.py instead of tests/fuzz/fuzz_gpu.py
 ops_wide = de.OperatorEnum(binary_operators=("+", "-", "/", "*", "max", "min", "pow_abs2", "^"),
                            unary_operators=("cos", "exp", "safe_log", "neg", "square", "cube", "abs", "tanh", "sin",
                                             "safe_sqrt", "atan", "relu"))

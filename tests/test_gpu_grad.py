@@ -307,7 +307,7 @@ def test_full_size_gradient_properties_config_C3(api):
 
 def test_gradient_flag_ignores_columns_the_tree_does_not_have(api):
     """A tree without constants has a 0-row gradient in constant mode: an infinite partial (d safe_sqrt / dx at 0)
-    must not clear `complete` through the window's unused column (found by tools/fuzz_grad.py)."""
+    must not clear `complete` through the window's unused column (found by tests/fuzz/fuzz_grad.py)."""
     ops = de.OperatorEnum(binary_operators=("max", "+"), unary_operators=("safe_sqrt", "relu", "square"))
     t0 = de.Node(1, de.Node(1, de.Node(2, de.Node(feature=2))), de.Node(3, de.Node(feature=1)))  # max(safe_sqrt(relu(x2)), square(x1))
     t1 = de.Node(2, t0.copy(), de.Node(val=0.5))  # same + one constant: the partial now meets a real column
