@@ -374,6 +374,26 @@ function _hip_eval_grad_tree_array(
     return (out, grad, ok[] != 0x00)
 end
 
+"""Single-direction derivative of one tree: `(evaluation, derivative, complete)` like
+`eval_diff_tree_array(tree, cX, operators, direction)` (src/EvaluateDerivative.jl:40-53; `direction` is the
+1-based feature, `complete` is always true on this path as in the reference, :68-119)."""
+function _hip_eval_diff_tree_array(
+    tree::AbstractExpressionNode{T}, cX::Matrix{T}, operators::OperatorEnum, direction::Integer
+) where {T<:Union{Float32,Float64}}
+    F, N = size(cX)
+    1 <= direction <= F || throw(ArgumentError("direction must be a feature of cX"))
+    pop = HIPPopulation([tree], operators, F)
+    out = Vector{T}(undef, N)
+    dout = Vector{T}(undef, N)
+    ok = Ref{UInt8}(0)
+    rc = GC.@preserve cX out dout ccall(
+        (:de_eval_diff, LIBDE), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{UInt8}),
+        pop.ctx.handle, pop.handle, cX, N, F, Int32(direction - 1), out, dout, N, ok)
+    check(pop.ctx, rc)
+    return (out, dout, ok[] != 0x00)
+end
+
 is_extension_loaded(::Val{:HIP}) = true
 
 end # module
