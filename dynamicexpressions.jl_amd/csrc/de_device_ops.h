@@ -16,12 +16,16 @@ namespace de {
 
 template <typename T> struct M; // math traits
 
+__device__ __forceinline__ float fast_exp_f32(float x); // below: exp2 of the reduced argument + ldexp, rounds into the subnormal range
+
 template <> struct M<float> {
     using T = float;
     static __device__ __forceinline__ T abs(T x) { return fabsf(x); }
     static __device__ __forceinline__ T sqrt(T x) { return sqrtf(x); }
     static __device__ __forceinline__ T cbrt(T x) { return cbrtf(x); }
-    static __device__ __forceinline__ T exp(T x) { return expf(x); }
+    // not OCML's expf: that returns 0 below log(2^-149) where the correctly rounded result is still 2^-149 (results in
+    // (1/2, 1) * 2^-149; Julia and glibc round them up), which `safe_log(pow_abs2(..))` turns into NaN against a finite value
+    static __device__ __forceinline__ T exp(T x) { return fast_exp_f32(x); }
     static __device__ __forceinline__ T exp2(T x) { return exp2f(x); }
     static __device__ __forceinline__ T log(T x) { return logf(x); }
     static __device__ __forceinline__ T log2(T x) { return log2f(x); }
@@ -40,7 +44,15 @@ template <> struct M<float> {
     static __device__ __forceinline__ T acosh(T x) { return acoshf(x); }
     static __device__ __forceinline__ T atanh(T x) { return atanhf(x); }
     static __device__ __forceinline__ T tgamma(T x) { return tgammaf(x); }
-    static __device__ __forceinline__ T pow(T x, T y) { return powf(x, y); }
+    static __device__ __forceinline__ T pow(T x, T y) {
+        T r = powf(x, y);
+        // OCML's powf has the same cut as its expf: results in (1/2, 1) * 2^-149 come back as 0 instead of 2^-149
+        if (r == 0.0f && x != 0.0f && __builtin_isfinite(x) && __builtin_isfinite(y)) {
+            const T e = fast_exp_f32(y * logf(fabsf(x))); // 0 or 2^-149 here
+            r = copysignf(e, r);
+        }
+        return r;
+    }
     static __device__ __forceinline__ T fmod(T x, T y) { return fmodf(x, y); }
     static __device__ __forceinline__ T rint(T x) { return rintf(x); }
     static __device__ __forceinline__ T floor(T x) { return floorf(x); }

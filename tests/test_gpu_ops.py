@@ -132,3 +132,34 @@ def test_division_fast_path_is_bit_identical_to_ieee(api):
             nan = np.isnan(w)
             assert np.array_equal(np.isnan(out), nan)
             np.testing.assert_array_equal(out[~nan].view(np.uint32), w[~nan].view(np.uint32))
+
+
+def test_exp_and_powers_round_into_the_last_subnormal_bits(api):
+    """Results c * 2^-149: Julia (and glibc, the oracle) round them to the nearest subnormal, 2^-149 for c in (1/2, 1);
+    OCML's expf/powf return 0 there, which `safe_log(x ^ y)` turns into NaN against a finite value (found by
+    tests/fuzz/fuzz_gpu.py) — Float32 `exp`, `^` and `pow_abs2` go through the ldexp-based exp instead."""
+    from oracle import oracle
+    ops = de.OperatorEnum(binary_operators=("^", "pow_abs2", "*"), unary_operators=("exp", "safe_log"))
+    C = np.array([0.4, 0.6, 0.9, 1.4, 1.6, 2.4, 2.6, 3.6, 100.3])
+    a = (np.log(C) - 149 * np.log(2.0)).astype(np.float32)
+    X = np.asfortranarray(np.stack([a, np.full_like(a, 0.5), np.full_like(a, -0.5)]))
+    want = np.array([0, 1, 1, 1, 2, 2, 3, 4, 100], dtype=np.float64) * 2.0 ** -149
+    x1, x2, x3 = (de.Node(feature=i) for i in (1, 2, 3))
+    expo = de.Node(3, x1, de.Node(val=-1.4426950408889634))  # 0.5 ^ expo = exp(x1)
+    trees = {
+        "exp": de.Node(1, x1),
+        "pow": de.Node(1, x2, expo),
+        "pow_abs2": de.Node(2, x2, expo),
+        "pow_abs2 of a negative base": de.Node(2, x3, expo),
+    }
+    for name, tree in trees.items():
+        for ec in (api.EvalContext(), api.EvalContext(use_fused=False), api.EvalContext(early_exit=False)):
+            y, ok = api.eval_tree_array(tree, X, ops, eval_context=ec)
+            tape, consts = de.flatten(tree, ops, np.float32)
+            yo, oko = oracle.eval_tree_array(tape, consts, X, ec.option_bits(ops), elementwise=True)
+            assert ok and oko, name
+            np.testing.assert_array_equal(y, yo, err_msg=name)
+            np.testing.assert_array_equal(y.astype(np.float64), want, err_msg=name)
+    # the consumer that made it visible: log of the smallest subnormal is finite
+    y, ok = api.eval_tree_array(de.Node(2, trees["pow"]), X[:, 1:], ops)
+    assert ok and np.all(np.isfinite(y))
