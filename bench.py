@@ -10,6 +10,11 @@ configuration BASELINE.json's metric is quoted on: 1000 random depth<=15 20-node
 (5 features x 10^7 samples) Float32 (`--workload C2` gives the 10^6-sample config).  With N
 GPUs the population is tree-sharded (weak scaling: 1000 trees per GPU, X replicated, no
 data-path collective; one RCCL all_gather of the per-tree completion flags per step).
+`--gpus N` with N > 1 and no launcher environment re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU), so the plain command
+form produces the N-GPU line as well.  `--workload C4` is BASELINE config 4: 10 000 trees x
+10^7 samples tree-sharded 8 ways (rank r owns trees {t : t mod 8 = r}, 1 250 trees and 50 GB of
+output per GPU); with fewer than 8 ranks the job covers the first N shards (N=1: rank 0's shard).
 
 Rank 0 prints ONE JSON line: metric node-evals/s (whole job), plus
   roofline     — the dominant kernel's ALGORITHMIC bytes / its average launch duration measured
@@ -20,8 +25,14 @@ Rank 0 prints ONE JSON line: metric node-evals/s (whole job), plus
                  measurement of the same launch (profiles/), and `single_tree_equivalent` restates
                  the rate in the north-star's 24 B/tree-sample accounting.  After X reuse the path
                  is issue-bound (VALU + scalar), not HBM-bound: see DESIGN.md §Roofline.
-  cpu_baseline — the CPU oracle (C restatement of the reference algorithm, 1 thread) timed on
-                 a bounded sample of the same workload on this box's host cores.
+                 `roofline.valu` is the binding ceiling: VALU issue slots per tree-wavefront (the
+                 population's dispatch histogram x the per-handler ISA slot counts of
+                 profiles/valu_slots.json, tools/valu_slots.py) -> SIMD cycles at 2.4 GHz -> the
+                 fraction of that floor the measured kernel time reaches.
+  cpu_baseline — the CPU oracle (C restatement of the reference algorithm) timed on bounded samples
+                 of the same workload on this box's host cores: one tree per task on ALL host cores
+                 (`value`, `cores`) and on ONE thread (`single_thread`), plus the result of probing
+                 for a `julia` binary (`julia_probe`; the reference itself cannot run on this box).
 """
 import argparse
 import json
@@ -57,22 +68,20 @@ WORKLOADS = {
                       "5 x 10^6 Float32: eval_tree_array + the :both-mode pullback (dY = randn) with the parameter rows "
                       "reduced by class, fused (SURVEY.md §8d C5; src/ChainRules.jl:56-77, "
                       "test/test_parametric_expression.jl:326-372)"),
+    "C4": dict(n_trees=1250, N=10**7, shards=8, seed=0xDE04,
+               desc="10000 random depth<=15 20-node trees x (5 x 10^7) Float32, tree-sharded x8 (rank r: trees t = r mod 8; "
+                    "1250 trees, 50 GB of output per GPU)"),
+    "C5N": dict(n_trees=1000, N=10**6, parametric=True, per_sample=True,
+                desc="1000 random 20-node ParametricNode trees, 8 PER-SAMPLE parameters (C = N classes, classes = 1:N), "
+                     "5 x 10^6 Float32: eval_tree_array (SURVEY.md §8d C5 stress)"),
     "tiny": dict(n_trees=64, N=10**5, desc="64 trees x (5 x 10^5) Float32 (plumbing)"),
 }
 
 
-def cpu_baseline(trees, ops, X_host, budget_s=12.0, threads=None):
-    """Oracle (kind 'port') on a bounded sample of the same workload: whole trees at N = 10^6 samples
-    (arrays far larger than L2, like the reference at this scale) for ~budget_s, on `threads` host
-    threads — the reference evaluates one tree per call single-threaded, a population is
-    parallelised over trees by its callers, which is what the thread pool does (ctypes releases the
-    GIL inside the C call).  `cores` = threads actually used."""
+def _oracle_timed(tapes, X_host, threads, budget_s):
+    """Whole trees of the workload on `threads` host threads for ~budget_s; returns (node-evals, trees, seconds)."""
     from concurrent.futures import ThreadPoolExecutor
-    import dynamicexpressions_jl_amd as de
     from oracle import oracle
-    threads = threads or max(1, min(64, (os.cpu_count() or 1) // 2))
-    tapes = [de.flatten(t, ops, np.float32) for t in trees]
-    oracle.eval_tree_array(tapes[0][0], tapes[0][1], X_host[:, :1000])  # load the library outside the timed region
     deadline = [0.0]
     done = []
 
@@ -85,13 +94,96 @@ def cpu_baseline(trees, ops, X_host, budget_s=12.0, threads=None):
 
     t0 = time.perf_counter()
     deadline[0] = t0 + budget_s
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        list(ex.map(work, range(len(tapes))))
+    if threads == 1:
+        for i in range(len(tapes)):
+            work(i)
+    else:
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            list(ex.map(work, range(len(tapes))))
     dt = time.perf_counter() - t0
-    return dict(value=sum(done) * X_host.shape[1] / dt, unit="node-evals/s", cores=threads, kind="port",
-                sample=f"{len(done)} trees x {X_host.shape[1]} samples of the same workload, "
-                       f"oracle/libde_oracle.so (C restatement of src/Evaluate.jl, early exit on), one tree per task on "
-                       f"{threads} threads, {dt:.1f} s; {os.cpu_count()} host cores available")
+    return sum(done) * X_host.shape[1], len(done), dt
+
+
+def julia_probe():
+    """probe for the reference's own runtime and record the result (it is not in this image)."""
+    import shutil
+    import subprocess
+    exe = shutil.which("julia")
+    if not exe:
+        return "julia: not found on PATH (the Julia reference cannot run on this box; baseline = C restatement)"
+    try:
+        v = subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=20).stdout.strip()
+    except Exception as e:  # pragma: no cover
+        v = f"{type(e).__name__}: {e}"
+    return f"{exe}: {v} (DynamicExpressions.jl itself is not installed: no network, no depot)"
+
+
+def cpu_baseline(trees, ops, X_host, budget_s=11.0, budget_1t_s=7.0):
+    """Oracle (kind 'port') on bounded samples of the same workload: whole trees at N = 10^6 samples (arrays
+    far larger than L2, like the reference at this scale), one tree per task — the reference evaluates one tree
+    per call single-threaded and its callers parallelise a population over trees — (i) on ALL host cores of the
+    box (ctypes releases the GIL inside the C call; `cores` = threads used) and (ii) on one thread."""
+    import dynamicexpressions_jl_amd as de
+    from oracle import oracle
+    tapes = [de.flatten(t, ops, np.float32) for t in trees]
+    oracle.eval_tree_array(tapes[0][0], tapes[0][1], X_host[:, :1000])  # load the library outside the timed region
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):  # pragma: no cover
+        pass
+    ne1, nt1, dt1 = _oracle_timed(tapes, X_host, 1, budget_1t_s)
+    nea, nta, dta = _oracle_timed(tapes, X_host, ncpu, budget_s)
+    what = "oracle/libde_oracle.so (C restatement of src/Evaluate.jl, early exit on, -O3 -march=native), one tree per task"
+    return dict(value=nea / dta, unit="node-evals/s", cores=ncpu, kind="port",
+                sample=f"{nta} trees x {X_host.shape[1]} samples of the same workload, {what} on {ncpu} threads "
+                       f"(= all host cores, nproc {os.cpu_count()}), {dta:.1f} s",
+                single_thread=dict(value=ne1 / dt1, unit="node-evals/s", cores=1,
+                                   sample=f"{nt1} trees x {X_host.shape[1]} samples, {what}, 1 thread, {dt1:.1f} s"),
+                julia_probe=julia_probe())
+
+
+def valu_ceiling(pop, n_trees, units, kernel_ms, dtype_tag="f32"):
+    """The binding ceiling of the eval kernel (SURVEY.md §8d "secondary ceiling"): VALU issue slots per
+    tree-wavefront = the fused program's dispatch histogram x the ISA slot count of every handler
+    (profiles/valu_slots.json, generated by tools/valu_slots.py from the shipped code object)."""
+    path = os.path.join(ROOT, "profiles", "valu_slots.json")
+    if not os.path.exists(path):
+        return None
+    from dynamicexpressions_jl_amd import api
+    with open(path) as fh:
+        tab = json.load(fh)
+    lib = api.library()
+    hist = {}
+    n_disp = 0
+    for t in range(n_trees):
+        n = lib.de_program_dump(pop._h, t, None, 0, 3)
+        if n <= 0:
+            return None
+        w = np.zeros(int(n), dtype=np.uint32)
+        lib.de_program_dump(pop._h, t, w.ctypes.data, w.size, 3)
+        ids = w.reshape(-1, 4)[:, 0]
+        n_disp += len(ids)
+        for k, c in zip(*np.unique(ids, return_counts=True)):
+            hist[int(k)] = hist.get(int(k), 0) + int(c)
+    slots, missing = 0.0, 0
+    for k, c in hist.items():
+        h = tab["handlers"].get(str(k))
+        if h is None:
+            missing += c
+            continue
+        slots += c * h["valu_slots"]
+    slots += n_disp * tab["dispatch_overhead_valu"] + n_trees * tab["per_tree_overhead_valu"]
+    per_tree_wave = slots / n_trees
+    samples_per_wave = 256  # 64 lanes x 4 Float32 samples
+    tree_waves = units / samples_per_wave
+    simds, clock = 256 * 4, 2.4e9  # MI355X: 256 CUs x 4 SIMD16, 2.4 GHz peak engine clock
+    floor_ms = tree_waves * per_tree_wave * 4 / (simds * clock) * 1e3  # a wave64 VALU instruction issues over 4 cycles
+    return dict(slots_per_tree_wave=per_tree_wave, dispatches_per_tree=n_disp / n_trees, samples_per_wave=samples_per_wave,
+                simd_cycles_per_tree_wave=per_tree_wave * 4, clock_ghz=2.4, simds=simds, floor_ms=floor_ms,
+                frac=floor_ms / kernel_ms, dispatches_without_slot_count=missing,
+                source="profiles/valu_slots.json (tools/valu_slots.py: shortest-path VALU slots per handler from the gfx950 ISA) "
+                       "x de_program_dump(stage 3) dispatch histogram of this population")
 
 
 def main():
@@ -103,13 +195,31 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one per GPU, RCCL over xGMI) and relay
+        # their output; rank 0 of the child job prints the JSON line with n_gpus = N
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); "
+                         f"use --nproc-per-node {args.gpus}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    if os.environ.get("DE_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) visible")
     # DE_BENCH_BACKEND=gloo: dry run of the multi-rank path on a box with fewer GPUs than ranks (ranks share
     # devices, flags are gathered through host memory) — exercises the code path, the timing means nothing
     backend = os.environ.get("DE_BENCH_BACKEND", "nccl")
@@ -132,12 +242,23 @@ def main():
     ops = de.synth.BENCH_OPERATORS
     # weak scaling: the job's population is n_per_gpu * world trees, round-robin sharded
     is_param = bool(wl.get("parametric"))
-    if is_param:
-        all_trees = de.synth.random_population(n_per_gpu * world, seed=0xDE05, node_type=de.ParametricNode, nparams=8)
+    shards = wl.get("shards")
+    if shards:
+        # a fixed population sharded `shards` ways (config C4: 10 000 trees x8); this job runs the first `world` shards
+        if world > shards:
+            raise SystemExit(f"workload {args.workload} has {shards} shards; --gpus must be <= {shards}")
+        full = de.synth.random_population(n_per_gpu * shards, seed=wl["seed"])
+        shard_ids = [dedist.shard_indices(len(full), r, shards) for r in range(world)]
+        all_trees = [full[i] for r in range(world) for i in shard_ids[r]]  # the trees this job evaluates
+        trees = [full[i] for i in shard_ids[rank]]
+        del full
     else:
-        all_trees = de.synth.random_population(n_per_gpu * world, seed=0xDE02)
-    my_ids = dedist.shard_indices(len(all_trees), rank, world)
-    trees = [all_trees[i] for i in my_ids]
+        if is_param:
+            all_trees = de.synth.random_population(n_per_gpu * world, seed=0xDE05, node_type=de.ParametricNode, nparams=8)
+        else:
+            all_trees = de.synth.random_population(n_per_gpu * world, seed=0xDE02)
+        my_ids = dedist.shard_indices(len(all_trees), rank, world)
+        trees = [all_trees[i] for i in my_ids]
     total_nodes = sum(de.count_nodes(t) for t in all_trees)
 
     ctx = api.Context(local_rank)
@@ -158,10 +279,14 @@ def main():
         lossv = torch.empty(len(trees), device=dev, dtype=torch.float32)
     grad = torch.empty(len(trees) * 5 * N, device=dev, dtype=torch.float32) if is_grad else None
 
+    per_sample = bool(wl.get("per_sample"))
     if is_param:
-        n_cls = 16
+        n_cls = N if per_sample else 16
         params = torch.randn((n_cls, 8), generator=g, device=dev, dtype=torch.float32)  # [P=8, C] column-major
-        classes = torch.randint(1, n_cls + 1, (N,), generator=g, device=dev, dtype=torch.int32)
+        if per_sample:  # "fully per-sample" parameters: classes = 1:N
+            classes = torch.arange(1, N + 1, device=dev, dtype=torch.int32)
+        else:
+            classes = torch.randint(1, n_cls + 1, (N,), generator=g, device=dev, dtype=torch.int32)
         by_class = bool(wl.get("by_class"))
         if by_class:  # the dataset is ordered by class once (classes belong to the dataset)
             classes = torch.sort(classes).values
@@ -180,12 +305,14 @@ def main():
         ng_c = np.array([pop.n_grad(t, 1) for t in range(len(trees))], dtype=np.int64)
         goffs = np.zeros(len(trees), dtype=np.int64)
         np.cumsum(ng_c[:-1] * N, out=goffs[1:])
-        gradc = None if wl.get("by_class") else torch.empty(max(int((ng_c * N).sum()), 1), device=dev, dtype=torch.float32)
+        gradc = None if (wl.get("by_class") or per_sample) else torch.empty(max(int((ng_c * N).sum()), 1), device=dev, dtype=torch.float32)
 
     def step():
         if is_param:
             ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, 5, pa_ref, out.data_ptr(), N, ok.data_ptr()))
-            if by_class:
+            if per_sample:
+                pass
+            elif by_class:
                 ctx.check(lib.de_eval_loss_grad_by_class(ctx._h, pop._h, X.data_ptr(), N, 5, pa_ref, 2, dY.data_ptr(), None, 2,
                                                          starts.ctypes.data, lossv.data_ptr(), dlossv.data_ptr(), None,
                                                          dparv.data_ptr(), ok.data_ptr()))
@@ -239,11 +366,14 @@ def main():
             k_eff = plan["trees_per_chunk"]
             k_avg_ms = ms_per_step
             b_unit = (F_FEATURES * ELEM / k_eff + ELEM) + (F_FEATURES * ELEM / 32 + float(ng_c.mean()) * ELEM)
-            if by_class:  # eval as above; pullback: X + class id + dY tile per chunk of 32 trees, (1 + n_grad) partials per wave
+            if per_sample:  # eval only; X + class id + the sample's 8 parameters per chunk of k_eff trees, one output
+                b_unit = ((F_FEATURES + 8) * ELEM + 4) / k_eff + ELEM
+            elif by_class:  # eval as above; pullback: X + class id + dY tile per chunk of 32 trees, (1 + n_grad) partials per wave
                 b_unit = ((F_FEATURES * ELEM + 4) / k_eff + ELEM) + ((F_FEATURES * ELEM + 4 + ELEM) / 32
                                                                      + (1 + float(ng_b.mean())) * 4 * ELEM / 256)
-        elif is_grad:  # one tree per X pass, writes x + 5 gradient rows: (F + 1 + F)*s  
-            k_eff, b_unit = 1, float((2 * F_FEATURES + 1) * ELEM)
+        elif is_grad:  # X tile staged once per chunk of 32 trees (the K-tile rule of SURVEY.md §8d), x + 5 gradient rows written
+            k_eff = 32
+            b_unit = F_FEATURES * ELEM / k_eff + (1 + F_FEATURES) * ELEM
         elif is_lossgrad:  # X (+ y) tile staged once per chunk of 32 trees; (1 + n_const) partials per wave
             k_eff = 32
             b_unit = (F_FEATURES + 1) * ELEM / k_eff + (1 + n_const / len(trees)) * 4 * ELEM / 256
@@ -253,6 +383,7 @@ def main():
         else:  # X tile staged once per chunk of trees
             k_eff = plan["trees_per_chunk"]
             b_unit = F_FEATURES * ELEM / k_eff + ELEM
+        plain_eval = not (is_param or is_grad or is_lossgrad)
         alg_bytes = b_unit * units
         achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
         single = BYTES_PER_TREE_SAMPLE_SINGLE * units / (k_avg_ms * 1e-3) / 1e9
@@ -266,7 +397,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl["desc"], "trees_per_gpu": n_per_gpu, "n_samples": N, "n_features": 5,
+            "config": {"workload": wl["desc"], "workload_key": args.workload, "trees_per_gpu": n_per_gpu, "n_samples": N, "n_features": 5,
                        "nodes_per_tree": 20, "operators": "+ - / * cos exp", "sharding": f"tree-sharded x{world}",
                        "complete_fraction": float(flags.float().mean().item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -276,6 +407,7 @@ def main():
                          "algorithmic_bytes_per_tree_sample": b_unit, "k_eff_trees_per_x_tile": k_eff,
                          "single_tree_equivalent": {"bytes_per_tree_sample": BYTES_PER_TREE_SAMPLE_SINGLE,
                                                     "achieved": single, "frac": single / HBM_PEAK_GBS},
+                         "valu": valu_ceiling(pop, len(trees), units, k_avg_ms) if plain_eval else None,
                          "note": "X tile reused by k_eff trees from LDS: HBM traffic ~= the output; the kernel is "
                                  "VALU/scalar-issue bound (DESIGN.md §Roofline)"},
         }

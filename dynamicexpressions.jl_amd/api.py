@@ -41,11 +41,11 @@ OPT_EARLY_EXIT, OPT_FUSE_DEG1, OPT_FUSE_DEG2, OPT_BUMPER_CHECKS = 1, 2, 4, 8
 
 EXPORTS = [
     "de_abi_version", "de_opcode_table_version", "de_opcode_by_name", "de_opcode_name",
-    "de_opcode_degree", "de_status_string", "de_ctx_create", "de_ctx_destroy",
+    "de_opcode_degree", "de_status_string", "de_ctx_create", "de_ctx_destroy", "de_ctx_set_stream",
     "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create",
     "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
     "de_program_n_grad", "de_program_dump", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad", "de_eval_loss_grad_by_class",
-    "de_eval_tree_array", "de_eval_plan", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
+    "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
 ]
 
 
@@ -91,6 +91,7 @@ def library() -> C.CDLL:
     lib.de_status_string.argtypes = [C.c_int]
     lib.de_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     lib.de_ctx_destroy.argtypes = [vp]
+    lib.de_ctx_set_stream.argtypes = [vp, vp]
     lib.de_ctx_synchronize.argtypes = [vp]
     lib.de_ctx_stream.restype = vp
     lib.de_ctx_stream.argtypes = [vp]
@@ -117,6 +118,7 @@ def library() -> C.CDLL:
     lib.de_eval_loss_grad_by_class.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), C.c_int, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp]
     lib.de_eval_grad.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), C.c_int, vp, i64, vp, vp, vp]
     lib.de_eval_diff.argtypes = [vp, vp, vp, i64, i64, i32, vp, vp, i64, vp]
+    lib.de_eval_pullback_dX.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), vp, vp, vp, vp]
     lib.de_eval_tree_array.argtypes = [vp, C.c_int, vp, i64, vp, i64, vp, i32, i64, u32, vp, vp]
     lib.de_eval_plan.argtypes = [vp, i64, vp]
     lib.de_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -163,7 +165,9 @@ class Context:
 
     def __init__(self, device: int = 0, stream: Optional[int] = None):
         lib = library()
+        follow = False
         if stream is None:
+            follow = True
             try:
                 import torch
                 if torch.cuda.is_available():
@@ -172,11 +176,26 @@ class Context:
             except ImportError:  # pragma: no cover
                 stream = None
         self._h = C.c_void_p()
+        self._follow_torch = follow  # launch on torch's CURRENT stream of each call (see use_torch_stream)
         rc = lib.de_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h))
         if rc != 0:
             raise DeviceError(f"de_ctx_create(device={device}) failed: {lib.de_status_string(rc).decode()} "
                               "(no MI355X visible? there is no CPU fallback)")
         self.device = device
+        self._stream = stream
+
+    def use_torch_stream(self) -> None:
+        """Called before every de_* call that takes torch tensors: inside ``with torch.cuda.stream(s):`` torch
+        allocates the outputs on ``s`` and expects the kernels there too, so the context follows torch's current
+        stream (one pointer compare when it has not changed; de_ctx_set_stream orders the new stream behind the
+        work already queued).  A context created with an explicit ``stream=`` keeps it."""
+        if not self._follow_torch:
+            return
+        import torch
+        cur = torch.cuda.current_stream(self.device).cuda_stream or -1
+        if cur != self._stream:
+            self.check(library().de_ctx_set_stream(self._h, C.c_void_p(cur)))
+            self._stream = cur
 
     def check(self, rc: int) -> None:
         if rc != 0:
@@ -312,6 +331,7 @@ class Population:
             n_features = max((max_feature(t) for t in trees), default=0)
         self.n_features, self.n_params = int(n_features), int(n_params)
         self.n_consts = np.diff(coff).astype(np.int64)
+        self._classes_checked = set()
         self._h = C.c_void_p()
         lib = library()
         self.ctx.check(lib.de_program_create(
@@ -384,26 +404,42 @@ class Population:
             if classes.dtype not in (torch.int32, torch.int64):
                 classes = classes.to(torch.int64)
             classes = classes.contiguous()
-            n_c, mx = classes.numel(), int(classes.max().item()) if classes.numel() else class_base
-            mn = int(classes.min().item()) if classes.numel() else class_base
+            n_c = classes.numel()
+            # @assert maximum(classes) <= n_classes (:378-379).  Reading min/max of a device tensor synchronises the
+            # stream, so the verdict is cached per (storage, version, shape): the hot path of a search loop — the same
+            # `classes` tensor call after call — stays asynchronous.
+            key = (classes.data_ptr(), n_c, classes._version, ncls, class_base)
+            if n_c and key not in self._classes_checked:
+                mn, mx = int(classes.min().item()), int(classes.max().item())
+                if mn < class_base or mx - class_base >= ncls:
+                    raise ValueError(f"class ids must lie in [{class_base}, {class_base + ncls}): got [{mn}, {mx}] "
+                                     "(maximum(classes) <= size(parameters, 2))")
+                if len(self._classes_checked) > 64:
+                    self._classes_checked.clear()
+                self._classes_checked.add(key)
             pa.classes, pa.classes_is_i64 = classes.data_ptr(), int(classes.dtype == torch.int64)
         else:
             classes = np.ascontiguousarray(classes)
             if classes.dtype not in (np.int32, np.int64):
                 classes = classes.astype(np.int64)
-            n_c, mx = classes.size, int(classes.max()) if classes.size else class_base
-            mn = int(classes.min()) if classes.size else class_base
+            n_c = classes.size
+            if n_c:
+                mn, mx = int(classes.min()), int(classes.max())
+                if mn < class_base or mx - class_base >= ncls:
+                    raise ValueError(f"class ids must lie in [{class_base}, {class_base + ncls}): got [{mn}, {mx}] "
+                                     "(maximum(classes) <= size(parameters, 2))")
             pa.classes, pa.classes_is_i64 = classes.ctypes.data, int(classes.dtype == np.int64)
-        # @assert length(classes) == size(X, 2); @assert maximum(classes) <= n_classes  (:378-379)
-        assert n_c == N, "length(classes) == size(X, 2)"
-        assert mx - class_base < ncls, "maximum(classes) <= size(parameters, 2)"
-        assert mn >= class_base, "class ids start at class_base"
+        # @assert length(classes) == size(X, 2)  (:378)
+        if n_c != N:
+            raise ValueError(f"length(classes) == size(X, 2) violated: {n_c} class ids for {N} samples")
         pa.n_classes, pa.class_base = ncls, class_base
         keep.extend([params, classes])
         return pa
 
     def eval(self, X, params=None, classes=None, class_base: int = 1):
         ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        if is_t:
+            self.ctx.use_torch_stream()
         if F < self.n_features:
             raise ValueError(f"X has {F} features but the trees use feature {self.n_features}")
         keep = [keep_x]
@@ -429,6 +465,8 @@ class Population:
         test/test_optim.jl:95,99).  Returns (loss[n_trees], ok[n_trees]); loss is NaN where not ok."""
         kind = {"L2": 0, "L1": 1}[loss]
         ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        if is_t:
+            self.ctx.use_torch_stream()
         if F < self.n_features:
             raise ValueError(f"X has {F} features but the trees use feature {self.n_features}")
         keep = [keep_x]
@@ -475,6 +513,8 @@ class Population:
         kind = {"L2": 0, "L1": 1, "pullback": 2}[loss]
         mode = _grad_mode(variable)
         ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        if is_t:
+            self.ctx.use_torch_stream()
         if F < self.n_features:
             raise ValueError(f"X has {F} features but the trees use feature {self.n_features}")
         keep = [keep_x]
@@ -548,6 +588,8 @@ class Population:
                 weights = None if weights is None else np.asarray(weights)[order]
             counts = np.bincount((classes - class_base).astype(np.int64), minlength=params.shape[1])
         ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        if is_t:
+            self.ctx.use_torch_stream()
         if F < self.n_features:
             raise ValueError(f"X has {F} features but the trees use feature {self.n_features}")
         keep = [keep_x]
@@ -605,6 +647,8 @@ class Population:
         packed buffer)."""
         mode = _grad_mode(variable)
         ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        if is_t:
+            self.ctx.use_torch_stream()
         if F < self.n_features:
             raise ValueError(f"X has {F} features but the trees use feature {self.n_features}")
         keep = [keep_x]
@@ -631,9 +675,44 @@ class Population:
         grads = [grad[offs[t]:offs[t + 1]].reshape((int(ng[t]), N), order="F") for t in range(self.n_trees)]
         return out, grads, ok.astype(bool)
 
+    def eval_pullback_dX(self, X, dY, params=None, classes=None, class_base: int = 1):
+        """The ``dX`` of the ChainRules pullback (``EvalPullback``, src/ChainRules.jl:56-77) for every tree:
+        ``dX[t][f, j] = d tree_t / d x_f (x_j) * dY[j]`` — ``dX_dY .* reshape(dY, 1, :)`` — NaN-filled where the
+        evaluation is incomplete (:62-64).  Returns (dX[n_trees, n_rows, N], ok); rows = (params,) features.  The
+        other half of the pullback, ``dtree``, is ``eval_loss_grad(..., loss="pullback")``."""
+        ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        if is_t:
+            self.ctx.use_torch_stream()
+        if F < self.n_features:
+            raise ValueError(f"X has {F} features but the trees use feature {self.n_features}")
+        keep = [keep_x]
+        pa = self._param_args(params, classes, class_base, N, keep)
+        lib = library()
+        G = self.n_params + self.n_features
+        if is_t:
+            import torch
+            dy = torch.as_tensor(dY, dtype=keep_x.dtype, device=keep_x.device).contiguous()
+            if dy.numel() != N:
+                raise ValueError(f"dY must have {N} entries")
+            dX = torch.empty((self.n_trees, N, G), dtype=keep_x.dtype, device=keep_x.device)
+            ok = torch.empty(self.n_trees, dtype=torch.uint8, device=keep_x.device)
+            self.ctx.check(lib.de_eval_pullback_dX(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None,
+                                                   dy.data_ptr(), dX.data_ptr(), None, ok.data_ptr()))
+            return dX.transpose(1, 2), ok.bool()
+        dy = np.ascontiguousarray(dY, dtype=self.dtype)
+        if dy.size != N:
+            raise ValueError(f"dY must have {N} entries")
+        dX = np.empty((self.n_trees, N, G), dtype=self.dtype)
+        ok = np.zeros(self.n_trees, dtype=np.uint8)
+        self.ctx.check(lib.de_eval_pullback_dX(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None,
+                                               dy.ctypes.data, dX.ctypes.data, None, ok.ctypes.data))
+        return dX.transpose(0, 2, 1), ok.astype(bool)
+
     def eval_diff(self, X, direction: int):
         """``direction`` is the 1-based feature index, as in the reference."""
         ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        if is_t:
+            self.ctx.use_torch_stream()
         lib = library()
         if is_t:
             import torch

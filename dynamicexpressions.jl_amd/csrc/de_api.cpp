@@ -341,6 +341,25 @@ int de_ctx_destroy(de_ctx_t *c) {
     return DE_OK;
 }
 
+int de_ctx_set_stream(de_ctx_t *c, void *stream) {
+    if (!c) return DE_ERR_INVALID_ARG;
+    if (!stream) return fail(c, DE_ERR_INVALID_ARG, "de_ctx_set_stream: pass a hipStream_t or DE_STREAM_NULL");
+    hipStream_t ns = stream == DE_STREAM_NULL ? nullptr : static_cast<hipStream_t>(stream);
+    if (ns == c->stream && !c->own_stream) return DE_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // the context's scratch buffers may still be in use by work queued on the old stream: order the new stream behind it
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(ns, c->ev1, 0));
+    if (c->own_stream && c->stream) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipStreamDestroy(c->stream);
+        c->own_stream = false;
+    }
+    c->stream = ns;
+    c->timed = false;
+    return DE_OK;
+}
+
 int de_ctx_synchronize(de_ctx_t *c) {
     if (!c) return DE_ERR_INVALID_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -975,12 +994,27 @@ static int stage_out(de_ctx *c, DevBuf &buf, void *user, size_t bytes, Staged *s
     return DE_OK;
 }
 
-static int check_param_args(de_ctx *c, const de_program *p, const de_param_args_t *pa) {
+static int check_param_args(de_ctx *c, const de_program *p, const de_param_args_t *pa, int64_t N) {
     if (!p->uses_params) return DE_OK;
     if (!pa || !pa->params || !pa->classes)
         return fail(c, DE_ERR_INVALID_ARG, "program has parameter leaves: params/classes required "
                                            "(reference: \"You must pass the `classes::Vector` argument\")");
     if (pa->ld_params < p->n_params || pa->n_classes <= 0) return fail(c, DE_ERR_INVALID_ARG, "bad parameter matrix shape");
+    // `@assert maximum(classes) <= size(parameters, 2)` (src/ParametricExpression.jl:378-379): checked here when the ids are
+    // host memory; ids already on the device are the caller's to check (the kernels clamp them, so a bad id cannot fault)
+    if (N > 0 && !is_device_ptr(pa->classes)) {
+        int64_t lo = pa->class_base, hi = pa->class_base;
+        if (pa->classes_is_i64) {
+            const int64_t *q = static_cast<const int64_t *>(pa->classes);
+            for (int64_t j = 0; j < N; j++) { lo = std::min(lo, q[j]); hi = std::max(hi, q[j]); }
+        } else {
+            const int32_t *q = static_cast<const int32_t *>(pa->classes);
+            for (int64_t j = 0; j < N; j++) { lo = std::min<int64_t>(lo, q[j]); hi = std::max<int64_t>(hi, q[j]); }
+        }
+        if (lo < pa->class_base || hi - pa->class_base >= pa->n_classes)
+            return fail(c, DE_ERR_OUT_OF_RANGE, "class id outside [%d, %lld): maximum(classes) <= size(parameters, 2) violated",
+                        (int)pa->class_base, (long long)(pa->class_base + pa->n_classes));
+    }
     return DE_OK;
 }
 
@@ -1016,7 +1050,7 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
                      void *out, int64_t ld_out, uint8_t *ok, const LossReq *lr) {
     if (p->ctx != c) return fail(c, DE_ERR_INVALID_ARG, "program belongs to another context");
     if (ldX < p->n_features) return fail(c, DE_ERR_INVALID_ARG, "ldX < n_features");
-    int rc = check_param_args(c, p, pa);
+    int rc = check_param_args(c, p, pa, N);
     if (rc != DE_OK) return rc;
     if (p->n_trees == 0) return DE_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1819,7 +1853,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
 // Shared body of de_eval_grad / de_eval_diff.
 static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
                      int mode, int diff_direction, void *out, int64_t ld_out, void *grad,
-                     const int64_t *grad_offsets, uint8_t *ok) {
+                     const int64_t *grad_offsets, uint8_t *ok, const void *dY = nullptr) {
     if (!c || !p) return DE_ERR_INVALID_ARG;
     if (p->ctx != c) return fail(c, DE_ERR_INVALID_ARG, "program belongs to another context");
     const bool diff = diff_direction >= 0;
@@ -1828,7 +1862,7 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
     if (!diff && mode != DE_GRAD_VARIABLE && mode != DE_GRAD_CONSTANT && mode != DE_GRAD_BOTH)
         return fail(c, DE_ERR_INVALID_ARG, "bad gradient mode");
     if (diff && diff_direction >= p->n_features) return fail(c, DE_ERR_OUT_OF_RANGE, "direction >= n_features");
-    int rc = check_param_args(c, p, pa);
+    int rc = check_param_args(c, p, pa, N);
     if (rc != DE_OK) return rc;
     if (p->n_trees == 0) return DE_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1930,8 +1964,15 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
         rc = ensure_grad_threaded(c, p, mode, ng, N, &g);
         if (rc) return rc;
     }
+    Staged sDY;
+    if (dY) {
+        rc = stage_in(c, c->sY, dY, (size_t)N * es, &sDY);
+        if (rc) return rc;
+    }
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, launch_grad(p->dtype, g, c->stream, &c->last_kernel));
+    if (dY) // the pullback's dX .* dY' (and its NaN fill) on the Jacobians just written
+        HIP_TRY(c, launch_pullback_scale(p->dtype, sGrad.dev, g.grad_off, g.n_grad, g.e.ok, sDY.dev, N, p->n_trees, maxg, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     if (out && sOut.staged)
@@ -1985,7 +2026,7 @@ static int loss_grad_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N
     if (mode != DE_GRAD_VARIABLE && mode != DE_GRAD_CONSTANT && mode != DE_GRAD_BOTH) return fail(c, DE_ERR_INVALID_ARG, "bad gradient mode");
     if (loss_kind != DE_LOSS_L2 && loss_kind != DE_LOSS_L1 && loss_kind != DE_LOSS_PULLBACK)
         return fail(c, DE_ERR_INVALID_ARG, "unknown loss_kind %d", loss_kind);
-    int rc = check_param_args(c, p, pa);
+    int rc = check_param_args(c, p, pa, N);
     if (rc != DE_OK) return rc;
     if (p->n_trees == 0) return DE_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -2299,6 +2340,12 @@ int de_eval_loss_grad_by_class(de_ctx_t *c, de_program_t *p, const void *X, int6
 int de_eval_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
                  int mode, void *out, int64_t ld_out, void *grad, const int64_t *grad_offsets, uint8_t *ok) {
     return grad_impl(c, p, X, N, ldX, pa, mode, -1, out, ld_out, grad, grad_offsets, ok);
+}
+
+int de_eval_pullback_dX(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
+                        const void *dY, void *dX, const int64_t *dX_offsets, uint8_t *ok) {
+    if (c && N > 0 && !dY) return fail(c, DE_ERR_INVALID_ARG, "null cotangent dY");
+    return grad_impl(c, p, X, N, ldX, pa, DE_GRAD_VARIABLE, -1, nullptr, N, dX, dX_offsets, ok, dY);
 }
 
 int de_eval_diff(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, int32_t direction, void *out,

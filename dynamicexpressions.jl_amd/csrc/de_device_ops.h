@@ -257,6 +257,13 @@ __device__ __forceinline__ DeF2 fast_exp_f32x2(DeF2 x) {
     return y;
 }
 
+// A class id outside [class_base, class_base + n_classes) is a caller error (the reference asserts on the host,
+// src/ParametricExpression.jl:378-379, and so do the shims); the device clamps the id so that such a call stays
+// memory-safe (the values of those samples are then those of the first / last class).
+__device__ __forceinline__ int64_t clamp_class(int64_t cl, int64_t n_classes) {
+    return cl < 0 ? 0 : (cl >= n_classes ? n_classes - 1 : cl);
+}
+
 // Julia max/min: NaN-propagating, -0 < +0.
 template <typename T> __device__ __forceinline__ T jl_max(T x, T y) {
     if (x != x) return x;

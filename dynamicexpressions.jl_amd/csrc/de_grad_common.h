@@ -29,7 +29,7 @@ template <typename T> struct GArgs {
     uint8_t *ok;
     const T *params;
     const void *classes;
-    int64_t N, ldX, ld_out, ld_params, n_tiles;
+    int64_t N, ldX, ld_out, ld_params, n_tiles, n_classes;
     int32_t F, P, n_trees, trees_per_chunk, n_chunks, n_slots, mode;
     int32_t FX; // threaded kernels: rows of X; F - FX further leaf rows hold the parameters gathered by class (0 elsewhere)
     int32_t classes_is_i64, class_base, uses_params, check;

@@ -49,8 +49,8 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
     jj0 = jj0 < last ? jj0 : last;
     int64_t cls = 0;
     if (a.uses_params)
-        cls = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj0]
-                                : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj0]) - a.class_base;
+        cls = clamp_class((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj0]
+                                            : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj0]) - a.class_base, a.n_classes);
     T yv = T(0), wv = T(0);
     if (a.loss_mode) {
         yv = a.y[jj0];
@@ -308,6 +308,7 @@ static hipError_t launch_grad_t(const GradArgs &ga, int windows, hipStream_t str
     a.mode = ga.mode;
     a.classes_is_i64 = e.classes_is_i64;
     a.class_base = e.class_base;
+    a.n_classes = e.n_classes > 0 ? e.n_classes : 1;
     a.uses_params = e.uses_params ? 1 : 0;
     a.check = ga.diff_direction >= 0 ? 0 : 1;
     a.diff_g0 = ga.diff_direction >= 0 ? ga.P + ga.diff_direction : -1;
@@ -424,6 +425,39 @@ __global__ void __launch_bounds__(256) de_by_class_combine_kernel(const ByClassA
         dloss[off + k] = ok ? (T)s : nan;
     }
 }
+// EvalPullback's `dX = dX_dY .* reshape(dY, 1, :)` (src/ChainRules.jl:74) on the Jacobians de_eval_grad just wrote:
+// tree t's [G, N] block (gradient index fastest) is scaled column j by dY[j]; an incomplete tree is NaN-filled
+// (`dX_constants_dY .= NaN`, :62-64).  blockIdx.y = tree, 16-byte accesses where the block is aligned.
+template <typename T>
+__global__ void __launch_bounds__(256) de_pullback_scale_kernel(T *__restrict__ grad, const int64_t *__restrict__ grad_off,
+                                                               const int32_t *__restrict__ n_grad, const uint8_t *__restrict__ ok,
+                                                               const T *__restrict__ dY, int64_t N) {
+    const int64_t t = blockIdx.y;
+    const uint32_t G = (uint32_t)n_grad[t];
+    if (G == 0) return;
+    T *__restrict__ g = grad + grad_off[t];
+    const bool complete = ok[t] != 0;
+    const int64_t total = (int64_t)G * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t j = e / G;
+        g[e] = complete ? g[e] * dY[j] : M<T>::nan();
+    }
+}
+hipError_t launch_pullback_scale(int dtype, void *grad, const int64_t *grad_off, const int32_t *n_grad, const uint8_t *ok,
+                                 const void *dY, int64_t N, int64_t n_trees, int32_t max_grad, hipStream_t stream) {
+    if (n_trees <= 0 || N <= 0 || max_grad <= 0) return hipSuccess;
+    int64_t bx = ((int64_t)max_grad * N + 256 * 8 - 1) / (256 * 8);
+    if (bx > 4096) bx = 4096;
+    const dim3 grid((unsigned)bx, (unsigned)n_trees);
+    if (dtype == DE_F32)
+        hipLaunchKernelGGL(de_pullback_scale_kernel<float>, grid, dim3(256), 0, stream, static_cast<float *>(grad), grad_off, n_grad, ok,
+                           static_cast<const float *>(dY), N);
+    else
+        hipLaunchKernelGGL(de_pullback_scale_kernel<double>, grid, dim3(256), 0, stream, static_cast<double *>(grad), grad_off, n_grad, ok,
+                           static_cast<const double *>(dY), N);
+    return hipGetLastError();
+}
+
 hipError_t launch_by_class_combine(int dtype, const ByClassArgs &a, hipStream_t stream) {
     const dim3 grid((unsigned)((a.n_trees + 255) / 256));
     if (dtype == DE_F32) hipLaunchKernelGGL(de_by_class_combine_kernel<float>, grid, dim3(256), 0, stream, a);

@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
             const uint32_t j = e / Pu, q = e - j * Pu;
             int64_t jj = base + j;
             jj = jj < last ? jj : last;
-            const int64_t cl = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj] : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base;
+            const int64_t cl = clamp_class((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj] : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base, a.n_classes);
             rows[((j / WSAMP) * (uint32_t)R + (uint32_t)a.FX + q) * WSAMP + (j % WSAMP)] = a.params[q + a.ld_params * cl];
         }
     }
@@ -551,6 +551,7 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStrea
     a.mode = ga.mode;
     a.classes_is_i64 = e.classes_is_i64;
     a.class_base = e.class_base;
+    a.n_classes = e.n_classes > 0 ? e.n_classes : 1;
     a.uses_params = e.uses_params ? 1 : 0;
     a.check = 1;
     a.diff_g0 = -1;

@@ -126,6 +126,9 @@ struct ByClassArgs {
     uint8_t *ok;
 };
 hipError_t launch_by_class_combine(int dtype, const ByClassArgs &a, hipStream_t stream);
+// de_eval_pullback_dX: grad[t][k, j] *= dY[j] (NaN where !ok[t]) over the Jacobians de_eval_grad wrote
+hipError_t launch_pullback_scale(int dtype, void *grad, const int64_t *grad_off, const int32_t *n_grad, const uint8_t *ok,
+                                 const void *dY, int64_t N, int64_t n_trees, int32_t max_grad, hipStream_t stream);
 
 // Threaded-code eval kernel: addresses of the TOP_COUNT device handlers (cached per process).
 hipError_t eval_handler_table(int dtype, uint64_t *table);

@@ -47,7 +47,7 @@ template <typename T> struct KArgs {
     uint8_t *ok;
     const T *params;
     const void *classes;
-    int64_t N, ldX, ld_out, ld_params, n_tiles;
+    int64_t N, ldX, ld_out, ld_params, n_tiles, n_classes;
     int32_t F, n_trees, trees_per_chunk, n_chunks, n_slots, xstride;
     int32_t classes_is_i64, class_base, vec_store;
     // fused loss (de_eval_loss): residual target, optional weights, per-wave partial sums
@@ -341,9 +341,9 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
         FOR_G FOR_I {
             int64_t jj = base + g * GT + tid * VW + i;
             jj = jj < last ? jj : last;
-            cls[g][i] = (a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
-                                          : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) -
-                        a.class_base;
+            cls[g][i] = clamp_class((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
+                                                      : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) -
+                                        a.class_base, a.n_classes);
         }
     }
     __syncthreads();
@@ -830,8 +830,9 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
         DE_UNROLL for (int i = 0; i < VW; i++) {
             int64_t jj = base + tid * VW + i;
             jj = jj < last ? jj : last;
-            cls[i] = (uint32_t)(a.ld_params * ((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
-                                                                 : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base));
+            cls[i] = (uint32_t)(a.ld_params * clamp_class((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
+                                                                             : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base,
+                                                          a.n_classes));
         }
         // a small table ([P, C] with few classes) is read once per workgroup; the interpreter then gathers from LDS
         // (a global load inside the loop costs a full memory round trip per parameter leaf)
@@ -1042,6 +1043,7 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
     a.xstride = 0;
     a.classes_is_i64 = e.classes_is_i64;
     a.class_base = e.class_base;
+    a.n_classes = e.n_classes > 0 ? e.n_classes : 1;
     a.vec_store = (reinterpret_cast<uintptr_t>(e.out) % 16 == 0 && (e.ld_out * sizeof(T)) % 16 == 0) ? 1 : 0;
 
     int32_t tpc, nch;
@@ -1133,6 +1135,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.xstride = 0;
     a.classes_is_i64 = e.classes_is_i64;
     a.class_base = e.class_base;
+    a.n_classes = e.n_classes > 0 ? e.n_classes : 1;
     a.vec_store = (reinterpret_cast<uintptr_t>(e.out) % 16 == 0 && (e.ld_out * sizeof(T)) % 16 == 0) ? 1 : 0;
     a.x_vec = (e.F >= 1 && e.ldX == e.F && reinterpret_cast<uintptr_t>(e.X) % 16 == 0 && (int64_t)TILE * e.F < 0x10000000LL) ? 1 : 0;
     a.f_magic = e.F > 1 ? (uint32_t)((0x100000000ull + (uint64_t)e.F - 1) / (uint64_t)e.F) : 0u;

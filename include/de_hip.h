@@ -133,6 +133,11 @@ const char *de_status_string(int status);
 #define DE_STREAM_NULL ((void *)(intptr_t)-1)
 int de_ctx_create(int device, void *stream, de_ctx_t **out_ctx);
 int de_ctx_destroy(de_ctx_t *ctx);
+/* Launch on another caller-owned stream (or DE_STREAM_NULL) from now on.  The new stream is ordered behind
+ * everything the context queued on the old one (its scratch buffers are shared); a stream the context created
+ * itself is drained and destroyed.  Cheap when `stream` is already the current one: shims call it before every
+ * de_* call with the caller's current stream (torch.cuda.current_stream(), AMDGPU.stream()). */
+int de_ctx_set_stream(de_ctx_t *ctx, void *stream);
 int de_ctx_synchronize(de_ctx_t *ctx);
 void *de_ctx_stream(de_ctx_t *ctx);
 const char *de_last_error(de_ctx_t *ctx); /* text of the last failure on this ctx */
@@ -274,6 +279,16 @@ int de_eval_loss_grad_by_class(de_ctx_t *ctx, de_program_t *prog, const void *X,
                                const de_param_args_t *pargs, int mode, const void *y, const void *w,
                                int32_t loss_kind, const int64_t *class_starts, void *loss, void *dloss,
                                const int64_t *dloss_offsets, void *dparams, uint8_t *ok);
+
+/* The `dX` of the ChainRules pullback of eval_tree_array (EvalPullback, src/ChainRules.jl:56-77):
+ *   dX_t[f, j] = d tree_t(x_j) / d x_f * dY[j]      (`dX = dX_dY .* reshape(dY, 1, length(dY))`, :74)
+ * for every tree: a [n_rows, N] column-major matrix per tree (rows = the VARIABLE-mode rows of de_eval_grad:
+ * (params,) features) at element offset dX_offsets[t] (host array; NULL: packed), NaN-filled where
+ * ok[t] == 0 (`dX_constants_dY .= NaN`, :62-64).  The other half of the pullback, `dtree` =
+ * sum_j dconstants[:, j] * dY[j], is de_eval_loss_grad(DE_LOSS_PULLBACK). */
+int de_eval_pullback_dX(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, int64_t ldX,
+                        const de_param_args_t *pargs, const void *dY, void *dX,
+                        const int64_t *dX_offsets, uint8_t *ok);
 
 /* ---- one-shot convenience with the reference's single-tree signature ------- */
 int de_eval_tree_array(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, int64_t n_nodes,

@@ -204,3 +204,131 @@ def _leaves_in_order(tree):
     for c in tree.children:
         res.extend(_leaves_in_order(c))
     return res
+
+
+# ---- conditioned tolerance for Jacobians -------------------------------------------------------------------------
+# float64 value / partial tables by Julia operator name (magnitudes are what matters here: the tie conventions of
+# DESIGN.md §6 live on sets of measure zero)
+def _safe(cond, f):
+    return lambda x: np.where(cond(x), f(np.where(cond(x), x, 1.0)), np.nan)
+
+
+_G1 = {
+    "cos": (np.cos, lambda x: -np.sin(x)), "sin": (np.sin, np.cos), "exp": (np.exp, np.exp),
+    "neg": (np.negative, lambda x: -np.ones_like(x)), "-": (np.negative, lambda x: -np.ones_like(x)),
+    "square": (np.square, lambda x: 2 * x), "cube": (lambda x: x ** 3, lambda x: 3 * x * x),
+    "abs": (np.abs, np.sign), "tanh": (np.tanh, lambda x: 1 - np.tanh(x) ** 2),
+    "log": (np.log, lambda x: 1 / x), "sqrt": (np.sqrt, lambda x: 0.5 / np.sqrt(x)),
+    "safe_log": (_safe(lambda x: x > 0, np.log), _safe(lambda x: x > 0, lambda x: 1 / x)),
+    "safe_sqrt": (_safe(lambda x: x >= 0, np.sqrt), _safe(lambda x: x >= 0, lambda x: 0.5 / np.sqrt(x))),
+    "relu": (lambda x: np.where(x < 0, 0.0, x), lambda x: (x > 0).astype(np.float64)),
+    "atan": (np.arctan, lambda x: 1 / (1 + x * x)),
+    "custom_cos": (lambda x: np.cos(x) ** 2, lambda x: -2 * np.cos(x) * np.sin(x)),
+}
+
+
+def _pow_abs2(x, y):
+    return np.exp(y * np.log(np.abs(x)))
+
+
+_G2 = {
+    "+": (lambda x, y: x + y, lambda x, y: (np.ones_like(x), np.ones_like(x))),
+    "-": (lambda x, y: x - y, lambda x, y: (np.ones_like(x), -np.ones_like(x))),
+    "sub": (lambda x, y: x - y, lambda x, y: (np.ones_like(x), -np.ones_like(x))),
+    "*": (lambda x, y: x * y, lambda x, y: (y, x)),
+    "/": (lambda x, y: x / y, lambda x, y: (1 / y, -x / (y * y))),
+    "max": (np.maximum, lambda x, y: ((x > y).astype(np.float64), (~(x > y)).astype(np.float64))),
+    "min": (np.minimum, lambda x, y: ((~(y < x)).astype(np.float64), (y < x).astype(np.float64))),
+    "pow_abs2": (_pow_abs2, lambda x, y: (y * _pow_abs2(x, y) / x, _pow_abs2(x, y) * np.log(np.abs(x)))),
+    "^": (np.power, lambda x, y: (y * np.power(x, y - 1), np.power(x, y) * np.log(np.where(x > 0, x, np.nan)))),
+}
+
+
+def grad_tolerance(tree, ops, X, dtype, mode, params=None, classes=None, class_base=1, draws=8, seed=0):
+    """Per-entry tolerance [n_grad, N] for comparing a device Jacobian with the oracle's — the gradient twin of
+    `parity_tolerance` (same model, SAME thresholds): the tree is differentiated in float64 by forward duals;
+      * P  = path-absolute Jacobian (sum over root-to-leaf paths of |product of partials|): the scale on which
+             the roundings of the dual arithmetic itself act (the 1e-5 / 1e-13 north-star factor applies to P);
+      * spread = how far an entry moves when every operator VALUE is perturbed by <= 1 ulp of `dtype` and every
+             PARTIAL by <= 2 ulp (they are one or two library calls each), `draws` random draws: the
+             amplification of legitimate last-bit differences between two math libraries through the curvature
+             of the tree (d/dx cos(exp(exp x)) has none of the robustness of its value).
+    tolerance = rel*P + 8*spread; entries with spread > 1e-3*P (or a non-finite clean value) are ILL-CONDITIONED:
+    +inf, not compared, and callers cap their share.  Returns None when an operator is not in the tables above."""
+    dtype = np.dtype(dtype)
+    X = np.asarray(X, dtype=np.float64)
+    F, N = X.shape
+    P_ = 0 if params is None else np.asarray(params).shape[0]
+    consts = [n for n in _leaves_in_order(tree) if n.constant]
+    ord_of = {id(n): k for k, n in enumerate(consts)}
+    G = {"variable": P_ + F, "constant": len(consts), "both": P_ + F + len(consts)}[mode]
+    eps = 2.0 ** -23 if dtype == np.float32 else 2.0 ** -52
+    rng = np.random.Generator(np.random.PCG64(seed))
+
+    def row_of(n):
+        if getattr(n, "is_parameter", False):
+            return None if mode == "constant" else n.parameter - 1
+        if n.constant:
+            return None if mode == "variable" else (ord_of[id(n)] if mode == "constant" else P_ + F + ord_of[id(n)])
+        return None if mode == "constant" else P_ + n.feature - 1
+
+    class Unsupported(Exception):
+        pass
+
+    def jitter(a, scale):
+        if scale == 0.0:
+            return a
+        step = rng.choice(np.array([-1.0, 1.0]), size=N) * rng.uniform(0.25, 1.0, size=N)
+        return a * (1.0 + scale * step)
+
+    def rec(n, noise, absolute):
+        if n.degree == 0:
+            if getattr(n, "is_parameter", False):
+                v = np.asarray(params, dtype=np.float64)[n.parameter - 1, np.asarray(classes) - class_base]
+            elif n.constant:
+                v = np.full(N, n.val)
+            else:
+                v = X[n.feature - 1]
+            d = np.zeros((G, N))
+            r = row_of(n)
+            if r is not None:
+                d[r] = 1.0
+            return v, d
+        name = ops.ops[n.degree - 1][n.op - 1]
+        kids = [rec(c, noise, absolute) for c in n.children]
+        if n.degree == 1:
+            if name not in _G1:
+                raise Unsupported(name)
+            f, g = _G1[name]
+            x, dx = kids[0]
+            p = jitter(g(x), 2 * noise)
+            return jitter(f(x), noise), (np.abs(p) if absolute else p)[None, :] * dx
+        if n.degree == 2:
+            if name not in _G2:
+                raise Unsupported(name)
+            f, g = _G2[name]
+            (x, dx), (y, dy) = kids
+            px, py = g(x, y)
+            px, py = jitter(px, 2 * noise), jitter(py, 2 * noise)
+            if absolute:
+                px, py = np.abs(px), np.abs(py)
+            return jitter(f(x, y), noise), px[None, :] * dx + py[None, :] * dy
+        raise Unsupported(name)
+
+    try:
+        with np.errstate(all="ignore"):
+            _, clean = rec(tree, 0.0, False)
+            _, pabs = rec(tree, 0.0, True)
+            spread = np.zeros((G, N))
+            for _ in range(draws):
+                _, noisy = rec(tree, eps, False)
+                d = np.abs(noisy - clean)
+                spread = np.maximum(spread, np.where(np.isfinite(d), d, np.inf))
+    except Unsupported:
+        return None
+    with np.errstate(all="ignore"):
+        rel = 1e-5 if dtype == np.float32 else 1e-13
+        floor = 1e-37 if dtype == np.float32 else 1e-300
+        tol = rel * pabs + 8.0 * spread + floor
+        ill = ~np.isfinite(clean) | ~np.isfinite(pabs) | ~(spread <= 1e-3 * pabs + floor)
+    return np.where(ill, np.inf, tol)

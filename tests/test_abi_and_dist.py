@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     lib = api.library()
     header = open(os.path.join(ROOT, "include", "de_hip.h")).read()
-    declared = set(re.findall(r"\b(de_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(de_[A-Za-z0-9_]+)\s*\(", header))
     declared -= {"de_status_t", "de_dtype_t"}
     assert declared, "no declarations found"
     for sym in sorted(declared):

@@ -48,7 +48,10 @@ def test_golden_known_answers_on_gpu(case, api):
         assert np.all(err <= tol), f"{case['name']}: max err {err.max()}"
 
 
-def compare_population(api, trees, ops, X, dtype, eval_context=None, use_torch=False, min_ok=1):
+ILL_FRACTION = {}  # label -> share of compared samples the tolerance model classed as ill-conditioned (printed, capped)
+
+
+def compare_population(api, trees, ops, X, dtype, eval_context=None, use_torch=False, min_ok=1, max_ill=0.05, label=None):
     pop = api.Population(trees, ops, dtype, n_features=X.shape[0], eval_context=eval_context)
     if use_torch:
         import torch
@@ -85,7 +88,11 @@ def compare_population(api, trees, ops, X, dtype, eval_context=None, use_torch=F
                 rel = np.nanmax(np.where(np.abs(y[m]) > 0, err / np.abs(y[m]), 0)) if m.any() else 0
             worst = max(worst, float(rel))
     assert n_ok >= min_ok
-    assert n_ill <= 0.2 * max(n_cmp, 1), f"{n_ill} of {n_cmp} samples ill-conditioned"
+    frac = n_ill / max(n_cmp, 1)
+    ILL_FRACTION[label or f"{len(trees)} trees x {X.shape[1]} {np.dtype(dtype).name}"] = frac
+    print(f"[eval parity {label or ''} {len(trees)} trees x {X.shape[1]} {np.dtype(dtype).name}] {n_cmp} samples bounded, "
+          f"{n_ill} ({100.0 * frac:.2f} %) ill-conditioned (flags/finiteness only), worst rel err {worst:.3g}")
+    assert frac <= max_ill, f"{n_ill} of {n_cmp} samples ill-conditioned (cap {max_ill})"
     pop.close()
     return n_ok, n_quirk, worst
 
@@ -125,7 +132,8 @@ def test_wide_operator_set_and_all_option_modes(api):
     X[0, 700] = np.nan
     for ec in (api.EvalContext(), api.EvalContext(early_exit=False), api.EvalContext(use_fused=False),
                api.EvalContext(bumper=True)):
-        compare_population(api, trees, ops, X, np.float32, eval_context=ec, min_ok=0)
+        # ^ / pow_abs2 / mod / round next to their discontinuities: a larger ill-conditioned share than the bench set
+        compare_population(api, trees, ops, X, np.float32, eval_context=ec, min_ok=0, max_ill=0.2, label="wide operator set")
 
 
 def test_ieee_exact_operators_are_bit_identical(api):

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import dynamicexpressions_jl_amd as de
-from helpers import case_X, case_tree, load_golden, parity_tolerance
+from helpers import case_X, case_tree, grad_tolerance, load_golden, parity_tolerance
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -59,12 +59,15 @@ def samples_per_lane(request, monkeypatch):
     return request.param
 
 
+ILL_FRACTION = {}  # (mode, dtype, N) -> share of Jacobian entries the tolerance model classed as ill-conditioned
+
+
 def grad_compare(api, trees, ops, X, dtype, mode_name, exact=False):
     variable, omode = MODES[mode_name]
     pop = api.Population(trees, ops, dtype, n_features=X.shape[0])
     out, grads, ok = pop.eval_grad(X, variable)
     n_ok = 0
-    n_ent = n_pass = 0
+    n_ent = n_ill = 0
     for t, tree in enumerate(trees):
         tape, consts = de.flatten(tree, ops, dtype)
         y, g, ok_el = oracle.eval_grad_tree_array(tape, consts, X, omode, elementwise=True)
@@ -79,18 +82,25 @@ def grad_compare(api, trees, ops, X, dtype, mode_name, exact=False):
             np.testing.assert_array_equal(np.ascontiguousarray(grads[t]).view(ui), np.ascontiguousarray(g).view(ui),
                                           err_msg=de.string_tree(tree, ops))
             continue
-        y64, g64, _ = oracle.eval_grad_tree_array(tape, consts.astype(np.float64), X.astype(np.float64), omode, True)
-        rel = 1e-4 if dtype == np.float32 else 1e-11
-        scale = np.max(np.abs(g64), axis=1, keepdims=True) if g.size else 0
-        tol = rel * np.abs(g64) + 128 * np.abs(g.astype(np.float64) - g64) + 1e-7 * rel * 1e4 * scale + 1e-300
-        okm = np.abs(grads[t].astype(np.float64) - g) <= tol
-        n_ent += okm.size
-        n_pass += int(okm.sum())
-        tolx = rel * np.abs(y64) + 128 * np.abs(y.astype(np.float64) - y64) + 1e-300
-        assert np.mean(np.abs(out[t].astype(np.float64) - y) <= tolx) > 0.99
+        # A BOUND on every entry, not a pass fraction: the conditioned model of helpers.grad_tolerance (the gradient twin
+        # of parity_tolerance); entries it classes as ill-conditioned are counted and capped below.
+        tol = grad_tolerance(tree, ops, X, dtype, mode_name)
+        assert tol is not None, f"no partial table for an operator of {de.string_tree(tree, ops)}"
+        err = np.abs(np.asarray(grads[t], dtype=np.float64) - g.astype(np.float64))
+        bad = err > tol
+        assert not bad.any(), (f"gradient entry beyond its bound [{mode_name}] tree {t}: {de.string_tree(tree, ops)} "
+                               f"worst err/tol {np.nanmax(np.where(np.isfinite(tol), err / tol, 0)):.3g}")
+        n_ent += tol.size
+        n_ill += int(np.isinf(tol).sum())
+        tolx = parity_tolerance(tree, ops, X, dtype)
+        m = np.isfinite(tolx)
+        assert np.all(np.abs(out[t].astype(np.float64) - y)[m] <= tolx[m]), de.string_tree(tree, ops)
     pop.close()
     if not exact and n_ent:
-        assert n_pass / n_ent > 0.995, f"only {n_pass}/{n_ent} gradient entries within tolerance [{mode_name}]"
+        ILL_FRACTION[(mode_name, np.dtype(dtype).name, X.shape[1])] = n_ill / n_ent
+        print(f"[grad parity {mode_name} {np.dtype(dtype).name} N={X.shape[1]}] {n_ent} entries bounded, "
+              f"{n_ill} ({100.0 * n_ill / n_ent:.2f} %) ill-conditioned (not compared)")
+        assert n_ill <= 0.05 * n_ent, f"{n_ill}/{n_ent} gradient entries ill-conditioned [{mode_name}]"
     return n_ok
 
 
@@ -219,7 +229,7 @@ def test_parametric_eval_and_constant_gradient_config_C5_shape(api):
     out, ok = pop.eval(X, params, classes)
     outg, grads, okg = pop.eval_grad(X, False, params, classes)
     outb, gradsb, okb = pop.eval_grad(X, "both", params, classes)
-    n_ok = 0
+    n_ok = n_ent = n_ill = 0
     for t, tree in enumerate(trees):
         tape, consts = de.flatten(tree, ops, np.float32)
         y, ok_el = oracle.eval_tree_array_parametric(tape, consts, X, params, classes.astype(np.int32), 1, elementwise=True)
@@ -234,13 +244,17 @@ def test_parametric_eval_and_constant_gradient_config_C5_shape(api):
             tol = parity_tolerance(tree, ops, X, np.float32, 7, params, classes - 1)
             assert np.all(np.abs(out[t].astype(np.float64) - y) <= tol), de.string_tree(tree, ops)
             assert np.mean(np.isinf(tol)) < 0.5
-        if okg_el and gg.size:
-            sc = np.max(np.abs(gg)) + 1e-30
-            assert np.mean(np.abs(grads[t] - gg) <= 1e-4 * np.abs(gg) + 1e-6 * sc) > 0.98
-        if okb_el:
-            sc = np.max(np.abs(gb)) + 1e-30
-            assert np.mean(np.abs(gradsb[t] - gb) <= 1e-4 * np.abs(gb) + 1e-6 * sc) > 0.98
+        for got, want, okm, mname in ((grads[t], gg, okg_el, "constant"), (gradsb[t], gb, okb_el, "both")):
+            if not (okm and want.size):
+                continue
+            tolg = grad_tolerance(tree, ops, X, np.float32, mname, params, classes, 1)
+            err = np.abs(np.asarray(got, dtype=np.float64) - want.astype(np.float64))
+            assert not (err > tolg).any(), f"{mname} gradient beyond its bound: {de.string_tree(tree, ops)}"
+            n_ent += tolg.size
+            n_ill += int(np.isinf(tolg).sum())
     assert n_ok > 5
+    print(f"[C5 miniature] {n_ent} gradient entries bounded, {100.0 * n_ill / max(n_ent, 1):.2f} % ill-conditioned")
+    assert n_ill <= 0.05 * n_ent
     with pytest.raises(ValueError):  # "You must pass the `classes::Vector` argument"
         pop.eval(X)
 
@@ -267,6 +281,7 @@ def test_random_population_diff_vs_oracle(api):
     X = de.synth.random_X(5, 900, seed=3)
     pop = api.Population(trees, ops, np.float32, n_features=5)
     _, grads, _ = pop.eval_grad(X, True)
+    n_ent = n_ill = 0
     for direction in (1, 3, 5):
         out, dout, ok = pop.eval_diff(X, direction)
         assert ok.all()
@@ -274,10 +289,13 @@ def test_random_population_diff_vs_oracle(api):
             np.testing.assert_array_equal(dout[t], grads[t][direction - 1])
             tape, consts = de.flatten(tree, ops, np.float32)
             yo, do, _ = oracle.eval_diff_tree_array(tape, consts, X, direction - 1)
-            m = np.isfinite(do) & np.isfinite(yo)
-            if m.any():
-                scale = np.max(np.abs(do[m])) + 1e-30
-                assert np.mean(np.abs(dout[t][m] - do[m]) <= 1e-4 * np.abs(do[m]) + 1e-6 * scale) > 0.97
+            tolg = grad_tolerance(tree, ops, X, np.float32, "variable")[direction - 1]
+            m = np.isfinite(do) & np.isfinite(yo) & np.isfinite(dout[t])
+            err = np.abs(dout[t].astype(np.float64) - do.astype(np.float64))
+            assert not (err[m] > tolg[m]).any(), de.string_tree(tree, ops)
+            n_ent += int(m.sum())
+            n_ill += int(np.isinf(tolg[m]).sum())
+    assert n_ill <= 0.05 * n_ent, f"{n_ill}/{n_ent} derivative entries ill-conditioned"
 
 
 def test_full_size_gradient_properties_config_C3(api):

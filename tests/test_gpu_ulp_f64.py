@@ -1,0 +1,209 @@
+"""north_star's Float64 criterion — "within 1 ulp" — measured per OPERATOR: every opcode of include/de_opcodes.h is
+evaluated on the device as a one-operator tree (through the public API, i.e. the shipped kernels) and compared with an
+80-bit `long double` reference (numpy longdouble: 64-bit mantissa, 11 guard bits; mpmath for gamma; exact rational
+arithmetic for fma).  The reference for a composite operator (`pow_abs2 = exp(y*log|x|)`, `custom_cos = cos(x)^2`) rounds
+the intermediate values to Float64 the way the operator's definition does (test/test_derivatives.jl:12,
+test/test_tree_construction.jl:11), so that the figure is the error of the device's last function call.
+The per-operator maxima are written to gpurun_out/ulp_f64.json (copied to profiles/ per round) and asserted against
+the bounds below: 0 for IEEE-exact operators, 1 ulp (the north-star bound) for the library functions."""
+import json
+import os
+import zlib
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+import dynamicexpressions_jl_amd as de
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LD = np.longdouble
+REPORT = {}
+
+
+@pytest.fixture(scope="module")
+def api():
+    from dynamicexpressions_jl_amd import api as _api
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    _api.library()
+    return _api
+
+
+def ulp_err(got, want_ld):
+    """|got - want| in units of the Float64 spacing at `want`."""
+    want_ld = np.asarray(want_ld, dtype=LD)
+    w64 = want_ld.astype(np.float64)
+    u = np.spacing(np.abs(w64)).astype(LD)
+    return (np.abs(got.astype(LD) - want_ld) / u).astype(np.float64)
+
+
+def grid(lo, hi, n, rng, log=False, signed=False):
+    if log:
+        x = 10.0 ** rng.uniform(np.log10(lo), np.log10(hi), n)
+        if signed:
+            x *= rng.choice([-1.0, 1.0], n)
+        return x
+    return rng.uniform(lo, hi, n)
+
+
+def _rn(x):  # round a long double to Float64 and back (an intermediate of a composite operator)
+    return np.asarray(x, dtype=LD).astype(np.float64).astype(LD)
+
+
+def _gamma_ref(x):
+    import mpmath
+    mpmath.mp.prec = 120
+    out = np.empty(x.size, dtype=LD)
+    for i, v in enumerate(x):
+        g = mpmath.gamma(mpmath.mpf(float(v)))
+        out[i] = LD(str(mpmath.nstr(g, 30)))
+    return out
+
+
+N = 40000
+# name -> (reference on long double, input sampler, bound in ulp)
+UNARY = {
+    "neg": (lambda x: -x, lambda r: grid(1e-300, 1e300, N, r, True, True), 0.0),
+    "abs": (np.abs, lambda r: grid(1e-300, 1e300, N, r, True, True), 0.0),
+    "square": (lambda x: x * x, lambda r: grid(1e-150, 1e150, N, r, True, True), 0.5),
+    "cube": (lambda x: _rn(x * x) * x, lambda r: grid(1e-100, 1e100, N, r, True, True), 0.5),
+    "relu": (lambda x: np.where(x < 0, LD(0), x), lambda r: grid(-5, 5, N, r), 0.0),
+    "sign": (np.sign, lambda r: grid(-5, 5, N, r), 0.0),
+    "round": (np.rint, lambda r: grid(-1e6, 1e6, N, r), 0.0),
+    "floor": (np.floor, lambda r: grid(-1e6, 1e6, N, r), 0.0),
+    "ceil": (np.ceil, lambda r: grid(-1e6, 1e6, N, r), 0.0),
+    "inv": (lambda x: 1 / x, lambda r: grid(1e-300, 1e300, N, r, True, True), 0.5),
+    "sqrt": (np.sqrt, lambda r: grid(1e-300, 1e300, N, r, True), 0.5),
+    "cbrt": (np.cbrt, lambda r: grid(1e-300, 1e300, N, r, True, True), 1.0),
+    "exp": (np.exp, lambda r: np.concatenate([grid(-700, 700, N, r), grid(-1, 1, N, r)]), 1.0),
+    "exp2": (np.exp2, lambda r: np.concatenate([grid(-1000, 1000, N, r), grid(-1, 1, N, r)]), 1.0),
+    "log": (np.log, lambda r: np.concatenate([grid(1e-300, 1e300, N, r, True), grid(0.5, 2, N, r)]), 1.0),
+    "log2": (np.log2, lambda r: np.concatenate([grid(1e-300, 1e300, N, r, True), grid(0.5, 2, N, r)]), 1.0),
+    "log10": (np.log10, lambda r: np.concatenate([grid(1e-300, 1e300, N, r, True), grid(0.5, 2, N, r)]), 1.0),
+    "log1p": (np.log1p, lambda r: np.concatenate([grid(-0.99, 10, N, r), grid(1e-20, 1e20, N, r, True)]), 1.0),
+    "sin": (np.sin, lambda r: np.concatenate([grid(-10, 10, N, r), grid(-1e6, 1e6, N, r)]), 1.0),
+    "cos": (np.cos, lambda r: np.concatenate([grid(-10, 10, N, r), grid(-1e6, 1e6, N, r)]), 1.0),
+    "tan": (np.tan, lambda r: np.concatenate([grid(-10, 10, N, r), grid(-1e4, 1e4, N, r)]), 1.0),
+    "sinh": (np.sinh, lambda r: np.concatenate([grid(-700, 700, N, r), grid(-1, 1, N, r)]), 1.0),
+    "cosh": (np.cosh, lambda r: grid(-700, 700, N, r), 1.0),
+    "tanh": (np.tanh, lambda r: np.concatenate([grid(-20, 20, N, r), grid(-1e-3, 1e-3, N, r)]), 1.0),
+    "asin": (np.arcsin, lambda r: grid(-1, 1, N, r), 1.0),
+    "acos": (np.arccos, lambda r: grid(-1, 1, N, r), 1.0),
+    "atan": (np.arctan, lambda r: np.concatenate([grid(-10, 10, N, r), grid(1e-10, 1e10, N, r, True, True)]), 1.0),
+    "asinh": (np.arcsinh, lambda r: np.concatenate([grid(-10, 10, N, r), grid(1e-10, 1e100, N, r, True, True)]), 1.0),
+    "acosh": (np.arccosh, lambda r: np.concatenate([grid(1, 10, N, r), grid(1, 1e100, N, r, True)]), 1.0),
+    "atanh": (np.arctanh, lambda r: grid(-0.999, 0.999, N, r), 1.0),
+    "safe_log": (np.log, lambda r: grid(1e-300, 1e300, N, r, True), 1.0),
+    "safe_log2": (np.log2, lambda r: grid(1e-300, 1e300, N, r, True), 1.0),
+    "safe_log10": (np.log10, lambda r: grid(1e-300, 1e300, N, r, True), 1.0),
+    "safe_log1p": (np.log1p, lambda r: grid(-0.99, 1e10, N, r), 1.0),
+    "safe_sqrt": (np.sqrt, lambda r: grid(1e-300, 1e300, N, r, True), 0.5),
+    "safe_acosh": (np.arccosh, lambda r: grid(1, 1e10, N, r), 1.0),
+    "custom_cos": (lambda x: _rn(np.cos(x)) * _rn(np.cos(x)), lambda r: grid(-10, 10, N, r), 1.5),
+    "gamma": (_gamma_ref, lambda r: np.concatenate([grid(0.05, 30, 400, r), grid(-5.9, -0.1, 200, r)]), 1.0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(UNARY))
+def test_unary_operator_ulp_f64(api, name):
+    ref, sampler, bound = UNARY[name]
+    rng = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode())))
+    x = np.asarray(sampler(rng), dtype=np.float64)
+    ops = de.OperatorEnum(binary_operators=("+",), unary_operators=(name,))
+    out, _ = api.eval_tree_array(de.Node(1, de.Node(feature=1)), np.asfortranarray(x[None, :]), ops,
+                                 eval_context=api.EvalContext(early_exit=False))
+    with np.errstate(all="ignore"):
+        want = ref(x.astype(LD))
+    w64 = want.astype(np.float64)
+    m = np.isfinite(w64) & ((np.abs(w64) >= np.finfo(np.float64).tiny) | (w64 == 0))
+    assert m.sum() > 0.5 * x.size
+    assert np.all(np.isfinite(out[m]))
+    zero = w64[m] == 0
+    e = np.where(zero, (out[m] != 0).astype(np.float64), ulp_err(out[m], np.where(zero, LD(1), want[m])))
+    REPORT[name] = dict(max_ulp=float(e.max()), mean_ulp=float(e.mean()), points=int(m.sum()), at=float(x[m][np.argmax(e)]), bound=bound)
+    # bound = admissible distance from the TRUE value: 0 exact, 0.5 correctly rounded (+2^-9 for the reference's own
+    # rounding to 64 mantissa bits), 1 = north_star's "within 1 ulp" for library functions
+    lim = bound + (2.0 ** -9 if bound > 0 else 0.0)
+    assert e.max() <= lim, f"{name}: max {e.max():.3f} ulp at x = {x[m][np.argmax(e)]!r} (bound {bound} ulp)"
+
+
+def _pow_abs2_ref(x, y):
+    l = _rn(np.log(np.abs(x)))
+    return np.exp(_rn(y * l))
+
+
+def _jl_mod(x, y):
+    r = np.fmod(x, y)
+    return np.where(r == 0, np.copysign(r, y), np.where((r > 0) != (y > 0), r + y, r))
+
+
+BINARY = {
+    "+": (lambda x, y: x + y, 0.5), "-": (lambda x, y: x - y, 0.5), "*": (lambda x, y: x * y, 0.5),
+    "/": (lambda x, y: x / y, 0.5), "^": (np.power, 1.0), "max": (np.maximum, 0.0), "min": (np.minimum, 0.0),
+    "mod": (_jl_mod, 0.5), "rem": (np.fmod, 0.0), "greater": (lambda x, y: (x > y).astype(LD), 0.0),
+    "pow_abs2": (_pow_abs2_ref, 1.0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BINARY))
+def test_binary_operator_ulp_f64(api, name):
+    ref, bound = BINARY[name]
+    rng = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode()) + 2))
+    if name in ("^", "pow_abs2"):
+        x = np.concatenate([grid(1e-3, 1e3, N, rng, True), grid(0.5, 2, N, rng)])
+        y = np.concatenate([grid(-30, 30, N, rng), grid(-300, 300, N, rng)])
+    elif name in ("mod", "rem"):
+        x = grid(-1e6, 1e6, N, rng)
+        y = grid(1e-2, 1e3, N, rng, True, True)
+    else:
+        x = grid(1e-100, 1e100, N, rng, True, True)
+        y = grid(1e-100, 1e100, N, rng, True, True)
+        if name in ("+", "-"):
+            y[: N // 2] = x[: N // 2] * rng.uniform(0.5, 2.0, N // 2) * rng.choice([-1, 1], N // 2)  # cancellation
+    ops = de.OperatorEnum(binary_operators=(name,))
+    X = np.asfortranarray(np.stack([x, y]).astype(np.float64))
+    out, _ = api.eval_tree_array(de.Node(1, de.Node(feature=1), de.Node(feature=2)), X, ops,
+                                 eval_context=api.EvalContext(early_exit=False))
+    with np.errstate(all="ignore"):
+        want = ref(X[0].astype(LD), X[1].astype(LD))
+    w64 = want.astype(np.float64)
+    m = np.isfinite(w64) & ((np.abs(w64) >= np.finfo(np.float64).tiny) | (w64 == 0))
+    assert m.sum() > 0.5 * x.size
+    e = np.where(w64[m] == 0, (out[m] != 0).astype(np.float64), ulp_err(out[m], np.where(w64[m] == 0, LD(1), want[m])))
+    REPORT[name + "(2)"] = dict(max_ulp=float(e.max()), mean_ulp=float(e.mean()), points=int(m.sum()), bound=bound)
+    lim = bound + (2.0 ** -9 if bound > 0 else 0.0)
+    assert e.max() <= lim, f"{name}: max {e.max():.4f} ulp (bound {bound} ulp)"
+
+
+def test_ternary_operators_exact_f64(api):
+    rng = np.random.Generator(np.random.PCG64(77))
+    n = 300
+    x, y, z = (grid(1e-5, 1e5, n, rng, True, True) for _ in range(3))
+    z[:100] = -(x[:100] * y[:100]) * (1 + rng.uniform(-1e-15, 1e-15, 100))  # fma: cancellation exposes a double rounding
+    X = np.asfortranarray(np.stack([x, y, z]))
+    ops = de.OperatorEnum(ternary_operators=("fma", "clamp", "+", "max"))
+    leaves = [de.Node(feature=i) for i in (1, 2, 3)]
+    want = {
+        "fma": np.array([float(Fraction(a) * Fraction(b) + Fraction(c)) for a, b, c in zip(x, y, z)]),
+        "clamp": np.where(x > z, z, np.where(x < y, y, x)),
+        "+": (x + y) + z,
+        "max": np.maximum(np.maximum(x, y), z),
+    }
+    for k, name in enumerate(("fma", "clamp", "+", "max"), start=1):
+        out, _ = api.eval_tree_array(de.Node(k, *[l.copy() for l in leaves]), X, ops, eval_context=api.EvalContext(early_exit=False))
+        np.testing.assert_array_equal(out, want[name], err_msg=name)
+        REPORT[name + "(3)"] = dict(max_ulp=0.0, points=n, bound=0.0)
+
+
+def test_zz_write_ulp_report():
+    """Runs last in this module: the per-operator figures for profiles/."""
+    assert len(REPORT) >= 40
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "ulp_f64.json"), "w") as fh:
+        json.dump(dict(what="max |device - long double reference| per operator, Float64, in ulps of Float64 "
+                            "(tests/test_gpu_ulp_f64.py); includes the 0.5 ulp of rounding the reference to Float64",
+                       operators=REPORT), fh, indent=1, sort_keys=True)
+    worst = max(REPORT.items(), key=lambda kv: kv[1]["max_ulp"])
+    print(f"[f64 ulp] {len(REPORT)} operators, worst {worst[0]}: {worst[1]['max_ulp']:.3f} ulp")

@@ -2,6 +2,7 @@
 call) and the reference-dispatch annotation that decides the `ok` flag.  The lowered program is
 executed by tests/prog_interp.py (a numpy model of the device machine) and compared with the
 oracle — values AND flags — on the golden cases and on seeded random trees."""
+import os
 import numpy as np
 import pytest
 
@@ -10,6 +11,8 @@ from dynamicexpressions_jl_amd import api
 from helpers import case_X, case_options, case_tree, load_golden, value_tolerance
 from oracle import oracle
 import prog_interp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CASES = [c for c in load_golden() if c["kind"] in ("eval", "flag", "param")]
 
@@ -248,3 +251,33 @@ def test_shared_subtrees_are_evaluated_like_their_expansion():
     c = np.cos(X[0] * 0.75)
     assert ok
     np.testing.assert_allclose(y, c + c * c, rtol=1e-15)
+
+
+def test_valu_slot_table_layout():
+    """tools/valu_slots.py restates the handler-id layout of csrc/de_bind.h in Python to name the handler functions in
+    the disassembly; every id the fused (stage 3) program of the bench population dispatches must resolve to a handler of
+    the shipped code object with a VALU slot count, and the committed table must agree with the current build."""
+    import importlib.util
+    import json
+    obj = os.path.join(ROOT, "dynamicexpressions.jl_amd", "csrc", "_obj", "irp_de_kernels", "k.out")
+    if not os.path.exists(obj):
+        pytest.skip("device code object not built here (csrc/_obj is a build artefact)")
+    spec = importlib.util.spec_from_file_location("valu_slots", os.path.join(ROOT, "tools", "valu_slots.py"))
+    vs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(vs)
+    slots, counts = vs.table(obj, "float")
+    assert len(slots) == counts["TOPX_COUNT"]  # every id has a function in the code object
+    ops = de.synth.BENCH_OPERATORS
+    used = set()
+    for tree in de.synth.random_population(300, seed=0xDE02):
+        tape, consts = de.flatten(tree, ops, np.float32)
+        w = api.lower_tape_stage(tape, consts, 5, 3)
+        used.update(int(v) for v in w[:, 0])
+    assert used and all(u in slots for u in used)
+    assert slots[5]["valu_slots"] == 2  # acc + row: two v_pk_add_f32
+    committed = os.path.join(ROOT, "profiles", "valu_slots.json")
+    if os.path.exists(committed):
+        with open(committed) as fh:
+            tab = json.load(fh)["handlers"]
+        stale = [k for k in used if tab.get(str(k), {}).get("valu_slots") != slots[k]["valu_slots"]]
+        assert not stale, f"profiles/valu_slots.json is stale for handlers {stale}: rerun tools/valu_slots.py"

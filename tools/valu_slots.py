@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""VALU issue slots of every handler of the threaded eval kernel, from the gfx950 ISA.
+
+    python tools/valu_slots.py [--dtype f32] [--obj <device ELF>] [-o profiles/valu_slots.json]
+
+The eval kernel is VALU-issue bound, so the binding ceiling of a launch is
+    sum over the dispatched handlers of their VALU issue slots  x 4 cycles (wave64 on a SIMD16)
+per wavefront.  This tool disassembles the device code object build.sh links for de_kernels.hip
+(csrc/_obj/irp_de_kernels/k.out), splits it per handler function and reports, per handler id of
+csrc/de_bind.h, the VALU slots on the SHORTEST path from the function entry to its return
+(`s_setpc_b64`): handlers keep their rare cases (division outside [2^-40, 2^40], |x| > 1e5 for
+cos/sin, the extremum select) behind wave-uniform branches, and the shortest path is the one a
+wavefront of ordinary data takes.  Quarter-rate transcendental instructions (v_rcp/v_exp/v_log/
+v_sqrt/v_rsq/v_sin/v_cos_f32) count 4 slots, every other v_* instruction 1 (v_pk_* = one slot
+for two elements).  bench.py multiplies the table with the dispatch histogram of the population
+(`roofline.valu`); no GPU is needed to produce it.
+"""
+import argparse
+import heapq
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = os.environ.get("LLVM", "/opt/rocm/lib/llvm/bin")
+TRANS = ("v_rcp_f32", "v_exp_f32", "v_log_f32", "v_sqrt_f32", "v_rsq_f32", "v_sin_f32", "v_cos_f32",
+         "v_rcp_iflag_f32", "v_rcp_f64", "v_rsq_f64", "v_sqrt_f64")
+
+
+def weight(mn: str) -> int:
+    if not mn.startswith("v_"):
+        return 0
+    return 4 if any(mn.startswith(t) for t in TRANS) else 1
+
+
+def functions(obj):
+    """{demangled name: [(addr, mnemonic, operands, branch target or None)]}"""
+    txt = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--demangle", obj], check=True,
+                         capture_output=True, text=True).stdout
+    out, cur = {}, None
+    head = re.compile(r"^([0-9a-f]+) <(.*)>:$")
+    ins = re.compile(r"^\s+(\S+)\s*(.*?)\s*// ([0-9A-F]+):")
+    for line in txt.splitlines():
+        m = head.match(line)
+        if m:
+            cur = out.setdefault(m.group(2), [])
+            continue
+        m = ins.match(line)
+        if m and cur is not None:
+            mn, ops, addr = m.group(1), m.group(2), int(m.group(3), 16)
+            tgt = None
+            if mn.startswith("s_cbranch") or mn == "s_branch":
+                off = int(ops.split()[0])
+                if off >= 32768:
+                    off -= 65536
+                tgt = addr + 4 + 4 * off
+            cur.append((addr, mn, ops, tgt))
+    return out
+
+
+def shortest_slots(code):
+    """(VALU slots, VALU instructions, all instructions) on the cheapest entry -> return path."""
+    idx = {a: i for i, (a, _, _, _) in enumerate(code)}
+    dist = {0: (0, 0, 0)}
+    heap = [(0, 0, 0, 0)]
+    while heap:
+        d, nv, ni, i = heapq.heappop(heap)
+        if dist.get(i, (1 << 60,))[0] < d:
+            continue
+        _, mn, _, tgt = code[i]
+        if mn.startswith("s_setpc") or mn == "s_endpgm":
+            return d, nv, ni
+        w = weight(mn)
+        nxt = []
+        if mn != "s_branch" and i + 1 < len(code):
+            nxt.append(i + 1)
+        if tgt is not None and tgt in idx:
+            nxt.append(idx[tgt])
+        for j in nxt:
+            c = (d + w, nv + (1 if w else 0), ni + 1)
+            if j not in dist or c[0] < dist[j][0]:
+                dist[j] = c
+                heapq.heappush(heap, (c[0], c[1], c[2], j))
+    return None
+
+
+def handler_names(ty: str):
+    """handler id -> template instantiation, restating the id layout of csrc/de_bind.h (checked against
+    TOPX_COUNT through de_lower_tape_stage's ids by tests/test_lowering.py::test_valu_slot_table_layout)."""
+    b = lambda v: "true" if v else "false"  # noqa: E731
+    names = {}
+    names[0] = f"h_load_row<{ty}>"
+    names[1] = f"h_load_const<{ty}>"
+    names[2] = f"h_push<{ty}>"
+    names[3] = f"h_check_row<{ty}>"
+    names[4] = f"h_check_acc<{ty}>"
+    BIN_BASE = 5
+    for k in range(6):
+        for v in range(4):
+            names[BIN_BASE + 4 * k + v] = f"h_bin<{ty}, {k}, {v}>"
+    UN_BASE = BIN_BASE + 24
+    for k in range(3):
+        for v in range(4):
+            names[UN_BASE + 4 * k + v] = f"h_un<{ty}, {k}, {v}>"
+    GEN = UN_BASE + 12
+    names[GEN + 0] = f"h_gen<{ty}, 0, false>"
+    names[GEN + 1] = f"h_gen<{ty}, 1, false>"
+    names[GEN + 2] = f"h_gen<{ty}, 2, false>"
+    names[GEN + 3] = f"h_nop<{ty}>"
+    names[GEN + 4] = f"h_tern<{ty}>"
+    names[GEN + 5] = f"h_gen<{ty}, 2, true>"
+    names[GEN + 6] = f"h_gen<{ty}, 0, true>"
+    BOP_COUNT = GEN + 7
+    LOADROW = BOP_COUNT
+    for p in (0, 1):
+        for c in (0, 1):
+            names[LOADROW + 2 * p + c] = f"h_loadrow_f<{ty}, {b(p)}, {b(c)}>" if (p or c) else f"h_load_row<{ty}>"
+    LCP = LOADROW + 4
+    names[LCP] = f"h_loadconst_push<{ty}>"
+    UNROW = LCP + 1
+    for k in range(3):
+        for o in (0, 1):
+            for p in (0, 1):
+                for c in (0, 1):
+                    names[UNROW + ((k * 2 + o) * 2 + p) * 2 + c] = f"h_unrow_f<{ty}, {k}, {b(o)}, {b(p)}, {b(c)}>"
+    BINROWC = UNROW + 24
+    for k in range(6):
+        for o in (0, 1):
+            names[BINROWC + k * 2 + o] = f"h_binrowc<{ty}, {k}, {b(o)}>"
+    BIN2 = BINROWC + 12
+    for k in range(6):
+        for cst in (0, 1):
+            for o in (0, 1):
+                for p in (0, 1):
+                    names[BIN2 + ((k * 2 + cst) * 2 + o) * 2 + p] = f"h_bin2<{ty}, {k}, {b(cst)}, {b(o)}, {b(p)}>"
+    TOP_COUNT = BIN2 + 48
+    for k in range(3, 13):
+        for s in (0, 1):
+            names[TOP_COUNT + (k - 3) * 2 + s] = f"h_un2<{ty}, {k}, {s}>"
+    XB = TOP_COUNT + 20
+    for i, (k, s) in enumerate(((6, 0), (6, 1), (7, 0), (7, 1))):
+        names[XB + i] = f"h_bin2<{ty}, {k}, {s}>"
+    return names, dict(BOP_COUNT=BOP_COUNT, TOP_COUNT=TOP_COUNT, TOPX_COUNT=XB + 4)
+
+
+def table(obj, ty="float"):
+    fns = functions(obj)
+    by_short = {}
+    for full, code in fns.items():
+        m = re.search(r"de::(h_\w+<[^(]*>)\(", full)
+        if m:
+            by_short[m.group(1)] = code
+    names, counts = handler_names(ty)
+    slots = {}
+    for hid, nm in names.items():
+        code = by_short.get(nm)
+        if code is None:
+            continue
+        r = shortest_slots(code)
+        if r is None:
+            continue
+        slots[hid] = dict(name=nm, valu_slots=r[0], valu_insts=r[1], insts=r[2])
+    return slots, counts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--obj", default=os.path.join(ROOT, "dynamicexpressions.jl_amd", "csrc", "_obj", "irp_de_kernels", "k.out"))
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("-o", "--out", default=os.path.join(ROOT, "profiles", "valu_slots.json"))
+    a = ap.parse_args()
+    slots, counts = table(a.obj, "float" if a.dtype == "f32" else "double")
+    doc = dict(source=f"tools/valu_slots.py over {os.path.relpath(a.obj, ROOT)} (llvm-objdump of the gfx950 code object)",
+               rule="VALU issue slots on the shortest entry->return path; quarter-rate transcendentals count 4",
+               dispatch_overhead_valu=2,  # v_add (LDS address) + v_mov (immediate) before s_swappc in the interpreter loop
+               per_tree_overhead_valu=8,  # state zeroing + output address + ballot compare around the loop
+               layout=counts, handlers={str(k): v for k, v in sorted(slots.items())})
+    with open(a.out, "w") as fh:
+        json.dump(doc, fh, indent=1)
+    print(f"{len(slots)} handlers -> {a.out}")
+    for k in sorted(slots)[:0]:
+        print(k, slots[k])
+
+
+if __name__ == "__main__":
+    sys.exit(main())
