@@ -143,7 +143,7 @@ def cpu_baseline(trees, ops, X_host, budget_s=11.0, budget_1t_s=7.0):
                 julia_probe=julia_probe())
 
 
-def valu_ceiling(pop, n_trees, units, kernel_ms, dtype_tag="f32"):
+def valu_ceiling(pop, n_trees, units, kernel_ms, turbo=False):
     """The binding ceiling of the eval kernel (SURVEY.md §8d "secondary ceiling"): VALU issue slots per
     tree-wavefront = the fused program's dispatch histogram x the ISA slot count of every handler
     (profiles/valu_slots.json, generated by tools/valu_slots.py from the shipped code object)."""
@@ -168,7 +168,7 @@ def valu_ceiling(pop, n_trees, units, kernel_ms, dtype_tag="f32"):
             hist[int(k)] = hist.get(int(k), 0) + int(c)
     slots, missing = 0.0, 0
     for k, c in hist.items():
-        h = tab["handlers"].get(str(k))
+        h = tab["handlers_turbo" if turbo else "handlers"].get(str(k))
         if h is None:
             missing += c
             continue
@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--turbo", action="store_true",
+                    help="EvalContext(turbo=true): the relaxed-accuracy Float32 operators (DE_OPT_TURBO) for the whole run; "
+                         "without it the plain-eval workloads time the exact mode and report turbo in a `turbo` sub-object")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -262,7 +265,8 @@ def main():
     total_nodes = sum(de.count_nodes(t) for t in all_trees)
 
     ctx = api.Context(local_rank)
-    pop = api.Population(trees, ops, np.float32, n_features=5, n_params=8 if is_param else 0, ctx=ctx)
+    ec = api.EvalContext(turbo=True) if args.turbo else None
+    pop = api.Population(trees, ops, np.float32, n_features=5, n_params=8 if is_param else 0, eval_context=ec, ctx=ctx)
     g = torch.Generator(device=dev).manual_seed(1)  # same X on every rank (replicated)
     X = torch.randn((N, 5), generator=g, device=dev, dtype=torch.float32).t()  # [5, N] feature-fastest
     out = None if (wl.get("loss") or wl.get("lossgrad")) else torch.empty((len(trees), N), device=dev, dtype=torch.float32)
@@ -355,6 +359,31 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    turbo_res = None
+    if not args.turbo and not (is_param or is_grad or is_lossgrad or is_loss):
+        # the same steps with the reference's turbo option (DE_OPT_TURBO), reported beside the exact-mode line
+        pop_t = api.Population(trees, ops, np.float32, n_features=5, eval_context=api.EvalContext(turbo=True), ctx=ctx)
+
+        def step_t():
+            ctx.check(lib.de_eval(ctx._h, pop_t._h, X.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
+        for _ in range(args.warmup):
+            step_t()
+        barrier()
+        t0t = time.perf_counter()
+        kt = []
+        for _ in range(args.steps):
+            step_t()
+            kt.append(ctx.last_kernel_ms() if args.steps <= 64 else None)
+        barrier()
+        el_t = time.perf_counter() - t0t
+        if world > 1:
+            tt = torch.tensor([el_t], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            el_t = float(tt.item())
+        kt = [k for k in kt if k is not None]
+        turbo_res = dict(ms_per_step=1e3 * el_t / args.steps, kernel_ms_avg=float(np.mean(kt)) if kt else 1e3 * el_t / args.steps,
+                         complete_fraction=float(ok.float().mean().item()), pop=pop_t)
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_nodes * N * args.steps / elapsed
@@ -411,6 +440,17 @@ def main():
                          "note": "X tile reused by k_eff trees from LDS: HBM traffic ~= the output; the kernel is "
                                  "VALU/scalar-issue bound (DESIGN.md §Roofline)"},
         }
+        res["config"]["turbo"] = bool(args.turbo)
+        if args.turbo and plain_eval:
+            res["roofline"]["valu"] = valu_ceiling(pop, len(trees), units, k_avg_ms, turbo=True)
+        if turbo_res is not None:
+            tk = turbo_res["kernel_ms_avg"]
+            res["turbo"] = {"option": "EvalContext(turbo=true) = DE_OPT_TURBO: relaxed-accuracy Float32 / exp cos sin (<= 1e-6 rel; "
+                                      "tests/test_gpu_turbo.py), same population, same steps",
+                            "ms_per_step": turbo_res["ms_per_step"], "value": total_nodes * N / (turbo_res["ms_per_step"] * 1e-3),
+                            "kernel_ms_avg": tk, "roofline_frac": alg_bytes / (tk * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "complete_fraction": turbo_res["complete_fraction"],
+                            "valu": valu_ceiling(turbo_res["pop"], len(trees), units, tk, turbo=True)}
         if not args.no_cpu_baseline and world == 1 and not is_param:  # reported at N=1 only (rank 0)
             Ns = min(N, 10**6)
             Xh = np.asfortranarray(X[:, :Ns].t().contiguous().cpu().numpy().T)

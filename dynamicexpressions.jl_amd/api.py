@@ -37,7 +37,7 @@ LIB_PATH = os.environ.get("DE_HIP_LIB") or os.path.join(_HERE, "csrc", "libde_hi
 
 DE_F32, DE_F64 = 0, 1
 GRAD_VARIABLE, GRAD_CONSTANT, GRAD_BOTH = 0, 1, 2
-OPT_EARLY_EXIT, OPT_FUSE_DEG1, OPT_FUSE_DEG2, OPT_BUMPER_CHECKS = 1, 2, 4, 8
+OPT_EARLY_EXIT, OPT_FUSE_DEG1, OPT_FUSE_DEG2, OPT_BUMPER_CHECKS, OPT_TURBO = 1, 2, 4, 8, 16
 
 EXPORTS = [
     "de_abi_version", "de_opcode_table_version", "de_opcode_by_name", "de_opcode_name",
@@ -143,8 +143,9 @@ def _dtype_code(dtype) -> int:
 class EvalContext:
     """``EvalContext(; turbo, bumper, early_exit, buffer, use_fused)`` (src/Evaluate.jl:156-181).
 
-    ``turbo`` (LoopVectorization) and ``buffer`` (ArrayBuffer arena) choose CPU back-end
-    details that have no device meaning and are accepted for signature compatibility;
+    ``turbo=True`` (the LoopVectorization path of the reference) selects the relaxed-accuracy Float32 operators
+    (``DE_OPT_TURBO``: <= 1e-6 relative, documented domain edges; Float64 and the gradient entry points run the exact
+    operators); ``buffer`` (ArrayBuffer arena) is a CPU allocation detail, accepted for signature compatibility;
     ``bumper=True`` selects the Bumper path's flag semantics."""
     turbo: bool = False
     bumper: bool = False
@@ -155,7 +156,7 @@ class EvalContext:
     def option_bits(self, operators: OperatorEnum) -> int:
         f1, f2 = operators.fuse_flags(self.use_fused)
         return ((OPT_EARLY_EXIT if self.early_exit else 0) | (OPT_FUSE_DEG1 if f1 else 0) |
-                (OPT_FUSE_DEG2 if f2 else 0) | (OPT_BUMPER_CHECKS if self.bumper else 0))
+                (OPT_FUSE_DEG2 if f2 else 0) | (OPT_BUMPER_CHECKS if self.bumper else 0) | (OPT_TURBO if self.turbo else 0))
 
 
 class Context:

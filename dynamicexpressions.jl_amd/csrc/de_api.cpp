@@ -412,7 +412,7 @@ static int make_threaded(de_ctx *c, de_program *p) {
     if (p->direct || !eval_uses_threaded()) return DE_OK;
     if ((int64_t)p->n_features + p->n_slots > 4000) return DE_OK; // row offsets must fit 24 bits
     uint64_t table[TOPX_COUNT];
-    hipError_t st = eval_handler_table(p->dtype, table);
+    hipError_t st = eval_handler_table(p->dtype, (p->options & DE_OPT_TURBO) != 0, table);
     if (st != hipSuccess) return fail(c, DE_ERR_HIP, "handler table: %s", hipGetErrorString(st));
     uint64_t base = table[0];
     for (int i = 0; i < (int)TOPX_COUNT; i++) base = std::min<uint64_t>(base, table[i]);
@@ -1142,6 +1142,7 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
         a.class_base = pa->class_base;
     }
     a.early_exit = (p->options & DE_OPT_EARLY_EXIT) != 0;
+    a.turbo = (p->options & DE_OPT_TURBO) != 0;
     a.threaded = p->threaded && !direct;
     a.direct = direct;
     a.handler_base = p->handler_base;

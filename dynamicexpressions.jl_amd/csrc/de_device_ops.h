@@ -257,6 +257,58 @@ __device__ __forceinline__ DeF2 fast_exp_f32x2(DeF2 x) {
     return y;
 }
 
+// ---- DE_OPT_TURBO: relaxed-accuracy Float32 operators (the reference's `turbo` = LoopVectorization/SLEEF path,
+// ext/DynamicExpressionsLoopVectorizationExt.jl:24-43, whose results drift from Base's by design,
+// test/test_supposition_consistency.jl:106-108).  Contract: <= 1e-6 relative on ordinary arguments — an order of
+// magnitude inside north_star's 1e-5 — with these documented domain edges, all far from symbolic-regression data:
+//   cos/sin : two-term pi (48 bits): absolute error <= 2e-7 up to |x| = 1e7 (the relative error next to a zero of the
+//             function grows as |x| * 1e-15 / distance); beyond 1e7, and for Inf, the OCML path under a wave-uniform
+//             branch as in the exact mode (cos(exp(exp(x))) is common in random trees, and a value outside [-1, 1]
+//             would change flags downstream); no exact-extremum select (cos(0) may be 1 - 2^-24, so `x ^ cos(0)`
+//             with x < 0 is NaN).
+//   exp     : results below 2^-126 flush to 0 (v_exp_f32 has no denormal results); an overflowing result is Inf or NaN
+//             (non-finite either way) and exp(-Inf) is NaN instead of 0 — visible only with early_exit=false, the
+//             argument of exp is validity-tested otherwise.
+//   /       : x * v_rcp_f32(y), <= 1.5 ulp; |y| < 2^-126 divides like 0 and |y| >= 2^126 like Inf (v_rcp_f32 flushes
+//             denormal inputs and results).
+// Flags: identical to the exact mode except through those edges (a value that is Inf/NaN/0 only in one mode).
+constexpr float DE_TURBO_TRIG_BOUND = 1.0e7f; // the magic-number rounding needs |x / pi| < 2^22
+#define DE_TURBO_S0 -0x1.55554ap-3f
+#define DE_TURBO_S1 0x1.110ea6p-7f
+#define DE_TURBO_S2 -0x1.9f6716p-13f
+#define DE_TURBO_S3 0x1.5d3a4ep-19f
+template <bool SIN> __device__ __forceinline__ DeF2 turbo_trig_f32x2(DeF2 x) {
+    const DeF2 t = SIN ? x * DE_F2(DE_TRIG_INV_PI) : __builtin_elementwise_fma(x, DE_F2(DE_TRIG_INV_PI), DE_F2(0.5f));
+    const DeF2 kk = t + DE_F2(DE_TRIG_MAGIC);
+    const DeF2 n = kk - DE_F2(DE_TRIG_MAGIC);
+    const DeF2 m = SIN ? n : n - DE_F2(0.5f);
+    DeF2 r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P1), x);
+    r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P2), r);
+    const DeF2 z = r * r;
+    DeF2 p = __builtin_elementwise_fma(z, DE_F2(DE_TURBO_S3), DE_F2(DE_TURBO_S2)); // degree-9 minimax of the relative error, 1.5e-7
+    p = __builtin_elementwise_fma(z, p, DE_F2(DE_TURBO_S1));
+    p = __builtin_elementwise_fma(z, p, DE_F2(DE_TURBO_S0));
+    const DeF2 s = __builtin_elementwise_fma(r * z, p, r);
+    // (-1)^n: the low mantissa bit of the magic sum is the parity of n; adding it at bit 31 flips the sign (v_lshl_add_u32)
+    DeF2 y;
+    y[0] = __uint_as_float((__float_as_uint(kk[0]) << 31) + __float_as_uint(s[0]));
+    y[1] = __uint_as_float((__float_as_uint(kk[1]) << 31) + __float_as_uint(s[1]));
+    return y;
+}
+// exp(x) = 2^t * (1 + e ln 2): t = RN(x log2 e) goes to v_exp_f32, e = the rounding error of that product (one FMA)
+__device__ __forceinline__ DeF2 turbo_exp_f32x2(DeF2 x) {
+    const DeF2 t = x * DE_F2(0x1.715476p+0f);
+    DeF2 e = __builtin_elementwise_fma(x, DE_F2(0x1.715476p+0f), -t);
+    e = __builtin_elementwise_fma(x, DE_F2(0x1.4ae0c0p-26f), e); // log2(e) - float(log2(e)): 1.3e-8 * |x| otherwise (1e-6 at |x| = 88)
+    const DeF2 v = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+    const DeF2 c = e * DE_F2(0x1.62e430p-1f);
+    return __builtin_elementwise_fma(v, c, v); // overflow: Inf or NaN (both non-finite); exp(-Inf) = NaN, not 0 (e = Inf - Inf)
+}
+__device__ __forceinline__ DeF2 turbo_div_f32x2(DeF2 n, DeF2 d) {
+    const DeF2 y = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return n * y;
+}
+
 // A class id outside [class_base, class_base + n_classes) is a caller error (the reference asserts on the host,
 // src/ParametricExpression.jl:378-379, and so do the shims); the device clamps the id so that such a call stays
 // memory-safe (the values of those samples are then those of the first / last class).

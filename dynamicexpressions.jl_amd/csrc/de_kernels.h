@@ -45,6 +45,7 @@ struct EvalArgs {
     int32_t classes_is_i64, class_base;
     // flags
     bool early_exit;
+    bool turbo;               // DE_OPT_TURBO (threaded kernel, Float32): relaxed-accuracy cos / exp / sin / division handlers
     // threaded-code variant: `code` holds handler OFFSETS (relative to handler_base) in word 0 and
     // LDS byte offsets in the low 24 bits of word 1
     bool threaded;
@@ -131,7 +132,7 @@ hipError_t launch_pullback_scale(int dtype, void *grad, const int64_t *grad_off,
                                  const void *dY, int64_t N, int64_t n_trees, int32_t max_grad, hipStream_t stream);
 
 // Threaded-code eval kernel: addresses of the TOP_COUNT device handlers (cached per process).
-hipError_t eval_handler_table(int dtype, uint64_t *table);
+hipError_t eval_handler_table(int dtype, bool turbo, uint64_t *table);
 bool eval_uses_threaded();
 
 // Launch plan of the eval kernel for (n_trees, N): samples per workgroup tile, tree chunks.

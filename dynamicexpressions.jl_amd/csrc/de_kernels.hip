@@ -55,6 +55,7 @@ template <typename T> struct KArgs {
     const T *w;
     T *partial; // [n_tiles][n_trees][4 waves]
     int32_t loss_kind;
+    int32_t turbo; // DE_OPT_TURBO program: parameter operands (resolved in the interpreter loop) use the relaxed operators too
     // vectorised staging of the X tile (threaded kernel): X 16-byte aligned with ldX == F
     int32_t x_vec;
     uint32_t f_magic; // ceil(2^32 / F) for F > 1 (e / F == umulhi(e, f_magic) while e * F < 2^32), 0 for F == 1
@@ -563,11 +564,17 @@ __device__ __forceinline__ VecOf<float>::type div_apply(VecOf<float>::type a, Ve
 }
 __device__ __forceinline__ VecOf<double>::type div_apply(VecOf<double>::type a, VecOf<double>::type b) { return a / b; }
 // K: 0 ADD 1 SUB 2 RSUB 3 MUL 4 DIV 5 RDIV  —  x op b (R*: b op x)
-template <typename T, int K> __device__ __forceinline__ typename VecOf<T>::type bin_apply(typename VecOf<T>::type x, typename VecOf<T>::type b) {
+// TB = DE_OPT_TURBO: the relaxed-accuracy Float32 operators of de_device_ops.h (Float64 has none: same code as exact)
+__device__ __forceinline__ VecOf<float>::type div_turbo(VecOf<float>::type a, VecOf<float>::type b) {
+    const DeF2 lo = turbo_div_f32x2(DeF2{a[0], a[1]}, DeF2{b[0], b[1]}), hi = turbo_div_f32x2(DeF2{a[2], a[3]}, DeF2{b[2], b[3]});
+    return VecOf<float>::type{lo[0], lo[1], hi[0], hi[1]};
+}
+template <typename T, int K, bool TB = false> __device__ __forceinline__ typename VecOf<T>::type bin_apply(typename VecOf<T>::type x, typename VecOf<T>::type b) {
     if constexpr (K == 0) return x + b;
     else if constexpr (K == 1) return x - b;
     else if constexpr (K == 2) return b - x;
     else if constexpr (K == 3) return x * b;
+    else if constexpr (TB && sizeof(T) == 4) return K == 4 ? div_turbo(x, b) : div_turbo(b, x);
     else if constexpr (K == 4) return div_apply(x, b);
     else return div_apply(b, x);
 }
@@ -578,11 +585,25 @@ template <typename T> __device__ __forceinline__ typename VecOf<T>::type splat(t
     return b;
 }
 // K: 0 COS 1 EXP 2 SIN
-template <typename T, int K> __device__ __forceinline__ typename VecOf<T>::type un_apply(typename VecOf<T>::type x) {
+template <typename T, int K, bool TB = false> __device__ __forceinline__ typename VecOf<T>::type un_apply(typename VecOf<T>::type x) {
     typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
     V r;
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (TB && sizeof(T) == 4) {
+        const DeF2 xa = {x[0], x[1]}, xb = {x[2], x[3]};
+        if constexpr (K == 1) {
+            const DeF2 a = turbo_exp_f32x2(xa), b = turbo_exp_f32x2(xb);
+            r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
+        } else {
+            const DeF2 a = turbo_trig_f32x2<K == 2>(xa), b = turbo_trig_f32x2<K == 2>(xb);
+            r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
+            const float mx = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
+            if (__ballot(mx > DE_TURBO_TRIG_BOUND) != 0ull) { // huge arguments and Inf: full range reduction (rare, wave-uniform)
+                DE_UNROLL for (int i = 0; i < VW; i++)
+                    if (fabsf(x[i]) > DE_TURBO_TRIG_BOUND) r[i] = K == 2 ? sinf(x[i]) : cosf(x[i]);
+            }
+        }
+    } else if constexpr (sizeof(T) == 4) {
         if constexpr (K == 1) {
             const DeF2 a = fast_exp_f32x2(DeF2{x[0], x[1]}), b = fast_exp_f32x2(DeF2{x[2], x[3]});
             r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
@@ -604,21 +625,21 @@ template <typename T, int K> __device__ __forceinline__ typename VecOf<T>::type 
     return r;
 }
 // VAR bit0 = validity-test the result, bit1 = constant operand
-template <typename T, int K, int VAR> __device__ __noinline__ HState<T> h_bin(HARGS) {
+template <typename T, int K, int VAR, bool TB = false> __device__ __noinline__ HState<T> h_bin(HARGS) {
     typedef typename VecOf<T>::type V;
     V b;
     if constexpr (VAR & 2) b = splat<T>(imm);
     else b = *LDSP(T, la);
-    st.acc = bin_apply<T, K>(st.acc, b);
+    st.acc = bin_apply<T, K, TB>(st.acc, b);
     if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
     return st;
 }
 // VAR bit0 = test the result, bit1 = operand is an LDS row (else acc)
-template <typename T, int K, int VAR> __device__ __noinline__ HState<T> h_un(HARGS) {
+template <typename T, int K, int VAR, bool TB = false> __device__ __noinline__ HState<T> h_un(HARGS) {
     typedef typename VecOf<T>::type V;
     V x = st.acc;
     if constexpr (VAR & 2) x = *LDSP(T, la);
-    st.acc = un_apply<T, K>(x);
+    st.acc = un_apply<T, K, TB>(x);
     if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
     return st;
 }
@@ -638,23 +659,23 @@ template <typename T> __device__ __noinline__ HState<T> h_loadconst_push(HARGS) 
     st.acc = splat<T>(imm);
     return st;
 }
-template <typename T, int K, bool OUT, bool PUSH, bool CHK> __device__ __noinline__ HState<T> h_unrow_f(HARGS) {
+template <typename T, int K, bool OUT, bool PUSH, bool CHK, bool TB = false> __device__ __noinline__ HState<T> h_unrow_f(HARGS) {
     if constexpr (PUSH) *LDSP(T, push_addr(la)) = st.acc;
     const typename VecOf<T>::type x = *LDSP(T, PUSH ? row_a(la) : la);
     if constexpr (CHK) hpoison<T>(st.poison, x);
-    st.acc = un_apply<T, K>(x);
+    st.acc = un_apply<T, K, TB>(x);
     if constexpr (OUT) hpoison<T>(st.poison, st.acc);
     return st;
 }
-template <typename T, int K, bool OUT> __device__ __noinline__ HState<T> h_binrowc(HARGS) { // operand row tested, then acc = acc op row
+template <typename T, int K, bool OUT, bool TB = false> __device__ __noinline__ HState<T> h_binrowc(HARGS) { // operand row tested, then acc = acc op row
     const typename VecOf<T>::type b = *LDSP(T, la);
     hpoison<T>(st.poison, b);
-    st.acc = bin_apply<T, K>(st.acc, b);
+    st.acc = bin_apply<T, K, TB>(st.acc, b);
     if constexpr (OUT) hpoison<T>(st.poison, st.acc);
     return st;
 }
 // acc = row A op (row B | constant); row B's byte distance from row A travels in the immediate
-template <typename T, int K, bool CST, bool OUT, bool PUSH> __device__ __noinline__ HState<T> h_bin2(HARGS) {
+template <typename T, int K, bool CST, bool OUT, bool PUSH, bool TB = false> __device__ __noinline__ HState<T> h_bin2(HARGS) {
     typedef typename VecOf<T>::type V;
     if constexpr (PUSH) *LDSP(T, push_addr(la)) = st.acc;
     const uint32_t a = PUSH ? row_a(la) : la;
@@ -662,7 +683,7 @@ template <typename T, int K, bool CST, bool OUT, bool PUSH> __device__ __noinlin
     V b;
     if constexpr (CST) b = splat<T>(imm);
     else b = *LDSP(T, a + (uint32_t)imm);
-    st.acc = bin_apply<T, K>(x, b);
+    st.acc = bin_apply<T, K, TB>(x, b);
     if constexpr (OUT) hpoison<T>(st.poison, st.acc);
     return st;
 }
@@ -724,11 +745,14 @@ template <typename T> __device__ __noinline__ HState<T> h_tern(HARGS) { // acc =
 }
 template <typename T> __device__ __noinline__ HState<T> h_nop(HARGS) { return st; }
 
-template <typename T> __global__ void de_fill_handlers(uint64_t *t) {
-#define HB(K) t[BOP_BIN_BASE + 4 * K + 0] = (uint64_t)&h_bin<T, K, 0>; t[BOP_BIN_BASE + 4 * K + 1] = (uint64_t)&h_bin<T, K, 1>; \
-              t[BOP_BIN_BASE + 4 * K + 2] = (uint64_t)&h_bin<T, K, 2>; t[BOP_BIN_BASE + 4 * K + 3] = (uint64_t)&h_bin<T, K, 3>;
-#define HU(K) t[BOP_UN_BASE + 4 * K + 0] = (uint64_t)&h_un<T, K, 0>; t[BOP_UN_BASE + 4 * K + 1] = (uint64_t)&h_un<T, K, 1>; \
-              t[BOP_UN_BASE + 4 * K + 2] = (uint64_t)&h_un<T, K, 2>; t[BOP_UN_BASE + 4 * K + 3] = (uint64_t)&h_un<T, K, 3>;
+// TB = handlers of a DE_OPT_TURBO program: same ids, the division / cos / exp / sin handlers are the relaxed-accuracy
+// instantiations (operators without a turbo version share the exact instantiation: TBK)
+template <typename T, bool TB> __global__ void de_fill_handlers(uint64_t *t) {
+#define TBK(K) (TB && (K) >= 4)
+#define HB(K) t[BOP_BIN_BASE + 4 * K + 0] = (uint64_t)&h_bin<T, K, 0, TBK(K)>; t[BOP_BIN_BASE + 4 * K + 1] = (uint64_t)&h_bin<T, K, 1, TBK(K)>; \
+              t[BOP_BIN_BASE + 4 * K + 2] = (uint64_t)&h_bin<T, K, 2, TBK(K)>; t[BOP_BIN_BASE + 4 * K + 3] = (uint64_t)&h_bin<T, K, 3, TBK(K)>;
+#define HU(K) t[BOP_UN_BASE + 4 * K + 0] = (uint64_t)&h_un<T, K, 0, TB>; t[BOP_UN_BASE + 4 * K + 1] = (uint64_t)&h_un<T, K, 1, TB>; \
+              t[BOP_UN_BASE + 4 * K + 2] = (uint64_t)&h_un<T, K, 2, TB>; t[BOP_UN_BASE + 4 * K + 3] = (uint64_t)&h_un<T, K, 3, TB>;
     t[BOP_LOAD_ROW] = (uint64_t)&h_load_row<T>;
     t[BOP_LOAD_CONST] = (uint64_t)&h_load_const<T>;
     t[BOP_PUSH] = (uint64_t)&h_push<T>;
@@ -756,19 +780,20 @@ template <typename T> __global__ void de_fill_handlers(uint64_t *t) {
     t[top_loadrow(true, false)] = (uint64_t)&h_loadrow_f<T, true, false>;
     t[top_loadrow(true, true)] = (uint64_t)&h_loadrow_f<T, true, true>;
     t[TOP_LOADCONST_PUSH] = (uint64_t)&h_loadconst_push<T>;
-#define TU1(K, O, P) t[top_unrow(K, O, P, false)] = (uint64_t)&h_unrow_f<T, K, O, P, false>; t[top_unrow(K, O, P, true)] = (uint64_t)&h_unrow_f<T, K, O, P, true>;
+#define TU1(K, O, P) t[top_unrow(K, O, P, false)] = (uint64_t)&h_unrow_f<T, K, O, P, false, TB>; t[top_unrow(K, O, P, true)] = (uint64_t)&h_unrow_f<T, K, O, P, true, TB>;
 #define TU(K) TU1(K, false, false) TU1(K, false, true) TU1(K, true, false) TU1(K, true, true)
     TU(0) TU(1) TU(2)
-#define TBC(K) t[top_binrowc(K, false)] = (uint64_t)&h_binrowc<T, K, false>; t[top_binrowc(K, true)] = (uint64_t)&h_binrowc<T, K, true>;
+#define TBC(K) t[top_binrowc(K, false)] = (uint64_t)&h_binrowc<T, K, false, TBK(K)>; t[top_binrowc(K, true)] = (uint64_t)&h_binrowc<T, K, true, TBK(K)>;
     TBC(0) TBC(1) TBC(2) TBC(3) TBC(4) TBC(5)
-#define TB1(K, C, O) t[top_bin2(K, C, O, false)] = (uint64_t)&h_bin2<T, K, C, O, false>; t[top_bin2(K, C, O, true)] = (uint64_t)&h_bin2<T, K, C, O, true>;
-#define TB(K) TB1(K, false, false) TB1(K, false, true) TB1(K, true, false) TB1(K, true, true)
-    TB(0) TB(1) TB(2) TB(3) TB(4) TB(5)
+#define TB1(K, C, O) t[top_bin2(K, C, O, false)] = (uint64_t)&h_bin2<T, K, C, O, false, TBK(K)>; t[top_bin2(K, C, O, true)] = (uint64_t)&h_bin2<T, K, C, O, true, TBK(K)>;
+#define TBF(K) TB1(K, false, false) TB1(K, false, true) TB1(K, true, false) TB1(K, true, true)
+    TBF(0) TBF(1) TBF(2) TBF(3) TBF(4) TBF(5)
 #undef TU1
 #undef TU
 #undef TBC
 #undef TB1
-#undef TB
+#undef TBF
+#undef TBK
 }
 
 template <typename T, bool PARAMS, bool LOSS = false>
@@ -890,11 +915,11 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
                 case DE_B_SUB: st.acc = bin_apply<T, 1>(st.acc, bv.v[0]); break;
                 case DOP_RSUB: st.acc = bin_apply<T, 2>(st.acc, bv.v[0]); break;
                 case DE_B_MUL: st.acc = bin_apply<T, 3>(st.acc, bv.v[0]); break;
-                case DE_B_DIV: st.acc = bin_apply<T, 4>(st.acc, bv.v[0]); break;
-                case DOP_RDIV: st.acc = bin_apply<T, 5>(st.acc, bv.v[0]); break;
-                case DE_U_COS: st.acc = un_apply<T, 0>(bv.v[0]); break; // unary operator on a parameter leaf
-                case DE_U_EXP: st.acc = un_apply<T, 1>(bv.v[0]); break;
-                case DE_U_SIN: st.acc = un_apply<T, 2>(bv.v[0]); break;
+                case DE_B_DIV: st.acc = a.turbo ? bin_apply<T, 4, true>(st.acc, bv.v[0]) : bin_apply<T, 4>(st.acc, bv.v[0]); break;
+                case DOP_RDIV: st.acc = a.turbo ? bin_apply<T, 5, true>(st.acc, bv.v[0]) : bin_apply<T, 5>(st.acc, bv.v[0]); break;
+                case DE_U_COS: st.acc = a.turbo ? un_apply<T, 0, true>(bv.v[0]) : un_apply<T, 0>(bv.v[0]); break; // unary operator on a parameter leaf
+                case DE_U_EXP: st.acc = a.turbo ? un_apply<T, 1, true>(bv.v[0]) : un_apply<T, 1>(bv.v[0]); break;
+                case DE_U_SIN: st.acc = a.turbo ? un_apply<T, 2, true>(bv.v[0]) : un_apply<T, 2>(bv.v[0]); break;
                 default: av.v[0] = st.acc; av = cold_op<T, 1>(op, av, bv); st.acc = av.v[0]; break;
                 }
                 continue;
@@ -1083,24 +1108,24 @@ static hipError_t launch_eval_geo(const EvalArgs &a, hipStream_t stream, const c
 }
 
 // ---- threaded variant: handler table + launch ---------------------------------------------
-template <typename T> static hipError_t fetch_handlers(uint64_t *host_table) {
+template <typename T, bool TB> static hipError_t fetch_handlers(uint64_t *host_table) {
     uint64_t *d = nullptr;
     hipError_t st = hipMalloc(reinterpret_cast<void **>(&d), TOPX_COUNT * sizeof(uint64_t));
     if (st != hipSuccess) return st;
-    hipLaunchKernelGGL(de_fill_handlers<T>, dim3(1), dim3(1), 0, 0, d);
+    hipLaunchKernelGGL((de_fill_handlers<T, TB>), dim3(1), dim3(1), 0, 0, d);
     st = hipMemcpy(host_table, d, TOPX_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     return st;
 }
 
-hipError_t eval_handler_table(int dtype, uint64_t *table) {
-    static uint64_t cache[2][TOPX_COUNT];
-    static bool have[2] = {false, false};
+hipError_t eval_handler_table(int dtype, bool turbo, uint64_t *table) {
+    static uint64_t cache[3][TOPX_COUNT]; // Float32, Float64, Float32 turbo (Float64 has no relaxed operators)
+    static bool have[3] = {false, false, false};
     static std::mutex mu; // contexts on several host threads may ask at once
     const std::lock_guard<std::mutex> lock(mu);
-    const int k = dtype == DE_F32 ? 0 : 1;
+    const int k = dtype == DE_F32 ? (turbo ? 2 : 0) : 1;
     if (!have[k]) {
-        hipError_t st = k == 0 ? fetch_handlers<float>(cache[k]) : fetch_handlers<double>(cache[k]);
+        hipError_t st = k == 0 ? fetch_handlers<float, false>(cache[k]) : (k == 2 ? fetch_handlers<float, true>(cache[k]) : fetch_handlers<double, false>(cache[k]));
         if (st != hipSuccess) return st;
         have[k] = true;
     }
@@ -1141,6 +1166,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.f_magic = e.F > 1 ? (uint32_t)((0x100000000ull + (uint64_t)e.F - 1) / (uint64_t)e.F) : 0u;
     a.x_vec = 0;
     a.f_magic = 0;
+    a.turbo = e.turbo ? 1 : 0;
     int32_t tpc, nch;
     plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc);
     a.trees_per_chunk = tpc;

@@ -78,8 +78,8 @@ typedef enum de_grad_mode {
 } de_grad_mode_t;
 
 /* Option bits = the reference's EvalContext knobs that change RESULTS
- * (src/Evaluate.jl:156-181).  turbo/bumper/buffer are CPU back-end choices
- * and have no meaning here, except DE_OPT_BUMPER_CHECKS below. */
+ * (src/Evaluate.jl:156-181).  bumper/buffer are CPU back-end choices and have
+ * no meaning here, except DE_OPT_BUMPER_CHECKS below; turbo maps to DE_OPT_TURBO. */
 enum de_options {
     /* EvalContext.early_exit (default true).  The GPU never exits early; the bit
      * selects the FLAG semantics: with it, `ok` is false iff any value the
@@ -96,6 +96,14 @@ enum de_options {
      * (ext/DynamicExpressionsBumperExt.jl:25-36,63): constant leaves tested,
      * feature leaves never tested, every operator result tested, no folding. */
     DE_OPT_BUMPER_CHECKS = 1u << 3,
+    /* EvalContext.turbo (the LoopVectorization path, ext/DynamicExpressionsLoopVectorizationExt.jl:24-278): permission
+     * to trade the last bits for speed, as the reference's @turbo loops do with SLEEF (their results drift from
+     * Base's, test/test_supposition_consistency.jl:106-108).  Float32 eval_tree_array only: `/` = x * v_rcp_f32(y),
+     * exp = v_exp_f32 + one correction FMA, cos/sin = two-term pi + degree-9 polynomial without the exact-extremum
+     * select and without the Payne-Hanek path — <= 1e-6 relative on ordinary arguments (north_star: 1e-5), flags
+     * identical except through the documented domain edges (csrc/de_device_ops.h).  Float64, the
+     * gradient entry points and wide-X programs ignore the bit (they run the exact operators). */
+    DE_OPT_TURBO = 1u << 4,
     DE_OPT_DEFAULT = (1u << 0) | (1u << 1) | (1u << 2)
 };
 

@@ -13,7 +13,7 @@ for wl in headline C2 C3 C4 C5 C5N loss lossgrad C5pb; do
 import json
 try:
     d = json.load(open("$O/bench_$wl.json"))
-    print("$wl", round(d["ms_per_step"], 3), "ms", "%.3g" % d["value"], "frac", round(d["roofline"]["frac"], 3), "valu", (d["roofline"].get("valu") or {}).get("frac"))
+    print("$wl", round(d["ms_per_step"], 3), "ms", "%.3g" % d["value"], "frac", round(d["roofline"]["frac"], 3), "valu", (d["roofline"].get("valu") or {}).get("frac"), "turbo", (d.get("turbo") or {}).get("ms_per_step"))
 except Exception as e:
     print("$wl: no line", e)
 PY

@@ -86,10 +86,12 @@ def shortest_slots(code):
     return None
 
 
-def handler_names(ty: str):
+def handler_names(ty: str, turbo: bool = False):
     """handler id -> template instantiation, restating the id layout of csrc/de_bind.h (checked against
     TOPX_COUNT through de_lower_tape_stage's ids by tests/test_lowering.py::test_valu_slot_table_layout)."""
     b = lambda v: "true" if v else "false"  # noqa: E731
+    tb = b(turbo)                       # cos / exp / sin handlers
+    tbk = lambda k: b(turbo and k >= 4)  # noqa: E731  binary handlers: only the divisions have a turbo instantiation
     names = {}
     names[0] = f"h_load_row<{ty}>"
     names[1] = f"h_load_const<{ty}>"
@@ -99,11 +101,11 @@ def handler_names(ty: str):
     BIN_BASE = 5
     for k in range(6):
         for v in range(4):
-            names[BIN_BASE + 4 * k + v] = f"h_bin<{ty}, {k}, {v}>"
+            names[BIN_BASE + 4 * k + v] = f"h_bin<{ty}, {k}, {v}, {tbk(k)}>"
     UN_BASE = BIN_BASE + 24
     for k in range(3):
         for v in range(4):
-            names[UN_BASE + 4 * k + v] = f"h_un<{ty}, {k}, {v}>"
+            names[UN_BASE + 4 * k + v] = f"h_un<{ty}, {k}, {v}, {tb}>"
     GEN = UN_BASE + 12
     names[GEN + 0] = f"h_gen<{ty}, 0, false>"
     names[GEN + 1] = f"h_gen<{ty}, 1, false>"
@@ -124,17 +126,17 @@ def handler_names(ty: str):
         for o in (0, 1):
             for p in (0, 1):
                 for c in (0, 1):
-                    names[UNROW + ((k * 2 + o) * 2 + p) * 2 + c] = f"h_unrow_f<{ty}, {k}, {b(o)}, {b(p)}, {b(c)}>"
+                    names[UNROW + ((k * 2 + o) * 2 + p) * 2 + c] = f"h_unrow_f<{ty}, {k}, {b(o)}, {b(p)}, {b(c)}, {tb}>"
     BINROWC = UNROW + 24
     for k in range(6):
         for o in (0, 1):
-            names[BINROWC + k * 2 + o] = f"h_binrowc<{ty}, {k}, {b(o)}>"
+            names[BINROWC + k * 2 + o] = f"h_binrowc<{ty}, {k}, {b(o)}, {tbk(k)}>"
     BIN2 = BINROWC + 12
     for k in range(6):
         for cst in (0, 1):
             for o in (0, 1):
                 for p in (0, 1):
-                    names[BIN2 + ((k * 2 + cst) * 2 + o) * 2 + p] = f"h_bin2<{ty}, {k}, {b(cst)}, {b(o)}, {b(p)}>"
+                    names[BIN2 + ((k * 2 + cst) * 2 + o) * 2 + p] = f"h_bin2<{ty}, {k}, {b(cst)}, {b(o)}, {b(p)}, {tbk(k)}>"
     TOP_COUNT = BIN2 + 48
     for k in range(3, 13):
         for s in (0, 1):
@@ -145,14 +147,14 @@ def handler_names(ty: str):
     return names, dict(BOP_COUNT=BOP_COUNT, TOP_COUNT=TOP_COUNT, TOPX_COUNT=XB + 4)
 
 
-def table(obj, ty="float"):
+def table(obj, ty="float", turbo=False):
     fns = functions(obj)
     by_short = {}
     for full, code in fns.items():
         m = re.search(r"de::(h_\w+<[^(]*>)\(", full)
         if m:
             by_short[m.group(1)] = code
-    names, counts = handler_names(ty)
+    names, counts = handler_names(ty, turbo)
     slots = {}
     for hid, nm in names.items():
         code = by_short.get(nm)
@@ -172,11 +174,13 @@ def main():
     ap.add_argument("-o", "--out", default=os.path.join(ROOT, "profiles", "valu_slots.json"))
     a = ap.parse_args()
     slots, counts = table(a.obj, "float" if a.dtype == "f32" else "double")
+    turbo = table(a.obj, "float", True)[0] if a.dtype == "f32" else {}
     doc = dict(source=f"tools/valu_slots.py over {os.path.relpath(a.obj, ROOT)} (llvm-objdump of the gfx950 code object)",
                rule="VALU issue slots on the shortest entry->return path; quarter-rate transcendentals count 4",
                dispatch_overhead_valu=2,  # v_add (LDS address) + v_mov (immediate) before s_swappc in the interpreter loop
                per_tree_overhead_valu=8,  # state zeroing + output address + ballot compare around the loop
-               layout=counts, handlers={str(k): v for k, v in sorted(slots.items())})
+               layout=counts, handlers={str(k): v for k, v in sorted(slots.items())},
+               handlers_turbo={str(k): v for k, v in sorted(turbo.items())})  # the same ids in a DE_OPT_TURBO program
     with open(a.out, "w") as fh:
         json.dump(doc, fh, indent=1)
     print(f"{len(slots)} handlers -> {a.out}")
