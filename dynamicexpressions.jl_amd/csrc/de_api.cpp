@@ -88,10 +88,14 @@ struct de_program {
     std::vector<BoundInstr> tcode;      // threaded form: handler address offsets + LDS byte offsets
     std::vector<BoundInstr> fbcode;     // fused (superinstruction) form the threaded code is made from
     std::vector<int32_t> tcode_off;     // n_trees + 1 offsets into tcode / fbcode
+    // what the threaded kernel reads (de_kernels.hip "direct-threaded dispatch"): per tree a header record and one
+    // 16-byte record per instruction {operand word, immediate, address of the NEXT handler}; made from tcode
+    std::vector<BoundInstr> ccode;
+    std::vector<int32_t> ccode_off;     // n_trees + 1: header record of each tree
+    uint64_t end_handler = 0;
     bool threaded = false;
     bool direct = false;                // X too wide for the LDS tile (decided at creation)
     uint64_t handler_base = 0;
-    uint32_t param_handler_off = 0;
     std::vector<int32_t> bcode_off;     // n_trees + 1
     BoundInstr *d_code = nullptr;
     int32_t *d_code_off = nullptr;
@@ -112,7 +116,7 @@ struct de_program {
     // gbcode / gtcode (unfolded program); -1 elsewhere.  Empty = not available (full rebuild instead).
     std::vector<int32_t> bsite, tsite, gbsite, gtsite_of_gb;
     // compact forms for de_program_set_consts (rebuilt when site_gen moves): only the instructions that carry an immediate
-    struct EvalSite { int32_t src, b, t; };          // source instruction (fcode/code), bcode index, tcode index
+    struct EvalSite { int32_t src, b, t, c; };       // source instruction (fcode/code), bcode index, tcode index, ccode index
     struct GradSite { int32_t src, gb, gt, rt; };   // code instruction, gbcode index, gtcode / rtcode index or -1
     std::vector<EvalSite> eval_sites;
     std::vector<GradSite> grad_sites;
@@ -405,19 +409,23 @@ static void rebind(de_program *p) {
 
 // Threaded-code form of the bound program (de_kernels.hip, de_eval_threaded_kernel): word 0 =
 // handler address - handler_base, word 1 = LDS byte offset of the operand row | aux << 24.
+static void make_chained(de_program *p);
 static int make_threaded(de_ctx *c, de_program *p) {
     p->threaded = false;
     // the LDS-staged kernels need (n_features + n_slots) rows of 4112 B; wider X uses the direct variant
     p->direct = ((size_t)p->n_features + (size_t)p->n_slots) * 257 * 16 > 150 * 1024;
     if (p->direct || !eval_uses_threaded()) return DE_OK;
     if ((int64_t)p->n_features + p->n_slots > 4000) return DE_OK; // row offsets must fit 24 bits
-    uint64_t table[TOPX_COUNT];
+    uint64_t table[TOPX_TABLE];
     hipError_t st = eval_handler_table(p->dtype, (p->options & DE_OPT_TURBO) != 0, table);
     if (st != hipSuccess) return fail(c, DE_ERR_HIP, "handler table: %s", hipGetErrorString(st));
     uint64_t base = table[0];
-    for (int i = 0; i < (int)TOPX_COUNT; i++) base = std::min<uint64_t>(base, table[i]);
-    for (int i = 0; i < (int)TOPX_COUNT; i++)
+    for (int i = 0; i < (int)TOPX_TABLE; i++) base = std::min<uint64_t>(base, table[i]);
+    for (int i = 0; i < (int)TOPX_TABLE; i++) {
         if (table[i] - base > 0xFFFFFFFFull) return DE_OK; // cannot encode: keep the switch kernel
+        // Float64 records carry 32 bits of the next handler's address (the high half is the current pc's)
+        if (p->dtype != DE_F32 && (table[i] >> 32) != (table[0] >> 32)) return DE_OK;
+    }
     const bool hot_unary = !getenv("DE_NO_CONST_UNARY_HOT"); // unary operators outside the binder's hot set: their own handlers
     const uint32_t row_bytes = 257 * 16;
     // superinstructions (de_bind.h): fewer dispatches for the same arithmetic
@@ -445,7 +453,10 @@ static int make_threaded(de_ctx *c, de_program *p) {
             t.bop = (uint32_t)(table[TOPX_BIN_BASE + ((b.arg >> 24) == (uint32_t)DE_B_MAX ? 0u : 2u) + (b.bop == BOP_GEN_CONST ? 1u : 0u)] - base);
         if (b.bop < BOP_COUNT && bop_is_const_source(b.bop)) {
             t.arg = b.arg & 0xFF000000u; // constant ordinal is only for the gradient kernel
-        } else if (b.bop != BOP_GEN_PARAM) {
+        } else if (b.bop == BOP_GEN_PARAM) { // immediate = LDS byte offset of the class row (behind X and the spill slots)
+            t.lo = (uint32_t)(p->n_features + p->n_slots) * row_bytes;
+            t.hi = 0;
+        } else {
             const uint32_t row = b.arg & 0xFFFFFFu, aux = b.arg >> 24;
             t.arg = (row * row_bytes) | (aux << 24);
             if (b.bop == BOP_TERN) t.lo = (b.lo - row) * row_bytes; // byte distance row B -> row C (mod 2^32)
@@ -461,9 +472,40 @@ static int make_threaded(de_ctx *c, de_program *p) {
         p->site_gen++;
     }
     p->handler_base = base;
-    p->param_handler_off = (uint32_t)(table[BOP_GEN_PARAM] - base);
+    p->end_handler = table[TOPX_END];
+    make_chained(p);
     p->threaded = true;
     return DE_OK;
+}
+
+// The device layout of the threaded program (see de_kernels.hip): record i of tree t = {tcode[i].arg, immediate,
+// address of the handler of instruction i + 1 (h_end after the last)}, behind a header record that points at the first.
+// BoundInstr fields by word: Float32 {bop: operand word, arg: imm, lo/hi: next}; Float64 {bop: operand word, arg: next.lo, lo/hi: imm}.
+static void make_chained(de_program *p) {
+    const bool f32 = p->dtype == DE_F32;
+    p->ccode.assign(p->tcode.size() + (size_t)p->n_trees, BoundInstr{0u, 0u, 0u, 0u});
+    p->ccode_off.assign((size_t)p->n_trees + 1, 0);
+    for (int64_t t = 0; t < p->n_trees; t++) {
+        const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1];
+        const size_t h = (size_t)i0 + (size_t)t;
+        p->ccode_off[(size_t)t] = (int32_t)h;
+        const uint64_t first = i1 > i0 ? p->handler_base + p->tcode[(size_t)i0].bop : p->end_handler;
+        p->ccode[h].lo = (uint32_t)first;
+        p->ccode[h].hi = (uint32_t)(first >> 32);
+        for (int32_t i = i0; i < i1; i++) {
+            const BoundInstr &s = p->tcode[(size_t)i];
+            const uint64_t next = i + 1 < i1 ? p->handler_base + p->tcode[(size_t)i + 1].bop : p->end_handler;
+            BoundInstr &r = p->ccode[h + 1 + (size_t)(i - i0)];
+            r.bop = s.arg;
+            if (f32) { r.arg = s.lo; r.lo = (uint32_t)next; r.hi = (uint32_t)(next >> 32); }
+            else { r.arg = (uint32_t)next; r.lo = s.lo; r.hi = s.hi; }
+        }
+    }
+    p->ccode_off[(size_t)p->n_trees] = (int32_t)p->ccode.size();
+}
+static inline void patch_chained_imm(de_program *p, int32_t c, uint32_t lo, uint32_t hi) {
+    if (p->dtype == DE_F32) p->ccode[(size_t)c].arg = lo;
+    else { p->ccode[(size_t)c].lo = lo; p->ccode[(size_t)c].hi = hi; }
 }
 
 static void recompute_host_ok(de_program *p) {
@@ -689,8 +731,9 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         try { rc = make_threaded(ctx, p.get()); } catch (const std::bad_alloc &) { rc = fail(ctx, DE_ERR_HIP, "out of host memory"); }
         if (rc != DE_OK) return rc;
     }
-    // one trailing pad instruction: the interpreter prefetches code[pc + 1]
-    const size_t cbytes = (p->bcode.size() + 1) * sizeof(BoundInstr); // the fused form is never longer
+    // one trailing pad instruction: the flat-switch interpreter prefetches code[pc + 1]; the chained form of the
+    // threaded kernel has one header record per tree (and the fused form is never longer than the bound one)
+    const size_t cbytes = (p->bcode.size() + (size_t)p->n_trees + 1) * sizeof(BoundInstr);
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->d_code), cbytes));
     HIP_TRY(ctx, hipMemset(p->d_code, 0, cbytes));
     hipError_t st = hipMalloc(reinterpret_cast<void **>(&p->d_code_off), p->bcode_off.size() * sizeof(int32_t));
@@ -699,10 +742,10 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(st));
     }
     if (!p->bcode.empty())
-        st = hipMemcpy(p->d_code, (p->threaded ? p->tcode : p->bcode).data(),
-                       (p->threaded ? p->tcode : p->bcode).size() * sizeof(BoundInstr), hipMemcpyHostToDevice);
+        st = hipMemcpy(p->d_code, (p->threaded ? p->ccode : p->bcode).data(),
+                       (p->threaded ? p->ccode : p->bcode).size() * sizeof(BoundInstr), hipMemcpyHostToDevice);
     if (st == hipSuccess)
-        st = hipMemcpy(p->d_code_off, (p->threaded ? p->tcode_off : p->bcode_off).data(), p->bcode_off.size() * sizeof(int32_t),
+        st = hipMemcpy(p->d_code_off, (p->threaded ? p->ccode_off : p->bcode_off).data(), p->bcode_off.size() * sizeof(int32_t),
                        hipMemcpyHostToDevice);
     if (st != hipSuccess) {
         (void)hipFree(p->d_code);
@@ -758,7 +801,12 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
             p->eval_sites.clear();
             p->grad_sites.clear();
             for (size_t i = 0; i < src.size(); i++)
-                if (p->bsite[i] >= 0) p->eval_sites.push_back({(int32_t)i, p->bsite[i], p->tsite[i]});
+                if (p->bsite[i] >= 0) {
+                    // record of tcode[j] in the chained stream: one header record per tree before it
+                    const int32_t j = p->tsite[i];
+                    const int64_t tree = (std::upper_bound(p->tcode_off.begin(), p->tcode_off.end(), j) - p->tcode_off.begin()) - 1;
+                    p->eval_sites.push_back({(int32_t)i, p->bsite[i], j, (int32_t)(j + tree + 1)});
+                }
             if (!p->gbsite.empty())
                 for (size_t i = 0; i < p->code.size(); i++) {
                     const int32_t gj = p->gbsite[i];
@@ -774,6 +822,7 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
             p->bcode[(size_t)e.b].hi = hi;
             p->tcode[(size_t)e.t].lo = lo;
             p->tcode[(size_t)e.t].hi = hi;
+            patch_chained_imm(p, e.c, lo, hi);
         }
         if (gpatch) {
             for (const de_program::GradSite &g : p->grad_sites) {
@@ -796,8 +845,8 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
         }
         const auto t4 = now();
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // the program may be in use by work already queued
-        if (!p->tcode.empty())
-            HIP_TRY(ctx, hipMemcpy(p->d_code, p->tcode.data(), p->tcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
+        if (!p->ccode.empty())
+            HIP_TRY(ctx, hipMemcpy(p->d_code, p->ccode.data(), p->ccode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
         if (gpatch) {
             if (!p->gbcode.empty())
                 HIP_TRY(ctx, hipMemcpy(p->d_gcode, p->gbcode.data(), p->gbcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
@@ -825,8 +874,8 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
     // the program may be in use by work already queued on the stream
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!p->bcode.empty())
-        HIP_TRY(ctx, hipMemcpy(p->d_code, (p->threaded ? p->tcode : p->bcode).data(),
-                               (p->threaded ? p->tcode : p->bcode).size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(p->d_code, (p->threaded ? p->ccode : p->bcode).data(),
+                               (p->threaded ? p->ccode : p->bcode).size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
     return DE_OK;
 }
 
@@ -1145,8 +1194,6 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
     a.turbo = (p->options & DE_OPT_TURBO) != 0;
     a.threaded = p->threaded && !direct;
     a.direct = direct;
-    a.handler_base = p->handler_base;
-    a.param_handler_off = p->param_handler_off;
     a.loss = lr ? &la : nullptr;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, launch_eval(p->dtype, a, c->stream, &c->last_kernel));

@@ -160,6 +160,9 @@ static_assert(gop_count(8) <= GOP_MAX, "GOP_MAX too small");
 constexpr uint32_t TOPX_UN_BASE = TOP_COUNT;                 // + (k - 3) * 2 + (src == ACC)
 constexpr uint32_t TOPX_BIN_BASE = TOPX_UN_BASE + 2 * (GUN_K - 3); // max / min: + (k - 6) * 2 + (src == CONST)
 constexpr uint32_t TOPX_COUNT = TOPX_BIN_BASE + 4;
+// handler table of the threaded eval kernel: the ids above + the end-of-tree handler every chain finishes in
+constexpr uint32_t TOPX_END = TOPX_COUNT;
+constexpr uint32_t TOPX_TABLE = TOPX_COUNT + 1;
 
 // True when a (bound or fused) instruction carries a constant's bits in lo/hi.  Every generic
 // instruction with a constant operand becomes exactly one such instruction, in program order, in the

@@ -50,8 +50,6 @@ struct EvalArgs {
     // LDS byte offsets in the low 24 bits of word 1
     bool threaded;
     bool direct; // feature matrix too wide for the LDS tile: gather features from global memory (flat-switch kernel)
-    uint64_t handler_base;
-    uint32_t param_handler_off;
     const LossArgs *loss; // non-null: fused loss instead of the output store (threaded kernel only)
 };
 
@@ -131,7 +129,7 @@ hipError_t launch_by_class_combine(int dtype, const ByClassArgs &a, hipStream_t 
 hipError_t launch_pullback_scale(int dtype, void *grad, const int64_t *grad_off, const int32_t *n_grad, const uint8_t *ok,
                                  const void *dY, int64_t N, int64_t n_trees, int32_t max_grad, hipStream_t stream);
 
-// Threaded-code eval kernel: addresses of the TOP_COUNT device handlers (cached per process).
+// Threaded-code eval kernel: addresses of the TOPX_TABLE device handlers (cached per process).
 hipError_t eval_handler_table(int dtype, bool turbo, uint64_t *table);
 bool eval_uses_threaded();
 

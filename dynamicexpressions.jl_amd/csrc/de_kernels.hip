@@ -55,15 +55,11 @@ template <typename T> struct KArgs {
     const T *w;
     T *partial; // [n_tiles][n_trees][4 waves]
     int32_t loss_kind;
-    int32_t turbo; // DE_OPT_TURBO program: parameter operands (resolved in the interpreter loop) use the relaxed operators too
+    uint32_t cls_row_off; // parametric populations (threaded kernel): LDS byte offset of the class row (h_param)
     // vectorised staging of the X tile (threaded kernel): X 16-byte aligned with ldX == F
     int32_t x_vec;
     uint32_t f_magic; // ceil(2^32 / F) for F > 1 (e / F == umulhi(e, f_magic) while e * F < 2^32), 0 for F == 1
-    // parametric populations: a parameter table of <= PTAB_MAX elements is copied to LDS behind the rows (threaded kernel)
-    int32_t ptab_elems;   // ld_params * n_classes, or 0: read the table from global memory
-    uint32_t ptab_offset; // LDS byte offset of the copy
 };
-constexpr int PTAB_MAX = 2048;
 
 // A thread owns G groups of VW consecutive samples (VW*sizeof(T) = 16 bytes, one
 // ds_read_b128 / global_store_dwordx4 per group): samples base + g*(BLOCK*VW) + tid*VW + i.
@@ -492,9 +488,41 @@ template <> struct ImmBits<double> { typedef uint64_t type; };
 template <typename T> __device__ __forceinline__ T imm_from(typename ImmBits<T>::type b);
 template <> __device__ __forceinline__ float imm_from<float>(uint32_t b) { return __uint_as_float(b); }
 template <> __device__ __forceinline__ double imm_from<double>(uint64_t b) { return __longlong_as_double((long long)b); }
+// Handler BODIES keep that signature (b_*: forceinline); what the instruction stream points at is h_chain<T, &body>
+// below, which fetches the body's operands from the stream and TAIL-CALLS the next instruction's handler.
 #define HARGS HState<T> st, uint32_t la, typename ImmBits<T>::type imm
 #define LDSP(T, addr) (reinterpret_cast<__attribute__((address_space(3))) typename VecOf<T>::type *>((uintptr_t)(addr)))
-template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, typename ImmBits<T>::type);
+template <typename T> using BodyFn = HState<T> (*)(HState<T>, uint32_t, typename ImmBits<T>::type);
+// ---- direct-threaded dispatch ------------------------------------------------------------------------------------
+// The interpreter has no central loop: every handler ends with a tail call (s_setpc_b64) to the handler of the next
+// instruction, whose address it reads — together with its own operands — from ONE 16-byte record of the stream:
+//   Float32 record  { la, imm, next.lo, next.hi }     la  = LDS byte offset of the operand row | aux << 24
+//   Float64 record  { la, next.lo, imm.lo, imm.hi }   (next.hi = the high half of the current pc: all handlers of a
+//                                                      code object lie in one 4 GiB window, checked on the host)
+// A tree is { header record (only `next` = the first handler) , one record per instruction }, the last `next` is
+// h_end, which returns to the kernel.  The stream pointer travels in SGPRs (csrc/irpatch.py marks the parameter
+// `inreg` in the optimised IR: clang has no source spelling for it on a device function), so a dispatch is
+//   s_load_dwordx4 ; s_add_u32 ; s_addc_u32 ; s_waitcnt ; ... body ... ; s_setpc_b64        + 1 VALU (the LDS address)
+// against 11 scalar + 1 scalar load + 2 VALU for the call/return loop it replaces (prefetch copy, handler address
+// arithmetic, loop counter and branch, s_swappc/s_setpc pair).
+template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, ConstU4Ptr);
+template <typename T> __device__ __forceinline__ HandlerFn<T> next_handler(const U32x4 &w);
+template <> __device__ __forceinline__ HandlerFn<float> next_handler<float>(const U32x4 &w) {
+    return reinterpret_cast<HandlerFn<float>>(((uint64_t)w.w << 32) | w.z);
+}
+template <> __device__ __forceinline__ HandlerFn<double> next_handler<double>(const U32x4 &w) {
+    return reinterpret_cast<HandlerFn<double>>((__builtin_amdgcn_s_getpc() & 0xFFFFFFFF00000000ull) | w.y);
+}
+template <typename T> __device__ __forceinline__ typename ImmBits<T>::type rec_imm(const U32x4 &w);
+template <> __device__ __forceinline__ uint32_t rec_imm<float>(const U32x4 &w) { return w.y; }
+template <> __device__ __forceinline__ uint64_t rec_imm<double>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
+#define DE_ROW_BYTES_C (257 * 16) // LDS row stride of the threaded kernel: 256 16-byte vectors + one of padding
+template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain(HState<T> st, uint32_t lds0, ConstU4Ptr code) {
+    const U32x4 w = *code;
+    st = BODY(st, lds0 + w.x, rec_imm<T>(w)); // w.x = row byte offset | aux << 24 (no carry: LDS < 2^18 bytes)
+    [[clang::musttail]] return next_handler<T>(w)(st, lds0, code + 1);
+}
+template <typename T> __device__ __noinline__ HState<T> h_end(HState<T> st, uint32_t, ConstU4Ptr) { return st; }
 
 __device__ __forceinline__ void hpoison_impl(PoisonOf<float>::type &poison, const VecOf<float>::type &v) {
     typedef PoisonOf<float>::type P2;
@@ -511,19 +539,19 @@ template <typename T> __device__ __forceinline__ void hpoison(typename PoisonOf<
 }
 __device__ __forceinline__ bool poison_set(const PoisonOf<float>::type &p) { return (p[0] != p[0]) | (p[1] != p[1]); }
 __device__ __forceinline__ bool poison_set(const double &p) { return p != p; }
-template <typename T> __device__ __noinline__ HState<T> h_load_row(HARGS) { st.acc = *LDSP(T, la); return st; }
-template <typename T> __device__ __noinline__ HState<T> h_load_const(HARGS) {
+template <typename T> __device__ __forceinline__ HState<T> b_load_row(HARGS) { st.acc = *LDSP(T, la); return st; }
+template <typename T> __device__ __forceinline__ HState<T> b_load_const(HARGS) {
     const T c = imm_from<T>(imm);
     DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = c;
     return st;
 }
-template <typename T> __device__ __noinline__ HState<T> h_push(HARGS) { *LDSP(T, la) = st.acc; return st; }
-template <typename T> __device__ __noinline__ HState<T> h_check_row(HARGS) {
+template <typename T> __device__ __forceinline__ HState<T> b_push(HARGS) { *LDSP(T, la) = st.acc; return st; }
+template <typename T> __device__ __forceinline__ HState<T> b_check_row(HARGS) {
     const typename VecOf<T>::type v = *LDSP(T, la);
     hpoison<T>(st.poison, v);
     return st;
 }
-template <typename T> __device__ __noinline__ HState<T> h_check_acc(HARGS) { hpoison<T>(st.poison, st.acc); return st; }
+template <typename T> __device__ __forceinline__ HState<T> b_check_acc(HARGS) { hpoison<T>(st.poison, st.acc); return st; }
 
 // Correctly rounded Float32 division, 4 samples.  The compiler's expansion of `/` is
 //   v_div_scale x2, v_rcp, 6 dependent FMA/MUL (Newton + two residual corrections), v_div_fmas, v_div_fixup
@@ -625,7 +653,7 @@ template <typename T, int K, bool TB = false> __device__ __forceinline__ typenam
     return r;
 }
 // VAR bit0 = validity-test the result, bit1 = constant operand
-template <typename T, int K, int VAR, bool TB = false> __device__ __noinline__ HState<T> h_bin(HARGS) {
+template <typename T, int K, int VAR, bool TB = false> __device__ __forceinline__ HState<T> b_bin(HARGS) {
     typedef typename VecOf<T>::type V;
     V b;
     if constexpr (VAR & 2) b = splat<T>(imm);
@@ -635,7 +663,7 @@ template <typename T, int K, int VAR, bool TB = false> __device__ __noinline__ H
     return st;
 }
 // VAR bit0 = test the result, bit1 = operand is an LDS row (else acc)
-template <typename T, int K, int VAR, bool TB = false> __device__ __noinline__ HState<T> h_un(HARGS) {
+template <typename T, int K, int VAR, bool TB = false> __device__ __forceinline__ HState<T> b_un(HARGS) {
     typedef typename VecOf<T>::type V;
     V x = st.acc;
     if constexpr (VAR & 2) x = *LDSP(T, la);
@@ -645,21 +673,22 @@ template <typename T, int K, int VAR, bool TB = false> __device__ __noinline__ H
 }
 // ---- superinstructions (de_bind.h, fuse_tree): la = LDS address of row A | int8 (push row - row A) << 24
 #define DE_ROW_BYTES (257 * 16)
+static_assert(DE_ROW_BYTES == DE_ROW_BYTES_C, "row stride");
 __device__ __forceinline__ uint32_t row_a(uint32_t la) { return la & 0xFFFFFFu; }
 __device__ __forceinline__ uint32_t push_addr(uint32_t la) { return (la & 0xFFFFFFu) + (uint32_t)(((int32_t)la >> 24) * DE_ROW_BYTES); }
-template <typename T, bool PUSH, bool CHK> __device__ __noinline__ HState<T> h_loadrow_f(HARGS) {
+template <typename T, bool PUSH, bool CHK> __device__ __forceinline__ HState<T> b_loadrow_f(HARGS) {
     if constexpr (PUSH) *LDSP(T, push_addr(la)) = st.acc;
     const typename VecOf<T>::type v = *LDSP(T, PUSH ? row_a(la) : la);
     if constexpr (CHK) hpoison<T>(st.poison, v);
     st.acc = v;
     return st;
 }
-template <typename T> __device__ __noinline__ HState<T> h_loadconst_push(HARGS) {
+template <typename T> __device__ __forceinline__ HState<T> b_loadconst_push(HARGS) {
     *LDSP(T, la) = st.acc;
     st.acc = splat<T>(imm);
     return st;
 }
-template <typename T, int K, bool OUT, bool PUSH, bool CHK, bool TB = false> __device__ __noinline__ HState<T> h_unrow_f(HARGS) {
+template <typename T, int K, bool OUT, bool PUSH, bool CHK, bool TB = false> __device__ __forceinline__ HState<T> b_unrow_f(HARGS) {
     if constexpr (PUSH) *LDSP(T, push_addr(la)) = st.acc;
     const typename VecOf<T>::type x = *LDSP(T, PUSH ? row_a(la) : la);
     if constexpr (CHK) hpoison<T>(st.poison, x);
@@ -667,7 +696,7 @@ template <typename T, int K, bool OUT, bool PUSH, bool CHK, bool TB = false> __d
     if constexpr (OUT) hpoison<T>(st.poison, st.acc);
     return st;
 }
-template <typename T, int K, bool OUT, bool TB = false> __device__ __noinline__ HState<T> h_binrowc(HARGS) { // operand row tested, then acc = acc op row
+template <typename T, int K, bool OUT, bool TB = false> __device__ __forceinline__ HState<T> b_binrowc(HARGS) { // operand row tested, then acc = acc op row
     const typename VecOf<T>::type b = *LDSP(T, la);
     hpoison<T>(st.poison, b);
     st.acc = bin_apply<T, K, TB>(st.acc, b);
@@ -675,7 +704,7 @@ template <typename T, int K, bool OUT, bool TB = false> __device__ __noinline__ 
     return st;
 }
 // acc = row A op (row B | constant); row B's byte distance from row A travels in the immediate
-template <typename T, int K, bool CST, bool OUT, bool PUSH, bool TB = false> __device__ __noinline__ HState<T> h_bin2(HARGS) {
+template <typename T, int K, bool CST, bool OUT, bool PUSH, bool TB = false> __device__ __forceinline__ HState<T> b_bin2(HARGS) {
     typedef typename VecOf<T>::type V;
     if constexpr (PUSH) *LDSP(T, push_addr(la)) = st.acc;
     const uint32_t a = PUSH ? row_a(la) : la;
@@ -688,7 +717,7 @@ template <typename T, int K, bool CST, bool OUT, bool PUSH, bool TB = false> __d
     return st;
 }
 // generic handlers: de_opcode in la[31:24].  SRC: 0 row, 1 const, 2 acc.  INJ: Inf-injection of the fused deg1 kernels.
-template <typename T, int SRC, bool INJ> __device__ __noinline__ HState<T> h_gen(HARGS) {
+template <typename T, int SRC, bool INJ> __device__ __forceinline__ HState<T> b_gen(HARGS) {
     typedef typename VecOf<T>::type V;
     const uint32_t aux = la >> 24;
     VG<T, 1> a, b;
@@ -704,7 +733,7 @@ template <typename T, int SRC, bool INJ> __device__ __noinline__ HState<T> h_gen
 }
 // Unary operators outside the binder's hot set, without the detour through the generic switch (cold_op): K = gun_index
 // (de_bind.h) 3 neg 4 square 5 cube 6 abs 7 log 8 safe_log 9 sqrt 10 safe_sqrt 11 tanh 12 relu — cold_op's expressions.
-template <typename T, int K, int SRC> __device__ __noinline__ HState<T> h_un2(HARGS) { // SRC 0: row, 1: accumulator
+template <typename T, int K, int SRC> __device__ __forceinline__ HState<T> b_un2(HARGS) { // SRC 0: row, 1: accumulator
     using m = M<T>;
     typename VecOf<T>::type x = st.acc;
     if constexpr (SRC == 0) x = *LDSP(T, la & 0xFFFFFFu);
@@ -726,14 +755,14 @@ template <typename T, int K, int SRC> __device__ __noinline__ HState<T> h_un2(HA
     return st;
 }
 // acc = max(acc, b) / min(acc, b) (K 6 / 7; cold_op's expressions) with b = a row (SRC 0) or a constant (SRC 1)
-template <typename T, int K, int SRC> __device__ __noinline__ HState<T> h_bin2(HARGS) {
+template <typename T, int K, int SRC> __device__ __forceinline__ HState<T> b_maxmin(HARGS) {
     typename VecOf<T>::type b;
     if constexpr (SRC == 0) b = *LDSP(T, la & 0xFFFFFFu);
     else { const T c = imm_from<T>(imm); DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) b[i] = c; }
     DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = K == 6 ? jl_max(st.acc[i], b[i]) : jl_min(st.acc[i], b[i]);
     return st;
 }
-template <typename T> __device__ __noinline__ HState<T> h_tern(HARGS) { // acc = op3(row B, row C, acc)
+template <typename T> __device__ __forceinline__ HState<T> b_tern(HARGS) { // acc = op3(row B, row C, acc)
     const uint32_t aux = la >> 24, lb = la & 0xFFFFFFu;
     VG<T, 1> a, b, c;
     a.v[0] = st.acc;
@@ -743,49 +772,87 @@ template <typename T> __device__ __noinline__ HState<T> h_tern(HARGS) { // acc =
     st.acc = a.v[0];
     return st;
 }
-template <typename T> __device__ __noinline__ HState<T> h_nop(HARGS) { return st; }
+template <typename T> __device__ __forceinline__ HState<T> b_nop(HARGS) { return st; }
+
+// Operand = params[row, class of the sample] (src/ParametricExpression.jl:381-389).  The kernel leaves, per thread, the
+// byte offsets of its samples' parameter columns in an LDS row of their own (the "class row", whose byte offset is the
+// record's immediate) and the table's address behind them (Float64: in the same 16-byte vector; Float32: in the row
+// behind), so the handler needs no kernel argument: 4 (2) gathers through the vector cache.  la[23] = validity-test the
+// operand, la[31:24] = DOP_LOAD or the operator applied to (acc, operand) — the hot ones inline, the rest through cold_op.
+template <typename T, bool TB> __device__ __noinline__ HState<T> h_param(HState<T> st, uint32_t lds0, ConstU4Ptr code) {
+    constexpr int VW = VecOf<T>::W;
+    const U32x4 w = *code;
+    const uint32_t op = w.x >> 24;
+    const uint32_t crow = lds0 + (uint32_t)rec_imm<T>(w);
+    const U32x4 cv = *reinterpret_cast<__attribute__((address_space(3))) U32x4 *>((uintptr_t)crow);
+    uint64_t tab;
+    if constexpr (sizeof(T) == 4) {
+        typedef uint32_t U2 __attribute__((ext_vector_type(2)));
+        const U2 pv = *reinterpret_cast<__attribute__((address_space(3))) U2 *>((uintptr_t)(crow + DE_ROW_BYTES_C));
+        tab = ((uint64_t)pv.y << 32) | pv.x;
+    } else tab = ((uint64_t)cv.w << 32) | cv.z;
+    const char *__restrict__ pb = reinterpret_cast<const char *>(tab) + (size_t)(w.x & 0xFFFFu) * sizeof(T);
+    VG<T, 1> av, bv;
+    DE_UNROLL for (int i = 0; i < VW; i++) bv.v[0][i] = *reinterpret_cast<const T *>(pb + cv[i]);
+    if (w.x & (1u << 23)) hpoison<T>(st.poison, bv.v[0]);
+    switch (op) {
+    case DOP_LOAD: st.acc = bv.v[0]; break;
+    case DE_B_ADD: st.acc = bin_apply<T, 0>(st.acc, bv.v[0]); break;
+    case DE_B_SUB: st.acc = bin_apply<T, 1>(st.acc, bv.v[0]); break;
+    case DOP_RSUB: st.acc = bin_apply<T, 2>(st.acc, bv.v[0]); break;
+    case DE_B_MUL: st.acc = bin_apply<T, 3>(st.acc, bv.v[0]); break;
+    case DE_B_DIV: st.acc = bin_apply<T, 4, TB>(st.acc, bv.v[0]); break;
+    case DOP_RDIV: st.acc = bin_apply<T, 5, TB>(st.acc, bv.v[0]); break;
+    case DE_U_COS: st.acc = un_apply<T, 0, TB>(bv.v[0]); break; // unary operator on a parameter leaf
+    case DE_U_EXP: st.acc = un_apply<T, 1, TB>(bv.v[0]); break;
+    case DE_U_SIN: st.acc = un_apply<T, 2, TB>(bv.v[0]); break;
+    default: av.v[0] = st.acc; av = cold_op<T, 1>(op, av, bv); st.acc = av.v[0]; break;
+    }
+    [[clang::musttail]] return next_handler<T>(w)(st, lds0, code + 1);
+}
 
 // TB = handlers of a DE_OPT_TURBO program: same ids, the division / cos / exp / sin handlers are the relaxed-accuracy
 // instantiations (operators without a turbo version share the exact instantiation: TBK)
 template <typename T, bool TB> __global__ void de_fill_handlers(uint64_t *t) {
 #define TBK(K) (TB && (K) >= 4)
-#define HB(K) t[BOP_BIN_BASE + 4 * K + 0] = (uint64_t)&h_bin<T, K, 0, TBK(K)>; t[BOP_BIN_BASE + 4 * K + 1] = (uint64_t)&h_bin<T, K, 1, TBK(K)>; \
-              t[BOP_BIN_BASE + 4 * K + 2] = (uint64_t)&h_bin<T, K, 2, TBK(K)>; t[BOP_BIN_BASE + 4 * K + 3] = (uint64_t)&h_bin<T, K, 3, TBK(K)>;
-#define HU(K) t[BOP_UN_BASE + 4 * K + 0] = (uint64_t)&h_un<T, K, 0, TB>; t[BOP_UN_BASE + 4 * K + 1] = (uint64_t)&h_un<T, K, 1, TB>; \
-              t[BOP_UN_BASE + 4 * K + 2] = (uint64_t)&h_un<T, K, 2, TB>; t[BOP_UN_BASE + 4 * K + 3] = (uint64_t)&h_un<T, K, 3, TB>;
-    t[BOP_LOAD_ROW] = (uint64_t)&h_load_row<T>;
-    t[BOP_LOAD_CONST] = (uint64_t)&h_load_const<T>;
-    t[BOP_PUSH] = (uint64_t)&h_push<T>;
-    t[BOP_CHECK_ROW] = (uint64_t)&h_check_row<T>;
-    t[BOP_CHECK_ACC] = (uint64_t)&h_check_acc<T>;
+#define HB(K) t[BOP_BIN_BASE + 4 * K + 0] = (uint64_t)&h_chain<T, &b_bin<T, K, 0, TBK(K)>>; t[BOP_BIN_BASE + 4 * K + 1] = (uint64_t)&h_chain<T, &b_bin<T, K, 1, TBK(K)>>; \
+              t[BOP_BIN_BASE + 4 * K + 2] = (uint64_t)&h_chain<T, &b_bin<T, K, 2, TBK(K)>>; t[BOP_BIN_BASE + 4 * K + 3] = (uint64_t)&h_chain<T, &b_bin<T, K, 3, TBK(K)>>;
+#define HU(K) t[BOP_UN_BASE + 4 * K + 0] = (uint64_t)&h_chain<T, &b_un<T, K, 0, TB>>; t[BOP_UN_BASE + 4 * K + 1] = (uint64_t)&h_chain<T, &b_un<T, K, 1, TB>>; \
+              t[BOP_UN_BASE + 4 * K + 2] = (uint64_t)&h_chain<T, &b_un<T, K, 2, TB>>; t[BOP_UN_BASE + 4 * K + 3] = (uint64_t)&h_chain<T, &b_un<T, K, 3, TB>>;
+    t[BOP_LOAD_ROW] = (uint64_t)&h_chain<T, &b_load_row<T>>;
+    t[BOP_LOAD_CONST] = (uint64_t)&h_chain<T, &b_load_const<T>>;
+    t[BOP_PUSH] = (uint64_t)&h_chain<T, &b_push<T>>;
+    t[BOP_CHECK_ROW] = (uint64_t)&h_chain<T, &b_check_row<T>>;
+    t[BOP_CHECK_ACC] = (uint64_t)&h_chain<T, &b_check_acc<T>>;
     HB(0) HB(1) HB(2) HB(3) HB(4) HB(5)
     HU(0) HU(1) HU(2)
-    t[BOP_GEN_ROW] = (uint64_t)&h_gen<T, 0, false>;
-    t[BOP_GEN_CONST] = (uint64_t)&h_gen<T, 1, false>;
-    t[BOP_GEN_ACC] = (uint64_t)&h_gen<T, 2, false>;
-    t[BOP_GEN_PARAM] = (uint64_t)&h_nop<T>; // parameter operands are resolved in the interpreter loop
-    t[BOP_TERN] = (uint64_t)&h_tern<T>;
-    t[BOP_INJ_ACC] = (uint64_t)&h_gen<T, 2, true>;
-    t[BOP_INJ_ROW] = (uint64_t)&h_gen<T, 0, true>;
-#define HX(K) t[TOPX_UN_BASE + (K - 3) * 2] = (uint64_t)&h_un2<T, K, 0>; t[TOPX_UN_BASE + (K - 3) * 2 + 1] = (uint64_t)&h_un2<T, K, 1>;
+    t[BOP_GEN_ROW] = (uint64_t)&h_chain<T, &b_gen<T, 0, false>>;
+    t[BOP_GEN_CONST] = (uint64_t)&h_chain<T, &b_gen<T, 1, false>>;
+    t[BOP_GEN_ACC] = (uint64_t)&h_chain<T, &b_gen<T, 2, false>>;
+    t[BOP_GEN_PARAM] = (uint64_t)&h_param<T, TB>;
+    t[TOPX_END] = (uint64_t)&h_end<T>;
+    t[BOP_TERN] = (uint64_t)&h_chain<T, &b_tern<T>>;
+    t[BOP_INJ_ACC] = (uint64_t)&h_chain<T, &b_gen<T, 2, true>>;
+    t[BOP_INJ_ROW] = (uint64_t)&h_chain<T, &b_gen<T, 0, true>>;
+#define HX(K) t[TOPX_UN_BASE + (K - 3) * 2] = (uint64_t)&h_chain<T, &b_un2<T, K, 0>>; t[TOPX_UN_BASE + (K - 3) * 2 + 1] = (uint64_t)&h_chain<T, &b_un2<T, K, 1>>;
     HX(3) HX(4) HX(5) HX(6) HX(7) HX(8) HX(9) HX(10) HX(11) HX(12)
 #undef HX
-    t[TOPX_BIN_BASE + 0] = (uint64_t)&h_bin2<T, 6, 0>; t[TOPX_BIN_BASE + 1] = (uint64_t)&h_bin2<T, 6, 1>;
-    t[TOPX_BIN_BASE + 2] = (uint64_t)&h_bin2<T, 7, 0>; t[TOPX_BIN_BASE + 3] = (uint64_t)&h_bin2<T, 7, 1>;
+    t[TOPX_BIN_BASE + 0] = (uint64_t)&h_chain<T, &b_maxmin<T, 6, 0>>; t[TOPX_BIN_BASE + 1] = (uint64_t)&h_chain<T, &b_maxmin<T, 6, 1>>;
+    t[TOPX_BIN_BASE + 2] = (uint64_t)&h_chain<T, &b_maxmin<T, 7, 0>>; t[TOPX_BIN_BASE + 3] = (uint64_t)&h_chain<T, &b_maxmin<T, 7, 1>>;
 #undef HB
 #undef HU
     // superinstructions
-    t[top_loadrow(false, false)] = (uint64_t)&h_load_row<T>;
-    t[top_loadrow(false, true)] = (uint64_t)&h_loadrow_f<T, false, true>;
-    t[top_loadrow(true, false)] = (uint64_t)&h_loadrow_f<T, true, false>;
-    t[top_loadrow(true, true)] = (uint64_t)&h_loadrow_f<T, true, true>;
-    t[TOP_LOADCONST_PUSH] = (uint64_t)&h_loadconst_push<T>;
-#define TU1(K, O, P) t[top_unrow(K, O, P, false)] = (uint64_t)&h_unrow_f<T, K, O, P, false, TB>; t[top_unrow(K, O, P, true)] = (uint64_t)&h_unrow_f<T, K, O, P, true, TB>;
+    t[top_loadrow(false, false)] = (uint64_t)&h_chain<T, &b_load_row<T>>;
+    t[top_loadrow(false, true)] = (uint64_t)&h_chain<T, &b_loadrow_f<T, false, true>>;
+    t[top_loadrow(true, false)] = (uint64_t)&h_chain<T, &b_loadrow_f<T, true, false>>;
+    t[top_loadrow(true, true)] = (uint64_t)&h_chain<T, &b_loadrow_f<T, true, true>>;
+    t[TOP_LOADCONST_PUSH] = (uint64_t)&h_chain<T, &b_loadconst_push<T>>;
+#define TU1(K, O, P) t[top_unrow(K, O, P, false)] = (uint64_t)&h_chain<T, &b_unrow_f<T, K, O, P, false, TB>>; t[top_unrow(K, O, P, true)] = (uint64_t)&h_chain<T, &b_unrow_f<T, K, O, P, true, TB>>;
 #define TU(K) TU1(K, false, false) TU1(K, false, true) TU1(K, true, false) TU1(K, true, true)
     TU(0) TU(1) TU(2)
-#define TBC(K) t[top_binrowc(K, false)] = (uint64_t)&h_binrowc<T, K, false, TBK(K)>; t[top_binrowc(K, true)] = (uint64_t)&h_binrowc<T, K, true, TBK(K)>;
+#define TBC(K) t[top_binrowc(K, false)] = (uint64_t)&h_chain<T, &b_binrowc<T, K, false, TBK(K)>>; t[top_binrowc(K, true)] = (uint64_t)&h_chain<T, &b_binrowc<T, K, true, TBK(K)>>;
     TBC(0) TBC(1) TBC(2) TBC(3) TBC(4) TBC(5)
-#define TB1(K, C, O) t[top_bin2(K, C, O, false)] = (uint64_t)&h_bin2<T, K, C, O, false, TBK(K)>; t[top_bin2(K, C, O, true)] = (uint64_t)&h_bin2<T, K, C, O, true, TBK(K)>;
+#define TB1(K, C, O) t[top_bin2(K, C, O, false)] = (uint64_t)&h_chain<T, &b_bin2<T, K, C, O, false, TBK(K)>>; t[top_bin2(K, C, O, true)] = (uint64_t)&h_chain<T, &b_bin2<T, K, C, O, true, TBK(K)>>;
 #define TBF(K) TB1(K, false, false) TB1(K, false, true) TB1(K, true, false) TB1(K, true, true)
     TBF(0) TBF(1) TBF(2) TBF(3) TBF(4) TBF(5)
 #undef TU1
@@ -797,7 +864,7 @@ template <typename T, bool TB> __global__ void de_fill_handlers(uint64_t *t) {
 }
 
 template <typename T, bool PARAMS, bool LOSS = false>
-__global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a, const uint64_t hbase, const uint32_t param_off) {
+__global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a) {
     typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
     constexpr int BLK = 256, TILE = BLK * VW, ROWV = BLK + 1;
@@ -850,19 +917,26 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
             }
         }
     }
-    uint32_t cls[VW]; // element offset of the sample's parameter column (the table has < 2^32 elements)
     if (PARAMS) {
+        // the class row: byte offsets of this thread's samples' parameter columns (the table has < 2^32 bytes: checked
+        // on the host), and the table's address for h_param (see there)
+        uint32_t cv[4] = {0u, 0u, 0u, 0u};
         DE_UNROLL for (int i = 0; i < VW; i++) {
             int64_t jj = base + tid * VW + i;
             jj = jj < last ? jj : last;
-            cls[i] = (uint32_t)(a.ld_params * clamp_class((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
-                                                                             : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base,
-                                                          a.n_classes));
+            cv[i] = (uint32_t)((uint64_t)a.ld_params * sizeof(T) *
+                               (uint64_t)clamp_class((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
+                                                                       : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base,
+                                                     a.n_classes));
         }
-        // a small table ([P, C] with few classes) is read once per workgroup; the interpreter then gathers from LDS
-        // (a global load inside the loop costs a full memory round trip per parameter leaf)
-        T *__restrict__ ptab = reinterpret_cast<T *>(smem_raw + a.ptab_offset);
-        for (int e = tid; e < a.ptab_elems; e += BLK) ptab[e] = a.params[e];
+        const uint64_t tab = (uint64_t)(uintptr_t)a.params;
+        unsigned char *crow = smem_raw + a.cls_row_off + tid * 16;
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<U32x4 *>(crow) = U32x4{cv[0], cv[1], cv[2], cv[3]};
+            *reinterpret_cast<U32x4 *>(crow + DE_ROW_BYTES) = U32x4{(uint32_t)tab, (uint32_t)(tab >> 32), 0u, 0u};
+        } else {
+            *reinterpret_cast<U32x4 *>(crow) = U32x4{cv[0], cv[1], (uint32_t)tab, (uint32_t)(tab >> 32)};
+        }
     }
     __syncthreads();
 
@@ -886,50 +960,14 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a,
         }
     }
 
-    int pe = code_off[t0];
     for (int tree = t0; tree < t1; ++tree) {
-        int pc = pe;
-        pe = code_off[tree + 1];
+        // code_off[tree] = the tree's header record: `next` = its first handler; the chain ends in h_end
+        const ConstU4Ptr rec = code + code_off[tree];
         HState<T> st;
         DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
         st.poison = typename PoisonOf<T>::type{};
-        U32x4 nxt = code[pc];
-        for (; pc < pe; ++pc) {
-            const U32x4 w = nxt;
-            nxt = code[pc + 1];
-            if (PARAMS && w.x == param_off) { // operand = params[row, class]: needs kernel arguments
-                const uint32_t op = w.y >> 24;
-                VG<T, 1> av, bv;
-                if (a.ptab_elems) {
-                    const uint32_t t0_ = (uint32_t)(uintptr_t)smem_raw + a.ptab_offset + (w.y & 0xFFFFu) * (uint32_t)sizeof(T);
-                    DE_UNROLL for (int i = 0; i < VW; i++)
-                        bv.v[0][i] = *reinterpret_cast<__attribute__((address_space(3))) T *>((uintptr_t)(t0_ + cls[i] * (uint32_t)sizeof(T)));
-                } else {
-                    const T *__restrict__ s_ = a.params + (w.y & 0xFFFFu);
-                    DE_UNROLL for (int i = 0; i < VW; i++) bv.v[0][i] = s_[cls[i]];
-                }
-                if (w.y & (1u << 23)) hpoison<T>(st.poison, bv.v[0]);
-                switch (op) { // the hot binary operators inline (same arithmetic as their handlers); the rest through the generic switch
-                case DOP_LOAD: st.acc = bv.v[0]; break;
-                case DE_B_ADD: st.acc = bin_apply<T, 0>(st.acc, bv.v[0]); break;
-                case DE_B_SUB: st.acc = bin_apply<T, 1>(st.acc, bv.v[0]); break;
-                case DOP_RSUB: st.acc = bin_apply<T, 2>(st.acc, bv.v[0]); break;
-                case DE_B_MUL: st.acc = bin_apply<T, 3>(st.acc, bv.v[0]); break;
-                case DE_B_DIV: st.acc = a.turbo ? bin_apply<T, 4, true>(st.acc, bv.v[0]) : bin_apply<T, 4>(st.acc, bv.v[0]); break;
-                case DOP_RDIV: st.acc = a.turbo ? bin_apply<T, 5, true>(st.acc, bv.v[0]) : bin_apply<T, 5>(st.acc, bv.v[0]); break;
-                case DE_U_COS: st.acc = a.turbo ? un_apply<T, 0, true>(bv.v[0]) : un_apply<T, 0>(bv.v[0]); break; // unary operator on a parameter leaf
-                case DE_U_EXP: st.acc = a.turbo ? un_apply<T, 1, true>(bv.v[0]) : un_apply<T, 1>(bv.v[0]); break;
-                case DE_U_SIN: st.acc = a.turbo ? un_apply<T, 2, true>(bv.v[0]) : un_apply<T, 2>(bv.v[0]); break;
-                default: av.v[0] = st.acc; av = cold_op<T, 1>(op, av, bv); st.acc = av.v[0]; break;
-                }
-                continue;
-            }
-            const HandlerFn<T> fn = reinterpret_cast<HandlerFn<T>>(hbase + w.x);
-            typename ImmBits<T>::type imm;
-            if constexpr (sizeof(T) == 4) imm = w.z;
-            else imm = ((uint64_t)w.w << 32) | w.z;
-            st = fn(st, lds0 + w.y, imm); // w.y = row byte offset | aux << 24 (no carry: LDS < 2^18 bytes)
-        }
+        const U32x4 hd = *rec;
+        st = reinterpret_cast<HandlerFn<T>>(((uint64_t)hd.w << 32) | hd.z)(st, lds0, rec + 1);
         if constexpr (LOSS) {
             // sum_j w_j * l(out_j - y_j) over this wave's 64*VW samples -> one partial per (tile, tree, wave)
             T s = T(0);
@@ -1048,8 +1086,6 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
     constexpr int VW = VecOf<T>::W;
     constexpr int TILE = BLK * VW * G;
     KArgs<T> a;
-    a.ptab_elems = 0;
-    a.ptab_offset = 0;
     a.code = e.code;
     a.code_off = e.code_off;
     a.X = static_cast<const T *>(e.X);
@@ -1110,16 +1146,16 @@ static hipError_t launch_eval_geo(const EvalArgs &a, hipStream_t stream, const c
 // ---- threaded variant: handler table + launch ---------------------------------------------
 template <typename T, bool TB> static hipError_t fetch_handlers(uint64_t *host_table) {
     uint64_t *d = nullptr;
-    hipError_t st = hipMalloc(reinterpret_cast<void **>(&d), TOPX_COUNT * sizeof(uint64_t));
+    hipError_t st = hipMalloc(reinterpret_cast<void **>(&d), TOPX_TABLE * sizeof(uint64_t));
     if (st != hipSuccess) return st;
     hipLaunchKernelGGL((de_fill_handlers<T, TB>), dim3(1), dim3(1), 0, 0, d);
-    st = hipMemcpy(host_table, d, TOPX_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    st = hipMemcpy(host_table, d, TOPX_TABLE * sizeof(uint64_t), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     return st;
 }
 
 hipError_t eval_handler_table(int dtype, bool turbo, uint64_t *table) {
-    static uint64_t cache[3][TOPX_COUNT]; // Float32, Float64, Float32 turbo (Float64 has no relaxed operators)
+    static uint64_t cache[3][TOPX_TABLE]; // Float32, Float64, Float32 turbo (Float64 has no relaxed operators)
     static bool have[3] = {false, false, false};
     static std::mutex mu; // contexts on several host threads may ask at once
     const std::lock_guard<std::mutex> lock(mu);
@@ -1129,7 +1165,7 @@ hipError_t eval_handler_table(int dtype, bool turbo, uint64_t *table) {
         if (st != hipSuccess) return st;
         have[k] = true;
     }
-    for (int i = 0; i < (int)TOPX_COUNT; i++) table[i] = cache[k][i];
+    for (int i = 0; i < (int)TOPX_TABLE; i++) table[i] = cache[k][i];
     return hipSuccess;
 }
 
@@ -1140,8 +1176,6 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     constexpr int VW = VecOf<T>::W;
     constexpr int TILE = 256 * VW;
     KArgs<T> a;
-    a.ptab_elems = 0;
-    a.ptab_offset = 0;
     a.code = e.code;
     a.code_off = e.code_off;
     a.X = static_cast<const T *>(e.X);
@@ -1166,21 +1200,18 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.f_magic = e.F > 1 ? (uint32_t)((0x100000000ull + (uint64_t)e.F - 1) / (uint64_t)e.F) : 0u;
     a.x_vec = 0;
     a.f_magic = 0;
-    a.turbo = e.turbo ? 1 : 0;
     int32_t tpc, nch;
     plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc);
     a.trees_per_chunk = tpc;
     a.n_chunks = nch;
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    size_t lds = (size_t)(a.F + a.n_slots + env_int("DE_EXTRA_LDS_ROWS", 0)) * 257 * 16;
-    a.ptab_elems = 0;
-    a.ptab_offset = (uint32_t)lds;
-    if (e.uses_params && e.ld_params * e.n_classes <= PTAB_MAX && env_int("DE_PARAM_LDS", 1)) {
-        a.ptab_elems = (int32_t)(e.ld_params * e.n_classes);
-        lds += (size_t)a.ptab_elems * sizeof(T);
-    }
-    void (*kern)(const KArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_eval_threaded_kernel<T, true> : de_eval_threaded_kernel<T, false>;
+    // rows: X, spill slots, then (parametric) the class row [+ the table-pointer row for Float32] of h_param
+    a.cls_row_off = (uint32_t)((size_t)(a.F + a.n_slots) * 257 * 16);
+    const int prm_rows = e.uses_params ? (sizeof(T) == 4 ? 2 : 1) : 0;
+    if (e.uses_params && (uint64_t)e.ld_params * (uint64_t)e.n_classes * sizeof(T) > 0xFFFFFFFFull) return hipErrorInvalidValue; // 32-bit column offsets
+    const size_t lds = (size_t)(a.F + a.n_slots + prm_rows + env_int("DE_EXTRA_LDS_ROWS", 0)) * 257 * 16;
+    void (*kern)(const KArgs<T>) = e.uses_params ? de_eval_threaded_kernel<T, true> : de_eval_threaded_kernel<T, false>;
     a.y = a.w = nullptr;
     a.partial = nullptr;
     a.loss_kind = 0;
@@ -1196,7 +1227,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (st != hipSuccess) return st;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a, e.handler_base, e.param_handler_off);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
     hipError_t st = hipGetLastError();
     if (st != hipSuccess || !e.loss) return st;
     int32_t n_segs = 1;

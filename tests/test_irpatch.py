@@ -15,28 +15,38 @@ SPEC.loader.exec_module(irpatch)
 
 IR = '''
 %"struct.de::HState" = type { <4 x float>, <2 x float>, [8 x i8] }
-define internal %"struct.de::HState" @h_a(<4 x float> %0, i32 %1) #0 {
+declare ptr addrspace(4) @llvm.amdgcn.queue.ptr()
+declare ptr addrspace(4) @llvm.amdgcn.implicitarg.ptr()
+define internal %"struct.de::HState" @h_a(<4 x float> %0, i32 %1, ptr addrspace(4) noundef %2) #0 {
   ret %"struct.de::HState" undef
 }
-define internal %"struct.de::HState" @h_b(<4 x float> %0, i32 %1) #1 {
+define internal %"struct.de::HState" @h_b(<4 x float> %0, i32 %1, ptr addrspace(4) noundef %2) #1 {
+  %q = call ptr addrspace(4) @llvm.amdgcn.queue.ptr()
+  %n = load ptr, ptr addrspace(4) %2
+  %r = musttail call %"struct.de::HState" %n(<4 x float> %0, i32 %1, ptr addrspace(4) noundef %2) #3
+  ret %"struct.de::HState" %r
+}
+define internal %"struct.de::HState" @h_c(<4 x float> %0, i32 %1, ptr addrspace(4) noundef %2) #1 {
+  call void @other(i32 %1)
   ret %"struct.de::HState" undef
 }
 define void @other(i32 %x) #2 {
+  %p = call ptr addrspace(4) @llvm.amdgcn.implicitarg.ptr()
   ret void
 }
-define protected amdgpu_kernel void @kern(ptr %fn) #2 {
-  %r = tail call %"struct.de::HState" %fn(<4 x float> zeroinitializer, i32 0) #3
-  %d = tail call %"struct.de::HState" @h_a(<4 x float> zeroinitializer, i32 0) #3
+define protected amdgpu_kernel void @kern(ptr %fn, ptr addrspace(4) %code) #2 {
+  %r = tail call %"struct.de::HState" %fn(<4 x float> zeroinitializer, i32 0, ptr addrspace(4) %code) #3
+  %d = tail call %"struct.de::HState" @h_a(<4 x float> zeroinitializer, i32 0, ptr addrspace(4) %code) #3
   ret void
 }
 attributes #0 = { nounwind "amdgpu-no-dispatch-ptr" "amdgpu-no-queue-ptr" "amdgpu-no-workitem-id-x" }
-attributes #1 = { nounwind "amdgpu-no-dispatch-ptr" "amdgpu-no-workitem-id-x" }
+attributes #1 = { nounwind }
 attributes #2 = { nounwind }
 attributes #3 = { convergent nounwind }
 '''
 
 
-def test_only_indirect_handler_calls_get_the_attributes_all_callees_share(tmp_path):
+def test_only_indirect_handler_calls_get_the_attributes_every_possible_callee_allows(tmp_path):
     src, dst = tmp_path / "k.ll", tmp_path / "k2.ll"
     src.write_text(IR)
     irpatch.main(str(src), str(dst))
@@ -47,9 +57,18 @@ def test_only_indirect_handler_calls_get_the_attributes_all_callees_share(tmp_pa
     assert direct.group(1) == "3"  # the direct call keeps its group
     new_group = re.search(r'^attributes #%s = \{(.*)\}$' % ind.group(1), out, re.M).group(1)
     assert ind.group(1) != "3" and "convergent" in new_group
+    # inputs no handler reads — itself or through a direct callee — are dropped, whether the attributor said so (h_a) or
+    # the closed-world body check did (h_b ends in an indirect tail call: the attributor gives up on it)
     assert '"amdgpu-no-dispatch-ptr"' in new_group and '"amdgpu-no-workitem-id-x"' in new_group
-    assert '"amdgpu-no-queue-ptr"' not in new_group  # h_b does not carry it
-    assert '"amdgpu-no-implicitarg-ptr"' not in new_group  # nobody carries it
+    assert '"amdgpu-no-queue-ptr"' not in new_group       # h_b reads the queue pointer
+    assert '"amdgpu-no-implicitarg-ptr"' not in new_group  # h_c calls @other, which reads the implicit-argument pointer
+    assert '"amdgpu-no-heap-ptr"' not in new_group         # ... and everything that lives behind it
+    # the handler definitions get the same attributes (the inputs are not live-ins either)
+    hb = re.search(r'^define [^\n]* @h_b\([^\n]*\) #(\d+)', out, re.M)
+    assert '"amdgpu-no-dispatch-ptr"' in re.search(r'^attributes #%s = \{(.*)\}$' % hb.group(1), out, re.M).group(1)
+    # the stream pointer of every handler definition and indirect handler call is `inreg`; the direct call is left alone
+    assert out.count("ptr addrspace(4) inreg") == 5  # 3 definitions + the musttail call + the kernel's indirect call
+    assert "ptr addrspace(4) inreg" not in direct.group(0)
 
 
 def test_refuses_a_module_without_handlers_or_without_indirect_calls(tmp_path):
@@ -57,6 +76,9 @@ def test_refuses_a_module_without_handlers_or_without_indirect_calls(tmp_path):
     src.write_text("define void @f() #0 {\n  ret void\n}\nattributes #0 = { nounwind }\n")
     with pytest.raises(SystemExit):
         irpatch.main(str(src), str(dst))
-    src.write_text(IR.replace('%r = tail call %"struct.de::HState" %fn(<4 x float> zeroinitializer, i32 0) #3\n', ''))
+    no_indirect = IR.replace('  %r = tail call %"struct.de::HState" %fn(<4 x float> zeroinitializer, i32 0, ptr addrspace(4) %code) #3\n', '')
+    no_indirect = no_indirect.replace('  %r = musttail call %"struct.de::HState" %n(<4 x float> %0, i32 %1, ptr addrspace(4) noundef %2) #3\n', '')
+    assert no_indirect.count("%r") == 1
+    src.write_text(no_indirect)
     with pytest.raises(SystemExit):
         irpatch.main(str(src), str(dst))

@@ -274,7 +274,7 @@ def test_valu_slot_table_layout():
         w = api.lower_tape_stage(tape, consts, 5, 3)
         used.update(int(v) for v in w[:, 0])
     assert used and all(u in slots for u in used)
-    assert slots[5]["valu_slots"] == 2  # acc + row: two v_pk_add_f32
+    assert slots[5]["valu_slots"] == 3  # acc + row: the LDS address add + two v_pk_add_f32
     committed = os.path.join(ROOT, "profiles", "valu_slots.json")
     if os.path.exists(committed):
         with open(committed) as fh:

@@ -8,7 +8,7 @@ The eval kernel is VALU-issue bound, so the binding ceiling of
 per wavefront.  This tool disassembles the device code object build.sh links for de_kernels.hip
 (csrc/_obj/irp_de_kernels/k.out), splits it per handler function and reports, per handler id of
 csrc/de_bind.h, the VALU slots on the SHORTEST path from the function entry to its return
-(`s_setpc_b64`): handlers keep their rare cases (division outside [2^-40, 2^40], |x| > 1e5 for
+(`s_setpc_b64` — since the direct-threaded dispatch, the tail call to the next handler): handlers keep their rare cases (division outside [2^-40, 2^40], |x| > 1e5 for
 cos/sin, the extremum select) behind wave-uniform branches, and the shortest path is the one a
 wavefront of ordinary data takes.  Quarter-rate transcendental instructions (v_rcp/v_exp/v_log/
 v_sqrt/v_rsq/v_sin/v_cos_f32) count 4 slots, every other v_* instruction 1 (v_pk_* = one slot
@@ -110,7 +110,7 @@ def handler_names(ty: str, turbo: bool = False):
     names[GEN + 0] = f"h_gen<{ty}, 0, false>"
     names[GEN + 1] = f"h_gen<{ty}, 1, false>"
     names[GEN + 2] = f"h_gen<{ty}, 2, false>"
-    names[GEN + 3] = f"h_nop<{ty}>"
+    names[GEN + 3] = f"h_param<{ty}, {tb}>"
     names[GEN + 4] = f"h_tern<{ty}>"
     names[GEN + 5] = f"h_gen<{ty}, 2, true>"
     names[GEN + 6] = f"h_gen<{ty}, 0, true>"
@@ -143,7 +143,7 @@ def handler_names(ty: str, turbo: bool = False):
             names[TOP_COUNT + (k - 3) * 2 + s] = f"h_un2<{ty}, {k}, {s}>"
     XB = TOP_COUNT + 20
     for i, (k, s) in enumerate(((6, 0), (6, 1), (7, 0), (7, 1))):
-        names[XB + i] = f"h_bin2<{ty}, {k}, {s}>"
+        names[XB + i] = f"h_maxmin<{ty}, {k}, {s}>"
     return names, dict(BOP_COUNT=BOP_COUNT, TOP_COUNT=TOP_COUNT, TOPX_COUNT=XB + 4)
 
 
@@ -151,7 +151,12 @@ def table(obj, ty="float", turbo=False):
     fns = functions(obj)
     by_short = {}
     for full, code in fns.items():
-        m = re.search(r"de::(h_\w+<[^(]*>)\(", full)
+        # direct-threaded handlers are h_chain<T, &body>: index them by the body's name with the historical h_ prefix
+        m = re.search(r"h_chain<\w+, &de::HState<\w+> de::b_(\w+<[^(]*>)\(", full)
+        if m:
+            by_short["h_" + m.group(1)] = code
+            continue
+        m = re.search(r"de::(h_param<[^(]*>)\(", full)
         if m:
             by_short[m.group(1)] = code
     names, counts = handler_names(ty, turbo)
@@ -177,7 +182,7 @@ def main():
     turbo = table(a.obj, "float", True)[0] if a.dtype == "f32" else {}
     doc = dict(source=f"tools/valu_slots.py over {os.path.relpath(a.obj, ROOT)} (llvm-objdump of the gfx950 code object)",
                rule="VALU issue slots on the shortest entry->return path; quarter-rate transcendentals count 4",
-               dispatch_overhead_valu=2,  # v_add (LDS address) + v_mov (immediate) before s_swappc in the interpreter loop
+               dispatch_overhead_valu=0,  # direct-threaded dispatch: the LDS address add is inside the handler (counted there)
                per_tree_overhead_valu=8,  # state zeroing + output address + ballot compare around the loop
                layout=counts, handlers={str(k): v for k, v in sorted(slots.items())},
                handlers_turbo={str(k): v for k, v in sorted(turbo.items())})  # the same ids in a DE_OPT_TURBO program
