@@ -166,24 +166,26 @@ def valu_ceiling(pop, n_trees, units, kernel_ms, turbo=False):
         n_disp += len(ids)
         for k, c in zip(*np.unique(ids, return_counts=True)):
             hist[int(k)] = hist.get(int(k), 0) + int(c)
-    slots, missing = 0.0, 0
+    cycles, missing = 0.0, 0
     for k, c in hist.items():
         h = tab["handlers_turbo" if turbo else "handlers"].get(str(k))
         if h is None:
             missing += c
             continue
-        slots += c * h["valu_slots"]
-    slots += n_disp * tab["dispatch_overhead_valu"] + n_trees * tab["per_tree_overhead_valu"]
-    per_tree_wave = slots / n_trees
+        cycles += c * h["valu_cycles"]
+    cycles += n_trees * tab["per_tree_overhead_cycles"]
+    per_tree_wave = cycles / n_trees
     samples_per_wave = 256  # 64 lanes x 4 Float32 samples
     tree_waves = units / samples_per_wave
-    simds, clock = 256 * 4, 2.4e9  # MI355X: 256 CUs x 4 SIMD16, 2.4 GHz peak engine clock
-    floor_ms = tree_waves * per_tree_wave * 4 / (simds * clock) * 1e3  # a wave64 VALU instruction issues over 4 cycles
-    return dict(slots_per_tree_wave=per_tree_wave, dispatches_per_tree=n_disp / n_trees, samples_per_wave=samples_per_wave,
-                simd_cycles_per_tree_wave=per_tree_wave * 4, clock_ghz=2.4, simds=simds, floor_ms=floor_ms,
-                frac=floor_ms / kernel_ms, dispatches_without_slot_count=missing,
-                source="profiles/valu_slots.json (tools/valu_slots.py: shortest-path VALU slots per handler from the gfx950 ISA) "
-                       "x de_program_dump(stage 3) dispatch histogram of this population")
+    simds, peak, sustained = 256 * 4, 2.4e9, 2.08e9  # MI355X: 256 CUs x 4 SIMDs; peak engine clock; clock an all-VALU loop sustains
+    floor_ms = tree_waves * per_tree_wave / (simds * peak) * 1e3
+    return dict(simd_cycles_per_tree_wave=per_tree_wave, dispatches_per_tree=n_disp / n_trees, samples_per_wave=samples_per_wave,
+                clock_ghz=2.4, simds=simds, floor_ms=floor_ms, frac=floor_ms / kernel_ms,
+                sustained_clock_ghz=2.08, floor_ms_at_sustained_clock=floor_ms * peak / sustained,
+                frac_at_sustained_clock=floor_ms * peak / sustained / kernel_ms, dispatches_without_cycle_count=missing,
+                source="profiles/valu_slots.json (tools/valu_slots.py: VALU cycles per handler on its shortest path, gfx950 ISA priced with "
+                       "the per-instruction issue costs measured by tools/probe/valu_rate.py, profiles/r2_valu_rate.json; sustained clock: "
+                       "profiles/r2_clock_probe.json) x de_program_dump(stage 3) dispatch histogram of this population")
 
 
 def main():
@@ -196,6 +198,7 @@ def main():
     ap.add_argument("--turbo", action="store_true",
                     help="EvalContext(turbo=true): the relaxed-accuracy Float32 operators (DE_OPT_TURBO) for the whole run; "
                          "without it the plain-eval workloads time the exact mode and report turbo in a `turbo` sub-object")
+    ap.add_argument("--no-turbo-leg", action="store_true", help="skip the secondary turbo timing (profiling runs: one kernel variant per process)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -360,7 +363,7 @@ def main():
         elapsed = float(t.item())
 
     turbo_res = None
-    if not args.turbo and not (is_param or is_grad or is_lossgrad or is_loss):
+    if not args.turbo and not args.no_turbo_leg and not (is_param or is_grad or is_lossgrad or is_loss):
         # the same steps with the reference's turbo option (DE_OPT_TURBO), reported beside the exact-mode line
         pop_t = api.Population(trees, ops, np.float32, n_features=5, eval_context=api.EvalContext(turbo=True), ctx=ctx)
 

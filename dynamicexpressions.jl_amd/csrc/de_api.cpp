@@ -88,10 +88,10 @@ struct de_program {
     std::vector<BoundInstr> tcode;      // threaded form: handler address offsets + LDS byte offsets
     std::vector<BoundInstr> fbcode;     // fused (superinstruction) form the threaded code is made from
     std::vector<int32_t> tcode_off;     // n_trees + 1 offsets into tcode / fbcode
-    // what the threaded kernel reads (de_kernels.hip "direct-threaded dispatch"): per tree a header record and one
-    // 16-byte record per instruction {operand word, immediate, address of the NEXT handler}; made from tcode
+    // what the threaded kernel reads (de_kernels.hip "direct-threaded dispatch"): one 16-byte record per instruction
+    // {operand word, immediate, address of its handler} and an end record per tree; made from tcode
     std::vector<BoundInstr> ccode;
-    std::vector<int32_t> ccode_off;     // n_trees + 1: header record of each tree
+    std::vector<int32_t> ccode_off;     // n_trees + 1: first record of each tree
     uint64_t end_handler = 0;
     bool threaded = false;
     bool direct = false;                // X too wide for the LDS tile (decided at creation)
@@ -413,7 +413,7 @@ static void make_chained(de_program *p);
 static int make_threaded(de_ctx *c, de_program *p) {
     p->threaded = false;
     // the LDS-staged kernels need (n_features + n_slots) rows of 4112 B; wider X uses the direct variant
-    p->direct = ((size_t)p->n_features + (size_t)p->n_slots) * 257 * 16 > 150 * 1024;
+    p->direct = ((size_t)p->n_features + (size_t)p->n_slots) * 257 * 16 > 150 * 1024; // (the flat-switch geometry decides)
     if (p->direct || !eval_uses_threaded()) return DE_OK;
     if ((int64_t)p->n_features + p->n_slots > 4000) return DE_OK; // row offsets must fit 24 bits
     uint64_t table[TOPX_TABLE];
@@ -427,7 +427,7 @@ static int make_threaded(de_ctx *c, de_program *p) {
         if (p->dtype != DE_F32 && (table[i] >> 32) != (table[0] >> 32)) return DE_OK;
     }
     const bool hot_unary = !getenv("DE_NO_CONST_UNARY_HOT"); // unary operators outside the binder's hot set: their own handlers
-    const uint32_t row_bytes = 257 * 16;
+    const uint32_t row_bytes = (uint32_t)TROW_BYTES;
     // superinstructions (de_bind.h): fewer dispatches for the same arithmetic
     const char *nf = getenv("DE_NO_FUSE");
     const bool fuse = !(nf && *nf == '1');
@@ -478,28 +478,27 @@ static int make_threaded(de_ctx *c, de_program *p) {
     return DE_OK;
 }
 
-// The device layout of the threaded program (see de_kernels.hip): record i of tree t = {tcode[i].arg, immediate,
-// address of the handler of instruction i + 1 (h_end after the last)}, behind a header record that points at the first.
-// BoundInstr fields by word: Float32 {bop: operand word, arg: imm, lo/hi: next}; Float64 {bop: operand word, arg: next.lo, lo/hi: imm}.
+// The device layout of the threaded program (see de_kernels.hip): one record per instruction {operand word, immediate,
+// address of ITS handler} and an end record per tree (h_end).  BoundInstr fields by word: Float32 {bop: operand word,
+// arg: imm, lo/hi: handler}; Float64 {bop: operand word, arg: handler.lo, lo/hi: imm}.
 static void make_chained(de_program *p) {
     const bool f32 = p->dtype == DE_F32;
     p->ccode.assign(p->tcode.size() + (size_t)p->n_trees, BoundInstr{0u, 0u, 0u, 0u});
     p->ccode_off.assign((size_t)p->n_trees + 1, 0);
+    auto put = [&](BoundInstr &r, uint32_t la, uint32_t lo, uint32_t hi, uint64_t handler) {
+        r.bop = la;
+        if (f32) { r.arg = lo; r.lo = (uint32_t)handler; r.hi = (uint32_t)(handler >> 32); }
+        else { r.arg = (uint32_t)handler; r.lo = lo; r.hi = hi; }
+    };
     for (int64_t t = 0; t < p->n_trees; t++) {
         const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1];
         const size_t h = (size_t)i0 + (size_t)t;
         p->ccode_off[(size_t)t] = (int32_t)h;
-        const uint64_t first = i1 > i0 ? p->handler_base + p->tcode[(size_t)i0].bop : p->end_handler;
-        p->ccode[h].lo = (uint32_t)first;
-        p->ccode[h].hi = (uint32_t)(first >> 32);
         for (int32_t i = i0; i < i1; i++) {
             const BoundInstr &s = p->tcode[(size_t)i];
-            const uint64_t next = i + 1 < i1 ? p->handler_base + p->tcode[(size_t)i + 1].bop : p->end_handler;
-            BoundInstr &r = p->ccode[h + 1 + (size_t)(i - i0)];
-            r.bop = s.arg;
-            if (f32) { r.arg = s.lo; r.lo = (uint32_t)next; r.hi = (uint32_t)(next >> 32); }
-            else { r.arg = (uint32_t)next; r.lo = s.lo; r.hi = s.hi; }
+            put(p->ccode[h + (size_t)(i - i0)], s.arg, s.lo, s.hi, p->handler_base + s.bop);
         }
+        put(p->ccode[h + (size_t)(i1 - i0)], 0u, 0u, 0u, p->end_handler);
     }
     p->ccode_off[(size_t)p->n_trees] = (int32_t)p->ccode.size();
 }
@@ -802,10 +801,10 @@ int de_program_set_consts(de_program_t *p, const void *consts) {
             p->grad_sites.clear();
             for (size_t i = 0; i < src.size(); i++)
                 if (p->bsite[i] >= 0) {
-                    // record of tcode[j] in the chained stream: one header record per tree before it
+                    // record of tcode[j] in the chained stream: one end record per preceding tree
                     const int32_t j = p->tsite[i];
                     const int64_t tree = (std::upper_bound(p->tcode_off.begin(), p->tcode_off.end(), j) - p->tcode_off.begin()) - 1;
-                    p->eval_sites.push_back({(int32_t)i, p->bsite[i], j, (int32_t)(j + tree + 1)});
+                    p->eval_sites.push_back({(int32_t)i, p->bsite[i], j, (int32_t)(j + tree)});
                 }
             if (!p->gbsite.empty())
                 for (size_t i = 0; i < p->code.size(); i++) {

@@ -261,8 +261,8 @@ __device__ __forceinline__ DeF2 fast_exp_f32x2(DeF2 x) {
 // ext/DynamicExpressionsLoopVectorizationExt.jl:24-43, whose results drift from Base's by design,
 // test/test_supposition_consistency.jl:106-108).  Contract: <= 1e-6 relative on ordinary arguments — an order of
 // magnitude inside north_star's 1e-5 — with these documented domain edges, all far from symbolic-regression data:
-//   cos/sin : two-term pi (48 bits): absolute error <= 2e-7 up to |x| = 1e7 (the relative error next to a zero of the
-//             function grows as |x| * 1e-15 / distance); beyond 1e7, and for Inf, the OCML path under a wave-uniform
+//   cos/sin : two-term pi (48 bits): absolute error <= 2e-7 up to |x| = 1e5 (the relative error next to a zero of the
+//             function grows as |x| * 1e-15 / distance); beyond 1e5, and for Inf, the OCML path under a wave-uniform
 //             branch as in the exact mode (cos(exp(exp(x))) is common in random trees, and a value outside [-1, 1]
 //             would change flags downstream); no exact-extremum select (cos(0) may be 1 - 2^-24, so `x ^ cos(0)`
 //             with x < 0 is NaN).
@@ -272,7 +272,7 @@ __device__ __forceinline__ DeF2 fast_exp_f32x2(DeF2 x) {
 //   /       : x * v_rcp_f32(y), <= 1.5 ulp; |y| < 2^-126 divides like 0 and |y| >= 2^126 like Inf (v_rcp_f32 flushes
 //             denormal inputs and results).
 // Flags: identical to the exact mode except through those edges (a value that is Inf/NaN/0 only in one mode).
-constexpr float DE_TURBO_TRIG_BOUND = 1.0e7f; // the magic-number rounding needs |x / pi| < 2^22
+constexpr float DE_TURBO_TRIG_BOUND = 1.0e5f; // = DE_TRIG_FAST_BOUND: beyond it x/pi rounded in Float32 no longer picks the right n
 #define DE_TURBO_S0 -0x1.55554ap-3f
 #define DE_TURBO_S1 0x1.110ea6p-7f
 #define DE_TURBO_S2 -0x1.9f6716p-13f

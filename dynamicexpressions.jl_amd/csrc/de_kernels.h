@@ -10,7 +10,15 @@
 
 namespace de {
 
-constexpr int BLOCK = 256; // threads per workgroup = 4 wavefronts of 64
+constexpr int BLOCK = 256; // threads per workgroup = 4 wavefronts of 64 (flat-switch and gradient kernels)
+// Threaded eval kernel: threads per workgroup.  The kernel is latency-bound: waves per SIMD are what hide
+// the LDS / instruction-fetch latency of every dispatch, and LDS — (n_features + slots) rows of DE_TBLK 16-byte vectors per
+// workgroup — is what limits them; 2-wave workgroups pack the 160 KB of a CU more tightly than 4-wave ones.
+#ifndef DE_TBLK
+#define DE_TBLK 128
+#endif
+constexpr int TBLK = DE_TBLK, TWAVES = DE_TBLK / 64;
+constexpr size_t TROW_BYTES = (size_t)(DE_TBLK + 1) * 16; // LDS row stride: DE_TBLK vectors + one of padding (bank spread)
 
 // Fused loss epilogue of the threaded eval kernel (de_eval_loss): instead of storing out[t][j] the
 // kernel reduces sum_j w_j * l(out[t][j] - y[j]) per tree (per-wave partials + two fixed-order passes).

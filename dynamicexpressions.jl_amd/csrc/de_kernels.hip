@@ -495,34 +495,40 @@ template <> __device__ __forceinline__ double imm_from<double>(uint64_t b) { ret
 template <typename T> using BodyFn = HState<T> (*)(HState<T>, uint32_t, typename ImmBits<T>::type);
 // ---- direct-threaded dispatch ------------------------------------------------------------------------------------
 // The interpreter has no central loop: every handler ends with a tail call (s_setpc_b64) to the handler of the next
-// instruction, whose address it reads — together with its own operands — from ONE 16-byte record of the stream:
-//   Float32 record  { la, imm, next.lo, next.hi }     la  = LDS byte offset of the operand row | aux << 24
-//   Float64 record  { la, next.lo, imm.lo, imm.hi }   (next.hi = the high half of the current pc: all handlers of a
-//                                                      code object lie in one 4 GiB window, checked on the host)
-// A tree is { header record (only `next` = the first handler) , one record per instruction }, the last `next` is
-// h_end, which returns to the kernel.  The stream pointer travels in SGPRs (csrc/irpatch.py marks the parameter
-// `inreg` in the optimised IR: clang has no source spelling for it on a device function), so a dispatch is
-//   s_load_dwordx4 ; s_add_u32 ; s_addc_u32 ; s_waitcnt ; ... body ... ; s_setpc_b64        + 1 VALU (the LDS address)
+// instruction.  The stream holds one 16-byte record per instruction, plus an end record per tree:
+//   Float32 record  { la, imm, handler.lo, handler.hi }     la = LDS byte offset of the operand row | aux << 24
+//   Float64 record  { la, handler.lo, imm.lo, imm.hi }      (handler.hi = the high half of the current pc: all handlers
+//                                                            of a code object lie in one 4 GiB window, checked on the host)
+// and it is SOFTWARE-PIPELINED: a handler receives its own operand words (la, imm) in SGPRs from its predecessor and, as
+// its first instruction, loads the NEXT record (s_load_dwordx4) — the scalar-cache latency overlaps with its own LDS
+// read and arithmetic instead of preceding them — then tail-calls the next handler with that record's operand words.
+// The end record names h_end, which returns to the kernel.  Stream pointer and operand words travel in SGPRs
+// (csrc/irpatch.py marks those parameters `inreg` in the optimised IR: clang has no source spelling for it on a device
+// function), so a dispatch is
+//   s_load_dwordx4 ; s_add_u32 ; s_addc_u32 ; ... body ... ; s_waitcnt ; 2-3 s_mov ; s_setpc_b64      + 1 VALU (LDS address)
 // against 11 scalar + 1 scalar load + 2 VALU for the call/return loop it replaces (prefetch copy, handler address
 // arithmetic, loop counter and branch, s_swappc/s_setpc pair).
-template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, ConstU4Ptr);
-template <typename T> __device__ __forceinline__ HandlerFn<T> next_handler(const U32x4 &w);
-template <> __device__ __forceinline__ HandlerFn<float> next_handler<float>(const U32x4 &w) {
+template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, ConstU4Ptr, uint32_t, typename ImmBits<T>::type);
+template <typename T> __device__ __forceinline__ HandlerFn<T> rec_handler(const U32x4 &w);
+template <> __device__ __forceinline__ HandlerFn<float> rec_handler<float>(const U32x4 &w) {
     return reinterpret_cast<HandlerFn<float>>(((uint64_t)w.w << 32) | w.z);
 }
-template <> __device__ __forceinline__ HandlerFn<double> next_handler<double>(const U32x4 &w) {
+template <> __device__ __forceinline__ HandlerFn<double> rec_handler<double>(const U32x4 &w) {
     return reinterpret_cast<HandlerFn<double>>((__builtin_amdgcn_s_getpc() & 0xFFFFFFFF00000000ull) | w.y);
 }
 template <typename T> __device__ __forceinline__ typename ImmBits<T>::type rec_imm(const U32x4 &w);
 template <> __device__ __forceinline__ uint32_t rec_imm<float>(const U32x4 &w) { return w.y; }
 template <> __device__ __forceinline__ uint64_t rec_imm<double>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
-#define DE_ROW_BYTES_C (257 * 16) // LDS row stride of the threaded kernel: 256 16-byte vectors + one of padding
-template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain(HState<T> st, uint32_t lds0, ConstU4Ptr code) {
+#define DE_ROW_BYTES_C ((DE_TBLK + 1) * 16) // LDS row stride of the threaded kernel: DE_TBLK 16-byte vectors + one of padding
+// `code` points at the record of the NEXT instruction; (la, imm) are this instruction's operand words
+#define HCHAIN_ARGS HState<T> st, uint32_t lds0, ConstU4Ptr code, uint32_t la, typename ImmBits<T>::type imm
+#define HCHAIN_NEXT(W) [[clang::musttail]] return rec_handler<T>(W)(st, lds0, code + 1, (W).x, rec_imm<T>(W))
+template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain(HCHAIN_ARGS) {
     const U32x4 w = *code;
-    st = BODY(st, lds0 + w.x, rec_imm<T>(w)); // w.x = row byte offset | aux << 24 (no carry: LDS < 2^18 bytes)
-    [[clang::musttail]] return next_handler<T>(w)(st, lds0, code + 1);
+    st = BODY(st, lds0 + la, imm); // la = row byte offset | aux << 24 (no carry: LDS < 2^18 bytes)
+    HCHAIN_NEXT(w);
 }
-template <typename T> __device__ __noinline__ HState<T> h_end(HState<T> st, uint32_t, ConstU4Ptr) { return st; }
+template <typename T> __device__ __noinline__ HState<T> h_end(HState<T> st, uint32_t, ConstU4Ptr, uint32_t, typename ImmBits<T>::type) { return st; }
 
 __device__ __forceinline__ void hpoison_impl(PoisonOf<float>::type &poison, const VecOf<float>::type &v) {
     typedef PoisonOf<float>::type P2;
@@ -672,7 +678,7 @@ template <typename T, int K, int VAR, bool TB = false> __device__ __forceinline_
     return st;
 }
 // ---- superinstructions (de_bind.h, fuse_tree): la = LDS address of row A | int8 (push row - row A) << 24
-#define DE_ROW_BYTES (257 * 16)
+#define DE_ROW_BYTES ((DE_TBLK + 1) * 16)
 static_assert(DE_ROW_BYTES == DE_ROW_BYTES_C, "row stride");
 __device__ __forceinline__ uint32_t row_a(uint32_t la) { return la & 0xFFFFFFu; }
 __device__ __forceinline__ uint32_t push_addr(uint32_t la) { return (la & 0xFFFFFFu) + (uint32_t)(((int32_t)la >> 24) * DE_ROW_BYTES); }
@@ -779,11 +785,11 @@ template <typename T> __device__ __forceinline__ HState<T> b_nop(HARGS) { return
 // record's immediate) and the table's address behind them (Float64: in the same 16-byte vector; Float32: in the row
 // behind), so the handler needs no kernel argument: 4 (2) gathers through the vector cache.  la[23] = validity-test the
 // operand, la[31:24] = DOP_LOAD or the operator applied to (acc, operand) — the hot ones inline, the rest through cold_op.
-template <typename T, bool TB> __device__ __noinline__ HState<T> h_param(HState<T> st, uint32_t lds0, ConstU4Ptr code) {
+template <typename T, bool TB> __device__ __noinline__ HState<T> h_param(HCHAIN_ARGS) {
     constexpr int VW = VecOf<T>::W;
     const U32x4 w = *code;
-    const uint32_t op = w.x >> 24;
-    const uint32_t crow = lds0 + (uint32_t)rec_imm<T>(w);
+    const uint32_t op = la >> 24;
+    const uint32_t crow = lds0 + (uint32_t)imm;
     const U32x4 cv = *reinterpret_cast<__attribute__((address_space(3))) U32x4 *>((uintptr_t)crow);
     uint64_t tab;
     if constexpr (sizeof(T) == 4) {
@@ -791,10 +797,10 @@ template <typename T, bool TB> __device__ __noinline__ HState<T> h_param(HState<
         const U2 pv = *reinterpret_cast<__attribute__((address_space(3))) U2 *>((uintptr_t)(crow + DE_ROW_BYTES_C));
         tab = ((uint64_t)pv.y << 32) | pv.x;
     } else tab = ((uint64_t)cv.w << 32) | cv.z;
-    const char *__restrict__ pb = reinterpret_cast<const char *>(tab) + (size_t)(w.x & 0xFFFFu) * sizeof(T);
+    const char *__restrict__ pb = reinterpret_cast<const char *>(tab) + (size_t)(la & 0xFFFFu) * sizeof(T);
     VG<T, 1> av, bv;
     DE_UNROLL for (int i = 0; i < VW; i++) bv.v[0][i] = *reinterpret_cast<const T *>(pb + cv[i]);
-    if (w.x & (1u << 23)) hpoison<T>(st.poison, bv.v[0]);
+    if (la & (1u << 23)) hpoison<T>(st.poison, bv.v[0]);
     switch (op) {
     case DOP_LOAD: st.acc = bv.v[0]; break;
     case DE_B_ADD: st.acc = bin_apply<T, 0>(st.acc, bv.v[0]); break;
@@ -808,7 +814,7 @@ template <typename T, bool TB> __device__ __noinline__ HState<T> h_param(HState<
     case DE_U_SIN: st.acc = un_apply<T, 2, TB>(bv.v[0]); break;
     default: av.v[0] = st.acc; av = cold_op<T, 1>(op, av, bv); st.acc = av.v[0]; break;
     }
-    [[clang::musttail]] return next_handler<T>(w)(st, lds0, code + 1);
+    HCHAIN_NEXT(w);
 }
 
 // TB = handlers of a DE_OPT_TURBO program: same ids, the division / cos / exp / sin handlers are the relaxed-accuracy
@@ -864,10 +870,10 @@ template <typename T, bool TB> __global__ void de_fill_handlers(uint64_t *t) {
 }
 
 template <typename T, bool PARAMS, bool LOSS = false>
-__global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a) {
+__global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T> a) {
     typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
-    constexpr int BLK = 256, TILE = BLK * VW, ROWV = BLK + 1;
+    constexpr int BLK = DE_TBLK, TILE = BLK * VW, ROWV = BLK + 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     T *__restrict__ rows = reinterpret_cast<T *>(smem_raw);
 
@@ -961,13 +967,13 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a)
     }
 
     for (int tree = t0; tree < t1; ++tree) {
-        // code_off[tree] = the tree's header record: `next` = its first handler; the chain ends in h_end
+        // code_off[tree] = the record of the tree's first instruction; the chain ends in h_end (the tree's end record)
         const ConstU4Ptr rec = code + code_off[tree];
         HState<T> st;
         DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
         st.poison = typename PoisonOf<T>::type{};
         const U32x4 hd = *rec;
-        st = reinterpret_cast<HandlerFn<T>>(((uint64_t)hd.w << 32) | hd.z)(st, lds0, rec + 1);
+        st = rec_handler<T>(hd)(st, lds0, rec + 1, hd.x, rec_imm<T>(hd));
         if constexpr (LOSS) {
             // sum_j w_j * l(out_j - y_j) over this wave's 64*VW samples -> one partial per (tile, tree, wave)
             T s = T(0);
@@ -977,10 +983,12 @@ __global__ void __launch_bounds__(256) de_eval_threaded_kernel(const KArgs<T> a)
                 s += wv[i] != T(0) ? wv[i] * l : T(0); // weight 0 really excludes the sample (0 * Inf would be NaN)
             }
             s = wave_sum_to_lane63(s);
-            if ((tid & 63) == 63) a.partial[((int64_t)tm.tile * a.n_trees + tree) * 4 + (tid >> 6)] = s;
+            if ((tid & 63) == 63) a.partial[((int64_t)tm.tile * a.n_trees + tree) * TWAVES + (tid >> 6)] = s;
         } else {
             T *__restrict__ o = a.out + (int64_t)tree * a.ld_out + base + tid * VW;
-            if (full && a.vec_store) {
+            if (a.vec_store == 2) { // DE_DEBUG_NO_STORE (measurement only): keep the value alive, write nothing
+                if (st.acc[0] == T(123456.789)) *o = st.acc[0];
+            } else if (full && a.vec_store) {
                 *reinterpret_cast<V *>(o) = st.acc;
             } else {
                 VG<T, 1> av;
@@ -1014,7 +1022,7 @@ __global__ void __launch_bounds__(256) de_loss_finish_kernel(const double *__res
     if (t >= n_trees) return;
     double s = 0.0;
     for (int32_t g = 0; g < n_segs; ++g)
-        for (int w = 0; w < 4; ++w) s += seg_sum[((int64_t)g * n_trees + t) * 4 + w];
+        for (int w = 0; w < TWAVES; ++w) s += seg_sum[((int64_t)g * n_trees + t) * TWAVES + w];
     loss[t] = ok[t] ? (T)s : M<T>::nan();
 }
 
@@ -1045,6 +1053,7 @@ size_t eval_lds_bytes(int dtype, int F, int n_slots, int *K_out) {
 }
 
 static void eval_geometry(int dtype, int *G, int *BLK);
+bool eval_uses_threaded();
 static int g_cu_count = 0;
 
 static int cu_count() {
@@ -1077,6 +1086,7 @@ static void plan_chunks(int64_t n_trees, int64_t n_tiles, int32_t *n_chunks_out,
 void eval_plan(int dtype, int64_t n_trees, int64_t N, int32_t *tile, int32_t *n_chunks, int32_t *trees_per_chunk) {
     int G, BLK;
     eval_geometry(dtype, &G, &BLK);
+    if (eval_uses_threaded()) { G = 1; BLK = TBLK; }
     *tile = BLK * G * (dtype == DE_F32 ? 4 : 2);
     plan_chunks(n_trees, (N + *tile - 1) / *tile, n_chunks, trees_per_chunk);
 }
@@ -1174,7 +1184,7 @@ bool eval_uses_threaded() { return env_int("DE_EVAL_THREADED", 1) != 0 && env_in
 template <typename T>
 static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const char **kname) {
     constexpr int VW = VecOf<T>::W;
-    constexpr int TILE = 256 * VW;
+    constexpr int TILE = TBLK * VW;
     KArgs<T> a;
     a.code = e.code;
     a.code_off = e.code_off;
@@ -1200,6 +1210,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.f_magic = e.F > 1 ? (uint32_t)((0x100000000ull + (uint64_t)e.F - 1) / (uint64_t)e.F) : 0u;
     a.x_vec = 0;
     a.f_magic = 0;
+    if (env_int("DE_DEBUG_NO_STORE", 0)) a.vec_store = 2;
     int32_t tpc, nch;
     plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc);
     a.trees_per_chunk = tpc;
@@ -1207,10 +1218,10 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // rows: X, spill slots, then (parametric) the class row [+ the table-pointer row for Float32] of h_param
-    a.cls_row_off = (uint32_t)((size_t)(a.F + a.n_slots) * 257 * 16);
+    a.cls_row_off = (uint32_t)((size_t)(a.F + a.n_slots) * TROW_BYTES);
     const int prm_rows = e.uses_params ? (sizeof(T) == 4 ? 2 : 1) : 0;
     if (e.uses_params && (uint64_t)e.ld_params * (uint64_t)e.n_classes * sizeof(T) > 0xFFFFFFFFull) return hipErrorInvalidValue; // 32-bit column offsets
-    const size_t lds = (size_t)(a.F + a.n_slots + prm_rows + env_int("DE_EXTRA_LDS_ROWS", 0)) * 257 * 16;
+    const size_t lds = (size_t)(a.F + a.n_slots + prm_rows + env_int("DE_EXTRA_LDS_ROWS", 0)) * TROW_BYTES;
     void (*kern)(const KArgs<T>) = e.uses_params ? de_eval_threaded_kernel<T, true> : de_eval_threaded_kernel<T, false>;
     a.y = a.w = nullptr;
     a.partial = nullptr;
@@ -1227,11 +1238,11 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (st != hipSuccess) return st;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TBLK), lds, stream, a);
     hipError_t st = hipGetLastError();
     if (st != hipSuccess || !e.loss) return st;
     int32_t n_segs = 1;
-    st = launch_loss_reduce_tiles(sizeof(T) == 4 ? DE_F32 : DE_F64, a.partial, (int64_t)e.n_trees * 4, a.n_tiles, e.loss->seg_sum, &n_segs, stream);
+    st = launch_loss_reduce_tiles(sizeof(T) == 4 ? DE_F32 : DE_F64, a.partial, (int64_t)e.n_trees * TWAVES, a.n_tiles, e.loss->seg_sum, &n_segs, stream);
     if (st != hipSuccess) return st;
     hipLaunchKernelGGL(de_loss_finish_kernel<T>, dim3((unsigned)((e.n_trees + 255) / 256)), dim3(256), 0, stream,
                        static_cast<const double *>(e.loss->seg_sum), (int64_t)e.n_trees, n_segs, e.ok, static_cast<T *>(e.loss->loss));
@@ -1255,10 +1266,10 @@ hipError_t launch_loss_reduce_tiles(int dtype, const void *partial, int64_t n_co
 
 int32_t loss_segments(int64_t n_tiles) { return (int32_t)(n_tiles < 64 ? (n_tiles < 1 ? 1 : n_tiles) : 64); }
 void loss_scratch_bytes(int dtype, int64_t n_trees, int64_t N, size_t *partial_bytes, size_t *seg_bytes) {
-    const int64_t tile = 256 * (dtype == DE_F32 ? 4 : 2);
+    const int64_t tile = TBLK * (dtype == DE_F32 ? 4 : 2);
     const int64_t n_tiles = (N + tile - 1) / tile;
-    *partial_bytes = (size_t)n_tiles * (size_t)n_trees * 4 * (dtype == DE_F32 ? 4 : 8);
-    *seg_bytes = (size_t)loss_segments(n_tiles) * (size_t)n_trees * 4 * sizeof(double);
+    *partial_bytes = (size_t)n_tiles * (size_t)n_trees * TWAVES * (dtype == DE_F32 ? 4 : 8);
+    *seg_bytes = (size_t)loss_segments(n_tiles) * (size_t)n_trees * TWAVES * sizeof(double);
 }
 
 hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const char **kernel_name) {

@@ -19,8 +19,8 @@ Second job (direct-threaded eval handlers, de_kernels.hip): the instruction-stre
 and hands to the next one is wave-uniform, but the C calling convention passes pointers in VGPRs; each handler would
 then spend two v_readfirstlane to read its record with a scalar load and could not tail-call (the backend refuses a
 sibling call through a divergent address).  The IR parameter attribute `inreg` puts the argument in SGPRs; HIP has no
-source spelling for it on a device function, so it is added here to the `ptr addrspace(4)` parameter of every handler
-definition AND of every indirect handler call (caller and callee must agree, and `musttail` requires identical
+source spelling for it on a device function, so it is added here to the `ptr addrspace(4)` parameter — and to the integer
+parameters behind it, the operand words one handler hands to the next — of every handler definition AND of every indirect handler call (caller and callee must agree, and `musttail` requires identical
 prototypes).  Only functions returning the handler state struct that have such a parameter are touched."""
 import re
 import sys
@@ -113,12 +113,22 @@ def main(src, dst):
     n_inreg = 0
 
     def add_inreg(m):
+        """The stream pointer and EVERY parameter after it (the operand words the predecessor hands over) are wave-uniform."""
         nonlocal n_inreg
         line = m.group(0)
-        if "ptr addrspace(4)" not in line or "ptr addrspace(4) inreg" in line:
+        k = line.find("ptr addrspace(4)")
+        if k < 0 or "ptr addrspace(4) inreg" in line:
             return line
-        n_inreg += 1
-        return line.replace("ptr addrspace(4)", "ptr addrspace(4) inreg")
+        end = line.rfind(")")
+        head, params, tail = line[:k], line[k:end], line[end:]
+        out = []
+        for prm in params.split(", "):
+            mt = re.match(r"(ptr addrspace\(4\)|i32|i64)( |$)", prm)
+            if mt:
+                prm = mt.group(1) + " inreg" + prm[len(mt.group(1)):]
+                n_inreg += 1
+            out.append(prm)
+        return head + ", ".join(out) + tail
     text = re.sub(r'^define [^\n]*?' + HSTATE + r' @[^\n(]+\([^\n]*$', add_inreg, text, flags=re.M)
     text = re.sub(r'^\s*%[\w.]+ = (?:tail |musttail |notail )?call ' + HSTATE + r' %[\w.]+\([^\n]*$', add_inreg, text, flags=re.M)
     text = text.rstrip("\n") + "\n" + "".join(f"attributes #{i} = {{{body}}}\n" for i, body in list(new_ids.values()) + list(def_ids.values()))

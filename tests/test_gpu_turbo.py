@@ -65,14 +65,15 @@ def test_turbo_trig_accuracy(api, name, f64):
     ol, wl = run1(api, name, 1, xl[None, :]), f64(xl.astype(np.float64))
     assert np.max(np.abs(ol.astype(np.float64) - wl)) <= 3e-7
     REPORT[name + " |x|<=1e4"] = dict(max_abs=float(np.max(np.abs(ol.astype(np.float64) - wl))), points=int(xl.size))
-    # non-finite in, non-finite out; arguments beyond 1e7 take the full range reduction of the exact mode (cos(exp(exp(x)))
+    # non-finite in, non-finite out; arguments beyond 1e5 take the full range reduction of the exact mode (cos(exp(exp(x)))
     # is common in random trees: a value outside [-1, 1] there would change flags downstream)
     xs = np.array([np.inf, -np.inf, np.nan, 3e38, -1e30, 1.5e7, -2.5e9], dtype=np.float32)
     o = run1(api, name, 1, xs[None, :])
     assert np.all(~np.isfinite(o[:3]))
     assert ulps32(o[3:], f64(xs[3:].astype(np.float64))).max() <= 2.0
     xm = g.uniform(-1e7, 1e7, 200_000).astype(np.float32)
-    assert np.max(np.abs(run1(api, name, 1, xm[None, :]).astype(np.float64) - f64(xm.astype(np.float64)))) <= 5e-7
+    xm[::2] = g.uniform(-1e5, 1e5, xm[::2].size).astype(np.float32)  # waves that mix both paths
+    assert np.max(np.abs(run1(api, name, 1, xm[None, :]).astype(np.float64) - f64(xm.astype(np.float64)))) <= 3e-7
     # and the exact mode is untouched by the option: bit-identical with and without an unrelated context field
     np.testing.assert_array_equal(run1(api, name, 1, x[None, :1000], turbo=False), run1(api, name, 1, x[None, :1000], turbo=False))
     assert np.any(run1(api, name, 1, x[None, :100000], turbo=False) != out[:100000])  # the option really selects other code

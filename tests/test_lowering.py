@@ -274,10 +274,10 @@ def test_valu_slot_table_layout():
         w = api.lower_tape_stage(tape, consts, 5, 3)
         used.update(int(v) for v in w[:, 0])
     assert used and all(u in slots for u in used)
-    assert slots[5]["valu_slots"] == 3  # acc + row: the LDS address add + two v_pk_add_f32
+    assert slots[5]["valu_cycles"] == pytest.approx(3 * 3.7)  # acc + row: the LDS address add (SGPR operand: half rate) + two v_pk_add_f32
     committed = os.path.join(ROOT, "profiles", "valu_slots.json")
     if os.path.exists(committed):
         with open(committed) as fh:
             tab = json.load(fh)["handlers"]
-        stale = [k for k in used if tab.get(str(k), {}).get("valu_slots") != slots[k]["valu_slots"]]
+        stale = [k for k in used if tab.get(str(k), {}).get("valu_cycles") != slots[k]["valu_cycles"]]
         assert not stale, f"profiles/valu_slots.json is stale for handlers {stale}: rerun tools/valu_slots.py"

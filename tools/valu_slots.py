@@ -4,16 +4,17 @@
     python tools/valu_slots.py [--dtype f32] [--obj <device ELF>] [-o profiles/valu_slots.json]
 
 The eval kernel is VALU-issue bound, so the binding ceiling of a launch is
-    sum over the dispatched handlers of their VALU issue slots  x 4 cycles (wave64 on a SIMD16)
+    sum over the dispatched handlers of the SIMD cycles their VALU instructions occupy
 per wavefront.  This tool disassembles the device code object build.sh links for de_kernels.hip
 (csrc/_obj/irp_de_kernels/k.out), splits it per handler function and reports, per handler id of
 csrc/de_bind.h, the VALU slots on the SHORTEST path from the function entry to its return
 (`s_setpc_b64` — since the direct-threaded dispatch, the tail call to the next handler): handlers keep their rare cases (division outside [2^-40, 2^40], |x| > 1e5 for
 cos/sin, the extremum select) behind wave-uniform branches, and the shortest path is the one a
-wavefront of ordinary data takes.  Quarter-rate transcendental instructions (v_rcp/v_exp/v_log/
-v_sqrt/v_rsq/v_sin/v_cos_f32) count 4 slots, every other v_* instruction 1 (v_pk_* = one slot
-for two elements).  bench.py multiplies the table with the dispatch histogram of the population
-(`roofline.valu`); no GPU is needed to produce it.
+wavefront of ordinary data takes.  Instructions are priced in SIMD cycles by the classes measured on
+MI355X with tools/probe/valu_rate.py (see `weight` below): FP32 fma/add/mul, moves and bit logic run at
+2 cycles per wave64 instruction, packed FP32 / min-max / compares / shifts / anything with an SGPR operand
+at ~3.7, transcendentals at ~7.4.  bench.py multiplies the table with the dispatch histogram of the
+population (`roofline.valu`); no GPU is needed to produce it.
 """
 import argparse
 import heapq
@@ -25,14 +26,31 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = os.environ.get("LLVM", "/opt/rocm/lib/llvm/bin")
+# Issue cost in SIMD cycles per wave64 instruction, MEASURED on MI355X (tools/probe/valu_rate.py ->
+# profiles/r2_valu_rate.json, v_fma_f32 = 2 cycles = the 32 FP32-FMA lanes per SIMD and cycle of the chip's vector peak):
+#   FULL  2.0  v_fma/fmac/fmamk/fmaak/add/sub/mul_f32, v_mov_b32, v_and/or/xor_b32, v_add/sub_u32 — with VGPR, literal or
+#              inline-constant operands and any modifiers;
+#   HALF  3.7  every v_pk_*_f32 (two elements: NO throughput gain over two full-rate instructions), v_max/min/max3/min3/
+#              med3, v_cmp_*, v_cndmask, shifts, v_lshl_add, v_bfi, v_ldexp, v_rndne, v_cvt, all Float64 arithmetic —
+#              and ANY instruction that reads an SGPR operand (a full-rate one becomes half rate: 3.6);
+#   TRANS 7.35 v_exp/rcp/log/sqrt/rsq/sin/cos_f32.
+FULL = ("v_fma_f32", "v_fmac_f32", "v_fmamk_f32", "v_fmaak_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_mov_b32",
+        "v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32")
 TRANS = ("v_rcp_f32", "v_exp_f32", "v_log_f32", "v_sqrt_f32", "v_rsq_f32", "v_sin_f32", "v_cos_f32",
          "v_rcp_iflag_f32", "v_rcp_f64", "v_rsq_f64", "v_sqrt_f64")
+C_FULL, C_HALF, C_TRANS = 2.0, 3.7, 7.35
+SGPR = re.compile(r"(?<![\w.])(s\d+|s\[\d+:\d+\]|vcc|exec|m0)(?![\w])")
 
 
-def weight(mn: str) -> int:
+def weight(mn: str, ops: str = "") -> float:
+    """SIMD cycles the instruction occupies the VALU for (0 for scalar / memory instructions)."""
     if not mn.startswith("v_"):
-        return 0
-    return 4 if any(mn.startswith(t) for t in TRANS) else 1
+        return 0.0
+    if any(mn.startswith(t) for t in TRANS):
+        return C_TRANS
+    if any(mn.startswith(t) for t in FULL) and not SGPR.search(ops):
+        return C_FULL
+    return C_HALF
 
 
 def functions(obj):
@@ -61,7 +79,7 @@ def functions(obj):
 
 
 def shortest_slots(code):
-    """(VALU slots, VALU instructions, all instructions) on the cheapest entry -> return path."""
+    """(VALU cycles, VALU instructions, all instructions) on the cheapest entry -> return path."""
     idx = {a: i for i, (a, _, _, _) in enumerate(code)}
     dist = {0: (0, 0, 0)}
     heap = [(0, 0, 0, 0)]
@@ -69,10 +87,10 @@ def shortest_slots(code):
         d, nv, ni, i = heapq.heappop(heap)
         if dist.get(i, (1 << 60,))[0] < d:
             continue
-        _, mn, _, tgt = code[i]
+        _, mn, ops, tgt = code[i]
         if mn.startswith("s_setpc") or mn == "s_endpgm":
-            return d, nv, ni
-        w = weight(mn)
+            return round(d, 2), nv, ni
+        w = weight(mn, ops)
         nxt = []
         if mn != "s_branch" and i + 1 < len(code):
             nxt.append(i + 1)
@@ -168,7 +186,7 @@ def table(obj, ty="float", turbo=False):
         r = shortest_slots(code)
         if r is None:
             continue
-        slots[hid] = dict(name=nm, valu_slots=r[0], valu_insts=r[1], insts=r[2])
+        slots[hid] = dict(name=nm, valu_cycles=r[0], valu_insts=r[1], insts=r[2])
     return slots, counts
 
 
@@ -181,9 +199,9 @@ def main():
     slots, counts = table(a.obj, "float" if a.dtype == "f32" else "double")
     turbo = table(a.obj, "float", True)[0] if a.dtype == "f32" else {}
     doc = dict(source=f"tools/valu_slots.py over {os.path.relpath(a.obj, ROOT)} (llvm-objdump of the gfx950 code object)",
-               rule="VALU issue slots on the shortest entry->return path; quarter-rate transcendentals count 4",
-               dispatch_overhead_valu=0,  # direct-threaded dispatch: the LDS address add is inside the handler (counted there)
-               per_tree_overhead_valu=8,  # state zeroing + output address + ballot compare around the loop
+               rule="VALU cycles (wave64 instruction occupancy of a SIMD) on the shortest entry->return path; measured classes: "
+                    f"full rate {C_FULL}, half rate / packed / SGPR operand {C_HALF}, transcendental {C_TRANS} (profiles/r2_valu_rate.json)",
+               per_tree_overhead_cycles=24.0,  # state zeroing, output address, ballot compare around the chain (~10 instructions)
                layout=counts, handlers={str(k): v for k, v in sorted(slots.items())},
                handlers_turbo={str(k): v for k, v in sorted(turbo.items())})  # the same ids in a DE_OPT_TURBO program
     with open(a.out, "w") as fh:
