@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""asmpatch.py OBJECT.o — let the output store of one tree overlap with the evaluation of the next.
+
+The AMDGPU backend opens every non-kernel function with `s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)` (SIInsertWaitcnts: a
+callee cannot know what its caller left in flight).  For the direct-threaded eval handlers (de_kernels.hip: h_chain<...>,
+h_param<...>, h_end<...>) the only vector-memory operation that can be in flight at their entry is the kernel's
+`global_store` of the PREVIOUS tree's result — nothing a handler reads — yet the first handler of every tree waits for its
+write acknowledgement (~1-2 us), once per tree and wavefront.  This pass rewrites that entry wait to
+`s_waitcnt expcnt(0) lgkmcnt(0)` in those functions only.  Why it is safe:
+  * handlers take their inputs in registers and LDS (lgkmcnt is still drained); none consumes a VMEM result it did not
+    issue itself, and a handler that does issue loads (h_param) waits for them with counts computed from its own
+    instructions — an extra OLDER store in flight can only make such a wait longer (vmcnt retires loads in order), never
+    let it pass early;
+  * gfx9 VMEM stores read their data registers when they issue, so overwriting those registers afterwards is fine;
+  * the kernel itself waits for vmcnt(0) before it ends (s_endpgm drains stores).
+  * ONLY handlers that contain no vector-memory instruction at all are relaxed.  A handler with a stack frame (h_param,
+    the generic handlers that call cold_op) restores its callee-saved VGPR with a `scratch_load` right before its tail call
+    and relies on the NEXT function's entry wait to complete it; a relaxed successor never touches that register (it has
+    no scratch instruction to save it with), so the restore lands harmlessly while it runs, and the chain always ends in
+    h_end — left untouched, full wait — before control returns to the kernel, which does use those registers.
+Works on the relocatable gfx950 object (one 32-bit instruction word per function); refuses to touch a function whose first
+instruction is not exactly that wait."""
+import os
+import re
+import struct
+import subprocess
+import sys
+
+TARGETS = re.compile(r"^(_ZN2de7h_chainI|_ZN2de7h_paramI)")  # never h_end: the end of every chain keeps the full wait
+VMEM = re.compile(r"^\s*(scratch_|flat_|global_|buffer_|tbuffer_|image_)")
+LLVM = os.environ.get("LLVM", "/opt/rocm/lib/llvm/bin")
+
+
+def vmem_free_functions(path):
+    """Names of the functions of the object whose bodies contain no vector-memory instruction."""
+    dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", path], check=True, capture_output=True, text=True).stdout
+    ok, name, clean = set(), None, True
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+        if m:
+            if name and clean:
+                ok.add(name)
+            name, clean = m.group(1), True
+        elif name and VMEM.match(line):
+            clean = False
+    if name and clean:
+        ok.add(name)
+    return ok
+ENTRY_WAIT = 0xBF8C0000      # s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)
+RELAXED_WAIT = 0xBF8CC00F    # s_waitcnt expcnt(0) lgkmcnt(0)    (gfx9 simm16: vmcnt = [15:14]:[3:0] = 63 = no wait)
+
+
+def main(path):
+    """Patches the relocatable object in place (the backend's own assembly does not survive a round trip through the
+    assembler: its resource-usage symbols of functions with indirect calls cannot be re-evaluated)."""
+    leaf = vmem_free_functions(path)
+    blob = bytearray(open(path, "rb").read())
+    assert blob[:4] == b"\x7fELF" and blob[4] == 2 and blob[5] == 1, "not a little-endian ELF64 file"
+    e_shoff, = struct.unpack_from("<Q", blob, 0x28)
+    e_shentsize, e_shnum, e_shstrndx = struct.unpack_from("<HHH", blob, 0x3A)
+    secs = []
+    for i in range(e_shnum):
+        name, typ, flags, addr, off, size, link, info, align, entsize = struct.unpack_from("<IIQQQQIIQQ", blob, e_shoff + i * e_shentsize)
+        secs.append(dict(name=name, type=typ, addr=addr, off=off, size=size, link=link, entsize=entsize))
+    symtab = next(s for s in secs if s["type"] == 2)  # SHT_SYMTAB
+    strtab = secs[symtab["link"]]
+    n = skipped = 0
+    for k in range(symtab["size"] // 24):
+        st_name, st_info, st_other, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", blob, symtab["off"] + 24 * k)
+        if (st_info & 0xF) != 2 or st_shndx == 0 or st_shndx >= len(secs):  # STT_FUNC, defined
+            continue
+        end = blob.index(b"\0", strtab["off"] + st_name)
+        name = blob[strtab["off"] + st_name:end].decode()
+        if not TARGETS.match(name):
+            continue
+        if name not in leaf:
+            skipped += 1
+            continue
+        sec = secs[st_shndx]
+        pos = sec["off"] + (st_value - sec["addr"])
+        word, = struct.unpack_from("<I", blob, pos)
+        if word != ENTRY_WAIT:
+            sys.exit(f"asmpatch: {name} does not start with the entry wait (0x{word:08X})")
+        struct.pack_into("<I", blob, pos, RELAXED_WAIT)
+        n += 1
+    if n == 0:
+        sys.exit("asmpatch: no handler entry found")
+    open(path, "wb").write(bytes(blob))
+    print(f"asmpatch: entry vmcnt wait dropped in {n} eval handlers ({skipped} with vector-memory instructions left alone)")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -1208,8 +1208,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.vec_store = (reinterpret_cast<uintptr_t>(e.out) % 16 == 0 && (e.ld_out * sizeof(T)) % 16 == 0) ? 1 : 0;
     a.x_vec = (e.F >= 1 && e.ldX == e.F && reinterpret_cast<uintptr_t>(e.X) % 16 == 0 && (int64_t)TILE * e.F < 0x10000000LL) ? 1 : 0;
     a.f_magic = e.F > 1 ? (uint32_t)((0x100000000ull + (uint64_t)e.F - 1) / (uint64_t)e.F) : 0u;
-    a.x_vec = 0;
-    a.f_magic = 0;
+    if (!env_int("DE_X_VEC", 1)) { a.x_vec = 0; a.f_magic = 0; } // scalar staging loop (A/B and the test of the vector path)
     if (env_int("DE_DEBUG_NO_STORE", 0)) a.vec_store = 2;
     int32_t tpc, nch;
     plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc);

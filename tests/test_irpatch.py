@@ -82,3 +82,38 @@ def test_refuses_a_module_without_handlers_or_without_indirect_calls(tmp_path):
     src.write_text(no_indirect)
     with pytest.raises(SystemExit):
         irpatch.main(str(src), str(dst))
+
+
+def test_asmpatch_relaxes_only_the_entry_wait_of_eval_handlers():
+    """csrc/asmpatch.py rewrites ONE instruction word — the function-entry `s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)` — of
+    the direct-threaded eval handlers that contain no vector-memory instruction; checked on the shipped code object: those
+    start with the relaxed wait, every other function (handlers with a stack frame, h_end, cold_op, flag_incomplete, OCML
+    helpers ...) keeps the full one."""
+    import subprocess
+    obj = os.path.join(HERE, "..", "dynamicexpressions.jl_amd", "csrc", "_obj", "irp_de_kernels", "k.out")
+    if not os.path.exists(obj):
+        pytest.skip("device code object not built here (csrc/_obj is a build artefact)")
+    dis = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", obj], check=True, capture_output=True, text=True).stdout
+    first, vmem = {}, {}
+    name = None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+        if m:
+            name = m.group(1)
+            vmem[name] = False
+            continue
+        if name and "//" in line:
+            ins = line.split("//")[0].strip()
+            first.setdefault(name, ins)
+            if re.match(r"(scratch_|flat_|global_|buffer_)", ins):
+                vmem[name] = True
+    handlers = {n: i for n, i in first.items() if re.match(r"_ZN2de(7h_chainI|7h_paramI)", n)}
+    others = {n: i for n, i in first.items() if n not in handlers and n.startswith("_ZN2de") and "kernel" not in n and "fill_handlers" not in n}
+    assert len(handlers) > 300 and others
+    relaxed = {n for n, i in handlers.items() if i == "s_waitcnt expcnt(0) lgkmcnt(0)"}
+    assert len(relaxed) > 250
+    assert all(not vmem[n] for n in relaxed)                 # only handlers without any vector-memory instruction
+    assert all(vmem[n] for n in handlers if n not in relaxed)  # ... and all of those
+    assert all(i == "s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)" for n, i in handlers.items() if n not in relaxed)
+    assert all(i == "s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)" for i in others.values()), others  # h_end among them
+    assert any("5h_endI" in n for n in others)
