@@ -338,6 +338,8 @@ def main():
         else:
             ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
         if world > 1:
+            if comm_c is not None:  # the C-ABI exchange (de_dist_gather_flags: ncclAllGather issued by the library itself)
+                return comm_c.gather_flags(ok, len(all_trees))
             return dedist.gather_flags(ok, len(all_trees), rank, world)
         return ok
 
@@ -345,6 +347,40 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    # N > 1: gather the flags through the library's own RCCL communicator (what a Julia / C caller uses, csrc/de_dist.cpp);
+    # torch.distributed only ships the 128-byte unique id.  Checked against the torch.distributed gather once; any failure
+    # falls back to that path (both are RCCL over xGMI) and is reported in the JSON line.
+    comm_c, gather_via = None, "none (1 GPU)"
+    if world > 1:
+        gather_via = "torch.distributed all_gather (RCCL)"
+        # opt-in (DE_BENCH_C_COMM=1): the default keeps the one collective library path that the CPU/gloo tests cover end to
+        # end; a multi-GPU box to try the C-ABI communicator on was never available to the builder
+        if backend == "nccl" and os.environ.get("DE_BENCH_C_COMM", "0") == "1":
+            try:
+                ids = [None]
+                if rank == 0:
+                    try:
+                        ids = [dedist.Comm.unique_id()]
+                    except Exception:
+                        ids = [None]
+                torch.distributed.broadcast_object_list(ids, src=0)
+                if ids[0] is None:
+                    raise RuntimeError("no RCCL unique id")
+                cand = dedist.Comm(ctx, rank, world, ids[0])
+                ok.fill_(1)
+                ok[::3] = 0
+                a = cand.gather_flags(ok, len(all_trees))
+                b = dedist.gather_flags(ok, len(all_trees), rank, world)
+                torch.cuda.synchronize()
+                same = torch.tensor([int(torch.equal(a, b))], device=dev)
+                torch.distributed.all_reduce(same, op=torch.distributed.ReduceOp.MIN)
+                if int(same.item()) == 1:
+                    comm_c, gather_via = cand, "de_dist_gather_flags (C ABI: ncclAllGather inside libde_hip.so)"
+                else:
+                    cand.close()
+            except Exception as e:  # pragma: no cover
+                print(f"[rank {rank}] C-ABI communicator unavailable, using torch.distributed: {e}", file=sys.stderr)
 
     for _ in range(args.warmup):
         step()
@@ -430,7 +466,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl["desc"], "workload_key": args.workload, "trees_per_gpu": n_per_gpu, "n_samples": N, "n_features": 5,
-                       "nodes_per_tree": 20, "operators": "+ - / * cos exp", "sharding": f"tree-sharded x{world}",
+                       "nodes_per_tree": 20, "operators": "+ - / * cos exp", "sharding": f"tree-sharded x{world}", "flag_gather": gather_via,
                        "complete_fraction": float(flags.float().mean().item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

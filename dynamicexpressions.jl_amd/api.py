@@ -44,8 +44,9 @@ EXPORTS = [
     "de_opcode_degree", "de_status_string", "de_ctx_create", "de_ctx_destroy", "de_ctx_set_stream",
     "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create",
     "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
-    "de_program_n_grad", "de_program_dump", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad", "de_eval_loss_grad_by_class",
-    "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
+    "de_program_n_grad", "de_program_dump", "de_program_verify", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad", "de_eval_loss_grad_by_class",
+    "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size",
+    "de_dist_broadcast", "de_dist_gather_flags", "de_dist_last_error", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
 ]
 
 
@@ -106,6 +107,7 @@ def library() -> C.CDLL:
     lib.de_program_n_nodes.argtypes = [vp]
     lib.de_program_n_grad.restype = i64
     lib.de_program_n_grad.argtypes = [vp, i64, C.c_int]
+    lib.de_program_verify.argtypes = [vp]
     lib.de_program_dump.restype = i64
     lib.de_program_dump.argtypes = [vp, i64, vp, i64, C.c_int]
     lib.de_lower_tape.restype = i64
@@ -121,6 +123,15 @@ def library() -> C.CDLL:
     lib.de_eval_pullback_dX.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), vp, vp, vp, vp]
     lib.de_eval_tree_array.argtypes = [vp, C.c_int, vp, i64, vp, i64, vp, i32, i64, u32, vp, vp]
     lib.de_eval_plan.argtypes = [vp, i64, vp]
+    lib.de_dist_unique_id.argtypes = [vp]
+    lib.de_dist_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    lib.de_dist_destroy.argtypes = [vp]
+    lib.de_dist_shard_size.restype = i64
+    lib.de_dist_shard_size.argtypes = [i64, C.c_int, C.c_int]
+    lib.de_dist_broadcast.argtypes = [vp, vp, C.c_size_t, C.c_int]
+    lib.de_dist_gather_flags.argtypes = [vp, vp, i64, vp]
+    lib.de_dist_last_error.restype = C.c_char_p
+    lib.de_dist_last_error.argtypes = [vp]
     lib.de_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.de_ctx_last_kernel_name.restype = C.c_char_p
     lib.de_ctx_last_kernel_name.argtypes = [vp]
@@ -347,6 +358,10 @@ class Population:
         if consts.size != int(self.n_consts.sum()):
             raise ValueError("wrong number of constants")
         self.ctx.check(library().de_program_set_consts(self._h, consts.ctypes.data if consts.size else None))
+
+    def verify(self) -> None:
+        """Program sanitizer (``de_program_verify``): raises ValueError naming the offending instruction."""
+        self.ctx.check(library().de_program_verify(self._h))
 
     def plan(self, N: int) -> dict:
         """Launch plan of ``eval`` for N samples (tile size, tree chunks, trees per chunk)."""

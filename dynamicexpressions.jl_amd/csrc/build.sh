@@ -18,6 +18,7 @@ build_obj() { # src obj extra...
 build_obj de_lower.cpp _obj/de_lower.o &
 build_obj de_api.cpp _obj/de_api.o &
 build_obj de_bind.cpp _obj/de_bind.o &
+build_obj de_dist.cpp _obj/de_dist.o &
 # de_kernels.hip goes through the same steps hipcc runs internally, with one extra pass over the optimised
 # device IR (irpatch.py: the interpreter's indirect handler calls need none of the implicit kernel inputs).
 # DE_NO_IRPATCH=1 builds it the plain way.
@@ -58,6 +59,6 @@ for spec in f:float d:double; do  # the reverse-accumulation kernel: one module 
 done
 build_obj de_grad_kernels.hip _obj/de_grad_kernels.o &
 wait
-for o in _obj/de_lower.o _obj/de_bind.o _obj/de_api.o _obj/de_kernels.o _obj/de_grad_kernels.o $GT_OBJS; do [ -f $o ] || { echo "missing $o"; exit 1; }; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libde_hip.so _obj/de_lower.o _obj/de_bind.o _obj/de_api.o _obj/de_kernels.o _obj/de_grad_kernels.o $GT_OBJS
+for o in _obj/de_lower.o _obj/de_bind.o _obj/de_dist.o _obj/de_api.o _obj/de_kernels.o _obj/de_grad_kernels.o $GT_OBJS; do [ -f $o ] || { echo "missing $o"; exit 1; }; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libde_hip.so _obj/de_lower.o _obj/de_bind.o _obj/de_dist.o _obj/de_api.o _obj/de_kernels.o _obj/de_grad_kernels.o $GT_OBJS -ldl
 echo "built $(pwd)/libde_hip.so"

@@ -111,6 +111,14 @@ struct de_program {
     int32_t *d_gtcode_off = nullptr;
     int32_t *d_gt_ids = nullptr;        // tree indices grouped by bucket
     uint8_t *d_ok_eval = nullptr;       // device copy of host_ok_eval (initial value of the flags of every eval call)
+    // device-resident per-call tables of de_eval_grad, so that a call copies nothing from pageable host memory and never
+    // blocks the stream: initial flags, gradient widths of the last mode and packed offsets of the last (mode, N)
+    uint8_t *d_ok_grad = nullptr;
+    int32_t *d_ng = nullptr;
+    int64_t *d_goff = nullptr;
+    int tab_mode = -1;
+    int64_t tab_N = -1;
+    bool tab_ok_stale = true;
     // immediate sites (set_consts patches constants in place): for a generic instruction with a constant
     // operand, the index of the instruction carrying its bits in bcode / tcode (eval source program) and in
     // gbcode / gtcode (unfolded program); -1 elsewhere.  Empty = not available (full rebuild instead).
@@ -293,6 +301,7 @@ const char *de_status_string(int s) {
     case DE_ERR_NO_DEVICE: return "no gfx950 device";
     case DE_ERR_OUT_OF_RANGE: return "index out of range";
     case DE_ERR_UNSUPPORTED: return "unsupported request";
+    case DE_ERR_RCCL: return "RCCL error";
     default: return "unknown status";
     }
 }
@@ -536,6 +545,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
 // Device copy of the host part of the eval flag: every de_eval starts from it with one device-to-device copy
 // (a pageable host-to-device copy per call costs ~10 us, a fifth of a small-population call).
 static int upload_ok_eval(de_ctx *c, de_program *p) {
+    p->tab_ok_stale = true; // host_ok_grad moves with the constants too
     if (p->n_trees == 0) return DE_OK;
     if (!p->d_ok_eval) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_ok_eval), (size_t)p->n_trees));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -755,11 +765,21 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         const int rc = upload_ok_eval(ctx, p.get());
         if (rc != DE_OK) return rc; // (~de_program is not run on this path: the process is out of device memory anyway)
     }
+    if (getenv("DE_VERIFY") && *getenv("DE_VERIFY") == '1') {
+        const int rc = de_program_verify(p.get());
+        if (rc != DE_OK) return rc;
+    }
     *out_program = p.release();
     return DE_OK;
 }
 
+static int set_consts_impl(de_program_t *p, const void *consts);
 int de_program_set_consts(de_program_t *p, const void *consts) {
+    const int rc = set_consts_impl(p, consts);
+    if (rc == DE_OK && p && getenv("DE_VERIFY") && *getenv("DE_VERIFY") == '1') return de_program_verify(p);
+    return rc;
+}
+static int set_consts_impl(de_program_t *p, const void *consts) {
     if (!p) return DE_ERR_INVALID_ARG;
     de_ctx *ctx = p->ctx;
     if (!consts && !p->consts.empty()) return fail(ctx, DE_ERR_INVALID_ARG, "consts is null");
@@ -893,6 +913,8 @@ int de_program_destroy(de_program_t *p) {
     for (void *q : {(void *)p->d_rtcode, (void *)p->d_rtcode_off, (void *)p->d_rtcode_mid, (void *)p->d_rt_ids})
         if (q) (void)hipFree(q);
     if (p->d_ok_eval) (void)hipFree(p->d_ok_eval);
+    for (void *q : {(void *)p->d_ok_grad, (void *)p->d_ng, (void *)p->d_goff})
+        if (q) (void)hipFree(q);
     delete p;
     return DE_OK;
 }
@@ -914,6 +936,100 @@ int64_t de_program_n_grad(const de_program_t *p, int64_t tree, int mode) {
 int de_eval_plan(const de_program_t *p, int64_t N, int32_t *plan) {
     if (!p || !plan || N < 0) return DE_ERR_INVALID_ARG;
     eval_plan(p->dtype, p->n_trees, N, &plan[0], &plan[1], &plan[2]);
+    return DE_OK;
+}
+
+// Program sanitizer (SURVEY.md §5 "sanitizer / bounds-checked debug"): the kernels trust the instruction streams —
+// an LDS offset, a spill slot, a handler address are used as they come.  This walks every stream of the program on the
+// host and checks each field against the bounds the launch will allocate: generic code (opcodes, operand rows <
+// n_features + n_slots, push / pop slots, constant slots), bound and fused code (handler ids, rows, the int8 push
+// distance of the superinstructions), and the chained stream the threaded kernel executes (every handler address is an
+// entry of the device handler table, LDS byte offsets lie inside the launch's allocation, every tree ends in the end
+// record).  DE_VERIFY=1 runs it after every de_program_create / de_program_set_consts.
+int de_program_verify(const de_program_t *p) {
+    if (!p) return DE_ERR_INVALID_ARG;
+    de_ctx *c = p->ctx;
+    const int64_t rows = (int64_t)p->n_features + p->n_slots;
+    auto bad = [&](const char *what, int64_t tree, int64_t i, uint64_t v) {
+        return fail(c, DE_ERR_BAD_TAPE, "program verify: %s (tree %lld, instruction %lld, value 0x%llx)", what, (long long)tree, (long long)i,
+                    (unsigned long long)v);
+    };
+    const std::vector<Instr> *gens[2] = {&p->code, p->folded ? &p->fcode : nullptr};
+    const std::vector<int32_t> *goffs[2] = {&p->code_off, p->folded ? &p->fcode_off : nullptr};
+    for (int g = 0; g < 2; g++) {
+        if (!gens[g]) continue;
+        const auto &code = *gens[g];
+        const auto &off = *goffs[g];
+        if ((int64_t)off.size() != p->n_trees + 1 || off[0] != 0 || off.back() != (int32_t)code.size()) return bad("generic offsets", -1, g, off.size());
+        for (int64_t t = 0; t < p->n_trees; t++) {
+            if (off[(size_t)t + 1] <= off[(size_t)t]) return bad("empty tree", t, 0, 0);
+            for (int32_t i = off[(size_t)t]; i < off[(size_t)t + 1]; i++) {
+                const Instr &ins = code[(size_t)i];
+                const uint32_t op = ins.hdr & H_OP_MASK, src = (ins.hdr >> H_SRC_SHIFT) & H_SRC_MASK;
+                const bool known = op == DOP_LOAD || (op >= DE_U_NEG && op < DE_U_LAST_) || (op >= DE_B_ADD && op < DE_B_LAST_) ||
+                                   (op >= DE_T_FMA && op < DE_T_LAST_) || (op >= DOP_RSUB && op <= DOP_RPOW_ABS2);
+                if (!known) return bad("unknown opcode", t, i, op);
+                if (src == SRC_ROW && (int64_t)(ins.feat & 0xFFFFu) >= rows) return bad("operand row outside X + spill slots", t, i, ins.feat);
+                if (src == SRC_PARAM && (int64_t)(ins.feat & 0xFFFFu) >= p->n_params) return bad("parameter row out of range", t, i, ins.feat);
+                if (src != SRC_ACC && src != SRC_ROW && src != SRC_CONST && src != SRC_PARAM) return bad("operand kind", t, i, src);
+                if ((ins.hdr & H_PUSH) && (int)((ins.hdr >> H_PUSH_SHIFT) & H_SLOT_MASK) >= p->n_slots) return bad("push slot", t, i, ins.hdr);
+                if (op >= DE_T_FMA && op < DE_T_LAST_ && (int)((ins.hdr >> H_POPC_SHIFT) & H_SLOT_MASK) >= p->n_slots) return bad("ternary slot", t, i, ins.hdr);
+            }
+        }
+    }
+    for (size_t i = 0; i < p->bcode.size(); i++) {
+        const BoundInstr &b = p->bcode[i];
+        if (b.bop >= BOP_COUNT) return bad("bound handler id", -1, (int64_t)i, b.bop);
+        if (!bop_is_const_source(b.bop) && b.bop != BOP_GEN_PARAM && b.bop != BOP_LOAD_CONST && b.bop != BOP_CHECK_ACC && b.bop != BOP_GEN_ACC &&
+            b.bop != BOP_INJ_ACC && !(b.bop >= BOP_UN_BASE && b.bop < BOP_UN_END && !((b.bop - BOP_UN_BASE) & 2)) &&
+            (int64_t)(b.arg & 0xFFFFFFu) >= rows)
+            return bad("bound operand row", -1, (int64_t)i, b.arg);
+    }
+    if (p->threaded) {
+        uint64_t table[TOPX_TABLE];
+        if (eval_handler_table(p->dtype, (p->options & DE_OPT_TURBO) != 0, table) != hipSuccess) return fail(c, DE_ERR_HIP, "handler table");
+        std::vector<uint64_t> valid(table, table + TOPX_TABLE);
+        std::sort(valid.begin(), valid.end());
+        const uint64_t lds_bytes = (uint64_t)(rows + (p->uses_params ? 2 : 0)) * TROW_BYTES;
+        if ((int64_t)p->ccode_off.size() != p->n_trees + 1 || p->ccode.size() != p->tcode.size() + (size_t)p->n_trees) return bad("chained layout", -1, 0, p->ccode.size());
+        const bool f32 = p->dtype == DE_F32;
+        for (int64_t t = 0; t < p->n_trees; t++) {
+            const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1], h = p->ccode_off[(size_t)t];
+            if (h != i0 + (int32_t)t) return bad("chained offset", t, h, (uint64_t)i0);
+            for (int32_t i = i0; i <= i1; i++) {
+                const BoundInstr &r = p->ccode[(size_t)(h + (i - i0))];
+                const uint64_t addr = f32 ? (((uint64_t)r.hi << 32) | r.lo) : ((table[0] & 0xFFFFFFFF00000000ull) | r.arg);
+                if (!std::binary_search(valid.begin(), valid.end(), addr)) return bad("handler address not in the device table", t, i - i0, addr);
+                if (i == i1) {
+                    if (addr != p->end_handler) return bad("tree does not end in the end record", t, i - i0, addr);
+                    continue;
+                }
+                const BoundInstr &fb = p->fbcode[(size_t)i];
+                if (addr != p->handler_base + p->tcode[(size_t)i].bop) return bad("record / threaded code mismatch", t, i - i0, addr);
+                if (fb.bop >= TOPX_COUNT) return bad("fused handler id", t, i - i0, fb.bop);
+                const bool no_row = top_is_const_source(fb.bop) || fb.bop == BOP_CHECK_ACC || fb.bop == BOP_GEN_ACC || fb.bop == BOP_INJ_ACC ||
+                                    fb.bop == BOP_GEN_PARAM || (fb.bop >= BOP_UN_BASE && fb.bop < BOP_UN_END && !((fb.bop - BOP_UN_BASE) & 2)) ||
+                                    (fb.bop >= TOPX_UN_BASE && fb.bop < TOPX_BIN_BASE && ((fb.bop - TOPX_UN_BASE) & 1)) ||
+                                    (fb.bop >= TOPX_BIN_BASE && ((fb.bop - TOPX_BIN_BASE) & 1));
+                if (!no_row) {
+                    const uint64_t off = r.bop & 0xFFFFFFu;
+                    if (off % TROW_BYTES != 0 || off + TROW_BYTES > lds_bytes) return bad("LDS operand offset outside the launch's allocation", t, i - i0, r.bop);
+                    const bool pushes = (fb.bop >= TOP_LOADROW_BASE && fb.bop < TOP_LOADCONST_PUSH && ((fb.bop - TOP_LOADROW_BASE) & 2)) ||
+                                        (fb.bop >= TOP_UNROW_BASE && fb.bop < TOP_BINROWC_BASE && ((fb.bop - TOP_UNROW_BASE) & 2)) ||
+                                        (fb.bop >= TOP_BIN2_BASE && fb.bop < TOP_COUNT && ((fb.bop - TOP_BIN2_BASE) & 1));
+                    if (pushes) {
+                        const int64_t prow = (int64_t)(off / TROW_BYTES) + (int8_t)(r.bop >> 24);
+                        if (prow < p->n_features || prow >= rows) return bad("push row of a superinstruction outside the spill slots", t, i - i0, r.bop);
+                    }
+                    if (fb.bop >= TOP_BIN2_BASE && fb.bop < TOP_COUNT && !(((fb.bop - TOP_BIN2_BASE) >> 2) & 1)) { // row-row: second row by distance
+                        const int64_t second = (int64_t)off + (int32_t)(f32 ? r.arg : r.lo);
+                        if (second < 0 || second % (int64_t)TROW_BYTES != 0 || (uint64_t)second + TROW_BYTES > lds_bytes) return bad("second operand row of a two-operand form", t, i - i0, (uint64_t)second);
+                    }
+                }
+                if (fb.bop == BOP_GEN_PARAM && (f32 ? r.arg : r.lo) != (uint32_t)rows * (uint32_t)TROW_BYTES) return bad("class-row offset of a parameter operand", t, i - i0, r.arg);
+            }
+        }
+    }
     return DE_OK;
 }
 
@@ -1963,19 +2079,50 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
         sOk.dev = c->sOk.p;
         sOk.staged = true;
     }
-    HIP_TRY(c, hipMemcpyAsync(sOk.dev, ok_init, (size_t)p->n_trees, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, c->sGoff.reserve(goff.size() * sizeof(int64_t)));
-    HIP_TRY(c, c->sNg.reserve(ng.size() * sizeof(int32_t)));
-    HIP_TRY(c, hipMemcpyAsync(c->sGoff.p, goff.data(), goff.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->sNg.p, ng.data(), ng.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    // The initial flags, the gradient widths and (packed layout) the offsets depend on the program, the mode and N only:
+    // they live on the device and are refreshed when one of those changes — the usual call copies nothing from pageable
+    // host memory and does not block.  Caller-supplied offsets and eval_diff take the staged path.
+    const bool cached = !diff && !grad_offsets;
+    const int64_t *d_goff_use = nullptr;
+    const int32_t *d_ng_use = nullptr;
+    if (cached) {
+        const size_t nt = (size_t)p->n_trees;
+        if (!p->d_ok_grad) {
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_ok_grad), nt));
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_ng), nt * sizeof(int32_t)));
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_goff), nt * sizeof(int64_t)));
+            p->tab_ok_stale = true;
+            p->tab_mode = -1;
+        }
+        if (p->tab_ok_stale || p->tab_mode != mode || p->tab_N != N) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream)); // earlier calls may still read the tables
+            HIP_TRY(c, hipMemcpy(p->d_ok_grad, p->host_ok_grad.data(), nt, hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(p->d_ng, ng.data(), nt * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(c, hipMemcpy(p->d_goff, goff.data(), nt * sizeof(int64_t), hipMemcpyHostToDevice));
+            p->tab_ok_stale = false;
+            p->tab_mode = mode;
+            p->tab_N = N;
+        }
+        HIP_TRY(c, hipMemcpyAsync(sOk.dev, p->d_ok_grad, nt, hipMemcpyDeviceToDevice, c->stream));
+        d_goff_use = p->d_goff;
+        d_ng_use = p->d_ng;
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(sOk.dev, ok_init, (size_t)p->n_trees, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, c->sGoff.reserve(goff.size() * sizeof(int64_t)));
+        HIP_TRY(c, c->sNg.reserve(ng.size() * sizeof(int32_t)));
+        HIP_TRY(c, hipMemcpyAsync(c->sGoff.p, goff.data(), goff.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->sNg.p, ng.data(), ng.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        d_goff_use = static_cast<const int64_t *>(c->sGoff.p);
+        d_ng_use = static_cast<const int32_t *>(c->sNg.p);
+    }
     if (p->uses_params) {
         rc = stage_in(c, c->sParams, pa->params, (size_t)pa->ld_params * (size_t)pa->n_classes * es, &sPar);
         if (rc) return rc;
         rc = stage_in(c, c->sClasses, pa->classes, (size_t)N * (pa->classes_is_i64 ? 8 : 4), &sCls);
         if (rc) return rc;
     }
-    // the pageable host vectors above must outlive their async copies
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // the pageable host vectors of the staged path must outlive their async copies
+    if (!cached) HIP_TRY(c, hipStreamSynchronize(c->stream));
 
     GradArgs g;
     std::memset(&g, 0, sizeof g);
@@ -2002,8 +2149,8 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
     g.mode = diff ? DE_GRAD_VARIABLE : mode;
     g.P = p->n_params;
     g.grad = sGrad.dev;
-    g.grad_off = static_cast<const int64_t *>(c->sGoff.p);
-    g.n_grad = static_cast<const int32_t *>(c->sNg.p);
+    g.grad_off = d_goff_use;
+    g.n_grad = d_ng_use;
     g.max_grad = maxg;
     g.diff_direction = diff ? diff_direction : -1;
     g.e.code_off = p->d_gcode_off;

@@ -1,0 +1,168 @@
+// de_dist.cpp — the multi-GPU exchange of the path behind the C ABI (include/de_hip.h, "multi-GPU"): a population is
+// tree-sharded round-robin over one process per GPU, X is replicated, every rank keeps its output slab,
+// and the ONLY data exchanged per evaluation are the per-tree completion flags — one ncclAllGather of ceil(n_trees /
+// world) bytes per rank over RCCL / xGMI, latency-bound.  A Julia (or C) caller gets the same three calls bench.py makes
+// through torch.distributed: replicate X once (broadcast), evaluate the local shard (de_eval), gather the flags.
+//
+// RCCL is loaded at run time (dlopen): libde_hip.so has no link dependency on it and single-GPU users never touch it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/de_hip.h"
+
+namespace {
+struct NcclId { char internal[128]; }; // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+typedef void *NcclComm;
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(NcclId *) = nullptr;
+    int (*CommInitRank)(NcclComm *, int, NcclId, int) = nullptr;
+    int (*CommDestroy)(NcclComm) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, NcclComm, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
+#define SYM(F, N)                                                           \
+    F = reinterpret_cast<decltype(F)>(dlsym(lib, N));                       \
+    if (!F) { err = std::string("librccl.so lacks ") + N; return false; }
+        SYM(GetUniqueId, "ncclGetUniqueId")
+        SYM(CommInitRank, "ncclCommInitRank")
+        SYM(CommDestroy, "ncclCommDestroy")
+        SYM(AllGather, "ncclAllGather")
+        SYM(Broadcast, "ncclBroadcast")
+        SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclUint8 = 1; // ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1
+} // namespace
+
+struct de_comm {
+    de_ctx_t *ctx = nullptr;
+    NcclComm comm = nullptr;
+    int rank = 0, world = 1;
+    uint8_t *send = nullptr, *recv = nullptr; // device staging: ceil(n / world) and world * ceil(n / world) bytes
+    size_t cap = 0;
+    std::string err;
+};
+
+static int dfail(de_comm *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_rccl.err = buf;
+    return code;
+}
+
+extern "C" {
+
+const char *de_dist_last_error(de_comm_t *c) { return c ? c->err.c_str() : g_rccl.err.c_str(); }
+
+int de_dist_unique_id(void *id) {
+    if (!id) return DE_ERR_INVALID_ARG;
+    if (!g_rccl.load()) return DE_ERR_RCCL;
+    NcclId u;
+    const int rc = g_rccl.GetUniqueId(&u);
+    if (rc != 0) return dfail(nullptr, DE_ERR_RCCL, "ncclGetUniqueId: %s", g_rccl.GetErrorString(rc));
+    std::memcpy(id, u.internal, sizeof u.internal);
+    return DE_OK;
+}
+
+int de_dist_init(de_ctx_t *ctx, int rank, int world, const void *id, de_comm_t **out) {
+    if (!ctx || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !id)) return DE_ERR_INVALID_ARG;
+    de_comm *c = new de_comm;
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    if (world > 1) {
+        if (!g_rccl.load()) { delete c; return DE_ERR_RCCL; }
+        NcclId u;
+        std::memcpy(u.internal, id, sizeof u.internal);
+        const int rc = g_rccl.CommInitRank(&c->comm, world, u, rank);
+        if (rc != 0) {
+            dfail(nullptr, DE_ERR_RCCL, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(rc));
+            delete c;
+            return DE_ERR_RCCL;
+        }
+    }
+    *out = c;
+    return DE_OK;
+}
+
+int de_dist_destroy(de_comm_t *c) {
+    if (!c) return DE_OK;
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    if (c->send) (void)hipFree(c->send);
+    if (c->recv) (void)hipFree(c->recv);
+    delete c;
+    return DE_OK;
+}
+
+int64_t de_dist_shard_size(int64_t n_trees, int rank, int world) { // trees {t : t mod world == rank}
+    return n_trees > rank ? (n_trees - rank + world - 1) / world : 0;
+}
+
+int de_dist_broadcast(de_comm_t *c, void *buf, size_t bytes, int root) {
+    if (!c || (!buf && bytes) || root < 0 || root >= c->world) return DE_ERR_INVALID_ARG;
+    if (c->world == 1 || bytes == 0) return DE_OK;
+    hipStream_t stream = static_cast<hipStream_t>(de_ctx_stream(c->ctx));
+    const int rc = g_rccl.Broadcast(buf, buf, bytes, kNcclUint8, root, c->comm, stream);
+    if (rc != 0) return dfail(c, DE_ERR_RCCL, "ncclBroadcast: %s", g_rccl.GetErrorString(rc));
+    return DE_OK;
+}
+
+int de_dist_gather_flags(de_comm_t *c, const uint8_t *ok_local, int64_t n_trees, uint8_t *ok_global) {
+    if (!c || n_trees < 0 || (n_trees > 0 && (!ok_local || !ok_global))) return DE_ERR_INVALID_ARG;
+    if (n_trees == 0) return DE_OK;
+    hipStream_t stream = static_cast<hipStream_t>(de_ctx_stream(c->ctx));
+    const int64_t mine = de_dist_shard_size(n_trees, c->rank, c->world);
+    const size_t per = (size_t)((n_trees + c->world - 1) / c->world);
+#define HIPD(expr)                                                                                      \
+    do {                                                                                                \
+        hipError_t st_ = (expr);                                                                        \
+        if (st_ != hipSuccess) return dfail(c, DE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(st_));  \
+    } while (0)
+    if (c->world == 1) {
+        HIPD(hipMemcpyAsync(ok_global, ok_local, (size_t)n_trees, hipMemcpyDefault, stream));
+        return DE_OK;
+    }
+    if (c->cap < per) {
+        if (c->send) (void)hipFree(c->send);
+        if (c->recv) (void)hipFree(c->recv);
+        c->send = c->recv = nullptr;
+        HIPD(hipMalloc(reinterpret_cast<void **>(&c->send), per));
+        HIPD(hipMalloc(reinterpret_cast<void **>(&c->recv), per * (size_t)c->world));
+        c->cap = per;
+    }
+    HIPD(hipMemsetAsync(c->send, 1, per, stream)); // padding entries (ranks with one tree fewer) read as complete
+    HIPD(hipMemcpyAsync(c->send, ok_local, (size_t)mine, hipMemcpyDefault, stream));
+    const int rc = g_rccl.AllGather(c->send, c->recv, per, kNcclUint8, c->comm, stream);
+    if (rc != 0) return dfail(c, DE_ERR_RCCL, "ncclAllGather: %s", g_rccl.GetErrorString(rc));
+    // rank r holds trees r, r + world, ...: entry [r][i] of the gathered block is tree r + i * world — a strided copy per rank
+    for (int r = 0; r < c->world; r++) {
+        const int64_t cnt = de_dist_shard_size(n_trees, r, c->world);
+        if (cnt > 0)
+            HIPD(hipMemcpy2DAsync(ok_global + r, (size_t)c->world, c->recv + (size_t)r * per, 1, 1, (size_t)cnt, hipMemcpyDefault, stream));
+    }
+#undef HIPD
+    return DE_OK;
+}
+
+} // extern "C"

@@ -50,3 +50,55 @@ def scatter_population(trees, rank: int, world: int):
 def unshard_order(n_trees: int, world: int) -> np.ndarray:
     """Permutation p with global_tree = p[k] for the concatenation of rank shards."""
     return np.concatenate([np.arange(r, n_trees, world) for r in range(world)]) if n_trees else np.zeros(0, int)
+
+
+class Comm:
+    """The same exchange through the C ABI (``de_dist_*``, csrc/de_dist.cpp: RCCL loaded by the library itself) — what a
+    Julia or C caller uses; no torch.distributed involved.  ``unique_id()`` on rank 0, ship the 128 bytes to the other
+    ranks by any means, ``Comm(ctx, rank, world, id)`` everywhere."""
+
+    def __init__(self, ctx, rank: int = 0, world: int = 1, unique_id: bytes = b""):
+        import ctypes as C
+        from . import api
+        self._lib, self._ctx, self.rank, self.world = api.library(), ctx, rank, world
+        self._h = C.c_void_p()
+        idbuf = C.create_string_buffer(bytes(unique_id), 128) if world > 1 else None
+        rc = self._lib.de_dist_init(ctx._h, rank, world, idbuf, C.byref(self._h))
+        if rc != 0:
+            raise api.DeviceError(f"de_dist_init: {self._lib.de_status_string(rc).decode()}: {self._lib.de_dist_last_error(None).decode()}")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import api
+        lib = api.library()
+        buf = C.create_string_buffer(128)
+        rc = lib.de_dist_unique_id(buf)
+        if rc != 0:
+            raise api.DeviceError(f"de_dist_unique_id: {lib.de_dist_last_error(None).decode()}")
+        return buf.raw
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            from . import api
+            raise api.DeviceError(f"{self._lib.de_status_string(rc).decode()}: {self._lib.de_dist_last_error(self._h).decode()}")
+
+    def shard_size(self, n_trees: int) -> int:
+        return int(self._lib.de_dist_shard_size(n_trees, self.rank, self.world))
+
+    def broadcast(self, tensor, root: int = 0) -> None:
+        """Replicate a device tensor (X) from ``root``; asynchronous on the context's stream."""
+        self._check(self._lib.de_dist_broadcast(self._h, tensor.data_ptr(), tensor.numel() * tensor.element_size(), root))
+
+    def gather_flags(self, ok_local, n_trees: int):
+        """Flags of ALL trees in global tree order (uint8 device tensor of length n_trees) from every rank's local flags."""
+        import torch
+        out = torch.empty(n_trees, dtype=torch.uint8, device=ok_local.device)
+        loc = ok_local.to(torch.uint8).contiguous()
+        self._check(self._lib.de_dist_gather_flags(self._h, loc.data_ptr(), n_trees, out.data_ptr()))
+        return out
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.de_dist_destroy(self._h)
+            self._h = None

@@ -65,7 +65,8 @@ typedef enum de_status {
     DE_ERR_HIP = 4,            /* a HIP runtime call failed (see de_last_error)  */
     DE_ERR_NO_DEVICE = 5,      /* no gfx950 device visible                       */
     DE_ERR_OUT_OF_RANGE = 6,   /* feature/param/const/class index out of range   */
-    DE_ERR_UNSUPPORTED = 7     /* valid request this build cannot serve          */
+    DE_ERR_UNSUPPORTED = 7,    /* valid request this build cannot serve          */
+    DE_ERR_RCCL = 8            /* librccl.so missing or an RCCL call failed (de_dist_last_error) */
 } de_status_t;
 
 typedef enum de_dtype { DE_F32 = 0, DE_F64 = 1 } de_dtype_t;
@@ -182,6 +183,14 @@ int64_t de_program_n_grad(const de_program_t *prog, int64_t tree, int mode);
 int64_t de_program_dump(const de_program_t *prog, int64_t tree, uint32_t *words, int64_t cap,
                         int which);
 
+/* Program sanitizer: walk every instruction stream of the program on the host and check each field against the bounds
+ * the launches allocate (operand rows, spill slots, LDS byte offsets, handler addresses against the device's handler
+ * table, end records).  Returns DE_OK, or DE_ERR_BAD_TAPE with the offending (tree, instruction) in de_last_error.
+ * With DE_VERIFY=1 in the environment it runs after every de_program_create / de_program_set_consts (debug builds of a
+ * caller, CI).  The kernels themselves clamp class ids and never read outside the caller's X / out extents
+ * (samples past N are clamped to N - 1 and not stored). */
+int de_program_verify(const de_program_t *prog);
+
 /* Host-only hook (makes no HIP call, works without a GPU): lower ONE tape and
  * return its instruction words (4 x uint32 each, csrc/de_program.h) in `words`
  * (capacity `cap` words).  meta[4] = {spill slots, host part of the eval flag,
@@ -297,6 +306,28 @@ int de_eval_loss_grad_by_class(de_ctx_t *ctx, de_program_t *prog, const void *X,
 int de_eval_pullback_dX(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, int64_t ldX,
                         const de_param_args_t *pargs, const void *dY, void *dX,
                         const int64_t *dX_offsets, uint8_t *ok);
+
+/* ---- multi-GPU: one process per GPU, population tree-sharded, RCCL over xGMI -----------------------------
+ * The path shards embarrassingly: rank r owns trees {t : t mod world == r} (round-robin balances node
+ * counts), X is replicated, every rank evaluates its shard with de_eval* into its own output slab, and the only exchange
+ * per evaluation is ONE all-gather of the per-tree completion flags (ceil(n_trees / world) bytes per rank, latency-bound).
+ * Outputs are never gathered (400 GB at BASELINE config 4).  Usage (every rank):
+ *     char id[DE_DIST_ID_BYTES];  if (rank == 0) de_dist_unique_id(id);   <ship the 128 bytes to the other ranks: MPI,
+ *     a file, a socket, Julia's Distributed>;   de_dist_init(ctx, rank, world, id, &comm);
+ *     de_dist_broadcast(comm, X_dev, bytes, 0);                     // once per dataset
+ *     de_eval(ctx, local_program, X_dev, ..., out_local, ld, ok_local);
+ *     de_dist_gather_flags(comm, ok_local, n_trees_global, ok_global);  // ok_global[t] in global tree order, on every rank
+ * All calls are asynchronous on the context's stream.  librccl.so is loaded on first use (dlopen); without it the
+ * calls return DE_ERR_RCCL and single-GPU use is unaffected.  world == 1 needs no id and no RCCL. */
+typedef struct de_comm de_comm_t;
+#define DE_DIST_ID_BYTES 128
+int de_dist_unique_id(void *id);
+int de_dist_init(de_ctx_t *ctx, int rank, int world, const void *id, de_comm_t **out_comm);
+int de_dist_destroy(de_comm_t *comm);
+int64_t de_dist_shard_size(int64_t n_trees, int rank, int world);
+int de_dist_broadcast(de_comm_t *comm, void *buf, size_t bytes, int root);
+int de_dist_gather_flags(de_comm_t *comm, const uint8_t *ok_local, int64_t n_trees, uint8_t *ok_global);
+const char *de_dist_last_error(de_comm_t *comm); /* comm may be NULL: errors of de_dist_unique_id / de_dist_init */
 
 /* ---- one-shot convenience with the reference's single-tree signature ------- */
 int de_eval_tree_array(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, int64_t n_nodes,

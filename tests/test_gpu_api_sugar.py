@@ -108,3 +108,32 @@ def test_pullback_dX_times_dY(api):
         else:
             assert np.all(np.isnan(dX[t]))  # src/ChainRules.jl:62-64: NaN cotangent when incomplete
     pop.close()
+
+
+def test_simplify_tree_folds_on_the_device_with_the_device_bits(api):
+    """simplify_tree! (src/Simplify.jl:118-136) folds ANY operator whose children are constants.  The host twin evaluates
+    the feature-free subtrees with the device library (one launch): the folded constants are the bits the device's own
+    constant folding produces, relu(-2) is +0 (so 1/relu(-2) stays +Inf), and operators without a numpy table entry fold."""
+    from dynamicexpressions_jl_amd import simplify
+    ops = de.OperatorEnum(binary_operators=("+", "*", "/", "mod", "pow_abs2"), unary_operators=("cos", "relu", "gamma", "exp"))
+    c = lambda v: de.Node(val=v)  # noqa: E731
+    x1 = de.Node(feature=1)
+    # x1 * (cos(2.5) + mod(7.5, 2.0))  +  pow_abs2(gamma(3.5), 0.3) / relu(-2.0)
+    t = de.Node(1, de.Node(2, x1, de.Node(1, de.Node(1, c(2.5)), de.Node(4, c(7.5), c(2.0)))),
+                de.Node(3, de.Node(5, de.Node(3, c(3.5)), c(0.3)), de.Node(2, c(-2.0))))
+    X = np.asfortranarray(np.linspace(-1, 1, 64, dtype=np.float32)[None, :])
+    before, _ = api.eval_tree_array(t.copy(), X, ops, eval_context=api.EvalContext(early_exit=False))
+    s = simplify.simplify_tree(t.copy(), ops, np.float32, use_device=True)
+    # cos(2.5) + mod(7.5, 2) and pow_abs2(gamma(3.5), 0.3) and relu(-2) are constants now; the division by +0 is not finite: kept
+    assert de.count_nodes(s) == 7 and de.string_tree(s, ops).count("relu") == 0
+    relu_leaf = s.children[1].children[1]
+    assert relu_leaf.degree == 0 and relu_leaf.val == 0.0 and not np.signbit(relu_leaf.val)
+    after, _ = api.eval_tree_array(s, X, ops, eval_context=api.EvalContext(early_exit=False))
+    assert np.all(np.isposinf(after)) and np.all(np.isposinf(before))
+    # a tree that stays finite: the simplified tree gives the bits of the original (device-side folding == host fold)
+    t2 = de.Node(1, de.Node(2, x1, de.Node(1, de.Node(1, c(2.5)), de.Node(4, c(7.5), c(2.0)))), de.Node(4, de.Node(3, c(3.5)), c(0.3)))
+    b2, ok2 = api.eval_tree_array(t2.copy(), X, ops)
+    s2 = simplify.simplify_tree(t2.copy(), ops, np.float32)
+    a2, oka = api.eval_tree_array(s2, X, ops)
+    assert ok2 and oka and de.count_nodes(s2) == 5
+    np.testing.assert_array_equal(a2, b2)

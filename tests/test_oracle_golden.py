@@ -1,11 +1,14 @@
 """Pins the CPU oracle against every known-answer the reference's own tests/docs hold for
 the hot path (tests/golden/reference_known_answers.json).  CPU only."""
+import os
 import numpy as np
 import pytest
 
 import dynamicexpressions_jl_amd as de
 from helpers import case_X, case_options, case_tree, check_values, load_golden
 from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CASES = load_golden()
 MODE = {"variable": oracle.GRAD_VARIABLE, "constant": oracle.GRAD_CONSTANT, "both": oracle.GRAD_BOTH}
@@ -108,3 +111,16 @@ def test_unfused_leaf_is_validity_tested_but_fused_leaf_is_not():
     # with fusion disabled (>15 operators of the degree) every leaf is tested
     _, ok = oracle.eval_tree_array(*de.flatten(t1, ops, np.float64), X, oracle.OPT_EARLY_EXIT)
     assert not ok
+
+
+def test_oracle_is_clean_under_address_and_ub_sanitizers():
+    """`make -C oracle asan`: the oracle's entry points under ASan + UBSan (oracle/selftest.c: 4000 random tapes over every
+    opcode through eval / grad / diff / parametric, malformed tapes, two known answers).  The oracle decides what every
+    parity test expects, so a memory error in it would surface as a wrong expectation, not as a crash."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc") and not shutil.which("cc"):
+        pytest.skip("no C compiler")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "oracle selftest OK" in r.stdout
