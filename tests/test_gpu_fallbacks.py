@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import dynamicexpressions_jl_amd as de
+from helpers import grad_tolerance, parity_tolerance
 
 pytestmark = pytest.mark.gpu
 
@@ -82,11 +83,16 @@ def test_gradient_fallback_kernel_matches_the_threaded_one(api, monkeypatch, dty
             alt.close()
             monkeypatch.delenv("DE_GRAD_THREADED")
             assert np.array_equal(ka, kb) and "tape" in name
+            mode = {True: "variable", False: "constant", "both": "both"}[variable]
             for t in np.nonzero(ka)[0]:
-                # the two kernels share the value/partial functions but not the hot-operator fast paths: rounding-level agreement
-                np.testing.assert_allclose(np.asarray(ga[t]), np.asarray(gb[t]), rtol=2e-5 if dtype == np.float32 else 1e-12,
-                                           atol=1e-30, err_msg=f"tree {t} {variable}")
-                np.testing.assert_allclose(oa[t], ob[t], rtol=2e-6 if dtype == np.float32 else 1e-13)
+                # the two kernels share the value/partial functions but not the hot-operator fast paths (cos/exp/sin): each is
+                # within the conditioned bound of the true Jacobian (helpers.grad_tolerance), so they are within twice that
+                tol = grad_tolerance(trees[t], ops, X, dtype, mode)
+                err = np.abs(np.asarray(ga[t], dtype=np.float64) - np.asarray(gb[t], dtype=np.float64))
+                assert tol is not None and not (err > 2 * tol).any(), f"tree {t} {variable}"
+                tx = parity_tolerance(trees[t], ops, X, dtype)
+                m = np.isfinite(tx)
+                assert np.all(np.abs(oa[t].astype(np.float64) - ob[t])[m] <= 2 * tx[m])
 
 
 def test_loss_gradient_forward_and_reverse_kernels_agree(api, monkeypatch):
