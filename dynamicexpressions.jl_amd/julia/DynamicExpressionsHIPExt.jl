@@ -31,8 +31,8 @@ const DE_OK = Cint(0)
 const DE_ERR_UNSUPPORTED_OP = Cint(3)
 const DE_LEAF_CONST, DE_LEAF_FEATURE, DE_LEAF_PARAM = UInt8(0), UInt8(1), UInt8(2)
 const DE_F32, DE_F64 = Cint(0), Cint(1)
-const DE_OPT_EARLY_EXIT, DE_OPT_FUSE_DEG1, DE_OPT_FUSE_DEG2, DE_OPT_BUMPER_CHECKS =
-    UInt32(1), UInt32(2), UInt32(4), UInt32(8)
+const DE_OPT_EARLY_EXIT, DE_OPT_FUSE_DEG1, DE_OPT_FUSE_DEG2, DE_OPT_BUMPER_CHECKS, DE_OPT_TURBO =
+    UInt32(1), UInt32(2), UInt32(4), UInt32(8), UInt32(16)
 const OPERATOR_LIMIT_BEFORE_SLOWDOWN = 15   # src/Evaluate.jl:14
 dtype_code(::Type{Float32}) = DE_F32
 dtype_code(::Type{Float64}) = DE_F64
@@ -42,18 +42,93 @@ struct UnsupportedOperator <: Exception
     degree::Int
 end
 
-# ---- OperatorEnum -> opcode table (by function NAME; the C table is authoritative) -----------
-"""Opcode of every operator of `operators`, per degree; throws `UnsupportedOperator` for a
-function the device table does not know (the caller then keeps the CPU path)."""
-function opcode_table(operators::OperatorEnum)
-    return ntuple(length(operators.ops)) do d
-        map(operators.ops[d]) do f
-            name = String(nameof(f))
-            code = ccall((:de_opcode_by_name, LIBDE), Cint, (Cstring, Cint), name, d)
-            code < 0 && throw(UnsupportedOperator(f, d))
-            UInt8(code)
+# ---- OperatorEnum -> opcode table: by function IDENTITY ----------------------------------------
+# An OperatorEnum holds arbitrary Julia functions (src/OperatorEnum.jl:14-49); the device knows a closed set of
+# opcodes (include/de_opcodes.h).  A function is mapped onto an opcode only when it IS one of the functions below
+# (`===`): Base's own `cos`, `+`, `max` ... .  A user function that merely shares a name with one of them (`cos(x) =
+# my_cos(x)`, an anonymous function, a method-extended copy in another module) is NOT the same object and has no opcode:
+# `opcode_table` throws `UnsupportedOperator` and the caller keeps the reference CPU path — never wrong values with
+# `complete = true`.
+const BASE_OPCODES = let t = IdDict{Any,Tuple{Vararg{Pair{Int,String}}}}()
+    reg(f, pairs...) = (t[f] = pairs)
+    for (f, n) in ((sin, "sin"), (cos, "cos"), (tan, "tan"), (exp, "exp"), (exp2, "exp2"), (log, "log"), (log2, "log2"),
+                   (log10, "log10"), (log1p, "log1p"), (sqrt, "sqrt"), (cbrt, "cbrt"), (abs, "abs"), (sinh, "sinh"),
+                   (cosh, "cosh"), (tanh, "tanh"), (asin, "asin"), (acos, "acos"), (atan, "atan"), (asinh, "asinh"),
+                   (acosh, "acosh"), (atanh, "atanh"), (round, "round"), (floor, "floor"), (ceil, "ceil"), (sign, "sign"),
+                   (inv, "inv"), (abs2, "square"))
+        reg(f, 1 => n)
+    end
+    reg(-, 1 => "neg", 2 => "-")                       # unary minus and subtraction are the same Julia function
+    reg(+, 2 => "+", 3 => "+")
+    reg(max, 2 => "max", 3 => "max")
+    for (f, n) in ((*, "*"), (/, "/"), (^, "^"), (min, "min"), (mod, "mod"), (rem, "rem"))
+        reg(f, 2 => n)
+    end
+    reg(fma, 3 => "fma")
+    reg(clamp, 3 => "clamp")
+    t
+end
+# Functions that are NOT in Base — the helpers the reference's own tests define (`safe_log`, `relu`, `square`, `cube`,
+# `custom_cos`, `pow_abs2`, `greater`, `sub` ..., test/test_params.jl:7-29) or SpecialFunctions.gamma — have opcodes too,
+# but only the user can vouch that THEIR function of that name has those semantics (and that gradient):
+#     register_hip_opcode(my_safe_log, :safe_log)
+# The registration probes the function on a few points against the opcode's definition and refuses a mismatch.
+const USER_OPCODES = IdDict{Any,Tuple{Int,String}}()
+const USER_OPCODES_LOCK = ReentrantLock()
+const PROBES = (0.37, 1.0, 2.5, -0.6, -2.25)
+const OPCODE_SEMANTICS = Dict{Symbol,Function}(
+    :safe_log => x -> x > 0 ? log(x) : NaN, :safe_log2 => x -> x > 0 ? log2(x) : NaN, :safe_log10 => x -> x > 0 ? log10(x) : NaN,
+    :safe_log1p => x -> x > -1 ? log1p(x) : NaN, :safe_sqrt => x -> x >= 0 ? sqrt(x) : NaN, :safe_acosh => x -> x >= 1 ? acosh(x) : NaN,
+    :relu => x -> x < 0 ? zero(x) : x, :square => x -> x * x, :cube => x -> x * x * x, :neg => x -> -x, :custom_cos => x -> cos(x)^2,
+    :greater => (x, y) -> x > y ? 1.0 : 0.0, :sub => (x, y) -> x - y, :pow_abs2 => (x, y) -> exp(y * log(abs(x))),
+    :add => (x, y) -> x + y, :mult => (x, y) -> x * y, :div => (x, y) -> x / y, :pow => (x, y) -> x^y,
+)
+"""
+    register_hip_opcode(f, name::Symbol)
+
+Declare that the user function `f` computes the device operator `name` (one of `keys(OPCODE_SEMANTICS)`, or `:gamma`).
+`f` is probed against the operator's definition on a few points (NaN pattern included); a mismatch throws.  Registration
+is by identity: other functions of the same name stay on the CPU path.
+"""
+function register_hip_opcode(f, name::Symbol)
+    degree = first(methods(f)).nargs - 1
+    code = ccall((:de_opcode_by_name, LIBDE), Cint, (Cstring, Cint), String(name), degree)
+    code < 0 && throw(ArgumentError("no device operator $(name) of degree $(degree)"))
+    if haskey(OPCODE_SEMANTICS, name)
+        g = OPCODE_SEMANTICS[name]
+        for x in PROBES, y in (degree == 2 ? PROBES : (0.0,))
+            a = try degree == 1 ? f(x) : f(x, y) catch; NaN end     # DomainError == NaN on the device
+            b = degree == 1 ? g(x) : g(x, y)
+            (isnan(a) && isnan(b)) || isapprox(a, b; rtol=1e-12) ||
+                throw(ArgumentError("$(f) is not the operator $(name): f($(x)$(degree == 2 ? ", $(y)" : "")) = $(a), expected $(b)"))
         end
     end
+    lock(USER_OPCODES_LOCK) do
+        USER_OPCODES[f] = (degree, String(name))
+    end
+    return f
+end
+
+function opcode_of(f, d::Int)
+    name = nothing
+    if haskey(BASE_OPCODES, f)
+        for (deg, n) in BASE_OPCODES[f]
+            deg == d && (name = n)
+        end
+    else
+        entry = lock(() -> get(USER_OPCODES, f, nothing), USER_OPCODES_LOCK)
+        entry !== nothing && entry[1] == d && (name = entry[2])
+    end
+    name === nothing && throw(UnsupportedOperator(f, d))
+    code = ccall((:de_opcode_by_name, LIBDE), Cint, (Cstring, Cint), name, d)
+    code < 0 && throw(UnsupportedOperator(f, d))
+    return UInt8(code)
+end
+
+"""Opcode of every operator of `operators`, per degree; throws `UnsupportedOperator` for a
+function that is neither one of Base's (by identity) nor registered (the caller then keeps the CPU path)."""
+function opcode_table(operators::OperatorEnum)
+    return ntuple(d -> map(f -> opcode_of(f, d), operators.ops[d]), length(operators.ops))
 end
 
 """EvalContext knobs that change RESULTS -> de_options bits (src/Evaluate.jl:156-181,496,607)."""
@@ -65,6 +140,7 @@ function option_bits(operators::OperatorEnum, ctx::EvalContext)
     fused && nops(1) <= OPERATOR_LIMIT_BEFORE_SLOWDOWN && (bits |= DE_OPT_FUSE_DEG1)
     fused && nops(2) <= OPERATOR_LIMIT_BEFORE_SLOWDOWN && (bits |= DE_OPT_FUSE_DEG2)
     ctx.bumper isa Val{true} && (bits |= DE_OPT_BUMPER_CHECKS)
+    ctx.turbo isa Val{true} && (bits |= DE_OPT_TURBO)   # the LoopVectorization knob = the relaxed-accuracy device operators
     return bits
 end
 
@@ -91,28 +167,44 @@ function flatten!(
     return nothing
 end
 
-# ---- context: one de_ctx_t per Julia task/thread --------------------------------------------
+# ---- context: one de_ctx_t per Julia TASK ---------------------------------------------------
+# A de_ctx_t is not thread-safe (INTEGRATION.md §4): every call on it — and the destruction of programs that live in it,
+# which finalizers run from arbitrary threads — takes the context's lock.  Programs hold a strong reference to their
+# context, so a context is finalized only after all of its programs; destroying a program whose context is already gone
+# (process exit, finalizer order unspecified) is a no-op.
 mutable struct HIPContext
     handle::Ptr{Cvoid}
+    lock::ReentrantLock
 end
 function HIPContext(device::Integer=0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:de_ctx_create, LIBDE), Cint, (Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, h)
     rc == DE_OK || error("de_ctx_create failed: ", unsafe_string(ccall((:de_status_string, LIBDE), Cstring, (Cint,), rc)))
-    ctx = HIPContext(h[])
-    finalizer(c -> ccall((:de_ctx_destroy, LIBDE), Cint, (Ptr{Cvoid},), c.handle), ctx)
+    ctx = HIPContext(h[], ReentrantLock())
+    finalizer(ctx) do c
+        # finalizers must not block on a lock a running task may hold: retry later if it is taken
+        if trylock(c.lock)
+            try
+                c.handle != C_NULL && ccall((:de_ctx_destroy, LIBDE), Cint, (Ptr{Cvoid},), c.handle)
+                c.handle = C_NULL
+            finally
+                unlock(c.lock)
+            end
+        else
+            finalizer(identity, c)  # re-arm: the object survives this collection
+        end
+    end
     return ctx
 end
-const CONTEXTS = Dict{Int,HIPContext}()
-const CONTEXTS_LOCK = ReentrantLock()
-function task_context()
-    tid = Threads.threadid()
-    lock(CONTEXTS_LOCK) do
-        get!(() -> HIPContext(0), CONTEXTS, tid)
-    end
+"""The calling task's context (task-local storage: tasks migrate between threads, `Threads.threadid()` is not a key)."""
+task_context() = get!(() -> HIPContext(0), task_local_storage(), :DynamicExpressionsHIPExt_context)::HIPContext
+function check(ctx::HIPContext, rc::Cint)
+    rc == DE_OK && return true
+    rc == DE_ERR_UNSUPPORTED_OP && throw(UnsupportedOperator(nothing, 0))
+    error(unsafe_string(ccall((:de_last_error, LIBDE), Cstring, (Ptr{Cvoid},), ctx.handle)))
 end
-check(ctx::HIPContext, rc::Cint) =
-    rc == DE_OK || error(unsafe_string(ccall((:de_last_error, LIBDE), Cstring, (Ptr{Cvoid},), ctx.handle)))
+"""Run `f(handle)` holding the context's lock."""
+with_ctx(f, ctx::HIPContext) = lock(() -> (ctx.handle == C_NULL && error("HIP context was destroyed"); f(ctx.handle)), ctx.lock)
 
 # ---- the whole-tree override (signature of _bumper_eval_tree_array) --------------------------
 """
@@ -139,12 +231,13 @@ function _hip_eval_tree_array(
     out = Vector{T}(undef, N)
     ok = Ref{UInt8}(0)
     ctx = task_context()
-    rc = GC.@preserve nodes consts X out ccall(
+    rc = lock(ctx.lock) do; GC.@preserve nodes consts X out ccall(
         (:de_eval_tree_array, LIBDE), Cint,
         (Ptr{Cvoid}, Cint, Ptr{TapeNode}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int32, Int64, UInt32,
          Ptr{Cvoid}, Ref{UInt8}),
         ctx.handle, dtype_code(T), nodes, length(nodes), consts, length(consts), X, F, N,
         option_bits(operators, eval_context), out, ok)
+    end
     check(ctx, rc)
     return (out, ok[] != 0x00)
 end
@@ -177,7 +270,20 @@ function HIPPopulation(
         n_params, option_bits(operators, eval_context), h)
     check(ctx, rc)
     pop = HIPPopulation{T}(ctx, h[], length(trees), n_features)
-    finalizer(p -> ccall((:de_program_destroy, LIBDE), Cint, (Ptr{Cvoid},), p.handle), pop)
+    finalizer(pop) do p
+        c = p.ctx
+        if trylock(c.lock)
+            try
+                # de_program_destroy synchronises the context's stream: skip it when the context is already gone
+                c.handle != C_NULL && p.handle != C_NULL && ccall((:de_program_destroy, LIBDE), Cint, (Ptr{Cvoid},), p.handle)
+                p.handle = C_NULL
+            finally
+                unlock(c.lock)
+            end
+        else
+            finalizer(identity, p)
+        end
+    end
     return pop
 end
 
@@ -393,6 +499,67 @@ function _hip_eval_diff_tree_array(
     check(pop.ctx, rc)
     return (out, dout, ok[] != 0x00)
 end
+
+"""
+    eval_population_pullback_dX(pop, X, dY) -> (dX::Array{T,3}(n_features × N × n_trees), ok)
+
+The `dX` of the ChainRules pullback of `eval_tree_array` (`EvalPullback`, src/ChainRules.jl:56-77): `dX[:, :, t] =
+dX_dY .* reshape(dY, 1, :)`, all-NaN where `ok[t]` is false (:62-64).  The `dtree` half is
+`eval_population_loss_grad(pop, X, dY; loss=:pullback, variable=Val(false))`.
+"""
+function eval_population_pullback_dX(pop::HIPPopulation{T}, X::Matrix{T}, dY::Vector{T}) where {T}
+    F, N = size(X)
+    @assert F >= pop.n_features && length(dY) == N
+    dX = Array{T,3}(undef, pop.n_features, N, pop.n_trees)
+    ok = Vector{UInt8}(undef, pop.n_trees)
+    rc = lock(pop.ctx.lock) do; GC.@preserve X dY dX ok ccall(
+        (:de_eval_pullback_dX, LIBDE), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{UInt8}),
+        pop.ctx.handle, pop.handle, X, N, F, C_NULL, dY, dX, C_NULL, ok)
+    end
+    check(pop.ctx, rc)
+    return dX, ok .!= 0x00
+end
+
+# ---- multi-GPU: one Julia process per GPU (Distributed / MPI), RCCL through the library ----------------------------
+"""
+    HIPComm(ctx, rank, world, id)  /  hip_unique_id()
+
+`de_dist_*` (include/de_hip.h "multi-GPU"): rank 0 calls `hip_unique_id()` and ships the 128 bytes to the other ranks
+(`Distributed.remotecall`, MPI.Bcast ...); every rank builds `HIPComm(task_context(), rank, world, id)`, evaluates its
+round-robin shard `trees[rank+1:world:end]`, and `gather_flags(comm, ok_local, n_trees)` returns the completion flags of
+ALL trees in global order (one ncclAllGather over xGMI).  Outputs stay sharded.
+"""
+mutable struct HIPComm
+    ctx::HIPContext
+    handle::Ptr{Cvoid}
+    rank::Int
+    world::Int
+end
+function hip_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    rc = ccall((:de_dist_unique_id, LIBDE), Cint, (Ptr{UInt8},), id)
+    rc == DE_OK || error(unsafe_string(ccall((:de_dist_last_error, LIBDE), Cstring, (Ptr{Cvoid},), C_NULL)))
+    return id
+end
+function HIPComm(ctx::HIPContext, rank::Integer, world::Integer, id::Vector{UInt8}=UInt8[])
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = GC.@preserve id ccall((:de_dist_init, LIBDE), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}, Ref{Ptr{Cvoid}}),
+                               ctx.handle, rank, world, world > 1 ? pointer(id) : C_NULL, h)
+    rc == DE_OK || error(unsafe_string(ccall((:de_dist_last_error, LIBDE), Cstring, (Ptr{Cvoid},), C_NULL)))
+    return HIPComm(ctx, h[], rank, world)
+end
+function gather_flags(comm::HIPComm, ok_local::Vector{Bool}, n_trees::Integer)
+    loc = UInt8.(ok_local)
+    out = Vector{UInt8}(undef, n_trees)
+    rc = lock(comm.ctx.lock) do; GC.@preserve loc out ccall((:de_dist_gather_flags, LIBDE), Cint,
+        (Ptr{Cvoid}, Ptr{UInt8}, Int64, Ptr{UInt8}), comm.handle, loc, n_trees, out)
+    end
+    rc == DE_OK || error(unsafe_string(ccall((:de_dist_last_error, LIBDE), Cstring, (Ptr{Cvoid},), comm.handle)))
+    ccall((:de_ctx_synchronize, LIBDE), Cint, (Ptr{Cvoid},), comm.ctx.handle)
+    return out .!= 0x00
+end
+close_comm(comm::HIPComm) = (ccall((:de_dist_destroy, LIBDE), Cint, (Ptr{Cvoid},), comm.handle); comm.handle = C_NULL; nothing)
 
 is_extension_loaded(::Val{:HIP}) = true
 
