@@ -166,13 +166,21 @@ def valu_ceiling(pop, n_trees, units, kernel_ms, turbo=False):
         n_disp += len(ids)
         for k, c in zip(*np.unique(ids, return_counts=True)):
             hist[int(k)] = hist.get(int(k), 0) + int(c)
+    import re
     cycles, missing = 0.0, 0
+    by_op = {}
+    fam = {"0": "cos", "1": "exp", "2": "sin"}
+    binf = {"0": "+", "1": "-", "2": "-", "3": "*", "4": "/", "5": "/"}
     for k, c in hist.items():
         h = tab["handlers_turbo" if turbo else "handlers"].get(str(k))
         if h is None:
             missing += c
             continue
         cycles += c * h["valu_cycles"]
+        m = re.match(r"h_(\w+)<\w+(?:, (\d+))?", h["name"])
+        kind, K = m.group(1), m.group(2)
+        label = fam.get(K, kind) if kind in ("un", "unrow_f") else (binf.get(K, kind) if kind in ("bin", "binrowc", "bin2") else "load/push/check/other")
+        by_op[label] = by_op.get(label, 0.0) + c * h["valu_cycles"] / n_trees
     cycles += n_trees * tab["per_tree_overhead_cycles"]
     per_tree_wave = cycles / n_trees
     samples_per_wave = 256  # 64 lanes x 4 Float32 samples
@@ -183,6 +191,7 @@ def valu_ceiling(pop, n_trees, units, kernel_ms, turbo=False):
                 clock_ghz=2.4, simds=simds, floor_ms=floor_ms, frac=floor_ms / kernel_ms,
                 sustained_clock_ghz=2.08, floor_ms_at_sustained_clock=floor_ms * peak / sustained,
                 frac_at_sustained_clock=floor_ms * peak / sustained / kernel_ms, dispatches_without_cycle_count=missing,
+                cycles_by_operator={k: round(v, 1) for k, v in sorted(by_op.items(), key=lambda kv: -kv[1])},
                 source="profiles/valu_slots.json (tools/valu_slots.py: VALU cycles per handler on its shortest path, gfx950 ISA priced with "
                        "the per-instruction issue costs measured by tools/probe/valu_rate.py, profiles/r2_valu_rate.json; sustained clock: "
                        "profiles/r2_clock_probe.json) x de_program_dump(stage 3) dispatch histogram of this population")

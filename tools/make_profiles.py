@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/profiles_<tag>/ (tools/profile_round.sh) into the committed profiles/ files.
-usage: python tools/make_profiles.py <tag> <round-prefix>   e.g.  r1b r1"""
+usage: python tools/make_profiles.py <tag> <round-prefix> [bench dir under gpurun_out]   e.g.  r2 r2 r2g"""
 import csv, json, os, shutil, sys
 tag, pre = sys.argv[1], sys.argv[2]
 src = f"gpurun_out/profiles_{tag}"
@@ -73,7 +73,15 @@ if os.path.exists(fc3) and os.path.exists(wc3):
 json.dump(summ, open("profiles/pmc_summary.json", "w"), indent=1)
 print(json.dumps(summ, indent=1))
 print("eval kernel avg us:", sum(ev) / len(ev), " grad:", sum(gr) / len(gr))
-for f in ("bench_r1_headline.json", "bench_r1_C2.json", "bench_r1_C3.json", "bench_r1_loss.json", "bench_r1_lossgrad.json",
-          "bench_r1_C5.json", "bench_r1_C5pb.json"):
-    if os.path.exists(f"gpurun_out/{f}"):
-        shutil.copy(f"gpurun_out/{f}", f"profiles/{pre}_" + f.replace("bench_r1_", "bench_"))
+if os.path.exists(f"{src}/stats_turbo/eval_kernel_stats.csv"):
+    kstats(f"{src}/stats_turbo/eval_kernel_stats.csv", f"profiles/{pre}_headline_turbo_kernel_stats.csv")
+    tv, _ = big_launches(f"{src}/stats_turbo/eval_kernel_trace.csv", "de_eval_")
+    summ["headline"]["turbo_avg_kernel_us_rocprof"] = sum(tv) / len(tv)
+    json.dump(summ, open("profiles/pmc_summary.json", "w"), indent=1)
+    print("turbo eval kernel avg us:", sum(tv) / len(tv))
+# bench lines of the same round: gpurun_out/<bench dir>/bench_<workload>.json (tools/gpu_check.sh)
+bdir = sys.argv[3] if len(sys.argv) > 3 else None
+if bdir:
+    for f in sorted(os.listdir(f"gpurun_out/{bdir}")):
+        if f.startswith("bench_") and f.endswith(".json") and os.path.getsize(f"gpurun_out/{bdir}/{f}") > 0:
+            shutil.copy(f"gpurun_out/{bdir}/{f}", f"profiles/{pre}_{f}")
