@@ -8,14 +8,14 @@ root-level shim ``dynamicexpressions_jl_amd.py``.
 """
 from .operators import OperatorEnum, UnsupportedOperatorError, OPCODES  # noqa: F401
 from .node import (  # noqa: F401
-    Node, ParametricNode, count_nodes, count_depth, count_constant_nodes, flatten,
+    Node, ParametricNode, GraphNode, flatten_graph, preserve_sharing, break_sharing, count_nodes, count_depth, count_constant_nodes, flatten,
     flatten_population, get_scalar_constants, set_scalar_constants, string_tree, postorder,
 )
 from .simplify import simplify_tree, combine_operators  # noqa: F401
 from . import synth  # noqa: F401
 
 __all__ = [
-    "OperatorEnum", "UnsupportedOperatorError", "Node", "ParametricNode", "count_nodes",
+    "OperatorEnum", "UnsupportedOperatorError", "Node", "ParametricNode", "GraphNode", "flatten_graph", "preserve_sharing", "break_sharing", "count_nodes",
     "count_depth", "count_constant_nodes", "flatten", "flatten_population",
     "get_scalar_constants", "set_scalar_constants", "string_tree", "simplify_tree", "combine_operators", "synth",
 ]

@@ -28,7 +28,7 @@ from typing import Optional, Sequence, Tuple, Union
 
 import numpy as np
 
-from .node import Node, count_constant_nodes, flatten_population, max_feature
+from .node import Node, TAPE_DTYPE, count_constant_nodes, flatten_graph, flatten_population, max_feature, preserve_sharing
 from .operators import OperatorEnum
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -42,7 +42,7 @@ OPT_EARLY_EXIT, OPT_FUSE_DEG1, OPT_FUSE_DEG2, OPT_BUMPER_CHECKS, OPT_TURBO = 1, 
 EXPORTS = [
     "de_abi_version", "de_opcode_table_version", "de_opcode_by_name", "de_opcode_name",
     "de_opcode_degree", "de_status_string", "de_ctx_create", "de_ctx_destroy", "de_ctx_set_stream",
-    "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create",
+    "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create", "de_program_create_cse",
     "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
     "de_program_n_grad", "de_program_dump", "de_program_verify", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad", "de_eval_loss_grad_by_class",
     "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size",
@@ -99,6 +99,7 @@ def library() -> C.CDLL:
     lib.de_last_error.restype = C.c_char_p
     lib.de_last_error.argtypes = [vp]
     lib.de_program_create.argtypes = [vp, C.c_int, vp, vp, i64, vp, vp, i32, i32, u32, C.POINTER(vp)]
+    lib.de_program_create_cse.argtypes = [vp, C.c_int, vp, vp, vp, vp, i64, vp, vp, i32, i32, u32, C.POINTER(vp)]
     lib.de_program_set_consts.argtypes = [vp, vp]
     lib.de_program_destroy.argtypes = [vp]
     lib.de_program_n_trees.restype = i64
@@ -342,14 +343,40 @@ class Population:
         if n_features is None:
             n_features = max((max_feature(t) for t in trees), default=0)
         self.n_features, self.n_params = int(n_features), int(n_params)
-        self.n_consts = np.diff(coff).astype(np.int64)
+        self.n_consts = np.diff(coff).astype(np.int64)  # per tree, as the user counts them (GraphNode: unique constants)
         self._classes_checked = set()
         self._h = C.c_void_p()
         lib = library()
-        self.ctx.check(lib.de_program_create(
-            self.ctx._h, _dtype_code(self.dtype), nodes.ctypes.data, noff.ctypes.data, self.n_trees,
-            consts.ctypes.data if len(consts) else None, coff.ctypes.data, self.n_features, self.n_params,
-            self.eval_context.option_bits(operators), C.byref(self._h)))
+        # GraphNode trees (src/Node.jl:138-166): the library gets the expanded tape (one constant slot per OCCURRENCE) plus
+        # a CSE tape for the eval program; a shared constant is ONE constant to the user: `_occ[t]` maps occurrence slots
+        # to unique constants, set_constants fans values out, the gradient entry points sum the occurrence rows.
+        self._occ = None
+        cse_ptrs = (None, None)
+        if any(preserve_sharing(t) for t in trees):
+            occ, cse_tapes = [], []
+            for t in trees:
+                _, _, cse, o = flatten_graph(t, operators, self.dtype) if preserve_sharing(t) else (None, None, None, None)
+                occ.append(o if o is not None and len(o) and len(np.unique(o)) < len(o) else None)
+                cse_tapes.append(cse if cse is not None else np.zeros(0, dtype=TAPE_DTYPE))
+            if any(o is not None for o in occ):
+                self._occ = occ
+                self.n_consts = np.array([len(np.unique(o)) if o is not None else int(n) for o, n in zip(occ, np.diff(coff))], dtype=np.int64)
+            if any(len(c) for c in cse_tapes):
+                self._cse_nodes = np.concatenate(cse_tapes) if cse_tapes else np.zeros(0, dtype=TAPE_DTYPE)
+                self._cse_off = np.zeros(len(trees) + 1, dtype=np.int64)
+                np.cumsum([len(c) for c in cse_tapes], out=self._cse_off[1:])
+                cse_ptrs = (self._cse_nodes.ctypes.data, self._cse_off.ctypes.data)
+        self._slots_per_tree = np.diff(coff).astype(np.int64)
+        if cse_ptrs[0] is not None:
+            self.ctx.check(lib.de_program_create_cse(
+                self.ctx._h, _dtype_code(self.dtype), nodes.ctypes.data, noff.ctypes.data, cse_ptrs[0], cse_ptrs[1], self.n_trees,
+                consts.ctypes.data if len(consts) else None, coff.ctypes.data, self.n_features, self.n_params,
+                self.eval_context.option_bits(operators), C.byref(self._h)))
+        else:
+            self.ctx.check(lib.de_program_create(
+                self.ctx._h, _dtype_code(self.dtype), nodes.ctypes.data, noff.ctypes.data, self.n_trees,
+                consts.ctypes.data if len(consts) else None, coff.ctypes.data, self.n_features, self.n_params,
+                self.eval_context.option_bits(operators), C.byref(self._h)))
         self.n_nodes = int(lib.de_program_n_nodes(self._h))
 
     # -- constants (optimiser inner loop, src/NodeUtils.jl:99-143) ------------------
@@ -357,11 +384,37 @@ class Population:
         consts = np.ascontiguousarray(consts, dtype=self.dtype)
         if consts.size != int(self.n_consts.sum()):
             raise ValueError("wrong number of constants")
+        if self._occ is not None:  # one value per unique constant -> one per occurrence slot
+            parts, at = [], 0
+            for o, nu, ns in zip(self._occ, self.n_consts, self._slots_per_tree):
+                vals = consts[at:at + int(nu)]
+                parts.append(vals[o] if o is not None else vals)
+                at += int(nu)
+            consts = np.ascontiguousarray(np.concatenate(parts) if parts else consts, dtype=self.dtype)
         self.ctx.check(library().de_program_set_consts(self._h, consts.ctypes.data if consts.size else None))
 
     def verify(self) -> None:
         """Program sanitizer (``de_program_verify``): raises ValueError naming the offending instruction."""
         self.ctx.check(library().de_program_verify(self._h))
+
+    def _combine_rows(self, t: int, g, mode: int):
+        """Gradient rows (or entries) of tree t in the library's per-occurrence layout -> the reference's layout for a
+        GraphNode: the rows of a shared constant are summed (its NodeIndex entry is shared, src/NodeUtils.jl:184-201)."""
+        if self._occ is None or self._occ[t] is None or mode == GRAD_VARIABLE:
+            return g
+        o = self._occ[t]
+        lead = g.shape[0] - len(o)  # (params,) features rows of the :both mode come first
+        nu = int(o.max()) + 1
+        if _is_torch(g):
+            import torch
+            out = torch.zeros((lead + nu,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+            out[:lead] = g[:lead]
+            out.index_add_(0, torch.as_tensor(o + lead, device=g.device), g[lead:])
+            return out
+        out = np.zeros((lead + nu,) + g.shape[1:], dtype=g.dtype)
+        out[:lead] = g[:lead]
+        np.add.at(out, o + lead, g[lead:])
+        return out
 
     def plan(self, N: int) -> dict:
         """Launch plan of ``eval`` for N samples (tile size, tree chunks, trees per chunk)."""
@@ -566,13 +619,13 @@ class Population:
             ok = torch.empty(self.n_trees, dtype=torch.uint8, device=keep_x.device)
             self.ctx.check(lib.de_eval_loss_grad(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None, mode,
                                                  yp, wp, kind, lo.data_ptr(), dl.data_ptr(), offs.ctypes.data, ok.data_ptr()))
-            return lo, list(torch.split(dl[:int(offs[-1])], ng.tolist())), ok.bool()
+            return lo, [self._combine_rows(t, d, mode) for t, d in enumerate(torch.split(dl[:int(offs[-1])], ng.tolist()))], ok.bool()
         lo = np.empty(self.n_trees, dtype=self.dtype)
         dl = np.empty(total, dtype=self.dtype)
         ok = np.zeros(self.n_trees, dtype=np.uint8)
         self.ctx.check(lib.de_eval_loss_grad(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None, mode,
                                              yp, wp, kind, lo.ctypes.data, dl.ctypes.data, offs.ctypes.data, ok.ctypes.data))
-        return lo, np.split(dl[:int(offs[-1])], offs[1:-1]), ok.astype(bool)
+        return lo, [self._combine_rows(t, d, mode) for t, d in enumerate(np.split(dl[:int(offs[-1])], offs[1:-1]))], ok.astype(bool)
 
     def eval_loss_grad_by_class(self, X, y, params, classes, weights=None, loss: str = "L2",
                                 variable: Union[bool, str] = "both", class_base: int = 1, grouped: bool = False):
@@ -681,14 +734,14 @@ class Population:
             ok = torch.empty(self.n_trees, dtype=torch.uint8, device=keep_x.device)
             self.ctx.check(lib.de_eval_grad(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None, mode,
                                             out.data_ptr(), N, grad.data_ptr(), offs.ctypes.data, ok.data_ptr()))
-            grads = [grad[offs[t]:offs[t + 1]].view(N, int(ng[t])).t() for t in range(self.n_trees)]
+            grads = [self._combine_rows(t, grad[offs[t]:offs[t + 1]].view(N, int(ng[t])).t(), mode) for t in range(self.n_trees)]
             return out, grads, ok.bool()
         out = np.empty((self.n_trees, N), dtype=self.dtype)
         grad = np.empty(max(total, 1), dtype=self.dtype)
         ok = np.zeros(self.n_trees, dtype=np.uint8)
         self.ctx.check(lib.de_eval_grad(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None, mode,
                                         out.ctypes.data, N, grad.ctypes.data, offs.ctypes.data, ok.ctypes.data))
-        grads = [grad[offs[t]:offs[t + 1]].reshape((int(ng[t]), N), order="F") for t in range(self.n_trees)]
+        grads = [self._combine_rows(t, grad[offs[t]:offs[t + 1]].reshape((int(ng[t]), N), order="F"), mode) for t in range(self.n_trees)]
         return out, grads, ok.astype(bool)
 
     def eval_pullback_dX(self, X, dY, params=None, classes=None, class_base: int = 1):

@@ -540,7 +540,8 @@ static void recompute_host_ok(de_program *p) {
 
 static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, const int64_t *node_offsets,
                        int64_t n_trees, const void *consts, const int64_t *const_offsets, int32_t n_features,
-                       int32_t n_params, uint32_t options, bool allow_fold, de_program_t **out_program);
+                       int32_t n_params, uint32_t options, bool allow_fold, de_program_t **out_program,
+                       const de_tape_node_t *cse_nodes = nullptr, const int64_t *cse_offsets = nullptr);
 
 // Device copy of the host part of the eval flag: every de_eval starts from it with one device-to-device copy
 // (a pageable host-to-device copy per call costs ~10 us, a fifth of a small-population call).
@@ -555,7 +556,7 @@ static int upload_ok_eval(de_ctx *c, de_program *p) {
 
 // (Re-)evaluate the folded constant subtrees on the device and patch their values into fcode.
 static int refresh_folds(de_ctx *c, de_program *p) {
-    if (!p->folded) return DE_OK;
+    if (!p->folded || p->folds.empty()) return DE_OK; // (a CSE-only eval program has no constant subtrees to evaluate)
     const size_t es = p->dtype == DE_F32 ? 4 : 8;
     const size_t na = p->folds.size();
     std::vector<unsigned char> ac(std::max<size_t>(p->aux_const_src.size(), 1) * es);
@@ -587,9 +588,23 @@ int de_program_create(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, con
                        !(nf && *nf == '1'), out_program);
 }
 
+int de_program_create_cse(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, const int64_t *node_offsets,
+                          const de_tape_node_t *cse_nodes, const int64_t *cse_offsets, int64_t n_trees, const void *consts,
+                          const int64_t *const_offsets, int32_t n_features, int32_t n_params, uint32_t options,
+                          de_program_t **out_program) {
+    const char *nf = getenv("DE_NO_FOLD"), *nc = getenv("DE_NO_CSE");
+    const bool fold = !(nf && *nf == '1'), cse = !(nc && *nc == '1');
+    if (n_trees > 0 && cse_nodes && !cse_offsets) return fail(ctx, DE_ERR_INVALID_ARG, "cse_offsets is null");
+    return create_impl(ctx, dtype, nodes, node_offsets, n_trees, consts, const_offsets, n_features, n_params, options, fold, out_program,
+                       fold && cse ? cse_nodes : nullptr, cse_offsets);
+}
+
+// The eval program of tree t is lowered from its CSE tape when the caller supplied one (a GraphNode tree: shared subtrees
+// appear once, de_program_create_cse); everything else — gradients, constant bookkeeping, flags — follows the expanded tape.
 static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, const int64_t *node_offsets,
                        int64_t n_trees, const void *consts, const int64_t *const_offsets, int32_t n_features,
-                       int32_t n_params, uint32_t options, bool allow_fold, de_program_t **out_program) {
+                       int32_t n_params, uint32_t options, bool allow_fold, de_program_t **out_program,
+                       const de_tape_node_t *cse_nodes, const int64_t *cse_offsets) {
     if (!ctx) return DE_ERR_INVALID_ARG;
     if (!out_program) return fail(ctx, DE_ERR_INVALID_ARG, "out_program is null");
     *out_program = nullptr;
@@ -642,8 +657,13 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                 const int64_t n0 = node_offsets[t], c0 = const_offsets[t];
                 try {
                     L.rc = lower_tree(nodes + n0, node_offsets[t + 1] - n0, const_offsets[t + 1] - c0, lo, &L.plain, &L.why);
-                    if (L.rc == DE_OK && allow_fold)
-                        L.rcf = lower_tree(nodes + n0, node_offsets[t + 1] - n0, const_offsets[t + 1] - c0, lof, &L.folded, &L.why);
+                    if (L.rc == DE_OK && allow_fold) {
+                        if (cse_nodes && cse_offsets[t + 1] > cse_offsets[t]) {
+                            LowerOptions loc = lof;
+                            loc.cse = true;
+                            L.rcf = lower_tree(cse_nodes + cse_offsets[t], cse_offsets[t + 1] - cse_offsets[t], const_offsets[t + 1] - c0, loc, &L.folded, &L.why);
+                        } else L.rcf = lower_tree(nodes + n0, node_offsets[t + 1] - n0, const_offsets[t + 1] - c0, lof, &L.folded, &L.why);
+                    }
                 } catch (const std::bad_alloc &) { oom = true; }
             });
             if (oom) return fail(ctx, DE_ERR_HIP, "out of host memory");
@@ -678,6 +698,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
             lo.fold = true;
             std::vector<de_tape_node_t> anodes;
             std::vector<int64_t> anoff{0}, acoff{0};
+            bool any_cse = false;
             p->fcode_off.assign((size_t)n_trees + 1, 0);
             p->fconst_instr.assign((size_t)total_consts, -1);
             for (int64_t t = 0; t < n_trees; t++) {
@@ -687,6 +708,10 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                 if (low[(size_t)t].rcf != DE_OK)
                     return fail(ctx, low[(size_t)t].rcf, "tree %lld (folded): %s", (long long)t, low[(size_t)t].why.c_str());
                 (void)n1;
+                const bool is_cse = cse_nodes && cse_offsets[t + 1] > cse_offsets[t];
+                const de_tape_node_t *src_nodes = is_cse ? cse_nodes + cse_offsets[t] : nodes + n0; // the tape the fold spans index
+                any_cse = any_cse || is_cse;
+                p->n_slots = std::max(p->n_slots, tp.n_slots); // a CSE program keeps one persistent row per shared subtree
                 const int64_t cb = c0 - const_offsets[0];
                 const int32_t ib = (int32_t)p->fcode.size();
                 for (int64_t k = 0; k < c1 - c0; k++) {
@@ -699,7 +724,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                     const FoldSpan &sp = tp.folds[f];
                     p->folds.push_back({(int32_t)t, ib + tp.const_instr[(size_t)(c1 - c0) + f], sp.tested_always});
                     for (int32_t q = sp.node_begin; q < sp.node_end; q++) {
-                        de_tape_node_t nd = nodes[n0 + q];
+                        de_tape_node_t nd = src_nodes[q];
                         if (nd.degree == 0 && nd.op == DE_LEAF_CONST) nd.arg = (uint16_t)(nd.arg - sp.const_begin);
                         anodes.push_back(nd);
                     }
@@ -724,6 +749,8 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                 p->folded = true;
                 rc = refresh_folds(ctx, p.get());
                 if (rc != DE_OK) return rc;
+            } else if (any_cse) {
+                p->folded = true; // the eval program is the CSE lowering even without a constant subtree to fold
             } else {
                 p->fcode.clear();
                 p->fcode_off.clear();
@@ -1078,6 +1105,8 @@ int64_t de_lower_tape(int dtype, const de_tape_node_t *nodes, int64_t n_nodes, c
         lo.n_features = n_features;
         lo.n_params = n_params;
         lo.dtype = dtype;
+        for (int64_t i = 0; i < n_nodes; i++) // a CSE tape (GraphNode sharing) announces itself by its markers
+            if ((nodes[i].degree == 1 && nodes[i].op == DE_OP_SHARE) || (nodes[i].degree == 0 && nodes[i].op == DE_LEAF_SHARED)) lo.cse = true;
         TreeProgram tp;
         std::string why;
         int rc = lower_tree(nodes, n_nodes, n_consts, lo, &tp, &why);
@@ -1086,7 +1115,7 @@ int64_t de_lower_tape(int dtype, const de_tape_node_t *nodes, int64_t n_nodes, c
         for (int64_t k = 0; k < n_consts; k++) {
             const double v = dtype == DE_F32 ? (double)static_cast<const float *>(consts)[k]
                                              : static_cast<const double *>(consts)[k];
-            write_imm(tp.code[(size_t)tp.const_instr[(size_t)k]], dtype, v);
+            if (tp.const_instr[(size_t)k] >= 0) write_imm(tp.code[(size_t)tp.const_instr[(size_t)k]], dtype, v);
             const bool fin = finite_in(dtype, v);
             ok_grad = ok_grad && fin;
             const uint8_t ch = tp.const_checks[(size_t)k];

@@ -183,8 +183,20 @@ template <bool SIN> __device__ __forceinline__ DeTrig2 fast_trig_core_f32x2(DeF2
     return o;
 }
 __device__ __forceinline__ DeF2 fast_trig_sign_f32x2(DeF2 s, DeF2 kk) {
-    const DeU2 bits = __builtin_bit_cast(DeU2, s) ^ (__builtin_bit_cast(DeU2, kk) << 31);
-    return __builtin_bit_cast(DeF2, bits);
+    // (-1)^n: the parity of n is the low mantissa bit of the magic sum; ADDING it at bit 31 flips the sign bit exactly like
+    // the xor would (the carry leaves the word) and is one v_lshl_add_u32 instead of a shift and a xor
+    DeF2 y;
+    y[0] = __uint_as_float((__float_as_uint(kk[0]) << 31) + __float_as_uint(s[0]));
+    y[1] = __uint_as_float((__float_as_uint(kk[1]) << 31) + __float_as_uint(s[1]));
+    return y;
+}
+// Wave-uniform "does any of the four arguments exceed `bound` in magnitude (or is NaN)?" at full VALU rate: the OR of the
+// magnitudes' bit patterns is >= each of them, so it exceeds bound's pattern whenever one of them does (a false positive —
+// two values in [2^16, bound) whose mantissa bits combine past it — only sends the wave through the slow path, whose
+// per-element condition is exact).  3 v_or + v_and + v_cmp instead of 4 half-rate max + v_cmp.
+__device__ __forceinline__ bool any_abs_exceeds_f32x4(float a, float b, float c, float d, float bound) {
+    const uint32_t m = (__float_as_uint(a) | __float_as_uint(b) | __float_as_uint(c) | __float_as_uint(d)) & 0x7fffffffu;
+    return m > __float_as_uint(bound);
 }
 // Four elements with a wave-uniform short cut for the extremum select: |r| within 2^-12 of pi/2 means
 // r^2 within ~7.7e-4 of pi^2/4; the test on the already computed r^2 costs 1.5 VALU per element and the

@@ -631,8 +631,7 @@ template <typename T, int K, bool TB = false> __device__ __forceinline__ typenam
         } else {
             const DeF2 a = turbo_trig_f32x2<K == 2>(xa), b = turbo_trig_f32x2<K == 2>(xb);
             r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
-            const float mx = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
-            if (__ballot(mx > DE_TURBO_TRIG_BOUND) != 0ull) { // huge arguments and Inf: full range reduction (rare, wave-uniform)
+            if (__ballot(any_abs_exceeds_f32x4(x[0], x[1], x[2], x[3], DE_TURBO_TRIG_BOUND)) != 0ull) { // huge arguments, Inf, NaN: full range reduction (rare, wave-uniform)
                 DE_UNROLL for (int i = 0; i < VW; i++)
                     if (fabsf(x[i]) > DE_TURBO_TRIG_BOUND) r[i] = K == 2 ? sinf(x[i]) : cosf(x[i]);
             }
@@ -646,9 +645,8 @@ template <typename T, int K, bool TB = false> __device__ __forceinline__ typenam
             float yo[4];
             fast_trig_f32x4<K == 2>(xi, yo);
             r[0] = yo[0]; r[1] = yo[1]; r[2] = yo[2]; r[3] = yo[3];
-            // max ignores NaN (which the fast path already propagates); Inf and |x| > 1e5 take the slow path
-            const float mx = fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3])));
-            if (__ballot(mx > DE_TRIG_FAST_BOUND) != 0ull) { // inline: a call here would turn every handler into a non-leaf function
+            // Inf, NaN and |x| > 1e5 take the slow path (the fast path propagates NaN too: same result either way)
+            if (__ballot(any_abs_exceeds_f32x4(x[0], x[1], x[2], x[3], DE_TRIG_FAST_BOUND)) != 0ull) { // inline: a call here would turn every handler into a non-leaf function
                 DE_UNROLL for (int i = 0; i < VW; i++)
                     if (fabsf(x[i]) > DE_TRIG_FAST_BOUND) r[i] = K == 2 ? sinf(x[i]) : cosf(x[i]);
             }

@@ -32,6 +32,8 @@ struct LNode {
     int first = 0;           // index of the first tape node of this subtree (post-order slice [first, i])
     int cfirst = 0, ccount = 0; // constant slots owned by the subtree
     int regs = 0;            // spill slots needed to evaluate into acc
+    int share_def = -1;      // >= 0: this node is the first occurrence of shared subtree share_def (CSE tapes)
+    uint32_t defs = 0, uses = 0; // share ids defined / referenced inside this subtree (bit masks)
 };
 
 struct Lowerer {
@@ -44,9 +46,21 @@ struct Lowerer {
 
     Lowerer(const LowerOptions &o, TreeProgram *p, std::string *e) : opt(o), out(p), err(e) {}
 
-    bool is_leaf(int i) const { return nodes[i].degree == 0; }
+    int share_base = 0;      // first persistent slot of the shared subtrees (= spill slots the tree needs)
+    // A DE_LEAF_SHARED operand is an operand for codegen (one LDS row read) but a SUBTREE for the reference's dispatch: the
+    // reference evaluates the shared node again at every occurrence (src/Evaluate.jl:337-364 has no cache), so the parent
+    // never takes a fused leaf kernel with it and its value is one the parent's @return_on_nonfinite_array tests — which
+    // the definition's unconditional result test (assign_check_out) already did on the same values.
+    bool is_shared_leaf(int i) const { return nodes[i].degree == 0 && nodes[i].op == DE_LEAF_SHARED; }
+    bool is_leaf(int i) const { return nodes[i].degree == 0 && nodes[i].op != DE_LEAF_SHARED; }
     // codegen view: a folded constant subtree is an operand, like a leaf
-    bool is_opnd(int i) const { return nodes[i].degree == 0 || nodes[i].fold_slot >= 0; }
+    bool is_opnd(int i) const { return (nodes[i].degree == 0 || nodes[i].fold_slot >= 0) && nodes[i].share_def < 0; }
+    // a definition must be evaluated before its references: the tape has it first (depth-first, left to right), the
+    // Sethi-Ullman order may not — the left child goes first whenever the right one reads a row the left one writes
+    // the node whose SHAPE the reference's dispatch sees at position i: a shared reference stands for the subtree it names
+    std::vector<int> share_node;
+    int shp(int i) const { return is_shared_leaf(i) ? share_node[nodes[i].arg] : i; }
+    bool left_first(int l, int r) const { return (nodes[r].uses & nodes[l].defs) != 0 || nodes[l].regs > nodes[r].regs; }
     bool is_const_leaf(int i) const { return nodes[i].degree == 0 && nodes[i].op == DE_LEAF_CONST; }
     bool bin_of_leaves(int i) const {
         return nodes[i].degree == 2 && is_leaf(nodes[i].child[0]) && is_leaf(nodes[i].child[1]);
@@ -79,13 +93,14 @@ struct Lowerer {
         if (n.is_const) { mark_constfold(i); return; }
         if (n.degree == 1) {
             int c = n.child[0];
-            if (opt.fuse1 && bin_of_leaves(c)) { // deg1_l2_ll0_lr0_eval
-                host_check_ee(nodes[c].child[0]);
-                host_check_ee(nodes[c].child[1]);
+            const int cs = shp(c); // a later occurrence of a shared subtree takes the same fused kernel as the first
+            if (opt.fuse1 && bin_of_leaves(cs)) { // deg1_l2_ll0_lr0_eval
+                host_check_ee(nodes[cs].child[0]);
+                host_check_ee(nodes[cs].child[1]);
                 n.inject = true;
                 return;
             }
-            if (opt.fuse1 && nodes[c].degree == 1 && is_leaf(nodes[c].child[0])) { // deg1_l1_ll0_eval
+            if (opt.fuse1 && nodes[cs].degree == 1 && is_leaf(nodes[cs].child[0])) { // deg1_l1_ll0_eval
                 n.inject = true;
                 return;
             }
@@ -101,9 +116,9 @@ struct Lowerer {
                 return;
             }
             if (opt.fuse2 && is_leaf(r)) {
-                if (bin_of_leaves(l)) { // deg2_branch0_eval :left
-                    host_check_ee(nodes[l].child[0]);
-                    host_check_ee(nodes[l].child[1]);
+                if (bin_of_leaves(shp(l))) { // deg2_branch0_eval :left
+                    host_check_ee(nodes[shp(l)].child[0]);
+                    host_check_ee(nodes[shp(l)].child[1]);
                     host_check_ee(r);
                     if (!is_const_leaf(r)) nodes[r].chk_leaf = true; // _fused_binary3 tests x3
                     return;
@@ -114,10 +129,10 @@ struct Lowerer {
                 return;
             }
             if (opt.fuse2 && is_leaf(l)) {
-                if (bin_of_leaves(r)) { // deg2_branch0_eval :right
+                if (bin_of_leaves(shp(r))) { // deg2_branch0_eval :right
                     host_check_ee(l);
-                    host_check_ee(nodes[r].child[0]);
-                    host_check_ee(nodes[r].child[1]);
+                    host_check_ee(nodes[shp(r)].child[0]);
+                    host_check_ee(nodes[shp(r)].child[1]);
                     if (!is_const_leaf(l)) nodes[l].chk_leaf = true; // _fused_binary3 tests x1
                     return;
                 }
@@ -153,6 +168,7 @@ struct Lowerer {
             else {
                 int a = nodes[l].regs, b = nodes[r].regs;
                 n.regs = (a == b) ? a + 1 : std::max(a, b);
+                if ((nodes[r].uses & nodes[l].defs) != 0) n.regs = std::max(a, b + 1); // forced order: l is held while r runs
             }
         } else {
             n.regs = std::max({nodes[n.child[0]].regs, 1 + nodes[n.child[1]].regs,
@@ -183,6 +199,9 @@ struct Lowerer {
             ins.hdr |= SRC_CONST << H_SRC_SHIFT;
             ins.feat = (uint32_t)lf.arg << 16;
             out->const_instr[lf.arg] = (int32_t)(&ins - out->code.data());
+        } else if (lf.op == DE_LEAF_SHARED) { // persistent row of shared subtree lf.arg, written at its definition
+            ins.hdr |= SRC_ROW << H_SRC_SHIFT;
+            ins.feat = (uint32_t)(opt.n_features + share_base + lf.arg);
         } else if (lf.op == DE_LEAF_FEATURE) {
             ins.hdr |= SRC_ROW << H_SRC_SHIFT;
             ins.feat = lf.arg;
@@ -217,8 +236,18 @@ struct Lowerer {
         if (n.inject) ins.hdr |= H_INJECT;
     }
 
-    // Emit code leaving the value of node i in acc; `depth` = occupied spill slots.
+    // Emit code leaving the value of node i in acc; `depth` = occupied spill slots.  A shared subtree's first occurrence
+    // additionally leaves its value in its persistent row: the push rides on the NEXT emitted instruction (H_PUSH runs
+    // before that instruction executes; the accumulator is unchanged).
     void gen(int i, int depth) {
+        gen_value(i, depth);
+        if (nodes[i].share_def >= 0) {
+            if (pending_push >= 0) { bad_share = true; return; }
+            pending_push = share_base + nodes[i].share_def;
+        }
+    }
+    bool bad_share = false;
+    void gen_value(int i, int depth) {
         const LNode n = nodes[i];
         if (n.degree == 0 || n.fold_slot >= 0) {
             Instr &ins = emit(DOP_LOAD);
@@ -256,30 +285,31 @@ struct Lowerer {
                 op_flags(ins, n);
                 return;
             }
-            max_slots = std::max(max_slots, depth + 1);
-            if (nodes[l].regs > nodes[r].regs) { // left first: result = op(pop=l, acc=r)
-                gen(l, depth);
+            const bool lf = left_first(l, r); // (on ties right first: natural operand order, no swap)
+            const int first = lf ? l : r, second = lf ? r : l;
+            int pop_slot = depth, next_depth = depth + 1;
+            gen(first, depth);
+            if (nodes[first].share_def >= 0) { // its persistent row doubles as the spill: no slot, the share push is pending
+                pop_slot = share_base + nodes[first].share_def;
+                next_depth = depth;
+            } else {
+                max_slots = std::max(max_slots, depth + 1);
                 pending_push = depth;
-                gen(r, depth + 1);
-                bool flag;
-                Instr &ins = emit(swapped(n.op, &flag));
-                set_pop_operand(ins, depth);
-                op_flags(ins, n);
-            } else { // right first (also on ties: natural operand order, no swap)
-                gen(r, depth);
-                pending_push = depth;
-                gen(l, depth + 1);
-                Instr &ins = emit(n.op);
-                set_pop_operand(ins, depth);
-                op_flags(ins, n);
             }
+            gen(second, next_depth);
+            bool flag;
+            Instr &ins = emit(lf ? swapped(n.op, &flag) : n.op); // left first: result = op(pop = l, acc = r)
+            set_pop_operand(ins, pop_slot);
+            op_flags(ins, n);
             return;
         }
         // degree 3: x -> slot depth, y -> slot depth+1, z -> acc ; acc = op(x, y, z)
         max_slots = std::max(max_slots, depth + 2);
         gen(n.child[0], depth);
+        if (pending_push >= 0) bad_share = true; // a shared subtree directly under a ternary operator: not served (the flattener avoids it)
         pending_push = depth;
         gen(n.child[1], depth + 1);
+        if (pending_push >= 0) bad_share = true;
         pending_push = depth + 1;
         gen(n.child[2], depth + 2);
         Instr &ins = emit(n.op);
@@ -309,7 +339,7 @@ bool propagates_nonfinite(uint32_t op, bool acc_pos) {
 }
 
 // Decide H_CHECK_OUT for every instruction (early-exit flag semantics, see de_program.h).
-void assign_check_out(std::vector<Instr> &code, int n_features) {
+void assign_check_out(std::vector<Instr> &code, int n_features, int share_base = 1 << 20) {
     const size_t n = code.size();
     for (size_t i = 0; i < n; i++) {
         Instr &ins = code[i];
@@ -318,7 +348,10 @@ void assign_check_out(std::vector<Instr> &code, int n_features) {
         bool need = true;
         if (i + 1 < n) {
             const Instr &nx = code[i + 1];
-            if (nx.hdr & H_PUSH) { // value is spilled: consumed later as an LDS row operand
+            if ((nx.hdr & H_PUSH) && (int)((nx.hdr >> H_PUSH_SHIFT) & H_SLOT_MASK) >= share_base) {
+                // definition of a shared subtree: read by several consumers — keep the result test (each occurrence's
+                // value is tested in the reference; they are the same values)
+            } else if (nx.hdr & H_PUSH) { // value is spilled: consumed later as an LDS row operand
                 const uint32_t row = (uint32_t)n_features + ((nx.hdr >> H_PUSH_SHIFT) & H_SLOT_MASK);
                 for (size_t j = i + 2; j < n; j++) {
                     const Instr &c = code[j];
@@ -364,6 +397,7 @@ int lower_tree(const de_tape_node_t *tape, int64_t n, int64_t n_consts, const Lo
     Lowerer L(opt, out, err);
     L.nodes.resize((size_t)n);
     std::vector<int> stack;
+    int n_shared_defs = 0;
     std::vector<int> depth((size_t)n, 1);
     stack.reserve((size_t)n);
     int64_t seen_consts = 0;
@@ -387,7 +421,21 @@ int lower_tree(const de_tape_node_t *tape, int64_t n, int64_t n_consts, const Lo
                 if ((int)nd.arg >= opt.n_features) return fail(DE_ERR_OUT_OF_RANGE, "feature index out of range");
             } else if (nd.op == DE_LEAF_PARAM) {
                 if ((int)nd.arg >= opt.n_params) return fail(DE_ERR_OUT_OF_RANGE, "parameter index out of range");
+            } else if (nd.op == DE_LEAF_SHARED && opt.cse) {
+                if ((int)nd.arg >= n_shared_defs) return fail(DE_ERR_BAD_TAPE, "DE_LEAF_SHARED before its DE_OP_SHARE definition");
+                nd.uses = 1u << nd.arg;
             } else return fail(DE_ERR_BAD_TAPE, "unknown leaf kind");
+        } else if (nd.degree == 1 && nd.op == DE_OP_SHARE && opt.cse) {
+            // transparent marker: the node on top of the stack is shared subtree nd.arg (ids in order of definition)
+            if (stack.empty()) return fail(DE_ERR_BAD_TAPE, "DE_OP_SHARE without a subtree");
+            LNode &def = L.nodes[(size_t)stack.back()];
+            if ((int)nd.arg != n_shared_defs || nd.arg >= 16) return fail(DE_ERR_BAD_TAPE, "share ids must be 0, 1, ... in order of definition (at most 16)");
+            if (def.degree == 0 || def.is_const || def.share_def >= 0) return fail(DE_ERR_BAD_TAPE, "only non-constant operator subtrees can be shared");
+            def.share_def = n_shared_defs++;
+            def.defs |= 1u << def.share_def;
+            L.share_node.push_back(stack.back());
+            nd.degree = 0xFF; // not a node of the tree
+            continue;
         } else if (nd.degree <= 3) {
             int lo = nd.degree == 1 ? DE_U_NEG : (nd.degree == 2 ? DE_B_ADD : DE_T_FMA);
             int hi = nd.degree == 1 ? DE_U_LAST_ : (nd.degree == 2 ? DE_B_LAST_ : DE_T_LAST_);
@@ -400,6 +448,8 @@ int lower_tree(const de_tape_node_t *tape, int64_t n, int64_t n_consts, const Lo
                 stack.pop_back();
                 const LNode &ch = L.nodes[(size_t)nd.child[k]];
                 nd.is_const = nd.is_const && ch.is_const;
+                nd.defs |= ch.defs;
+                nd.uses |= ch.uses;
                 d = std::max(d, depth[(size_t)nd.child[k]]);
                 nd.first = std::min(nd.first, ch.first);
                 if (ch.ccount) {
@@ -413,7 +463,9 @@ int lower_tree(const de_tape_node_t *tape, int64_t n, int64_t n_consts, const Lo
         stack.push_back((int)i);
     }
     if (stack.size() != 1) return fail(DE_ERR_BAD_TAPE, "tape does not reduce to a single root");
-    if (seen_consts != n_consts) return fail(DE_ERR_BAD_TAPE, "constant pool size does not match tape");
+    if (seen_consts != n_consts && !(opt.cse && seen_consts < n_consts)) return fail(DE_ERR_BAD_TAPE, "constant pool size does not match tape");
+    for (int64_t k = 0; k < n_consts; k++) // (CSE tapes reference a subset of the slots)
+        if (out->const_instr[(size_t)k] == -2) out->const_instr[(size_t)k] = -1;
     int root = stack[0];
 
     if (opt.bumper) {
@@ -441,17 +493,20 @@ int lower_tree(const de_tape_node_t *tape, int64_t n, int64_t n_consts, const Lo
     // slots n_consts .. n_consts+folds-1 are the folded subtrees' values
     out->const_instr.resize((size_t)n_consts + out->folds.size(), -1);
     L.compute_regs(root);
-    if (L.nodes[(size_t)root].regs > MAX_SLOTS)
+    if (L.nodes[(size_t)root].regs + n_shared_defs > MAX_SLOTS)
         return fail(DE_ERR_UNSUPPORTED, "tree needs more than 16 spill slots");
+    L.share_base = L.nodes[(size_t)root].regs;
     out->code.reserve((size_t)n);
     L.gen(root, 0);
+    if (L.bad_share || L.pending_push >= 0) return fail(DE_ERR_UNSUPPORTED, "shared subtree in a position the lowering cannot serve (root, or child of a ternary operator)");
     // set_leaf_operand stored indices while the vector could still grow: recompute them.
     for (size_t k = 0; k < out->code.size(); k++) {
         const Instr &ins = out->code[k];
         if (((ins.hdr >> H_SRC_SHIFT) & H_SRC_MASK) == SRC_CONST) out->const_instr[ins.feat >> 16] = (int32_t)k;
     }
-    assign_check_out(out->code, opt.n_features);
-    out->n_slots = L.max_slots;
+    assign_check_out(out->code, opt.n_features, n_shared_defs ? L.share_base : 1 << 20);
+    out->n_shared = n_shared_defs;
+    out->n_slots = n_shared_defs ? L.share_base + n_shared_defs : L.max_slots;
     return DE_OK;
 }
 

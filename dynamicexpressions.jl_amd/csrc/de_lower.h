@@ -22,6 +22,10 @@ struct LowerOptions {
     // launch — the reference folds the same subtrees on the host, dispatch_constant_tree,
     // src/Evaluate.jl:347-354,1002-1067.  Flag annotation still follows the ORIGINAL tree.
     bool fold = false;
+    // The tape is the CSE form of a GraphNode tree (DE_OP_SHARE / DE_LEAF_SHARED, include/de_opcodes.h): its constant
+    // leaves use the slot numbering of the EXPANDED tape but only the first occurrence of every shared subtree is
+    // present, so fewer than n_consts slots may be referenced.
+    bool cse = false;
 };
 
 // How a constant slot takes part in the host-side part of the `ok` flag.
@@ -46,7 +50,8 @@ struct TreeProgram {
     std::vector<Instr> code;
     std::vector<int32_t> const_instr;  // const slot -> index into `code` holding its immediate
     std::vector<uint8_t> const_checks; // const slot -> CONST_CHECK_* bits
-    int n_slots = 0;                   // spill slots needed
+    int n_slots = 0;                   // spill slots needed (CSE tapes: + one persistent row per shared subtree)
+    int n_shared = 0;                  // shared subtrees of a CSE tape
     int n_nodes = 0;
     int n_consts = 0;
     bool uses_params = false;

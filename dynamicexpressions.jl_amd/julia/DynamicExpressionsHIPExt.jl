@@ -15,8 +15,8 @@
 module DynamicExpressionsHIPExt
 
 using DynamicExpressions:
-    AbstractExpressionNode, Node, OperatorEnum, EvalContext, get_child, get_children,
-    count_constant_nodes
+    AbstractExpressionNode, Node, GraphNode, OperatorEnum, EvalContext, get_child, get_children,
+    count_constant_nodes, preserve_sharing
 import DynamicExpressions.ExtensionInterfaceModule: is_extension_loaded
 
 const LIBDE = get(ENV, "DE_HIP_LIB", "libde_hip")
@@ -29,7 +29,8 @@ struct TapeNode            # de_tape_node_t
 end
 const DE_OK = Cint(0)
 const DE_ERR_UNSUPPORTED_OP = Cint(3)
-const DE_LEAF_CONST, DE_LEAF_FEATURE, DE_LEAF_PARAM = UInt8(0), UInt8(1), UInt8(2)
+const DE_LEAF_CONST, DE_LEAF_FEATURE, DE_LEAF_PARAM, DE_LEAF_SHARED = UInt8(0), UInt8(1), UInt8(2), UInt8(3)
+const DE_OP_SHARE = UInt8(0xFE)   # include/de_opcodes.h: "the subtree just emitted is shared subtree `arg`"
 const DE_F32, DE_F64 = Cint(0), Cint(1)
 const DE_OPT_EARLY_EXIT, DE_OPT_FUSE_DEG1, DE_OPT_FUSE_DEG2, DE_OPT_BUMPER_CHECKS, DE_OPT_TURBO =
     UInt32(1), UInt32(2), UInt32(4), UInt32(8), UInt32(16)
@@ -167,6 +168,67 @@ function flatten!(
     return nothing
 end
 
+# ---- GraphNode (src/Node.jl:138-166): the CSE tape of de_program_create_cse -------------------------------------
+# `flatten!` above walks a GraphNode like the reference's evaluator does — a shared node once per parent — and gives the
+# EXPANDED tape with one constant slot per occurrence.  `flatten_cse!` restates the tree with every shared, non-constant
+# operator subtree once: DE_OP_SHARE after its first occurrence, DE_LEAF_SHARED afterwards; constant leaves keep the slot
+# of their first occurrence in the expanded numbering.  Returns the number of shared subtrees (0: pass an empty range).
+# `occurrence_map` gives, per expanded slot, the index of the unique constant (get_scalar_constants order): the shim keeps
+# occurrence slots equal (set_population_constants!) and sums their gradient rows.
+function flatten_cse!(nodes::Vector{TapeNode}, tree::AbstractExpressionNode{T}, optable) where {T}
+    count = IdDict{Any,Int}()
+    isconst = IdDict{Any,Bool}()
+    nparents = IdDict{Any,Int}()
+    function survey(n, first::Bool)
+        count[n] = get(count, n, 0) + 1
+        if n.degree == 0
+            isconst[n] = n.constant
+        else
+            cs = get_children(n, Int(n.degree))
+            for c in cs
+                first && (nparents[c] = get(nparents, c, 0) + 1)   # parent slots seen from distinct parent OBJECTS
+                survey(c, first && count[c] == 0 || !haskey(count, c))
+            end
+            isconst[n] = all(c -> isconst[c], cs)
+        end
+    end
+    survey(tree, true)
+    defined = IdDict{Any,Int}()
+    slot = Ref(0)
+    skip(n) = n.degree == 0 ? (n.constant && (slot[] += 1)) : foreach(skip, get_children(n, Int(n.degree)))
+    function emit(n, under_ternary::Bool)
+        if haskey(defined, n)
+            push!(nodes, TapeNode(0x00, DE_LEAF_SHARED, UInt16(defined[n])))
+            skip(n)
+            return
+        end
+        if n.degree == 0
+            if n.constant
+                push!(nodes, TapeNode(0x00, DE_LEAF_CONST, UInt16(slot[]))); slot[] += 1
+            else
+                push!(nodes, TapeNode(0x00, DE_LEAF_FEATURE, UInt16(n.feature - 1)))
+            end
+            return
+        end
+        d = Int(n.degree)
+        foreach(c -> emit(c, d == 3), get_children(n, d))
+        push!(nodes, TapeNode(UInt8(d), optable[d][n.op], 0x0000))
+        if get(nparents, n, 0) > 1 && !isconst[n] && !under_ternary && n !== tree && length(defined) < 12
+            defined[n] = length(defined)
+            push!(nodes, TapeNode(0x01, DE_OP_SHARE, UInt16(defined[n])))
+        end
+    end
+    emit(tree, false)
+    return length(defined)
+end
+function occurrence_map(tree::AbstractExpressionNode)
+    uniq = IdDict{Any,Int}()
+    occ = Int[]
+    walk(n) = n.degree == 0 ? (n.constant && push!(occ, get!(uniq, n, length(uniq) + 1))) : foreach(walk, get_children(n, Int(n.degree)))
+    walk(tree)
+    return occ
+end
+
 # ---- context: one de_ctx_t per Julia TASK ---------------------------------------------------
 # A de_ctx_t is not thread-safe (INTEGRATION.md §4): every call on it — and the destruction of programs that live in it,
 # which finalizers run from arbitrary threads — takes the context's lock.  Programs hold a strong reference to their
@@ -254,20 +316,26 @@ function HIPPopulation(
     eval_context::EvalContext=EvalContext(), n_params::Integer=0,
 ) where {T<:Union{Float32,Float64}}
     optable = opcode_table(operators)
-    nodes, consts = TapeNode[], T[]
-    node_off, const_off = Int64[0], Int64[0]
+    nodes, consts, cse = TapeNode[], T[], TapeNode[]
+    node_off, const_off, cse_off = Int64[0], Int64[0], Int64[0]
     for t in trees
         flatten!(nodes, consts, t, optable)
         push!(node_off, length(nodes)); push!(const_off, length(consts))
+        if preserve_sharing(typeof(t))            # GraphNode: a second, CSE tape for the eval program
+            mark = length(cse)
+            flatten_cse!(cse, t, optable) == 0 && resize!(cse, mark)
+        end
+        push!(cse_off, length(cse))
     end
     ctx = task_context()
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    rc = GC.@preserve nodes consts node_off const_off ccall(
-        (:de_program_create, LIBDE), Cint,
-        (Ptr{Cvoid}, Cint, Ptr{TapeNode}, Ptr{Int64}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int32, Int32, UInt32,
-         Ref{Ptr{Cvoid}}),
-        ctx.handle, dtype_code(T), nodes, node_off, length(trees), consts, const_off, n_features,
-        n_params, option_bits(operators, eval_context), h)
+    rc = lock(ctx.lock) do; GC.@preserve nodes consts node_off const_off cse cse_off ccall(
+        (:de_program_create_cse, LIBDE), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{TapeNode}, Ptr{Int64}, Ptr{TapeNode}, Ptr{Int64}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int32, Int32,
+         UInt32, Ref{Ptr{Cvoid}}),
+        ctx.handle, dtype_code(T), nodes, node_off, isempty(cse) ? C_NULL : pointer(cse), cse_off, length(trees), consts,
+        const_off, n_features, n_params, option_bits(operators, eval_context), h)
+    end
     check(ctx, rc)
     pop = HIPPopulation{T}(ctx, h[], length(trees), n_features)
     finalizer(pop) do p

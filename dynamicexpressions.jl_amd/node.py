@@ -15,7 +15,8 @@ import numpy as np
 
 from .operators import OperatorEnum
 
-LEAF_CONST, LEAF_FEATURE, LEAF_PARAM = 0, 1, 2
+LEAF_CONST, LEAF_FEATURE, LEAF_PARAM, LEAF_SHARED = 0, 1, 2, 3
+OP_SHARE = 0xFE  # DE_OP_SHARE (include/de_opcodes.h): "the subtree just emitted is shared subtree `arg`"
 
 TAPE_DTYPE = np.dtype([("degree", np.uint8), ("op", np.uint8), ("arg", np.uint16)])
 assert TAPE_DTYPE.itemsize == 4
@@ -106,6 +107,51 @@ class ParametricNode(Node):
             super().__init__(*args, **kw)
 
 
+class GraphNode(Node):
+    """``GraphNode{T,D}`` (src/Node.jl:138-166): exactly ``Node``, with the assumption that some nodes are SHARED — the
+    same object used as a child in several places.  ``preserve_sharing`` (src/Node.jl:341-342) changes what the
+    constant bookkeeping means: a shared constant is ONE constant (``count_constant_nodes`` with ``f_on_shared``,
+    src/NodeUtils.jl:43-51; one gradient row, the sum over its occurrences), and ``copy`` keeps the graph structure.
+    Evaluation is unchanged in value — the reference evaluates a shared node once per parent — so the device may, and
+    does, evaluate it once per tape (``flatten_graph``, ``de_program_create_cse``)."""
+
+    __slots__ = ()
+
+    def copy(self, _memo=None) -> "GraphNode":
+        import copy as _copy
+
+        memo = {} if _memo is None else _memo
+        if id(self) in memo:
+            return memo[id(self)]
+        n = _copy.copy(self)
+        memo[id(self)] = n
+        n.children = tuple(c.copy(memo) if isinstance(c, GraphNode) else c.copy() for c in self.children)
+        return n
+
+
+def break_sharing(tree: Node) -> Node:
+    """``copy(tree; break_sharing=Val(true))`` (src/base.jl:37-46) as a plain ``Node`` tree: every occurrence its own node."""
+    if tree.degree == 0:
+        n = Node(val=tree.val) if tree.constant else Node(feature=tree.feature)
+        return n
+    return Node(tree.op, *[break_sharing(c) for c in tree.children])
+
+
+def preserve_sharing(tree: Node) -> bool:  # src/Node.jl:341-342
+    return isinstance(tree, GraphNode)
+
+
+def _unique_postorder(tree: Node) -> List[Node]:
+    """Post-order with every shared node visited once, at its first occurrence (tree_mapreduce with an id_map,
+    src/base.jl:83-120)."""
+    seen, out = set(), []
+    for n in postorder(tree):
+        if id(n) not in seen:
+            seen.add(id(n))
+            out.append(n)
+    return out
+
+
 def count_nodes(tree: Node) -> int:  # src/base.jl:271-280
     return sum(1 for _ in tree)
 
@@ -124,8 +170,9 @@ def is_node_constant(n: Node) -> bool:  # src/NodeUtils.jl:37
     return n.degree == 0 and n.constant
 
 
-def count_constant_nodes(tree: Node) -> int:  # src/NodeUtils.jl:43-51
-    return sum(1 for n in tree if is_node_constant(n))
+def count_constant_nodes(tree: Node) -> int:  # src/NodeUtils.jl:43-51 (a shared constant counts once: f_on_shared)
+    nodes = _unique_postorder(tree) if preserve_sharing(tree) else tree
+    return sum(1 for n in nodes if is_node_constant(n))
 
 
 def postorder(tree: Node) -> List[Node]:
@@ -145,7 +192,7 @@ def postorder(tree: Node) -> List[Node]:
 def get_scalar_constants(tree: Node) -> Tuple[np.ndarray, List[Node]]:
     """Constants in depth-first left-to-right order (src/NodeUtils.jl:99-120) — the same
     order as index_constant_nodes (:184-201), i.e. the constant-gradient row order."""
-    refs = [n for n in postorder(tree) if is_node_constant(n)]
+    refs = [n for n in (_unique_postorder(tree) if preserve_sharing(tree) else postorder(tree)) if is_node_constant(n)]
     return np.array([n.val for n in refs], dtype=np.float64), refs
 
 
@@ -184,6 +231,89 @@ def flatten(tree: Node, operators: OperatorEnum, dtype=np.float32) -> Tuple[np.n
     if len(consts) > 65535:
         raise ValueError("more than 65535 constants in one tree")
     return tape, np.asarray(consts, dtype=dtype)
+
+
+def flatten_graph(tree: Node, operators: OperatorEnum, dtype=np.float32):
+    """GraphNode tree -> (expanded tape, consts, cse tape | None, occurrence_of).
+
+    * the EXPANDED tape is what ``flatten`` gives (the reference's evaluation order: a shared node once per parent), one
+      constant slot per OCCURRENCE of a constant leaf;
+    * ``occurrence_of[s]`` = the index of the unique constant (order of ``get_scalar_constants``) slot ``s`` is an
+      occurrence of: the host keeps the occurrence slots of a shared constant equal and sums their gradient rows
+      (``Population`` does both), which is what the reference's shared ``NodeIndex`` row amounts to;
+    * the CSE tape restates the tree with every shared, non-constant operator subtree ONCE (``DE_OP_SHARE`` after its
+      first occurrence, ``DE_LEAF_SHARED`` afterwards; constant leaves keep the slot of their first occurrence), or None
+      when nothing can be shared (shared leaves and constant subtrees are cheaper re-read / folded than stored; a shared
+      subtree that is the root or a direct child of a ternary operator is left expanded, include/de_hip.h)."""
+    tape, consts = flatten(tree, operators, dtype)
+    # unique constants in order of first occurrence; slot -> unique index
+    uniq, occ = {}, []
+    for n in postorder(tree):
+        if is_node_constant(n):
+            occ.append(uniq.setdefault(id(n), len(uniq)))
+    occurrence_of = np.asarray(occ, dtype=np.int64)
+    # which operator subtrees occur more than once?
+    count, is_const_sub = {}, {}
+    for n in postorder(tree):
+        count[id(n)] = count.get(id(n), 0) + 1
+        is_const_sub[id(n)] = is_node_constant(n) if n.degree == 0 else all(is_const_sub[id(c)] for c in n.children)
+    # a node reached only through an already-shared ancestor is not shared in its own right
+    parents = {}
+    for n in _unique_postorder(tree):
+        for c in n.children:
+            parents.setdefault(id(c), set()).add(id(n))
+    shareable = {k for k, c in count.items() if c > 1}
+    cse: List[Tuple[int, int, int]] = []
+    defined = {}
+    slot = [0]
+
+    def emit(n: Node, under_ternary: bool) -> None:
+        key = id(n)
+        if key in defined:
+            cse.append((0, LEAF_SHARED, defined[key]))
+            skip(n)
+            return
+        if n.degree == 0:
+            if n.constant:
+                cse.append((0, LEAF_CONST, slot[0]))
+                slot[0] += 1
+            elif getattr(n, "is_parameter", False):
+                cse.append((0, LEAF_PARAM, n.parameter - 1))
+            else:
+                cse.append((0, LEAF_FEATURE, n.feature - 1))
+            return
+        for c in n.children:
+            emit(c, n.degree == 3)
+        cse.append((n.degree, operators.opcode(n.degree, n.op), 0))
+        if (key in shareable and not is_const_sub[key] and not under_ternary and n is not tree and len(defined) < 12
+                and multi_use(n)):
+            defined[key] = len(defined)
+            cse.append((1, OP_SHARE, defined[key]))
+
+    def skip(n: Node) -> None:  # a later occurrence: its constant leaves still own slots in the expanded numbering
+        for m in postorder(n):
+            if is_node_constant(m):
+                slot[0] += 1
+
+    def multi_use(n: Node) -> bool:
+        # used again OUTSIDE the occurrences already covered by a shared ancestor: more than one distinct parent, or the
+        # same parent twice
+        ps = parents.get(id(n), set())
+        if len(ps) > 1:
+            return True
+        (p_id,) = tuple(ps) if ps else (None,)
+        for q in _unique_postorder(tree):
+            if id(q) == p_id:
+                return sum(1 for c in q.children if c is n) > 1
+        return False
+
+    emit(tree, False)
+    if not defined:
+        return tape, consts, None, occurrence_of
+    cse_tape = np.zeros(len(cse), dtype=TAPE_DTYPE)
+    for i, rec in enumerate(cse):
+        cse_tape[i] = rec
+    return tape, consts, cse_tape, occurrence_of
 
 
 def flatten_population(trees: Sequence[Node], operators: OperatorEnum, dtype=np.float32):

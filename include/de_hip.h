@@ -167,6 +167,21 @@ int de_program_create(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes,
                       const int64_t *node_offsets, int64_t n_trees, const void *consts,
                       const int64_t *const_offsets, int32_t n_features, int32_t n_params,
                       uint32_t options, de_program_t **out_program);
+/* The same with a second, CSE tape per tree for GraphNode expressions (shared subtrees, src/Node.jl:138-166).  The
+ * reference evaluates a shared node once PER PARENT (its recursion has no cache); `nodes` is therefore the EXPANDED tape,
+ * exactly as for de_program_create — gradients, constants and flags follow it — and `cse_nodes` (tree t =
+ * cse_nodes[cse_offsets[t] .. cse_offsets[t+1]); an empty range = no sharing) restates the same tree with every shared,
+ * non-constant operator subtree present ONCE: its post-order slice followed by a DE_OP_SHARE marker at the first
+ * occurrence, one DE_LEAF_SHARED leaf at every later one (include/de_opcodes.h).  Constant leaves of the CSE tape use
+ * the slot numbers of their first occurrence in the expanded tape (the host keeps all occurrence slots of a shared constant
+ * equal).  The eval program (de_eval, de_eval_loss) is lowered from the CSE tape: the shared value is computed once per
+ * tape into a persistent LDS row and re-read — bit-identical values and flags, fewer dispatches.  Share ids are 0, 1, ... in
+ * order of definition, at most 16 minus the tree's spill slots; a shared subtree must not be the root or a direct child of
+ * a ternary operator (DE_ERR_UNSUPPORTED otherwise: pass an empty CSE range for that tree).  DE_NO_CSE=1 ignores the CSE tapes. */
+int de_program_create_cse(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, const int64_t *node_offsets,
+                          const de_tape_node_t *cse_nodes, const int64_t *cse_offsets, int64_t n_trees,
+                          const void *consts, const int64_t *const_offsets, int32_t n_features,
+                          int32_t n_params, uint32_t options, de_program_t **out_program);
 /* Replace all constants (same counts, same order) without re-flattening: the
  * optimiser inner loop of get/set_scalar_constants (src/NodeUtils.jl:99-143). */
 int de_program_set_consts(de_program_t *prog, const void *consts);

@@ -26,8 +26,15 @@
 enum de_leaf_kind {
     DE_LEAF_CONST = 0,   /* arg = constant slot (0-based, depth-first order)      */
     DE_LEAF_FEATURE = 1, /* arg = 0-based feature row of X                         */
-    DE_LEAF_PARAM = 2    /* arg = 0-based parameter row (ParametricExpression)     */
+    DE_LEAF_PARAM = 2,   /* arg = 0-based parameter row (ParametricExpression)     */
+    /* CSE tapes only (de_program_create_cse): the value of shared subtree `arg`, defined earlier in the
+     * same tape by a DE_OP_SHARE marker (GraphNode sharing, src/Node.jl:138-166).                        */
+    DE_LEAF_SHARED = 3
 };
+/* CSE tapes only: a degree-1 pseudo node (op = DE_OP_SHARE, arg = share id 0..15) that follows the
+ * post-order slice of a shared subtree at its FIRST occurrence: "this value is shared subtree `arg`".
+ * It is transparent (the value passes through) and costs no instruction of its own. */
+#define DE_OP_SHARE 0xFE
 
 /* Operator ids: value of de_tape_node_t.op when degree >= 1. */
 enum de_opcode {

@@ -1,0 +1,121 @@
+"""GraphNode expressions (shared subtrees, /root/reference/src/Node.jl:138-166) on the GPU: the eval
+program is lowered from the CSE tape (`de_program_create_cse`: a shared subtree is evaluated once per tape into a persistent
+LDS row), everything else from the expanded tape.  Contract: the values and flags of the EXPANDED tree (the reference
+evaluates a shared node once per parent), bit for bit; a shared constant is one constant with one gradient row (the sum
+over its occurrences: the reference's shared `NodeIndex` entry); fewer dispatches."""
+import numpy as np
+import pytest
+
+import dynamicexpressions_jl_amd as de
+from oracle import oracle
+from test_lowering import random_graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from dynamicexpressions_jl_amd import api as _api
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    _api.library()
+    return _api
+
+
+def dispatches(api, pop):
+    lib = api.library()
+    return sum(int(lib.de_program_dump(pop._h, t, None, 0, 3)) // 4 for t in range(pop.n_trees))
+
+
+OPS = de.OperatorEnum(binary_operators=("+", "-", "*", "/"), unary_operators=("cos", "exp", "safe_log", "square"))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_graph_population_matches_its_expansion_bit_for_bit_with_fewer_dispatches(api, dtype):
+    rng = de.synth.Xoshiro256ss(77)
+    graphs = [random_graph(rng, OPS, 6 + i % 24, 4, 1 + i % 4, dtype) for i in range(400)]
+    expanded = [de.break_sharing(g) for g in graphs]
+    assert sum(de.flatten_graph(g, OPS, dtype)[2] is not None for g in graphs) > 150
+    X = de.synth.random_X(4, 3000, seed=5, dtype=dtype)
+    X[2, 11] = np.inf
+    for ec in (api.EvalContext(), api.EvalContext(early_exit=False), api.EvalContext(use_fused=False), api.EvalContext(bumper=True)):
+        pg = api.Population(graphs, OPS, dtype, n_features=4, eval_context=ec)
+        pe = api.Population(expanded, OPS, dtype, n_features=4, eval_context=ec)
+        pg.verify()
+        a, ka = pg.eval(X)
+        b, kb = pe.eval(X)
+        assert np.array_equal(ka, kb)
+        sel = ka if ec.early_exit else np.ones_like(ka)
+        ui = np.uint32 if dtype == np.float32 else np.uint64
+        m = ~(np.isnan(a[sel]) & np.isnan(b[sel]))
+        np.testing.assert_array_equal(a[sel].view(ui)[m], b[sel].view(ui)[m])
+        nd_g, nd_e = dispatches(api, pg), dispatches(api, pe)
+        print(f"[graph CSE {np.dtype(dtype).name} ee={ec.early_exit} fused={ec.use_fused}] dispatches {nd_e} -> {nd_g} "
+              f"({100.0 * (nd_e - nd_g) / nd_e:.1f} % fewer)")
+        assert nd_g < 0.93 * nd_e
+        # fused loss goes through the same eval program
+        y = np.cos(np.arange(X.shape[1])).astype(dtype)
+        la, _ = pg.eval_loss(X[:, :1024], y[:1024])
+        lb, _ = pe.eval_loss(X[:, :1024], y[:1024])
+        mm = ~(np.isnan(la) & np.isnan(lb))
+        np.testing.assert_array_equal(la[mm], lb[mm])
+        pg.close()
+        pe.close()
+
+
+def test_shared_constants_are_one_constant_with_a_summed_gradient_row(api):
+    G = de.GraphNode
+    ops = de.OperatorEnum(binary_operators=("+", "*"), unary_operators=("cos",))
+    x1, c = G(feature=1), G(val=0.75)
+    s = G(1, G(2, x1, c))                     # cos(x1 * c), c is ONE node
+    dag = G(1, s, G(2, s, G(2, c, x1)))       # s + s * (c * x1): c occurs three times, s twice
+    assert de.count_constant_nodes(dag) == 1 and de.count_nodes(de.break_sharing(dag)) == 13
+    X = np.asfortranarray(np.linspace(-2, 2, 513, dtype=np.float64)[None, :])
+    pop = api.Population([dag], ops, np.float64, n_features=1)
+    assert list(pop.n_consts) == [1]
+    out, grads, ok = pop.eval_grad(X, variable=False)
+    assert ok[0] and grads[0].shape == (1, 513)
+    # oracle on the expanded tree: three rows, the reference's shared row is their sum
+    tape, consts = de.flatten(de.break_sharing(dag), ops, np.float64)
+    y, g3, okr = oracle.eval_grad_tree_array(tape, consts, X, oracle.GRAD_CONSTANT)
+    assert okr and g3.shape == (3, 513)
+    np.testing.assert_array_equal(out[0], y)
+    np.testing.assert_allclose(np.asarray(grads[0])[0], g3.sum(axis=0), rtol=1e-13, atol=1e-15)
+    xx, cc = X[0], 0.75
+    sv, dsv = np.cos(xx * cc), -np.sin(xx * cc) * xx
+    np.testing.assert_allclose(np.asarray(grads[0])[0], dsv + dsv * (cc * xx) + sv * xx, rtol=1e-12, atol=1e-14)
+    # :both mode keeps the feature rows in front
+    _, gb, _ = pop.eval_grad(X, variable="both")
+    assert gb[0].shape == (2, 513)
+    np.testing.assert_allclose(np.asarray(gb[0])[1], np.asarray(grads[0])[0], rtol=1e-13)
+    # set_constants takes ONE value and reaches every occurrence (eval program and gradient program alike)
+    pop.set_constants(np.array([1.25]))
+    out2, g2, _ = pop.eval_grad(X, variable=False)
+    ev, _ = pop.eval(X)
+    np.testing.assert_array_equal(ev[0], out2[0])
+    c.val = 1.25
+    fresh = api.Population([dag], ops, np.float64, n_features=1)
+    o3, g3b, _ = fresh.eval_grad(X, variable=False)
+    np.testing.assert_array_equal(out2[0], o3[0])
+    np.testing.assert_array_equal(np.asarray(g2[0]), np.asarray(g3b[0]))
+    # fused loss gradient: one entry
+    yv = np.sin(X[0])
+    _, dl, _ = fresh.eval_loss_grad(X, yv)
+    assert dl[0].shape == (1,)
+    np.testing.assert_allclose(dl[0][0], np.sum(2 * (o3[0] - yv) * np.asarray(g3b[0])[0]), rtol=1e-10)
+    pop.close()
+    fresh.close()
+
+
+def test_cse_can_be_switched_off(api, monkeypatch):
+    rng = de.synth.Xoshiro256ss(5)
+    graphs = [random_graph(rng, OPS, 20, 3, 3, np.float32) for _ in range(50)]
+    X = de.synth.random_X(3, 777, seed=1)
+    a = api.Population(graphs, OPS, np.float32, n_features=3)
+    monkeypatch.setenv("DE_NO_CSE", "1")
+    b = api.Population(graphs, OPS, np.float32, n_features=3)
+    monkeypatch.delenv("DE_NO_CSE")
+    oa, ka = a.eval(X)
+    ob, kb = b.eval(X)
+    assert np.array_equal(ka, kb) and dispatches(api, a) < dispatches(api, b)
+    np.testing.assert_array_equal(oa[ka].view(np.uint32), ob[kb].view(np.uint32))

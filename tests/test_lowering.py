@@ -281,3 +281,89 @@ def test_valu_slot_table_layout():
             tab = json.load(fh)["handlers"]
         stale = [k for k in used if tab.get(str(k), {}).get("valu_cycles") != slots[k]["valu_cycles"]]
         assert not stale, f"profiles/valu_slots.json is stale for handlers {stale}: rerun tools/valu_slots.py"
+
+
+def random_graph(rng, ops, n_nodes, n_features, n_shares, dtype=np.float64):
+    """A random GraphNode DAG: a random tree in which `n_shares` leaves are replaced by references to operator subtrees
+    that already exist elsewhere in the tree (never an ancestor: the result stays acyclic)."""
+    G = de.GraphNode
+    tree = de.synth.gen_random_tree_fixed_size(n_nodes, ops, n_features, rng, dtype, node_type=G)
+    for _ in range(n_shares):
+        nodes = list(de.postorder(tree))
+        inner = [n for n in nodes if n.degree > 0 and n is not tree]
+        parents = [n for n in nodes if n.degree > 0]
+        if not inner or not parents:
+            break
+        target = inner[rng.randint(len(inner)) - 1]
+        below = {id(m) for m in de.postorder(target)}
+        # a parent outside the target's subtree whose child slot holds a leaf
+        cands = [(p, k) for p in parents if id(p) not in below for k, c in enumerate(p.children) if c.degree == 0]
+        cands = [(p, k) for p, k in cands if not _is_ancestor(p, target)]
+        if not cands:
+            continue
+        p, k = cands[rng.randint(len(cands)) - 1]
+        ch = list(p.children)
+        ch[k] = target
+        p.children = tuple(ch)
+    return tree
+
+
+def _is_ancestor(p, target):
+    """Would making `target` a child of `p` create a cycle?  (p reachable from target)"""
+    return any(m is p for m in de.postorder(target))
+
+
+@pytest.mark.parametrize("options", [7, 6, 1, 0, 15])
+def test_cse_tapes_of_graph_nodes_lower_to_the_values_and_flags_of_the_expanded_tree(options):
+    """GraphNode sharing (src/Node.jl:138-166): the CSE tape (shared subtree once + DE_OP_SHARE, then
+    DE_LEAF_SHARED) must lower to a program that gives, on the numpy model of the accumulator machine, exactly the values
+    AND the flag the oracle gives for the EXPANDED tree — the reference evaluates a shared node once per parent — with
+    fewer instructions."""
+    ops = de.OperatorEnum(binary_operators=("+", "-", "*", "/"), unary_operators=("cos", "exp", "safe_log", "square"))
+    rng = de.synth.Xoshiro256ss(4242 + options)
+    X = np.asfortranarray(de.synth.random_X(3, 64, seed=9, dtype=np.float64))
+    X[1, 7] = np.inf
+    n_cse = saved = 0
+    for it in range(300):
+        g = random_graph(rng, ops, 6 + it % 22, 3, 1 + it % 4)
+        tape, consts, cse, occ = de.flatten_graph(g, ops, np.float64)
+        # constants: one slot per occurrence in the expanded tape; a shared constant node owns several
+        assert len(consts) == len(occ) and de.count_constant_nodes(g) == (len(np.unique(occ)) if len(occ) else 0)
+        y, ok = oracle.eval_tree_array(tape, consts, X, options, elementwise=True)
+        w_exp, _ = api.lower_tape(tape, consts, 3, 0, options, np.float64)
+        if cse is None:
+            continue
+        n_cse += 1
+        w_cse, meta = api.lower_tape(cse, consts, 3, 0, options, np.float64)
+        out, ok_c = prog_interp.run(w_cse, X, bool(options & 1), host_ok=meta["host_ok_eval"])
+        ref, ok_e = prog_interp.run(w_exp, X, bool(options & 1), host_ok=meta["host_ok_eval"])
+        assert ok_c == ok == ok_e, (it, de.string_tree(g, ops))  # the reference's flag (oracle, expanded tree)
+        if ok or not (options & 1):
+            # the same machine model, the same libm: the CSE program reproduces the expanded program bit for bit ...
+            m = ~(np.isnan(ref) & np.isnan(out))
+            np.testing.assert_array_equal(out[m], ref[m], err_msg=de.string_tree(g, ops))
+            # (the expanded program against the oracle's values is the subject of the tests above)
+        assert len(w_cse) <= len(w_exp)
+        saved += len(w_exp) - len(w_cse)
+    assert n_cse > 100 and saved > 2 * n_cse  # sharing really shortens the programs
+
+
+def test_cse_tape_validation():
+    G = de.GraphNode
+    ops = de.OperatorEnum(binary_operators=("+", "*"), unary_operators=("cos",))
+    T = de.node.TAPE_DTYPE
+    c = np.zeros(0)
+    ok_tape = np.array([(0, 1, 0), (1, 20, 0), (1, 0xFE, 0), (0, 3, 0), (2, 64, 0)], dtype=T)   # cos(x1){0} + {0}
+    w, _ = api.lower_tape(ok_tape, c, 1, 0, 7, np.float64)
+    assert len(w) == 2  # cos(row) [pushed to the share row by the next instruction], + share row
+    for bad in ([(0, 3, 0), (1, 20, 0)],                                   # reference before definition
+                [(0, 1, 0), (1, 0xFE, 0), (1, 20, 0)],                      # a leaf cannot be shared
+                [(0, 1, 0), (1, 20, 0), (1, 0xFE, 1), (0, 3, 1), (2, 64, 0)],  # ids must start at 0
+                [(0, 1, 0), (1, 20, 0), (1, 0xFE, 0)]):                     # shared root
+        with pytest.raises(ValueError):
+            api.lower_tape(np.array(bad, dtype=T), c, 1, 0, 7, np.float64)
+    # a plain (non-CSE) program must keep rejecting the markers
+    x = G(feature=1)
+    s = G(1, x)
+    tree = G(1, s, s)
+    assert de.flatten_graph(tree, ops, np.float64)[2] is not None
