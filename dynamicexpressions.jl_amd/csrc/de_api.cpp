@@ -488,7 +488,8 @@ static int make_threaded(de_ctx *c, de_program *p) {
 }
 
 // The device layout of the threaded program (see de_kernels.hip): one record per instruction {operand word, immediate,
-// address of ITS handler} and an end record per tree (h_end).  BoundInstr fields by word: Float32 {bop: operand word,
+// address of ITS handler} and an end record per tree (h_tree_end, operand word = tree index); tree t + 1 follows tree t
+// directly — a chunk of consecutive trees is ONE chain.  BoundInstr fields by word: Float32 {bop: operand word,
 // arg: imm, lo/hi: handler}; Float64 {bop: operand word, arg: handler.lo, lo/hi: imm}.
 static void make_chained(de_program *p) {
     const bool f32 = p->dtype == DE_F32;
@@ -507,7 +508,7 @@ static void make_chained(de_program *p) {
             const BoundInstr &s = p->tcode[(size_t)i];
             put(p->ccode[h + (size_t)(i - i0)], s.arg, s.lo, s.hi, p->handler_base + s.bop);
         }
-        put(p->ccode[h + (size_t)(i1 - i0)], 0u, 0u, 0u, p->end_handler);
+        put(p->ccode[h + (size_t)(i1 - i0)], (uint32_t)t, 0u, 0u, p->end_handler); // end record: operand word = the tree's index (h_tree_end)
     }
     p->ccode_off[(size_t)p->n_trees] = (int32_t)p->ccode.size();
 }
@@ -1029,6 +1030,7 @@ int de_program_verify(const de_program_t *p) {
                 if (!std::binary_search(valid.begin(), valid.end(), addr)) return bad("handler address not in the device table", t, i - i0, addr);
                 if (i == i1) {
                     if (addr != p->end_handler) return bad("tree does not end in the end record", t, i - i0, addr);
+                    if (r.bop != (uint32_t)t) return bad("end record does not name its tree", t, i - i0, r.bop);
                     continue;
                 }
                 const BoundInstr &fb = p->fbcode[(size_t)i];

@@ -114,22 +114,23 @@ template <> struct M<double> {
 // (3 FMAs: the first is exact — (n - 1/2)*P1 has its last bit at 2^-23 and |r| < 2 — the other
 // two round relative to the already-small r, which keeps full relative accuracy at the zeros).
 // n comes from the 1.5*2^23 magic add (packable; its low mantissa bit is the parity of n, i.e.
-// the sign flip).  sin(r) = r + r^3 Q(r^2), Q = degree-4 minimax of the relative error on
-// |r| <= pi/2 + 0.02 (2.8e-11).  11 VALU per element (6.5 when two elements share v_pk_* ops)
-// instead of 20 (+3 for the exact-extremum select below); <= 2.0 ulp over |x| <= 1e5 (measured:
-// tests/test_gpu_ops.py).  |x| > 1e5 and
+// the sign flip).  sin(r) = r + r^3 Q(r^2), Q = degree-3 minimax of the relative error on
+// |r| <= pi/2 + 0.02 (6.9e-9, tools/fit/trig_fit.py: the Float32 Horner steps and the final r + r^3 Q cancellation
+// near |r| = pi/2 dominate the error, so the degree-4 Q of round 1 (2.8e-11) bought nothing: 1.97 -> 2.03 ulp worst
+// case in the emulation).  10 VALU per element (two elements share every v_pk_* op) + 1 for the exact-extremum
+// test below; <= 2.1 ulp over |x| <= 1e5 (measured: tests/test_gpu_ops.py).  |x| > 1e5 and
 // Inf take the OCML Payne-Hanek path under a divergent branch; NaN flows through the fast path.
 constexpr float DE_TRIG_FAST_BOUND = 1.0e5f;
+constexpr float DE_TRIG_FAST_BOUND_M = 31829.5f; // < rint(1e5/pi + 1/2) = 31830 <= rint(|x|/pi [+ 1/2]) for |x| > 1e5: the wave-uniform pre-test on the multiple of pi
 #define DE_TRIG_INV_PI 0x1.45f306p-2f
 #define DE_TRIG_MAGIC 12582912.0f
 #define DE_TRIG_P1 0x1.921fb6p+1f
 #define DE_TRIG_P2 -0x1.777a5cp-24f
 #define DE_TRIG_P3 -0x1.ee59dap-49f
-#define DE_TRIG_S0 -0x1.555556p-3f
-#define DE_TRIG_S1 0x1.11110cp-7f
-#define DE_TRIG_S2 -0x1.a017aep-13f
-#define DE_TRIG_S3 0x1.716ac4p-19f
-#define DE_TRIG_S4 -0x1.99e5cap-26f
+#define DE_TRIG_S0 -0x1.55554ap-3f
+#define DE_TRIG_S1 0x1.110ea0p-7f // 3 ulp below the minimax coefficient: the worst case of the Float32 EVALUATION drops from 2.03 to 1.75 ulp (tools/fit/trig_fit.py)
+#define DE_TRIG_S2 -0x1.9f6716p-13f
+#define DE_TRIG_S3 0x1.5d3a4ep-19f
 // Within 2^-12 of +-pi/2 the correctly rounded sine IS +-1 (1 - d^2/2 with d^2/2 <= 2^-25): return it
 // exactly, so that cos(0) == 1, cos(2k*pi) == 1, sin(pi/2 + k*pi) == +-1 hold bit for bit (the
 // polynomial's 2-ulp worst case sits exactly there, where r + r^3 Q cancels from 1.57 to 1).
@@ -147,8 +148,7 @@ template <bool SIN> __device__ __forceinline__ float fast_trig_f32(float x) {
     r = __builtin_fmaf(-m, DE_TRIG_P2, r);
     r = __builtin_fmaf(-m, DE_TRIG_P3, r);
     const float z = r * r;
-    float p = __builtin_fmaf(z, DE_TRIG_S4, DE_TRIG_S3);
-    p = __builtin_fmaf(z, p, DE_TRIG_S2);
+    float p = __builtin_fmaf(z, DE_TRIG_S3, DE_TRIG_S2);
     p = __builtin_fmaf(z, p, DE_TRIG_S1);
     p = __builtin_fmaf(z, p, DE_TRIG_S0);
     float s = __builtin_fmaf(r * z, p, r);
@@ -162,19 +162,19 @@ typedef float DeF2 __attribute__((ext_vector_type(2)));
 typedef unsigned DeU2 __attribute__((ext_vector_type(2)));
 #define DE_F2(c) (DeF2{(c), (c)})
 // The two-element core: reduced argument r, its square z, sin(r) and the magic-add word (parity of n).
-struct DeTrig2 { DeF2 r, z, s, kk; };
+struct DeTrig2 { DeF2 r, z, s, kk, m; };
 template <bool SIN> __device__ __forceinline__ DeTrig2 fast_trig_core_f32x2(DeF2 x) {
     DeTrig2 o;
     const DeF2 t = SIN ? x * DE_F2(DE_TRIG_INV_PI) : __builtin_elementwise_fma(x, DE_F2(DE_TRIG_INV_PI), DE_F2(0.5f));
     o.kk = t + DE_F2(DE_TRIG_MAGIC);
     const DeF2 n = o.kk - DE_F2(DE_TRIG_MAGIC);
     const DeF2 m = SIN ? n : n - DE_F2(0.5f);
+    o.m = n; // the wave-uniform range pre-test reads the multiple itself
     DeF2 r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P1), x);
     r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P2), r);
     r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P3), r);
     const DeF2 z = r * r;
-    DeF2 p = __builtin_elementwise_fma(z, DE_F2(DE_TRIG_S4), DE_F2(DE_TRIG_S3));
-    p = __builtin_elementwise_fma(z, p, DE_F2(DE_TRIG_S2));
+    DeF2 p = __builtin_elementwise_fma(z, DE_F2(DE_TRIG_S3), DE_F2(DE_TRIG_S2));
     p = __builtin_elementwise_fma(z, p, DE_F2(DE_TRIG_S1));
     p = __builtin_elementwise_fma(z, p, DE_F2(DE_TRIG_S0));
     o.r = r;
@@ -190,23 +190,28 @@ __device__ __forceinline__ DeF2 fast_trig_sign_f32x2(DeF2 s, DeF2 kk) {
     y[1] = __uint_as_float((__float_as_uint(kk[1]) << 31) + __float_as_uint(s[1]));
     return y;
 }
-// Wave-uniform "does any of the four arguments exceed `bound` in magnitude (or is NaN)?" at full VALU rate: the OR of the
-// magnitudes' bit patterns is >= each of them, so it exceeds bound's pattern whenever one of them does (a false positive —
-// two values in [2^16, bound) whose mantissa bits combine past it — only sends the wave through the slow path, whose
-// per-element condition is exact).  3 v_or + v_and + v_cmp instead of 4 half-rate max + v_cmp.
+// "Does any of the four arguments exceed `bound` in magnitude?" — v_max3_f32 + v_max_f32 on |.| + v_cmp (3 VALU for four
+// elements).  NaN arguments are NOT reported (maxnum drops them): every caller's fast path propagates NaN by itself.
+// (Round 2 first tried the OR of the four bit patterns against bound's: the OR of the exponent fields of 1.5 and 2.5 is
+// already 0x7F8 — practically every wavefront took the slow path's per-element tests.)
+// Callers pass RESULTS of arithmetic (the multiple of pi, x log2 e): on a raw input the compiler must first quiet a
+// signalling NaN (one v_max_f32 x, x per operand).
 __device__ __forceinline__ bool any_abs_exceeds_f32x4(float a, float b, float c, float d, float bound) {
-    const uint32_t m = (__float_as_uint(a) | __float_as_uint(b) | __float_as_uint(c) | __float_as_uint(d)) & 0x7fffffffu;
-    return m > __float_as_uint(bound);
+    // spelled out: from fmaxf(fabsf(.)) the compiler sometimes adds a v_max_f32 |x|, |x| per operand (sNaN quieting)
+    float m;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(m) : "v"(m), "v"(d));
+    return m > bound;
 }
-// Four elements with a wave-uniform short cut for the extremum select: |r| within 2^-12 of pi/2 means
-// r^2 within ~7.7e-4 of pi^2/4; the test on the already computed r^2 costs 1.5 VALU per element and the
-// select itself (4 per element) runs only in the ~4 % of wavefronts where some lane is that close.
-template <bool SIN> __device__ __forceinline__ void fast_trig_f32x4(const float (&x)[4], float (&y)[4]) {
+// Four elements with a wave-uniform short cut for the extremum select: |r| within 2^-12 of pi/2 (or beyond it: |r| never
+// exceeds pi/2 by more than 0.006) means r^2 > pi^2/4 - 8e-4; the one-sided test on the already computed r^2 is a
+// v_max3 + v_max + v_cmp per FOUR elements and the select itself (4 per element) runs only in the ~4 % of wavefronts
+// where some lane is that close.
+template <bool SIN> __device__ __forceinline__ bool fast_trig_f32x4(const float (&x)[4], float (&y)[4]) {
     DeTrig2 a = fast_trig_core_f32x2<SIN>(DeF2{x[0], x[1]}), b = fast_trig_core_f32x2<SIN>(DeF2{x[2], x[3]});
 #ifndef DE_TRIG_NO_EXTREMUM_FIX
-    const DeF2 da = a.z - DE_F2(0x1.3bd3ccp+1f), db = b.z - DE_F2(0x1.3bd3ccp+1f); // pi^2/4
-    const bool near = (__builtin_fabsf(da[0]) < 8.0e-4f) | (__builtin_fabsf(da[1]) < 8.0e-4f) |
-                      (__builtin_fabsf(db[0]) < 8.0e-4f) | (__builtin_fabsf(db[1]) < 8.0e-4f);
+    // NaN: fmax drops it (the select would leave a NaN alone anyway)
+    const bool near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(a.z[0], a.z[1]), b.z[0]), b.z[1]) > (0x1.3bd3ccp+1f - 8.0e-4f); // pi^2/4
     if (__ballot(near) != 0ull) {
         a.s[0] = trig_extremum_fix(a.r[0], a.s[0]);
         a.s[1] = trig_extremum_fix(a.r[1], a.s[1]);
@@ -216,6 +221,9 @@ template <bool SIN> __device__ __forceinline__ void fast_trig_f32x4(const float 
 #endif
     const DeF2 ya = fast_trig_sign_f32x2(a.s, a.kk), yb = fast_trig_sign_f32x2(b.s, b.kk);
     y[0] = ya[0]; y[1] = ya[1]; y[2] = yb[0]; y[3] = yb[1];
+    // |x| > 1e5 (or Inf) somewhere in the wavefront?  Tested on the multiple of pi the reduction found — |x| > 1e5 means
+    // |n| >= 31830 — the caller then applies the exact per-element condition on x.
+    return __ballot(any_abs_exceeds_f32x4(a.m[0], a.m[1], b.m[0], b.m[1], DE_TRIG_FAST_BOUND_M)) != 0ull;
 }
 // sin and cos of the same argument (value + derivative of cos/sin in the gradient kernel):
 // one reduction, both polynomials, two quadrant selects.  Same accuracy as fast_trig_f32.
@@ -240,10 +248,14 @@ __device__ __forceinline__ void fast_sincos_f32(float x, float *sn, float *cs) {
     *sn = __uint_as_float(__float_as_uint(odd ? c : s) ^ ssign);
     *cs = __uint_as_float(__float_as_uint(odd ? s : c) ^ csign);
 }
-// exp(x) = 2^(x*log2(e)): k = rint(x*L), r = x*L - k in two FMAs (hi/lo split of L),
-// hardware v_exp_f32 on r in [-0.5, 0.5], v_ldexp_f32 for the 2^k scaling (gradual
-// underflow and overflow to Inf come from ldexp).  ~10 VALU vs 15; <= 2 ulp.
-__device__ __forceinline__ float fast_exp_f32(float x) {
+// exp(x) = 2^(x*log2(e)).  ldexp form: k = rint(x*L), r = x*L - k in two FMAs (hi/lo split of L), hardware v_exp_f32 on
+// r in [-0.5, 0.5], v_ldexp_f32 for the 2^k scaling (gradual underflow and overflow to Inf come from ldexp); <= 2 ulp.
+// Results in the normal range (|x log2 e| <= 125.9) come from the direct form 2^RN(x log2 e) * (1 + e ln 2), e = the
+// rounding error of the product (two FMAs) — one v_exp_f32, no rint / clamp / ldexp, 1.3 ulp; everything else (gradual
+// underflow, overflow, Inf) from the ldexp form.  The choice is PER ELEMENT, so every kernel (the packed handlers of the
+// threaded interpreter take the ldexp branch wave-uniformly and select per element) returns the same bits.
+constexpr float DE_EXP_DIRECT_BOUND_T = 125.9f;
+__device__ __forceinline__ float fast_exp_ldexp_f32(float x) {
     const float xc = __builtin_fminf(__builtin_fmaxf(x, -105.0f), 89.0f);
     const float k = __builtin_rintf(xc * 0x1.715476p+0f);
     float r = __builtin_fmaf(xc, 0x1.715476p+0f, -k);
@@ -251,6 +263,14 @@ __device__ __forceinline__ float fast_exp_f32(float x) {
     const float e = __builtin_amdgcn_exp2f(r);
     const float y = __builtin_amdgcn_ldexpf(e, (int)k);
     return x != x ? x : y;
+}
+__device__ __forceinline__ float fast_exp_f32(float x) {
+    const float t = x * 0x1.715476p+0f;
+    if (__builtin_fabsf(t) > DE_EXP_DIRECT_BOUND_T) return fast_exp_ldexp_f32(x);
+    float e = __builtin_fmaf(x, 0x1.715476p+0f, -t);
+    e = __builtin_fmaf(x, 0x1.4ae0c0p-26f, e);
+    const float v = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(v, e * 0x1.62e430p-1f, v); // NaN: t is NaN, the comparison above false, v NaN
 }
 
 // Two elements at a time (v_pk_mul/v_pk_fma for the reduction; exp2/ldexp/rint stay per element).
@@ -285,19 +305,20 @@ __device__ __forceinline__ DeF2 fast_exp_f32x2(DeF2 x) {
 //             denormal inputs and results).
 // Flags: identical to the exact mode except through those edges (a value that is Inf/NaN/0 only in one mode).
 constexpr float DE_TURBO_TRIG_BOUND = 1.0e5f; // = DE_TRIG_FAST_BOUND: beyond it x/pi rounded in Float32 no longer picks the right n
-#define DE_TURBO_S0 -0x1.55554ap-3f
-#define DE_TURBO_S1 0x1.110ea6p-7f
-#define DE_TURBO_S2 -0x1.9f6716p-13f
-#define DE_TURBO_S3 0x1.5d3a4ep-19f
-template <bool SIN> __device__ __forceinline__ DeF2 turbo_trig_f32x2(DeF2 x) {
+#define DE_TURBO_S0 DE_TRIG_S0 // the exact mode's polynomial (degree 9)
+#define DE_TURBO_S1 DE_TRIG_S1
+#define DE_TURBO_S2 DE_TRIG_S2
+#define DE_TURBO_S3 DE_TRIG_S3
+template <bool SIN> __device__ __forceinline__ DeF2 turbo_trig_f32x2(DeF2 x, DeF2 &m) {
     const DeF2 t = SIN ? x * DE_F2(DE_TRIG_INV_PI) : __builtin_elementwise_fma(x, DE_F2(DE_TRIG_INV_PI), DE_F2(0.5f));
     const DeF2 kk = t + DE_F2(DE_TRIG_MAGIC);
     const DeF2 n = kk - DE_F2(DE_TRIG_MAGIC);
-    const DeF2 m = SIN ? n : n - DE_F2(0.5f);
-    DeF2 r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P1), x);
-    r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P2), r);
+    const DeF2 m_ = SIN ? n : n - DE_F2(0.5f);
+    m = n; // out: the multiple, for the caller's range pre-test
+    DeF2 r = __builtin_elementwise_fma(-m_, DE_F2(DE_TRIG_P1), x);
+    r = __builtin_elementwise_fma(-m_, DE_F2(DE_TRIG_P2), r);
     const DeF2 z = r * r;
-    DeF2 p = __builtin_elementwise_fma(z, DE_F2(DE_TURBO_S3), DE_F2(DE_TURBO_S2)); // degree-9 minimax of the relative error, 1.5e-7
+    DeF2 p = __builtin_elementwise_fma(z, DE_F2(DE_TURBO_S3), DE_F2(DE_TURBO_S2));
     p = __builtin_elementwise_fma(z, p, DE_F2(DE_TURBO_S1));
     p = __builtin_elementwise_fma(z, p, DE_F2(DE_TURBO_S0));
     const DeF2 s = __builtin_elementwise_fma(r * z, p, r);
@@ -308,8 +329,9 @@ template <bool SIN> __device__ __forceinline__ DeF2 turbo_trig_f32x2(DeF2 x) {
     return y;
 }
 // exp(x) = 2^t * (1 + e ln 2): t = RN(x log2 e) goes to v_exp_f32, e = the rounding error of that product (one FMA)
-__device__ __forceinline__ DeF2 turbo_exp_f32x2(DeF2 x) {
-    const DeF2 t = x * DE_F2(0x1.715476p+0f);
+__device__ __forceinline__ DeF2 turbo_exp_f32x2(DeF2 x, DeF2 t);
+__device__ __forceinline__ DeF2 turbo_exp_f32x2(DeF2 x) { return turbo_exp_f32x2(x, x * DE_F2(0x1.715476p+0f)); }
+__device__ __forceinline__ DeF2 turbo_exp_f32x2(DeF2 x, DeF2 t) { // t = x * float(log2 e)
     DeF2 e = __builtin_elementwise_fma(x, DE_F2(0x1.715476p+0f), -t);
     e = __builtin_elementwise_fma(x, DE_F2(0x1.4ae0c0p-26f), e); // log2(e) - float(log2(e)): 1.3e-8 * |x| otherwise (1e-6 at |x| = 88)
     const DeF2 v = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};

@@ -508,7 +508,13 @@ template <typename T> using BodyFn = HState<T> (*)(HState<T>, uint32_t, typename
 //   s_load_dwordx4 ; s_add_u32 ; s_addc_u32 ; ... body ... ; s_waitcnt ; 2-3 s_mov ; s_setpc_b64      + 1 VALU (LDS address)
 // against 11 scalar + 1 scalar load + 2 VALU for the call/return loop it replaces (prefetch copy, handler address
 // arithmetic, loop counter and branch, s_swappc/s_setpc pair).
-template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, ConstU4Ptr, uint32_t, typename ImmBits<T>::type);
+// Behind the operand words every handler hands on five more wave-uniform words untouched (they stay in their SGPRs from
+// the kernel's call to the last handler of the chunk): what h_tree_end needs to finish a tree WITHOUT returning to the kernel.
+//   outp  : address of out[0, first sample of this tile] minus the LDS base (so that outp + tree * ldo + lds0 is this lane's vector)
+//   okp   : the completion flags;   ldo : bytes between two trees' output rows;   left : trees of this chunk still to run
+//   flags : HF_* | samples of the tile inside N (slow store)
+template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, ConstU4Ptr, uint32_t, typename ImmBits<T>::type, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t);
+enum : uint32_t { HF_RETURN_EACH = 1u << 31, HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu };
 template <typename T> __device__ __forceinline__ HandlerFn<T> rec_handler(const U32x4 &w);
 template <> __device__ __forceinline__ HandlerFn<float> rec_handler<float>(const U32x4 &w) {
     return reinterpret_cast<HandlerFn<float>>(((uint64_t)w.w << 32) | w.z);
@@ -521,15 +527,13 @@ template <> __device__ __forceinline__ uint32_t rec_imm<float>(const U32x4 &w) {
 template <> __device__ __forceinline__ uint64_t rec_imm<double>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
 #define DE_ROW_BYTES_C ((DE_TBLK + 1) * 16) // LDS row stride of the threaded kernel: DE_TBLK 16-byte vectors + one of padding
 // `code` points at the record of the NEXT instruction; (la, imm) are this instruction's operand words
-#define HCHAIN_ARGS HState<T> st, uint32_t lds0, ConstU4Ptr code, uint32_t la, typename ImmBits<T>::type imm
-#define HCHAIN_NEXT(W) [[clang::musttail]] return rec_handler<T>(W)(st, lds0, code + 1, (W).x, rec_imm<T>(W))
+#define HCHAIN_ARGS HState<T> st, uint32_t lds0, ConstU4Ptr code, uint32_t la, typename ImmBits<T>::type imm, uint64_t outp, uint64_t okp, uint64_t ldo, uint32_t left, uint32_t flags
+#define HCHAIN_NEXT(W) [[clang::musttail]] return rec_handler<T>(W)(st, lds0, code + 1, (W).x, rec_imm<T>(W), outp, okp, ldo, left, flags)
 template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain(HCHAIN_ARGS) {
     const U32x4 w = *code;
     st = BODY(st, lds0 + la, imm); // la = row byte offset | aux << 24 (no carry: LDS < 2^18 bytes)
     HCHAIN_NEXT(w);
 }
-template <typename T> __device__ __noinline__ HState<T> h_end(HState<T> st, uint32_t, ConstU4Ptr, uint32_t, typename ImmBits<T>::type) { return st; }
-
 __device__ __forceinline__ void hpoison_impl(PoisonOf<float>::type &poison, const VecOf<float>::type &v) {
     typedef PoisonOf<float>::type P2;
     const P2 z = {0.0f, 0.0f};
@@ -545,6 +549,38 @@ template <typename T> __device__ __forceinline__ void hpoison(typename PoisonOf<
 }
 __device__ __forceinline__ bool poison_set(const PoisonOf<float>::type &p) { return (p[0] != p[0]) | (p[1] != p[1]); }
 __device__ __forceinline__ bool poison_set(const double &p) { return p != p; }
+// The end record of a tree (la = the tree's index).  The trees of a chunk are consecutive in the stream, so the record
+// behind it is the first instruction of the next tree: the handler stores the tree's results and its flag, clears the
+// state and tail-calls on — the next record was requested at its first instruction, the store is still in flight when
+// the next tree starts (the eval handlers do not wait for vector memory at entry: csrc/asmpatch.py).  Measured with
+// tools/exp_dispatch_cost.py: returning to a per-tree loop in the kernel (index load, first-record load, two dependent
+// scalar-cache round trips per tree) cost ~250 SIMD cycles per tree and wavefront, a quarter of the headline's time.
+// HF_RETURN_EACH (fused loss): the kernel owns the epilogue and re-enters the stream per tree.
+template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VW = VecOf<T>::W;
+    if (flags & HF_RETURN_EACH) return st;
+    const U32x4 w = *code;
+    typedef __attribute__((address_space(1))) char *GPtr; // global, not flat: a flat store also ties up lgkmcnt
+    const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)la * ldo); // wave-uniform: the store takes it as its scalar base
+    if (__builtin_expect((flags & (HF_SLOW_STORE | HF_NO_STORE)) == 0u, 1)) {
+        *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0) = st.acc;
+    } else if (flags & HF_SLOW_STORE) { // ragged last tile / output rows that are not 16-byte aligned (LDS base = 0: lds0 = 16 * thread)
+        const int remaining = (int)(flags & HF_VALID_MASK) - (int)(lds0 / (uint32_t)sizeof(T));
+        DE_UNROLL for (int i = 0; i < VW; i++)
+            if (i < remaining) reinterpret_cast<__attribute__((address_space(1))) T *>(row + lds0)[i] = st.acc[i];
+    } else if (st.acc[0] == T(123456.789)) { // DE_DEBUG_NO_STORE (measurement only): keep the value alive, write nothing
+        *reinterpret_cast<__attribute__((address_space(1))) T *>(row + lds0) = st.acc[0];
+    }
+    if (__builtin_expect(__ballot(poison_set(st.poison)) != 0ull, 0))
+        *reinterpret_cast<__attribute__((address_space(1))) uint8_t *>(okp + la) = 0; // every lane the same byte
+    if (left <= 1u) return st;
+    DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
+    st.poison = typename PoisonOf<T>::type{};
+    left -= 1u;
+    HCHAIN_NEXT(w);
+}
+
 template <typename T> __device__ __forceinline__ HState<T> b_load_row(HARGS) { st.acc = *LDSP(T, la); return st; }
 template <typename T> __device__ __forceinline__ HState<T> b_load_const(HARGS) {
     const T c = imm_from<T>(imm);
@@ -570,14 +606,16 @@ template <typename T> __device__ __forceinline__ HState<T> b_check_acc(HARGS) { 
 // propagates through the FMAs) takes the generic expansion, under a wave-uniform branch.
 __device__ __forceinline__ VecOf<float>::type div_apply(VecOf<float>::type a, VecOf<float>::type b) {
     typedef VecOf<float>::type V;
-    float hi = fmaxf(fmaxf(fabsf(a[0]), fabsf(b[0])), fabsf(a[1]));
-    hi = fmaxf(fmaxf(hi, fabsf(b[1])), fabsf(a[2]));
-    hi = fmaxf(fmaxf(hi, fabsf(b[2])), fabsf(a[3]));
-    hi = fmaxf(hi, fabsf(b[3]));
-    float lo = fminf(fminf(fabsf(a[0]), fabsf(b[0])), fabsf(a[1]));
-    lo = fminf(fminf(lo, fabsf(b[1])), fabsf(a[2]));
-    lo = fminf(fminf(lo, fabsf(b[2])), fabsf(a[3]));
-    lo = fminf(lo, fabsf(b[3]));
+    // v_max3 / v_min3 on |.|, spelled out (fmaxf(fabsf(.)) costs an extra v_max_f32 |x|, |x| per raw operand: sNaN quieting)
+    float hi, lo;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(hi) : "v"(a[0]), "v"(b[0]), "v"(a[1]));
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(hi) : "v"(hi), "v"(b[1]), "v"(a[2]));
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(hi) : "v"(hi), "v"(b[2]), "v"(a[3]));
+    asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(hi) : "v"(hi), "v"(b[3]));
+    asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(lo) : "v"(a[0]), "v"(b[0]), "v"(a[1]));
+    asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(lo) : "v"(lo), "v"(b[1]), "v"(a[2]));
+    asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(lo) : "v"(lo), "v"(b[2]), "v"(a[3]));
+    asm("v_min_f32_e64 %0, %1, |%2|" : "=v"(lo) : "v"(lo), "v"(b[3]));
     const bool safe = (hi < 0x1p+40f) & (lo > 0x1p-40f); // all-NaN compares false: generic path
     if (__ballot(!safe) != 0ull) return a / b;
     V q;
@@ -629,24 +667,39 @@ template <typename T, int K, bool TB = false> __device__ __forceinline__ typenam
             const DeF2 a = turbo_exp_f32x2(xa), b = turbo_exp_f32x2(xb);
             r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
         } else {
-            const DeF2 a = turbo_trig_f32x2<K == 2>(xa), b = turbo_trig_f32x2<K == 2>(xb);
+            DeF2 ma, mb;
+            const DeF2 a = turbo_trig_f32x2<K == 2>(xa, ma), b = turbo_trig_f32x2<K == 2>(xb, mb);
             r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
-            if (__ballot(any_abs_exceeds_f32x4(x[0], x[1], x[2], x[3], DE_TURBO_TRIG_BOUND)) != 0ull) { // huge arguments, Inf, NaN: full range reduction (rare, wave-uniform)
+            if (__ballot(any_abs_exceeds_f32x4(ma[0], ma[1], mb[0], mb[1], DE_TRIG_FAST_BOUND_M)) != 0ull) { // huge arguments, Inf: full range reduction (rare, wave-uniform)
                 DE_UNROLL for (int i = 0; i < VW; i++)
                     if (fabsf(x[i]) > DE_TURBO_TRIG_BOUND) r[i] = K == 2 ? sinf(x[i]) : cosf(x[i]);
             }
         }
     } else if constexpr (sizeof(T) == 4) {
         if constexpr (K == 1) {
-            const DeF2 a = fast_exp_f32x2(DeF2{x[0], x[1]}), b = fast_exp_f32x2(DeF2{x[2], x[3]});
+            // |x log2 e| <= 125.9: the result is a normal number and 2^RN(x log2 e) * (1 + e ln 2) (de_device_ops.h: one v_exp_f32,
+            // no rint / clamp / ldexp) is as accurate as the ldexp formulation (1.3 vs 1.2 ulp).  Subnormal results (gradual
+            // underflow), overflow and Inf take that one under a wave-uniform branch; NaN flows through either.
+            const DeF2 xa = {x[0], x[1]}, xb = {x[2], x[3]};
+            const DeF2 ta = xa * DE_F2(0x1.715476p+0f), tb = xb * DE_F2(0x1.715476p+0f);
+            DeF2 a = turbo_exp_f32x2(xa, ta), b = turbo_exp_f32x2(xb, tb);
             r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1];
+            if (__ballot(any_abs_exceeds_f32x4(ta[0], ta[1], tb[0], tb[1], DE_EXP_DIRECT_BOUND_T)) != 0ull) {
+                // per-element select (not a plain overwrite): keeps the direct results above the branch and in the result registers
+                a = fast_exp_f32x2(xa);
+                b = fast_exp_f32x2(xb);
+                r[0] = __builtin_fabsf(ta[0]) > DE_EXP_DIRECT_BOUND_T ? a[0] : r[0];
+                r[1] = __builtin_fabsf(ta[1]) > DE_EXP_DIRECT_BOUND_T ? a[1] : r[1];
+                r[2] = __builtin_fabsf(tb[0]) > DE_EXP_DIRECT_BOUND_T ? b[0] : r[2];
+                r[3] = __builtin_fabsf(tb[1]) > DE_EXP_DIRECT_BOUND_T ? b[1] : r[3];
+            }
         } else {
             const float xi[4] = {x[0], x[1], x[2], x[3]};
             float yo[4];
-            fast_trig_f32x4<K == 2>(xi, yo);
+            const bool slow = fast_trig_f32x4<K == 2>(xi, yo);
             r[0] = yo[0]; r[1] = yo[1]; r[2] = yo[2]; r[3] = yo[3];
-            // Inf, NaN and |x| > 1e5 take the slow path (the fast path propagates NaN too: same result either way)
-            if (__ballot(any_abs_exceeds_f32x4(x[0], x[1], x[2], x[3], DE_TRIG_FAST_BOUND)) != 0ull) { // inline: a call here would turn every handler into a non-leaf function
+            // Inf and |x| > 1e5 take the slow path (the fast path propagates NaN: same result either way)
+            if (slow) { // inline: a call here would turn every handler into a non-leaf function
                 DE_UNROLL for (int i = 0; i < VW; i++)
                     if (fabsf(x[i]) > DE_TRIG_FAST_BOUND) r[i] = K == 2 ? sinf(x[i]) : cosf(x[i]);
             }
@@ -834,7 +887,7 @@ template <typename T, bool TB> __global__ void de_fill_handlers(uint64_t *t) {
     t[BOP_GEN_CONST] = (uint64_t)&h_chain<T, &b_gen<T, 1, false>>;
     t[BOP_GEN_ACC] = (uint64_t)&h_chain<T, &b_gen<T, 2, false>>;
     t[BOP_GEN_PARAM] = (uint64_t)&h_param<T, TB>;
-    t[TOPX_END] = (uint64_t)&h_end<T>;
+    t[TOPX_END] = (uint64_t)&h_tree_end<T>;
     t[BOP_TERN] = (uint64_t)&h_chain<T, &b_tern<T>>;
     t[BOP_INJ_ACC] = (uint64_t)&h_chain<T, &b_gen<T, 2, true>>;
     t[BOP_INJ_ROW] = (uint64_t)&h_chain<T, &b_gen<T, 0, true>>;
@@ -964,15 +1017,30 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         }
     }
 
-    for (int tree = t0; tree < t1; ++tree) {
-        // code_off[tree] = the record of the tree's first instruction; the chain ends in h_end (the tree's end record)
-        const ConstU4Ptr rec = code + code_off[tree];
+    if (t0 >= t1) return;
+    const uint64_t ldo = (uint64_t)a.ld_out * sizeof(T);
+    if constexpr (!LOSS) {
+        // ONE call per chunk: the trees t0..t1 are consecutive in the stream and every tree's end record (h_tree_end)
+        // stores its results and runs on into the next tree; the call returns after the last one.
+        const ConstU4Ptr rec = code + code_off[t0];
         HState<T> st;
         DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
         st.poison = typename PoisonOf<T>::type{};
+        const int64_t in_tile = a.N - base < (int64_t)TILE ? a.N - base : (int64_t)TILE;
+        const uint32_t flags = a.vec_store == 2 ? HF_NO_STORE : ((full && a.vec_store) ? 0u : (HF_SLOW_STORE | (uint32_t)in_tile));
+        const uint64_t outp = (uint64_t)(uintptr_t)(a.out + base) - (uint64_t)(uint32_t)(uintptr_t)smem_raw;
         const U32x4 hd = *rec;
-        st = rec_handler<T>(hd)(st, lds0, rec + 1, hd.x, rec_imm<T>(hd));
-        if constexpr (LOSS) {
+        st = rec_handler<T>(hd)(st, lds0, rec + 1, hd.x, rec_imm<T>(hd), outp, (uint64_t)(uintptr_t)a.ok, ldo, (uint32_t)(t1 - t0), flags);
+        (void)st;
+    } else {
+        for (int tree = t0; tree < t1; ++tree) {
+            // code_off[tree] = the record of the tree's first instruction; h_tree_end returns here (HF_RETURN_EACH)
+            const ConstU4Ptr rec = code + code_off[tree];
+            HState<T> st;
+            DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
+            st.poison = typename PoisonOf<T>::type{};
+            const U32x4 hd = *rec;
+            st = rec_handler<T>(hd)(st, lds0, rec + 1, hd.x, rec_imm<T>(hd), 0ull, 0ull, 0ull, 1u, (uint32_t)HF_RETURN_EACH);
             // sum_j w_j * l(out_j - y_j) over this wave's 64*VW samples -> one partial per (tile, tree, wave)
             T s = T(0);
             DE_UNROLL for (int i = 0; i < VW; i++) {
@@ -982,19 +1050,8 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             }
             s = wave_sum_to_lane63(s);
             if ((tid & 63) == 63) a.partial[((int64_t)tm.tile * a.n_trees + tree) * TWAVES + (tid >> 6)] = s;
-        } else {
-            T *__restrict__ o = a.out + (int64_t)tree * a.ld_out + base + tid * VW;
-            if (a.vec_store == 2) { // DE_DEBUG_NO_STORE (measurement only): keep the value alive, write nothing
-                if (st.acc[0] == T(123456.789)) *o = st.acc[0];
-            } else if (full && a.vec_store) {
-                *reinterpret_cast<V *>(o) = st.acc;
-            } else {
-                VG<T, 1> av;
-                av.v[0] = st.acc;
-                store_ragged<T, 1>(o, av, a.N - (base + tid * VW), TILE);
-            }
+            if (__ballot(poison_set(st.poison)) != 0ull) flag_incomplete(a.ok + tree);
         }
-        if (__ballot(poison_set(st.poison)) != 0ull) flag_incomplete(a.ok + tree);
     }
 }
 

@@ -87,7 +87,7 @@ def test_refuses_a_module_without_handlers_or_without_indirect_calls(tmp_path):
 def test_asmpatch_relaxes_only_the_entry_wait_of_eval_handlers():
     """csrc/asmpatch.py rewrites ONE instruction word — the function-entry `s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)` — of
     the direct-threaded eval handlers that contain no vector-memory instruction; checked on the shipped code object: those
-    start with the relaxed wait, every other function (handlers with a stack frame, h_end, cold_op, flag_incomplete, OCML
+    start with the relaxed wait, every other function (handlers with a stack frame, h_tree_end, cold_op, flag_incomplete, OCML
     helpers ...) keeps the full one."""
     import subprocess
     obj = os.path.join(HERE, "..", "dynamicexpressions.jl_amd", "csrc", "_obj", "irp_de_kernels", "k.out")
@@ -115,5 +115,5 @@ def test_asmpatch_relaxes_only_the_entry_wait_of_eval_handlers():
     assert all(not vmem[n] for n in relaxed)                 # only handlers without any vector-memory instruction
     assert all(vmem[n] for n in handlers if n not in relaxed)  # ... and all of those
     assert all(i == "s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)" for n, i in handlers.items() if n not in relaxed)
-    assert all(i == "s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)" for i in others.values()), others  # h_end among them
-    assert any("5h_endI" in n for n in others)
+    assert all(i == "s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)" for i in others.values()), others  # h_tree_end among them
+    assert any("10h_tree_endI" in n for n in others)
