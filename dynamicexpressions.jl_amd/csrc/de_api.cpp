@@ -1665,6 +1665,8 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                 p->gtsite_of_gb[(size_t)i] = (int32_t)out.size();
                 out.push_back(o);
             }
+            // the end record: every tree's chain finishes in g_end (the table slot of round 1's parameter handler)
+            out.push_back(BoundInstr{(uint32_t)(table[gop_param(GC)] - base), 0u, 0u, 0u});
             tree_cnt[(size_t)t] = (int32_t)(out.size() - out_before);
         }
         });
@@ -1688,8 +1690,10 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         }
         if (!p->d_gtcode) {
             // a unary operator on a constant leaf becomes two instructions: at most twice the bound program
-            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode), (2 * p->gbcode.size() + 1) * sizeof(BoundInstr)));
-            HIP_TRY(c, hipMemset(p->d_gtcode, 0, (2 * p->gbcode.size() + 1) * sizeof(BoundInstr)));
+            // ... plus one end record per tree and one of padding (every handler reads the record behind its own)
+            const size_t gt_cap = 2 * p->gbcode.size() + (size_t)p->n_trees + 1;
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode), gt_cap * sizeof(BoundInstr)));
+            HIP_TRY(c, hipMemset(p->d_gtcode, 0, gt_cap * sizeof(BoundInstr)));
             HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode_off), p->gtcode_off.size() * sizeof(int32_t)));
             HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gt_ids), std::max<size_t>(ids.size(), 1) * sizeof(int32_t)));
         }
@@ -1932,6 +1936,9 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                 } else ok = false; // INJ_*: only bound with early_exit=false, never for gradients
             }
             if (!ok) break;
+            // end record of the forward sweep (r_end: the table slot of round 1's parameter handler); the backward sweep's
+            // first record follows it
+            p->rtcode.push_back(mk(ROP_PARAM, 0, 0, 0));
             p->rtcode_mid[(size_t)t] = (int32_t)p->rtcode.size();
             // Gradient rows several leaves share (features, parameters): the leaves' contributions are added per
             // SAMPLE in an LDS row and reduced once, at the last of them — paths that cancel within a sample then
@@ -1962,6 +1969,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
             }
             if (!ok) break;
             if (PR0 + n_prows + n_acc > 0x3FFFu) { ok = false; break; }
+            p->rtcode.push_back(mk(ROP_PARAM, 0, 0, 0)); // end record of the backward sweep
             p->rtcode_off[(size_t)t + 1] = (int32_t)p->rtcode.size();
             max_prows = std::max(max_prows, n_prows + n_acc);
             need[(size_t)t] = n_prows + n_acc;

@@ -4,12 +4,15 @@
 // carries a dual number (x, d[0..GC)) through the bound UNFOLDED program.  The flat switch of that
 // kernel costs ~37 scalar instructions per interpreted instruction and a gradient wave holds ONE
 // sample per lane, so scalar issue — not the dual arithmetic — was its limit.  Here every
-// (operator, operand kind, check) combination is its own leaf function, reached by one indirect
-// call (14 scalar + 2 vector instructions with csrc/irpatch.py); operand kinds are resolved on the
-// host (leaf row / spill slot / constant), so handlers are straight-line code.
+// (operator, operand kind, check) combination is its own leaf function; operand kinds are resolved on the
+// host (leaf row / spill slot / constant), so handlers are straight-line code.  Dispatch is DIRECT-THREADED like the
+// eval kernel's (de_kernels.hip): a handler loads the next record first (s_load_dwordx4, overlapping its own LDS reads
+// and arithmetic), runs its body and tail-calls the next handler (s_setpc_b64) with that record's operand words in
+// SGPRs; the tree's end record (g_end) returns to the kernel for the epilogue.  ~9 scalar + 1 vector instruction per
+// dispatch against 14 + 2 for the call/return loop of round 1.
 //
 // Instruction word (16 B, built by de_api.cpp make_grad_threaded from the bound program):
-//   x = handler address - handler base
+//   x = handler address - handler base (the base travels with the chain in SGPRs: one code object module per window width)
 //   y = LDS byte offset of the operand (leaf row or spill slot base) | aux << 24
 //         aux = gradient row seeded by a leaf/constant operand (0xFF: none in this mode);
 //         for GOP_GEN_CONST y[23:16] = de_opcode (no LDS operand), for GOP_TERN aux = de_opcode
@@ -76,7 +79,16 @@ template <typename T, int GC> struct GDual {
     LV(T) d[GC];
 };
 #define GHARGS GState<T, GC> st, uint32_t la, typename GImm<T>::type imm
-template <typename T, int GC> using GHandlerFn = GState<T, GC> (*)(GState<T, GC>, uint32_t, typename GImm<T>::type);
+template <typename T, int GC> using GBodyFn = GState<T, GC> (*)(GState<T, GC>, uint32_t, typename GImm<T>::type);
+// what the stream points at: gh_chain<T, GC, &body>.  `code` = the NEXT record; (la, imm) = this instruction's operand words;
+// lds0 = the lane's LDS base; hbase = handler base of this module.  csrc/irpatch.py moves code, la, imm, hbase to SGPRs.
+#define GCHAIN_ARGS GState<T, GC> st, uint32_t lds0, ConstU4Ptr code, uint32_t la, typename GImm<T>::type imm, uint64_t hbase
+template <typename T, int GC> using GHandlerFn = GState<T, GC> (*)(GState<T, GC>, uint32_t, ConstU4Ptr, uint32_t, typename GImm<T>::type, uint64_t);
+template <typename T> __device__ __forceinline__ typename GImm<T>::type grec_imm(const U32x4 &w);
+template <> __device__ __forceinline__ uint32_t grec_imm<float>(const U32x4 &w) { return w.z; }
+template <> __device__ __forceinline__ uint64_t grec_imm<double>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
+#define GCHAIN_NEXT(W) [[clang::musttail]] return reinterpret_cast<GHandlerFn<T, GC>>(hbase + (W).x)(st, lds0, code + 1, (W).y, grec_imm<T>(W), hbase)
+#define GH(...) (uint64_t)&gh_chain<T, GC, &__VA_ARGS__>
 #define GLDS(T, addr) (reinterpret_cast<__attribute__((address_space(3))) LV(T) *>((uintptr_t)(addr)))
 // LDS is laid out wave-major: wave w owns rows [w*R, (w+1)*R), a row = the 64*VS samples of that wave
 // (512 B for Float32 x 2) — everything a wave touches is private to it and contiguous, which the epilogue
@@ -128,21 +140,21 @@ template <typename T, int GC, int SRC, int SV> __device__ __forceinline__ void g
     }
 }
 
-template <typename T, int GC, int SRC, int SV> __device__ __noinline__ GState<T, GC> g_load(GHARGS) {
+template <typename T, int GC, int SRC, int SV> __device__ __forceinline__ GState<T, GC> g_load(GHARGS) {
     const GOperand<T, GC, SRC, SV> b = goperand<T, GC, SRC, SV>(st, la, imm);
     st.x = b.x;
     if constexpr ((SRC == GS_LEAF || SRC == GS_CONST) && SV >= 1) { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = lv_splat<T>((k == SV - 2) ? T(1) : T(0)); }
     else { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = b.d[k]; }
     return st;
 }
-template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_push(GHARGS) {
+template <typename T, int GC> __device__ __forceinline__ GState<T, GC> g_push(GHARGS) {
     *GLDS(T, la) = st.x;
     DE_UNROLL for (int k = 0; k < GC; k++) *GLDS(T, la + (1 + k) * grow_bytes<T>()) = st.d[k];
     return st;
 }
 // PUSH + LOAD in one dispatch.  LEAF: la = the row (| run-time seed << 24), imm = byte distance from the row to the slot;
 // CONST: la = the slot (| run-time seed << 24), imm = the constant.
-template <typename T, int GC, int SRC, int SV> __device__ __noinline__ GState<T, GC> g_pushload(GHARGS) {
+template <typename T, int GC, int SRC, int SV> __device__ __forceinline__ GState<T, GC> g_pushload(GHARGS) {
     uint32_t slot = la & 0xFFFFFFu;
     if constexpr (SRC == GS_LEAF) slot += (uint32_t)imm;
     *GLDS(T, slot) = st.x;
@@ -153,15 +165,15 @@ template <typename T, int GC, int SRC, int SV> __device__ __noinline__ GState<T,
     else { DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = b.d[k]; }
     return st;
 }
-template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_check_acc(GHARGS) {
+template <typename T, int GC> __device__ __forceinline__ GState<T, GC> g_check_acc(GHARGS) {
     gpoison<T>(st.poison, st.x);
     return st;
 }
-template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_nop(GHARGS) { return st; }
+template <typename T, int GC> __device__ __forceinline__ GState<T, GC> g_nop(GHARGS) { return st; }
 
 // binary hot ops: value v and partials (gl, gr) w.r.t. (left, right); K 2/5 (RSUB/RDIV): left = operand.
 // The formulas (and their operation order) are the oracle's / the switch kernel's: d = gl*dl + gr*dr dense.
-template <typename T, int GC, int K, int SRC, int SV, bool CHK> __device__ __noinline__ GState<T, GC> g_bin(GHARGS) {
+template <typename T, int GC, int K, int SRC, int SV, bool CHK> __device__ __forceinline__ GState<T, GC> g_bin(GHARGS) {
     const GOperand<T, GC, SRC, SV> b = goperand<T, GC, SRC, SV>(st, la, imm);
     constexpr bool REV = (K == 2 || K == 5);
     const LV(T) lx = REV ? b.x : st.x, ly = REV ? st.x : b.x;
@@ -187,7 +199,7 @@ template <typename T, int GC, int K, int SRC, int SV, bool CHK> __device__ __noi
     return st;
 }
 // unary hot ops (K: 0 cos, 1 exp, 2 sin, 3.. see gun_inline)
-template <typename T, int GC, int K, int SRC, int SV, bool CHK> __device__ __noinline__ GState<T, GC> g_un(GHARGS) {
+template <typename T, int GC, int K, int SRC, int SV, bool CHK> __device__ __forceinline__ GState<T, GC> g_un(GHARGS) {
     const GOperand<T, GC, SRC, SV> b = goperand<T, GC, SRC, SV>(st, la, imm);
     LV(T) y, g;
     if constexpr (K >= 3) {
@@ -264,7 +276,7 @@ template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_gen_apply(
     }
     return st;
 }
-template <typename T, int GC, int SRC> __device__ __noinline__ GState<T, GC> g_gen(GHARGS) {
+template <typename T, int GC, int SRC> __device__ __forceinline__ GState<T, GC> g_gen(GHARGS) {
     uint32_t gop;
     if constexpr (SRC == GS_CONST) gop = ((la - (st.g0 & 0xFFFF0000u)) >> 16) & 0xFFu; // no LDS operand: the opcode rides in la[23:16] above the lane's LDS base, whose upper half st.g0 carries
     else gop = (uint32_t)imm;
@@ -274,7 +286,7 @@ template <typename T, int GC, int SRC> __device__ __noinline__ GState<T, GC> g_g
     DE_UNROLL for (int k = 0; k < GC; k++) b.d[k] = o.d[k];
     return g_gen_apply<T, GC>(st, gop, b);
 }
-template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_tern(GHARGS) { // acc = op3(slot B, slot C, acc)
+template <typename T, int GC> __device__ __forceinline__ GState<T, GC> g_tern(GHARGS) { // acc = op3(slot B, slot C, acc)
     const uint32_t lb = la & 0xFFFFFFu, lc = lb + (uint32_t)imm;
     const LV(T) xb = *GLDS(T, lb), xc = *GLDS(T, lc);
     LV(T) g0, g1, g2;
@@ -288,21 +300,29 @@ template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_tern(GHARG
     return st;
 }
 
+// ---- direct-threaded dispatch (see the head of the file) ----------------------------------------------------------
+template <typename T, int GC, GBodyFn<T, GC> BODY> __device__ __noinline__ GState<T, GC> gh_chain(GCHAIN_ARGS) {
+    const U32x4 w = *code;
+    st = BODY(st, lds0 + la, imm);
+    GCHAIN_NEXT(w);
+}
+template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_end(GState<T, GC> st, uint32_t, ConstU4Ptr, uint32_t, typename GImm<T>::type, uint64_t) { return st; }
+
 // handler table: seed variants enumerated at compile time
 template <typename T, int GC, int SV> __device__ __forceinline__ void fill_seeded(uint64_t *t) {
     if constexpr (SV < GC + 2) {
-        t[gop_load(GC, GS_LEAF, SV)] = (uint64_t)&g_load<T, GC, GS_LEAF, SV>;
-        t[gop_load(GC, GS_CONST, SV)] = (uint64_t)&g_load<T, GC, GS_CONST, SV>;
-        t[gop_pushload(GC, GS_LEAF, SV)] = (uint64_t)&g_pushload<T, GC, GS_LEAF, SV>;
-        t[gop_pushload(GC, GS_CONST, SV)] = (uint64_t)&g_pushload<T, GC, GS_CONST, SV>;
-#define GB1(K) t[gop_bin(GC, K, GS_LEAF, SV, false)] = (uint64_t)&g_bin<T, GC, K, GS_LEAF, SV, false>; \
-               t[gop_bin(GC, K, GS_LEAF, SV, true)] = (uint64_t)&g_bin<T, GC, K, GS_LEAF, SV, true>;    \
-               t[gop_bin(GC, K, GS_CONST, SV, false)] = (uint64_t)&g_bin<T, GC, K, GS_CONST, SV, false>; \
-               t[gop_bin(GC, K, GS_CONST, SV, true)] = (uint64_t)&g_bin<T, GC, K, GS_CONST, SV, true>;
+        t[gop_load(GC, GS_LEAF, SV)] = GH(g_load<T, GC, GS_LEAF, SV>);
+        t[gop_load(GC, GS_CONST, SV)] = GH(g_load<T, GC, GS_CONST, SV>);
+        t[gop_pushload(GC, GS_LEAF, SV)] = GH(g_pushload<T, GC, GS_LEAF, SV>);
+        t[gop_pushload(GC, GS_CONST, SV)] = GH(g_pushload<T, GC, GS_CONST, SV>);
+#define GB1(K) t[gop_bin(GC, K, GS_LEAF, SV, false)] = GH(g_bin<T, GC, K, GS_LEAF, SV, false>); \
+               t[gop_bin(GC, K, GS_LEAF, SV, true)] = GH(g_bin<T, GC, K, GS_LEAF, SV, true>);    \
+               t[gop_bin(GC, K, GS_CONST, SV, false)] = GH(g_bin<T, GC, K, GS_CONST, SV, false>); \
+               t[gop_bin(GC, K, GS_CONST, SV, true)] = GH(g_bin<T, GC, K, GS_CONST, SV, true>);
         GB1(0) GB1(1) GB1(2) GB1(3) GB1(4) GB1(5) GB1(6) GB1(7)
 #undef GB1
-#define GU1(K) t[gop_un(GC, K, GS_LEAF, SV, false)] = (uint64_t)&g_un<T, GC, K, GS_LEAF, SV, false>; \
-               t[gop_un(GC, K, GS_LEAF, SV, true)] = (uint64_t)&g_un<T, GC, K, GS_LEAF, SV, true>;
+#define GU1(K) t[gop_un(GC, K, GS_LEAF, SV, false)] = GH(g_un<T, GC, K, GS_LEAF, SV, false>); \
+               t[gop_un(GC, K, GS_LEAF, SV, true)] = GH(g_un<T, GC, K, GS_LEAF, SV, true>);
         GU1(0) GU1(1) GU1(2) GU1(3) GU1(4) GU1(5) GU1(6) GU1(7) GU1(8) GU1(9) GU1(10) GU1(11) GU1(12)
 #undef GU1
         fill_seeded<T, GC, SV + 1>(t);
@@ -310,24 +330,24 @@ template <typename T, int GC, int SV> __device__ __forceinline__ void fill_seede
 }
 template <typename T, int GC> __global__ void de_grad_fill_handlers(uint64_t *t) {
     fill_seeded<T, GC, 0>(t);
-    t[gop_load(GC, GS_SLOT, 0)] = (uint64_t)&g_load<T, GC, GS_SLOT, 0>;
-    t[gop_push(GC)] = (uint64_t)&g_push<T, GC>;
-    t[gop_check_acc(GC)] = (uint64_t)&g_check_acc<T, GC>;
-#define GB2(K) t[gop_bin(GC, K, GS_SLOT, 0, false)] = (uint64_t)&g_bin<T, GC, K, GS_SLOT, 0, false>; \
-               t[gop_bin(GC, K, GS_SLOT, 0, true)] = (uint64_t)&g_bin<T, GC, K, GS_SLOT, 0, true>;
+    t[gop_load(GC, GS_SLOT, 0)] = GH(g_load<T, GC, GS_SLOT, 0>);
+    t[gop_push(GC)] = GH(g_push<T, GC>);
+    t[gop_check_acc(GC)] = GH(g_check_acc<T, GC>);
+#define GB2(K) t[gop_bin(GC, K, GS_SLOT, 0, false)] = GH(g_bin<T, GC, K, GS_SLOT, 0, false>); \
+               t[gop_bin(GC, K, GS_SLOT, 0, true)] = GH(g_bin<T, GC, K, GS_SLOT, 0, true>);
     GB2(0) GB2(1) GB2(2) GB2(3) GB2(4) GB2(5) GB2(6) GB2(7)
 #undef GB2
-#define GU2(K, S) t[gop_un(GC, K, S, 0, false)] = (uint64_t)&g_un<T, GC, K, S, 0, false>; t[gop_un(GC, K, S, 0, true)] = (uint64_t)&g_un<T, GC, K, S, 0, true>;
+#define GU2(K, S) t[gop_un(GC, K, S, 0, false)] = GH(g_un<T, GC, K, S, 0, false>); t[gop_un(GC, K, S, 0, true)] = GH(g_un<T, GC, K, S, 0, true>);
 #define GU3(K) GU2(K, GS_SLOT) GU2(K, GS_ACC)
     GU3(0) GU3(1) GU3(2) GU3(3) GU3(4) GU3(5) GU3(6) GU3(7) GU3(8) GU3(9) GU3(10) GU3(11) GU3(12)
 #undef GU3
 #undef GU2
-    t[gop_gen(GC, GS_LEAF)] = (uint64_t)&g_gen<T, GC, GS_LEAF>;
-    t[gop_gen(GC, GS_SLOT)] = (uint64_t)&g_gen<T, GC, GS_SLOT>;
-    t[gop_gen(GC, GS_CONST)] = (uint64_t)&g_gen<T, GC, GS_CONST>;
-    t[gop_gen(GC, GS_ACC)] = (uint64_t)&g_gen<T, GC, GS_ACC>;
-    t[gop_param(GC)] = (uint64_t)&g_nop<T, GC>; // parameter operands are resolved in the interpreter loop
-    t[gop_tern(GC)] = (uint64_t)&g_tern<T, GC>;
+    t[gop_gen(GC, GS_LEAF)] = GH(g_gen<T, GC, GS_LEAF>);
+    t[gop_gen(GC, GS_SLOT)] = GH(g_gen<T, GC, GS_SLOT>);
+    t[gop_gen(GC, GS_CONST)] = GH(g_gen<T, GC, GS_CONST>);
+    t[gop_gen(GC, GS_ACC)] = GH(g_gen<T, GC, GS_ACC>);
+    t[gop_param(GC)] = (uint64_t)&g_end<T, GC>; // the end record of every tree (the id is a leftover of round 1's parameter handler)
+    t[gop_tern(GC)] = GH(g_tern<T, GC>);
 }
 
 // End of a tree: store (or reduce) the wave's results.  Out of line on purpose, and fed with plain values
@@ -475,15 +495,11 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
         DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = lv_splat<T>(T(0));
         st.poison = T(0);
         st.g0 = (uint32_t)g0 | (lds0 & 0xFFFF0000u); // window offset (< 2^16) | upper half of the lane's LDS base (g_gen)
-        U32x4 nxt = code[pc];
-        for (; pc < pe; ++pc) {
-            const U32x4 w = nxt;
-            nxt = code[pc + 1];
-            const GHandlerFn<T, GC> fn = reinterpret_cast<GHandlerFn<T, GC>>(hbase + w.x);
-            typename GImm<T>::type imm;
-            if constexpr (sizeof(T) == 4) imm = w.z;
-            else imm = ((uint64_t)w.w << 32) | w.z;
-            st = fn(st, lds0 + w.y, imm);
+        (void)pe;
+        {   // one call per tree: the chain ends in the tree's end record (g_end)
+            const ConstU4Ptr rec = code + pc;
+            const U32x4 hd = *rec;
+            st = reinterpret_cast<GHandlerFn<T, GC>>(hbase + hd.x)(st, lds0, rec + 1, hd.y, grec_imm<T>(hd), hbase);
         }
         // a non-finite d[k] always survives to the root (every update is linear in it), so the gradient
         // is validity-tested once, here; x was tested where the lowering kept a test (H_CHECK_OUT)

@@ -16,6 +16,9 @@
 // with the ADJOINT in the accumulator and adjoint spill slots in the same LDS rows: a unary operator multiplies
 // the adjoint by its partial; a binary operator sends (adjoint x partial) to its operand — a spill slot, or a
 // leaf whose gradient row is reduced over the wavefront right there — and continues with the accumulator side.
+// Dispatch is direct-threaded (as in de_kernels.hip / de_grad_threaded.hip): a handler loads the next record first, runs its
+// body and tail-calls the next handler with that record's operand words in SGPRs; each sweep ends in an end record (r_end)
+// that returns to the kernel.
 // Instruction words (BoundInstr): x = handler offset, y = LDS byte offset added to the lane's base, z/w = immediate.
 //   forward, row operand   : y = operand row, z = partial row (| generic opcode << 24)
 //   forward, const operand : y = partial row (| generic opcode << 24), z/w = the constant
@@ -52,8 +55,17 @@ template <typename T> struct GState {
     uint32_t lds0;  // the lane's LDS base
     uint32_t stage; // LDS address of this tree's column sums (the wave's staging area)
 };
-template <typename T> using RHandlerFn = GState<T> (*)(GState<T>, uint32_t, typename RImm<T>::type);
+template <typename T> using RBodyFn = GState<T> (*)(GState<T>, uint32_t, typename RImm<T>::type);
 #define RHARGS GState<T> st, uint32_t la, typename RImm<T>::type imm
+// what the stream points at: rh_chain<T, &body>.  `code` = the NEXT record; (la, imm) = this instruction's operand words (la
+// still without the lane's base: st.lds0 is added here); hbase = the module's handler base.  irpatch.py: code, la, imm, hbase in SGPRs.
+#define RCHAIN_ARGS GState<T> st, ConstU4Ptr code, uint32_t la, typename RImm<T>::type imm, uint64_t hbase
+template <typename T> using RHandlerFn = GState<T> (*)(GState<T>, ConstU4Ptr, uint32_t, typename RImm<T>::type, uint64_t);
+template <typename T> __device__ __forceinline__ typename RImm<T>::type rrec_imm(const U32x4 &w);
+template <> __device__ __forceinline__ uint32_t rrec_imm<float>(const U32x4 &w) { return w.z; }
+template <> __device__ __forceinline__ uint64_t rrec_imm<double>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
+#define RCHAIN_NEXT(W) [[clang::musttail]] return reinterpret_cast<RHandlerFn<T>>(hbase + (W).x)(st, code + 1, (W).y, rrec_imm<T>(W), hbase)
+#define RH(...) (uint64_t)&rh_chain<T, &__VA_ARGS__>
 #define RLDS(T, addr) (reinterpret_cast<__attribute__((address_space(3))) T *>((uintptr_t)(addr)))
 template <typename T> constexpr uint32_t rrow_bytes() { return (uint32_t)(64 * sizeof(T)); }
 template <typename T> __device__ __forceinline__ void rpoison(T &p, T v) { p = M<T>::fma(v, T(0), p); }
@@ -75,23 +87,23 @@ template <typename T, int SRC> __device__ __forceinline__ uint32_t rprow(const G
     if constexpr (SRC == RS_CONST || SRC == RS_ACC) return la & 0xFFFFFFu;
     else return st.lds0 + ((uint32_t)imm & 0xFFFFFFu);
 }
-template <typename T, int SRC> __device__ __noinline__ GState<T> f_load(RHARGS) {
+template <typename T, int SRC> __device__ __forceinline__ GState<T> f_load(RHARGS) {
     st.x = roperand<T, SRC>(st, la, imm);
     return st;
 }
-template <typename T> __device__ __noinline__ GState<T> f_push(RHARGS) {
+template <typename T> __device__ __forceinline__ GState<T> f_push(RHARGS) {
     *RLDS(T, la) = st.x;
     return st;
 }
-template <typename T> __device__ __noinline__ GState<T> f_check(RHARGS) {
+template <typename T> __device__ __forceinline__ GState<T> f_check(RHARGS) {
     rpoison<T>(st.vpoison, st.x);
     return st;
 }
-template <typename T> __device__ __noinline__ GState<T> r_nop(RHARGS) { return st; }
+template <typename T> __device__ __forceinline__ GState<T> r_nop(RHARGS) { return st; }
 
 // binary hot ops, K = 0 ADD, 1 SUB, 2 RSUB, 3 MUL, 4 DIV, 5 RDIV (K 2/5: left = operand).  Partials are stored
 // as (d/d acc, d/d operand); + and - store nothing (the backward handlers know them).
-template <typename T, int K, int SRC, bool CHK> __device__ __noinline__ GState<T> f_bin(RHARGS) {
+template <typename T, int K, int SRC, bool CHK> __device__ __forceinline__ GState<T> f_bin(RHARGS) {
     const T b = roperand<T, SRC>(st, la, imm);
     constexpr bool REV = (K == 2 || K == 5);
     const T lx = REV ? b : st.x, ly = REV ? st.x : b;
@@ -119,7 +131,7 @@ template <typename T, int K, int SRC, bool CHK> __device__ __noinline__ GState<T
     return st;
 }
 // unary hot ops (K: 0 cos, 1 exp, 2 sin, 3.. gun_inline); SRC = RS_ACC or RS_LEAF (fused leaf load)
-template <typename T, int K, int SRC, bool CHK> __device__ __noinline__ GState<T> f_un(RHARGS) {
+template <typename T, int K, int SRC, bool CHK> __device__ __forceinline__ GState<T> f_un(RHARGS) {
     const T b = roperand<T, SRC>(st, la, imm);
     T y, g;
     if constexpr (K >= 3) { // the cheap unary operators, same expressions as the generic table (gun_inline, de_grad_common.h)
@@ -177,13 +189,13 @@ template <typename T> __device__ __noinline__ GState<T> r_gen_apply(GState<T> st
     rpoison<T>(st.gpoison, gb);
     return st;
 }
-template <typename T, int SRC> __device__ __noinline__ GState<T> f_gen(RHARGS) {
+template <typename T, int SRC> __device__ __forceinline__ GState<T> f_gen(RHARGS) {
     const uint32_t gop = (SRC == RS_CONST || SRC == RS_ACC) ? (la >> 24) : ((uint32_t)imm >> 24);
     const T b = roperand<T, SRC>(st, la, imm);
     return r_gen_apply<T>(st, gop, b, rprow<T, SRC>(st, la, imm));
 }
 // acc = op3(slot B, slot C, acc): la = partial rows (3) | op << 24, imm = row index B | row index C << 16
-template <typename T> __device__ __noinline__ GState<T> f_tern(RHARGS) {
+template <typename T> __device__ __forceinline__ GState<T> f_tern(RHARGS) {
     const uint32_t lb = st.lds0 + ((uint32_t)imm & 0xFFFFu) * rrow_bytes<T>(), lc = st.lds0 + (((uint32_t)imm >> 16) & 0xFFFFu) * rrow_bytes<T>();
     const uint32_t pr = la & 0xFFFFFFu;
     const TG<T> r = ternary_vg<T>(la >> 24, *RLDS(T, lb), *RLDS(T, lc), st.x);
@@ -216,24 +228,24 @@ template <typename T> __device__ __forceinline__ void r_reduce(GState<T> &st, T 
     // staged in LDS and written once per batch of trees by the interpreter loop
     if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 63u) *RLDS(T, st.stage + (colw & 0xFFFFu) * (uint32_t)sizeof(T)) = s;
 }
-template <typename T> __device__ __noinline__ GState<T> r_un(RHARGS) { // also: binary with an untracked leaf operand
+template <typename T> __device__ __forceinline__ GState<T> r_un(RHARGS) { // also: binary with an untracked leaf operand
     st.x = st.x * *RLDS(T, la);
     return st;
 }
-template <typename T> __device__ __noinline__ GState<T> r_neg(RHARGS) {
+template <typename T> __device__ __forceinline__ GState<T> r_neg(RHARGS) {
     st.x = -st.x;
     return st;
 }
-template <typename T> __device__ __noinline__ GState<T> r_pop(RHARGS) { // reverse of PUSH: continue with the slot's adjoint
+template <typename T> __device__ __forceinline__ GState<T> r_pop(RHARGS) { // reverse of PUSH: continue with the slot's adjoint
     st.x = *RLDS(T, la);
     return st;
 }
-template <typename T> __device__ __noinline__ GState<T> r_leaf(RHARGS) { // reverse of a LOAD of a tracked leaf
+template <typename T> __device__ __forceinline__ GState<T> r_leaf(RHARGS) { // reverse of a LOAD of a tracked leaf
     r_reduce<T>(st, st.x, (uint32_t)imm);
     return st;
 }
 // PK: 0 partial rows at la, 1 ADD, 2 SUB (acc - b), 3 RSUB (b - acc).  OK: 0 slot (imm = byte offset), 1 column (imm)
-template <typename T, int PK, int OK> __device__ __noinline__ GState<T> r_bin(RHARGS) {
+template <typename T, int PK, int OK> __device__ __forceinline__ GState<T> r_bin(RHARGS) {
     T ab, aa;
     if constexpr (PK == 0) { aa = st.x * *RLDS(T, la); ab = st.x * *RLDS(T, la + rrow_bytes<T>()); }
     else if constexpr (PK == 1) { aa = st.x; ab = st.x; }
@@ -244,7 +256,7 @@ template <typename T, int PK, int OK> __device__ __noinline__ GState<T> r_bin(RH
     st.x = aa;
     return st;
 }
-template <typename T> __device__ __noinline__ GState<T> r_tern(RHARGS) {
+template <typename T> __device__ __forceinline__ GState<T> r_tern(RHARGS) {
     const uint32_t lb = st.lds0 + ((uint32_t)imm & 0xFFFFu) * rrow_bytes<T>(), lc = st.lds0 + (((uint32_t)imm >> 16) & 0xFFFFu) * rrow_bytes<T>();
     const uint32_t pr = la & 0xFFFFFFu;
     *RLDS(T, lb) = st.x * *RLDS(T, pr);
@@ -253,32 +265,39 @@ template <typename T> __device__ __noinline__ GState<T> r_tern(RHARGS) {
     return st;
 }
 
+template <typename T, RBodyFn<T> BODY> __device__ __noinline__ GState<T> rh_chain(RCHAIN_ARGS) {
+    const U32x4 w = *code;
+    st = BODY(st, st.lds0 + la, imm);
+    RCHAIN_NEXT(w);
+}
+template <typename T> __device__ __noinline__ GState<T> r_end(GState<T> st, ConstU4Ptr, uint32_t, typename RImm<T>::type, uint64_t) { return st; }
+
 template <typename T> __global__ void de_rev_fill_handlers(uint64_t *t) {
-    for (int i = 0; i < (int)ROP_COUNT; i++) t[i] = (uint64_t)&r_nop<T>;
-    t[rop_load(RS_LEAF)] = (uint64_t)&f_load<T, RS_LEAF>;
-    t[rop_load(RS_SLOT)] = (uint64_t)&f_load<T, RS_SLOT>;
-    t[rop_load(RS_CONST)] = (uint64_t)&f_load<T, RS_CONST>;
-    t[ROP_PUSH] = (uint64_t)&f_push<T>;
-    t[ROP_CHECK] = (uint64_t)&f_check<T>;
-#define RB2(K, S) t[rop_bin(K, S, false)] = (uint64_t)&f_bin<T, K, S, false>; t[rop_bin(K, S, true)] = (uint64_t)&f_bin<T, K, S, true>;
+    for (int i = 0; i < (int)ROP_COUNT; i++) t[i] = RH(r_nop<T>);
+    t[rop_load(RS_LEAF)] = RH(f_load<T, RS_LEAF>);
+    t[rop_load(RS_SLOT)] = RH(f_load<T, RS_SLOT>);
+    t[rop_load(RS_CONST)] = RH(f_load<T, RS_CONST>);
+    t[ROP_PUSH] = RH(f_push<T>);
+    t[ROP_CHECK] = RH(f_check<T>);
+#define RB2(K, S) t[rop_bin(K, S, false)] = RH(f_bin<T, K, S, false>); t[rop_bin(K, S, true)] = RH(f_bin<T, K, S, true>);
 #define RB1(K) RB2(K, RS_LEAF) RB2(K, RS_SLOT) RB2(K, RS_CONST)
     RB1(0) RB1(1) RB1(2) RB1(3) RB1(4) RB1(5) RB1(6) RB1(7)
-#define RU2(K, S) t[rop_un(K, S, false)] = (uint64_t)&f_un<T, K, S, false>; t[rop_un(K, S, true)] = (uint64_t)&f_un<T, K, S, true>;
+#define RU2(K, S) t[rop_un(K, S, false)] = RH(f_un<T, K, S, false>); t[rop_un(K, S, true)] = RH(f_un<T, K, S, true>);
 #define RU1(K) RU2(K, RS_ACC) RU2(K, RS_LEAF)
     RU1(0) RU1(1) RU1(2) RU1(3) RU1(4) RU1(5) RU1(6) RU1(7) RU1(8) RU1(9) RU1(10) RU1(11) RU1(12)
-    t[rop_gen(RS_LEAF)] = (uint64_t)&f_gen<T, RS_LEAF>;
-    t[rop_gen(RS_SLOT)] = (uint64_t)&f_gen<T, RS_SLOT>;
-    t[rop_gen(RS_CONST)] = (uint64_t)&f_gen<T, RS_CONST>;
-    t[rop_gen(RS_ACC)] = (uint64_t)&f_gen<T, RS_ACC>;
-    t[ROP_TERN] = (uint64_t)&f_tern<T>;
-    t[ROP_PARAM] = (uint64_t)&r_nop<T>; // parameter operands are resolved in the interpreter loop
-    t[ROP_R_UN] = (uint64_t)&r_un<T>;
-    t[ROP_R_NEG] = (uint64_t)&r_neg<T>;
-    t[ROP_R_POP] = (uint64_t)&r_pop<T>;
-    t[ROP_R_LEAF] = (uint64_t)&r_leaf<T>;
-#define RR(PK) t[rop_rbin(PK, 0)] = (uint64_t)&r_bin<T, PK, 0>; t[rop_rbin(PK, 1)] = (uint64_t)&r_bin<T, PK, 1>;
+    t[rop_gen(RS_LEAF)] = RH(f_gen<T, RS_LEAF>);
+    t[rop_gen(RS_SLOT)] = RH(f_gen<T, RS_SLOT>);
+    t[rop_gen(RS_CONST)] = RH(f_gen<T, RS_CONST>);
+    t[rop_gen(RS_ACC)] = RH(f_gen<T, RS_ACC>);
+    t[ROP_TERN] = RH(f_tern<T>);
+    t[ROP_PARAM] = (uint64_t)&r_end<T>; // the end record of either sweep (the id is a leftover of round 1's parameter handler)
+    t[ROP_R_UN] = RH(r_un<T>);
+    t[ROP_R_NEG] = RH(r_neg<T>);
+    t[ROP_R_POP] = RH(r_pop<T>);
+    t[ROP_R_LEAF] = RH(r_leaf<T>);
+#define RR(PK) t[rop_rbin(PK, 0)] = RH(r_bin<T, PK, 0>); t[rop_rbin(PK, 1)] = RH(r_bin<T, PK, 1>);
     RR(0) RR(1) RR(2) RR(3)
-    t[ROP_R_TERN] = (uint64_t)&r_tern<T>;
+    t[ROP_R_TERN] = RH(r_tern<T>);
 }
 
 // One sample per lane; wave-major LDS: per wave rows [0,F) = its slice of the X tile, [F, F+n_slots) spill slots
@@ -360,15 +379,11 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
         staged += nc;
         int pc = code_off[tree];
         const int pm = code_mid[tree], pe = code_off[tree + 1];
-        U32x4 nxt = code[pc];
-        for (; pc < pm; ++pc) { // forward sweep
-            const U32x4 w = nxt;
-            nxt = code[pc + 1];
-            const RHandlerFn<T> fn = reinterpret_cast<RHandlerFn<T>>(hbase + w.x);
-            typename RImm<T>::type imm;
-            if constexpr (sizeof(T) == 4) imm = w.z;
-            else imm = ((uint64_t)w.w << 32) | w.z;
-            st = fn(st, st.lds0 + w.y, imm);
+        (void)pe;
+        {   // forward sweep: one chain, ending in the end record in front of code[pm]
+            const ConstU4Ptr rec = code + pc;
+            const U32x4 hd = *rec;
+            st = reinterpret_cast<RHandlerFn<T>>(hbase + hd.x)(st, rec + 1, hd.y, rrec_imm<T>(hd), hbase);
         }
         rpoison<T>(st.vpoison, st.x);
         { // loss term and the seed of the backward sweep
@@ -383,14 +398,10 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
             st.lp = lp;
             st.x = T(1);
         }
-        for (; pc < pe; ++pc) { // backward sweep (instructions stored in execution order)
-            const U32x4 w = nxt;
-            nxt = code[pc + 1];
-            const RHandlerFn<T> fn = reinterpret_cast<RHandlerFn<T>>(hbase + w.x);
-            typename RImm<T>::type imm;
-            if constexpr (sizeof(T) == 4) imm = w.z;
-            else imm = ((uint64_t)w.w << 32) | w.z;
-            st = fn(st, st.lds0 + w.y, imm);
+        {   // backward sweep (instructions stored in execution order), ending in the tree's last record
+            const ConstU4Ptr rec = code + pm;
+            const U32x4 hd = *rec;
+            st = reinterpret_cast<RHandlerFn<T>>(hbase + hd.x)(st, rec + 1, hd.y, rrec_imm<T>(hd), hbase);
         }
         const bool bad = (st.vpoison != st.vpoison) || (nc > 1 && st.gpoison != st.gpoison);
         if (__ballot(bad) != 0ull) gflag_incomplete(a.ok + tree);
