@@ -2,10 +2,11 @@
 """asmpatch.py OBJECT.o — let the output store of one tree overlap with the evaluation of the next.
 
 The AMDGPU backend opens every non-kernel function with `s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)` (SIInsertWaitcnts: a
-callee cannot know what its caller left in flight).  For the direct-threaded eval handlers (de_kernels.hip: h_chain<...>,
-h_param<...>, h_end<...>) the only vector-memory operation that can be in flight at their entry is the kernel's
-`global_store` of the PREVIOUS tree's result — nothing a handler reads — yet the first handler of every tree waits for its
-write acknowledgement (~1-2 us), once per tree and wavefront.  This pass rewrites that entry wait to
+callee cannot know what its caller left in flight).  For the direct-threaded handlers (de_kernels.hip: h_chain<...>, h_param<...>;
+de_grad_threaded.hip: gh_chain<...>; de_rev_threaded.hip: rh_chain<...>) the only vector-memory operations that can be in
+flight at their entry are the `global_store`s of the PREVIOUS tree's results (h_tree_end / the gradient kernels' epilogues)
+— nothing a handler reads — yet the first handler of every tree would wait for their write acknowledgement (~1-2 us), once
+per tree and wavefront.  This pass rewrites that entry wait to
 `s_waitcnt expcnt(0) lgkmcnt(0)` in those functions only.  Why it is safe:
   * handlers take their inputs in registers and LDS (lgkmcnt is still drained); none consumes a VMEM result it did not
     issue itself, and a handler that does issue loads (h_param) waits for them with counts computed from its own
@@ -17,7 +18,8 @@ write acknowledgement (~1-2 us), once per tree and wavefront.  This pass rewrite
     the generic handlers that call cold_op) restores its callee-saved VGPR with a `scratch_load` right before its tail call
     and relies on the NEXT function's entry wait to complete it; a relaxed successor never touches that register (it has
     no scratch instruction to save it with), so the restore lands harmlessly while it runs, and the chain always ends in
-    h_end — left untouched, full wait — before control returns to the kernel, which does use those registers.
+    an end handler (h_tree_end, g_end, r_end) — left untouched, full wait — before control returns to the kernel, which
+    does use those registers and which assumes, like every caller, that a call has drained the loads issued before it.
 Works on the relocatable gfx950 object (one 32-bit instruction word per function); refuses to touch a function whose first
 instruction is not exactly that wait."""
 import os
@@ -26,7 +28,7 @@ import struct
 import subprocess
 import sys
 
-TARGETS = re.compile(r"^(_ZN2de7h_chainI|_ZN2de7h_paramI)")  # never h_end: the end of every chain keeps the full wait
+TARGETS = re.compile(r"^_ZN2de(7h_chainI|7h_paramI|\d+[gr]tm_\w+?8[gr]h_chainI)")  # never an end handler (h_tree_end, g_end, r_end): the end of every chain keeps the full wait
 VMEM = re.compile(r"^\s*(scratch_|flat_|global_|buffer_|tbuffer_|image_)")
 LLVM = os.environ.get("LLVM", "/opt/rocm/lib/llvm/bin")
 
