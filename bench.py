@@ -183,6 +183,13 @@ def valu_ceiling(pop, n_trees, units, kernel_ms, turbo=False):
         by_op[label] = by_op.get(label, 0.0) + c * h["valu_cycles"] / n_trees
     cycles += n_trees * tab["per_tree_overhead_cycles"]
     per_tree_wave = cycles / n_trees
+    # second figure: what a dispatch really costs in the kernel (tools/exp_dispatch_cost.py, profiles/r2_dispatch_cost_*.json):
+    # expensive handlers run at their VALU cycles, a cheap one (+ - * on a row or a constant: 7-18 cycles) cannot go below the
+    # latency chain of a dispatch (record fetch -> s_setpc -> instruction fetch) shared by the ~5.5 resident waves of a SIMD,
+    # ~30 cycles; a tree costs ~100 cycles beyond its dispatches (first load, end record + store, its share of the X staging)
+    disp_floor, per_tree_meas = 30.0, 100.0
+    modelled = sum(c * max(tab["handlers_turbo" if turbo else "handlers"][str(k)]["valu_cycles"], disp_floor)
+                   for k, c in hist.items() if str(k) in tab["handlers_turbo" if turbo else "handlers"]) / n_trees + per_tree_meas
     samples_per_wave = 256  # 64 lanes x 4 Float32 samples
     tree_waves = units / samples_per_wave
     simds, peak, sustained = 256 * 4, 2.4e9, 2.08e9  # MI355X: 256 CUs x 4 SIMDs; peak engine clock; clock an all-VALU loop sustains
@@ -191,6 +198,10 @@ def valu_ceiling(pop, n_trees, units, kernel_ms, turbo=False):
                 clock_ghz=2.4, simds=simds, floor_ms=floor_ms, frac=floor_ms / kernel_ms,
                 sustained_clock_ghz=2.08, floor_ms_at_sustained_clock=floor_ms * peak / sustained,
                 frac_at_sustained_clock=floor_ms * peak / sustained / kernel_ms, dispatches_without_cycle_count=missing,
+                issue_model=dict(dispatch_floor_cycles=disp_floor, per_tree_cycles=per_tree_meas, simd_cycles_per_tree_wave=modelled,
+                                 ms_at_sustained_clock=tree_waves * modelled / (simds * sustained) * 1e3,
+                                 frac=tree_waves * modelled / (simds * sustained) * 1e3 / kernel_ms,
+                                 source="tools/exp_dispatch_cost.py: slope of kernel time over chain length per handler family"),
                 cycles_by_operator={k: round(v, 1) for k, v in sorted(by_op.items(), key=lambda kv: -kv[1])},
                 source="profiles/valu_slots.json (tools/valu_slots.py: VALU cycles per handler on its shortest path, gfx950 ISA priced with "
                        "the per-instruction issue costs measured by tools/probe/valu_rate.py, profiles/r2_valu_rate.json; sustained clock: "

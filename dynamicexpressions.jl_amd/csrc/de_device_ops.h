@@ -255,6 +255,8 @@ __device__ __forceinline__ void fast_sincos_f32(float x, float *sn, float *cs) {
 // underflow, overflow, Inf) from the ldexp form.  The choice is PER ELEMENT, so every kernel (the packed handlers of the
 // threaded interpreter take the ldexp branch wave-uniformly and select per element) returns the same bits.
 constexpr float DE_EXP_DIRECT_BOUND_T = 125.9f;
+#define DE_LN2_HI 0x1.62e430p-1f  // ln 2 = HI + LO to 2^-50: t * (HI + LO) misses t ln 2 by < 2^-43 for |t| <= 126
+#define DE_LN2_LO -0x1.05c610p-29f
 __device__ __forceinline__ float fast_exp_ldexp_f32(float x) {
     const float xc = __builtin_fminf(__builtin_fmaxf(x, -105.0f), 89.0f);
     const float k = __builtin_rintf(xc * 0x1.715476p+0f);
@@ -267,10 +269,10 @@ __device__ __forceinline__ float fast_exp_ldexp_f32(float x) {
 __device__ __forceinline__ float fast_exp_f32(float x) {
     const float t = x * 0x1.715476p+0f;
     if (__builtin_fabsf(t) > DE_EXP_DIRECT_BOUND_T) return fast_exp_ldexp_f32(x);
-    float e = __builtin_fmaf(x, 0x1.715476p+0f, -t);
-    e = __builtin_fmaf(x, 0x1.4ae0c0p-26f, e);
+    float r = __builtin_fmaf(-t, DE_LN2_HI, x); // x - t ln 2 = (x log2 e - t) ln 2: what 2^t still lacks, in natural units
+    r = __builtin_fmaf(-t, DE_LN2_LO, r);
     const float v = __builtin_amdgcn_exp2f(t);
-    return __builtin_fmaf(v, e * 0x1.62e430p-1f, v); // NaN: t is NaN, the comparison above false, v NaN
+    return __builtin_fmaf(v, r, v); // NaN: t is NaN, the comparison above false, v NaN
 }
 
 // Two elements at a time (v_pk_mul/v_pk_fma for the reduction; exp2/ldexp/rint stay per element).
@@ -328,15 +330,14 @@ template <bool SIN> __device__ __forceinline__ DeF2 turbo_trig_f32x2(DeF2 x, DeF
     y[1] = __uint_as_float((__float_as_uint(kk[1]) << 31) + __float_as_uint(s[1]));
     return y;
 }
-// exp(x) = 2^t * (1 + e ln 2): t = RN(x log2 e) goes to v_exp_f32, e = the rounding error of that product (one FMA)
+// exp(x) = 2^t * (1 + r), r = x - t ln 2: t = RN(x log2 e) goes to v_exp_f32, r is what the rounded product left out
 __device__ __forceinline__ DeF2 turbo_exp_f32x2(DeF2 x, DeF2 t);
 __device__ __forceinline__ DeF2 turbo_exp_f32x2(DeF2 x) { return turbo_exp_f32x2(x, x * DE_F2(0x1.715476p+0f)); }
 __device__ __forceinline__ DeF2 turbo_exp_f32x2(DeF2 x, DeF2 t) { // t = x * float(log2 e)
-    DeF2 e = __builtin_elementwise_fma(x, DE_F2(0x1.715476p+0f), -t);
-    e = __builtin_elementwise_fma(x, DE_F2(0x1.4ae0c0p-26f), e); // log2(e) - float(log2(e)): 1.3e-8 * |x| otherwise (1e-6 at |x| = 88)
+    DeF2 r = __builtin_elementwise_fma(-t, DE_F2(DE_LN2_HI), x); // x - t ln 2 in two FMAs (the first cancels to ~|x| 2^-24: exact)
+    r = __builtin_elementwise_fma(-t, DE_F2(DE_LN2_LO), r);
     const DeF2 v = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-    const DeF2 c = e * DE_F2(0x1.62e430p-1f);
-    return __builtin_elementwise_fma(v, c, v); // overflow: Inf or NaN (both non-finite); exp(-Inf) = NaN, not 0 (e = Inf - Inf)
+    return __builtin_elementwise_fma(v, r, v); // overflow: Inf or NaN (both non-finite); exp(-Inf) = NaN, not 0 (r = Inf - Inf)
 }
 __device__ __forceinline__ DeF2 turbo_div_f32x2(DeF2 n, DeF2 d) {
     const DeF2 y = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
