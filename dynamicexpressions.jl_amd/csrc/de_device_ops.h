@@ -124,9 +124,11 @@ constexpr float DE_TRIG_FAST_BOUND = 1.0e5f;
 constexpr float DE_TRIG_FAST_BOUND_M = 31829.5f; // < rint(1e5/pi + 1/2) = 31830 <= rint(|x|/pi [+ 1/2]) for |x| > 1e5: the wave-uniform pre-test on the multiple of pi
 #define DE_TRIG_INV_PI 0x1.45f306p-2f
 #define DE_TRIG_MAGIC 12582912.0f
-#define DE_TRIG_P1 0x1.921fb6p+1f
-#define DE_TRIG_P2 -0x1.777a5cp-24f
-#define DE_TRIG_P3 -0x1.ee59dap-49f
+// pi rounded DOWN term by term: all three positive, so that for x = -0 every step is (-0) * P + (-0) = -0 — with a negative
+// P2 the second step was (+0) + (-0) = +0 and sin(-0) came out +0 (1 / sin(-0) = -Inf in the reference; tests/fuzz/fuzz_gpu.py 102)
+#define DE_TRIG_P1 0x1.921fb4p+1f
+#define DE_TRIG_P2 0x1.4442d0p-23f
+#define DE_TRIG_P3 0x1.846988p-47f
 #define DE_TRIG_S0 -0x1.55554ap-3f
 #define DE_TRIG_S1 0x1.110ea0p-7f // 3 ulp below the minimax coefficient: the worst case of the Float32 EVALUATION drops from 2.03 to 1.75 ulp (tools/fit/trig_fit.py)
 #define DE_TRIG_S2 -0x1.9f6716p-13f
@@ -152,6 +154,7 @@ template <bool SIN> __device__ __forceinline__ float fast_trig_f32(float x) {
     p = __builtin_fmaf(z, p, DE_TRIG_S1);
     p = __builtin_fmaf(z, p, DE_TRIG_S0);
     float s = __builtin_fmaf(r * z, p, r);
+    if constexpr (SIN) s = __builtin_copysignf(s, r); // sin(-0) = -0: the sum of the -0 argument and its +0 correction term is +0
 #ifndef DE_TRIG_NO_EXTREMUM_FIX
     s = trig_extremum_fix(r, s);
 #endif
@@ -180,6 +183,9 @@ template <bool SIN> __device__ __forceinline__ DeTrig2 fast_trig_core_f32x2(DeF2
     o.r = r;
     o.z = z;
     o.s = __builtin_elementwise_fma(r * z, p, r);
+    // sin(-0) = -0 (IEEE, Julia): r = -0 there, but r + r^3 Q adds a +0 correction to it and the sum of opposite zeros is +0.
+    // |s| <= |r| and their signs agree everywhere else, so copying r's sign (v_bfi_b32) changes nothing but that zero.
+    if constexpr (SIN) { o.s[0] = __builtin_copysignf(o.s[0], r[0]); o.s[1] = __builtin_copysignf(o.s[1], r[1]); }
     return o;
 }
 __device__ __forceinline__ DeF2 fast_trig_sign_f32x2(DeF2 s, DeF2 kk) {
@@ -245,7 +251,8 @@ __device__ __forceinline__ void fast_sincos_f32(float x, float *sn, float *cs) {
     const bool odd = q & 1;
     const unsigned ssign = ((unsigned)q << 30) & 0x80000000u;                 // sin: negative in quadrants 2,3
     const unsigned csign = (((unsigned)q << 30) + 0x40000000u) & 0x80000000u; // cos: negative in quadrants 1,2
-    *sn = __uint_as_float(__float_as_uint(odd ? c : s) ^ ssign);
+    const float sn_ = __uint_as_float(__float_as_uint(odd ? c : s) ^ ssign);
+    *sn = x == 0.0f ? x : sn_; // sin(-0) = -0: the reduction (k = -0: +0 * P + -0) and r + r^3 Q both turn the zero positive
     *cs = __uint_as_float(__float_as_uint(odd ? s : c) ^ csign);
 }
 // exp(x) = 2^(x*log2(e)).  ldexp form: k = rint(x*L), r = x*L - k in two FMAs (hi/lo split of L), hardware v_exp_f32 on
@@ -323,7 +330,8 @@ template <bool SIN> __device__ __forceinline__ DeF2 turbo_trig_f32x2(DeF2 x, DeF
     DeF2 p = __builtin_elementwise_fma(z, DE_F2(DE_TURBO_S3), DE_F2(DE_TURBO_S2));
     p = __builtin_elementwise_fma(z, p, DE_F2(DE_TURBO_S1));
     p = __builtin_elementwise_fma(z, p, DE_F2(DE_TURBO_S0));
-    const DeF2 s = __builtin_elementwise_fma(r * z, p, r);
+    DeF2 s = __builtin_elementwise_fma(r * z, p, r);
+    if constexpr (SIN) { s[0] = __builtin_copysignf(s[0], r[0]); s[1] = __builtin_copysignf(s[1], r[1]); } // sin(-0) = -0, as in the exact mode
     // (-1)^n: the low mantissa bit of the magic sum is the parity of n; adding it at bit 31 flips the sign (v_lshl_add_u32)
     DeF2 y;
     y[0] = __uint_as_float((__float_as_uint(kk[0]) << 31) + __float_as_uint(s[0]));

@@ -63,6 +63,31 @@ def test_fast_trig_within_two_ulp_up_to_1e5(api, name, f64):
     np.testing.assert_array_equal(out2, out)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sin_keeps_the_sign_of_zero(api, dtype):
+    """sin(-0) = -0 (IEEE; Julia): visible through 1 / sin(neg(relu(x))) = -Inf (found by tests/fuzz/fuzz_gpu.py 102: the
+    Float32 fast path added a +0 correction term to the -0 argument).  Eval (packed and turbo handlers), the value output of
+    the gradient kernels (their sincos), and a wave that mixes zeros with ordinary arguments."""
+    ops = de.OperatorEnum(binary_operators=("/",), unary_operators=("sin", "cos"))
+    x = np.array([-0.0, 0.0, 1.5, -1.5, -0.0, 1e-45, -1e-45, 3.0] * 40, dtype=dtype)
+    X = np.asfortranarray(x[None, :])
+    want = np.sin(x)
+    tree = de.Node(1, de.Node(feature=1))
+    for ec in (api.EvalContext(), api.EvalContext(turbo=True), api.EvalContext(early_exit=False)):
+        out, ok = api.eval_tree_array(tree, X, ops, eval_context=ec)
+        assert ok
+        np.testing.assert_array_equal(np.signbit(out), np.signbit(want))
+        np.testing.assert_array_equal(out[x == 0], x[x == 0])
+    # 1 / sin(-0) = -Inf, 1 / sin(+0) = +Inf
+    inv = de.Node(1, de.Node(val=1.0), tree)
+    o, _ = api.eval_tree_array(inv, X, ops, eval_context=api.EvalContext(early_exit=False))
+    assert np.all(np.isneginf(o[(x == 0) & np.signbit(x)])) and np.all(np.isposinf(o[(x == 0) & ~np.signbit(x)]))
+    og, grad, okg = api.eval_grad_tree_array(tree, X, ops, variable=True)
+    assert okg
+    np.testing.assert_array_equal(np.signbit(og), np.signbit(want))
+    np.testing.assert_array_equal(grad[0][x == 0], np.ones(int((x == 0).sum()), dtype=dtype))  # cos(+-0) = 1
+
+
 @pytest.mark.parametrize("name,f64", [("cos", np.cos), ("sin", np.sin)])
 def test_trig_beyond_fast_range_uses_full_range_reduction(api, name, f64):
     ops = de.OperatorEnum(binary_operators=("+",), unary_operators=(name,))

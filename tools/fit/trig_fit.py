@@ -67,7 +67,7 @@ def emulate(x, S, sin=False, terms=3):
     x = f32(x)
     INV_PI = np.float32(float.fromhex('0x1.45f306p-2'))
     MAGIC = np.float32(12582912.0)
-    P = [np.float32(float.fromhex(h)) for h in ('0x1.921fb6p+1', '-0x1.777a5cp-24', '-0x1.ee59dap-49')]
+    P = [np.float32(float.fromhex(h)) for h in ('0x1.921fb4p+1', '0x1.4442d0p-23', '0x1.846988p-47')]  # pi rounded DOWN term by term: all positive (sign of zero)
     t = f32(x * INV_PI) if sin else fma32(x, np.full_like(x, INV_PI), np.full_like(x, np.float32(0.5)))
     kk = f32(t + MAGIC)
     n = f32(kk - MAGIC)
