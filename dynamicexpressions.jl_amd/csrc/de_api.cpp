@@ -487,29 +487,38 @@ static int make_threaded(de_ctx *c, de_program *p) {
     return DE_OK;
 }
 
-// The device layout of the threaded program (see de_kernels.hip): one record per instruction {operand word, immediate,
-// address of ITS handler} and an end record per tree (h_tree_end, operand word = tree index); tree t + 1 follows tree t
-// directly — a chunk of consecutive trees is ONE chain.  BoundInstr fields by word: Float32 {bop: operand word,
-// arg: imm, lo/hi: handler}; Float64 {bop: operand word, arg: handler.lo, lo/hi: imm}.
+// The device layout of the threaded program (see de_kernels.hip): one head record, then per tree one record per instruction
+// and an end record.  A record = {its operand word, its immediate, the address of the NEXT record's handler}: the head record
+// names the first handler of tree 0, a tree's last instruction names h_tree_end (whose operand word is the tree's index), an
+// end record names the first handler of the next tree — a chunk of consecutive trees is ONE chain and a handler knows where
+// to jump before the record it has to fetch arrives.  BoundInstr fields by word: Float32 {bop: operand word, arg: imm, lo/hi:
+// next handler}; Float64 {bop: operand word, arg: next handler (low half), lo/hi: imm}.
 static void make_chained(de_program *p) {
     const bool f32 = p->dtype == DE_F32;
-    p->ccode.assign(p->tcode.size() + (size_t)p->n_trees, BoundInstr{0u, 0u, 0u, 0u});
+    p->ccode.assign(p->tcode.size() + (size_t)p->n_trees + 1, BoundInstr{0u, 0u, 0u, 0u});
     p->ccode_off.assign((size_t)p->n_trees + 1, 0);
-    auto put = [&](BoundInstr &r, uint32_t la, uint32_t lo, uint32_t hi, uint64_t handler) {
+    auto put = [&](BoundInstr &r, uint32_t la, uint32_t lo, uint32_t hi) { // operand words; the handler word is set by the predecessor
         r.bop = la;
-        if (f32) { r.arg = lo; r.lo = (uint32_t)handler; r.hi = (uint32_t)(handler >> 32); }
-        else { r.arg = (uint32_t)handler; r.lo = lo; r.hi = hi; }
+        if (f32) r.arg = lo;
+        else { r.lo = lo; r.hi = hi; }
+    };
+    auto name_next = [&](BoundInstr &r, uint64_t handler) {
+        if (f32) { r.lo = (uint32_t)handler; r.hi = (uint32_t)(handler >> 32); }
+        else r.arg = (uint32_t)handler;
     };
     for (int64_t t = 0; t < p->n_trees; t++) {
         const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1];
-        const size_t h = (size_t)i0 + (size_t)t;
+        const size_t h = (size_t)i0 + (size_t)t + 1; // one end record per preceding tree + the head record
         p->ccode_off[(size_t)t] = (int32_t)h;
         for (int32_t i = i0; i < i1; i++) {
             const BoundInstr &s = p->tcode[(size_t)i];
-            put(p->ccode[h + (size_t)(i - i0)], s.arg, s.lo, s.hi, p->handler_base + s.bop);
+            put(p->ccode[h + (size_t)(i - i0)], s.arg, s.lo, s.hi);
+            name_next(p->ccode[h + (size_t)(i - i0) - 1], p->handler_base + s.bop); // in the record in front (head / previous end record / previous instruction)
         }
-        put(p->ccode[h + (size_t)(i1 - i0)], (uint32_t)t, 0u, 0u, p->end_handler); // end record: operand word = the tree's index (h_tree_end)
+        put(p->ccode[h + (size_t)(i1 - i0)], (uint32_t)t, 0u, 0u); // end record: operand word = the tree's index (h_tree_end)
+        name_next(p->ccode[h + (size_t)(i1 - i0) - 1], p->end_handler);
     }
+    if (p->n_trees > 0) name_next(p->ccode.back(), p->end_handler); // never followed: the last tree's end record returns (left == 1)
     p->ccode_off[(size_t)p->n_trees] = (int32_t)p->ccode.size();
 }
 static inline void patch_chained_imm(de_program *p, int32_t c, uint32_t lo, uint32_t hi) {
@@ -769,8 +778,8 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         if (rc != DE_OK) return rc;
     }
     // one trailing pad instruction: the flat-switch interpreter prefetches code[pc + 1]; the chained form of the
-    // threaded kernel has one header record per tree (and the fused form is never longer than the bound one)
-    const size_t cbytes = (p->bcode.size() + (size_t)p->n_trees + 1) * sizeof(BoundInstr);
+    // threaded kernel has one end record per tree and a head record (and the fused form is never longer than the bound one)
+    const size_t cbytes = (p->bcode.size() + (size_t)p->n_trees + 2) * sizeof(BoundInstr); // + head record + one of padding
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->d_code), cbytes));
     HIP_TRY(ctx, hipMemset(p->d_code, 0, cbytes));
     hipError_t st = hipMalloc(reinterpret_cast<void **>(&p->d_code_off), p->bcode_off.size() * sizeof(int32_t));
@@ -849,10 +858,10 @@ static int set_consts_impl(de_program_t *p, const void *consts) {
             p->grad_sites.clear();
             for (size_t i = 0; i < src.size(); i++)
                 if (p->bsite[i] >= 0) {
-                    // record of tcode[j] in the chained stream: one end record per preceding tree
+                    // record of tcode[j] in the chained stream: one end record per preceding tree, behind the head record
                     const int32_t j = p->tsite[i];
                     const int64_t tree = (std::upper_bound(p->tcode_off.begin(), p->tcode_off.end(), j) - p->tcode_off.begin()) - 1;
-                    p->eval_sites.push_back({(int32_t)i, p->bsite[i], j, (int32_t)(j + tree)});
+                    p->eval_sites.push_back({(int32_t)i, p->bsite[i], j, (int32_t)(j + tree + 1)}); // + the head record
                 }
             if (!p->gbsite.empty())
                 for (size_t i = 0; i < p->code.size(); i++) {
@@ -1019,14 +1028,15 @@ int de_program_verify(const de_program_t *p) {
         std::vector<uint64_t> valid(table, table + TOPX_TABLE);
         std::sort(valid.begin(), valid.end());
         const uint64_t lds_bytes = (uint64_t)(rows + (p->uses_params ? 2 : 0)) * TROW_BYTES;
-        if ((int64_t)p->ccode_off.size() != p->n_trees + 1 || p->ccode.size() != p->tcode.size() + (size_t)p->n_trees) return bad("chained layout", -1, 0, p->ccode.size());
+        if ((int64_t)p->ccode_off.size() != p->n_trees + 1 || p->ccode.size() != p->tcode.size() + (size_t)p->n_trees + 1) return bad("chained layout", -1, 0, p->ccode.size());
         const bool f32 = p->dtype == DE_F32;
         for (int64_t t = 0; t < p->n_trees; t++) {
             const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1], h = p->ccode_off[(size_t)t];
-            if (h != i0 + (int32_t)t) return bad("chained offset", t, h, (uint64_t)i0);
+            if (h != i0 + (int32_t)t + 1) return bad("chained offset", t, h, (uint64_t)i0);
             for (int32_t i = i0; i <= i1; i++) {
                 const BoundInstr &r = p->ccode[(size_t)(h + (i - i0))];
-                const uint64_t addr = f32 ? (((uint64_t)r.hi << 32) | r.lo) : ((table[0] & 0xFFFFFFFF00000000ull) | r.arg);
+                const BoundInstr &q = p->ccode[(size_t)(h + (i - i0) - 1)]; // a record's handler is named by the record in front of it
+                const uint64_t addr = f32 ? (((uint64_t)q.hi << 32) | q.lo) : ((table[0] & 0xFFFFFFFF00000000ull) | q.arg);
                 if (!std::binary_search(valid.begin(), valid.end(), addr)) return bad("handler address not in the device table", t, i - i0, addr);
                 if (i == i1) {
                     if (addr != p->end_handler) return bad("tree does not end in the end record", t, i - i0, addr);

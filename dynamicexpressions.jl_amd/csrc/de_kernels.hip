@@ -495,45 +495,48 @@ template <> __device__ __forceinline__ double imm_from<double>(uint64_t b) { ret
 template <typename T> using BodyFn = HState<T> (*)(HState<T>, uint32_t, typename ImmBits<T>::type);
 // ---- direct-threaded dispatch ------------------------------------------------------------------------------------
 // The interpreter has no central loop: every handler ends with a tail call (s_setpc_b64) to the handler of the next
-// instruction.  The stream holds one 16-byte record per instruction, plus an end record per tree:
-//   Float32 record  { la, imm, handler.lo, handler.hi }     la = LDS byte offset of the operand row | aux << 24
-//   Float64 record  { la, handler.lo, imm.lo, imm.hi }      (handler.hi = the high half of the current pc: all handlers
-//                                                            of a code object lie in one 4 GiB window, checked on the host)
-// and it is SOFTWARE-PIPELINED: a handler receives its own operand words (la, imm) in SGPRs from its predecessor and, as
-// its first instruction, loads the NEXT record (s_load_dwordx4) — the scalar-cache latency overlaps with its own LDS
-// read and arithmetic instead of preceding them — then tail-calls the next handler with that record's operand words.
-// The end record names h_end, which returns to the kernel.  Stream pointer and operand words travel in SGPRs
-// (csrc/irpatch.py marks those parameters `inreg` in the optimised IR: clang has no source spelling for it on a device
-// function), so a dispatch is
-//   s_load_dwordx4 ; s_add_u32 ; s_addc_u32 ; ... body ... ; s_waitcnt ; 2-3 s_mov ; s_setpc_b64      + 1 VALU (LDS address)
-// against 11 scalar + 1 scalar load + 2 VALU for the call/return loop it replaces (prefetch copy, handler address
-// arithmetic, loop counter and branch, s_swappc/s_setpc pair).
+// instruction.  The stream holds one 16-byte record per instruction, plus an end record per tree and one head record in
+// front of the first tree; a record carries its own operand words and the address of the NEXT record's handler:
+//   Float32 record  { la, imm, next.lo, next.hi }     la = LDS byte offset of the operand row | aux << 24
+//   Float64 record  { la, next.lo, imm.lo, imm.hi }   (next.hi = the high half of the current pc: all handlers of a code
+//                                                      object lie in one 4 GiB window, checked on the host)
+// and it is SOFTWARE-PIPELINED: a handler receives its record's words in SGPRs from its predecessor and, as its first
+// instruction, loads the NEXT record (s_load_dwordx4) — the scalar-cache latency overlaps with its own LDS read and
+// arithmetic — then tail-calls the next handler, whose address it has known since entry, WITHOUT waiting for that load: the
+// record's words travel to the callee still in flight (they are loaded straight into the argument registers) and the
+// callee's entry wait completes them, so the instruction fetch of the jump overlaps with the tail of the load as well.
+// (Before, the jump target came out of the load itself: every tiny handler sat out the whole scalar-cache latency before it
+// could jump, §4.3 of DESIGN.md.)  The end record's handler is h_tree_end; its `next` is the first handler of the next tree.
+// Stream pointer and operand words travel in SGPRs (csrc/irpatch.py marks those parameters `inreg` in the optimised IR:
+// clang has no source spelling for it on a device function); the argument order puts the record's four words in an aligned
+// SGPR quad (s[4:7]) so that the load can target them.
 // Behind the operand words every handler hands on five more wave-uniform words untouched (they stay in their SGPRs from
 // the kernel's call to the last handler of the chunk): what h_tree_end needs to finish a tree WITHOUT returning to the kernel.
 //   outp  : address of out[0, first sample of this tile] minus the LDS base (so that outp + tree * ldo + lds0 is this lane's vector)
 //   okp   : the completion flags;   ldo : bytes between two trees' output rows;   left : trees of this chunk still to run
 //   flags : HF_* | samples of the tile inside N (slow store)
-template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, ConstU4Ptr, uint32_t, typename ImmBits<T>::type, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t);
+// argument words of a handler: (la, w1, w23) = the record as loaded { x, y, z:w }
+//   Float32: w1 = imm, w23 = next handler      Float64: w1 = next handler (low half), w23 = imm
+template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t);
 enum : uint32_t { HF_RETURN_EACH = 1u << 31, HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu };
-template <typename T> __device__ __forceinline__ HandlerFn<T> rec_handler(const U32x4 &w);
-template <> __device__ __forceinline__ HandlerFn<float> rec_handler<float>(const U32x4 &w) {
-    return reinterpret_cast<HandlerFn<float>>(((uint64_t)w.w << 32) | w.z);
+template <typename T> __device__ __forceinline__ HandlerFn<T> arg_next(uint32_t w1, uint64_t w23);
+template <> __device__ __forceinline__ HandlerFn<float> arg_next<float>(uint32_t, uint64_t w23) { return reinterpret_cast<HandlerFn<float>>(w23); }
+template <> __device__ __forceinline__ HandlerFn<double> arg_next<double>(uint32_t w1, uint64_t) {
+    return reinterpret_cast<HandlerFn<double>>((__builtin_amdgcn_s_getpc() & 0xFFFFFFFF00000000ull) | w1);
 }
-template <> __device__ __forceinline__ HandlerFn<double> rec_handler<double>(const U32x4 &w) {
-    return reinterpret_cast<HandlerFn<double>>((__builtin_amdgcn_s_getpc() & 0xFFFFFFFF00000000ull) | w.y);
-}
-template <typename T> __device__ __forceinline__ typename ImmBits<T>::type rec_imm(const U32x4 &w);
-template <> __device__ __forceinline__ uint32_t rec_imm<float>(const U32x4 &w) { return w.y; }
-template <> __device__ __forceinline__ uint64_t rec_imm<double>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
+template <typename T> __device__ __forceinline__ typename ImmBits<T>::type arg_imm(uint32_t w1, uint64_t w23);
+template <> __device__ __forceinline__ uint32_t arg_imm<float>(uint32_t w1, uint64_t) { return w1; }
+template <> __device__ __forceinline__ uint64_t arg_imm<double>(uint32_t, uint64_t w23) { return w23; }
 #define DE_ROW_BYTES_C ((DE_TBLK + 1) * 16) // LDS row stride of the threaded kernel: DE_TBLK 16-byte vectors + one of padding
-// `code` points at the record of the NEXT instruction; (la, imm) are this instruction's operand words
-#define HCHAIN_ARGS HState<T> st, uint32_t lds0, ConstU4Ptr code, uint32_t la, typename ImmBits<T>::type imm, uint64_t outp, uint64_t okp, uint64_t ldo, uint32_t left, uint32_t flags
-#define HCHAIN_NEXT(W) [[clang::musttail]] return rec_handler<T>(W)(st, lds0, code + 1, (W).x, rec_imm<T>(W), outp, okp, ldo, left, flags)
+// `code` points at the record of the NEXT instruction; (la, w1, w23) are this instruction's record
+#define HCHAIN_ARGS HState<T> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint32_t left, uint32_t flags
+#define HCHAIN_NEXT(W) [[clang::musttail]] return arg_next<T>(w1, w23)(st, lds0, code + 1, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, left, flags)
 template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain(HCHAIN_ARGS) {
     const U32x4 w = *code;
-    st = BODY(st, lds0 + la, imm); // la = row byte offset | aux << 24 (no carry: LDS < 2^18 bytes)
+    st = BODY(st, lds0 + la, arg_imm<T>(w1, w23)); // la = row byte offset | aux << 24 (no carry: LDS < 2^18 bytes)
     HCHAIN_NEXT(w);
 }
+
 __device__ __forceinline__ void hpoison_impl(PoisonOf<float>::type &poison, const VecOf<float>::type &v) {
     typedef PoisonOf<float>::type P2;
     const P2 z = {0.0f, 0.0f};
@@ -840,7 +843,7 @@ template <typename T, bool TB> __device__ __noinline__ HState<T> h_param(HCHAIN_
     constexpr int VW = VecOf<T>::W;
     const U32x4 w = *code;
     const uint32_t op = la >> 24;
-    const uint32_t crow = lds0 + (uint32_t)imm;
+    const uint32_t crow = lds0 + (uint32_t)arg_imm<T>(w1, w23);
     const U32x4 cv = *reinterpret_cast<__attribute__((address_space(3))) U32x4 *>((uintptr_t)crow);
     uint64_t tab;
     if constexpr (sizeof(T) == 4) {
@@ -1029,8 +1032,9 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         const int64_t in_tile = a.N - base < (int64_t)TILE ? a.N - base : (int64_t)TILE;
         const uint32_t flags = a.vec_store == 2 ? HF_NO_STORE : ((full && a.vec_store) ? 0u : (HF_SLOW_STORE | (uint32_t)in_tile));
         const uint64_t outp = (uint64_t)(uintptr_t)(a.out + base) - (uint64_t)(uint32_t)(uintptr_t)smem_raw;
-        const U32x4 hd = *rec;
-        st = rec_handler<T>(hd)(st, lds0, rec + 1, hd.x, rec_imm<T>(hd), outp, (uint64_t)(uintptr_t)a.ok, ldo, (uint32_t)(t1 - t0), flags);
+        const U32x4 hp = rec[-1], hd = *rec; // the first handler's address is in the record in front (the previous tree's end record / the head record)
+        st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, lds0, rec + 1, outp, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, (uint64_t)(uintptr_t)a.ok,
+                                                              ldo, (uint32_t)(t1 - t0), flags);
         (void)st;
     } else {
         for (int tree = t0; tree < t1; ++tree) {
@@ -1039,8 +1043,9 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             HState<T> st;
             DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
             st.poison = typename PoisonOf<T>::type{};
-            const U32x4 hd = *rec;
-            st = rec_handler<T>(hd)(st, lds0, rec + 1, hd.x, rec_imm<T>(hd), 0ull, 0ull, 0ull, 1u, (uint32_t)HF_RETURN_EACH);
+            const U32x4 hp = rec[-1], hd = *rec;
+            st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, lds0, rec + 1, 0ull, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, 0ull, 0ull, 1u,
+                                                                  (uint32_t)HF_RETURN_EACH);
             // sum_j w_j * l(out_j - y_j) over this wave's 64*VW samples -> one partial per (tile, tree, wave)
             T s = T(0);
             DE_UNROLL for (int i = 0; i < VW; i++) {
