@@ -14,7 +14,8 @@ per tree and wavefront.  This pass rewrites that entry wait to
     let it pass early;
   * gfx9 VMEM stores read their data registers when they issue, so overwriting those registers afterwards is fine;
   * the kernel itself waits for vmcnt(0) before it ends (s_endpgm drains stores).
-  * ONLY handlers that contain no vector-memory instruction at all are relaxed.  A handler with a stack frame (h_param,
+  * ONLY handlers that contain no vector-memory instruction at all are relaxed — plus the eval kernel's h_tree_end, which
+    only STORES (checked: no vector load, and a vmcnt(0) wait in front of every return to the kernel; end_handler_is_safe).  A handler with a stack frame (h_param,
     the generic handlers that call cold_op) restores its callee-saved VGPR with a `scratch_load` right before its tail call
     and relies on the NEXT function's entry wait to complete it; a relaxed successor never touches that register (it has
     no scratch instruction to save it with), so the restore lands harmlessly while it runs, and the chain always ends in
@@ -28,7 +29,7 @@ import struct
 import subprocess
 import sys
 
-TARGETS = re.compile(r"^_ZN2de(7h_chainI|7h_paramI|\d+[gr]tm_\w+?8[gr]h_chainI)")  # never an end handler (h_tree_end, g_end, r_end): the end of every chain keeps the full wait
+TARGETS = re.compile(r"^_ZN2de(7h_chainI|7h_paramI|10h_tree_endI|\d+[gr]tm_\w+?8[gr]h_chainI)")  # never an end handler (h_tree_end, g_end, r_end): the end of every chain keeps the full wait
 VMEM = re.compile(r"^\s*(scratch_|flat_|global_|buffer_|tbuffer_|image_)")
 LLVM = os.environ.get("LLVM", "/opt/rocm/lib/llvm/bin")
 
@@ -48,6 +49,28 @@ def vmem_free_functions(path):
     if name and clean:
         ok.add(name)
     return ok
+END = re.compile(r"^_ZN2de10h_tree_endI")  # the eval kernel's end-of-tree handler: stores, reads nothing back
+
+
+def end_handler_is_safe(path, name):
+    """h_tree_end issues the tree's output store itself, so it is not VMEM-free — but its entry wait only makes it wait for
+    the PREVIOUS tree's store.  It may be relaxed too if it never reads vector memory (only stores) and every return to the
+    kernel (s_setpc_b64 s[30:31]) is preceded by a wait for vmcnt(0): the guarantee the callers of a chain rely on."""
+    dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", path], check=True, capture_output=True, text=True).stdout
+    body, on = [], False
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+        if m:
+            on = m.group(1) == name
+            continue
+        if on and "//" in line:
+            body.append(line.split("//")[0].strip())
+    if not body or any(re.match(r"(scratch_|flat_|buffer_|tbuffer_|image_|global_load|global_atomic)", i) for i in body):
+        return False
+    rets = [k for k, i in enumerate(body) if i.startswith("s_setpc_b64 s[30:31]")]
+    return bool(rets) and all(k > 0 and body[k - 1].startswith("s_waitcnt") and "vmcnt(0)" in body[k - 1] for k in rets)
+
+
 ENTRY_WAIT = 0xBF8C0000      # s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)
 RELAXED_WAIT = 0xBF8CC00F    # s_waitcnt expcnt(0) lgkmcnt(0)    (gfx9 simm16: vmcnt = [15:14]:[3:0] = 63 = no wait)
 
@@ -75,7 +98,7 @@ def main(path):
         name = blob[strtab["off"] + st_name:end].decode()
         if not TARGETS.match(name):
             continue
-        if name not in leaf:
+        if name not in leaf and not (END.match(name) and end_handler_is_safe(path, name)):
             skipped += 1
             continue
         sec = secs[st_shndx]

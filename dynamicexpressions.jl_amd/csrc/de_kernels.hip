@@ -559,29 +559,40 @@ __device__ __forceinline__ bool poison_set(const double &p) { return p != p; }
 // tools/exp_dispatch_cost.py: returning to a per-tree loop in the kernel (index load, first-record load, two dependent
 // scalar-cache round trips per tree) cost ~250 SIMD cycles per tree and wavefront, a quarter of the headline's time.
 // HF_RETURN_EACH (fused loss): the kernel owns the epilogue and re-enters the stream per tree.
-template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) {
-    typedef typename VecOf<T>::type V;
+// the rest of a tree's end: flag byte, last tree of the chunk?, clear the state, on to the next tree (W = its first record)
+#define HTREE_END_TAIL(REC)                                                                                  \
+    if (__builtin_expect(__ballot(poison_set(st.poison)) != 0ull, 0))                                        \
+        *reinterpret_cast<__attribute__((address_space(1))) uint8_t *>(okp + la) = 0; /* every lane the same byte */ \
+    if (__builtin_expect(left <= 1u, 0)) return st;                                                          \
+    DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = T(0);                                        \
+    st.poison = typename PoisonOf<T>::type{};                                                                \
+    left -= 1u;                                                                                              \
+    HCHAIN_NEXT(REC)
+typedef __attribute__((address_space(1))) char *GPtr; // global, not flat: a flat store also ties up lgkmcnt
+// The other store modes (flags != 0), out of line so that h_tree_end itself is straight-line code: HF_RETURN_EACH (fused loss:
+// the kernel owns the epilogue), HF_SLOW_STORE (ragged last tile / output rows that are not 16-byte aligned; LDS base = 0:
+// lds0 = 16 * thread), HF_NO_STORE (DE_DEBUG_NO_STORE, measurement only: keep the value alive, write nothing).
+template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_ARGS) {
     constexpr int VW = VecOf<T>::W;
     if (flags & HF_RETURN_EACH) return st;
     const U32x4 w = *code;
-    typedef __attribute__((address_space(1))) char *GPtr; // global, not flat: a flat store also ties up lgkmcnt
-    const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)la * ldo); // wave-uniform: the store takes it as its scalar base
-    if (__builtin_expect((flags & (HF_SLOW_STORE | HF_NO_STORE)) == 0u, 1)) {
-        *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0) = st.acc;
-    } else if (flags & HF_SLOW_STORE) { // ragged last tile / output rows that are not 16-byte aligned (LDS base = 0: lds0 = 16 * thread)
+    const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)la * ldo);
+    if (flags & HF_SLOW_STORE) {
         const int remaining = (int)(flags & HF_VALID_MASK) - (int)(lds0 / (uint32_t)sizeof(T));
         DE_UNROLL for (int i = 0; i < VW; i++)
             if (i < remaining) reinterpret_cast<__attribute__((address_space(1))) T *>(row + lds0)[i] = st.acc[i];
-    } else if (st.acc[0] == T(123456.789)) { // DE_DEBUG_NO_STORE (measurement only): keep the value alive, write nothing
+    } else if (st.acc[0] == T(123456.789)) {
         *reinterpret_cast<__attribute__((address_space(1))) T *>(row + lds0) = st.acc[0];
     }
-    if (__builtin_expect(__ballot(poison_set(st.poison)) != 0ull, 0))
-        *reinterpret_cast<__attribute__((address_space(1))) uint8_t *>(okp + la) = 0; // every lane the same byte
-    if (left <= 1u) return st;
-    DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
-    st.poison = typename PoisonOf<T>::type{};
-    left -= 1u;
-    HCHAIN_NEXT(w);
+    HTREE_END_TAIL(w);
+}
+template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) {
+    typedef typename VecOf<T>::type V;
+    if (__builtin_expect(flags != 0u, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, lds0, code, outp, la, w1, w23, okp, ldo, left, flags);
+    const U32x4 w = *code;
+    const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)la * ldo); // wave-uniform: the store takes it as its scalar base
+    *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0) = st.acc; // full tile, aligned rows
+    HTREE_END_TAIL(w);
 }
 
 template <typename T> __device__ __forceinline__ HState<T> b_load_row(HARGS) { st.acc = *LDSP(T, la); return st; }

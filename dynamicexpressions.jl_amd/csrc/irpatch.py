@@ -130,7 +130,8 @@ def main(src, dst):
             out.append(prm)
         return head + ", ".join(out) + tail
     text = re.sub(r'^define [^\n]*?' + HSTATE + r' @[^\n(]+\([^\n]*$', add_inreg, text, flags=re.M)
-    text = re.sub(r'^\s*%[\w.]+ = (?:tail |musttail |notail )?call ' + HSTATE + r' %[\w.]+\([^\n]*$', add_inreg, text, flags=re.M)
+    # (indirect calls, and direct calls of one handler by another: h_tree_end -> h_tree_end_slow)
+    text = re.sub(r'^\s*%[\w.]+ = (?:tail |musttail |notail )?call ' + HSTATE + r' [%@][^\s(]+\([^\n]*$', add_inreg, text, flags=re.M)
     text = text.rstrip("\n") + "\n" + "".join(f"attributes #{i} = {{{body}}}\n" for i, body in list(new_ids.values()) + list(def_ids.values()))
     open(dst, "w").write(text)
     print(f"irpatch: {len(calls)} indirect handler call(s), {len(defs)} handlers, {len(allowed)}/{len(NO_ATTRS)} inputs dropped, "
