@@ -32,7 +32,7 @@ build_kernels() { # src obj [extra flags...]
   if [ "${DE_NO_IRPATCH:-0}" = 1 ]; then $HIPCC $FLAGS ${DE_KERNEL_FLAGS:-} -c $src -o $obj; return; fi
   $HIPCC $FLAGS ${DE_KERNEL_FLAGS:-} --cuda-device-only -emit-llvm -S $src -o $tmp/k.ll
   python3 irpatch.py $tmp/k.ll $tmp/k2.ll
-  $LLVM/clang -x ir $tmp/k2.ll -target amdgcn-amd-amdhsa -mcpu=gfx950 -O3 -fPIC -ffp-contract=off -Wno-override-module -c -o $tmp/k.o
+  $LLVM/clang -x ir $tmp/k2.ll -target amdgcn-amd-amdhsa -mcpu=gfx950 -O3 -fPIC -ffp-contract=off -Wno-override-module ${DE_LLC_FLAGS:-} -c -o $tmp/k.o
   # one more pass, over the object code of the handlers: asmpatch.py (their entry wait need not cover the previous tree's output stores)
   if [ "${DE_NO_ASMPATCH:-0}" != 1 ]; then python3 asmpatch.py $tmp/k.o; fi
   $LLVM/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o $tmp/k.out $tmp/k.o
