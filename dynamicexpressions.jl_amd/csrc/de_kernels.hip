@@ -1143,7 +1143,8 @@ static int cu_count() {
 // X-tile staging (one L2 read of the tile per chunk) stays a few percent of the work; with few
 // sample tiles, split further so the grid still covers the chip several times.
 static void plan_chunks(int64_t n_trees, int64_t n_tiles, int32_t *n_chunks_out, int32_t *tpc_out) {
-    int64_t n_chunks = (n_trees + 63) / 64;
+    const int64_t tpc_env = env_int("DE_EVAL_TPC", 64); // trees per chunk (experiments: X staging per tree against the tail of a short launch)
+    int64_t n_chunks = (n_trees + tpc_env - 1) / (tpc_env > 0 ? tpc_env : 64);
     const int64_t want_blocks = (int64_t)cu_count() * 4 * 8;
     if (n_tiles * n_chunks < want_blocks) n_chunks = (want_blocks + n_tiles - 1) / n_tiles;
     const int64_t max_chunks = (n_trees + 7) / 8; // >= 8 trees per chunk
