@@ -113,6 +113,24 @@ def test_random_population_f64_vs_oracle(api):
     compare_population(api, trees, ops, X, np.float64, min_ok=20)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_chunk_and_tile_boundaries_of_the_chained_stream(api, dtype):
+    """The eval kernel runs a chunk of consecutive trees as ONE chain (every tree's end record runs on into the next tree,
+    csrc/de_kernels.hip h_tree_end): populations of 1 .. 130 trees (one tree, one short chunk, exactly 64, one more, three
+    chunks; few samples re-split the launch into 8-tree chunks) x sample counts around the 512-sample tile (one sample, one
+    short of a tile, exactly two tiles, ragged third tile), leaf-only trees included; values and flags against the oracle."""
+    ops = de.synth.BENCH_OPERATORS
+    rng = de.synth.Xoshiro256ss(77)
+    pool = [de.synth.gen_random_tree_fixed_size(1 + (i * 5) % 23, ops, 5, rng, dtype) for i in range(130)]
+    g = np.random.Generator(np.random.PCG64(3))
+    for n_trees in (1, 7, 8, 9, 64, 65, 130):
+        for N in (1, 511, 1024, 1031):
+            X = np.asfortranarray(g.standard_normal((5, N)).astype(dtype))
+            compare_population(api, pool[:n_trees], ops, X, dtype, min_ok=0, max_ill=1.0)
+            if n_trees in (9, 65):  # the same on device tensors (16-byte aligned rows or not, by N)
+                compare_population(api, pool[:n_trees], ops, X, dtype, use_torch=True, min_ok=0, max_ill=1.0)
+
+
 def test_torch_device_tensors_zero_copy_path(api):
     ops = de.synth.BENCH_OPERATORS
     trees = de.synth.random_population(64, seed=11)
