@@ -74,6 +74,9 @@ WORKLOADS = {
     "C5N": dict(n_trees=1000, N=10**6, parametric=True, per_sample=True,
                 desc="1000 random 20-node ParametricNode trees, 8 PER-SAMPLE parameters (C = N classes, classes = 1:N), "
                      "5 x 10^6 Float32: eval_tree_array (SURVEY.md §8d C5 stress)"),
+    "C5Ng": dict(n_trees=1000, N=10**6, parametric=True, per_sample=True, per_sample_grad=True,
+                 desc="1000 random 20-node ParametricNode trees, 8 PER-SAMPLE parameters (C = N classes, classes = 1:N), "
+                      "5 x 10^6 Float32: eval_tree_array + eval_grad_tree_array(variable=false) per step (BASELINE config 5 read literally)"),
     "tiny": dict(n_trees=64, N=10**5, desc="64 trees x (5 x 10^5) Float32 (plumbing)"),
 }
 
@@ -332,12 +335,13 @@ def main():
         ng_c = np.array([pop.n_grad(t, 1) for t in range(len(trees))], dtype=np.int64)
         goffs = np.zeros(len(trees), dtype=np.int64)
         np.cumsum(ng_c[:-1] * N, out=goffs[1:])
-        gradc = None if (wl.get("by_class") or per_sample) else torch.empty(max(int((ng_c * N).sum()), 1), device=dev, dtype=torch.float32)
+        ps_grad = bool(wl.get("per_sample_grad"))
+        gradc = None if (wl.get("by_class") or (per_sample and not ps_grad)) else torch.empty(max(int((ng_c * N).sum()), 1), device=dev, dtype=torch.float32)
 
     def step():
         if is_param:
             ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, 5, pa_ref, out.data_ptr(), N, ok.data_ptr()))
-            if per_sample:
+            if per_sample and not ps_grad:
                 pass
             elif by_class:
                 ctx.check(lib.de_eval_loss_grad_by_class(ctx._h, pop._h, X.data_ptr(), N, 5, pa_ref, 2, dY.data_ptr(), None, 2,
@@ -454,8 +458,10 @@ def main():
             k_eff = plan["trees_per_chunk"]
             k_avg_ms = ms_per_step
             b_unit = (F_FEATURES * ELEM / k_eff + ELEM) + (F_FEATURES * ELEM / 32 + float(ng_c.mean()) * ELEM)
-            if per_sample:  # eval only; X + class id + the sample's 8 parameters per chunk of k_eff trees, one output
+            if per_sample and not ps_grad:  # eval only; X + class id + the sample's 8 parameters per chunk of k_eff trees, one output
                 b_unit = ((F_FEATURES + 8) * ELEM + 4) / k_eff + ELEM
+            elif per_sample:  # ... + the constant-mode Jacobian: X + class id + parameters per chunk of 32 trees, n_grad rows written
+                b_unit = (((F_FEATURES + 8) * ELEM + 4) / k_eff + ELEM) + (((F_FEATURES + 8) * ELEM + 4) / 32 + float(ng_c.mean()) * ELEM)
             elif by_class:  # eval as above; pullback: X + class id + dY tile per chunk of 32 trees, (1 + n_grad) partials per wave
                 b_unit = ((F_FEATURES * ELEM + 4) / k_eff + ELEM) + ((F_FEATURES * ELEM + 4 + ELEM) / 32
                                                                      + (1 + float(ng_b.mean())) * 4 * ELEM / 256)

@@ -6,7 +6,7 @@ TAG=${1:-check}; shift || true
 O=gpurun_out/$TAG; mkdir -p $O
 python -m pytest tests -m gpu -q -rs "$@" > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log
 tail -25 $O/pytest.log
-for wl in headline C2 C3 C4 C5 C5N loss lossgrad C5pb; do
+for wl in headline C2 C3 C4 C5 C5N C5Ng loss lossgrad C5pb; do
   extra=""; [ $wl = headline ] || extra="--no-cpu-baseline"
   timeout 900 python bench.py --workload $wl --steps 10 --warmup 2 $extra > $O/bench_$wl.json 2> $O/bench_$wl.err || echo "bench $wl failed rc=$?"
   python - <<PY
