@@ -66,6 +66,35 @@ template <> struct M<float> {
     static __device__ __forceinline__ bool signbit(T x) { return __builtin_signbit(x); }
 };
 
+// Float64 atan: the algorithm Julia's Base.atan uses (the FreeBSD msun / fdlibm scheme: argument reduction at 7/16, 11/16, 19/16,
+// 39/16 to atan(0.5), atan(1), atan(1.5), atan(inf) in hi + lo parts, odd/even split of a degree-11 polynomial in x^2).  Same
+// constants, same operation order, no contraction (-ffp-contract=off): the reference's bits, 0.85 ulp worst case — OCML's atan
+// measured 1.36 ulp, outside north_star's 1 ulp (tests/test_gpu_ulp_f64.py).  Divisions are IEEE (v_div_* sequence).
+static __device__ __noinline__ double de_atan_f64(double x) {
+    const double ax = __builtin_fabs(x);
+    if (!(ax < 0x1p+66)) return x != x ? x + x : __builtin_copysign(1.57079632679489655800e+00 + 6.12323399573676603587e-17, x);
+    double hi = 0.0, lo = 0.0, t = x;
+    bool reduced = true;
+    if (ax < 0.4375) {
+        if (ax < 0x1p-29) return x;
+        reduced = false;
+    } else if (ax < 1.1875) {
+        if (ax < 0.6875) { hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; t = (2.0 * ax - 1.0) / (2.0 + ax); }
+        else { hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; t = (ax - 1.0) / (ax + 1.0); }
+    } else {
+        if (ax < 2.4375) { hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; t = (ax - 1.5) / (1.0 + 1.5 * ax); }
+        else { hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; t = -1.0 / ax; }
+    }
+    const double z = t * t, w = z * z;
+    const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
+                      w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
+                      w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+    if (!reduced) return t - t * (s1 + s2);
+    const double r = hi - ((t * (s1 + s2) - lo) - t);
+    return x < 0.0 ? -r : r;
+}
+
 template <> struct M<double> {
     using T = double;
     static __device__ __forceinline__ T abs(T x) { return ::fabs(x); }
@@ -85,7 +114,7 @@ template <> struct M<double> {
     static __device__ __forceinline__ T tanh(T x) { return ::tanh(x); }
     static __device__ __forceinline__ T asin(T x) { return ::asin(x); }
     static __device__ __forceinline__ T acos(T x) { return ::acos(x); }
-    static __device__ __forceinline__ T atan(T x) { return ::atan(x); }
+    static __device__ __forceinline__ T atan(T x) { return de_atan_f64(x); }
     static __device__ __forceinline__ T asinh(T x) { return ::asinh(x); }
     static __device__ __forceinline__ T acosh(T x) { return ::acosh(x); }
     static __device__ __forceinline__ T atanh(T x) { return ::atanh(x); }

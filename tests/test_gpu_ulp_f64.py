@@ -6,9 +6,10 @@ the intermediate values to Float64 the way the operator's definition does (test/
 test/test_tree_construction.jl:11), so that the figure is the error of the device's last function call.
 The per-operator maxima are written to gpurun_out/ulp_f64.json (copied to profiles/ per round) and asserted against
 the bounds below: 0 for IEEE-exact operators, 0.5 for correctly rounded ones, 1 ulp (the north-star bound) for the
-library functions — EXCEPT four OCML Float64 functions that measure above 1 ulp on MI355X (ROCm 7.2): atan 1.36,
-tan 1.03, `^` (pow) 1.26, gamma 4.3.  They are held to their measured level + margin and listed as
-`within_north_star: false` in the report; everything else is within 1 ulp (worst: sinh/exp2 0.83)."""
+library functions — EXCEPT three OCML Float64 functions that measure above 1 ulp on MI355X (ROCm 7.2): tan 1.03,
+`^` (pow) 1.26, gamma 4.3.  They are held to their measured level + margin and listed as `within_north_star: false` in the
+report; everything else is within 1 ulp (worst: atan 0.85 — the library's own since OCML's measured 1.36:
+csrc/de_device_ops.h de_atan_f64, the algorithm and constants of Julia's Base.atan — and sinh/exp2 0.83)."""
 import json
 import os
 import zlib
@@ -95,7 +96,9 @@ UNARY = {
     "tanh": (np.tanh, lambda r: np.concatenate([grid(-20, 20, N, r), grid(-1e-3, 1e-3, N, r)]), 1.0),
     "asin": (np.arcsin, lambda r: grid(-1, 1, N, r), 1.0),
     "acos": (np.arccos, lambda r: grid(-1, 1, N, r), 1.0),
-    "atan": (np.arctan, lambda r: np.concatenate([grid(-10, 10, N, r), grid(1e-10, 1e10, N, r, True, True)]), 1.5),  # OCML: 1.36 measured
+    "atan": (np.arctan, lambda r: np.concatenate([grid(-10, 10, N, r), grid(1e-10, 1e10, N, r, True, True),
+                                                  np.array([0.0, -0.0, 0.4375, 0.6875, 1.1875, 2.4375, 2.0 ** 66, -2.0 ** 70, np.inf, -np.inf,
+                                                            2.0 ** -30, -2.0 ** -29, 1e-300])]), 1.0),  # de_atan_f64 (OCML: 1.36)
     "asinh": (np.arcsinh, lambda r: np.concatenate([grid(-10, 10, N, r), grid(1e-10, 1e100, N, r, True, True)]), 1.0),
     "acosh": (np.arccosh, lambda r: np.concatenate([grid(1, 10, N, r), grid(1, 1e100, N, r, True)]), 1.0),
     "atanh": (np.arctanh, lambda r: grid(-0.999, 0.999, N, r), 1.0),
@@ -109,6 +112,45 @@ UNARY = {
     "custom_cos": (lambda x: _rn(np.cos(x)) * _rn(np.cos(x)), lambda r: grid(-10, 10, N, r), 3.5),
     "gamma": (_gamma_ref, lambda r: np.concatenate([grid(0.05, 30, 400, r), grid(-5.9, -0.1, 200, r)]), 5.0),  # OCML tgamma: 4.3 measured
 }
+
+
+def _msun_atan(x):
+    """The reference's Float64 atan in numpy (IEEE double operations, no contraction): Julia's Base.atan is the FreeBSD msun
+    algorithm — reduction to atan(0.5 | 1 | 1.5 | inf) in hi + lo parts, odd/even split of the polynomial in x^2 — whose
+    constants and operation order csrc/de_device_ops.h de_atan_f64 restates."""
+    hi_t = np.array([4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01, 1.57079632679489655800e+00])
+    lo_t = np.array([2.26987774529616870924e-17, 3.06161699786838301793e-17, 1.39033110312309984516e-17, 6.12323399573676603587e-17])
+    a = [3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01, -1.11111104054623557880e-01,
+         9.09088713343650656196e-02, -7.69187620504482999495e-02, 6.66107313738753120669e-02, -5.83357013379057348645e-02,
+         4.97687799461593236017e-02, -3.65315727442169155270e-02, 1.62858201153657823623e-02]
+    x = np.asarray(x, dtype=np.float64)
+    ax = np.abs(x)
+    idx = np.select([ax < 0.4375, ax < 0.6875, ax < 1.1875, ax < 2.4375], [-1, 0, 1, 2], 3)
+    with np.errstate(all="ignore"):
+        t = np.select([idx == -1, idx == 0, idx == 1, idx == 2], [x, (2.0 * ax - 1.0) / (2.0 + ax), (ax - 1.0) / (ax + 1.0),
+                                                                  (ax - 1.5) / (1.0 + 1.5 * ax)], -1.0 / ax)
+        z = t * t
+        w = z * z
+        s1 = z * (a[0] + w * (a[2] + w * (a[4] + w * (a[6] + w * (a[8] + w * a[10])))))
+        s2 = w * (a[1] + w * (a[3] + w * (a[5] + w * (a[7] + w * a[9]))))
+        k = np.maximum(idx, 0)
+        big = hi_t[k] - ((t * (s1 + s2) - lo_t[k]) - t)
+        r = np.where(idx < 0, t - t * (s1 + s2), np.where(x < 0, -big, big))
+    r = np.where(ax < 2.0 ** -29, x, r)
+    return np.where(ax >= 2.0 ** 66, np.copysign(hi_t[3] + lo_t[3], x), r)
+
+
+def test_atan_f64_has_the_bits_of_the_reference_algorithm(api):
+    """Bit for bit against the numpy restatement above (1.2 million arguments, every reduction interval and its edges)."""
+    g = np.random.Generator(np.random.PCG64(5))
+    x = np.concatenate([g.uniform(-4, 4, 600_000), g.uniform(-100, 100, 200_000), 10.0 ** g.uniform(-40, 40, 400_000) * g.choice([-1.0, 1.0], 400_000),
+                        [0.0, -0.0, 0.4375, -0.4375, 0.6875, 1.1875, 2.4375, 2.0 ** 66, -2.0 ** 70, np.inf, -np.inf, 2.0 ** -30, 1e-310,
+                         np.nextafter(0.4375, 0), np.nextafter(0.6875, 0), np.nextafter(1.1875, 0), np.nextafter(2.4375, 0)]])
+    ops = de.OperatorEnum(binary_operators=("+",), unary_operators=("atan",))
+    out, _ = api.eval_tree_array(de.Node(1, de.Node(feature=1)), np.asfortranarray(x[None, :]), ops, eval_context=api.EvalContext(early_exit=False))
+    np.testing.assert_array_equal(out.view(np.uint64), _msun_atan(x).view(np.uint64))
+    o, _ = api.eval_tree_array(de.Node(1, de.Node(feature=1)), np.asfortranarray(np.array([[np.nan]])), ops, eval_context=api.EvalContext(early_exit=False))
+    assert np.isnan(o[0])
 
 
 @pytest.mark.parametrize("name", sorted(UNARY))
