@@ -93,6 +93,7 @@ struct de_program {
     std::vector<BoundInstr> ccode;
     std::vector<int32_t> ccode_off;     // n_trees + 1: first record of each tree
     uint64_t end_handler = 0;
+    uint64_t endv_handler[TOPX_ENDV_COUNT] = {0}; // "last instruction + end of tree" variants (de_bind.h topx_endv_of)
     bool threaded = false;
     bool direct = false;                // X too wide for the LDS tile (decided at creation)
     uint64_t handler_base = 0;
@@ -482,6 +483,7 @@ static int make_threaded(de_ctx *c, de_program *p) {
     }
     p->handler_base = base;
     p->end_handler = table[TOPX_END];
+    for (uint32_t k = 0; k < TOPX_ENDV_COUNT; k++) p->endv_handler[k] = table[TOPX_ENDV_BASE + k];
     make_chained(p);
     p->threaded = true;
     return DE_OK;
@@ -506,19 +508,29 @@ static void make_chained(de_program *p) {
         if (f32) { r.lo = (uint32_t)handler; r.hi = (uint32_t)(handler >> 32); }
         else r.arg = (uint32_t)handler;
     };
+    const char *ne = getenv("DE_NO_END_FUSE");
+    const bool end_fuse = !(ne && *ne == '1');
+    bool prev_fused = false; // the previous tree finishes in an end-fused handler: ITS last instruction names this tree's first handler
     for (int64_t t = 0; t < p->n_trees; t++) {
         const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1];
         const size_t h = (size_t)i0 + (size_t)t + 1; // one end record per preceding tree + the head record
         p->ccode_off[(size_t)t] = (int32_t)h;
+        // a tree that finishes in a validity-tested hot operator runs that instruction and its end as ONE dispatch (h_chain_end);
+        // a one-instruction tree keeps the plain form (the kernel's first call cannot tell the two apart)
+        const int ev = (end_fuse && i1 - i0 >= 2) ? topx_endv_of(p->fbcode[(size_t)i1 - 1].bop) : -1;
+        const bool ev_ok = ev >= 0;
         for (int32_t i = i0; i < i1; i++) {
             const BoundInstr &s = p->tcode[(size_t)i];
             put(p->ccode[h + (size_t)(i - i0)], s.arg, s.lo, s.hi);
-            name_next(p->ccode[h + (size_t)(i - i0) - 1], p->handler_base + s.bop); // in the record in front (head / previous end record / previous instruction)
+            const uint64_t handler = (i == i1 - 1 && ev_ok) ? p->endv_handler[ev] : p->handler_base + s.bop;
+            name_next(p->ccode[h + (size_t)(i - i0) - 1], handler); // in the record in front (head / previous end record / previous instruction)
+            if (i == i0 && prev_fused) name_next(p->ccode[h - 2], handler); // ... and in the previous tree's last instruction, which steps over its end record
         }
-        put(p->ccode[h + (size_t)(i1 - i0)], (uint32_t)t, 0u, 0u); // end record: operand word = the tree's index (h_tree_end)
+        put(p->ccode[h + (size_t)(i1 - i0)], (uint32_t)t, 0u, 0u); // end record (operand word: the tree's index, informational)
         name_next(p->ccode[h + (size_t)(i1 - i0) - 1], p->end_handler);
+        prev_fused = ev_ok;
     }
-    if (p->n_trees > 0) name_next(p->ccode.back(), p->end_handler); // never followed: the last tree's end record returns (left == 1)
+    if (p->n_trees > 0) name_next(p->ccode.back(), p->end_handler); // never followed: the last tree's end returns (left == 1)
     p->ccode_off[(size_t)p->n_trees] = (int32_t)p->ccode.size();
 }
 static inline void patch_chained_imm(de_program *p, int32_t c, uint32_t lo, uint32_t hi) {
@@ -1025,7 +1037,7 @@ int de_program_verify(const de_program_t *p) {
     if (p->threaded) {
         uint64_t table[TOPX_TABLE];
         if (eval_handler_table(p->dtype, (p->options & DE_OPT_TURBO) != 0, table) != hipSuccess) return fail(c, DE_ERR_HIP, "handler table");
-        std::vector<uint64_t> valid(table, table + TOPX_TABLE);
+        std::vector<uint64_t> valid(table, table + TOPX_TABLE); // (the end-fused variants included)
         std::sort(valid.begin(), valid.end());
         const uint64_t lds_bytes = (uint64_t)(rows + (p->uses_params ? 2 : 0)) * TROW_BYTES;
         if ((int64_t)p->ccode_off.size() != p->n_trees + 1 || p->ccode.size() != p->tcode.size() + (size_t)p->n_trees + 1) return bad("chained layout", -1, 0, p->ccode.size());
@@ -1038,13 +1050,22 @@ int de_program_verify(const de_program_t *p) {
                 const BoundInstr &q = p->ccode[(size_t)(h + (i - i0) - 1)]; // a record's handler is named by the record in front of it
                 const uint64_t addr = f32 ? (((uint64_t)q.hi << 32) | q.lo) : ((table[0] & 0xFFFFFFFF00000000ull) | q.arg);
                 if (!std::binary_search(valid.begin(), valid.end(), addr)) return bad("handler address not in the device table", t, i - i0, addr);
+                // an end-fused last instruction (h_chain_end) steps over the end record: its own record names what the end record names
+                const int ev = i1 - i0 >= 2 ? topx_endv_of(p->fbcode[(size_t)i1 - 1].bop) : -1;
+                const uint64_t last_plain = p->handler_base + p->tcode[(size_t)i1 - 1].bop;
+                const BoundInstr &lastq = p->ccode[(size_t)(h + (i1 - 1 - i0) - 1)];
+                const uint64_t last_addr = f32 ? (((uint64_t)lastq.hi << 32) | lastq.lo) : ((table[0] & 0xFFFFFFFF00000000ull) | lastq.arg);
+                const bool fused_end = ev >= 0 && last_addr == p->endv_handler[ev] && last_addr != last_plain;
                 if (i == i1) {
-                    if (addr != p->end_handler) return bad("tree does not end in the end record", t, i - i0, addr);
+                    const BoundInstr &e = p->ccode[(size_t)(h + (i1 - i0))]; // the end record itself names the next tree's first handler
+                    const uint64_t after = f32 ? (((uint64_t)e.hi << 32) | e.lo) : ((table[0] & 0xFFFFFFFF00000000ull) | e.arg);
+                    if (fused_end ? addr != after : addr != p->end_handler) return bad("tree does not end in the end record", t, i - i0, addr);
                     if (r.bop != (uint32_t)t) return bad("end record does not name its tree", t, i - i0, r.bop);
                     continue;
                 }
                 const BoundInstr &fb = p->fbcode[(size_t)i];
-                if (addr != p->handler_base + p->tcode[(size_t)i].bop) return bad("record / threaded code mismatch", t, i - i0, addr);
+                if (i == i1 - 1 ? (addr != last_plain && !fused_end) : addr != p->handler_base + p->tcode[(size_t)i].bop)
+                    return bad("record / threaded code mismatch", t, i - i0, addr);
                 if (fb.bop >= TOPX_COUNT) return bad("fused handler id", t, i - i0, fb.bop);
                 const bool no_row = top_is_const_source(fb.bop) || fb.bop == BOP_CHECK_ACC || fb.bop == BOP_GEN_ACC || fb.bop == BOP_INJ_ACC ||
                                     fb.bop == BOP_GEN_PARAM || (fb.bop >= BOP_UN_BASE && fb.bop < BOP_UN_END && !((fb.bop - BOP_UN_BASE) & 2)) ||

@@ -162,7 +162,16 @@ constexpr uint32_t TOPX_BIN_BASE = TOPX_UN_BASE + 2 * (GUN_K - 3); // max / min:
 constexpr uint32_t TOPX_COUNT = TOPX_BIN_BASE + 4;
 // handler table of the threaded eval kernel: the ids above + the end-of-tree handler every chain finishes in
 constexpr uint32_t TOPX_END = TOPX_COUNT;
-constexpr uint32_t TOPX_TABLE = TOPX_COUNT + 1;
+// ... and "last instruction of a tree + its end" variants of the handlers most trees finish in (a validity-tested hot binary or
+// unary operator): the stream's end record is then skipped, one dispatch less per tree.  Chosen by make_chained (de_api.cpp).
+constexpr uint32_t TOPX_ENDV_BASE = TOPX_END + 1;                 // + k * 2 + (operand is a constant), k < 6   | 12 + k, k < 3 (unary on acc)
+constexpr uint32_t TOPX_ENDV_COUNT = 15;
+constexpr uint32_t TOPX_TABLE = TOPX_ENDV_BASE + TOPX_ENDV_COUNT;
+// end variant of a fused / bound handler id, or -1
+constexpr int topx_endv_of(uint32_t id) {
+    return (id >= BOP_BIN_BASE && id < BOP_BIN_END && ((id - BOP_BIN_BASE) & 1)) ? (int)(((id - BOP_BIN_BASE) >> 2) * 2 + (((id - BOP_BIN_BASE) >> 1) & 1))
+         : (id >= BOP_UN_BASE && id < BOP_UN_END && ((id - BOP_UN_BASE) & 3) == 1) ? 12 + (int)((id - BOP_UN_BASE) >> 2) : -1;
+}
 
 // True when a (bound or fused) instruction carries a constant's bits in lo/hi.  Every generic
 // instruction with a constant operand becomes exactly one such instruction, in program order, in the

@@ -515,9 +515,10 @@ template <typename T> using BodyFn = HState<T> (*)(HState<T>, uint32_t, typename
 //   outp  : address of out[0, first sample of this tile] minus the LDS base (so that outp + tree * ldo + lds0 is this lane's vector)
 //   okp   : the completion flags;   ldo : bytes between two trees' output rows;   left : trees of this chunk still to run
 //   flags : HF_* | samples of the tile inside N (slow store)
+//   tree  : index of the tree being evaluated (the end handlers count it up)
 // argument words of a handler: (la, w1, w23) = the record as loaded { x, y, z:w }
 //   Float32: w1 = imm, w23 = next handler      Float64: w1 = next handler (low half), w23 = imm
-template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t);
+template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t, uint32_t);
 enum : uint32_t { HF_RETURN_EACH = 1u << 31, HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu };
 template <typename T> __device__ __forceinline__ HandlerFn<T> arg_next(uint32_t w1, uint64_t w23);
 template <> __device__ __forceinline__ HandlerFn<float> arg_next<float>(uint32_t, uint64_t w23) { return reinterpret_cast<HandlerFn<float>>(w23); }
@@ -529,8 +530,9 @@ template <> __device__ __forceinline__ uint32_t arg_imm<float>(uint32_t w1, uint
 template <> __device__ __forceinline__ uint64_t arg_imm<double>(uint32_t, uint64_t w23) { return w23; }
 #define DE_ROW_BYTES_C ((DE_TBLK + 1) * 16) // LDS row stride of the threaded kernel: DE_TBLK 16-byte vectors + one of padding
 // `code` points at the record of the NEXT instruction; (la, w1, w23) are this instruction's record
-#define HCHAIN_ARGS HState<T> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint32_t left, uint32_t flags
-#define HCHAIN_NEXT(W) [[clang::musttail]] return arg_next<T>(w1, w23)(st, lds0, code + 1, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, left, flags)
+#define HCHAIN_ARGS HState<T> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint32_t left, uint32_t flags, uint32_t tree
+#define HCHAIN_NEXT_AT(W, NEXT) [[clang::musttail]] return arg_next<T>(w1, w23)(st, lds0, NEXT, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, left, flags, tree)
+#define HCHAIN_NEXT(W) HCHAIN_NEXT_AT(W, code + 1)
 template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain(HCHAIN_ARGS) {
     const U32x4 w = *code;
     st = BODY(st, lds0 + la, arg_imm<T>(w1, w23)); // la = row byte offset | aux << 24 (no carry: LDS < 2^18 bytes)
@@ -560,14 +562,15 @@ __device__ __forceinline__ bool poison_set(const double &p) { return p != p; }
 // scalar-cache round trips per tree) cost ~250 SIMD cycles per tree and wavefront, a quarter of the headline's time.
 // HF_RETURN_EACH (fused loss): the kernel owns the epilogue and re-enters the stream per tree.
 // the rest of a tree's end: flag byte, last tree of the chunk?, clear the state, on to the next tree (W = its first record)
-#define HTREE_END_TAIL(REC)                                                                                  \
+#define HTREE_END_TAIL(REC, NEXT)                                                                            \
     if (__builtin_expect(__ballot(poison_set(st.poison)) != 0ull, 0))                                        \
-        *reinterpret_cast<__attribute__((address_space(1))) uint8_t *>(okp + la) = 0; /* every lane the same byte */ \
+        *reinterpret_cast<__attribute__((address_space(1))) uint8_t *>(okp + tree) = 0; /* every lane the same byte */ \
     if (__builtin_expect(left <= 1u, 0)) return st;                                                          \
     DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = T(0);                                        \
     st.poison = typename PoisonOf<T>::type{};                                                                \
     left -= 1u;                                                                                              \
-    HCHAIN_NEXT(REC)
+    tree += 1u;                                                                                              \
+    HCHAIN_NEXT_AT(REC, NEXT)
 typedef __attribute__((address_space(1))) char *GPtr; // global, not flat: a flat store also ties up lgkmcnt
 // The other store modes (flags != 0), out of line so that h_tree_end itself is straight-line code: HF_RETURN_EACH (fused loss:
 // the kernel owns the epilogue), HF_SLOW_STORE (ragged last tile / output rows that are not 16-byte aligned; LDS base = 0:
@@ -576,7 +579,7 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_A
     constexpr int VW = VecOf<T>::W;
     if (flags & HF_RETURN_EACH) return st;
     const U32x4 w = *code;
-    const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)la * ldo);
+    const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);
     if (flags & HF_SLOW_STORE) {
         const int remaining = (int)(flags & HF_VALID_MASK) - (int)(lds0 / (uint32_t)sizeof(T));
         DE_UNROLL for (int i = 0; i < VW; i++)
@@ -584,15 +587,31 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_A
     } else if (st.acc[0] == T(123456.789)) {
         *reinterpret_cast<__attribute__((address_space(1))) T *>(row + lds0) = st.acc[0];
     }
-    HTREE_END_TAIL(w);
+    HTREE_END_TAIL(w, code + 1);
 }
 template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) {
     typedef typename VecOf<T>::type V;
-    if (__builtin_expect(flags != 0u, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, lds0, code, outp, la, w1, w23, okp, ldo, left, flags);
+    if (__builtin_expect(flags != 0u, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, lds0, code, outp, la, w1, w23, okp, ldo, left, flags, tree);
     const U32x4 w = *code;
-    const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)la * ldo); // wave-uniform: the store takes it as its scalar base
+    const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo); // wave-uniform: the store takes it as its scalar base
     *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0) = st.acc; // full tile, aligned rows
-    HTREE_END_TAIL(w);
+    HTREE_END_TAIL(w, code + 1);
+}
+// The last instruction of a tree and its end in one dispatch (make_chained picks it when the tree finishes in a validity-tested
+// hot operator: ~85 % of the bench population): the body, then what h_tree_end does.  The stream keeps its end record — this
+// handler steps over it (code[0]) to the next tree's first record — and this instruction's record names the next tree's first
+// handler, as the end record does.
+template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain_end(HCHAIN_ARGS) {
+    typedef typename VecOf<T>::type V;
+    if (__builtin_expect(flags != 0u, 0)) {
+        st = BODY(st, lds0 + la, arg_imm<T>(w1, w23));
+        [[clang::musttail]] return h_tree_end_slow<T>(st, lds0, code + 1, outp, la, w1, w23, okp, ldo, left, flags, tree);
+    }
+    const U32x4 w = code[1];
+    st = BODY(st, lds0 + la, arg_imm<T>(w1, w23));
+    const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);
+    *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0) = st.acc;
+    HTREE_END_TAIL(w, code + 2);
 }
 
 template <typename T> __device__ __forceinline__ HState<T> b_load_row(HARGS) { st.acc = *LDSP(T, la); return st; }
@@ -902,6 +921,12 @@ template <typename T, bool TB> __global__ void de_fill_handlers(uint64_t *t) {
     t[BOP_GEN_ACC] = (uint64_t)&h_chain<T, &b_gen<T, 2, false>>;
     t[BOP_GEN_PARAM] = (uint64_t)&h_param<T, TB>;
     t[TOPX_END] = (uint64_t)&h_tree_end<T>;
+#define HEB(K) t[TOPX_ENDV_BASE + K * 2] = (uint64_t)&h_chain_end<T, &b_bin<T, K, 1, TBK(K)>>; t[TOPX_ENDV_BASE + K * 2 + 1] = (uint64_t)&h_chain_end<T, &b_bin<T, K, 3, TBK(K)>>;
+    HEB(0) HEB(1) HEB(2) HEB(3) HEB(4) HEB(5)
+#undef HEB
+    t[TOPX_ENDV_BASE + 12] = (uint64_t)&h_chain_end<T, &b_un<T, 0, 1, TB>>;
+    t[TOPX_ENDV_BASE + 13] = (uint64_t)&h_chain_end<T, &b_un<T, 1, 1, TB>>;
+    t[TOPX_ENDV_BASE + 14] = (uint64_t)&h_chain_end<T, &b_un<T, 2, 1, TB>>;
     t[BOP_TERN] = (uint64_t)&h_chain<T, &b_tern<T>>;
     t[BOP_INJ_ACC] = (uint64_t)&h_chain<T, &b_gen<T, 2, true>>;
     t[BOP_INJ_ROW] = (uint64_t)&h_chain<T, &b_gen<T, 0, true>>;
@@ -1045,7 +1070,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         const uint64_t outp = (uint64_t)(uintptr_t)(a.out + base) - (uint64_t)(uint32_t)(uintptr_t)smem_raw;
         const U32x4 hp = rec[-1], hd = *rec; // the first handler's address is in the record in front (the previous tree's end record / the head record)
         st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, lds0, rec + 1, outp, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, (uint64_t)(uintptr_t)a.ok,
-                                                              ldo, (uint32_t)(t1 - t0), flags);
+                                                              ldo, (uint32_t)(t1 - t0), flags, (uint32_t)t0);
         (void)st;
     } else {
         for (int tree = t0; tree < t1; ++tree) {
@@ -1056,7 +1081,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             st.poison = typename PoisonOf<T>::type{};
             const U32x4 hp = rec[-1], hd = *rec;
             st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, lds0, rec + 1, 0ull, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, 0ull, 0ull, 1u,
-                                                                  (uint32_t)HF_RETURN_EACH);
+                                                                  (uint32_t)HF_RETURN_EACH, (uint32_t)tree);
             // sum_j w_j * l(out_j - y_j) over this wave's 64*VW samples -> one partial per (tile, tree, wave)
             T s = T(0);
             DE_UNROLL for (int i = 0; i < VW; i++) {
