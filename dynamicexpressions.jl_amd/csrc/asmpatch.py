@@ -29,7 +29,7 @@ import struct
 import subprocess
 import sys
 
-TARGETS = re.compile(r"^_ZN2de(7h_chainI|7h_paramI|10h_tree_endI|11h_chain_endI|\d+[gr]tm_\w+?8[gr]h_chainI)")  # never an end handler (h_tree_end, g_end, r_end): the end of every chain keeps the full wait
+TARGETS = re.compile(r"^_ZN2de(7h_chainI|7h_paramI|9h_un_fastI|10h_div_fastI|10h_tree_endI|11h_chain_endI|\d+[gr]tm_\w+?8[gr]h_chainI)")  # never an end handler (h_tree_end, g_end, r_end): the end of every chain keeps the full wait
 VMEM = re.compile(r"^\s*(scratch_|flat_|global_|buffer_|tbuffer_|image_)")
 LLVM = os.environ.get("LLVM", "/opt/rocm/lib/llvm/bin")
 

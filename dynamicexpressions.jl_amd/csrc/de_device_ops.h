@@ -217,6 +217,25 @@ template <bool SIN> __device__ __forceinline__ DeTrig2 fast_trig_core_f32x2(DeF2
     if constexpr (SIN) { o.s[0] = __builtin_copysignf(o.s[0], r[0]); o.s[1] = __builtin_copysignf(o.s[1], r[1]); }
     return o;
 }
+// The same arithmetic in two pieces, for handlers that test the multiple n before anything else (h_un_fast, de_kernels.hip):
+// the reduced argument r(x, n) and sin(r).  TB = the turbo mode's two-term pi.
+template <bool SIN, bool TB> __device__ __forceinline__ DeF2 trig_reduced_f32x2(DeF2 x, DeF2 n) {
+    const DeF2 m = SIN ? n : n - DE_F2(0.5f);
+    DeF2 r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P1), x);
+    r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P2), r);
+    if constexpr (!TB) r = __builtin_elementwise_fma(-m, DE_F2(DE_TRIG_P3), r);
+    return r;
+}
+template <bool SIN, bool TB> __device__ __forceinline__ DeF2 trig_poly_f32x2(DeF2 x, DeF2 n) {
+    const DeF2 r = trig_reduced_f32x2<SIN, TB>(x, n);
+    const DeF2 z = r * r;
+    DeF2 p = __builtin_elementwise_fma(z, DE_F2(DE_TRIG_S3), DE_F2(DE_TRIG_S2));
+    p = __builtin_elementwise_fma(z, p, DE_F2(DE_TRIG_S1));
+    p = __builtin_elementwise_fma(z, p, DE_F2(DE_TRIG_S0));
+    DeF2 s = __builtin_elementwise_fma(r * z, p, r);
+    if constexpr (SIN) { s[0] = __builtin_copysignf(s[0], r[0]); s[1] = __builtin_copysignf(s[1], r[1]); } // sin(-0) = -0
+    return s;
+}
 __device__ __forceinline__ DeF2 fast_trig_sign_f32x2(DeF2 s, DeF2 kk) {
     // (-1)^n: the parity of n is the low mantissa bit of the magic sum; ADDING it at bit 31 flips the sign bit exactly like
     // the xor would (the carry leaves the word) and is one v_lshl_add_u32 instead of a shift and a xor

@@ -637,8 +637,8 @@ template <typename T> __device__ __forceinline__ HState<T> b_check_acc(HARGS) { 
 // elements per v_pk_fma_f32 without them — bit-identical results, 38 issue slots instead of 56.
 // Anything else in the wave (zeros, Inf, huge/tiny values; NaN is transparent to max/min and
 // propagates through the FMAs) takes the generic expansion, under a wave-uniform branch.
-__device__ __forceinline__ VecOf<float>::type div_apply(VecOf<float>::type a, VecOf<float>::type b) {
-    typedef VecOf<float>::type V;
+// all eight operands of a wavefront's four divisions in [2^-40, 2^40]?  (all-NaN compares false: generic path)
+__device__ __forceinline__ bool div_operands_safe(VecOf<float>::type a, VecOf<float>::type b) {
     // v_max3 / v_min3 on |.|, spelled out (fmaxf(fabsf(.)) costs an extra v_max_f32 |x|, |x| per raw operand: sNaN quieting)
     float hi, lo;
     asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(hi) : "v"(a[0]), "v"(b[0]), "v"(a[1]));
@@ -649,9 +649,11 @@ __device__ __forceinline__ VecOf<float>::type div_apply(VecOf<float>::type a, Ve
     asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(lo) : "v"(lo), "v"(b[1]), "v"(a[2]));
     asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(lo) : "v"(lo), "v"(b[2]), "v"(a[3]));
     asm("v_min_f32_e64 %0, %1, |%2|" : "=v"(lo) : "v"(lo), "v"(b[3]));
-    const bool safe = (hi < 0x1p+40f) & (lo > 0x1p-40f); // all-NaN compares false: generic path
-    if (__ballot(!safe) != 0ull) return a / b;
-    V q;
+    return (hi < 0x1p+40f) & (lo > 0x1p-40f);
+}
+// the correctly rounded quotients of operands that passed div_operands_safe: reciprocal, one Newton step, two residual corrections
+__device__ __forceinline__ VecOf<float>::type div_safe(VecOf<float>::type a, VecOf<float>::type b) {
+    VecOf<float>::type q;
     DE_UNROLL for (int h = 0; h < 2; h++) {
         const DeF2 n = {a[2 * h], a[2 * h + 1]}, d = {b[2 * h], b[2 * h + 1]};
         DeF2 y = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
@@ -666,6 +668,11 @@ __device__ __forceinline__ VecOf<float>::type div_apply(VecOf<float>::type a, Ve
         q[2 * h + 1] = t[1];
     }
     return q;
+}
+__device__ __forceinline__ VecOf<float>::type div_apply(VecOf<float>::type a, VecOf<float>::type b) {
+    const bool safe = div_operands_safe(a, b);
+    if (__ballot(!safe) != 0ull) return a / b;
+    return div_safe(a, b);
 }
 __device__ __forceinline__ VecOf<double>::type div_apply(VecOf<double>::type a, VecOf<double>::type b) { return a / b; }
 // K: 0 ADD 1 SUB 2 RSUB 3 MUL 4 DIV 5 RDIV  —  x op b (R*: b op x)
@@ -760,6 +767,73 @@ template <typename T, int K, int VAR, bool TB = false> __device__ __forceinline_
     st.acc = un_apply<T, K, TB>(x);
     if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
     return st;
+}
+// The Float32 cos / exp / sin handlers on the accumulator or a row, FAST PATH ONLY: the wave-uniform range test comes first and
+// a wavefront that fails it tail-calls the full handler (h_chain<b_un>: same arguments, nothing modified yet), which repeats the
+// test and resolves it per element.  With the slow paths (OCML's Payne-Hanek reduction, the ldexp form of exp) out of the
+// function the argument is dead after its last use and the result is computed in place: no v_mov of the accumulator around
+// the body (4-5 of them before: 7-10 % of the handler).
+template <int K, int VAR, bool TB> __device__ __noinline__ HState<float> h_un_fast(HState<float> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la,
+                                                                                  uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint32_t left,
+                                                                                  uint32_t flags, uint32_t tree) {
+    typedef float T;
+    typedef VecOf<float>::type V;
+    const U32x4 w = *code;
+    V x = st.acc;
+    if constexpr (VAR & 2) x = *LDSP(T, lds0 + la);
+    const DeF2 xa = {x[0], x[1]}, xb = {x[2], x[3]};
+    V r;
+    if constexpr (K == 1) { // exact exp (turbo exp has no slow path: it keeps h_chain)
+        const DeF2 ta = xa * DE_F2(0x1.715476p+0f), tb = xb * DE_F2(0x1.715476p+0f);
+        if (__builtin_expect(__ballot(any_abs_exceeds_f32x4(ta[0], ta[1], tb[0], tb[1], DE_EXP_DIRECT_BOUND_T)) != 0ull, 0))
+            [[clang::musttail]] return h_chain<T, &b_un<T, K, VAR, TB>>(st, lds0, code, outp, la, w1, w23, okp, ldo, left, flags, tree);
+        const DeF2 a = turbo_exp_f32x2(xa, ta), b = turbo_exp_f32x2(xb, tb);
+        r = V{a[0], a[1], b[0], b[1]};
+    } else {
+        constexpr bool SIN = K == 2;
+        // the multiple of pi first (what the range test reads), then the test, then the rest of the reduction and the polynomial
+        const DeF2 ta = SIN ? xa * DE_F2(DE_TRIG_INV_PI) : __builtin_elementwise_fma(xa, DE_F2(DE_TRIG_INV_PI), DE_F2(0.5f));
+        const DeF2 tb = SIN ? xb * DE_F2(DE_TRIG_INV_PI) : __builtin_elementwise_fma(xb, DE_F2(DE_TRIG_INV_PI), DE_F2(0.5f));
+        const DeF2 ka = ta + DE_F2(DE_TRIG_MAGIC), kb = tb + DE_F2(DE_TRIG_MAGIC);
+        const DeF2 na = ka - DE_F2(DE_TRIG_MAGIC), nb = kb - DE_F2(DE_TRIG_MAGIC);
+        if (__builtin_expect(__ballot(any_abs_exceeds_f32x4(na[0], na[1], nb[0], nb[1], DE_TRIG_FAST_BOUND_M)) != 0ull, 0))
+            [[clang::musttail]] return h_chain<T, &b_un<T, K, VAR, TB>>(st, lds0, code, outp, la, w1, w23, okp, ldo, left, flags, tree);
+        DeF2 sa = trig_poly_f32x2<SIN, TB>(xa, na), sb = trig_poly_f32x2<SIN, TB>(xb, nb);
+        if constexpr (!TB) { // exact mode: results within 2^-12 of +-pi/2 are exactly +-1 (de_device_ops.h)
+#ifndef DE_TRIG_NO_EXTREMUM_FIX
+            const DeF2 ra = trig_reduced_f32x2<SIN, TB>(xa, na), rb = trig_reduced_f32x2<SIN, TB>(xb, nb); // (common subexpressions of trig_poly)
+            const DeF2 za = ra * ra, zb = rb * rb;
+            const bool near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(za[0], za[1]), zb[0]), zb[1]) > (0x1.3bd3ccp+1f - 8.0e-4f);
+            if (__ballot(near) != 0ull) {
+                sa[0] = trig_extremum_fix(ra[0], sa[0]); sa[1] = trig_extremum_fix(ra[1], sa[1]);
+                sb[0] = trig_extremum_fix(rb[0], sb[0]); sb[1] = trig_extremum_fix(rb[1], sb[1]);
+            }
+#endif
+        }
+        const DeF2 ya = fast_trig_sign_f32x2(sa, ka), yb = fast_trig_sign_f32x2(sb, kb);
+        r = V{ya[0], ya[1], yb[0], yb[1]};
+    }
+    st.acc = r;
+    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
+    [[clang::musttail]] return arg_next<T>(w1, w23)(st, lds0, code + 1, outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, left, flags, tree);
+}
+// The exact Float32 divisions (K = 4: acc / operand, 5: operand / acc; VAR as in b_bin) likewise: range test, then either the
+// tail call into the full handler (generic IEEE expansion) or the packed fast path computed in place.
+template <int K, int VAR> __device__ __noinline__ HState<float> h_div_fast(HState<float> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la,
+                                                                         uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint32_t left,
+                                                                         uint32_t flags, uint32_t tree) {
+    typedef float T;
+    typedef VecOf<float>::type V;
+    const U32x4 w = *code;
+    V b;
+    if constexpr (VAR & 2) b = splat<T>(w1);
+    else b = *LDSP(T, lds0 + la);
+    const V num = K == 4 ? st.acc : b, den = K == 4 ? b : st.acc;
+    if (__builtin_expect(__ballot(!div_operands_safe(num, den)) != 0ull, 0))
+        [[clang::musttail]] return h_chain<T, &b_bin<T, K, VAR, false>>(st, lds0, code, outp, la, w1, w23, okp, ldo, left, flags, tree);
+    st.acc = div_safe(num, den);
+    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
+    [[clang::musttail]] return arg_next<T>(w1, w23)(st, lds0, code + 1, outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, left, flags, tree);
 }
 // ---- superinstructions (de_bind.h, fuse_tree): la = LDS address of row A | int8 (push row - row A) << 24
 #define DE_ROW_BYTES ((DE_TBLK + 1) * 16)
@@ -916,6 +990,19 @@ template <typename T, bool TB> __global__ void de_fill_handlers(uint64_t *t) {
     t[BOP_CHECK_ACC] = (uint64_t)&h_chain<T, &b_check_acc<T>>;
     HB(0) HB(1) HB(2) HB(3) HB(4) HB(5)
     HU(0) HU(1) HU(2)
+    if constexpr (sizeof(T) == 4) { // Float32: fast-path-only forms of the hot unary handlers (h_un_fast; turbo exp has no slow path)
+#define HUF(K) t[BOP_UN_BASE + 4 * K + 0] = (uint64_t)&h_un_fast<K, 0, TB>; t[BOP_UN_BASE + 4 * K + 1] = (uint64_t)&h_un_fast<K, 1, TB>; \
+               t[BOP_UN_BASE + 4 * K + 2] = (uint64_t)&h_un_fast<K, 2, TB>; t[BOP_UN_BASE + 4 * K + 3] = (uint64_t)&h_un_fast<K, 3, TB>;
+        HUF(0) HUF(2)
+        if constexpr (!TB) { HUF(1) }
+#undef HUF
+        if constexpr (!TB) { // exact divisions (turbo: x * rcp(y), no slow path)
+#define HDF(K) t[BOP_BIN_BASE + 4 * K + 0] = (uint64_t)&h_div_fast<K, 0>; t[BOP_BIN_BASE + 4 * K + 1] = (uint64_t)&h_div_fast<K, 1>; \
+               t[BOP_BIN_BASE + 4 * K + 2] = (uint64_t)&h_div_fast<K, 2>; t[BOP_BIN_BASE + 4 * K + 3] = (uint64_t)&h_div_fast<K, 3>;
+            HDF(4) HDF(5)
+#undef HDF
+        }
+    }
     t[BOP_GEN_ROW] = (uint64_t)&h_chain<T, &b_gen<T, 0, false>>;
     t[BOP_GEN_CONST] = (uint64_t)&h_chain<T, &b_gen<T, 1, false>>;
     t[BOP_GEN_ACC] = (uint64_t)&h_chain<T, &b_gen<T, 2, false>>;

@@ -89,6 +89,12 @@ def shortest_slots(code):
             continue
         _, mn, ops, tgt = code[i]
         if mn.startswith("s_setpc") or mn == "s_endpgm":
+            # a jump through a pc-relative address (s_getpc_b64 + s_add_u32 into the same pair a few instructions up) is the
+            # tail call into a handler's out-of-line slow twin (h_un_fast -> h_chain<b_un>, h_tree_end -> h_tree_end_slow): not
+            # the path ordinary data takes
+            pair = ops.split()[0].rstrip(",") if ops else ""
+            if any(code[j][1] == "s_getpc_b64" and code[j][2].split()[0].rstrip(",") == pair for j in range(max(0, i - 8), i)):
+                continue
             return round(d, 2), nv, ni
         w = weight(mn, ops)
         nxt = []
@@ -167,7 +173,7 @@ def handler_names(ty: str, turbo: bool = False):
 
 def table(obj, ty="float", turbo=False):
     fns = functions(obj)
-    by_short = {}
+    by_short, fast = {}, {}
     for full, code in fns.items():
         # direct-threaded handlers are h_chain<T, &body>: index them by the body's name with the historical h_ prefix
         m = re.search(r"h_chain<\w+, &de::HState<\w+> de::b_(\w+<[^(]*>)\(", full)
@@ -177,6 +183,16 @@ def table(obj, ty="float", turbo=False):
         m = re.search(r"de::(h_param<[^(]*>)\(", full)
         if m:
             by_short[m.group(1)] = code
+            continue
+        m = re.search(r"de::h_un_fast<(\d), (\d), (true|false)>\(", full)  # Float32 hot unary handlers: the fast-path-only forms are what the table points at
+        if m:
+            fast[f"h_un<float, {m.group(1)}, {m.group(2)}, {m.group(3)}>"] = code
+            continue
+        m = re.search(r"de::h_div_fast<(\d), (\d)>\(", full)  # ... and of the exact Float32 divisions
+        if m:
+            fast[f"h_bin<float, {m.group(1)}, {m.group(2)}, false>"] = code
+    if ty == "float":
+        by_short.update(fast)
     names, counts = handler_names(ty, turbo)
     slots = {}
     for hid, nm in names.items():
