@@ -29,7 +29,7 @@ import struct
 import subprocess
 import sys
 
-TARGETS = re.compile(r"^_ZN2de(7h_chainI|7h_paramI|9h_un_fastI|10h_div_fastI|10h_tree_endI|11h_chain_endI|\d+[gr]tm_\w+?8[gr]h_chainI)")  # never an end handler (h_tree_end, g_end, r_end): the end of every chain keeps the full wait
+TARGETS = re.compile(r"^_ZN2de(7h_chainI|7h_paramI|9h_un_fastI|10h_div_fastI|12h_unrow_fastI|14h_divrowc_fastI|11h_div2_fastI|13h_un_end_fastI|14h_div_end_fastI|10h_tree_endI|11h_chain_endI|\d+[gr]tm_\w+?8[gr]h_chainI)")  # never an end handler (h_tree_end, g_end, r_end): the end of every chain keeps the full wait
 VMEM = re.compile(r"^\s*(scratch_|flat_|global_|buffer_|tbuffer_|image_)")
 LLVM = os.environ.get("LLVM", "/opt/rocm/lib/llvm/bin")
 
@@ -49,7 +49,7 @@ def vmem_free_functions(path):
     if name and clean:
         ok.add(name)
     return ok
-END = re.compile(r"^_ZN2de(10h_tree_endI|11h_chain_endI)")  # the eval kernel's end-of-tree handlers: they store, and read nothing back
+END = re.compile(r"^_ZN2de(10h_tree_endI|11h_chain_endI|13h_un_end_fastI|14h_div_end_fastI)")  # the eval kernel's end-of-tree handlers: they store, and read nothing back
 
 
 def end_handler_is_safe(path, name):

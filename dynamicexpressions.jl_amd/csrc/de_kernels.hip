@@ -768,73 +768,6 @@ template <typename T, int K, int VAR, bool TB = false> __device__ __forceinline_
     if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
     return st;
 }
-// The Float32 cos / exp / sin handlers on the accumulator or a row, FAST PATH ONLY: the wave-uniform range test comes first and
-// a wavefront that fails it tail-calls the full handler (h_chain<b_un>: same arguments, nothing modified yet), which repeats the
-// test and resolves it per element.  With the slow paths (OCML's Payne-Hanek reduction, the ldexp form of exp) out of the
-// function the argument is dead after its last use and the result is computed in place: no v_mov of the accumulator around
-// the body (4-5 of them before: 7-10 % of the handler).
-template <int K, int VAR, bool TB> __device__ __noinline__ HState<float> h_un_fast(HState<float> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la,
-                                                                                  uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint32_t left,
-                                                                                  uint32_t flags, uint32_t tree) {
-    typedef float T;
-    typedef VecOf<float>::type V;
-    const U32x4 w = *code;
-    V x = st.acc;
-    if constexpr (VAR & 2) x = *LDSP(T, lds0 + la);
-    const DeF2 xa = {x[0], x[1]}, xb = {x[2], x[3]};
-    V r;
-    if constexpr (K == 1) { // exact exp (turbo exp has no slow path: it keeps h_chain)
-        const DeF2 ta = xa * DE_F2(0x1.715476p+0f), tb = xb * DE_F2(0x1.715476p+0f);
-        if (__builtin_expect(__ballot(any_abs_exceeds_f32x4(ta[0], ta[1], tb[0], tb[1], DE_EXP_DIRECT_BOUND_T)) != 0ull, 0))
-            [[clang::musttail]] return h_chain<T, &b_un<T, K, VAR, TB>>(st, lds0, code, outp, la, w1, w23, okp, ldo, left, flags, tree);
-        const DeF2 a = turbo_exp_f32x2(xa, ta), b = turbo_exp_f32x2(xb, tb);
-        r = V{a[0], a[1], b[0], b[1]};
-    } else {
-        constexpr bool SIN = K == 2;
-        // the multiple of pi first (what the range test reads), then the test, then the rest of the reduction and the polynomial
-        const DeF2 ta = SIN ? xa * DE_F2(DE_TRIG_INV_PI) : __builtin_elementwise_fma(xa, DE_F2(DE_TRIG_INV_PI), DE_F2(0.5f));
-        const DeF2 tb = SIN ? xb * DE_F2(DE_TRIG_INV_PI) : __builtin_elementwise_fma(xb, DE_F2(DE_TRIG_INV_PI), DE_F2(0.5f));
-        const DeF2 ka = ta + DE_F2(DE_TRIG_MAGIC), kb = tb + DE_F2(DE_TRIG_MAGIC);
-        const DeF2 na = ka - DE_F2(DE_TRIG_MAGIC), nb = kb - DE_F2(DE_TRIG_MAGIC);
-        if (__builtin_expect(__ballot(any_abs_exceeds_f32x4(na[0], na[1], nb[0], nb[1], DE_TRIG_FAST_BOUND_M)) != 0ull, 0))
-            [[clang::musttail]] return h_chain<T, &b_un<T, K, VAR, TB>>(st, lds0, code, outp, la, w1, w23, okp, ldo, left, flags, tree);
-        DeF2 sa = trig_poly_f32x2<SIN, TB>(xa, na), sb = trig_poly_f32x2<SIN, TB>(xb, nb);
-        if constexpr (!TB) { // exact mode: results within 2^-12 of +-pi/2 are exactly +-1 (de_device_ops.h)
-#ifndef DE_TRIG_NO_EXTREMUM_FIX
-            const DeF2 ra = trig_reduced_f32x2<SIN, TB>(xa, na), rb = trig_reduced_f32x2<SIN, TB>(xb, nb); // (common subexpressions of trig_poly)
-            const DeF2 za = ra * ra, zb = rb * rb;
-            const bool near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(za[0], za[1]), zb[0]), zb[1]) > (0x1.3bd3ccp+1f - 8.0e-4f);
-            if (__ballot(near) != 0ull) {
-                sa[0] = trig_extremum_fix(ra[0], sa[0]); sa[1] = trig_extremum_fix(ra[1], sa[1]);
-                sb[0] = trig_extremum_fix(rb[0], sb[0]); sb[1] = trig_extremum_fix(rb[1], sb[1]);
-            }
-#endif
-        }
-        const DeF2 ya = fast_trig_sign_f32x2(sa, ka), yb = fast_trig_sign_f32x2(sb, kb);
-        r = V{ya[0], ya[1], yb[0], yb[1]};
-    }
-    st.acc = r;
-    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
-    [[clang::musttail]] return arg_next<T>(w1, w23)(st, lds0, code + 1, outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, left, flags, tree);
-}
-// The exact Float32 divisions (K = 4: acc / operand, 5: operand / acc; VAR as in b_bin) likewise: range test, then either the
-// tail call into the full handler (generic IEEE expansion) or the packed fast path computed in place.
-template <int K, int VAR> __device__ __noinline__ HState<float> h_div_fast(HState<float> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la,
-                                                                         uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint32_t left,
-                                                                         uint32_t flags, uint32_t tree) {
-    typedef float T;
-    typedef VecOf<float>::type V;
-    const U32x4 w = *code;
-    V b;
-    if constexpr (VAR & 2) b = splat<T>(w1);
-    else b = *LDSP(T, lds0 + la);
-    const V num = K == 4 ? st.acc : b, den = K == 4 ? b : st.acc;
-    if (__builtin_expect(__ballot(!div_operands_safe(num, den)) != 0ull, 0))
-        [[clang::musttail]] return h_chain<T, &b_bin<T, K, VAR, false>>(st, lds0, code, outp, la, w1, w23, okp, ldo, left, flags, tree);
-    st.acc = div_safe(num, den);
-    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
-    [[clang::musttail]] return arg_next<T>(w1, w23)(st, lds0, code + 1, outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, left, flags, tree);
-}
 // ---- superinstructions (de_bind.h, fuse_tree): la = LDS address of row A | int8 (push row - row A) << 24
 #define DE_ROW_BYTES ((DE_TBLK + 1) * 16)
 static_assert(DE_ROW_BYTES == DE_ROW_BYTES_C, "row stride");
@@ -879,6 +812,165 @@ template <typename T, int K, bool CST, bool OUT, bool PUSH, bool TB = false> __d
     st.acc = bin_apply<T, K, TB>(x, b);
     if constexpr (OUT) hpoison<T>(st.poison, st.acc);
     return st;
+}
+// ---- FAST-PATH-ONLY handlers (Float32 cos / exp / sin, exact division) ------------------------------------------------------
+// The wave-uniform range test comes first and a wavefront that fails it tail-calls the FULL handler of the same instruction (same
+// arguments, nothing modified yet; a spill it may already have written is written again with the same value), which repeats the
+// test and resolves it per element.  With the slow paths (OCML's Payne-Hanek reduction, the ldexp form of exp, the generic IEEE
+// division) out of the function the argument is dead after its last use and the result is computed in place: no v_mov of the
+// accumulator around the body (4-5 of them before: 6-10 % of the handler).  Two phases, so that every handler shape (plain,
+// fused with a spill / a row test, fused with the end of the tree) can place its tail call between them:
+//   un_pretest: the part of the arithmetic the range test reads (x log2 e | the multiple of pi), and the test;
+//   un_finish : the rest.  Same operations in the same order as un_apply's fast paths: the same bits.
+struct UnPre { DeF2 ta, tb, ka, kb; }; // exp: ta, tb = x log2 e;  trig: ta, tb = the multiple n, ka, kb = the magic sums (parity)
+template <int K, bool TB> __device__ __forceinline__ bool un_pretest(VecOf<float>::type x, UnPre &p) {
+    const DeF2 xa = {x[0], x[1]}, xb = {x[2], x[3]};
+    if constexpr (K == 1) {
+        p.ta = xa * DE_F2(0x1.715476p+0f);
+        p.tb = xb * DE_F2(0x1.715476p+0f);
+        if constexpr (TB) return false; // turbo exp has no slow path
+        else return __ballot(any_abs_exceeds_f32x4(p.ta[0], p.ta[1], p.tb[0], p.tb[1], DE_EXP_DIRECT_BOUND_T)) != 0ull;
+    } else {
+        constexpr bool SIN = K == 2;
+        const DeF2 ta = SIN ? xa * DE_F2(DE_TRIG_INV_PI) : __builtin_elementwise_fma(xa, DE_F2(DE_TRIG_INV_PI), DE_F2(0.5f));
+        const DeF2 tb = SIN ? xb * DE_F2(DE_TRIG_INV_PI) : __builtin_elementwise_fma(xb, DE_F2(DE_TRIG_INV_PI), DE_F2(0.5f));
+        p.ka = ta + DE_F2(DE_TRIG_MAGIC);
+        p.kb = tb + DE_F2(DE_TRIG_MAGIC);
+        p.ta = p.ka - DE_F2(DE_TRIG_MAGIC);
+        p.tb = p.kb - DE_F2(DE_TRIG_MAGIC);
+        return __ballot(any_abs_exceeds_f32x4(p.ta[0], p.ta[1], p.tb[0], p.tb[1], DE_TRIG_FAST_BOUND_M)) != 0ull;
+    }
+}
+template <int K, bool TB> __device__ __forceinline__ VecOf<float>::type un_finish(VecOf<float>::type x, const UnPre &p) {
+    typedef VecOf<float>::type V;
+    const DeF2 xa = {x[0], x[1]}, xb = {x[2], x[3]};
+    if constexpr (K == 1) {
+        const DeF2 a = turbo_exp_f32x2(xa, p.ta), b = turbo_exp_f32x2(xb, p.tb);
+        return V{a[0], a[1], b[0], b[1]};
+    } else {
+        constexpr bool SIN = K == 2;
+        DeF2 sa = trig_poly_f32x2<SIN, TB>(xa, p.ta), sb = trig_poly_f32x2<SIN, TB>(xb, p.tb);
+        if constexpr (!TB) { // exact mode: results within 2^-12 of +-pi/2 are exactly +-1 (de_device_ops.h)
+#ifndef DE_TRIG_NO_EXTREMUM_FIX
+            const DeF2 ra = trig_reduced_f32x2<SIN, TB>(xa, p.ta), rb = trig_reduced_f32x2<SIN, TB>(xb, p.tb); // (common subexpressions of trig_poly)
+            const DeF2 za = ra * ra, zb = rb * rb;
+            const bool near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(za[0], za[1]), zb[0]), zb[1]) > (0x1.3bd3ccp+1f - 8.0e-4f);
+            if (__ballot(near) != 0ull) {
+                sa[0] = trig_extremum_fix(ra[0], sa[0]); sa[1] = trig_extremum_fix(ra[1], sa[1]);
+                sb[0] = trig_extremum_fix(rb[0], sb[0]); sb[1] = trig_extremum_fix(rb[1], sb[1]);
+            }
+#endif
+        }
+        const DeF2 ya = fast_trig_sign_f32x2(sa, p.ka), yb = fast_trig_sign_f32x2(sb, p.kb);
+        return V{ya[0], ya[1], yb[0], yb[1]};
+    }
+}
+#define HFAST_ARGS HState<float> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, \
+                   uint32_t left, uint32_t flags, uint32_t tree
+#define HFAST_PASS st, lds0, code, outp, la, w1, w23, okp, ldo, left, flags, tree
+#define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, lds0, code + 1, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, left, flags, tree)
+// the end of a tree behind a fast-path body: what h_chain_end does (T = float)
+#define HFAST_END_TAIL()                                                                                                    \
+    {                                                                                                                       \
+        typedef float T;                                                                                                    \
+        const U32x4 wn = code[1];                                                                                           \
+        const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);                                               \
+        *reinterpret_cast<__attribute__((address_space(1))) VecOf<float>::type *>(row + lds0) = st.acc;                     \
+        HTREE_END_TAIL(wn, code + 2);                                                                                       \
+    }
+// cos / exp / sin on the accumulator or a row (VAR as in b_un)
+template <int K, int VAR, bool TB> __device__ __noinline__ HState<float> h_un_fast(HFAST_ARGS) {
+    typedef float T;
+    const U32x4 w = *code;
+    VecOf<float>::type x = st.acc;
+    if constexpr (VAR & 2) x = *LDSP(T, lds0 + la);
+    UnPre p;
+    if (__builtin_expect(un_pretest<K, TB>(x, p), 0)) [[clang::musttail]] return h_chain<T, &b_un<T, K, VAR, TB>>(HFAST_PASS);
+    st.acc = un_finish<K, TB>(x, p);
+    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
+    HFAST_NEXT(w);
+}
+// ... as the last instruction of a tree (the end-fused form of b_un<K, 1>: accumulator operand, tested result)
+template <int K, bool TB> __device__ __noinline__ HState<float> h_un_end_fast(HFAST_ARGS) {
+    typedef float T;
+    UnPre p;
+    if (__builtin_expect((flags != 0u) | un_pretest<K, TB>(st.acc, p), 0)) [[clang::musttail]] return h_chain_end<T, &b_un<T, K, 1, TB>>(HFAST_PASS);
+    st.acc = un_finish<K, TB>(st.acc, p);
+    hpoison<T>(st.poison, st.acc);
+    HFAST_END_TAIL()
+}
+// ... fused with a spill of the accumulator and / or the validity test of its row operand (b_unrow_f)
+template <int K, bool OUT, bool PUSH, bool CHK, bool TB> __device__ __noinline__ HState<float> h_unrow_fast(HFAST_ARGS) {
+    typedef float T;
+    const U32x4 w = *code;
+    const uint32_t a = lds0 + la;
+    if constexpr (PUSH) *LDSP(T, push_addr(a)) = st.acc; // first, as in b_unrow_f (the full handler would write it again: same value)
+    const VecOf<float>::type x = *LDSP(T, PUSH ? row_a(a) : a);
+    UnPre p;
+    if (__builtin_expect(un_pretest<K, TB>(x, p), 0)) [[clang::musttail]] return h_chain<T, &b_unrow_f<T, K, OUT, PUSH, CHK, TB>>(HFAST_PASS);
+    if constexpr (CHK) hpoison<T>(st.poison, x);
+    st.acc = un_finish<K, TB>(x, p);
+    if constexpr (OUT) hpoison<T>(st.poison, st.acc);
+    HFAST_NEXT(w);
+}
+// The exact Float32 divisions (K = 4: acc / operand, 5: operand / acc; VAR as in b_bin) likewise: range test, then either the
+// tail call into the full handler (generic IEEE expansion) or the packed fast path computed in place.
+template <int K, int VAR> __device__ __noinline__ HState<float> h_div_fast(HFAST_ARGS) {
+    typedef float T;
+    typedef VecOf<float>::type V;
+    const U32x4 w = *code;
+    V b;
+    if constexpr (VAR & 2) b = splat<T>(w1);
+    else b = *LDSP(T, lds0 + la);
+    const V num = K == 4 ? st.acc : b, den = K == 4 ? b : st.acc;
+    if (__builtin_expect(__ballot(!div_operands_safe(num, den)) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_bin<T, K, VAR, false>>(HFAST_PASS);
+    st.acc = div_safe(num, den);
+    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
+    HFAST_NEXT(w);
+}
+// ... as the last instruction of a tree (the end-fused forms of b_bin<K, 1> / <K, 3>: tested result)
+template <int K, bool CST> __device__ __noinline__ HState<float> h_div_end_fast(HFAST_ARGS) {
+    typedef float T;
+    typedef VecOf<float>::type V;
+    V b;
+    if constexpr (CST) b = splat<T>(w1);
+    else b = *LDSP(T, lds0 + la);
+    const V num = K == 4 ? st.acc : b, den = K == 4 ? b : st.acc;
+    if (__builtin_expect((flags != 0u) | (__ballot(!div_operands_safe(num, den)) != 0ull), 0))
+        [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, CST ? 3 : 1, false>>(HFAST_PASS);
+    st.acc = div_safe(num, den);
+    hpoison<T>(st.poison, st.acc);
+    HFAST_END_TAIL()
+}
+// ... fused with the validity test of the row operand (b_binrowc) / with the load of row A, a constant or row B as the other
+// operand and possibly a spill (b_bin2): the exact divisions among the superinstructions
+template <int K, bool OUT> __device__ __noinline__ HState<float> h_divrowc_fast(HFAST_ARGS) {
+    typedef float T;
+    typedef VecOf<float>::type V;
+    const U32x4 w = *code;
+    const V b = *LDSP(T, lds0 + la);
+    const V num = K == 4 ? st.acc : b, den = K == 4 ? b : st.acc;
+    if (__builtin_expect(__ballot(!div_operands_safe(num, den)) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_binrowc<T, K, OUT, false>>(HFAST_PASS);
+    hpoison<T>(st.poison, b);
+    st.acc = div_safe(num, den);
+    if constexpr (OUT) hpoison<T>(st.poison, st.acc);
+    HFAST_NEXT(w);
+}
+template <int K, bool CST, bool OUT, bool PUSH> __device__ __noinline__ HState<float> h_div2_fast(HFAST_ARGS) {
+    typedef float T;
+    typedef VecOf<float>::type V;
+    const U32x4 w = *code;
+    const uint32_t a0 = lds0 + la, a = PUSH ? row_a(a0) : a0;
+    if constexpr (PUSH) *LDSP(T, push_addr(a0)) = st.acc; // first, as in b_bin2: row B may be this very slot (the full handler would write it again: same value)
+    const V x = *LDSP(T, a);
+    V b;
+    if constexpr (CST) b = splat<T>(w1);
+    else b = *LDSP(T, a + w1);
+    const V num = K == 4 ? x : b, den = K == 4 ? b : x;
+    if (__builtin_expect(__ballot(!div_operands_safe(num, den)) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_bin2<T, K, CST, OUT, PUSH, false>>(HFAST_PASS);
+    st.acc = div_safe(num, den);
+    if constexpr (OUT) hpoison<T>(st.poison, st.acc);
+    HFAST_NEXT(w);
 }
 // generic handlers: de_opcode in la[31:24].  SRC: 0 row, 1 const, 2 acc.  INJ: Inf-injection of the fused deg1 kernels.
 template <typename T, int SRC, bool INJ> __device__ __forceinline__ HState<T> b_gen(HARGS) {
@@ -990,19 +1082,6 @@ template <typename T, bool TB> __global__ void de_fill_handlers(uint64_t *t) {
     t[BOP_CHECK_ACC] = (uint64_t)&h_chain<T, &b_check_acc<T>>;
     HB(0) HB(1) HB(2) HB(3) HB(4) HB(5)
     HU(0) HU(1) HU(2)
-    if constexpr (sizeof(T) == 4) { // Float32: fast-path-only forms of the hot unary handlers (h_un_fast; turbo exp has no slow path)
-#define HUF(K) t[BOP_UN_BASE + 4 * K + 0] = (uint64_t)&h_un_fast<K, 0, TB>; t[BOP_UN_BASE + 4 * K + 1] = (uint64_t)&h_un_fast<K, 1, TB>; \
-               t[BOP_UN_BASE + 4 * K + 2] = (uint64_t)&h_un_fast<K, 2, TB>; t[BOP_UN_BASE + 4 * K + 3] = (uint64_t)&h_un_fast<K, 3, TB>;
-        HUF(0) HUF(2)
-        if constexpr (!TB) { HUF(1) }
-#undef HUF
-        if constexpr (!TB) { // exact divisions (turbo: x * rcp(y), no slow path)
-#define HDF(K) t[BOP_BIN_BASE + 4 * K + 0] = (uint64_t)&h_div_fast<K, 0>; t[BOP_BIN_BASE + 4 * K + 1] = (uint64_t)&h_div_fast<K, 1>; \
-               t[BOP_BIN_BASE + 4 * K + 2] = (uint64_t)&h_div_fast<K, 2>; t[BOP_BIN_BASE + 4 * K + 3] = (uint64_t)&h_div_fast<K, 3>;
-            HDF(4) HDF(5)
-#undef HDF
-        }
-    }
     t[BOP_GEN_ROW] = (uint64_t)&h_chain<T, &b_gen<T, 0, false>>;
     t[BOP_GEN_CONST] = (uint64_t)&h_chain<T, &b_gen<T, 1, false>>;
     t[BOP_GEN_ACC] = (uint64_t)&h_chain<T, &b_gen<T, 2, false>>;
@@ -1043,6 +1122,30 @@ template <typename T, bool TB> __global__ void de_fill_handlers(uint64_t *t) {
 #undef TBC
 #undef TB1
 #undef TBF
+    if constexpr (sizeof(T) == 4) { // Float32: the fast-path-only forms (h_*_fast above) replace the full handlers in the table
+#define HUF(K) t[BOP_UN_BASE + 4 * K + 0] = (uint64_t)&h_un_fast<K, 0, TB>; t[BOP_UN_BASE + 4 * K + 1] = (uint64_t)&h_un_fast<K, 1, TB>; \
+               t[BOP_UN_BASE + 4 * K + 2] = (uint64_t)&h_un_fast<K, 2, TB>; t[BOP_UN_BASE + 4 * K + 3] = (uint64_t)&h_un_fast<K, 3, TB>; \
+               t[TOPX_ENDV_BASE + 12 + K] = (uint64_t)&h_un_end_fast<K, TB>;
+#define HURF1(K, O, P) t[top_unrow(K, O, P, false)] = (uint64_t)&h_unrow_fast<K, O, P, false, TB>; t[top_unrow(K, O, P, true)] = (uint64_t)&h_unrow_fast<K, O, P, true, TB>;
+#define HURF(K) HURF1(K, false, false) HURF1(K, false, true) HURF1(K, true, false) HURF1(K, true, true)
+        HUF(0) HUF(2) HURF(0) HURF(2)
+        if constexpr (!TB) { // (turbo exp and the turbo divisions have no slow path)
+            HUF(1) HURF(1)
+#define HDF(K) t[BOP_BIN_BASE + 4 * K + 0] = (uint64_t)&h_div_fast<K, 0>; t[BOP_BIN_BASE + 4 * K + 1] = (uint64_t)&h_div_fast<K, 1>; \
+               t[BOP_BIN_BASE + 4 * K + 2] = (uint64_t)&h_div_fast<K, 2>; t[BOP_BIN_BASE + 4 * K + 3] = (uint64_t)&h_div_fast<K, 3>; \
+               t[TOPX_ENDV_BASE + K * 2] = (uint64_t)&h_div_end_fast<K, false>; t[TOPX_ENDV_BASE + K * 2 + 1] = (uint64_t)&h_div_end_fast<K, true>; \
+               t[top_binrowc(K, false)] = (uint64_t)&h_divrowc_fast<K, false>; t[top_binrowc(K, true)] = (uint64_t)&h_divrowc_fast<K, true>;
+#define HD2(K, C, O) t[top_bin2(K, C, O, false)] = (uint64_t)&h_div2_fast<K, C, O, false>; t[top_bin2(K, C, O, true)] = (uint64_t)&h_div2_fast<K, C, O, true>;
+#define HD2K(K) HD2(K, false, false) HD2(K, false, true) HD2(K, true, false) HD2(K, true, true)
+            HDF(4) HDF(5) HD2K(4) HD2K(5)
+#undef HD2K
+#undef HD2
+#undef HDF
+        }
+#undef HURF
+#undef HURF1
+#undef HUF
+    }
 #undef TBK
 }
 

@@ -108,7 +108,7 @@ def test_asmpatch_relaxes_only_the_entry_wait_of_eval_handlers():
             first.setdefault(name, ins)
             if re.match(r"(scratch_|flat_|global_|buffer_)", ins):
                 vmem[name] = True
-    handlers = {n: i for n, i in first.items() if re.match(r"_ZN2de(7h_chainI|7h_paramI|9h_un_fastI|10h_div_fastI)", n)}  # (h_un_fast / h_div_fast: fast-path-only Float32 cos / exp / sin and exact divisions)
+    handlers = {n: i for n, i in first.items() if re.match(r"_ZN2de(7h_chainI|7h_paramI|9h_un_fastI|10h_div_fastI|12h_unrow_fastI|14h_divrowc_fastI|11h_div2_fastI)", n)}  # (h_un_fast / h_div_fast: fast-path-only Float32 cos / exp / sin and exact divisions)
     others = {n: i for n, i in first.items() if n not in handlers and n.startswith("_ZN2de") and "kernel" not in n and "fill_handlers" not in n}
     assert len(handlers) > 300 and others
     relaxed = {n for n, i in handlers.items() if i == "s_waitcnt expcnt(0) lgkmcnt(0)"}
@@ -118,7 +118,7 @@ def test_asmpatch_relaxes_only_the_entry_wait_of_eval_handlers():
     assert all(i == "s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)" for n, i in handlers.items() if n not in relaxed)
     # ... except h_tree_end, which only stores: relaxed too, while its out-of-line twin for the rare store modes is not
     # (and the end-fused last-instruction handlers h_chain_end<body>, relaxed where the same two conditions hold)
-    ends = {n: i for n, i in others.items() if ("10h_tree_endI" in n or "11h_chain_endI" in n) and i == "s_waitcnt expcnt(0) lgkmcnt(0)"}
+    ends = {n: i for n, i in others.items() if ("10h_tree_endI" in n or "11h_chain_endI" in n or "13h_un_end_fastI" in n or "14h_div_end_fastI" in n) and i == "s_waitcnt expcnt(0) lgkmcnt(0)"}
     assert sum("10h_tree_endI" in n for n in ends) == 2 and sum("11h_chain_endI" in n for n in ends) >= 20
     assert all(i == "s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)" for n, i in others.items() if n not in ends), others
     assert sum("15h_tree_end_slowI" in n for n in others) == 2

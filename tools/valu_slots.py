@@ -191,6 +191,18 @@ def table(obj, ty="float", turbo=False):
         m = re.search(r"de::h_div_fast<(\d), (\d)>\(", full)  # ... and of the exact Float32 divisions
         if m:
             fast[f"h_bin<float, {m.group(1)}, {m.group(2)}, false>"] = code
+            continue
+        m = re.search(r"de::h_unrow_fast<(\d), (true|false), (true|false), (true|false), (true|false)>\(", full)  # ... and their fused forms
+        if m:
+            fast["h_unrow_f<float, %s, %s, %s, %s, %s>" % m.groups()] = code
+            continue
+        m = re.search(r"de::h_divrowc_fast<(\d), (true|false)>\(", full)
+        if m:
+            fast["h_binrowc<float, %s, %s, false>" % m.groups()] = code
+            continue
+        m = re.search(r"de::h_div2_fast<(\d), (true|false), (true|false), (true|false)>\(", full)
+        if m:
+            fast["h_bin2<float, %s, %s, %s, %s, false>" % m.groups()] = code
     if ty == "float":
         by_short.update(fast)
     names, counts = handler_names(ty, turbo)
