@@ -146,7 +146,7 @@ def cpu_baseline(trees, ops, X_host, budget_s=11.0, budget_1t_s=7.0):
                 julia_probe=julia_probe())
 
 
-def valu_ceiling(pop, n_trees, units, kernel_ms, turbo=False):
+def valu_ceiling(pop, n_trees, units, kernel_ms, turbo=False, complete=None):
     """The binding ceiling of the eval kernel (SURVEY.md §8d "secondary ceiling"): VALU issue slots per
     tree-wavefront = the fused program's dispatch histogram x the ISA slot count of every handler
     (profiles/valu_slots.json, generated by tools/valu_slots.py from the shipped code object)."""
@@ -159,7 +159,15 @@ def valu_ceiling(pop, n_trees, units, kernel_ms, turbo=False):
     lib = api.library()
     hist = {}
     n_disp = 0
-    for t in range(n_trees):
+    n_all = n_trees
+    if complete is not None:  # early exit: incomplete trees are (mostly) not evaluated — the floor is that of the complete ones
+        n_trees = int(np.count_nonzero(complete))
+        units = units * n_trees / max(n_all, 1)
+        if n_trees == 0:
+            return None
+    for t in range(n_all):
+        if complete is not None and not complete[t]:
+            continue
         n = lib.de_program_dump(pop._h, t, None, 0, 3)
         if n <= 0:
             return None
@@ -197,7 +205,9 @@ def valu_ceiling(pop, n_trees, units, kernel_ms, turbo=False):
     tree_waves = units / samples_per_wave
     simds, peak, sustained = 256 * 4, 2.4e9, 2.08e9  # MI355X: 256 CUs x 4 SIMDs; peak engine clock; clock an all-VALU loop sustains
     floor_ms = tree_waves * per_tree_wave / (simds * peak) * 1e3
-    return dict(simd_cycles_per_tree_wave=per_tree_wave, dispatches_per_tree=n_disp / n_trees, samples_per_wave=samples_per_wave,
+    return dict(trees_counted=n_trees, trees_counted_note="complete trees only (the others leave the kernel at their first flagged workgroup: "
+                "early exit); their partial evaluation is real work the floor does not contain" if complete is not None else "all",
+                simd_cycles_per_tree_wave=per_tree_wave, dispatches_per_tree=n_disp / n_trees, samples_per_wave=samples_per_wave,
                 clock_ghz=2.4, simds=simds, floor_ms=floor_ms, frac=floor_ms / kernel_ms,
                 sustained_clock_ghz=2.08, floor_ms_at_sustained_clock=floor_ms * peak / sustained,
                 frac_at_sustained_clock=floor_ms * peak / sustained / kernel_ms, dispatches_without_cycle_count=missing,
@@ -222,6 +232,7 @@ def main():
                     help="EvalContext(turbo=true): the relaxed-accuracy Float32 operators (DE_OPT_TURBO) for the whole run; "
                          "without it the plain-eval workloads time the exact mode and report turbo in a `turbo` sub-object")
     ap.add_argument("--no-turbo-leg", action="store_true", help="skip the secondary turbo timing (profiling runs: one kernel variant per process)")
+    ap.add_argument("--no-full-eval-leg", action="store_true", help="skip the secondary timing without the early exit (DE_OPT_FULL_EVAL)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -417,6 +428,7 @@ def main():
         kernel_ms[-1] = ctx.last_kernel_ms() if args.steps <= 64 else None
     barrier()
     elapsed = time.perf_counter() - t0
+    ok_main = ok.clone()  # this rank's flags of the timed (exact / --turbo) steps: the secondary legs reuse the buffer
     if world > 1:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -446,6 +458,29 @@ def main():
         kt = [k for k in kt if k is not None]
         turbo_res = dict(ms_per_step=1e3 * el_t / args.steps, kernel_ms_avg=float(np.mean(kt)) if kt else 1e3 * el_t / args.steps,
                          complete_fraction=float(ok.float().mean().item()), pop=pop_t)
+
+    full_res = None
+    if not args.no_full_eval_leg and not (is_param or is_grad or is_lossgrad or is_loss):
+        # the same steps WITHOUT the early exit (DE_OPT_FULL_EVAL: every tree on every sample, what rounds 1-2 timed)
+        ecf = api.EvalContext(turbo=bool(args.turbo), full_eval=True)
+        pop_f = api.Population(trees, ops, np.float32, n_features=5, eval_context=ecf, ctx=ctx)
+
+        def step_f():
+            ctx.check(lib.de_eval(ctx._h, pop_f._h, X.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
+        for _ in range(args.warmup):
+            step_f()
+        barrier()
+        t0f = time.perf_counter()
+        for _ in range(args.steps):
+            step_f()
+        barrier()
+        el_f = time.perf_counter() - t0f
+        if world > 1:
+            tf = torch.tensor([el_f], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            torch.distributed.all_reduce(tf, op=torch.distributed.ReduceOp.MAX)
+            el_f = float(tf.item())
+        full_res = dict(ms_per_step=1e3 * el_f / args.steps, kernel_ms=ctx.last_kernel_ms(), flags_equal=bool(torch.equal(ok, ok_main)))
+        pop_f.close()
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -478,6 +513,15 @@ def main():
             k_eff = plan["trees_per_chunk"]
             b_unit = F_FEATURES * ELEM / k_eff + ELEM
         plain_eval = not (is_param or is_grad or is_lossgrad)
+        # Early exit (the reference's @return_on_nonfinite_array, at tree granularity here): a tree found incomplete is not
+        # evaluated by the workgroups that start afterwards, and its row is unspecified.  The roofline is priced on
+        # what MUST move: the tree-samples of the trees that came out complete (a lower bound of what the launch evaluated; the
+        # partial evaluation of the others is not credited).  `all_units` restates it for every tree-sample of the job — the
+        # count the node-evals/s metric uses, as the reference's own benchmark does for its early-exiting evaluator.
+        okh = ok_main.cpu().numpy().astype(bool)
+        complete_frac = float(okh.mean())
+        units_all = units
+        units = units_all * complete_frac
         alg_bytes = b_unit * units
         achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
         single = BYTES_PER_TREE_SAMPLE_SINGLE * units / (k_avg_ms * 1e-3) / 1e9
@@ -493,21 +537,27 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["desc"], "workload_key": args.workload, "trees_per_gpu": n_per_gpu, "n_samples": N, "n_features": 5,
                        "nodes_per_tree": 20, "operators": "+ - / * cos exp", "sharding": f"tree-sharded x{world}", "flag_gather": gather_via,
-                       "complete_fraction": float(flags.float().mean().item())},
+                       "complete_fraction": float(flags.float().mean().item()),
+                       "early_exit": "EvalContext.early_exit = true (the reference's default): a tree is not evaluated by workgroups that start "
+                                     "after its flag went to 0 (include/de_hip.h DE_OPT_EARLY_EXIT; `full_evaluation` = the same steps with DE_OPT_FULL_EVAL)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": ctx.last_kernel_name(), "kernel_ms_avg": k_avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         "units": "tree-samples of the COMPLETE trees of this launch (early exit: see config.early_exit)",
+                         "all_units": {"tree_samples": units_all, "achieved": b_unit * units_all / (k_avg_ms * 1e-3) / 1e9,
+                                       "frac": b_unit * units_all / (k_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "note": "SURVEY §8d per-unit figure x EVERY tree-sample of the job (the metric's count): not what moved"},
                          "algorithmic_bytes_per_tree_sample": b_unit, "k_eff_trees_per_x_tile": k_eff,
                          "single_tree_equivalent": {"bytes_per_tree_sample": BYTES_PER_TREE_SAMPLE_SINGLE,
                                                     "achieved": single, "frac": single / HBM_PEAK_GBS},
-                         "valu": valu_ceiling(pop, len(trees), units, k_avg_ms) if plain_eval else None,
+                         "valu": valu_ceiling(pop, len(trees), units_all, k_avg_ms, complete=okh) if plain_eval else None,
                          "note": "X tile reused by k_eff trees from LDS: HBM traffic ~= the output; the kernel is "
                                  "VALU/scalar-issue bound (DESIGN.md §Roofline)"},
         }
         res["config"]["turbo"] = bool(args.turbo)
         if args.turbo and plain_eval:
-            res["roofline"]["valu"] = valu_ceiling(pop, len(trees), units, k_avg_ms, turbo=True)
+            res["roofline"]["valu"] = valu_ceiling(pop, len(trees), units_all, k_avg_ms, turbo=True, complete=okh)
         if turbo_res is not None:
             tk = turbo_res["kernel_ms_avg"]
             res["turbo"] = {"option": "EvalContext(turbo=true) = DE_OPT_TURBO: relaxed-accuracy Float32 / exp cos sin (<= 1e-6 rel; "
@@ -515,7 +565,12 @@ def main():
                             "ms_per_step": turbo_res["ms_per_step"], "value": total_nodes * N / (turbo_res["ms_per_step"] * 1e-3),
                             "kernel_ms_avg": tk, "roofline_frac": alg_bytes / (tk * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "complete_fraction": turbo_res["complete_fraction"],
-                            "valu": valu_ceiling(turbo_res["pop"], len(trees), units, tk, turbo=True)}
+                            "valu": valu_ceiling(turbo_res["pop"], len(trees), units_all, tk, turbo=True, complete=okh)}
+        if full_res is not None:
+            res["full_evaluation"] = {"option": "DE_OPT_FULL_EVAL: no early exit, every tree evaluated on every sample (rounds 1-2 timed this)",
+                                      "ms_per_step": full_res["ms_per_step"], "kernel_ms_last": full_res["kernel_ms"],
+                                      "value": total_nodes * N / (full_res["ms_per_step"] * 1e-3), "flags_equal_to_early_exit": full_res["flags_equal"],
+                                      "roofline_frac": b_unit * units_all / (full_res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if not args.no_cpu_baseline and world == 1 and not is_param:  # reported at N=1 only (rank 0)
             Ns = min(N, 10**6)
             Xh = np.asfortranarray(X[:, :Ns].t().contiguous().cpu().numpy().T)

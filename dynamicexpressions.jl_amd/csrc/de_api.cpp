@@ -398,6 +398,12 @@ static void write_imm(Instr &ins, int dtype, double v) {
         ins.imm.f32 = (float)v;
     } else ins.imm.f64 = v;
 }
+// Early exit at tree granularity (kernels: a workgroup does not evaluate the trees whose flag is already 0).  DE_NO_TREE_SKIP=1
+// restores the evaluate-everything behaviour for A/B measurements (the option bit DE_OPT_FULL_EVAL does the same per program).
+static bool tree_skip_enabled() {
+    static const bool on = [] { const char *v = getenv("DE_NO_TREE_SKIP"); return !(v && *v == '1'); }();
+    return on;
+}
 static bool finite_in(int dtype, double v) { return dtype == DE_F32 ? std::isfinite((float)v) : std::isfinite(v); }
 
 static void rebind(de_program *p) {
@@ -527,6 +533,9 @@ static void make_chained(de_program *p) {
             if (i == i0 && prev_fused) name_next(p->ccode[h - 2], handler); // ... and in the previous tree's last instruction, which steps over its end record
         }
         put(p->ccode[h + (size_t)(i1 - i0)], (uint32_t)t, 0u, 0u); // end record (operand word: the tree's index, informational)
+        // the record in front of the tree (head record / previous tree's end record) is its HEADER: its immediate = the number of
+        // instruction records of the tree, which is what h_tree_skip needs to step over a tree that is not evaluated
+        put(p->ccode[h - 1], t == 0 ? 0u : (uint32_t)(t - 1), (uint32_t)(i1 - i0), 0u);
         name_next(p->ccode[h + (size_t)(i1 - i0) - 1], p->end_handler);
         prev_fused = ev_ok;
     }
@@ -1045,6 +1054,10 @@ int de_program_verify(const de_program_t *p) {
         for (int64_t t = 0; t < p->n_trees; t++) {
             const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1], h = p->ccode_off[(size_t)t];
             if (h != i0 + (int32_t)t + 1) return bad("chained offset", t, h, (uint64_t)i0);
+            { // the header record (in front of the tree) carries the tree's record count: h_tree_skip steps over the tree with it
+                const BoundInstr &hd = p->ccode[(size_t)h - 1];
+                if ((f32 ? hd.arg : hd.lo) != (uint32_t)(i1 - i0)) return bad("tree header does not carry the tree's length", t, 0, f32 ? hd.arg : hd.lo);
+            }
             for (int32_t i = i0; i <= i1; i++) {
                 const BoundInstr &r = p->ccode[(size_t)(h + (i - i0))];
                 const BoundInstr &q = p->ccode[(size_t)(h + (i - i0) - 1)]; // a record's handler is named by the record in front of it
@@ -1368,6 +1381,7 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
         a.class_base = pa->class_base;
     }
     a.early_exit = (p->options & DE_OPT_EARLY_EXIT) != 0;
+    a.skip_flagged = a.early_exit && !(p->options & DE_OPT_FULL_EVAL) && tree_skip_enabled();
     a.turbo = (p->options & DE_OPT_TURBO) != 0;
     a.threaded = p->threaded && !direct;
     a.direct = direct;
@@ -2199,6 +2213,7 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
     g.generic_code = p->d_gcode;
     g.e.code_off = nullptr;
     g.e.n_trees = (int32_t)p->n_trees;
+    g.e.skip_flagged = !(p->options & DE_OPT_FULL_EVAL) && tree_skip_enabled(); // (the gradient entry points always test validity)
     g.e.n_slots = p->n_slots;
     g.e.uses_params = p->uses_params;
     g.e.X = sX.dev;
@@ -2403,6 +2418,7 @@ static int loss_grad_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N
     g.generic_code = p->d_gcode;
     g.e.code_off = p->d_gcode_off;
     g.e.n_trees = (int32_t)p->n_trees;
+    g.e.skip_flagged = !(p->options & DE_OPT_FULL_EVAL) && tree_skip_enabled(); // (the gradient entry points always test validity)
     g.e.n_slots = p->n_slots;
     g.e.uses_params = p->uses_params;
     g.e.X = sX.dev;

@@ -33,6 +33,7 @@ template <typename T> struct GArgs {
     int32_t F, P, n_trees, trees_per_chunk, n_chunks, n_slots, mode;
     int32_t FX; // threaded kernels: rows of X; F - FX further leaf rows hold the parameters gathered by class (0 elsewhere)
     int32_t classes_is_i64, class_base, uses_params, check;
+    int32_t skip_flagged; // early exit at tree granularity: the trees of a chunk whose flag is already 0 are not evaluated (de_kernels.hip)
     int32_t diff_g0; // >= 0: eval_diff mode — single component diff_g0, dense [n_trees, ld_out] output
     // fused loss + pullback (de_eval_loss_grad): instead of storing x and d[k] the kernel reduces
     //   sum_j w_j l(x_j - y_j)   and   sum_j w_j l'(x_j - y_j) d_k[j]   per wavefront
@@ -53,6 +54,18 @@ template <typename T> struct GArgs {
 };
 
 constexpr int GPTAB_MAX = 2048;
+// Early exit at tree granularity (src/Evaluate.jl:26-32, src/EvaluateDerivative.jl:230-243: the reference returns at the first
+// non-finite array): bit i = the i-th tree of this workgroup's chunk was already flagged incomplete when the workgroup started —
+// by a workgroup that ran earlier or by the host (non-finite constant).  Its values / Jacobian rows are unspecified then (SURVEY
+// §8a), fused reductions of it are NaN (the finish kernels look at the flag), so the chunk loop steps over it.  Chunks have <= 64
+// trees (else: no skipping).  Agent-scope load: past this CU's vector cache.
+template <typename IDS> __device__ __forceinline__ uint64_t gskip_mask(const uint8_t *ok, IDS tree_ids, int t0, int t1, int enabled) {
+    if (!enabled || t1 - t0 > 64) return 0ull;
+    const int i = t0 + (int)(threadIdx.x & 63);
+    uint8_t f = 1;
+    if (i < t1) f = __hip_atomic_load(ok + (tree_ids ? tree_ids[i] : i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __ballot(f == 0);
+}
 template <typename T> __device__ __forceinline__ T gimm(uint32_t w2, uint32_t w3);
 template <> __device__ __forceinline__ float gimm<float>(uint32_t w2, uint32_t) { return __uint_as_float(w2); }
 template <> __device__ __forceinline__ double gimm<double>(uint32_t w2, uint32_t w3) {
@@ -223,8 +236,11 @@ __device__ __forceinline__ GTileMap gmap_block(uint32_t bid, int32_t n_chunks, i
     return m;
 }
 
-__device__ __noinline__ void gflag_incomplete(uint8_t *ok) {
-    if ((threadIdx.x & 63) == 0) *ok = 0;
+__device__ __noinline__ void gflag_incomplete(uint8_t *ok, int agent) { // agent scope (written through): workgroups that start later skip the tree
+    if ((threadIdx.x & 63) == 0) {
+        if (agent) __hip_atomic_store(ok, (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *ok = 0;
+    }
 }
 
 constexpr int GBLK = 256;

@@ -72,7 +72,9 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
     const int param_seed0 = a.mode != DE_GRAD_CONSTANT ? -g0 : -0x40000000;
     const int const_seed0 = a.mode == DE_GRAD_CONSTANT ? -g0 : (a.mode == DE_GRAD_BOTH ? P + F - g0 : -0x40000000);
 
+    const uint64_t skip = gskip_mask(a.ok, (const int32_t *)nullptr, t0, t1, a.skip_flagged && a.check);
     for (int tree = t0; tree < t1; ++tree) {
+        if ((skip >> (tree - t0)) & 1ull) continue; // already incomplete (early exit)
         const int G = a.diff_g0 >= 0 ? 1 : n_grad[tree];
         if (a.diff_g0 < 0 && g0 >= G && g0 > 0) continue; // window without a component of this tree (window 0 always runs: x, flag)
         int pc = code_off[tree];
@@ -249,7 +251,7 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
                     if (g0 + k < G) gp[k] = d[k];
             }
         }
-        if (a.check && __ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree);
+        if (a.check && __ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree, a.skip_flagged);
     }
 }
 
@@ -311,6 +313,7 @@ static hipError_t launch_grad_t(const GradArgs &ga, int windows, hipStream_t str
     a.n_classes = e.n_classes > 0 ? e.n_classes : 1;
     a.uses_params = e.uses_params ? 1 : 0;
     a.check = ga.diff_direction >= 0 ? 0 : 1;
+    a.skip_flagged = e.skip_flagged ? 1 : 0;
     a.diff_g0 = ga.diff_direction >= 0 ? ga.P + ga.diff_direction : -1;
     a.code = ga.generic_code;
     a.tree_ids = nullptr;

@@ -484,7 +484,9 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
     const uint32_t stage0 = wave_base + (uint32_t)F * grow_bytes<T>(); // the wave's slot area, free between trees
 
     const ConstI32Ptr tree_ids = (ConstI32Ptr)(uintptr_t)a.tree_ids;
+    const uint64_t skip = gskip_mask(a.ok, tree_ids, t0, t1, a.skip_flagged);
     for (int ti = t0; ti < t1; ++ti) {
+        if ((skip >> (ti - t0)) & 1ull) continue; // already incomplete (early exit)
         const int tree = tree_ids[ti];
         const int G = n_grad[tree];
         if (g0 >= G && g0 > 0) continue; // window without a component of this tree (window 0 always runs: x, flag)
@@ -515,7 +517,7 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
         } else {
             g_epilogue_store<T, GC>(st, a.out ? a.out + (int64_t)tree * a.ld_out : nullptr, a.grad + grad_off[tree], a.N, G, g0, (int64_t)tm.tile, stage0);
         }
-        if (__ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree);
+        if (__ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree, a.skip_flagged);
     }
 }
 
@@ -570,6 +572,7 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStrea
     a.n_classes = e.n_classes > 0 ? e.n_classes : 1;
     a.uses_params = e.uses_params ? 1 : 0;
     a.check = 1;
+    a.skip_flagged = e.skip_flagged ? 1 : 0;
     a.diff_g0 = -1;
     a.loss_mode = 0;
     a.y = a.w = nullptr;

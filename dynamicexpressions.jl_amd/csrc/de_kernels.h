@@ -53,6 +53,7 @@ struct EvalArgs {
     int32_t classes_is_i64, class_base;
     // flags
     bool early_exit;
+    bool skip_flagged;        // early exit at tree granularity: workgroups do not evaluate trees whose flag is already 0 (off: DE_OPT_FULL_EVAL)
     bool turbo;               // DE_OPT_TURBO (threaded kernel, Float32): relaxed-accuracy cos / exp / sin / division handlers
     // threaded-code variant: `code` holds handler OFFSETS (relative to handler_base) in word 0 and
     // LDS byte offsets in the low 24 bits of word 1

@@ -58,6 +58,9 @@ template <typename T> struct KArgs {
     uint32_t cls_row_off; // parametric populations (threaded kernel): LDS byte offset of the class row (h_param)
     // vectorised staging of the X tile (threaded kernel): X 16-byte aligned with ldX == F
     int32_t x_vec;
+    // early exit at tree granularity (threaded kernel): a workgroup reads the flags of its chunk's trees once and does not
+    // evaluate the trees already known to be incomplete (h_tree_skip); needs trees_per_chunk <= 64
+    int32_t skip_flagged;
     uint32_t f_magic; // ceil(2^32 / F) for F > 1 (e / F == umulhi(e, f_magic) while e * F < 2^32), 0 for F == 1
 };
 
@@ -290,8 +293,11 @@ __device__ __noinline__ void store_ragged(T *o, VG<T, G> v, int64_t remaining, i
     constexpr int VW = VecOf<T>::W;
     FOR_G FOR_I if ((int64_t)g * plane + i < remaining) o[g * plane + i] = v.v[g][i];
 }
-__device__ __noinline__ void flag_incomplete(uint8_t *ok) {
-    if ((threadIdx.x & 63) == 0) *ok = 0;
+__device__ __noinline__ void flag_incomplete(uint8_t *ok, int agent) { // agent scope: workgroups that start later skip the tree (early exit)
+    if ((threadIdx.x & 63) == 0) {
+        if (agent) __hip_atomic_store(ok, (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *ok = 0;
+    }
 }
 
 // DIRECT = true: wide feature matrices whose X tile does not fit in LDS — feature operands are
@@ -350,12 +356,18 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
     const int t0 = tm.chunk * a.trees_per_chunk;
     const int t1 = (t0 + a.trees_per_chunk < a.n_trees) ? t0 + a.trees_per_chunk : a.n_trees;
     const bool full = base + TILE <= a.N;
-
+    uint64_t skip = 0ull; // trees of the chunk already known to be incomplete (see de_eval_threaded_kernel): not evaluated
+    if (EE && a.skip_flagged && t1 - t0 <= 64) {
+        const int i = t0 + (tid & 63);
+        const uint8_t f = i < t1 ? __hip_atomic_load(a.ok + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)1;
+        skip = __ballot(f == 0);
+    }
 
     int pe = code_off[t0];
     for (int tree = t0; tree < t1; ++tree) {
         int pc = pe;
         pe = code_off[tree + 1];
+        if ((skip >> (tree - t0)) & 1ull) continue;
         V acc[G];
         FOR_G FOR_I acc[g][i] = T(0);
         T poison = T(0);
@@ -454,7 +466,7 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
             store_ragged<T, G>(o, av, a.N - (base + tid * VW), GT);
         }
         // ---- completion flag: one ballot per wave, one byte store per failing wave
-        if (__ballot(poison != poison) != 0ull) flag_incomplete(a.ok + tree);
+        if (__ballot(poison != poison) != 0ull) flag_incomplete(a.ok + tree, a.skip_flagged);
     }
 }
 
@@ -518,8 +530,13 @@ template <typename T> using BodyFn = HState<T> (*)(HState<T>, uint32_t, typename
 //   tree  : index of the tree being evaluated (the end handlers count it up)
 // argument words of a handler: (la, w1, w23) = the record as loaded { x, y, z:w }
 //   Float32: w1 = imm, w23 = next handler      Float64: w1 = next handler (low half), w23 = imm
-template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t, uint32_t);
-enum : uint32_t { HF_RETURN_EACH = 1u << 31, HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu };
+template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t, uint32_t);
+enum : uint32_t { HF_RETURN_EACH = 1u << 31, HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu,
+                  HF_SLOW = HF_RETURN_EACH | HF_SLOW_STORE | HF_NO_STORE, // any of them: the out-of-line end of a tree
+                  // no workgroup reads the flags while the kernel runs (no early exit at tree granularity): plain flag stores.  Otherwise
+                  // they are agent-scope (written through, so that workgroups on other XCDs see them too) — which would cost a full
+                  // evaluation a memory write per incomplete tree and wavefront
+                  HF_PLAIN_FLAG = 1u << 28 };
 template <typename T> __device__ __forceinline__ HandlerFn<T> arg_next(uint32_t w1, uint64_t w23);
 template <> __device__ __forceinline__ HandlerFn<float> arg_next<float>(uint32_t, uint64_t w23) { return reinterpret_cast<HandlerFn<float>>(w23); }
 template <> __device__ __forceinline__ HandlerFn<double> arg_next<double>(uint32_t w1, uint64_t) {
@@ -530,8 +547,8 @@ template <> __device__ __forceinline__ uint32_t arg_imm<float>(uint32_t w1, uint
 template <> __device__ __forceinline__ uint64_t arg_imm<double>(uint32_t, uint64_t w23) { return w23; }
 #define DE_ROW_BYTES_C ((DE_TBLK + 1) * 16) // LDS row stride of the threaded kernel: DE_TBLK 16-byte vectors + one of padding
 // `code` points at the record of the NEXT instruction; (la, w1, w23) are this instruction's record
-#define HCHAIN_ARGS HState<T> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint32_t left, uint32_t flags, uint32_t tree
-#define HCHAIN_NEXT_AT(W, NEXT) [[clang::musttail]] return arg_next<T>(w1, w23)(st, lds0, NEXT, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, left, flags, tree)
+#define HCHAIN_ARGS HState<T> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint64_t skip, uint32_t left, uint32_t flags, uint32_t tree
+#define HCHAIN_NEXT_AT(W, NEXT) [[clang::musttail]] return arg_next<T>(w1, w23)(st, lds0, NEXT, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags, tree)
 #define HCHAIN_NEXT(W) HCHAIN_NEXT_AT(W, code + 1)
 template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain(HCHAIN_ARGS) {
     const U32x4 w = *code;
@@ -561,15 +578,40 @@ __device__ __forceinline__ bool poison_set(const double &p) { return p != p; }
 // tools/exp_dispatch_cost.py: returning to a per-tree loop in the kernel (index load, first-record load, two dependent
 // scalar-cache round trips per tree) cost ~250 SIMD cycles per tree and wavefront, a quarter of the headline's time.
 // HF_RETURN_EACH (fused loss): the kernel owns the epilogue and re-enters the stream per tree.
-// the rest of a tree's end: flag byte, last tree of the chunk?, clear the state, on to the next tree (W = its first record)
-#define HTREE_END_TAIL(REC, NEXT)                                                                            \
-    if (__builtin_expect(__ballot(poison_set(st.poison)) != 0ull, 0))                                        \
-        *reinterpret_cast<__attribute__((address_space(1))) uint8_t *>(okp + tree) = 0; /* every lane the same byte */ \
+// EARLY EXIT (src/Evaluate.jl:26-32: the reference stops evaluating a tree at its first non-finite intermediate array; SURVEY §8a:
+// with ok == false only the flag is contractual).  `skip` = the trees from the current one on whose flag was already 0 when this
+// workgroup started (bit 0: the current tree; the kernel reads the flags once per chunk, DE_OPT_FULL_EVAL / early_exit = false: 0).
+// Such a tree is not evaluated: the end of its predecessor tail-calls h_tree_skip, which walks the HEADER records — the
+// record in front of a tree's first instruction (the previous tree's end record / the head record) carries the number of records of
+// the tree — to the next tree that still has to run.  One scalar load per skipped tree instead of its evaluation.
+template <typename T> __device__ __forceinline__ uint32_t hdr_len(const U32x4 &h) { return sizeof(T) == 4 ? h.y : h.z; } // the immediate's (low) word
+template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS) { // code -> the header of tree `tree`, which is skipped
+    const U32x4 h = *code;
+    const ConstU4Ptr nh = code + 1 + hdr_len<T>(h); // its end record = the next tree's header
+    if (left <= 1u) return st;
+    left -= 1u;
+    tree += 1u;
+    skip >>= 1;
+    if (skip & 1ull) [[clang::musttail]] return h_tree_skip<T>(st, lds0, nh, outp, la, w1, w23, okp, ldo, skip, left, flags, tree);
+    const U32x4 hn = nh[0], w = nh[1];
+    [[clang::musttail]] return arg_next<T>(hn.y, ((uint64_t)hn.w << 32) | hn.z)(st, lds0, nh + 2, outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, skip, left, flags,
+                                                                             tree);
+}
+// the rest of a tree's end: flag byte, last tree of the chunk?, clear the state, on to the next tree (W = its first record,
+// HDR = the address of its header record) unless that one is skipped
+#define HTREE_END_TAIL(REC, NEXT, HDR)                                                                       \
+    if (__builtin_expect(__ballot(poison_set(st.poison)) != 0ull, 0)) { /* every lane the same byte */         \
+        if (flags & HF_PLAIN_FLAG) *reinterpret_cast<__attribute__((address_space(1))) uint8_t *>(okp + tree) = 0; \
+        else __hip_atomic_store(reinterpret_cast<__attribute__((address_space(1))) uint8_t *>(okp + tree), (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* visible to the workgroups that start later */ \
+    }                                                                                                        \
     if (__builtin_expect(left <= 1u, 0)) return st;                                                          \
     DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = T(0);                                        \
     st.poison = typename PoisonOf<T>::type{};                                                                \
     left -= 1u;                                                                                              \
     tree += 1u;                                                                                              \
+    skip >>= 1;                                                                                              \
+    if (__builtin_expect((skip & 1ull) != 0ull, 0))                                                          \
+        [[clang::musttail]] return h_tree_skip<T>(st, lds0, HDR, outp, la, w1, w23, okp, ldo, skip, left, flags, tree); \
     HCHAIN_NEXT_AT(REC, NEXT)
 typedef __attribute__((address_space(1))) char *GPtr; // global, not flat: a flat store also ties up lgkmcnt
 // The other store modes (flags != 0), out of line so that h_tree_end itself is straight-line code: HF_RETURN_EACH (fused loss:
@@ -587,15 +629,15 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_A
     } else if (st.acc[0] == T(123456.789)) {
         *reinterpret_cast<__attribute__((address_space(1))) T *>(row + lds0) = st.acc[0];
     }
-    HTREE_END_TAIL(w, code + 1);
+    HTREE_END_TAIL(w, code + 1, code - 1);
 }
 template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) {
     typedef typename VecOf<T>::type V;
-    if (__builtin_expect(flags != 0u, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, lds0, code, outp, la, w1, w23, okp, ldo, left, flags, tree);
+    if (__builtin_expect((flags & HF_SLOW) != 0u, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags, tree);
     const U32x4 w = *code;
     const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo); // wave-uniform: the store takes it as its scalar base
     *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0) = st.acc; // full tile, aligned rows
-    HTREE_END_TAIL(w, code + 1);
+    HTREE_END_TAIL(w, code + 1, code - 1);
 }
 // The last instruction of a tree and its end in one dispatch (make_chained picks it when the tree finishes in a validity-tested
 // hot operator: ~85 % of the bench population): the body, then what h_tree_end does.  The stream keeps its end record — this
@@ -603,15 +645,15 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) 
 // handler, as the end record does.
 template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain_end(HCHAIN_ARGS) {
     typedef typename VecOf<T>::type V;
-    if (__builtin_expect(flags != 0u, 0)) {
+    if (__builtin_expect((flags & HF_SLOW) != 0u, 0)) {
         st = BODY(st, lds0 + la, arg_imm<T>(w1, w23));
-        [[clang::musttail]] return h_tree_end_slow<T>(st, lds0, code + 1, outp, la, w1, w23, okp, ldo, left, flags, tree);
+        [[clang::musttail]] return h_tree_end_slow<T>(st, lds0, code + 1, outp, la, w1, w23, okp, ldo, skip, left, flags, tree);
     }
     const U32x4 w = code[1];
     st = BODY(st, lds0 + la, arg_imm<T>(w1, w23));
     const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);
     *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0) = st.acc;
-    HTREE_END_TAIL(w, code + 2);
+    HTREE_END_TAIL(w, code + 2, code);
 }
 
 template <typename T> __device__ __forceinline__ HState<T> b_load_row(HARGS) { st.acc = *LDSP(T, la); return st; }
@@ -651,7 +693,12 @@ __device__ __forceinline__ bool div_operands_safe(VecOf<float>::type a, VecOf<fl
     asm("v_min_f32_e64 %0, %1, |%2|" : "=v"(lo) : "v"(lo), "v"(b[3]));
     return (hi < 0x1p+40f) & (lo > 0x1p-40f);
 }
-// the correctly rounded quotients of operands that passed div_operands_safe: reciprocal, one Newton step, two residual corrections
+// the correctly rounded quotients of operands that passed div_operands_safe: reciprocal, one Newton step, ONE residual correction.
+// (The compiler's expansion runs a second correction; round 3 dropped it.  Markstein's theorem: with y = RN(1/d) and q0 within an
+// ulp of n/d, RN(q0 + (n - d q0) y) — the residual is exact in an FMA — IS RN(n/d).  tools/probe/div_probe.hip checked on gfx950 that
+// the Newton-refined v_rcp_f32 equals RN(1/d) for ALL 2^23 significands, and the five-operation sequence against the IEEE quotient on
+// 1.4e11 random pairs with exponents in [-40, 40] and 1.6e9 quotients placed at rounding boundaries: 0 differences,
+// profiles/r3_div_probe.json.  tests/test_gpu_ops.py keeps the bit-identity test against IEEE division.)
 __device__ __forceinline__ VecOf<float>::type div_safe(VecOf<float>::type a, VecOf<float>::type b) {
     VecOf<float>::type q;
     DE_UNROLL for (int h = 0; h < 2; h++) {
@@ -660,9 +707,7 @@ __device__ __forceinline__ VecOf<float>::type div_safe(VecOf<float>::type a, Vec
         const DeF2 e = __builtin_elementwise_fma(-d, y, DE_F2(1.0f));
         y = __builtin_elementwise_fma(e, y, y);
         DeF2 t = n * y;
-        DeF2 r = __builtin_elementwise_fma(-d, t, n);
-        t = __builtin_elementwise_fma(r, y, t);
-        r = __builtin_elementwise_fma(-d, t, n);
+        const DeF2 r = __builtin_elementwise_fma(-d, t, n);
         t = __builtin_elementwise_fma(r, y, t);
         q[2 * h] = t[0];
         q[2 * h + 1] = t[1];
@@ -866,9 +911,9 @@ template <int K, bool TB> __device__ __forceinline__ VecOf<float>::type un_finis
     }
 }
 #define HFAST_ARGS HState<float> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, \
-                   uint32_t left, uint32_t flags, uint32_t tree
-#define HFAST_PASS st, lds0, code, outp, la, w1, w23, okp, ldo, left, flags, tree
-#define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, lds0, code + 1, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, left, flags, tree)
+                   uint64_t skip, uint32_t left, uint32_t flags, uint32_t tree
+#define HFAST_PASS st, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags, tree
+#define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, lds0, code + 1, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags, tree)
 // the end of a tree behind a fast-path body: what h_chain_end does (T = float)
 #define HFAST_END_TAIL()                                                                                                    \
     {                                                                                                                       \
@@ -876,7 +921,7 @@ template <int K, bool TB> __device__ __forceinline__ VecOf<float>::type un_finis
         const U32x4 wn = code[1];                                                                                           \
         const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);                                               \
         *reinterpret_cast<__attribute__((address_space(1))) VecOf<float>::type *>(row + lds0) = st.acc;                     \
-        HTREE_END_TAIL(wn, code + 2);                                                                                       \
+        HTREE_END_TAIL(wn, code + 2, code);                                                                                     \
     }
 // cos / exp / sin on the accumulator or a row (VAR as in b_un)
 template <int K, int VAR, bool TB> __device__ __noinline__ HState<float> h_un_fast(HFAST_ARGS) {
@@ -894,7 +939,7 @@ template <int K, int VAR, bool TB> __device__ __noinline__ HState<float> h_un_fa
 template <int K, bool TB> __device__ __noinline__ HState<float> h_un_end_fast(HFAST_ARGS) {
     typedef float T;
     UnPre p;
-    if (__builtin_expect((flags != 0u) | un_pretest<K, TB>(st.acc, p), 0)) [[clang::musttail]] return h_chain_end<T, &b_un<T, K, 1, TB>>(HFAST_PASS);
+    if (__builtin_expect(((flags & HF_SLOW) != 0u) | un_pretest<K, TB>(st.acc, p), 0)) [[clang::musttail]] return h_chain_end<T, &b_un<T, K, 1, TB>>(HFAST_PASS);
     st.acc = un_finish<K, TB>(st.acc, p);
     hpoison<T>(st.poison, st.acc);
     HFAST_END_TAIL()
@@ -936,7 +981,7 @@ template <int K, bool CST> __device__ __noinline__ HState<float> h_div_end_fast(
     if constexpr (CST) b = splat<T>(w1);
     else b = *LDSP(T, lds0 + la);
     const V num = K == 4 ? st.acc : b, den = K == 4 ? b : st.acc;
-    if (__builtin_expect((flags != 0u) | (__ballot(!div_operands_safe(num, den)) != 0ull), 0))
+    if (__builtin_expect(((flags & HF_SLOW) != 0u) | (__ballot(!div_operands_safe(num, den)) != 0ull), 0))
         [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, CST ? 3 : 1, false>>(HFAST_PASS);
     st.acc = div_safe(num, den);
     hpoison<T>(st.poison, st.acc);
@@ -1247,30 +1292,48 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     }
 
     if (t0 >= t1) return;
+    // the trees of this chunk whose flag is already 0 (bit i: tree t0 + i): found incomplete by a workgroup that ran earlier (or
+    // by the host: a non-finite constant) — the reference stops evaluating such a tree at its first non-finite array
+    // (src/Evaluate.jl:26-32), this kernel stops at the next workgroup.  Agent scope: past this CU's vector cache.
+    uint64_t skip = 0ull;
+    if (a.skip_flagged) {
+        const int i = t0 + (tid & 63);
+        const uint8_t f = i < t1 ? __hip_atomic_load(a.ok + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)1;
+        skip = __ballot(f == 0);
+    }
     const uint64_t ldo = (uint64_t)a.ld_out * sizeof(T);
     if constexpr (!LOSS) {
         // ONE call per chunk: the trees t0..t1 are consecutive in the stream and every tree's end record (h_tree_end)
         // stores its results and runs on into the next tree; the call returns after the last one.
-        const ConstU4Ptr rec = code + code_off[t0];
+        int first = t0;
+        if (skip & 1ull) { // leading skipped trees
+            if (~skip == 0ull) return;
+            const int n = __builtin_ctzll(~skip);
+            first += n;
+            skip >>= n;
+            if (first >= t1) return;
+        }
+        const ConstU4Ptr rec = code + code_off[first];
         HState<T> st;
         DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
         st.poison = typename PoisonOf<T>::type{};
         const int64_t in_tile = a.N - base < (int64_t)TILE ? a.N - base : (int64_t)TILE;
-        const uint32_t flags = a.vec_store == 2 ? HF_NO_STORE : ((full && a.vec_store) ? 0u : (HF_SLOW_STORE | (uint32_t)in_tile));
+        const uint32_t flags = (a.vec_store == 2 ? HF_NO_STORE : ((full && a.vec_store) ? 0u : (HF_SLOW_STORE | (uint32_t)in_tile))) | (a.skip_flagged ? 0u : HF_PLAIN_FLAG);
         const uint64_t outp = (uint64_t)(uintptr_t)(a.out + base) - (uint64_t)(uint32_t)(uintptr_t)smem_raw;
         const U32x4 hp = rec[-1], hd = *rec; // the first handler's address is in the record in front (the previous tree's end record / the head record)
         st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, lds0, rec + 1, outp, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, (uint64_t)(uintptr_t)a.ok,
-                                                              ldo, (uint32_t)(t1 - t0), flags, (uint32_t)t0);
+                                                              ldo, skip, (uint32_t)(t1 - first), flags, (uint32_t)first);
         (void)st;
     } else {
         for (int tree = t0; tree < t1; ++tree) {
+            if ((skip >> (tree - t0)) & 1ull) continue; // already incomplete: its loss is NaN whatever the partials hold (de_loss_finish_kernel)
             // code_off[tree] = the record of the tree's first instruction; h_tree_end returns here (HF_RETURN_EACH)
             const ConstU4Ptr rec = code + code_off[tree];
             HState<T> st;
             DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
             st.poison = typename PoisonOf<T>::type{};
             const U32x4 hp = rec[-1], hd = *rec;
-            st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, lds0, rec + 1, 0ull, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, 0ull, 0ull, 1u,
+            st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, lds0, rec + 1, 0ull, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, 0ull, 0ull, 0ull, 1u,
                                                                   (uint32_t)HF_RETURN_EACH, (uint32_t)tree);
             // sum_j w_j * l(out_j - y_j) over this wave's 64*VW samples -> one partial per (tile, tree, wave)
             T s = T(0);
@@ -1281,7 +1344,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             }
             s = wave_sum_to_lane63(s);
             if ((tid & 63) == 63) a.partial[((int64_t)tm.tile * a.n_trees + tree) * TWAVES + (tid >> 6)] = s;
-            if (__ballot(poison_set(st.poison)) != 0ull) flag_incomplete(a.ok + tree);
+            if (__ballot(poison_set(st.poison)) != 0ull) flag_incomplete(a.ok + tree, a.skip_flagged);
         }
     }
 }
@@ -1408,6 +1471,9 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
     plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc);
     a.trees_per_chunk = tpc;
     a.n_chunks = nch;
+    a.skip_flagged = (e.early_exit && e.skip_flagged && tpc <= 64) ? 1 : 0;
+    a.x_vec = 0;
+    a.f_magic = 0;
 
     const int64_t tile_groups = (a.n_tiles + 7) / 8;
     const int64_t blocks = tile_groups * 8 * a.n_chunks;
@@ -1501,6 +1567,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc);
     a.trees_per_chunk = tpc;
     a.n_chunks = nch;
+    a.skip_flagged = (e.early_exit && e.skip_flagged && tpc <= 64) ? 1 : 0; // (the skip mask of a chunk is one 64-bit ballot)
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // rows: X, spill slots, then (parametric) the class row [+ the table-pointer row for Float32] of h_param

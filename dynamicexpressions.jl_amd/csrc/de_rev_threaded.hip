@@ -364,7 +364,9 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
         for (int i = RT_LANE(); i < staged; i += 64) dst[(int64_t)i * 4] = *RLDS(T, stage0 + (uint32_t)i * (uint32_t)sizeof(T));
         staged = 0;
     };
+    const uint64_t skip = gskip_mask(a.ok, tree_ids, t0, t1, a.skip_flagged);
     for (int ti = t0; ti < t1; ++ti) {
+        if ((skip >> (ti - t0)) & 1ull) continue; // already incomplete (early exit): its reductions are NaN whatever the partials hold
         const int tree = tree_ids[ti];
         const int64_t c0 = col_off[tree];
         const int nc = 1 + n_grad[tree];
@@ -404,7 +406,7 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
             st = reinterpret_cast<RHandlerFn<T>>(hbase + hd.x)(st, rec + 1, hd.y, rrec_imm<T>(hd), hbase);
         }
         const bool bad = (st.vpoison != st.vpoison) || (nc > 1 && st.gpoison != st.gpoison);
-        if (__ballot(bad) != 0ull) gflag_incomplete(a.ok + tree);
+        if (__ballot(bad) != 0ull) gflag_incomplete(a.ok + tree, a.skip_flagged);
     }
     if (staged > 0) flush();
 }
@@ -460,6 +462,7 @@ hipError_t DE_RT_NAME(rev_thr_launch_)(const GradArgs &ga, int group, hipStream_
     a.n_classes = e.n_classes > 0 ? e.n_classes : 1;
     a.uses_params = e.uses_params ? 1 : 0;
     a.check = 1;
+    a.skip_flagged = e.skip_flagged ? 1 : 0;
     a.diff_g0 = -1;
     a.loss_mode = 1 + ga.loss->kind;
     a.y = static_cast<const T *>(ga.loss->y);

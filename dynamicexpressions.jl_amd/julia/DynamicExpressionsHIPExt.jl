@@ -176,23 +176,26 @@ end
 # `occurrence_map` gives, per expanded slot, the index of the unique constant (get_scalar_constants order): the shim keeps
 # occurrence slots equal (set_population_constants!) and sums their gradient rows.
 function flatten_cse!(nodes::Vector{TapeNode}, tree::AbstractExpressionNode{T}, optable) where {T}
-    count = IdDict{Any,Int}()
     isconst = IdDict{Any,Bool}()
     nparents = IdDict{Any,Int}()
-    function survey(n, first::Bool)
-        count[n] = get(count, n, 0) + 1
+    # every node OBJECT once: nparents[c] = the number of (parent object, child slot) pairs that hold c — more than one
+    # distinct parent, or the same parent twice, is what makes a subtree shared in its own right (a node reached only
+    # through an already-shared ancestor has one).  Mirrors `multi_use` of the Python twin (node.py flatten_graph).
+    function survey(n)
+        haskey(isconst, n) && return nothing
         if n.degree == 0
             isconst[n] = n.constant
         else
             cs = get_children(n, Int(n.degree))
             for c in cs
-                first && (nparents[c] = get(nparents, c, 0) + 1)   # parent slots seen from distinct parent OBJECTS
-                survey(c, first && count[c] == 0 || !haskey(count, c))
+                nparents[c] = get(nparents, c, 0) + 1
+                survey(c)
             end
             isconst[n] = all(c -> isconst[c], cs)
         end
+        return nothing
     end
-    survey(tree, true)
+    survey(tree)
     defined = IdDict{Any,Int}()
     slot = Ref(0)
     skip(n) = n.degree == 0 ? (n.constant && (slot[] += 1)) : foreach(skip, get_children(n, Int(n.degree)))
@@ -238,24 +241,27 @@ mutable struct HIPContext
     handle::Ptr{Cvoid}
     lock::ReentrantLock
 end
+# Finalizers must not block on a lock a running task may hold: when the lock is taken, the SAME cleanup is registered again
+# (the object survives this collection and the next one retries) — re-arming with `identity` would leak the handle.
+function finalize_context(c::HIPContext)
+    if trylock(c.lock)
+        try
+            c.handle != C_NULL && ccall((:de_ctx_destroy, LIBDE), Cint, (Ptr{Cvoid},), c.handle)
+            c.handle = C_NULL
+        finally
+            unlock(c.lock)
+        end
+    else
+        finalizer(finalize_context, c)
+    end
+    return nothing
+end
 function HIPContext(device::Integer=0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:de_ctx_create, LIBDE), Cint, (Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, h)
     rc == DE_OK || error("de_ctx_create failed: ", unsafe_string(ccall((:de_status_string, LIBDE), Cstring, (Cint,), rc)))
     ctx = HIPContext(h[], ReentrantLock())
-    finalizer(ctx) do c
-        # finalizers must not block on a lock a running task may hold: retry later if it is taken
-        if trylock(c.lock)
-            try
-                c.handle != C_NULL && ccall((:de_ctx_destroy, LIBDE), Cint, (Ptr{Cvoid},), c.handle)
-                c.handle = C_NULL
-            finally
-                unlock(c.lock)
-            end
-        else
-            finalizer(identity, c)  # re-arm: the object survives this collection
-        end
-    end
+    finalizer(finalize_context, ctx)
     return ctx
 end
 """The calling task's context (task-local storage: tasks migrate between threads, `Threads.threadid()` is not a key)."""
@@ -311,6 +317,21 @@ mutable struct HIPPopulation{T}
     n_trees::Int
     n_features::Int
 end
+function finalize_population(p::HIPPopulation)
+    c = p.ctx
+    if trylock(c.lock)
+        try
+            # de_program_destroy synchronises the context's stream: skip it when the context is already gone
+            c.handle != C_NULL && p.handle != C_NULL && ccall((:de_program_destroy, LIBDE), Cint, (Ptr{Cvoid},), p.handle)
+            p.handle = C_NULL
+        finally
+            unlock(c.lock)
+        end
+    else
+        finalizer(finalize_population, p)   # lock taken: the same cleanup again at the next collection (see finalize_context)
+    end
+    return nothing
+end
 function HIPPopulation(
     trees::AbstractVector{<:AbstractExpressionNode{T}}, operators::OperatorEnum, n_features::Integer;
     eval_context::EvalContext=EvalContext(), n_params::Integer=0,
@@ -338,20 +359,7 @@ function HIPPopulation(
     end
     check(ctx, rc)
     pop = HIPPopulation{T}(ctx, h[], length(trees), n_features)
-    finalizer(pop) do p
-        c = p.ctx
-        if trylock(c.lock)
-            try
-                # de_program_destroy synchronises the context's stream: skip it when the context is already gone
-                c.handle != C_NULL && p.handle != C_NULL && ccall((:de_program_destroy, LIBDE), Cint, (Ptr{Cvoid},), p.handle)
-                p.handle = C_NULL
-            finally
-                unlock(c.lock)
-            end
-        else
-            finalizer(identity, p)
-        end
-    end
+    finalizer(finalize_population, pop)
     return pop
 end
 

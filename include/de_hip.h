@@ -82,10 +82,17 @@ typedef enum de_grad_mode {
  * (src/Evaluate.jl:156-181).  bumper/buffer are CPU back-end choices and have
  * no meaning here, except DE_OPT_BUMPER_CHECKS below; turbo maps to DE_OPT_TURBO. */
 enum de_options {
-    /* EvalContext.early_exit (default true).  The GPU never exits early; the bit
-     * selects the FLAG semantics: with it, `ok` is false iff any value the
-     * reference would have tested is non-finite; without it, only constant
-     * folding can clear `ok` (src/Evaluate.jl:305-308,347-354). */
+    /* EvalContext.early_exit (default true).  The bit selects the FLAG semantics:
+     * with it, `ok` is false iff any value the reference would have tested is
+     * non-finite; without it, only constant folding can clear `ok`
+     * (src/Evaluate.jl:305-308,347-354).  And, as in the reference, the exit
+     * itself (@return_on_nonfinite_array, src/Evaluate.jl:26-32), at TREE
+     * granularity: once a tree's flag is 0, workgroups that start afterwards do
+     * not evaluate that tree on their samples, so the out / grad rows of a tree
+     * with ok == 0 are PARTIALLY WRITTEN (unspecified, as the reference's
+     * buffer after its early return, src/Evaluate.jl:350-351; fused losses of
+     * such a tree are NaN).  The flags and every row with ok == 1 do not depend
+     * on it.  DE_OPT_FULL_EVAL below turns the exit off. */
     DE_OPT_EARLY_EXIT = 1u << 0,
     /* The reference's fused 2/3-node kernels decide WHICH leaves are validity
      * tested and where `Inf` is substituted (src/Evaluate.jl:488-691).  They are
@@ -105,6 +112,10 @@ enum de_options {
      * identical except through the documented domain edges (csrc/de_device_ops.h).  Float64, the
      * gradient entry points and wide-X programs ignore the bit (they run the exact operators). */
     DE_OPT_TURBO = 1u << 4,
+    /* Evaluate every tree on every sample even after it is known to be incomplete (no early exit at tree granularity): the
+     * rows of an incomplete tree then hold the values the non-finite intermediates propagate to.  Same flags, same rows where
+     * ok == 1; costs the evaluation of trees whose results nobody may read (55 % of the benchmark's random population). */
+    DE_OPT_FULL_EVAL = 1u << 5,
     DE_OPT_DEFAULT = (1u << 0) | (1u << 1) | (1u << 2)
 };
 

@@ -1,0 +1,159 @@
+"""Early exit at tree granularity (`pytest -m gpu`).
+
+The reference stops evaluating a tree at the first non-finite intermediate array (`@return_on_nonfinite_array`,
+src/Evaluate.jl:26-32; per-node `ok` in src/EvaluateDerivative.jl:230-243) and returns a partially evaluated buffer
+(src/Evaluate.jl:350-351); SURVEY.md §8a: with ok == false only the flag is contractual.  The kernels do the same per
+workgroup: a tree whose flag is already 0 when a workgroup starts is not evaluated on that workgroup's samples.  Contract
+tested here, against the evaluate-everything mode (`EvalContext(full_eval=True)` = DE_OPT_FULL_EVAL):
+  * the flags are identical;
+  * every row / Jacobian / fused loss of a COMPLETE tree has the same bits;
+  * rows of incomplete trees are really left alone (a sentinel survives in them) — the exit happens;
+  * fused losses of incomplete trees are NaN in both modes;
+  * early_exit=False never skips (its flags stay true)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import dynamicexpressions_jl_amd as de
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from dynamicexpressions_jl_amd import api as _api
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    _api.library()
+    return _api
+
+
+def _population(n=192, seed=0xEE01):
+    # random bench-style trees + hand-made ones that fail early, late (one sample in the last tile) and never
+    trees = de.synth.random_population(n, seed=seed)
+    x1, x2 = de.Node(feature=1), de.Node(feature=2)
+    ops = de.synth.BENCH_OPERATORS
+    B = {n_: i + 1 for i, n_ in enumerate(ops.binops)}
+    U = {n_: i + 1 for i, n_ in enumerate(ops.unaops)}
+    trees.append(de.Node(U["exp"], de.Node(U["exp"], de.Node(B["*"], x1, de.Node(val=40.0)))))   # overflows on most tiles
+    trees.append(de.Node(B["/"], de.Node(val=1.0), de.Node(B["-"], x2, x2)))                      # 1 / 0 everywhere
+    trees.append(de.Node(B["+"], de.Node(U["cos"], x1), x2))                                      # always complete
+    return trees, ops
+
+
+def _X(N, seed=3):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randn((N, 5), generator=g, device="cuda", dtype=torch.float32).t()
+
+
+@pytest.mark.parametrize("turbo", [False, True])
+def test_eval_flags_and_complete_rows_do_not_depend_on_the_exit(api, turbo):
+    import torch
+    trees, ops = _population()
+    N = 3 * 2**19 + 77  # many more sample tiles than the chip runs at once, ragged tail
+    Xd = _X(N)
+    lib = api.library()
+    res = {}
+    for full in (True, False):
+        pop = api.Population(trees, ops, np.float32, n_features=5, eval_context=api.EvalContext(turbo=turbo, full_eval=full))
+        out = torch.full((len(trees), N), 12345.0, device="cuda", dtype=torch.float32)
+        ok = torch.empty(len(trees), device="cuda", dtype=torch.uint8)
+        pop.ctx.use_torch_stream()
+        pop.ctx.check(lib.de_eval(pop.ctx._h, pop._h, Xd.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
+        torch.cuda.synchronize()
+        res[full] = (out, ok.bool())
+        pop.close()
+    (of, kf), (oe, ke) = res[True], res[False]
+    assert torch.equal(kf, ke)
+    assert 0 < int(kf.sum()) < len(trees)
+    assert torch.equal(of[kf], oe[kf])                      # complete trees: the same bits
+    assert int((of[kf] == 12345.0).sum()) == 0
+    assert int((of[~kf] == 12345.0).sum()) == 0             # full evaluation writes every row ...
+    left_alone = (oe[~ke] == 12345.0).float().mean(dim=1)   # ... the early exit leaves most of an incomplete row alone
+    assert float(left_alone.max()) > 0.9, left_alone
+    assert float(left_alone.mean()) > 0.3, left_alone
+    assert not bool(ke[-2]) and not bool(ke[-3]) and bool(ke[-1])
+
+
+def test_early_exit_false_evaluates_everything(api):
+    import torch
+    trees, ops = _population(64)
+    N = 2**19
+    Xd = _X(N)
+    pop = api.Population(trees, ops, np.float32, n_features=5, eval_context=api.EvalContext(early_exit=False))
+    lib = api.library()
+    out = torch.full((len(trees), N), 12345.0, device="cuda", dtype=torch.float32)
+    ok = torch.empty(len(trees), device="cuda", dtype=torch.uint8)
+    pop.ctx.use_torch_stream()
+    pop.ctx.check(lib.de_eval(pop.ctx._h, pop._h, Xd.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
+    torch.cuda.synchronize()
+    assert bool(ok.bool().all())            # no validity tests, nothing to exit on (src/Evaluate.jl:305-308)
+    assert int((out == 12345.0).sum()) == 0
+
+
+@pytest.mark.parametrize("variable", [True, False, "both"])
+def test_gradients_of_complete_trees_do_not_depend_on_the_exit(api, variable):
+    import torch
+    trees, ops = _population(96, seed=0xEE02)
+    N = 2**18 + 5
+    Xd = _X(N, seed=4)
+    res = {}
+    for full in (True, False):
+        pop = api.Population(trees, ops, np.float32, n_features=5, eval_context=api.EvalContext(full_eval=full))
+        out, grads, ok = pop.eval_grad(Xd, variable=variable)
+        torch.cuda.synchronize()
+        res[full] = (out, grads, ok)
+        pop.close()
+    (of, gf, kf), (oe, ge, ke) = res[True], res[False]
+    assert torch.equal(kf, ke) and 0 < int(kf.sum()) < len(trees)
+    for t in range(len(trees)):
+        if bool(kf[t]):
+            assert torch.equal(of[t], oe[t]), t
+            assert torch.equal(gf[t], ge[t]), t
+
+
+@pytest.mark.parametrize("reverse", ["0", "1"])
+def test_fused_losses_do_not_depend_on_the_exit(api, reverse, monkeypatch):
+    import torch
+    monkeypatch.setenv("DE_LOSS_GRAD_REVERSE", reverse)
+    trees, ops = _population(96, seed=0xEE03)
+    N = 2**18 + 5
+    Xd = _X(N, seed=5)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    y = torch.randn(N, generator=g, device="cuda", dtype=torch.float32)
+    res = {}
+    for full in (True, False):
+        pop = api.Population(trees, ops, np.float32, n_features=5, eval_context=api.EvalContext(full_eval=full))
+        l0, k0 = pop.eval_loss(Xd, y)
+        l1, d1, k1 = pop.eval_loss_grad(Xd, y, variable=False)
+        torch.cuda.synchronize()
+        res[full] = (l0, k0, l1, d1, k1)
+        pop.close()
+    (l0f, k0f, l1f, d1f, k1f), (l0e, k0e, l1e, d1e, k1e) = res[True], res[False]
+    assert torch.equal(k0f, k0e) and torch.equal(k1f, k1e)
+    assert torch.equal(l0f[k0f], l0e[k0f]) and bool(torch.isnan(l0e[~k0e]).all()) and bool(torch.isnan(l0f[~k0f]).all())
+    assert torch.equal(l1f[k1f], l1e[k1f]) and bool(torch.isnan(l1e[~k1e]).all())
+    for t in range(len(trees)):
+        if bool(k1f[t]):
+            assert torch.equal(d1f[t], d1e[t]), t
+        else:
+            assert bool(torch.isnan(d1e[t]).all()), t
+
+
+def test_host_buffers_and_the_flat_switch_kernel(api, monkeypatch):
+    # numpy (host, staged) inputs through the fall-back kernel: same contract
+    monkeypatch.setenv("DE_EVAL_THREADED", "0")
+    trees, ops = _population(40, seed=0xEE04)
+    N = 2**17 + 3
+    X = np.asfortranarray(_X(N, seed=6).cpu().numpy())
+    res = {}
+    for full in (True, False):
+        pop = api.Population(trees, ops, np.float32, n_features=5, eval_context=api.EvalContext(full_eval=full))
+        out, ok = pop.eval(X)
+        res[full] = (out, ok)
+        pop.close()
+    (of, kf), (oe, ke) = res[True], res[False]
+    assert np.array_equal(kf, ke) and 0 < kf.sum() < len(trees)
+    assert np.array_equal(of[kf].view(np.uint32), oe[kf].view(np.uint32))
