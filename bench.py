@@ -525,11 +525,20 @@ def main():
         alg_bytes = b_unit * units
         achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
         single = BYTES_PER_TREE_SAMPLE_SINGLE * units / (k_avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_note = None, "no profiles/pmc_summary.json"
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(prof):  # measured by tools/profile_round.sh with rocprofv3 --pmc (separate passes)
             with open(prof) as fh:
-                traffic = json.load(fh).get(args.workload, {}).get("hbm_bytes_per_launch")
+                pm = json.load(fh)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from make_profiles import kernel_source_hash
+            key = "turbo" if (args.turbo and args.workload == "headline") else args.workload
+            if pm.get("kernel_source_hash") != kernel_source_hash():
+                # the counters were collected with OTHER kernels than the ones running now: not this launch's traffic
+                traffic_note = "profiles/pmc_summary.json is stale (kernel_source_hash differs from the sources of the running library): rerun tools/profile_round.sh"
+            else:
+                traffic = pm.get(key, {}).get("hbm_bytes_per_launch")
+                traffic_note = f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per step, profiles/pmc_summary.json[{key}] (same kernel sources: hash checked)"
         res = {
             "metric": "node-evals/sec", "value": value, "unit": "node-evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -541,7 +550,7 @@ def main():
                        "early_exit": "EvalContext.early_exit = true (the reference's default): a tree is not evaluated by workgroups that start "
                                      "after its flag went to 0 (include/de_hip.h DE_OPT_EARLY_EXIT; `full_evaluation` = the same steps with DE_OPT_FULL_EVAL)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": ctx.last_kernel_name(), "kernel_ms_avg": k_avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "units": "tree-samples of the COMPLETE trees of this launch (early exit: see config.early_exit)",

@@ -677,7 +677,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
             if (node_offsets[t + 1] < node_offsets[t] || const_offsets[t + 1] < const_offsets[t])
                 return fail(ctx, DE_ERR_INVALID_ARG, "offsets not monotone at tree %lld", (long long)t);
         // both lowerings of every tree (plain, and with constant subtrees folded), on host threads
-        struct Lowered { TreeProgram plain, folded; int rc = DE_OK, rcf = DE_OK; std::string why; };
+        struct Lowered { TreeProgram plain, folded; int rc = DE_OK, rcf = DE_OK; bool cse = false; std::string why; };
         std::vector<Lowered> low((size_t)n_trees);
         {
             LowerOptions lof = lo;
@@ -693,6 +693,15 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                             LowerOptions loc = lof;
                             loc.cse = true;
                             L.rcf = lower_tree(cse_nodes + cse_offsets[t], cse_offsets[t + 1] - cse_offsets[t], const_offsets[t + 1] - c0, loc, &L.folded, &L.why);
+                            L.cse = L.rcf == DE_OK;
+                            if (L.rcf == DE_ERR_UNSUPPORTED) {
+                                // the CSE form does not fit (spill slots + shared rows > 16, a share in an unsupported position): the
+                                // expanded tape has the same values and flags (the reference evaluates a shared node once per
+                                // parent), so this tree alone runs expanded instead of failing the whole population
+                                L.folded = TreeProgram();
+                                L.why.clear();
+                                L.rcf = lower_tree(nodes + n0, node_offsets[t + 1] - n0, const_offsets[t + 1] - c0, lof, &L.folded, &L.why);
+                            }
                         } else L.rcf = lower_tree(nodes + n0, node_offsets[t + 1] - n0, const_offsets[t + 1] - c0, lof, &L.folded, &L.why);
                     }
                 } catch (const std::bad_alloc &) { oom = true; }
@@ -739,7 +748,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                 if (low[(size_t)t].rcf != DE_OK)
                     return fail(ctx, low[(size_t)t].rcf, "tree %lld (folded): %s", (long long)t, low[(size_t)t].why.c_str());
                 (void)n1;
-                const bool is_cse = cse_nodes && cse_offsets[t + 1] > cse_offsets[t];
+                const bool is_cse = low[(size_t)t].cse;
                 const de_tape_node_t *src_nodes = is_cse ? cse_nodes + cse_offsets[t] : nodes + n0; // the tape the fold spans index
                 any_cse = any_cse || is_cse;
                 p->n_slots = std::max(p->n_slots, tp.n_slots); // a CSE program keeps one persistent row per shared subtree

@@ -166,7 +166,10 @@ constexpr uint32_t TOPX_END = TOPX_COUNT;
 // unary operator): the stream's end record is then skipped, one dispatch less per tree.  Chosen by make_chained (de_api.cpp).
 constexpr uint32_t TOPX_ENDV_BASE = TOPX_END + 1;                 // + k * 2 + (operand is a constant), k < 6   | 12 + k, k < 3 (unary on acc)
 constexpr uint32_t TOPX_ENDV_COUNT = 15;
-constexpr uint32_t TOPX_TABLE = TOPX_ENDV_BASE + TOPX_ENDV_COUNT;
+// ... and two handlers no record names but every chain can reach (the out-of-line end of a tree, the early-exit walk over skipped
+// trees): in the table so that the host's address-window checks (32-bit offsets; Float64: one 4 GiB window) cover them too
+constexpr uint32_t TOPX_AUX_BASE = TOPX_ENDV_BASE + TOPX_ENDV_COUNT; // + 0: h_tree_end_slow, + 1: h_tree_skip
+constexpr uint32_t TOPX_TABLE = TOPX_AUX_BASE + 2;
 // end variant of a fused / bound handler id, or -1
 constexpr int topx_endv_of(uint32_t id) {
     return (id >= BOP_BIN_BASE && id < BOP_BIN_END && ((id - BOP_BIN_BASE) & 1)) ? (int)(((id - BOP_BIN_BASE) >> 2) * 2 + (((id - BOP_BIN_BASE) >> 1) & 1))

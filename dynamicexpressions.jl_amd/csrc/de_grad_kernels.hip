@@ -434,16 +434,17 @@ __global__ void __launch_bounds__(256) de_by_class_combine_kernel(const ByClassA
 template <typename T>
 __global__ void __launch_bounds__(256) de_pullback_scale_kernel(T *__restrict__ grad, const int64_t *__restrict__ grad_off,
                                                                const int32_t *__restrict__ n_grad, const uint8_t *__restrict__ ok,
-                                                               const T *__restrict__ dY, int64_t N) {
-    const int64_t t = blockIdx.y;
-    const uint32_t G = (uint32_t)n_grad[t];
-    if (G == 0) return;
-    T *__restrict__ g = grad + grad_off[t];
-    const bool complete = ok[t] != 0;
-    const int64_t total = (int64_t)G * N;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t j = e / G;
-        g[e] = complete ? g[e] * dY[j] : M<T>::nan();
+                                                               const T *__restrict__ dY, int64_t N, int64_t n_trees) {
+    for (int64_t t = blockIdx.y; t < n_trees; t += gridDim.y) { // (gridDim.y <= 65535: larger populations stride)
+        const uint32_t G = (uint32_t)n_grad[t];
+        if (G == 0) continue;
+        T *__restrict__ g = grad + grad_off[t];
+        const bool complete = ok[t] != 0;
+        const int64_t total = (int64_t)G * N;
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+            const int64_t j = e / G;
+            g[e] = complete ? g[e] * dY[j] : M<T>::nan();
+        }
     }
 }
 hipError_t launch_pullback_scale(int dtype, void *grad, const int64_t *grad_off, const int32_t *n_grad, const uint8_t *ok,
@@ -451,13 +452,13 @@ hipError_t launch_pullback_scale(int dtype, void *grad, const int64_t *grad_off,
     if (n_trees <= 0 || N <= 0 || max_grad <= 0) return hipSuccess;
     int64_t bx = ((int64_t)max_grad * N + 256 * 8 - 1) / (256 * 8);
     if (bx > 4096) bx = 4096;
-    const dim3 grid((unsigned)bx, (unsigned)n_trees);
+    const dim3 grid((unsigned)bx, (unsigned)(n_trees < 65535 ? n_trees : 65535)); // HIP limits gridDim.y: the kernel strides over trees
     if (dtype == DE_F32)
         hipLaunchKernelGGL(de_pullback_scale_kernel<float>, grid, dim3(256), 0, stream, static_cast<float *>(grad), grad_off, n_grad, ok,
-                           static_cast<const float *>(dY), N);
+                           static_cast<const float *>(dY), N, n_trees);
     else
         hipLaunchKernelGGL(de_pullback_scale_kernel<double>, grid, dim3(256), 0, stream, static_cast<double *>(grad), grad_off, n_grad, ok,
-                           static_cast<const double *>(dY), N);
+                           static_cast<const double *>(dY), N, n_trees);
     return hipGetLastError();
 }
 
@@ -489,6 +490,7 @@ hipError_t grad_handler_table(int dtype, int GC, int VS, uint64_t *table) {
     static uint64_t cache[2][9][3][GOP_MAX];
     static bool have[2][9][3] = {};
     static std::mutex mu; // contexts on several host threads may ask at once
+    { const hipError_t dst = handler_device_check(); if (dst != hipSuccess) return dst; }
     const std::lock_guard<std::mutex> lock(mu);
     const int k = dtype == DE_F32 ? 0 : 1;
     if (!grad_threaded_has(dtype, GC, VS)) return hipErrorInvalidValue;
@@ -536,6 +538,7 @@ hipError_t rev_handler_table(int dtype, uint64_t *table) {
     static uint64_t cache[2][ROP_COUNT];
     static bool have[2] = {false, false};
     static std::mutex mu; // contexts on several host threads may ask at once
+    { const hipError_t dst = handler_device_check(); if (dst != hipSuccess) return dst; }
     const std::lock_guard<std::mutex> lock(mu);
     const int k = dtype == DE_F32 ? 0 : 1;
     if (!have[k]) {

@@ -138,6 +138,8 @@ hipError_t launch_by_class_combine(int dtype, const ByClassArgs &a, hipStream_t 
 hipError_t launch_pullback_scale(int dtype, void *grad, const int64_t *grad_off, const int32_t *n_grad, const uint8_t *ok,
                                  const void *dY, int64_t N, int64_t n_trees, int32_t max_grad, hipStream_t stream);
 
+// One device per process owns the cached handler addresses (de_kernels.hip): hipErrorInvalidDevice for any other current device.
+hipError_t handler_device_check();
 // Threaded-code eval kernel: addresses of the TOPX_TABLE device handlers (cached per process).
 hipError_t eval_handler_table(int dtype, bool turbo, uint64_t *table);
 bool eval_uses_threaded();

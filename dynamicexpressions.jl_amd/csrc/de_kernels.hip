@@ -1132,6 +1132,8 @@ template <typename T, bool TB> __global__ void de_fill_handlers(uint64_t *t) {
     t[BOP_GEN_ACC] = (uint64_t)&h_chain<T, &b_gen<T, 2, false>>;
     t[BOP_GEN_PARAM] = (uint64_t)&h_param<T, TB>;
     t[TOPX_END] = (uint64_t)&h_tree_end<T>;
+    t[TOPX_AUX_BASE + 0] = (uint64_t)&h_tree_end_slow<T>;
+    t[TOPX_AUX_BASE + 1] = (uint64_t)&h_tree_skip<T>;
 #define HEB(K) t[TOPX_ENDV_BASE + K * 2] = (uint64_t)&h_chain_end<T, &b_bin<T, K, 1, TBK(K)>>; t[TOPX_ENDV_BASE + K * 2 + 1] = (uint64_t)&h_chain_end<T, &b_bin<T, K, 3, TBK(K)>>;
     HEB(0) HEB(1) HEB(2) HEB(3) HEB(4) HEB(5)
 #undef HEB
@@ -1517,10 +1519,26 @@ template <typename T, bool TB> static hipError_t fetch_handlers(uint64_t *host_t
     return st;
 }
 
+// Handler addresses are cached per PROCESS and baked into every record of the instruction streams, so they belong to one
+// device's copy of the code object: the library serves one device per process (the deployment model: one process per GPU,
+// INTEGRATION.md).  The first device that asks owns the caches; a context on another device is refused here, explicitly, instead
+// of jumping to addresses of the other device's code object.
+hipError_t handler_device_check() {
+    static int owner = -1;
+    static std::mutex mu;
+    int dev = 0;
+    hipError_t st = hipGetDevice(&dev);
+    if (st != hipSuccess) return st;
+    const std::lock_guard<std::mutex> lock(mu);
+    if (owner < 0) owner = dev;
+    return owner == dev ? hipSuccess : hipErrorInvalidDevice;
+}
+
 hipError_t eval_handler_table(int dtype, bool turbo, uint64_t *table) {
     static uint64_t cache[3][TOPX_TABLE]; // Float32, Float64, Float32 turbo (Float64 has no relaxed operators)
     static bool have[3] = {false, false, false};
     static std::mutex mu; // contexts on several host threads may ask at once
+    { const hipError_t dst = handler_device_check(); if (dst != hipSuccess) return dst; }
     const std::lock_guard<std::mutex> lock(mu);
     const int k = dtype == DE_F32 ? (turbo ? 2 : 0) : 1;
     if (!have[k]) {

@@ -71,8 +71,10 @@ def test_eval_flags_and_complete_rows_do_not_depend_on_the_exit(api, turbo):
     assert torch.equal(of[kf], oe[kf])                      # complete trees: the same bits
     assert int((of[kf] == 12345.0).sum()) == 0
     assert int((of[~kf] == 12345.0).sum()) == 0             # full evaluation writes every row ...
-    left_alone = (oe[~ke] == 12345.0).float().mean(dim=1)   # ... the early exit leaves most of an incomplete row alone
-    assert float(left_alone.max()) > 0.9, left_alone
+    # ... the early exit leaves an incomplete row alone from the second wave of workgroups on (the chip holds ~2800 workgroups
+    # = ~700 of this launch's 3073 sample tiles at once: those start before any flag is known)
+    left_alone = (oe[~ke] == 12345.0).float().mean(dim=1)
+    assert float(left_alone.max()) > 0.6, left_alone
     assert float(left_alone.mean()) > 0.3, left_alone
     assert not bool(ke[-2]) and not bool(ke[-3]) and bool(ke[-1])
 
@@ -133,11 +135,11 @@ def test_fused_losses_do_not_depend_on_the_exit(api, reverse, monkeypatch):
         pop.close()
     (l0f, k0f, l1f, d1f, k1f), (l0e, k0e, l1e, d1e, k1e) = res[True], res[False]
     assert torch.equal(k0f, k0e) and torch.equal(k1f, k1e)
-    assert torch.equal(l0f[k0f], l0e[k0f]) and bool(torch.isnan(l0e[~k0e]).all()) and bool(torch.isnan(l0f[~k0f]).all())
-    assert torch.equal(l1f[k1f], l1e[k1f]) and bool(torch.isnan(l1e[~k1e]).all())
+    assert torch.equal(l0f[k0f].view(torch.int32), l0e[k0f].view(torch.int32)) and bool(torch.isnan(l0e[~k0e]).all()) and bool(torch.isnan(l0f[~k0f]).all())
+    assert torch.equal(l1f[k1f].view(torch.int32), l1e[k1f].view(torch.int32)) and bool(torch.isnan(l1e[~k1e]).all())
     for t in range(len(trees)):
-        if bool(k1f[t]):
-            assert torch.equal(d1f[t], d1e[t]), t
+        if bool(k1f[t]):  # bit patterns: a sum of finite entries may overflow to Inf - Inf = NaN without touching the flag
+            assert torch.equal(d1f[t].view(torch.int32), d1e[t].view(torch.int32)), t
         else:
             assert bool(torch.isnan(d1e[t]).all()), t
 

@@ -318,7 +318,7 @@ def test_strided_buffers_through_the_c_abi(api):
     assert lib.de_eval(ctx._h, pop._h, big.ctypes.data, N, ldX, None, out.ctypes.data, ld_out, ok.ctypes.data) == 0
     X = np.asfortranarray(big[:, :5].T)
     ref, okr = pop.eval(X)
-    np.testing.assert_array_equal(out[:, :N], ref)
+    np.testing.assert_array_equal(out[okr, :N], ref[okr])  # (rows of incomplete trees are unspecified: early exit)
     assert np.all(out[:, N:] == -7.0)  # padding untouched
     np.testing.assert_array_equal(ok.astype(bool), okr)
 
@@ -476,6 +476,8 @@ def test_eval_handlers_of_more_unary_operators_and_max_min(api, monkeypatch):
             monkeypatch.delenv("DE_NO_CONST_UNARY_HOT")
             assert np.array_equal(ka, kb)
             ui = np.uint32 if dtype == np.float32 else np.uint64
+            if ec.early_exit:  # rows of incomplete trees (log / sqrt of negative samples) are unspecified: early exit
+                a, b = a[ka], b[kb]
             m = ~(np.isnan(a) & np.isnan(b))
             np.testing.assert_array_equal(a.view(ui)[m], b.view(ui)[m])
         for t, tree in enumerate(trees):  # IEEE-exact operators: the oracle's bits

@@ -119,3 +119,29 @@ def test_cse_can_be_switched_off(api, monkeypatch):
     ob, kb = b.eval(X)
     assert np.array_equal(ka, kb) and dispatches(api, a) < dispatches(api, b)
     np.testing.assert_array_equal(oa[ka].view(np.uint32), ob[kb].view(np.uint32))
+
+
+def test_graph_that_does_not_fit_the_cse_rows_runs_expanded_instead_of_failing(api):
+    """spill slots + shared rows > 16 used to make de_program_create_cse fail for the WHOLE population although
+    the expanded tape of the same tree lowers fine.  That tree alone now falls back to the expanded lowering."""
+    G = de.GraphNode
+    ops = de.OperatorEnum(binary_operators=("+", "*"), unary_operators=("cos",))
+    feats = [G(feature=1 + i % 3) for i in range(3)]
+
+    def deep(level, k):  # balanced product of operator subtrees: level - 1 spill slots
+        if level == 0:
+            return G(1, G(2, feats[k % 3], G(val=0.5 + 0.01 * k)))
+        return G(2, deep(level - 1, 2 * k), deep(level - 1, 2 * k + 1))
+    shares = [G(1, G(2, feats[i % 3], G(val=1.0 + 0.1 * i))) for i in range(12)]   # cos(x * c_i), each used twice
+    acc = deep(6, 0)
+    for s in shares:
+        acc = G(1, G(1, acc, s), s)
+    small = G(1, shares[0], shares[0])
+    X = de.synth.random_X(3, 700, seed=8, dtype=np.float32)
+    pg = api.Population([acc, small], ops, np.float32, n_features=3)       # used to raise DE_ERR_UNSUPPORTED
+    pe = api.Population([de.break_sharing(acc), de.break_sharing(small)], ops, np.float32, n_features=3)
+    a, ka = pg.eval(X)
+    b, kb = pe.eval(X)
+    assert np.array_equal(ka, kb) and ka.all()
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert dispatches(api, pg) < dispatches(api, pe)   # the small tree still shares

@@ -1,17 +1,20 @@
 #!/usr/bin/env bash
 # Per-round profile collection (run on the GPU box through gpurun):
-#   tools/profile_round.sh <round-tag>
-# -> gpurun_out/profiles_<tag>/ : rocprofv3 --kernel-trace --stats summary of `python bench.py`
-#    (headline workload) and FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, as the pool requires).
+#   tools/profile_round.sh <tag> [workload ...]          (default: every workload of tools/gpu_check.sh + the turbo headline)
+# -> gpurun_out/profiles_<tag>/<workload>/{stats,pmc_fetch,pmc_write}: rocprofv3 --kernel-trace --stats of `python bench.py
+#    --workload W` and FETCH_SIZE / WRITE_SIZE PMC passes — each counter in its own run, never combined with a trace domain
+#    (the pool refuses that).  tools/make_profiles.py condenses the result into profiles/.
 set -u
-TAG=$1
+TAG=$1; shift
+WLS=${*:-"headline turbo C2 C3 C4 C5 C5N C5Ng loss lossgrad C5pb"}
 R=$PWD; export TMPDIR=/tmp; O=$R/gpurun_out/profiles_$TAG; mkdir -p $O; cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o eval -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-turbo-leg > $O/bench_under_rocprof.json 2>$O/stats.log
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o eval -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-turbo-leg > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o eval -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-turbo-leg > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_C3 -o grad -- python $R/bench.py --workload C3 --steps 5 --warmup 1 --no-cpu-baseline --no-turbo-leg > $O/bench_C3_under_rocprof.json 2>>$O/stats.log
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_C3 -o grad -- python $R/bench.py --workload C3 --steps 2 --warmup 1 --no-cpu-baseline --no-turbo-leg > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_C3 -o grad -- python $R/bench.py --workload C3 --steps 2 --warmup 1 --no-cpu-baseline --no-turbo-leg > /dev/null 2>&1
-# the turbo variant of the headline (EvalContext(turbo=true)): kernel stats only
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_turbo -o eval -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --turbo > $O/bench_turbo_under_rocprof.json 2>>$O/stats.log
-find $O -name "*.csv" | head -20
+for wl in $WLS; do
+  args="--workload $wl"; [ $wl = turbo ] && args="--workload headline --turbo"
+  common="--no-cpu-baseline --no-turbo-leg --no-full-eval-leg"
+  mkdir -p $O/$wl
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$wl/stats -o k -- python $R/bench.py $args --steps 5 --warmup 1 $common > $O/$wl/bench_under_rocprof.json 2>$O/$wl/stats.log
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/$wl/pmc_$c -o k -- python $R/bench.py $args --steps 2 --warmup 1 $common > /dev/null 2>$O/$wl/pmc_$c.log
+  done
+  echo "$wl: $(find $O/$wl -name '*.csv' | wc -l) csv files"
+done
