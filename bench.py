@@ -231,6 +231,9 @@ def main():
     ap.add_argument("--turbo", action="store_true",
                     help="EvalContext(turbo=true): the relaxed-accuracy Float32 operators (DE_OPT_TURBO) for the whole run; "
                          "without it the plain-eval workloads time the exact mode and report turbo in a `turbo` sub-object")
+    ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto",
+                    help="N > 1: 'strong' = the workload's population split over the N ranks (the metric of BASELINE.json: 1000 trees x "
+                         "10^7 samples at 1/2/4/8 GPUs), 'weak' = the workload's population PER rank.  auto = strong (C4: its 8-way shards)")
     ap.add_argument("--no-turbo-leg", action="store_true", help="skip the secondary turbo timing (profiling runs: one kernel variant per process)")
     ap.add_argument("--no-full-eval-leg", action="store_true", help="skip the secondary timing without the early exit (DE_OPT_FULL_EVAL)")
     args = ap.parse_args()
@@ -280,7 +283,10 @@ def main():
     wl = WORKLOADS[args.workload]
     n_per_gpu, N = wl["n_trees"], wl["N"]
     ops = de.synth.BENCH_OPERATORS
-    # weak scaling: the job's population is n_per_gpu * world trees, round-robin sharded
+    # strong scaling (default; the metric is quoted on ONE population at 1/2/4/8 GPUs): the workload's n_trees round-robin sharded
+    # over the ranks.  weak: n_trees PER rank (the job's population grows with the world).
+    strong = args.scaling in ("auto", "strong")
+    n_job = n_per_gpu if strong else n_per_gpu * world
     is_param = bool(wl.get("parametric"))
     shards = wl.get("shards")
     if shards:
@@ -294,9 +300,9 @@ def main():
         del full
     else:
         if is_param:
-            all_trees = de.synth.random_population(n_per_gpu * world, seed=0xDE05, node_type=de.ParametricNode, nparams=8)
+            all_trees = de.synth.random_population(n_job, seed=0xDE05, node_type=de.ParametricNode, nparams=8)
         else:
-            all_trees = de.synth.random_population(n_per_gpu * world, seed=0xDE02)
+            all_trees = de.synth.random_population(n_job, seed=0xDE02)
         my_ids = dedist.shard_indices(len(all_trees), rank, world)
         trees = [all_trees[i] for i in my_ids]
     total_nodes = sum(de.count_nodes(t) for t in all_trees)
@@ -387,11 +393,13 @@ def main():
     # torch.distributed only ships the 128-byte unique id.  Checked against the torch.distributed gather once; any failure
     # falls back to that path (both are RCCL over xGMI) and is reported in the JSON line.
     comm_c, gather_via = None, "none (1 GPU)"
+    comm_world = 1  # as the communicator reports it (not the environment)
     if world > 1:
+        comm_world = int(torch.distributed.get_world_size())
         gather_via = "torch.distributed all_gather (RCCL)"
-        # opt-in (DE_BENCH_C_COMM=1): the default keeps the one collective library path that the CPU/gloo tests cover end to
-        # end; a multi-GPU box to try the C-ABI communicator on was never available to the builder
-        if backend == "nccl" and os.environ.get("DE_BENCH_C_COMM", "0") == "1":
+        # default on (DE_BENCH_C_COMM=0 turns it off): the driver's multi-GPU run exercises de_dist_* — checked once against the
+        # torch.distributed gather below and dropped for it on any mismatch or error (a multi-GPU box was never available to the builder)
+        if backend == "nccl" and os.environ.get("DE_BENCH_C_COMM", "1") == "1":
             try:
                 ids = [None]
                 if rank == 0:
@@ -412,6 +420,7 @@ def main():
                 torch.distributed.all_reduce(same, op=torch.distributed.ReduceOp.MIN)
                 if int(same.item()) == 1:
                     comm_c, gather_via = cand, "de_dist_gather_flags (C ABI: ncclAllGather inside libde_hip.so)"
+                    comm_world = cand.world_size()  # ncclCommCount of the library's own communicator
                 else:
                     cand.close()
             except Exception as e:  # pragma: no cover
@@ -539,12 +548,15 @@ def main():
             else:
                 traffic = pm.get(key, {}).get("hbm_bytes_per_launch")
                 traffic_note = f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per step, profiles/pmc_summary.json[{key}] (same kernel sources: hash checked)"
+        # C4 is a fixed 8-way sharded population: a job of N <= 8 ranks runs the first N shards (per-GPU work fixed: weak)
+        scaling_kind = "weak" if (shards or not strong) else "strong"
         res = {
             "metric": "node-evals/sec", "value": value, "unit": "node-evals/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": scaling_kind, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl["desc"], "workload_key": args.workload, "trees_per_gpu": n_per_gpu, "n_samples": N, "n_features": 5,
+            "config": {"workload": wl["desc"], "workload_key": args.workload, "trees_job": len(all_trees), "trees_this_rank": len(trees),
+                       "n_samples": N, "n_features": 5, "rccl_world_size": comm_world,
                        "nodes_per_tree": 20, "operators": "+ - / * cos exp", "sharding": f"tree-sharded x{world}", "flag_gather": gather_via,
                        "complete_fraction": float(flags.float().mean().item()),
                        "early_exit": "EvalContext.early_exit = true (the reference's default): a tree is not evaluated by workgroups that start "

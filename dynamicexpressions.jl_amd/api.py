@@ -45,7 +45,7 @@ EXPORTS = [
     "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create", "de_program_create_cse",
     "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
     "de_program_n_grad", "de_program_dump", "de_program_verify", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad", "de_eval_loss_grad_by_class",
-    "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size",
+    "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size", "de_dist_world_size",
     "de_dist_broadcast", "de_dist_gather_flags", "de_dist_last_error", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
 ]
 
@@ -127,6 +127,7 @@ def library() -> C.CDLL:
     lib.de_dist_unique_id.argtypes = [vp]
     lib.de_dist_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     lib.de_dist_destroy.argtypes = [vp]
+    lib.de_dist_world_size.argtypes = [vp]
     lib.de_dist_shard_size.restype = i64
     lib.de_dist_shard_size.argtypes = [i64, C.c_int, C.c_int]
     lib.de_dist_broadcast.argtypes = [vp, vp, C.c_size_t, C.c_int]

@@ -112,7 +112,11 @@ def main(path):
         sys.exit("asmpatch: no handler entry found")
     open(path, "wb").write(bytes(blob))
     print(f"asmpatch: entry vmcnt wait dropped in {n} eval handlers ({skipped} with vector-memory instructions left alone)")
+    return dict(asmpatch_relaxed=n, asmpatch_left_alone=skipped)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    stats = main(sys.argv[1])
+    if len(sys.argv) > 2:
+        import patch_expect
+        patch_expect.check(sys.argv[2], stats)

@@ -23,6 +23,18 @@ build_obj de_dist.cpp _obj/de_dist.o &
 # device IR (irpatch.py: the interpreter's indirect handler calls need none of the implicit kernel inputs).
 # DE_NO_IRPATCH=1 builds it the plain way.
 LLVM=${LLVM:-/opt/rocm/lib/llvm/bin}
+# The IR / object-code passes below are validated against ONE toolchain: refuse any other (DE_ALLOW_TOOLCHAIN=1 overrides; the
+# per-module match counts of csrc/patch_expect/ are then the only guard).  The version in use is recorded next to the objects.
+TOOLCHAIN="$($LLVM/clang --version | head -1)"
+echo "$TOOLCHAIN" > _obj/toolchain.txt
+case "$TOOLCHAIN" in
+  *"clang version 22."*"roc-7.2."*) ;;
+  *) if [ "${DE_ALLOW_TOOLCHAIN:-0}" != 1 ]; then
+       echo "build.sh: irpatch.py / asmpatch.py are validated against ROCm 7.2 (AMD clang 22); found: $TOOLCHAIN" >&2
+       echo "          set DE_ALLOW_TOOLCHAIN=1 to try anyway (tests/test_irpatch.py checks the result on the shipped code object)" >&2
+       exit 1
+     fi ;;
+esac
 build_kernels() { # src obj [extra flags...]
   local src=$1 obj=$2 tmp=_obj/irp_$(basename $2 .o); shift 2
   local DE_KERNEL_FLAGS="${DE_KERNEL_FLAGS:-} $*"
@@ -31,10 +43,10 @@ build_kernels() { # src obj [extra flags...]
   rm -f "$obj"; mkdir -p $tmp
   if [ "${DE_NO_IRPATCH:-0}" = 1 ]; then $HIPCC $FLAGS ${DE_KERNEL_FLAGS:-} -c $src -o $obj; return; fi
   $HIPCC $FLAGS ${DE_KERNEL_FLAGS:-} --cuda-device-only -emit-llvm -S $src -o $tmp/k.ll
-  python3 irpatch.py $tmp/k.ll $tmp/k2.ll
+  python3 irpatch.py $tmp/k.ll $tmp/k2.ll $(basename $obj .o)
   $LLVM/clang -x ir $tmp/k2.ll -target amdgcn-amd-amdhsa -mcpu=gfx950 -O3 -fPIC -ffp-contract=off -Wno-override-module ${DE_LLC_FLAGS:-} -c -o $tmp/k.o
   # one more pass, over the object code of the handlers: asmpatch.py (their entry wait need not cover the previous tree's output stores)
-  if [ "${DE_NO_ASMPATCH:-0}" != 1 ]; then python3 asmpatch.py $tmp/k.o; fi
+  if [ "${DE_NO_ASMPATCH:-0}" != 1 ]; then python3 asmpatch.py $tmp/k.o $(basename $obj .o); fi
   $LLVM/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o $tmp/k.out $tmp/k.o
   $LLVM/clang-offload-bundler -type=o -bundle-align=4096 -targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950 \
       -input=/dev/null -input=$tmp/k.out -output=$tmp/k.hipfb

@@ -514,8 +514,7 @@ static void make_chained(de_program *p) {
         if (f32) { r.lo = (uint32_t)handler; r.hi = (uint32_t)(handler >> 32); }
         else r.arg = (uint32_t)handler;
     };
-    const char *ne = getenv("DE_NO_END_FUSE");
-    const bool end_fuse = !(ne && *ne == '1');
+    const bool end_fuse = true; // (the DE_NO_END_FUSE switch of round 2 measured <= 1 % and is gone)
     bool prev_fused = false; // the previous tree finishes in an end-fused handler: ITS last instruction names this tree's first handler
     for (int64_t t = 0; t < p->n_trees; t++) {
         const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1];
@@ -1488,7 +1487,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
     // stages a tile (the reference's formulation, src/ParametricExpression.jl:381-389), so every hot handler serves them.
     const int FE = F + (p->uses_params ? P : 0);
     const bool hot_const_unary = !getenv("DE_NO_CONST_UNARY_HOT"); // unary operators outside the binder's hot set through hot handlers
-    const bool fuse_push = !getenv("DE_NO_GRAD_PUSHLOAD");         // PUSH + LOAD pairs as one instruction
+    const bool fuse_push = true;                                   // PUSH + LOAD pairs as one instruction
     auto gun_of = [&](uint32_t op) { // hot unary index of a de_opcode (de_bind.h), or -1
         return hot_const_unary ? gun_index((int)op, DE_U_COS, DE_U_EXP, DE_U_SIN, DE_U_NEG, DE_U_SQUARE, DE_U_CUBE, DE_U_ABS, DE_U_LOG, DE_U_SAFE_LOG,
                                            DE_U_SQRT, DE_U_SAFE_SQRT, DE_U_TANH, DE_U_RELU) : -1;
@@ -1829,7 +1828,6 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
         p->site_gen++;
         uint32_t max_prows = 0;
         bool ok = true;
-        std::vector<int> row_hist; // trees by partial + accumulation rows (DE_DEBUG_ROWS=1 prints it)
         std::vector<uint32_t> need((size_t)p->n_trees, 0);
         std::vector<BoundInstr> rv;
         std::vector<uint8_t> rv_col; // rv[k] carries a gradient column word in .lo
@@ -2027,32 +2025,22 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
             p->rtcode_off[(size_t)t + 1] = (int32_t)p->rtcode.size();
             max_prows = std::max(max_prows, n_prows + n_acc);
             need[(size_t)t] = n_prows + n_acc;
-            if (row_hist.size() <= n_prows + n_acc) row_hist.resize(n_prows + n_acc + 1, 0);
-            row_hist[n_prows + n_acc]++;
-        }
-        if (getenv("DE_DEBUG_ROWS")) {
-            fprintf(stderr, "rev rows: PR0=%u;", PR0);
-            for (size_t r = 0; r < row_hist.size(); r++) if (row_hist[r]) fprintf(stderr, " %zu:%d", r, row_hist[r]);
-            fprintf(stderr, "\n");
         }
         // per-wave staging of the column sums: one LDS row, or the widest tree's columns
         int64_t stage_cols = 64;
         for (int64_t t = 0; t < p->n_trees; t++) stage_cols = std::max<int64_t>(stage_cols, 1 + de_program_n_grad(p, t, mode));
         const uint64_t stage_rows = ((uint64_t)stage_cols * es32 + RB - 1) / RB;
-        const char *envx = getenv("DE_REV_EXTRA_ROWS"); // occupancy experiments: pad the LDS allocation
-        const uint64_t extra_rows = envx ? (uint64_t)atoi(envx) : 0;
-        const uint64_t rows = (uint64_t)PR0 + max_prows + stage_rows + extra_rows;
+        const uint64_t rows = (uint64_t)PR0 + max_prows + stage_rows;
         if (!ok || 4 * rows * RB > 160 * 1024 || rows * RB >= (1u << 24)) { p->rtsite_of_gb.clear(); p->site_gen++; return DE_OK; }
         // The kernel is latency-bound and its occupancy is set by the LDS rows of the neediest tree of a launch
         // (5 -> 4 workgroups per CU: +17 % time): trees are grouped by the number of workgroups per CU their own
         // need allows and every group is a launch of its own (small groups join the next needier one).
-        auto wgs_of = [&](uint32_t nd) { return (int)std::min<uint64_t>(8, (160 * 1024) / (4 * ((uint64_t)PR0 + nd + stage_rows + extra_rows) * RB)); };
+        auto wgs_of = [&](uint32_t nd) { return (int)std::min<uint64_t>(8, (160 * 1024) / (4 * ((uint64_t)PR0 + nd + stage_rows) * RB)); };
         std::vector<int32_t> ids((size_t)p->n_trees);
         for (int64_t t = 0; t < p->n_trees; t++) ids[(size_t)t] = (int32_t)t;
         std::stable_sort(ids.begin(), ids.end(), [&](int32_t x, int32_t y) { return need[(size_t)x] < need[(size_t)y]; });
         p->rt_n_groups = 0;
-        const char *envg = getenv("DE_REV_GROUPS");
-        const bool grouping = !(envg && *envg == '0');
+        const bool grouping = true;
         for (int64_t k = 0; k < p->n_trees;) {
             int64_t e = k;
             const int w = wgs_of(need[(size_t)ids[(size_t)k]]);
@@ -2065,7 +2053,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
             GradArgs::RevGroup &gr = p->rt_groups[p->rt_n_groups++];
             gr.first = (int32_t)k;
             gr.n = (int32_t)(e - k);
-            gr.rows = (int32_t)(PR0 + need[(size_t)ids[(size_t)e - 1]] + stage_rows + extra_rows);
+            gr.rows = (int32_t)(PR0 + need[(size_t)ids[(size_t)e - 1]] + stage_rows);
             std::sort(ids.begin() + k, ids.begin() + e); // tree order inside a group: adjacent trees share staging batches
             k = e;
         }

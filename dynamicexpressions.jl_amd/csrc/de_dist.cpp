@@ -23,6 +23,7 @@ struct Rccl {
     int (*GetUniqueId)(NcclId *) = nullptr;
     int (*CommInitRank)(NcclComm *, int, NcclId, int) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
+    int (*CommCount)(NcclComm, int *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, NcclComm, hipStream_t) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -40,6 +41,7 @@ struct Rccl {
         SYM(GetUniqueId, "ncclGetUniqueId")
         SYM(CommInitRank, "ncclCommInitRank")
         SYM(CommDestroy, "ncclCommDestroy")
+        SYM(CommCount, "ncclCommCount")
         SYM(AllGather, "ncclAllGather")
         SYM(Broadcast, "ncclBroadcast")
         SYM(GetErrorString, "ncclGetErrorString")
@@ -113,6 +115,15 @@ int de_dist_destroy(de_comm_t *c) {
     if (c->recv) (void)hipFree(c->recv);
     delete c;
     return DE_OK;
+}
+
+int de_dist_world_size(de_comm_t *c) { // the communicator's own count (ncclCommCount), not what the caller passed to de_dist_init
+    if (!c) return -1;
+    if (c->world == 1 || !c->comm) return 1;
+    int n = -1;
+    const int rc = g_rccl.CommCount(c->comm, &n);
+    if (rc != 0) { dfail(c, DE_ERR_RCCL, "ncclCommCount: %s", g_rccl.GetErrorString(rc)); return -1; }
+    return n;
 }
 
 int64_t de_dist_shard_size(int64_t n_trees, int rank, int world) { // trees {t : t mod world == rank}

@@ -3,21 +3,23 @@
 // (deg*_eval and the fused deg1_l*/deg2_* kernels, :366-993) and
 // src/EvaluateDerivative.jl (grad_degn_eval :340-365, diff_degn_eval :99-119).
 //
-// Design (see DESIGN.md §Kernels):
-//  * grid  = sample tiles x tree chunks; a workgroup (256 threads = 4 wave64)
-//    owns TILE = 256*K consecutive samples and loops over a chunk of trees.
+// Design (see DESIGN.md §4):
+//  * grid  = sample tiles x tree chunks.  The threaded kernel (the default): a workgroup of DE_TBLK = 128 threads = 2 wave64
+//    owns TILE = 512 consecutive Float32 samples (4 per thread; 256 Float64) and runs a chunk of <= 64 trees as ONE chain of
+//    direct-threaded handlers; the flat-switch fall-back kernel uses 256 threads = 4 wave64 and G vectors per thread.
 //  * The X tile ([F, TILE], feature-fastest in HBM) is read ONCE per workgroup with
 //    fully coalesced loads and transposed into LDS as xs[f][sample], so a leaf
-//    read is one conflict-free ds_read_b128 per thread (K=4 f32 samples).
+//    read is one conflict-free ds_read_b128 per thread.
 //  * Each tree is a wave-uniform accumulator program (de_program.h): instruction
-//    words are fetched through the SCALAR cache (constant address space ->
-//    s_load_dwordx4, next instruction prefetched while the current one executes),
-//    decode and dispatch run on the scalar unit, the VALU only sees operator
-//    arithmetic on K independent samples per lane.  Intermediates live in
+//    records are fetched through the SCALAR cache (constant address space ->
+//    s_load_dwordx4, the next record requested while the current handler runs),
+//    dispatch runs on the scalar unit, the VALU only sees operator
+//    arithmetic on 4 (2) independent samples per lane.  Intermediates live in
 //    registers; only the rare both-children-are-subtrees case spills one value
 //    per sample to LDS.
-//  * NaN/Inf flag: per-lane predicate, one wavefront ballot per tree, one byte
-//    store per failing wave (no atomics).
+//  * NaN/Inf flag: per-lane poison, one wavefront ballot per tree, one byte
+//    store per failing wave (no atomics) — and the reference's EARLY EXIT at tree granularity: a workgroup reads the flags of
+//    its chunk once and does not evaluate trees that an earlier workgroup already found incomplete (h_tree_skip).
 //  * blockIdx -> (tile, chunk) is XCD-aware: all chunks of one X tile run on the
 //    same XCD, so the tile is fetched from HBM once and re-served by that XCD's L2.
 //  * No MFMA: this is an elementwise map, not a contraction.

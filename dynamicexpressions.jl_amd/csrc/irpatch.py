@@ -136,7 +136,11 @@ def main(src, dst):
     open(dst, "w").write(text)
     print(f"irpatch: {len(calls)} indirect handler call(s), {len(defs)} handlers, {len(allowed)}/{len(NO_ATTRS)} inputs dropped, "
           f"{n_inreg} stream-pointer parameter(s) moved to SGPRs")
+    return dict(irpatch_indirect_calls=len(calls), irpatch_handlers=len(defs), irpatch_inputs_dropped=len(allowed), irpatch_inreg=n_inreg)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    stats = main(sys.argv[1], sys.argv[2])
+    if len(sys.argv) > 3:  # build.sh: compare with / record the counts this module is known to produce
+        import patch_expect
+        patch_expect.check(sys.argv[3], stats)

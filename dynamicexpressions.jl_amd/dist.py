@@ -83,6 +83,10 @@ class Comm:
             from . import api
             raise api.DeviceError(f"{self._lib.de_status_string(rc).decode()}: {self._lib.de_dist_last_error(self._h).decode()}")
 
+    def world_size(self) -> int:
+        """Ranks of the communicator as RCCL reports them (ncclCommCount)."""
+        return int(self._lib.de_dist_world_size(self._h))
+
     def shard_size(self, n_trees: int) -> int:
         return int(self._lib.de_dist_shard_size(n_trees, self.rank, self.world))
 

@@ -350,6 +350,7 @@ typedef struct de_comm de_comm_t;
 int de_dist_unique_id(void *id);
 int de_dist_init(de_ctx_t *ctx, int rank, int world, const void *id, de_comm_t **out_comm);
 int de_dist_destroy(de_comm_t *comm);
+int de_dist_world_size(de_comm_t *comm); /* ranks of the communicator as RCCL reports them (ncclCommCount); 1 for a one-rank comm; -1 on error */
 int64_t de_dist_shard_size(int64_t n_trees, int rank, int world);
 int de_dist_broadcast(de_comm_t *comm, void *buf, size_t bytes, int root);
 int de_dist_gather_flags(de_comm_t *comm, const uint8_t *ok_local, int64_t n_trees, uint8_t *ok_global);

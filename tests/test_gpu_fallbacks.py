@@ -153,7 +153,7 @@ def test_dist_c_abi_single_rank_and_rccl_loading(api):
     from dynamicexpressions_jl_amd import dist as dedist
     ctx = api.default_context()
     comm = dedist.Comm(ctx, 0, 1)
-    assert comm.shard_size(10) == 10
+    assert comm.shard_size(10) == 10 and comm.world_size() == 1
     ok = torch.tensor([1, 0, 1, 1, 0], dtype=torch.uint8, device="cuda")
     g = comm.gather_flags(ok, 5)
     X = torch.arange(12, dtype=torch.float32, device="cuda")
@@ -172,3 +172,26 @@ def test_dist_c_abi_single_rank_and_rccl_loading(api):
     # (world = 1 short-cuts RCCL inside the library; the calls above already proved the symbols resolve)
     assert lib.de_dist_init(ctx._h, 0, 1, idb, C.byref(h)) == 0 and lib.de_dist_destroy(h) == 0
     assert lib.de_dist_init(ctx._h, 2, 2, idb, C.byref(h)) == 1  # rank outside the world: invalid argument, no RCCL call
+
+
+def test_bench_two_ranks_on_one_gpu_strong_scaling_line(api):
+    """`bench.py --gpus 2` (self-launching, one rank per process) with the ranks sharing this box's GPU
+    and the flags gathered through gloo (DE_BENCH_BACKEND=gloo: a dry run of the multi-rank code path — sharding, flag
+    gather, max-over-ranks timing; the timing itself means nothing).  The line must say n_gpus 2, strong scaling (ONE
+    population split over the ranks: the metric's 1/2/4/8-GPU series) and the communicator's own world size."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "tiny", "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["rccl_world_size"] == 2 and d["config"]["trees_job"] == 64 and d["config"]["trees_this_rank"] == 32
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
