@@ -2,7 +2,8 @@
 """asmpatch.py OBJECT.o — let the output store of one tree overlap with the evaluation of the next.
 
 The AMDGPU backend opens every non-kernel function with `s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)` (SIInsertWaitcnts: a
-callee cannot know what its caller left in flight).  For the direct-threaded handlers (de_kernels.hip: h_chain<...>, h_param<...>;
+callee cannot know what its caller left in flight).  For the direct-threaded handlers (de_kernels.hip: h_chain<...>, h_param<...>, h_tree_skip<...> — the early-exit walk runs right behind a tree's
+output store and reads only LDS and the scalar stream;
 de_grad_threaded.hip: gh_chain<...>; de_rev_threaded.hip: rh_chain<...>) the only vector-memory operations that can be in
 flight at their entry are the `global_store`s of the PREVIOUS tree's results (h_tree_end / the gradient kernels' epilogues)
 — nothing a handler reads — yet the first handler of every tree would wait for their write acknowledgement (~1-2 us), once
@@ -29,7 +30,7 @@ import struct
 import subprocess
 import sys
 
-TARGETS = re.compile(r"^_ZN2de(7h_chainI|7h_paramI|9h_un_fastI|10h_div_fastI|12h_unrow_fastI|14h_divrowc_fastI|11h_div2_fastI|13h_un_end_fastI|14h_div_end_fastI|10h_tree_endI|11h_chain_endI|\d+[gr]tm_\w+?8[gr]h_chainI)")  # never an end handler (h_tree_end, g_end, r_end): the end of every chain keeps the full wait
+TARGETS = re.compile(r"^_ZN2de(7h_chainI|7h_paramI|9h_un_fastI|10h_div_fastI|12h_unrow_fastI|14h_divrowc_fastI|11h_div2_fastI|13h_un_end_fastI|14h_div_end_fastI|10h_tree_endI|11h_tree_skipI|11h_chain_endI|\d+[gr]tm_\w+?8[gr]h_chainI)")  # never an end handler (h_tree_end, g_end, r_end): the end of every chain keeps the full wait
 VMEM = re.compile(r"^\s*(scratch_|flat_|global_|buffer_|tbuffer_|image_)")
 LLVM = os.environ.get("LLVM", "/opt/rocm/lib/llvm/bin")
 

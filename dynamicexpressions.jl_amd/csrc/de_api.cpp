@@ -809,7 +809,25 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
     // one trailing pad instruction: the flat-switch interpreter prefetches code[pc + 1]; the chained form of the
     // threaded kernel has one end record per tree and a head record (and the fused form is never longer than the bound one)
     const size_t cbytes = (p->bcode.size() + (size_t)p->n_trees + 2) * sizeof(BoundInstr); // + head record + one of padding
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p->d_code), cbytes));
+    {
+        // the early-exit walk (h_tree_skip) rebuilds record addresses from their low 32 bits: the stream must lie inside one
+        // 4 GiB window.  An allocation that straddles a boundary (once in ~10^4 for a 400 KB stream) is set aside and redone.
+        void *rejected[4] = {nullptr, nullptr, nullptr, nullptr};
+        int n_rej = 0;
+        hipError_t ast = hipSuccess;
+        for (;;) {
+            ast = hipMalloc(reinterpret_cast<void **>(&p->d_code), cbytes);
+            if (ast != hipSuccess) break;
+            const uint64_t a0 = (uint64_t)(uintptr_t)p->d_code, a1 = a0 + cbytes - 1;
+            if ((a0 >> 32) == (a1 >> 32) || n_rej == 4) break;
+            rejected[n_rej++] = p->d_code;
+            p->d_code = nullptr;
+        }
+        for (int k = 0; k < n_rej; k++) (void)hipFree(rejected[k]);
+        if (ast != hipSuccess) return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(ast));
+        const uint64_t a0 = (uint64_t)(uintptr_t)p->d_code;
+        if ((a0 >> 32) != ((a0 + cbytes - 1) >> 32)) return fail(ctx, DE_ERR_HIP, "instruction stream straddles a 4 GiB boundary");
+    }
     HIP_TRY(ctx, hipMemset(p->d_code, 0, cbytes));
     hipError_t st = hipMalloc(reinterpret_cast<void **>(&p->d_code_off), p->bcode_off.size() * sizeof(int32_t));
     if (st != hipSuccess) {

@@ -95,6 +95,162 @@ static __device__ __noinline__ double de_atan_f64(double x) {
     return x < 0.0 ? -r : r;
 }
 
+// Float64 tan: the algorithm of the reference's Base.tan (Julia base/special/trig.jl `tan_kernel` + `rem_pio2_kernel`, themselves
+// the FreeBSD msun __kernel_tan / __ieee754_rem_pio2): Cody-Waite reduction by pi/2 in up to three steps of 33 + 53 bits
+// (pio2_1 .. pio2_3t; good to 151 bits, covers |x| < 2^20 pi/2), then on |r| <= pi/4 the odd degree-27 polynomial T[] — for
+// |r| >= 0.6744 after the reflection r -> pi/4 - r — and for odd multiples -1/tan(r) from a reciprocal corrected in two parts.
+// Same constants (checked against msun's hex words), same operation order, no contraction: < 1 ulp (OCML's tan measured 1.03,
+// outside north_star's 1 ulp; tests/test_gpu_ulp_f64.py).  |x| >= 2^20 pi/2, Inf and NaN keep OCML's Payne-Hanek path.
+static __device__ __noinline__ double de_tan_f64(double x) {
+    const double ax = __builtin_fabs(x);
+    if (!(ax < 1647099.0)) return ::tan(x); // 2^20 * pi/2 = 1647099.33: the medium reduction's domain
+    double y0 = x, y1 = 0.0;
+    int n = 0;
+    if (ax > 7.85398163397448278999e-01) {
+        const double fn = __builtin_rint(x * 6.36619772367581382433e-01);
+        n = (int)fn;
+        double r = x - fn * 1.57079632673412561417e+00;
+        double w = fn * 6.07710050650619224932e-11; // first step: good to 85 bits
+        y0 = r - w;
+        const int ex = (int)((__double_as_longlong(ax) >> 52) & 0x7ff);
+        if (ex - (int)((__double_as_longlong(y0) >> 52) & 0x7ff) > 16) { // cancellation: second step, 118 bits
+            double t = r;
+            w = fn * 6.07710050630396597660e-11;
+            r = t - w;
+            w = fn * 2.02226624879595063154e-21 - ((t - r) - w);
+            y0 = r - w;
+            if (ex - (int)((__double_as_longlong(y0) >> 52) & 0x7ff) > 49) { // third step, 151 bits: covers every case
+                t = r;
+                w = fn * 2.02226624871116645580e-21;
+                r = t - w;
+                w = fn * 8.47842766036889956997e-32 - ((t - r) - w);
+                y0 = r - w;
+            }
+        }
+        y1 = (r - y0) - w;
+    } else if (ax < 0x1p-27) {
+        return x; // tan(x) = x to the last bit (and keeps -0, subnormals)
+    }
+    // __kernel_tan(y0, y1, iy), iy = 1: tan, -1: -1/tan
+    const int iy = 1 - ((n & 1) << 1);
+    double xx = y0, yy = y1;
+    const bool big = __builtin_fabs(xx) >= 0.6743354797363281; // msun compares the high word with 0x3FE59428
+    const bool negx = xx < 0.0;
+    if (big) {
+        if (negx) { xx = -xx; yy = -yy; }
+        const double z0 = 7.85398163397448278999e-01 - xx, w0 = 3.06161699786838301793e-17 - yy;
+        xx = z0 + w0;
+        yy = 0.0;
+    }
+    double z = xx * xx, w = z * z;
+    double r = 1.33333333333201242699e-01 + w * (2.18694882948595424599e-02 + w * (3.59207910759131235356e-03 +
+               w * (5.88041240820264096874e-04 + w * (7.81794442939557092300e-05 + w * -1.85586374855275456654e-05))));
+    double v = z * (5.39682539762260521377e-02 + w * (8.86323982359930005737e-03 + w * (1.45620945432529025516e-03 +
+               w * (2.46463134818469906812e-04 + w * (7.14072491382608190305e-05 + w * 2.59073051863633712884e-05)))));
+    double sx = z * xx;
+    r = yy + z * (sx * (r + v) + yy);
+    r += 3.33333333333334091986e-01 * sx;
+    w = xx + r;
+    if (big) {
+        v = (double)iy;
+        return (negx ? -1.0 : 1.0) * (v - 2.0 * (xx - (w * w / (w + v) - r)));
+    }
+    if (iy == 1) return w;
+    // -1 / (xx + r), accurately: the reciprocal and w split at 32 bits
+    const double zt = __longlong_as_double(__double_as_longlong(w) & ~0xFFFFFFFFLL);
+    v = r - (zt - xx); // zt + v = r + xx
+    const double a = -1.0 / w;
+    const double t = __longlong_as_double(__double_as_longlong(a) & ~0xFFFFFFFFLL);
+    sx = 1.0 + t * zt;
+    return t + a * (sx + t * v);
+}
+
+// Float64 x^y: the FreeBSD msun __ieee754_pow core (error < 0.70 ulp; OCML's pow measured 1.26 ulp, outside north_star's 1 ulp,
+// tests/test_gpu_ulp_f64.py).  log2|x| = n + dp_h + z_h + z_l from s = (m - bp)/(m + bp), bp = 1 or 1.5, carried as head + tail
+// (s_h + s_l, the degree-6 series L1..L6 in s^2, 2/(3 ln 2) = cp_h + cp_l), y log2|x| formed from the split operands as p_h + p_l,
+// 2^(p_h + p_l) by the exp kernel P1..P5 after removing the integer part.  Constants checked against msun's hex words.  The main
+// path: x finite and non-zero (negative with an integral y), y finite and non-zero, |y| <= 2^31; every other case (signed zeros,
+// Inf, NaN, huge |y|, negative base with fractional exponent) keeps OCML's case analysis — those results are exact or NaN.
+static __device__ __noinline__ double de_pow_f64(double x, double y) {
+    const bool yint = y == __builtin_rint(y);
+    if (!(__builtin_isfinite(x) && __builtin_isfinite(y) && x != 0.0 && y != 0.0 && __builtin_fabs(y) <= 0x1p31 && (x > 0.0 || yint))) return ::pow(x, y);
+    if (y == 1.0) return x;
+    if (y == 2.0) return x * x;
+    if (y == -1.0) return 1.0 / x;
+    if (y == 0.5 && x > 0.0) return __builtin_sqrt(x);
+    const double sgn = (x < 0.0 && ((long long)y & 1LL)) ? -1.0 : 1.0; // (-|x|)^(odd integer)
+    double ax = __builtin_fabs(x);
+    if (ax == 1.0) return sgn;
+    int n = 0;
+    long long bits = __double_as_longlong(ax);
+    if ((bits >> 52) == 0) { ax *= 0x1p53; n = -53; bits = __double_as_longlong(ax); } // subnormal base
+    int ix = (int)(bits >> 32);
+    n += (ix >> 20) - 0x3ff;
+    const int j = ix & 0x000fffff;
+    ix = j | 0x3ff00000; // mantissa in [1, 2)
+    int k;
+    if (j <= 0x3988E) k = 0;       // m < sqrt(3/2)
+    else if (j < 0xBB67A) k = 1;   // m < sqrt(3)
+    else { k = 0; n += 1; ix -= 0x00100000; }
+    ax = __longlong_as_double(((long long)ix << 32) | (bits & 0xFFFFFFFFLL));
+    const double bp = k ? 1.5 : 1.0, dp_h = k ? 5.84962487220764160156e-01 : 0.0, dp_l = k ? 1.35003920212974897128e-08 : 0.0;
+    const long long HI = ~0xFFFFFFFFLL;
+#define DE_TRUNC32(v) __longlong_as_double(__double_as_longlong(v) & HI)
+    // ss = s_h + s_l = (m - bp) / (m + bp)
+    double u = ax - bp, v = 1.0 / (ax + bp);
+    const double ss = u * v;
+    const double s_h = DE_TRUNC32(ss);
+    double t_h = __longlong_as_double((long long)(((ix >> 1) | 0x20000000) + 0x00080000 + (k << 18)) << 32); // high part of m + bp
+    double t_l = ax - (t_h - bp);
+    const double s_l = v * ((u - s_h * t_h) - s_h * t_l);
+    // log(m)
+    double s2 = ss * ss;
+    double r = s2 * s2 * (5.99999999999994648725e-01 + s2 * (4.28571428578550184252e-01 + s2 * (3.33333329818377432918e-01 +
+               s2 * (2.72728123808534006489e-01 + s2 * (2.30660745775561754067e-01 + s2 * 2.06975017800338417784e-01)))));
+    r += s_l * (s_h + ss);
+    s2 = s_h * s_h;
+    t_h = DE_TRUNC32(3.0 + s2 + r);
+    t_l = r - ((t_h - 3.0) - s2);
+    u = s_h * t_h;
+    v = s_l * t_h + t_l * ss;
+    double p_h = DE_TRUNC32(u + v);
+    double p_l = v - (p_h - u);
+    const double z_h = 9.61796700954437255859e-01 * p_h; // cp_h + cp_l = 2 / (3 ln 2)
+    const double z_l = -7.02846165095275826516e-09 * p_h + p_l * 9.61796693925975554329e-01 + dp_l;
+    double t = (double)n;
+    const double t1 = DE_TRUNC32(((z_h + z_l) + dp_h) + t); // log2|x| = t1 + t2
+    const double t2 = z_l - (((t1 - t) - dp_h) - z_h);
+    // y * log2|x| = p_h + p_l with y split as y1 + y2
+    const double y1 = DE_TRUNC32(y);
+    p_l = (y - y1) * t1 + y * t2;
+    p_h = y1 * t1;
+    double z = p_l + p_h;
+    if (z >= 1024.0) { // overflow unless the sum is a hair below 1024
+        if (z > 1024.0 || p_l + 8.0085662595372944372e-17 > z - p_h) return sgn * __builtin_inf();
+    } else if (z <= -1075.0) {
+        if (z < -1075.0 || p_l <= z - p_h) return sgn * 0.0;
+    }
+    // 2^(p_h + p_l): integer part out, exp kernel on the rest
+    int ni = 0;
+    if (__builtin_fabs(z) > 0.5) {
+        const double zi = __builtin_rint(z);
+        ni = (int)zi;
+        p_h -= zi;
+    }
+    t = DE_TRUNC32(p_l + p_h);
+    u = t * 6.93147182464599609375e-01;
+    v = (p_l - (t - p_h)) * 6.93147180559945286227e-01 + t * -1.90465429995776804525e-09;
+    z = u + v;
+    const double w = v - (z - u);
+    t = z * z;
+    const double tt = z - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 +
+                      t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))));
+    r = (z * tt) / (tt - 2.0) - (w + z * w);
+    z = 1.0 - (r - z);
+#undef DE_TRUNC32
+    return sgn * ::ldexp(z, ni);
+}
+
 template <> struct M<double> {
     using T = double;
     static __device__ __forceinline__ T abs(T x) { return ::fabs(x); }
@@ -108,7 +264,7 @@ template <> struct M<double> {
     static __device__ __forceinline__ T log1p(T x) { return ::log1p(x); }
     static __device__ __forceinline__ T sin(T x) { return ::sin(x); }
     static __device__ __forceinline__ T cos(T x) { return ::cos(x); }
-    static __device__ __forceinline__ T tan(T x) { return ::tan(x); }
+    static __device__ __forceinline__ T tan(T x) { return de_tan_f64(x); }
     static __device__ __forceinline__ T sinh(T x) { return ::sinh(x); }
     static __device__ __forceinline__ T cosh(T x) { return ::cosh(x); }
     static __device__ __forceinline__ T tanh(T x) { return ::tanh(x); }
@@ -119,7 +275,7 @@ template <> struct M<double> {
     static __device__ __forceinline__ T acosh(T x) { return ::acosh(x); }
     static __device__ __forceinline__ T atanh(T x) { return ::atanh(x); }
     static __device__ __forceinline__ T tgamma(T x) { return ::tgamma(x); }
-    static __device__ __forceinline__ T pow(T x, T y) { return ::pow(x, y); }
+    static __device__ __forceinline__ T pow(T x, T y) { return de_pow_f64(x, y); }
     static __device__ __forceinline__ T fmod(T x, T y) { return ::fmod(x, y); }
     static __device__ __forceinline__ T rint(T x) { return ::rint(x); }
     static __device__ __forceinline__ T floor(T x) { return ::floor(x); }

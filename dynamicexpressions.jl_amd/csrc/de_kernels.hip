@@ -547,6 +547,7 @@ template <> __device__ __forceinline__ HandlerFn<double> arg_next<double>(uint32
 template <typename T> __device__ __forceinline__ typename ImmBits<T>::type arg_imm(uint32_t w1, uint64_t w23);
 template <> __device__ __forceinline__ uint32_t arg_imm<float>(uint32_t w1, uint64_t) { return w1; }
 template <> __device__ __forceinline__ uint64_t arg_imm<double>(uint32_t, uint64_t w23) { return w23; }
+#define DE_SKIPLIST_BYTES 256u // LDS bytes in front of row 0: the live trees of the running (sub-)chunk (h_tree_skip), 64 x 4 bytes
 #define DE_ROW_BYTES_C ((DE_TBLK + 1) * 16) // LDS row stride of the threaded kernel: DE_TBLK 16-byte vectors + one of padding
 // `code` points at the record of the NEXT instruction; (la, w1, w23) are this instruction's record
 #define HCHAIN_ARGS HState<T> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint64_t skip, uint32_t left, uint32_t flags, uint32_t tree
@@ -586,15 +587,23 @@ __device__ __forceinline__ bool poison_set(const double &p) { return p != p; }
 // Such a tree is not evaluated: the end of its predecessor tail-calls h_tree_skip, which walks the HEADER records — the
 // record in front of a tree's first instruction (the previous tree's end record / the head record) carries the number of records of
 // the tree — to the next tree that still has to run.  One scalar load per skipped tree instead of its evaluation.
-template <typename T> __device__ __forceinline__ uint32_t hdr_len(const U32x4 &h) { return sizeof(T) == 4 ? h.y : h.z; } // the immediate's (low) word
-template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS) { // code -> the header of tree `tree`, which is skipped
-    const U32x4 h = *code;
-    const ConstU4Ptr nh = code + 1 + hdr_len<T>(h); // its end record = the next tree's header
-    if (left <= 1u) return st;
-    left -= 1u;
-    tree += 1u;
-    skip >>= 1;
-    if (skip & 1ull) [[clang::musttail]] return h_tree_skip<T>(st, lds0, nh, outp, la, w1, w23, okp, ldo, skip, left, flags, tree);
+// The walk is ONE LDS read and ONE scalar load per run of skipped trees: when a (sub-)chunk starts, the kernel writes the header
+// addresses (low 32 bits; the stream lies inside one 4 GiB window: checked on the host) of its LIVE trees to the first
+// DE_SKIPLIST_BYTES of LDS, in REVERSE order — entry r = the live tree that has r live trees after it — so that a handler finds
+// the next live tree from what it carries anyway: r = (trees left after it) - (skip bits set after it).
+// (Round 3's first version followed the headers tree by tree — a dependent scalar-cache round trip per skipped tree, 64 SIMD
+// cycles per skipped tree and wavefront, 0.65 ms of the 7.9 ms headline; tools/exp_skip_cost.py.)
+template <typename T> __device__ __forceinline__ uint32_t hdr_len(const U32x4 &h) { return sizeof(T) == 4 ? h.y : h.z; } // the immediate's (low) word: records of the tree (de_program_verify)
+template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS) { // bit 0 of `skip` = tree `tree`, which is skipped
+    const uint32_t n = (uint32_t)__builtin_ctzll(~skip); // the run of skipped trees (>= 1; bits beyond the chunk are 0)
+    if (n >= left) return st;
+    skip >>= n;
+    left -= n;
+    tree += n;
+    const uint32_t r = left - 1u - (uint32_t)__builtin_popcountll(skip >> 1); // live trees after the one the chain goes on with
+    const uint32_t lo = *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(r * 4u)); // (wave-uniform address)
+    const uint64_t hdr = ((uint64_t)(uintptr_t)code & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+    const ConstU4Ptr nh = (ConstU4Ptr)(uintptr_t)hdr; // the tree's header record (the record in front of its first instruction)
     const U32x4 hn = nh[0], w = nh[1];
     [[clang::musttail]] return arg_next<T>(hn.y, ((uint64_t)hn.w << 32) | hn.z)(st, lds0, nh + 2, outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, skip, left, flags,
                                                                              tree);
@@ -618,14 +627,14 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS)
 typedef __attribute__((address_space(1))) char *GPtr; // global, not flat: a flat store also ties up lgkmcnt
 // The other store modes (flags != 0), out of line so that h_tree_end itself is straight-line code: HF_RETURN_EACH (fused loss:
 // the kernel owns the epilogue), HF_SLOW_STORE (ragged last tile / output rows that are not 16-byte aligned; LDS base = 0:
-// lds0 = 16 * thread), HF_NO_STORE (DE_DEBUG_NO_STORE, measurement only: keep the value alive, write nothing).
+// lds0 = DE_SKIPLIST_BYTES + 16 * thread), HF_NO_STORE (DE_DEBUG_NO_STORE, measurement only: keep the value alive, write nothing).
 template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_ARGS) {
     constexpr int VW = VecOf<T>::W;
     if (flags & HF_RETURN_EACH) return st;
     const U32x4 w = *code;
     const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);
     if (flags & HF_SLOW_STORE) {
-        const int remaining = (int)(flags & HF_VALID_MASK) - (int)(lds0 / (uint32_t)sizeof(T));
+        const int remaining = (int)(flags & HF_VALID_MASK) - (int)((lds0 - DE_SKIPLIST_BYTES) / (uint32_t)sizeof(T));
         DE_UNROLL for (int i = 0; i < VW; i++)
             if (i < remaining) reinterpret_cast<__attribute__((address_space(1))) T *>(row + lds0)[i] = st.acc[i];
     } else if (st.acc[0] == T(123456.789)) {
@@ -1203,7 +1212,8 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
     constexpr int BLK = DE_TBLK, TILE = BLK * VW, ROWV = BLK + 1;
-    extern __shared__ __align__(16) unsigned char smem_raw[];
+    extern __shared__ __align__(16) unsigned char smem_base[];
+    unsigned char *const smem_raw = smem_base + DE_SKIPLIST_BYTES; // [0, DE_SKIPLIST_BYTES): the live-tree list of h_tree_skip; rows behind it
     T *__restrict__ rows = reinterpret_cast<T *>(smem_raw);
 
     const TileMap tm = map_block(blockIdx.x, a.n_chunks, a.n_tiles);
@@ -1211,6 +1221,17 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     const int tid = threadIdx.x;
     const int64_t base = tm.tile * TILE;
     const int64_t last = a.N - 1;
+    const int tA = tm.chunk * a.trees_per_chunk; // this workgroup's trees: [tA, tB)
+    const int tB = (tA + a.trees_per_chunk < a.n_trees) ? tA + a.trees_per_chunk : a.n_trees;
+    // early exit: the flags of the first <= 64 trees, requested before the X tile so that the two latencies overlap
+    // (wave 0 reads them for the whole workgroup: two waves reading at different moments could see different flags, and the
+    // workgroup shares ONE live-tree list)
+    uint8_t f_first = 1;
+    if (a.skip_flagged && tid < 64 && tA + tid < tB)
+        f_first = __hip_atomic_load(a.ok + tA + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the 64-bit skip mask travels from wave 0 to the others through the padding vector of LDS row 0 (16 unused bytes behind the
+    // DE_TBLK vectors of every row)
+    uint64_t *const mask_slot = reinterpret_cast<uint64_t *>(smem_raw + (size_t)DE_TBLK * 16);
     {
         const uint32_t F = (uint32_t)a.F;
         const uint32_t total = (uint32_t)TILE * F;
@@ -1273,12 +1294,14 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             *reinterpret_cast<U32x4 *>(crow) = U32x4{cv[0], cv[1], (uint32_t)tab, (uint32_t)(tab >> 32)};
         }
     }
+    if (a.skip_flagged && tid < 64) { // (all 64 lanes of wave 0 take part in the ballot)
+        const uint64_t m0 = __ballot(f_first == 0);
+        if (tid == 0) *mask_slot = m0;
+    }
     __syncthreads();
 
     const ConstU4Ptr code = (ConstU4Ptr)(uintptr_t)a.code;
     const ConstI32Ptr code_off = (ConstI32Ptr)(uintptr_t)a.code_off;
-    const int t0 = tm.chunk * a.trees_per_chunk;
-    const int t1 = (t0 + a.trees_per_chunk < a.n_trees) ? t0 + a.trees_per_chunk : a.n_trees;
     const bool full = base + TILE <= a.N;
     // LDS byte address of this thread's vector in row 0 (the dynamic LDS segment starts at 0)
     // (the low 32 bits of a flat pointer into LDS are the LDS byte offset)
@@ -1295,27 +1318,54 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         }
     }
 
-    if (t0 >= t1) return;
-    // the trees of this chunk whose flag is already 0 (bit i: tree t0 + i): found incomplete by a workgroup that ran earlier (or
-    // by the host: a non-finite constant) — the reference stops evaluating such a tree at its first non-finite array
+    if (tA >= tB) return;
+    const uint64_t ldo = (uint64_t)a.ld_out * sizeof(T);
+    // A chunk runs in sub-chunks of <= 64 trees: the flags of a sub-chunk are read when it starts (one 64-bit ballot; the later
+    // ones see what other workgroups found in the meantime), then its trees run as ONE chain.  Without the early exit the whole
+    // chunk is one sub-chunk.
+    const int sub = a.skip_flagged ? 64 : (tB - tA);
+    for (int t0 = tA; t0 < tB; t0 += sub) {
+    const int t1 = t0 + sub < tB ? t0 + sub : tB;
+    // the trees of this sub-chunk whose flag is already 0 (bit i: tree t0 + i): found incomplete by a workgroup that ran earlier
+    // (or by the host: a non-finite constant) — the reference stops evaluating such a tree at its first non-finite array
     // (src/Evaluate.jl:26-32), this kernel stops at the next workgroup.  Agent scope: past this CU's vector cache.
     uint64_t skip = 0ull;
     if (a.skip_flagged) {
-        const int i = t0 + (tid & 63);
-        const uint8_t f = i < t1 ? __hip_atomic_load(a.ok + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)1;
-        skip = __ballot(f == 0);
+        if (t0 != tA) { // a later sub-chunk: wave 0 reads its flags once every wave is done with the previous list
+            __syncthreads();
+            if (tid < 64) {
+                const int i = t0 + tid;
+                const uint8_t f = i < t1 ? __hip_atomic_load(a.ok + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)1;
+                const uint64_t m0 = __ballot(f == 0);
+                if (tid == 0) *mask_slot = m0;
+            }
+            __syncthreads();
+        }
+        { // (the first sub-chunk's mask was written before the barrier behind the X staging)
+            const uint64_t m = *mask_slot;
+            skip = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+        }
+        if constexpr (!LOSS) {
+            // the live trees' header addresses, in reverse order (see h_tree_skip); every wave writes the whole list (same values):
+            // a wave reads only what it wrote itself, no barrier
+            const int i = t0 + (tid & 63);
+            if (i < t1 && !((skip >> (tid & 63)) & 1ull)) {
+                const uint32_t r = (uint32_t)__builtin_popcountll((~skip & ((t1 - t0) >= 64 ? ~0ull : ((1ull << (t1 - t0)) - 1ull))) >> 1 >> (tid & 63));
+                const uint64_t hdr = (uint64_t)(uintptr_t)(a.code + a.code_off[i] - 1);
+                reinterpret_cast<uint32_t *>(smem_base)[r] = (uint32_t)hdr;
+            }
+        }
     }
-    const uint64_t ldo = (uint64_t)a.ld_out * sizeof(T);
     if constexpr (!LOSS) {
-        // ONE call per chunk: the trees t0..t1 are consecutive in the stream and every tree's end record (h_tree_end)
+        // ONE call per sub-chunk: the trees t0..t1 are consecutive in the stream and every tree's end record (h_tree_end)
         // stores its results and runs on into the next tree; the call returns after the last one.
         int first = t0;
         if (skip & 1ull) { // leading skipped trees
-            if (~skip == 0ull) return;
+            if (~skip == 0ull) continue;
             const int n = __builtin_ctzll(~skip);
             first += n;
             skip >>= n;
-            if (first >= t1) return;
+            if (first >= t1) continue;
         }
         const ConstU4Ptr rec = code + code_off[first];
         HState<T> st;
@@ -1351,6 +1401,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             if (__ballot(poison_set(st.poison)) != 0ull) flag_incomplete(a.ok + tree, a.skip_flagged);
         }
     }
+    } // sub-chunks
 }
 
 // ---- fused loss, passes 2 and 3: deterministic fixed-order reduction of the per-wave partials.
@@ -1587,14 +1638,14 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc);
     a.trees_per_chunk = tpc;
     a.n_chunks = nch;
-    a.skip_flagged = (e.early_exit && e.skip_flagged && tpc <= 64) ? 1 : 0; // (the skip mask of a chunk is one 64-bit ballot)
+    a.skip_flagged = (e.early_exit && e.skip_flagged && a.F + a.n_slots >= 1) ? 1 : 0; // (chunks of more than 64 trees run in sub-chunks: one 64-bit ballot each; the mask travels through row 0's padding)
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // rows: X, spill slots, then (parametric) the class row [+ the table-pointer row for Float32] of h_param
     a.cls_row_off = (uint32_t)((size_t)(a.F + a.n_slots) * TROW_BYTES);
     const int prm_rows = e.uses_params ? (sizeof(T) == 4 ? 2 : 1) : 0;
     if (e.uses_params && (uint64_t)e.ld_params * (uint64_t)e.n_classes * sizeof(T) > 0xFFFFFFFFull) return hipErrorInvalidValue; // 32-bit column offsets
-    const size_t lds = (size_t)(a.F + a.n_slots + prm_rows + env_int("DE_EXTRA_LDS_ROWS", 0)) * TROW_BYTES;
+    const size_t lds = (size_t)(a.F + a.n_slots + prm_rows + env_int("DE_EXTRA_LDS_ROWS", 0)) * TROW_BYTES + DE_SKIPLIST_BYTES;
     void (*kern)(const KArgs<T>) = e.uses_params ? de_eval_threaded_kernel<T, true> : de_eval_threaded_kernel<T, false>;
     a.y = a.w = nullptr;
     a.partial = nullptr;

@@ -1,0 +1,182 @@
+# runtests_hip.jl — what a maintainer with Julia, DynamicExpressions.jl and an MI355X runs to close SURVEY.md §8f-2:
+#
+#     DE_HIP_LIB=/path/to/libde_hip.so julia --project=<env with DynamicExpressions> runtests_hip.jl
+#
+# The builder's image has no Julia: this file (like the shim it loads) was never executed there.  It checks the shim
+# against the REAL reference — DynamicExpressions.jl's own CPU `eval_tree_array` / `eval_grad_tree_array` on the same
+# (tree, X) — which is the parity the C restatement under oracle/ can only approximate:
+#   1. the 118 known answers transcribed from the reference's tests and docs (golden_cases.jl, generated from
+#      tests/golden/reference_known_answers.json): flag, values at the case's tolerance, AND agreement with the CPU path
+#      (1e-5 relative Float32 / 1e-12 Float64 on the samples where both are finite; identical `complete`);
+#   2. a random population through HIPPopulation against the CPU path tree by tree;
+#   3. GraphNode trees with shared subtrees (the CSE tape: ADVICE r2 — `flatten_cse!` threw a KeyError before round 3);
+#   4. forward-mode gradients in the three modes.
+using Test
+using DynamicExpressions
+using DynamicExpressions: Node, GraphNode, OperatorEnum, EvalContext, eval_tree_array, eval_grad_tree_array
+
+include(joinpath(@__DIR__, "DynamicExpressionsHIPExt.jl"))
+const HIP = DynamicExpressionsHIPExt
+include(joinpath(@__DIR__, "golden_cases.jl"))
+
+# ---- the helper operators the reference's tests define (test/test_params.jl:7-29 and friends), registered by identity ----
+safe_log(x::T) where {T} = x > zero(T) ? log(x) : T(NaN)
+safe_log2(x::T) where {T} = x > zero(T) ? log2(x) : T(NaN)
+safe_log10(x::T) where {T} = x > zero(T) ? log10(x) : T(NaN)
+safe_sqrt(x::T) where {T} = x >= zero(T) ? sqrt(x) : T(NaN)
+safe_acosh(x::T) where {T} = x >= one(T) ? acosh(x) : T(NaN)
+relu(x::T) where {T} = x < zero(T) ? zero(T) : x
+square(x) = x * x
+cube(x) = x * x * x
+neg(x) = -x
+custom_cos(x) = cos(x)^2
+pow_abs2(x, y) = exp(y * log(abs(x)))
+for (f, n) in ((safe_log, :safe_log), (safe_log2, :safe_log2), (safe_log10, :safe_log10), (safe_sqrt, :safe_sqrt),
+               (safe_acosh, :safe_acosh), (relu, :relu), (square, :square), (cube, :cube), (neg, :neg),
+               (custom_cos, :custom_cos), (pow_abs2, :pow_abs2))
+    HIP.register_hip_opcode(f, n)
+end
+const NAMED = Dict{String,Any}(
+    "cos" => cos, "sin" => sin, "exp" => exp, "abs" => abs, "sqrt" => sqrt, "+" => +, "-" => -, "*" => *, "/" => /, "^" => ^,
+    "max" => max, "min" => min, "rem" => rem, "fma" => fma, "clamp" => clamp, "safe_log" => safe_log, "safe_log2" => safe_log2,
+    "safe_log10" => safe_log10, "safe_sqrt" => safe_sqrt, "safe_acosh" => safe_acosh, "relu" => relu, "square" => square,
+    "cube" => cube, "neg" => neg, "custom_cos" => custom_cos, "pow_abs2" => pow_abs2,
+)
+
+function operators_of(case)
+    names = (case.unary, case.binary, case.ternary)
+    all(n -> haskey(NAMED, n), Iterators.flatten(names)) || return nothing   # (gamma: SpecialFunctions, optional)
+    una = Tuple(NAMED[n] for n in case.unary)
+    bin = Tuple(NAMED[n] for n in case.binary)
+    ter = Tuple(NAMED[n] for n in case.ternary)
+    return isempty(ter) ? OperatorEnum(1 => una, 2 => bin) : OperatorEnum(1 => una, 2 => bin, 3 => ter)
+end
+
+# S-expression -> Node{T,D} (degree D = 2, or 3 when the case has ternary operators)
+function build(s, ::Type{T}, case, ::Val{D}, ::Type{N}=Node) where {T,D,N}
+    s isa Number && return N{T,D}(; val=T(s))
+    head = s[1]
+    if head == "x" && length(s) == 2 && s[2] isa Integer
+        return N{T,D}(; feature=Int(s[2]))
+    end
+    kids = [build(c, T, case, Val(D), N) for c in s[2:end]]
+    names = (case.unary, case.binary, case.ternary)[length(kids)]
+    op = findfirst(==(head), names)
+    return N{T,D}(; op=op, children=Tuple(kids))
+end
+has_param(s) = !(s isa Number) && ((s[1] == "p" && length(s) == 2 && s[2] isa Integer) || any(has_param, s[2:end]))
+
+matrix(::Type{T}, rows) where {T} = isempty(rows) ? zeros(T, 0, 0) : T[T(rows[f][j]) for f in 1:length(rows), j in 1:length(rows[1])]
+
+function agree(a::AbstractVector{T}, b::AbstractVector{T}) where {T}
+    rel = T === Float32 ? 1e-5 : 1e-12
+    for (x, y) in zip(a, b)
+        (isfinite(x) && isfinite(y)) || continue
+        abs(Float64(x) - Float64(y)) <= rel * abs(Float64(y)) + 1e-30 || return false
+    end
+    return true
+end
+
+@testset "known answers of the reference through the HIP shim" begin
+    n_run = 0
+    for case in GOLDEN_CASES
+        case.kind in ("eval", "flag", "grad") || continue          # (ParametricExpression: see the population tests below)
+        has_param(case.tree) && continue
+        ops = operators_of(case)
+        ops === nothing && continue
+        T = case.dtype == "float32" ? Float32 : Float64
+        D = isempty(case.ternary) ? 2 : 3
+        tree = build(case.tree, T, case, Val(D))
+        X = matrix(T, case.X)
+        ctx = EvalContext(; early_exit=Val(case.early_exit), bumper=Val(false))   # the Bumper FLAG semantics are covered in Python
+        case.bumper && continue
+        if case.kind == "grad"
+            variable = case.mode == "variable" ? Val(true) : case.mode == "both" ? Val(:both) : Val(false)
+            y, g, ok = HIP._hip_eval_grad_tree_array(tree, X, ops; variable)
+            yr, gr, okr = eval_grad_tree_array(tree, X, ops; variable)
+            @test ok == okr == case.ok
+            if ok
+                @test agree(y, yr)
+                @test all(k -> agree(view(g, k, :), view(gr, k, :)), axes(g, 1))
+            end
+        else
+            r = HIP._hip_eval_tree_array(tree, X, ops, ctx)
+            @test r !== nothing
+            y, ok = r
+            yr, okr = eval_tree_array(tree, X, ops; eval_context=ctx)
+            @test ok == case.ok
+            @test ok == okr
+            if ok
+                @test agree(y, yr)
+                if case.y !== nothing
+                    want = Float64[v for v in case.y]
+                    for j in eachindex(want)
+                        (j - 1) in case.y_nonfinite_idx && (@test !isfinite(y[j]); continue)
+                        isfinite(want[j]) || continue
+                        @test abs(Float64(y[j]) - want[j]) <= max(case.atol, 1e-30) + max(case.rtol, T === Float32 ? 1e-5 : 1e-13) * abs(want[j])
+                    end
+                end
+            end
+        end
+        n_run += 1
+    end
+    @test n_run >= 90
+end
+
+@testset "a random population: HIPPopulation against the reference CPU path" begin
+    ops = OperatorEnum(1 => (cos, exp), 2 => (+, -, /, *))          # benchmark/benchmarks.jl:32-35
+    for T in (Float32, Float64)
+        x = [Node{T}(; feature=i) for i in 1:5]
+        trees = Node{T,2}[
+            x[1] * cos(x[2] - T(3.2)),                                # README.md:30-39
+            exp(x[3]) / (x[4] * x[4] + T(1.5)),
+            cos(exp(x[1] * T(0.3))) - x[5] * (x[2] + T(0.25)),
+            x[1] / (x[2] - x[2]),                                     # 1 / 0: incomplete
+            exp(exp(x[3] * T(40))),                                   # overflows: incomplete
+        ]
+        X = randn(T, 5, 4099)
+        pop = HIP.HIPPopulation(trees, ops, 5)
+        out, ok = HIP.eval_population(pop, X)
+        for (t, tree) in enumerate(trees)
+            yr, okr = eval_tree_array(tree, X, ops)
+            @test ok[t] == okr
+            okr && @test agree(view(out, :, t), yr)
+        end
+        @test ok == [true, true, true, false, false]
+    end
+end
+
+@testset "GraphNode: shared subtrees through the CSE tape" begin
+    ops = OperatorEnum(1 => (cos, exp), 2 => (+, -, /, *))
+    for T in (Float32, Float64)
+        x1, x2 = GraphNode{T}(; feature=1), GraphNode{T}(; feature=2)
+        c = GraphNode{T}(; val=T(0.75))
+        s = cos(x1 * c)                                               # ONE node object ...
+        g1 = s + s * (c * x2)                                         # ... used twice; c three times
+        g2 = exp(s) / (s + T(2))
+        g3 = x1 * x2 + c                                              # nothing shared
+        X = randn(T, 2, 1031)
+        pop = HIP.HIPPopulation([g1, g2, g3], ops, 2)                 # threw KeyError in flatten_cse! before round 3
+        out, ok = HIP.eval_population(pop, X)
+        for (t, g) in enumerate((g1, g2, g3))
+            yr, okr = eval_tree_array(g, X, ops)
+            @test ok[t] == okr == true
+            @test agree(view(out, :, t), yr)
+        end
+    end
+end
+
+@testset "forward-mode gradients in the three modes" begin
+    ops = OperatorEnum(1 => (cos, exp), 2 => (+, -, /, *))
+    x = [Node{Float64}(; feature=i) for i in 1:3]
+    tree = x[1] * cos(x[2] * 0.7 - 3.2) + exp(x[3] * 0.1) / (x[1] * x[1] + 2.5)
+    X = randn(Float64, 3, 257)
+    for variable in (Val(true), Val(false), Val(:both))
+        y, g, ok = HIP._hip_eval_grad_tree_array(tree, X, ops; variable)
+        yr, gr, okr = eval_grad_tree_array(tree, X, ops; variable)
+        @test ok == okr == true
+        @test size(g) == size(gr)
+        @test agree(y, yr)
+        @test all(k -> agree(view(g, k, :), view(gr, k, :)), axes(g, 1))
+    end
+end

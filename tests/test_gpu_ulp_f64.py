@@ -90,7 +90,9 @@ UNARY = {
     "log1p": (np.log1p, lambda r: np.concatenate([grid(-0.99, 10, N, r), grid(1e-20, 1e20, N, r, True)]), 1.0),
     "sin": (np.sin, lambda r: np.concatenate([grid(-10, 10, N, r), grid(-1e6, 1e6, N, r)]), 1.0),
     "cos": (np.cos, lambda r: np.concatenate([grid(-10, 10, N, r), grid(-1e6, 1e6, N, r)]), 1.0),
-    "tan": (np.tan, lambda r: np.concatenate([grid(-10, 10, N, r), grid(-1e4, 1e4, N, r)]), 1.25),  # OCML: 1.03 measured
+    "tan": (np.tan, lambda r: np.concatenate([grid(-10, 10, N, r), grid(-1e4, 1e4, N, r), grid(-1.6e6, 1.6e6, N, r),
+                                              np.array([0.0, -0.0, 1e-300, 2.0 ** -28, 0.6743354797363281, 0.7853981633974483, 1647098.9, 1e22])]),
+            1.0),  # de_tan_f64 = msun __kernel_tan + rem_pio2 (round 3): 0.80 measured (OCML: 1.03)
     "sinh": (np.sinh, lambda r: np.concatenate([grid(-700, 700, N, r), grid(-1, 1, N, r)]), 1.0),
     "cosh": (np.cosh, lambda r: grid(-700, 700, N, r), 1.0),
     "tanh": (np.tanh, lambda r: np.concatenate([grid(-20, 20, N, r), grid(-1e-3, 1e-3, N, r)]), 1.0),
@@ -189,7 +191,7 @@ def _jl_mod(x, y):
 
 BINARY = {
     "+": (lambda x, y: x + y, 0.5), "-": (lambda x, y: x - y, 0.5), "*": (lambda x, y: x * y, 0.5),
-    "/": (lambda x, y: x / y, 0.5), "^": (np.power, 1.5), "max": (np.maximum, 0.0), "min": (np.minimum, 0.0),  # OCML pow: 1.26 measured
+    "/": (lambda x, y: x / y, 0.5), "^": (np.power, 1.0), "max": (np.maximum, 0.0), "min": (np.minimum, 0.0),  # de_pow_f64 = msun pow core (round 3): 0.80 measured (OCML: 1.26)
     "mod": (_jl_mod, 0.5), "rem": (np.fmod, 0.0), "greater": (lambda x, y: (x > y).astype(LD), 0.0),
     # per unit of amplification: (0.63 ulp of log + 0.5 of the product) x 2 (binade position of m) x 2 (of the result) = 4.5
     "pow_abs2": (_pow_abs2_ref, 4.5),

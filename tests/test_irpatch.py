@@ -108,7 +108,7 @@ def test_asmpatch_relaxes_only_the_entry_wait_of_eval_handlers():
             first.setdefault(name, ins)
             if re.match(r"(scratch_|flat_|global_|buffer_)", ins):
                 vmem[name] = True
-    handlers = {n: i for n, i in first.items() if re.match(r"_ZN2de(7h_chainI|7h_paramI|9h_un_fastI|10h_div_fastI|12h_unrow_fastI|14h_divrowc_fastI|11h_div2_fastI)", n)}  # (h_un_fast / h_div_fast: fast-path-only Float32 cos / exp / sin and exact divisions)
+    handlers = {n: i for n, i in first.items() if re.match(r"_ZN2de(7h_chainI|7h_paramI|9h_un_fastI|10h_div_fastI|12h_unrow_fastI|14h_divrowc_fastI|11h_div2_fastI|11h_tree_skipI)", n)}  # (h_un_fast / h_div_fast: fast-path-only Float32 cos / exp / sin and exact divisions; h_tree_skip: the early-exit walk, LDS + scalar loads only)
     others = {n: i for n, i in first.items() if n not in handlers and n.startswith("_ZN2de") and "kernel" not in n and "fill_handlers" not in n}
     assert len(handlers) > 300 and others
     relaxed = {n for n, i in handlers.items() if i == "s_waitcnt expcnt(0) lgkmcnt(0)"}

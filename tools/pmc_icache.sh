@@ -16,7 +16,7 @@ for set in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_D
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
   d=$O/$(echo $set | cut -d' ' -f1)
-  rocprofv3 --pmc $set --output-format csv -d $d -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-turbo-leg "$@" > /dev/null 2>$d.err
+  rocprofv3 --pmc $set --output-format csv -d $d -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-turbo-leg --no-full-eval-leg "$@" > /dev/null 2>$d.err
 done
 python $R/tools/pmc_parse.py $O $O/summary.txt
 head -c 6000 $O/avail.txt
