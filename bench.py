@@ -221,6 +221,56 @@ def valu_ceiling(pop, n_trees, units, kernel_ms, turbo=False, complete=None):
                        "profiles/r2_clock_probe.json) x de_program_dump(stage 3) dispatch histogram of this population")
 
 
+def valu_measured(pm_entry):
+    """The VALU ceiling from EXECUTED instruction counts (hardware counters of tools/profile_round.sh, same kernel sources:
+    hash checked by the caller): VALU instructions x their issue cost against the SIMD cycles the step's kernels had.  The
+    counters do not tell packed / SGPR-operand forms (3.7 cycles) from plain ones (2.0): `busy_bounds` prices all of them one
+    way or the other, `busy_est` uses the static share of half-rate forms in the kernel's code object
+    (profiles/valu_static_mix.json).  Transcendentals are counted exactly (7.35 cycles).  Works for every kernel of the
+    library — the gradient, reverse and fused-loss ones have no per-handler cycle table."""
+    sq = (pm_entry or {}).get("sq_per_step_by_kernel")
+    times = (pm_entry or {}).get("kernels_us_per_step")
+    if not sq or not times:
+        return None
+    mix_path = os.path.join(ROOT, "profiles", "valu_static_mix.json")
+    mods = {}
+    if os.path.exists(mix_path):
+        with open(mix_path) as fh:
+            mods = json.load(fh).get("modules", {})
+    import re
+    tot = dict(valu=0.0, trans=0.0, salu=0.0, lo=0.0, hi=0.0, est=0.0, avail=0.0, us=0.0)
+    clocks = []
+    for k, c in sq.items():
+        v, t = c.get("SQ_INSTS_VALU", 0.0), c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+        m = re.search(r"(gtm|rtm)_(\w+?)::", k)
+        mod = ("de_gt_" if m and m.group(1) == "gtm" else "de_rt_") + m.group(2) if m else "de_kernels"
+        h = mods.get(mod, {}).get("half_share_of_non_trans", 0.5)
+        us = times.get(k)
+        if us is None:
+            continue
+        grbm = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # summed over the 8 XCDs
+        # (the counter pass and the timing pass are separate runs of the same steps: the clock is cycles of one over time of the other)
+        if grbm > 0 and us > 0:
+            clocks.append((grbm / (us * 1e-6), us))
+        tot["valu"] += v
+        tot["trans"] += t
+        tot["salu"] += c.get("SQ_INSTS_SALU", 0.0)
+        tot["lo"] += (v - t) * 2.0 + t * 7.35
+        tot["hi"] += (v - t) * 3.7 + t * 7.35
+        tot["est"] += (v - t) * (2.0 * (1 - h) + 3.7 * h) + t * 7.35
+        tot["us"] += us
+    if tot["us"] <= 0:
+        return None
+    clock = sum(c * w for c, w in clocks) / sum(w for _, w in clocks) if clocks else 2.08e9
+    avail = tot["us"] * 1e-6 * clock * 1024  # SIMD cycles of 256 CUs x 4 SIMDs over the kernels' time
+    return dict(valu_insts_per_step=tot["valu"], trans_insts_per_step=tot["trans"], salu_per_valu=tot["salu"] / max(tot["valu"], 1.0),
+                kernels_us_per_step=tot["us"], engine_clock_ghz=clock / 1e9, simd_cycles_available=avail,
+                valu_cycles_est=tot["est"], busy_est=tot["est"] / avail, busy_bounds=[tot["lo"] / avail, tot["hi"] / avail],
+                floor_ms_est=tot["est"] / (1024 * clock) * 1e3,
+                source="profiles/pmc_summary.json (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 ... of the same workload) x "
+                       "issue costs of profiles/r2_valu_rate.json; half-rate share from profiles/valu_static_mix.json")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -534,6 +584,7 @@ def main():
         alg_bytes = b_unit * units
         achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9
         single = BYTES_PER_TREE_SAMPLE_SINGLE * units / (k_avg_ms * 1e-3) / 1e9
+        pm_entry = None
         traffic, traffic_note = None, "no profiles/pmc_summary.json"
         prof = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(prof):  # measured by tools/profile_round.sh with rocprofv3 --pmc (separate passes)
@@ -546,7 +597,8 @@ def main():
                 # the counters were collected with OTHER kernels than the ones running now: not this launch's traffic
                 traffic_note = "profiles/pmc_summary.json is stale (kernel_source_hash differs from the sources of the running library): rerun tools/profile_round.sh"
             else:
-                traffic = pm.get(key, {}).get("hbm_bytes_per_launch")
+                pm_entry = pm.get(key, {})
+                traffic = pm_entry.get("hbm_bytes_per_launch")
                 traffic_note = f"rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per step, profiles/pmc_summary.json[{key}] (same kernel sources: hash checked)"
         # C4 is a fixed 8-way sharded population: a job of N <= 8 ranks runs the first N shards (per-GPU work fixed: weak)
         scaling_kind = "weak" if (shards or not strong) else "strong"
@@ -573,6 +625,7 @@ def main():
                          "single_tree_equivalent": {"bytes_per_tree_sample": BYTES_PER_TREE_SAMPLE_SINGLE,
                                                     "achieved": single, "frac": single / HBM_PEAK_GBS},
                          "valu": valu_ceiling(pop, len(trees), units_all, k_avg_ms, complete=okh) if plain_eval else None,
+                         "valu_measured": valu_measured(pm_entry),
                          "note": "X tile reused by k_eff trees from LDS: HBM traffic ~= the output; the kernel is "
                                  "VALU/scalar-issue bound (DESIGN.md §Roofline)"},
         }

@@ -236,6 +236,31 @@ def test_binary_operator_ulp_f64(api, name):
     assert e.max() <= lim, f"{name}: max {e.max():.4f} ulp (bound {bound} ulp)"
 
 
+def test_pow_f64_special_cases_and_edges(api):
+    """de_pow_f64 (csrc/de_device_ops.h) takes the msun main path for finite non-zero x (negative with an integral y) and finite
+    non-zero |y| <= 2^31 and OCML's case analysis elsewhere: signs of negative bases, exact small powers, subnormal bases,
+    results next to overflow / underflow, zeros, infinities and NaN must come out as IEEE pow defines them (numpy = C pow)."""
+    xs = np.array([-2.0, -2.0, -2.0, -0.5, -3.0, -1.0, -1.0, 5e-324, 1e-310, 2.0, 2.0, 2.0, 0.5, 1.0000000000000002, 0.9999999999999999,
+                   10.0, 10.0, 1.7976931348623157e308, 0.0, -0.0, 0.0, np.inf, -np.inf, np.nan, 2.0, 1.0, -8.0, 3.0, 3.0, 1e-300, 7.0, 7.0])
+    ys = np.array([3.0, 4.0, -3.0, 2.0, 0.5, 1e9, 1e9 + 1, 0.5, 2.0, 1023.0, 1024.0, -1074.0, 1075.0, 4.5e15, 4.5e15,
+                   308.0, 309.0, 1.0, 3.0, 3.0, -1.0, -2.0, 3.0, 1.0, np.nan, np.nan, 1.0 / 3.0, 2.0, -1.0, -1.03, 0.0, 1e-320])
+    X = np.asfortranarray(np.stack([xs, ys]))
+    ops = de.OperatorEnum(binary_operators=("^",))
+    out, _ = api.eval_tree_array(de.Node(1, de.Node(feature=1), de.Node(feature=2)), X, ops, eval_context=api.EvalContext(early_exit=False))
+    with np.errstate(all="ignore"):
+        want = np.power(xs, ys)
+    assert np.array_equal(np.isnan(out), np.isnan(want)), (out, want)
+    fin = np.isfinite(want)
+    assert np.array_equal(out[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)])          # the infinities, with their signs
+    assert np.array_equal(np.signbit(out[fin]), np.signbit(want[fin]))                        # (-2)^3 < 0, (-0)^3 = -0, underflow to +-0
+    exact = np.array([0, 1, 2, 3, 9, 17, 18, 19, 27, 28, 30])                                 # small integer powers, x^1, x^0 ... are exact
+    np.testing.assert_array_equal(out[exact], want[exact])
+    with np.errstate(all="ignore"):
+        sel = fin & (want != 0) & (np.abs(want) >= np.finfo(np.float64).tiny)
+        e = ulp_err(out[sel], np.power(xs[sel].astype(LD), ys[sel].astype(LD)))
+    assert e.max() <= 1.0, (e, out, want)
+
+
 def test_ternary_operators_exact_f64(api):
     rng = np.random.Generator(np.random.PCG64(77))
     n = 300

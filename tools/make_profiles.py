@@ -105,6 +105,17 @@ def main():
             e[f"{c}_KiB_per_step"] = tot[c]
         if len(tot) == 2:
             e["hbm_bytes_per_launch"] = (2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024  # per STEP (= per launch for the plain eval)
+        f = one(os.path.join(wdir, "pmc_SQ", "**", "*counter_collection.csv"))
+        if f:  # executed instruction counts per step, summed over the de_* kernels (full-size launches)
+            rr = [r for r in csv.DictReader(open(f)) if "de_" in r["Kernel_Name"] and "fill_handlers" not in r["Kernel_Name"]]
+            gm = collections.defaultdict(int)
+            for r in rr:
+                gm[r["Kernel_Name"]] = max(gm[r["Kernel_Name"]], int(r["Grid_Size"]))
+            rr = [r for r in rr if 2 * int(r["Grid_Size"]) >= gm[r["Kernel_Name"]] and gm[r["Kernel_Name"]] > 64 * 256]
+            sq = collections.defaultdict(lambda: collections.defaultdict(float))
+            for r in rr:
+                sq[r["Kernel_Name"].split("(")[0][-70:]][r["Counter_Name"]] += float(r["Counter_Value"]) / 3  # --steps 2 --warmup 1
+            e["sq_per_step_by_kernel"] = {k: dict(v) for k, v in sq.items()}
         b = os.path.join(wdir, "bench_under_rocprof.json")
         if os.path.exists(b) and os.path.getsize(b):
             try:

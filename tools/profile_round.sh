@@ -16,5 +16,7 @@ for wl in $WLS; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $c --output-format csv -d $O/$wl/pmc_$c -o k -- python $R/bench.py $args --steps 2 --warmup 1 $common > /dev/null 2>$O/$wl/pmc_$c.log
   done
+  # executed instruction mix of every kernel of the step (the VALU ceiling of bench.py's `roofline.valu_measured`)
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/$wl/pmc_SQ -o k -- python $R/bench.py $args --steps 2 --warmup 1 $common > /dev/null 2>$O/$wl/pmc_SQ.log
   echo "$wl: $(find $O/$wl -name '*.csv' | wc -l) csv files"
 done

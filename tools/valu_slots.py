@@ -218,7 +218,44 @@ def table(obj, ty="float", turbo=False):
     return slots, counts
 
 
+def static_mix(obj):
+    """Static VALU instruction mix of a code object: (full-rate, half-rate, transcendental) counts over every function.  Used to
+    price EXECUTED instruction counts from the hardware counters (bench.py `roofline.valu_measured`): the counters tell how many
+    VALU instructions ran, not whether they were packed / SGPR-operand forms."""
+    n = [0, 0, 0]
+    for _, code in functions(obj).items():
+        for _, mn, ops, _ in code:
+            w = weight(mn, ops)
+            if w == C_FULL:
+                n[0] += 1
+            elif w == C_HALF:
+                n[1] += 1
+            elif w == C_TRANS:
+                n[2] += 1
+    return n
+
+
+def write_static_mix(out):
+    """profiles/valu_static_mix.json: per code-object module of the build (csrc/_obj/irp_*/k.out)."""
+    import glob
+    res = {}
+    for k in sorted(glob.glob(os.path.join(ROOT, "dynamicexpressions.jl_amd", "csrc", "_obj", "irp_*", "k.out"))):
+        mod = os.path.basename(os.path.dirname(k))[4:]
+        full, half, trans = static_mix(k)
+        res[mod] = dict(full_rate=full, half_rate=half, transcendental=trans, half_share_of_non_trans=half / max(full + half, 1))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_profiles import kernel_source_hash
+    doc = dict(kernel_source_hash=kernel_source_hash(), cycles=dict(full=C_FULL, half=C_HALF, trans=C_TRANS),
+               source="tools/valu_slots.py --static-mix: llvm-objdump of every device code object of the build, instruction classes of "
+                      "profiles/r2_valu_rate.json", modules=res)
+    with open(out, "w") as fh:
+        json.dump(doc, fh, indent=1)
+    print(f"{len(res)} modules -> {out}")
+
+
 def main():
+    if "--static-mix" in sys.argv:
+        return write_static_mix(os.path.join(ROOT, "profiles", "valu_static_mix.json"))
     ap = argparse.ArgumentParser()
     ap.add_argument("--obj", default=os.path.join(ROOT, "dynamicexpressions.jl_amd", "csrc", "_obj", "irp_de_kernels", "k.out"))
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
