@@ -1080,6 +1080,12 @@ int de_program_verify(const de_program_t *p) {
         for (int64_t t = 0; t < p->n_trees; t++) {
             const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1], h = p->ccode_off[(size_t)t];
             if (h != i0 + (int32_t)t + 1) return bad("chained offset", t, h, (uint64_t)i0);
+            if (i1 > i0) { // a tree never starts by reading the accumulator: the end of the previous tree leaves it as it is
+                const BoundInstr &f0 = p->fbcode[(size_t)i0];
+                const uint32_t aux0 = f0.arg >> 24;
+                const int deg0 = aux0 == (uint32_t)DOP_LOAD ? 0 : de_opcode_degree((int)aux0);
+                if (top_reads_acc(f0.bop, deg0)) return bad("first instruction of a tree reads the accumulator", t, 0, f0.bop);
+            }
             { // the header record (in front of the tree) carries the tree's record count: h_tree_skip steps over the tree with it
                 const BoundInstr &hd = p->ccode[(size_t)h - 1];
                 if ((f32 ? hd.arg : hd.lo) != (uint32_t)(i1 - i0)) return bad("tree header does not carry the tree's length", t, 0, f32 ? hd.arg : hd.lo);

@@ -176,6 +176,23 @@ constexpr int topx_endv_of(uint32_t id) {
          : (id >= BOP_UN_BASE && id < BOP_UN_END && ((id - BOP_UN_BASE) & 3) == 1) ? 12 + (int)((id - BOP_UN_BASE) >> 2) : -1;
 }
 
+// True when a (bound or fused) instruction READS the accumulator (or spills it).  A tree never starts with one — the accumulator
+// is undefined at the start of a tree — which is what lets the end of a tree leave it uncleared (de_kernels.hip HTREE_END_TAIL);
+// de_program_verify checks it.  (aux = the de_opcode's degree for the generic row / parameter handlers: unary = operand only.)
+inline bool top_reads_acc(uint32_t top, int generic_degree) {
+    if (top == BOP_LOAD_ROW || top == BOP_LOAD_CONST || top == BOP_CHECK_ROW || top == BOP_INJ_ROW) return false;
+    if (top == BOP_GEN_ROW || top == BOP_GEN_CONST || top == BOP_GEN_PARAM) return generic_degree != 1 && generic_degree != 0; // degree 0: plain load of a parameter
+    if (top >= BOP_UN_BASE && top < BOP_UN_END) return ((top - BOP_UN_BASE) & 2u) == 0; // bit 1 = the operand is a row
+    if (top < BOP_COUNT) return true; // PUSH, CHECK_ACC, the binary block, GEN_ACC, TERN, INJ_ACC
+    if (top >= TOP_LOADROW_BASE && top < TOP_LOADCONST_PUSH) return ((top - TOP_LOADROW_BASE) & 2u) != 0; // push
+    if (top == TOP_LOADCONST_PUSH) return true;
+    if (top >= TOP_UNROW_BASE && top < TOP_BINROWC_BASE) return ((top - TOP_UNROW_BASE) & 2u) != 0; // push
+    if (top >= TOP_BINROWC_BASE && top < TOP_BIN2_BASE) return true;
+    if (top >= TOP_BIN2_BASE && top < TOP_COUNT) return ((top - TOP_BIN2_BASE) & 1u) != 0; // push
+    if (top >= TOPX_UN_BASE && top < TOPX_BIN_BASE) return ((top - TOPX_UN_BASE) & 1u) != 0; // src == ACC
+    return true; // max / min handlers, anything unknown
+}
+
 // True when a (bound or fused) instruction carries a constant's bits in lo/hi.  Every generic
 // instruction with a constant operand becomes exactly one such instruction, in program order, in the
 // bound and in the fused stream — which is how de_program_set_consts patches immediates in place.

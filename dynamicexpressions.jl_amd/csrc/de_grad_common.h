@@ -59,11 +59,11 @@ constexpr int GPTAB_MAX = 2048;
 // by a workgroup that ran earlier or by the host (non-finite constant).  Its values / Jacobian rows are unspecified then (SURVEY
 // §8a), fused reductions of it are NaN (the finish kernels look at the flag), so the chunk loop steps over it.  Chunks have <= 64
 // trees (else: no skipping).  Agent-scope load: past this CU's vector cache.
-template <typename IDS> __device__ __forceinline__ uint64_t gskip_mask(const uint8_t *ok, IDS tree_ids, int t0, int t1, int enabled) {
+template <typename IDS> __device__ __forceinline__ uint64_t gskip_mask(uint8_t *ok, IDS tree_ids, int t0, int t1, int enabled, int64_t tile) {
     if (!enabled || t1 - t0 > 64) return 0ull;
     const int i = t0 + (int)(threadIdx.x & 63);
     uint8_t f = 1;
-    if (i < t1) f = __hip_atomic_load(ok + (tree_ids ? tree_ids[i] : i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i < t1) f = skip_flag_load(ok + (tree_ids ? tree_ids[i] : i), enabled, tile);
     return __ballot(f == 0);
 }
 template <typename T> __device__ __forceinline__ T gimm(uint32_t w2, uint32_t w3);

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
     const int param_seed0 = a.mode != DE_GRAD_CONSTANT ? -g0 : -0x40000000;
     const int const_seed0 = a.mode == DE_GRAD_CONSTANT ? -g0 : (a.mode == DE_GRAD_BOTH ? P + F - g0 : -0x40000000);
 
-    const uint64_t skip = gskip_mask(a.ok, (const int32_t *)nullptr, t0, t1, a.skip_flagged && a.check);
+    const uint64_t skip = gskip_mask(a.ok, (const int32_t *)nullptr, t0, t1, a.check ? a.skip_flagged : 0, (int64_t)tm.tile);
     for (int tree = t0; tree < t1; ++tree) {
         if ((skip >> (tree - t0)) & 1ull) continue; // already incomplete (early exit)
         const int G = a.diff_g0 >= 0 ? 1 : n_grad[tree];
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(GBLK) de_grad_tape_kernel(const GArgs<T> a) {
                     if (g0 + k < G) gp[k] = d[k];
             }
         }
-        if (a.check && __ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree, a.skip_flagged);
+        if (a.check && __ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree, a.skip_flagged == 1);
     }
 }
 
@@ -342,6 +342,7 @@ static hipError_t launch_grad_t(const GradArgs &ga, int windows, hipStream_t str
     if (n_chunks > max_chunks) n_chunks = max_chunks;
     if (n_chunks < 1) n_chunks = 1;
     a.trees_per_chunk = (int32_t)((e.n_trees + n_chunks - 1) / n_chunks);
+    if (a.skip_flagged) a.skip_flagged = a.trees_per_chunk >= 8 ? 1 : 2; // flag protocol (skip_flag_load, de_device_ops.h): these kernels write little, their L1 lines go stale under 2 (reverse kernel 17.0 / 16.0 ms); 2 only for tiny chunks (many tiles on one flag line)
     a.n_chunks = (int32_t)((e.n_trees + a.trees_per_chunk - 1) / a.trees_per_chunk);
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL || windows > 65535) return hipErrorInvalidValue;

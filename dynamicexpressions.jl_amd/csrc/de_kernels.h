@@ -13,9 +13,11 @@ namespace de {
 constexpr int BLOCK = 256; // threads per workgroup = 4 wavefronts of 64 (flat-switch and gradient kernels)
 // Threaded eval kernel: threads per workgroup.  The kernel is latency-bound: waves per SIMD are what hide
 // the LDS / instruction-fetch latency of every dispatch, and LDS — (n_features + slots) rows of DE_TBLK 16-byte vectors per
-// workgroup — is what limits them; 2-wave workgroups pack the 160 KB of a CU more tightly than 4-wave ones.
+// workgroup — is what limits them.  ONE wave per workgroup since round 3 (256-sample tiles): the same LDS bytes per wave as
+// with two, but a wave no longer holds its partner's LDS and slot while that one finishes its trees, and the staging barrier
+// is wave-local (headline 7.73 -> 7.61 ms, C4 9.88 -> 9.63; 4-16 trees x 5e7 samples 3-5 % slower; round 2: 256 -> 128 neutral).
 #ifndef DE_TBLK
-#define DE_TBLK 128
+#define DE_TBLK 64
 #endif
 constexpr int TBLK = DE_TBLK, TWAVES = DE_TBLK / 64;
 constexpr size_t TROW_BYTES = (size_t)(DE_TBLK + 1) * 16; // LDS row stride: DE_TBLK vectors + one of padding (bank spread)

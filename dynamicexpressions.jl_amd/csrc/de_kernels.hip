@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
     uint64_t skip = 0ull; // trees of the chunk already known to be incomplete (see de_eval_threaded_kernel): not evaluated
     if (EE && a.skip_flagged && t1 - t0 <= 64) {
         const int i = t0 + (tid & 63);
-        const uint8_t f = i < t1 ? __hip_atomic_load(a.ok + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)1;
+        const uint8_t f = i >= t1 ? (uint8_t)1 : skip_flag_load(a.ok + i, a.skip_flagged, tm.tile);
         skip = __ballot(f == 0);
     }
 
@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
             store_ragged<T, G>(o, av, a.N - (base + tid * VW), GT);
         }
         // ---- completion flag: one ballot per wave, one byte store per failing wave
-        if (__ballot(poison != poison) != 0ull) flag_incomplete(a.ok + tree, a.skip_flagged);
+        if (__ballot(poison != poison) != 0ull) flag_incomplete(a.ok + tree, a.skip_flagged == 1);
     }
 }
 
@@ -535,9 +535,8 @@ template <typename T> using BodyFn = HState<T> (*)(HState<T>, uint32_t, typename
 template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t, uint32_t);
 enum : uint32_t { HF_RETURN_EACH = 1u << 31, HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu,
                   HF_SLOW = HF_RETURN_EACH | HF_SLOW_STORE | HF_NO_STORE, // any of them: the out-of-line end of a tree
-                  // no workgroup reads the flags while the kernel runs (no early exit at tree granularity): plain flag stores.  Otherwise
-                  // they are agent-scope (written through, so that workgroups on other XCDs see them too) — which would cost a full
-                  // evaluation a memory write per incomplete tree and wavefront
+                  // plain flag stores (through the caches): always, except under flag protocol 1 (agent scope for every access, an
+                  // experiment: skip_flag_load, de_device_ops.h)
                   HF_PLAIN_FLAG = 1u << 28 };
 template <typename T> __device__ __forceinline__ HandlerFn<T> arg_next(uint32_t w1, uint64_t w23);
 template <> __device__ __forceinline__ HandlerFn<float> arg_next<float>(uint32_t, uint64_t w23) { return reinterpret_cast<HandlerFn<float>>(w23); }
@@ -616,7 +615,7 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS)
         else __hip_atomic_store(reinterpret_cast<__attribute__((address_space(1))) uint8_t *>(okp + tree), (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* visible to the workgroups that start later */ \
     }                                                                                                        \
     if (__builtin_expect(left <= 1u, 0)) return st;                                                          \
-    DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = T(0);                                        \
+    /* (the accumulator is left as it is: no tree starts by reading it — de_bind.h top_reads_acc, checked by de_program_verify) */ \
     st.poison = typename PoisonOf<T>::type{};                                                                \
     left -= 1u;                                                                                              \
     tree += 1u;                                                                                              \
@@ -1227,11 +1226,14 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     // (wave 0 reads them for the whole workgroup: two waves reading at different moments could see different flags, and the
     // workgroup shares ONE live-tree list)
     uint8_t f_first = 1;
-    if (a.skip_flagged && tid < 64 && tA + tid < tB)
-        f_first = __hip_atomic_load(a.ok + tA + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.skip_flagged && tid < 64 && tA + tid < tB) f_first = skip_flag_load(a.ok + tA + tid, a.skip_flagged, tm.tile);
     // the 64-bit skip mask travels from wave 0 to the others through the padding vector of LDS row 0 (16 unused bytes behind the
     // DE_TBLK vectors of every row)
     uint64_t *const mask_slot = reinterpret_cast<uint64_t *>(smem_raw + (size_t)DE_TBLK * 16);
+    // ... and every wave's copy of the trees' record offsets (the live-tree list below), requested before the X tile as well: with
+    // one tree per workgroup (the reference's own call shape, 1 tree x 5e7 samples) a load issued behind the barrier was +50 %
+    int32_t co_first = 0;
+    if (a.skip_flagged && !LOSS && tA + (tid & 63) < tB) co_first = a.code_off[tA + (tid & 63)];
     {
         const uint32_t F = (uint32_t)a.F;
         const uint32_t total = (uint32_t)TILE * F;
@@ -1335,7 +1337,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             __syncthreads();
             if (tid < 64) {
                 const int i = t0 + tid;
-                const uint8_t f = i < t1 ? __hip_atomic_load(a.ok + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint8_t)1;
+                const uint8_t f = i >= t1 ? (uint8_t)1 : skip_flag_load(a.ok + i, a.skip_flagged, tm.tile);
                 const uint64_t m0 = __ballot(f == 0);
                 if (tid == 0) *mask_slot = m0;
             }
@@ -1351,7 +1353,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             const int i = t0 + (tid & 63);
             if (i < t1 && !((skip >> (tid & 63)) & 1ull)) {
                 const uint32_t r = (uint32_t)__builtin_popcountll((~skip & ((t1 - t0) >= 64 ? ~0ull : ((1ull << (t1 - t0)) - 1ull))) >> 1 >> (tid & 63));
-                const uint64_t hdr = (uint64_t)(uintptr_t)(a.code + a.code_off[i] - 1);
+                const uint64_t hdr = (uint64_t)(uintptr_t)(a.code + (t0 == tA ? co_first : a.code_off[i]) - 1);
                 reinterpret_cast<uint32_t *>(smem_base)[r] = (uint32_t)hdr;
             }
         }
@@ -1372,7 +1374,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
         st.poison = typename PoisonOf<T>::type{};
         const int64_t in_tile = a.N - base < (int64_t)TILE ? a.N - base : (int64_t)TILE;
-        const uint32_t flags = (a.vec_store == 2 ? HF_NO_STORE : ((full && a.vec_store) ? 0u : (HF_SLOW_STORE | (uint32_t)in_tile))) | (a.skip_flagged ? 0u : HF_PLAIN_FLAG);
+        const uint32_t flags = (a.vec_store == 2 ? HF_NO_STORE : ((full && a.vec_store) ? 0u : (HF_SLOW_STORE | (uint32_t)in_tile))) | (a.skip_flagged == 1 ? 0u : HF_PLAIN_FLAG);
         const uint64_t outp = (uint64_t)(uintptr_t)(a.out + base) - (uint64_t)(uint32_t)(uintptr_t)smem_raw;
         const U32x4 hp = rec[-1], hd = *rec; // the first handler's address is in the record in front (the previous tree's end record / the head record)
         st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, lds0, rec + 1, outp, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, (uint64_t)(uintptr_t)a.ok,
@@ -1398,7 +1400,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             }
             s = wave_sum_to_lane63(s);
             if ((tid & 63) == 63) a.partial[((int64_t)tm.tile * a.n_trees + tree) * TWAVES + (tid >> 6)] = s;
-            if (__ballot(poison_set(st.poison)) != 0ull) flag_incomplete(a.ok + tree, a.skip_flagged);
+            if (__ballot(poison_set(st.poison)) != 0ull) flag_incomplete(a.ok + tree, a.skip_flagged == 1);
         }
     }
     } // sub-chunks
@@ -1526,7 +1528,7 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
     plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc);
     a.trees_per_chunk = tpc;
     a.n_chunks = nch;
-    a.skip_flagged = (e.early_exit && e.skip_flagged && tpc <= 64) ? 1 : 0;
+    a.skip_flagged = (e.early_exit && e.skip_flagged && tpc <= 64) ? 2 : 0; // (2: the flag protocol of launch_threaded_t)
     a.x_vec = 0;
     a.f_magic = 0;
 
@@ -1638,7 +1640,12 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc);
     a.trees_per_chunk = tpc;
     a.n_chunks = nch;
-    a.skip_flagged = (e.early_exit && e.skip_flagged && a.F + a.n_slots >= 1) ? 1 : 0; // (chunks of more than 64 trees run in sub-chunks: one 64-bit ballot each; the mask travels through row 0's padding)
+    a.skip_flagged = (e.early_exit && e.skip_flagged && a.F + a.n_slots >= 1) ? 1 : 0;
+    // Flag protocol (skip_flag_load, de_device_ops.h): 2 = through the caches + refresher tiles (default), 1 = agent scope for every access
+    // The plain eval kernel writes 20+ GB per launch: flag lines leave the L1s / L2s all the time and protocol 2 is as good as 1 on the
+    // headline (7.52 / 7.59 ms) and far better with few trees.  The fused-loss variant writes almost nothing: under protocol 2 a CU
+    // keeps re-reading its stale L1 line (10.7 instead of 8.4 ms), so it uses protocol 1 unless its chunks are tiny.
+    if (a.skip_flagged) a.skip_flagged = env_int("DE_SKIP_PROTOCOL", (e.loss && tpc >= 8) ? 1 : 2) == 1 ? 1 : 2;
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // rows: X, spill slots, then (parametric) the class row [+ the table-pointer row for Float32] of h_param

@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
         for (int i = RT_LANE(); i < staged; i += 64) dst[(int64_t)i * 4] = *RLDS(T, stage0 + (uint32_t)i * (uint32_t)sizeof(T));
         staged = 0;
     };
-    const uint64_t skip = gskip_mask(a.ok, tree_ids, t0, t1, a.skip_flagged);
+    const uint64_t skip = gskip_mask(a.ok, tree_ids, t0, t1, a.skip_flagged, (int64_t)tm.tile);
     for (int ti = t0; ti < t1; ++ti) {
         if ((skip >> (ti - t0)) & 1ull) continue; // already incomplete (early exit): its reductions are NaN whatever the partials hold
         const int tree = tree_ids[ti];
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
             st = reinterpret_cast<RHandlerFn<T>>(hbase + hd.x)(st, rec + 1, hd.y, rrec_imm<T>(hd), hbase);
         }
         const bool bad = (st.vpoison != st.vpoison) || (nc > 1 && st.gpoison != st.gpoison);
-        if (__ballot(bad) != 0ull) gflag_incomplete(a.ok + tree, a.skip_flagged);
+        if (__ballot(bad) != 0ull) gflag_incomplete(a.ok + tree, a.skip_flagged == 1);
     }
     if (staged > 0) flush();
 }
@@ -482,6 +482,7 @@ hipError_t DE_RT_NAME(rev_thr_launch_)(const GradArgs &ga, int group, hipStream_
     if (n_chunks > max_chunks) n_chunks = max_chunks;
     if (n_chunks < 1) n_chunks = 1;
     a.trees_per_chunk = (int32_t)((grp.n + n_chunks - 1) / n_chunks);
+    if (a.skip_flagged) a.skip_flagged = a.trees_per_chunk >= 8 ? 1 : 2; // flag protocol (skip_flag_load, de_device_ops.h): these kernels write little, their L1 lines go stale under 2 (reverse kernel 17.0 / 16.0 ms); 2 only for tiny chunks (many tiles on one flag line)
     a.n_chunks = (int32_t)((grp.n + a.trees_per_chunk - 1) / a.trees_per_chunk);
     const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;

@@ -159,3 +159,31 @@ def test_host_buffers_and_the_flat_switch_kernel(api, monkeypatch):
     (of, kf), (oe, ke) = res[True], res[False]
     assert np.array_equal(kf, ke) and 0 < kf.sum() < len(trees)
     assert np.array_equal(of[kf].view(np.uint32), oe[kf].view(np.uint32))
+
+
+@pytest.mark.parametrize("tpc", ["16", "128"])
+def test_float64_parametric_and_sub_chunks(api, tpc, monkeypatch):
+    """The same contract for Float64 (32-bit handler addresses in the records: the walk rebuilds them from the program counter's
+    high half), for a ParametricExpression population (the class-row variant of the kernel) and with DE_EVAL_TPC != 64 (more
+    than 64 trees per workgroup run as 64-tree sub-chunks with a fresh mask each; fewer: more workgroups per tile)."""
+    import torch
+    monkeypatch.setenv("DE_EVAL_TPC", tpc)
+    ops = de.synth.BENCH_OPERATORS
+    N = 2**18 + 3
+    g = torch.Generator(device="cuda").manual_seed(7)
+    X = torch.randn((N, 5), generator=g, device="cuda", dtype=torch.float64).t()
+    plain = de.synth.random_population(150, seed=0xEE05, dtype=np.float64)
+    par = de.synth.random_population(150, seed=0xEE06, dtype=np.float64, node_type=de.ParametricNode, nparams=3)
+    params = torch.randn((4, 3), generator=g, device="cuda", dtype=torch.float64).t()  # [P=3, C=4], column-major
+    classes = torch.randint(1, 5, (N,), generator=g, device="cuda", dtype=torch.int32)
+    for trees, kw, P in ((plain, {}, 0), (par, dict(params=params, classes=classes), 3)):
+        res = {}
+        for full in (True, False):
+            pop = api.Population(trees, ops, np.float64, n_features=5, n_params=P, eval_context=api.EvalContext(full_eval=full))
+            out, ok = pop.eval(X, **kw)
+            torch.cuda.synchronize()
+            res[full] = (out, ok)
+            pop.close()
+        (of, kf), (oe, ke) = res[True], res[False]
+        assert torch.equal(kf, ke) and 0 < int(kf.sum()) < len(trees)
+        assert torch.equal(of[kf].view(torch.int64), oe[kf].view(torch.int64))

@@ -12,14 +12,20 @@ X = torch.randn((N, 5), generator=g, device="cuda").t()
 lib = api.library()
 for nt in (1, 2, 4, 8, 16, 64):
     trees = de.synth.random_population(nt, seed=0xDE02)
-    pop = api.Population(trees, ops, np.float32, n_features=5, ctx=ctx)
     out = torch.empty((nt, N), device="cuda")
     ok = torch.empty(nt, device="cuda", dtype=torch.uint8)
-    ms = []
-    for _ in range(6):
-        ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
-        ms.append(ctx.last_kernel_ms())
-    t = np.median(ms[2:])
-    hbm = (5 * 4 * N * max(1, -(-nt // pop.plan(N)["trees_per_chunk"])) + 4 * N * nt) / (t * 1e-3) / 1e9
-    print(f"n_trees {nt:3d}  kernel {t:8.3f} ms  {nt * N / (t * 1e-3):.3e} tree-samples/s  plan {pop.plan(N)}  approx HBM {hbm:7.1f} GB/s")
-    pop.close()
+    line = f"n_trees {nt:3d}"
+    for full in (False, True):  # default (early exit: incomplete trees are skipped) / DE_OPT_FULL_EVAL (every tree on every sample)
+        pop = api.Population(trees, ops, np.float32, n_features=5, ctx=ctx, eval_context=api.EvalContext(full_eval=full))
+        ms = []
+        for _ in range(6):
+            ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
+            ms.append(ctx.last_kernel_ms())
+        t = np.median(ms[2:])
+        if full:
+            hbm = (5 * 4 * N * max(1, -(-nt // pop.plan(N)["trees_per_chunk"])) + 4 * N * nt) / (t * 1e-3) / 1e9
+            line += f"  full eval {t:7.3f} ms = {hbm:6.0f} GB/s of X + out  plan {pop.plan(N)}"
+        else:
+            line += f"  kernel {t:7.3f} ms ({int(ok.sum().item())}/{nt} complete)"
+        pop.close()
+    print(line)

@@ -76,7 +76,7 @@ def main():
         by = collections.defaultdict(list)
         for r in t:
             k = r["Kernel_Name"].split("(")[0][-70:]
-            if 2 * int(r["Grid_Size_X"]) >= gmax[k] and gmax[k] > 64 * 256:
+            if 50 * int(r["Grid_Size_X"]) >= gmax[k] and gmax[k] > 64 * 256:  # (>= 2 % of the kernel's largest grid: the launch groups of the reverse / gradient kernels differ in size)
                 by[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         steps = 6  # --steps 5 --warmup 1
         e = {"kernels_us_per_step": {k: sum(v) / steps for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1]))},
@@ -100,7 +100,7 @@ def main():
             gm = collections.defaultdict(int)
             for r in rr:
                 gm[r["Kernel_Name"]] = max(gm[r["Kernel_Name"]], int(r["Grid_Size"]))
-            rr = [r for r in rr if 2 * int(r["Grid_Size"]) >= gm[r["Kernel_Name"]] and gm[r["Kernel_Name"]] > 64 * 256]
+            rr = [r for r in rr if 50 * int(r["Grid_Size"]) >= gm[r["Kernel_Name"]] and gm[r["Kernel_Name"]] > 64 * 256]
             tot[c] = sum(float(r["Counter_Value"]) for r in rr) / 3  # --steps 2 --warmup 1
             e[f"{c}_KiB_per_step"] = tot[c]
         if len(tot) == 2:
@@ -111,7 +111,7 @@ def main():
             gm = collections.defaultdict(int)
             for r in rr:
                 gm[r["Kernel_Name"]] = max(gm[r["Kernel_Name"]], int(r["Grid_Size"]))
-            rr = [r for r in rr if 2 * int(r["Grid_Size"]) >= gm[r["Kernel_Name"]] and gm[r["Kernel_Name"]] > 64 * 256]
+            rr = [r for r in rr if 50 * int(r["Grid_Size"]) >= gm[r["Kernel_Name"]] and gm[r["Kernel_Name"]] > 64 * 256]
             sq = collections.defaultdict(lambda: collections.defaultdict(float))
             for r in rr:
                 sq[r["Kernel_Name"].split("(")[0][-70:]][r["Counter_Name"]] += float(r["Counter_Value"]) / 3  # --steps 2 --warmup 1
