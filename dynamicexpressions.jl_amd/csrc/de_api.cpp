@@ -69,6 +69,7 @@ struct de_program {
     std::vector<int32_t> const_instr;   // per const (global index): global instr index
     std::vector<uint8_t> const_checks;  // per const: CONST_CHECK_* bits
     std::vector<int32_t> n_consts_tree; // per tree
+    bool cse_generic = false;           // some tree's GENERIC (gradient) program is the CSE lowering: a persistent row has several consumers (no reverse accumulation)
     std::vector<uint8_t> host_ok_eval;  // per tree: constant part of the eval flag
     std::vector<uint8_t> host_ok_grad;  // per tree: all constants finite
     std::vector<double> consts;         // current constants as double
@@ -676,7 +677,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
             if (node_offsets[t + 1] < node_offsets[t] || const_offsets[t + 1] < const_offsets[t])
                 return fail(ctx, DE_ERR_INVALID_ARG, "offsets not monotone at tree %lld", (long long)t);
         // both lowerings of every tree (plain, and with constant subtrees folded), on host threads
-        struct Lowered { TreeProgram plain, folded; int rc = DE_OK, rcf = DE_OK; bool cse = false; std::string why; };
+        struct Lowered { TreeProgram plain, folded; int rc = DE_OK, rcf = DE_OK; bool cse = false, cse_plain = false; std::string why; };
         std::vector<Lowered> low((size_t)n_trees);
         {
             LowerOptions lof = lo;
@@ -687,6 +688,22 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                 const int64_t n0 = node_offsets[t], c0 = const_offsets[t];
                 try {
                     L.rc = lower_tree(nodes + n0, node_offsets[t + 1] - n0, const_offsets[t + 1] - c0, lo, &L.plain, &L.why);
+                    if (L.rc == DE_OK && cse_nodes && cse_offsets[t + 1] > cse_offsets[t] && !getenv("DE_NO_GRAD_CSE")) {
+                        // GraphNode sharing in the GENERIC program too (round 3; the gradient kernels, eval_diff and the unfolded
+                        // eval run it): a shared subtree's dual number is computed once into a persistent slot and read by every
+                        // consumer — the reference evaluates it once per parent with the same arithmetic, so values, Jacobian rows
+                        // of features / parameters and flags are those of the expansion.  A constant inside a shared subtree keeps
+                        // the gradient row of its FIRST occurrence, which receives every consumer's contribution; the rows of its
+                        // later occurrences stay zero (callers sum the occurrence rows: the reference's shared NodeIndex row).
+                        TreeProgram pc;
+                        std::string why2;
+                        LowerOptions loc = lo;
+                        loc.cse = true;
+                        if (lower_tree(cse_nodes + cse_offsets[t], cse_offsets[t + 1] - cse_offsets[t], const_offsets[t + 1] - c0, loc, &pc, &why2) == DE_OK) {
+                            L.plain = std::move(pc);
+                            L.cse_plain = true;
+                        }
+                    }
                     if (L.rc == DE_OK && allow_fold) {
                         if (cse_nodes && cse_offsets[t + 1] > cse_offsets[t]) {
                             LowerOptions loc = lof;
@@ -721,12 +738,14 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                 const double v = dtype == DE_F32 ? (double)static_cast<const float *>(consts)[c0 + k]
                                                  : static_cast<const double *>(consts)[c0 + k];
                 p->consts[(size_t)(cb + k)] = v;
-                p->const_instr[(size_t)(cb + k)] = ib + tp.const_instr[(size_t)k];
+                // (a CSE lowering has no instruction for the later occurrences of a constant inside a shared subtree: -1)
+                p->const_instr[(size_t)(cb + k)] = tp.const_instr[(size_t)k] >= 0 ? ib + tp.const_instr[(size_t)k] : -1;
                 p->const_checks[(size_t)(cb + k)] = tp.const_checks[(size_t)k];
-                write_imm(tp.code[(size_t)tp.const_instr[(size_t)k]], dtype, v);
+                if (tp.const_instr[(size_t)k] >= 0) write_imm(tp.code[(size_t)tp.const_instr[(size_t)k]], dtype, v);
             }
             p->code.insert(p->code.end(), tp.code.begin(), tp.code.end());
             p->code_off[(size_t)t + 1] = (int32_t)p->code.size();
+            p->cse_generic = p->cse_generic || low[(size_t)t].cse_plain;
             p->n_slots = std::max(p->n_slots, tp.n_slots);
             p->uses_params = p->uses_params || tp.uses_params;
             p->n_nodes += n1 - n0;
@@ -875,7 +894,7 @@ static int set_consts_impl(de_program_t *p, const void *consts) {
         const double v = p->dtype == DE_F32 ? (double)static_cast<const float *>(consts)[k]
                                             : static_cast<const double *>(consts)[k];
         p->consts[k] = v;
-        write_imm(p->code[(size_t)p->const_instr[k]], p->dtype, v);
+        if (p->const_instr[k] >= 0) write_imm(p->code[(size_t)p->const_instr[k]], p->dtype, v);
         if (p->folded && p->fconst_instr[k] >= 0) write_imm(p->fcode[(size_t)p->fconst_instr[k]], p->dtype, v);
     }
     const auto t1 = now();
@@ -1815,6 +1834,9 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
     // (20-node trees: 3.5 rows 9.6 ms forward / 17.2 ms reverse; 17 rows 44.6 ms / 30.2 ms).  DE_LOSS_GRAD_REVERSE=1|0 forces.
     const char *env = getenv("DE_LOSS_GRAD_REVERSE");
     if (env && *env == '0') return DE_OK;
+    // a CSE program reads a persistent row from several consumers: the backward sweep would have to ACCUMULATE adjoints into that
+    // row; its handlers store.  Forward duals run such populations.
+    if (p->cse_generic) return DE_OK;
     if (!(env && *env == '1')) {
         int64_t total = 0;
         for (int64_t t = 0; t < p->n_trees; t++) total += de_program_n_grad(p, t, mode);

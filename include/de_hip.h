@@ -186,9 +186,14 @@ int de_program_create(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes,
  * occurrence, one DE_LEAF_SHARED leaf at every later one (include/de_opcodes.h).  Constant leaves of the CSE tape use
  * the slot numbers of their first occurrence in the expanded tape (the host keeps all occurrence slots of a shared constant
  * equal).  The eval program (de_eval, de_eval_loss) is lowered from the CSE tape: the shared value is computed once per
- * tape into a persistent LDS row and re-read — bit-identical values and flags, fewer dispatches.  Share ids are 0, 1, ... in
- * order of definition, at most 16 minus the tree's spill slots; a shared subtree must not be the root or a direct child of
- * a ternary operator (DE_ERR_UNSUPPORTED otherwise: pass an empty CSE range for that tree).  DE_NO_CSE=1 ignores the CSE tapes. */
+ * tape into a persistent LDS row and re-read — bit-identical values and flags, fewer dispatches.  So are, since round 3, the
+ * programs of de_eval_grad / de_eval_diff / de_eval_loss_grad: values, flags and the Jacobian rows of features and parameters
+ * are the expansion's bit for bit; a constant INSIDE a shared subtree gets every consumer's contribution in the gradient row of
+ * its FIRST occurrence slot and zeros in the rows of its later occurrence slots (n_grad is unchanged: sum the occurrence rows
+ * of a shared constant, as before — the totals are the expansion's to rounding).  Reverse accumulation is not used for such a
+ * program.  Share ids are 0, 1, ... in order of definition, at most 16 minus the tree's spill slots; a shared subtree must not
+ * be the root or a direct child of a ternary operator — a tree whose CSE form does not fit runs from its expanded tape (that
+ * tree alone).  DE_NO_CSE=1 ignores the CSE tapes, DE_NO_GRAD_CSE=1 only for the gradient programs. */
 int de_program_create_cse(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, const int64_t *node_offsets,
                           const de_tape_node_t *cse_nodes, const int64_t *cse_offsets, int64_t n_trees,
                           const void *consts, const int64_t *const_offsets, int32_t n_features,

@@ -145,3 +145,83 @@ def test_graph_that_does_not_fit_the_cse_rows_runs_expanded_instead_of_failing(a
     assert np.array_equal(ka, kb) and ka.all()
     np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
     assert dispatches(api, pg) < dispatches(api, pe)   # the small tree still shares
+
+
+def generic_instructions(api, pop):
+    lib = api.library()
+    return sum(int(lib.de_program_dump(pop._h, t, None, 0, 0)) // 4 for t in range(pop.n_trees))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gradient_programs_share_subtrees_too(api, dtype):
+    """Round 3: the GENERIC program — what the gradient kernels, eval_diff and the fused loss gradient run —
+    is lowered from the CSE tape as well: a shared subtree's dual number is computed once into a persistent slot.  Contract: the
+    Jacobian of the EXPANDED tree.  Feature rows and values: bit for bit (same arithmetic, once instead of per parent).  Constant
+    rows: a constant inside a shared subtree accumulates every consumer's contribution in the row of its first occurrence, the
+    expanded program keeps one row per occurrence and the caller sums them (`_combine_rows`) — the same terms in another order of
+    additions: equal to rounding.  Flags identical; fewer instructions."""
+    rng = de.synth.Xoshiro256ss(91)
+    graphs = [random_graph(rng, OPS, 6 + i % 24, 4, 1 + i % 4, dtype) for i in range(240)]
+    expanded = [de.break_sharing(g) for g in graphs]
+    X = de.synth.random_X(4, 1500, seed=6, dtype=dtype)
+    pg = api.Population(graphs, OPS, dtype, n_features=4)
+    pe = api.Population(expanded, OPS, dtype, n_features=4)
+    pg.verify()
+    ng, ne = generic_instructions(api, pg), generic_instructions(api, pe)
+    print(f"[graph CSE, generic program {np.dtype(dtype).name}] instructions {ne} -> {ng} ({100.0 * (ne - ng) / ne:.1f} % fewer)")
+    assert ng < 0.95 * ne
+    ui = np.uint32 if dtype == np.float32 else np.uint64
+
+    def same_bits(a, b, what):
+        a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        m = ~(np.isnan(a) & np.isnan(b))
+        np.testing.assert_array_equal(a.view(ui)[m], b.view(ui)[m], err_msg=what)
+
+    # feature rows: the same bits
+    oa, ga, ka = pg.eval_grad(X, True)
+    ob, gb, kb = pe.eval_grad(X, True)
+    assert np.array_equal(ka, kb) and ka.sum() > 50
+    for t in np.nonzero(ka)[0]:
+        same_bits(oa[t], ob[t], f"value tree {t}")
+        same_bits(ga[t], gb[t], f"feature rows tree {t}")
+    # eval_diff runs the same program
+    da, dda, _ = pg.eval_diff(X, 2)
+    db, ddb, _ = pe.eval_diff(X, 2)
+    sel = ka
+    same_bits(da[sel], db[sel], "eval_diff values")
+    same_bits(dda[sel], ddb[sel], "eval_diff derivative")
+    # constant rows (one per UNIQUE constant after the caller's summation) and the :both mode: equal to rounding
+    for variable in (False, "both"):
+        oa, ga, ka = pg.eval_grad(X, variable)
+        ob, gb, kb = pe.eval_grad(X, variable)
+        assert np.array_equal(ka, kb)
+        for t in np.nonzero(ka)[0]:
+            a, b = np.asarray(ga[t], dtype=np.float64), np.asarray(gb[t], dtype=np.float64)
+            # the expanded population is a TREE: its rows are per occurrence; sum them like the graph population's are
+            occ = de.flatten_graph(graphs[t], OPS, dtype)[3]
+            if variable == "both":
+                head, tail = b[:4], b[4:]
+            else:
+                head, tail = b[:0], b
+            comb = np.zeros((int(occ.max()) + 1 if occ.size else 0, b.shape[1]))
+            mag = np.zeros_like(comb)  # the occurrence rows of a constant may cancel: the rounding scale is the sum of their magnitudes
+            for s_, u in enumerate(occ):
+                comb[u] += tail[s_]
+                mag[u] += np.abs(tail[s_])
+            want = np.concatenate([head, comb]) if comb.size or head.size else b[:0]
+            mag = np.concatenate([np.abs(head), mag]) if comb.size or head.size else b[:0]
+            assert a.shape == want.shape, (t, a.shape, want.shape)
+            with np.errstate(all="ignore"):
+                fin = np.isfinite(a) & np.isfinite(want) & np.isfinite(mag)
+                tol = (3e-5 if dtype == np.float32 else 1e-11) * (mag + mag.max(axis=1, keepdims=True, initial=0)) + 1e-30
+            assert np.all(np.abs(a - want)[fin] <= tol[fin]), f"constant rows tree {t} [{variable}]"
+    # the fused loss gradient (forward duals: reverse accumulation is off for programs with shared rows)
+    y = np.cos(np.arange(X.shape[1])).astype(dtype)
+    la, dla, ka = pg.eval_loss_grad(X, y, variable=True)
+    lb, dlb, kb = pe.eval_loss_grad(X, y, variable=True)
+    assert np.array_equal(ka, kb)
+    same_bits(la[ka], lb[kb], "loss")
+    for t in np.nonzero(ka)[0]:
+        same_bits(dla[t], dlb[t], f"loss gradient tree {t}")
+    pg.close()
+    pe.close()
