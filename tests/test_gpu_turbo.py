@@ -132,8 +132,11 @@ def test_turbo_bench_population_within_north_star_of_the_oracle(api, N):
         tape, consts = de.flatten(tree, ops, np.float32)
         y, ok_el = oracle.eval_tree_array(tape, consts, X, elementwise=True)
         if bool(ok[t]) != ok_el:
-            n_flag += 1  # only through a documented domain edge: a value that overflows / hits a pole in one mode only
+            # only through a documented domain edge — a value that overflows / hits a pole in one mode only — i.e. on a tree the
+            # tolerance model itself classes as ill-conditioned somewhere; anywhere else a flag difference is a bug
+            n_flag += 1
             print("turbo flag differs:", de.string_tree(tree, ops))
+            assert np.isinf(parity_tolerance(tree, ops, X, np.float32)).any(), f"turbo flag differs on a well-conditioned tree: {de.string_tree(tree, ops)}"
             continue
         if not ok_el:
             continue
@@ -153,7 +156,7 @@ def test_turbo_bench_population_within_north_star_of_the_oracle(api, N):
           f"worst rel err on well-conditioned samples {worst:.3g}, {n_flag} flag differences")
     REPORT[f"bench population N={N}"] = dict(worst_rel_well_conditioned=worst, flag_differences=n_flag, trees=len(trees))
     assert n_ok > 50 and n_flag <= 1 and n_ill <= 0.05 * n_cmp
-    assert np.array_equal(ok_x, ok) or n_flag > 0 or True  # (informational: the exact mode's flags)
+    assert int((np.asarray(ok_x) != np.asarray(ok)).sum()) <= n_flag  # the exact mode has the oracle's flags: turbo differs from it only where counted above
 
 
 def test_turbo_is_ignored_where_it_has_no_meaning(api):
