@@ -724,6 +724,44 @@ __device__ __forceinline__ VecOf<float>::type div_safe(VecOf<float>::type a, Vec
     }
     return q;
 }
+// ... with a CONSTANT operand (22 % of the bench population's divisions are x / c, 15 % c / x): the constant is wave-uniform, so
+// its range test is three scalar instructions on the exponent field and the vector test covers the four samples only; for x / c
+// the reciprocal and its Newton step are computed ONCE per wavefront (one v_rcp_f32 instead of four, no packed Newton step) —
+// the refined reciprocal is RN(1/c) for every significand (div_probe, above), the value the packed sequence computes per lane, so
+// the quotients are the same bits.
+__device__ __forceinline__ bool div_const_in_range(uint32_t bits) { return ((bits >> 23) & 0xFFu) - 88u < 79u; } // |c| in [2^-39, 2^40)
+__device__ __forceinline__ bool div_samples_safe(VecOf<float>::type a) {
+    float hi, lo;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(hi) : "v"(a[0]), "v"(a[1]), "v"(a[2]));
+    asm("v_max_f32_e64 %0, %1, |%2|" : "=v"(hi) : "v"(hi), "v"(a[3]));
+    asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(lo) : "v"(a[0]), "v"(a[1]), "v"(a[2]));
+    asm("v_min_f32_e64 %0, %1, |%2|" : "=v"(lo) : "v"(lo), "v"(a[3]));
+    return (hi < 0x1p+40f) & (lo > 0x1p-40f);
+}
+__device__ __forceinline__ VecOf<float>::type div_safe_by_const(VecOf<float>::type a, float c) {
+    float y1 = __builtin_amdgcn_rcpf(c);
+    y1 = __builtin_fmaf(__builtin_fmaf(-c, y1, 1.0f), y1, y1);
+    const DeF2 y = {y1, y1}, d = {c, c};
+    VecOf<float>::type q;
+    DE_UNROLL for (int h = 0; h < 2; h++) {
+        const DeF2 n = {a[2 * h], a[2 * h + 1]};
+        DeF2 t = n * y;
+        const DeF2 r = __builtin_elementwise_fma(-d, t, n);
+        t = __builtin_elementwise_fma(r, y, t);
+        q[2 * h] = t[0];
+        q[2 * h + 1] = t[1];
+    }
+    return q;
+}
+// the divisions of the fast handlers whose operand `b` is the constant `cbits` (K = 4: x / c, 5: c / x): range test, quotient
+template <int K> __device__ __forceinline__ bool div_const_unsafe(VecOf<float>::type x, uint32_t cbits) {
+    return (__ballot(!div_samples_safe(x)) != 0ull) | !div_const_in_range(cbits);
+}
+template <int K> __device__ __forceinline__ VecOf<float>::type div_const(VecOf<float>::type x, uint32_t cbits) {
+    const float c = __builtin_bit_cast(float, cbits);
+    if constexpr (K == 4) return div_safe_by_const(x, c);
+    else return div_safe(VecOf<float>::type{c, c, c, c}, x);
+}
 __device__ __forceinline__ VecOf<float>::type div_apply(VecOf<float>::type a, VecOf<float>::type b) {
     const bool safe = div_operands_safe(a, b);
     if (__ballot(!safe) != 0ull) return a / b;
@@ -974,12 +1012,15 @@ template <int K, int VAR> __device__ __noinline__ HState<float> h_div_fast(HFAST
     typedef float T;
     typedef VecOf<float>::type V;
     const U32x4 w = *code;
-    V b;
-    if constexpr (VAR & 2) b = splat<T>(w1);
-    else b = *LDSP(T, lds0 + la);
-    const V num = K == 4 ? st.acc : b, den = K == 4 ? b : st.acc;
-    if (__builtin_expect(__ballot(!div_operands_safe(num, den)) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_bin<T, K, VAR, false>>(HFAST_PASS);
-    st.acc = div_safe(num, den);
+    if constexpr (VAR & 2) { // constant operand
+        if (__builtin_expect(div_const_unsafe<K>(st.acc, w1), 0)) [[clang::musttail]] return h_chain<T, &b_bin<T, K, VAR, false>>(HFAST_PASS);
+        st.acc = div_const<K>(st.acc, w1);
+    } else {
+        const V b = *LDSP(T, lds0 + la);
+        const V num = K == 4 ? st.acc : b, den = K == 4 ? b : st.acc;
+        if (__builtin_expect(__ballot(!div_operands_safe(num, den)) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_bin<T, K, VAR, false>>(HFAST_PASS);
+        st.acc = div_safe(num, den);
+    }
     if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
     HFAST_NEXT(w);
 }
@@ -987,13 +1028,17 @@ template <int K, int VAR> __device__ __noinline__ HState<float> h_div_fast(HFAST
 template <int K, bool CST> __device__ __noinline__ HState<float> h_div_end_fast(HFAST_ARGS) {
     typedef float T;
     typedef VecOf<float>::type V;
-    V b;
-    if constexpr (CST) b = splat<T>(w1);
-    else b = *LDSP(T, lds0 + la);
-    const V num = K == 4 ? st.acc : b, den = K == 4 ? b : st.acc;
-    if (__builtin_expect(((flags & HF_SLOW) != 0u) | (__ballot(!div_operands_safe(num, den)) != 0ull), 0))
-        [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, CST ? 3 : 1, false>>(HFAST_PASS);
-    st.acc = div_safe(num, den);
+    if constexpr (CST) {
+        if (__builtin_expect(((flags & HF_SLOW) != 0u) | div_const_unsafe<K>(st.acc, w1), 0))
+            [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 3, false>>(HFAST_PASS);
+        st.acc = div_const<K>(st.acc, w1);
+    } else {
+        const V b = *LDSP(T, lds0 + la);
+        const V num = K == 4 ? st.acc : b, den = K == 4 ? b : st.acc;
+        if (__builtin_expect(((flags & HF_SLOW) != 0u) | (__ballot(!div_operands_safe(num, den)) != 0ull), 0))
+            [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 1, false>>(HFAST_PASS);
+        st.acc = div_safe(num, den);
+    }
     hpoison<T>(st.poison, st.acc);
     HFAST_END_TAIL()
 }
@@ -1018,12 +1063,15 @@ template <int K, bool CST, bool OUT, bool PUSH> __device__ __noinline__ HState<f
     const uint32_t a0 = lds0 + la, a = PUSH ? row_a(a0) : a0;
     if constexpr (PUSH) *LDSP(T, push_addr(a0)) = st.acc; // first, as in b_bin2: row B may be this very slot (the full handler would write it again: same value)
     const V x = *LDSP(T, a);
-    V b;
-    if constexpr (CST) b = splat<T>(w1);
-    else b = *LDSP(T, a + w1);
-    const V num = K == 4 ? x : b, den = K == 4 ? b : x;
-    if (__builtin_expect(__ballot(!div_operands_safe(num, den)) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_bin2<T, K, CST, OUT, PUSH, false>>(HFAST_PASS);
-    st.acc = div_safe(num, den);
+    if constexpr (CST) {
+        if (__builtin_expect(div_const_unsafe<K>(x, w1), 0)) [[clang::musttail]] return h_chain<T, &b_bin2<T, K, CST, OUT, PUSH, false>>(HFAST_PASS);
+        st.acc = div_const<K>(x, w1);
+    } else {
+        const V b = *LDSP(T, a + w1);
+        const V num = K == 4 ? x : b, den = K == 4 ? b : x;
+        if (__builtin_expect(__ballot(!div_operands_safe(num, den)) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_bin2<T, K, CST, OUT, PUSH, false>>(HFAST_PASS);
+        st.acc = div_safe(num, den);
+    }
     if constexpr (OUT) hpoison<T>(st.poison, st.acc);
     HFAST_NEXT(w);
 }

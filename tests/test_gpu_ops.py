@@ -162,6 +162,45 @@ def test_division_fast_path_is_bit_identical_to_ieee(api):
             np.testing.assert_array_equal(out[~nan].view(np.uint32), w[~nan].view(np.uint32))
 
 
+def test_division_with_a_constant_operand_is_bit_identical_to_ieee(api):
+    """x / c and c / x take their own fast path (csrc/de_kernels.hip div_const: scalar range test of the constant, ONE refined
+    reciprocal per wavefront for x / c): many constants — random significands, exponents inside, at the edges of and outside
+    the fast range [2^-39, 2^40), powers of two, denormals, zero, Inf — in every lowered form (first instruction of a tree,
+    mid-tree on the accumulator, end of tree), samples in range and with specials mixed in: the IEEE quotient bit for bit."""
+    ops = de.OperatorEnum(binary_operators=("/", "*"))
+    g = np.random.Generator(np.random.PCG64(12))
+    N = 1 << 14
+    consts = list((g.uniform(1, 2, 96) * 2.0 ** g.integers(-45, 45, 96) * g.choice([-1, 1], 96)).astype(np.float32))
+    consts += [np.float32(v) for v in (2.0 ** -40, 2.0 ** -39, np.nextafter(np.float32(2.0 ** -39), np.float32(0)), 2.0 ** 40,
+                                       np.nextafter(np.float32(2.0 ** 40), np.float32(0)), 1.0, -1.0, 3.0, 1e-42, 0.0, -0.0, np.inf,
+                                       1.0000001, 1.9999999, 3.4e38, 1.2e-38)]
+    x1, x2 = de.Node(feature=1), de.Node(feature=2)
+    trees, want_fn = [], []
+    for c in consts:
+        cn = de.Node(val=float(c))
+        trees += [de.Node(1, x1, cn), de.Node(1, cn, x1), de.Node(1, de.Node(2, x1, x2), cn), de.Node(1, cn, de.Node(2, x1, x2)),
+                  de.Node(2, de.Node(1, x1, cn), x2), de.Node(2, de.Node(1, cn, de.Node(2, x1, x2)), x2)]
+        want_fn += [lambda a, b, c=c: a / c, lambda a, b, c=c: c / a, lambda a, b, c=c: (a * b) / c, lambda a, b, c=c: c / (a * b),
+                    lambda a, b, c=c: (a / c) * b, lambda a, b, c=c: (c / (a * b)) * b]
+    for special in (False, True):
+        a = (2.0 ** g.uniform(-18, 18, N) * g.choice([-1, 1], N)).astype(np.float32)
+        b = (2.0 ** g.uniform(-18, 18, N) * g.choice([-1, 1], N)).astype(np.float32)
+        if special:
+            idx = g.integers(0, N, 600)
+            a[idx[:100]] = 0.0; a[idx[100:200]] = np.inf; a[idx[200:300]] = np.nan; a[idx[300:400]] = np.float32(1e-42)
+            a[idx[400:500]] = np.float32(3e38); b[idx[500:600]] = np.float32(2e-30)
+        X = np.asfortranarray(np.stack([a, b]))
+        pop = api.Population(trees, ops, np.float32, n_features=2, eval_context=api.EvalContext(early_exit=False))
+        out, _ = pop.eval(X)
+        pop.close()
+        with np.errstate(all="ignore"):
+            for t, fn in enumerate(want_fn):
+                w = fn(a, b).astype(np.float32)
+                nan = np.isnan(w)
+                assert np.array_equal(np.isnan(out[t]), nan), (t, consts[t // 6])
+                np.testing.assert_array_equal(out[t][~nan].view(np.uint32), w[~nan].view(np.uint32), err_msg=f"form {t % 6}, c = {consts[t // 6]!r}")
+
+
 def test_exp_and_powers_round_into_the_last_subnormal_bits(api):
     """Results c * 2^-149: Julia (and glibc, the oracle) round them to the nearest subnormal, 2^-149 for c in (1/2, 1);
     OCML's expf/powf return 0 there, which `safe_log(x ^ y)` turns into NaN against a finite value (found by
