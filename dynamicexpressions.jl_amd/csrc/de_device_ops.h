@@ -192,16 +192,9 @@ static __device__ __noinline__ double de_tan_f64(double x) {
 // 2^(p_h + p_l) by the exp kernel P1..P5 after removing the integer part.  Constants checked against msun's hex words.  The main
 // path: x finite and non-zero (negative with an integral y), y finite and non-zero, |y| <= 2^31; every other case (signed zeros,
 // Inf, NaN, huge |y|, negative base with fractional exponent) keeps OCML's case analysis — those results are exact or NaN.
-static __device__ __noinline__ double de_pow_f64(double x, double y) {
-    const bool yint = y == __builtin_rint(y);
-    if (!(__builtin_isfinite(x) && __builtin_isfinite(y) && x != 0.0 && y != 0.0 && __builtin_fabs(y) <= 0x1p31 && (x > 0.0 || yint))) return ::pow(x, y);
-    if (y == 1.0) return x;
-    if (y == 2.0) return x * x;
-    if (y == -1.0) return 1.0 / x;
-    if (y == 0.5 && x > 0.0) return __builtin_sqrt(x);
-    const double sgn = (x < 0.0 && ((long long)y & 1LL)) ? -1.0 : 1.0; // (-|x|)^(odd integer)
-    double ax = __builtin_fabs(x);
-    if (ax == 1.0) return sgn;
+#define DE_TRUNC32(v) __longlong_as_double(__double_as_longlong(v) & ~0xFFFFFFFFLL)
+// log2(ax) = t1 + t2 for a finite ax > 0 (msun pow's logarithm: t1 carries the leading 21 bits, the sum is good to ~2^-68)
+static __device__ __forceinline__ void pow_log2_core(double ax, double &t1_out, double &t2_out) {
     int n = 0;
     long long bits = __double_as_longlong(ax);
     if ((bits >> 52) == 0) { ax *= 0x1p53; n = -53; bits = __double_as_longlong(ax); } // subnormal base
@@ -215,8 +208,6 @@ static __device__ __noinline__ double de_pow_f64(double x, double y) {
     else { k = 0; n += 1; ix -= 0x00100000; }
     ax = __longlong_as_double(((long long)ix << 32) | (bits & 0xFFFFFFFFLL));
     const double bp = k ? 1.5 : 1.0, dp_h = k ? 5.84962487220764160156e-01 : 0.0, dp_l = k ? 1.35003920212974897128e-08 : 0.0;
-    const long long HI = ~0xFFFFFFFFLL;
-#define DE_TRUNC32(v) __longlong_as_double(__double_as_longlong(v) & HI)
     // ss = s_h + s_l = (m - bp) / (m + bp)
     double u = ax - bp, v = 1.0 / (ax + bp);
     const double ss = u * v;
@@ -234,43 +225,145 @@ static __device__ __noinline__ double de_pow_f64(double x, double y) {
     t_l = r - ((t_h - 3.0) - s2);
     u = s_h * t_h;
     v = s_l * t_h + t_l * ss;
-    double p_h = DE_TRUNC32(u + v);
-    double p_l = v - (p_h - u);
+    const double p_h = DE_TRUNC32(u + v);
+    const double p_l = v - (p_h - u);
     const double z_h = 9.61796700954437255859e-01 * p_h; // cp_h + cp_l = 2 / (3 ln 2)
     const double z_l = -7.02846165095275826516e-09 * p_h + p_l * 9.61796693925975554329e-01 + dp_l;
-    double t = (double)n;
-    const double t1 = DE_TRUNC32(((z_h + z_l) + dp_h) + t); // log2|x| = t1 + t2
-    const double t2 = z_l - (((t1 - t) - dp_h) - z_h);
-    // y * log2|x| = p_h + p_l with y split as y1 + y2
-    const double y1 = DE_TRUNC32(y);
-    p_l = (y - y1) * t1 + y * t2;
-    p_h = y1 * t1;
+    const double t = (double)n;
+    const double t1 = DE_TRUNC32(((z_h + z_l) + dp_h) + t);
+    t1_out = t1;
+    t2_out = z_l - (((t1 - t) - dp_h) - z_h);
+}
+// 2^(p_h + p_l), |p_h + p_l| inside the exponent range (the callers test): integer part out, msun's exp kernel on the rest
+static __device__ __forceinline__ double pow_exp2_core(double p_h, double p_l) {
     double z = p_l + p_h;
-    if (z >= 1024.0) { // overflow unless the sum is a hair below 1024
-        if (z > 1024.0 || p_l + 8.0085662595372944372e-17 > z - p_h) return sgn * __builtin_inf();
-    } else if (z <= -1075.0) {
-        if (z < -1075.0 || p_l <= z - p_h) return sgn * 0.0;
-    }
-    // 2^(p_h + p_l): integer part out, exp kernel on the rest
     int ni = 0;
     if (__builtin_fabs(z) > 0.5) {
         const double zi = __builtin_rint(z);
         ni = (int)zi;
         p_h -= zi;
     }
-    t = DE_TRUNC32(p_l + p_h);
-    u = t * 6.93147182464599609375e-01;
-    v = (p_l - (t - p_h)) * 6.93147180559945286227e-01 + t * -1.90465429995776804525e-09;
+    double t = DE_TRUNC32(p_l + p_h);
+    const double u = t * 6.93147182464599609375e-01;
+    const double v = (p_l - (t - p_h)) * 6.93147180559945286227e-01 + t * -1.90465429995776804525e-09;
     z = u + v;
     const double w = v - (z - u);
     t = z * z;
     const double tt = z - t * (1.66666666666666019037e-01 + t * (-2.77777777770155933842e-03 + t * (6.61375632143793436117e-05 +
                       t * (-1.65339022054652515390e-06 + t * 4.13813679705723846039e-08))));
-    r = (z * tt) / (tt - 2.0) - (w + z * w);
+    const double r = (z * tt) / (tt - 2.0) - (w + z * w);
     z = 1.0 - (r - z);
-#undef DE_TRUNC32
-    return sgn * ::ldexp(z, ni);
+    return ::ldexp(z, ni);
 }
+static __device__ __noinline__ double de_pow_f64(double x, double y) {
+    const bool yint = y == __builtin_rint(y);
+    if (!(__builtin_isfinite(x) && __builtin_isfinite(y) && x != 0.0 && y != 0.0 && __builtin_fabs(y) <= 0x1p31 && (x > 0.0 || yint))) return ::pow(x, y);
+    if (y == 1.0) return x;
+    if (y == 2.0) return x * x;
+    if (y == -1.0) return 1.0 / x;
+    if (y == 0.5 && x > 0.0) return __builtin_sqrt(x);
+    const double sgn = (x < 0.0 && ((long long)y & 1LL)) ? -1.0 : 1.0; // (-|x|)^(odd integer)
+    const double ax = __builtin_fabs(x);
+    if (ax == 1.0) return sgn;
+    double t1, t2; // log2|x| = t1 + t2
+    pow_log2_core(ax, t1, t2);
+    // y * log2|x| = p_h + p_l with y split as y1 + y2
+    const double y1 = DE_TRUNC32(y);
+    const double p_l = (y - y1) * t1 + y * t2;
+    const double p_h = y1 * t1;
+    const double z = p_l + p_h;
+    if (z >= 1024.0) { // overflow unless the sum is a hair below 1024
+        if (z > 1024.0 || p_l + 8.0085662595372944372e-17 > z - p_h) return sgn * __builtin_inf();
+    } else if (z <= -1075.0) {
+        if (z < -1075.0 || p_l <= z - p_h) return sgn * 0.0;
+    }
+    return sgn * pow_exp2_core(p_h, p_l);
+}
+
+// Float64 gamma: 2^E with E accumulated in head + tail and ONE final rounding in pow's exp kernel (OCML's tgamma measured 4.3 ulp,
+// outside north_star's 1 ulp: tests/test_gpu_ulp_f64.py; this one 0.77 over (-170, 171.6) incl. the neighbourhoods of the poles,
+// tools/fit/gamma_proto.py against mpmath).  x is shifted up to y = x + n >= 16 with the product P = x (x + 1) .. (x + n - 1) in
+// double-double (every factor an exact two_sum: relative accuracy survives next to a pole), Gamma(x) = Gamma(y) / P and
+//   log2 Gamma(y) = (y - 1/2) log2 y - y log2 e + log2(2 pi) / 2 + log2 e * (1/(12 y) - 1/(360 y^3) + .. - 3617/(122400 y^15))
+// (Stirling; the tail is < 2^-63 at y = 16), the logarithms from pow_log2_core.  Zero, the negative integers, NaN, Inf and
+// x < -180 (the result underflows) keep OCML's results.
+static __device__ __forceinline__ void dd_two_sum(double a, double b, double &s, double &e) {
+    s = a + b;
+    const double bb = s - a;
+    e = (a - (s - bb)) + (b - bb);
+}
+static __device__ __forceinline__ void dd_fast_two_sum(double a, double b, double &s, double &e) {
+    s = a + b;
+    e = b - (s - a);
+}
+static __device__ __forceinline__ void dd_mul(double &ah, double &al, double bh, double bl) { // a *= b
+    const double p = ah * bh;
+    double e = __builtin_fma(ah, bh, -p);
+    e += ah * bl + al * bh;
+    dd_fast_two_sum(p, e, ah, al);
+}
+static __device__ __forceinline__ void dd_add(double &ah, double &al, double bh, double bl) { // a += b
+    double s, e;
+    dd_two_sum(ah, bh, s, e);
+    e += al + bl;
+    dd_fast_two_sum(s, e, ah, al);
+}
+static __device__ __noinline__ double de_gamma_f64(double x) {
+    if (!__builtin_isfinite(x) || x == 0.0 || (x < 0.0 && x == __builtin_floor(x)) || x < -180.0) return ::tgamma(x);
+    if (__builtin_fabs(x) < 0x1p-55) return 1.0 / x; // Gamma(x) = 1/x - gamma + O(x)
+    const int n = x >= 16.0 ? 0 : (int)__builtin_ceil(16.0 - x);
+    double ph = 1.0, pl = 0.0;
+    int esum = 0;
+    for (int k = 0; k < n; k++) {
+        double fh, fl;
+        dd_two_sum(x, (double)k, fh, fl);
+        dd_mul(ph, pl, fh, fl);
+        if (__builtin_fabs(ph) > 0x1p500) { ph *= 0x1p-500; pl *= 0x1p-500; esum += 500; }
+        else if (__builtin_fabs(ph) < 0x1p-500) { ph *= 0x1p500; pl *= 0x1p500; esum -= 500; }
+    }
+    double yh = x, yl = 0.0;
+    if (n) dd_two_sum(x, (double)n, yh, yl);
+    const double INV_LN2 = 0x1.71547652b82fep+0, LOG2E_LO = 0x1.777d0ffda0d24p-56;
+    double t1, t2;
+    pow_log2_core(yh, t1, t2);
+    const double a_h = yh - 0.5, a1 = DE_TRUNC32(a_h); // (exact: yh >= 16)
+    const double p_l = (a_h - a1) * t1 + a_h * t2 + yl * (t1 + t2) + a_h * (yl / yh) * INV_LN2; // log2(yh + yl) = log2 yh + yl / (yh ln 2)
+    double eh, el;
+    dd_fast_two_sum(a1 * t1, p_l, eh, el);
+    { // - y log2 e
+        const double qh = yh * INV_LN2;
+        const double ql = __builtin_fma(yh, INV_LN2, -qh) + (yh * LOG2E_LO + yl * INV_LN2);
+        double qs, qe;
+        dd_fast_two_sum(qh, ql, qs, qe);
+        dd_add(eh, el, -qs, -qe);
+    }
+    dd_add(eh, el, 0x1.536439a4c6efcp+0, -0x1.49e49a361efebp-54); // log2(2 pi) / 2
+    {
+        const double r = 1.0 / yh, r2 = r * r;
+        double s = -0x1.e4286cb0f5398p-6;
+        s = s * r2 + 0x1.a41a41a41a41ap-8;
+        s = s * r2 + -0x1.f6ab0d9993c7dp-10;
+        s = s * r2 + 0x1.b951e2b18ff23p-11;
+        s = s * r2 + -0x1.3813813813814p-11;
+        s = s * r2 + 0x1.a01a01a01a01ap-11;
+        s = s * r2 + -0x1.6c16c16c16c17p-9;
+        s = s * r2 + 0x1.5555555555555p-4;
+        el += s * r * INV_LN2;
+    }
+    double sign = 1.0;
+    if (n) { // - log2 |P|
+        if (ph < 0.0) { sign = -1.0; ph = -ph; pl = -pl; }
+        double l1, l2;
+        pow_log2_core(ph, l1, l2);
+        l2 += (pl / ph) * INV_LN2;
+        dd_add(eh, el, -l1 - (double)esum, -l2);
+    }
+    const double z = eh + el;
+    if (z >= 1024.0) return sign * __builtin_inf();
+    if (z <= -1075.0) return sign * 0.0;
+    return sign * pow_exp2_core(eh, el);
+}
+#undef DE_TRUNC32
 
 template <> struct M<double> {
     using T = double;
@@ -295,7 +388,7 @@ template <> struct M<double> {
     static __device__ __forceinline__ T asinh(T x) { return ::asinh(x); }
     static __device__ __forceinline__ T acosh(T x) { return ::acosh(x); }
     static __device__ __forceinline__ T atanh(T x) { return ::atanh(x); }
-    static __device__ __forceinline__ T tgamma(T x) { return ::tgamma(x); }
+    static __device__ __forceinline__ T tgamma(T x) { return de_gamma_f64(x); }
     static __device__ __forceinline__ T pow(T x, T y) { return de_pow_f64(x, y); }
     static __device__ __forceinline__ T fmod(T x, T y) { return ::fmod(x, y); }
     static __device__ __forceinline__ T rint(T x) { return ::rint(x); }
