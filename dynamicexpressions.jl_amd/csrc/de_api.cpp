@@ -62,6 +62,7 @@ struct de_program {
     int32_t n_features = 0, n_params = 0;
     int64_t n_trees = 0, n_nodes = 0;
     int n_slots = 0;
+    bool prows = false; // eval kernels: the parameters are staged per tile as LDS rows F + n_slots + p (rebind), operands like features; false: BOP_GEN_PARAM gathers
     bool uses_params = false;
     std::vector<Instr> code;            // host copy (patched by set_consts)
     std::vector<int32_t> code_off;      // n_trees + 1
@@ -407,15 +408,27 @@ static bool tree_skip_enabled() {
 }
 static bool finite_in(int dtype, double v) { return dtype == DE_F32 ? std::isfinite((float)v) : std::isfinite(v); }
 
+// Parameters as staged rows (round 3): every use of a parameter was a gather of its samples' values through the vector cache (h_param:
+// 4 loads per lane and use; per-sample parameters, C = N, ran at 27 % VALU utilisation).  With <= 16 parameters the eval kernels
+// instead stage the tile's parameter values once per workgroup, transposed like X, into P more LDS rows behind the spill slots and
+// the binder treats a parameter operand as a row operand (every fused form applies).  DE_NO_PARAM_ROWS=1: the gathers.
+static bool param_rows_enabled() {
+    static const bool on = [] { const char *v = getenv("DE_NO_PARAM_ROWS"); return !(v && *v == '1'); }();
+    return on;
+}
+static int64_t eval_rows(const de_program *p) { return (int64_t)p->n_features + p->n_slots + (p->prows ? p->n_params : 0); }
 static void rebind(de_program *p) {
     const bool ee = (p->options & DE_OPT_EARLY_EXIT) != 0;
+    p->prows = p->uses_params && p->n_params > 0 && p->n_params <= 16 && param_rows_enabled() &&
+               ((size_t)p->n_features + (size_t)p->n_slots + (size_t)p->n_params) * 257 * 16 <= 150 * 1024;
+    const int prb = p->prows ? p->n_features + p->n_slots : -1;
     p->bcode.clear();
     p->bcode_off.assign((size_t)p->n_trees + 1, 0);
     const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
     const std::vector<int32_t> &off = p->folded ? p->fcode_off : p->code_off;
     for (int64_t t = 0; t < p->n_trees; t++) {
         const int32_t i0 = off[(size_t)t], i1 = off[(size_t)t + 1];
-        bind_tree(src.data() + i0, (size_t)(i1 - i0), ee, p->n_features, &p->bcode);
+        bind_tree(src.data() + i0, (size_t)(i1 - i0), ee, p->n_features, &p->bcode, prb);
         p->bcode_off[(size_t)t + 1] = (int32_t)p->bcode.size();
     }
     match_const_sites(src, off, p->bcode, p->bcode_off, p->n_trees, [](const BoundInstr &b) { return bop_is_const_source(b.bop); }, &p->bsite);
@@ -430,9 +443,9 @@ static void make_chained(de_program *p);
 static int make_threaded(de_ctx *c, de_program *p) {
     p->threaded = false;
     // the LDS-staged kernels need (n_features + n_slots) rows of 4112 B; wider X uses the direct variant
-    p->direct = ((size_t)p->n_features + (size_t)p->n_slots) * 257 * 16 > 150 * 1024; // (the flat-switch geometry decides)
+    p->direct = (size_t)eval_rows(p) * 257 * 16 > 150 * 1024; // (the flat-switch geometry decides)
     if (p->direct || !eval_uses_threaded()) return DE_OK;
-    if ((int64_t)p->n_features + p->n_slots > 4000) return DE_OK; // row offsets must fit 24 bits
+    if (eval_rows(p) > 4000) return DE_OK; // row offsets must fit 24 bits
     uint64_t table[TOPX_TABLE];
     hipError_t st = eval_handler_table(p->dtype, (p->options & DE_OPT_TURBO) != 0, table);
     if (st != hipSuccess) return fail(c, DE_ERR_HIP, "handler table: %s", hipGetErrorString(st));
@@ -1052,7 +1065,7 @@ int de_eval_plan(const de_program_t *p, int64_t N, int32_t *plan) {
 int de_program_verify(const de_program_t *p) {
     if (!p) return DE_ERR_INVALID_ARG;
     de_ctx *c = p->ctx;
-    const int64_t rows = (int64_t)p->n_features + p->n_slots;
+    const int64_t rows = eval_rows(p), spill_end = (int64_t)p->n_features + p->n_slots;
     auto bad = [&](const char *what, int64_t tree, int64_t i, uint64_t v) {
         return fail(c, DE_ERR_BAD_TAPE, "program verify: %s (tree %lld, instruction %lld, value 0x%llx)", what, (long long)tree, (long long)i,
                     (unsigned long long)v);
@@ -1143,7 +1156,7 @@ int de_program_verify(const de_program_t *p) {
                                         (fb.bop >= TOP_BIN2_BASE && fb.bop < TOP_COUNT && ((fb.bop - TOP_BIN2_BASE) & 1));
                     if (pushes) {
                         const int64_t prow = (int64_t)(off / TROW_BYTES) + (int8_t)(r.bop >> 24);
-                        if (prow < p->n_features || prow >= rows) return bad("push row of a superinstruction outside the spill slots", t, i - i0, r.bop);
+                        if (prow < p->n_features || prow >= spill_end) return bad("push row of a superinstruction outside the spill slots", t, i - i0, r.bop);
                     }
                     if (fb.bop >= TOP_BIN2_BASE && fb.bop < TOP_COUNT && !(((fb.bop - TOP_BIN2_BASE) >> 2) & 1)) { // row-row: second row by distance
                         const int64_t second = (int64_t)off + (int32_t)(f32 ? r.arg : r.lo);
@@ -1414,7 +1427,9 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
     a.code = p->d_code;
     a.code_off = p->d_code_off;
     a.n_trees = (int32_t)p->n_trees;
-    a.n_slots = p->n_slots;
+    a.n_slots = p->n_slots + (p->prows ? p->n_params : 0); // (LDS rows behind X: spill slots, then the staged parameter rows)
+    a.prow_base = p->prows ? p->n_features + p->n_slots : 0;
+    a.n_prows = p->prows ? p->n_params : 0;
     a.uses_params = p->uses_params;
     a.X = sX.dev;
     a.N = N;

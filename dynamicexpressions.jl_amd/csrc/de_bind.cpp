@@ -36,13 +36,17 @@ BoundInstr mk(uint32_t bop, uint32_t arg, uint32_t lo = 0, uint32_t hi = 0) {
 
 } // namespace
 
-void bind_tree(const Instr *code, size_t n, bool ee, int n_features, std::vector<BoundInstr> *out) {
+void bind_tree(const Instr *code, size_t n, bool ee, int n_features, std::vector<BoundInstr> *out, int param_row_base) {
     for (size_t i = 0; i < n; i++) {
         const Instr &ins = code[i];
         const uint32_t hdr = ins.hdr;
         const uint32_t op = hdr & H_OP_MASK;
-        const uint32_t src = (hdr >> H_SRC_SHIFT) & H_SRC_MASK;
-        const uint32_t row = ins.feat & 0xFFFFu;
+        uint32_t src = (hdr >> H_SRC_SHIFT) & H_SRC_MASK;
+        uint32_t row = ins.feat & 0xFFFFu;
+        if (src == SRC_PARAM && param_row_base >= 0) { // a parameter = one more staged row
+            src = SRC_ROW;
+            row += (uint32_t)param_row_base;
+        }
         const uint32_t lo = ins.imm.u32[0], hi = ins.imm.u32[1];
         if (hdr & H_PUSH) out->push_back(mk(BOP_PUSH, (uint32_t)n_features + ((hdr >> H_PUSH_SHIFT) & H_SLOT_MASK)));
         const bool check_b = ee && (hdr & H_CHECK_B);

@@ -209,6 +209,8 @@ void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out);
 bool top_is_const_source(uint32_t top);
 
 // Append the bound form of `code` (one tree) to `out`.
-void bind_tree(const Instr *code, size_t n, bool early_exit, int n_features, std::vector<BoundInstr> *out);
+// param_row_base >= 0: parameter operands are LDS rows param_row_base + p (the eval kernels stage the tile's parameter values like
+// features: de_api.cpp `prows`); < 0: BOP_GEN_PARAM, a gather per use
+void bind_tree(const Instr *code, size_t n, bool early_exit, int n_features, std::vector<BoundInstr> *out, int param_row_base = -1);
 
 } // namespace de

@@ -38,7 +38,8 @@ struct EvalArgs {
     const BoundInstr *code;   // device: all trees' BOUND instructions (de_bind.h), +1 pad
     const int32_t *code_off;  // device: n_trees+1 offsets into code
     int32_t n_trees;
-    int32_t n_slots;          // spill slots (max over trees)
+    int32_t n_slots;          // LDS rows behind X: spill slots (max over trees) + staged parameter rows
+    int32_t prow_base, n_prows; // parameters staged as LDS rows prow_base .. prow_base + n_prows - 1 (0: gathered per use, BOP_GEN_PARAM)
     bool uses_params;
     // data
     const void *X;            // device, [F, N] col-major, ld = ldX

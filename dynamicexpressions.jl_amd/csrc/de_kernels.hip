@@ -51,6 +51,7 @@ template <typename T> struct KArgs {
     const void *classes;
     int64_t N, ldX, ld_out, ld_params, n_tiles, n_classes;
     int32_t F, n_trees, trees_per_chunk, n_chunks, n_slots, xstride;
+    int32_t prow_base, n_prows; // parameters staged as LDS rows (EvalArgs)
     int32_t classes_is_i64, class_base, vec_store;
     // fused loss (de_eval_loss): residual target, optional weights, per-wave partial sums
     const T *y;
@@ -290,6 +291,20 @@ __device__ __forceinline__ TileMap map_block(uint32_t bid, int32_t n_chunks, int
     return m;
 }
 
+// Parameters as rows: row prow_base + p of the tile holds params[p, class of the sample] (src/ParametricExpression.jl:381-389), staged
+// once per workgroup like the X tile.  row_elems = elements between two rows; samples past N repeat the last one (as X does).
+template <typename T>
+__device__ __forceinline__ void stage_param_rows(const KArgs<T> &a, T *__restrict__ rows, int row_elems, int64_t base, int tile, int tid, int blk) {
+    const int64_t last = a.N - 1;
+    for (int j = tid; j < tile; j += blk) {
+        int64_t jj = base + j;
+        jj = jj < last ? jj : last;
+        const int64_t cl = clamp_class((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
+                                                         : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base, a.n_classes);
+        const T *__restrict__ col = a.params + a.ld_params * cl;
+        for (int p = 0; p < a.n_prows; p++) rows[(size_t)(a.prow_base + p) * row_elems + j] = col[p];
+    }
+}
 template <typename T, int G>
 __device__ __noinline__ void store_ragged(T *o, VG<T, G> v, int64_t remaining, int plane) {
     constexpr int VW = VecOf<T>::W;
@@ -341,6 +356,7 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
             }
         }
     }
+    if (PARAMS && !DIRECT && a.n_prows > 0) stage_param_rows<T>(a, rows, ROWV * VW, base, TILE, tid, BLK);
     int64_t cls[G][VW];
     if (PARAMS) {
         FOR_G FOR_I {
@@ -1323,7 +1339,9 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             }
         }
     }
-    if (PARAMS) {
+    if (PARAMS && a.n_prows > 0) {
+        stage_param_rows<T>(a, rows, ROWV * VW, base, TILE, tid, BLK);
+    } else if (PARAMS) {
         // the class row: byte offsets of this thread's samples' parameter columns (the table has < 2^32 bytes: checked
         // on the host), and the table's address for h_param (see there)
         uint32_t cv[4] = {0u, 0u, 0u, 0u};
@@ -1562,6 +1580,8 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
     a.ldX = e.ldX;
     a.ld_out = e.ld_out;
     a.ld_params = e.ld_params;
+    a.prow_base = e.prow_base;
+    a.n_prows = e.n_prows;
     a.n_tiles = (e.N + TILE - 1) / TILE;
     a.F = e.F;
     a.n_trees = e.n_trees;
@@ -1671,6 +1691,8 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.ldX = e.ldX;
     a.ld_out = e.ld_out;
     a.ld_params = e.ld_params;
+    a.prow_base = e.prow_base;
+    a.n_prows = e.n_prows;
     a.n_tiles = (e.N + TILE - 1) / TILE;
     a.F = e.F;
     a.n_trees = e.n_trees;
@@ -1698,7 +1720,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // rows: X, spill slots, then (parametric) the class row [+ the table-pointer row for Float32] of h_param
     a.cls_row_off = (uint32_t)((size_t)(a.F + a.n_slots) * TROW_BYTES);
-    const int prm_rows = e.uses_params ? (sizeof(T) == 4 ? 2 : 1) : 0;
+    const int prm_rows = (e.uses_params && e.n_prows == 0) ? (sizeof(T) == 4 ? 2 : 1) : 0; // (the class row of h_param; staged parameter rows count as slots)
     if (e.uses_params && (uint64_t)e.ld_params * (uint64_t)e.n_classes * sizeof(T) > 0xFFFFFFFFull) return hipErrorInvalidValue; // 32-bit column offsets
     const size_t lds = (size_t)(a.F + a.n_slots + prm_rows + env_int("DE_EXTRA_LDS_ROWS", 0)) * TROW_BYTES + DE_SKIPLIST_BYTES;
     void (*kern)(const KArgs<T>) = e.uses_params ? de_eval_threaded_kernel<T, true> : de_eval_threaded_kernel<T, false>;
