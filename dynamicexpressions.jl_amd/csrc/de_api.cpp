@@ -412,9 +412,9 @@ static bool finite_in(int dtype, double v) { return dtype == DE_F32 ? std::isfin
 // 4 loads per lane and use; per-sample parameters, C = N, ran at 27 % VALU utilisation).  With <= 16 parameters the eval kernels
 // instead stage the tile's parameter values once per workgroup, transposed like X, into P more LDS rows behind the spill slots and
 // the binder treats a parameter operand as a row operand (every fused form applies).  DE_NO_PARAM_ROWS=1: the gathers.
-static bool param_rows_enabled() {
-    static const bool on = [] { const char *v = getenv("DE_NO_PARAM_ROWS"); return !(v && *v == '1'); }();
-    return on;
+static bool param_rows_enabled() { // (read at every de_program_create: the tests switch it inside one process)
+    const char *v = getenv("DE_NO_PARAM_ROWS");
+    return !(v && *v == '1');
 }
 static int64_t eval_rows(const de_program *p) { return (int64_t)p->n_features + p->n_slots + (p->prows ? p->n_params : 0); }
 static void rebind(de_program *p) {

@@ -126,6 +126,27 @@ def test_fuzz_parametric_expressions(api, seed):
     gate(tot, "wide", f"ParametricExpression, seed {seed}")
 
 
+@pytest.mark.parametrize("case", ["DE_NO_PARAM_ROWS", "20 parameters"])
+def test_fuzz_parametric_gather_fallback(api, case, monkeypatch):
+    """The eval kernels stage <= 16 parameters as LDS rows (csrc/de_api.cpp rebind); beyond that, or with DE_NO_PARAM_ROWS=1, every use
+    of a parameter gathers its samples' values (h_param, BOP_GEN_PARAM): the same differential run on that path."""
+    if case == "DE_NO_PARAM_ROWS":
+        monkeypatch.setenv("DE_NO_PARAM_ROWS", "1")
+    P = 20 if case == "20 parameters" else 5
+    tot = FZ.Findings()
+    rng = de.synth.Xoshiro256ss(4242)
+    for dtype in (np.float32, np.float64):
+        trees = FZ.random_trees(rng, FZ.OPS_HOT, 3, dtype, 90, 27, 1, de.ParametricNode, P)
+        g = np.random.Generator(np.random.PCG64(4243))
+        N, C = 777, 6
+        X = np.asfortranarray(g.standard_normal((3, N)).astype(dtype))
+        params = np.asfortranarray((g.standard_normal((P, C)) * 2).astype(dtype))
+        classes = g.integers(1, C + 1, N).astype(np.int64)
+        for ec in contexts(api)[:3]:
+            tot.add(FZ.fuzz_eval(api, trees, FZ.OPS_HOT, X, dtype, ec, params, classes, label=f"param gathers ({case})"))
+    gate(tot, "wide", f"ParametricExpression, gathered parameters ({case})")
+
+
 MIXED = de.OperatorEnum(unary_operators=("abs", "cos", "exp"), binary_operators=("+", "-", "*", "/"),
                         ternary_operators=("fma", "clamp", "+", "max"))  # test/test_supposition_consistency.jl:20
 
