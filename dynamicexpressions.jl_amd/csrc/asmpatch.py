@@ -15,8 +15,9 @@ per tree and wavefront.  This pass rewrites that entry wait to
     let it pass early;
   * gfx9 VMEM stores read their data registers when they issue, so overwriting those registers afterwards is fine;
   * the kernel itself waits for vmcnt(0) before it ends (s_endpgm drains stores).
-  * ONLY handlers that contain no vector-memory instruction at all are relaxed — plus the eval kernel's h_tree_end, which
-    only STORES (checked: no vector load, and a vmcnt(0) wait in front of every return to the kernel; end_handler_is_safe).  A handler with a stack frame (h_param,
+  * ONLY handlers that contain no vector-memory instruction at all are relaxed — plus the eval kernel's h_tree_end (and its out-of-line
+    twin h_tree_end_slow: ragged stores, the fused loss's partial — every tree of a fused-loss launch ends there), which
+    only STORE (checked: no vector load, and a vmcnt(0) wait in front of every return to the kernel; end_handler_is_safe).  A handler with a stack frame (h_param,
     the generic handlers that call cold_op) restores its callee-saved VGPR with a `scratch_load` right before its tail call
     and relies on the NEXT function's entry wait to complete it; a relaxed successor never touches that register (it has
     no scratch instruction to save it with), so the restore lands harmlessly while it runs, and the chain always ends in
@@ -30,7 +31,7 @@ import struct
 import subprocess
 import sys
 
-TARGETS = re.compile(r"^_ZN2de(7h_chainI|7h_paramI|9h_un_fastI|10h_div_fastI|12h_unrow_fastI|14h_divrowc_fastI|11h_div2_fastI|13h_un_end_fastI|14h_div_end_fastI|10h_tree_endI|11h_tree_skipI|11h_chain_endI|\d+[gr]tm_\w+?8[gr]h_chainI)")  # never an end handler (h_tree_end, g_end, r_end): the end of every chain keeps the full wait
+TARGETS = re.compile(r"^_ZN2de(7h_chainI|7h_paramI|9h_un_fastI|10h_div_fastI|12h_unrow_fastI|14h_divrowc_fastI|11h_div2_fastI|13h_un_end_fastI|14h_div_end_fastI|10h_tree_endI|15h_tree_end_slowI|11h_tree_skipI|11h_chain_endI|\d+[gr]tm_\w+?8[gr]h_chainI)")  # never an end handler (h_tree_end, g_end, r_end): the end of every chain keeps the full wait
 VMEM = re.compile(r"^\s*(scratch_|flat_|global_|buffer_|tbuffer_|image_)")
 LLVM = os.environ.get("LLVM", "/opt/rocm/lib/llvm/bin")
 
@@ -50,7 +51,7 @@ def vmem_free_functions(path):
     if name and clean:
         ok.add(name)
     return ok
-END = re.compile(r"^_ZN2de(10h_tree_endI|11h_chain_endI|13h_un_end_fastI|14h_div_end_fastI)")  # the eval kernel's end-of-tree handlers: they store, and read nothing back
+END = re.compile(r"^_ZN2de(10h_tree_endI|15h_tree_end_slowI|11h_chain_endI|13h_un_end_fastI|14h_div_end_fastI)")  # the eval kernel's end-of-tree handlers: they store, and read nothing back
 
 
 def end_handler_is_safe(path, name):

@@ -732,13 +732,15 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 #undef DE_DPP_ADD
     return v;
 }
-__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+__device__ __forceinline__ double wave_sum_to_lane63(double v, int lane) { // lane = this thread's lane (a handler derives it from its LDS address: no work-item id input)
     _Pragma("unroll") for (int m = 1; m < 64; m <<= 1) {
         const double o = __shfl_up(v, m, 64);
-        if ((int)(threadIdx.x & 63) >= m) v += o;
+        if (lane >= m) v += o;
     }
     return v;
 }
+__device__ __forceinline__ double wave_sum_to_lane63(double v) { return wave_sum_to_lane63(v, (int)(threadIdx.x & 63)); }
+__device__ __forceinline__ float wave_sum_to_lane63(float v, int) { return wave_sum_to_lane63(v); }
 
 
 } // namespace de

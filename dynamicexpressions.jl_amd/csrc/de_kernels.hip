@@ -500,7 +500,9 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
 // samples (2 VALU per tested vector instead of 4).
 template <typename T> struct PoisonOf { typedef T type; };
 template <> struct PoisonOf<float> { typedef float type __attribute__((ext_vector_type(2))); };
-template <typename T> struct HState {
+// (packed: the 16-byte alignment of `acc` would give the struct 8 bytes of tail padding, which the calling convention passes as
+// eight i8 arguments — eight vector registers; they now carry the fused loss's targets and weights, HL_PARAMS below)
+template <typename T> struct __attribute__((packed, aligned(8))) HState {
     typename VecOf<T>::type acc;
     typename PoisonOf<T>::type poison;
 };
@@ -548,12 +550,18 @@ template <typename T> using BodyFn = HState<T> (*)(HState<T>, uint32_t, typename
 //   tree  : index of the tree being evaluated (the end handlers count it up)
 // argument words of a handler: (la, w1, w23) = the record as loaded { x, y, z:w }
 //   Float32: w1 = imm, w23 = next handler      Float64: w1 = next handler (low half), w23 = imm
-template <typename T> using HandlerFn = HState<T> (*)(HState<T>, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t, uint32_t);
-enum : uint32_t { HF_RETURN_EACH = 1u << 31, HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu,
-                  HF_SLOW = HF_RETURN_EACH | HF_SLOW_STORE | HF_NO_STORE, // any of them: the out-of-line end of a tree
+// ... and, in VECTOR registers, this thread's residual targets and weights of the fused loss (ly, lw: 8 registers every handler passes
+// on untouched, undefined outside a fused-loss launch): the end of a tree forms its loss partial from them (h_tree_end_slow, HF_LOSS).
+#define HL_T typename VecOf<T>::type
+template <typename T> using HandlerFn = HState<T> (*)(HState<T>, HL_T, HL_T, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t, uint32_t);
+enum : uint32_t { HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu,
+                  HF_SLOW = HF_SLOW_STORE | HF_NO_STORE | (1u << 27), // any of them (and HF_LOSS): the out-of-line end of a tree
                   // plain flag stores (through the caches): always, except under flag protocol 1 (agent scope for every access, an
                   // experiment: skip_flag_load, de_device_ops.h)
-                  HF_PLAIN_FLAG = 1u << 28 };
+                  HF_PLAIN_FLAG = 1u << 28,
+                  // fused loss: the end of a tree forms the tree's loss partial of this tile instead of storing the values (h_tree_end_slow);
+                  // HF_LOSS_L1 = |e| instead of e^2
+                  HF_LOSS = 1u << 27, HF_LOSS_L1 = 1u << 26 };
 template <typename T> __device__ __forceinline__ HandlerFn<T> arg_next(uint32_t w1, uint64_t w23);
 template <> __device__ __forceinline__ HandlerFn<float> arg_next<float>(uint32_t, uint64_t w23) { return reinterpret_cast<HandlerFn<float>>(w23); }
 template <> __device__ __forceinline__ HandlerFn<double> arg_next<double>(uint32_t w1, uint64_t) {
@@ -565,8 +573,8 @@ template <> __device__ __forceinline__ uint64_t arg_imm<double>(uint32_t, uint64
 #define DE_SKIPLIST_BYTES 256u // LDS bytes in front of row 0: the live trees of the running (sub-)chunk (h_tree_skip), 64 x 4 bytes
 #define DE_ROW_BYTES_C ((DE_TBLK + 1) * 16) // LDS row stride of the threaded kernel: DE_TBLK 16-byte vectors + one of padding
 // `code` points at the record of the NEXT instruction; (la, w1, w23) are this instruction's record
-#define HCHAIN_ARGS HState<T> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint64_t skip, uint32_t left, uint32_t flags, uint32_t tree
-#define HCHAIN_NEXT_AT(W, NEXT) [[clang::musttail]] return arg_next<T>(w1, w23)(st, lds0, NEXT, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags, tree)
+#define HCHAIN_ARGS HState<T> st, HL_T ly, HL_T lw, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint64_t skip, uint32_t left, uint32_t flags, uint32_t tree
+#define HCHAIN_NEXT_AT(W, NEXT) [[clang::musttail]] return arg_next<T>(w1, w23)(st, ly, lw, lds0, NEXT, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags, tree)
 #define HCHAIN_NEXT(W) HCHAIN_NEXT_AT(W, code + 1)
 template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain(HCHAIN_ARGS) {
     const U32x4 w = *code;
@@ -595,7 +603,7 @@ __device__ __forceinline__ bool poison_set(const double &p) { return p != p; }
 // the next tree starts (the eval handlers do not wait for vector memory at entry: csrc/asmpatch.py).  Measured with
 // tools/exp_dispatch_cost.py: returning to a per-tree loop in the kernel (index load, first-record load, two dependent
 // scalar-cache round trips per tree) cost ~250 SIMD cycles per tree and wavefront, a quarter of the headline's time.
-// HF_RETURN_EACH (fused loss): the kernel owns the epilogue and re-enters the stream per tree.
+// Fused loss (HF_LOSS): the same chain; the end of a tree forms its loss partial instead of storing the values (h_tree_end_slow).
 // EARLY EXIT (src/Evaluate.jl:26-32: the reference stops evaluating a tree at its first non-finite intermediate array; SURVEY §8a:
 // with ok == false only the flag is contractual).  `skip` = the trees from the current one on whose flag was already 0 when this
 // workgroup started (bit 0: the current tree; the kernel reads the flags once per chunk, DE_OPT_FULL_EVAL / early_exit = false: 0).
@@ -620,7 +628,7 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS)
     const uint64_t hdr = ((uint64_t)(uintptr_t)code & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
     const ConstU4Ptr nh = (ConstU4Ptr)(uintptr_t)hdr; // the tree's header record (the record in front of its first instruction)
     const U32x4 hn = nh[0], w = nh[1];
-    [[clang::musttail]] return arg_next<T>(hn.y, ((uint64_t)hn.w << 32) | hn.z)(st, lds0, nh + 2, outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, skip, left, flags,
+    [[clang::musttail]] return arg_next<T>(hn.y, ((uint64_t)hn.w << 32) | hn.z)(st, ly, lw, lds0, nh + 2, outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, skip, left, flags,
                                                                              tree);
 }
 // the rest of a tree's end: flag byte, last tree of the chunk?, clear the state, on to the next tree (W = its first record,
@@ -637,17 +645,30 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS)
     tree += 1u;                                                                                              \
     skip >>= 1;                                                                                              \
     if (__builtin_expect((skip & 1ull) != 0ull, 0))                                                          \
-        [[clang::musttail]] return h_tree_skip<T>(st, lds0, HDR, outp, la, w1, w23, okp, ldo, skip, left, flags, tree); \
+        [[clang::musttail]] return h_tree_skip<T>(st, ly, lw, lds0, HDR, outp, la, w1, w23, okp, ldo, skip, left, flags, tree); \
     HCHAIN_NEXT_AT(REC, NEXT)
 typedef __attribute__((address_space(1))) char *GPtr; // global, not flat: a flat store also ties up lgkmcnt
-// The other store modes (flags != 0), out of line so that h_tree_end itself is straight-line code: HF_RETURN_EACH (fused loss:
-// the kernel owns the epilogue), HF_SLOW_STORE (ragged last tile / output rows that are not 16-byte aligned; LDS base = 0:
+// The other ends of a tree (flags & HF_SLOW), out of line so that h_tree_end itself is straight-line code: HF_LOSS (fused loss:
+// the tree's loss partial of this tile), HF_SLOW_STORE (ragged last tile / output rows that are not 16-byte aligned; LDS base = 0:
 // lds0 = DE_SKIPLIST_BYTES + 16 * thread), HF_NO_STORE (DE_DEBUG_NO_STORE, measurement only: keep the value alive, write nothing).
 template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_ARGS) {
     constexpr int VW = VecOf<T>::W;
-    if (flags & HF_RETURN_EACH) return st;
     const U32x4 w = *code;
     const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);
+    if (flags & HF_LOSS) {
+        // sum_j w_j * l(out_j - y_j) over this wave's 64 * VW samples -> one partial per (tile, tree, wave): outp = &partial[tile, 0, wave],
+        // ldo = bytes between two trees' partials (weight 0: samples past N)
+        T s = T(0);
+        DE_UNROLL for (int i = 0; i < VW; i++) {
+            const T e = st.acc[i] - ly[i];
+            const T l = (flags & HF_LOSS_L1) ? M<T>::abs(e) : e * e;
+            s += lw[i] != T(0) ? lw[i] * l : T(0); // weight 0 really excludes the sample (0 * Inf would be NaN)
+        }
+        const int lane = (int)(((lds0 - DE_SKIPLIST_BYTES) >> 4) & 63u); // (no work-item id input in a handler)
+        s = wave_sum_to_lane63(s, lane);
+        if (lane == 63) *reinterpret_cast<__attribute__((address_space(1))) T *>(row) = s;
+        HTREE_END_TAIL(w, code + 1, code - 1);
+    }
     if (flags & HF_SLOW_STORE) {
         const int remaining = (int)(flags & HF_VALID_MASK) - (int)((lds0 - DE_SKIPLIST_BYTES) / (uint32_t)sizeof(T));
         DE_UNROLL for (int i = 0; i < VW; i++)
@@ -659,7 +680,7 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_A
 }
 template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) {
     typedef typename VecOf<T>::type V;
-    if (__builtin_expect((flags & HF_SLOW) != 0u, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags, tree);
+    if (__builtin_expect((flags & HF_SLOW) != 0u, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, ly, lw, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags, tree);
     const U32x4 w = *code;
     const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo); // wave-uniform: the store takes it as its scalar base
     *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0) = st.acc; // full tile, aligned rows
@@ -673,7 +694,7 @@ template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain_
     typedef typename VecOf<T>::type V;
     if (__builtin_expect((flags & HF_SLOW) != 0u, 0)) {
         st = BODY(st, lds0 + la, arg_imm<T>(w1, w23));
-        [[clang::musttail]] return h_tree_end_slow<T>(st, lds0, code + 1, outp, la, w1, w23, okp, ldo, skip, left, flags, tree);
+        [[clang::musttail]] return h_tree_end_slow<T>(st, ly, lw, lds0, code + 1, outp, la, w1, w23, okp, ldo, skip, left, flags, tree);
     }
     const U32x4 w = code[1];
     st = BODY(st, lds0 + la, arg_imm<T>(w1, w23));
@@ -974,10 +995,10 @@ template <int K, bool TB> __device__ __forceinline__ VecOf<float>::type un_finis
         return V{ya[0], ya[1], yb[0], yb[1]};
     }
 }
-#define HFAST_ARGS HState<float> st, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, \
+#define HFAST_ARGS HState<float> st, VecOf<float>::type ly, VecOf<float>::type lw, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, \
                    uint64_t skip, uint32_t left, uint32_t flags, uint32_t tree
-#define HFAST_PASS st, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags, tree
-#define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, lds0, code + 1, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags, tree)
+#define HFAST_PASS st, ly, lw, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags, tree
+#define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, ly, lw, lds0, code + 1, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags, tree)
 // the end of a tree behind a fast-path body: what h_chain_end does (T = float)
 #define HFAST_END_TAIL()                                                                                                    \
     {                                                                                                                       \
@@ -1297,7 +1318,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     // ... and every wave's copy of the trees' record offsets (the live-tree list below), requested before the X tile as well: with
     // one tree per workgroup (the reference's own call shape, 1 tree x 5e7 samples) a load issued behind the barrier was +50 %
     int32_t co_first = 0;
-    if (a.skip_flagged && !LOSS && tA + (tid & 63) < tB) co_first = a.code_off[tA + (tid & 63)];
+    if (a.skip_flagged && tA + (tid & 63) < tB) co_first = a.code_off[tA + (tid & 63)];
     {
         const uint32_t F = (uint32_t)a.F;
         const uint32_t total = (uint32_t)TILE * F;
@@ -1376,7 +1397,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw + tid * 16;
     // fused loss: this thread's residual targets and weights stay in registers for every tree of
     // the chunk; samples past N get weight 0 (their X columns are clamped copies of the last one)
-    V yv, wv;
+    V yv = V{}, wv = V{};
     if constexpr (LOSS) {
         DE_UNROLL for (int i = 0; i < VW; i++) {
             const int64_t j = base + tid * VW + i;
@@ -1413,7 +1434,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             const uint64_t m = *mask_slot;
             skip = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
         }
-        if constexpr (!LOSS) {
+        {
             // the live trees' header addresses, in reverse order (see h_tree_skip); every wave writes the whole list (same values):
             // a wave reads only what it wrote itself, no barrier
             const int i = t0 + (tid & 63);
@@ -1424,9 +1445,9 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             }
         }
     }
-    if constexpr (!LOSS) {
+    {
         // ONE call per sub-chunk: the trees t0..t1 are consecutive in the stream and every tree's end record (h_tree_end)
-        // stores its results and runs on into the next tree; the call returns after the last one.
+        // stores its results (fused loss: forms its loss partial) and runs on into the next tree; the call returns after the last one.
         int first = t0;
         if (skip & 1ull) { // leading skipped trees
             if (~skip == 0ull) continue;
@@ -1440,34 +1461,20 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
         st.poison = typename PoisonOf<T>::type{};
         const int64_t in_tile = a.N - base < (int64_t)TILE ? a.N - base : (int64_t)TILE;
-        const uint32_t flags = (a.vec_store == 2 ? HF_NO_STORE : ((full && a.vec_store) ? 0u : (HF_SLOW_STORE | (uint32_t)in_tile))) | (a.skip_flagged == 1 ? 0u : HF_PLAIN_FLAG);
-        const uint64_t outp = (uint64_t)(uintptr_t)(a.out + base) - (uint64_t)(uint32_t)(uintptr_t)smem_raw;
-        const U32x4 hp = rec[-1], hd = *rec; // the first handler's address is in the record in front (the previous tree's end record / the head record)
-        st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, lds0, rec + 1, outp, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, (uint64_t)(uintptr_t)a.ok,
-                                                              ldo, skip, (uint32_t)(t1 - first), flags, (uint32_t)first);
-        (void)st;
-    } else {
-        for (int tree = t0; tree < t1; ++tree) {
-            if ((skip >> (tree - t0)) & 1ull) continue; // already incomplete: its loss is NaN whatever the partials hold (de_loss_finish_kernel)
-            // code_off[tree] = the record of the tree's first instruction; h_tree_end returns here (HF_RETURN_EACH)
-            const ConstU4Ptr rec = code + code_off[tree];
-            HState<T> st;
-            DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
-            st.poison = typename PoisonOf<T>::type{};
-            const U32x4 hp = rec[-1], hd = *rec;
-            st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, lds0, rec + 1, 0ull, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, 0ull, 0ull, 0ull, 1u,
-                                                                  (uint32_t)HF_RETURN_EACH, (uint32_t)tree);
-            // sum_j w_j * l(out_j - y_j) over this wave's 64*VW samples -> one partial per (tile, tree, wave)
-            T s = T(0);
-            DE_UNROLL for (int i = 0; i < VW; i++) {
-                const T e = st.acc[i] - yv[i];
-                const T l = a.loss_kind == DE_LOSS_L1 ? M<T>::abs(e) : e * e;
-                s += wv[i] != T(0) ? wv[i] * l : T(0); // weight 0 really excludes the sample (0 * Inf would be NaN)
-            }
-            s = wave_sum_to_lane63(s);
-            if ((tid & 63) == 63) a.partial[((int64_t)tm.tile * a.n_trees + tree) * TWAVES + (tid >> 6)] = s;
-            if (__ballot(poison_set(st.poison)) != 0ull) flag_incomplete(a.ok + tree, a.skip_flagged == 1);
+        uint32_t flags = a.skip_flagged == 1 ? 0u : HF_PLAIN_FLAG;
+        uint64_t outp, ldo_arg = ldo;
+        if constexpr (LOSS) {
+            flags |= HF_LOSS | (a.loss_kind == DE_LOSS_L1 ? (uint32_t)HF_LOSS_L1 : 0u);
+            outp = (uint64_t)(uintptr_t)(a.partial + ((int64_t)tm.tile * a.n_trees) * TWAVES + __builtin_amdgcn_readfirstlane(tid >> 6)); // (wave-uniform: an SGPR argument)
+            ldo_arg = (uint64_t)TWAVES * sizeof(T);
+        } else {
+            flags |= a.vec_store == 2 ? HF_NO_STORE : ((full && a.vec_store) ? 0u : (HF_SLOW_STORE | (uint32_t)in_tile));
+            outp = (uint64_t)(uintptr_t)(a.out + base) - (uint64_t)(uint32_t)(uintptr_t)smem_raw;
         }
+        const U32x4 hp = rec[-1], hd = *rec; // the first handler's address is in the record in front (the previous tree's end record / the head record)
+        st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, yv, wv, lds0, rec + 1, outp, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, (uint64_t)(uintptr_t)a.ok,
+                                                              ldo_arg, skip, (uint32_t)(t1 - first), flags, (uint32_t)first);
+        (void)st;
     }
     } // sub-chunks
 }

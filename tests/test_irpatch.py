@@ -116,9 +116,9 @@ def test_asmpatch_relaxes_only_the_entry_wait_of_eval_handlers():
     assert all(not vmem[n] for n in relaxed)                 # only handlers without any vector-memory instruction
     assert all(vmem[n] for n in handlers if n not in relaxed)  # ... and all of those
     assert all(i == "s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)" for n, i in handlers.items() if n not in relaxed)
-    # ... except h_tree_end, which only stores: relaxed too, while its out-of-line twin for the rare store modes is not
+    # ... except h_tree_end and its out-of-line twin (ragged stores, the fused loss's partials), which only store: relaxed too
     # (and the end-fused last-instruction handlers h_chain_end<body>, relaxed where the same two conditions hold)
-    ends = {n: i for n, i in others.items() if ("10h_tree_endI" in n or "11h_chain_endI" in n or "13h_un_end_fastI" in n or "14h_div_end_fastI" in n) and i == "s_waitcnt expcnt(0) lgkmcnt(0)"}
+    ends = {n: i for n, i in others.items() if ("10h_tree_endI" in n or "15h_tree_end_slowI" in n or "11h_chain_endI" in n or "13h_un_end_fastI" in n or "14h_div_end_fastI" in n) and i == "s_waitcnt expcnt(0) lgkmcnt(0)"}
     assert sum("10h_tree_endI" in n for n in ends) == 2 and sum("11h_chain_endI" in n for n in ends) >= 20
     assert all(i == "s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)" for n, i in others.items() if n not in ends), others
     assert sum("15h_tree_end_slowI" in n for n in others) == 2
