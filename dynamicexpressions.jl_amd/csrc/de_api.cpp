@@ -50,7 +50,7 @@ struct de_ctx {
     bool timed = false;
     std::string err;
     const char *last_kernel = "";
-    DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2, sGoff, sNg, sY, sW, sLoss, sPartial, sSeg, sDloss, sColOff, sDoff;
+    DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2, sGoff, sNg, sY, sW, sLoss, sPartial, sSeg, sDloss, sColOff, sDoff, sPrio;
     DevBuf sBcLoss, sBcDloss, sBcOk, sBcNg, sBcDoff, sBcOut, sBcTiles; // de_eval_loss_grad_by_class
     int nested = 0; // > 0 inside a call made of several inner calls: those do not touch the timing events
 };
@@ -349,7 +349,7 @@ int de_ctx_destroy(de_ctx_t *c) {
     if (!c) return DE_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff, &c->sBcLoss, &c->sBcDloss, &c->sBcOk, &c->sBcNg, &c->sBcDoff, &c->sBcOut, &c->sBcTiles}) b->release();
+    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff, &c->sPrio, &c->sBcLoss, &c->sBcDloss, &c->sBcOk, &c->sBcNg, &c->sBcDoff, &c->sBcOut, &c->sBcTiles}) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1452,6 +1452,8 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
     a.threaded = p->threaded && !direct;
     a.direct = direct;
     a.loss = lr ? &la : nullptr;
+    HIP_TRY(c, c->sPrio.reserve((size_t)3 * DE_PRIO_MAX_F * sizeof(unsigned long long)));
+    a.prio_keys = c->sPrio.p;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, launch_eval(p->dtype, a, c->stream, &c->last_kernel));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));

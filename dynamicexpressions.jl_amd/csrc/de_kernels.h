@@ -63,7 +63,9 @@ struct EvalArgs {
     bool threaded;
     bool direct; // feature matrix too wide for the LDS tile: gather features from global memory (flat-switch kernel)
     const LossArgs *loss; // non-null: fused loss instead of the output store (threaded kernel only)
+    void *prio_keys;      // device scratch, 3 * DE_PRIO_MAX_F 64-bit keys: the priority tiles of a large early-exit launch (de_kernels.hip de_tile_extremes_kernel); null: none
 };
+constexpr int DE_PRIO_MAX_F = 64;
 
 struct GradArgs {
     EvalArgs e;               // e.code is unused: the gradient kernel runs the bound UNFOLDED program

@@ -52,6 +52,9 @@ template <typename T> struct KArgs {
     int64_t N, ldX, ld_out, ld_params, n_tiles, n_classes;
     int32_t F, n_trees, trees_per_chunk, n_chunks, n_slots, xstride;
     int32_t prow_base, n_prows; // parameters staged as LDS rows (EvalArgs)
+    // threaded kernel: the first n_prio_blocks workgroups run the (tile prio[k] & 0xFFFFFFFF, chunk) pairs of the PRIORITY tiles (below)
+    const unsigned long long *prio;
+    uint32_t n_prio_blocks, n_prio;
     int32_t classes_is_i64, class_base, vec_store;
     // fused loss (de_eval_loss): residual target, optional weights, per-wave partial sums
     const T *y;
@@ -1291,6 +1294,52 @@ template <typename T, bool TB> __global__ void de_fill_handlers(uint64_t *t) {
 #undef TBK
 }
 
+// PRIORITY TILES (round 3).  A tree that is incomplete only on a few samples is evaluated on every tile until the workgroup holding
+// such a sample has run — 1.1 ms of the 7.6 ms headline.  Those samples are not anywhere: a value overflows where a
+// feature is largest or smallest, a quotient where one is closest to zero.  On the benchmark's data the 3 F tiles that hold, per
+// feature, its largest value, its smallest value and its value closest to zero flag 534 of the 557 incomplete trees (first 16 tiles
+// of the launch: 258; 16 random ones: 263; tools/exp_extremes.py).  So the launch first finds those tiles (this kernel: one pass over X,
+// a record-breaking atomicMax per statistic) and runs them as its first workgroups — a second time, nothing is reordered: the pairs
+// stay where map_block puts them and find their trees flagged.  Order only: flags and the rows of complete trees cannot change.
+// key = orderable(value) << 32 | tile; statistic 3 f + 0: x, + 1: -x, + 2: -|x| (NaN / Inf rank first everywhere).
+__device__ __forceinline__ uint32_t orderable_f32(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+template <typename T>
+__global__ void __launch_bounds__(64) de_tile_extremes_kernel(const T *__restrict__ X, int64_t N, int64_t ldX, int F, int tile_samples,
+                                                              unsigned long long *__restrict__ keys) {
+    const int64_t base = (int64_t)blockIdx.x * tile_samples;
+    const int per = tile_samples / 64;
+    const float inf = __builtin_inff();
+    for (int f = 0; f < F; f++) {
+        float hi = -inf, lo = -inf, zr = -inf; // max x, max -x, max -|x|
+        for (int i = 0; i < per; i++) {
+            const int64_t j = base + (int64_t)threadIdx.x * per + i;
+            if (j < N) {
+                const float x = (float)X[f + ldX * j];
+                const bool fin = __builtin_fabsf(x) < inf; // false for NaN and Inf
+                hi = __builtin_fmaxf(hi, fin ? x : inf);
+                lo = __builtin_fmaxf(lo, fin ? -x : inf);
+                zr = __builtin_fmaxf(zr, fin ? -__builtin_fabsf(x) : inf);
+            }
+        }
+        DE_UNROLL for (int m = 32; m >= 1; m >>= 1) {
+            hi = __builtin_fmaxf(hi, __shfl_xor(hi, m, 64));
+            lo = __builtin_fmaxf(lo, __shfl_xor(lo, m, 64));
+            zr = __builtin_fmaxf(zr, __shfl_xor(zr, m, 64));
+        }
+        if (threadIdx.x == 0) {
+            const float v[3] = {hi, lo, zr};
+            DE_UNROLL for (int k = 0; k < 3; k++) {
+                const unsigned long long key = ((unsigned long long)orderable_f32(v[k]) << 32) | (unsigned long long)blockIdx.x;
+                unsigned long long *slot = keys + 3 * f + k;
+                if (key > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, key); // (a handful of records per slot)
+            }
+        }
+    }
+}
+
 template <typename T, bool PARAMS, bool LOSS = false>
 __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T> a) {
     typedef typename VecOf<T>::type V;
@@ -1300,7 +1349,16 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     unsigned char *const smem_raw = smem_base + DE_SKIPLIST_BYTES; // [0, DE_SKIPLIST_BYTES): the live-tree list of h_tree_skip; rows behind it
     T *__restrict__ rows = reinterpret_cast<T *>(smem_raw);
 
-    const TileMap tm = map_block(blockIdx.x, a.n_chunks, a.n_tiles);
+    TileMap tm;
+    int flag_protocol = a.skip_flagged;
+    if (blockIdx.x < a.n_prio_blocks) { // a priority tile (see de_tile_extremes_kernel): its flags go straight to memory and come from there
+        const uint32_t k = blockIdx.x / (uint32_t)a.n_chunks;
+        if (k >= a.n_prio) return;
+        tm.tile = (int64_t)(uint32_t)a.prio[k];
+        tm.chunk = (int32_t)(blockIdx.x % (uint32_t)a.n_chunks);
+        tm.valid = tm.tile < a.n_tiles;
+        flag_protocol = 1;
+    } else tm = map_block(blockIdx.x - a.n_prio_blocks, a.n_chunks, a.n_tiles);
     if (!tm.valid) return;
     const int tid = threadIdx.x;
     const int64_t base = tm.tile * TILE;
@@ -1311,7 +1369,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     // (wave 0 reads them for the whole workgroup: two waves reading at different moments could see different flags, and the
     // workgroup shares ONE live-tree list)
     uint8_t f_first = 1;
-    if (a.skip_flagged && tid < 64 && tA + tid < tB) f_first = skip_flag_load(a.ok + tA + tid, a.skip_flagged, tm.tile);
+    if (a.skip_flagged && tid < 64 && tA + tid < tB) f_first = skip_flag_load(a.ok + tA + tid, flag_protocol, tm.tile);
     // the 64-bit skip mask travels from wave 0 to the others through the padding vector of LDS row 0 (16 unused bytes behind the
     // DE_TBLK vectors of every row)
     uint64_t *const mask_slot = reinterpret_cast<uint64_t *>(smem_raw + (size_t)DE_TBLK * 16);
@@ -1424,7 +1482,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             __syncthreads();
             if (tid < 64) {
                 const int i = t0 + tid;
-                const uint8_t f = i >= t1 ? (uint8_t)1 : skip_flag_load(a.ok + i, a.skip_flagged, tm.tile);
+                const uint8_t f = i >= t1 ? (uint8_t)1 : skip_flag_load(a.ok + i, flag_protocol, tm.tile);
                 const uint64_t m0 = __ballot(f == 0);
                 if (tid == 0) *mask_slot = m0;
             }
@@ -1461,7 +1519,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
         st.poison = typename PoisonOf<T>::type{};
         const int64_t in_tile = a.N - base < (int64_t)TILE ? a.N - base : (int64_t)TILE;
-        uint32_t flags = a.skip_flagged == 1 ? 0u : HF_PLAIN_FLAG;
+        uint32_t flags = flag_protocol == 1 ? 0u : HF_PLAIN_FLAG;
         uint64_t outp, ldo_arg = ldo;
         if constexpr (LOSS) {
             flags |= HF_LOSS | (a.loss_kind == DE_LOSS_L1 ? (uint32_t)HF_LOSS_L1 : 0u);
@@ -1723,8 +1781,26 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     // headline (7.52 / 7.59 ms) and far better with few trees.  The fused-loss variant writes almost nothing: under protocol 2 a CU
     // keeps re-reading its stale L1 line (10.7 instead of 8.4 ms), so it uses protocol 1 unless its chunks are tiny.
     if (a.skip_flagged) a.skip_flagged = env_int("DE_SKIP_PROTOCOL", (e.loss && tpc >= 8) ? 1 : 2) == 1 ? 1 : 2;
-    const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
+    int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    // priority tiles (de_tile_extremes_kernel): launches over many samples with the early exit on; 3 F tiles, run first and once more in
+    // place.  The pre-pass (a memset, one read of X, a dependent launch) costs ~0.08 ms: 10^6 samples lose 7 %, 10^7 gain 3.5 % — from 4 M on
+    a.prio = nullptr;
+    a.n_prio_blocks = a.n_prio = 0;
+    if (TBLK == 64 && a.skip_flagged && e.prio_keys && a.F >= 1 && a.F <= DE_PRIO_MAX_F && a.n_tiles >= env_int("DE_PRIO_MIN_TILES", 16384) && !env_int("DE_NO_PRIO_TILES", 0)) {
+        const int np = 3 * a.F;
+        hipError_t ps = hipMemsetAsync(e.prio_keys, 0, (size_t)np * sizeof(unsigned long long), stream);
+        if (ps != hipSuccess) return ps;
+        hipLaunchKernelGGL(de_tile_extremes_kernel<T>, dim3((unsigned)a.n_tiles), dim3(64), 0, stream, a.X, a.N, a.ldX, (int)a.F, (int)(TBLK * (16 / (int)sizeof(T))),
+                           static_cast<unsigned long long *>(e.prio_keys));
+        ps = hipGetLastError();
+        if (ps != hipSuccess) return ps;
+        a.prio = static_cast<const unsigned long long *>(e.prio_keys);
+        a.n_prio = (uint32_t)np;
+        a.n_prio_blocks = (uint32_t)(((int64_t)np * a.n_chunks + 7) / 8 * 8);
+        blocks += a.n_prio_blocks;
+        if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    }
     // rows: X, spill slots, then (parametric) the class row [+ the table-pointer row for Float32] of h_param
     a.cls_row_off = (uint32_t)((size_t)(a.F + a.n_slots) * TROW_BYTES);
     const int prm_rows = (e.uses_params && e.n_prows == 0) ? (sizeof(T) == 4 ? 2 : 1) : 0; // (the class row of h_param; staged parameter rows count as slots)
