@@ -65,7 +65,7 @@ struct EvalArgs {
     const LossArgs *loss; // non-null: fused loss instead of the output store (threaded kernel only)
     void *prio_keys;      // device scratch, 3 * DE_PRIO_MAX_F 64-bit keys: the priority tiles of a large early-exit launch (de_kernels.hip de_tile_extremes_kernel); null: none
 };
-constexpr int DE_PRIO_MAX_F = 64;
+constexpr int DE_PRIO_MAX_F = 8; // (the pre-pass keeps 6 registers per feature)
 
 struct GradArgs {
     EvalArgs e;               // e.code is unused: the gradient kernel runs the bound UNFOLDED program

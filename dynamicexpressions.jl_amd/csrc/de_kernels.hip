@@ -1299,44 +1299,55 @@ template <typename T, bool TB> __global__ void de_fill_handlers(uint64_t *t) {
 // feature is largest or smallest, a quotient where one is closest to zero.  On the benchmark's data the 3 F tiles that hold, per
 // feature, its largest value, its smallest value and its value closest to zero flag 534 of the 557 incomplete trees (first 16 tiles
 // of the launch: 258; 16 random ones: 263; tools/exp_extremes.py).  So the launch first finds those tiles (this kernel: one pass over X,
-// a record-breaking atomicMax per statistic) and runs them as its first workgroups — a second time, nothing is reordered: the pairs
+// a record-breaking atomicMax per statistic and workgroup; F <= DE_PRIO_MAX_F) and runs them as its first workgroups — a second time, nothing is reordered: the pairs
 // stay where map_block puts them and find their trees flagged.  Order only: flags and the rows of complete trees cannot change.
 // key = orderable(value) << 32 | tile; statistic 3 f + 0: x, + 1: -x, + 2: -|x| (NaN / Inf rank first everywhere).
 __device__ __forceinline__ uint32_t orderable_f32(float v) {
     const uint32_t b = __float_as_uint(v);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
-template <typename T>
-__global__ void __launch_bounds__(64) de_tile_extremes_kernel(const T *__restrict__ X, int64_t N, int64_t ldX, int F, int tile_samples,
-                                                              unsigned long long *__restrict__ keys) {
-    const int64_t base = (int64_t)blockIdx.x * tile_samples;
-    const int per = tile_samples / 64;
+// Grid-stride over the samples (consecutive threads read consecutive samples: X is F contiguous values per sample), every thread keeps
+// its best (value, tile) per statistic in registers (F <= FMAX: compile-time indices), one wave + block reduction of the 64-bit keys
+// per workgroup, then at most 3 F atomics per workgroup: ~0.1 ms for 10^7 x 5 Float32 (the first version — a wave per tile, a shuffle
+// reduction per tile and feature — took 0.49 ms).
+template <typename T, int FMAX>
+__global__ void __launch_bounds__(256) de_tile_extremes_kernel(const T *__restrict__ X, int64_t N, int64_t ldX, int F, int tile_shift,
+                                                               unsigned long long *__restrict__ keys) {
     const float inf = __builtin_inff();
-    for (int f = 0; f < F; f++) {
-        float hi = -inf, lo = -inf, zr = -inf; // max x, max -x, max -|x|
-        for (int i = 0; i < per; i++) {
-            const int64_t j = base + (int64_t)threadIdx.x * per + i;
-            if (j < N) {
+    float v[3][FMAX];
+    uint32_t at[3][FMAX];
+    DE_UNROLL for (int f = 0; f < FMAX; f++) DE_UNROLL for (int k = 0; k < 3; k++) { v[k][f] = -inf; at[k][f] = 0u; }
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < N; j += (int64_t)gridDim.x * 256) {
+        const uint32_t tile = (uint32_t)(j >> tile_shift);
+        DE_UNROLL for (int f = 0; f < FMAX; f++) {
+            if (f < F) {
                 const float x = (float)X[f + ldX * j];
-                const bool fin = __builtin_fabsf(x) < inf; // false for NaN and Inf
-                hi = __builtin_fmaxf(hi, fin ? x : inf);
-                lo = __builtin_fmaxf(lo, fin ? -x : inf);
-                zr = __builtin_fmaxf(zr, fin ? -__builtin_fabsf(x) : inf);
+                const bool fin = __builtin_fabsf(x) < inf; // false for NaN and Inf: they rank first in every statistic
+                const float c[3] = {fin ? x : inf, fin ? -x : inf, fin ? -__builtin_fabsf(x) : inf};
+                DE_UNROLL for (int k = 0; k < 3; k++)
+                    if (c[k] > v[k][f]) { v[k][f] = c[k]; at[k][f] = tile; }
             }
         }
-        DE_UNROLL for (int m = 32; m >= 1; m >>= 1) {
-            hi = __builtin_fmaxf(hi, __shfl_xor(hi, m, 64));
-            lo = __builtin_fmaxf(lo, __shfl_xor(lo, m, 64));
-            zr = __builtin_fmaxf(zr, __shfl_xor(zr, m, 64));
-        }
-        if (threadIdx.x == 0) {
-            const float v[3] = {hi, lo, zr};
+    }
+    __shared__ unsigned long long best[4][3 * FMAX];
+    DE_UNROLL for (int f = 0; f < FMAX; f++) {
+        if (f < F) {
             DE_UNROLL for (int k = 0; k < 3; k++) {
-                const unsigned long long key = ((unsigned long long)orderable_f32(v[k]) << 32) | (unsigned long long)blockIdx.x;
-                unsigned long long *slot = keys + 3 * f + k;
-                if (key > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, key); // (a handful of records per slot)
+                unsigned long long key = ((unsigned long long)orderable_f32(v[k][f]) << 32) | (unsigned long long)at[k][f];
+                DE_UNROLL for (int m = 32; m >= 1; m >>= 1) {
+                    const unsigned long long o = __shfl_xor(key, m, 64);
+                    key = o > key ? o : key;
+                }
+                if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6][3 * f + k] = key;
             }
         }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 3 * F) {
+        unsigned long long key = best[0][threadIdx.x];
+        DE_UNROLL for (int w = 1; w < 4; w++) key = best[w][threadIdx.x] > key ? best[w][threadIdx.x] : key;
+        unsigned long long *slot = keys + threadIdx.x;
+        if (key > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, key);
     }
 }
 
@@ -1783,16 +1794,21 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     if (a.skip_flagged) a.skip_flagged = env_int("DE_SKIP_PROTOCOL", (e.loss && tpc >= 8) ? 1 : 2) == 1 ? 1 : 2;
     int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    // priority tiles (de_tile_extremes_kernel): launches over many samples with the early exit on; 3 F tiles, run first and once more in
-    // place.  The pre-pass (a memset, one read of X, a dependent launch) costs ~0.08 ms: 10^6 samples lose 7 %, 10^7 gain 3.5 % — from 4 M on
+    // priority tiles (de_tile_extremes_kernel): launches over >= 2048 sample tiles with the early exit on; 3 F tiles, run first and once
+    // more in place.  The pre-pass (a memset, one read of X, a dependent launch: 0.11 ms at 10^7 samples) pays from ~5 10^5 samples on
+    // (10^6: -4 .. -7 %, 10^7: -10 %)
     a.prio = nullptr;
     a.n_prio_blocks = a.n_prio = 0;
-    if (TBLK == 64 && a.skip_flagged && e.prio_keys && a.F >= 1 && a.F <= DE_PRIO_MAX_F && a.n_tiles >= env_int("DE_PRIO_MIN_TILES", 16384) && !env_int("DE_NO_PRIO_TILES", 0)) {
+    if (TBLK == 64 && a.skip_flagged && e.prio_keys && a.F >= 1 && a.F <= DE_PRIO_MAX_F && a.n_tiles >= env_int("DE_PRIO_MIN_TILES", 2048) && !env_int("DE_NO_PRIO_TILES", 0)) {
         const int np = 3 * a.F;
         hipError_t ps = hipMemsetAsync(e.prio_keys, 0, (size_t)np * sizeof(unsigned long long), stream);
         if (ps != hipSuccess) return ps;
-        hipLaunchKernelGGL(de_tile_extremes_kernel<T>, dim3((unsigned)a.n_tiles), dim3(64), 0, stream, a.X, a.N, a.ldX, (int)a.F, (int)(TBLK * (16 / (int)sizeof(T))),
-                           static_cast<unsigned long long *>(e.prio_keys));
+        const int tile_samples = TBLK * (16 / (int)sizeof(T)); // 256 / 128: a power of two
+        int tile_shift = 0;
+        while ((1 << tile_shift) < tile_samples) ++tile_shift;
+        const int64_t want = (a.N + 255) / 256;
+        hipLaunchKernelGGL((de_tile_extremes_kernel<T, DE_PRIO_MAX_F>), dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, stream, a.X, a.N, a.ldX, (int)a.F,
+                           tile_shift, static_cast<unsigned long long *>(e.prio_keys));
         ps = hipGetLastError();
         if (ps != hipSuccess) return ps;
         a.prio = static_cast<const unsigned long long *>(e.prio_keys);
