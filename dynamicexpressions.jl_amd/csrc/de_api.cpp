@@ -2274,6 +2274,8 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
     g.e.code_off = nullptr;
     g.e.n_trees = (int32_t)p->n_trees;
     g.e.skip_flagged = !(p->options & DE_OPT_FULL_EVAL) && tree_skip_enabled(); // (the gradient entry points always test validity)
+    if (c->sPrio.reserve((size_t)3 * DE_PRIO_MAX_F * sizeof(unsigned long long)) == hipSuccess) g.e.prio_keys = c->sPrio.p; // priority tiles (de_kernels.hip)
+    g.prio_ready = false;
     g.e.n_slots = p->n_slots;
     g.e.uses_params = p->uses_params;
     g.e.X = sX.dev;
@@ -2479,6 +2481,8 @@ static int loss_grad_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N
     g.e.code_off = p->d_gcode_off;
     g.e.n_trees = (int32_t)p->n_trees;
     g.e.skip_flagged = !(p->options & DE_OPT_FULL_EVAL) && tree_skip_enabled(); // (the gradient entry points always test validity)
+    if (c->sPrio.reserve((size_t)3 * DE_PRIO_MAX_F * sizeof(unsigned long long)) == hipSuccess) g.e.prio_keys = c->sPrio.p; // priority tiles (de_kernels.hip)
+    g.prio_ready = false;
     g.e.n_slots = p->n_slots;
     g.e.uses_params = p->uses_params;
     g.e.X = sX.dev;

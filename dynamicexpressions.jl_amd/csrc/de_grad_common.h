@@ -51,6 +51,10 @@ template <typename T> struct GArgs {
     const int32_t *rev_mid;  // de_rev_threaded.hip: first backward instruction of every tree
     int32_t rev_rows;        // ... and LDS rows per wave (X + slots + partial rows + staging)
     int32_t rev_stage_cols, rev_stage_rows; // per-wave staging of the column sums (elements / rows)
+    // priority tiles (de_kernels.hip de_tile_extremes_kernel): the first n_prio_blocks workgroups (of every window) run the tiles
+    // (prio[k] & 0xFFFFFFFF) >> prio_shift first; null / 0: none
+    const unsigned long long *prio;
+    uint32_t n_prio, n_prio_blocks, prio_shift;
 };
 
 constexpr int GPTAB_MAX = 2048;
@@ -218,7 +222,7 @@ template <typename T> __device__ __noinline__ TG<T> ternary_vg(uint32_t op, T x,
     return r;
 }
 
-struct GTileMap { int64_t tile; int32_t chunk; bool valid; };
+struct GTileMap { int64_t tile; int32_t chunk; bool valid; bool prio = false; };
 __device__ __forceinline__ GTileMap gmap_block(uint32_t bid, int32_t n_chunks, int64_t n_tiles) {
     GTileMap m;
     if (n_tiles < 64) {
@@ -234,6 +238,27 @@ __device__ __forceinline__ GTileMap gmap_block(uint32_t bid, int32_t n_chunks, i
     m.tile = (int64_t)(idx / (uint32_t)n_chunks) * 8 + xcd;
     m.valid = m.tile < n_tiles;
     return m;
+}
+
+// ... with the launch's priority tiles in front (their flags travel at agent scope whatever the launch's protocol is)
+template <typename T> __device__ __forceinline__ GTileMap gmap_block_prio(const GArgs<T> &a, uint32_t bid) {
+    if (bid >= a.n_prio_blocks) return gmap_block(bid - a.n_prio_blocks, a.n_chunks, a.n_tiles);
+    GTileMap m;
+    const uint32_t k = bid / (uint32_t)a.n_chunks;
+    m.chunk = (int32_t)(bid % (uint32_t)a.n_chunks);
+    m.tile = k < a.n_prio ? (int64_t)((uint32_t)a.prio[k] >> a.prio_shift) : 0;
+    m.valid = k < a.n_prio && m.tile < a.n_tiles;
+    m.prio = true;
+    return m;
+}
+// (host) fills the priority fields of a launch with n_chunks chunks and tile_samples per tile; returns the blocks to add to the grid
+template <typename T> inline int64_t gprio_setup(GArgs<T> &a, const void *keys, int x_features, int tile_samples) {
+    a.prio = static_cast<const unsigned long long *>(keys);
+    a.n_prio = (uint32_t)(3 * x_features);
+    a.prio_shift = 0;
+    while ((64 << a.prio_shift) < tile_samples) ++a.prio_shift;
+    a.n_prio_blocks = (uint32_t)(((int64_t)a.n_prio * a.n_chunks + 7) / 8 * 8);
+    return (int64_t)a.n_prio_blocks;
 }
 
 __device__ __noinline__ void gflag_incomplete(uint8_t *ok, int agent) { // agent scope (written through): workgroups that start later skip the tree

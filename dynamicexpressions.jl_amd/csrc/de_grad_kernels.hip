@@ -506,8 +506,11 @@ hipError_t grad_handler_table(int dtype, int GC, int VS, uint64_t *table) {
     return hipSuccess;
 }
 
-hipError_t launch_grad_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name) {
+static hipError_t grad_prio_prepass(int dtype, const GradArgs &a, hipStream_t stream, GradArgs *with);
+hipError_t launch_grad_threaded(int dtype, const GradArgs &a0, hipStream_t stream, const char **kernel_name) {
     if (kernel_name) *kernel_name = "de_grad_threaded_kernel";
+    GradArgs a;
+    { const hipError_t ps = grad_prio_prepass(dtype, a0, stream, &a); if (ps != hipSuccess) return ps; }
     const int k = dtype == DE_F32 ? 0 : 1;
     if (a.loss) { // two-sample modules use 512-sample tiles: the 256-sample tile slots they never write must read as 0
         bool wide = false;
@@ -550,8 +553,19 @@ hipError_t rev_handler_table(int dtype, uint64_t *table) {
     for (int i = 0; i < (int)ROP_COUNT; i++) table[i] = cache[k][i];
     return hipSuccess;
 }
-hipError_t launch_rev_threaded(int dtype, const GradArgs &a, hipStream_t stream, const char **kernel_name) {
+// the priority tiles of a gradient / reverse launch: one pre-pass over X for all its buckets (de_kernels.hip de_tile_extremes_kernel)
+static hipError_t grad_prio_prepass(int dtype, const GradArgs &a, hipStream_t stream, GradArgs *with) {
+    *with = a;
+    with->prio_ready = false;
+    if (!a.e.skip_flagged || !a.e.prio_keys || !a.e.X || !prio_tiles_wanted(a.e.N, a.e.F)) return hipSuccess;
+    const hipError_t st = launch_tile_extremes(dtype, a.e.X, a.e.N, a.e.ldX, a.e.F, a.e.prio_keys, stream);
+    if (st == hipSuccess) with->prio_ready = true;
+    return st;
+}
+hipError_t launch_rev_threaded(int dtype, const GradArgs &a0, hipStream_t stream, const char **kernel_name) {
     if (kernel_name) *kernel_name = "de_rev_threaded_kernel";
+    GradArgs a;
+    { const hipError_t ps = a0.rev_tile_range ? (a = a0, a.prio_ready = false, hipSuccess) : grad_prio_prepass(dtype, a0, stream, &a); if (ps != hipSuccess) return ps; }
     const int64_t n_tiles = (a.e.N + GBLK - 1) / GBLK;
     for (int k = 0; k < a.rev_n_groups; k++) { // one launch per LDS-need group of trees
         const hipError_t st = dtype == DE_F32 ? rev_thr_launch_f(a, k, stream) : rev_thr_launch_d(a, k, stream);

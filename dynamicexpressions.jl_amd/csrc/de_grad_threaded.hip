@@ -441,8 +441,9 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
     extern __shared__ __align__(16) unsigned char gtsmem[];
     T *__restrict__ rows = reinterpret_cast<T *>(gtsmem);
 
-    const GTileMap tm = gmap_block(blockIdx.x, a.n_chunks, a.n_tiles);
+    const GTileMap tm = gmap_block_prio(a, blockIdx.x);
     if (!tm.valid) return;
+    const int flag_protocol = tm.prio ? 1 : a.skip_flagged;
     const int tid = threadIdx.x;
     const int64_t base = tm.tile * TILE;
     const int64_t last = a.N - 1;
@@ -484,7 +485,7 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
     const uint32_t stage0 = wave_base + (uint32_t)F * grow_bytes<T>(); // the wave's slot area, free between trees
 
     const ConstI32Ptr tree_ids = (ConstI32Ptr)(uintptr_t)a.tree_ids;
-    const uint64_t skip = gskip_mask(a.ok, tree_ids, t0, t1, a.skip_flagged, (int64_t)tm.tile);
+    const uint64_t skip = gskip_mask(a.ok, tree_ids, t0, t1, flag_protocol, (int64_t)tm.tile);
     for (int ti = t0; ti < t1; ++ti) {
         if ((skip >> (ti - t0)) & 1ull) continue; // already incomplete (early exit)
         const int tree = tree_ids[ti];
@@ -517,7 +518,7 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
         } else {
             g_epilogue_store<T, GC>(st, a.out ? a.out + (int64_t)tree * a.ld_out : nullptr, a.grad + grad_off[tree], a.N, G, g0, (int64_t)tm.tile, stage0);
         }
-        if (__ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree, a.skip_flagged == 1);
+        if (__ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree, flag_protocol == 1);
     }
 }
 
@@ -600,7 +601,10 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStrea
     a.trees_per_chunk = (int32_t)((bk.n + n_chunks - 1) / n_chunks);
     if (a.skip_flagged) a.skip_flagged = a.trees_per_chunk >= 8 ? 1 : 2; // flag protocol (skip_flag_load, de_device_ops.h): these kernels write little, their L1 lines go stale under 2 (reverse kernel 17.0 / 16.0 ms); 2 only for tiny chunks (many tiles on one flag line)
     a.n_chunks = (int32_t)((bk.n + a.trees_per_chunk - 1) / a.trees_per_chunk);
-    const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
+    int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
+    a.prio = nullptr;
+    a.n_prio = a.n_prio_blocks = a.prio_shift = 0;
+    if (a.skip_flagged && ga.prio_ready) blocks += gprio_setup(a, e.prio_keys, e.F, GBLK * VS);
     if (blocks <= 0 || blocks > 0x7fffffffLL || windows > 65535) return hipErrorInvalidValue;
     const size_t slot_rows = std::max<size_t>((size_t)a.n_slots * (1 + GC), (size_t)GC);
     const size_t lds = 4 * ((size_t)a.F + slot_rows) * 64 * VS * sizeof(T); // 4 waves x rows x one wave's samples

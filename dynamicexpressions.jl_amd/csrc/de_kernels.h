@@ -66,6 +66,9 @@ struct EvalArgs {
     void *prio_keys;      // device scratch, 3 * DE_PRIO_MAX_F 64-bit keys: the priority tiles of a large early-exit launch (de_kernels.hip de_tile_extremes_kernel); null: none
 };
 constexpr int DE_PRIO_MAX_F = 8; // (the pre-pass keeps 6 registers per feature)
+constexpr int DE_PRIO_UNIT = 64;  // samples per unit of the keys' position field (every kernel's tile is a multiple)
+hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX, int F, void *keys, hipStream_t stream);
+bool prio_tiles_wanted(int64_t N, int F);
 
 struct GradArgs {
     EvalArgs e;               // e.code is unused: the gradient kernel runs the bound UNFOLDED program
@@ -98,6 +101,7 @@ struct GradArgs {
     int32_t rev_stage_cols;                     // column sums a wave stages in LDS between two writes
     uint64_t rev_handler_base;
     uint32_t rev_param_off;
+    bool prio_ready;  // e.prio_keys holds this launch's priority tiles (launch_grad_threaded / launch_rev_threaded run the pre-pass)
     int32_t n_buckets;
     struct Bucket {
         int32_t GC, VS;                // module: window width, samples per lane

@@ -54,7 +54,7 @@ template <typename T> struct KArgs {
     int32_t prow_base, n_prows; // parameters staged as LDS rows (EvalArgs)
     // threaded kernel: the first n_prio_blocks workgroups run the (tile prio[k] & 0xFFFFFFFF, chunk) pairs of the PRIORITY tiles (below)
     const unsigned long long *prio;
-    uint32_t n_prio_blocks, n_prio;
+    uint32_t n_prio_blocks, n_prio, prio_shift; // (keys hold 64-sample units: tile = unit >> prio_shift)
     int32_t classes_is_i64, class_base, vec_store;
     // fused loss (de_eval_loss): residual target, optional weights, per-wave partial sums
     const T *y;
@@ -1365,7 +1365,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     if (blockIdx.x < a.n_prio_blocks) { // a priority tile (see de_tile_extremes_kernel): its flags go straight to memory and come from there
         const uint32_t k = blockIdx.x / (uint32_t)a.n_chunks;
         if (k >= a.n_prio) return;
-        tm.tile = (int64_t)(uint32_t)a.prio[k];
+        tm.tile = (int64_t)((uint32_t)a.prio[k] >> a.prio_shift);
         tm.chunk = (int32_t)(blockIdx.x % (uint32_t)a.n_chunks);
         tm.valid = tm.tile < a.n_tiles;
         flag_protocol = 1;
@@ -1751,6 +1751,27 @@ hipError_t eval_handler_table(int dtype, bool turbo, uint64_t *table) {
 
 bool eval_uses_threaded() { return env_int("DE_EVAL_THREADED", 1) != 0 && env_int("DE_EVAL_G", 1) == 1 && env_int("DE_EVAL_BLOCK", 256) == 256; }
 
+// The pre-pass of the priority tiles (de_tile_extremes_kernel) for X[F, N]: keys[3 F] = orderable(value) << 32 | (sample / DE_PRIO_UNIT).
+hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX, int F, void *keys, hipStream_t stream) {
+    if (!keys || F < 1 || F > DE_PRIO_MAX_F || N < 1) return hipErrorInvalidValue;
+    hipError_t st = hipMemsetAsync(keys, 0, (size_t)3 * F * sizeof(unsigned long long), stream);
+    if (st != hipSuccess) return st;
+    int shift = 0;
+    while ((1 << shift) < DE_PRIO_UNIT) ++shift;
+    const int64_t want = (N + 255) / 256;
+    const dim3 grid((unsigned)(want < 2048 ? want : 2048));
+    if (dtype == DE_F32)
+        hipLaunchKernelGGL((de_tile_extremes_kernel<float, DE_PRIO_MAX_F>), grid, dim3(256), 0, stream, static_cast<const float *>(X), N, ldX, F, shift,
+                           static_cast<unsigned long long *>(keys));
+    else
+        hipLaunchKernelGGL((de_tile_extremes_kernel<double, DE_PRIO_MAX_F>), grid, dim3(256), 0, stream, static_cast<const double *>(X), N, ldX, F, shift,
+                           static_cast<unsigned long long *>(keys));
+    return hipGetLastError();
+}
+bool prio_tiles_wanted(int64_t N, int F) { // (the pre-pass pays from ~5 10^5 samples on: launch_threaded_t)
+    return F >= 1 && F <= DE_PRIO_MAX_F && (N + 255) / 256 >= env_int("DE_PRIO_MIN_TILES", 2048) && !env_int("DE_NO_PRIO_TILES", 0);
+}
+
 template <typename T>
 static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const char **kname) {
     constexpr int VW = VecOf<T>::W;
@@ -1799,18 +1820,13 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     // (10^6: -4 .. -7 %, 10^7: -10 %)
     a.prio = nullptr;
     a.n_prio_blocks = a.n_prio = 0;
-    if (TBLK == 64 && a.skip_flagged && e.prio_keys && a.F >= 1 && a.F <= DE_PRIO_MAX_F && a.n_tiles >= env_int("DE_PRIO_MIN_TILES", 2048) && !env_int("DE_NO_PRIO_TILES", 0)) {
+    if (TBLK == 64 && a.skip_flagged && e.prio_keys && a.F >= 1 && prio_tiles_wanted(a.N, a.F)) {
         const int np = 3 * a.F;
-        hipError_t ps = hipMemsetAsync(e.prio_keys, 0, (size_t)np * sizeof(unsigned long long), stream);
+        hipError_t ps = launch_tile_extremes(sizeof(T) == 4 ? DE_F32 : DE_F64, a.X, a.N, a.ldX, a.F, e.prio_keys, stream);
         if (ps != hipSuccess) return ps;
         const int tile_samples = TBLK * (16 / (int)sizeof(T)); // 256 / 128: a power of two
-        int tile_shift = 0;
-        while ((1 << tile_shift) < tile_samples) ++tile_shift;
-        const int64_t want = (a.N + 255) / 256;
-        hipLaunchKernelGGL((de_tile_extremes_kernel<T, DE_PRIO_MAX_F>), dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, stream, a.X, a.N, a.ldX, (int)a.F,
-                           tile_shift, static_cast<unsigned long long *>(e.prio_keys));
-        ps = hipGetLastError();
-        if (ps != hipSuccess) return ps;
+        a.prio_shift = 0;
+        while ((DE_PRIO_UNIT << a.prio_shift) < tile_samples) ++a.prio_shift;
         a.prio = static_cast<const unsigned long long *>(e.prio_keys);
         a.n_prio = (uint32_t)np;
         a.n_prio_blocks = (uint32_t)(((int64_t)np * a.n_chunks + 7) / 8 * 8);

@@ -306,8 +306,9 @@ template <typename T, bool PARAMS>
 __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a, const uint64_t hbase, const uint32_t param_off) {
     extern __shared__ __align__(16) unsigned char rtsmem[];
     T *__restrict__ rows = reinterpret_cast<T *>(rtsmem);
-    const GTileMap tm = gmap_block(blockIdx.x, a.n_chunks, a.n_tiles);
+    const GTileMap tm = gmap_block_prio(a, blockIdx.x);
     if (!tm.valid) return;
+    const int flag_protocol = tm.prio ? 1 : a.skip_flagged;
     // few per-lane values may live across the handler calls: they sit in callee-saved VGPRs, which the ABI hands out
     // in blocks of 8 at v40, v56, v72, v88 — a fourth block costs a fifth of the occupancy
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -364,7 +365,7 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
         for (int i = RT_LANE(); i < staged; i += 64) dst[(int64_t)i * 4] = *RLDS(T, stage0 + (uint32_t)i * (uint32_t)sizeof(T));
         staged = 0;
     };
-    const uint64_t skip = gskip_mask(a.ok, tree_ids, t0, t1, a.skip_flagged, (int64_t)tm.tile);
+    const uint64_t skip = gskip_mask(a.ok, tree_ids, t0, t1, flag_protocol, (int64_t)tm.tile);
     for (int ti = t0; ti < t1; ++ti) {
         if ((skip >> (ti - t0)) & 1ull) continue; // already incomplete (early exit): its reductions are NaN whatever the partials hold
         const int tree = tree_ids[ti];
@@ -406,7 +407,7 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
             st = reinterpret_cast<RHandlerFn<T>>(hbase + hd.x)(st, rec + 1, hd.y, rrec_imm<T>(hd), hbase);
         }
         const bool bad = (st.vpoison != st.vpoison) || (nc > 1 && st.gpoison != st.gpoison);
-        if (__ballot(bad) != 0ull) gflag_incomplete(a.ok + tree, a.skip_flagged == 1);
+        if (__ballot(bad) != 0ull) gflag_incomplete(a.ok + tree, flag_protocol == 1);
     }
     if (staged > 0) flush();
 }
@@ -484,7 +485,10 @@ hipError_t DE_RT_NAME(rev_thr_launch_)(const GradArgs &ga, int group, hipStream_
     a.trees_per_chunk = (int32_t)((grp.n + n_chunks - 1) / n_chunks);
     if (a.skip_flagged) a.skip_flagged = a.trees_per_chunk >= 8 ? 1 : 2; // flag protocol (skip_flag_load, de_device_ops.h): these kernels write little, their L1 lines go stale under 2 (reverse kernel 17.0 / 16.0 ms); 2 only for tiny chunks (many tiles on one flag line)
     a.n_chunks = (int32_t)((grp.n + a.trees_per_chunk - 1) / a.trees_per_chunk);
-    const int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
+    int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
+    a.prio = nullptr;
+    a.n_prio = a.n_prio_blocks = a.prio_shift = 0;
+    if (a.skip_flagged && ga.prio_ready && !ga.rev_tile_range) blocks += gprio_setup(a, e.prio_keys, e.F, GBLK); // (class-aligned tiles: no)
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const size_t lds = 4 * (size_t)a.rev_rows * 64 * sizeof(T);
     void (*kern)(const GArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_rev_threaded_kernel<T, true> : de_rev_threaded_kernel<T, false>;

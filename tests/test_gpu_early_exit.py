@@ -112,17 +112,26 @@ def test_priority_tiles_change_nothing_but_the_order(api, dtype, monkeypatch):
         pop.ctx.use_torch_stream()
         pop.ctx.check(lib.de_eval(pop.ctx._h, pop._h, Xd.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
         loss, lk = pop.eval_loss(Xd, y)
+        gy, gg, gk = pop.eval_grad(Xd, True)                       # forward-mode kernel with the priority tiles in front
+        l1, d1, k1 = pop.eval_loss_grad(Xd, y, variable=False)     # reverse / forward loss gradient
         torch.cuda.synchronize()
-        res[tag] = (out, ok.bool(), loss, lk)
+        res[tag] = (out, ok.bool(), loss, lk, gg, gk, l1, d1, k1)
         pop.close()
     kf = res["full"][1]
     assert not bool(kf[-1]) and 0 < int(kf.sum()) < len(trees)
     it = torch.int32 if dtype == np.float32 else torch.int64
     for tag in ("plain", "prio"):
-        out, k, loss, lk = res[tag]
+        out, k, loss, lk, gg, gk, l1, d1, k1 = res[tag]
         assert torch.equal(k, kf) and torch.equal(lk, res["full"][3])
         assert torch.equal(out[kf], res["full"][0][kf])
         assert torch.equal(loss[kf].view(it), res["full"][2][kf].view(it)) and bool(torch.isnan(loss[~kf]).all())
+        assert torch.equal(gk, res["full"][5]) and torch.equal(k1, res["full"][8])
+        assert torch.equal(l1[k1].view(it), res["full"][6][k1].view(it))
+        for t in range(len(trees)):
+            if bool(gk[t]):
+                assert torch.equal(gg[t].view(it), res["full"][4][t].view(it)), t
+            if bool(k1[t]):
+                assert torch.equal(d1[t].view(it), res["full"][7][t].view(it)), t
     alone = {tag: float((res[tag][0][-1] == 12345.0).float().mean()) for tag in ("plain", "prio")}
     print("row of the tree that fails on one sample of the last tile, share left alone:", alone)
     # found by the first workgroups (the chip holds a third of this launch at once: those start before any flag is known) / by the last ones
