@@ -92,7 +92,9 @@ enum de_options {
      * with ok == 0 are PARTIALLY WRITTEN (unspecified, as the reference's
      * buffer after its early return, src/Evaluate.jl:350-351; fused losses of
      * such a tree are NaN).  The flags and every row with ok == 1 do not depend
-     * on it.  DE_OPT_FULL_EVAL below turns the exit off. */
+     * on it — nor on the order in which a launch visits its sample tiles (large
+     * launches run the tiles with the features' extreme values first).
+     * DE_OPT_FULL_EVAL below turns the exit off. */
     DE_OPT_EARLY_EXIT = 1u << 0,
     /* The reference's fused 2/3-node kernels decide WHICH leaves are validity
      * tested and where `Inf` is substituted (src/Evaluate.jl:488-691).  They are
