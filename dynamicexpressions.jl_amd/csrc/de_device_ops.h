@@ -25,7 +25,9 @@ namespace de {
 // keeps it forever (fused loss: 10.7 instead of 8.4 ms: the late-flagged trees stayed alive on seven XCDs).
 __device__ __forceinline__ uint8_t skip_flag_load(uint8_t *q, int protocol, int64_t tile) {
     if (protocol == 1) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint8_t f = *q;
+    // protocol 3 (experiment): as 2, but the load is non-temporal — the vector L1 does not keep the line, so a CU cannot sit on a stale
+    // copy in a kernel that writes little; the XCD's L2 answers
+    uint8_t f = protocol == 3 ? __builtin_nontemporal_load(q) : *q;
     if (((tile >> 3) & 31) == 0) { // (tiles of one XCD are 8 apart: map_block / gmap_block)
         const uint8_t m = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (m == 0 && f != 0) { *q = 0; f = 0; }

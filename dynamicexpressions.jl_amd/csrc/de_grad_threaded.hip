@@ -599,7 +599,10 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStrea
     if (n_chunks > max_chunks) n_chunks = max_chunks;
     if (n_chunks < 1) n_chunks = 1;
     a.trees_per_chunk = (int32_t)((bk.n + n_chunks - 1) / n_chunks);
-    if (a.skip_flagged) a.skip_flagged = a.trees_per_chunk >= 8 ? 1 : 2; // flag protocol (skip_flag_load, de_device_ops.h): these kernels write little, their L1 lines go stale under 2 (reverse kernel 17.0 / 16.0 ms); 2 only for tiny chunks (many tiles on one flag line)
+    // ... unless the launch has priority tiles (below): the flags are then down before most workgroups first look, a stale line is rare and
+    // the cached protocol wins (fused loss gradient 6.65 -> 5.98 ms; the reverse kernel keeps protocol 1: 15.9 against 16.9 ms)
+    if (a.skip_flagged) a.skip_flagged = (a.trees_per_chunk >= 8 && !ga.prio_ready) ? 1 : 2;
+    if (a.skip_flagged) { const char *pv = getenv("DE_SKIP_PROTOCOL"); if (pv && *pv >= '1' && *pv <= '3') a.skip_flagged = *pv - '0'; } // (experiments) // flag protocol (skip_flag_load, de_device_ops.h): these kernels write little, their L1 lines go stale under 2 (reverse kernel 17.0 / 16.0 ms); 2 only for tiny chunks (many tiles on one flag line)
     a.n_chunks = (int32_t)((bk.n + a.trees_per_chunk - 1) / a.trees_per_chunk);
     int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     a.prio = nullptr;

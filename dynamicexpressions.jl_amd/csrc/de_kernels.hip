@@ -1812,7 +1812,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     // The plain eval kernel writes 20+ GB per launch: flag lines leave the L1s / L2s all the time and protocol 2 is as good as 1 on the
     // headline (7.52 / 7.59 ms) and far better with few trees.  The fused-loss variant writes almost nothing: under protocol 2 a CU
     // keeps re-reading its stale L1 line (10.7 instead of 8.4 ms), so it uses protocol 1 unless its chunks are tiny.
-    if (a.skip_flagged) a.skip_flagged = env_int("DE_SKIP_PROTOCOL", (e.loss && tpc >= 8) ? 1 : 2) == 1 ? 1 : 2;
+    if (a.skip_flagged) { const int pr = env_int("DE_SKIP_PROTOCOL", (e.loss && tpc >= 8) ? 1 : 2); a.skip_flagged = pr >= 1 && pr <= 3 ? pr : 2; }
     int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // priority tiles (de_tile_extremes_kernel): launches over >= 2048 sample tiles with the early exit on; 3 F tiles, run first and once
