@@ -557,7 +557,7 @@ hipError_t rev_handler_table(int dtype, uint64_t *table) {
 static hipError_t grad_prio_prepass(int dtype, const GradArgs &a, hipStream_t stream, GradArgs *with) {
     *with = a;
     with->prio_ready = false;
-    if (!a.e.skip_flagged || !a.e.prio_keys || !a.e.X || !prio_tiles_wanted(a.e.N, a.e.F)) return hipSuccess;
+    if (!a.e.skip_flagged || !a.e.prio_keys || !a.e.X || !prio_tiles_wanted(a.e.N, a.e.F, a.e.n_trees)) return hipSuccess;
     const hipError_t st = launch_tile_extremes(dtype, a.e.X, a.e.N, a.e.ldX, a.e.F, a.e.prio_keys, stream);
     if (st == hipSuccess) with->prio_ready = true;
     return st;

@@ -68,7 +68,7 @@ struct EvalArgs {
 constexpr int DE_PRIO_MAX_F = 8; // (the pre-pass keeps 6 registers per feature)
 constexpr int DE_PRIO_UNIT = 64;  // samples per unit of the keys' position field (every kernel's tile is a multiple)
 hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX, int F, void *keys, hipStream_t stream);
-bool prio_tiles_wanted(int64_t N, int F);
+bool prio_tiles_wanted(int64_t N, int F, int64_t n_trees);
 
 struct GradArgs {
     EvalArgs e;               // e.code is unused: the gradient kernel runs the bound UNFOLDED program

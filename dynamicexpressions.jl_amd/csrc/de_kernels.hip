@@ -1768,8 +1768,11 @@ hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX
                            static_cast<unsigned long long *>(keys));
     return hipGetLastError();
 }
-bool prio_tiles_wanted(int64_t N, int F) { // (the pre-pass pays from ~5 10^5 samples on: launch_threaded_t)
-    return F >= 1 && F <= DE_PRIO_MAX_F && (N + 255) / 256 >= env_int("DE_PRIO_MIN_TILES", 2048) && !env_int("DE_NO_PRIO_TILES", 0);
+bool prio_tiles_wanted(int64_t N, int F, int64_t n_trees) {
+    // the pre-pass costs a read of X; what it saves grows with the trees: at 10^7 samples 32 trees lose 13 %, 64 break even, 125 gain 6 %,
+    // 250+ gain 13 % (tools/exp_prio_trees.py); and it pays from ~5 10^5 samples on (launch_threaded_t)
+    return F >= 1 && F <= DE_PRIO_MAX_F && n_trees >= env_int("DE_PRIO_MIN_TREES", 96) && (N + 255) / 256 >= env_int("DE_PRIO_MIN_TILES", 2048) &&
+           !env_int("DE_NO_PRIO_TILES", 0);
 }
 
 template <typename T>
@@ -1820,7 +1823,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     // (10^6: -4 .. -7 %, 10^7: -10 %)
     a.prio = nullptr;
     a.n_prio_blocks = a.n_prio = 0;
-    if (TBLK == 64 && a.skip_flagged && e.prio_keys && a.F >= 1 && prio_tiles_wanted(a.N, a.F)) {
+    if (TBLK == 64 && a.skip_flagged && e.prio_keys && a.F >= 1 && prio_tiles_wanted(a.N, a.F, a.n_trees)) {
         const int np = 3 * a.F;
         hipError_t ps = launch_tile_extremes(sizeof(T) == 4 ? DE_F32 : DE_F64, a.X, a.N, a.ldX, a.F, e.prio_keys, stream);
         if (ps != hipSuccess) return ps;
