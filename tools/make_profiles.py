@@ -125,6 +125,8 @@ def main():
                 e["bench_under_rocprof"] = str(ex)
         summ[wl] = e
         print(wl, json.dumps({k: v for k, v in e.items() if k not in ("kernels_us_per_step", "launches_per_step")}))
+    if not any(isinstance(v, dict) for v in summ.values()):
+        sys.exit(f"make_profiles: nothing under gpurun_out/profiles_{tag} (did the profile run happen?) — profiles/pmc_summary.json left as it is")
     json.dump(summ, open(os.path.join(ROOT, "profiles", "pmc_summary.json"), "w"), indent=1)
     shutil.copy(os.path.join(ROOT, "profiles", "pmc_summary.json"), os.path.join(ROOT, "profiles", f"{pre}_pmc_summary.json"))
     bdir = sys.argv[3] if len(sys.argv) > 3 else None
