@@ -612,7 +612,11 @@ def main():
                        "nodes_per_tree": 20, "operators": "+ - / * cos exp", "sharding": f"tree-sharded x{world}", "flag_gather": gather_via,
                        "complete_fraction": float(flags.float().mean().item()),
                        "early_exit": "EvalContext.early_exit = true (the reference's default): a tree is not evaluated by workgroups that start "
-                                     "after its flag went to 0 (include/de_hip.h DE_OPT_EARLY_EXIT; `full_evaluation` = the same steps with DE_OPT_FULL_EVAL)"},
+                                     "after its flag went to 0 (include/de_hip.h DE_OPT_EARLY_EXIT; `full_evaluation` = the same steps with DE_OPT_FULL_EVAL)",
+                       "priority_tiles": ("every step first reads X once (de_tile_extremes_kernel, inside the timed region and inside roofline.kernel_ms_avg) and runs the "
+                                          "3 F sample tiles holding each feature's largest, smallest and closest-to-zero value first: order only (DESIGN.md 4.0)"
+                                          if (N + 255) // 256 >= int(os.environ.get("DE_PRIO_MIN_TILES", "2048")) and len(trees) >= int(os.environ.get("DE_PRIO_MIN_TREES", "96"))
+                                          and os.environ.get("DE_NO_PRIO_TILES", "0") != "1" else "off for this launch size")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": ctx.last_kernel_name(), "kernel_ms_avg": k_avg_ms,
