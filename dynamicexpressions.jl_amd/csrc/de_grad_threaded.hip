@@ -617,6 +617,18 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStrea
         hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (st != hipSuccess) return st;
     }
+    if (a.n_prio) { // the priority tiles as a launch of their own in front, in short chunks (de_kernels.hip launch_threaded_t: no blind first wave)
+        GArgs<T> pa = a;
+        pa.trees_per_chunk = 4;
+        pa.n_chunks = (int32_t)((bk.n + 3) / 4);
+        pa.n_prio_blocks = (uint32_t)(((int64_t)pa.n_prio * pa.n_chunks + 7) / 8 * 8);
+        hipLaunchKernelGGL(kern, dim3(pa.n_prio_blocks, (unsigned)windows), dim3(GBLK), lds, stream, pa, bk.handler_base, bk.param_handler_off);
+        const hipError_t ps = hipGetLastError();
+        if (ps != hipSuccess) return ps;
+        blocks -= a.n_prio_blocks;
+        a.n_prio = a.n_prio_blocks = 0;
+        a.prio = nullptr;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)windows), dim3(GBLK), lds, stream, a, bk.handler_base, bk.param_handler_off);
     return hipGetLastError(); // the loss reduction passes run once, after the last bucket (de_grad_kernels.hip)
 }

@@ -498,6 +498,18 @@ hipError_t DE_RT_NAME(rev_thr_launch_)(const GradArgs &ga, int group, hipStream_
         hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (st != hipSuccess) return st;
     }
+    if (a.n_prio) { // the priority tiles as a launch of their own in front, in short chunks (de_kernels.hip launch_threaded_t: no blind first wave)
+        GArgs<T> pa = a;
+        pa.trees_per_chunk = 4;
+        pa.n_chunks = (int32_t)((grp.n + 3) / 4);
+        pa.n_prio_blocks = (uint32_t)(((int64_t)pa.n_prio * pa.n_chunks + 7) / 8 * 8);
+        hipLaunchKernelGGL(kern, dim3(pa.n_prio_blocks), dim3(GBLK), lds, stream, pa, ga.rev_handler_base, ga.rev_param_off);
+        const hipError_t ps = hipGetLastError();
+        if (ps != hipSuccess) return ps;
+        blocks -= a.n_prio_blocks;
+        a.n_prio = a.n_prio_blocks = 0;
+        a.prio = nullptr;
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(GBLK), lds, stream, a, ga.rev_handler_base, ga.rev_param_off);
     return hipGetLastError();
 }
