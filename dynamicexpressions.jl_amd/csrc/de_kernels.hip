@@ -1770,8 +1770,9 @@ hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX
 }
 bool prio_tiles_wanted(int64_t N, int F, int64_t n_trees) {
     // the pre-pass costs a read of X; what it saves grows with the trees: at 10^7 samples 32 trees lose 13 %, 64 break even, 125 gain 6 %,
-    // 250+ gain 13 % (tools/exp_prio_trees.py); and it pays from ~5 10^5 samples on (launch_threaded_t)
-    return F >= 1 && F <= DE_PRIO_MAX_F && n_trees >= env_int("DE_PRIO_MIN_TREES", 96) && (N + 255) / 256 >= env_int("DE_PRIO_MIN_TILES", 2048) &&
+    // 250+ gain 13 % (tools/exp_prio_trees.py); with the probe launch it pays from 512 sample tiles on (1000 trees: 256 tiles +8 %, 512 -11 %,
+    // 1024 -10 %, 4096 -13 %; tools/exp_prio_smallN.py)
+    return F >= 1 && F <= DE_PRIO_MAX_F && n_trees >= env_int("DE_PRIO_MIN_TREES", 96) && (N + 255) / 256 >= env_int("DE_PRIO_MIN_TILES", 512) &&
            !env_int("DE_NO_PRIO_TILES", 0);
 }
 
@@ -1818,9 +1819,8 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     if (a.skip_flagged) { const int pr = env_int("DE_SKIP_PROTOCOL", (e.loss && tpc >= 8) ? 1 : 2); a.skip_flagged = pr >= 1 && pr <= 3 ? pr : 2; }
     int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    // priority tiles (de_tile_extremes_kernel): launches over >= 2048 sample tiles with the early exit on; 3 F tiles, run first and once
-    // more in place.  The pre-pass (a memset, one read of X, a dependent launch: 0.11 ms at 10^7 samples) pays from ~5 10^5 samples on
-    // (10^6: -4 .. -7 %, 10^7: -10 %)
+    // priority tiles (de_tile_extremes_kernel): launches over >= 512 sample tiles and >= 96 trees with the early exit on; 3 F tiles, run
+    // first and once more in place.  The pre-pass: a memset, one read of X, a dependent launch (0.11 ms at 10^7 samples)
     a.prio = nullptr;
     a.n_prio_blocks = a.n_prio = 0;
     if (TBLK == 64 && a.skip_flagged && e.prio_keys && a.F >= 1 && prio_tiles_wanted(a.N, a.F, a.n_trees)) {

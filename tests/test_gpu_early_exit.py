@@ -81,7 +81,7 @@ def test_eval_flags_and_complete_rows_do_not_depend_on_the_exit(api, turbo):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_priority_tiles_change_nothing_but_the_order(api, dtype, monkeypatch):
-    """Launches over >= 2048 sample tiles first run the tiles that hold each feature's largest, smallest and closest-to-zero value
+    """Launches over >= 512 sample tiles first run the tiles that hold each feature's largest, smallest and closest-to-zero value
     (csrc/de_kernels.hip de_tile_extremes_kernel: those samples flag most incomplete trees at once).  Forced here on a small launch
     (DE_PRIO_MIN_TILES=1): same flags and the same bits in every complete row as without them and as the evaluate-everything
     mode, for the eval, the fused loss and a parametric population; the tree that fails on ONE sample — the largest x1, placed in the
