@@ -156,6 +156,11 @@ def valu_ceiling(pop, n_trees, units, kernel_ms, turbo=False, complete=None):
     from dynamicexpressions_jl_amd import api
     with open(path) as fh:
         tab = json.load(fh)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_profiles import kernel_source_hash
+    if tab.get("kernel_source_hash") != kernel_source_hash():  # a table of OTHER kernels prices nothing (python tools/valu_slots.py regenerates it, no GPU needed)
+        return dict(stale="profiles/valu_slots.json was generated from other kernel sources than the running library (kernel_source_hash differs): "
+                          "rerun `python tools/valu_slots.py` after the build")
     lib = api.library()
     hist = {}
     n_disp = 0
@@ -286,6 +291,8 @@ def main():
                          "10^7 samples at 1/2/4/8 GPUs), 'weak' = the workload's population PER rank.  auto = strong (C4: its 8-way shards)")
     ap.add_argument("--no-turbo-leg", action="store_true", help="skip the secondary turbo timing (profiling runs: one kernel variant per process)")
     ap.add_argument("--no-full-eval-leg", action="store_true", help="skip the secondary timing without the early exit (DE_OPT_FULL_EVAL)")
+    ap.add_argument("--no-complete-leg", action="store_true",
+                    help="skip the `complete_only` leg: the same generator rejection-sampled to a population of COMPLETE trees (the kernel-quality number)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -541,6 +548,44 @@ def main():
         full_res = dict(ms_per_step=1e3 * el_f / args.steps, kernel_ms=ctx.last_kernel_ms(), flags_equal=bool(torch.equal(ok, ok_main)))
         pop_f.close()
 
+    complete_res = None
+    if not args.no_complete_leg and world == 1 and not (is_param or is_grad or is_lossgrad or is_loss):
+        # COMPLETE TREES ONLY: the same generator (another seed), rejection-sampled on this X to len(trees) trees whose evaluation
+        # comes out complete — nothing exits early, every tree-sample is executed.  This is the number that says what the KERNEL
+        # does per executed tree-sample; the headline beside it also contains the reference's early exit (config.early_exit).
+        cand = de.synth.random_population(3 * len(trees), seed=0xDE0C)
+        chosen = []
+        for b in range(0, len(cand), len(trees)):
+            if len(chosen) >= len(trees):
+                break
+            batch = cand[b:b + len(trees)]
+            pop_b = api.Population(batch, ops, np.float32, n_features=5, eval_context=ec, ctx=ctx)
+            okb = torch.empty(len(batch), device=dev, dtype=torch.uint8)
+            ctx.check(lib.de_eval(ctx._h, pop_b._h, X.data_ptr(), N, 5, None, out.data_ptr(), N, okb.data_ptr()))
+            torch.cuda.synchronize()
+            chosen += [t for t, k in zip(batch, okb.cpu().numpy()) if k]
+            pop_b.close()
+        if len(chosen) >= len(trees):
+            chosen = chosen[:len(trees)]
+            pop_c = api.Population(chosen, ops, np.float32, n_features=5, eval_context=ec, ctx=ctx)
+
+            def step_c():
+                ctx.check(lib.de_eval(ctx._h, pop_c._h, X.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
+            for _ in range(args.warmup):
+                step_c()
+            barrier()
+            t0c = time.perf_counter()
+            kc = []
+            for _ in range(args.steps):
+                step_c()
+                kc.append(ctx.last_kernel_ms() if args.steps <= 64 else None)
+            barrier()
+            el_c = time.perf_counter() - t0c
+            kc = [k for k in kc if k is not None]
+            complete_res = dict(ms_per_step=1e3 * el_c / args.steps, kernel_ms_avg=float(np.mean(kc)) if kc else 1e3 * el_c / args.steps,
+                                complete_fraction=float(ok.float().mean().item()), nodes=sum(de.count_nodes(t) for t in chosen),
+                                candidates=len(cand), pop=pop_c, n=len(chosen))
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_nodes * N * args.steps / elapsed
@@ -613,10 +658,11 @@ def main():
                        "complete_fraction": float(flags.float().mean().item()),
                        "early_exit": "EvalContext.early_exit = true (the reference's default): a tree is not evaluated by workgroups that start "
                                      "after its flag went to 0 (include/de_hip.h DE_OPT_EARLY_EXIT; `full_evaluation` = the same steps with DE_OPT_FULL_EVAL)",
-                       "priority_tiles": ("every step first reads X once (de_tile_extremes_kernel, inside the timed region and inside roofline.kernel_ms_avg) and runs the "
-                                          "3 F sample tiles holding each feature's largest, smallest and closest-to-zero value first: order only (DESIGN.md 4.0)"
-                                          if (N + 255) // 256 >= int(os.environ.get("DE_PRIO_MIN_TILES", "2048")) and len(trees) >= int(os.environ.get("DE_PRIO_MIN_TREES", "96"))
-                                          and os.environ.get("DE_NO_PRIO_TILES", "0") != "1" else "off for this launch size")},
+                       "priority_tiles": ("every step first reads X once (de_tile_extremes_kernel, inside the timed region and inside roofline.kernel_ms_avg), runs the "
+                                          "3 F sample tiles holding each feature's largest, smallest and closest-to-zero value as a probe launch, then re-links the "
+                                          "records of the trees that are still live (de_compact_live_kernel) and runs the launch proper over dense chunks of them: "
+                                          "order only (DESIGN.md 4.0)"
+                                          if lib.de_prio_tiles_wanted(N, 5, len(trees)) else "off for this launch size (the library decides: de_prio_tiles_wanted)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": ctx.last_kernel_name(), "kernel_ms_avg": k_avg_ms,
@@ -644,6 +690,30 @@ def main():
                             "kernel_ms_avg": tk, "roofline_frac": alg_bytes / (tk * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "complete_fraction": turbo_res["complete_fraction"],
                             "valu": valu_ceiling(turbo_res["pop"], len(trees), units_all, tk, turbo=True, complete=okh)}
+        # what the headline `value` contains (VERDICT r3 / ADVICE r3): it counts every tree-sample of the job, as the reference's own
+        # benchmark does for its early-exiting evaluator; `value_executed` counts only the node-evals of the trees that came out complete
+        # (what was certainly executed); `full_evaluation.value` is the rate with the exit switched off; `complete_only` is the kernel on a
+        # population in which nothing exits.
+        nodes_complete = sum(de.count_nodes(t) for t, k in zip(trees, okh) if k) if world == 1 else None
+        if nodes_complete is not None:
+            res["value_executed"] = nodes_complete * N / (ms_per_step * 1e-3)
+            res["value_note"] = ("`value` = node-evals of EVERY tree of the job / time (the metric; includes the reference's early exit: "
+                                 f"{100 * (1 - complete_frac):.1f} % of the trees are incomplete and leave the kernel at their first flagged workgroup); "
+                                 "`value_executed` = node-evals of the complete trees only / the same time; `full_evaluation.value` = no exit; "
+                                 "`complete_only` = a population of complete trees (kernel quality)")
+        if complete_res is not None:
+            ck = complete_res["kernel_ms_avg"]
+            cu = complete_res["n"] * N
+            res["complete_only"] = {"workload": f"{complete_res['n']} COMPLETE trees (same generator, seed 0xDE0C, rejection-sampled from {complete_res['candidates']} "
+                                                f"candidates on this X) x (5 x {N}) Float32: nothing exits early, every tree-sample is executed",
+                                    "ms_per_step": complete_res["ms_per_step"], "kernel_ms_avg": ck,
+                                    "value": complete_res["nodes"] * N / (complete_res["ms_per_step"] * 1e-3),
+                                    "complete_fraction": complete_res["complete_fraction"],
+                                    "us_per_tree_1e7_samples": 1e3 * ck / complete_res["n"] * (1e7 / N),
+                                    "roofline": {"bound": "hbm", "achieved": b_unit * cu / (ck * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                 "frac": b_unit * cu / (ck * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b_unit * cu,
+                                                 "valu": valu_ceiling(complete_res["pop"], complete_res["n"], cu, ck, turbo=bool(args.turbo))}}
+            complete_res["pop"].close()
         if full_res is not None:
             res["full_evaluation"] = {"option": "DE_OPT_FULL_EVAL: no early exit, every tree evaluated on every sample (rounds 1-2 timed this)",
                                       "ms_per_step": full_res["ms_per_step"], "kernel_ms_last": full_res["kernel_ms"],

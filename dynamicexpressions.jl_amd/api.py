@@ -37,6 +37,7 @@ LIB_PATH = os.environ.get("DE_HIP_LIB") or os.path.join(_HERE, "csrc", "libde_hi
 
 DE_F32, DE_F64 = 0, 1
 GRAD_VARIABLE, GRAD_CONSTANT, GRAD_BOTH = 0, 1, 2
+ABI_VERSION = 2  # DE_HIP_ABI_VERSION of include/de_hip.h this module was written for
 OPT_EARLY_EXIT, OPT_FUSE_DEG1, OPT_FUSE_DEG2, OPT_BUMPER_CHECKS, OPT_TURBO, OPT_FULL_EVAL = 1, 2, 4, 8, 16, 32
 
 EXPORTS = [
@@ -45,7 +46,7 @@ EXPORTS = [
     "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create", "de_program_create_cse",
     "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
     "de_program_n_grad", "de_program_dump", "de_program_verify", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad", "de_eval_loss_grad_by_class",
-    "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size", "de_dist_world_size",
+    "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_prio_tiles_wanted", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size", "de_dist_world_size",
     "de_dist_broadcast", "de_dist_gather_flags", "de_dist_last_error", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
 ]
 
@@ -83,6 +84,8 @@ def library() -> C.CDLL:
         raise DeviceError(f"cannot load {LIB_PATH}: {e}") from e
     vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
     lib.de_abi_version.restype = C.c_int
+    if lib.de_abi_version() != ABI_VERSION:  # include/de_hip.h lists what changed between versions
+        raise DeviceError(f"{LIB_PATH} has ABI version {lib.de_abi_version()}, this module was written for {ABI_VERSION}: rebuild (csrc/build.sh)")
     lib.de_opcode_table_version.restype = C.c_int
     lib.de_opcode_by_name.argtypes = [C.c_char_p, C.c_int]
     lib.de_opcode_name.restype = C.c_char_p
@@ -124,6 +127,7 @@ def library() -> C.CDLL:
     lib.de_eval_pullback_dX.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), vp, vp, vp, vp]
     lib.de_eval_tree_array.argtypes = [vp, C.c_int, vp, i64, vp, i64, vp, i32, i64, u32, vp, vp]
     lib.de_eval_plan.argtypes = [vp, i64, vp]
+    lib.de_prio_tiles_wanted.argtypes = [i64, i32, i64]
     lib.de_dist_unique_id.argtypes = [vp]
     lib.de_dist_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     lib.de_dist_destroy.argtypes = [vp]

@@ -102,6 +102,10 @@ struct de_program {
     std::vector<int32_t> bcode_off;     // n_trees + 1
     BoundInstr *d_code = nullptr;
     int32_t *d_code_off = nullptr;
+    // compaction of the live trees (de_kernels.hip de_compact_live_kernel): the second half of the d_code allocation (same 4 GiB window) and
+    // (n_trees + 1) + n_trees + 4 ints; null when the program is not threaded
+    BoundInstr *d_compact_code = nullptr;
+    int32_t *d_compact_ints = nullptr;
     BoundInstr *d_gcode = nullptr;      // bound UNFOLDED program on the device (gradient kernels), lazily uploaded
     int32_t *d_gcode_off = nullptr;
     std::vector<BoundInstr> gbcode;
@@ -548,7 +552,9 @@ static void make_chained(de_program *p) {
         put(p->ccode[h + (size_t)(i1 - i0)], (uint32_t)t, 0u, 0u); // end record (operand word: the tree's index, informational)
         // the record in front of the tree (head record / previous tree's end record) is its HEADER: its immediate = the number of
         // instruction records of the tree, which is what h_tree_skip needs to step over a tree that is not evaluated
-        put(p->ccode[h - 1], t == 0 ? 0u : (uint32_t)(t - 1), (uint32_t)(i1 - i0), 0u);
+        // bit 31 = the tree finishes in an end-fused handler (its last instruction record names the next tree's first handler too):
+        // what de_compact_live_kernel (de_kernels.hip) needs to re-link a tree behind another one
+        put(p->ccode[h - 1], t == 0 ? 0u : (uint32_t)(t - 1), (uint32_t)(i1 - i0) | (ev_ok ? DE_HDR_FUSED_END : 0u), 0u);
         name_next(p->ccode[h + (size_t)(i1 - i0) - 1], p->end_handler);
         prev_fused = ev_ok;
     }
@@ -844,13 +850,15 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
     {
         // the early-exit walk (h_tree_skip) rebuilds record addresses from their low 32 bits: the stream must lie inside one
         // 4 GiB window.  An allocation that straddles a boundary (once in ~10^4 for a 400 KB stream) is set aside and redone.
+        // (a threaded program allocates the stream twice: the second half receives the re-linked stream of the live trees, de_compact_live_kernel)
         void *rejected[4] = {nullptr, nullptr, nullptr, nullptr};
         int n_rej = 0;
         hipError_t ast = hipSuccess;
+        const size_t abytes = p->threaded ? 2 * cbytes : cbytes;
         for (;;) {
-            ast = hipMalloc(reinterpret_cast<void **>(&p->d_code), cbytes);
+            ast = hipMalloc(reinterpret_cast<void **>(&p->d_code), abytes);
             if (ast != hipSuccess) break;
-            const uint64_t a0 = (uint64_t)(uintptr_t)p->d_code, a1 = a0 + cbytes - 1;
+            const uint64_t a0 = (uint64_t)(uintptr_t)p->d_code, a1 = a0 + abytes - 1;
             if ((a0 >> 32) == (a1 >> 32) || n_rej == 4) break;
             rejected[n_rej++] = p->d_code;
             p->d_code = nullptr;
@@ -858,7 +866,15 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         for (int k = 0; k < n_rej; k++) (void)hipFree(rejected[k]);
         if (ast != hipSuccess) return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(ast));
         const uint64_t a0 = (uint64_t)(uintptr_t)p->d_code;
-        if ((a0 >> 32) != ((a0 + cbytes - 1) >> 32)) return fail(ctx, DE_ERR_HIP, "instruction stream straddles a 4 GiB boundary");
+        if ((a0 >> 32) != ((a0 + abytes - 1) >> 32)) return fail(ctx, DE_ERR_HIP, "instruction stream straddles a 4 GiB boundary");
+        if (p->threaded) {
+            p->d_compact_code = p->d_code + cbytes / sizeof(BoundInstr);
+            if (hipMalloc(reinterpret_cast<void **>(&p->d_compact_ints), ((size_t)2 * (size_t)p->n_trees + 5) * sizeof(int32_t)) != hipSuccess) {
+                (void)hipGetLastError();
+                p->d_compact_ints = nullptr; // (the launch proper then walks past flagged trees as in round 3)
+                p->d_compact_code = nullptr;
+            }
+        }
     }
     HIP_TRY(ctx, hipMemset(p->d_code, 0, cbytes));
     hipError_t st = hipMalloc(reinterpret_cast<void **>(&p->d_code_off), p->bcode_off.size() * sizeof(int32_t));
@@ -1020,6 +1036,7 @@ int de_program_destroy(de_program_t *p) {
     (void)hipStreamSynchronize(p->ctx->stream);
     if (p->d_code) (void)hipFree(p->d_code);
     if (p->d_code_off) (void)hipFree(p->d_code_off);
+    if (p->d_compact_ints) (void)hipFree(p->d_compact_ints);
     if (p->aux) de_program_destroy(p->aux);
     if (p->d_gcode) (void)hipFree(p->d_gcode);
     if (p->d_gcode_off) (void)hipFree(p->d_gcode_off);
@@ -1048,6 +1065,8 @@ int64_t de_program_n_grad(const de_program_t *p, int64_t tree, int mode) {
     default: return -1;
     }
 }
+
+int de_prio_tiles_wanted(int64_t N, int32_t n_features, int64_t n_trees) { return prio_tiles_wanted(N, n_features, n_trees) ? 1 : 0; }
 
 int de_eval_plan(const de_program_t *p, int64_t N, int32_t *plan) {
     if (!p || !plan || N < 0) return DE_ERR_INVALID_ARG;
@@ -1120,7 +1139,7 @@ int de_program_verify(const de_program_t *p) {
             }
             { // the header record (in front of the tree) carries the tree's record count: h_tree_skip steps over the tree with it
                 const BoundInstr &hd = p->ccode[(size_t)h - 1];
-                if ((f32 ? hd.arg : hd.lo) != (uint32_t)(i1 - i0)) return bad("tree header does not carry the tree's length", t, 0, f32 ? hd.arg : hd.lo);
+                if (((f32 ? hd.arg : hd.lo) & ~DE_HDR_FUSED_END) != (uint32_t)(i1 - i0)) return bad("tree header does not carry the tree's length", t, 0, f32 ? hd.arg : hd.lo);
             }
             for (int32_t i = i0; i <= i1; i++) {
                 const BoundInstr &r = p->ccode[(size_t)(h + (i - i0))];
@@ -1133,6 +1152,8 @@ int de_program_verify(const de_program_t *p) {
                 const BoundInstr &lastq = p->ccode[(size_t)(h + (i1 - 1 - i0) - 1)];
                 const uint64_t last_addr = f32 ? (((uint64_t)lastq.hi << 32) | lastq.lo) : ((table[0] & 0xFFFFFFFF00000000ull) | lastq.arg);
                 const bool fused_end = ev >= 0 && last_addr == p->endv_handler[ev] && last_addr != last_plain;
+                if (i == i0 && (((f32 ? p->ccode[(size_t)h - 1].arg : p->ccode[(size_t)h - 1].lo) & DE_HDR_FUSED_END) != 0) != fused_end)
+                    return bad("tree header's end-fused bit", t, 0, (uint64_t)fused_end);
                 if (i == i1) {
                     const BoundInstr &e = p->ccode[(size_t)(h + (i1 - i0))]; // the end record itself names the next tree's first handler
                     const uint64_t after = f32 ? (((uint64_t)e.hi << 32) | e.lo) : ((table[0] & 0xFFFFFFFF00000000ull) | e.arg);
@@ -1454,6 +1475,8 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
     a.loss = lr ? &la : nullptr;
     HIP_TRY(c, c->sPrio.reserve((size_t)3 * DE_PRIO_MAX_F * sizeof(unsigned long long)));
     a.prio_keys = c->sPrio.p;
+    a.compact_code = p->d_compact_code;
+    a.compact_ints = p->d_compact_ints;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     HIP_TRY(c, launch_eval(p->dtype, a, c->stream, &c->last_kernel));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -1471,6 +1494,23 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
     if (sOk.staged) HIP_TRY(c, hipMemcpyAsync(ok, sOk.dev, (size_t)p->n_trees, hipMemcpyDeviceToHost, c->stream));
     if (sX.staged || sOut.staged || sOk.staged || sPar.staged || sCls.staged || sY.staged || sW.staged || sLoss.staged)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (sOut.staged && a.skip_flagged) {
+        // host output buffer: the rows of incomplete trees were only partly written on the device, and the staging buffer is shared by
+        // every program of the context — they would carry an earlier call's data.  NaN-fill them (what the callable sugar does anyway,
+        // src/EvaluationHelpers.jl:29-33); the flags come from the caller's host array or, for a device `ok`, from a copy.
+        std::vector<uint8_t> okh;
+        const uint8_t *okp = ok;
+        if (ok_dev) {
+            okh.resize((size_t)p->n_trees);
+            HIP_TRY(c, hipMemcpy(okh.data(), ok, (size_t)p->n_trees, hipMemcpyDeviceToHost));
+            okp = okh.data();
+        }
+        for (int64_t t = 0; t < p->n_trees; t++) {
+            if (okp[t]) continue;
+            if (p->dtype == DE_F32) std::fill_n(static_cast<float *>(out) + (size_t)t * (size_t)ld_out, (size_t)N, std::nanf(""));
+            else std::fill_n(static_cast<double *>(out) + (size_t)t * (size_t)ld_out, (size_t)N, std::nan(""));
+        }
+    }
     return DE_OK;
 }
 

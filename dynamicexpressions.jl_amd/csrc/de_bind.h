@@ -170,6 +170,8 @@ constexpr uint32_t TOPX_ENDV_COUNT = 15;
 // trees): in the table so that the host's address-window checks (32-bit offsets; Float64: one 4 GiB window) cover them too
 constexpr uint32_t TOPX_AUX_BASE = TOPX_ENDV_BASE + TOPX_ENDV_COUNT; // + 0: h_tree_end_slow, + 1: h_tree_skip
 constexpr uint32_t TOPX_TABLE = TOPX_AUX_BASE + 2;
+// chained stream (de_api.cpp make_chained): bit 31 of a tree header's length word = the tree finishes in an end-fused handler
+constexpr uint32_t DE_HDR_FUSED_END = 0x80000000u;
 // end variant of a fused / bound handler id, or -1
 constexpr int topx_endv_of(uint32_t id) {
     return (id >= BOP_BIN_BASE && id < BOP_BIN_END && ((id - BOP_BIN_BASE) & 1)) ? (int)(((id - BOP_BIN_BASE) >> 2) * 2 + (((id - BOP_BIN_BASE) >> 1) & 1))

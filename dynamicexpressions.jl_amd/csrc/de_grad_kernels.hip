@@ -13,6 +13,7 @@
 //   * eval_diff (single direction) performs NO validity test (:99-119).
 // Partial derivatives restate ChainRules' scalar rules (same table as oracle/de_oracle_ops.h).
 #include "de_grad_common.h"
+#include <memory>
 #include <mutex>
 
 namespace de {
@@ -488,11 +489,15 @@ bool grad_threaded_has(int dtype, int GC, int VS) {
 }
 
 hipError_t grad_handler_table(int dtype, int GC, int VS, uint64_t *table) {
-    static uint64_t cache[2][9][3][GOP_MAX];
-    static bool have[2][9][3] = {};
+    struct Cache { uint64_t t[2][9][3][GOP_MAX]; bool have[2][9][3] = {}; };
+    static std::unique_ptr<Cache> caches[DE_MAX_DEVICES]; // per device (de_kernels.hip handler_device_slot)
     static std::mutex mu; // contexts on several host threads may ask at once
-    { const hipError_t dst = handler_device_check(); if (dst != hipSuccess) return dst; }
+    int dev = 0;
+    { const hipError_t dst = handler_device_slot(&dev); if (dst != hipSuccess) return dst; }
     const std::lock_guard<std::mutex> lock(mu);
+    if (!caches[dev]) caches[dev].reset(new Cache());
+    auto &cache = caches[dev]->t;
+    auto &have = caches[dev]->have;
     const int k = dtype == DE_F32 ? 0 : 1;
     if (!grad_threaded_has(dtype, GC, VS)) return hipErrorInvalidValue;
     if (!have[k][GC][VS]) {
@@ -539,11 +544,15 @@ hipError_t rev_thr_fetch_d(uint64_t *host_table);
 hipError_t rev_thr_launch_f(const GradArgs &ga, int group, hipStream_t stream);
 hipError_t rev_thr_launch_d(const GradArgs &ga, int group, hipStream_t stream);
 hipError_t rev_handler_table(int dtype, uint64_t *table) {
-    static uint64_t cache[2][ROP_COUNT];
-    static bool have[2] = {false, false};
+    struct Cache { uint64_t t[2][ROP_COUNT]; bool have[2] = {false, false}; };
+    static std::unique_ptr<Cache> caches[DE_MAX_DEVICES]; // per device
     static std::mutex mu; // contexts on several host threads may ask at once
-    { const hipError_t dst = handler_device_check(); if (dst != hipSuccess) return dst; }
+    int dev = 0;
+    { const hipError_t dst = handler_device_slot(&dev); if (dst != hipSuccess) return dst; }
     const std::lock_guard<std::mutex> lock(mu);
+    if (!caches[dev]) caches[dev].reset(new Cache());
+    auto &cache = caches[dev]->t;
+    auto &have = caches[dev]->have;
     const int k = dtype == DE_F32 ? 0 : 1;
     if (!have[k]) {
         const hipError_t st = k == 0 ? rev_thr_fetch_f(cache[k]) : rev_thr_fetch_d(cache[k]);

@@ -64,6 +64,11 @@ struct EvalArgs {
     bool direct; // feature matrix too wide for the LDS tile: gather features from global memory (flat-switch kernel)
     const LossArgs *loss; // non-null: fused loss instead of the output store (threaded kernel only)
     void *prio_keys;      // device scratch, 3 * DE_PRIO_MAX_F 64-bit keys: the priority tiles of a large early-exit launch (de_kernels.hip de_tile_extremes_kernel); null: none
+    // compaction of the live trees behind the probe launch of the priority tiles (de_kernels.hip de_compact_live_kernel; threaded kernel only):
+    // compact_code = room for a second copy of the chained stream INSIDE the same 4 GiB window as `code`, compact_ints = (n_trees + 1) record
+    // offsets + n_trees tree indices + 4 control words.  Null: the launch proper walks past flagged trees (round 3).
+    void *compact_code;
+    int32_t *compact_ints;
 };
 constexpr int DE_PRIO_MAX_F = 8; // (the pre-pass keeps 6 registers per feature)
 constexpr int DE_PRIO_UNIT = 64;  // samples per unit of the keys' position field (every kernel's tile is a multiple)
@@ -147,9 +152,10 @@ hipError_t launch_by_class_combine(int dtype, const ByClassArgs &a, hipStream_t 
 hipError_t launch_pullback_scale(int dtype, void *grad, const int64_t *grad_off, const int32_t *n_grad, const uint8_t *ok,
                                  const void *dY, int64_t N, int64_t n_trees, int32_t max_grad, hipStream_t stream);
 
-// One device per process owns the cached handler addresses (de_kernels.hip): hipErrorInvalidDevice for any other current device.
-hipError_t handler_device_check();
-// Threaded-code eval kernel: addresses of the TOPX_TABLE device handlers (cached per process).
+// The cached handler addresses are per device (every device loads its own copy of the code object): slot = the current device.
+constexpr int DE_MAX_DEVICES = 64;
+hipError_t handler_device_slot(int *slot);
+// Threaded-code eval kernel: addresses of the TOPX_TABLE device handlers (cached per device).
 hipError_t eval_handler_table(int dtype, bool turbo, uint64_t *table);
 bool eval_uses_threaded();
 

@@ -24,6 +24,7 @@
 //    same XCD, so the tile is fetched from HBM once and re-served by that XCD's L2.
 //  * No MFMA: this is an elementwise map, not a contraction.
 #include <hip/hip_runtime.h>
+#include <memory>
 #include <mutex>
 
 #include <cstdlib>
@@ -68,7 +69,29 @@ template <typename T> struct KArgs {
     // evaluate the trees already known to be incomplete (h_tree_skip); needs trees_per_chunk <= 64
     int32_t skip_flagged;
     uint32_t f_magic; // ceil(2^32 / F) for F > 1 (e / F == umulhi(e, f_magic) while e * F < 2^32), 0 for F == 1
+    // COMPACTED launch (threaded kernel, behind the probe launch of the priority tiles): `code` / `code_off` are the re-linked stream of
+    // the trees whose flag was still 1 after the probe (de_compact_live_kernel), live_idx[k] = the population index of compact tree k (for
+    // its flag byte; the output row comes from the tree's end record) and ctrl = {live trees, chunks, trees per chunk} as the device
+    // planned them — n_trees / n_chunks / trees_per_chunk above are the host's upper bounds (the grid).  Null: a plain launch.
+    const int32_t *live_idx;
+    const int32_t *ctrl;
 };
+
+// Chunk plan of a launch over n trees and n_tiles sample tiles (host: plan_chunks; device: de_compact_live_kernel for the live trees):
+// chunks of <= tpc_max trees, more of them while the grid would not cover the chip `want_blocks` times, never fewer than 8 trees per chunk.
+// nc0 = the chunk count before trees are spread evenly: an upper bound of the final count that is monotone in n.
+__host__ __device__ inline void chunk_plan(int64_t n, int64_t n_tiles, int64_t tpc_max, int64_t want_blocks, int32_t *n_chunks_out, int32_t *tpc_out, int32_t *nc0_out) {
+    if (tpc_max < 1) tpc_max = 64;
+    int64_t n_chunks = (n + tpc_max - 1) / tpc_max;
+    if (n_tiles > 0 && n_tiles * n_chunks < want_blocks) n_chunks = (want_blocks + n_tiles - 1) / n_tiles;
+    const int64_t max_chunks = (n + 7) / 8; // >= 8 trees per chunk
+    if (n_chunks > max_chunks) n_chunks = max_chunks;
+    if (n_chunks < 1) n_chunks = 1;
+    if (nc0_out) *nc0_out = (int32_t)n_chunks;
+    const int64_t tpc = n > 0 ? (n + n_chunks - 1) / n_chunks : 1;
+    *tpc_out = (int32_t)tpc;
+    *n_chunks_out = (int32_t)(n > 0 ? (n + tpc - 1) / tpc : 0);
+}
 
 // A thread owns G groups of VW consecutive samples (VW*sizeof(T) = 16 bytes, one
 // ds_read_b128 / global_store_dwordx4 per group): samples base + g*(BLOCK*VW) + tid*VW + i.
@@ -556,7 +579,7 @@ template <typename T> using BodyFn = HState<T> (*)(HState<T>, uint32_t, typename
 // ... and, in VECTOR registers, this thread's residual targets and weights of the fused loss (ly, lw: 8 registers every handler passes
 // on untouched, undefined outside a fused-loss launch): the end of a tree forms its loss partial from them (h_tree_end_slow, HF_LOSS).
 #define HL_T typename VecOf<T>::type
-template <typename T> using HandlerFn = HState<T> (*)(HState<T>, HL_T, HL_T, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t, uint32_t);
+template <typename T> using HandlerFn = HState<T> (*)(HState<T>, HL_T, HL_T, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t);
 enum : uint32_t { HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu,
                   HF_SLOW = HF_SLOW_STORE | HF_NO_STORE | (1u << 27), // any of them (and HF_LOSS): the out-of-line end of a tree
                   // plain flag stores (through the caches): always, except under flag protocol 1 (agent scope for every access, an
@@ -576,8 +599,8 @@ template <> __device__ __forceinline__ uint64_t arg_imm<double>(uint32_t, uint64
 #define DE_SKIPLIST_BYTES 256u // LDS bytes in front of row 0: the live trees of the running (sub-)chunk (h_tree_skip), 64 x 4 bytes
 #define DE_ROW_BYTES_C ((DE_TBLK + 1) * 16) // LDS row stride of the threaded kernel: DE_TBLK 16-byte vectors + one of padding
 // `code` points at the record of the NEXT instruction; (la, w1, w23) are this instruction's record
-#define HCHAIN_ARGS HState<T> st, HL_T ly, HL_T lw, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint64_t skip, uint32_t left, uint32_t flags, uint32_t tree
-#define HCHAIN_NEXT_AT(W, NEXT) [[clang::musttail]] return arg_next<T>(w1, w23)(st, ly, lw, lds0, NEXT, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags, tree)
+#define HCHAIN_ARGS HState<T> st, HL_T ly, HL_T lw, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint64_t skip, uint32_t left, uint32_t flags
+#define HCHAIN_NEXT_AT(W, NEXT) [[clang::musttail]] return arg_next<T>(w1, w23)(st, ly, lw, lds0, NEXT, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
 #define HCHAIN_NEXT(W) HCHAIN_NEXT_AT(W, code + 1)
 template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain(HCHAIN_ARGS) {
     const U32x4 w = *code;
@@ -619,23 +642,22 @@ __device__ __forceinline__ bool poison_set(const double &p) { return p != p; }
 // the next live tree from what it carries anyway: r = (trees left after it) - (skip bits set after it).
 // (Round 3's first version followed the headers tree by tree — a dependent scalar-cache round trip per skipped tree, 64 SIMD
 // cycles per skipped tree and wavefront, 0.65 ms of the 7.9 ms headline; tools/exp_skip_cost.py.)
-template <typename T> __device__ __forceinline__ uint32_t hdr_len(const U32x4 &h) { return sizeof(T) == 4 ? h.y : h.z; } // the immediate's (low) word: records of the tree (de_program_verify)
-template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS) { // bit 0 of `skip` = tree `tree`, which is skipped
+template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS) { // bit 0 of `skip` = the next tree of the stream, which is skipped
     const uint32_t n = (uint32_t)__builtin_ctzll(~skip); // the run of skipped trees (>= 1; bits beyond the chunk are 0)
     if (n >= left) return st;
     skip >>= n;
     left -= n;
-    tree += n;
     const uint32_t r = left - 1u - (uint32_t)__builtin_popcountll(skip >> 1); // live trees after the one the chain goes on with
     const uint32_t lo = *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(r * 4u)); // (wave-uniform address)
     const uint64_t hdr = ((uint64_t)(uintptr_t)code & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
     const ConstU4Ptr nh = (ConstU4Ptr)(uintptr_t)hdr; // the tree's header record (the record in front of its first instruction)
     const U32x4 hn = nh[0], w = nh[1];
-    [[clang::musttail]] return arg_next<T>(hn.y, ((uint64_t)hn.w << 32) | hn.z)(st, ly, lw, lds0, nh + 2, outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, skip, left, flags,
-                                                                             tree);
+    [[clang::musttail]] return arg_next<T>(hn.y, ((uint64_t)hn.w << 32) | hn.z)(st, ly, lw, lds0, nh + 2, outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, skip, left, flags);
 }
 // the rest of a tree's end: flag byte, last tree of the chunk?, clear the state, on to the next tree (W = its first record,
-// HDR = the address of its header record) unless that one is skipped
+// HDR = the address of its header record) unless that one is skipped.  `tree` (a local of the caller) = the tree's index, the
+// operand word of its END RECORD — not a counter the chain carries: the trees of a chunk need not be consecutive trees of the
+// population (the live trees of a compacted launch: de_compact_live_kernel)
 #define HTREE_END_TAIL(REC, NEXT, HDR)                                                                       \
     if (__builtin_expect(__ballot(poison_set(st.poison)) != 0ull, 0)) { /* every lane the same byte */         \
         if (flags & HF_PLAIN_FLAG) *reinterpret_cast<__attribute__((address_space(1))) uint8_t *>(okp + tree) = 0; \
@@ -645,18 +667,18 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS)
     /* (the accumulator is left as it is: no tree starts by reading it — de_bind.h top_reads_acc, checked by de_program_verify) */ \
     st.poison = typename PoisonOf<T>::type{};                                                                \
     left -= 1u;                                                                                              \
-    tree += 1u;                                                                                              \
     skip >>= 1;                                                                                              \
     if (__builtin_expect((skip & 1ull) != 0ull, 0))                                                          \
-        [[clang::musttail]] return h_tree_skip<T>(st, ly, lw, lds0, HDR, outp, la, w1, w23, okp, ldo, skip, left, flags, tree); \
+        [[clang::musttail]] return h_tree_skip<T>(st, ly, lw, lds0, HDR, outp, la, w1, w23, okp, ldo, skip, left, flags); \
     HCHAIN_NEXT_AT(REC, NEXT)
 typedef __attribute__((address_space(1))) char *GPtr; // global, not flat: a flat store also ties up lgkmcnt
 // The other ends of a tree (flags & HF_SLOW), out of line so that h_tree_end itself is straight-line code: HF_LOSS (fused loss:
 // the tree's loss partial of this tile), HF_SLOW_STORE (ragged last tile / output rows that are not 16-byte aligned; LDS base = 0:
 // lds0 = DE_SKIPLIST_BYTES + 16 * thread), HF_NO_STORE (DE_DEBUG_NO_STORE, measurement only: keep the value alive, write nothing).
-template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_ARGS) {
+template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_ARGS) { // la = the tree's index (both callers)
     constexpr int VW = VecOf<T>::W;
     const U32x4 w = *code;
+    const uint32_t tree = la;
     const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);
     if (flags & HF_LOSS) {
         // sum_j w_j * l(out_j - y_j) over this wave's 64 * VW samples -> one partial per (tile, tree, wave): outp = &partial[tile, 0, wave],
@@ -683,8 +705,9 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_A
 }
 template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) {
     typedef typename VecOf<T>::type V;
-    if (__builtin_expect((flags & HF_SLOW) != 0u, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, ly, lw, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags, tree);
+    if (__builtin_expect((flags & HF_SLOW) != 0u, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, ly, lw, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags);
     const U32x4 w = *code;
+    const uint32_t tree = la; // this IS the end record
     const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo); // wave-uniform: the store takes it as its scalar base
     *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0) = st.acc; // full tile, aligned rows
     HTREE_END_TAIL(w, code + 1, code - 1);
@@ -695,9 +718,10 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) 
 // handler, as the end record does.
 template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain_end(HCHAIN_ARGS) {
     typedef typename VecOf<T>::type V;
+    const uint32_t tree = *reinterpret_cast<const DE_CONSTANT uint32_t *>(code); // the end record this handler steps over: its operand word
     if (__builtin_expect((flags & HF_SLOW) != 0u, 0)) {
         st = BODY(st, lds0 + la, arg_imm<T>(w1, w23));
-        [[clang::musttail]] return h_tree_end_slow<T>(st, ly, lw, lds0, code + 1, outp, la, w1, w23, okp, ldo, skip, left, flags, tree);
+        [[clang::musttail]] return h_tree_end_slow<T>(st, ly, lw, lds0, code + 1, outp, tree, w1, w23, okp, ldo, skip, left, flags);
     }
     const U32x4 w = code[1];
     st = BODY(st, lds0 + la, arg_imm<T>(w1, w23));
@@ -795,7 +819,7 @@ __device__ __forceinline__ VecOf<float>::type div_safe_by_const(VecOf<float>::ty
 }
 // the divisions of the fast handlers whose operand `b` is the constant `cbits` (K = 4: x / c, 5: c / x): range test, quotient
 template <int K> __device__ __forceinline__ bool div_const_unsafe(VecOf<float>::type x, uint32_t cbits) {
-    return (__ballot(!div_samples_safe(x)) != 0ull) | !div_const_in_range(cbits);
+    return (int)(__ballot(!div_samples_safe(x)) != 0ull) | (int)!div_const_in_range(cbits);
 }
 template <int K> __device__ __forceinline__ VecOf<float>::type div_const(VecOf<float>::type x, uint32_t cbits) {
     const float c = __builtin_bit_cast(float, cbits);
@@ -999,14 +1023,15 @@ template <int K, bool TB> __device__ __forceinline__ VecOf<float>::type un_finis
     }
 }
 #define HFAST_ARGS HState<float> st, VecOf<float>::type ly, VecOf<float>::type lw, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, \
-                   uint64_t skip, uint32_t left, uint32_t flags, uint32_t tree
-#define HFAST_PASS st, ly, lw, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags, tree
-#define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, ly, lw, lds0, code + 1, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags, tree)
+                   uint64_t skip, uint32_t left, uint32_t flags
+#define HFAST_PASS st, ly, lw, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags
+#define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, ly, lw, lds0, code + 1, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
 // the end of a tree behind a fast-path body: what h_chain_end does (T = float)
 #define HFAST_END_TAIL()                                                                                                    \
     {                                                                                                                       \
         typedef float T;                                                                                                    \
         const U32x4 wn = code[1];                                                                                           \
+        const uint32_t tree = *reinterpret_cast<const DE_CONSTANT uint32_t *>(code); /* the end record's operand word */      \
         const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);                                               \
         *reinterpret_cast<__attribute__((address_space(1))) VecOf<float>::type *>(row + lds0) = st.acc;                     \
         HTREE_END_TAIL(wn, code + 2, code);                                                                                     \
@@ -1351,6 +1376,77 @@ __global__ void __launch_bounds__(256) de_tile_extremes_kernel(const T *__restri
     }
 }
 
+// COMPACTION OF THE LIVE TREES (round 4).  After the probe launch of the priority tiles most incomplete trees are flagged (534 of 557 on
+// the benchmark's data), but they stay where they are in the population: a 64-tree chunk of the launch proper holds ~28 live trees, so the
+// launch runs 2.3 x the workgroups for the same live work, each staging X for fewer trees and walking ~15 runs of skipped trees (0.45 ms of
+// the 6.7 ms headline).  This kernel — one workgroup between the probe and the launch proper — RE-LINKS the chained stream:
+// the records of every tree whose flag is still 1 are copied, in population order, into a second stream in which the live trees follow
+// each other (a tree's end record — and its last instruction's record when that one is end-fused, the header's DE_HDR_FUSED_END bit —
+// names the first handler of the next LIVE tree, which is what the header record of that tree names in the original stream).  Records are
+// position-independent otherwise; the tree's index travels in its end record.  The launch proper then runs dense chunks over the compact
+// stream (trees flagged later still drop out through the skip mask).  Order only: which trees run where — flags and complete rows cannot
+// change (tests/test_gpu_early_exit.py).  ctrl = {n_live, n_chunks, trees per chunk, 0}.
+template <bool F32>
+__global__ void __launch_bounds__(1024) de_compact_live_kernel(const U32x4 *__restrict__ code, const int32_t *__restrict__ code_off, const uint8_t *__restrict__ ok,
+                                                              int32_t n_trees, U32x4 *__restrict__ ccode, int32_t *__restrict__ coff, int32_t *__restrict__ live_idx,
+                                                              int32_t *__restrict__ ctrl, int64_t n_tiles, int64_t want_blocks, int32_t tpc_max) {
+    __shared__ int32_t wsum[2][16];
+    __shared__ int32_t run[2]; // live trees / records placed so far
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { run[0] = 0; run[1] = 1; } // record 0 of the compact stream = the head record
+    __syncthreads();
+    for (int32_t b = 0; b < n_trees; b += 1024) {
+        const int32_t t = b + tid;
+        const bool live = t < n_trees && ok[t] != 0;
+        const int32_t len = live ? code_off[t + 1] - code_off[t] : 0; // instruction records + the end record
+        int32_t s0 = live ? 1 : 0, s1 = len;
+        DE_UNROLL for (int d = 1; d < 64; d <<= 1) { // inclusive scan inside the wave
+            const int32_t u0 = __shfl_up(s0, d, 64), u1 = __shfl_up(s1, d, 64);
+            if (lane >= d) { s0 += u0; s1 += u1; }
+        }
+        if (lane == 63) { wsum[0][wv] = s0; wsum[1][wv] = s1; }
+        __syncthreads();
+        int32_t o0 = run[0], o1 = run[1];
+        for (int w = 0; w < wv; w++) { o0 += wsum[0][w]; o1 += wsum[1][w]; }
+        if (live) {
+            live_idx[o0 + s0 - 1] = t;
+            coff[o0 + s0 - 1] = o1 + s1 - len;
+        }
+        __syncthreads();
+        if (tid == 1023) { run[0] = o0 + s0; run[1] = o1 + s1; }
+        __syncthreads();
+    }
+    const int32_t n_live = run[0];
+    if (tid == 0) {
+        coff[n_live] = run[1];
+        int32_t nc = 0, tpc = 1;
+        chunk_plan(n_live, n_tiles, tpc_max, want_blocks, &nc, &tpc, nullptr);
+        ctrl[0] = n_live;
+        ctrl[1] = nc;
+        ctrl[2] = tpc;
+        ctrl[3] = 0;
+    }
+    // (live_idx / coff were written by this workgroup: visible to it behind the barriers above)
+    for (int32_t k = tid; k < n_live; k += 1024) {
+        const int32_t t = live_idx[k], tn = k + 1 < n_live ? live_idx[k + 1] : -1;
+        const int32_t src = code_off[t], len = code_off[t + 1] - src, dst = coff[k];
+        const U32x4 hdr = code[src - 1]; // this tree's header: length word (F32: .y, F64: .z) | DE_HDR_FUSED_END
+        if (k == 0) ccode[0] = hdr;      // the head record names the first live tree's first handler
+        for (int32_t i = 0; i < len; i++) ccode[dst + i] = code[src + i];
+        if (tn >= 0) {
+            const U32x4 hn = code[code_off[tn] - 1]; // names the next live tree's first handler (and carries its length word)
+            U32x4 e = code[src + len - 1];
+            e.y = hn.y; e.z = hn.z; e.w = hn.w;       // the operand word stays: this tree's index
+            ccode[dst + len - 1] = e;
+            if (((F32 ? hdr.y : hdr.z) & DE_HDR_FUSED_END) && len >= 2) { // the end-fused last instruction names it too
+                U32x4 q = code[src + len - 2];
+                if (F32) { q.z = hn.z; q.w = hn.w; } else q.y = hn.y;
+                ccode[dst + len - 2] = q;
+            }
+        }
+    }
+}
+
 template <typename T, bool PARAMS, bool LOSS = false>
 __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T> a) {
     typedef typename VecOf<T>::type V;
@@ -1362,6 +1458,15 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
 
     TileMap tm;
     int flag_protocol = a.skip_flagged;
+    // a compacted launch (de_compact_live_kernel): the trees, chunks and trees per chunk the device planned for the live trees
+    int32_t n_trees = a.n_trees, n_chunks = a.n_chunks, tpc = a.trees_per_chunk;
+    if (a.ctrl) {
+        const ConstI32Ptr ct = (ConstI32Ptr)(uintptr_t)a.ctrl;
+        n_trees = ct[0];
+        n_chunks = ct[1];
+        tpc = ct[2];
+        if (n_trees <= 0) return;
+    }
     if (blockIdx.x < a.n_prio_blocks) { // a priority tile (see de_tile_extremes_kernel): its flags go straight to memory and come from there
         const uint32_t k = blockIdx.x / (uint32_t)a.n_chunks;
         if (k >= a.n_prio) return;
@@ -1369,18 +1474,18 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         tm.chunk = (int32_t)(blockIdx.x % (uint32_t)a.n_chunks);
         tm.valid = tm.tile < a.n_tiles;
         flag_protocol = 1;
-    } else tm = map_block(blockIdx.x - a.n_prio_blocks, a.n_chunks, a.n_tiles);
+    } else tm = map_block(blockIdx.x - a.n_prio_blocks, n_chunks, a.n_tiles);
     if (!tm.valid) return;
     const int tid = threadIdx.x;
     const int64_t base = tm.tile * TILE;
     const int64_t last = a.N - 1;
-    const int tA = tm.chunk * a.trees_per_chunk; // this workgroup's trees: [tA, tB)
-    const int tB = (tA + a.trees_per_chunk < a.n_trees) ? tA + a.trees_per_chunk : a.n_trees;
+    const int tA = tm.chunk * tpc; // this workgroup's trees: [tA, tB) (of the compact stream in a compacted launch)
+    const int tB = (tA + tpc < n_trees) ? tA + tpc : n_trees;
     // early exit: the flags of the first <= 64 trees, requested before the X tile so that the two latencies overlap
     // (wave 0 reads them for the whole workgroup: two waves reading at different moments could see different flags, and the
     // workgroup shares ONE live-tree list)
     uint8_t f_first = 1;
-    if (a.skip_flagged && tid < 64 && tA + tid < tB) f_first = skip_flag_load(a.ok + tA + tid, flag_protocol, tm.tile);
+    if (a.skip_flagged && tid < 64 && tA + tid < tB) f_first = skip_flag_load(a.ok + (a.live_idx ? a.live_idx[tA + tid] : tA + tid), flag_protocol, tm.tile);
     // the 64-bit skip mask travels from wave 0 to the others through the padding vector of LDS row 0 (16 unused bytes behind the
     // DE_TBLK vectors of every row)
     uint64_t *const mask_slot = reinterpret_cast<uint64_t *>(smem_raw + (size_t)DE_TBLK * 16);
@@ -1493,7 +1598,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             __syncthreads();
             if (tid < 64) {
                 const int i = t0 + tid;
-                const uint8_t f = i >= t1 ? (uint8_t)1 : skip_flag_load(a.ok + i, flag_protocol, tm.tile);
+                const uint8_t f = i >= t1 ? (uint8_t)1 : skip_flag_load(a.ok + (a.live_idx ? a.live_idx[i] : i), flag_protocol, tm.tile);
                 const uint64_t m0 = __ballot(f == 0);
                 if (tid == 0) *mask_slot = m0;
             }
@@ -1542,7 +1647,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         }
         const U32x4 hp = rec[-1], hd = *rec; // the first handler's address is in the record in front (the previous tree's end record / the head record)
         st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, yv, wv, lds0, rec + 1, outp, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, (uint64_t)(uintptr_t)a.ok,
-                                                              ldo_arg, skip, (uint32_t)(t1 - first), flags, (uint32_t)first);
+                                                              ldo_arg, skip, (uint32_t)(t1 - first), flags);
         (void)st;
     }
     } // sub-chunks
@@ -1619,17 +1724,10 @@ static int cu_count() {
 // Tree chunking: chunks of ~64 trees keep workgroups short (fine-grained tail) while the
 // X-tile staging (one L2 read of the tile per chunk) stays a few percent of the work; with few
 // sample tiles, split further so the grid still covers the chip several times.
-static void plan_chunks(int64_t n_trees, int64_t n_tiles, int32_t *n_chunks_out, int32_t *tpc_out) {
+static void plan_chunks(int64_t n_trees, int64_t n_tiles, int32_t *n_chunks_out, int32_t *tpc_out, int32_t *nc0_out = nullptr) {
     const int64_t tpc_env = env_int("DE_EVAL_TPC", 64); // trees per chunk (experiments: X staging per tree against the tail of a short launch)
-    int64_t n_chunks = (n_trees + tpc_env - 1) / (tpc_env > 0 ? tpc_env : 64);
-    const int64_t want_blocks = (int64_t)cu_count() * 4 * 8;
-    if (n_tiles * n_chunks < want_blocks) n_chunks = (want_blocks + n_tiles - 1) / n_tiles;
-    const int64_t max_chunks = (n_trees + 7) / 8; // >= 8 trees per chunk
-    if (n_chunks > max_chunks) n_chunks = max_chunks;
-    if (n_chunks < 1) n_chunks = 1;
-    const int64_t tpc = (n_trees + n_chunks - 1) / n_chunks;
-    *tpc_out = (int32_t)tpc;
-    *n_chunks_out = (int32_t)((n_trees + tpc - 1) / tpc);
+    chunk_plan(n_trees, n_tiles, tpc_env, (int64_t)cu_count() * 4 * 8, n_chunks_out, tpc_out, nc0_out);
+    if (*n_chunks_out < 1) *n_chunks_out = 1;
 }
 
 void eval_plan(int dtype, int64_t n_trees, int64_t N, int32_t *tile, int32_t *n_chunks, int32_t *trees_per_chunk) {
@@ -1718,34 +1816,35 @@ template <typename T, bool TB> static hipError_t fetch_handlers(uint64_t *host_t
     return st;
 }
 
-// Handler addresses are cached per PROCESS and baked into every record of the instruction streams, so they belong to one
-// device's copy of the code object: the library serves one device per process (the deployment model: one process per GPU,
-// INTEGRATION.md).  The first device that asks owns the caches; a context on another device is refused here, explicitly, instead
-// of jumping to addresses of the other device's code object.
-hipError_t handler_device_check() {
-    static int owner = -1;
-    static std::mutex mu;
+// Handler addresses are baked into every record of the instruction streams and belong to ONE device's copy of the code object
+// (every device loads its own): the caches of the three handler tables (eval here, gradient and reverse in de_grad_kernels.hip) are
+// keyed by the CURRENT device — the device of the context that creates the program (de_api.cpp sets it before it asks).  A process may
+// therefore hold contexts on several GPUs (round 3 refused every device but the first: ADVICE r3).
+hipError_t handler_device_slot(int *slot) {
     int dev = 0;
-    hipError_t st = hipGetDevice(&dev);
+    const hipError_t st = hipGetDevice(&dev);
     if (st != hipSuccess) return st;
-    const std::lock_guard<std::mutex> lock(mu);
-    if (owner < 0) owner = dev;
-    return owner == dev ? hipSuccess : hipErrorInvalidDevice;
+    if (dev < 0 || dev >= DE_MAX_DEVICES) return hipErrorInvalidDevice;
+    *slot = dev;
+    return hipSuccess;
 }
 
 hipError_t eval_handler_table(int dtype, bool turbo, uint64_t *table) {
-    static uint64_t cache[3][TOPX_TABLE]; // Float32, Float64, Float32 turbo (Float64 has no relaxed operators)
-    static bool have[3] = {false, false, false};
+    struct Cache { uint64_t t[3][TOPX_TABLE]; bool have[3] = {false, false, false}; }; // Float32, Float64, Float32 turbo (Float64 has no relaxed operators)
+    static std::unique_ptr<Cache> caches[DE_MAX_DEVICES];
     static std::mutex mu; // contexts on several host threads may ask at once
-    { const hipError_t dst = handler_device_check(); if (dst != hipSuccess) return dst; }
+    int dev = 0;
+    { const hipError_t dst = handler_device_slot(&dev); if (dst != hipSuccess) return dst; }
     const std::lock_guard<std::mutex> lock(mu);
+    if (!caches[dev]) caches[dev].reset(new Cache());
+    Cache &c = *caches[dev];
     const int k = dtype == DE_F32 ? (turbo ? 2 : 0) : 1;
-    if (!have[k]) {
-        hipError_t st = k == 0 ? fetch_handlers<float, false>(cache[k]) : (k == 2 ? fetch_handlers<float, true>(cache[k]) : fetch_handlers<double, false>(cache[k]));
+    if (!c.have[k]) {
+        hipError_t st = k == 0 ? fetch_handlers<float, false>(c.t[k]) : (k == 2 ? fetch_handlers<float, true>(c.t[k]) : fetch_handlers<double, false>(c.t[k]));
         if (st != hipSuccess) return st;
-        have[k] = true;
+        c.have[k] = true;
     }
-    for (int i = 0; i < (int)TOPX_TABLE; i++) table[i] = cache[k][i];
+    for (int i = 0; i < (int)TOPX_TABLE; i++) table[i] = c.t[k][i];
     return hipSuccess;
 }
 
@@ -1807,10 +1906,11 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.f_magic = e.F > 1 ? (uint32_t)((0x100000000ull + (uint64_t)e.F - 1) / (uint64_t)e.F) : 0u;
     if (!env_int("DE_X_VEC", 1)) { a.x_vec = 0; a.f_magic = 0; } // scalar staging loop (A/B and the test of the vector path)
     if (env_int("DE_DEBUG_NO_STORE", 0)) a.vec_store = 2;
-    int32_t tpc, nch;
-    plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc);
+    int32_t tpc, nch, nc0;
+    plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc, &nc0);
     a.trees_per_chunk = tpc;
     a.n_chunks = nch;
+    a.live_idx = a.ctrl = nullptr;
     a.skip_flagged = (e.early_exit && e.skip_flagged && a.F + a.n_slots >= 1) ? 1 : 0;
     // Flag protocol (skip_flag_load, de_device_ops.h): 2 = through the caches + refresher tiles (default), 1 = agent scope for every access
     // The plain eval kernel writes 20+ GB per launch: flag lines leave the L1s / L2s all the time and protocol 2 is as good as 1 on the
@@ -1862,6 +1962,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         // launch proper starts, the flags are down for its very first workgroups too (no blind first wave: 9 % of the tiles at 10^6 samples)
         KArgs<T> pa = a;
         pa.trees_per_chunk = env_int("DE_PRIO_PROBE_TPC", 8);
+        pa.trees_per_chunk = pa.trees_per_chunk < 1 ? 1 : (pa.trees_per_chunk > 64 ? 64 : pa.trees_per_chunk); // (a divisor, and the skip mask has 64 bits)
         pa.n_chunks = (a.n_trees + pa.trees_per_chunk - 1) / pa.trees_per_chunk;
         pa.n_prio_blocks = (uint32_t)(((int64_t)pa.n_prio * pa.n_chunks + 7) / 8 * 8);
         hipLaunchKernelGGL(kern, dim3(pa.n_prio_blocks), dim3(TBLK), lds, stream, pa);
@@ -1870,6 +1971,27 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         blocks -= a.n_prio_blocks;
         a.n_prio_blocks = a.n_prio = 0;
         a.prio = nullptr;
+        // ... and the launch proper runs DENSE chunks over the trees that are still live (de_compact_live_kernel re-links their records
+        // into e.compact_code; chunk plan on the device: the grid below is the host's upper bound, workgroups beyond the device's plan exit)
+        if (e.compact_code && e.compact_ints && tpc <= 64 && env_int("DE_COMPACT", 1)) {
+            int32_t *coff = e.compact_ints, *live_idx = coff + (size_t)e.n_trees + 1, *ctrl = live_idx + e.n_trees;
+            const int64_t want_blocks = (int64_t)cu_count() * 4 * 8;
+            const int32_t tpc_max = env_int("DE_EVAL_TPC", 64);
+            if (sizeof(T) == 4)
+                hipLaunchKernelGGL(de_compact_live_kernel<true>, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const U32x4 *>(e.code), e.code_off, e.ok,
+                                   e.n_trees, reinterpret_cast<U32x4 *>(e.compact_code), coff, live_idx, ctrl, a.n_tiles, want_blocks, tpc_max);
+            else
+                hipLaunchKernelGGL(de_compact_live_kernel<false>, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const U32x4 *>(e.code), e.code_off, e.ok,
+                                   e.n_trees, reinterpret_cast<U32x4 *>(e.compact_code), coff, live_idx, ctrl, a.n_tiles, want_blocks, tpc_max);
+            const hipError_t cs = hipGetLastError();
+            if (cs != hipSuccess) return cs;
+            a.code = static_cast<const BoundInstr *>(e.compact_code);
+            a.code_off = coff;
+            a.live_idx = live_idx;
+            a.ctrl = ctrl;
+            blocks = ((a.n_tiles + 7) / 8) * 8 * (int64_t)nc0;
+            if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+        }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TBLK), lds, stream, a);
     hipError_t st = hipGetLastError();

@@ -32,8 +32,21 @@ const DE_ERR_UNSUPPORTED_OP = Cint(3)
 const DE_LEAF_CONST, DE_LEAF_FEATURE, DE_LEAF_PARAM, DE_LEAF_SHARED = UInt8(0), UInt8(1), UInt8(2), UInt8(3)
 const DE_OP_SHARE = UInt8(0xFE)   # include/de_opcodes.h: "the subtree just emitted is shared subtree `arg`"
 const DE_F32, DE_F64 = Cint(0), Cint(1)
-const DE_OPT_EARLY_EXIT, DE_OPT_FUSE_DEG1, DE_OPT_FUSE_DEG2, DE_OPT_BUMPER_CHECKS, DE_OPT_TURBO =
-    UInt32(1), UInt32(2), UInt32(4), UInt32(8), UInt32(16)
+const DE_OPT_EARLY_EXIT, DE_OPT_FUSE_DEG1, DE_OPT_FUSE_DEG2, DE_OPT_BUMPER_CHECKS, DE_OPT_TURBO, DE_OPT_FULL_EVAL =
+    UInt32(1), UInt32(2), UInt32(4), UInt32(8), UInt32(16), UInt32(32)
+# The ABI this file was written for (include/de_hip.h lists what changed between versions).  Version 2: the rows / gradients of a tree
+# with `complete == false` are NOT evaluated to the end (the reference's early exit, src/Evaluate.jl:26-32): with the host arrays this
+# shim passes, the library NaN-fills them; `full_eval=true` (DE_OPT_FULL_EVAL) evaluates every tree on every sample instead.
+const DE_HIP_ABI_VERSION = Cint(2)
+function __init__()
+    v = try
+        ccall((:de_abi_version, LIBDE), Cint, ())
+    catch
+        return nothing   # library not present: every entry point fails loudly when it is used
+    end
+    v == DE_HIP_ABI_VERSION || error("libde_hip has ABI version $(v), DynamicExpressionsHIPExt was written for $(DE_HIP_ABI_VERSION)")
+    return nothing
+end
 const OPERATOR_LIMIT_BEFORE_SLOWDOWN = 15   # src/Evaluate.jl:14
 dtype_code(::Type{Float32}) = DE_F32
 dtype_code(::Type{Float64}) = DE_F64
@@ -133,7 +146,7 @@ function opcode_table(operators::OperatorEnum)
 end
 
 """EvalContext knobs that change RESULTS -> de_options bits (src/Evaluate.jl:156-181,496,607)."""
-function option_bits(operators::OperatorEnum, ctx::EvalContext)
+function option_bits(operators::OperatorEnum, ctx::EvalContext; full_eval::Bool=false)
     nops(d) = d <= length(operators.ops) ? length(operators.ops[d]) : 0
     fused = ctx.use_fused isa Val{true}
     bits = UInt32(0)
@@ -142,6 +155,7 @@ function option_bits(operators::OperatorEnum, ctx::EvalContext)
     fused && nops(2) <= OPERATOR_LIMIT_BEFORE_SLOWDOWN && (bits |= DE_OPT_FUSE_DEG2)
     ctx.bumper isa Val{true} && (bits |= DE_OPT_BUMPER_CHECKS)
     ctx.turbo isa Val{true} && (bits |= DE_OPT_TURBO)   # the LoopVectorization knob = the relaxed-accuracy device operators
+    full_eval && (bits |= DE_OPT_FULL_EVAL)             # no early exit at tree granularity: rows of incomplete trees are fully evaluated
     return bits
 end
 
@@ -256,6 +270,7 @@ function finalize_context(c::HIPContext)
     end
     return nothing
 end
+# (Several contexts on DIFFERENT devices may live in one process: the library caches its handler tables per device, ABI version 2.)
 function HIPContext(device::Integer=0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:de_ctx_create, LIBDE), Cint, (Cint, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, h)
@@ -284,7 +299,7 @@ Drop-in for `eval_tree_array`'s body: same `(output, complete)` tuple, `cX` is t
 """
 function _hip_eval_tree_array(
     tree::AbstractExpressionNode{T}, cX::AbstractMatrix{T}, operators::OperatorEnum,
-    eval_context::EvalContext,
+    eval_context::EvalContext; full_eval::Bool=false,
 ) where {T<:Union{Float32,Float64}}
     optable = try
         opcode_table(operators)
@@ -304,10 +319,10 @@ function _hip_eval_tree_array(
         (Ptr{Cvoid}, Cint, Ptr{TapeNode}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int32, Int64, UInt32,
          Ptr{Cvoid}, Ref{UInt8}),
         ctx.handle, dtype_code(T), nodes, length(nodes), consts, length(consts), X, F, N,
-        option_bits(operators, eval_context), out, ok)
+        option_bits(operators, eval_context; full_eval), out, ok)
     end
     check(ctx, rc)
-    return (out, ok[] != 0x00)
+    return (out, ok[] != 0x00)   # ok == false: `out` is all NaN unless full_eval (only the flag is contractual, SURVEY.md §8a)
 end
 
 # ---- population form: lower many trees once, evaluate in one launch -------------------------
@@ -334,7 +349,7 @@ function finalize_population(p::HIPPopulation)
 end
 function HIPPopulation(
     trees::AbstractVector{<:AbstractExpressionNode{T}}, operators::OperatorEnum, n_features::Integer;
-    eval_context::EvalContext=EvalContext(), n_params::Integer=0,
+    eval_context::EvalContext=EvalContext(), n_params::Integer=0, full_eval::Bool=false,
 ) where {T<:Union{Float32,Float64}}
     optable = opcode_table(operators)
     nodes, consts, cse = TapeNode[], T[], TapeNode[]
@@ -355,7 +370,7 @@ function HIPPopulation(
         (Ptr{Cvoid}, Cint, Ptr{TapeNode}, Ptr{Int64}, Ptr{TapeNode}, Ptr{Int64}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int32, Int32,
          UInt32, Ref{Ptr{Cvoid}}),
         ctx.handle, dtype_code(T), nodes, node_off, isempty(cse) ? C_NULL : pointer(cse), cse_off, length(trees), consts,
-        const_off, n_features, n_params, option_bits(operators, eval_context), h)
+        const_off, n_features, n_params, option_bits(operators, eval_context; full_eval), h)
     end
     check(ctx, rc)
     pop = HIPPopulation{T}(ctx, h[], length(trees), n_features)
@@ -363,7 +378,9 @@ function HIPPopulation(
     return pop
 end
 
-"""`(out::Matrix{T}(N × n_trees), ok::Vector{Bool})`; column t is `eval_tree_array(trees[t], X)`."""
+"""`(out::Matrix{T}(N × n_trees), ok::Vector{Bool})`; column t is `eval_tree_array(trees[t], X)`.  Columns with `ok[t] == false`
+are NaN (the tree left the kernel at its first flagged workgroup, like the reference's early return) unless the population
+was made with `full_eval=true`."""
 function eval_population(pop::HIPPopulation{T}, X::Matrix{T}) where {T}
     F, N = size(X)
     @assert F >= pop.n_features

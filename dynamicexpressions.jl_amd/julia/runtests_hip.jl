@@ -180,3 +180,28 @@ end
         @test all(k -> agree(view(g, k, :), view(gr, k, :)), axes(g, 1))
     end
 end
+
+@testset "early exit: rows of incomplete trees are NaN, full_eval=true evaluates them (ABI version 2)" begin
+    @test ccall((:de_abi_version, HIP.LIBDE), Cint, ()) == HIP.DE_HIP_ABI_VERSION
+    ops = OperatorEnum(1 => (cos, exp), 2 => (+, -, /, *))
+    x1, x2 = Node{Float32}(; feature=1), Node{Float32}(; feature=2)
+    good = x1 * cos(x2 - 3.2f0)
+    bad = exp(exp(x1 * 40.0f0)) + x2            # overflows on most samples: complete == false
+    X = randn(Float32, 2, 70_001)               # several hundred sample tiles: the exit really happens
+    for full_eval in (false, true)
+        pop = HIP.HIPPopulation([good, bad], ops, 2; full_eval)
+        out, ok = HIP.eval_population(pop, X)
+        yr, okr = eval_tree_array(good, X, ops)
+        @test ok == [true, false] && okr
+        @test agree(view(out, :, 1), yr)        # the complete tree does not depend on the option
+        if full_eval                            # every sample evaluated: the finite samples carry their values
+            yb, _ = eval_tree_array(bad, X, ops; eval_context=EvalContext(; early_exit=false))
+            fin = isfinite.(yb)
+            @test any(fin) && agree(view(out, :, 2)[fin], yb[fin])
+        else                                    # host arrays: the library NaN-fills the rows of incomplete trees
+            @test all(isnan, view(out, :, 2))
+        end
+    end
+    y1, ok1 = HIP._hip_eval_tree_array(bad, X, ops, EvalContext())
+    @test !ok1 && all(isnan, y1)
+end

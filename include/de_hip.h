@@ -55,7 +55,17 @@
 extern "C" {
 #endif
 
-#define DE_HIP_ABI_VERSION 1
+/* ABI history (callers compare de_abi_version() with the version they were written for):
+ *   1  rounds 1-2.
+ *   2  round 3-4.  OBSERVABLE changes against 1, none of them in a signature:
+ *      (a) early exit at tree granularity is the default: the out / grad rows of a tree with ok == 0 are PARTIALLY written
+ *          (device buffers) or NaN-filled (host buffers: the library fills them after the copy) — only the flag is
+ *          contractual, as in the reference; DE_OPT_FULL_EVAL (new option bit 5) restores full rows;
+ *      (b) programs made by de_program_create_cse: the gradient row of a shared constant's FIRST occurrence carries the
+ *          total over its occurrences, the rows of the later occurrences are 0 (callers sum the occurrence rows);
+ *      (c) new exports: de_dist_world_size, de_prio_tiles_wanted;
+ *      (d) a process may hold contexts on several devices (the handler caches are per device). */
+#define DE_HIP_ABI_VERSION 2
 
 typedef enum de_status {
     DE_OK = 0,
@@ -373,6 +383,10 @@ int de_eval_tree_array(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, in
  * plan[1] = tree chunks, plan[2] = trees per chunk (the trees that share one staged X
  * tile: the K_eff of the algorithmic-bytes formula). */
 int de_eval_plan(const de_program_t *prog, int64_t N, int32_t *plan);
+/* 1 when an early-exit launch of n_trees trees over X[n_features, N] first runs the PRIORITY TILES (one pass over X, a probe
+ * launch on the 3 F tiles with the features' extreme values, then the launch proper over the compacted live trees): the
+ * library's own thresholds (sample tiles, trees, features; DE_PRIO_MIN_TILES / DE_PRIO_MIN_TREES / DE_NO_PRIO_TILES). */
+int de_prio_tiles_wanted(int64_t N, int32_t n_features, int64_t n_trees);
 /* Device time of the kernels launched by the most recent de_eval* call on this
  * context, measured with hipEvents recorded on the context's stream.  Blocks
  * until that work has finished. */

@@ -246,3 +246,57 @@ def test_float64_parametric_and_sub_chunks(api, tpc, monkeypatch):
         (of, kf), (oe, ke) = res[True], res[False]
         assert torch.equal(kf, ke) and 0 < int(kf.sum()) < len(trees)
         assert torch.equal(of[kf].view(torch.int64), oe[kf].view(torch.int64))
+
+
+@pytest.mark.parametrize("dtype,turbo", [(np.float32, False), (np.float32, True), (np.float64, False)])
+def test_compaction_of_the_live_trees_changes_nothing_but_the_order(api, dtype, turbo, monkeypatch):
+    """Behind the probe launch of the priority tiles one workgroup re-links the records of the trees whose flag is still 1 into a second
+    stream (csrc/de_kernels.hip de_compact_live_kernel) and the launch proper runs dense chunks over it.  Same flags and the same bits
+    in every complete row as without the compaction (DE_COMPACT=0: the launch proper walks past flagged trees) and as the
+    evaluate-everything mode — eval, fused loss, a parametric population — and a tree the probe launch flags is now left alone on
+    EVERY tile of the launch proper (only the <= 15 priority tiles ever touch its row)."""
+    import torch
+    trees, ops = _population(300, seed=0xEE11)  # 5 chunks of the plain launch, ~2-3 compact ones
+    n = len(trees)
+    N = 2**19 + 131  # 2049 sample tiles: priority tiles by default
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    it = torch.int32 if dtype == np.float32 else torch.int64
+    g = torch.Generator(device="cuda").manual_seed(21)
+    Xd = torch.randn((N, 5), generator=g, device="cuda", dtype=tdt).t()
+    y = torch.randn(N, generator=g, device="cuda", dtype=tdt)
+    par = de.synth.random_population(200, seed=0xEE12, dtype=dtype, node_type=de.ParametricNode, nparams=3)
+    params = torch.randn((4, 3), generator=g, device="cuda", dtype=tdt).t()
+    classes = torch.randint(1, 5, (N,), generator=g, device="cuda", dtype=torch.int32)
+    lib = api.library()
+    res = {}
+    for tag, env, full in (("full", {}, True), ("walk", {"DE_COMPACT": "0"}, False), ("compact", {"DE_COMPACT": "1"}, False)):
+        monkeypatch.delenv("DE_COMPACT", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = api.EvalContext(turbo=turbo, full_eval=full)
+        pop = api.Population(trees, ops, dtype, n_features=5, eval_context=ctx)
+        out = torch.full((n, N), 12345.0, device="cuda", dtype=tdt)
+        ok = torch.empty(n, device="cuda", dtype=torch.uint8)
+        pop.ctx.use_torch_stream()
+        pop.ctx.check(lib.de_eval(pop.ctx._h, pop._h, Xd.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
+        loss, lk = pop.eval_loss(Xd, y)
+        ppop = api.Population(par, ops, dtype, n_features=5, n_params=3, eval_context=ctx)
+        pout, pok = ppop.eval(Xd, params=params, classes=classes)
+        torch.cuda.synchronize()
+        res[tag] = (out, ok.bool(), loss, lk, pout, pok)
+        pop.close()
+        ppop.close()
+    of, kf, lf, lkf, pf, pkf = res["full"]
+    assert 0 < int(kf.sum()) < n and 0 < int(pkf.sum()) < len(par)
+    for tag in ("walk", "compact"):
+        out, k, loss, lk, pout, pok = res[tag]
+        assert torch.equal(k, kf) and torch.equal(lk, lkf) and torch.equal(pok, pkf), tag
+        assert torch.equal(out[kf].view(it), of[kf].view(it)), tag
+        assert int((out[kf] == 12345.0).sum()) == 0, tag
+        assert torch.equal(loss[kf].view(it), lf[kf].view(it)) and bool(torch.isnan(loss[~kf]).all()), tag
+        assert torch.equal(pout[pkf].view(it), pf[pkf].view(it)), tag
+    # 1 / (x2 - x2): flagged by the very first workgroup of the probe launch.  Compacted launch: its row is only ever touched by the
+    # priority tiles (<= 15 x 256 samples); walking launch: the same here (flag known to every workgroup), so equal shares are fine
+    alone = {tag: float((res[tag][0][n - 2] == 12345.0).float().mean()) for tag in ("walk", "compact")}
+    print("row of the tree that fails everywhere, share left alone:", alone)
+    assert alone["compact"] >= 1.0 - 15 * 256 / N - 1e-9, alone

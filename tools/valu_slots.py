@@ -263,7 +263,10 @@ def main():
     a = ap.parse_args()
     slots, counts = table(a.obj, "float" if a.dtype == "f32" else "double")
     turbo = table(a.obj, "float", True)[0] if a.dtype == "f32" else {}
-    doc = dict(source=f"tools/valu_slots.py over {os.path.relpath(a.obj, ROOT)} (llvm-objdump of the gfx950 code object)",
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_profiles import kernel_source_hash
+    doc = dict(kernel_source_hash=kernel_source_hash(),  # bench.py refuses the table when the library was built from other sources
+               source=f"tools/valu_slots.py over {os.path.relpath(a.obj, ROOT)} (llvm-objdump of the gfx950 code object)",
                rule="VALU cycles (wave64 instruction occupancy of a SIMD) on the shortest entry->return path; measured classes: "
                     f"full rate {C_FULL}, half rate / packed / SGPR operand {C_HALF}, transcendental {C_TRANS} (profiles/r2_valu_rate.json)",
                per_tree_overhead_cycles=24.0,  # state zeroing, output address, ballot compare around the chain (~10 instructions)
