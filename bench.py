@@ -206,7 +206,8 @@ def valu_ceiling(pop, n_trees, units, kernel_ms, turbo=False, complete=None):
     disp_floor, per_tree_meas = 30.0, 100.0
     modelled = sum(c * max(tab["handlers_turbo" if turbo else "handlers"][str(k)]["valu_cycles"], disp_floor)
                    for k, c in hist.items() if str(k) in tab["handlers_turbo" if turbo else "handlers"]) / n_trees + per_tree_meas
-    samples_per_wave = 256  # 64 lanes x 4 Float32 samples
+    samples_per_wave = pop.plan(10**6)["tile"]  # 64 lanes x the Float32 samples of a lane (8 with two planes, 4 with one: csrc/de_kernels.h DE_TG)
+    # (the ISA table counts a handler's VALU cycles for ALL planes of a dispatch; per_tree_overhead_cycles likewise)
     tree_waves = units / samples_per_wave
     simds, peak, sustained = 256 * 4, 2.4e9, 2.08e9  # MI355X: 256 CUs x 4 SIMDs; peak engine clock; clock an all-VALU loop sustains
     floor_ms = tree_waves * per_tree_wave / (simds * peak) * 1e3

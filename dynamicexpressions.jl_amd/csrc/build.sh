@@ -5,8 +5,11 @@ set -euo pipefail
 fail=0
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno -Wall -Wno-unused-function"
-mkdir -p _obj
+# variants for A/B runs: DE_EXTRA_FLAGS (every translation unit: e.g. -DDE_TG=1), DE_OBJ_DIR (objects), DE_OUT_LIB (the library)
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-math-errno -Wall -Wno-unused-function ${DE_EXTRA_FLAGS:-}"
+OBJ=${DE_OBJ_DIR:-_obj}
+OUT=${DE_OUT_LIB:-libde_hip.so}
+mkdir -p $OBJ
 build_obj() { # src obj extra...
   local src=$1 obj=$2; shift 2
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ -n "$(find . ../../include -maxdepth 1 \( -name '*.h' \) -newer "$obj" 2>/dev/null | head -1)" ]; then
@@ -15,10 +18,10 @@ build_obj() { # src obj extra...
     $HIPCC $FLAGS "$@" -c "$src" -o "$obj"
   fi
 }
-build_obj de_lower.cpp _obj/de_lower.o &
-build_obj de_api.cpp _obj/de_api.o &
-build_obj de_bind.cpp _obj/de_bind.o &
-build_obj de_dist.cpp _obj/de_dist.o &
+build_obj de_lower.cpp $OBJ/de_lower.o &
+build_obj de_api.cpp $OBJ/de_api.o &
+build_obj de_bind.cpp $OBJ/de_bind.o &
+build_obj de_dist.cpp $OBJ/de_dist.o &
 # de_kernels.hip goes through the same steps hipcc runs internally, with one extra pass over the optimised
 # device IR (irpatch.py: the interpreter's indirect handler calls need none of the implicit kernel inputs).
 # DE_NO_IRPATCH=1 builds it the plain way.
@@ -26,7 +29,7 @@ LLVM=${LLVM:-/opt/rocm/lib/llvm/bin}
 # The IR / object-code passes below are validated against ONE toolchain: refuse any other (DE_ALLOW_TOOLCHAIN=1 overrides; the
 # per-module match counts of csrc/patch_expect/ are then the only guard).  The version in use is recorded next to the objects.
 TOOLCHAIN="$($LLVM/clang --version | head -1)"
-echo "$TOOLCHAIN" > _obj/toolchain.txt
+echo "$TOOLCHAIN" > $OBJ/toolchain.txt
 case "$TOOLCHAIN" in
   *"clang version 22."*"roc-7.2."*) ;;
   *) if [ "${DE_ALLOW_TOOLCHAIN:-0}" != 1 ]; then
@@ -36,7 +39,7 @@ case "$TOOLCHAIN" in
      fi ;;
 esac
 build_kernels() { # src obj [extra flags...]
-  local src=$1 obj=$2 tmp=_obj/irp_$(basename $2 .o); shift 2
+  local src=$1 obj=$2 tmp=$OBJ/irp_$(basename $2 .o); shift 2
   local DE_KERNEL_FLAGS="${DE_KERNEL_FLAGS:-} $*"
   if [ -f "$obj" ] && [ ! "$src" -nt "$obj" ] && [ ! irpatch.py -nt "$obj" ] && [ ! asmpatch.py -nt "$obj" ] && [ -z "$(find . ../../include -maxdepth 1 -name '*.h' -newer "$obj" 2>/dev/null | head -1)" ]; then return 0; fi
   echo "  hipcc $src $* (device IR -> irpatch -> gfx950 code object -> host object)"
@@ -52,25 +55,25 @@ build_kernels() { # src obj [extra flags...]
       -input=/dev/null -input=$tmp/k.out -output=$tmp/k.hipfb
   $HIPCC $FLAGS ${DE_KERNEL_FLAGS:-} --cuda-host-only -Xclang -fcuda-include-gpubinary -Xclang $tmp/k.hipfb -c $src -o $obj
 }
-build_kernels de_kernels.hip _obj/de_kernels.o &
+build_kernels de_kernels.hip $OBJ/de_kernels.o &
 # the threaded gradient kernel: one module per (element type, window width), see de_grad_threaded.hip
 GT_OBJS=""
 for spec in f:float:1:1 f:float:2:1 f:float:3:1 f:float:4:1 f:float:5:1 f:float:6:1 f:float:8:1 \
             f:float:1:2 f:float:2:2 f:float:3:2 f:float:4:2 f:float:5:2 f:float:6:2 \
             d:double:1:1 d:double:2:1 d:double:3:1 d:double:4:1 d:double:5:1; do  # = DE_GT_ALL in de_grad_kernels.hip
   IFS=: read tag ty gc vs <<< "$spec"
-  GT_OBJS="$GT_OBJS _obj/de_gt_$tag${gc}v$vs.o"
+  GT_OBJS="$GT_OBJS $OBJ/de_gt_$tag${gc}v$vs.o"
   while [ "$(jobs -r | wc -l)" -ge "${DE_BUILD_JOBS:-8}" ]; do sleep 0.2; done
-  build_kernels de_grad_threaded.hip _obj/de_gt_$tag${gc}v$vs.o -DDE_GT_T=$ty -DDE_GT_TAG=$tag -DDE_GT_GC=$gc -DDE_GT_VS=$vs &
+  build_kernels de_grad_threaded.hip $OBJ/de_gt_$tag${gc}v$vs.o -DDE_GT_T=$ty -DDE_GT_TAG=$tag -DDE_GT_GC=$gc -DDE_GT_VS=$vs &
 done
 for spec in f:float d:double; do  # the reverse-accumulation kernel: one module per element type
   IFS=: read tag ty <<< "$spec"
-  GT_OBJS="$GT_OBJS _obj/de_rt_$tag.o"
+  GT_OBJS="$GT_OBJS $OBJ/de_rt_$tag.o"
   while [ "$(jobs -r | wc -l)" -ge "${DE_BUILD_JOBS:-8}" ]; do sleep 0.2; done
-  build_kernels de_rev_threaded.hip _obj/de_rt_$tag.o -DDE_RT_T=$ty -DDE_RT_TAG=$tag &
+  build_kernels de_rev_threaded.hip $OBJ/de_rt_$tag.o -DDE_RT_T=$ty -DDE_RT_TAG=$tag &
 done
-build_obj de_grad_kernels.hip _obj/de_grad_kernels.o &
+build_obj de_grad_kernels.hip $OBJ/de_grad_kernels.o &
 wait
-for o in _obj/de_lower.o _obj/de_bind.o _obj/de_dist.o _obj/de_api.o _obj/de_kernels.o _obj/de_grad_kernels.o $GT_OBJS; do [ -f $o ] || { echo "missing $o"; exit 1; }; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libde_hip.so _obj/de_lower.o _obj/de_bind.o _obj/de_dist.o _obj/de_api.o _obj/de_kernels.o _obj/de_grad_kernels.o $GT_OBJS -ldl
-echo "built $(pwd)/libde_hip.so"
+for o in $OBJ/de_lower.o $OBJ/de_bind.o $OBJ/de_dist.o $OBJ/de_api.o $OBJ/de_kernels.o $OBJ/de_grad_kernels.o $GT_OBJS; do [ -f $o ] || { echo "missing $o"; exit 1; }; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/de_lower.o $OBJ/de_bind.o $OBJ/de_dist.o $OBJ/de_api.o $OBJ/de_kernels.o $OBJ/de_grad_kernels.o $GT_OBJS -ldl
+echo "built $(pwd)/$OUT"

@@ -461,7 +461,7 @@ static int make_threaded(de_ctx *c, de_program *p) {
         if (p->dtype != DE_F32 && (table[i] >> 32) != (table[0] >> 32)) return DE_OK;
     }
     const bool hot_unary = !getenv("DE_NO_CONST_UNARY_HOT"); // unary operators outside the binder's hot set: their own handlers
-    const uint32_t row_bytes = (uint32_t)TROW_BYTES;
+    const uint32_t row_bytes = (uint32_t)trow_bytes(p->dtype);
     // superinstructions (de_bind.h): fewer dispatches for the same arithmetic
     const char *nf = getenv("DE_NO_FUSE");
     const bool fuse = !(nf && *nf == '1');
@@ -1125,7 +1125,7 @@ int de_program_verify(const de_program_t *p) {
         if (eval_handler_table(p->dtype, (p->options & DE_OPT_TURBO) != 0, table) != hipSuccess) return fail(c, DE_ERR_HIP, "handler table");
         std::vector<uint64_t> valid(table, table + TOPX_TABLE); // (the end-fused variants included)
         std::sort(valid.begin(), valid.end());
-        const uint64_t lds_bytes = (uint64_t)(rows + (p->uses_params ? 2 : 0)) * TROW_BYTES;
+        const uint64_t lds_bytes = (uint64_t)(rows + (p->uses_params ? 2 : 0)) * trow_bytes(p->dtype);
         if ((int64_t)p->ccode_off.size() != p->n_trees + 1 || p->ccode.size() != p->tcode.size() + (size_t)p->n_trees + 1) return bad("chained layout", -1, 0, p->ccode.size());
         const bool f32 = p->dtype == DE_F32;
         for (int64_t t = 0; t < p->n_trees; t++) {
@@ -1171,20 +1171,20 @@ int de_program_verify(const de_program_t *p) {
                                     (fb.bop >= TOPX_BIN_BASE && ((fb.bop - TOPX_BIN_BASE) & 1));
                 if (!no_row) {
                     const uint64_t off = r.bop & 0xFFFFFFu;
-                    if (off % TROW_BYTES != 0 || off + TROW_BYTES > lds_bytes) return bad("LDS operand offset outside the launch's allocation", t, i - i0, r.bop);
+                    if (off % trow_bytes(p->dtype) != 0 || off + trow_bytes(p->dtype) > lds_bytes) return bad("LDS operand offset outside the launch's allocation", t, i - i0, r.bop);
                     const bool pushes = (fb.bop >= TOP_LOADROW_BASE && fb.bop < TOP_LOADCONST_PUSH && ((fb.bop - TOP_LOADROW_BASE) & 2)) ||
                                         (fb.bop >= TOP_UNROW_BASE && fb.bop < TOP_BINROWC_BASE && ((fb.bop - TOP_UNROW_BASE) & 2)) ||
                                         (fb.bop >= TOP_BIN2_BASE && fb.bop < TOP_COUNT && ((fb.bop - TOP_BIN2_BASE) & 1));
                     if (pushes) {
-                        const int64_t prow = (int64_t)(off / TROW_BYTES) + (int8_t)(r.bop >> 24);
+                        const int64_t prow = (int64_t)(off / trow_bytes(p->dtype)) + (int8_t)(r.bop >> 24);
                         if (prow < p->n_features || prow >= spill_end) return bad("push row of a superinstruction outside the spill slots", t, i - i0, r.bop);
                     }
                     if (fb.bop >= TOP_BIN2_BASE && fb.bop < TOP_COUNT && !(((fb.bop - TOP_BIN2_BASE) >> 2) & 1)) { // row-row: second row by distance
                         const int64_t second = (int64_t)off + (int32_t)(f32 ? r.arg : r.lo);
-                        if (second < 0 || second % (int64_t)TROW_BYTES != 0 || (uint64_t)second + TROW_BYTES > lds_bytes) return bad("second operand row of a two-operand form", t, i - i0, (uint64_t)second);
+                        if (second < 0 || second % (int64_t)trow_bytes(p->dtype) != 0 || (uint64_t)second + trow_bytes(p->dtype) > lds_bytes) return bad("second operand row of a two-operand form", t, i - i0, (uint64_t)second);
                     }
                 }
-                if (fb.bop == BOP_GEN_PARAM && (f32 ? r.arg : r.lo) != (uint32_t)rows * (uint32_t)TROW_BYTES) return bad("class-row offset of a parameter operand", t, i - i0, r.arg);
+                if (fb.bop == BOP_GEN_PARAM && (f32 ? r.arg : r.lo) != (uint32_t)rows * (uint32_t)trow_bytes(p->dtype)) return bad("class-row offset of a parameter operand", t, i - i0, r.arg);
             }
         }
     }

@@ -20,7 +20,20 @@ constexpr int BLOCK = 256; // threads per workgroup = 4 wavefronts of 64 (flat-s
 #define DE_TBLK 64
 #endif
 constexpr int TBLK = DE_TBLK, TWAVES = DE_TBLK / 64;
-constexpr size_t TROW_BYTES = (size_t)(DE_TBLK + 1) * 16; // LDS row stride: DE_TBLK vectors + one of padding (bank spread)
+// PLANES: 16-byte vectors per lane and row (de_kernels.hip TG<T>).  The handlers are written for any number of planes; the shipped
+// build uses ONE for both element types (4 Float32 / 2 Float64 samples per lane, 256- / 128-sample tiles).  Two Float32 planes
+// (DE_EXTRA_FLAGS=-DDE_TG=2 bash build.sh: 8 samples per lane, 512-sample tiles, half the dispatches, scalar instructions and tree ends per
+// sample, an independent twin for every dependent VALU chain) were built, pass the GPU tests and measured SLOWER in round 4: rows twice as
+// long leave 2.75 instead of 5.25 waves per SIMD and the kernel saturates there (complete trees only, same box: 15.3 against 14.6 ms;
+// headline 7.17 / 6.95-7.5; turbo 6.02 / 5.42; full evaluation 19.9 / 17.7; occupancy sweeps of both in profiles/r4_planes_occupancy.txt):
+// what binds the kernel is VALU work per sample, not the per-dispatch overhead.
+#ifndef DE_TG
+#define DE_TG 1
+#endif
+constexpr int TG_F32 = DE_TG, TG_F64 = 1;
+constexpr int tg_planes(int dtype) { return dtype == DE_F32 ? TG_F32 : TG_F64; }
+constexpr int ttile_samples(int dtype) { return TBLK * tg_planes(dtype) * (dtype == DE_F32 ? 4 : 2); } // samples per workgroup tile
+constexpr size_t trow_bytes(int dtype) { return (size_t)(TBLK * tg_planes(dtype) + 1) * 16; } // LDS row stride: the planes + one vector of padding (bank spread)
 
 // Fused loss epilogue of the threaded eval kernel (de_eval_loss): instead of storing out[t][j] the
 // kernel reduces sum_j w_j * l(out[t][j] - y[j]) per tree (per-wave partials + two fixed-order passes).

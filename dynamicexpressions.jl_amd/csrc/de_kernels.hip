@@ -528,10 +528,29 @@ template <typename T> struct PoisonOf { typedef T type; };
 template <> struct PoisonOf<float> { typedef float type __attribute__((ext_vector_type(2))); };
 // (packed: the 16-byte alignment of `acc` would give the struct 8 bytes of tail padding, which the calling convention passes as
 // eight i8 arguments — eight vector registers; they now carry the fused loss's targets and weights, HL_PARAMS below)
+// PLANES (round 4).  A lane of the threaded kernel owns TG<T>::G 16-byte vectors per row — "planes": plane g of a row holds the
+// samples g * 64 * VW + lane * VW + i of the tile, 1024 bytes behind plane g - 1 both in the LDS row and in the output row — and a
+// handler applies its instruction to all of them in one dispatch.  The shipped build has ONE plane; two Float32 planes (-DDE_TG=2: the
+// per-dispatch and per-tree costs paid once per 8 samples, an independent twin for every dependent VALU chain) measured slower because
+// the longer rows halve the resident waves (de_kernels.h; profiles/r4_planes_occupancy.txt).
+template <typename T> struct TG { static constexpr int G = sizeof(T) == 4 ? DE_TG : 1; };
+static_assert(DE_TG == TG_F32, "de_kernels.h TG_F32 and DE_TG disagree");
+#define DE_PLANE_BYTES (DE_TBLK * 16u) // bytes between two planes of a row (LDS and output alike)
+#define FOR_PLANES DE_UNROLL for (int g = 0; g < TG<T>::G; g++)
+// the chain's state: what every handler receives, updates and hands on
 template <typename T> struct __attribute__((packed, aligned(8))) HState {
+    typename VecOf<T>::type acc[TG<T>::G];
+    typename PoisonOf<T>::type poison;
+};
+// ... and ONE plane of it: what the handler BODIES (b_*) work on
+template <typename T> struct __attribute__((packed, aligned(8))) BState {
     typename VecOf<T>::type acc;
     typename PoisonOf<T>::type poison;
 };
+// this thread's residual targets / weights of the fused loss, per plane: they travel as FOUR vector arguments (ly0, ly1, lw0, lw1: plane 1's
+// are unused with one plane) — clang passes an aggregate in registers only while all aggregates of the signature fit 16 registers, and the
+// state above takes 10 of them: a struct of the four vectors went through the stack (a scratch pointer per dispatch)
+template <typename T> struct HLoss { typename VecOf<T>::type v[2]; };
 // ONE call signature for every handler (several call sites with different signatures make the
 // compiler shuffle the returned state through a dozen v_movs per call):
 //   st  : accumulator + validity poison, in and out, stays in v0..v4 across calls
@@ -548,9 +567,9 @@ template <> __device__ __forceinline__ float imm_from<float>(uint32_t b) { retur
 template <> __device__ __forceinline__ double imm_from<double>(uint64_t b) { return __longlong_as_double((long long)b); }
 // Handler BODIES keep that signature (b_*: forceinline); what the instruction stream points at is h_chain<T, &body>
 // below, which fetches the body's operands from the stream and TAIL-CALLS the next instruction's handler.
-#define HARGS HState<T> st, uint32_t la, typename ImmBits<T>::type imm
+#define HARGS BState<T> st, uint32_t la, typename ImmBits<T>::type imm
 #define LDSP(T, addr) (reinterpret_cast<__attribute__((address_space(3))) typename VecOf<T>::type *>((uintptr_t)(addr)))
-template <typename T> using BodyFn = HState<T> (*)(HState<T>, uint32_t, typename ImmBits<T>::type);
+template <typename T> using BodyFn = BState<T> (*)(BState<T>, uint32_t, typename ImmBits<T>::type);
 // ---- direct-threaded dispatch ------------------------------------------------------------------------------------
 // The interpreter has no central loop: every handler ends with a tail call (s_setpc_b64) to the handler of the next
 // instruction.  The stream holds one 16-byte record per instruction, plus an end record per tree and one head record in
@@ -579,7 +598,9 @@ template <typename T> using BodyFn = HState<T> (*)(HState<T>, uint32_t, typename
 // ... and, in VECTOR registers, this thread's residual targets and weights of the fused loss (ly, lw: 8 registers every handler passes
 // on untouched, undefined outside a fused-loss launch): the end of a tree forms its loss partial from them (h_tree_end_slow, HF_LOSS).
 #define HL_T typename VecOf<T>::type
-template <typename T> using HandlerFn = HState<T> (*)(HState<T>, HL_T, HL_T, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t);
+#define HL_PARAMS HL_T ly0, HL_T ly1, HL_T lw0, HL_T lw1
+#define HL_PASS ly0, ly1, lw0, lw1
+template <typename T> using HandlerFn = HState<T> (*)(HState<T>, HL_T, HL_T, HL_T, HL_T, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t);
 enum : uint32_t { HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu,
                   HF_SLOW = HF_SLOW_STORE | HF_NO_STORE | (1u << 27), // any of them (and HF_LOSS): the out-of-line end of a tree
                   // plain flag stores (through the caches): always, except under flag protocol 1 (agent scope for every access, an
@@ -597,14 +618,23 @@ template <typename T> __device__ __forceinline__ typename ImmBits<T>::type arg_i
 template <> __device__ __forceinline__ uint32_t arg_imm<float>(uint32_t w1, uint64_t) { return w1; }
 template <> __device__ __forceinline__ uint64_t arg_imm<double>(uint32_t, uint64_t w23) { return w23; }
 #define DE_SKIPLIST_BYTES 256u // LDS bytes in front of row 0: the live trees of the running (sub-)chunk (h_tree_skip), 64 x 4 bytes
-#define DE_ROW_BYTES_C ((DE_TBLK + 1) * 16) // LDS row stride of the threaded kernel: DE_TBLK 16-byte vectors + one of padding
+template <typename T> struct RowOf { static constexpr uint32_t BYTES = (uint32_t)(DE_TBLK * TG<T>::G + 1) * 16u; }; // LDS row stride: the planes + one vector of padding (= trow_bytes, de_kernels.h)
 // `code` points at the record of the NEXT instruction; (la, w1, w23) are this instruction's record
-#define HCHAIN_ARGS HState<T> st, HL_T ly, HL_T lw, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint64_t skip, uint32_t left, uint32_t flags
-#define HCHAIN_NEXT_AT(W, NEXT) [[clang::musttail]] return arg_next<T>(w1, w23)(st, ly, lw, lds0, NEXT, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
+#define HCHAIN_ARGS HState<T> st, HL_PARAMS, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint64_t skip, uint32_t left, uint32_t flags
+#define HCHAIN_NEXT_AT(W, NEXT) [[clang::musttail]] return arg_next<T>(w1, w23)(st, HL_PASS, lds0, NEXT, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
 #define HCHAIN_NEXT(W) HCHAIN_NEXT_AT(W, code + 1)
+// every plane through a body (the planes' instruction sequences are independent: the scheduler interleaves them)
+template <typename T, BodyFn<T> BODY> __device__ __forceinline__ void planes_apply(HState<T> &st, uint32_t a, typename ImmBits<T>::type imm) {
+    FOR_PLANES {
+        BState<T> b{st.acc[g], st.poison};
+        b = BODY(b, a + (uint32_t)g * DE_PLANE_BYTES, imm); // (no carry into the aux byte: LDS < 2^18 bytes)
+        st.acc[g] = b.acc;
+        st.poison = b.poison;
+    }
+}
 template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain(HCHAIN_ARGS) {
     const U32x4 w = *code;
-    st = BODY(st, lds0 + la, arg_imm<T>(w1, w23)); // la = row byte offset | aux << 24 (no carry: LDS < 2^18 bytes)
+    planes_apply<T, BODY>(st, lds0 + la, arg_imm<T>(w1, w23)); // la = row byte offset | aux << 24
     HCHAIN_NEXT(w);
 }
 
@@ -652,7 +682,7 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS)
     const uint64_t hdr = ((uint64_t)(uintptr_t)code & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
     const ConstU4Ptr nh = (ConstU4Ptr)(uintptr_t)hdr; // the tree's header record (the record in front of its first instruction)
     const U32x4 hn = nh[0], w = nh[1];
-    [[clang::musttail]] return arg_next<T>(hn.y, ((uint64_t)hn.w << 32) | hn.z)(st, ly, lw, lds0, nh + 2, outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, skip, left, flags);
+    [[clang::musttail]] return arg_next<T>(hn.y, ((uint64_t)hn.w << 32) | hn.z)(st, HL_PASS, lds0, nh + 2, outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, skip, left, flags);
 }
 // the rest of a tree's end: flag byte, last tree of the chunk?, clear the state, on to the next tree (W = its first record,
 // HDR = the address of its header record) unless that one is skipped.  `tree` (a local of the caller) = the tree's index, the
@@ -669,7 +699,7 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS)
     left -= 1u;                                                                                              \
     skip >>= 1;                                                                                              \
     if (__builtin_expect((skip & 1ull) != 0ull, 0))                                                          \
-        [[clang::musttail]] return h_tree_skip<T>(st, ly, lw, lds0, HDR, outp, la, w1, w23, okp, ldo, skip, left, flags); \
+        [[clang::musttail]] return h_tree_skip<T>(st, HL_PASS, lds0, HDR, outp, la, w1, w23, okp, ldo, skip, left, flags); \
     HCHAIN_NEXT_AT(REC, NEXT)
 typedef __attribute__((address_space(1))) char *GPtr; // global, not flat: a flat store also ties up lgkmcnt
 // The other ends of a tree (flags & HF_SLOW), out of line so that h_tree_end itself is straight-line code: HF_LOSS (fused loss:
@@ -684,10 +714,11 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_A
         // sum_j w_j * l(out_j - y_j) over this wave's 64 * VW samples -> one partial per (tile, tree, wave): outp = &partial[tile, 0, wave],
         // ldo = bytes between two trees' partials (weight 0: samples past N)
         T s = T(0);
-        DE_UNROLL for (int i = 0; i < VW; i++) {
-            const T e = st.acc[i] - ly[i];
+        const HLoss<T> ly{{ly0, ly1}}, lw{{lw0, lw1}};
+        FOR_PLANES DE_UNROLL for (int i = 0; i < VW; i++) {
+            const T e = st.acc[g][i] - ly.v[g][i];
             const T l = (flags & HF_LOSS_L1) ? M<T>::abs(e) : e * e;
-            s += lw[i] != T(0) ? lw[i] * l : T(0); // weight 0 really excludes the sample (0 * Inf would be NaN)
+            s += lw.v[g][i] != T(0) ? lw.v[g][i] * l : T(0); // weight 0 really excludes the sample (0 * Inf would be NaN)
         }
         const int lane = (int)(((lds0 - DE_SKIPLIST_BYTES) >> 4) & 63u); // (no work-item id input in a handler)
         s = wave_sum_to_lane63(s, lane);
@@ -695,21 +726,23 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_A
         HTREE_END_TAIL(w, code + 1, code - 1);
     }
     if (flags & HF_SLOW_STORE) {
-        const int remaining = (int)(flags & HF_VALID_MASK) - (int)((lds0 - DE_SKIPLIST_BYTES) / (uint32_t)sizeof(T));
-        DE_UNROLL for (int i = 0; i < VW; i++)
-            if (i < remaining) reinterpret_cast<__attribute__((address_space(1))) T *>(row + lds0)[i] = st.acc[i];
-    } else if (st.acc[0] == T(123456.789)) {
-        *reinterpret_cast<__attribute__((address_space(1))) T *>(row + lds0) = st.acc[0];
+        FOR_PLANES {
+            const int remaining = (int)(flags & HF_VALID_MASK) - (int)((lds0 - DE_SKIPLIST_BYTES + (uint32_t)g * DE_PLANE_BYTES) / (uint32_t)sizeof(T));
+            DE_UNROLL for (int i = 0; i < VW; i++)
+                if (i < remaining) reinterpret_cast<__attribute__((address_space(1))) T *>(row + lds0 + (uint32_t)g * DE_PLANE_BYTES)[i] = st.acc[g][i];
+        }
+    } else {
+        FOR_PLANES if (st.acc[g][0] == T(123456.789)) *reinterpret_cast<__attribute__((address_space(1))) T *>(row + lds0) = st.acc[g][0];
     }
     HTREE_END_TAIL(w, code + 1, code - 1);
 }
 template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) {
     typedef typename VecOf<T>::type V;
-    if (__builtin_expect((flags & HF_SLOW) != 0u, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, ly, lw, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags);
+    if (__builtin_expect((flags & HF_SLOW) != 0u, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, HL_PASS, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags);
     const U32x4 w = *code;
     const uint32_t tree = la; // this IS the end record
     const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo); // wave-uniform: the store takes it as its scalar base
-    *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0) = st.acc; // full tile, aligned rows
+    FOR_PLANES *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0 + (uint32_t)g * DE_PLANE_BYTES) = st.acc[g]; // full tile, aligned rows
     HTREE_END_TAIL(w, code + 1, code - 1);
 }
 // The last instruction of a tree and its end in one dispatch (make_chained picks it when the tree finishes in a validity-tested
@@ -720,29 +753,29 @@ template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain_
     typedef typename VecOf<T>::type V;
     const uint32_t tree = *reinterpret_cast<const DE_CONSTANT uint32_t *>(code); // the end record this handler steps over: its operand word
     if (__builtin_expect((flags & HF_SLOW) != 0u, 0)) {
-        st = BODY(st, lds0 + la, arg_imm<T>(w1, w23));
-        [[clang::musttail]] return h_tree_end_slow<T>(st, ly, lw, lds0, code + 1, outp, tree, w1, w23, okp, ldo, skip, left, flags);
+        planes_apply<T, BODY>(st, lds0 + la, arg_imm<T>(w1, w23));
+        [[clang::musttail]] return h_tree_end_slow<T>(st, HL_PASS, lds0, code + 1, outp, tree, w1, w23, okp, ldo, skip, left, flags);
     }
     const U32x4 w = code[1];
-    st = BODY(st, lds0 + la, arg_imm<T>(w1, w23));
+    planes_apply<T, BODY>(st, lds0 + la, arg_imm<T>(w1, w23));
     const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);
-    *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0) = st.acc;
+    FOR_PLANES *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0 + (uint32_t)g * DE_PLANE_BYTES) = st.acc[g];
     HTREE_END_TAIL(w, code + 2, code);
 }
 
-template <typename T> __device__ __forceinline__ HState<T> b_load_row(HARGS) { st.acc = *LDSP(T, la); return st; }
-template <typename T> __device__ __forceinline__ HState<T> b_load_const(HARGS) {
+template <typename T> __device__ __forceinline__ BState<T> b_load_row(HARGS) { st.acc = *LDSP(T, la); return st; }
+template <typename T> __device__ __forceinline__ BState<T> b_load_const(HARGS) {
     const T c = imm_from<T>(imm);
     DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = c;
     return st;
 }
-template <typename T> __device__ __forceinline__ HState<T> b_push(HARGS) { *LDSP(T, la) = st.acc; return st; }
-template <typename T> __device__ __forceinline__ HState<T> b_check_row(HARGS) {
+template <typename T> __device__ __forceinline__ BState<T> b_push(HARGS) { *LDSP(T, la) = st.acc; return st; }
+template <typename T> __device__ __forceinline__ BState<T> b_check_row(HARGS) {
     const typename VecOf<T>::type v = *LDSP(T, la);
     hpoison<T>(st.poison, v);
     return st;
 }
-template <typename T> __device__ __forceinline__ HState<T> b_check_acc(HARGS) { hpoison<T>(st.poison, st.acc); return st; }
+template <typename T> __device__ __forceinline__ BState<T> b_check_acc(HARGS) { hpoison<T>(st.poison, st.acc); return st; }
 
 // Correctly rounded Float32 division, 4 samples.  The compiler's expansion of `/` is
 //   v_div_scale x2, v_rcp, 6 dependent FMA/MUL (Newton + two residual corrections), v_div_fmas, v_div_fixup
@@ -818,7 +851,7 @@ __device__ __forceinline__ VecOf<float>::type div_safe_by_const(VecOf<float>::ty
     return q;
 }
 // the divisions of the fast handlers whose operand `b` is the constant `cbits` (K = 4: x / c, 5: c / x): range test, quotient
-template <int K> __device__ __forceinline__ bool div_const_unsafe(VecOf<float>::type x, uint32_t cbits) {
+template <int K> __device__ __forceinline__ bool div_const_unsafe(VecOf<float>::type x, uint32_t cbits) { // (one plane: the full handlers' own test)
     return (int)(__ballot(!div_samples_safe(x)) != 0ull) | (int)!div_const_in_range(cbits);
 }
 template <int K> __device__ __forceinline__ VecOf<float>::type div_const(VecOf<float>::type x, uint32_t cbits) {
@@ -907,7 +940,7 @@ template <typename T, int K, bool TB = false> __device__ __forceinline__ typenam
     return r;
 }
 // VAR bit0 = validity-test the result, bit1 = constant operand
-template <typename T, int K, int VAR, bool TB = false> __device__ __forceinline__ HState<T> b_bin(HARGS) {
+template <typename T, int K, int VAR, bool TB = false> __device__ __forceinline__ BState<T> b_bin(HARGS) {
     typedef typename VecOf<T>::type V;
     V b;
     if constexpr (VAR & 2) b = splat<T>(imm);
@@ -917,7 +950,7 @@ template <typename T, int K, int VAR, bool TB = false> __device__ __forceinline_
     return st;
 }
 // VAR bit0 = test the result, bit1 = operand is an LDS row (else acc)
-template <typename T, int K, int VAR, bool TB = false> __device__ __forceinline__ HState<T> b_un(HARGS) {
+template <typename T, int K, int VAR, bool TB = false> __device__ __forceinline__ BState<T> b_un(HARGS) {
     typedef typename VecOf<T>::type V;
     V x = st.acc;
     if constexpr (VAR & 2) x = *LDSP(T, la);
@@ -926,31 +959,29 @@ template <typename T, int K, int VAR, bool TB = false> __device__ __forceinline_
     return st;
 }
 // ---- superinstructions (de_bind.h, fuse_tree): la = LDS address of row A | int8 (push row - row A) << 24
-#define DE_ROW_BYTES ((DE_TBLK + 1) * 16)
-static_assert(DE_ROW_BYTES == DE_ROW_BYTES_C, "row stride");
 __device__ __forceinline__ uint32_t row_a(uint32_t la) { return la & 0xFFFFFFu; }
-__device__ __forceinline__ uint32_t push_addr(uint32_t la) { return (la & 0xFFFFFFu) + (uint32_t)(((int32_t)la >> 24) * DE_ROW_BYTES); }
-template <typename T, bool PUSH, bool CHK> __device__ __forceinline__ HState<T> b_loadrow_f(HARGS) {
-    if constexpr (PUSH) *LDSP(T, push_addr(la)) = st.acc;
+template <typename T> __device__ __forceinline__ uint32_t push_addr(uint32_t la) { return (la & 0xFFFFFFu) + (uint32_t)(((int32_t)la >> 24) * (int32_t)RowOf<T>::BYTES); }
+template <typename T, bool PUSH, bool CHK> __device__ __forceinline__ BState<T> b_loadrow_f(HARGS) {
+    if constexpr (PUSH) *LDSP(T, push_addr<T>(la)) = st.acc;
     const typename VecOf<T>::type v = *LDSP(T, PUSH ? row_a(la) : la);
     if constexpr (CHK) hpoison<T>(st.poison, v);
     st.acc = v;
     return st;
 }
-template <typename T> __device__ __forceinline__ HState<T> b_loadconst_push(HARGS) {
+template <typename T> __device__ __forceinline__ BState<T> b_loadconst_push(HARGS) {
     *LDSP(T, la) = st.acc;
     st.acc = splat<T>(imm);
     return st;
 }
-template <typename T, int K, bool OUT, bool PUSH, bool CHK, bool TB = false> __device__ __forceinline__ HState<T> b_unrow_f(HARGS) {
-    if constexpr (PUSH) *LDSP(T, push_addr(la)) = st.acc;
+template <typename T, int K, bool OUT, bool PUSH, bool CHK, bool TB = false> __device__ __forceinline__ BState<T> b_unrow_f(HARGS) {
+    if constexpr (PUSH) *LDSP(T, push_addr<T>(la)) = st.acc;
     const typename VecOf<T>::type x = *LDSP(T, PUSH ? row_a(la) : la);
     if constexpr (CHK) hpoison<T>(st.poison, x);
     st.acc = un_apply<T, K, TB>(x);
     if constexpr (OUT) hpoison<T>(st.poison, st.acc);
     return st;
 }
-template <typename T, int K, bool OUT, bool TB = false> __device__ __forceinline__ HState<T> b_binrowc(HARGS) { // operand row tested, then acc = acc op row
+template <typename T, int K, bool OUT, bool TB = false> __device__ __forceinline__ BState<T> b_binrowc(HARGS) { // operand row tested, then acc = acc op row
     const typename VecOf<T>::type b = *LDSP(T, la);
     hpoison<T>(st.poison, b);
     st.acc = bin_apply<T, K, TB>(st.acc, b);
@@ -958,9 +989,9 @@ template <typename T, int K, bool OUT, bool TB = false> __device__ __forceinline
     return st;
 }
 // acc = row A op (row B | constant); row B's byte distance from row A travels in the immediate
-template <typename T, int K, bool CST, bool OUT, bool PUSH, bool TB = false> __device__ __forceinline__ HState<T> b_bin2(HARGS) {
+template <typename T, int K, bool CST, bool OUT, bool PUSH, bool TB = false> __device__ __forceinline__ BState<T> b_bin2(HARGS) {
     typedef typename VecOf<T>::type V;
-    if constexpr (PUSH) *LDSP(T, push_addr(la)) = st.acc;
+    if constexpr (PUSH) *LDSP(T, push_addr<T>(la)) = st.acc;
     const uint32_t a = PUSH ? row_a(la) : la;
     const V x = *LDSP(T, a);
     V b;
@@ -977,7 +1008,8 @@ template <typename T, int K, bool CST, bool OUT, bool PUSH, bool TB = false> __d
 // division) out of the function the argument is dead after its last use and the result is computed in place: no v_mov of the
 // accumulator around the body (4-5 of them before: 6-10 % of the handler).  Two phases, so that every handler shape (plain,
 // fused with a spill / a row test, fused with the end of the tree) can place its tail call between them:
-//   un_pretest: the part of the arithmetic the range test reads (x log2 e | the multiple of pi), and the test;
+//   un_pretest: the part of the arithmetic the range test reads (x log2 e | the multiple of pi), and the test — PER LANE: the caller
+//               ORs the planes' results and takes ONE ballot;
 //   un_finish : the rest.  Same operations in the same order as un_apply's fast paths: the same bits.
 struct UnPre { DeF2 ta, tb, ka, kb; }; // exp: ta, tb = x log2 e;  trig: ta, tb = the multiple n, ka, kb = the magic sums (parity)
 template <int K, bool TB> __device__ __forceinline__ bool un_pretest(VecOf<float>::type x, UnPre &p) {
@@ -986,7 +1018,7 @@ template <int K, bool TB> __device__ __forceinline__ bool un_pretest(VecOf<float
         p.ta = xa * DE_F2(0x1.715476p+0f);
         p.tb = xb * DE_F2(0x1.715476p+0f);
         if constexpr (TB) return false; // turbo exp has no slow path
-        else return __ballot(any_abs_exceeds_f32x4(p.ta[0], p.ta[1], p.tb[0], p.tb[1], DE_EXP_DIRECT_BOUND_T)) != 0ull;
+        else return any_abs_exceeds_f32x4(p.ta[0], p.ta[1], p.tb[0], p.tb[1], DE_EXP_DIRECT_BOUND_T);
     } else {
         constexpr bool SIN = K == 2;
         const DeF2 ta = SIN ? xa * DE_F2(DE_TRIG_INV_PI) : __builtin_elementwise_fma(xa, DE_F2(DE_TRIG_INV_PI), DE_F2(0.5f));
@@ -995,7 +1027,7 @@ template <int K, bool TB> __device__ __forceinline__ bool un_pretest(VecOf<float
         p.kb = tb + DE_F2(DE_TRIG_MAGIC);
         p.ta = p.ka - DE_F2(DE_TRIG_MAGIC);
         p.tb = p.kb - DE_F2(DE_TRIG_MAGIC);
-        return __ballot(any_abs_exceeds_f32x4(p.ta[0], p.ta[1], p.tb[0], p.tb[1], DE_TRIG_FAST_BOUND_M)) != 0ull;
+        return any_abs_exceeds_f32x4(p.ta[0], p.ta[1], p.tb[0], p.tb[1], DE_TRIG_FAST_BOUND_M);
     }
 }
 template <int K, bool TB> __device__ __forceinline__ VecOf<float>::type un_finish(VecOf<float>::type x, const UnPre &p) {
@@ -1022,53 +1054,73 @@ template <int K, bool TB> __device__ __forceinline__ VecOf<float>::type un_finis
         return V{ya[0], ya[1], yb[0], yb[1]};
     }
 }
-#define HFAST_ARGS HState<float> st, VecOf<float>::type ly, VecOf<float>::type lw, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, \
+#define HFAST_ARGS HState<float> st, VecOf<float>::type ly0, VecOf<float>::type ly1, VecOf<float>::type lw0, VecOf<float>::type lw1, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, \
                    uint64_t skip, uint32_t left, uint32_t flags
-#define HFAST_PASS st, ly, lw, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags
-#define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, ly, lw, lds0, code + 1, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
+#define HFAST_PASS st, HL_PASS, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags
+#define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, HL_PASS, lds0, code + 1, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
 // the end of a tree behind a fast-path body: what h_chain_end does (T = float)
 #define HFAST_END_TAIL()                                                                                                    \
     {                                                                                                                       \
-        typedef float T;                                                                                                    \
         const U32x4 wn = code[1];                                                                                           \
         const uint32_t tree = *reinterpret_cast<const DE_CONSTANT uint32_t *>(code); /* the end record's operand word */      \
         const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);                                               \
-        *reinterpret_cast<__attribute__((address_space(1))) VecOf<float>::type *>(row + lds0) = st.acc;                     \
+        FOR_PLANES *reinterpret_cast<__attribute__((address_space(1))) VecOf<float>::type *>(row + lds0 + (uint32_t)g * DE_PLANE_BYTES) = st.acc[g]; \
         HTREE_END_TAIL(wn, code + 2, code);                                                                                     \
     }
+#define PLANE_ADDR(A, g) ((A) + (uint32_t)(g) * DE_PLANE_BYTES)
+// (the planes of a fast handler: every plane's range test first — one wave-uniform decision for the whole dispatch: a wavefront
+// that fails it on ANY plane tail-calls the full handler, which redoes all planes —, then every plane's arithmetic)
 // cos / exp / sin on the accumulator or a row (VAR as in b_un)
 template <int K, int VAR, bool TB> __device__ __noinline__ HState<float> h_un_fast(HFAST_ARGS) {
     typedef float T;
+    constexpr int G = TG<T>::G;
     const U32x4 w = *code;
-    VecOf<float>::type x = st.acc;
-    if constexpr (VAR & 2) x = *LDSP(T, lds0 + la);
-    UnPre p;
-    if (__builtin_expect(un_pretest<K, TB>(x, p), 0)) [[clang::musttail]] return h_chain<T, &b_un<T, K, VAR, TB>>(HFAST_PASS);
-    st.acc = un_finish<K, TB>(x, p);
-    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
+    VecOf<float>::type x[G];
+    FOR_PLANES x[g] = (VAR & 2) ? *LDSP(T, PLANE_ADDR(lds0 + la, g)) : st.acc[g];
+    UnPre p[G];
+    bool slow = false;
+    FOR_PLANES slow |= un_pretest<K, TB>(x[g], p[g]);
+    if (__builtin_expect(__ballot(slow) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_un<T, K, VAR, TB>>(HFAST_PASS);
+    FOR_PLANES {
+        st.acc[g] = un_finish<K, TB>(x[g], p[g]);
+        if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc[g]);
+    }
     HFAST_NEXT(w);
 }
 // ... as the last instruction of a tree (the end-fused form of b_un<K, 1>: accumulator operand, tested result)
 template <int K, bool TB> __device__ __noinline__ HState<float> h_un_end_fast(HFAST_ARGS) {
     typedef float T;
-    UnPre p;
-    if (__builtin_expect(((flags & HF_SLOW) != 0u) | un_pretest<K, TB>(st.acc, p), 0)) [[clang::musttail]] return h_chain_end<T, &b_un<T, K, 1, TB>>(HFAST_PASS);
-    st.acc = un_finish<K, TB>(st.acc, p);
-    hpoison<T>(st.poison, st.acc);
+    constexpr int G = TG<T>::G;
+    UnPre p[G];
+    bool slow = false;
+    FOR_PLANES slow |= un_pretest<K, TB>(st.acc[g], p[g]);
+    if (__builtin_expect(((flags & HF_SLOW) != 0u) | (__ballot(slow) != 0ull), 0)) [[clang::musttail]] return h_chain_end<T, &b_un<T, K, 1, TB>>(HFAST_PASS);
+    FOR_PLANES {
+        st.acc[g] = un_finish<K, TB>(st.acc[g], p[g]);
+        hpoison<T>(st.poison, st.acc[g]);
+    }
     HFAST_END_TAIL()
 }
 // ... fused with a spill of the accumulator and / or the validity test of its row operand (b_unrow_f)
 template <int K, bool OUT, bool PUSH, bool CHK, bool TB> __device__ __noinline__ HState<float> h_unrow_fast(HFAST_ARGS) {
     typedef float T;
+    constexpr int G = TG<T>::G;
     const U32x4 w = *code;
     const uint32_t a = lds0 + la;
-    if constexpr (PUSH) *LDSP(T, push_addr(a)) = st.acc; // first, as in b_unrow_f (the full handler would write it again: same value)
-    const VecOf<float>::type x = *LDSP(T, PUSH ? row_a(a) : a);
-    UnPre p;
-    if (__builtin_expect(un_pretest<K, TB>(x, p), 0)) [[clang::musttail]] return h_chain<T, &b_unrow_f<T, K, OUT, PUSH, CHK, TB>>(HFAST_PASS);
-    if constexpr (CHK) hpoison<T>(st.poison, x);
-    st.acc = un_finish<K, TB>(x, p);
-    if constexpr (OUT) hpoison<T>(st.poison, st.acc);
+    VecOf<float>::type x[G];
+    FOR_PLANES {
+        if constexpr (PUSH) *LDSP(T, push_addr<T>(PLANE_ADDR(a, g))) = st.acc[g]; // first, as in b_unrow_f (the full handler would write it again: same value)
+        x[g] = *LDSP(T, PUSH ? row_a(PLANE_ADDR(a, g)) : PLANE_ADDR(a, g));
+    }
+    UnPre p[G];
+    bool slow = false;
+    FOR_PLANES slow |= un_pretest<K, TB>(x[g], p[g]);
+    if (__builtin_expect(__ballot(slow) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_unrow_f<T, K, OUT, PUSH, CHK, TB>>(HFAST_PASS);
+    FOR_PLANES {
+        if constexpr (CHK) hpoison<T>(st.poison, x[g]);
+        st.acc[g] = un_finish<K, TB>(x[g], p[g]);
+        if constexpr (OUT) hpoison<T>(st.poison, st.acc[g]);
+    }
     HFAST_NEXT(w);
 }
 // The exact Float32 divisions (K = 4: acc / operand, 5: operand / acc; VAR as in b_bin) likewise: range test, then either the
@@ -1076,35 +1128,52 @@ template <int K, bool OUT, bool PUSH, bool CHK, bool TB> __device__ __noinline__
 template <int K, int VAR> __device__ __noinline__ HState<float> h_div_fast(HFAST_ARGS) {
     typedef float T;
     typedef VecOf<float>::type V;
+    constexpr int G = TG<T>::G;
     const U32x4 w = *code;
     if constexpr (VAR & 2) { // constant operand
-        if (__builtin_expect(div_const_unsafe<K>(st.acc, w1), 0)) [[clang::musttail]] return h_chain<T, &b_bin<T, K, VAR, false>>(HFAST_PASS);
-        st.acc = div_const<K>(st.acc, w1);
+        bool unsafe = false;
+        FOR_PLANES unsafe |= !div_samples_safe(st.acc[g]);
+        if (__builtin_expect((int)(__ballot(unsafe) != 0ull) | (int)!div_const_in_range(w1), 0)) [[clang::musttail]] return h_chain<T, &b_bin<T, K, VAR, false>>(HFAST_PASS);
+        FOR_PLANES st.acc[g] = div_const<K>(st.acc[g], w1);
     } else {
-        const V b = *LDSP(T, lds0 + la);
-        const V num = K == 4 ? st.acc : b, den = K == 4 ? b : st.acc;
-        if (__builtin_expect(__ballot(!div_operands_safe(num, den)) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_bin<T, K, VAR, false>>(HFAST_PASS);
-        st.acc = div_safe(num, den);
+        V num[G], den[G];
+        bool unsafe = false;
+        FOR_PLANES {
+            const V b = *LDSP(T, PLANE_ADDR(lds0 + la, g));
+            num[g] = K == 4 ? st.acc[g] : b;
+            den[g] = K == 4 ? b : st.acc[g];
+            unsafe |= !div_operands_safe(num[g], den[g]);
+        }
+        if (__builtin_expect(__ballot(unsafe) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_bin<T, K, VAR, false>>(HFAST_PASS);
+        FOR_PLANES st.acc[g] = div_safe(num[g], den[g]);
     }
-    if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc);
+    if constexpr (VAR & 1) FOR_PLANES hpoison<T>(st.poison, st.acc[g]);
     HFAST_NEXT(w);
 }
 // ... as the last instruction of a tree (the end-fused forms of b_bin<K, 1> / <K, 3>: tested result)
 template <int K, bool CST> __device__ __noinline__ HState<float> h_div_end_fast(HFAST_ARGS) {
     typedef float T;
     typedef VecOf<float>::type V;
+    constexpr int G = TG<T>::G;
     if constexpr (CST) {
-        if (__builtin_expect(((flags & HF_SLOW) != 0u) | div_const_unsafe<K>(st.acc, w1), 0))
-            [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 3, false>>(HFAST_PASS);
-        st.acc = div_const<K>(st.acc, w1);
+        bool unsafe = false;
+        FOR_PLANES unsafe |= !div_samples_safe(st.acc[g]);
+        if (__builtin_expect((int)((flags & HF_SLOW) != 0u) | (int)(__ballot(unsafe) != 0ull) | (int)!div_const_in_range(w1), 0)) [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 3, false>>(HFAST_PASS);
+        FOR_PLANES st.acc[g] = div_const<K>(st.acc[g], w1);
     } else {
-        const V b = *LDSP(T, lds0 + la);
-        const V num = K == 4 ? st.acc : b, den = K == 4 ? b : st.acc;
-        if (__builtin_expect(((flags & HF_SLOW) != 0u) | (__ballot(!div_operands_safe(num, den)) != 0ull), 0))
+        V num[G], den[G];
+        bool unsafe = false;
+        FOR_PLANES {
+            const V b = *LDSP(T, PLANE_ADDR(lds0 + la, g));
+            num[g] = K == 4 ? st.acc[g] : b;
+            den[g] = K == 4 ? b : st.acc[g];
+            unsafe |= !div_operands_safe(num[g], den[g]);
+        }
+        if (__builtin_expect(((flags & HF_SLOW) != 0u) | (__ballot(unsafe) != 0ull), 0))
             [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 1, false>>(HFAST_PASS);
-        st.acc = div_safe(num, den);
+        FOR_PLANES st.acc[g] = div_safe(num[g], den[g]);
     }
-    hpoison<T>(st.poison, st.acc);
+    FOR_PLANES hpoison<T>(st.poison, st.acc[g]);
     HFAST_END_TAIL()
 }
 // ... fused with the validity test of the row operand (b_binrowc) / with the load of row A, a constant or row B as the other
@@ -1112,36 +1181,59 @@ template <int K, bool CST> __device__ __noinline__ HState<float> h_div_end_fast(
 template <int K, bool OUT> __device__ __noinline__ HState<float> h_divrowc_fast(HFAST_ARGS) {
     typedef float T;
     typedef VecOf<float>::type V;
+    constexpr int G = TG<T>::G;
     const U32x4 w = *code;
-    const V b = *LDSP(T, lds0 + la);
-    const V num = K == 4 ? st.acc : b, den = K == 4 ? b : st.acc;
-    if (__builtin_expect(__ballot(!div_operands_safe(num, den)) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_binrowc<T, K, OUT, false>>(HFAST_PASS);
-    hpoison<T>(st.poison, b);
-    st.acc = div_safe(num, den);
-    if constexpr (OUT) hpoison<T>(st.poison, st.acc);
+    V b[G], num[G], den[G];
+    bool unsafe = false;
+    FOR_PLANES {
+        b[g] = *LDSP(T, PLANE_ADDR(lds0 + la, g));
+        num[g] = K == 4 ? st.acc[g] : b[g];
+        den[g] = K == 4 ? b[g] : st.acc[g];
+        unsafe |= !div_operands_safe(num[g], den[g]);
+    }
+    if (__builtin_expect(__ballot(unsafe) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_binrowc<T, K, OUT, false>>(HFAST_PASS);
+    FOR_PLANES {
+        hpoison<T>(st.poison, b[g]);
+        st.acc[g] = div_safe(num[g], den[g]);
+        if constexpr (OUT) hpoison<T>(st.poison, st.acc[g]);
+    }
     HFAST_NEXT(w);
 }
 template <int K, bool CST, bool OUT, bool PUSH> __device__ __noinline__ HState<float> h_div2_fast(HFAST_ARGS) {
     typedef float T;
     typedef VecOf<float>::type V;
+    constexpr int G = TG<T>::G;
     const U32x4 w = *code;
-    const uint32_t a0 = lds0 + la, a = PUSH ? row_a(a0) : a0;
-    if constexpr (PUSH) *LDSP(T, push_addr(a0)) = st.acc; // first, as in b_bin2: row B may be this very slot (the full handler would write it again: same value)
-    const V x = *LDSP(T, a);
-    if constexpr (CST) {
-        if (__builtin_expect(div_const_unsafe<K>(x, w1), 0)) [[clang::musttail]] return h_chain<T, &b_bin2<T, K, CST, OUT, PUSH, false>>(HFAST_PASS);
-        st.acc = div_const<K>(x, w1);
-    } else {
-        const V b = *LDSP(T, a + w1);
-        const V num = K == 4 ? x : b, den = K == 4 ? b : x;
-        if (__builtin_expect(__ballot(!div_operands_safe(num, den)) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_bin2<T, K, CST, OUT, PUSH, false>>(HFAST_PASS);
-        st.acc = div_safe(num, den);
+    const uint32_t a0 = lds0 + la;
+    V x[G];
+    FOR_PLANES {
+        const uint32_t ag = PLANE_ADDR(a0, g);
+        if constexpr (PUSH) *LDSP(T, push_addr<T>(ag)) = st.acc[g]; // first, as in b_bin2: row B may be this very slot (the full handler would write it again: same value)
+        x[g] = *LDSP(T, PUSH ? row_a(ag) : ag);
     }
-    if constexpr (OUT) hpoison<T>(st.poison, st.acc);
+    if constexpr (CST) {
+        bool unsafe = false;
+        FOR_PLANES unsafe |= !div_samples_safe(x[g]);
+        if (__builtin_expect((int)(__ballot(unsafe) != 0ull) | (int)!div_const_in_range(w1), 0)) [[clang::musttail]] return h_chain<T, &b_bin2<T, K, CST, OUT, PUSH, false>>(HFAST_PASS);
+        FOR_PLANES st.acc[g] = div_const<K>(x[g], w1);
+    } else {
+        V num[G], den[G];
+        bool unsafe = false;
+        FOR_PLANES {
+            const uint32_t ag = PLANE_ADDR(a0, g);
+            const V b = *LDSP(T, (PUSH ? row_a(ag) : ag) + w1);
+            num[g] = K == 4 ? x[g] : b;
+            den[g] = K == 4 ? b : x[g];
+            unsafe |= !div_operands_safe(num[g], den[g]);
+        }
+        if (__builtin_expect(__ballot(unsafe) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_bin2<T, K, CST, OUT, PUSH, false>>(HFAST_PASS);
+        FOR_PLANES st.acc[g] = div_safe(num[g], den[g]);
+    }
+    if constexpr (OUT) FOR_PLANES hpoison<T>(st.poison, st.acc[g]);
     HFAST_NEXT(w);
 }
 // generic handlers: de_opcode in la[31:24].  SRC: 0 row, 1 const, 2 acc.  INJ: Inf-injection of the fused deg1 kernels.
-template <typename T, int SRC, bool INJ> __device__ __forceinline__ HState<T> b_gen(HARGS) {
+template <typename T, int SRC, bool INJ> __device__ __forceinline__ BState<T> b_gen(HARGS) {
     typedef typename VecOf<T>::type V;
     const uint32_t aux = la >> 24;
     VG<T, 1> a, b;
@@ -1157,7 +1249,7 @@ template <typename T, int SRC, bool INJ> __device__ __forceinline__ HState<T> b_
 }
 // Unary operators outside the binder's hot set, without the detour through the generic switch (cold_op): K = gun_index
 // (de_bind.h) 3 neg 4 square 5 cube 6 abs 7 log 8 safe_log 9 sqrt 10 safe_sqrt 11 tanh 12 relu — cold_op's expressions.
-template <typename T, int K, int SRC> __device__ __forceinline__ HState<T> b_un2(HARGS) { // SRC 0: row, 1: accumulator
+template <typename T, int K, int SRC> __device__ __forceinline__ BState<T> b_un2(HARGS) { // SRC 0: row, 1: accumulator
     using m = M<T>;
     typename VecOf<T>::type x = st.acc;
     if constexpr (SRC == 0) x = *LDSP(T, la & 0xFFFFFFu);
@@ -1179,14 +1271,14 @@ template <typename T, int K, int SRC> __device__ __forceinline__ HState<T> b_un2
     return st;
 }
 // acc = max(acc, b) / min(acc, b) (K 6 / 7; cold_op's expressions) with b = a row (SRC 0) or a constant (SRC 1)
-template <typename T, int K, int SRC> __device__ __forceinline__ HState<T> b_maxmin(HARGS) {
+template <typename T, int K, int SRC> __device__ __forceinline__ BState<T> b_maxmin(HARGS) {
     typename VecOf<T>::type b;
     if constexpr (SRC == 0) b = *LDSP(T, la & 0xFFFFFFu);
     else { const T c = imm_from<T>(imm); DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) b[i] = c; }
     DE_UNROLL for (int i = 0; i < VecOf<T>::W; i++) st.acc[i] = K == 6 ? jl_max(st.acc[i], b[i]) : jl_min(st.acc[i], b[i]);
     return st;
 }
-template <typename T> __device__ __forceinline__ HState<T> b_tern(HARGS) { // acc = op3(row B, row C, acc)
+template <typename T> __device__ __forceinline__ BState<T> b_tern(HARGS) { // acc = op3(row B, row C, acc)
     const uint32_t aux = la >> 24, lb = la & 0xFFFFFFu;
     VG<T, 1> a, b, c;
     a.v[0] = st.acc;
@@ -1196,7 +1288,7 @@ template <typename T> __device__ __forceinline__ HState<T> b_tern(HARGS) { // ac
     st.acc = a.v[0];
     return st;
 }
-template <typename T> __device__ __forceinline__ HState<T> b_nop(HARGS) { return st; }
+template <typename T> __device__ __forceinline__ BState<T> b_nop(HARGS) { return st; }
 
 // Operand = params[row, class of the sample] (src/ParametricExpression.jl:381-389).  The kernel leaves, per thread, the
 // byte offsets of its samples' parameter columns in an LDS row of their own (the "class row", whose byte offset is the
@@ -1207,30 +1299,32 @@ template <typename T, bool TB> __device__ __noinline__ HState<T> h_param(HCHAIN_
     constexpr int VW = VecOf<T>::W;
     const U32x4 w = *code;
     const uint32_t op = la >> 24;
-    const uint32_t crow = lds0 + (uint32_t)arg_imm<T>(w1, w23);
-    const U32x4 cv = *reinterpret_cast<__attribute__((address_space(3))) U32x4 *>((uintptr_t)crow);
-    uint64_t tab;
-    if constexpr (sizeof(T) == 4) {
-        typedef uint32_t U2 __attribute__((ext_vector_type(2)));
-        const U2 pv = *reinterpret_cast<__attribute__((address_space(3))) U2 *>((uintptr_t)(crow + DE_ROW_BYTES_C));
-        tab = ((uint64_t)pv.y << 32) | pv.x;
-    } else tab = ((uint64_t)cv.w << 32) | cv.z;
-    const char *__restrict__ pb = reinterpret_cast<const char *>(tab) + (size_t)(la & 0xFFFFu) * sizeof(T);
-    VG<T, 1> av, bv;
-    DE_UNROLL for (int i = 0; i < VW; i++) bv.v[0][i] = *reinterpret_cast<const T *>(pb + cv[i]);
-    if (la & (1u << 23)) hpoison<T>(st.poison, bv.v[0]);
-    switch (op) {
-    case DOP_LOAD: st.acc = bv.v[0]; break;
-    case DE_B_ADD: st.acc = bin_apply<T, 0>(st.acc, bv.v[0]); break;
-    case DE_B_SUB: st.acc = bin_apply<T, 1>(st.acc, bv.v[0]); break;
-    case DOP_RSUB: st.acc = bin_apply<T, 2>(st.acc, bv.v[0]); break;
-    case DE_B_MUL: st.acc = bin_apply<T, 3>(st.acc, bv.v[0]); break;
-    case DE_B_DIV: st.acc = bin_apply<T, 4, TB>(st.acc, bv.v[0]); break;
-    case DOP_RDIV: st.acc = bin_apply<T, 5, TB>(st.acc, bv.v[0]); break;
-    case DE_U_COS: st.acc = un_apply<T, 0, TB>(bv.v[0]); break; // unary operator on a parameter leaf
-    case DE_U_EXP: st.acc = un_apply<T, 1, TB>(bv.v[0]); break;
-    case DE_U_SIN: st.acc = un_apply<T, 2, TB>(bv.v[0]); break;
-    default: av.v[0] = st.acc; av = cold_op<T, 1>(op, av, bv); st.acc = av.v[0]; break;
+    FOR_PLANES { // (the class row has the planes of every row; the table's address is read once per plane: same value)
+        const uint32_t crow = lds0 + (uint32_t)arg_imm<T>(w1, w23) + (uint32_t)g * DE_PLANE_BYTES;
+        const U32x4 cv = *reinterpret_cast<__attribute__((address_space(3))) U32x4 *>((uintptr_t)crow);
+        uint64_t tab;
+        if constexpr (sizeof(T) == 4) {
+            typedef uint32_t U2 __attribute__((ext_vector_type(2)));
+            const U2 pv = *reinterpret_cast<__attribute__((address_space(3))) U2 *>((uintptr_t)(crow + RowOf<T>::BYTES));
+            tab = ((uint64_t)pv.y << 32) | pv.x;
+        } else tab = ((uint64_t)cv.w << 32) | cv.z;
+        const char *__restrict__ pb = reinterpret_cast<const char *>(tab) + (size_t)(la & 0xFFFFu) * sizeof(T);
+        VG<T, 1> av, bv;
+        DE_UNROLL for (int i = 0; i < VW; i++) bv.v[0][i] = *reinterpret_cast<const T *>(pb + cv[i]);
+        if (la & (1u << 23)) hpoison<T>(st.poison, bv.v[0]);
+        switch (op) {
+        case DOP_LOAD: st.acc[g] = bv.v[0]; break;
+        case DE_B_ADD: st.acc[g] = bin_apply<T, 0>(st.acc[g], bv.v[0]); break;
+        case DE_B_SUB: st.acc[g] = bin_apply<T, 1>(st.acc[g], bv.v[0]); break;
+        case DOP_RSUB: st.acc[g] = bin_apply<T, 2>(st.acc[g], bv.v[0]); break;
+        case DE_B_MUL: st.acc[g] = bin_apply<T, 3>(st.acc[g], bv.v[0]); break;
+        case DE_B_DIV: st.acc[g] = bin_apply<T, 4, TB>(st.acc[g], bv.v[0]); break;
+        case DOP_RDIV: st.acc[g] = bin_apply<T, 5, TB>(st.acc[g], bv.v[0]); break;
+        case DE_U_COS: st.acc[g] = un_apply<T, 0, TB>(bv.v[0]); break; // unary operator on a parameter leaf
+        case DE_U_EXP: st.acc[g] = un_apply<T, 1, TB>(bv.v[0]); break;
+        case DE_U_SIN: st.acc[g] = un_apply<T, 2, TB>(bv.v[0]); break;
+        default: av.v[0] = st.acc[g]; av = cold_op<T, 1>(op, av, bv); st.acc[g] = av.v[0]; break;
+        }
     }
     HCHAIN_NEXT(w);
 }
@@ -1451,7 +1545,7 @@ template <typename T, bool PARAMS, bool LOSS = false>
 __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T> a) {
     typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
-    constexpr int BLK = DE_TBLK, TILE = BLK * VW, ROWV = BLK + 1;
+    constexpr int BLK = DE_TBLK, G = TG<T>::G, PLANE = BLK * VW, TILE = PLANE * G, ROWV = BLK * G + 1; // (PLANE samples per plane, G planes per row)
     extern __shared__ __align__(16) unsigned char smem_base[];
     unsigned char *const smem_raw = smem_base + DE_SKIPLIST_BYTES; // [0, DE_SKIPLIST_BYTES): the live-tree list of h_tree_skip; rows behind it
     T *__restrict__ rows = reinterpret_cast<T *>(smem_raw);
@@ -1488,7 +1582,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     if (a.skip_flagged && tid < 64 && tA + tid < tB) f_first = skip_flag_load(a.ok + (a.live_idx ? a.live_idx[tA + tid] : tA + tid), flag_protocol, tm.tile);
     // the 64-bit skip mask travels from wave 0 to the others through the padding vector of LDS row 0 (16 unused bytes behind the
     // DE_TBLK vectors of every row)
-    uint64_t *const mask_slot = reinterpret_cast<uint64_t *>(smem_raw + (size_t)DE_TBLK * 16);
+    uint64_t *const mask_slot = reinterpret_cast<uint64_t *>(smem_raw + (size_t)BLK * G * 16);
     // ... and every wave's copy of the trees' record offsets (the live-tree list below), requested before the X tile as well: with
     // one tree per workgroup (the reference's own call shape, 1 tree x 5e7 samples) a load issued behind the barrier was +50 %
     int32_t co_first = 0;
@@ -1497,17 +1591,18 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         const uint32_t F = (uint32_t)a.F;
         const uint32_t total = (uint32_t)TILE * F;
         if (a.x_vec && base + TILE <= a.N) {
-            // The tile is TILE*F contiguous elements = exactly F 16-byte vectors per thread.  Up to 8 vector
+            // The tile is TILE*F contiguous elements = exactly G*F 16-byte vectors per thread.  Up to 8 vector
             // loads are issued before the first LDS write (few trees per chunk = HBM-bound: memory-level
             // parallelism is what counts there); (sample, feature) of an element by a host-computed
             // reciprocal instead of a run-time division.
             const V *__restrict__ src = reinterpret_cast<const V *>(a.X + base * (int64_t)F);
-            for (uint32_t i0 = 0; i0 < F; i0 += 8) {
+            const uint32_t GF = (uint32_t)G * F;
+            for (uint32_t i0 = 0; i0 < GF; i0 += 8) {
                 V buf[8];
                 DE_UNROLL for (uint32_t u = 0; u < 8; u++)
-                    if (i0 + u < F) buf[u] = src[tid + (i0 + u) * BLK];
+                    if (i0 + u < GF) buf[u] = src[tid + (i0 + u) * BLK];
                 DE_UNROLL for (uint32_t u = 0; u < 8; u++) {
-                    if (i0 + u < F) {
+                    if (i0 + u < GF) {
                         const uint32_t e = (tid + (i0 + u) * BLK) * VW;
                         uint32_t j = a.f_magic ? __umulhi(e, a.f_magic) : e;
                         uint32_t f = e - j * F;
@@ -1539,22 +1634,24 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     } else if (PARAMS) {
         // the class row: byte offsets of this thread's samples' parameter columns (the table has < 2^32 bytes: checked
         // on the host), and the table's address for h_param (see there)
-        uint32_t cv[4] = {0u, 0u, 0u, 0u};
-        DE_UNROLL for (int i = 0; i < VW; i++) {
-            int64_t jj = base + tid * VW + i;
-            jj = jj < last ? jj : last;
-            cv[i] = (uint32_t)((uint64_t)a.ld_params * sizeof(T) *
-                               (uint64_t)clamp_class((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
-                                                                       : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base,
-                                                     a.n_classes));
-        }
-        const uint64_t tab = (uint64_t)(uintptr_t)a.params;
-        unsigned char *crow = smem_raw + a.cls_row_off + tid * 16;
-        if constexpr (sizeof(T) == 4) {
-            *reinterpret_cast<U32x4 *>(crow) = U32x4{cv[0], cv[1], cv[2], cv[3]};
-            *reinterpret_cast<U32x4 *>(crow + DE_ROW_BYTES) = U32x4{(uint32_t)tab, (uint32_t)(tab >> 32), 0u, 0u};
-        } else {
-            *reinterpret_cast<U32x4 *>(crow) = U32x4{cv[0], cv[1], (uint32_t)tab, (uint32_t)(tab >> 32)};
+        DE_UNROLL for (int g = 0; g < G; g++) {
+            uint32_t cv[4] = {0u, 0u, 0u, 0u};
+            DE_UNROLL for (int i = 0; i < VW; i++) {
+                int64_t jj = base + g * PLANE + tid * VW + i;
+                jj = jj < last ? jj : last;
+                cv[i] = (uint32_t)((uint64_t)a.ld_params * sizeof(T) *
+                                   (uint64_t)clamp_class((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj]
+                                                                           : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base,
+                                                         a.n_classes));
+            }
+            const uint64_t tab = (uint64_t)(uintptr_t)a.params;
+            unsigned char *crow = smem_raw + a.cls_row_off + g * DE_PLANE_BYTES + tid * 16;
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<U32x4 *>(crow) = U32x4{cv[0], cv[1], cv[2], cv[3]};
+                *reinterpret_cast<U32x4 *>(crow + RowOf<T>::BYTES) = U32x4{(uint32_t)tab, (uint32_t)(tab >> 32), 0u, 0u};
+            } else {
+                *reinterpret_cast<U32x4 *>(crow) = U32x4{cv[0], cv[1], (uint32_t)tab, (uint32_t)(tab >> 32)};
+            }
         }
     }
     if (a.skip_flagged && tid < 64) { // (all 64 lanes of wave 0 take part in the ballot)
@@ -1571,13 +1668,14 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw + tid * 16;
     // fused loss: this thread's residual targets and weights stay in registers for every tree of
     // the chunk; samples past N get weight 0 (their X columns are clamped copies of the last one)
-    V yv = V{}, wv = V{};
+    HLoss<T> yv, wv;
+    DE_UNROLL for (int g = 0; g < 2; g++) { yv.v[g] = V{}; wv.v[g] = V{}; }
     if constexpr (LOSS) {
-        DE_UNROLL for (int i = 0; i < VW; i++) {
-            const int64_t j = base + tid * VW + i;
+        DE_UNROLL for (int g = 0; g < G; g++) DE_UNROLL for (int i = 0; i < VW; i++) {
+            const int64_t j = base + g * PLANE + tid * VW + i;
             const int64_t jj = j < last ? j : last;
-            yv[i] = a.y[jj];
-            wv[i] = j <= last ? (a.w ? a.w[jj] : T(1)) : T(0);
+            yv.v[g][i] = a.y[jj];
+            wv.v[g][i] = j <= last ? (a.w ? a.w[jj] : T(1)) : T(0);
         }
     }
 
@@ -1632,7 +1730,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         }
         const ConstU4Ptr rec = code + code_off[first];
         HState<T> st;
-        DE_UNROLL for (int i = 0; i < VW; i++) st.acc[i] = T(0);
+        DE_UNROLL for (int g = 0; g < G; g++) DE_UNROLL for (int i = 0; i < VW; i++) st.acc[g][i] = T(0);
         st.poison = typename PoisonOf<T>::type{};
         const int64_t in_tile = a.N - base < (int64_t)TILE ? a.N - base : (int64_t)TILE;
         uint32_t flags = flag_protocol == 1 ? 0u : HF_PLAIN_FLAG;
@@ -1646,7 +1744,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             outp = (uint64_t)(uintptr_t)(a.out + base) - (uint64_t)(uint32_t)(uintptr_t)smem_raw;
         }
         const U32x4 hp = rec[-1], hd = *rec; // the first handler's address is in the record in front (the previous tree's end record / the head record)
-        st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, yv, wv, lds0, rec + 1, outp, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, (uint64_t)(uintptr_t)a.ok,
+        st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, yv.v[0], yv.v[1], wv.v[0], wv.v[1], lds0, rec + 1, outp, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, (uint64_t)(uintptr_t)a.ok,
                                                               ldo_arg, skip, (uint32_t)(t1 - first), flags);
         (void)st;
     }
@@ -1733,7 +1831,7 @@ static void plan_chunks(int64_t n_trees, int64_t n_tiles, int32_t *n_chunks_out,
 void eval_plan(int dtype, int64_t n_trees, int64_t N, int32_t *tile, int32_t *n_chunks, int32_t *trees_per_chunk) {
     int G, BLK;
     eval_geometry(dtype, &G, &BLK);
-    if (eval_uses_threaded()) { G = 1; BLK = TBLK; }
+    if (eval_uses_threaded()) { G = tg_planes(dtype); BLK = TBLK; }
     *tile = BLK * G * (dtype == DE_F32 ? 4 : 2);
     plan_chunks(n_trees, (N + *tile - 1) / *tile, n_chunks, trees_per_chunk);
 }
@@ -1878,7 +1976,7 @@ bool prio_tiles_wanted(int64_t N, int F, int64_t n_trees) {
 template <typename T>
 static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const char **kname) {
     constexpr int VW = VecOf<T>::W;
-    constexpr int TILE = TBLK * VW;
+    constexpr int TILE = TBLK * VW * TG<T>::G;
     KArgs<T> a;
     a.code = e.code;
     a.code_off = e.code_off;
@@ -1927,7 +2025,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         const int np = 3 * a.F;
         hipError_t ps = launch_tile_extremes(sizeof(T) == 4 ? DE_F32 : DE_F64, a.X, a.N, a.ldX, a.F, e.prio_keys, stream);
         if (ps != hipSuccess) return ps;
-        const int tile_samples = TBLK * (16 / (int)sizeof(T)); // 256 / 128: a power of two
+        const int tile_samples = TILE; // 512 / 128: a power of two
         a.prio_shift = 0;
         while ((DE_PRIO_UNIT << a.prio_shift) < tile_samples) ++a.prio_shift;
         a.prio = static_cast<const unsigned long long *>(e.prio_keys);
@@ -1937,10 +2035,10 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     }
     // rows: X, spill slots, then (parametric) the class row [+ the table-pointer row for Float32] of h_param
-    a.cls_row_off = (uint32_t)((size_t)(a.F + a.n_slots) * TROW_BYTES);
+    a.cls_row_off = (uint32_t)((size_t)(a.F + a.n_slots) * RowOf<T>::BYTES);
     const int prm_rows = (e.uses_params && e.n_prows == 0) ? (sizeof(T) == 4 ? 2 : 1) : 0; // (the class row of h_param; staged parameter rows count as slots)
     if (e.uses_params && (uint64_t)e.ld_params * (uint64_t)e.n_classes * sizeof(T) > 0xFFFFFFFFull) return hipErrorInvalidValue; // 32-bit column offsets
-    const size_t lds = (size_t)(a.F + a.n_slots + prm_rows + env_int("DE_EXTRA_LDS_ROWS", 0)) * TROW_BYTES + DE_SKIPLIST_BYTES;
+    const size_t lds = (size_t)(a.F + a.n_slots + prm_rows + env_int("DE_EXTRA_LDS_ROWS", 0)) * RowOf<T>::BYTES + DE_SKIPLIST_BYTES;
     void (*kern)(const KArgs<T>) = e.uses_params ? de_eval_threaded_kernel<T, true> : de_eval_threaded_kernel<T, false>;
     a.y = a.w = nullptr;
     a.partial = nullptr;
@@ -2021,7 +2119,7 @@ hipError_t launch_loss_reduce_tiles(int dtype, const void *partial, int64_t n_co
 
 int32_t loss_segments(int64_t n_tiles) { return (int32_t)(n_tiles < 64 ? (n_tiles < 1 ? 1 : n_tiles) : 64); }
 void loss_scratch_bytes(int dtype, int64_t n_trees, int64_t N, size_t *partial_bytes, size_t *seg_bytes) {
-    const int64_t tile = TBLK * (dtype == DE_F32 ? 4 : 2);
+    const int64_t tile = ttile_samples(dtype);
     const int64_t n_tiles = (N + tile - 1) / tile;
     *partial_bytes = (size_t)n_tiles * (size_t)n_trees * TWAVES * (dtype == DE_F32 ? 4 : 8);
     *seg_bytes = (size_t)loss_segments(n_tiles) * (size_t)n_trees * TWAVES * sizeof(double);

@@ -299,4 +299,4 @@ def test_compaction_of_the_live_trees_changes_nothing_but_the_order(api, dtype, 
     # priority tiles (<= 15 x 256 samples); walking launch: the same here (flag known to every workgroup), so equal shares are fine
     alone = {tag: float((res[tag][0][n - 2] == 12345.0).float().mean()) for tag in ("walk", "compact")}
     print("row of the tree that fails everywhere, share left alone:", alone)
-    assert alone["compact"] >= 1.0 - 15 * 256 / N - 1e-9, alone
+    assert alone["compact"] >= 1.0 - 15 * 512 / N - 1e-9, alone  # (<= 15 priority tiles of <= 512 samples)

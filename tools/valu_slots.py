@@ -176,7 +176,7 @@ def table(obj, ty="float", turbo=False):
     by_short, fast = {}, {}
     for full, code in fns.items():
         # direct-threaded handlers are h_chain<T, &body>: index them by the body's name with the historical h_ prefix
-        m = re.search(r"h_chain<\w+, &de::HState<\w+> de::b_(\w+<[^(]*>)\(", full)
+        m = re.search(r"h_chain<\w+, &de::BState<\w+> de::b_(\w+<[^(]*>)\(", full)
         if m:
             by_short["h_" + m.group(1)] = code
             continue
