@@ -536,7 +536,13 @@ template <> struct PoisonOf<float> { typedef float type __attribute__((ext_vecto
 template <typename T> struct TG { static constexpr int G = sizeof(T) == 4 ? DE_TG : 1; };
 static_assert(DE_TG == TG_F32, "de_kernels.h TG_F32 and DE_TG disagree");
 #define DE_PLANE_BYTES (DE_TBLK * 16u) // bytes between two planes of a row (LDS and output alike)
+#if DE_TG == 1
+// one plane everywhere: NOT a loop (a one-trip loop is unrolled late, and clang's earlier branch-versus-select decisions then differ from
+// straight-line code: the exact-extremum branch of cos / sin and the NaN / signed-zero branches of max / min came out if-converted)
+#define FOR_PLANES if (constexpr int g = 0; true)
+#else
 #define FOR_PLANES DE_UNROLL for (int g = 0; g < TG<T>::G; g++)
+#endif
 // the chain's state: what every handler receives, updates and hands on
 template <typename T> struct __attribute__((packed, aligned(8))) HState {
     typename VecOf<T>::type acc[TG<T>::G];
@@ -598,9 +604,18 @@ template <typename T> using BodyFn = BState<T> (*)(BState<T>, uint32_t, typename
 // ... and, in VECTOR registers, this thread's residual targets and weights of the fused loss (ly, lw: 8 registers every handler passes
 // on untouched, undefined outside a fused-loss launch): the end of a tree forms its loss partial from them (h_tree_end_slow, HF_LOSS).
 #define HL_T typename VecOf<T>::type
+#if DE_TG == 1
+#define HL_PARAMS HL_T ly0, HL_T lw0
+#define HL_PASS ly0, lw0
+#define HL_BOTH(ly, lw) const HLoss<T> ly{{ly0, ly0}}, lw{{lw0, lw0}}
+#define HL_TYPES(V) V, V
+#else
 #define HL_PARAMS HL_T ly0, HL_T ly1, HL_T lw0, HL_T lw1
 #define HL_PASS ly0, ly1, lw0, lw1
-template <typename T> using HandlerFn = HState<T> (*)(HState<T>, HL_T, HL_T, HL_T, HL_T, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t);
+#define HL_BOTH(ly, lw) const HLoss<T> ly{{ly0, ly1}}, lw{{lw0, lw1}}
+#define HL_TYPES(V) V, V, V, V
+#endif
+template <typename T> using HandlerFn = HState<T> (*)(HState<T>, HL_TYPES(HL_T), uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t);
 enum : uint32_t { HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu,
                   HF_SLOW = HF_SLOW_STORE | HF_NO_STORE | (1u << 27), // any of them (and HF_LOSS): the out-of-line end of a tree
                   // plain flag stores (through the caches): always, except under flag protocol 1 (agent scope for every access, an
@@ -714,7 +729,7 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_A
         // sum_j w_j * l(out_j - y_j) over this wave's 64 * VW samples -> one partial per (tile, tree, wave): outp = &partial[tile, 0, wave],
         // ldo = bytes between two trees' partials (weight 0: samples past N)
         T s = T(0);
-        const HLoss<T> ly{{ly0, ly1}}, lw{{lw0, lw1}};
+        HL_BOTH(ly, lw);
         FOR_PLANES DE_UNROLL for (int i = 0; i < VW; i++) {
             const T e = st.acc[g][i] - ly.v[g][i];
             const T l = (flags & HF_LOSS_L1) ? M<T>::abs(e) : e * e;
@@ -1044,7 +1059,8 @@ template <int K, bool TB> __device__ __forceinline__ VecOf<float>::type un_finis
             const DeF2 ra = trig_reduced_f32x2<SIN, TB>(xa, p.ta), rb = trig_reduced_f32x2<SIN, TB>(xb, p.tb); // (common subexpressions of trig_poly)
             const DeF2 za = ra * ra, zb = rb * rb;
             const bool near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(za[0], za[1]), zb[0]), zb[1]) > (0x1.3bd3ccp+1f - 8.0e-4f);
-            if (__ballot(near) != 0ull) {
+            if (__builtin_expect(__ballot(near) != 0ull, 0)) {
+                asm volatile("" ::: "memory"); // a REAL branch: if-converted (the fix computed for every wave, then selected), cos / sin cost 59 instead of 37 VALU instructions
                 sa[0] = trig_extremum_fix(ra[0], sa[0]); sa[1] = trig_extremum_fix(ra[1], sa[1]);
                 sb[0] = trig_extremum_fix(rb[0], sb[0]); sb[1] = trig_extremum_fix(rb[1], sb[1]);
             }
@@ -1054,7 +1070,12 @@ template <int K, bool TB> __device__ __forceinline__ VecOf<float>::type un_finis
         return V{ya[0], ya[1], yb[0], yb[1]};
     }
 }
-#define HFAST_ARGS HState<float> st, VecOf<float>::type ly0, VecOf<float>::type ly1, VecOf<float>::type lw0, VecOf<float>::type lw1, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, \
+#if DE_TG == 1
+#define HFAST_LOSS VecOf<float>::type ly0, VecOf<float>::type lw0
+#else
+#define HFAST_LOSS VecOf<float>::type ly0, VecOf<float>::type ly1, VecOf<float>::type lw0, VecOf<float>::type lw1
+#endif
+#define HFAST_ARGS HState<float> st, HFAST_LOSS, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, \
                    uint64_t skip, uint32_t left, uint32_t flags
 #define HFAST_PASS st, HL_PASS, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags
 #define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, HL_PASS, lds0, code + 1, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
@@ -1744,7 +1765,13 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             outp = (uint64_t)(uintptr_t)(a.out + base) - (uint64_t)(uint32_t)(uintptr_t)smem_raw;
         }
         const U32x4 hp = rec[-1], hd = *rec; // the first handler's address is in the record in front (the previous tree's end record / the head record)
-        st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st, yv.v[0], yv.v[1], wv.v[0], wv.v[1], lds0, rec + 1, outp, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, (uint64_t)(uintptr_t)a.ok,
+        st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st,
+#if DE_TG == 1
+                                                              yv.v[0], wv.v[0],
+#else
+                                                              yv.v[0], yv.v[1], wv.v[0], wv.v[1],
+#endif
+                                                              lds0, rec + 1, outp, hd.x, hd.y, ((uint64_t)hd.w << 32) | hd.z, (uint64_t)(uintptr_t)a.ok,
                                                               ldo_arg, skip, (uint32_t)(t1 - first), flags);
         (void)st;
     }
