@@ -46,7 +46,7 @@ EXPORTS = [
     "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create", "de_program_create_cse",
     "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
     "de_program_n_grad", "de_program_dump", "de_program_verify", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad", "de_eval_loss_grad_by_class",
-    "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_prio_tiles_wanted", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size", "de_dist_world_size",
+    "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_prio_tiles_wanted", "de_program_last_live_trees", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size", "de_dist_world_size",
     "de_dist_broadcast", "de_dist_gather_flags", "de_dist_last_error", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
 ]
 
@@ -128,6 +128,7 @@ def library() -> C.CDLL:
     lib.de_eval_tree_array.argtypes = [vp, C.c_int, vp, i64, vp, i64, vp, i32, i64, u32, vp, vp]
     lib.de_eval_plan.argtypes = [vp, i64, vp]
     lib.de_prio_tiles_wanted.argtypes = [i64, i32, i64]
+    lib.de_program_last_live_trees.argtypes = [vp, C.POINTER(i64)]
     lib.de_dist_unique_id.argtypes = [vp]
     lib.de_dist_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     lib.de_dist_destroy.argtypes = [vp]
@@ -428,6 +429,13 @@ class Population:
         pl = np.zeros(3, dtype=np.int32)
         self.ctx.check(library().de_eval_plan(self._h, N, pl.ctypes.data))
         return dict(tile=int(pl[0]), n_chunks=int(pl[1]), trees_per_chunk=int(pl[2]))
+
+    def last_live_trees(self) -> int:
+        """Trees still live behind the probe launch of the priority tiles in the most recent ``eval`` / ``eval_loss`` (the launch proper
+        ran dense chunks over them); -1 when that call did not compact (small launch, full_eval, early_exit off)."""
+        n = C.c_int64(-1)
+        self.ctx.check(library().de_program_last_live_trees(self._h, C.byref(n)))
+        return int(n.value)
 
     def n_grad(self, tree: int, mode: int) -> int:
         return int(library().de_program_n_grad(self._h, tree, mode))

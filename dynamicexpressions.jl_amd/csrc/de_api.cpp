@@ -106,6 +106,7 @@ struct de_program {
     // (n_trees + 1) + n_trees + 4 ints; null when the program is not threaded
     BoundInstr *d_compact_code = nullptr;
     int32_t *d_compact_ints = nullptr;
+    bool last_compacted = false; // the most recent eval launch compacted its live trees (de_program_last_live_trees)
     BoundInstr *d_gcode = nullptr;      // bound UNFOLDED program on the device (gradient kernels), lazily uploaded
     int32_t *d_gcode_off = nullptr;
     std::vector<BoundInstr> gbcode;
@@ -1066,6 +1067,19 @@ int64_t de_program_n_grad(const de_program_t *p, int64_t tree, int mode) {
     }
 }
 
+int de_program_last_live_trees(de_program_t *p, int64_t *n_live) {
+    if (!p || !n_live) return DE_ERR_INVALID_ARG;
+    *n_live = -1;
+    if (!p->last_compacted || !p->d_compact_ints) return DE_OK;
+    de_ctx *c = p->ctx;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int32_t v = -1;
+    HIP_TRY(c, hipMemcpy(&v, p->d_compact_ints + (2 * (size_t)p->n_trees + 1), sizeof v, hipMemcpyDeviceToHost));
+    *n_live = v;
+    return DE_OK;
+}
+
 int de_prio_tiles_wanted(int64_t N, int32_t n_features, int64_t n_trees) { return prio_tiles_wanted(N, n_features, n_trees) ? 1 : 0; }
 
 int de_eval_plan(const de_program_t *p, int64_t N, int32_t *plan) {
@@ -1478,6 +1492,8 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
     a.compact_code = p->d_compact_code;
     a.compact_ints = p->d_compact_ints;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    a.compacted = &p->last_compacted;
+    p->last_compacted = false;
     HIP_TRY(c, launch_eval(p->dtype, a, c->stream, &c->last_kernel));
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;

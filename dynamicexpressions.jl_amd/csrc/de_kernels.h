@@ -82,6 +82,7 @@ struct EvalArgs {
     // offsets + n_trees tree indices + 4 control words.  Null: the launch proper walks past flagged trees (round 3).
     void *compact_code;
     int32_t *compact_ints;
+    bool *compacted; // out (may be null): this launch compacted its live trees
 };
 constexpr int DE_PRIO_MAX_F = 8; // (the pre-pass keeps 6 registers per feature)
 constexpr int DE_PRIO_UNIT = 64;  // samples per unit of the keys' position field (every kernel's tile is a multiple)

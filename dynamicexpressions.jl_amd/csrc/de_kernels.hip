@@ -623,7 +623,11 @@ enum : uint32_t { HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MAS
                   HF_PLAIN_FLAG = 1u << 28,
                   // fused loss: the end of a tree forms the tree's loss partial of this tile instead of storing the values (h_tree_end_slow);
                   // HF_LOSS_L1 = |e| instead of e^2
-                  HF_LOSS = 1u << 27, HF_LOSS_L1 = 1u << 26 };
+                  HF_LOSS = 1u << 27, HF_LOSS_L1 = 1u << 26,
+                  // ... of a full tile without weights: sum of e^2 / |e| without the per-sample weight selects (14 instead of ~40 VALU instructions
+                  // per tree and wavefront: the fused loss was SLOWER than the eval it replaces, 75 cycles per tree-wave of loss arithmetic
+                  // against one store)
+                  HF_LOSS_PLAIN = 1u << 25 };
 template <typename T> __device__ __forceinline__ HandlerFn<T> arg_next(uint32_t w1, uint64_t w23);
 template <> __device__ __forceinline__ HandlerFn<float> arg_next<float>(uint32_t, uint64_t w23) { return reinterpret_cast<HandlerFn<float>>(w23); }
 template <> __device__ __forceinline__ HandlerFn<double> arg_next<double>(uint32_t w1, uint64_t) {
@@ -730,10 +734,25 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_A
         // ldo = bytes between two trees' partials (weight 0: samples past N)
         T s = T(0);
         HL_BOTH(ly, lw);
-        FOR_PLANES DE_UNROLL for (int i = 0; i < VW; i++) {
-            const T e = st.acc[g][i] - ly.v[g][i];
-            const T l = (flags & HF_LOSS_L1) ? M<T>::abs(e) : e * e;
-            s += lw.v[g][i] != T(0) ? lw.v[g][i] * l : T(0); // weight 0 really excludes the sample (0 * Inf would be NaN)
+        if (flags & HF_LOSS_PLAIN) { // every sample of the tile counts with weight 1
+            FOR_PLANES {
+                const typename VecOf<T>::type e = st.acc[g] - ly.v[g];
+                if (flags & HF_LOSS_L1) {
+                    T a = M<T>::abs(e[0]);
+                    DE_UNROLL for (int i = 1; i < VW; i++) a += M<T>::abs(e[i]);
+                    s += a;
+                } else {
+                    T q = e[0] * e[0];
+                    DE_UNROLL for (int i = 1; i < VW; i++) q = M<T>::fma(e[i], e[i], q);
+                    s += q;
+                }
+            }
+        } else {
+            FOR_PLANES DE_UNROLL for (int i = 0; i < VW; i++) {
+                const T e = st.acc[g][i] - ly.v[g][i];
+                const T l = (flags & HF_LOSS_L1) ? M<T>::abs(e) : e * e;
+                s += lw.v[g][i] != T(0) ? lw.v[g][i] * l : T(0); // weight 0 really excludes the sample (0 * Inf would be NaN)
+            }
         }
         const int lane = (int)(((lds0 - DE_SKIPLIST_BYTES) >> 4) & 63u); // (no work-item id input in a handler)
         s = wave_sum_to_lane63(s, lane);
@@ -1757,7 +1776,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         uint32_t flags = flag_protocol == 1 ? 0u : HF_PLAIN_FLAG;
         uint64_t outp, ldo_arg = ldo;
         if constexpr (LOSS) {
-            flags |= HF_LOSS | (a.loss_kind == DE_LOSS_L1 ? (uint32_t)HF_LOSS_L1 : 0u);
+            flags |= HF_LOSS | (a.loss_kind == DE_LOSS_L1 ? (uint32_t)HF_LOSS_L1 : 0u) | ((full && !a.w) ? (uint32_t)HF_LOSS_PLAIN : 0u);
             outp = (uint64_t)(uintptr_t)(a.partial + ((int64_t)tm.tile * a.n_trees) * TWAVES + __builtin_amdgcn_readfirstlane(tid >> 6)); // (wave-uniform: an SGPR argument)
             ldo_arg = (uint64_t)TWAVES * sizeof(T);
         } else {
@@ -2114,6 +2133,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
             a.code_off = coff;
             a.live_idx = live_idx;
             a.ctrl = ctrl;
+            if (e.compacted) *e.compacted = true;
             blocks = ((a.n_tiles + 7) / 8) * 8 * (int64_t)nc0;
             if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
         }

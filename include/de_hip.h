@@ -387,6 +387,10 @@ int de_eval_plan(const de_program_t *prog, int64_t N, int32_t *plan);
  * launch on the 3 F tiles with the features' extreme values, then the launch proper over the compacted live trees): the
  * library's own thresholds (sample tiles, trees, features; DE_PRIO_MIN_TILES / DE_PRIO_MIN_TREES / DE_NO_PRIO_TILES). */
 int de_prio_tiles_wanted(int64_t N, int32_t n_features, int64_t n_trees);
+/* Trees still live (flag 1) behind the probe launch of the priority tiles in the most recent de_eval / de_eval_loss of this
+ * program that compacted its live trees: *n_live; -1 when that call did not (small launch, DE_OPT_FULL_EVAL, early_exit off).
+ * Blocks until the call has finished.  n_trees - n_live = what the 3 F priority tiles flagged. */
+int de_program_last_live_trees(de_program_t *prog, int64_t *n_live);
 /* Device time of the kernels launched by the most recent de_eval* call on this
  * context, measured with hipEvents recorded on the context's stream.  Blocks
  * until that work has finished. */

@@ -224,3 +224,195 @@ def test_fuzz_loss_gradient_reverse_against_forward(api, monkeypatch):
     assert checked > 3000
     assert bad <= max(3, 0.002 * checked), findings[:10]
     assert flagdiff <= max(3, 0.002 * checked)
+
+
+# ---- the EXIT PATH against the oracle ------------------------------------------------------------------------
+# Launches over >= 512 sample tiles and >= 96 trees run the priority tiles as a probe launch, compact the live trees and run the
+# launch proper over dense chunks (csrc/de_kernels.hip); the fuzzers above use a few thousand samples and never get there.  Forced
+# here on every launch (DE_PRIO_MIN_TILES = DE_PRIO_MIN_TREES = 1): the same differential runs — eval in every option mode, Jacobians
+# in the three modes, ParametricExpression, the fused loss — against the ORACLE, not against the library's own full evaluation.
+def _force_exit_path(monkeypatch):
+    monkeypatch.setenv("DE_PRIO_MIN_TILES", "1")
+    monkeypatch.setenv("DE_PRIO_MIN_TREES", "1")
+
+
+@pytest.mark.parametrize("seed", [261, 262])
+def test_fuzz_exit_path_forced_eval_and_jacobians(api, seed, monkeypatch):
+    _force_exit_path(monkeypatch)
+    tot, totg = FZ.Findings(), FZ.Findings()
+    live = []
+    for rep in range(2):
+        rng = de.synth.Xoshiro256ss(seed * 53 + rep)
+        for dtype in (np.float32, np.float64):
+            F = 2 + (seed + rep) % 5
+            trees = FZ.random_trees(rng, FZ.OPS_HOT, F, dtype, 140, 36, rep)
+            g = np.random.Generator(np.random.PCG64(seed * 3 + rep))
+            N = int(g.choice([2049, 4100, 6007]))  # 9-24 sample tiles: probe launch on <= 3 F of them, then the compacted launch
+            X = np.asfortranarray((g.standard_normal((F, N)) * g.choice([0.5, 1, 3])).astype(dtype))
+            for ec in contexts(api):
+                tot.add(FZ.fuzz_eval(api, trees, FZ.OPS_HOT, X, dtype, ec, label=f"exit path seed {seed} rep {rep} N={N}"))
+            for mode in ("variable", "constant", "both"):
+                totg.add(FZ.fuzz_grad(api, trees, FZ.OPS_HOT, X, dtype, mode, label=f"exit path grad seed {seed} rep {rep} N={N}"))
+            pop = api.Population(trees, FZ.OPS_HOT, dtype, n_features=F)
+            pop.eval(X)
+            live.append((pop.last_live_trees(), len(trees)))
+            pop.close()
+    print("live trees behind the probe launch:", live)
+    assert all(0 <= n < m for n, m in live), live  # the launches really compacted (and flagged something)
+    gate(tot, "hot", f"exit path forced, eval, seed {seed}")
+    gate(totg, "wide", f"exit path forced, Jacobians, seed {seed}")
+
+
+def test_fuzz_exit_path_forced_parametric_and_loss(api, monkeypatch):
+    from oracle import oracle
+    _force_exit_path(monkeypatch)
+    tot = FZ.Findings()
+    for rep in range(2):
+        rng = de.synth.Xoshiro256ss(27100 + rep)
+        for dtype in (np.float32, np.float64):
+            P, F = 2 + rep * 3, 3
+            trees = FZ.random_trees(rng, FZ.OPS_HOT, F, dtype, 120, 27, rep, de.ParametricNode, P)
+            g = np.random.Generator(np.random.PCG64(2710 + rep))
+            N, C = int(g.choice([2500, 5200])), int(g.integers(2, 9))
+            X = np.asfortranarray(g.standard_normal((F, N)).astype(dtype))
+            params = np.asfortranarray((g.standard_normal((P, C)) * 2).astype(dtype))
+            classes = g.integers(1, C + 1, N).astype(np.int64)
+            for ec in contexts(api)[:3]:
+                tot.add(FZ.fuzz_eval(api, trees, FZ.OPS_HOT, X, dtype, ec, params, classes, label=f"exit path param rep {rep}"))
+            for mode in ("constant", "both"):
+                tot.add(FZ.fuzz_grad(api, trees, FZ.OPS_HOT, X, dtype, mode, params, classes, label=f"exit path param grad rep {rep}"))
+    gate(tot, "wide", "exit path forced, ParametricExpression")
+    # the fused loss: sum (tree(X) - y)^2 against the oracle's rows reduced in float64; NaN exactly where the oracle's flag is false
+    for dtype in (np.float32, np.float64):
+        rng = de.synth.Xoshiro256ss(27200)
+        trees = FZ.random_trees(rng, FZ.OPS_HOT, 4, dtype, 150, 30)
+        g = np.random.Generator(np.random.PCG64(2720))
+        N = 4611
+        X = np.asfortranarray(g.standard_normal((4, N)).astype(dtype))
+        y = g.standard_normal(N).astype(dtype)
+        pop = api.Population(trees, FZ.OPS_HOT, dtype, n_features=4)
+        loss, ok = pop.eval_loss(X, y)
+        n_live = pop.last_live_trees()
+        pop.close()
+        assert 0 <= n_live < len(trees)
+        bad = []
+        for t, tree in enumerate(trees):
+            tape, consts = de.flatten(tree, FZ.OPS_HOT, dtype)
+            yo, ok_o = oracle.eval_tree_array(tape, consts, X, elementwise=True)
+            if bool(ok[t]) != ok_o:
+                tol = FZ.parity_tolerance(tree, FZ.OPS_HOT, X, dtype)
+                if not np.isinf(tol).any():
+                    bad.append(f"FLAG tree {t}")
+                continue
+            if not ok_o:
+                assert np.isnan(loss[t]), t
+                continue
+            tol = FZ.parity_tolerance(tree, FZ.OPS_HOT, X, dtype)
+            if np.isinf(tol).any():
+                continue
+            e = yo.astype(np.float64) - y.astype(np.float64)
+            ref = float(np.sum(e * e))
+            bound = float(np.sum(2 * np.abs(e) * tol + tol * tol)) + (1e-5 if dtype == np.float32 else 1e-12) * ref
+            if not np.isfinite(ref) or not np.isfinite(bound):  # a sum of finite squares that overflows the float64 reference or its bound: nothing to compare
+                continue
+            if not abs(float(loss[t]) - ref) <= bound:
+                bad.append(f"LOSS tree {t}: {float(loss[t])} vs {ref} (bound {bound})")
+        assert not bad, bad[:10]
+
+
+def _oracle_rows(trees, ops, X, dtype):
+    """Oracle rows and flags of a population, one tree per host thread (ctypes releases the GIL inside the C call)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    tapes = [de.flatten(t, ops, dtype) for t in trees]
+    with ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 1)) as ex:
+        return list(ex.map(lambda tc: oracle.eval_tree_array(tc[0], tc[1], X, elementwise=True), tapes))
+
+
+def _hand_made(ops):
+    x1, x2 = de.Node(feature=1), de.Node(feature=2)
+    B = {n_: i + 1 for i, n_ in enumerate(ops.binops)}
+    U = {n_: i + 1 for i, n_ in enumerate(ops.unaops)}
+    return [de.Node(U["exp"], de.Node(U["exp"], de.Node(B["*"], x1, de.Node(val=40.0)))),  # overflows on most tiles
+            de.Node(B["/"], de.Node(val=1.0), de.Node(B["-"], x2, x2)),                     # 1 / 0 everywhere
+            de.Node(U["exp"], de.Node(U["exp"], de.Node(B["*"], x1, de.Node(val=0.5)))),    # overflows for x1 > 8.97 only
+            de.Node(B["+"], de.Node(U["cos"], x1), x2)]                                    # always complete
+
+
+def _check_against_oracle(api, trees, ops, X, what):
+    """early exit (default thresholds) == full evaluation == oracle: flags, and the rows of complete trees within the suite's
+    per-sample tolerance model on a subset of the samples (the model costs ~16 float64 re-evaluations per tree) and within 1e-4
+    relative on 99.9 % of ALL samples."""
+    import torch
+    dtype = np.float32
+    n, N = len(trees), X.shape[1]
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda().t()
+    res = {}
+    for full in (True, False):
+        pop = api.Population(trees, ops, dtype, n_features=X.shape[0], eval_context=api.EvalContext(full_eval=full))
+        out, ok = pop.eval(Xd)
+        torch.cuda.synchronize()
+        res[full] = (out.cpu().numpy(), ok.cpu().numpy().astype(bool), pop.last_live_trees())
+        pop.close()
+    (of, kf, _), (oe, ke, n_live) = res[True], res[False]
+    rows = _oracle_rows(trees, ops, X, dtype)
+    ko = np.array([r[1] for r in rows])
+    assert np.array_equal(kf, ke), what
+    ill = 0
+    for t in np.nonzero(ke != ko)[0]:  # a flag may legitimately differ where an overflow is a rounding away
+        tol = FZ.parity_tolerance(trees[t], ops, X[:, ::max(1, N // 65536)], dtype)
+        assert np.isinf(tol).any() or not np.isfinite(rows[t][0]).all(), f"{what}: flag of tree {t} differs from the oracle's"
+        ill += 1
+    assert ill <= max(2, 0.03 * n), (what, ill)
+    assert n_live >= 0, f"{what}: the launch did not take the priority-tile / compaction path"
+    by_prio = (n - n_live) / max(1, int((~ke).sum()))
+    print(f"[{what}] {n} trees, {int((~ke).sum())} incomplete, {n - n_live} of them flagged by the probe launch of the priority tiles ({100 * by_prio:.0f} %)")
+    sub = np.random.Generator(np.random.PCG64(5)).choice(N, 4096, replace=False)
+    for t in np.nonzero(ke & ko)[0]:
+        assert np.array_equal(oe[t].view(np.uint32), of[t].view(np.uint32)), (what, t)
+        y = rows[t][0]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rel = np.where(y != 0, np.abs(oe[t] - y) / np.abs(y), np.abs(oe[t]))
+        tol = FZ.parity_tolerance(trees[t], ops, X[:, sub], dtype)
+        m = np.isfinite(tol)
+        err = np.abs(oe[t][sub].astype(np.float64) - y[sub].astype(np.float64))
+        assert not np.any(err[m] > tol[m]), (what, t, float(np.max(err[m] / tol[m])))
+        if np.mean(m & (tol <= 1e-4 * np.abs(y[sub]))) > 0.99:  # a well-conditioned tree (by the model, on the subset): EVERY sample of the row
+            assert np.mean(rel <= 1e-4) >= 0.995, (what, t, float(np.mean(rel <= 1e-4)))
+    return by_prio
+
+
+def test_exit_path_at_default_thresholds_matches_the_oracle(api):
+    """2^20 + 77 samples x 132 trees with the library's own thresholds (4097 sample tiles: priority tiles, probe launch, compaction):
+    flags and complete rows against the oracle."""
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(128, seed=0xEE21) + _hand_made(ops)
+    X = de.synth.random_X(5, 2**20 + 77, seed=21)
+    assert api.library().de_prio_tiles_wanted(X.shape[1], 5, len(trees)) == 1
+    _check_against_oracle(api, trees, ops, np.asfortranarray(X), "randn X, 2^20 samples")
+
+
+@pytest.mark.parametrize("kind", ["uniform_positive", "lognormal", "constant_column", "nan_inf_planted"])
+def test_priority_tiles_on_non_gaussian_data(api, kind):
+    """The priority tiles were tuned on randn features.  Other data: all-positive uniform, heavy-tailed, a constant
+    column, NaN / Inf planted in X (the pre-pass ranks those first) — flags == full evaluation == oracle, complete rows within
+    tolerance, and the share of incomplete trees the probe launch flags is reported."""
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(156, seed=0xEE22) + _hand_made(ops)
+    N = 2**18 + 5  # 1025 sample tiles
+    g = np.random.Generator(np.random.PCG64(0xEE23))
+    if kind == "uniform_positive":
+        X = g.uniform(0.5, 4.0, (5, N))
+    elif kind == "lognormal":
+        X = g.lognormal(0.0, 1.5, (5, N))
+    elif kind == "constant_column":
+        X = g.standard_normal((5, N))
+        X[2, :] = 1.25
+    else:
+        X = g.standard_normal((5, N))
+        X[0, N - 3] = np.nan
+        X[3, 17] = np.inf
+        X[4, N // 2] = -np.inf
+    X = np.asfortranarray(X.astype(np.float32))
+    assert api.library().de_prio_tiles_wanted(N, 5, len(trees)) == 1
+    _check_against_oracle(api, trees, ops, X, f"{kind} X")
