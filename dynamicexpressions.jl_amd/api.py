@@ -43,7 +43,7 @@ OPT_EARLY_EXIT, OPT_FUSE_DEG1, OPT_FUSE_DEG2, OPT_BUMPER_CHECKS, OPT_TURBO, OPT_
 EXPORTS = [
     "de_abi_version", "de_opcode_table_version", "de_opcode_by_name", "de_opcode_name",
     "de_opcode_degree", "de_status_string", "de_ctx_create", "de_ctx_destroy", "de_ctx_set_stream",
-    "de_ctx_synchronize", "de_ctx_stream", "de_last_error", "de_program_create", "de_program_create_cse",
+    "de_ctx_synchronize", "de_ctx_declare_dataset", "de_ctx_stream", "de_last_error", "de_program_create", "de_program_create_cse",
     "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
     "de_program_n_grad", "de_program_dump", "de_program_verify", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad", "de_eval_loss_grad_by_class",
     "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_prio_tiles_wanted", "de_program_last_live_trees", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size", "de_dist_world_size",
@@ -97,6 +97,7 @@ def library() -> C.CDLL:
     lib.de_ctx_destroy.argtypes = [vp]
     lib.de_ctx_set_stream.argtypes = [vp, vp]
     lib.de_ctx_synchronize.argtypes = [vp]
+    lib.de_ctx_declare_dataset.argtypes = [vp, C.c_int, vp, i64, i64, i32]
     lib.de_ctx_stream.restype = vp
     lib.de_ctx_stream.argtypes = [vp]
     lib.de_last_error.restype = C.c_char_p
@@ -232,6 +233,18 @@ class Context:
 
     def synchronize(self) -> None:
         self.check(library().de_ctx_synchronize(self._h))
+
+    def declare_dataset(self, X, dtype=None) -> None:
+        """``X``: a device tensor ``[F, N]`` (feature index fastest, as ``eval`` takes it) that stays unchanged between calls — the
+        library computes its per-dataset statistics (the priority-tile keys) once instead of in every call; ``None`` withdraws."""
+        lib = library()
+        if X is None:
+            self.check(lib.de_ctx_declare_dataset(self._h, 0, None, 0, 0, 0))
+            return
+        F, N = int(X.shape[0]), int(X.shape[1])
+        ldX = int(X.stride(1)) if hasattr(X, "stride") and callable(X.stride) else F
+        dt = DE_F32 if str(X.dtype).endswith("float32") else DE_F64
+        self.check(lib.de_ctx_declare_dataset(self._h, dt, X.data_ptr(), N, ldX, F))
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float(0)

@@ -53,6 +53,12 @@ struct de_ctx {
     DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2, sGoff, sNg, sY, sW, sLoss, sPartial, sSeg, sDloss, sColOff, sDoff, sPrio;
     DevBuf sBcLoss, sBcDloss, sBcOk, sBcNg, sBcDoff, sBcOut, sBcTiles; // de_eval_loss_grad_by_class
     int nested = 0; // > 0 inside a call made of several inner calls: those do not touch the timing events
+    // de_ctx_declare_dataset: a device-resident X the caller promises not to modify — its priority-tile keys are computed once
+    const void *ds_X = nullptr;
+    int64_t ds_N = 0, ds_ldX = 0;
+    int32_t ds_F = 0;
+    int ds_dtype = -1;
+    DevBuf sPrioDs;
 };
 
 struct de_program {
@@ -387,6 +393,32 @@ int de_ctx_synchronize(de_ctx_t *c) {
     return DE_OK;
 }
 void *de_ctx_stream(de_ctx_t *c) { return c ? c->stream : nullptr; }
+// A dataset that stays as it is between calls (X of a symbolic-regression search: thousands of de_eval* calls on the same matrix):
+// statistics of it — today the 3 F priority-tile keys, a pass over X of 0.11 ms at 10^7 samples — are computed here, once, and every
+// later call on this context whose (X, N, ldX) are the declared ones skips its own pass.  X == NULL withdraws the declaration.
+int de_ctx_declare_dataset(de_ctx_t *c, int dtype, const void *X, int64_t N, int64_t ldX, int32_t n_features) {
+    if (!c) return DE_ERR_INVALID_ARG;
+    c->ds_X = nullptr;
+    if (!X) return DE_OK;
+    if ((dtype != DE_F32 && dtype != DE_F64) || N < 1 || n_features < 1 || ldX < n_features) return fail(c, DE_ERR_INVALID_ARG, "bad dataset shape");
+    if (!is_device_ptr(X)) return fail(c, DE_ERR_INVALID_ARG, "de_ctx_declare_dataset needs a device-resident X (host buffers are staged on every call)");
+    if (n_features > DE_PRIO_MAX_F) return DE_OK; // nothing to cache for such an X (no priority tiles): not an error
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->sPrioDs.reserve((size_t)3 * DE_PRIO_MAX_F * sizeof(unsigned long long)));
+    HIP_TRY(c, launch_tile_extremes(dtype, X, N, ldX, n_features, c->sPrioDs.p, c->stream));
+    c->ds_X = X;
+    c->ds_N = N;
+    c->ds_ldX = ldX;
+    c->ds_F = n_features;
+    c->ds_dtype = dtype;
+    return DE_OK;
+}
+static bool dataset_keys(const de_ctx *c, int dtype, const void *X, int64_t N, int64_t ldX, int32_t F, void **keys) {
+    if (!c->ds_X || c->ds_X != X || c->ds_N != N || c->ds_ldX != ldX || c->ds_F != F || c->ds_dtype != dtype) return false;
+    *keys = c->sPrioDs.p;
+    return true;
+}
+
 const char *de_last_error(de_ctx_t *c) { return c ? c->err.c_str() : "null context"; }
 
 int de_ctx_last_kernel_ms(de_ctx_t *c, float *ms) {
@@ -1489,6 +1521,7 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
     a.loss = lr ? &la : nullptr;
     HIP_TRY(c, c->sPrio.reserve((size_t)3 * DE_PRIO_MAX_F * sizeof(unsigned long long)));
     a.prio_keys = c->sPrio.p;
+    a.prio_keys_ready = !sX.staged && dataset_keys(c, p->dtype, X, N, ldX, p->n_features, &a.prio_keys);
     a.compact_code = p->d_compact_code;
     a.compact_ints = p->d_compact_ints;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -2332,6 +2365,7 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
     g.e.skip_flagged = !(p->options & DE_OPT_FULL_EVAL) && tree_skip_enabled(); // (the gradient entry points always test validity)
     if (c->sPrio.reserve((size_t)3 * DE_PRIO_MAX_F * sizeof(unsigned long long)) == hipSuccess) g.e.prio_keys = c->sPrio.p; // priority tiles (de_kernels.hip)
     g.prio_ready = false;
+    g.e.prio_keys_ready = !sX.staged && g.e.prio_keys && dataset_keys(c, p->dtype, X, N, ldX, p->n_features, &g.e.prio_keys);
     g.e.n_slots = p->n_slots;
     g.e.uses_params = p->uses_params;
     g.e.X = sX.dev;
@@ -2539,6 +2573,7 @@ static int loss_grad_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N
     g.e.skip_flagged = !(p->options & DE_OPT_FULL_EVAL) && tree_skip_enabled(); // (the gradient entry points always test validity)
     if (c->sPrio.reserve((size_t)3 * DE_PRIO_MAX_F * sizeof(unsigned long long)) == hipSuccess) g.e.prio_keys = c->sPrio.p; // priority tiles (de_kernels.hip)
     g.prio_ready = false;
+    g.e.prio_keys_ready = !sX.staged && g.e.prio_keys && dataset_keys(c, p->dtype, X, N, ldX, p->n_features, &g.e.prio_keys);
     g.e.n_slots = p->n_slots;
     g.e.uses_params = p->uses_params;
     g.e.X = sX.dev;

@@ -567,7 +567,7 @@ static hipError_t grad_prio_prepass(int dtype, const GradArgs &a, hipStream_t st
     *with = a;
     with->prio_ready = false;
     if (!a.e.skip_flagged || !a.e.prio_keys || !a.e.X || !prio_tiles_wanted(a.e.N, a.e.F, a.e.n_trees)) return hipSuccess;
-    const hipError_t st = launch_tile_extremes(dtype, a.e.X, a.e.N, a.e.ldX, a.e.F, a.e.prio_keys, stream);
+    const hipError_t st = a.e.prio_keys_ready ? hipSuccess : launch_tile_extremes(dtype, a.e.X, a.e.N, a.e.ldX, a.e.F, a.e.prio_keys, stream);
     if (st == hipSuccess) with->prio_ready = true;
     return st;
 }

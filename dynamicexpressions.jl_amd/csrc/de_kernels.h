@@ -77,6 +77,7 @@ struct EvalArgs {
     bool direct; // feature matrix too wide for the LDS tile: gather features from global memory (flat-switch kernel)
     const LossArgs *loss; // non-null: fused loss instead of the output store (threaded kernel only)
     void *prio_keys;      // device scratch, 3 * DE_PRIO_MAX_F 64-bit keys: the priority tiles of a large early-exit launch (de_kernels.hip de_tile_extremes_kernel); null: none
+    bool prio_keys_ready; // prio_keys already hold the keys of THIS X (de_ctx_declare_dataset: computed once for a dataset that does not change between calls): no pre-pass
     // compaction of the live trees behind the probe launch of the priority tiles (de_kernels.hip de_compact_live_kernel; threaded kernel only):
     // compact_code = room for a second copy of the chained stream INSIDE the same 4 GiB window as `code`, compact_ints = (n_trees + 1) record
     // offsets + n_trees tree indices + 4 control words.  Null: the launch proper walks past flagged trees (round 3).

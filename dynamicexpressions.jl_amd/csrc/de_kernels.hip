@@ -2069,7 +2069,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.n_prio_blocks = a.n_prio = 0;
     if (TBLK == 64 && a.skip_flagged && e.prio_keys && a.F >= 1 && prio_tiles_wanted(a.N, a.F, a.n_trees)) {
         const int np = 3 * a.F;
-        hipError_t ps = launch_tile_extremes(sizeof(T) == 4 ? DE_F32 : DE_F64, a.X, a.N, a.ldX, a.F, e.prio_keys, stream);
+        hipError_t ps = e.prio_keys_ready ? hipSuccess : launch_tile_extremes(sizeof(T) == 4 ? DE_F32 : DE_F64, a.X, a.N, a.ldX, a.F, e.prio_keys, stream);
         if (ps != hipSuccess) return ps;
         const int tile_samples = TILE; // 512 / 128: a power of two
         a.prio_shift = 0;

@@ -63,7 +63,7 @@ extern "C" {
  *          contractual, as in the reference; DE_OPT_FULL_EVAL (new option bit 5) restores full rows;
  *      (b) programs made by de_program_create_cse: the gradient row of a shared constant's FIRST occurrence carries the
  *          total over its occurrences, the rows of the later occurrences are 0 (callers sum the occurrence rows);
- *      (c) new exports: de_dist_world_size, de_prio_tiles_wanted;
+ *      (c) new exports: de_dist_world_size, de_prio_tiles_wanted, de_program_last_live_trees, de_ctx_declare_dataset;
  *      (d) a process may hold contexts on several devices (the handler caches are per device). */
 #define DE_HIP_ABI_VERSION 2
 
@@ -171,6 +171,11 @@ int de_ctx_destroy(de_ctx_t *ctx);
  * de_* call with the caller's current stream (torch.cuda.current_stream(), AMDGPU.stream()). */
 int de_ctx_set_stream(de_ctx_t *ctx, void *stream);
 int de_ctx_synchronize(de_ctx_t *ctx);
+/* Declare a DEVICE-resident feature matrix that does not change between calls (the X of a search: thousands of de_eval* calls on one
+ * matrix): the library computes its per-dataset statistics — the 3 F priority-tile keys of large early-exit launches, one pass over
+ * X — here, once, and every later call on this context with the same (X, N, ldX) skips its own pass.  The caller must re-declare (or
+ * pass X = NULL to withdraw) before it modifies X.  Results never depend on it (the keys only decide which sample tiles run first). */
+int de_ctx_declare_dataset(de_ctx_t *ctx, int dtype, const void *X, int64_t N, int64_t ldX, int32_t n_features);
 void *de_ctx_stream(de_ctx_t *ctx);
 const char *de_last_error(de_ctx_t *ctx); /* text of the last failure on this ctx */
 

@@ -300,3 +300,37 @@ def test_compaction_of_the_live_trees_changes_nothing_but_the_order(api, dtype, 
     alone = {tag: float((res[tag][0][n - 2] == 12345.0).float().mean()) for tag in ("walk", "compact")}
     print("row of the tree that fails everywhere, share left alone:", alone)
     assert alone["compact"] >= 1.0 - 15 * 512 / N - 1e-9, alone  # (<= 15 priority tiles of <= 512 samples)
+
+
+def test_declared_dataset_skips_the_pre_pass_and_changes_nothing(api):
+    """`de_ctx_declare_dataset`: the priority-tile keys of an X that does not change between calls are computed once; eval, fused loss and
+    the gradient entry points then skip their own pass over X.  Same flags, same bits; a different X (or a withdrawn declaration) takes
+    the per-call pass again."""
+    import torch
+    trees, ops = _population(200, seed=0xEE31)
+    N = 2**18 + 9
+    Xa, Xb = _X(N, seed=31), _X(N, seed=32)
+    y = torch.randn(N, device="cuda", dtype=torch.float32)
+    pop = api.Population(trees, ops, np.float32, n_features=5)
+    ref = {}
+    for tag, X in (("a", Xa), ("b", Xb)):
+        ref[tag] = (pop.eval(X), pop.eval_loss(X, y), pop.eval_loss_grad(X, y, variable=False), pop.last_live_trees())
+    torch.cuda.synchronize()
+    pop.ctx.declare_dataset(Xa)
+    for rep in range(2):
+        for tag, X in (("a", Xa), ("b", Xb)):  # b: not the declared matrix -> its own pre-pass
+            (o, k), (l, lk), (l1, d1, k1) = pop.eval(X), pop.eval_loss(X, y), pop.eval_loss_grad(X, y, variable=False)
+            torch.cuda.synchronize()
+            (ro, rk), (rl, rlk), (rl1, rd1, rk1), _ = ref[tag]
+            assert torch.equal(k, rk) and torch.equal(lk, rlk) and torch.equal(k1, rk1)
+            assert torch.equal(o[k.bool()], ro[rk.bool()])
+            assert torch.equal(l[lk.bool()].view(torch.int32), rl[rlk.bool()].view(torch.int32))
+            for t in range(len(trees)):
+                if bool(k1[t]):
+                    assert torch.equal(d1[t].view(torch.int32), rd1[t].view(torch.int32)), t
+    pop.eval(Xa)
+    assert pop.last_live_trees() == ref["a"][3] >= 0
+    pop.ctx.declare_dataset(None)
+    o, k = pop.eval(Xa)
+    assert torch.equal(k, ref["a"][0][1])
+    pop.close()
