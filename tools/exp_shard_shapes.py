@@ -27,7 +27,7 @@ lib = api.library()
 ctx = api.Context(0)
 
 
-def timed(trees, steps=10, warmup=2):
+def timed(trees, steps=30, warmup=3):
     pop = api.Population(trees, ops, np.float32, n_features=5, ctx=ctx)
     out = torch.empty((len(trees), N), device=dev, dtype=torch.float32)
     ok = torch.empty(len(trees), device=dev, dtype=torch.uint8)
