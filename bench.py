@@ -77,6 +77,9 @@ WORKLOADS = {
     "C5Ng": dict(n_trees=1000, N=10**6, parametric=True, per_sample=True, per_sample_grad=True,
                  desc="1000 random 20-node ParametricNode trees, 8 PER-SAMPLE parameters (C = N classes, classes = 1:N), "
                       "5 x 10^6 Float32: eval_tree_array + eval_grad_tree_array(variable=false) per step (BASELINE config 5 read literally)"),
+    "complete": dict(n_trees=1000, N=10**7, complete=True,
+                     desc="1000 COMPLETE random depth<=15 20-node trees (the headline's generator, seed 0xDE0C, rejection-sampled on this X: nothing exits "
+                          "early) x (5 x 10^7) Float32 — the kernel-quality workload (the headline's `complete_only` leg as a workload of its own, for profiling)"),
     "tiny": dict(n_trees=64, N=10**5, desc="64 trees x (5 x 10^5) Float32 (plumbing)"),
 }
 
@@ -367,12 +370,37 @@ def main():
 
     ctx = api.Context(local_rank)
     ec = api.EvalContext(turbo=True) if args.turbo else None
-    pop = api.Population(trees, ops, np.float32, n_features=5, n_params=8 if is_param else 0, eval_context=ec, ctx=ctx)
     g = torch.Generator(device=dev).manual_seed(1)  # same X on every rank (replicated)
     X = torch.randn((N, 5), generator=g, device=dev, dtype=torch.float32).t()  # [5, N] feature-fastest
+    lib = api.library()
+
+    def complete_population(n):
+        """n trees of the generator (seed 0xDE0C) whose evaluation on this X comes out complete; (trees, candidates drawn)"""
+        cand = de.synth.random_population(3 * n, seed=0xDE0C)
+        chosen = []
+        scratch = torch.empty((n, N), device=dev, dtype=torch.float32)
+        for b in range(0, len(cand), n):
+            if len(chosen) >= n:
+                break
+            batch = cand[b:b + n]
+            pop_b = api.Population(batch, ops, np.float32, n_features=5, eval_context=ec, ctx=ctx)
+            okb = torch.empty(len(batch), device=dev, dtype=torch.uint8)
+            ctx.check(lib.de_eval(ctx._h, pop_b._h, X.data_ptr(), N, 5, None, scratch.data_ptr(), N, okb.data_ptr()))
+            torch.cuda.synchronize()
+            chosen += [t for t, k in zip(batch, okb.cpu().numpy()) if k]
+            pop_b.close()
+        del scratch
+        return (chosen[:n] if len(chosen) >= n else None), len(cand)
+
+    if wl.get("complete"):
+        if world != 1:
+            raise SystemExit("workload complete: one GPU")
+        trees, _ = complete_population(len(trees))
+        all_trees = trees
+        total_nodes = sum(de.count_nodes(t) for t in all_trees)
+    pop = api.Population(trees, ops, np.float32, n_features=5, n_params=8 if is_param else 0, eval_context=ec, ctx=ctx)
     out = None if (wl.get("loss") or wl.get("lossgrad")) else torch.empty((len(trees), N), device=dev, dtype=torch.float32)
     ok = torch.empty(len(trees), device=dev, dtype=torch.uint8)
-    lib = api.library()
     is_grad = bool(wl.get("grad"))
     is_loss = bool(wl.get("loss"))
     is_lossgrad = bool(wl.get("lossgrad"))
@@ -550,24 +578,12 @@ def main():
         pop_f.close()
 
     complete_res = None
-    if not args.no_complete_leg and world == 1 and not (is_param or is_grad or is_lossgrad or is_loss):
+    if not args.no_complete_leg and world == 1 and not (is_param or is_grad or is_lossgrad or is_loss) and not wl.get("complete"):
         # COMPLETE TREES ONLY: the same generator (another seed), rejection-sampled on this X to len(trees) trees whose evaluation
         # comes out complete — nothing exits early, every tree-sample is executed.  This is the number that says what the KERNEL
         # does per executed tree-sample; the headline beside it also contains the reference's early exit (config.early_exit).
-        cand = de.synth.random_population(3 * len(trees), seed=0xDE0C)
-        chosen = []
-        for b in range(0, len(cand), len(trees)):
-            if len(chosen) >= len(trees):
-                break
-            batch = cand[b:b + len(trees)]
-            pop_b = api.Population(batch, ops, np.float32, n_features=5, eval_context=ec, ctx=ctx)
-            okb = torch.empty(len(batch), device=dev, dtype=torch.uint8)
-            ctx.check(lib.de_eval(ctx._h, pop_b._h, X.data_ptr(), N, 5, None, out.data_ptr(), N, okb.data_ptr()))
-            torch.cuda.synchronize()
-            chosen += [t for t, k in zip(batch, okb.cpu().numpy()) if k]
-            pop_b.close()
-        if len(chosen) >= len(trees):
-            chosen = chosen[:len(trees)]
+        chosen, n_cand = complete_population(len(trees))
+        if chosen is not None:
             pop_c = api.Population(chosen, ops, np.float32, n_features=5, eval_context=ec, ctx=ctx)
 
             def step_c():
@@ -585,7 +601,7 @@ def main():
             kc = [k for k in kc if k is not None]
             complete_res = dict(ms_per_step=1e3 * el_c / args.steps, kernel_ms_avg=float(np.mean(kc)) if kc else 1e3 * el_c / args.steps,
                                 complete_fraction=float(ok.float().mean().item()), nodes=sum(de.count_nodes(t) for t in chosen),
-                                candidates=len(cand), pop=pop_c, n=len(chosen))
+                                candidates=n_cand, pop=pop_c, n=len(chosen))
 
     declared_res = None
     if world == 1 and not (is_param or is_grad or is_lossgrad or is_loss) and not args.no_complete_leg:

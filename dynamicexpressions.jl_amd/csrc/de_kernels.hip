@@ -28,6 +28,7 @@
 #include <mutex>
 
 #include <cstdlib>
+#include <cstring>
 
 #include "de_bind.h"
 #include "de_device_ops.h"
@@ -1520,10 +1521,22 @@ __global__ void __launch_bounds__(256) de_tile_extremes_kernel(const T *__restri
 // position-independent otherwise; the tree's index travels in its end record.  The launch proper then runs dense chunks over the compact
 // stream (trees flagged later still drop out through the skip mask).  Order only: which trees run where — flags and complete rows cannot
 // change (tests/test_gpu_early_exit.py).  ctrl = {n_live, n_chunks, trees per chunk, 0}.
+// FUSED-LOSS launches also re-name the ENDS of the trees while they re-link them (LossEnds, by value): in the shared stream a tree ends in
+// h_tree_end — or, 85 % of the bench population, in an end-fused last instruction — and both reach the loss epilogue only through their
+// out-of-line detours (flags & HF_SLOW: the full form of the last instruction, then a tail call into h_tree_end_slow).  In the compact stream
+// of a loss launch the last instruction is named in its PLAIN form (plain[k] for endv[k]) and names h_tree_end_slow (`slow_end`) directly.
+struct LossEnds {
+    uint64_t end, slow_end; // h_tree_end, h_tree_end_slow; slow_end == 0: not a loss launch, nothing is re-named
+    uint64_t endv[TOPX_ENDV_COUNT], plain[TOPX_ENDV_COUNT];
+};
+template <bool F32> __device__ __forceinline__ uint64_t rec_next(const U32x4 &r, uint64_t hi) { return F32 ? (((uint64_t)r.w << 32) | r.z) : (hi | r.y); }
+template <bool F32> __device__ __forceinline__ void rec_set_next(U32x4 &r, uint64_t h) {
+    if (F32) { r.z = (uint32_t)h; r.w = (uint32_t)(h >> 32); } else r.y = (uint32_t)h;
+}
 template <bool F32>
 __global__ void __launch_bounds__(1024) de_compact_live_kernel(const U32x4 *__restrict__ code, const int32_t *__restrict__ code_off, const uint8_t *__restrict__ ok,
                                                               int32_t n_trees, U32x4 *__restrict__ ccode, int32_t *__restrict__ coff, int32_t *__restrict__ live_idx,
-                                                              int32_t *__restrict__ ctrl, int64_t n_tiles, int64_t want_blocks, int32_t tpc_max) {
+                                                              int32_t *__restrict__ ctrl, int64_t n_tiles, int64_t want_blocks, int32_t tpc_max, const LossEnds le) {
     __shared__ int32_t wsum[2][16];
     __shared__ int32_t run[2]; // live trees / records placed so far
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1572,10 +1585,23 @@ __global__ void __launch_bounds__(1024) de_compact_live_kernel(const U32x4 *__re
             U32x4 e = code[src + len - 1];
             e.y = hn.y; e.z = hn.z; e.w = hn.w;       // the operand word stays: this tree's index
             ccode[dst + len - 1] = e;
-            if (((F32 ? hdr.y : hdr.z) & DE_HDR_FUSED_END) && len >= 2) { // the end-fused last instruction names it too
+            if (((F32 ? hdr.y : hdr.z) & DE_HDR_FUSED_END) && len >= 2 && !le.slow_end) { // the end-fused last instruction names it too
                 U32x4 q = code[src + len - 2];
                 if (F32) { q.z = hn.z; q.w = hn.w; } else q.y = hn.y;
                 ccode[dst + len - 2] = q;
+            }
+        }
+        if (le.slow_end && len >= 2) { // fused loss: plain last instruction -> h_tree_end_slow (see LossEnds)
+            const uint64_t hi = le.end & 0xFFFFFFFF00000000ull; // (Float64 records carry the low half; all handlers share the high one)
+            U32x4 q = ccode[dst + len - 2];
+            rec_set_next<F32>(q, le.slow_end);
+            ccode[dst + len - 2] = q;
+            if ((F32 ? hdr.y : hdr.z) & DE_HDR_FUSED_END) { // the record in front of the last instruction (>= 2 instructions: never the header) names endv[k]
+                U32x4 f = ccode[dst + len - 3];
+                const uint64_t named = rec_next<F32>(f, hi);
+                DE_UNROLL for (int q2 = 0; q2 < (int)TOPX_ENDV_COUNT; q2++)
+                    if (named == (F32 ? le.endv[q2] : (hi | (uint32_t)le.endv[q2]))) rec_set_next<F32>(f, le.plain[q2]);
+                ccode[dst + len - 3] = f;
             }
         }
     }
@@ -2121,12 +2147,25 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
             int32_t *coff = e.compact_ints, *live_idx = coff + (size_t)e.n_trees + 1, *ctrl = live_idx + e.n_trees;
             const int64_t want_blocks = (int64_t)cu_count() * 4 * 8;
             const int32_t tpc_max = env_int("DE_EVAL_TPC", 64);
+            LossEnds le;
+            std::memset(&le, 0, sizeof le);
+            if (e.loss && env_int("DE_LOSS_PLAIN_ENDS", 1)) {
+                uint64_t table[TOPX_TABLE];
+                const hipError_t ts = eval_handler_table(sizeof(T) == 4 ? DE_F32 : DE_F64, e.turbo, table);
+                if (ts != hipSuccess) return ts;
+                le.end = table[TOPX_END];
+                le.slow_end = table[TOPX_AUX_BASE + 0];
+                for (uint32_t k = 0; k < TOPX_ENDV_COUNT; k++) {
+                    le.endv[k] = table[TOPX_ENDV_BASE + k];
+                    le.plain[k] = k < 12 ? table[BOP_BIN_BASE + 4 * (k / 2) + ((k & 1) ? 3 : 1)] : table[BOP_UN_BASE + 4 * (k - 12) + 1]; // (de_bind.h topx_endv_of, inverted)
+                }
+            }
             if (sizeof(T) == 4)
                 hipLaunchKernelGGL(de_compact_live_kernel<true>, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const U32x4 *>(e.code), e.code_off, e.ok,
-                                   e.n_trees, reinterpret_cast<U32x4 *>(e.compact_code), coff, live_idx, ctrl, a.n_tiles, want_blocks, tpc_max);
+                                   e.n_trees, reinterpret_cast<U32x4 *>(e.compact_code), coff, live_idx, ctrl, a.n_tiles, want_blocks, tpc_max, le);
             else
                 hipLaunchKernelGGL(de_compact_live_kernel<false>, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const U32x4 *>(e.code), e.code_off, e.ok,
-                                   e.n_trees, reinterpret_cast<U32x4 *>(e.compact_code), coff, live_idx, ctrl, a.n_tiles, want_blocks, tpc_max);
+                                   e.n_trees, reinterpret_cast<U32x4 *>(e.compact_code), coff, live_idx, ctrl, a.n_tiles, want_blocks, tpc_max, le);
             const hipError_t cs = hipGetLastError();
             if (cs != hipSuccess) return cs;
             a.code = static_cast<const BoundInstr *>(e.compact_code);
