@@ -633,9 +633,11 @@ def main():
                 b_unit = ((F_FEATURES + 8) * ELEM + 4) / k_eff + ELEM
             elif per_sample:  # ... + the constant-mode Jacobian: X + class id + parameters per chunk of 32 trees, n_grad rows written
                 b_unit = (((F_FEATURES + 8) * ELEM + 4) / k_eff + ELEM) + (((F_FEATURES + 8) * ELEM + 4) / 32 + float(ng_c.mean()) * ELEM)
-            elif by_class:  # eval as above; pullback: X + class id + dY tile per chunk of 32 trees, (1 + n_grad) partials per wave
+            elif by_class:  # eval as above; pullback: X + class id + dY tile per chunk of 32 trees, (1 + n_grad) partials per wave —
+                # written by the sweep kernel AND read back by the fixed-order finish pass (the two-pass reduction is what makes the
+                # result reproducible: both directions are bytes the algorithm needs; round 3 counted the write only)
                 b_unit = ((F_FEATURES * ELEM + 4) / k_eff + ELEM) + ((F_FEATURES * ELEM + 4 + ELEM) / 32
-                                                                     + (1 + float(ng_b.mean())) * 4 * ELEM / 256)
+                                                                     + 2 * (1 + float(ng_b.mean())) * 4 * ELEM / 256)
         elif is_grad:  # X tile staged once per chunk of 32 trees (the K-tile rule of SURVEY.md §8d), x + 5 gradient rows written
             k_eff = 32
             b_unit = F_FEATURES * ELEM / k_eff + (1 + F_FEATURES) * ELEM

@@ -1983,10 +1983,18 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
         std::vector<uint32_t> need((size_t)p->n_trees, 0);
         std::vector<BoundInstr> rv;
         std::vector<uint8_t> rv_col; // rv[k] carries a gradient column word in .lo
+        std::vector<uint32_t> rv_rop; // rop of rv[k]
+        std::vector<BoundInstr> bw;   // a tree's backward records in execution order
+        std::vector<uint32_t> bw_rop;
         std::map<uint32_t, std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> occ; // column -> (leaves, (seen, row))
+        std::map<uint32_t, uint32_t> rop_of_off; // handler offset -> rop id (DE_REV_STATS)
+        uint32_t mk_rop = 0;                     // rop of the record `mk` made last (the emitters below read it)
+        const bool rfuse = !getenv("DE_REV_NO_FUSE"); // fused pairs / triples (de_rev_threaded.hip rh_pushload ...): same bits, fewer dispatches
         auto mk = [&](uint32_t rop, uint32_t y, uint32_t z, uint32_t w) {
             BoundInstr o;
             o.bop = (uint32_t)(table[rop] - base);
+            rop_of_off[o.bop] = rop;
+            mk_rop = rop;
             o.arg = y;
             o.lo = z;
             o.hi = w;
@@ -1996,9 +2004,34 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
             uint32_t n_prows = 0;
             rv.clear();
             rv_col.clear();
+            rv_rop.clear();
             auto alloc = [&](uint32_t n) { const uint32_t r = (PR0 + n_prows) * RB; n_prows += n; return r; };
-            auto F_ = [&](const BoundInstr &o) { p->rtcode.push_back(o); };
-            auto R_ = [&](const BoundInstr &o, bool has_col = false) { rv.push_back(o); rv_col.push_back(has_col ? 1 : 0); }; // pushed in forward order, reversed below
+            uint32_t last_f_rop = 0xFFFFFFFFu; // rop of this tree's last forward record
+            auto F_ = [&](const BoundInstr &o) -> int32_t {
+                const uint32_t rop = mk_rop;
+                if (rfuse && last_f_rop == ROP_PUSH) { // PUSH + the load / unary function of a leaf that starts the next subtree: one record
+                    const uint32_t push_off = p->rtcode.back().arg;
+                    const bool un_leaf = rop >= ROP_UN_BASE && rop < ROP_GEN_BASE && (((rop - ROP_UN_BASE) >> 1) & 1u);
+                    BoundInstr f{0u, 0u, 0u, 0u};
+                    bool fused = false;
+                    if (rop == rop_load(RSRC_LEAF) && push_off < 65536u && o.arg < 65536u) { f = mk(ROP_F_PUSHLOAD_BASE + 0, push_off | (o.arg << 16), 0, 0); fused = true; }
+                    else if (rop == rop_load(RSRC_CONST) && push_off < 65536u) { f = mk(ROP_F_PUSHLOAD_BASE + 1, push_off, o.lo, o.hi); fused = true; }
+                    else if (un_leaf && push_off < 65536u && o.arg < 65536u) {
+                        const uint32_t v = rop - ROP_UN_BASE;
+                        f = mk(rop_pushun((int)(v >> 2), (v & 1u) != 0), push_off | (o.arg << 16), o.lo, 0);
+                        fused = true;
+                    }
+                    if (fused) {
+                        p->rtcode.back() = f;
+                        last_f_rop = 0xFFFFFFFEu;
+                        return (int32_t)p->rtcode.size() - 1;
+                    }
+                }
+                p->rtcode.push_back(o);
+                last_f_rop = rop;
+                return (int32_t)p->rtcode.size() - 1; // (the record that carries o's immediate: de_program_set_consts patches it there)
+            };
+            auto R_ = [&](const BoundInstr &o, bool has_col = false) { rv.push_back(o); rv_col.push_back(has_col ? 1 : 0); rv_rop.push_back(mk_rop); }; // pushed in forward order, reversed below
             // backward of "acc' = op(acc, operand)" whose partial rows (d/d acc, d/d operand) start at pr
             auto back_binary = [&](int pk, uint32_t pr, bool slot, uint32_t slot_byte, uint32_t col) {
                 if (slot) R_(mk(rop_rbin(pk, 0), pk == 0 ? pr : 0, slot_byte, 0));
@@ -2021,8 +2054,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     F_(mk(rop_load(RSRC_LEAF), rowb(row), 0, 0));
                     if (leaf_col(row) != NONE) R_(mk(ROP_R_LEAF, 0, leaf_col(row), 0), true);
                 } else if (b.bop == BOP_LOAD_CONST) {
-                    p->rtsite_of_gb[(size_t)i] = (int32_t)p->rtcode.size();
-                    F_(mk(rop_load(RSRC_CONST), 0, b.lo, b.hi));
+                    p->rtsite_of_gb[(size_t)i] = F_(mk(rop_load(RSRC_CONST), 0, b.lo, b.hi));
                     if (const_col(ord) != NONE) R_(mk(ROP_R_LEAF, 0, const_col(ord), 0), true);
                 } else if (b.bop == BOP_PUSH) {
                     F_(mk(ROP_PUSH, rowb(row), 0, 0));
@@ -2036,8 +2068,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     const uint32_t pr = k >= 3 ? alloc(2) : 0;
                     const int pk = k == 0 ? 1 : (k == 1 ? 2 : (k == 2 ? 3 : 0));
                     if (cst) {
-                        p->rtsite_of_gb[(size_t)i] = (int32_t)p->rtcode.size();
-                        F_(mk(rop_bin(k, RSRC_CONST, chk), pr, b.lo, b.hi));
+                                                p->rtsite_of_gb[(size_t)i] = F_(mk(rop_bin(k, RSRC_CONST, chk), pr, b.lo, b.hi));
                         back_binary(pk, pr, false, 0, const_col(ord));
                     } else {
                         F_(mk(rop_bin(k, is_leaf ? RSRC_LEAF : RSRC_SLOT, chk), rowb(row), pr, 0));
@@ -2073,21 +2104,18 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     else back_binary(0, pr, !is_leaf, rowb(row), is_leaf ? leaf_col(row) : NONE);
                 } else if (b.bop == BOP_GEN_CONST && hot_const_unary && (aux == (uint32_t)DE_B_MAX || aux == (uint32_t)DE_B_MIN)) {
                     const uint32_t pr = alloc(2);
-                    p->rtsite_of_gb[(size_t)i] = (int32_t)p->rtcode.size();
-                    F_(mk(rop_bin(aux == (uint32_t)DE_B_MAX ? 6 : 7, RSRC_CONST, false), pr, b.lo, b.hi));
+                    p->rtsite_of_gb[(size_t)i] = F_(mk(rop_bin(aux == (uint32_t)DE_B_MAX ? 6 : 7, RSRC_CONST, false), pr, b.lo, b.hi));
                     back_binary(0, pr, false, 0, const_col(ord));
                 } else if (b.bop == BOP_GEN_CONST && gun_of(aux) >= 0) {
                     // cos / exp / sin of a constant leaf: load + hot unary handler instead of the generic one
                     const uint32_t pr = alloc(1);
-                    p->rtsite_of_gb[(size_t)i] = (int32_t)p->rtcode.size();
-                    F_(mk(rop_load(RSRC_CONST), 0, b.lo, b.hi));
+                    p->rtsite_of_gb[(size_t)i] = F_(mk(rop_load(RSRC_CONST), 0, b.lo, b.hi));
                     F_(mk(rop_un(gun_of(aux), RSRC_ACC, false), pr, 0, 0));
                     back_unary_leaf(pr, const_col(ord));
                 } else if (b.bop == BOP_GEN_CONST) {
                     const bool unary = aux < (uint32_t)DE_B_ADD;
                     const uint32_t pr = alloc(unary ? 1 : 2);
-                    p->rtsite_of_gb[(size_t)i] = (int32_t)p->rtcode.size();
-                    F_(mk(rop_gen(RSRC_CONST), pr | (aux << 24), b.lo, b.hi));
+                    p->rtsite_of_gb[(size_t)i] = F_(mk(rop_gen(RSRC_CONST), pr | (aux << 24), b.lo, b.hi));
                     if (unary) back_unary_leaf(pr, const_col(ord));
                     else back_binary(0, pr, false, 0, const_col(ord));
                 } else if (b.bop == BOP_GEN_ACC && gun_of(aux) >= 0) {
@@ -2152,6 +2180,8 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
             for (size_t k = 0; k < rv.size(); k++)
                 if (rv_col[k] && (rv[k].lo & ACC)) occ[rv[k].lo & 0xFFFFu].first++;
             uint32_t n_acc = 0;
+            bw.clear();
+            bw_rop.clear();
             for (size_t k = rv.size(); k-- > 0;) { // execution order
                 BoundInstr o = rv[k];
                 if (rv_col[k]) {
@@ -2169,14 +2199,70 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     }
                     o.lo = word;
                 }
-                p->rtcode.push_back(o);
+                bw.push_back(o);
+                bw_rop.push_back(rv_rop[k]);
             }
             if (!ok) break;
+            for (size_t k = 0; k < bw.size();) { // fused backward sequences: [r_un] r_leaf [r_pop]  and  r_bin<PK, column> r_leaf [r_pop]
+                auto is = [&](size_t q, uint32_t rop) { return q < bw.size() && bw_rop[q] == rop; };
+                auto small = [&](size_t q) { return q >= bw.size() || bw[q].arg < 65536u; };
+                if (rfuse && is(k, ROP_R_UN) && is(k + 1, ROP_R_LEAF) && small(k) && (!is(k + 2, ROP_R_POP) || small(k + 2))) {
+                    const bool pop = is(k + 2, ROP_R_POP);
+                    p->rtcode.push_back(mk(rop_leafx(true, pop), bw[k].arg | (pop ? bw[k + 2].arg << 16 : 0u), bw[k + 1].lo, 0));
+                    k += pop ? 3 : 2;
+                } else if (rfuse && is(k, ROP_R_LEAF) && is(k + 1, ROP_R_POP) && small(k + 1)) {
+                    p->rtcode.push_back(mk(rop_leafx(false, true), bw[k + 1].arg << 16, bw[k].lo, 0));
+                    k += 2;
+                } else if (rfuse && k < bw.size() && bw_rop[k] >= ROP_R_BIN_BASE && bw_rop[k] < ROP_R_TERN && ((bw_rop[k] - ROP_R_BIN_BASE) & 1u) && is(k + 1, ROP_R_LEAF) &&
+                           small(k) && (!is(k + 2, ROP_R_POP) || small(k + 2))) {
+                    const bool pop = is(k + 2, ROP_R_POP);
+                    p->rtcode.push_back(mk(rop_bincolx((int)((bw_rop[k] - ROP_R_BIN_BASE) >> 1), pop), bw[k].arg | (pop ? bw[k + 2].arg << 16 : 0u), bw[k].lo, bw[k + 1].lo));
+                    k += pop ? 3 : 2;
+                } else {
+                    p->rtcode.push_back(bw[k]);
+                    k += 1;
+                }
+            }
             if (PR0 + n_prows + n_acc > 0x3FFFu) { ok = false; break; }
             p->rtcode.push_back(mk(ROP_PARAM, 0, 0, 0)); // end record of the backward sweep
             p->rtcode_off[(size_t)t + 1] = (int32_t)p->rtcode.size();
             max_prows = std::max(max_prows, n_prows + n_acc);
             need[(size_t)t] = n_prows + n_acc;
+        }
+        if (getenv("DE_REV_STATS") && ok) { // dispatch classes and adjacent pairs of the two sweeps (what a fusion would save)
+            auto cls = [&](uint32_t off) -> std::string {
+                const uint32_t r = rop_of_off.count(off) ? rop_of_off[off] : 9999u;
+                char buf[48];
+                if (r < 3) snprintf(buf, sizeof buf, "LOAD%c", "LSC"[r]);
+                else if (r == ROP_PUSH) return "PUSH";
+                else if (r == ROP_CHECK) return "CHECK";
+                else if (r >= ROP_BIN_BASE && r < ROP_UN_BASE) snprintf(buf, sizeof buf, "BIN%c", "LSC"[((r - ROP_BIN_BASE) / 2) % 3]);
+                else if (r >= ROP_UN_BASE && r < ROP_GEN_BASE) snprintf(buf, sizeof buf, "UN%c", ((r - ROP_UN_BASE) / 2) % 2 ? 'L' : 'A');
+                else if (r >= ROP_GEN_BASE && r < ROP_TERN) return "GEN";
+                else if (r == ROP_PARAM) return "END";
+                else if (r == ROP_R_UN) return "r_un";
+                else if (r == ROP_R_NEG) return "r_neg";
+                else if (r == ROP_R_POP) return "r_pop";
+                else if (r == ROP_R_LEAF) return "r_leaf";
+                else if (r >= ROP_R_BIN_BASE && r < ROP_R_TERN) snprintf(buf, sizeof buf, "r_bin%s", (r - ROP_R_BIN_BASE) % 2 ? "col" : "slot");
+                else if (r >= ROP_F_PUSHLOAD_BASE && r < ROP_R_LEAFX_BASE) return "PUSH+";
+                else if (r >= ROP_R_LEAFX_BASE && r < ROP_R_BINCOLX_BASE) return "r_leafx";
+                else if (r >= ROP_R_BINCOLX_BASE && r < ROP_COUNT) return "r_bincolx";
+                else return "other";
+                return buf;
+            };
+            std::map<std::string, int64_t> one, two;
+            for (size_t i = 0; i < p->rtcode.size(); i++) {
+                const std::string a = cls(p->rtcode[i].bop);
+                one[a]++;
+                if (i + 1 < p->rtcode.size() && a != "END") two[a + " " + cls(p->rtcode[i + 1].bop)]++;
+            }
+            fprintf(stderr, "DE_REV_STATS: %zu records, %lld trees: %.2f dispatches per tree\n", p->rtcode.size(), (long long)p->n_trees, (double)p->rtcode.size() / (double)p->n_trees);
+            for (auto &kv : one) fprintf(stderr, "  %-10s %8.3f per tree\n", kv.first.c_str(), (double)kv.second / (double)p->n_trees);
+            std::vector<std::pair<int64_t, std::string>> v;
+            for (auto &kv : two) v.push_back({kv.second, kv.first});
+            std::sort(v.rbegin(), v.rend());
+            for (size_t i = 0; i < v.size() && i < 24; i++) fprintf(stderr, "  pair %-22s %8.3f per tree\n", v[i].second.c_str(), (double)v[i].first / (double)p->n_trees);
         }
         // per-wave staging of the column sums: one LDS row, or the widest tree's columns
         int64_t stage_cols = 64;

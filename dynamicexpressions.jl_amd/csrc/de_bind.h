@@ -59,13 +59,21 @@ enum RevOp : uint32_t {
     ROP_R_LEAF,
     ROP_R_BIN_BASE,                    // + PK*2 + OK   (PK: 0 partial rows, 1 ADD, 2 SUB, 3 RSUB; OK: 0 slot, 1 column)
     ROP_R_TERN = ROP_R_BIN_BASE + 8,
-    ROP_COUNT
+    // fused pairs / triples (round 4: 37.8 -> ~28 dispatches per tree of the C5 pullback; de_rev_threaded.hip):
+    ROP_F_PUSHLOAD_BASE,                                // forward  PUSH + LOAD: + 0 leaf, + 1 constant
+    ROP_F_PUSHUN_BASE = ROP_F_PUSHLOAD_BASE + 2,        // forward  PUSH + unary(leaf): + K*2 + checked, K < GUN_K
+    ROP_R_LEAFX_BASE = ROP_F_PUSHUN_BASE + 26,          // backward [r_un] r_leaf [r_pop]: + PRE*2 + POP  (0: unused)
+    ROP_R_BINCOLX_BASE = ROP_R_LEAFX_BASE + 4,          // backward r_bin<PK, column> r_leaf [r_pop]: + PK*2 + POP
+    ROP_COUNT = ROP_R_BINCOLX_BASE + 8
 };
 constexpr uint32_t rop_load(int src) { return ROP_LOAD_BASE + (uint32_t)src; }
 constexpr uint32_t rop_bin(int k, int src, bool chk) { return ROP_BIN_BASE + (uint32_t)((k * 3 + src) * 2 + (chk ? 1 : 0)); }
 constexpr uint32_t rop_un(int k, int src, bool chk) { return ROP_UN_BASE + (uint32_t)((k * 2 + (src == RSRC_LEAF ? 1 : 0)) * 2 + (chk ? 1 : 0)); }
 constexpr uint32_t rop_gen(int src) { return ROP_GEN_BASE + (uint32_t)src; }
 constexpr uint32_t rop_rbin(int pk, int ok) { return ROP_R_BIN_BASE + (uint32_t)(pk * 2 + ok); }
+constexpr uint32_t rop_pushun(int k, bool chk) { return ROP_F_PUSHUN_BASE + (uint32_t)(k * 2 + (chk ? 1 : 0)); }
+constexpr uint32_t rop_leafx(bool pre, bool pop) { return ROP_R_LEAFX_BASE + (pre ? 2u : 0u) + (pop ? 1u : 0u); }
+constexpr uint32_t rop_bincolx(int pk, bool pop) { return ROP_R_BINCOLX_BASE + (uint32_t)(pk * 2 + (pop ? 1 : 0)); }
 
 struct alignas(16) BoundInstr {
     uint32_t bop;

@@ -40,10 +40,10 @@ namespace de {
 namespace DE_RT_NAME(rtm_) { // per-module names: see de_grad_threaded.hip
 
 template <typename T> struct RImm;
-template <> struct RImm<float> { typedef uint32_t type; };
+template <> struct RImm<float> { typedef uint64_t type; }; // (z | w << 32: the fused backward handlers carry a second column word in w)
 template <> struct RImm<double> { typedef uint64_t type; };
 template <typename T> __device__ __forceinline__ T rimm_from(typename RImm<T>::type b);
-template <> __device__ __forceinline__ float rimm_from<float>(uint32_t b) { return __uint_as_float(b); }
+template <> __device__ __forceinline__ float rimm_from<float>(uint64_t b) { return __uint_as_float((uint32_t)b); }
 template <> __device__ __forceinline__ double rimm_from<double>(uint64_t b) { return __longlong_as_double((long long)b); }
 
 // Named GState so that irpatch.py recognises the handlers (return type %"struct.de::<module>::GState").
@@ -62,7 +62,7 @@ template <typename T> using RBodyFn = GState<T> (*)(GState<T>, uint32_t, typenam
 #define RCHAIN_ARGS GState<T> st, ConstU4Ptr code, uint32_t la, typename RImm<T>::type imm, uint64_t hbase
 template <typename T> using RHandlerFn = GState<T> (*)(GState<T>, ConstU4Ptr, uint32_t, typename RImm<T>::type, uint64_t);
 template <typename T> __device__ __forceinline__ typename RImm<T>::type rrec_imm(const U32x4 &w);
-template <> __device__ __forceinline__ uint32_t rrec_imm<float>(const U32x4 &w) { return w.z; }
+template <> __device__ __forceinline__ uint64_t rrec_imm<float>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
 template <> __device__ __forceinline__ uint64_t rrec_imm<double>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
 #define RCHAIN_NEXT(W) [[clang::musttail]] return reinterpret_cast<RHandlerFn<T>>(hbase + (W).x)(st, code + 1, (W).y, rrec_imm<T>(W), hbase)
 #define RH(...) (uint64_t)&rh_chain<T, &__VA_ARGS__>
@@ -272,6 +272,45 @@ template <typename T, RBodyFn<T> BODY> __device__ __noinline__ GState<T> rh_chai
 }
 template <typename T> __device__ __noinline__ GState<T> r_end(GState<T> st, ConstU4Ptr, uint32_t, typename RImm<T>::type, uint64_t) { return st; }
 
+// ---- fused pairs / triples (round 4) --------------------------------------------------------------------------------------------------
+// One sample per lane makes this kernel dispatch-bound (VALU 40 % busy, as many scalar as vector instructions): every dispatch saved is
+// time saved.  The C5 pullback's streams (37.8 dispatches per tree) are full of fixed sequences — every PUSH is followed by the load (or the
+// unary function of a leaf) that starts the next subtree; backwards, every r_pop follows the r_leaf of that load, 1.9 r_leaf per tree follow
+// the r_un of a unary function of a leaf and 1.9 follow an r_bin whose operand is a tracked leaf.  The encoder (de_api.cpp
+// ensure_rev_threaded) emits them as ONE record: la = two 16-bit LDS byte offsets relative to the lane's base (a wave's rows span < 64 KB:
+// checked there), imm = the column word(s).  Same arithmetic in the same order: the same bits as the unfused stream (DE_REV_NO_FUSE=1).
+template <typename T, int SRC> __device__ __noinline__ GState<T> rh_pushload(RCHAIN_ARGS) { // la = push slot | leaf row << 16 (CONST: imm = the constant)
+    const U32x4 w = *code;
+    *RLDS(T, st.lds0 + (la & 0xFFFFu)) = st.x;
+    if constexpr (SRC == RS_CONST) st.x = rimm_from<T>(imm);
+    else {
+        const T v = *RLDS(T, st.lds0 + (la >> 16));
+        rpoison<T>(st.vpoison, v);
+        st.x = v;
+    }
+    RCHAIN_NEXT(w);
+}
+template <typename T, int K, bool CHK> __device__ __noinline__ GState<T> rh_pushun(RCHAIN_ARGS) { // la = push slot | leaf row << 16, imm = partial row
+    const U32x4 w = *code;
+    *RLDS(T, st.lds0 + (la & 0xFFFFu)) = st.x;
+    st = f_un<T, K, RS_LEAF, CHK>(st, st.lds0 + (la >> 16), imm);
+    RCHAIN_NEXT(w);
+}
+template <typename T, bool PRE, bool POP> __device__ __noinline__ GState<T> rh_leafx(RCHAIN_ARGS) { // la = partial row (PRE) | slot row << 16 (POP), imm = column word
+    const U32x4 w = *code;
+    if constexpr (PRE) st.x = st.x * *RLDS(T, st.lds0 + (la & 0xFFFFu));
+    r_reduce<T>(st, st.x, (uint32_t)imm);
+    if constexpr (POP) st.x = *RLDS(T, st.lds0 + (la >> 16));
+    RCHAIN_NEXT(w);
+}
+template <typename T, int PK, bool POP> __device__ __noinline__ GState<T> rh_bincolx(RCHAIN_ARGS) { // r_bin<PK, column>, r_leaf, [r_pop]: imm = column | leaf's column << 32
+    const U32x4 w = *code;
+    st = r_bin<T, PK, 1>(st, st.lds0 + (la & 0xFFFFu), (typename RImm<T>::type)(uint32_t)imm);
+    r_reduce<T>(st, st.x, (uint32_t)(imm >> 32));
+    if constexpr (POP) st.x = *RLDS(T, st.lds0 + (la >> 16));
+    RCHAIN_NEXT(w);
+}
+
 template <typename T> __global__ void de_rev_fill_handlers(uint64_t *t) {
     for (int i = 0; i < (int)ROP_COUNT; i++) t[i] = RH(r_nop<T>);
     t[rop_load(RS_LEAF)] = RH(f_load<T, RS_LEAF>);
@@ -298,6 +337,17 @@ template <typename T> __global__ void de_rev_fill_handlers(uint64_t *t) {
 #define RR(PK) t[rop_rbin(PK, 0)] = RH(r_bin<T, PK, 0>); t[rop_rbin(PK, 1)] = RH(r_bin<T, PK, 1>);
     RR(0) RR(1) RR(2) RR(3)
     t[ROP_R_TERN] = RH(r_tern<T>);
+    t[ROP_F_PUSHLOAD_BASE + 0] = (uint64_t)&rh_pushload<T, RS_LEAF>;
+    t[ROP_F_PUSHLOAD_BASE + 1] = (uint64_t)&rh_pushload<T, RS_CONST>;
+#define RPU(K) t[rop_pushun(K, false)] = (uint64_t)&rh_pushun<T, K, false>; t[rop_pushun(K, true)] = (uint64_t)&rh_pushun<T, K, true>;
+    RPU(0) RPU(1) RPU(2) RPU(3) RPU(4) RPU(5) RPU(6) RPU(7) RPU(8) RPU(9) RPU(10) RPU(11) RPU(12)
+#undef RPU
+    t[rop_leafx(false, true)] = (uint64_t)&rh_leafx<T, false, true>;
+    t[rop_leafx(true, false)] = (uint64_t)&rh_leafx<T, true, false>;
+    t[rop_leafx(true, true)] = (uint64_t)&rh_leafx<T, true, true>;
+#define RBX(PK) t[rop_bincolx(PK, false)] = (uint64_t)&rh_bincolx<T, PK, false>; t[rop_bincolx(PK, true)] = (uint64_t)&rh_bincolx<T, PK, true>;
+    RBX(0) RBX(1) RBX(2) RBX(3)
+#undef RBX
 }
 
 // One sample per lane; wave-major LDS: per wave rows [0,F) = its slice of the X tile, [F, F+n_slots) spill slots
