@@ -502,3 +502,38 @@ def test_fused_loss_grad_empty_and_error_paths(api):
     with pytest.raises(KeyError):
         pop.eval_loss(X, np.zeros(10, np.float32), loss="pullback")  # value-only entry point has no cotangent mode
     pop.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_reverse_kernel_fused_records_give_the_same_bits(api, dtype, monkeypatch):
+    """The reverse-accumulation streams fuse fixed sequences into one record (csrc/de_api.cpp ensure_rev_threaded: PUSH + load / unary of
+    a leaf; [r_un] r_leaf [r_pop]; r_bin<column> r_leaf [r_pop]) — the same arithmetic in the same order: losses, gradients and flags
+    are bit-identical to the unfused streams (DE_REV_NO_FUSE=1), for plain and parametric populations and the three modes."""
+    import dynamicexpressions_jl_amd as de
+    monkeypatch.setenv("DE_LOSS_GRAD_REVERSE", "1")
+    ops = de.synth.BENCH_OPERATORS
+    g = np.random.Generator(np.random.PCG64(77))
+    N = 1500
+    X = np.asfortranarray(g.standard_normal((4, N)).astype(dtype))
+    y = g.standard_normal(N).astype(dtype)
+    w = (g.random(N) > 0.1).astype(dtype)
+    plain = de.synth.random_population(120, seed=0xF05E, dtype=dtype, nfeatures=4)
+    par = de.synth.random_population(120, seed=0xF05F, dtype=dtype, nfeatures=4, node_type=de.ParametricNode, nparams=3)
+    params = np.asfortranarray(g.standard_normal((3, 5)).astype(dtype))
+    classes = g.integers(1, 6, N)
+    it = np.uint32 if dtype == np.float32 else np.uint64
+    for trees, P, kw in ((plain, 0, {}), (par, 3, dict(params=params, classes=classes))):
+        res = {}
+        for nofuse in ("0", "1"):
+            if nofuse == "1":
+                monkeypatch.setenv("DE_REV_NO_FUSE", "1")
+            else:
+                monkeypatch.delenv("DE_REV_NO_FUSE", raising=False)
+            pop = api.Population(trees, ops, dtype, n_features=4, n_params=P)
+            res[nofuse] = [pop.eval_loss_grad(X, y, weights=w, loss=kind, variable=v, **kw) for v in (False, True, "both") for kind in ("L2", "pullback")]
+            pop.close()
+        for (l0, d0, k0), (l1, d1, k1) in zip(res["0"], res["1"]):
+            assert np.array_equal(k0, k1) and 0 < k0.sum() < len(trees)
+            assert np.array_equal(np.asarray(l0).view(it), np.asarray(l1).view(it))
+            for a, b in zip(d0, d1):
+                assert np.array_equal(np.asarray(a).view(it), np.asarray(b).view(it))
