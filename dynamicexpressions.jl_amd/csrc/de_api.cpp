@@ -1940,9 +1940,9 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
     // (20-node trees: 3.5 rows 9.6 ms forward / 17.2 ms reverse; 17 rows 44.6 ms / 30.2 ms).  DE_LOSS_GRAD_REVERSE=1|0 forces.
     const char *env = getenv("DE_LOSS_GRAD_REVERSE");
     if (env && *env == '0') return DE_OK;
-    // a CSE program reads a persistent row from several consumers: the backward sweep would have to ACCUMULATE adjoints into that
-    // row; its handlers store.  Forward duals run such populations.
-    if (p->cse_generic) return DE_OK;
+    // a CSE program (GraphNode trees, §3.1) reads a persistent row from several consumers: the backward sweep ACCUMULATES their adjoints
+    // into that row (round 4: `acc_use` below); DE_REV_NO_SHARED=1 restores round 3's fall-back to forward duals for such populations
+    if (p->cse_generic && getenv("DE_REV_NO_SHARED")) return DE_OK;
     if (!(env && *env == '1')) {
         int64_t total = 0;
         for (int64_t t = 0; t < p->n_trees; t++) total += de_program_n_grad(p, t, mode);
@@ -1986,6 +1986,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
         std::vector<uint32_t> rv_rop; // rop of rv[k]
         std::vector<BoundInstr> bw;   // a tree's backward records in execution order
         std::vector<uint32_t> bw_rop;
+        std::vector<uint8_t> acc_use; // per instruction of the tree: reads a shared row and is not its last reader (adds its adjoint)
         std::map<uint32_t, std::pair<uint32_t, std::pair<uint32_t, uint32_t>>> occ; // column -> (leaves, (seen, row))
         std::map<uint32_t, uint32_t> rop_of_off; // handler offset -> rop id (DE_REV_STATS)
         uint32_t mk_rop = 0;                     // rop of the record `mk` made last (the emitters below read it)
@@ -2032,9 +2033,30 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                 return (int32_t)p->rtcode.size() - 1; // (the record that carries o's immediate: de_program_set_consts patches it there)
             };
             auto R_ = [&](const BoundInstr &o, bool has_col = false) { rv.push_back(o); rv_col.push_back(has_col ? 1 : 0); rv_rop.push_back(mk_rop); }; // pushed in forward order, reversed below
+            // SHARED ROWS.  A slot row is written by a PUSH and normally read once; a GraphNode program reads a persistent row from several
+            // consumers.  Backwards the consumers run in reverse order and the definition's r_pop last: the consumer that runs FIRST in the
+            // backward sweep (the last reader in program order) stores its adjoint contribution into the row, every other one adds to it.
+            // acc_use[i] = instruction i reads a slot row and is NOT that row's last reader before its next PUSH.
+            acc_use.assign((size_t)(p->gbcode_off[(size_t)t + 1] - p->gbcode_off[(size_t)t]), 0);
+            {
+                std::map<uint32_t, int32_t> last_reader; // slot row -> the last instruction seen reading it since its PUSH
+                for (int32_t i = p->gbcode_off[(size_t)t]; i < p->gbcode_off[(size_t)t + 1]; i++) {
+                    const BoundInstr &b = p->gbcode[(size_t)i];
+                    const uint32_t row = b.arg & 0xFFFFFFu;
+                    if (b.bop == BOP_PUSH) { last_reader.erase(row); continue; }
+                    const bool reads_row = b.bop == BOP_LOAD_ROW || b.bop == BOP_GEN_ROW || (b.bop >= BOP_BIN_BASE && b.bop < BOP_BIN_END && !((b.bop - BOP_BIN_BASE) & 2)) ||
+                                           (b.bop >= BOP_UN_BASE && b.bop < BOP_UN_END && ((b.bop - BOP_UN_BASE) & 2));
+                    if (!reads_row || row < (uint32_t)F) continue;
+                    auto it = last_reader.find(row);
+                    if (it != last_reader.end()) acc_use[(size_t)(it->second - p->gbcode_off[(size_t)t])] = 1; // no longer the last reader: it adds
+                    last_reader[row] = i;
+                }
+            }
+            auto accumulates = [&](int32_t i) { return acc_use[(size_t)(i - p->gbcode_off[(size_t)t])] != 0; };
             // backward of "acc' = op(acc, operand)" whose partial rows (d/d acc, d/d operand) start at pr
-            auto back_binary = [&](int pk, uint32_t pr, bool slot, uint32_t slot_byte, uint32_t col) {
-                if (slot) R_(mk(rop_rbin(pk, 0), pk == 0 ? pr : 0, slot_byte, 0));
+            auto back_binary = [&](int pk, uint32_t pr, bool slot, uint32_t slot_byte, uint32_t col, bool add = false) {
+                if (slot && add) R_(mk(ROP_R_BINACC_BASE + (uint32_t)pk, pk == 0 ? pr : 0, slot_byte, 0));
+                else if (slot) R_(mk(rop_rbin(pk, 0), pk == 0 ? pr : 0, slot_byte, 0));
                 else if (col != NONE) R_(mk(rop_rbin(pk, 1), pk == 0 ? pr : 0, col, 0), true);
                 else if (pk == 0) R_(mk(ROP_R_UN, pr, 0, 0));
                 else if (pk == 3) R_(mk(ROP_R_NEG, 0, 0, 0));
@@ -2044,21 +2066,39 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                 if (col != NONE) R_(mk(ROP_R_LEAF, 0, col, 0), true);
                 R_(mk(ROP_R_UN, pr, 0, 0));
             };
+            // backward of "acc' = f(shared row)": the unary partial, then the row's adjoint receives the result
+            auto back_unary_slot = [&](uint32_t pr, uint32_t slot_byte, bool add) {
+                R_(mk(ROP_R_SLOTACC_BASE + (add ? 1u : 0u), slot_byte, 0, 0));
+                R_(mk(ROP_R_UN, pr, 0, 0));
+            };
             for (int32_t i = p->gbcode_off[(size_t)t]; i < p->gbcode_off[(size_t)t + 1] && ok; i++) {
                 const BoundInstr &b = p->gbcode[(size_t)i];
                 const uint32_t row = b.arg & 0xFFFFFFu, aux = b.arg >> 24, ord = b.arg & 0xFFFFu;
                 const bool is_leaf = row < (uint32_t)F;
                 if (b.bop == BOP_CHECK_ROW) continue; // leaf operands are tested where they are read
-                if (b.bop == BOP_LOAD_ROW) {
-                    if (!is_leaf) { ok = false; break; }
+                if (b.bop == BOP_LOAD_ROW && !is_leaf) { // acc = a shared (persistent) row
+                    F_(mk(rop_load(RSRC_SLOT), rowb(row), 0, 0));
+                    R_(mk(ROP_R_SLOTACC_BASE + (accumulates(i) ? 1u : 0u), rowb(row), 0, 0));
+                } else if (b.bop == BOP_LOAD_ROW) {
                     F_(mk(rop_load(RSRC_LEAF), rowb(row), 0, 0));
                     if (leaf_col(row) != NONE) R_(mk(ROP_R_LEAF, 0, leaf_col(row), 0), true);
                 } else if (b.bop == BOP_LOAD_CONST) {
                     p->rtsite_of_gb[(size_t)i] = F_(mk(rop_load(RSRC_CONST), 0, b.lo, b.hi));
                     if (const_col(ord) != NONE) R_(mk(ROP_R_LEAF, 0, const_col(ord), 0), true);
                 } else if (b.bop == BOP_PUSH) {
+                    // A spill is followed by the load that starts the next subtree (the accumulator's value is dead: the backward sweep
+                    // continues with the slot's adjoint).  A SHARED definition that is used at once stays in the accumulator: the next
+                    // instruction reads it, and backwards BOTH adjoints — the accumulator's and the row's — flow into the definition.
+                    bool acc_live = false;
+                    for (int32_t q = i + 1; q < p->gbcode_off[(size_t)t + 1]; q++) {
+                        const BoundInstr &nx = p->gbcode[(size_t)q];
+                        if (nx.bop == BOP_CHECK_ROW || nx.bop == BOP_CHECK_ACC || nx.bop == BOP_PUSH) continue;
+                        const uint32_t nau = nx.arg >> 24;
+                        acc_live = top_reads_acc(nx.bop, nau == (uint32_t)DOP_LOAD ? 0 : de_opcode_degree((int)nau));
+                        break;
+                    }
                     F_(mk(ROP_PUSH, rowb(row), 0, 0));
-                    R_(mk(ROP_R_POP, rowb(row), 0, 0));
+                    R_(mk(acc_live ? (uint32_t)ROP_R_POPADD : (uint32_t)ROP_R_POP, rowb(row), 0, 0));
                 } else if (b.bop == BOP_CHECK_ACC) {
                     F_(mk(ROP_CHECK, 0, 0, 0));
                 } else if (b.bop >= BOP_BIN_BASE && b.bop < BOP_BIN_END) {
@@ -2072,15 +2112,17 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                         back_binary(pk, pr, false, 0, const_col(ord));
                     } else {
                         F_(mk(rop_bin(k, is_leaf ? RSRC_LEAF : RSRC_SLOT, chk), rowb(row), pr, 0));
-                        back_binary(pk, pr, !is_leaf, rowb(row), is_leaf ? leaf_col(row) : NONE);
+                        back_binary(pk, pr, !is_leaf, rowb(row), is_leaf ? leaf_col(row) : NONE, !is_leaf && accumulates(i));
                     }
                 } else if (b.bop >= BOP_UN_BASE && b.bop < BOP_UN_END) {
                     const uint32_t v = b.bop - BOP_UN_BASE;
                     const int k = (int)(v >> 2);
                     const bool from_row = (v & 2) != 0, chk = (v & 1) != 0;
                     const uint32_t pr = alloc(1);
-                    if (from_row) {
-                        if (!is_leaf) { ok = false; break; }
+                    if (from_row && !is_leaf) { // unary function of a shared row
+                        F_(mk(rop_un_slot(k, chk), rowb(row), pr, 0));
+                        back_unary_slot(pr, rowb(row), accumulates(i));
+                    } else if (from_row) {
                         F_(mk(rop_un(k, RSRC_LEAF, chk), rowb(row), pr, 0));
                         back_unary_leaf(pr, leaf_col(row));
                     } else {
@@ -2090,7 +2132,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                 } else if (b.bop == BOP_GEN_ROW && hot_const_unary && (aux == (uint32_t)DE_B_MAX || aux == (uint32_t)DE_B_MIN)) {
                     const uint32_t pr = alloc(2);
                     F_(mk(rop_bin(aux == (uint32_t)DE_B_MAX ? 6 : 7, is_leaf ? RSRC_LEAF : RSRC_SLOT, false), rowb(row), pr, 0));
-                    back_binary(0, pr, !is_leaf, rowb(row), is_leaf ? leaf_col(row) : NONE);
+                    back_binary(0, pr, !is_leaf, rowb(row), is_leaf ? leaf_col(row) : NONE, !is_leaf && accumulates(i));
                 } else if (b.bop == BOP_GEN_ROW && gun_of(aux) >= 0 && is_leaf) {
                     const uint32_t pr = alloc(1);
                     F_(mk(rop_un(gun_of(aux), RSRC_LEAF, false), rowb(row), pr, 0));
@@ -2098,10 +2140,10 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                 } else if (b.bop == BOP_GEN_ROW) {
                     const bool unary = aux < (uint32_t)DE_B_ADD;
                     const uint32_t pr = alloc(unary ? 1 : 2);
-                    if (unary && !is_leaf) { ok = false; break; }
                     F_(mk(rop_gen(is_leaf ? RSRC_LEAF : RSRC_SLOT), rowb(row), pr | (aux << 24), 0));
-                    if (unary) back_unary_leaf(pr, leaf_col(row));
-                    else back_binary(0, pr, !is_leaf, rowb(row), is_leaf ? leaf_col(row) : NONE);
+                    if (unary && !is_leaf) back_unary_slot(pr, rowb(row), accumulates(i));
+                    else if (unary) back_unary_leaf(pr, leaf_col(row));
+                    else back_binary(0, pr, !is_leaf, rowb(row), is_leaf ? leaf_col(row) : NONE, !is_leaf && accumulates(i));
                 } else if (b.bop == BOP_GEN_CONST && hot_const_unary && (aux == (uint32_t)DE_B_MAX || aux == (uint32_t)DE_B_MIN)) {
                     const uint32_t pr = alloc(2);
                     p->rtsite_of_gb[(size_t)i] = F_(mk(rop_bin(aux == (uint32_t)DE_B_MAX ? 6 : 7, RSRC_CONST, false), pr, b.lo, b.hi));
@@ -2160,6 +2202,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
                     }
                 } else if (b.bop == BOP_TERN) {
                     if (is_leaf || b.lo < (uint32_t)F || row > 0xFFFFu || b.lo > 0xFFFFu) { ok = false; break; }
+                    if (p->cse_generic) { ok = false; break; } // (a ternary operator's slot operands may be shared rows: r_tern stores; such populations keep forward duals)
                     const uint32_t pr = alloc(3);
                     const uint32_t rb_ = row + (FE - (uint32_t)F), rc_ = b.lo + (FE - (uint32_t)F);
                     if (rb_ > 0xFFFFu || rc_ > 0xFFFFu) { ok = false; break; }

@@ -64,7 +64,12 @@ enum RevOp : uint32_t {
     ROP_F_PUSHUN_BASE = ROP_F_PUSHLOAD_BASE + 2,        // forward  PUSH + unary(leaf): + K*2 + checked, K < GUN_K
     ROP_R_LEAFX_BASE = ROP_F_PUSHUN_BASE + 26,          // backward [r_un] r_leaf [r_pop]: + PRE*2 + POP  (0: unused)
     ROP_R_BINCOLX_BASE = ROP_R_LEAFX_BASE + 4,          // backward r_bin<PK, column> r_leaf [r_pop]: + PK*2 + POP
-    ROP_COUNT = ROP_R_BINCOLX_BASE + 8
+    // shared (GraphNode) rows, round 4: a persistent slot row read by SEVERAL consumers — the backward sweep accumulates their adjoints
+    ROP_UN_SLOT_BASE = ROP_R_BINCOLX_BASE + 8,          // forward  unary(slot row): + K*2 + checked, K < GUN_K
+    ROP_R_SLOTACC_BASE = ROP_UN_SLOT_BASE + 26,         // backward of "acc = slot" / of unary(slot): + 0 slot = adjoint, + 1 slot += adjoint
+    ROP_R_BINACC_BASE = ROP_R_SLOTACC_BASE + 2,         // backward r_bin<PK, slot> that ADDS to the slot's adjoint: + PK
+    ROP_R_POPADD = ROP_R_BINACC_BASE + 4,               // backward of a PUSH behind which the accumulator stays live (a shared definition used at once): adjoint += slot
+    ROP_COUNT
 };
 constexpr uint32_t rop_load(int src) { return ROP_LOAD_BASE + (uint32_t)src; }
 constexpr uint32_t rop_bin(int k, int src, bool chk) { return ROP_BIN_BASE + (uint32_t)((k * 3 + src) * 2 + (chk ? 1 : 0)); }
@@ -73,6 +78,7 @@ constexpr uint32_t rop_gen(int src) { return ROP_GEN_BASE + (uint32_t)src; }
 constexpr uint32_t rop_rbin(int pk, int ok) { return ROP_R_BIN_BASE + (uint32_t)(pk * 2 + ok); }
 constexpr uint32_t rop_pushun(int k, bool chk) { return ROP_F_PUSHUN_BASE + (uint32_t)(k * 2 + (chk ? 1 : 0)); }
 constexpr uint32_t rop_leafx(bool pre, bool pop) { return ROP_R_LEAFX_BASE + (pre ? 2u : 0u) + (pop ? 1u : 0u); }
+constexpr uint32_t rop_un_slot(int k, bool chk) { return ROP_UN_SLOT_BASE + (uint32_t)(k * 2 + (chk ? 1 : 0)); }
 constexpr uint32_t rop_bincolx(int pk, bool pop) { return ROP_R_BINCOLX_BASE + (uint32_t)(pk * 2 + (pop ? 1 : 0)); }
 
 struct alignas(16) BoundInstr {

