@@ -4,9 +4,11 @@
 // src/EvaluateDerivative.jl (grad_degn_eval :340-365, diff_degn_eval :99-119).
 //
 // Design:
-//  * grid  = sample tiles x tree chunks.  The threaded kernel (the default): a workgroup of DE_TBLK = 128 threads = 2 wave64
-//    owns TILE = 512 consecutive Float32 samples (4 per thread; 256 Float64) and runs a chunk of <= 64 trees as ONE chain of
+//  * grid  = sample tiles x tree chunks.  The threaded kernel (the default): a workgroup is ONE wave64 (DE_TBLK = 64) that owns
+//    TILE = 256 consecutive Float32 samples (4 per lane; 128 Float64) and runs a chunk of <= 64 trees as ONE chain of
 //    direct-threaded handlers; the flat-switch fall-back kernel uses 256 threads = 4 wave64 and G vectors per thread.
+//    Large early-exit launches are three launches: the priority tiles as a probe, the compaction of the live trees
+//    (de_compact_live_kernel), the launch proper over the re-linked stream.
 //  * The X tile ([F, TILE], feature-fastest in HBM) is read ONCE per workgroup with
 //    fully coalesced loads and transposed into LDS as xs[f][sample], so a leaf
 //    read is one conflict-free ds_read_b128 per thread.
