@@ -9,6 +9,6 @@ B="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY 
 C="SQ_IFETCH SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LEVEL_WAVES SQ_CYCLES GRBM_GUI_ACTIVE"
 for P in A B C; do
   eval CN=\$$P
-  rocprofv3 --pmc $CN --output-format csv -d $R/gpurun_out/pmc_$TAG/$P -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-turbo-leg --no-full-eval-leg "$@" > /dev/null 2>&1
+  rocprofv3 --pmc $CN --output-format csv -d $R/gpurun_out/pmc_$TAG/$P -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-turbo-leg --no-full-eval-leg --no-complete-leg "$@" > /dev/null 2>&1
 done
 python $R/tools/pmc_parse.py $R/gpurun_out/pmc_$TAG $R/gpurun_out/pmc_$TAG/summary.txt
