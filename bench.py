@@ -374,11 +374,13 @@ def main():
     X = torch.randn((N, 5), generator=g, device=dev, dtype=torch.float32).t()  # [5, N] feature-fastest
     lib = api.library()
 
+    out_buf = [None]  # the step's output buffer, once it exists: the rejection sampling below evaluates into it instead of a second 40 GB
+
     def complete_population(n):
         """n trees of the generator (seed 0xDE0C) whose evaluation on this X comes out complete; (trees, candidates drawn)"""
         cand = de.synth.random_population(3 * n, seed=0xDE0C)
         chosen = []
-        scratch = torch.empty((n, N), device=dev, dtype=torch.float32)
+        scratch = out_buf[0] if out_buf and out_buf[0] is not None and out_buf[0].shape[0] >= n else torch.empty((n, N), device=dev, dtype=torch.float32)
         for b in range(0, len(cand), n):
             if len(chosen) >= n:
                 break
@@ -400,6 +402,7 @@ def main():
         total_nodes = sum(de.count_nodes(t) for t in all_trees)
     pop = api.Population(trees, ops, np.float32, n_features=5, n_params=8 if is_param else 0, eval_context=ec, ctx=ctx)
     out = None if (wl.get("loss") or wl.get("lossgrad")) else torch.empty((len(trees), N), device=dev, dtype=torch.float32)
+    out_buf[0] = out
     ok = torch.empty(len(trees), device=dev, dtype=torch.uint8)
     is_grad = bool(wl.get("grad"))
     is_loss = bool(wl.get("loss"))
