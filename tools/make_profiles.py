@@ -40,6 +40,17 @@ def one(path_glob):
     return f[0] if f else None
 
 
+def _last_per_kernel(rows, n):
+    """The rows of the last n launches (dispatch ids) of every kernel, all counters of those launches."""
+    ids = collections.defaultdict(list)
+    for r in rows:
+        d = int(r["Dispatch_Id"])
+        if d not in ids[r["Kernel_Name"]]:
+            ids[r["Kernel_Name"]].append(d)
+    keep = {k: set(sorted(v)[-n:]) for k, v in ids.items()}
+    return [r for r in rows if int(r["Dispatch_Id"]) in keep[r["Kernel_Name"]]]
+
+
 def main():
     tag, pre = sys.argv[1], sys.argv[2]
     src = os.path.join(ROOT, "gpurun_out", f"profiles_{tag}")
@@ -79,6 +90,8 @@ def main():
             if 50 * int(r["Grid_Size_X"]) >= gmax[k] and gmax[k] > 64 * 256:  # (>= 2 % of the kernel's largest grid: the launch groups of the reverse / gradient kernels differ in size)
                 by[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         steps = 6  # --steps 5 --warmup 1
+        if wl == "complete":  # the rejection sampling in front of the steps launches the same kernels (3 batches): only the steps count
+            by = collections.defaultdict(list, {k: v[-steps:] for k, v in by.items()})
         e = {"kernels_us_per_step": {k: sum(v) / steps for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1]))},
              "launches_per_step": {k: len(v) / steps for k, v in by.items()},
              "us_per_step_all_de_kernels": sum(sum(v) for v in by.values()) / steps}
@@ -101,6 +114,8 @@ def main():
             for r in rr:
                 gm[r["Kernel_Name"]] = max(gm[r["Kernel_Name"]], int(r["Grid_Size"]))
             rr = [r for r in rr if 50 * int(r["Grid_Size"]) >= gm[r["Kernel_Name"]] and gm[r["Kernel_Name"]] > 64 * 256]
+            if wl == "complete":  # (see above: the last 3 launches of every kernel are the steps)
+                rr = _last_per_kernel(rr, 3)
             tot[c] = sum(float(r["Counter_Value"]) for r in rr) / 3  # --steps 2 --warmup 1
             e[f"{c}_KiB_per_step"] = tot[c]
         if len(tot) == 2:
@@ -112,6 +127,8 @@ def main():
             for r in rr:
                 gm[r["Kernel_Name"]] = max(gm[r["Kernel_Name"]], int(r["Grid_Size"]))
             rr = [r for r in rr if 50 * int(r["Grid_Size"]) >= gm[r["Kernel_Name"]] and gm[r["Kernel_Name"]] > 64 * 256]
+            if wl == "complete":
+                rr = _last_per_kernel(rr, 3)
             sq = collections.defaultdict(lambda: collections.defaultdict(float))
             for r in rr:
                 sq[r["Kernel_Name"].split("(")[0][-70:]][r["Counter_Name"]] += float(r["Counter_Value"]) / 3  # --steps 2 --warmup 1
