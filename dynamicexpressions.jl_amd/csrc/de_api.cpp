@@ -2556,6 +2556,27 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
     }
     if (sOk.staged) HIP_TRY(c, hipMemcpyAsync(ok, sOk.dev, (size_t)p->n_trees, hipMemcpyDeviceToHost, c->stream));
     if (sX.staged || sOut.staged || sGrad.staged || sOk.staged || sPar.staged || sCls.staged) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (g.e.skip_flagged && ((out && sOut.staged) || sGrad.staged)) {
+        // host buffers: rows / Jacobians of incomplete trees were only partly written into staging buffers every program of the context
+        // shares — NaN-fill them (as eval_impl does; src/EvaluationHelpers.jl:56-62 does the same one level up)
+        std::vector<uint8_t> okh;
+        const uint8_t *okp = ok;
+        if (ok_dev) {
+            okh.resize((size_t)p->n_trees);
+            HIP_TRY(c, hipMemcpy(okh.data(), ok, (size_t)p->n_trees, hipMemcpyDeviceToHost));
+            okp = okh.data();
+        }
+        auto fill = [&](void *base, size_t off, size_t n) {
+            if (p->dtype == DE_F32) std::fill_n(static_cast<float *>(base) + off, n, std::nanf(""));
+            else std::fill_n(static_cast<double *>(base) + off, n, std::nan(""));
+        };
+        for (int64_t t = 0; t < p->n_trees; t++) {
+            if (okp[t]) continue;
+            if (out && sOut.staged) fill(out, (size_t)t * (size_t)ld_out, (size_t)N);
+            if (sGrad.staged && diff) fill(grad, (size_t)t * (size_t)ld_out, (size_t)N);
+            else if (sGrad.staged && ng[(size_t)t] > 0) fill(grad, (size_t)goff[(size_t)t], (size_t)ng[(size_t)t] * (size_t)N);
+        }
+    }
     return DE_OK;
 }
 
