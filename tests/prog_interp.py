@@ -68,13 +68,16 @@ TERNARY = {
 }
 
 
-def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noise_eps=0.0, rng=None):
+def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noise_eps=0.0, rng=None, select_log=None):
     """Execute instruction words ([n,4] uint32) on X [F, N].  Returns (out, ok).
 
     ``noise_eps`` > 0 multiplies every operator result by (1 +- u*noise_eps), u uniform in [1/4, 1], with a random sign
     per sample (discrete stochastic arithmetic): the spread of the outputs over a few such runs
     measures how strongly a sample amplifies a one-rounding-error difference between two
-    implementations of the same operator (used for the parity tolerance, helpers.py)."""
+    implementations of the same operator (used for the parity tolerance, helpers.py).
+
+    ``select_log`` (a list) receives, in program order, the operand pair (x, y) of every SELECTING operator (max, min,
+    greater, clamp, max3): helpers.unstable_selections compares the pairs of a clean and of the perturbed runs."""
     dt = X.dtype
     N = X.shape[1]
     acc = np.zeros(N, dtype=dt)
@@ -102,6 +105,9 @@ def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noi
                 bad |= bool(np.any(~np.isfinite(b)))
             if 128 <= op < DOP_LOAD:
                 c2 = stack[F + ((hdr >> 24) & 15)]
+                if select_log is not None and op in (129, 131):
+                    select_log.append((b.astype(np.float64), c2.astype(np.float64)))
+                    select_log.append((_jlmax(b, c2).astype(np.float64) if op == 131 else b.astype(np.float64), acc.astype(np.float64)))
                 acc = TERNARY[op](b, c2, acc).astype(dt)
             else:
                 if op == DOP_LOAD:
@@ -109,6 +115,8 @@ def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noi
                 elif op < 64:
                     acc = UNARY[op](b).astype(dt)
                 else:
+                    if select_log is not None and op in (69, 70, 73, 0xF6):
+                        select_log.append((acc.astype(np.float64), b.astype(np.float64)))
                     acc = BINARY[op](acc, b).astype(dt)
                 if (not early_exit) and (hdr & (1 << 14)):
                     acc = np.where(np.isfinite(b), acc, np.inf).astype(dt)

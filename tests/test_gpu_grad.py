@@ -280,13 +280,15 @@ def test_random_population_diff_vs_oracle(api):
     trees = de.synth.random_population(40, seed=77)
     X = de.synth.random_X(5, 900, seed=3)
     pop = api.Population(trees, ops, np.float32, n_features=5)
-    _, grads, _ = pop.eval_grad(X, True)
+    _, grads, ok_grad = pop.eval_grad(X, True)
+    assert ok_grad.sum() >= 15
     n_ent = n_ill = 0
     for direction in (1, 3, 5):
         out, dout, ok = pop.eval_diff(X, direction)
         assert ok.all()
         for t, tree in enumerate(trees):
-            np.testing.assert_array_equal(dout[t], grads[t][direction - 1])
+            if ok_grad[t]:  # (ABI v2: the host rows of a tree the Jacobian call found incomplete — a non-finite entry in ANY row — are NaN)
+                np.testing.assert_array_equal(dout[t], grads[t][direction - 1])
             tape, consts = de.flatten(tree, ops, np.float32)
             yo, do, _ = oracle.eval_diff_tree_array(tape, consts, X, direction - 1)
             tolg = grad_tolerance(tree, ops, X, np.float32, "variable")[direction - 1]

@@ -164,6 +164,85 @@ def jacobian_findings(seed0, out):
                 pop.close()
 
 
+def gpu_findings(seed0, out):
+    """tests/fuzz/fuzz_gpu.py <seed>: eval values (default context) and Jacobians, both element types."""
+    for rep in range(6):
+        rng = de.synth.Xoshiro256ss(seed0 * 1000 + rep)
+        for ops, F in ((FZ.OPS_HOT, 5), (FZ.OPS_WIDE, 3), (FZ.OPS_HOT, 2)):
+            for dtype in (np.float32, np.float64):
+                trees = FZ.random_trees(rng, ops, F, dtype, 400, 33, rep)
+                g = np.random.Generator(np.random.PCG64(seed0 + rep))
+                N = int(g.integers(1, 1500))
+                X = np.asfortranarray((g.standard_normal((F, N)) * g.choice([0.1, 1, 10])).astype(dtype))
+                if rep % 2:
+                    X[0, N // 2] = np.inf
+                pop = api.Population(trees, ops, dtype, n_features=F)
+                o, ok = pop.eval(X)
+                for t, tree in enumerate(trees):
+                    tape, consts = de.flatten(tree, ops, dtype)
+                    y, ok_el = oracle.eval_tree_array(tape, consts, X, elementwise=True)
+                    if not ok_el or not ok[t]:
+                        continue
+                    tol = parity_tolerance(tree, ops, X, dtype)
+                    m = np.isfinite(y) & np.isfinite(o[t]) & np.isfinite(tol)
+                    err = np.abs(o[t].astype(np.float64) - y.astype(np.float64))
+                    with np.errstate(invalid="ignore", divide="ignore"):
+                        ratio = np.where(m & (tol > 0), err / np.where(tol > 0, tol, 1), 0)
+                    STATS["trees_compared"] += 1
+                    STATS["entries_compared"] += int(m.sum())
+                    if ratio.max() <= 1.0:
+                        continue
+                    j = int(np.argmax(ratio))
+                    leaf = lambda n: mpf(float(dtype(n.val))) if n.constant else mpf(float(X[n.feature - 1, j]))  # noqa: E731
+                    try:
+                        d = truth(tree, ops, leaf, 0, lambda n: None).v
+                        eg, eo = float(abs(mpf(float(o[t][j])) - d)), float(abs(mpf(float(y[j])) - d))
+                    except Exception as e:  # noqa: BLE001
+                        d, eg, eo = None, None, str(e)
+                    rec = dict(kind="value", fuzz=f"fuzz_gpu {seed0} rep {rep}", dtype=np.dtype(dtype).name, tree=de.string_tree(tree, ops)[:240], sample=j,
+                               x=[float(v) for v in X[:, j]], err_over_tol=float(ratio[j]), tol=float(tol[j]), gpu=float(o[t][j]), oracle=float(y[j]),
+                               truth=None if d is None else float(d), gpu_err_over_tol=None if eg is None else eg / float(tol[j]),
+                               oracle_err_over_tol=eo / float(tol[j]) if isinstance(eo, float) else eo)
+                    out.append(rec)
+                    print(json.dumps(rec), flush=True)
+                trees_g = trees[:150]
+                popg = api.Population(trees_g, ops, dtype, n_features=F)
+                for mode in ("variable", "constant", "both"):
+                    variable, omode = FZ.GRAD_MODES[mode]
+                    _, grads, okg = popg.eval_grad(X, variable)
+                    for t, tree in enumerate(trees_g):
+                        tape, consts = de.flatten(tree, ops, dtype)
+                        _, go_, ok_el = oracle.eval_grad_tree_array(tape, consts, X, omode, elementwise=True)
+                        if not ok_el or not okg[t] or go_.size == 0:
+                            continue
+                        tol = grad_tolerance(tree, ops, X, dtype, mode)
+                        if tol is None:
+                            continue
+                        G = np.asarray(grads[t], dtype=np.float64)
+                        err = np.abs(G - go_.astype(np.float64))
+                        with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+                            ratio = np.where(np.isfinite(tol) & (tol > 0), err / np.where(tol > 0, tol, 1), 0)
+                        if not np.isfinite(ratio).all():
+                            ratio = np.nan_to_num(ratio, nan=0.0, posinf=1e300)
+                        if ratio.max() <= 1.0:
+                            continue
+                        k, j = np.unravel_index(np.argmax(ratio), ratio.shape)
+                        try:
+                            d = trace_grad(tree, ops, X, dtype, mode, int(j), int(k))
+                            eg, eo = float(abs(mpf(float(G[k, j])) - d)), float(abs(mpf(float(go_[k, j])) - d))
+                        except Exception as e:  # noqa: BLE001
+                            d, eg, eo = None, None, str(e)
+                        rec = dict(kind="jacobian", fuzz=f"fuzz_gpu {seed0} rep {rep}", dtype=np.dtype(dtype).name, mode=mode, tree=de.string_tree(tree, ops)[:240],
+                                   entry=[int(k), int(j)], x=[float(v) for v in X[:, j]], err_over_tol=float(ratio[k, j]), tol=float(tol[k, j]), gpu=float(G[k, j]),
+                                   oracle=float(go_[k, j]), truth=None if d is None else float(d),
+                                   gpu_err_over_tol=None if eg is None else (eg / float(tol[k, j]) if tol[k, j] > 0 else None),
+                                   oracle_err_over_tol=(eo / float(tol[k, j]) if isinstance(eo, float) and tol[k, j] > 0 else eo))
+                        out.append(rec)
+                        print(json.dumps(rec), flush=True)
+                popg.close()
+                pop.close()
+
+
 def param_findings(seed0, out):
     for rep in range(4):
         rng = de.synth.Xoshiro256ss(seed0 * 77 + rep)
@@ -222,7 +301,7 @@ if __name__ == "__main__":
     found = []
     which = sys.argv[1:] or ["param31", "param32", "jac31", "jac32"]
     for w in which:
-        (param_findings if w.startswith("param") else jacobian_findings)(int(w[-2:]), found)
+        (param_findings if w.startswith("param") else (gpu_findings if w.startswith("gpu") else jacobian_findings))(int(w[-2:]), found)
     print(json.dumps(dict(summary=True, flavours=which, findings=len(found), **STATS,
                           device_is_the_outlier=sum(1 for r in found if isinstance(r.get("gpu_err_over_tol"), float) and isinstance(r.get("oracle_err_over_tol"), float)
                                                     and r["gpu_err_over_tol"] > 1.0 and r["gpu_err_over_tol"] > r["oracle_err_over_tol"]))))
