@@ -78,13 +78,15 @@ template <typename T> struct KArgs {
     // planned them — n_trees / n_chunks / trees_per_chunk above are the host's upper bounds (the grid).  Null: a plain launch.
     const int32_t *live_idx;
     const int32_t *ctrl;
+    // threaded kernel: sample tiles per XCD that run one chunk before the next chunk starts (map_block_grouped); 0 = chunk-fastest (map_block)
+    int32_t map_group;
 };
 
 // Chunk plan of a launch over n trees and n_tiles sample tiles (host: plan_chunks; device: de_compact_live_kernel for the live trees):
 // chunks of <= tpc_max trees, more of them while the grid would not cover the chip `want_blocks` times, never fewer than 8 trees per chunk.
 // nc0 = the chunk count before trees are spread evenly: an upper bound of the final count that is monotone in n.
 __host__ __device__ inline void chunk_plan(int64_t n, int64_t n_tiles, int64_t tpc_max, int64_t want_blocks, int32_t *n_chunks_out, int32_t *tpc_out, int32_t *nc0_out) {
-    if (tpc_max < 1) tpc_max = 64;
+    if (tpc_max < 1) tpc_max = 63;
     int64_t n_chunks = (n + tpc_max - 1) / tpc_max;
     if (n_tiles > 0 && n_tiles * n_chunks < want_blocks) n_chunks = (want_blocks + n_tiles - 1) / n_tiles;
     const int64_t max_chunks = (n + 7) / 8; // >= 8 trees per chunk
@@ -316,6 +318,20 @@ __device__ __forceinline__ TileMap map_block(uint32_t bid, int32_t n_chunks, int
     const uint32_t xcd = bid & 7u, idx = bid >> 3;
     m.chunk = (int32_t)(idx % (uint32_t)n_chunks);
     m.tile = (int64_t)(idx / (uint32_t)n_chunks) * 8 + xcd;
+    m.valid = m.tile < n_tiles;
+    return m;
+}
+
+// The same map with the CHUNK slower than a group of `grp` sample tiles (per XCD): the workgroups resident on a CU at one time then walk
+// ONE record stream (~10 KB for 64 trees) instead of all of them (n_chunks x 10 KB against a 16 KB scalar cache), and a group's X tiles
+// (grp x 5 KB) are still re-served by the XCD's L2 when the next chunk comes round.  grid = ceil(ceil(n_tiles / 8) / grp) * grp * 8 * n_chunks.
+__device__ __forceinline__ TileMap map_block_grouped(uint32_t bid, int32_t n_chunks, int64_t n_tiles, uint32_t grp) {
+    TileMap m;
+    const uint32_t xcd = bid & 7u, idx = bid >> 3;
+    const uint32_t per = grp * (uint32_t)n_chunks;
+    const uint32_t g = idx / per, r = idx - g * per;
+    m.chunk = (int32_t)(r / grp);
+    m.tile = ((int64_t)g * grp + (r - (uint32_t)m.chunk * grp)) * 8 + xcd;
     m.valid = m.tile < n_tiles;
     return m;
 }
@@ -620,7 +636,7 @@ template <typename T> using BodyFn = BState<T> (*)(BState<T>, uint32_t, typename
 #endif
 template <typename T> using HandlerFn = HState<T> (*)(HState<T>, HL_TYPES(HL_T), uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t);
 enum : uint32_t { HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu,
-                  HF_SLOW = HF_SLOW_STORE | HF_NO_STORE | (1u << 27), // any of them (and HF_LOSS): the out-of-line end of a tree
+                  HF_SLOW = 1u << 31, // set with any of HF_SLOW_STORE / HF_NO_STORE / HF_LOSS: the out-of-line end of a tree (the sign bit: ONE scalar compare)
                   // plain flag stores (through the caches): always, except under flag protocol 1 (agent scope for every access, an
                   // experiment: skip_flag_load, de_device_ops.h)
                   HF_PLAIN_FLAG = 1u << 28,
@@ -644,7 +660,14 @@ template <typename T> struct RowOf { static constexpr uint32_t BYTES = (uint32_t
 // `code` points at the record of the NEXT instruction; (la, w1, w23) are this instruction's record
 #define HCHAIN_ARGS HState<T> st, HL_PARAMS, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint64_t skip, uint32_t left, uint32_t flags
 #define HCHAIN_NEXT_AT(W, NEXT) [[clang::musttail]] return arg_next<T>(w1, w23)(st, HL_PASS, lds0, NEXT, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
-#define HCHAIN_NEXT(W) HCHAIN_NEXT_AT(W, code + 1)
+// record address + k records WITHOUT a carry into the high half: the stream lies inside one 4 GiB window (checked where it is allocated,
+// de_api.cpp), so the bump is ONE scalar instruction (s_add_u32) instead of the add / add-with-carry pair — the cheap handlers are bound
+// by their scalar instructions (tools/probe/issue_probe.py: one per ~4 cycles and SIMD; `acc * const` = 6 of them = 24 cycles)
+__device__ __forceinline__ ConstU4Ptr code_at(ConstU4Ptr c, int k) {
+    const uint64_t a = (uint64_t)(uintptr_t)c;
+    return (ConstU4Ptr)(uintptr_t)((a & 0xFFFFFFFF00000000ull) | (uint64_t)((uint32_t)a + (uint32_t)(16 * k)));
+}
+#define HCHAIN_NEXT(W) HCHAIN_NEXT_AT(W, code_at(code, 1))
 // every plane through a body (the planes' instruction sequences are independent: the scheduler interleaves them)
 template <typename T, BodyFn<T> BODY> __device__ __forceinline__ void planes_apply(HState<T> &st, uint32_t a, typename ImmBits<T>::type imm) {
     FOR_PLANES {
@@ -695,16 +718,16 @@ __device__ __forceinline__ bool poison_set(const double &p) { return p != p; }
 // (Round 3's first version followed the headers tree by tree — a dependent scalar-cache round trip per skipped tree, 64 SIMD
 // cycles per skipped tree and wavefront, 0.65 ms of the 7.9 ms headline; tools/exp_skip_cost.py.)
 template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS) { // bit 0 of `skip` = the next tree of the stream, which is skipped
-    const uint32_t n = (uint32_t)__builtin_ctzll(~skip); // the run of skipped trees (>= 1; bits beyond the chunk are 0)
+    const uint32_t n = (uint32_t)__builtin_ctzll(~skip); // the run of skipped trees (>= 1; bit `left` is the sentinel behind the last tree, nothing above it)
     if (n >= left) return st;
     skip >>= n;
     left -= n;
-    const uint32_t r = left - 1u - (uint32_t)__builtin_popcountll(skip >> 1); // live trees after the one the chain goes on with
+    const uint32_t r = left - (uint32_t)__builtin_popcountll(skip >> 1); // live trees after the one the chain goes on with (the count holds the sentinel)
     const uint32_t lo = *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(r * 4u)); // (wave-uniform address)
     const uint64_t hdr = ((uint64_t)(uintptr_t)code & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
     const ConstU4Ptr nh = (ConstU4Ptr)(uintptr_t)hdr; // the tree's header record (the record in front of its first instruction)
     const U32x4 hn = nh[0], w = nh[1];
-    [[clang::musttail]] return arg_next<T>(hn.y, ((uint64_t)hn.w << 32) | hn.z)(st, HL_PASS, lds0, nh + 2, outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, skip, left, flags);
+    [[clang::musttail]] return arg_next<T>(hn.y, ((uint64_t)hn.w << 32) | hn.z)(st, HL_PASS, lds0, code_at(nh, 2), outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, skip, left, flags);
 }
 // the rest of a tree's end: flag byte, last tree of the chunk?, clear the state, on to the next tree (W = its first record,
 // HDR = the address of its header record) unless that one is skipped.  `tree` (a local of the caller) = the tree's index, the
@@ -715,14 +738,21 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS)
         if (flags & HF_PLAIN_FLAG) *reinterpret_cast<__attribute__((address_space(1))) uint8_t *>(okp + tree) = 0; \
         else __hip_atomic_store(reinterpret_cast<__attribute__((address_space(1))) uint8_t *>(okp + tree), (uint8_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* visible to the workgroups that start later */ \
     }                                                                                                        \
-    if (__builtin_expect(left <= 1u, 0)) return st;                                                          \
     /* (the accumulator is left as it is: no tree starts by reading it — de_bind.h top_reads_acc, checked by de_program_verify) */ \
     st.poison = typename PoisonOf<T>::type{};                                                                \
-    left -= 1u;                                                                                              \
-    skip >>= 1;                                                                                              \
-    if (__builtin_expect((skip & 1ull) != 0ull, 0))                                                          \
-        [[clang::musttail]] return h_tree_skip<T>(st, HL_PASS, lds0, HDR, outp, la, w1, w23, okp, ldo, skip, left, flags); \
-    HCHAIN_NEXT_AT(REC, NEXT)
+    {                                                                                                        \
+        /* ONE test for "the next tree is skipped" and "this was the last tree": bit 1 of the mask — a skip bit, or the SENTINEL the   \
+           kernel puts behind the last tree's bit (a chain runs <= 63 trees).  Written as the two scalar instructions it is: from   \
+           `(skip & 2) != 0` the compiler makes a 64-bit and / compare on a copy, and a counter of the trees left costs three more */ \
+        __label__ de_end_special;                                                                            \
+        asm goto("s_bitcmp1_b32 %0, 1\n\ts_cbranch_scc1 %l[de_end_special]" : : "s"((uint32_t)skip) : "scc" : de_end_special); \
+        asm("s_lshr_b64 %0, %0, 1" : "+s"(skip) : : "scc");                                                  \
+        HCHAIN_NEXT_AT(REC, NEXT);                                                                           \
+    de_end_special:;                                                                                         \
+        const uint32_t left_now = 63u - (uint32_t)__builtin_clzll(skip); /* trees left including this one = the sentinel's bit */ \
+        if (left_now <= 1u) return st;                                                                       \
+        [[clang::musttail]] return h_tree_skip<T>(st, HL_PASS, lds0, HDR, outp, la, w1, w23, okp, ldo, skip >> 1, left_now - 1u, flags); \
+    }
 typedef __attribute__((address_space(1))) char *GPtr; // global, not flat: a flat store also ties up lgkmcnt
 // The other ends of a tree (flags & HF_SLOW), out of line so that h_tree_end itself is straight-line code: HF_LOSS (fused loss:
 // the tree's loss partial of this tile), HF_SLOW_STORE (ragged last tile / output rows that are not 16-byte aligned; LDS base = 0:
@@ -760,7 +790,7 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_A
         const int lane = (int)(((lds0 - DE_SKIPLIST_BYTES) >> 4) & 63u); // (no work-item id input in a handler)
         s = wave_sum_to_lane63(s, lane);
         if (lane == 63) *reinterpret_cast<__attribute__((address_space(1))) T *>(row) = s;
-        HTREE_END_TAIL(w, code + 1, code - 1);
+        HTREE_END_TAIL(w, code_at(code, 1), code_at(code, -1));
     }
     if (flags & HF_SLOW_STORE) {
         FOR_PLANES {
@@ -771,16 +801,16 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_A
     } else {
         FOR_PLANES if (st.acc[g][0] == T(123456.789)) *reinterpret_cast<__attribute__((address_space(1))) T *>(row + lds0) = st.acc[g][0];
     }
-    HTREE_END_TAIL(w, code + 1, code - 1);
+    HTREE_END_TAIL(w, code_at(code, 1), code_at(code, -1));
 }
 template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) {
     typedef typename VecOf<T>::type V;
-    if (__builtin_expect((flags & HF_SLOW) != 0u, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, HL_PASS, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags);
+    if (__builtin_expect((int32_t)flags < 0, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, HL_PASS, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags);
     const U32x4 w = *code;
     const uint32_t tree = la; // this IS the end record
-    const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo); // wave-uniform: the store takes it as its scalar base
+    const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * (uint64_t)(uint32_t)ldo); // wave-uniform: the store takes it as its scalar base
     FOR_PLANES *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0 + (uint32_t)g * DE_PLANE_BYTES) = st.acc[g]; // full tile, aligned rows
-    HTREE_END_TAIL(w, code + 1, code - 1);
+    HTREE_END_TAIL(w, code_at(code, 1), code_at(code, -1));
 }
 // The last instruction of a tree and its end in one dispatch (make_chained picks it when the tree finishes in a validity-tested
 // hot operator: ~85 % of the bench population): the body, then what h_tree_end does.  The stream keeps its end record — this
@@ -789,15 +819,15 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) 
 template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain_end(HCHAIN_ARGS) {
     typedef typename VecOf<T>::type V;
     const uint32_t tree = *reinterpret_cast<const DE_CONSTANT uint32_t *>(code); // the end record this handler steps over: its operand word
-    if (__builtin_expect((flags & HF_SLOW) != 0u, 0)) {
+    if (__builtin_expect((int32_t)flags < 0, 0)) {
         planes_apply<T, BODY>(st, lds0 + la, arg_imm<T>(w1, w23));
-        [[clang::musttail]] return h_tree_end_slow<T>(st, HL_PASS, lds0, code + 1, outp, tree, w1, w23, okp, ldo, skip, left, flags);
+        [[clang::musttail]] return h_tree_end_slow<T>(st, HL_PASS, lds0, code_at(code, 1), outp, tree, w1, w23, okp, ldo, skip, left, flags);
     }
     const U32x4 w = code[1];
     planes_apply<T, BODY>(st, lds0 + la, arg_imm<T>(w1, w23));
-    const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);
+    const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * (uint64_t)(uint32_t)ldo);
     FOR_PLANES *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0 + (uint32_t)g * DE_PLANE_BYTES) = st.acc[g];
-    HTREE_END_TAIL(w, code + 2, code);
+    HTREE_END_TAIL(w, code_at(code, 2), code);
 }
 
 template <typename T> __device__ __forceinline__ BState<T> b_load_row(HARGS) { st.acc = *LDSP(T, la); return st; }
@@ -1100,15 +1130,15 @@ template <int K, bool TB> __device__ __forceinline__ VecOf<float>::type un_finis
 #define HFAST_ARGS HState<float> st, HFAST_LOSS, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, \
                    uint64_t skip, uint32_t left, uint32_t flags
 #define HFAST_PASS st, HL_PASS, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags
-#define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, HL_PASS, lds0, code + 1, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
+#define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, HL_PASS, lds0, code_at(code, 1), outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
 // the end of a tree behind a fast-path body: what h_chain_end does (T = float)
 #define HFAST_END_TAIL()                                                                                                    \
     {                                                                                                                       \
         const U32x4 wn = code[1];                                                                                           \
         const uint32_t tree = *reinterpret_cast<const DE_CONSTANT uint32_t *>(code); /* the end record's operand word */      \
-        const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);                                               \
+        const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * (uint64_t)(uint32_t)ldo);                                               \
         FOR_PLANES *reinterpret_cast<__attribute__((address_space(1))) VecOf<float>::type *>(row + lds0 + (uint32_t)g * DE_PLANE_BYTES) = st.acc[g]; \
-        HTREE_END_TAIL(wn, code + 2, code);                                                                                     \
+        HTREE_END_TAIL(wn, code_at(code, 2), code);                                                                                     \
     }
 #define PLANE_ADDR(A, g) ((A) + (uint32_t)(g) * DE_PLANE_BYTES)
 // (the planes of a fast handler: every plane's range test first — one wave-uniform decision for the whole dispatch: a wavefront
@@ -1137,7 +1167,7 @@ template <int K, bool TB> __device__ __noinline__ HState<float> h_un_end_fast(HF
     UnPre p[G];
     bool slow = false;
     FOR_PLANES slow |= un_pretest<K, TB>(st.acc[g], p[g]);
-    if (__builtin_expect(((flags & HF_SLOW) != 0u) | (__ballot(slow) != 0ull), 0)) [[clang::musttail]] return h_chain_end<T, &b_un<T, K, 1, TB>>(HFAST_PASS);
+    if (__builtin_expect(((int32_t)flags < 0) | (__ballot(slow) != 0ull), 0)) [[clang::musttail]] return h_chain_end<T, &b_un<T, K, 1, TB>>(HFAST_PASS);
     FOR_PLANES {
         st.acc[g] = un_finish<K, TB>(st.acc[g], p[g]);
         hpoison<T>(st.poison, st.acc[g]);
@@ -1201,7 +1231,7 @@ template <int K, bool CST> __device__ __noinline__ HState<float> h_div_end_fast(
     if constexpr (CST) {
         bool unsafe = false;
         FOR_PLANES unsafe |= !div_samples_safe(st.acc[g]);
-        if (__builtin_expect((int)((flags & HF_SLOW) != 0u) | (int)(__ballot(unsafe) != 0ull) | (int)!div_const_in_range(w1), 0)) [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 3, false>>(HFAST_PASS);
+        if (__builtin_expect((int)((int32_t)flags < 0) | (int)(__ballot(unsafe) != 0ull) | (int)!div_const_in_range(w1), 0)) [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 3, false>>(HFAST_PASS);
         FOR_PLANES st.acc[g] = div_const<K>(st.acc[g], w1);
     } else {
         V num[G], den[G];
@@ -1212,7 +1242,7 @@ template <int K, bool CST> __device__ __noinline__ HState<float> h_div_end_fast(
             den[g] = K == 4 ? b : st.acc[g];
             unsafe |= !div_operands_safe(num[g], den[g]);
         }
-        if (__builtin_expect(((flags & HF_SLOW) != 0u) | (__ballot(unsafe) != 0ull), 0))
+        if (__builtin_expect(((int32_t)flags < 0) | (__ballot(unsafe) != 0ull), 0))
             [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 1, false>>(HFAST_PASS);
         FOR_PLANES st.acc[g] = div_safe(num[g], den[g]);
     }
@@ -1636,7 +1666,8 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         tm.chunk = (int32_t)(blockIdx.x % (uint32_t)a.n_chunks);
         tm.valid = tm.tile < a.n_tiles;
         flag_protocol = 1;
-    } else tm = map_block(blockIdx.x - a.n_prio_blocks, n_chunks, a.n_tiles);
+    } else tm = a.map_group > 0 ? map_block_grouped(blockIdx.x - a.n_prio_blocks, n_chunks, a.n_tiles, (uint32_t)a.map_group)
+                                : map_block(blockIdx.x - a.n_prio_blocks, n_chunks, a.n_tiles);
     if (!tm.valid) return;
     const int tid = threadIdx.x;
     const int64_t base = tm.tile * TILE;
@@ -1752,7 +1783,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     // A chunk runs in sub-chunks of <= 64 trees: the flags of a sub-chunk are read when it starts (one 64-bit ballot; the later
     // ones see what other workgroups found in the meantime), then its trees run as ONE chain.  Without the early exit the whole
     // chunk is one sub-chunk.
-    const int sub = a.skip_flagged ? 64 : (tB - tA);
+    const int sub = 63; // (a chain runs <= 63 trees: bit (trees of the chain) of `skip` is the sentinel HTREE_END_TAIL tests; without the early exit the sub-chunks cost nothing)
     for (int t0 = tA; t0 < tB; t0 += sub) {
     const int t1 = t0 + sub < tB ? t0 + sub : tB;
     // the trees of this sub-chunk whose flag is already 0 (bit i: tree t0 + i): found incomplete by a workgroup that ran earlier
@@ -1773,13 +1804,14 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         { // (the first sub-chunk's mask was written before the barrier behind the X staging)
             const uint64_t m = *mask_slot;
             skip = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+            skip &= (1ull << (t1 - t0)) - 1ull; // (the first mask holds the flags of 64 trees: the 64th belongs to the next sub-chunk)
         }
         {
             // the live trees' header addresses, in reverse order (see h_tree_skip); every wave writes the whole list (same values):
             // a wave reads only what it wrote itself, no barrier
             const int i = t0 + (tid & 63);
             if (i < t1 && !((skip >> (tid & 63)) & 1ull)) {
-                const uint32_t r = (uint32_t)__builtin_popcountll((~skip & ((t1 - t0) >= 64 ? ~0ull : ((1ull << (t1 - t0)) - 1ull))) >> 1 >> (tid & 63));
+                const uint32_t r = (uint32_t)__builtin_popcountll((~skip & ((1ull << (t1 - t0)) - 1ull)) >> 1 >> (tid & 63));
                 const uint64_t hdr = (uint64_t)(uintptr_t)(a.code + (t0 == tA ? co_first : a.code_off[i]) - 1);
                 reinterpret_cast<uint32_t *>(smem_base)[r] = (uint32_t)hdr;
             }
@@ -1796,6 +1828,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             skip >>= n;
             if (first >= t1) continue;
         }
+        skip |= 1ull << (t1 - first); // the sentinel behind the last tree of this chain (t1 - first <= 63)
         const ConstU4Ptr rec = code + code_off[first];
         HState<T> st;
         DE_UNROLL for (int g = 0; g < G; g++) DE_UNROLL for (int i = 0; i < VW; i++) st.acc[g][i] = T(0);
@@ -1804,11 +1837,11 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         uint32_t flags = flag_protocol == 1 ? 0u : HF_PLAIN_FLAG;
         uint64_t outp, ldo_arg = ldo;
         if constexpr (LOSS) {
-            flags |= HF_LOSS | (a.loss_kind == DE_LOSS_L1 ? (uint32_t)HF_LOSS_L1 : 0u) | ((full && !a.w) ? (uint32_t)HF_LOSS_PLAIN : 0u);
+            flags |= HF_SLOW | HF_LOSS | (a.loss_kind == DE_LOSS_L1 ? (uint32_t)HF_LOSS_L1 : 0u) | ((full && !a.w) ? (uint32_t)HF_LOSS_PLAIN : 0u);
             outp = (uint64_t)(uintptr_t)(a.partial + ((int64_t)tm.tile * a.n_trees) * TWAVES + __builtin_amdgcn_readfirstlane(tid >> 6)); // (wave-uniform: an SGPR argument)
             ldo_arg = (uint64_t)TWAVES * sizeof(T);
         } else {
-            flags |= a.vec_store == 2 ? HF_NO_STORE : ((full && a.vec_store) ? 0u : (HF_SLOW_STORE | (uint32_t)in_tile));
+            flags |= a.vec_store == 2 ? (HF_SLOW | HF_NO_STORE) : ((full && a.vec_store) ? 0u : (HF_SLOW | HF_SLOW_STORE | (uint32_t)in_tile));
             outp = (uint64_t)(uintptr_t)(a.out + base) - (uint64_t)(uint32_t)(uintptr_t)smem_raw;
         }
         const U32x4 hp = rec[-1], hd = *rec; // the first handler's address is in the record in front (the previous tree's end record / the head record)
@@ -1897,7 +1930,7 @@ static int cu_count() {
 // X-tile staging (one L2 read of the tile per chunk) stays a few percent of the work; with few
 // sample tiles, split further so the grid still covers the chip several times.
 static void plan_chunks(int64_t n_trees, int64_t n_tiles, int32_t *n_chunks_out, int32_t *tpc_out, int32_t *nc0_out = nullptr) {
-    const int64_t tpc_env = env_int("DE_EVAL_TPC", 64); // trees per chunk (experiments: X staging per tree against the tail of a short launch)
+    const int64_t tpc_env = env_int("DE_EVAL_TPC", 63); // trees per chunk (experiments: X staging per tree against the tail of a short launch)
     chunk_plan(n_trees, n_tiles, tpc_env, (int64_t)cu_count() * 4 * 8, n_chunks_out, tpc_out, nc0_out);
     if (*n_chunks_out < 1) *n_chunks_out = 1;
 }
@@ -2073,7 +2106,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.classes_is_i64 = e.classes_is_i64;
     a.class_base = e.class_base;
     a.n_classes = e.n_classes > 0 ? e.n_classes : 1;
-    a.vec_store = (reinterpret_cast<uintptr_t>(e.out) % 16 == 0 && (e.ld_out * sizeof(T)) % 16 == 0) ? 1 : 0;
+    a.vec_store = (reinterpret_cast<uintptr_t>(e.out) % 16 == 0 && (e.ld_out * sizeof(T)) % 16 == 0 && (uint64_t)e.ld_out * sizeof(T) < (1ull << 32)) ? 1 : 0; // (the fast ends of a tree take a 32-bit row stride)
     a.x_vec = (e.F >= 1 && e.ldX == e.F && reinterpret_cast<uintptr_t>(e.X) % 16 == 0 && (int64_t)TILE * e.F < 0x10000000LL) ? 1 : 0;
     a.f_magic = e.F > 1 ? (uint32_t)((0x100000000ull + (uint64_t)e.F - 1) / (uint64_t)e.F) : 0u;
     if (!env_int("DE_X_VEC", 1)) { a.x_vec = 0; a.f_magic = 0; } // scalar staging loop (A/B and the test of the vector path)
@@ -2089,7 +2122,20 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     // headline (7.52 / 7.59 ms) and far better with few trees.  The fused-loss variant writes almost nothing: under protocol 2 a CU
     // keeps re-reading its stale L1 line (10.7 instead of 8.4 ms), so it uses protocol 1 unless its chunks are tiny.
     if (a.skip_flagged) { const int pr = env_int("DE_SKIP_PROTOCOL", (e.loss && tpc >= 8) ? 1 : 2); a.skip_flagged = pr >= 1 && pr <= 3 ? pr : 2; }
-    int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
+    // block order: chunk-fastest, or the chunk slower than a group of sample tiles (map_block_grouped) when there are several chunks
+    const int64_t tiles8 = (a.n_tiles + 7) / 8;
+    a.map_group = 0;
+    if (a.n_tiles >= 64 && a.n_chunks > 1) {
+        // Default: chunk-MAJOR (one group = all tiles) while the X tile is small beside the rows a workgroup writes (F <= trees per chunk / 8):
+        // every workgroup in flight then walks the same ~10 KB of records — scalar-cache misses 12 % -> 1.3 % of the record loads
+        // (tools/pmc_smem.sh), complete trees -2.5 %, fused loss -4 %, headline -1.2 % (tools/exp_map_group.sh; groups of 128 ... 2048 tiles
+        // measured WORSE than either end) — and X is re-read from HBM once per chunk instead of once (+7 % traffic at F = 5, 16 chunks).
+        // Wide X keeps the chunk-fastest order (its tile is re-served by the XCD's L2).
+        const int64_t g = env_int("DE_MAP_GROUP", (int64_t)a.F * 8 <= (int64_t)a.trees_per_chunk ? (int)(tiles8 > 0x3fffffff ? 0x3fffffff : tiles8) : 0);
+        a.map_group = (int32_t)(g <= 0 ? 0 : (g > tiles8 ? tiles8 : g));
+    }
+    const int64_t tiles8g = a.map_group > 0 ? (tiles8 + a.map_group - 1) / a.map_group * a.map_group : tiles8;
+    int64_t blocks = tiles8g * 8 * a.n_chunks;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // priority tiles (de_tile_extremes_kernel): launches over >= 512 sample tiles and >= 96 trees with the early exit on; 3 F tiles, run
     // first and once more in place.  The pre-pass: a memset, one read of X, a dependent launch (0.11 ms at 10^7 samples)
@@ -2148,7 +2194,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         if (e.compact_code && e.compact_ints && tpc <= 64 && env_int("DE_COMPACT", 1)) {
             int32_t *coff = e.compact_ints, *live_idx = coff + (size_t)e.n_trees + 1, *ctrl = live_idx + e.n_trees;
             const int64_t want_blocks = (int64_t)cu_count() * 4 * 8;
-            const int32_t tpc_max = env_int("DE_EVAL_TPC", 64);
+            const int32_t tpc_max = env_int("DE_EVAL_TPC", 63);
             LossEnds le;
             std::memset(&le, 0, sizeof le);
             if (e.loss && env_int("DE_LOSS_PLAIN_ENDS", 1)) {
@@ -2175,7 +2221,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
             a.live_idx = live_idx;
             a.ctrl = ctrl;
             if (e.compacted) *e.compacted = true;
-            blocks = ((a.n_tiles + 7) / 8) * 8 * (int64_t)nc0;
+            blocks = tiles8g * 8 * (int64_t)nc0;
             if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
         }
     }
