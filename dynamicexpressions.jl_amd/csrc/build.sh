@@ -41,15 +41,24 @@ esac
 build_kernels() { # src obj [extra flags...]
   local src=$1 obj=$2 tmp=$OBJ/irp_$(basename $2 .o); shift 2
   local DE_KERNEL_FLAGS="${DE_KERNEL_FLAGS:-} $*"
-  if [ -f "$obj" ] && [ ! "$src" -nt "$obj" ] && [ ! irpatch.py -nt "$obj" ] && [ ! asmpatch.py -nt "$obj" ] && [ -z "$(find . ../../include -maxdepth 1 -name '*.h' -newer "$obj" 2>/dev/null | head -1)" ]; then return 0; fi
+  if [ -f "$obj" ] && [ ! "$src" -nt "$obj" ] && [ ! irpatch.py -nt "$obj" ] && [ ! asmpatch.py -nt "$obj" ] && [ ! asmopt.py -nt "$obj" ] && [ -z "$(find . ../../include -maxdepth 1 -name '*.h' -newer "$obj" 2>/dev/null | head -1)" ]; then return 0; fi
   echo "  hipcc $src $* (device IR -> irpatch -> gfx950 code object -> host object)"
   rm -f "$obj"; mkdir -p $tmp
   if [ "${DE_NO_IRPATCH:-0}" = 1 ]; then $HIPCC $FLAGS ${DE_KERNEL_FLAGS:-} -c $src -o $obj; return; fi
   # (clang 22 of ROCm 7.2 was seen to crash once in ~30 builds of de_kernels.hip under 8 parallel compiles: one retry)
   $HIPCC $FLAGS ${DE_KERNEL_FLAGS:-} --cuda-device-only -emit-llvm -S $src -o $tmp/k.ll || $HIPCC $FLAGS ${DE_KERNEL_FLAGS:-} --cuda-device-only -emit-llvm -S $src -o $tmp/k.ll
   python3 irpatch.py $tmp/k.ll $tmp/k2.ll $(basename $obj .o)
+  # the backend's ASSEMBLY, one peephole pass over it (asmopt.py: the two s_mov_b32 that save a handler's successor address become one
+  # s_mov_b64 — an instruction per dispatch), then the assembler.  DE_ASMOPT=0: the object straight from the backend.
+  if [ "${DE_ASMOPT:-1}" = 1 ]; then
+    $LLVM/clang -x ir $tmp/k2.ll -target amdgcn-amd-amdhsa -mcpu=gfx950 -O3 -fPIC -ffp-contract=off -Wno-override-module ${DE_LLC_FLAGS:-} -S -o $tmp/k.s || \
+      $LLVM/clang -x ir $tmp/k2.ll -target amdgcn-amd-amdhsa -mcpu=gfx950 -O3 -fPIC -ffp-contract=off -Wno-override-module ${DE_LLC_FLAGS:-} -S -o $tmp/k.s
+    python3 asmopt.py $tmp/k.s $tmp/k_opt.s $(basename $obj .o)
+    $LLVM/clang -x assembler $tmp/k_opt.s -target amdgcn-amd-amdhsa -mcpu=gfx950 -c -o $tmp/k.o
+  else
   $LLVM/clang -x ir $tmp/k2.ll -target amdgcn-amd-amdhsa -mcpu=gfx950 -O3 -fPIC -ffp-contract=off -Wno-override-module ${DE_LLC_FLAGS:-} -c -o $tmp/k.o || \
     $LLVM/clang -x ir $tmp/k2.ll -target amdgcn-amd-amdhsa -mcpu=gfx950 -O3 -fPIC -ffp-contract=off -Wno-override-module ${DE_LLC_FLAGS:-} -c -o $tmp/k.o
+  fi
   # one more pass, over the object code of the handlers: asmpatch.py (their entry wait need not cover the previous tree's output stores)
   if [ "${DE_NO_ASMPATCH:-0}" != 1 ]; then python3 asmpatch.py $tmp/k.o $(basename $obj .o); fi
   $LLVM/lld -flavor gnu -m elf64_amdgpu --no-undefined -shared -o $tmp/k.out $tmp/k.o
