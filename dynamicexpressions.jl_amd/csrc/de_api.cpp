@@ -1882,6 +1882,15 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                 for (int32_t i = p->gbcode_off[(size_t)part_first[k]]; i < p->gbcode_off[(size_t)part_last[k]]; i++)
                     if (p->gtsite_of_gb[(size_t)i] >= 0) p->gtsite_of_gb[(size_t)i] += base_k;
         }
+        // the handler word of a record names the handler of the record BEHIND it, the end record names the tree's first handler
+        // (de_grad_threaded.hip: a handler knows its successor at entry and jumps without waiting for the record it loads)
+        for (int64_t t = 0; t < p->n_trees; t++) {
+            const int32_t a0 = p->gtcode_off[(size_t)t], b0 = p->gtcode_off[(size_t)t + 1];
+            if (b0 - a0 < 2) continue;
+            const uint32_t first = p->gtcode[(size_t)a0].bop;
+            for (int32_t i = a0; i < b0 - 1; i++) p->gtcode[(size_t)i].bop = p->gtcode[(size_t)i + 1].bop;
+            p->gtcode[(size_t)b0 - 1].bop = first;
+        }
         std::vector<int32_t> ids((size_t)p->n_trees);
         int32_t start[NB], run = 0;
         for (int b = 0; b < NB; b++) { start[b] = run; run += count[b]; }
@@ -1894,7 +1903,24 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             // a unary operator on a constant leaf becomes two instructions: at most twice the bound program
             // ... plus one end record per tree and one of padding (every handler reads the record behind its own)
             const size_t gt_cap = 2 * p->gbcode.size() + (size_t)p->n_trees + 1;
-            HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode), gt_cap * sizeof(BoundInstr)));
+            // (inside one 4 GiB window: the handlers bump the record pointer without a carry; a straddling allocation is set aside and redone)
+            {
+                void *rejected[4] = {nullptr, nullptr, nullptr, nullptr};
+                int n_rej = 0;
+                hipError_t ast = hipSuccess;
+                for (;;) {
+                    ast = hipMalloc(reinterpret_cast<void **>(&p->d_gtcode), gt_cap * sizeof(BoundInstr));
+                    if (ast != hipSuccess) break;
+                    const uint64_t a0 = (uint64_t)(uintptr_t)p->d_gtcode, a1 = a0 + gt_cap * sizeof(BoundInstr) - 1;
+                    if ((a0 >> 32) == (a1 >> 32) || n_rej == 4) break;
+                    rejected[n_rej++] = p->d_gtcode;
+                    p->d_gtcode = nullptr;
+                }
+                for (int k = 0; k < n_rej; k++) (void)hipFree(rejected[k]);
+                if (ast != hipSuccess) return fail(c, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(ast));
+                const uint64_t a0 = (uint64_t)(uintptr_t)p->d_gtcode;
+                if ((a0 >> 32) != ((a0 + gt_cap * sizeof(BoundInstr) - 1) >> 32)) return fail(c, DE_ERR_HIP, "gradient instruction stream straddles a 4 GiB boundary");
+            }
             HIP_TRY(c, hipMemset(p->d_gtcode, 0, gt_cap * sizeof(BoundInstr)));
             HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode_off), p->gtcode_off.size() * sizeof(int32_t)));
             HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gt_ids), std::max<size_t>(ids.size(), 1) * sizeof(int32_t)));

@@ -8,11 +8,12 @@
 // host (leaf row / spill slot / constant), so handlers are straight-line code.  Dispatch is DIRECT-THREADED like the
 // eval kernel's (de_kernels.hip): a handler loads the next record first (s_load_dwordx4, overlapping its own LDS reads
 // and arithmetic), runs its body and tail-calls the next handler (s_setpc_b64) with that record's operand words in
-// SGPRs; the tree's end record (g_end) returns to the kernel for the epilogue.  ~9 scalar + 1 vector instruction per
-// dispatch against 14 + 2 for the call/return loop of round 1.
+// SGPRs — knowing its successor since entry, without waiting for that load (round 4) —; the tree's end record (g_end) returns to
+// the kernel for the epilogue.  6 scalar + 1 vector instruction per dispatch against 14 + 2 for the call/return loop of round 1.
 //
 // Instruction word (16 B, built by de_api.cpp make_grad_threaded from the bound program):
-//   x = handler address - handler base (the base travels with the chain in SGPRs: one code object module per window width)
+//   x = handler address - handler base OF THE NEXT RECORD (end record: of the tree's first record); the base travels with the chain
+//       in SGPRs: one code object module per window width
 //   y = LDS byte offset of the operand (leaf row or spill slot base) | aux << 24
 //         aux = gradient row seeded by a leaf/constant operand (0xFF: none in this mode);
 //         for GOP_GEN_CONST y[23:16] = de_opcode (no LDS operand), for GOP_TERN aux = de_opcode
@@ -80,14 +81,24 @@ template <typename T, int GC> struct GDual {
 };
 #define GHARGS GState<T, GC> st, uint32_t la, typename GImm<T>::type imm
 template <typename T, int GC> using GBodyFn = GState<T, GC> (*)(GState<T, GC>, uint32_t, typename GImm<T>::type);
-// what the stream points at: gh_chain<T, GC, &body>.  `code` = the NEXT record; (la, imm) = this instruction's operand words;
-// lds0 = the lane's LDS base; hbase = handler base of this module.  csrc/irpatch.py moves code, la, imm, hbase to SGPRs.
-#define GCHAIN_ARGS GState<T, GC> st, uint32_t lds0, ConstU4Ptr code, uint32_t la, typename GImm<T>::type imm, uint64_t hbase
-template <typename T, int GC> using GHandlerFn = GState<T, GC> (*)(GState<T, GC>, uint32_t, ConstU4Ptr, uint32_t, typename GImm<T>::type, uint64_t);
+// what the stream points at: gh_chain<T, GC, &body>.  `code` = the NEXT record; (la, imm) = this instruction's operand words; nx = the
+// handler of the NEXT record (address - hbase) — it stands in THIS instruction's record (round 4: x of record k names the handler of
+// record k + 1, the end record names the tree's first handler), so a handler knows its successor at entry, loads the next record
+// straight into the successor's argument registers (the aligned SGPR quad nx, la, imm) and jumps WITHOUT waiting for the load:
+// the callee's entry wait completes it, the jump's instruction fetch overlaps with it.  (Before, the target came out of the loaded
+// record: every handler sat out the scalar-cache latency before it could jump — the eval kernel dropped that in round 2.)
+// lds0 = the lane's LDS base; hbase = handler base of this module.  csrc/irpatch.py moves code, hbase, nx, la, imm to SGPRs.
+#define GCHAIN_ARGS GState<T, GC> st, uint32_t lds0, ConstU4Ptr code, uint64_t hbase, uint32_t nx, uint32_t la, typename GImm<T>::type imm
+template <typename T, int GC> using GHandlerFn = GState<T, GC> (*)(GState<T, GC>, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, typename GImm<T>::type);
 template <typename T> __device__ __forceinline__ typename GImm<T>::type grec_imm(const U32x4 &w);
 template <> __device__ __forceinline__ uint32_t grec_imm<float>(const U32x4 &w) { return w.z; }
 template <> __device__ __forceinline__ uint64_t grec_imm<double>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
-#define GCHAIN_NEXT(W) [[clang::musttail]] return reinterpret_cast<GHandlerFn<T, GC>>(hbase + (W).x)(st, lds0, code + 1, (W).y, grec_imm<T>(W), hbase)
+// record address + 1 WITHOUT a carry into the high half (the stream lies inside one 4 GiB window: de_api.cpp checks the allocation)
+__device__ __forceinline__ ConstU4Ptr gcode_next(ConstU4Ptr c) {
+    const uint64_t a = (uint64_t)(uintptr_t)c;
+    return (ConstU4Ptr)(uintptr_t)((a & 0xFFFFFFFF00000000ull) | (uint64_t)((uint32_t)a + 16u));
+}
+#define GCHAIN_NEXT(W) [[clang::musttail]] return reinterpret_cast<GHandlerFn<T, GC>>(hbase + nx)(st, lds0, gcode_next(code), hbase, (W).x, (W).y, grec_imm<T>(W))
 #define GH(...) (uint64_t)&gh_chain<T, GC, &__VA_ARGS__>
 #define GLDS(T, addr) (reinterpret_cast<__attribute__((address_space(3))) LV(T) *>((uintptr_t)(addr)))
 // LDS is laid out wave-major: wave w owns rows [w*R, (w+1)*R), a row = the 64*VS samples of that wave
@@ -306,7 +317,7 @@ template <typename T, int GC, GBodyFn<T, GC> BODY> __device__ __noinline__ GStat
     st = BODY(st, lds0 + la, imm);
     GCHAIN_NEXT(w);
 }
-template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_end(GState<T, GC> st, uint32_t, ConstU4Ptr, uint32_t, typename GImm<T>::type, uint64_t) { return st; }
+template <typename T, int GC> __device__ __noinline__ GState<T, GC> g_end(GState<T, GC> st, uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, typename GImm<T>::type) { return st; }
 
 // handler table: seed variants enumerated at compile time
 template <typename T, int GC, int SV> __device__ __forceinline__ void fill_seeded(uint64_t *t) {
@@ -498,11 +509,11 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
         DE_UNROLL for (int k = 0; k < GC; k++) st.d[k] = lv_splat<T>(T(0));
         st.poison = T(0);
         st.g0 = (uint32_t)g0 | (lds0 & 0xFFFF0000u); // window offset (< 2^16) | upper half of the lane's LDS base (g_gen)
-        (void)pe;
         {   // one call per tree: the chain ends in the tree's end record (g_end)
             const ConstU4Ptr rec = code + pc;
             const U32x4 hd = *rec;
-            st = reinterpret_cast<GHandlerFn<T, GC>>(hbase + hd.x)(st, lds0, rec + 1, hd.y, grec_imm<T>(hd), hbase);
+            const uint32_t first = code[pe - 1].x; // the end record names the tree's first handler (every other record: its successor's)
+            st = reinterpret_cast<GHandlerFn<T, GC>>(hbase + first)(st, lds0, rec + 1, hbase, hd.x, hd.y, grec_imm<T>(hd));
         }
         // a non-finite d[k] always survives to the root (every update is linear in it), so the gradient
         // is validity-tested once, here; x was tested where the lowering kept a test (H_CHECK_OUT)
