@@ -2364,12 +2364,41 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
             std::sort(ids.begin() + k, ids.begin() + e); // tree order inside a group: adjacent trees share staging batches
             k = e;
         }
+        // the handler word of a record names the handler of the record BEHIND it; the end record of a sweep names the sweep's first
+        // handler (de_rev_threaded.hip: a handler knows its successor at entry)
+        for (int64_t t = 0; t < p->n_trees; t++) {
+            const int32_t lim[3] = {p->rtcode_off[(size_t)t], p->rtcode_mid[(size_t)t], p->rtcode_off[(size_t)t + 1]};
+            for (int sw = 0; sw < 2; sw++) {
+                const int32_t a0 = lim[sw], b0 = lim[sw + 1];
+                if (b0 - a0 < 2) continue;
+                const uint32_t first = p->rtcode[(size_t)a0].bop;
+                for (int32_t i = a0; i < b0 - 1; i++) p->rtcode[(size_t)i].bop = p->rtcode[(size_t)i + 1].bop;
+                p->rtcode[(size_t)b0 - 1].bop = first;
+            }
+        }
         HIP_TRY(c, hipStreamSynchronize(c->stream)); // the previous form may be in use by queued work
         if (p->d_rtcode) { // sizes depend on the mode
             (void)hipFree(p->d_rtcode);
             p->d_rtcode = nullptr;
         }
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_rtcode), (p->rtcode.size() + 1) * sizeof(BoundInstr)));
+        { // (inside one 4 GiB window: the handlers bump the record pointer without a carry)
+            const size_t rbytes = (p->rtcode.size() + 1) * sizeof(BoundInstr);
+            void *rejected[4] = {nullptr, nullptr, nullptr, nullptr};
+            int n_rej = 0;
+            hipError_t ast = hipSuccess;
+            for (;;) {
+                ast = hipMalloc(reinterpret_cast<void **>(&p->d_rtcode), rbytes);
+                if (ast != hipSuccess) break;
+                const uint64_t a0 = (uint64_t)(uintptr_t)p->d_rtcode;
+                if ((a0 >> 32) == ((a0 + rbytes - 1) >> 32) || n_rej == 4) break;
+                rejected[n_rej++] = p->d_rtcode;
+                p->d_rtcode = nullptr;
+            }
+            for (int k = 0; k < n_rej; k++) (void)hipFree(rejected[k]);
+            if (ast != hipSuccess) return fail(c, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(ast));
+            const uint64_t a0 = (uint64_t)(uintptr_t)p->d_rtcode;
+            if ((a0 >> 32) != ((a0 + rbytes - 1) >> 32)) return fail(c, DE_ERR_HIP, "reverse instruction stream straddles a 4 GiB boundary");
+        }
         HIP_TRY(c, hipMemset(p->d_rtcode, 0, (p->rtcode.size() + 1) * sizeof(BoundInstr)));
         if (!p->d_rtcode_off) {
             HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_rtcode_off), p->rtcode_off.size() * sizeof(int32_t)));

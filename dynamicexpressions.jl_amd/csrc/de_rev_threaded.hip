@@ -58,13 +58,21 @@ template <typename T> struct GState {
 template <typename T> using RBodyFn = GState<T> (*)(GState<T>, uint32_t, typename RImm<T>::type);
 #define RHARGS GState<T> st, uint32_t la, typename RImm<T>::type imm
 // what the stream points at: rh_chain<T, &body>.  `code` = the NEXT record; (la, imm) = this instruction's operand words (la
-// still without the lane's base: st.lds0 is added here); hbase = the module's handler base.  irpatch.py: code, la, imm, hbase in SGPRs.
-#define RCHAIN_ARGS GState<T> st, ConstU4Ptr code, uint32_t la, typename RImm<T>::type imm, uint64_t hbase
-template <typename T> using RHandlerFn = GState<T> (*)(GState<T>, ConstU4Ptr, uint32_t, typename RImm<T>::type, uint64_t);
+// still without the lane's base: st.lds0 is added here); nx = the handler of the NEXT record (address - hbase): x of record k names the
+// handler of record k + 1, the end record of a sweep names the sweep's first handler (round 4, as in de_grad_threaded.hip) — a handler
+// knows its successor at entry, loads the next record into the successor's argument registers and jumps without waiting for it;
+// hbase = the module's handler base.  irpatch.py: code, hbase, nx, la, imm in SGPRs.
+#define RCHAIN_ARGS GState<T> st, ConstU4Ptr code, uint64_t hbase, uint32_t nx, uint32_t la, typename RImm<T>::type imm
+template <typename T> using RHandlerFn = GState<T> (*)(GState<T>, ConstU4Ptr, uint64_t, uint32_t, uint32_t, typename RImm<T>::type);
 template <typename T> __device__ __forceinline__ typename RImm<T>::type rrec_imm(const U32x4 &w);
 template <> __device__ __forceinline__ uint64_t rrec_imm<float>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
 template <> __device__ __forceinline__ uint64_t rrec_imm<double>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
-#define RCHAIN_NEXT(W) [[clang::musttail]] return reinterpret_cast<RHandlerFn<T>>(hbase + (W).x)(st, code + 1, (W).y, rrec_imm<T>(W), hbase)
+// record address + 1 WITHOUT a carry into the high half (the stream lies inside one 4 GiB window: de_api.cpp checks the allocation)
+__device__ __forceinline__ ConstU4Ptr rcode_next(ConstU4Ptr c) {
+    const uint64_t a = (uint64_t)(uintptr_t)c;
+    return (ConstU4Ptr)(uintptr_t)((a & 0xFFFFFFFF00000000ull) | (uint64_t)((uint32_t)a + 16u));
+}
+#define RCHAIN_NEXT(W) [[clang::musttail]] return reinterpret_cast<RHandlerFn<T>>(hbase + nx)(st, rcode_next(code), hbase, (W).x, (W).y, rrec_imm<T>(W))
 #define RH(...) (uint64_t)&rh_chain<T, &__VA_ARGS__>
 #define RLDS(T, addr) (reinterpret_cast<__attribute__((address_space(3))) T *>((uintptr_t)(addr)))
 template <typename T> constexpr uint32_t rrow_bytes() { return (uint32_t)(64 * sizeof(T)); }
@@ -281,7 +289,7 @@ template <typename T, RBodyFn<T> BODY> __device__ __noinline__ GState<T> rh_chai
     st = BODY(st, st.lds0 + la, imm);
     RCHAIN_NEXT(w);
 }
-template <typename T> __device__ __noinline__ GState<T> r_end(GState<T> st, ConstU4Ptr, uint32_t, typename RImm<T>::type, uint64_t) { return st; }
+template <typename T> __device__ __noinline__ GState<T> r_end(GState<T> st, ConstU4Ptr, uint64_t, uint32_t, uint32_t, typename RImm<T>::type) { return st; }
 
 // ---- fused pairs / triples (round 4) --------------------------------------------------------------------------------------------------
 // One sample per lane makes this kernel dispatch-bound (VALU 40 % busy, as many scalar as vector instructions): every dispatch saved is
@@ -453,11 +461,11 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
         staged += nc;
         int pc = code_off[tree];
         const int pm = code_mid[tree], pe = code_off[tree + 1];
-        (void)pe;
         {   // forward sweep: one chain, ending in the end record in front of code[pm]
             const ConstU4Ptr rec = code + pc;
             const U32x4 hd = *rec;
-            st = reinterpret_cast<RHandlerFn<T>>(hbase + hd.x)(st, rec + 1, hd.y, rrec_imm<T>(hd), hbase);
+            const uint32_t first = code[pm - 1].x; // the sweep's end record names its first handler
+            st = reinterpret_cast<RHandlerFn<T>>(hbase + first)(st, rec + 1, hbase, hd.x, hd.y, rrec_imm<T>(hd));
         }
         rpoison<T>(st.vpoison, st.x);
         { // loss term and the seed of the backward sweep
@@ -475,7 +483,8 @@ __global__ void __launch_bounds__(GBLK) de_rev_threaded_kernel(const GArgs<T> a,
         {   // backward sweep (instructions stored in execution order), ending in the tree's last record
             const ConstU4Ptr rec = code + pm;
             const U32x4 hd = *rec;
-            st = reinterpret_cast<RHandlerFn<T>>(hbase + hd.x)(st, rec + 1, hd.y, rrec_imm<T>(hd), hbase);
+            const uint32_t first = code[pe - 1].x;
+            st = reinterpret_cast<RHandlerFn<T>>(hbase + first)(st, rec + 1, hbase, hd.x, hd.y, rrec_imm<T>(hd));
         }
         const bool bad = (st.vpoison != st.vpoison) || (nc > 1 && st.gpoison != st.gpoison);
         if (__ballot(bad) != 0ull) gflag_incomplete(a.ok + tree, flag_protocol == 1);
