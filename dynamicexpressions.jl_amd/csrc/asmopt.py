@@ -10,6 +10,12 @@ the SGPR pair the next record is loaded into — with TWO s_mov_b32, because the
   P1  s_mov_b32 s(2k+1), s(2m+1)  ...  s_mov_b32 s(2k), s(2m)      (either order, same basic block, nothing in between touches the
       four registers)                                 ->  s_mov_b64 s[2k:2k+1], s[2m:2m+1]   at the place of the first
 
+  P2  s_mov_b32 sA, sB ; [s_load_dword*/v_*/ds_*/s_waitcnt/s_nop that do not touch sA, sC or write sB... the load of the next record
+      overwrites sB] ; s_add_u32 sA, sC, sA          ->  s_add_u32 sA, sC, sB   at the place of the copy
+      (the gradient / reverse chains: successor address = handler base + the offset that arrived in the quad the next record is
+      loaded into; the backend copies the offset out of the way first).  Nothing that reads or writes SCC may stand between the copy
+      and the add — the add's carry feeds the s_addc_u32 behind it, which stays where it is.
+
 The pass also appends the `.set amdgpu.max_num_named_barrier` the printer of this toolchain forgets (without it the assembler cannot
 evaluate the kernels' resource symbols: "cannot evaluate equated symbol ... num_named_barrier"); with it the round trip
 llc -S -> assembler gives the same text, kernel descriptors and metadata as llc -c (checked once per build by build.sh: DE_ASMOPT_VERIFY=1).
@@ -75,19 +81,73 @@ def merge_pairs(lines):
     return merged
 
 
+ADD = re.compile(r'^\ts_add_u32 s(\d+), s(\d+), s(\d+)\s*$')
+# instructions the add may be hoisted over: they neither read nor write SCC (vector, LDS, scalar loads, waits, plain scalar moves)
+SCC_NEUTRAL = re.compile(r'^\t(v_|ds_|s_load_dword|s_waitcnt|s_nop|s_mov_b32|s_mov_b64|global_|buffer_|;)')
+
+
+def fold_copy_into_add(lines):
+    folded = 0
+    i = 0
+    n = len(lines)
+    while i < n:
+        m = MOV.match(lines[i])
+        if not m:
+            i += 1
+            continue
+        a, b = int(m.group(1)), int(m.group(2))
+        j = i + 1
+        found = -1
+        while j < n and j - i <= 8:
+            lj = lines[j]
+            if BARRIER.match(lj):
+                break
+            ma = ADD.match(lj)
+            if ma and int(ma.group(1)) == a and a in (int(ma.group(2)), int(ma.group(3))) and int(ma.group(2)) != int(ma.group(3)):
+                c = int(ma.group(3)) if int(ma.group(2)) == a else int(ma.group(2))
+                # sC must hold the same value at the copy's place: nothing in between may mention it as a destination — checked below
+                ok = c not in (a, b) and all(c not in sregs_written(lines[k]) for k in range(i + 1, j))
+                if ok:
+                    found = j
+                    cc = c
+                break
+            if not SCC_NEUTRAL.match(lj) or a in sregs(lj):
+                break
+            j += 1
+        if found < 0:
+            i += 1
+            continue
+        lines[i] = f'\ts_add_u32 s{a}, s{cc}, s{b}\n'
+        del lines[found]
+        n -= 1
+        folded += 1
+        i += 1
+    return folded
+
+
+def sregs_written(line):
+    """SGPRs an instruction of the SCC_NEUTRAL set may write: the first operand of s_load / s_mov (vector and LDS instructions write none)"""
+    code = line.split(';', 1)[0].strip()
+    if not (code.startswith('s_load') or code.startswith('s_mov')):
+        return set()
+    first = code.split(None, 1)[1].split(',')[0] if len(code.split(None, 1)) > 1 else ''
+    return sregs('\t' + first)
+
+
 def main(src, dst, module):
     lines = open(src).read().splitlines(keepends=True)
     merged = merge_pairs(lines)
+    folded = fold_copy_into_add(lines)
     text = ''.join(lines)
     if 'amdgpu.max_num_named_barrier' in text and not re.search(r'^\t\.set amdgpu\.max_num_named_barrier,', text, re.M):
         text += '\t.set amdgpu.max_num_named_barrier, 0\n'
     open(dst, 'w').write(text)
-    print(f'asmopt: {merged} s_mov_b32 pair(s) merged into s_mov_b64' + (f' ({module})' if module else ''))
+    print(f'asmopt: {merged} s_mov_b32 pair(s) merged into s_mov_b64, {folded} copies folded into s_add_u32' + (f' ({module})' if module else ''))
     if module:
         import os
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         import patch_expect
-        patch_expect.check(module, {'asmopt_pairs': merged})
+        patch_expect.check(module, {'asmopt_pairs': merged, 'asmopt_folded': folded})
 
 
 if __name__ == '__main__':

@@ -55,6 +55,17 @@ build_kernels() { # src obj [extra flags...]
       $LLVM/clang -x ir $tmp/k2.ll -target amdgcn-amd-amdhsa -mcpu=gfx950 -O3 -fPIC -ffp-contract=off -Wno-override-module ${DE_LLC_FLAGS:-} -S -o $tmp/k.s
     python3 asmopt.py $tmp/k.s $tmp/k_opt.s $(basename $obj .o)
     $LLVM/clang -x assembler $tmp/k_opt.s -target amdgcn-amd-amdhsa -mcpu=gfx950 -c -o $tmp/k.o
+    if [ "${DE_ASMOPT_VERIFY:-0}" = 1 ]; then
+      # the round trip itself changes nothing: the UNMODIFIED assembly (+ the symbol the printer forgets) assembles to the same code,
+      # kernel descriptors and metadata as the object straight from the backend
+      $LLVM/clang -x ir $tmp/k2.ll -target amdgcn-amd-amdhsa -mcpu=gfx950 -O3 -fPIC -ffp-contract=off -Wno-override-module ${DE_LLC_FLAGS:-} -c -o $tmp/k_direct.o
+      cp $tmp/k.s $tmp/k_rt.s; grep -q '^\s*\.set amdgpu\.max_num_named_barrier,' $tmp/k_rt.s || printf '\t.set amdgpu.max_num_named_barrier, 0\n' >> $tmp/k_rt.s
+      $LLVM/clang -x assembler $tmp/k_rt.s -target amdgcn-amd-amdhsa -mcpu=gfx950 -c -o $tmp/k_rt.o
+      for sec in "-d" "-s -j .rodata" "-s -j .note"; do
+        cmp <($LLVM/llvm-objdump $sec $tmp/k_direct.o | tail -n +3) <($LLVM/llvm-objdump $sec $tmp/k_rt.o | tail -n +3) || { echo "asmopt verify: $(basename $obj .o): llvm-objdump $sec differs between llc -c and llc -S | as" >&2; exit 1; }
+      done
+      echo "  asmopt verify: $(basename $obj .o): llc -S | assembler == llc -c (code, kernel descriptors, notes)"
+    fi
   else
   $LLVM/clang -x ir $tmp/k2.ll -target amdgcn-amd-amdhsa -mcpu=gfx950 -O3 -fPIC -ffp-contract=off -Wno-override-module ${DE_LLC_FLAGS:-} -c -o $tmp/k.o || \
     $LLVM/clang -x ir $tmp/k2.ll -target amdgcn-amd-amdhsa -mcpu=gfx950 -O3 -fPIC -ffp-contract=off -Wno-override-module ${DE_LLC_FLAGS:-} -c -o $tmp/k.o
