@@ -334,3 +334,60 @@ def test_declared_dataset_skips_the_pre_pass_and_changes_nothing(api):
     o, k = pop.eval(Xa)
     assert torch.equal(k, ref["a"][0][1])
     pop.close()
+
+
+@pytest.mark.parametrize("compact", ["1", "0"])
+def test_chain_lengths_around_the_sentinel_bit(api, compact, monkeypatch):
+    """A chain of tail calls runs <= 63 trees and finds its end — and a skipped successor — through ONE bit of the skip mask (the sentinel
+    behind the last tree's bit, HTREE_END_TAIL / h_tree_skip of csrc/de_kernels.hip).  Populations of 1 ... 130 trees over 8193 sample
+    tiles (chains of 1, 2, 62, 63 trees; 64 and more: several chunks; DE_EVAL_TPC=200: sub-chunks of 63 + 63 + 4) with the incomplete
+    trees — 1 / (x2 - x2): flagged by the probe launch of the priority tiles — at the first, the last, the last two, every other, all
+    but one and all positions; with the live trees re-linked into a dense stream (default) and with the walking launch (DE_COMPACT=0):
+    same flags and the same bits in every complete row as the evaluate-everything mode."""
+    import torch
+    ops = de.synth.BENCH_OPERATORS
+    B = {n_: i + 1 for i, n_ in enumerate(ops.binops)}
+    U = {n_: i + 1 for i, n_ in enumerate(ops.unaops)}
+    x1, x2 = de.Node(feature=1), de.Node(feature=2)
+    bad = lambda: de.Node(B["/"], de.Node(val=1.0), de.Node(B["-"], x2, x2))
+    good = lambda i: de.Node(B["+"], de.Node(U["cos"], de.Node(B["*"], x1, de.Node(val=0.5 + 0.01 * i))), x2)
+    N = 2**21 + 77
+    Xd = _X(N, seed=9)
+    lib = api.library()
+    monkeypatch.setenv("DE_PRIO_MIN_TILES", "1")
+    monkeypatch.setenv("DE_PRIO_MIN_TREES", "1")
+    monkeypatch.setenv("DE_COMPACT", compact)
+    patterns = {
+        "none": lambda n: set(), "first": lambda n: {0}, "last": lambda n: {n - 1}, "last2": lambda n: {n - 1, n - 2} & set(range(n)),
+        "alternate": lambda n: set(range(0, n, 2)), "all_but_first": lambda n: set(range(1, n)), "all_but_last": lambda n: set(range(n - 1)),
+        "all": lambda n: set(range(n)),
+    }
+    checked = 0
+    for n, tpc in ((1, None), (2, None), (62, None), (63, None), (64, None), (65, None), (126, None), (127, None), (130, "200")):
+        if tpc:
+            monkeypatch.setenv("DE_EVAL_TPC", tpc)
+        else:
+            monkeypatch.delenv("DE_EVAL_TPC", raising=False)
+        for name, pat in patterns.items():
+            badset = pat(n)
+            trees = [bad() if i in badset else good(i) for i in range(n)]
+            res = {}
+            for full in (True, False):
+                pop = api.Population(trees, ops, np.float32, n_features=5, eval_context=api.EvalContext(full_eval=full))
+                out = torch.full((n, N), 12345.0, device="cuda", dtype=torch.float32)
+                ok = torch.empty(n, device="cuda", dtype=torch.uint8)
+                pop.ctx.use_torch_stream()
+                pop.ctx.check(lib.de_eval(pop.ctx._h, pop._h, Xd.data_ptr(), N, 5, None, out.data_ptr(), N, ok.data_ptr()))
+                torch.cuda.synchronize()
+                res[full] = (out, ok.bool().cpu())
+                pop.close()
+            (of, kf), (oe, ke) = res[True], res[False]
+            want = torch.tensor([i not in badset for i in range(n)])
+            assert torch.equal(kf, want) and torch.equal(ke, want), (n, name, compact)
+            if bool(want.any()):
+                idx = want.nonzero().flatten().cuda()
+                assert torch.equal(of[idx], oe[idx]), (n, name, compact)
+                assert int((oe[idx] == 12345.0).sum()) == 0, (n, name, compact)   # every complete row written on every tile
+            del of, oe, res
+            checked += 1
+    assert checked == 72
