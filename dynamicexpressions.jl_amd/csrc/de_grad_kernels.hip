@@ -15,6 +15,10 @@
 #include "de_grad_common.h"
 #include <memory>
 #include <mutex>
+#include <utility>
+#include <vector>
+#include <algorithm>
+#include <cstdlib>
 
 namespace de {
 
@@ -511,6 +515,68 @@ hipError_t grad_handler_table(int dtype, int GC, int VS, uint64_t *table) {
     return hipSuccess;
 }
 
+// Side streams of a caller's stream: the buckets of one gradient call (one launch — with its probe launch in front — per window width and
+// samples-per-lane class: 2 ... 9 per call) are independent of each other, and each is short enough (0.2 ... 1.7 ms at 10^6 samples)
+// that its ramp and tail are a tenth of it; spread over DE_GRAD_STREAMS streams (default 3; 1 = all on the caller's stream) the tail of
+// one bucket runs beside the next.  Fork / join by events (legal under stream capture); one set per caller stream, made on first use.
+struct SideStreams {
+    hipStream_t s[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
+    int n = 0;
+};
+static SideStreams *side_streams_of(hipStream_t main, int want) {
+    static std::mutex mu;
+    static std::vector<std::pair<std::pair<int, hipStream_t>, std::unique_ptr<SideStreams>>> all;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    const std::lock_guard<std::mutex> lock(mu);
+    for (auto &e : all) if (e.first.first == dev && e.first.second == main) return e.second->n >= want ? e.second.get() : nullptr;
+    std::unique_ptr<SideStreams> ss(new SideStreams());
+    if (hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    for (int i = 0; i < 3; i++) {
+        if (hipStreamCreateWithFlags(&ss->s[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ss->join[i], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        ss->n = i + 1;
+    }
+    all.emplace_back(std::make_pair(dev, main), std::move(ss));
+    SideStreams *r = all.back().second.get();
+    return r->n >= want ? r : nullptr;
+}
+
+// n_launches independent launch sequences of one call over the caller's stream and its side streams: fork(), next() per sequence, join()
+struct ForkJoin {
+    hipStream_t main;
+    SideStreams *ss = nullptr;
+    int n_side = 0, slot = 0;
+    ForkJoin(hipStream_t m, int n_launches) : main(m) {
+        static const int n_env = [] { const char *v = getenv("DE_GRAD_STREAMS"); const int n = v ? atoi(v) : 3; return n < 1 ? 1 : (n > 4 ? 4 : n); }();
+        n_side = n_launches >= 2 ? std::min(n_env, n_launches) - 1 : 0;
+        ss = n_side > 0 ? side_streams_of(m, n_side) : nullptr;
+        if (!ss) n_side = 0;
+    }
+    hipError_t fork() {
+        if (!ss) return hipSuccess;
+        hipError_t st = hipEventRecord(ss->fork, main);
+        for (int i = 0; i < n_side && st == hipSuccess; i++) st = hipStreamWaitEvent(ss->s[i], ss->fork, 0);
+        return st;
+    }
+    hipStream_t next() {
+        const int k = slot++ % (n_side + 1);
+        return k == 0 ? main : ss->s[k - 1];
+    }
+    hipError_t join() { // (also after an error: the side streams must not run on behind the caller's back)
+        hipError_t err = hipSuccess;
+        for (int i = 0; i < n_side; i++) {
+            hipError_t st = hipEventRecord(ss->join[i], ss->s[i]);
+            if (st == hipSuccess) st = hipStreamWaitEvent(main, ss->join[i], 0);
+            if (st != hipSuccess && err == hipSuccess) err = st;
+        }
+        return err;
+    }
+};
+
 static hipError_t grad_prio_prepass(int dtype, const GradArgs &a, hipStream_t stream, GradArgs *with);
 hipError_t launch_grad_threaded(int dtype, const GradArgs &a0, hipStream_t stream, const char **kernel_name) {
     if (kernel_name) *kernel_name = "de_grad_threaded_kernel";
@@ -526,14 +592,22 @@ hipError_t launch_grad_threaded(int dtype, const GradArgs &a0, hipStream_t strea
             if (st != hipSuccess) return st;
         }
     }
+    int n_active = 0;
+    for (int b = 0; b < a.n_buckets; b++) n_active += a.buckets[b].n > 0;
+    ForkJoin fj(stream, n_active);
+    hipError_t first_err = fj.fork();
+    if (first_err != hipSuccess) return first_err;
     for (int b = 0; b < a.n_buckets; b++) {
         const GradArgs::Bucket &bk = a.buckets[b];
         if (bk.n <= 0) continue;
+        const hipStream_t bs = fj.next();
         hipError_t st = hipErrorInvalidValue;
-#define DE_GT_LAUNCH(TAG, G, V) if (k == (#TAG[0] == 'f' ? 0 : 1) && bk.GC == G && bk.VS == V) st = grad_thr_launch_##TAG##G##v##V(a, b, stream);
+#define DE_GT_LAUNCH(TAG, G, V) if (k == (#TAG[0] == 'f' ? 0 : 1) && bk.GC == G && bk.VS == V) st = grad_thr_launch_##TAG##G##v##V(a, b, bs);
         DE_GT_ALL(DE_GT_LAUNCH)
-        if (st != hipSuccess) return st;
+        if (st != hipSuccess) { first_err = st; break; }
     }
+    { const hipError_t js = fj.join(); if (first_err == hipSuccess) first_err = js; }
+    if (first_err != hipSuccess) return first_err;
     if (!a.loss) return hipSuccess;
     return launch_loss_grad_finish(dtype, a, (a.e.N + GBLK - 1) / GBLK, stream);
 }
@@ -576,10 +650,15 @@ hipError_t launch_rev_threaded(int dtype, const GradArgs &a0, hipStream_t stream
     GradArgs a;
     { const hipError_t ps = a0.rev_tile_range ? (a = a0, a.prio_ready = false, hipSuccess) : grad_prio_prepass(dtype, a0, stream, &a); if (ps != hipSuccess) return ps; }
     const int64_t n_tiles = (a.e.N + GBLK - 1) / GBLK;
-    for (int k = 0; k < a.rev_n_groups; k++) { // one launch per LDS-need group of trees
-        const hipError_t st = dtype == DE_F32 ? rev_thr_launch_f(a, k, stream) : rev_thr_launch_d(a, k, stream);
-        if (st != hipSuccess) return st;
+    ForkJoin fj(stream, a.rev_n_groups);
+    hipError_t first_err = fj.fork();
+    if (first_err != hipSuccess) return first_err;
+    for (int k = 0; k < a.rev_n_groups; k++) { // one launch per LDS-need group of trees, spread over the side streams
+        const hipError_t st = dtype == DE_F32 ? rev_thr_launch_f(a, k, fj.next()) : rev_thr_launch_d(a, k, fj.next());
+        if (st != hipSuccess) { first_err = st; break; }
     }
+    { const hipError_t js = fj.join(); if (first_err == hipSuccess) first_err = js; }
+    if (first_err != hipSuccess) return first_err;
     if (a.rev_tile_range) return hipSuccess; // by-class: the caller reduces every class's tile range itself
     return launch_loss_grad_finish(dtype, a, n_tiles, stream);
 }
