@@ -531,6 +531,7 @@ static SideStreams *side_streams_of(hipStream_t main, int want) {
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     const std::lock_guard<std::mutex> lock(mu);
     for (auto &e : all) if (e.first.first == dev && e.first.second == main) return e.second->n >= want ? e.second.get() : nullptr;
+    if (all.size() >= 32) return nullptr; // a caller that makes a new stream per call: no side streams for the later ones (nothing is ever freed here)
     std::unique_ptr<SideStreams> ss(new SideStreams());
     if (hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
     for (int i = 0; i < 3; i++) {
