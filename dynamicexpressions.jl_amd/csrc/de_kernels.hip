@@ -2055,6 +2055,65 @@ hipError_t eval_handler_table(int dtype, bool turbo, uint64_t *table) {
 
 bool eval_uses_threaded() { return env_int("DE_EVAL_THREADED", 1) != 0 && env_int("DE_EVAL_G", 1) == 1 && env_int("DE_EVAL_BLOCK", 256) == 256; }
 
+// The same statistics for PACKED, 16-byte aligned Float32 X (ldX == F): a thread takes groups of four consecutive samples = F 16-byte
+// vectors (4 F consecutive floats), so the pass issues a quarter of the load instructions of the scalar loop — which reads X at 1.8 TB/s
+// (0.118 ms for the headline's 200 MB, 2 % of the step).  F is a template parameter: element s * F + f of the group is a fixed register.
+// The <= 3 samples behind the last full group go through the scalar statistics of thread 0 of workgroup 0.
+template <int F>
+__global__ void __launch_bounds__(256) de_tile_extremes_vec_kernel(const float *__restrict__ X, int64_t N, int tile_shift, unsigned long long *__restrict__ keys) {
+    typedef float V4 __attribute__((ext_vector_type(4)));
+    const float inf = __builtin_inff();
+    float v[3][F];
+    uint32_t at[3][F];
+    DE_UNROLL for (int f = 0; f < F; f++) DE_UNROLL for (int k = 0; k < 3; k++) { v[k][f] = -inf; at[k][f] = 0u; }
+    const int64_t groups = N >> 2;
+    const V4 *__restrict__ Xv = reinterpret_cast<const V4 *>(X);
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (int64_t)gridDim.x * 256) {
+        float e[4 * F];
+        DE_UNROLL for (int q = 0; q < F; q++) {
+            const V4 w = Xv[g * F + q];
+            e[4 * q] = w[0]; e[4 * q + 1] = w[1]; e[4 * q + 2] = w[2]; e[4 * q + 3] = w[3];
+        }
+        const uint32_t tile = (uint32_t)((g << 2) >> tile_shift); // (four samples of one group lie in one unit of >= 4 samples)
+        DE_UNROLL for (int sm = 0; sm < 4; sm++)
+            DE_UNROLL for (int f = 0; f < F; f++) {
+                const float x = e[sm * F + f];
+                const bool fin = __builtin_fabsf(x) < inf;
+                const float c[3] = {fin ? x : inf, fin ? -x : inf, fin ? -__builtin_fabsf(x) : inf};
+                DE_UNROLL for (int k = 0; k < 3; k++)
+                    if (c[k] > v[k][f]) { v[k][f] = c[k]; at[k][f] = tile; }
+            }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t j = groups << 2; j < N; j++) {
+            const uint32_t tile = (uint32_t)(j >> tile_shift);
+            DE_UNROLL for (int f = 0; f < F; f++) {
+                const float x = X[f + (int64_t)F * j];
+                const bool fin = __builtin_fabsf(x) < inf;
+                const float c[3] = {fin ? x : inf, fin ? -x : inf, fin ? -__builtin_fabsf(x) : inf};
+                DE_UNROLL for (int k = 0; k < 3; k++)
+                    if (c[k] > v[k][f]) { v[k][f] = c[k]; at[k][f] = tile; }
+            }
+        }
+    __shared__ unsigned long long best[4][3 * F];
+    DE_UNROLL for (int f = 0; f < F; f++)
+        DE_UNROLL for (int k = 0; k < 3; k++) {
+            unsigned long long key = ((unsigned long long)orderable_f32(v[k][f]) << 32) | (unsigned long long)at[k][f];
+            DE_UNROLL for (int m = 32; m >= 1; m >>= 1) {
+                const unsigned long long o = __shfl_xor(key, m, 64);
+                key = o > key ? o : key;
+            }
+            if ((threadIdx.x & 63) == 0) best[threadIdx.x >> 6][3 * f + k] = key;
+        }
+    __syncthreads();
+    if ((int)threadIdx.x < 3 * F) {
+        unsigned long long key = best[0][threadIdx.x];
+        DE_UNROLL for (int w = 1; w < 4; w++) key = best[w][threadIdx.x] > key ? best[w][threadIdx.x] : key;
+        unsigned long long *slot = keys + threadIdx.x;
+        if (key > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, key);
+    }
+}
+
 // The pre-pass of the priority tiles (de_tile_extremes_kernel) for X[F, N]: keys[3 F] = orderable(value) << 32 | (sample / DE_PRIO_UNIT).
 hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX, int F, void *keys, hipStream_t stream) {
     if (!keys || F < 1 || F > DE_PRIO_MAX_F || N < 1) return hipErrorInvalidValue;
@@ -2064,6 +2123,19 @@ hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX
     while ((1 << shift) < DE_PRIO_UNIT) ++shift;
     const int64_t want = (N + 255) / 256;
     const dim3 grid((unsigned)(want < 2048 ? want : 2048));
+    if (dtype == DE_F32 && ldX == F && N >= 4 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0 && DE_PRIO_UNIT >= 4 && env_int("DE_PRIO_VEC", 1)) {
+        const int64_t wantv = ((N >> 2) + 255) / 256;
+        const dim3 gv((unsigned)(wantv < 2048 ? wantv : 2048));
+        unsigned long long *k = static_cast<unsigned long long *>(keys);
+        const float *x = static_cast<const float *>(X);
+        switch (F) {
+#define DE_TEV(FF) case FF: hipLaunchKernelGGL((de_tile_extremes_vec_kernel<FF>), gv, dim3(256), 0, stream, x, N, shift, k); break;
+            DE_TEV(1) DE_TEV(2) DE_TEV(3) DE_TEV(4) DE_TEV(5) DE_TEV(6) DE_TEV(7) DE_TEV(8)
+#undef DE_TEV
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     if (dtype == DE_F32)
         hipLaunchKernelGGL((de_tile_extremes_kernel<float, DE_PRIO_MAX_F>), grid, dim3(256), 0, stream, static_cast<const float *>(X), N, ldX, F, shift,
                            static_cast<unsigned long long *>(keys));
