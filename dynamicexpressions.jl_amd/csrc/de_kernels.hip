@@ -5,7 +5,7 @@
 //
 // Design:
 //  * grid  = sample tiles x tree chunks.  The threaded kernel (the default): a workgroup is ONE wave64 (DE_TBLK = 64) that owns
-//    TILE = 256 consecutive Float32 samples (4 per lane; 128 Float64) and runs a chunk of <= 64 trees as ONE chain of
+//    TILE = 256 consecutive Float32 samples (4 per lane; 128 Float64) and runs a chunk of <= 63 trees as ONE chain of
 //    direct-threaded handlers; the flat-switch fall-back kernel uses 256 threads = 4 wave64 and G vectors per thread.
 //    Large early-exit launches are three launches: the priority tiles as a probe, the compaction of the live trees
 //    (de_compact_live_kernel), the launch proper over the re-linked stream.
@@ -22,8 +22,9 @@
 //  * NaN/Inf flag: per-lane poison, one wavefront ballot per tree, one byte
 //    store per failing wave (no atomics) — and the reference's EARLY EXIT at tree granularity: a workgroup reads the flags of
 //    its chunk once and does not evaluate trees that an earlier workgroup already found incomplete (h_tree_skip).
-//  * blockIdx -> (tile, chunk) is XCD-aware: all chunks of one X tile run on the
-//    same XCD, so the tile is fetched from HBM once and re-served by that XCD's L2.
+//  * blockIdx -> (tile, chunk) is XCD-aware (block b runs on XCD b % 8).  Narrow X (F <= trees per chunk / 8, the default case): chunk-MAJOR,
+//    every workgroup in flight walks the same chunk's records (scalar-cache hits) and X is re-read from HBM once per chunk; wide X:
+//    all chunks of one X tile back to back on one XCD, the tile re-served by that XCD's L2 (map_block / map_block_grouped).
 //  * No MFMA: this is an elementwise map, not a contraction.
 #include <hip/hip_runtime.h>
 #include <memory>
