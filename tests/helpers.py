@@ -89,8 +89,8 @@ def value_tolerance(y, y64, dtype):
 
 
 def unstable_selections(clean, noisy_runs, N):
-    """[N] bool: samples where a SELECTING operator (max, min, greater, clamp) could pick differently in two correct
-    implementations.  `clean` = the (x, y) operand pairs of the selecting operators of an unperturbed float64 run, in program
+    """[N] bool: samples where a SELECTING operator (max, min, greater, clamp; abs / relu / sign against 0, floor / ceil / round against
+    their nearest edge) could pick differently in two correct implementations.  `clean` = the (x, y) operand pairs of the selecting operators of an unperturbed float64 run, in program
     order; `noisy_runs` = the same lists of the 1-ulp-perturbed runs.  A sample is unstable when the operands are closer
     than 8x (the factor of the tolerance itself) the largest deviation the perturbed operands showed.
 
@@ -98,7 +98,9 @@ def unstable_selections(clean, noisy_runs, N):
     operand 8 % of the time above 0.966 shows no spread in 16 draws one time in four (fuzz seed 42, tree 398: device =
     the mpmath value, the ORACLE 778 x the old tolerance off), and the derivative of such a node switches between two
     unrelated values (seed 41: the device on the other branch of neg(max(tanh(..), cos(exp(x1)))), 2e17 x the old tolerance;
-    profiles/r4_fuzz_summary.md, tools/trace_findings.py).  Ties of bit-identical operands (dev == 0) stay comparable."""
+    profiles/r4_fuzz_summary.md, tools/trace_findings.py).  Unary selectors joined after fuzz seed 51 (tree 148, relu(sin(square(abs(cube(..)))))
+    with the sine's argument ~1e4 in Float32: device and oracle agree to 8e-8 on one side of relu's edge, the float64 model sits on the other
+    and prices a derivative of exactly 0).  Ties of bit-identical operands (dev == 0) stay comparable."""
     bad = np.zeros(N, dtype=bool)
     with np.errstate(all="ignore"):
         for i, (xc, yc) in enumerate(clean):
@@ -328,6 +330,12 @@ def grad_tolerance(tree, ops, X, dtype, mode, params=None, classes=None, class_b
                 raise Unsupported(name)
             f, g = _G1[name]
             x, dx = kids[0]
+            if name in ("abs", "relu", "sign"):       # unary SELECTORS: the derivative (sign: the value) jumps at 0
+                sel_log.append((x, np.zeros_like(x)))
+            elif name in ("floor", "ceil"):
+                sel_log.append((x, np.rint(x)))
+            elif name == "round":
+                sel_log.append((x, np.floor(x) + 0.5))
             p = jitter(g(x), 2 * noise)
             if name == "tanh" and noise != 0.0:
                 # d tanh = 1 - tanh^2 is a DIFFERENCE: next to saturation its error is an ulp of 1, not of the (tiny) partial — the

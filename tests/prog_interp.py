@@ -76,7 +76,7 @@ def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noi
     measures how strongly a sample amplifies a one-rounding-error difference between two
     implementations of the same operator (used for the parity tolerance, helpers.py).
 
-    ``select_log`` (a list) receives, in program order, the operand pair (x, y) of every SELECTING operator (max, min,
+    ``select_log`` (a list) receives, in program order, the operand pair (x, y) of every SELECTING operator (abs / relu / sign / floor / ceil / round: the operand and the edge it is compared with; max, min,
     greater, clamp, max3): helpers.unstable_selections compares the pairs of a clean and of the perturbed runs."""
     dt = X.dtype
     N = X.shape[1]
@@ -113,6 +113,12 @@ def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noi
                 if op == DOP_LOAD:
                     acc = b
                 elif op < 64:
+                    if select_log is not None and op in (2, 5, 6, 7, 8, 9):
+                        # unary operators that SELECT: abs / relu / sign against 0 (their derivative — for sign the value — jumps there),
+                        # floor / ceil against the nearest integer, round against the nearest half-integer (the value jumps)
+                        b64 = b.astype(np.float64)
+                        edge = np.zeros_like(b64) if op in (2, 5, 6) else (np.rint(b64) if op in (8, 9) else np.floor(b64) + 0.5)
+                        select_log.append((b64, edge))
                     acc = UNARY[op](b).astype(dt)
                 else:
                     if select_log is not None and op in (69, 70, 73, 0xF6):
