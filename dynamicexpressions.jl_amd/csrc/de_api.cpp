@@ -2746,7 +2746,10 @@ static int loss_grad_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N
         n_tiles = (int64_t)(tile_range.size() / 2);
     }
     HIP_TRY(c, c->sPartial.reserve((size_t)n_tiles * (size_t)n_cols * 4 * es));
-    HIP_TRY(c, c->sSeg.reserve((size_t)loss_segments(n_tiles) * (size_t)n_cols * 4 * sizeof(double)));
+    // (by class: three regions — the finish passes of the classes run on the caller's stream and two side streams, launch_loss_grad_finish_ranges)
+    const size_t seg_region = (size_t)loss_segments(n_tiles) * (size_t)n_cols * 4 * sizeof(double);
+    const int seg_regions = plan ? 3 : 1;
+    HIP_TRY(c, c->sSeg.reserve(seg_region * (size_t)seg_regions));
     HIP_TRY(c, c->sNg.reserve(ng.size() * sizeof(int32_t)));
     HIP_TRY(c, c->sColOff.reserve(coloff.size() * sizeof(int64_t)));
     HIP_TRY(c, c->sDoff.reserve(doff.size() * sizeof(int64_t)));
@@ -2835,10 +2838,8 @@ static int loss_grad_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N
     if (g.rev_code) HIP_TRY(c, launch_rev_threaded(p->dtype, g, c->stream, &c->last_kernel));
     else HIP_TRY(c, launch_grad(p->dtype, g, c->stream, &c->last_kernel));
     if (plan) { // one pair of finish passes per class over its own tiles
-        for (int64_t k = 0; k < plan->C; k++)
-            HIP_TRY(c, launch_loss_grad_finish_range(p->dtype, g, class_tile0[(size_t)k], class_tile0[(size_t)k + 1] - class_tile0[(size_t)k],
-                                                     static_cast<char *>(plan->loss_c) + (size_t)k * (size_t)p->n_trees * es,
-                                                     static_cast<char *>(plan->dloss_c) + (size_t)k * (size_t)plan->span * es, c->stream));
+        HIP_TRY(c, launch_loss_grad_finish_ranges(p->dtype, g, plan->C, class_tile0.data(), plan->loss_c, (size_t)p->n_trees * es, plan->dloss_c,
+                                                  (size_t)plan->span * es, seg_region, seg_regions, c->stream));
         plan->done = true;
     }
     if (!c->nested) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));

@@ -578,6 +578,32 @@ struct ForkJoin {
     }
 };
 
+// de_eval_loss_grad_by_class: the pair of finish passes of every class over its own tiles (class k: tiles [tile0[k], tile0[k + 1])) — 2 C
+// launches of ~25 us each, independent of each other except for the segment sums they stage: spread over the caller's stream and its side
+// streams, each with a region of its own in `seg_sum` (seg_stride bytes apart; classes of one stream run in order).  Same launches, same
+// reduction order per class: the same bits as one call per class.
+hipError_t launch_loss_grad_finish_ranges(int dtype, const GradArgs &ga, int64_t n_classes, const int64_t *tile0, void *loss, size_t loss_stride,
+                                          void *dloss, size_t dloss_stride, size_t seg_stride, int seg_regions, hipStream_t stream) {
+    ForkJoin fj(stream, seg_regions > 1 ? (int)std::min<int64_t>(n_classes, seg_regions) : 1);
+    hipError_t first_err = fj.fork();
+    if (first_err != hipSuccess) return first_err;
+    for (int64_t k = 0; k < n_classes; k++) {
+        const int slot = fj.slot % (fj.n_side + 1);
+        const hipStream_t ks = fj.next();
+        LossArgs la = *ga.loss;
+        GradArgs g = ga;
+        la.partial = static_cast<char *>(la.partial) + (size_t)tile0[k] * (size_t)ga.n_cols * 4 * (dtype == DE_F32 ? 4 : 8);
+        la.seg_sum = static_cast<char *>(la.seg_sum) + (size_t)slot * seg_stride;
+        la.loss = static_cast<char *>(loss) + (size_t)k * loss_stride;
+        g.loss = &la;
+        g.dloss = static_cast<char *>(dloss) + (size_t)k * dloss_stride;
+        const hipError_t st = dtype == DE_F32 ? loss_grad_finish_t<float>(g, tile0[k + 1] - tile0[k], ks) : loss_grad_finish_t<double>(g, tile0[k + 1] - tile0[k], ks);
+        if (st != hipSuccess) { first_err = st; break; }
+    }
+    { const hipError_t js = fj.join(); if (first_err == hipSuccess) first_err = js; }
+    return first_err;
+}
+
 static hipError_t grad_prio_prepass(int dtype, const GradArgs &a, hipStream_t stream, GradArgs *with);
 hipError_t launch_grad_threaded(int dtype, const GradArgs &a0, hipStream_t stream, const char **kernel_name) {
     if (kernel_name) *kernel_name = "de_grad_threaded_kernel";

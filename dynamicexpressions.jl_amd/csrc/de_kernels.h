@@ -150,6 +150,9 @@ hipError_t launch_grad_threaded(int dtype, const GradArgs &a, hipStream_t stream
 hipError_t launch_loss_grad_finish(int dtype, const GradArgs &ga, int64_t n_tiles, hipStream_t stream);
 // the same over tiles [tile0, tile0 + n_tiles) only, results to loss / dloss (by-class reduction: one call per class)
 hipError_t launch_loss_grad_finish_range(int dtype, const GradArgs &ga, int64_t tile0, int64_t n_tiles, void *loss, void *dloss, hipStream_t stream);
+// ... of all classes at once, over the caller's stream and its side streams: seg_regions regions of ga.loss->seg_sum, seg_stride bytes apart
+hipError_t launch_loss_grad_finish_ranges(int dtype, const GradArgs &ga, int64_t n_classes, const int64_t *tile0, void *loss, size_t loss_stride,
+                                          void *dloss, size_t dloss_stride, size_t seg_stride, int seg_regions, hipStream_t stream);
 // de_eval_loss_grad_by_class: per-class results ([C][n_trees] losses and flags, [C][span] gradients) -> outputs
 struct ByClassArgs {
     const void *loss_c, *dloss_c;
