@@ -624,18 +624,28 @@ template <typename T> using BodyFn = BState<T> (*)(BState<T>, uint32_t, typename
 // ... and, in VECTOR registers, this thread's residual targets and weights of the fused loss (ly, lw: 8 registers every handler passes
 // on untouched, undefined outside a fused-loss launch): the end of a tree forms its loss partial from them (h_tree_end_slow, HF_LOSS).
 #define HL_T typename VecOf<T>::type
-#if DE_TG == 1
-#define HL_PARAMS HL_T ly0, HL_T lw0
-#define HL_PASS ly0, lw0
-#define HL_BOTH(ly, lw) const HLoss<T> ly{{ly0, ly0}}, lw{{lw0, lw0}}
-#define HL_TYPES(V) V, V
-#else
-#define HL_PARAMS HL_T ly0, HL_T ly1, HL_T lw0, HL_T lw1
-#define HL_PASS ly0, ly1, lw0, lw1
-#define HL_BOTH(ly, lw) const HLoss<T> ly{{ly0, ly1}}, lw{{lw0, lw1}}
-#define HL_TYPES(V) V, V, V, V
+// (the *_C forms carry their trailing comma: a build without the fused loss — -DDE_NO_LOSS=1, the cross-wave module de_kernels_xs — drops
+// the arguments altogether: 8 / 16 vector registers every handler would otherwise keep pinned)
+#ifndef DE_NO_LOSS
+#define DE_NO_LOSS 0
 #endif
-template <typename T> using HandlerFn = HState<T> (*)(HState<T>, HL_TYPES(HL_T), uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t);
+#if DE_NO_LOSS
+#define HL_PARAMS_C
+#define HL_PASS_C
+#define HL_BOTH(ly, lw) const HLoss<T> ly{}, lw{}
+#define HL_TYPES_C(V)
+#elif DE_TG == 1
+#define HL_PARAMS_C HL_T ly0, HL_T lw0,
+#define HL_PASS_C ly0, lw0,
+#define HL_BOTH(ly, lw) const HLoss<T> ly{{ly0, ly0}}, lw{{lw0, lw0}}
+#define HL_TYPES_C(V) V, V,
+#else
+#define HL_PARAMS_C HL_T ly0, HL_T ly1, HL_T lw0, HL_T lw1,
+#define HL_PASS_C ly0, ly1, lw0, lw1,
+#define HL_BOTH(ly, lw) const HLoss<T> ly{{ly0, ly1}}, lw{{lw0, lw1}}
+#define HL_TYPES_C(V) V, V, V, V,
+#endif
+template <typename T> using HandlerFn = HState<T> (*)(HState<T>, HL_TYPES_C(HL_T) uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t);
 enum : uint32_t { HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu,
                   HF_SLOW = 1u << 31, // set with any of HF_SLOW_STORE / HF_NO_STORE / HF_LOSS: the out-of-line end of a tree (the sign bit: ONE scalar compare)
                   // plain flag stores (through the caches): always, except under flag protocol 1 (agent scope for every access, an
@@ -659,8 +669,8 @@ template <> __device__ __forceinline__ uint64_t arg_imm<double>(uint32_t, uint64
 #define DE_SKIPLIST_BYTES 256u // LDS bytes in front of row 0: the live trees of the running (sub-)chunk (h_tree_skip), 64 x 4 bytes
 template <typename T> struct RowOf { static constexpr uint32_t BYTES = (uint32_t)(DE_TBLK * TG<T>::G + 1) * 16u; }; // LDS row stride: the planes + one vector of padding (= trow_bytes, de_kernels.h)
 // `code` points at the record of the NEXT instruction; (la, w1, w23) are this instruction's record
-#define HCHAIN_ARGS HState<T> st, HL_PARAMS, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint64_t skip, uint32_t left, uint32_t flags
-#define HCHAIN_NEXT_AT(W, NEXT) [[clang::musttail]] return arg_next<T>(w1, w23)(st, HL_PASS, lds0, NEXT, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
+#define HCHAIN_ARGS HState<T> st, HL_PARAMS_C uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint64_t skip, uint32_t left, uint32_t flags
+#define HCHAIN_NEXT_AT(W, NEXT) [[clang::musttail]] return arg_next<T>(w1, w23)(st, HL_PASS_C lds0, NEXT, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
 // record address + k records WITHOUT a carry into the high half: the stream lies inside one 4 GiB window (checked where it is allocated,
 // de_api.cpp), so the bump is ONE scalar instruction (s_add_u32) instead of the add / add-with-carry pair — the cheap handlers are bound
 // by their scalar instructions (tools/probe/issue_probe.py: one per ~4 cycles and SIMD; `acc * const` = 6 of them = 24 cycles)
@@ -728,7 +738,7 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS)
     const uint64_t hdr = ((uint64_t)(uintptr_t)code & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
     const ConstU4Ptr nh = (ConstU4Ptr)(uintptr_t)hdr; // the tree's header record (the record in front of its first instruction)
     const U32x4 hn = nh[0], w = nh[1];
-    [[clang::musttail]] return arg_next<T>(hn.y, ((uint64_t)hn.w << 32) | hn.z)(st, HL_PASS, lds0, code_at(nh, 2), outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, skip, left, flags);
+    [[clang::musttail]] return arg_next<T>(hn.y, ((uint64_t)hn.w << 32) | hn.z)(st, HL_PASS_C lds0, code_at(nh, 2), outp, w.x, w.y, ((uint64_t)w.w << 32) | w.z, okp, ldo, skip, left, flags);
 }
 // the rest of a tree's end: flag byte, last tree of the chunk?, clear the state, on to the next tree (W = its first record,
 // HDR = the address of its header record) unless that one is skipped.  `tree` (a local of the caller) = the tree's index, the
@@ -752,7 +762,7 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS)
     de_end_special:;                                                                                         \
         const uint32_t left_now = 63u - (uint32_t)__builtin_clzll(skip); /* trees left including this one = the sentinel's bit */ \
         if (left_now <= 1u) return st;                                                                       \
-        [[clang::musttail]] return h_tree_skip<T>(st, HL_PASS, lds0, HDR, outp, la, w1, w23, okp, ldo, skip >> 1, left_now - 1u, flags); \
+        [[clang::musttail]] return h_tree_skip<T>(st, HL_PASS_C lds0, HDR, outp, la, w1, w23, okp, ldo, skip >> 1, left_now - 1u, flags); \
     }
 typedef __attribute__((address_space(1))) char *GPtr; // global, not flat: a flat store also ties up lgkmcnt
 // The other ends of a tree (flags & HF_SLOW), out of line so that h_tree_end itself is straight-line code: HF_LOSS (fused loss:
@@ -763,7 +773,7 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_A
     const U32x4 w = *code;
     const uint32_t tree = la;
     const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * ldo);
-    if (flags & HF_LOSS) {
+    if (!DE_NO_LOSS && (flags & HF_LOSS)) {
         // sum_j w_j * l(out_j - y_j) over this wave's 64 * VW samples -> one partial per (tile, tree, wave): outp = &partial[tile, 0, wave],
         // ldo = bytes between two trees' partials (weight 0: samples past N)
         T s = T(0);
@@ -806,7 +816,7 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end_slow(HCHAIN_A
 }
 template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) {
     typedef typename VecOf<T>::type V;
-    if (__builtin_expect((int32_t)flags < 0, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, HL_PASS, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags);
+    if (__builtin_expect((int32_t)flags < 0, 0)) [[clang::musttail]] return h_tree_end_slow<T>(st, HL_PASS_C lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags);
     const U32x4 w = *code;
     const uint32_t tree = la; // this IS the end record
     const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * (uint64_t)(uint32_t)ldo); // wave-uniform: the store takes it as its scalar base
@@ -822,7 +832,7 @@ template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain_
     const uint32_t tree = *reinterpret_cast<const DE_CONSTANT uint32_t *>(code); // the end record this handler steps over: its operand word
     if (__builtin_expect((int32_t)flags < 0, 0)) {
         planes_apply<T, BODY>(st, lds0 + la, arg_imm<T>(w1, w23));
-        [[clang::musttail]] return h_tree_end_slow<T>(st, HL_PASS, lds0, code_at(code, 1), outp, tree, w1, w23, okp, ldo, skip, left, flags);
+        [[clang::musttail]] return h_tree_end_slow<T>(st, HL_PASS_C lds0, code_at(code, 1), outp, tree, w1, w23, okp, ldo, skip, left, flags);
     }
     const U32x4 w = code[1];
     planes_apply<T, BODY>(st, lds0 + la, arg_imm<T>(w1, w23));
@@ -1123,15 +1133,54 @@ template <int K, bool TB> __device__ __forceinline__ VecOf<float>::type un_finis
         return V{ya[0], ya[1], yb[0], yb[1]};
     }
 }
-#if DE_TG == 1
-#define HFAST_LOSS VecOf<float>::type ly0, VecOf<float>::type lw0
-#else
-#define HFAST_LOSS VecOf<float>::type ly0, VecOf<float>::type ly1, VecOf<float>::type lw0, VecOf<float>::type lw1
+// ... for ALL planes of a dispatch (two planes, exact mode): both planes' polynomials first, ONE wave-uniform extremum decision for the
+// dispatch (per plane it would be a branch between the planes' instruction streams: the scheduler could not interleave them), then the
+// signs.  The same operations per element as un_finish: the same bits.
+template <int K, bool TB, int G> __device__ __forceinline__ void un_finish_planes(VecOf<float>::type (&out)[G], const VecOf<float>::type (&x)[G], const UnPre (&p)[G]) {
+    typedef VecOf<float>::type V;
+    if constexpr (K == 1 || TB || G == 1) {
+        DE_UNROLL for (int g = 0; g < G; g++) out[g] = un_finish<K, TB>(x[g], p[g]);
+    } else {
+        constexpr bool SIN = K == 2;
+        DeF2 sa[G], sb[G];
+        DE_UNROLL for (int g = 0; g < G; g++) {
+            sa[g] = trig_poly_f32x2<SIN, TB>(DeF2{x[g][0], x[g][1]}, p[g].ta);
+            sb[g] = trig_poly_f32x2<SIN, TB>(DeF2{x[g][2], x[g][3]}, p[g].tb);
+        }
+#ifndef DE_TRIG_NO_EXTREMUM_FIX
+        DeF2 ra[G], rb[G];
+        bool near = false;
+        DE_UNROLL for (int g = 0; g < G; g++) {
+            ra[g] = trig_reduced_f32x2<SIN, TB>(DeF2{x[g][0], x[g][1]}, p[g].ta);
+            rb[g] = trig_reduced_f32x2<SIN, TB>(DeF2{x[g][2], x[g][3]}, p[g].tb);
+            const DeF2 za = ra[g] * ra[g], zb = rb[g] * rb[g];
+            near |= __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(za[0], za[1]), zb[0]), zb[1]) > (0x1.3bd3ccp+1f - 8.0e-4f);
+        }
+        if (__builtin_expect(__ballot(near) != 0ull, 0)) {
+            asm volatile("" ::: "memory"); // a REAL branch (see un_finish)
+            DE_UNROLL for (int g = 0; g < G; g++) {
+                sa[g][0] = trig_extremum_fix(ra[g][0], sa[g][0]); sa[g][1] = trig_extremum_fix(ra[g][1], sa[g][1]);
+                sb[g][0] = trig_extremum_fix(rb[g][0], sb[g][0]); sb[g][1] = trig_extremum_fix(rb[g][1], sb[g][1]);
+            }
+        }
 #endif
-#define HFAST_ARGS HState<float> st, HFAST_LOSS, uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, \
+        DE_UNROLL for (int g = 0; g < G; g++) {
+            const DeF2 ya = fast_trig_sign_f32x2(sa[g], p[g].ka), yb = fast_trig_sign_f32x2(sb[g], p[g].kb);
+            out[g] = V{ya[0], ya[1], yb[0], yb[1]};
+        }
+    }
+}
+#if DE_NO_LOSS
+#define HFAST_LOSS_C
+#elif DE_TG == 1
+#define HFAST_LOSS_C VecOf<float>::type ly0, VecOf<float>::type lw0,
+#else
+#define HFAST_LOSS_C VecOf<float>::type ly0, VecOf<float>::type ly1, VecOf<float>::type lw0, VecOf<float>::type lw1,
+#endif
+#define HFAST_ARGS HState<float> st, HFAST_LOSS_C uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, \
                    uint64_t skip, uint32_t left, uint32_t flags
-#define HFAST_PASS st, HL_PASS, lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags
-#define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, HL_PASS, lds0, code_at(code, 1), outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
+#define HFAST_PASS st, HL_PASS_C lds0, code, outp, la, w1, w23, okp, ldo, skip, left, flags
+#define HFAST_NEXT(W) [[clang::musttail]] return arg_next<float>(w1, w23)(st, HL_PASS_C lds0, code_at(code, 1), outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
 // the end of a tree behind a fast-path body: what h_chain_end does (T = float)
 #define HFAST_END_TAIL()                                                                                                    \
     {                                                                                                                       \
@@ -1155,10 +1204,15 @@ template <int K, int VAR, bool TB> __device__ __noinline__ HState<float> h_un_fa
     bool slow = false;
     FOR_PLANES slow |= un_pretest<K, TB>(x[g], p[g]);
     if (__builtin_expect(__ballot(slow) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_un<T, K, VAR, TB>>(HFAST_PASS);
+#if DE_TG == 1
     FOR_PLANES {
         st.acc[g] = un_finish<K, TB>(x[g], p[g]);
         if constexpr (VAR & 1) hpoison<T>(st.poison, st.acc[g]);
     }
+#else
+    un_finish_planes<K, TB, G>(st.acc, x, p);
+    if constexpr (VAR & 1) FOR_PLANES hpoison<T>(st.poison, st.acc[g]);
+#endif
     HFAST_NEXT(w);
 }
 // ... as the last instruction of a tree (the end-fused form of b_un<K, 1>: accumulator operand, tested result)
@@ -1169,10 +1223,15 @@ template <int K, bool TB> __device__ __noinline__ HState<float> h_un_end_fast(HF
     bool slow = false;
     FOR_PLANES slow |= un_pretest<K, TB>(st.acc[g], p[g]);
     if (__builtin_expect(((int32_t)flags < 0) | (__ballot(slow) != 0ull), 0)) [[clang::musttail]] return h_chain_end<T, &b_un<T, K, 1, TB>>(HFAST_PASS);
+#if DE_TG == 1
     FOR_PLANES {
         st.acc[g] = un_finish<K, TB>(st.acc[g], p[g]);
         hpoison<T>(st.poison, st.acc[g]);
     }
+#else
+    un_finish_planes<K, TB, G>(st.acc, st.acc, p);
+    FOR_PLANES hpoison<T>(st.poison, st.acc[g]);
+#endif
     HFAST_END_TAIL()
 }
 // ... fused with a spill of the accumulator and / or the validity test of its row operand (b_unrow_f)
@@ -1190,11 +1249,17 @@ template <int K, bool OUT, bool PUSH, bool CHK, bool TB> __device__ __noinline__
     bool slow = false;
     FOR_PLANES slow |= un_pretest<K, TB>(x[g], p[g]);
     if (__builtin_expect(__ballot(slow) != 0ull, 0)) [[clang::musttail]] return h_chain<T, &b_unrow_f<T, K, OUT, PUSH, CHK, TB>>(HFAST_PASS);
+#if DE_TG == 1
     FOR_PLANES {
         if constexpr (CHK) hpoison<T>(st.poison, x[g]);
         st.acc[g] = un_finish<K, TB>(x[g], p[g]);
         if constexpr (OUT) hpoison<T>(st.poison, st.acc[g]);
     }
+#else
+    if constexpr (CHK) FOR_PLANES hpoison<T>(st.poison, x[g]);
+    un_finish_planes<K, TB, G>(st.acc, x, p);
+    if constexpr (OUT) FOR_PLANES hpoison<T>(st.poison, st.acc[g]);
+#endif
     HFAST_NEXT(w);
 }
 // The exact Float32 divisions (K = 4: acc / operand, 5: operand / acc; VAR as in b_bin) likewise: range test, then either the
@@ -1847,7 +1912,8 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         }
         const U32x4 hp = rec[-1], hd = *rec; // the first handler's address is in the record in front (the previous tree's end record / the head record)
         st = arg_next<T>(hp.y, ((uint64_t)hp.w << 32) | hp.z)(st,
-#if DE_TG == 1
+#if DE_NO_LOSS
+#elif DE_TG == 1
                                                               yv.v[0], wv.v[0],
 #else
                                                               yv.v[0], yv.v[1], wv.v[0], wv.v[1],
@@ -2236,6 +2302,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.y = a.w = nullptr;
     a.partial = nullptr;
     a.loss_kind = 0;
+    if (e.loss && DE_NO_LOSS) return hipErrorInvalidValue; // (a build without the loss arguments)
     if (e.loss) {
         kern = e.uses_params ? de_eval_threaded_kernel<T, true, true> : de_eval_threaded_kernel<T, false, true>;
         a.y = static_cast<const T *>(e.loss->y);

@@ -160,13 +160,14 @@ function option_bits(operators::OperatorEnum, ctx::EvalContext; full_eval::Bool=
 end
 
 # ---- flattening: post-order tape + constant pool (depth-first, left to right) ---------------
+# (`cbase` = length(consts) when the tree starts: constant slots are numbered per tree, the pool of a population is shared)
 function flatten!(
-    nodes::Vector{TapeNode}, consts::Vector{T}, tree::AbstractExpressionNode{T}, optable
+    nodes::Vector{TapeNode}, consts::Vector{T}, tree::AbstractExpressionNode{T}, optable, cbase::Int=0
 ) where {T}
     if tree.degree == 0
         if tree.constant
             push!(consts, tree.val)
-            push!(nodes, TapeNode(0x00, DE_LEAF_CONST, UInt16(length(consts) - 1)))
+            push!(nodes, TapeNode(0x00, DE_LEAF_CONST, UInt16(length(consts) - 1 - cbase)))
         elseif hasproperty(tree, :is_parameter) && tree.is_parameter   # ParametricNode
             push!(nodes, TapeNode(0x00, DE_LEAF_PARAM, UInt16(tree.parameter - 1)))
         else
@@ -175,7 +176,7 @@ function flatten!(
     else
         d = Int(tree.degree)
         for c in get_children(tree, d)
-            flatten!(nodes, consts, c, optable)
+            flatten!(nodes, consts, c, optable, cbase)
         end
         push!(nodes, TapeNode(UInt8(d), optable[d][tree.op], 0x0000))
     end
@@ -314,23 +315,31 @@ function _hip_eval_tree_array(
     out = Vector{T}(undef, N)
     ok = Ref{UInt8}(0)
     ctx = task_context()
-    rc = lock(ctx.lock) do; GC.@preserve nodes consts X out ccall(
-        (:de_eval_tree_array, LIBDE), Cint,
-        (Ptr{Cvoid}, Cint, Ptr{TapeNode}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int32, Int64, UInt32,
-         Ptr{Cvoid}, Ref{UInt8}),
-        ctx.handle, dtype_code(T), nodes, length(nodes), consts, length(consts), X, F, N,
-        option_bits(operators, eval_context; full_eval), out, ok)
+    with_ctx(ctx) do h
+        check(ctx, GC.@preserve nodes consts X out ccall(
+            (:de_eval_tree_array, LIBDE), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{TapeNode}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int32, Int64, UInt32,
+             Ptr{Cvoid}, Ref{UInt8}),
+            h, dtype_code(T), nodes, length(nodes), consts, length(consts), X, F, N,
+            option_bits(operators, eval_context; full_eval), out, ok))
     end
-    check(ctx, rc)
     return (out, ok[] != 0x00)   # ok == false: `out` is all NaN unless full_eval (only the flag is contractual, SURVEY.md §8a)
 end
 
 # ---- population form: lower many trees once, evaluate in one launch -------------------------
+# GraphNode populations: the library keeps one constant slot per OCCURRENCE of a constant leaf (the expanded tape); to the user a
+# shared constant is ONE constant (count_constant_nodes with f_on_shared, src/NodeUtils.jl:43-51) with ONE gradient row (the shared
+# NodeIndex entry, :184-201).  `occ[t]` (occurrence_map) maps tree t's slots to its unique constants — `nothing` when no constant
+# of the tree is shared —, `n_slots[t]` / `n_consts[t]` count both: set_population_constants! fans values out, the gradient
+# entry points sum the occurrence rows (combine_rows) — the mirror of api.py's `_occ` / `_combine_rows`.
 mutable struct HIPPopulation{T}
     ctx::HIPContext
     handle::Ptr{Cvoid}
     n_trees::Int
     n_features::Int
+    occ::Vector{Union{Nothing,Vector{Int}}}
+    n_slots::Vector{Int}
+    n_consts::Vector{Int}
 end
 function finalize_population(p::HIPPopulation)
     c = p.ctx
@@ -347,6 +356,14 @@ function finalize_population(p::HIPPopulation)
     end
     return nothing
 end
+"""Run `f(context handle, program handle)` holding the lock of the population's context (every entry point does: a `de_ctx_t` is
+not thread-safe, and `finalize_population` of ANOTHER population of the same context may run on a GC thread at any time)."""
+function with_pop(f, pop::HIPPopulation)
+    return with_ctx(pop.ctx) do h
+        pop.handle == C_NULL && error("HIP population was destroyed")
+        f(h, pop.handle)
+    end
+end
 function HIPPopulation(
     trees::AbstractVector{<:AbstractExpressionNode{T}}, operators::OperatorEnum, n_features::Integer;
     eval_context::EvalContext=EvalContext(), n_params::Integer=0, full_eval::Bool=false,
@@ -354,28 +371,59 @@ function HIPPopulation(
     optable = opcode_table(operators)
     nodes, consts, cse = TapeNode[], T[], TapeNode[]
     node_off, const_off, cse_off = Int64[0], Int64[0], Int64[0]
+    occ = Union{Nothing,Vector{Int}}[]
+    n_slots, n_consts = Int[], Int[]
     for t in trees
-        flatten!(nodes, consts, t, optable)
+        c0 = length(consts)
+        flatten!(nodes, consts, t, optable, c0)   # constant slots are numbered PER TREE (de_tape_node_t.arg)
         push!(node_off, length(nodes)); push!(const_off, length(consts))
+        o = nothing
         if preserve_sharing(typeof(t))            # GraphNode: a second, CSE tape for the eval program
             mark = length(cse)
             flatten_cse!(cse, t, optable) == 0 && resize!(cse, mark)
+            om = occurrence_map(t)
+            (!isempty(om) && maximum(om) < length(om)) && (o = om)   # some constant leaf occurs more than once
         end
         push!(cse_off, length(cse))
+        push!(occ, o)
+        push!(n_slots, length(consts) - c0)
+        push!(n_consts, o === nothing ? length(consts) - c0 : maximum(o))
     end
     ctx = task_context()
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    rc = lock(ctx.lock) do; GC.@preserve nodes consts node_off const_off cse cse_off ccall(
-        (:de_program_create_cse, LIBDE), Cint,
-        (Ptr{Cvoid}, Cint, Ptr{TapeNode}, Ptr{Int64}, Ptr{TapeNode}, Ptr{Int64}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int32, Int32,
-         UInt32, Ref{Ptr{Cvoid}}),
-        ctx.handle, dtype_code(T), nodes, node_off, isempty(cse) ? C_NULL : pointer(cse), cse_off, length(trees), consts,
-        const_off, n_features, n_params, option_bits(operators, eval_context; full_eval), h)
+    with_ctx(ctx) do hc
+        check(ctx, GC.@preserve nodes consts node_off const_off cse cse_off ccall(
+            (:de_program_create_cse, LIBDE), Cint,
+            (Ptr{Cvoid}, Cint, Ptr{TapeNode}, Ptr{Int64}, Ptr{TapeNode}, Ptr{Int64}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int32, Int32,
+             UInt32, Ref{Ptr{Cvoid}}),
+            hc, dtype_code(T), nodes, node_off, isempty(cse) ? C_NULL : pointer(cse), cse_off, length(trees), consts,
+            const_off, n_features, n_params, option_bits(operators, eval_context; full_eval), h))
     end
-    check(ctx, rc)
-    pop = HIPPopulation{T}(ctx, h[], length(trees), n_features)
+    pop = HIPPopulation{T}(ctx, h[], length(trees), n_features, occ, n_slots, n_consts)
     finalizer(finalize_population, pop)
     return pop
+end
+"""Gradient rows (or entries) of tree `t` in the library's per-occurrence layout -> the reference's layout: the rows of a shared
+constant are summed.  `g` is a vector of entries or a matrix with one ROW per gradient component; the `lead` rows in front of
+the constants (features in `:both` mode) pass through.  `mode == 0` (`variable=true`) has no constant rows."""
+function combine_rows(pop::HIPPopulation, t::Integer, g::AbstractVecOrMat, mode::Integer)
+    o = pop.occ[t]
+    (o === nothing || mode == 0) && return g
+    lead = size(g, 1) - length(o)
+    nu = pop.n_consts[t]
+    out = g isa AbstractVector ? zeros(eltype(g), lead + nu) : zeros(eltype(g), lead + nu, size(g, 2))
+    if g isa AbstractVector
+        out[1:lead] .= g[1:lead]
+        for (k, u) in enumerate(o)
+            out[lead + u] += g[lead + k]
+        end
+    else
+        out[1:lead, :] .= g[1:lead, :]
+        for (k, u) in enumerate(o)
+            out[lead + u, :] .+= g[lead + k, :]
+        end
+    end
+    return out
 end
 
 """`(out::Matrix{T}(N × n_trees), ok::Vector{Bool})`; column t is `eval_tree_array(trees[t], X)`.  Columns with `ok[t] == false`
@@ -386,11 +434,12 @@ function eval_population(pop::HIPPopulation{T}, X::Matrix{T}) where {T}
     @assert F >= pop.n_features
     out = Matrix{T}(undef, N, pop.n_trees)          # row t of the C layout = column t here
     ok = Vector{UInt8}(undef, pop.n_trees)
-    rc = GC.@preserve X out ok ccall(
-        (:de_eval, LIBDE), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{UInt8}),
-        pop.ctx.handle, pop.handle, X, N, F, C_NULL, out, N, ok)
-    check(pop.ctx, rc)
+    with_pop(pop) do hc, hp
+        check(pop.ctx, GC.@preserve X out ok ccall(
+            (:de_eval, LIBDE), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{UInt8}),
+            hc, hp, X, N, F, C_NULL, out, N, ok))
+    end
     return out, ok .!= 0x00
 end
 
@@ -419,13 +468,14 @@ function eval_population(
     @assert isempty(classes) || (minimum(classes) >= 1 && maximum(classes) <= size(parameters, 2))
     out = Matrix{T}(undef, N, pop.n_trees)
     ok = Vector{UInt8}(undef, pop.n_trees)
-    rc = GC.@preserve X parameters classes out ok begin
-        pa = Ref(ParamArgs(pointer(parameters), size(parameters, 1), size(parameters, 2), pointer(classes), 1, 1))
-        ccall((:de_eval, LIBDE), Cint,
-            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ref{ParamArgs}, Ptr{Cvoid}, Int64, Ptr{UInt8}),
-            pop.ctx.handle, pop.handle, X, N, F, pa, out, N, ok)
+    with_pop(pop) do hc, hp
+        check(pop.ctx, GC.@preserve X parameters classes out ok begin
+            pa = Ref(ParamArgs(pointer(parameters), size(parameters, 1), size(parameters, 2), pointer(classes), 1, 1))
+            ccall((:de_eval, LIBDE), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ref{ParamArgs}, Ptr{Cvoid}, Int64, Ptr{UInt8}),
+                hc, hp, X, N, F, pa, out, N, ok)
+        end)
     end
-    check(pop.ctx, rc)
     return out, ok .!= 0x00
 end
 
@@ -443,13 +493,13 @@ function eval_population_loss(
     @assert F >= pop.n_features && length(y) == N
     out = Vector{T}(undef, pop.n_trees)
     ok = Vector{UInt8}(undef, pop.n_trees)
-    w = weights === nothing ? C_NULL : pointer(weights)
-    rc = GC.@preserve X y weights out ok ccall(
-        (:de_eval_loss, LIBDE), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32,
-         Ptr{Cvoid}, Ptr{UInt8}),
-        pop.ctx.handle, pop.handle, X, N, F, C_NULL, y, w, loss === :L1 ? 1 : 0, out, ok)
-    check(pop.ctx, rc)
+    with_pop(pop) do hc, hp
+        check(pop.ctx, GC.@preserve X y weights out ok ccall(
+            (:de_eval_loss, LIBDE), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32,
+             Ptr{Cvoid}, Ptr{UInt8}),
+            hc, hp, X, N, F, C_NULL, y, weights === nothing ? C_NULL : pointer(weights), loss === :L1 ? 1 : 0, out, ok))
+    end
     return out, ok .!= 0x00
 end
 
@@ -457,14 +507,36 @@ end
     set_population_constants!(pop, constants::Vector{T})
 
 New constants for the trees of `pop`, same shapes: `constants` = the trees' `get_scalar_constants` vectors
-(src/NodeUtils.jl:99-143: depth-first leaf order) back to back.  Nothing is re-flattened or re-lowered — the
-immediates are patched inside the device programs (`de_program_set_consts`), which is what an optimiser
-loop (`ext/DynamicExpressionsOptimExt.jl:182-224`) calls between `eval_population_loss_grad` evaluations.
+(src/NodeUtils.jl:99-143: depth-first leaf order; a GraphNode's shared constant ONCE) back to back.  Nothing is
+re-flattened or re-lowered — the immediates are patched inside the device programs (`de_program_set_consts`), which is
+what an optimiser loop (`ext/DynamicExpressionsOptimExt.jl:182-224`) calls between `eval_population_loss_grad`
+evaluations.  For a GraphNode population the values are fanned out to the occurrence slots of the library.
 """
 function set_population_constants!(pop::HIPPopulation{T}, constants::Vector{T}) where {T}
-    rc = GC.@preserve constants ccall((:de_program_set_consts, LIBDE), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), pop.handle, constants)
-    check(pop.ctx, rc)
+    length(constants) == sum(pop.n_consts) || throw(ArgumentError("wrong number of constants"))
+    vals = constants
+    if any(o -> o !== nothing, pop.occ)          # one value per unique constant -> one per occurrence slot
+        vals = Vector{T}(undef, sum(pop.n_slots))
+        at, to = 0, 0
+        for t in 1:pop.n_trees
+            o = pop.occ[t]
+            for k in 1:pop.n_slots[t]
+                vals[to + k] = constants[at + (o === nothing ? k : o[k])]
+            end
+            at += pop.n_consts[t]; to += pop.n_slots[t]
+        end
+    end
+    with_pop(pop) do hc, hp
+        check(pop.ctx, GC.@preserve vals ccall((:de_program_set_consts, LIBDE), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), hp, vals))
+    end
     return pop
+end
+
+grad_mode(variable) = variable isa Val{true} || variable === true ? Cint(0) : variable isa Val{:both} ? Cint(2) : Cint(1)
+"""Gradient widths of the trees in the LIBRARY's layout (one row per occurrence slot) and their packed offsets."""
+function grad_widths(hp::Ptr{Cvoid}, n_trees::Int, mode::Cint)
+    ng = [ccall((:de_program_n_grad, LIBDE), Int64, (Ptr{Cvoid}, Int64, Cint), hp, t - 1, mode) for t in 1:n_trees]
+    return ng, Int64[0; cumsum(ng)]
 end
 
 """
@@ -480,25 +552,23 @@ function eval_population_loss_grad(
     pop::HIPPopulation{T}, X::Matrix{T}, y::Vector{T}; weights::Union{Nothing,Vector{T}}=nothing,
     loss::Symbol=:L2, variable=Val(false),
 ) where {T}
-    mode = variable isa Val{true} || variable === true ? Cint(0) :
-           variable isa Val{:both} ? Cint(2) : Cint(1)
+    mode = grad_mode(variable)
     F, N = size(X)
     @assert F >= pop.n_features && length(y) == N
-    ng = [ccall((:de_program_n_grad, LIBDE), Int64, (Ptr{Cvoid}, Int64, Cint), pop.handle, t - 1, mode)
-          for t in 1:pop.n_trees]
-    offs = Int64[0; cumsum(ng)]
     lossv = Vector{T}(undef, pop.n_trees)
-    dl = Vector{T}(undef, max(offs[end], 1))
     ok = Vector{UInt8}(undef, pop.n_trees)
-    w = weights === nothing ? C_NULL : pointer(weights)
     kind = loss === :L1 ? 1 : loss === :pullback ? 2 : 0
-    rc = GC.@preserve X y weights lossv dl offs ok ccall(
-        (:de_eval_loss_grad, LIBDE), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int32,
-         Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{UInt8}),
-        pop.ctx.handle, pop.handle, X, N, F, C_NULL, mode, y, w, kind, lossv, dl, offs, ok)
-    check(pop.ctx, rc)
-    return lossv, [dl[(offs[t] + 1):offs[t + 1]] for t in 1:pop.n_trees], ok .!= 0x00
+    dl, offs = with_pop(pop) do hc, hp
+        ng, offs = grad_widths(hp, pop.n_trees, mode)
+        dl = Vector{T}(undef, max(offs[end], 1))
+        check(pop.ctx, GC.@preserve X y weights lossv dl offs ok ccall(
+            (:de_eval_loss_grad, LIBDE), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int32,
+             Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{UInt8}),
+            hc, hp, X, N, F, C_NULL, mode, y, weights === nothing ? C_NULL : pointer(weights), kind, lossv, dl, offs, ok))
+        (dl, offs)
+    end
+    return lossv, [combine_rows(pop, t, dl[(offs[t] + 1):offs[t + 1]], mode) for t in 1:pop.n_trees], ok .!= 0x00
 end
 
 """
@@ -520,7 +590,7 @@ function eval_population_loss_grad_by_class(
     F, N = size(X)
     P, C = size(parameters)
     @assert F >= pop.n_features && length(y) == N && length(classes) == N
-    @assert maximum(classes; init=1) <= C   # src/ParametricExpression.jl:378-379
+    @assert isempty(classes) || (minimum(classes) >= 1 && maximum(classes) <= C)   # src/ParametricExpression.jl:378-379 (the library trusts the ids)
     if !grouped
         perm = sortperm(classes; alg=MergeSort)
         X, y, classes = X[:, perm], y[perm], classes[perm]
@@ -531,46 +601,49 @@ function eval_population_loss_grad_by_class(
         starts[c + 1] += 1
     end
     cumsum!(starts, starts)
-    ng = [ccall((:de_program_n_grad, LIBDE), Int64, (Ptr{Cvoid}, Int64, Cint), pop.handle, t - 1, mode)
-          for t in 1:pop.n_trees]
-    offs = Int64[0; cumsum(ng)]
     lossv = Vector{T}(undef, pop.n_trees)
-    dl = Vector{T}(undef, max(offs[end], 1))
     dp = Array{T,3}(undef, P, C, pop.n_trees)
     ok = Vector{UInt8}(undef, pop.n_trees)
-    w = weights === nothing ? C_NULL : pointer(weights)
     kind = loss === :L1 ? 1 : loss === :pullback ? 2 : 0
-    pa = Ref(ParamArgs(pointer(parameters), P, C, pointer(classes), 1, 1))
-    rc = GC.@preserve X y weights parameters classes starts lossv dl dp offs ok ccall(
-        (:de_eval_loss_grad_by_class, LIBDE), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ref{ParamArgs}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int32,
-         Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{Cvoid}, Ptr{UInt8}),
-        pop.ctx.handle, pop.handle, X, N, F, pa, mode, y, w, kind, starts, lossv, dl, offs, dp, ok)
-    check(pop.ctx, rc)
-    return lossv, [dl[(offs[t] + 1):offs[t + 1]] for t in 1:pop.n_trees], [dp[:, :, t] for t in 1:pop.n_trees],
-           ok .!= 0x00
+    dl, offs = with_pop(pop) do hc, hp
+        ng, offs = grad_widths(hp, pop.n_trees, mode)
+        dl = Vector{T}(undef, max(offs[end], 1))
+        check(pop.ctx, GC.@preserve X y weights parameters classes starts lossv dl dp offs ok begin
+            pa = Ref(ParamArgs(pointer(parameters), P, C, pointer(classes), 1, 1))
+            ccall((:de_eval_loss_grad_by_class, LIBDE), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ref{ParamArgs}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Int32,
+                 Ptr{Int64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{Cvoid}, Ptr{UInt8}),
+                hc, hp, X, N, F, pa, mode, y, weights === nothing ? C_NULL : pointer(weights), kind, starts, lossv, dl, offs,
+                dp, ok)
+        end)
+        (dl, offs)
+    end
+    return lossv, [combine_rows(pop, t, dl[(offs[t] + 1):offs[t + 1]], mode) for t in 1:pop.n_trees],
+           [dp[:, :, t] for t in 1:pop.n_trees], ok .!= 0x00
 end
 
 """Forward-mode gradient of one tree: `(evaluation, gradient(n_grad × N), complete)` like
-`eval_grad_tree_array(tree, cX, operators; variable)` (src/EvaluateDerivative.jl:193-228)."""
+`eval_grad_tree_array(tree, cX, operators; variable)` (src/EvaluateDerivative.jl:193-228); a GraphNode's shared constant has
+ONE row (the sum over its occurrences)."""
 function _hip_eval_grad_tree_array(
     tree::AbstractExpressionNode{T}, cX::Matrix{T}, operators::OperatorEnum; variable=Val(false)
 ) where {T<:Union{Float32,Float64}}
-    mode = variable isa Val{true} || variable === true ? Cint(0) :
-           variable isa Val{:both} ? Cint(2) : Cint(1)
+    mode = grad_mode(variable)
     F, N = size(cX)
     pop = HIPPopulation([tree], operators, F)
-    ng = ccall((:de_program_n_grad, LIBDE), Int64, (Ptr{Cvoid}, Int64, Cint), pop.handle, 0, mode)
     out = Vector{T}(undef, N)
-    grad = Matrix{T}(undef, ng, N)
     ok = Ref{UInt8}(0)
-    rc = GC.@preserve cX out grad ccall(
-        (:de_eval_grad, LIBDE), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid},
-         Ptr{Int64}, Ref{UInt8}),
-        pop.ctx.handle, pop.handle, cX, N, F, C_NULL, mode, out, N, grad, C_NULL, ok)
-    check(pop.ctx, rc)
-    return (out, grad, ok[] != 0x00)
+    grad = with_pop(pop) do hc, hp
+        ng = ccall((:de_program_n_grad, LIBDE), Int64, (Ptr{Cvoid}, Int64, Cint), hp, 0, mode)
+        grad = Matrix{T}(undef, ng, N)
+        check(pop.ctx, GC.@preserve cX out grad ccall(
+            (:de_eval_grad, LIBDE), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Int64, Ptr{Cvoid},
+             Ptr{Int64}, Ref{UInt8}),
+            hc, hp, cX, N, F, C_NULL, mode, out, N, grad, C_NULL, ok))
+        grad
+    end
+    return (out, combine_rows(pop, 1, grad, mode), ok[] != 0x00)
 end
 
 """Single-direction derivative of one tree: `(evaluation, derivative, complete)` like
@@ -585,11 +658,12 @@ function _hip_eval_diff_tree_array(
     out = Vector{T}(undef, N)
     dout = Vector{T}(undef, N)
     ok = Ref{UInt8}(0)
-    rc = GC.@preserve cX out dout ccall(
-        (:de_eval_diff, LIBDE), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{UInt8}),
-        pop.ctx.handle, pop.handle, cX, N, F, Int32(direction - 1), out, dout, N, ok)
-    check(pop.ctx, rc)
+    with_pop(pop) do hc, hp
+        check(pop.ctx, GC.@preserve cX out dout ccall(
+            (:de_eval_diff, LIBDE), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{UInt8}),
+            hc, hp, cX, N, F, Int32(direction - 1), out, dout, N, ok))
+    end
     return (out, dout, ok[] != 0x00)
 end
 
@@ -605,12 +679,12 @@ function eval_population_pullback_dX(pop::HIPPopulation{T}, X::Matrix{T}, dY::Ve
     @assert F >= pop.n_features && length(dY) == N
     dX = Array{T,3}(undef, pop.n_features, N, pop.n_trees)
     ok = Vector{UInt8}(undef, pop.n_trees)
-    rc = lock(pop.ctx.lock) do; GC.@preserve X dY dX ok ccall(
-        (:de_eval_pullback_dX, LIBDE), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{UInt8}),
-        pop.ctx.handle, pop.handle, X, N, F, C_NULL, dY, dX, C_NULL, ok)
+    with_pop(pop) do hc, hp
+        check(pop.ctx, GC.@preserve X dY dX ok ccall(
+            (:de_eval_pullback_dX, LIBDE), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int64}, Ptr{UInt8}),
+            hc, hp, X, N, F, C_NULL, dY, dX, C_NULL, ok))
     end
-    check(pop.ctx, rc)
     return dX, ok .!= 0x00
 end
 
@@ -637,22 +711,29 @@ function hip_unique_id()
 end
 function HIPComm(ctx::HIPContext, rank::Integer, world::Integer, id::Vector{UInt8}=UInt8[])
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    rc = GC.@preserve id ccall((:de_dist_init, LIBDE), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}, Ref{Ptr{Cvoid}}),
-                               ctx.handle, rank, world, world > 1 ? pointer(id) : C_NULL, h)
+    rc = with_ctx(ctx) do hc
+        GC.@preserve id ccall((:de_dist_init, LIBDE), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}, Ref{Ptr{Cvoid}}),
+                              hc, rank, world, world > 1 ? pointer(id) : C_NULL, h)
+    end
     rc == DE_OK || error(unsafe_string(ccall((:de_dist_last_error, LIBDE), Cstring, (Ptr{Cvoid},), C_NULL)))
     return HIPComm(ctx, h[], rank, world)
 end
 function gather_flags(comm::HIPComm, ok_local::Vector{Bool}, n_trees::Integer)
     loc = UInt8.(ok_local)
     out = Vector{UInt8}(undef, n_trees)
-    rc = lock(comm.ctx.lock) do; GC.@preserve loc out ccall((:de_dist_gather_flags, LIBDE), Cint,
-        (Ptr{Cvoid}, Ptr{UInt8}, Int64, Ptr{UInt8}), comm.handle, loc, n_trees, out)
+    with_ctx(comm.ctx) do hc
+        rc = GC.@preserve loc out ccall((:de_dist_gather_flags, LIBDE), Cint,
+            (Ptr{Cvoid}, Ptr{UInt8}, Int64, Ptr{UInt8}), comm.handle, loc, n_trees, out)
+        rc == DE_OK || error(unsafe_string(ccall((:de_dist_last_error, LIBDE), Cstring, (Ptr{Cvoid},), comm.handle)))
+        check(comm.ctx, ccall((:de_ctx_synchronize, LIBDE), Cint, (Ptr{Cvoid},), hc))
     end
-    rc == DE_OK || error(unsafe_string(ccall((:de_dist_last_error, LIBDE), Cstring, (Ptr{Cvoid},), comm.handle)))
-    ccall((:de_ctx_synchronize, LIBDE), Cint, (Ptr{Cvoid},), comm.ctx.handle)
     return out .!= 0x00
 end
-close_comm(comm::HIPComm) = (ccall((:de_dist_destroy, LIBDE), Cint, (Ptr{Cvoid},), comm.handle); comm.handle = C_NULL; nothing)
+close_comm(comm::HIPComm) = with_ctx(comm.ctx) do _
+    comm.handle != C_NULL && ccall((:de_dist_destroy, LIBDE), Cint, (Ptr{Cvoid},), comm.handle)
+    comm.handle = C_NULL
+    nothing
+end
 
 is_extension_loaded(::Val{:HIP}) = true
 

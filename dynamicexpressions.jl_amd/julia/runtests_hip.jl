@@ -205,3 +205,31 @@ end
     y1, ok1 = HIP._hip_eval_tree_array(bad, X, ops, EvalContext())
     @test !ok1 && all(isnan, y1)
 end
+
+@testset "GraphNode: a shared CONSTANT is one constant (fan-out of set_population_constants!, summed gradient rows)" begin
+    # src/NodeUtils.jl:43-51 (count_constant_nodes with f_on_shared), :184-201 (the shared NodeIndex entry): the library keeps one
+    # slot per occurrence, the shim fans values out and sums the occurrence rows (round 5: `occ` of HIPPopulation, combine_rows)
+    ops = OperatorEnum(1 => (cos, exp), 2 => (+, -, /, *))
+    x1, x2 = GraphNode{Float64}(; feature=1), GraphNode{Float64}(; feature=2)
+    c = GraphNode{Float64}(; val=0.7)
+    g = (x1 * c) + cos(c * x2)                  # ONE constant, two occurrences
+    t2 = Node{Float64}(; feature=1) * 1.5 - 0.25  # a plain tree with two constants of its own: per-tree slot numbering
+    X = randn(Float64, 2, 1_000)
+    y = randn(Float64, 1_000)
+    pop = HIP.HIPPopulation([g, t2], ops, 2)
+    @test pop.n_consts == [1, 2] && pop.n_slots == [2, 2]
+    out, ok = HIP.eval_population(pop, X)
+    @test all(ok) && agree(view(out, :, 1), eval_tree_array(g, X, ops)[1]) && agree(view(out, :, 2), eval_tree_array(t2, X, ops)[1])
+    lossv, dl, okl = HIP.eval_population_loss_grad(pop, X, y)
+    @test length(dl[1]) == 1 && length(dl[2]) == 2
+    _, gr, _ = eval_grad_tree_array(g, X, ops; variable=Val(false))      # 1 x N: the shared constant's single row
+    yg, _ = eval_tree_array(g, X, ops)
+    @test isapprox(dl[1][1], sum(2 .* (yg .- y) .* view(gr, 1, :)); rtol=1e-9)
+    HIP.set_population_constants!(pop, [0.3, 2.0, -1.0])                 # g's constant, then t2's two
+    c.val = 0.3
+    out2, _ = HIP.eval_population(pop, X)
+    @test agree(view(out2, :, 1), eval_tree_array(g, X, ops)[1])
+    @test agree(view(out2, :, 2), X[1, :] .* 2.0 .- (-1.0))
+    _, gm, _ = HIP._hip_eval_grad_tree_array(g, X, ops; variable=Val(false))
+    @test size(gm, 1) == 1
+end

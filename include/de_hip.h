@@ -207,8 +207,9 @@ int de_program_create(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes,
  * programs of de_eval_grad / de_eval_diff / de_eval_loss_grad: values, flags and the Jacobian rows of features and parameters
  * are the expansion's bit for bit; a constant INSIDE a shared subtree gets every consumer's contribution in the gradient row of
  * its FIRST occurrence slot and zeros in the rows of its later occurrence slots (n_grad is unchanged: sum the occurrence rows
- * of a shared constant, as before — the totals are the expansion's to rounding).  Reverse accumulation is not used for such a
- * program.  Share ids are 0, 1, ... in order of definition, at most 16 minus the tree's spill slots; a shared subtree must not
+ * of a shared constant, as before — the totals are the expansion's to rounding).  Reverse accumulation (de_eval_loss_grad's default
+ * from 8 gradient rows per tree on) runs over shared rows too since round 4: the backward sweep accumulates the adjoints of a row's
+ * consumers (DE_REV_NO_SHARED=1: forward duals for such programs; ternary operators with shared operands always fall back).  Share ids are 0, 1, ... in order of definition, at most 16 minus the tree's spill slots; a shared subtree must not
  * be the root or a direct child of a ternary operator — a tree whose CSE form does not fit runs from its expanded tape (that
  * tree alone).  DE_NO_CSE=1 ignores the CSE tapes, DE_NO_GRAD_CSE=1 only for the gradient programs. */
 int de_program_create_cse(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, const int64_t *node_offsets,
