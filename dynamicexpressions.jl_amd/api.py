@@ -48,6 +48,7 @@ EXPORTS = [
     "de_program_n_grad", "de_program_dump", "de_program_verify", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad", "de_eval_loss_grad_by_class",
     "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_prio_tiles_wanted", "de_program_last_live_trees", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size", "de_dist_world_size",
     "de_dist_broadcast", "de_dist_gather_flags", "de_dist_last_error", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
+    "de_ctx_device", "de_ctx_timing_ring", "de_ctx_timing_read", "de_dist_reorder_selftest",
 ]
 
 
@@ -143,6 +144,10 @@ def library() -> C.CDLL:
     lib.de_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.de_ctx_last_kernel_name.restype = C.c_char_p
     lib.de_ctx_last_kernel_name.argtypes = [vp]
+    lib.de_ctx_device.argtypes = [vp]
+    lib.de_ctx_timing_ring.argtypes = [vp, i32]
+    lib.de_ctx_timing_read.argtypes = [vp, vp, i32, C.POINTER(i32)]
+    lib.de_dist_reorder_selftest.argtypes = [vp, vp, i64, C.c_int, vp, C.POINTER(C.c_float)]
     _lib = lib
     return lib
 
@@ -241,15 +246,37 @@ class Context:
         if X is None:
             self.check(lib.de_ctx_declare_dataset(self._h, 0, None, 0, 0, 0))
             return
+        # the declaration is matched by (pointer, N, ldX): it must be the very tensor `eval` will use IN PLACE — a device tensor of the
+        # feature-fastest layout.  Anything `eval` would copy first (host array, wrong layout) can never match: refuse it loudly.
+        if not _is_torch(X) or not X.is_cuda or X.dim() != 2:
+            raise ValueError("declare_dataset needs the 2-d DEVICE tensor [F, N] that eval() is called with")
+        name = str(X.dtype)
+        if name not in ("torch.float32", "torch.float64"):
+            raise ValueError(f"declare_dataset: dtype {name} is neither float32 nor float64")
         F, N = int(X.shape[0]), int(X.shape[1])
-        ldX = int(X.stride(1)) if hasattr(X, "stride") and callable(X.stride) else F
-        dt = DE_F32 if str(X.dtype).endswith("float32") else DE_F64
+        if N > 1 and (int(X.stride(0)) != 1 or int(X.stride(1)) < F):
+            raise ValueError("declare_dataset: X must be feature-fastest ([N, F] storage viewed as [F, N], e.g. Xs.t()): "
+                             f"strides {tuple(X.stride())} would be copied by eval() and the declaration would never match")
+        ldX = int(X.stride(1)) if N > 1 else F
+        dt = DE_F32 if name == "torch.float32" else DE_F64
         self.check(lib.de_ctx_declare_dataset(self._h, dt, X.data_ptr(), N, ldX, F))
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float(0)
         self.check(library().de_ctx_last_kernel_ms(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def timing_ring(self, n: int) -> None:
+        """Keep the event pairs of the last ``n`` timed calls (0: off): ``timing_read`` then returns the device time of every call of a
+        free-running loop without a synchronisation per call (``last_kernel_ms`` blocks)."""
+        self.check(library().de_ctx_timing_ring(self._h, int(n)))
+
+    def timing_read(self, cap: int = 4096) -> list:
+        """Device ms of the timed calls since ``timing_ring`` / the last read, oldest first (waits for the last one)."""
+        buf = (C.c_float * int(cap))()
+        n = C.c_int32(0)
+        self.check(library().de_ctx_timing_read(self._h, C.cast(buf, C.c_void_p), int(cap), C.byref(n)))
+        return [float(buf[i]) for i in range(n.value)]
 
     def last_kernel_name(self) -> str:
         return library().de_ctx_last_kernel_name(self._h).decode()

@@ -126,8 +126,12 @@ def fold_copy_into_add(lines):
 
 
 def sregs_written(line):
-    """SGPRs an instruction of the SCC_NEUTRAL set may write: the first operand of s_load / s_mov (vector and LDS instructions write none)"""
+    """SGPRs an instruction of the SCC_NEUTRAL set may write: the first operand of s_load / s_mov; any SGPR a vector instruction names"""
     code = line.split(';', 1)[0].strip()
+    if code.startswith('v_'):
+        # v_readfirstlane / v_readlane, VOP3 compares, carry-out adds, v_div_scale, v_mad_u64_u32 ... DO write SGPRs, in various operand
+        # positions: every SGPR a vector instruction mentions counts as written (conservative: the hoist is refused; ADVICE r4)
+        return sregs(line)
     if not (code.startswith('s_load') or code.startswith('s_mov')):
         return set()
     first = code.split(None, 1)[1].split(',')[0] if len(code.split(None, 1)) > 1 else ''

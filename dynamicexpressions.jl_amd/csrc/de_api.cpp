@@ -48,6 +48,10 @@ struct de_ctx {
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // de_ctx_timing_ring: pairs of events for the last `ring.size() / 2` timed calls, so that a caller can read the device time of EVERY
+    // call of a free-running loop afterwards (de_ctx_last_kernel_ms blocks until the call is done)
+    std::vector<hipEvent_t> ring;
+    uint64_t ring_at = 0;
     std::string err;
     const char *last_kernel = "";
     DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2, sGoff, sNg, sY, sW, sLoss, sPartial, sSeg, sDloss, sColOff, sDoff, sPrio;
@@ -179,6 +183,16 @@ static int fail(de_ctx *c, int code, const char *fmt, ...) {
         }                                                                                    \
     } while (0)
 
+// the pair of events that brackets the launches of a call: the context's own pair, or the next slot of the timing ring
+static hipError_t time_begin(de_ctx *c) {
+    return hipEventRecord(c->ring.empty() ? c->ev0 : c->ring[(size_t)(c->ring_at % (c->ring.size() / 2)) * 2], c->stream);
+}
+static hipError_t time_end(de_ctx *c) {
+    hipEvent_t e = c->ev1;
+    if (!c->ring.empty()) { e = c->ring[(size_t)(c->ring_at % (c->ring.size() / 2)) * 2 + 1]; c->ring_at++; }
+    c->timed = true;
+    return hipEventRecord(e, c->stream);
+}
 static bool is_device_ptr(const void *p) {
     if (!p) return false;
     hipPointerAttribute_t at;
@@ -360,9 +374,10 @@ int de_ctx_destroy(de_ctx_t *c) {
     if (!c) return DE_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff, &c->sPrio, &c->sBcLoss, &c->sBcDloss, &c->sBcOk, &c->sBcNg, &c->sBcDoff, &c->sBcOut, &c->sBcTiles}) b->release();
+    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff, &c->sPrio, &c->sPrioDs, &c->sBcLoss, &c->sBcDloss, &c->sBcOk, &c->sBcNg, &c->sBcDoff, &c->sBcOut, &c->sBcTiles}) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->ring) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return DE_OK;
@@ -393,6 +408,7 @@ int de_ctx_synchronize(de_ctx_t *c) {
     return DE_OK;
 }
 void *de_ctx_stream(de_ctx_t *c) { return c ? c->stream : nullptr; }
+int de_ctx_device(de_ctx_t *c) { return c ? c->device : -1; }
 // A dataset that stays as it is between calls (X of a symbolic-regression search: thousands of de_eval* calls on the same matrix):
 // statistics of it — today the 3 F priority-tile keys, a pass over X of 0.11 ms at 10^7 samples — are computed here, once, and every
 // later call on this context whose (X, N, ldX) are the declared ones skips its own pass.  X == NULL withdraws the declaration.
@@ -405,6 +421,7 @@ int de_ctx_declare_dataset(de_ctx_t *c, int dtype, const void *X, int64_t N, int
     if (n_features > DE_PRIO_MAX_F) return DE_OK; // nothing to cache for such an X (no priority tiles): not an error
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, c->sPrioDs.reserve((size_t)3 * DE_PRIO_MAX_F * sizeof(unsigned long long)));
+    // (the pass runs on the context's CURRENT stream; a later de_ctx_set_stream orders the new stream behind everything queued on this one)
     HIP_TRY(c, launch_tile_extremes(dtype, X, N, ldX, n_features, c->sPrioDs.p, c->stream));
     c->ds_X = X;
     c->ds_N = N;
@@ -424,8 +441,48 @@ const char *de_last_error(de_ctx_t *c) { return c ? c->err.c_str() : "null conte
 int de_ctx_last_kernel_ms(de_ctx_t *c, float *ms) {
     if (!c || !ms) return DE_ERR_INVALID_ARG;
     if (!c->timed) return fail(c, DE_ERR_INVALID_ARG, "no timed launch on this context yet");
-    HIP_TRY(c, hipEventSynchronize(c->ev1));
-    HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    hipEvent_t e0 = c->ev0, e1 = c->ev1;
+    if (!c->ring.empty()) {
+        if (c->ring_at == 0) return fail(c, DE_ERR_INVALID_ARG, "no timed launch since de_ctx_timing_ring");
+        const size_t k = (size_t)((c->ring_at - 1) % (c->ring.size() / 2));
+        e0 = c->ring[2 * k];
+        e1 = c->ring[2 * k + 1];
+    }
+    HIP_TRY(c, hipEventSynchronize(e1));
+    HIP_TRY(c, hipEventElapsedTime(ms, e0, e1));
+    return DE_OK;
+}
+// n > 0: keep the event pairs of the last n timed calls (de_eval*, one pair per call); n == 0: back to the single pair.
+int de_ctx_timing_ring(de_ctx_t *c, int32_t n) {
+    if (!c || n < 0 || n > 65536) return DE_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (hipEvent_t e : c->ring) (void)hipEventDestroy(e);
+    c->ring.clear();
+    c->ring_at = 0;
+    c->timed = false;
+    for (int32_t i = 0; i < 2 * n; i++) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(c, hipEventCreate(&e));
+        c->ring.push_back(e);
+    }
+    return DE_OK;
+}
+// Device time (ms) of the timed calls since de_ctx_timing_ring / the last read, oldest first, at most `cap` and at most the ring's size
+// (older ones are overwritten); waits for the last one.  *n_out = how many were written.  The ring restarts.
+int de_ctx_timing_read(de_ctx_t *c, float *ms, int32_t cap, int32_t *n_out) {
+    if (!c || !ms || !n_out || cap < 0) return DE_ERR_INVALID_ARG;
+    *n_out = 0;
+    if (c->ring.empty()) return fail(c, DE_ERR_INVALID_ARG, "de_ctx_timing_read without de_ctx_timing_ring");
+    const uint64_t slots = c->ring.size() / 2, have = c->ring_at < slots ? c->ring_at : slots;
+    const uint64_t take = have < (uint64_t)cap ? have : (uint64_t)cap;
+    for (uint64_t i = 0; i < take; i++) {
+        const size_t k = (size_t)((c->ring_at - take + i) % slots);
+        HIP_TRY(c, hipEventSynchronize(c->ring[2 * k + 1]));
+        HIP_TRY(c, hipEventElapsedTime(ms + i, c->ring[2 * k], c->ring[2 * k + 1]));
+    }
+    *n_out = (int32_t)take;
+    c->ring_at = 0;
     return DE_OK;
 }
 const char *de_ctx_last_kernel_name(de_ctx_t *c) { return c ? c->last_kernel : ""; }
@@ -1130,6 +1187,7 @@ int de_eval_plan(const de_program_t *p, int64_t N, int32_t *plan) {
 int de_program_verify(const de_program_t *p) {
     if (!p) return DE_ERR_INVALID_ARG;
     de_ctx *c = p->ctx;
+    HIP_TRY(c, hipSetDevice(c->device)); // the handler tables are cached per device: the program's addresses are its OWN device's
     const int64_t rows = eval_rows(p), spill_end = (int64_t)p->n_features + p->n_slots;
     auto bad = [&](const char *what, int64_t tree, int64_t i, uint64_t v) {
         return fail(c, DE_ERR_BAD_TAPE, "program verify: %s (tree %lld, instruction %lld, value 0x%llx)", what, (long long)tree, (long long)i,
@@ -1524,12 +1582,11 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
     a.prio_keys_ready = !sX.staged && dataset_keys(c, p->dtype, X, N, ldX, p->n_features, &a.prio_keys);
     a.compact_code = p->d_compact_code;
     a.compact_ints = p->d_compact_ints;
-    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(c, time_begin(c));
     a.compacted = &p->last_compacted;
     p->last_compacted = false;
     HIP_TRY(c, launch_eval(p->dtype, a, c->stream, &c->last_kernel));
-    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(c, time_end(c));
     if (sLoss.staged) HIP_TRY(c, hipMemcpyAsync(lr->loss, sLoss.dev, (size_t)p->n_trees * es, hipMemcpyDeviceToHost, c->stream));
     if (sOut.staged) {
         if (ld_out == N) // one block (the constant-folding population is 10^3..10^5 one-sample rows)
@@ -2584,12 +2641,11 @@ static int grad_impl(de_ctx *c, de_program *p, const void *X, int64_t N, int64_t
         rc = stage_in(c, c->sY, dY, (size_t)N * es, &sDY);
         if (rc) return rc;
     }
-    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(c, time_begin(c));
     HIP_TRY(c, launch_grad(p->dtype, g, c->stream, &c->last_kernel));
     if (dY) // the pullback's dX .* dY' (and its NaN fill) on the Jacobians just written
         HIP_TRY(c, launch_pullback_scale(p->dtype, sGrad.dev, g.grad_off, g.n_grad, g.e.ok, sDY.dev, N, p->n_trees, maxg, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(c, time_end(c));
     if (out && sOut.staged)
         for (int64_t t = 0; t < p->n_trees; t++)
             HIP_TRY(c, hipMemcpyAsync(static_cast<char *>(out) + (size_t)t * (size_t)ld_out * es,
@@ -2834,7 +2890,7 @@ static int loss_grad_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N
                 (long)std::chrono::duration_cast<std::chrono::microseconds>(tg1 - tg0).count(),
                 (long)std::chrono::duration_cast<std::chrono::microseconds>(tg2 - tg1).count());
     }
-    if (!c->nested) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (!c->nested) HIP_TRY(c, time_begin(c));
     if (g.rev_code) HIP_TRY(c, launch_rev_threaded(p->dtype, g, c->stream, &c->last_kernel));
     else HIP_TRY(c, launch_grad(p->dtype, g, c->stream, &c->last_kernel));
     if (plan) { // one pair of finish passes per class over its own tiles
@@ -2842,8 +2898,7 @@ static int loss_grad_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N
                                                   (size_t)plan->span * es, seg_region, seg_regions, c->stream));
         plan->done = true;
     }
-    if (!c->nested) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    if (!c->nested) HIP_TRY(c, time_end(c));
     if (sLoss.staged) HIP_TRY(c, hipMemcpyAsync(loss, sLoss.dev, (size_t)p->n_trees * es, hipMemcpyDeviceToHost, c->stream));
     if (sDl.staged)
         for (int64_t t = 0; t < p->n_trees; t++)
@@ -2899,7 +2954,7 @@ int de_eval_loss_grad_by_class(de_ctx_t *c, de_program_t *p, const void *X, int6
     HIP_TRY(c, hipMemcpyAsync(c->sBcDoff.p, doff.data(), doff.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     // dloss entries no tree owns (caller-chosen offsets) are never read by the combine pass
     HIP_TRY(c, hipMemsetAsync(c->sBcDloss.p, 0, (size_t)C * (size_t)span * es, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(c, time_begin(c));
     ByClassPlan plan{class_starts, C, span, c->sBcLoss.p, c->sBcDloss.p, false};
     bool shared_ok = false; // one pass: a single flag array instead of one per class
     {
@@ -2963,8 +3018,7 @@ int de_eval_loss_grad_by_class(de_ctx_t *c, de_program_t *p, const void *X, int6
     a.dparams = sDp.dev;
     a.ok = static_cast<uint8_t *>(sOk.dev);
     HIP_TRY(c, launch_by_class_combine(p->dtype, a, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(c, time_end(c));
     if (sLoss.staged) HIP_TRY(c, hipMemcpyAsync(loss, sLoss.dev, (size_t)p->n_trees * es, hipMemcpyDeviceToHost, c->stream));
     if (sDl.staged)
         for (int64_t t = 0; t < p->n_trees; t++)

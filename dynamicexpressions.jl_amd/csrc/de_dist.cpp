@@ -14,6 +14,7 @@
 #include <string>
 
 #include "../../include/de_hip.h"
+#include "de_kernels.h"
 
 namespace {
 struct NcclId { char internal[128]; }; // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
@@ -50,6 +51,11 @@ struct Rccl {
     }
 };
 Rccl g_rccl;
+bool is_dev(const void *p) {
+    hipPointerAttribute_t at;
+    if (!p || hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
 constexpr int kNcclUint8 = 1; // ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1
 } // namespace
 
@@ -58,7 +64,8 @@ struct de_comm {
     NcclComm comm = nullptr;
     int rank = 0, world = 1;
     uint8_t *send = nullptr, *recv = nullptr; // device staging: ceil(n / world) and world * ceil(n / world) bytes
-    size_t cap = 0;
+    uint8_t *stage = nullptr;                 // device staging for HOST flag arrays: n bytes (local flags in, global flags out)
+    size_t cap = 0, stage_cap = 0;
     std::string err;
 };
 
@@ -97,7 +104,18 @@ int de_dist_init(de_ctx_t *ctx, int rank, int world, const void *id, de_comm_t *
         if (!g_rccl.load()) { delete c; return DE_ERR_RCCL; }
         NcclId u;
         std::memcpy(u.internal, id, sizeof u.internal);
+        // ncclCommInitRank binds the communicator to the CURRENT device of the calling thread: make that the context's (a process may hold
+        // contexts on several GPUs, ABI version 2 (d)), and put the caller's device back afterwards
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        const int dev = de_ctx_device(ctx);
+        if (dev < 0 || hipSetDevice(dev) != hipSuccess) {
+            dfail(nullptr, DE_ERR_HIP, "de_dist_init: cannot select the context's device %d", dev);
+            delete c;
+            return DE_ERR_HIP;
+        }
         const int rc = g_rccl.CommInitRank(&c->comm, world, u, rank);
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
         if (rc != 0) {
             dfail(nullptr, DE_ERR_RCCL, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(rc));
             delete c;
@@ -113,6 +131,7 @@ int de_dist_destroy(de_comm_t *c) {
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
     if (c->send) (void)hipFree(c->send);
     if (c->recv) (void)hipFree(c->recv);
+    if (c->stage) (void)hipFree(c->stage);
     delete c;
     return DE_OK;
 }
@@ -158,22 +177,78 @@ int de_dist_gather_flags(de_comm_t *c, const uint8_t *ok_local, int64_t n_trees,
         if (c->send) (void)hipFree(c->send);
         if (c->recv) (void)hipFree(c->recv);
         c->send = c->recv = nullptr;
+        c->cap = 0;
         HIPD(hipMalloc(reinterpret_cast<void **>(&c->send), per));
         HIPD(hipMalloc(reinterpret_cast<void **>(&c->recv), per * (size_t)c->world));
         c->cap = per;
     }
-    HIPD(hipMemsetAsync(c->send, 1, per, stream)); // padding entries (ranks with one tree fewer) read as complete
-    HIPD(hipMemcpyAsync(c->send, ok_local, (size_t)mine, hipMemcpyDefault, stream));
+    // THREE stream operations per exchange when the flags live on the device (round 5; eleven before: memset + copy + all_gather + one
+    // strided 1-byte-row copy per rank): pack (pads the ranks with one tree fewer with 1 = complete), all_gather, unpack (entry [r][i]
+    // of the gathered block is tree r + i * world).  Host arrays go through a device staging buffer: one copy in, one copy out.
+    const bool loc_dev = is_dev(ok_local), glob_dev = is_dev(ok_global);
+    if ((!loc_dev || !glob_dev) && c->stage_cap < (size_t)n_trees) {
+        if (c->stage) (void)hipFree(c->stage);
+        c->stage = nullptr;
+        c->stage_cap = 0;
+        HIPD(hipMalloc(reinterpret_cast<void **>(&c->stage), (size_t)n_trees));
+        c->stage_cap = (size_t)n_trees;
+    }
+    const uint8_t *src = ok_local;
+    if (!loc_dev) {
+        if (mine > 0) HIPD(hipMemcpyAsync(c->stage, ok_local, (size_t)mine, hipMemcpyHostToDevice, stream));
+        src = c->stage;
+    }
+    HIPD(de::launch_dist_pack(c->send, src, mine, (int64_t)per, stream));
     const int rc = g_rccl.AllGather(c->send, c->recv, per, kNcclUint8, c->comm, stream);
     if (rc != 0) return dfail(c, DE_ERR_RCCL, "ncclAllGather: %s", g_rccl.GetErrorString(rc));
-    // rank r holds trees r, r + world, ...: entry [r][i] of the gathered block is tree r + i * world — a strided copy per rank
-    for (int r = 0; r < c->world; r++) {
-        const int64_t cnt = de_dist_shard_size(n_trees, r, c->world);
-        if (cnt > 0)
-            HIPD(hipMemcpy2DAsync(ok_global + r, (size_t)c->world, c->recv + (size_t)r * per, 1, 1, (size_t)cnt, hipMemcpyDefault, stream));
-    }
+    HIPD(de::launch_dist_unpack(glob_dev ? ok_global : c->stage, c->recv, (int64_t)per, c->world, n_trees, stream));
+    if (!glob_dev) HIPD(hipMemcpyAsync(ok_global, c->stage, (size_t)n_trees, hipMemcpyDeviceToHost, stream));
 #undef HIPD
     return DE_OK;
+}
+
+// Test / measurement hook (no RCCL needed): the pack and unpack launches of de_dist_gather_flags for a SIMULATED world on one GPU — every
+// rank's shard of `flags_global` (host, n_trees bytes) is packed into its block of the gathered buffer (what the all_gather would deliver),
+// then unpacked into `out` (host, n_trees bytes: must equal flags_global).  *ms (may be null) = device time of ONE rank's share of an
+// exchange: one pack + one unpack launch (hipEvents).
+int de_dist_reorder_selftest(de_ctx_t *ctx, const uint8_t *flags_global, int64_t n_trees, int world, uint8_t *out, float *ms) {
+    if (!ctx || !flags_global || !out || n_trees < 1 || world < 1) return DE_ERR_INVALID_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(de_ctx_stream(ctx));
+    const int64_t per = (n_trees + world - 1) / world;
+    uint8_t *loc = nullptr, *send = nullptr, *recv = nullptr, *glob = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = DE_OK;
+#define HIPS(expr) do { if (rc == DE_OK && (expr) != hipSuccess) { (void)hipGetLastError(); rc = DE_ERR_HIP; } } while (0)
+    HIPS(hipSetDevice(de_ctx_device(ctx)));
+    HIPS(hipMalloc(reinterpret_cast<void **>(&loc), (size_t)per));
+    HIPS(hipMalloc(reinterpret_cast<void **>(&send), (size_t)per));
+    HIPS(hipMalloc(reinterpret_cast<void **>(&recv), (size_t)per * world));
+    HIPS(hipMalloc(reinterpret_cast<void **>(&glob), (size_t)n_trees));
+    HIPS(hipEventCreate(&e0));
+    HIPS(hipEventCreate(&e1));
+    std::string shard((size_t)per, '\0');
+    for (int r = 0; r < world && rc == DE_OK; r++) {
+        const int64_t mine = de_dist_shard_size(n_trees, r, world);
+        for (int64_t i = 0; i < mine; i++) shard[(size_t)i] = (char)flags_global[r + i * world];
+        if (mine > 0) HIPS(hipMemcpyAsync(loc, shard.data(), (size_t)mine, hipMemcpyHostToDevice, stream));
+        HIPS(hipStreamSynchronize(stream));
+        if (r == 0) HIPS(hipEventRecord(e0, stream));
+        HIPS(de::launch_dist_pack(send, loc, mine, per, stream));
+        if (r == 0) { // rank 0's own exchange: pack, (all_gather), unpack — timed without the collective; its unpack result is overwritten below
+            HIPS(de::launch_dist_unpack(glob, recv, per, world, n_trees, stream));
+            HIPS(hipEventRecord(e1, stream));
+        }
+        HIPS(hipMemcpyAsync(recv + (size_t)r * per, send, (size_t)per, hipMemcpyDeviceToDevice, stream));
+    }
+    HIPS(de::launch_dist_unpack(glob, recv, per, world, n_trees, stream));
+    HIPS(hipMemcpyAsync(out, glob, (size_t)n_trees, hipMemcpyDeviceToHost, stream));
+    HIPS(hipStreamSynchronize(stream));
+    if (ms && rc == DE_OK) HIPS(hipEventElapsedTime(ms, e0, e1));
+#undef HIPS
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    for (uint8_t *q : {loc, send, recv, glob}) if (q) (void)hipFree(q);
+    return rc;
 }
 
 } // extern "C"

@@ -2399,6 +2399,28 @@ void loss_scratch_bytes(int dtype, int64_t n_trees, int64_t N, size_t *partial_b
     *seg_bytes = (size_t)loss_segments(n_tiles) * (size_t)n_trees * TWAVES * sizeof(double);
 }
 
+// ---- multi-GPU flag exchange (de_dist.cpp): the two re-orderings around the one ncclAllGather of a step.  Rank r owns trees r, r + world,
+// ...; it sends ceil(n / world) bytes (its flags, padded with 1 = complete) and receives world such blocks: entry [r][i] of the gathered
+// buffer is tree r + i * world.  One tiny launch each instead of a memset + a copy in front and `world` strided 1-byte-row copies behind.
+__global__ void __launch_bounds__(256) de_dist_pack_kernel(uint8_t *__restrict__ send, const uint8_t *__restrict__ ok_local, int64_t mine, int64_t per) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < per) send[i] = i < mine ? ok_local[i] : (uint8_t)1;
+}
+__global__ void __launch_bounds__(256) de_dist_unpack_kernel(uint8_t *__restrict__ ok_global, const uint8_t *__restrict__ recv, int64_t per, int32_t world, int64_t n_trees) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n_trees) ok_global[t] = recv[(t % world) * per + t / world];
+}
+hipError_t launch_dist_pack(uint8_t *send, const uint8_t *ok_local_dev, int64_t mine, int64_t per, hipStream_t stream) {
+    if (per <= 0) return hipSuccess;
+    hipLaunchKernelGGL(de_dist_pack_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream, send, ok_local_dev, mine, per);
+    return hipGetLastError();
+}
+hipError_t launch_dist_unpack(uint8_t *ok_global_dev, const uint8_t *recv, int64_t per, int32_t world, int64_t n_trees, hipStream_t stream) {
+    if (n_trees <= 0) return hipSuccess;
+    hipLaunchKernelGGL(de_dist_unpack_kernel, dim3((unsigned)((n_trees + 255) / 256)), dim3(256), 0, stream, ok_global_dev, recv, per, world, n_trees);
+    return hipGetLastError();
+}
+
 hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const char **kernel_name) {
     if (a.direct) return dtype == DE_F32 ? launch_eval_t<float, 1, 256>(a, stream, kernel_name) : launch_eval_t<double, 1, 256>(a, stream, kernel_name);
     if (a.threaded) return dtype == DE_F32 ? launch_threaded_t<float>(a, stream, kernel_name) : launch_threaded_t<double>(a, stream, kernel_name);

@@ -177,6 +177,7 @@ int de_ctx_synchronize(de_ctx_t *ctx);
  * pass X = NULL to withdraw) before it modifies X.  Results never depend on it (the keys only decide which sample tiles run first). */
 int de_ctx_declare_dataset(de_ctx_t *ctx, int dtype, const void *X, int64_t N, int64_t ldX, int32_t n_features);
 void *de_ctx_stream(de_ctx_t *ctx);
+int de_ctx_device(de_ctx_t *ctx); /* the device index the context was created on (-1: null) */
 const char *de_last_error(de_ctx_t *ctx); /* text of the last failure on this ctx */
 
 /* ---- population program --------------------------------------------------- */
@@ -377,6 +378,9 @@ int de_dist_world_size(de_comm_t *comm); /* ranks of the communicator as RCCL re
 int64_t de_dist_shard_size(int64_t n_trees, int rank, int world);
 int de_dist_broadcast(de_comm_t *comm, void *buf, size_t bytes, int root);
 int de_dist_gather_flags(de_comm_t *comm, const uint8_t *ok_local, int64_t n_trees, uint8_t *ok_global);
+/* test / measurement hook, no RCCL involved: packs every SIMULATED rank's shard of flags_global (host) the way de_dist_gather_flags
+ * does, unpacks the gathered buffer into out (host; must equal flags_global), *ms = one rank's pack + unpack launches (may be NULL) */
+int de_dist_reorder_selftest(de_ctx_t *ctx, const uint8_t *flags_global, int64_t n_trees, int world, uint8_t *out, float *ms);
 const char *de_dist_last_error(de_comm_t *comm); /* comm may be NULL: errors of de_dist_unique_id / de_dist_init */
 
 /* ---- one-shot convenience with the reference's single-tree signature ------- */
@@ -404,6 +408,11 @@ int de_ctx_last_kernel_ms(de_ctx_t *ctx, float *ms);
 /* Name of the dominant kernel symbol of the most recent call (for matching the
  * rocprofv3 kernel-trace rows). */
 const char *de_ctx_last_kernel_name(de_ctx_t *ctx);
+/* Device time of EVERY call of a free-running loop: de_ctx_timing_ring(ctx, n) keeps the event pairs of the last n timed calls
+ * (n = 0: back to one pair), de_ctx_timing_read waits for the last call and returns their durations, oldest first (at most cap;
+ * *n_out written), then restarts the ring.  (de_ctx_last_kernel_ms blocks per call; round 5.) */
+int de_ctx_timing_ring(de_ctx_t *ctx, int32_t n);
+int de_ctx_timing_read(de_ctx_t *ctx, float *ms, int32_t cap, int32_t *n_out);
 
 #ifdef __cplusplus
 }
