@@ -8,6 +8,31 @@ import dynamicexpressions_jl_amd as de
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# ---- the tolerance model is VERSIONED: every change of what parity_tolerance / grad_tolerance declare comparable gets
+# a number and one line here citing the traced finding that forced it; tests/test_tolerance_model.py pins the share of samples the model
+# declares ill-conditioned on three fixed populations (tests/golden/tolerance_model_shares.json, recorded per MODEL_VERSION: it may not grow
+# silently).
+MODEL_VERSION = 7
+MODEL_CHANGELOG = (
+    (1, "rounds 1-3: north-star base (1e-5 Float32 / 1e-13 Float64) + 8 x the measured spread of 16 one-ulp-perturbed float64 re-evaluations; "
+        "spread > 1e-3 |y| = ill-conditioned (DESIGN 5)"),
+    (2, "round 4: unstable_selections for BINARY selectors (max / min / greater / clamp): fuzz seeds 41, 42 — profiles/r4_findings_traced.json, "
+        "tools/trace_findings.py"),
+    (3, "round 4: ... and UNARY selectors (abs / relu / sign at 0, floor / ceil / round at their edges): fuzz seed 51 tree 148 — "
+        "profiles/r4_fuzz_summary.md item 4"),
+    (4, "round 4: pow_abs2 priced with its three roundings, -(x/y)/y with both divisions (grad_tolerance): profiles/r4_fuzz_summary.md items 2-3"),
+    (5, "round 4: Float32 chaos floor 1e-30 -> 1e-36 (a result that underflows is chaotic relative to its own size): fuzz_hot seed 54 — "
+        "profiles/r4_findings_value_traced.json"),
+    (6, "round 5: Float64 end-to-end base 1e-13 (450 ulp) -> 8 ulp = 1.78e-15 (VERDICT r4 item 3a); what the tighter base rejects is in "
+        "profiles/r5_f64_base_8ulp.md"),
+    (7, "round 5: samples behind a CHAOTIC INTERMEDIATE (an operator result that moves by > 0.1 % under one-ulp perturbations while the output "
+        "does not) get 128 draws instead of 16 — the heavy tail of cos(small / chaotic cosine), fuzz seed 55 Float64: profiles/r4_fuzz_summary.md "
+        "item 7, tools/trace_value_findings.py; no other sample's tolerance changes"),
+)
+# Float64 north-star base of the end-to-end comparisons, relative: 8 ulp (DE_TOL_F64_BASE overrides it for the experiment that produced
+# profiles/r5_f64_base_8ulp.md)
+F64_BASE = float(os.environ.get("DE_TOL_F64_BASE", 8 * 2.0 ** -52))
+
 
 def load_golden():
     with open(os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")) as fh:
@@ -113,7 +138,7 @@ def unstable_selections(clean, noisy_runs, N):
     return bad
 
 
-def parity_tolerance(tree, ops, X, dtype, options=7, params=None, classes0=None, draws=16, seed=0):
+def parity_tolerance(tree, ops, X, dtype, options=7, params=None, classes0=None, draws=16, seed=0, extra_draws=112):
     """Per-sample tolerance for comparing the GPU with the oracle on one tree.
 
     north_star: 1e-5 relative for Float32, 1 ulp PER OPERATION for Float64.  The device math
@@ -125,7 +150,7 @@ def parity_tolerance(tree, ops, X, dtype, options=7, params=None, classes0=None,
     operator, tests/prog_interp.py); `spread` = the largest deviation from the unperturbed
     float64 result.
       * spread <= 1e-3*|y| (the sample is not chaotic): tolerance = north-star bound
-        (1e-5*|y| f32, 1e-13*|y| f64) + 8*spread.  On well-conditioned samples spread is a few
+        (1e-5*|y| f32, 8 ulp = 1.8e-15*|y| f64 since model version 6) + 8*spread.  On well-conditioned samples spread is a few
         1e-7*|y| and the north-star bound is what is enforced.
       * otherwise the sample is ILL-CONDITIONED (a one-ulp change of an intermediate moves the
         result by >0.1 %): values are not comparable between any two implementations, the
@@ -147,15 +172,34 @@ def parity_tolerance(tree, ops, X, dtype, options=7, params=None, classes0=None,
     rng = np.random.Generator(np.random.PCG64(seed))
     spread = np.zeros(X64.shape[1])
     with np.errstate(all="ignore"):
-        sel_clean, sel_noisy = [], []
-        prog_interp.run(words, X64, bool(options & 1), p64, classes0, select_log=sel_clean)
+        sel_clean, sel_noisy, val_clean = [], [], []
+        prog_interp.run(words, X64, bool(options & 1), p64, classes0, select_log=sel_clean, value_log=val_clean)
+        behind_chaos = np.zeros(X64.shape[1], dtype=bool)  # some INTERMEDIATE of the sample moved by > 0.1 % under one-ulp perturbations
+        cfloor = 1e-36 if dtype == np.float32 else 1e-290
         for _ in range(draws):
             sel_noisy.append([])
-            noisy, _ = prog_interp.run(words, X64, bool(options & 1), p64, classes0, noise_eps=eps, rng=rng, select_log=sel_noisy[-1])
+            val_noisy = []
+            noisy, _ = prog_interp.run(words, X64, bool(options & 1), p64, classes0, noise_eps=eps, rng=rng, select_log=sel_noisy[-1], value_log=val_noisy)
             d = np.abs(noisy - clean)
             spread = np.maximum(spread, np.where(np.isfinite(d), d, np.inf))
+            for vc, vn in zip(val_clean, val_noisy):
+                behind_chaos |= ~(np.abs(vn - vc) <= 1e-3 * np.abs(vc) + cfloor) & np.isfinite(vc)
+        # Model version 7: the OUTPUT of such a sample may still be well-conditioned (cos(small / c) with c a chaotic cosine is ~1 for most
+        # c) but its deviation is heavy-tailed in the chaotic intermediate, and 8 x the largest of 16 draws underestimates that tail one
+        # time in a few thousand chaotic samples (fuzz seed 55, Float64: device 1.11 x the bound; profiles/r4_fuzz_summary.md item 7).
+        # Those samples — and only those — get MORE DRAWS (128 in all): the tail is measured instead of declaring everything behind a
+        # chaotic intermediate incomparable.
+        sub = np.nonzero(behind_chaos & np.isfinite(spread))[0]
+        if sub.size and extra_draws > 0:
+            Xs = np.ascontiguousarray(X64[:, sub])
+            cs = None if classes0 is None else np.asarray(classes0)[sub]
+            clean_s = clean[sub]
+            for _ in range(extra_draws):
+                noisy, _ = prog_interp.run(words, Xs, bool(options & 1), p64, cs, noise_eps=eps, rng=rng)
+                d = np.abs(noisy - clean_s)
+                spread[sub] = np.maximum(spread[sub], np.where(np.isfinite(d), d, np.inf))
         spread = np.where(unstable_selections(sel_clean, sel_noisy, X64.shape[1]), np.inf, spread)
-        base = (1e-5 if dtype == np.float32 else 1e-13) * np.abs(clean) + (1e-37 if dtype == np.float32 else 1e-300)
+        base = (1e-5 if dtype == np.float32 else F64_BASE) * np.abs(clean) + (1e-37 if dtype == np.float32 else 1e-300)
         tol = base + 8.0 * spread
         # (the absolute term is the size of a few Float32 subnormal steps, not more: with 1e-30 a result that underflows — fuzz_hot seed 54,
         # n / exp(80 * c / cos(cos(2.9e25))): 0 for most values of the chaotic cosine, 5e-32 for the few next to cos = 0, which is where the
@@ -387,7 +431,7 @@ def grad_tolerance(tree, ops, X, dtype, mode, params=None, classes=None, class_b
     except Unsupported:
         return None
     with np.errstate(all="ignore"):
-        rel = 1e-5 if dtype == np.float32 else 1e-13
+        rel = 1e-5 if dtype == np.float32 else F64_BASE
         floor = 1e-37 if dtype == np.float32 else 1e-300
         tol = rel * pabs + 8.0 * spread + floor
         ill = ~np.isfinite(clean) | ~np.isfinite(pabs) | ~(spread <= 1e-3 * pabs + floor)

@@ -68,7 +68,7 @@ TERNARY = {
 }
 
 
-def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noise_eps=0.0, rng=None, select_log=None):
+def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noise_eps=0.0, rng=None, select_log=None, value_log=None):
     """Execute instruction words ([n,4] uint32) on X [F, N].  Returns (out, ok).
 
     ``noise_eps`` > 0 multiplies every operator result by (1 +- u*noise_eps), u uniform in [1/4, 1], with a random sign
@@ -77,7 +77,10 @@ def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noi
     implementations of the same operator (used for the parity tolerance, helpers.py).
 
     ``select_log`` (a list) receives, in program order, the operand pair (x, y) of every SELECTING operator (abs / relu / sign / floor / ceil / round: the operand and the edge it is compared with; max, min,
-    greater, clamp, max3): helpers.unstable_selections compares the pairs of a clean and of the perturbed runs."""
+    greater, clamp, max3): helpers.unstable_selections compares the pairs of a clean and of the perturbed runs.
+
+    ``value_log`` (a list) receives every operator RESULT in program order (float64): helpers.parity_tolerance compares the intermediates
+    of the perturbed runs with the clean ones to find the samples that sit behind a chaotic intermediate."""
     dt = X.dtype
     N = X.shape[1]
     acc = np.zeros(N, dtype=dt)
@@ -137,6 +140,8 @@ def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noi
                     m = np.where(np.isfinite(m), m, 0.0)
                     step2 = rng.choice(np.array([-1.0, 1.0]), size=N) * rng.uniform(0.25, 1.0, size=N)
                     acc = (acc * (1.0 + noise_eps * 2.0 * m * step2)).astype(dt)
+            if value_log is not None and op != DOP_LOAD:
+                value_log.append(acc.astype(np.float64))
             check = bool(hdr & (1 << 15)) if early_exit else bool(hdr & (1 << 13))
             if check:
                 bad |= bool(np.any(~np.isfinite(acc)))

@@ -16,8 +16,10 @@ import fuzzlib as FZ
 
 pytestmark = pytest.mark.gpu
 
-ILL_VALUE_CAP = {"hot": 0.05, "wide": 0.20}   # share of compared samples / entries the model may class as ill-conditioned
-ILL_FLAG_CAP = 0.03                           # share of trees whose FLAG differs through an ill-conditioned sample
+# Caps = what was OBSERVED, with a factor of two, not a free allowance (round 5's run of the gate,
+# profiles/r5_pytest_gpu.log: the largest ill-conditioned share of any flavour is 1.13 % (mixed arity), and NO flag differs anywhere):
+ILL_VALUE_CAP = {"hot": 0.015, "wide": 0.025}  # share of compared samples / entries the model may class as ill-conditioned (0.05 / 0.20 until round 4)
+ILL_FLAG_CAP_ABS = 2                           # trees whose FLAG differs through an ill-conditioned sample, per gate (3 % of the trees until round 4; observed: 0)
 
 
 @pytest.fixture(scope="module")
@@ -33,7 +35,7 @@ def gate(f, kind, what):
     print(f"[fuzz gate {what}] {f.summary()}")
     assert not f.real, f"{len(f.real)} finding(s) outside the tolerance model [{what}]:\n  " + "\n  ".join(f.real[:12])
     assert f.ill_values <= ILL_VALUE_CAP[kind] * max(f.compared, 1), f"ill-conditioned share above the cap [{what}]: {f.summary()}"
-    assert f.ill_flags <= max(2, ILL_FLAG_CAP * f.flag_checks), f"flag differences on ill-conditioned trees above the cap [{what}]: {f.summary()}"
+    assert f.ill_flags <= ILL_FLAG_CAP_ABS, f"flag differences on ill-conditioned trees above the cap [{what}]: {f.summary()}"
 
 
 def contexts(api):
@@ -363,7 +365,8 @@ def _check_against_oracle(api, trees, ops, X, what):
         tol = FZ.parity_tolerance(trees[t], ops, X[:, ::max(1, N // 65536)], dtype)
         assert np.isinf(tol).any() or not np.isfinite(rows[t][0]).all(), f"{what}: flag of tree {t} differs from the oracle's"
         ill += 1
-    assert ill <= max(2, 0.03 * n), (what, ill)
+    print(f"[{what}] {ill} flag(s) differ from the oracle's on ill-conditioned trees (cap {ILL_FLAG_CAP_ABS})")
+    assert ill <= ILL_FLAG_CAP_ABS, (what, ill)
     assert n_live >= 0, f"{what}: the launch did not take the priority-tile / compaction path"
     by_prio = (n - n_live) / max(1, int((~ke).sum()))
     print(f"[{what}] {n} trees, {int((~ke).sum())} incomplete, {n - n_live} of them flagged by the probe launch of the priority tiles ({100 * by_prio:.0f} %)")
