@@ -723,6 +723,9 @@ template <typename T> __device__ inline T dev_digamma(T x) {
 // Sum over the 64 lanes of a wavefront; the total is valid in lane 63.  Float32: DPP row
 // operations fused into the adds (no LDS traffic); Float64: cross-lane shuffles.
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
+#ifdef DE_STUB_WAVE_SUM // MEASUREMENT ONLY (wrong results): what the kernels would cost without their wave reductions (profiles/r5_rev_bound.md)
+    return v;
+#endif
 #define DE_DPP_ADD(CTRL, ROWMASK)                                                                          \
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
     DE_DPP_ADD(0x111, 0xf) // row_shr:1

@@ -81,6 +81,9 @@ template <typename T> struct KArgs {
     const int32_t *ctrl;
     // threaded kernel: sample tiles per XCD that run one chunk before the next chunk starts (map_block_grouped); 0 = chunk-fastest (map_block)
     int32_t map_group;
+    // threaded kernel: the LAST chunk of the plan runs as `tail_split` sub-chunks (1 = as it is): the workgroups that finish a launch are
+    // short ones — the tail of a launch that fills the chip only a few times (10^6 samples: ~9 times, one 60-tree workgroup = 100 us of 900)
+    int32_t tail_split;
 };
 
 // Chunk plan of a launch over n trees and n_tiles sample tiles (host: plan_chunks; device: de_compact_live_kernel for the live trees):
@@ -889,10 +892,12 @@ __device__ __forceinline__ VecOf<float>::type div_safe(VecOf<float>::type a, Vec
     DE_UNROLL for (int h = 0; h < 2; h++) {
         const DeF2 n = {a[2 * h], a[2 * h + 1]}, d = {b[2 * h], b[2 * h + 1]};
         DeF2 y = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-        const DeF2 e = __builtin_elementwise_fma(-d, y, DE_F2(1.0f));
+        // (the negations sit on the fresh temporaries y and t — free source modifiers; on `d` the compiler materialised -d of the second
+        // pair with two v_xor_b32: its register had been reused.  -(d) * y == d * (-y) exactly: the same bits)
+        const DeF2 e = __builtin_elementwise_fma(d, -y, DE_F2(1.0f));
         y = __builtin_elementwise_fma(e, y, y);
         DeF2 t = n * y;
-        const DeF2 r = __builtin_elementwise_fma(-d, t, n);
+        const DeF2 r = __builtin_elementwise_fma(d, -t, n);
         t = __builtin_elementwise_fma(r, y, t);
         q[2 * h] = t[0];
         q[2 * h + 1] = t[1];
@@ -929,6 +934,10 @@ __device__ __forceinline__ VecOf<float>::type div_safe_by_const(VecOf<float>::ty
     return q;
 }
 // the divisions of the fast handlers whose operand `b` is the constant `cbits` (K = 4: x / c, 5: c / x): range test, quotient
+// "some lane of the wavefront": the ballot builtin on the predicate itself.  (`__ballot(p) != 0` combined with a SCALAR condition in one
+// `if` made the compiler materialise the predicate as 0 / 1 in a vector register and compare it again — two more vector and half a
+// dozen scalar instructions in every division by a constant; the scalar condition now has a branch of its own.)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 template <int K> __device__ __forceinline__ bool div_const_unsafe(VecOf<float>::type x, uint32_t cbits) { // (one plane: the full handlers' own test)
     return (int)(__ballot(!div_samples_safe(x)) != 0ull) | (int)!div_const_in_range(cbits);
 }
@@ -1222,7 +1231,8 @@ template <int K, bool TB> __device__ __noinline__ HState<float> h_un_end_fast(HF
     UnPre p[G];
     bool slow = false;
     FOR_PLANES slow |= un_pretest<K, TB>(st.acc[g], p[g]);
-    if (__builtin_expect(((int32_t)flags < 0) | (__ballot(slow) != 0ull), 0)) [[clang::musttail]] return h_chain_end<T, &b_un<T, K, 1, TB>>(HFAST_PASS);
+    if (__builtin_expect((int32_t)flags < 0, 0)) [[clang::musttail]] return h_chain_end<T, &b_un<T, K, 1, TB>>(HFAST_PASS);
+    if (__builtin_expect(wave_any(slow), 0)) [[clang::musttail]] return h_chain_end<T, &b_un<T, K, 1, TB>>(HFAST_PASS);
 #if DE_TG == 1
     FOR_PLANES {
         st.acc[g] = un_finish<K, TB>(st.acc[g], p[g]);
@@ -1272,7 +1282,8 @@ template <int K, int VAR> __device__ __noinline__ HState<float> h_div_fast(HFAST
     if constexpr (VAR & 2) { // constant operand
         bool unsafe = false;
         FOR_PLANES unsafe |= !div_samples_safe(st.acc[g]);
-        if (__builtin_expect((int)(__ballot(unsafe) != 0ull) | (int)!div_const_in_range(w1), 0)) [[clang::musttail]] return h_chain<T, &b_bin<T, K, VAR, false>>(HFAST_PASS);
+        if (__builtin_expect(!div_const_in_range(w1), 0)) [[clang::musttail]] return h_chain<T, &b_bin<T, K, VAR, false>>(HFAST_PASS);
+        if (__builtin_expect(wave_any(unsafe), 0)) [[clang::musttail]] return h_chain<T, &b_bin<T, K, VAR, false>>(HFAST_PASS);
         FOR_PLANES st.acc[g] = div_const<K>(st.acc[g], w1);
     } else {
         V num[G], den[G];
@@ -1297,7 +1308,8 @@ template <int K, bool CST> __device__ __noinline__ HState<float> h_div_end_fast(
     if constexpr (CST) {
         bool unsafe = false;
         FOR_PLANES unsafe |= !div_samples_safe(st.acc[g]);
-        if (__builtin_expect((int)((int32_t)flags < 0) | (int)(__ballot(unsafe) != 0ull) | (int)!div_const_in_range(w1), 0)) [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 3, false>>(HFAST_PASS);
+        if (__builtin_expect(((int32_t)flags < 0) | !div_const_in_range(w1), 0)) [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 3, false>>(HFAST_PASS);
+        if (__builtin_expect(wave_any(unsafe), 0)) [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 3, false>>(HFAST_PASS);
         FOR_PLANES st.acc[g] = div_const<K>(st.acc[g], w1);
     } else {
         V num[G], den[G];
@@ -1308,8 +1320,8 @@ template <int K, bool CST> __device__ __noinline__ HState<float> h_div_end_fast(
             den[g] = K == 4 ? b : st.acc[g];
             unsafe |= !div_operands_safe(num[g], den[g]);
         }
-        if (__builtin_expect(((int32_t)flags < 0) | (__ballot(unsafe) != 0ull), 0))
-            [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 1, false>>(HFAST_PASS);
+        if (__builtin_expect((int32_t)flags < 0, 0)) [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 1, false>>(HFAST_PASS);
+        if (__builtin_expect(wave_any(unsafe), 0)) [[clang::musttail]] return h_chain_end<T, &b_bin<T, K, 1, false>>(HFAST_PASS);
         FOR_PLANES st.acc[g] = div_safe(num[g], den[g]);
     }
     FOR_PLANES hpoison<T>(st.poison, st.acc[g]);
@@ -1353,7 +1365,8 @@ template <int K, bool CST, bool OUT, bool PUSH> __device__ __noinline__ HState<f
     if constexpr (CST) {
         bool unsafe = false;
         FOR_PLANES unsafe |= !div_samples_safe(x[g]);
-        if (__builtin_expect((int)(__ballot(unsafe) != 0ull) | (int)!div_const_in_range(w1), 0)) [[clang::musttail]] return h_chain<T, &b_bin2<T, K, CST, OUT, PUSH, false>>(HFAST_PASS);
+        if (__builtin_expect(!div_const_in_range(w1), 0)) [[clang::musttail]] return h_chain<T, &b_bin2<T, K, CST, OUT, PUSH, false>>(HFAST_PASS);
+        if (__builtin_expect(wave_any(unsafe), 0)) [[clang::musttail]] return h_chain<T, &b_bin2<T, K, CST, OUT, PUSH, false>>(HFAST_PASS);
         FOR_PLANES st.acc[g] = div_const<K>(x[g], w1);
     } else {
         V num[G], den[G];
@@ -1732,14 +1745,21 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         tm.chunk = (int32_t)(blockIdx.x % (uint32_t)a.n_chunks);
         tm.valid = tm.tile < a.n_tiles;
         flag_protocol = 1;
-    } else tm = a.map_group > 0 ? map_block_grouped(blockIdx.x - a.n_prio_blocks, n_chunks, a.n_tiles, (uint32_t)a.map_group)
-                                : map_block(blockIdx.x - a.n_prio_blocks, n_chunks, a.n_tiles);
+    } else tm = a.map_group > 0 ? map_block_grouped(blockIdx.x - a.n_prio_blocks, n_chunks + a.tail_split - 1, a.n_tiles, (uint32_t)a.map_group)
+                                : map_block(blockIdx.x - a.n_prio_blocks, n_chunks + a.tail_split - 1, a.n_tiles);
     if (!tm.valid) return;
     const int tid = threadIdx.x;
     const int64_t base = tm.tile * TILE;
     const int64_t last = a.N - 1;
-    const int tA = tm.chunk * tpc; // this workgroup's trees: [tA, tB) (of the compact stream in a compacted launch)
-    const int tB = (tA + tpc < n_trees) ? tA + tpc : n_trees;
+    int tA = tm.chunk * tpc; // this workgroup's trees: [tA, tB) (of the compact stream in a compacted launch)
+    int tB = (tA + tpc < n_trees) ? tA + tpc : n_trees;
+    if (a.tail_split > 1 && tm.chunk >= n_chunks - 1) { // the plan's last chunk in `tail_split` pieces (chunk-major order: the last workgroups of the launch)
+        const int b0 = (n_chunks - 1) * tpc, rem = n_trees - b0;
+        const int sub = (rem + a.tail_split - 1) / a.tail_split;
+        tA = b0 + (tm.chunk - (n_chunks - 1)) * sub;
+        tB = tA + sub < n_trees ? tA + sub : n_trees;
+        if (tA >= tB) return; // (before anything is staged: a workgroup is one wave here, no barrier is left waiting)
+    }
     // early exit: the flags of the first <= 64 trees, requested before the X tile so that the two latencies overlap
     // (wave 0 reads them for the whole workgroup: two waves reading at different moments could see different flags, and the
     // workgroup shares ONE live-tree list)
@@ -2274,7 +2294,20 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         a.map_group = (int32_t)(g <= 0 ? 0 : (g > tiles8 ? tiles8 : g));
     }
     const int64_t tiles8g = a.map_group > 0 ? (tiles8 + a.map_group - 1) / a.map_group * a.map_group : tiles8;
-    int64_t blocks = tiles8g * 8 * a.n_chunks;
+    // The tail of the launch: under the chunk-major order the LAST workgroups all belong to the last chunk, and one workgroup of ~60 trees
+    // runs ~100 us at full occupancy — a launch that fills the chip N times loses ~half a workgroup's time at its end (10^6 samples: ~9
+    // fills, ~5 %).  The last chunk therefore runs as DE_TAIL_SPLIT (default 4) sub-chunks of >= 8 trees: the workgroups that finish the
+    // launch are short.  Order of the trees' evaluation only; one wave per workgroup (the sub-chunks of an empty tail exit before staging).
+    // Measured (same box, profiles/r5_ab_tail_split.txt): 10^6 samples (8 fills) -1.0 ... -1.5 %, 10^7 samples (80 fills) +0.8 % (the last
+    // chunk's X tiles staged four times) — so only launches of <= DE_TAIL_SPLIT_FILLS (24) fills of the chip split their last chunk.
+    a.tail_split = 1;
+    const int64_t fills = (a.n_tiles * (int64_t)a.n_chunks) / ((int64_t)(cu_count() > 0 ? cu_count() : 256) * 21);
+    if (TBLK == 64 && a.map_group > 0 && a.n_chunks > 1 && fills <= env_int("DE_TAIL_SPLIT_FILLS", 24)) {
+        const int ts = env_int("DE_TAIL_SPLIT", 4);
+        const int most = tpc / 8; // (a sub-chunk keeps >= 8 trees when the chunk is full)
+        a.tail_split = ts < 1 ? 1 : (ts > most ? (most < 1 ? 1 : most) : ts);
+    }
+    int64_t blocks = tiles8g * 8 * ((int64_t)a.n_chunks + a.tail_split - 1);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // priority tiles (de_tile_extremes_kernel): launches over >= 512 sample tiles and >= 96 trees with the early exit on; 3 F tiles, run
     // first and once more in place.  The pre-pass: a memset, one read of X, a dependent launch (0.11 ms at 10^7 samples)
@@ -2290,6 +2323,10 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         a.prio = static_cast<const unsigned long long *>(e.prio_keys);
         a.n_prio = (uint32_t)np;
         a.n_prio_blocks = (uint32_t)(((int64_t)np * a.n_chunks + 7) / 8 * 8);
+        if (!env_int("DE_PRIO_PROBE", 1)) { // (the priority tiles as the first workgroups of the ONE launch: they index the plain chunks)
+            blocks = tiles8g * 8 * (int64_t)a.n_chunks;
+            a.tail_split = 1;
+        }
         blocks += a.n_prio_blocks;
         if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     }
@@ -2319,6 +2356,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         // the priority tiles as a launch of their OWN in front, in chunks of DE_PRIO_PROBE_TPC trees (short workgroups, many of them): when the
         // launch proper starts, the flags are down for its very first workgroups too (no blind first wave: 9 % of the tiles at 10^6 samples)
         KArgs<T> pa = a;
+        pa.tail_split = 1;
         pa.trees_per_chunk = env_int("DE_PRIO_PROBE_TPC", 8);
         pa.trees_per_chunk = pa.trees_per_chunk < 1 ? 1 : (pa.trees_per_chunk > 64 ? 64 : pa.trees_per_chunk); // (a divisor, and the skip mask has 64 bits)
         pa.n_chunks = (a.n_trees + pa.trees_per_chunk - 1) / pa.trees_per_chunk;
@@ -2361,7 +2399,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
             a.live_idx = live_idx;
             a.ctrl = ctrl;
             if (e.compacted) *e.compacted = true;
-            blocks = tiles8g * 8 * (int64_t)nc0;
+            blocks = tiles8g * 8 * ((int64_t)nc0 + a.tail_split - 1);
             if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
         }
     }

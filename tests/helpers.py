@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # a number and one line here citing the traced finding that forced it; tests/test_tolerance_model.py pins the share of samples the model
 # declares ill-conditioned on three fixed populations (tests/golden/tolerance_model_shares.json, recorded per MODEL_VERSION: it may not grow
 # silently).
-MODEL_VERSION = 7
+MODEL_VERSION = 8
 MODEL_CHANGELOG = (
     (1, "rounds 1-3: north-star base (1e-5 Float32 / 1e-13 Float64) + 8 x the measured spread of 16 one-ulp-perturbed float64 re-evaluations; "
         "spread > 1e-3 |y| = ill-conditioned (DESIGN 5)"),
@@ -28,6 +28,9 @@ MODEL_CHANGELOG = (
     (7, "round 5: samples behind a CHAOTIC INTERMEDIATE (an operator result that moves by > 0.1 % under one-ulp perturbations while the output "
         "does not) get 128 draws instead of 16 — the heavy tail of cos(small / chaotic cosine), fuzz seed 55 Float64: profiles/r4_fuzz_summary.md "
         "item 7, tools/trace_value_findings.py; no other sample's tolerance changes"),
+    (8, "round 5: the float64 model OVERFLOWS where Float32 does (an operator result beyond 3.4e38 is Inf in the model too): fuzz seed 61, "
+        "min(154.39, safe_log(pow_abs2(x3, x1) ^ c + c')) with pow_abs2 = 4.6e38 — device and oracle agree to 3e-7, the float64 model took the "
+        "other branch of min and priced the tolerance against 1.35: profiles/r5_value_findings_61.jsonl"),
 )
 # Float64 north-star base of the end-to-end comparisons, relative: 8 ulp (DE_TOL_F64_BASE overrides it for the experiment that produced
 # profiles/r5_f64_base_8ulp.md)
@@ -167,19 +170,20 @@ def parity_tolerance(tree, ops, X, dtype, options=7, params=None, classes0=None,
     words, _ = api.lower_tape(tape, consts.astype(np.float64), X.shape[0], P, options, np.float64)
     X64 = np.asarray(X, dtype=np.float64)
     p64 = None if params is None else np.asarray(params, dtype=np.float64)
-    clean, _ = prog_interp.run(words, X64, bool(options & 1), p64, classes0)
+    ovf = float(np.finfo(dtype).max) if dtype == np.float32 else None  # model version 8: the float64 model overflows where the element type does
+    clean, _ = prog_interp.run(words, X64, bool(options & 1), p64, classes0, overflow_at=ovf)
     eps = 2.0 ** -23 if dtype == np.float32 else 2.0 ** -52
     rng = np.random.Generator(np.random.PCG64(seed))
     spread = np.zeros(X64.shape[1])
     with np.errstate(all="ignore"):
         sel_clean, sel_noisy, val_clean = [], [], []
-        prog_interp.run(words, X64, bool(options & 1), p64, classes0, select_log=sel_clean, value_log=val_clean)
+        prog_interp.run(words, X64, bool(options & 1), p64, classes0, select_log=sel_clean, value_log=val_clean, overflow_at=ovf)
         behind_chaos = np.zeros(X64.shape[1], dtype=bool)  # some INTERMEDIATE of the sample moved by > 0.1 % under one-ulp perturbations
         cfloor = 1e-36 if dtype == np.float32 else 1e-290
         for _ in range(draws):
             sel_noisy.append([])
             val_noisy = []
-            noisy, _ = prog_interp.run(words, X64, bool(options & 1), p64, classes0, noise_eps=eps, rng=rng, select_log=sel_noisy[-1], value_log=val_noisy)
+            noisy, _ = prog_interp.run(words, X64, bool(options & 1), p64, classes0, noise_eps=eps, rng=rng, select_log=sel_noisy[-1], value_log=val_noisy, overflow_at=ovf)
             d = np.abs(noisy - clean)
             spread = np.maximum(spread, np.where(np.isfinite(d), d, np.inf))
             for vc, vn in zip(val_clean, val_noisy):
@@ -195,7 +199,7 @@ def parity_tolerance(tree, ops, X, dtype, options=7, params=None, classes0=None,
             cs = None if classes0 is None else np.asarray(classes0)[sub]
             clean_s = clean[sub]
             for _ in range(extra_draws):
-                noisy, _ = prog_interp.run(words, Xs, bool(options & 1), p64, cs, noise_eps=eps, rng=rng)
+                noisy, _ = prog_interp.run(words, Xs, bool(options & 1), p64, cs, noise_eps=eps, rng=rng, overflow_at=ovf)
                 d = np.abs(noisy - clean_s)
                 spread[sub] = np.maximum(spread[sub], np.where(np.isfinite(d), d, np.inf))
         spread = np.where(unstable_selections(sel_clean, sel_noisy, X64.shape[1]), np.inf, spread)

@@ -68,7 +68,7 @@ TERNARY = {
 }
 
 
-def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noise_eps=0.0, rng=None, select_log=None, value_log=None):
+def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noise_eps=0.0, rng=None, select_log=None, value_log=None, overflow_at=None):
     """Execute instruction words ([n,4] uint32) on X [F, N].  Returns (out, ok).
 
     ``noise_eps`` > 0 multiplies every operator result by (1 +- u*noise_eps), u uniform in [1/4, 1], with a random sign
@@ -78,6 +78,10 @@ def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noi
 
     ``select_log`` (a list) receives, in program order, the operand pair (x, y) of every SELECTING operator (abs / relu / sign / floor / ceil / round: the operand and the edge it is compared with; max, min,
     greater, clamp, max3): helpers.unstable_selections compares the pairs of a clean and of the perturbed runs.
+
+    ``overflow_at`` (the element type's largest finite value when X is wider than the element type being modelled): an operator result
+    beyond it becomes +-Inf, as it does in the element type — exp(x1 log|x3|) = 4.6e38 is Inf in Float32, and everything downstream of it
+    (min(., safe_log(Inf)) ...) follows the Float32 evaluation, not the float64 one (fuzz seed 61, profiles/r5_value_findings_61.jsonl).
 
     ``value_log`` (a list) receives every operator RESULT in program order (float64): helpers.parity_tolerance compares the intermediates
     of the perturbed runs with the clean ones to find the samples that sit behind a chaotic intermediate."""
@@ -129,6 +133,8 @@ def run(words, X, early_exit=True, params=None, classes0=None, host_ok=True, noi
                     acc = BINARY[op](acc, b).astype(dt)
                 if (not early_exit) and (hdr & (1 << 14)):
                     acc = np.where(np.isfinite(b), acc, np.inf).astype(dt)
+            if overflow_at is not None and op != DOP_LOAD:
+                acc = np.where(np.abs(acc) > overflow_at, np.copysign(np.inf, acc), acc).astype(dt)
             if noise_eps and op != DOP_LOAD:
                 # random sign AND magnitude in [1/4, 1] of noise_eps: a fixed step can land on a period of the
                 # function downstream (1.05e8 * 2^-23 = 12.55 ~ 4*pi hid a chaotic cos(exp(x)) sample)
