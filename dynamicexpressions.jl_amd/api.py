@@ -48,7 +48,7 @@ EXPORTS = [
     "de_program_n_grad", "de_program_dump", "de_program_verify", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad", "de_eval_loss_grad_by_class",
     "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_prio_tiles_wanted", "de_program_last_live_trees", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size", "de_dist_world_size",
     "de_dist_broadcast", "de_dist_gather_flags", "de_dist_last_error", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
-    "de_ctx_device", "de_ctx_timing_ring", "de_ctx_timing_read", "de_dist_reorder_selftest",
+    "de_ctx_device", "de_ctx_timing_ring", "de_ctx_timing_read", "de_dist_reorder_selftest", "de_eval_sum_certificate",
 ]
 
 
@@ -148,6 +148,7 @@ def library() -> C.CDLL:
     lib.de_ctx_timing_ring.argtypes = [vp, i32]
     lib.de_ctx_timing_read.argtypes = [vp, vp, i32, C.POINTER(i32)]
     lib.de_dist_reorder_selftest.argtypes = [vp, vp, i64, C.c_int, vp, C.POINTER(C.c_float)]
+    lib.de_eval_sum_certificate.argtypes = [vp, vp, vp, i64, i64, C.POINTER(ParamArgs), vp, vp, vp]
     _lib = lib
     return lib
 
@@ -581,6 +582,24 @@ class Population:
         self.ctx.check(lib.de_eval(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None,
                                    out.ctypes.data, N, ok.ctypes.data))
         return out, ok.astype(bool)
+
+    def sum_certificate(self, X, params=None, classes=None, class_base: int = 1):
+        """``(ok, certified, max_abs)`` (numpy, per tree): the certificate of ``de_eval_sum_certificate`` — ``certified[t]`` says that the
+        reference's ``complete`` (``isfinite(sum(x))`` per tested array, src/ValueInterface.jl:9) provably equals the element-wise flag
+        ``ok[t]`` the kernels compute; ``max_abs[t]`` = the largest |tested value or constant operand| of the tree."""
+        ptr, F, N, ldX, keep_x, is_t = _prep_X(X, self.dtype)
+        if is_t:
+            self.ctx.use_torch_stream()
+        if F < self.n_features:
+            raise ValueError(f"X has {F} features but the trees use feature {self.n_features}")
+        keep = [keep_x]
+        pa = self._param_args(params, classes, class_base, N, keep)
+        ok = np.zeros(self.n_trees, dtype=np.uint8)
+        cert = np.zeros(self.n_trees, dtype=np.uint8)
+        mx = np.zeros(self.n_trees, dtype=np.float64)
+        self.ctx.check(library().de_eval_sum_certificate(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None,
+                                                         ok.ctypes.data, cert.ctypes.data, mx.ctypes.data))
+        return ok.astype(bool), cert.astype(bool), mx
 
     def eval_loss(self, X, y, weights=None, loss: str = "L2", params=None, classes=None, class_base: int = 1):
         """Fused ``sum_j w_j * l(tree_t(X[:, j]) - y[j])`` for every tree (l = abs2 for "L2", abs for

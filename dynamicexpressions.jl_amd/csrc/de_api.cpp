@@ -55,6 +55,7 @@ struct de_ctx {
     std::string err;
     const char *last_kernel = "";
     DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2, sGoff, sNg, sY, sW, sLoss, sPartial, sSeg, sDloss, sColOff, sDoff, sPrio;
+    DevBuf sCert; // de_eval_sum_certificate: per-tree maxima
     DevBuf sBcLoss, sBcDloss, sBcOk, sBcNg, sBcDoff, sBcOut, sBcTiles; // de_eval_loss_grad_by_class
     int nested = 0; // > 0 inside a call made of several inner calls: those do not touch the timing events
     // de_ctx_declare_dataset: a device-resident X the caller promises not to modify — its priority-tile keys are computed once
@@ -117,6 +118,11 @@ struct de_program {
     BoundInstr *d_compact_code = nullptr;
     int32_t *d_compact_ints = nullptr;
     bool last_compacted = false; // the most recent eval launch compacted its live trees (de_program_last_live_trees)
+    // de_eval_sum_certificate: the eval program with EVERY operator result validity-tested (no exact elision), bound for the flat-switch kernel
+    BoundInstr *d_cert_code = nullptr;
+    int32_t *d_cert_off = nullptr;
+    size_t cert_cap = 0;
+    std::vector<double> cert_cmax; // per tree: the largest |constant operand| (an array of N copies of it is summed by the reference)
     BoundInstr *d_gcode = nullptr;      // bound UNFOLDED program on the device (gradient kernels), lazily uploaded
     int32_t *d_gcode_off = nullptr;
     std::vector<BoundInstr> gbcode;
@@ -374,7 +380,7 @@ int de_ctx_destroy(de_ctx_t *c) {
     if (!c) return DE_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff, &c->sPrio, &c->sPrioDs, &c->sBcLoss, &c->sBcDloss, &c->sBcOk, &c->sBcNg, &c->sBcDoff, &c->sBcOut, &c->sBcTiles}) b->release();
+    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff, &c->sPrio, &c->sPrioDs, &c->sCert, &c->sBcLoss, &c->sBcDloss, &c->sBcOk, &c->sBcNg, &c->sBcDoff, &c->sBcOut, &c->sBcTiles}) b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->ring) (void)hipEventDestroy(e);
@@ -1127,6 +1133,8 @@ int de_program_destroy(de_program_t *p) {
     if (p->d_code) (void)hipFree(p->d_code);
     if (p->d_code_off) (void)hipFree(p->d_code_off);
     if (p->d_compact_ints) (void)hipFree(p->d_compact_ints);
+    if (p->d_cert_code) (void)hipFree(p->d_cert_code);
+    if (p->d_cert_off) (void)hipFree(p->d_cert_off);
     if (p->aux) de_program_destroy(p->aux);
     if (p->d_gcode) (void)hipFree(p->d_gcode);
     if (p->d_gcode_off) (void)hipFree(p->d_gcode_off);
@@ -1452,8 +1460,74 @@ struct LossReq {
     void *loss;
 };
 
+struct CertReq {
+    uint8_t *certified; // host, n_trees
+    double *max_abs;    // host, n_trees, or null
+};
 static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
-                     void *out, int64_t ld_out, uint8_t *ok, const LossReq *lr);
+                     void *out, int64_t ld_out, uint8_t *ok, const LossReq *lr, const CertReq *cr = nullptr);
+static int ensure_cert_program(de_ctx *c, de_program *p);
+
+// The certificate program (de_eval_sum_certificate): the eval program's generic form with the result of EVERY operator validity-tested —
+// the exact elision of de_lower.cpp (a test is dropped when the value's consumer maps a non-finite input onto a tested non-finite output)
+// keeps the FLAG exact but drops values the reference still sums — bound for the flat-switch kernel; plus, per tree, the largest
+// |constant operand| (deg0_eval of a constant is an array of N copies: the reference sums that too).  A superset of the arrays the
+// reference sums (the inner values of its fused 2/3-node kernels are never materialised there): sound, slightly conservative.
+// Rebuilt at every call (constants may have moved; ~1 us per tree).
+static int ensure_cert_program(de_ctx *c, de_program *p) {
+    const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
+    const std::vector<int32_t> &off = p->folded ? p->fcode_off : p->code_off;
+    const int prb = p->prows ? p->n_features + p->n_slots : -1;
+    std::vector<BoundInstr> bc;
+    std::vector<int32_t> boff((size_t)p->n_trees + 1, 0);
+    std::vector<Instr> tmp;
+    p->cert_cmax.assign((size_t)p->n_trees, 0.0);
+    for (int64_t t = 0; t < p->n_trees; t++) {
+        tmp.assign(src.begin() + off[(size_t)t], src.begin() + off[(size_t)t + 1]);
+        double cm = 0.0;
+        for (Instr &ins : tmp) {
+            if ((ins.hdr & H_OP_MASK) != DOP_LOAD) ins.hdr |= H_CHECK_OUT;
+            if (((ins.hdr >> H_SRC_SHIFT) & H_SRC_MASK) == SRC_CONST) {
+                const double v = p->dtype == DE_F32 ? (double)ins.imm.f32 : ins.imm.f64;
+                if (v == v) cm = std::max(cm, std::fabs(v));
+            }
+        }
+        p->cert_cmax[(size_t)t] = cm;
+        bind_tree(tmp.data(), tmp.size(), true, p->n_features, &bc, prb);
+        boff[(size_t)t + 1] = (int32_t)bc.size();
+    }
+    bc.push_back(BoundInstr{0u, 0u, 0u, 0u}); // (the kernel prefetches pc + 1)
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (p->cert_cap < bc.size()) {
+        if (p->d_cert_code) (void)hipFree(p->d_cert_code);
+        p->d_cert_code = nullptr;
+        p->cert_cap = 0;
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_cert_code), bc.size() * sizeof(BoundInstr)));
+        p->cert_cap = bc.size();
+    }
+    if (!p->d_cert_off) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_cert_off), boff.size() * sizeof(int32_t)));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // (an earlier certificate launch may still read the buffers)
+    HIP_TRY(c, hipMemcpy(p->d_cert_code, bc.data(), bc.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(p->d_cert_off, boff.data(), boff.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return DE_OK;
+}
+
+int de_eval_sum_certificate(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
+                            uint8_t *ok, uint8_t *certified, double *max_abs) {
+    if (!c || !p) return DE_ERR_INVALID_ARG;
+    if (N < 0 || !ok || !certified || (p->n_trees > 0 && N > 0 && !X)) return fail(c, DE_ERR_INVALID_ARG, "null buffer");
+    if (is_device_ptr(certified) || (max_abs && is_device_ptr(max_abs))) return fail(c, DE_ERR_INVALID_ARG, "certified / max_abs are host arrays");
+    if (p->direct) return fail(c, DE_ERR_UNSUPPORTED, "de_eval_sum_certificate needs the LDS-tiled kernel (feature matrix too wide)");
+    if (!(p->options & DE_OPT_EARLY_EXIT) || N == 0) {
+        // early_exit = false: the reference sums nothing (src/Evaluate.jl:16-32 are no-ops), the flag is the constant part alone; N = 0: sum(empty) = 0
+        for (int64_t t = 0; t < p->n_trees; t++) { certified[t] = 1; if (max_abs) max_abs[t] = 0.0; }
+        if (is_device_ptr(ok)) { HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipMemcpy(ok, p->host_ok_eval.data(), (size_t)p->n_trees, hipMemcpyHostToDevice)); }
+        else std::memcpy(ok, p->host_ok_eval.data(), (size_t)p->n_trees);
+        return DE_OK;
+    }
+    const CertReq cr{certified, max_abs};
+    return eval_impl(c, p, X, N, ldX, pa, nullptr, N, ok, nullptr, &cr);
+}
 
 int de_eval(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
             void *out, int64_t ld_out, uint8_t *ok) {
@@ -1475,7 +1549,7 @@ int de_eval_loss(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t
 }
 
 static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
-                     void *out, int64_t ld_out, uint8_t *ok, const LossReq *lr) {
+                     void *out, int64_t ld_out, uint8_t *ok, const LossReq *lr, const CertReq *cr) {
     if (p->ctx != c) return fail(c, DE_ERR_INVALID_ARG, "program belongs to another context");
     if (ldX < p->n_features) return fail(c, DE_ERR_INVALID_ARG, "ldX < n_features");
     int rc = check_param_args(c, p, pa, N);
@@ -1527,9 +1601,15 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
         la.partial = c->sPartial.p;
         la.seg_sum = c->sSeg.p;
         la.loss = sLoss.dev;
-    } else {
+    } else if (!cr) {
         rc = stage_out(c, c->sOut, out, ((size_t)(p->n_trees - 1) * (size_t)ld_out + (size_t)N) * es, &sOut);
         if (rc) return rc;
+    }
+    if (cr) {
+        rc = ensure_cert_program(c, p);
+        if (rc) return rc;
+        HIP_TRY(c, c->sCert.reserve((size_t)p->n_trees * es));
+        HIP_TRY(c, hipMemsetAsync(c->sCert.p, 0, (size_t)p->n_trees * es, c->stream));
     }
     // ok[] starts as the host-side (constant) part of the flag; the kernel only clears bytes
     if (ok_dev) {
@@ -1582,6 +1662,16 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
     a.prio_keys_ready = !sX.staged && dataset_keys(c, p->dtype, X, N, ldX, p->n_features, &a.prio_keys);
     a.compact_code = p->d_compact_code;
     a.compact_ints = p->d_compact_ints;
+    if (cr) { // the certificate pass: the un-elided program through the flat-switch kernel's CERT variant, nothing stored
+        a.code = p->d_cert_code;
+        a.code_off = p->d_cert_off;
+        a.threaded = false;
+        a.cert_max = c->sCert.p;
+        a.out = nullptr;
+        a.prio_keys = nullptr;
+        a.compact_code = nullptr;
+        a.compact_ints = nullptr;
+    }
     HIP_TRY(c, time_begin(c));
     a.compacted = &p->last_compacted;
     p->last_compacted = false;
@@ -1598,6 +1688,24 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
                                           (size_t)N * es, hipMemcpyDeviceToHost, c->stream));
     }
     if (sOk.staged) HIP_TRY(c, hipMemcpyAsync(ok, sOk.dev, (size_t)p->n_trees, hipMemcpyDeviceToHost, c->stream));
+    if (cr) {
+        // certified[t]: the reference's `complete` provably equals ok[t].  It tests isfinite(sum(x)) over N values (src/ValueInterface.jl:9)
+        // where the device tests every element: the two differ only when all elements are finite and a (partial) sum overflows — impossible
+        // while N * max|x| stays below the largest finite value.  ok[t] == 0 means some element is non-finite: its sum is too.
+        std::vector<unsigned char> mx((size_t)p->n_trees * es);
+        std::vector<uint8_t> okh((size_t)p->n_trees);
+        HIP_TRY(c, hipMemcpyAsync(mx.data(), c->sCert.p, mx.size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(okh.data(), sOk.dev, okh.size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const double top = p->dtype == DE_F32 ? (double)std::numeric_limits<float>::max() : std::numeric_limits<double>::max();
+        for (int64_t t = 0; t < p->n_trees; t++) {
+            double m = p->dtype == DE_F32 ? (double)reinterpret_cast<float *>(mx.data())[t] : reinterpret_cast<double *>(mx.data())[t];
+            m = std::max(m, p->cert_cmax[(size_t)t]);
+            if (cr->max_abs) cr->max_abs[t] = m;
+            cr->certified[t] = (!okh[(size_t)t] || m * (double)N * 1.001 < top || !(m == m)) ? 1 : 0; // (the margin: the summation's own roundings)
+            if (!std::isfinite(m) && okh[(size_t)t]) cr->certified[t] = 0;
+        }
+    }
     if (sX.staged || sOut.staged || sOk.staged || sPar.staged || sCls.staged || sY.staged || sW.staged || sLoss.staged)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (sOut.staged && a.skip_flagged) {

@@ -84,6 +84,9 @@ struct EvalArgs {
     void *compact_code;
     int32_t *compact_ints;
     bool *compacted; // out (may be null): this launch compacted its live trees
+    // de_eval_sum_certificate: device array of n_trees zeroed words of the element type's size; non-null selects the CERT variant of the
+    // flat-switch kernel (no output): the bits of the largest |validity-tested value| of every tree
+    void *cert_max;
 };
 constexpr int DE_PRIO_MAX_F = 8; // (the pre-pass keeps 6 registers per feature)
 constexpr int DE_PRIO_UNIT = 64;  // samples per unit of the keys' position field (every kernel's tile is a multiple)

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <memory>
 #include <mutex>
+#include <type_traits>
 
 #include <cstdlib>
 #include <cstring>
@@ -81,6 +82,9 @@ template <typename T> struct KArgs {
     const int32_t *ctrl;
     // threaded kernel: sample tiles per XCD that run one chunk before the next chunk starts (map_block_grouped); 0 = chunk-fastest (map_block)
     int32_t map_group;
+    // flat-switch kernel, CERT variant (de_eval_sum_certificate): per tree the largest |value| among the values the kernel validity-tests,
+    // as the bits of a non-negative T in an unsigned word (atomicMax); nothing is stored to `out`
+    void *cert_max;
     // threaded kernel: the LAST chunk of the plan runs as `tail_split` sub-chunks (1 = as it is): the workgroups that finish a launch are
     // short ones — the tail of a launch that fills the chip only a few times (10^6 samples: ~9 times, one 60-tree workgroup = 100 us of 900)
     int32_t tail_split;
@@ -247,6 +251,13 @@ __device__ __forceinline__ void poison_with(T &poison, const V (&v)[G]) {
     constexpr int VW = VecOf<T>::W;
     FOR_G FOR_I poison = M<T>::fma(v[g][i], T(0), poison);
 }
+// ... and, in the CERT variant of the flat-switch kernel, the running maximum of |tested value| (NaN is dropped by fmax: the poison has it)
+template <typename T, int G, typename V, bool CERT>
+__device__ __forceinline__ void test_with(T &poison, T &vmax, const V (&v)[G]) {
+    constexpr int VW = VecOf<T>::W;
+    poison_with<T, G, V>(poison, v);
+    if constexpr (CERT) { FOR_G FOR_I vmax = M<T>::abs(v[g][i]) > vmax ? M<T>::abs(v[g][i]) : vmax; }
+}
 
 // cos/sin/exp over the G*VW samples of a thread.  Float32 uses the fast versions of
 // de_device_ops.h with ONE divergent fix-up region for out-of-range arguments.
@@ -368,7 +379,7 @@ __device__ __noinline__ void flag_incomplete(uint8_t *ok, int agent) { // agent 
 
 // DIRECT = true: wide feature matrices whose X tile does not fit in LDS — feature operands are
 // gathered from global memory (L1/L2 absorb the re-reads), LDS holds only the spill rows.
-template <typename T, int G, int BLK, bool EE, bool PARAMS, bool DIRECT = false>
+template <typename T, int G, int BLK, bool EE, bool PARAMS, bool DIRECT = false, bool CERT = false>
 __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
     typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
@@ -438,6 +449,7 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
         V acc[G];
         FOR_G FOR_I acc[g][i] = T(0);
         T poison = T(0);
+        T vmax = T(0); // (CERT) largest |tested value| of this thread's samples
         U32x4 nxt = code[pc]; // scalar load; a tree has at least one instruction
         for (; pc < pe; ++pc) {
             const U32x4 w = nxt;
@@ -460,20 +472,20 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
     }
 #define BIN4(K, EXPR)                                                                                   \
     case BOP_BIN_BASE + 4 * K + 0: { V b[G]; LOAD_ROW(b, w.y) FOR_G FOR_I { const T x = acc[g][i], y = b[g][i]; acc[g][i] = (EXPR); } } break; \
-    case BOP_BIN_BASE + 4 * K + 1: { V b[G]; LOAD_ROW(b, w.y) FOR_G FOR_I { const T x = acc[g][i], y = b[g][i]; acc[g][i] = (EXPR); } poison_with<T, G, V>(poison, acc); } break; \
+    case BOP_BIN_BASE + 4 * K + 1: { V b[G]; LOAD_ROW(b, w.y) FOR_G FOR_I { const T x = acc[g][i], y = b[g][i]; acc[g][i] = (EXPR); } test_with<T, G, V, CERT>(poison, vmax, acc); } break; \
     case BOP_BIN_BASE + 4 * K + 2: { const T y = imm_of<T>(w.z, w.w); FOR_G FOR_I { const T x = acc[g][i]; acc[g][i] = (EXPR); } } break; \
-    case BOP_BIN_BASE + 4 * K + 3: { const T y = imm_of<T>(w.z, w.w); FOR_G FOR_I { const T x = acc[g][i]; acc[g][i] = (EXPR); } poison_with<T, G, V>(poison, acc); } break;
+    case BOP_BIN_BASE + 4 * K + 3: { const T y = imm_of<T>(w.z, w.w); FOR_G FOR_I { const T x = acc[g][i]; acc[g][i] = (EXPR); } test_with<T, G, V, CERT>(poison, vmax, acc); } break;
 #define UN4(K, CALL)                                                                                    \
     case BOP_UN_BASE + 4 * K + 0: { V x_[G]; FOR_G x_[g] = acc[g]; CALL; } break;                      \
-    case BOP_UN_BASE + 4 * K + 1: { V x_[G]; FOR_G x_[g] = acc[g]; CALL; poison_with<T, G, V>(poison, acc); } break; \
+    case BOP_UN_BASE + 4 * K + 1: { V x_[G]; FOR_G x_[g] = acc[g]; CALL; test_with<T, G, V, CERT>(poison, vmax, acc); } break; \
     case BOP_UN_BASE + 4 * K + 2: { V x_[G]; LOAD_ROW(x_, w.y) CALL; } break;                          \
-    case BOP_UN_BASE + 4 * K + 3: { V x_[G]; LOAD_ROW(x_, w.y) CALL; poison_with<T, G, V>(poison, acc); } break;
+    case BOP_UN_BASE + 4 * K + 3: { V x_[G]; LOAD_ROW(x_, w.y) CALL; test_with<T, G, V, CERT>(poison, vmax, acc); } break;
             switch (w.x) {
             case BOP_LOAD_ROW: LOAD_ROW(acc, w.y) break;
             case BOP_LOAD_CONST: { const T c = imm_of<T>(w.z, w.w); FOR_G FOR_I acc[g][i] = c; } break;
             case BOP_PUSH: { V *__restrict__ s_ = ROWP(w.y); FOR_G s_[g * BLK] = acc[g]; } break;
-            case BOP_CHECK_ROW: { V b[G]; LOAD_ROW(b, w.y) poison_with<T, G, V>(poison, b); } break;
-            case BOP_CHECK_ACC: poison_with<T, G, V>(poison, acc); break;
+            case BOP_CHECK_ROW: { V b[G]; LOAD_ROW(b, w.y) test_with<T, G, V, CERT>(poison, vmax, b); } break;
+            case BOP_CHECK_ACC: test_with<T, G, V, CERT>(poison, vmax, acc); break;
             BIN4(0, x + y)
             BIN4(1, x - y)
             BIN4(2, y - x)
@@ -515,7 +527,7 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
                     V b[G];
                     const T *__restrict__ s_ = a.params + (w.y & 0xFFFFu);
                     FOR_G FOR_I b[g][i] = s_[a.ld_params * cls[g][i]];
-                    if (EE && (w.y & (1u << 23))) poison_with<T, G, V>(poison, b);
+                    if (EE && (w.y & (1u << 23))) test_with<T, G, V, CERT>(poison, vmax, b);
                     if (op == DOP_LOAD) { FOR_G acc[g] = b[g]; }
                     else COLD_CALL(b)
                 }
@@ -524,6 +536,22 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
             }
         }
         // ---- store out[tree][...]: one 16-byte store per group, coalesced over the wave
+        if constexpr (CERT) {
+            // the largest |tested value| of the tree so far: wave maximum, one atomicMax per wave on the value's bits (non-negative
+            // floats order like unsigned integers); samples past N repeat the last real one, so they add nothing
+            typedef typename std::conditional<sizeof(T) == 4, unsigned int, unsigned long long>::type UB;
+            DE_UNROLL for (int m = 32; m >= 1; m >>= 1) {
+                const T o2 = __shfl_xor(vmax, m, 64);
+                vmax = o2 > vmax ? o2 : vmax;
+            }
+            if ((tid & 63) == 0 && vmax > T(0)) {
+                UB bits;
+                __builtin_memcpy(&bits, &vmax, sizeof bits);
+                atomicMax(reinterpret_cast<UB *>(a.cert_max) + tree, bits);
+            }
+            if (__ballot(poison != poison) != 0ull) flag_incomplete(a.ok + tree, a.skip_flagged == 1);
+            continue;
+        }
         T *__restrict__ o = a.out + (int64_t)tree * a.ld_out + base + tid * VW;
         if (full && a.vec_store) {
             FOR_G *reinterpret_cast<V *>(o + g * GT) = acc[g];
@@ -2072,7 +2100,14 @@ static hipError_t launch_eval_t(const EvalArgs &e, hipStream_t stream, const cha
     void (*kern)(const KArgs<T>);
     if (e.early_exit) kern = e.uses_params ? de_eval_tape_kernel<T, G, BLK, true, true> : de_eval_tape_kernel<T, G, BLK, true, false>;
     else kern = e.uses_params ? de_eval_tape_kernel<T, G, BLK, false, true> : de_eval_tape_kernel<T, G, BLK, false, false>;
-    if (kname) *kname = "de_eval_tape_kernel";
+    a.cert_max = e.cert_max;
+    if constexpr (G == 1 && BLK == 256) {
+        if (e.cert_max) { // the certificate pass (de_eval_sum_certificate): early-exit flag semantics, no output
+            if (!e.early_exit || e.direct) return hipErrorInvalidValue;
+            kern = e.uses_params ? de_eval_tape_kernel<T, 1, 256, true, true, false, true> : de_eval_tape_kernel<T, 1, 256, true, false, false, true>;
+        }
+    } else if (e.cert_max) return hipErrorInvalidValue;
+    if (kname) *kname = e.cert_max ? "de_eval_tape_kernel<cert>" : "de_eval_tape_kernel";
     size_t lds = (size_t)(a.F + a.n_slots) * ((size_t)BLK * G + 1) * 16;
     if constexpr (G == 1 && BLK == 256) {
         if (e.direct) {
@@ -2275,6 +2310,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.trees_per_chunk = tpc;
     a.n_chunks = nch;
     a.live_idx = a.ctrl = nullptr;
+    a.cert_max = nullptr;
     a.skip_flagged = (e.early_exit && e.skip_flagged && a.F + a.n_slots >= 1) ? 1 : 0;
     // Flag protocol (skip_flag_load, de_device_ops.h): 2 = through the caches + refresher tiles (default), 1 = agent scope for every access
     // The plain eval kernel writes 20+ GB per launch: flag lines leave the L1s / L2s all the time and protocol 2 is as good as 1 on the
@@ -2460,6 +2496,7 @@ hipError_t launch_dist_unpack(uint8_t *ok_global_dev, const uint8_t *recv, int64
 }
 
 hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const char **kernel_name) {
+    if (a.cert_max && !a.direct) return dtype == DE_F32 ? launch_eval_t<float, 1, 256>(a, stream, kernel_name) : launch_eval_t<double, 1, 256>(a, stream, kernel_name);
     if (a.direct) return dtype == DE_F32 ? launch_eval_t<float, 1, 256>(a, stream, kernel_name) : launch_eval_t<double, 1, 256>(a, stream, kernel_name);
     if (a.threaded) return dtype == DE_F32 ? launch_threaded_t<float>(a, stream, kernel_name) : launch_threaded_t<double>(a, stream, kernel_name);
     int G, BLK;

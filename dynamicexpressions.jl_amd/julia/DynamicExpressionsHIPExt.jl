@@ -443,6 +443,28 @@ function eval_population(pop::HIPPopulation{T}, X::Matrix{T}) where {T}
     return out, ok .!= 0x00
 end
 
+"""
+    population_sum_certificate(pop, X) -> (ok, certified, max_abs)
+
+`de_eval_sum_certificate`: the reference tests `isfinite(sum(x))` (src/ValueInterface.jl:9), the kernels every element; `certified[t]`
+says the two provably agree for tree t (some element non-finite, or `N * max|tested value|` below `floatmax(T)`).  Only the trees
+with `certified[t] == false` can carry a flag that differs from `eval_tree_array`'s — re-derive those on the CPU when the bit matters.
+"""
+function population_sum_certificate(pop::HIPPopulation{T}, X::Matrix{T}) where {T}
+    F, N = size(X)
+    @assert F >= pop.n_features
+    ok = Vector{UInt8}(undef, pop.n_trees)
+    cert = Vector{UInt8}(undef, pop.n_trees)
+    mx = Vector{Float64}(undef, pop.n_trees)
+    with_pop(pop) do hc, hp
+        check(pop.ctx, GC.@preserve X ok cert mx ccall(
+            (:de_eval_sum_certificate, LIBDE), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{UInt8}, Ptr{UInt8}, Ptr{Float64}),
+            hc, hp, X, N, F, C_NULL, ok, cert, mx))
+    end
+    return ok .!= 0x00, cert .!= 0x00, mx
+end
+
 struct ParamArgs            # de_param_args_t
     params::Ptr{Cvoid}
     ld_params::Int64

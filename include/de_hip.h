@@ -277,6 +277,17 @@ typedef struct de_param_args {
 int de_eval(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, int64_t ldX,
             const de_param_args_t *pargs, void *out, int64_t ld_out, uint8_t *ok);
 
+/* The `isfinite(sum(x))` quirk, certified (round 5).  The reference's validity test of an array is isfinite(sum(x))
+ * (src/ValueInterface.jl:9); the kernels test every element.  The two agree unless all elements are finite and the SUM overflows — values
+ * of ~floatmax / N.  This call evaluates the population once more through a certificate pass (every operator result tested, nothing stored)
+ * and reports per tree: ok[t] as de_eval would (host or device array), certified[t] (host) = 1 when the reference's `complete` provably
+ * equals ok[t] — some element is non-finite (its sum is too), or N * max|tested value or constant operand| stays below the largest finite
+ * value —, max_abs[t] (host doubles, may be NULL) = that maximum.  Trees with certified[t] == 0 are the only ones whose flag a caller who
+ * needs the reference's bit has to re-derive on the CPU.  Programs without DE_OPT_EARLY_EXIT sum nothing: all certified.  Slower than
+ * de_eval (the flat-switch kernel): a checker, not the hot path. */
+int de_eval_sum_certificate(de_ctx_t *ctx, de_program_t *prog, const void *X, int64_t N, int64_t ldX,
+                            const de_param_args_t *pargs, uint8_t *ok, uint8_t *certified, double *max_abs);
+
 /* Forward-mode gradient of every tree.  grad holds, for tree t, an
  * [n_grad_t, N] column-major matrix starting at element grad_offsets[t]
  * (host array of n_trees entries), or packed back to back when grad_offsets is

@@ -86,3 +86,69 @@ def test_program_verify_runs_on_the_programs_own_device(api):
     pop.verify()
     pop.close()
     ctx.close()
+
+
+def _flags_of_oracle(trees, ops, X, dtype):
+    from oracle import oracle
+    el, sm = [], []
+    for t in trees:
+        tape, consts = de.flatten(t, ops, dtype)
+        el.append(oracle.eval_tree_array(tape, consts, X, 7, elementwise=True)[1])
+        sm.append(oracle.eval_tree_array(tape, consts, X, 7, elementwise=False)[1])
+    return np.array(el), np.array(sm)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_sum_certificate_closes_the_isfinite_sum_quirk(api, dtype):
+    """src/ValueInterface.jl:9: the reference tests isfinite(sum(x)), the kernels every element.  de_eval_sum_certificate says for which
+    trees the two PROVABLY agree; on the others (finite elements, overflowing sum — constructed here) the caller re-derives the flag.
+    The oracle has both flavours."""
+    ops = de.OperatorEnum(binary_operators=("+", "-", "/", "*"), unary_operators=("cos", "exp"))
+    N = 4096
+    big = 3e34 if dtype == np.float32 else 1e305   # N * big overflows, big does not
+    x1, x2 = de.Node(feature=1), de.Node(feature=2)
+    mul, div, add = ops.index("*", 2), ops.index("/", 2), ops.index("+", 2)
+    cos = ops.index("cos", 1)
+    quirk_inner = de.Node(div, de.Node(mul, de.Node(add, x1, de.Node(val=2.5)), de.Node(val=big)), de.Node(val=big))  # ((x1 + 2.5) * big) / big: the inner product's SUM overflows
+    quirk_const = de.Node(mul, de.Node(cos, x1), de.Node(div, de.Node(val=1.0), de.Node(add, x2, de.Node(val=big))))  # a constant leaf array of N copies of `big` is summed
+    plain = de.synth.random_population(60, seed=0xC0DE, dtype=dtype)
+    trees = [quirk_inner, quirk_const] + plain
+    g = np.random.Generator(np.random.PCG64(3))
+    X = np.asfortranarray(np.abs(g.standard_normal((5, N))).astype(dtype) + dtype(0.5))
+    el, sm = _flags_of_oracle(trees, ops, X, dtype)
+    assert el[0] and not sm[0], "the constructed tree must show the quirk in the oracle itself"
+    pop = api.Population(trees, ops, dtype, n_features=5)
+    _, ok_eval = pop.eval(X)
+    ok, cert, mx = pop.sum_certificate(X)
+    assert np.array_equal(ok, np.asarray(ok_eval, dtype=bool)), "the certificate pass computes the flags de_eval computes"
+    assert np.array_equal(ok, el), "element-wise flags = the oracle's element-wise flavour"
+    assert not cert[0] and mx[0] >= big * 2.9, (cert[0], mx[0])       # not certified: the sum overflows although every element is finite
+    # soundness: wherever the certificate is given, the reference's flag (sum flavour) IS the device's
+    assert np.array_equal(ok[cert], sm[cert]), "certified trees must carry the reference's own flag"
+    # usefulness: ordinary trees are certified (all of the incomplete ones, and the complete ones far from floatmax / N)
+    assert cert[2:].mean() > 0.9, cert[2:].mean()
+    # a program without early_exit sums nothing
+    pop2 = api.Population(trees, ops, dtype, n_features=5, eval_context=api.EvalContext(early_exit=False))
+    _, c2, _ = pop2.sum_certificate(X)
+    assert c2.all()
+    pop.close(); pop2.close()
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e18, 1e33])
+def test_sum_certificate_is_sound_on_random_trees_near_the_overflow(api, scale):
+    """Soundness on data that DOES come near floatmax / N: wherever the certificate is given, the oracle's sum flavour equals the device flag
+    (300 random trees over X scaled into the 1e18 / 1e33 range, Float32)."""
+    dtype = np.float32
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(300, seed=0x5EED, dtype=dtype, node_count=12)
+    g = np.random.Generator(np.random.PCG64(int(np.log10(scale)) + 11))
+    X = np.asfortranarray((g.standard_normal((5, 3000)) * scale).astype(dtype))
+    el, sm = _flags_of_oracle(trees, ops, X, dtype)
+    pop = api.Population(trees, ops, dtype, n_features=5)
+    ok, cert, mx = pop.sum_certificate(X)
+    pop.close()
+    assert np.array_equal(ok, el)
+    assert np.array_equal(ok[cert], sm[cert])
+    print(f"[sum certificate, X scale {scale:g}] {int(cert.sum())} of {len(trees)} trees certified, {int((el != sm).sum())} show the quirk in the oracle, "
+          f"{int(((el != sm) & cert).sum())} of those certified (must be 0)")
+    assert not ((el != sm) & cert).any()
