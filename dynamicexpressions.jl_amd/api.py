@@ -38,7 +38,7 @@ LIB_PATH = os.environ.get("DE_HIP_LIB") or os.path.join(_HERE, "csrc", "libde_hi
 DE_F32, DE_F64 = 0, 1
 GRAD_VARIABLE, GRAD_CONSTANT, GRAD_BOTH = 0, 1, 2
 ABI_VERSION = 2  # DE_HIP_ABI_VERSION of include/de_hip.h this module was written for
-OPT_EARLY_EXIT, OPT_FUSE_DEG1, OPT_FUSE_DEG2, OPT_BUMPER_CHECKS, OPT_TURBO, OPT_FULL_EVAL = 1, 2, 4, 8, 16, 32
+OPT_EARLY_EXIT, OPT_FUSE_DEG1, OPT_FUSE_DEG2, OPT_BUMPER_CHECKS, OPT_TURBO, OPT_FULL_EVAL, OPT_FORWARD_GRAD = 1, 2, 4, 8, 16, 32, 64
 
 EXPORTS = [
     "de_abi_version", "de_opcode_table_version", "de_opcode_by_name", "de_opcode_name",
@@ -178,12 +178,13 @@ class EvalContext:
     buffer: object = None
     use_fused: bool = True
     full_eval: bool = False  # DE_OPT_FULL_EVAL: evaluate incomplete trees to the end as well (no early exit at tree granularity)
+    forward_grad: bool = False  # DE_OPT_FORWARD_GRAD: fused loss gradients always by forward duals (the reference's flag semantics exactly)
 
     def option_bits(self, operators: OperatorEnum) -> int:
         f1, f2 = operators.fuse_flags(self.use_fused)
         return ((OPT_EARLY_EXIT if self.early_exit else 0) | (OPT_FUSE_DEG1 if f1 else 0) |
                 (OPT_FUSE_DEG2 if f2 else 0) | (OPT_BUMPER_CHECKS if self.bumper else 0) | (OPT_TURBO if self.turbo else 0) |
-                (OPT_FULL_EVAL if self.full_eval else 0))
+                (OPT_FULL_EVAL if self.full_eval else 0) | (OPT_FORWARD_GRAD if self.forward_grad else 0))
 
 
 class Context:

@@ -32,8 +32,8 @@ const DE_ERR_UNSUPPORTED_OP = Cint(3)
 const DE_LEAF_CONST, DE_LEAF_FEATURE, DE_LEAF_PARAM, DE_LEAF_SHARED = UInt8(0), UInt8(1), UInt8(2), UInt8(3)
 const DE_OP_SHARE = UInt8(0xFE)   # include/de_opcodes.h: "the subtree just emitted is shared subtree `arg`"
 const DE_F32, DE_F64 = Cint(0), Cint(1)
-const DE_OPT_EARLY_EXIT, DE_OPT_FUSE_DEG1, DE_OPT_FUSE_DEG2, DE_OPT_BUMPER_CHECKS, DE_OPT_TURBO, DE_OPT_FULL_EVAL =
-    UInt32(1), UInt32(2), UInt32(4), UInt32(8), UInt32(16), UInt32(32)
+const DE_OPT_EARLY_EXIT, DE_OPT_FUSE_DEG1, DE_OPT_FUSE_DEG2, DE_OPT_BUMPER_CHECKS, DE_OPT_TURBO, DE_OPT_FULL_EVAL, DE_OPT_FORWARD_GRAD =
+    UInt32(1), UInt32(2), UInt32(4), UInt32(8), UInt32(16), UInt32(32), UInt32(64)
 # The ABI this file was written for (include/de_hip.h lists what changed between versions).  Version 2: the rows / gradients of a tree
 # with `complete == false` are NOT evaluated to the end (the reference's early exit, src/Evaluate.jl:26-32): with the host arrays this
 # shim passes, the library NaN-fills them; `full_eval=true` (DE_OPT_FULL_EVAL) evaluates every tree on every sample instead.
@@ -146,7 +146,7 @@ function opcode_table(operators::OperatorEnum)
 end
 
 """EvalContext knobs that change RESULTS -> de_options bits (src/Evaluate.jl:156-181,496,607)."""
-function option_bits(operators::OperatorEnum, ctx::EvalContext; full_eval::Bool=false)
+function option_bits(operators::OperatorEnum, ctx::EvalContext; full_eval::Bool=false, forward_grad::Bool=false)
     nops(d) = d <= length(operators.ops) ? length(operators.ops[d]) : 0
     fused = ctx.use_fused isa Val{true}
     bits = UInt32(0)
@@ -156,6 +156,7 @@ function option_bits(operators::OperatorEnum, ctx::EvalContext; full_eval::Bool=
     ctx.bumper isa Val{true} && (bits |= DE_OPT_BUMPER_CHECKS)
     ctx.turbo isa Val{true} && (bits |= DE_OPT_TURBO)   # the LoopVectorization knob = the relaxed-accuracy device operators
     full_eval && (bits |= DE_OPT_FULL_EVAL)             # no early exit at tree granularity: rows of incomplete trees are fully evaluated
+    forward_grad && (bits |= DE_OPT_FORWARD_GRAD)       # fused loss gradients by forward duals whatever the width: the reference's flag semantics exactly
     return bits
 end
 
@@ -366,7 +367,7 @@ function with_pop(f, pop::HIPPopulation)
 end
 function HIPPopulation(
     trees::AbstractVector{<:AbstractExpressionNode{T}}, operators::OperatorEnum, n_features::Integer;
-    eval_context::EvalContext=EvalContext(), n_params::Integer=0, full_eval::Bool=false,
+    eval_context::EvalContext=EvalContext(), n_params::Integer=0, full_eval::Bool=false, forward_grad::Bool=false,
 ) where {T<:Union{Float32,Float64}}
     optable = opcode_table(operators)
     nodes, consts, cse = TapeNode[], T[], TapeNode[]
@@ -397,7 +398,7 @@ function HIPPopulation(
             (Ptr{Cvoid}, Cint, Ptr{TapeNode}, Ptr{Int64}, Ptr{TapeNode}, Ptr{Int64}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int32, Int32,
              UInt32, Ref{Ptr{Cvoid}}),
             hc, dtype_code(T), nodes, node_off, isempty(cse) ? C_NULL : pointer(cse), cse_off, length(trees), consts,
-            const_off, n_features, n_params, option_bits(operators, eval_context; full_eval), h))
+            const_off, n_features, n_params, option_bits(operators, eval_context; full_eval, forward_grad), h))
     end
     pop = HIPPopulation{T}(ctx, h[], length(trees), n_features, occ, n_slots, n_consts)
     finalizer(finalize_population, pop)

@@ -128,6 +128,12 @@ enum de_options {
      * rows of an incomplete tree then hold the values the non-finite intermediates propagate to.  Same flags, same rows where
      * ok == 1; costs the evaluation of trees whose results nobody may read (55 % of the benchmark's random population). */
     DE_OPT_FULL_EVAL = 1u << 5,
+    /* de_eval_loss_grad / de_eval_loss_grad_by_class: always forward-mode duals, whatever the gradient width.  From 8 gradient rows per
+     * tree on the library otherwise picks reverse accumulation (two sweeps whatever the width), whose products are associated leaf-wards:
+     * entries agree with the forward Jacobian to rounding, but a product chain that overflows in ONE association only flips `ok` (~0.03 %
+     * of Float32 fuzz cases, never seen in Float64) — the reference (src/EvaluateDerivative.jl:230-243,340-365) is forward-mode.  This
+     * bit buys its flag semantics exactly, at the forward kernels' cost (C5 pullback: 44.6 against 30.2 ms in round 3). */
+    DE_OPT_FORWARD_GRAD = 1u << 6,
     DE_OPT_DEFAULT = (1u << 0) | (1u << 1) | (1u << 2)
 };
 

@@ -152,3 +152,34 @@ def test_sum_certificate_is_sound_on_random_trees_near_the_overflow(api, scale):
     print(f"[sum certificate, X scale {scale:g}] {int(cert.sum())} of {len(trees)} trees certified, {int((el != sm).sum())} show the quirk in the oracle, "
           f"{int(((el != sm) & cert).sum())} of those certified (must be 0)")
     assert not ((el != sm) & cert).any()
+
+
+def test_forward_grad_option_keeps_the_reference_forward_mode_flag_semantics(api):
+    """DE_OPT_FORWARD_GRAD: a population wide enough for reverse accumulation (>= 8 gradient rows per tree) runs forward duals — the
+    kernel of de_eval_loss_grad is the forward one and the results are bit for bit what the default population gives when reverse
+    accumulation is switched off (reverse accumulation associates the products leaf-wards and may flip `ok` where a product
+    chain overflows in one association only; the reference is forward-mode)."""
+    import os
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(60, seed=0xF0, node_count=45, max_depth=40)  # ~11 constants per tree: reverse by default
+    g = np.random.Generator(np.random.PCG64(9))
+    X = np.asfortranarray(g.standard_normal((5, 5000)).astype(np.float32))
+    y = g.standard_normal(5000).astype(np.float32)
+    pop_d = api.Population(trees, ops, np.float32, n_features=5)
+    pop_d.eval_loss_grad(X, y)
+    assert pop_d.ctx.last_kernel_name() == "de_rev_threaded_kernel", pop_d.ctx.last_kernel_name()
+    pop_f = api.Population(trees, ops, np.float32, n_features=5, eval_context=api.EvalContext(forward_grad=True))
+    lf, df, okf = pop_f.eval_loss_grad(X, y)
+    assert pop_f.ctx.last_kernel_name() != "de_rev_threaded_kernel", pop_f.ctx.last_kernel_name()
+    os.environ["DE_LOSS_GRAD_REVERSE"] = "0"
+    try:
+        pop_0 = api.Population(trees, ops, np.float32, n_features=5)
+        l0, d0, ok0 = pop_0.eval_loss_grad(X, y)
+    finally:
+        del os.environ["DE_LOSS_GRAD_REVERSE"]
+    assert np.array_equal(np.asarray(okf), np.asarray(ok0))
+    assert np.array_equal(np.asarray(lf).view(np.uint32), np.asarray(l0).view(np.uint32))
+    for a, b in zip(df, d0):
+        assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+    for p in (pop_d, pop_f, pop_0):
+        p.close()
