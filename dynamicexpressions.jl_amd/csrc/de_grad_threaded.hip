@@ -398,6 +398,16 @@ __device__ __noinline__ void g_epilogue_loss(GState<T, GC> st, const T *y, const
         }
     }
 }
+// The Jacobian block and the values are written once and never read by the kernel: non-temporal stores (round 5: the eval kernel's output
+// stream gained 2 % from them; -DDE_GRAD_NT_STORE=0 for the A/B)
+#ifndef DE_GRAD_NT_STORE
+#define DE_GRAD_NT_STORE 1
+#endif
+#if DE_GRAD_NT_STORE
+#define DE_G_STORE(PTR, VAL) __builtin_nontemporal_store((VAL), (PTR))
+#else
+#define DE_G_STORE(PTR, VAL) (*(PTR) = (VAL))
+#endif
 template <typename T, int GC>
 __device__ __noinline__ void g_epilogue_store(GState<T, GC> st, T *out_row, T *grad_tree, int64_t N, int G, int g0, int64_t tile, uint32_t stage0) {
     constexpr int TILE = GBLK * VS, WSAMP = 64 * VS;
@@ -410,7 +420,7 @@ __device__ __noinline__ void g_epilogue_store(GState<T, GC> st, T *out_row, T *g
         // would each touch 4 of every 4*G*VS bytes.
         DE_UNROLL for (int i = 0; i < VS; i++) {
             const int64_t j = base + (int64_t)tid * VS + i;
-            if (j <= last && out_row) out_row[j] = st.x[i];
+            if (j <= last && out_row) DE_G_STORE(out_row + j, (T)st.x[i]);
         }
         const int64_t j0 = base + (int64_t)wave * WSAMP;         // first sample of this wave
         const int64_t n_valid = N - j0 < WSAMP ? N - j0 : WSAMP; // samples of this wave inside N (may be <= 0)
@@ -426,7 +436,7 @@ __device__ __noinline__ void g_epilogue_store(GState<T, GC> st, T *out_row, T *g
             for (int e = lane * PER16; e < total; e += 64 * PER16) {
                 typedef T V16 __attribute__((ext_vector_type(PER16)));
                 const V16 v = *reinterpret_cast<__attribute__((address_space(3))) V16 *>((uintptr_t)(stage0 + (uint32_t)(e * sizeof(T))));
-                if (aligned && e + PER16 <= total) *reinterpret_cast<V16 *>(gdst + e) = v;
+                if (aligned && e + PER16 <= total) DE_G_STORE(reinterpret_cast<V16 *>(gdst + e), v);
                 else { DE_UNROLL for (int q = 0; q < PER16; q++) if (e + q < total) gdst[e + q] = v[q]; }
             }
             __builtin_amdgcn_wave_barrier();

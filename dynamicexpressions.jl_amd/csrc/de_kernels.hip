@@ -795,6 +795,16 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS)
         if (left_now <= 1u) return st;                                                                       \
         [[clang::musttail]] return h_tree_skip<T>(st, HL_PASS_C lds0, HDR, outp, la, w1, w23, okp, ldo, skip >> 1, left_now - 1u, flags); \
     }
+// the output store of a tree's fast end: 16 bytes per lane, 1 KiB contiguous per wavefront.  -DDE_NT_STORE=1 (an A/B switch): non-temporal
+// (the 40 GB output stream of the headline is written once and never read by the kernel)
+#ifndef DE_NT_STORE
+#define DE_NT_STORE 1
+#endif
+#if DE_NT_STORE
+#define DE_OUT_STORE(VT, PTR, VAL) __builtin_nontemporal_store((VAL), reinterpret_cast<__attribute__((address_space(1))) VT *>(PTR))
+#else
+#define DE_OUT_STORE(VT, PTR, VAL) (*reinterpret_cast<__attribute__((address_space(1))) VT *>(PTR) = (VAL))
+#endif
 typedef __attribute__((address_space(1))) char *GPtr; // global, not flat: a flat store also ties up lgkmcnt
 // The other ends of a tree (flags & HF_SLOW), out of line so that h_tree_end itself is straight-line code: HF_LOSS (fused loss:
 // the tree's loss partial of this tile), HF_SLOW_STORE (ragged last tile / output rows that are not 16-byte aligned; LDS base = 0:
@@ -851,7 +861,7 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_end(HCHAIN_ARGS) 
     const U32x4 w = *code;
     const uint32_t tree = la; // this IS the end record
     const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * (uint64_t)(uint32_t)ldo); // wave-uniform: the store takes it as its scalar base
-    FOR_PLANES *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0 + (uint32_t)g * DE_PLANE_BYTES) = st.acc[g]; // full tile, aligned rows
+    FOR_PLANES DE_OUT_STORE(V, row + lds0 + (uint32_t)g * DE_PLANE_BYTES, st.acc[g]); // full tile, aligned rows
     HTREE_END_TAIL(w, code_at(code, 1), code_at(code, -1));
 }
 // The last instruction of a tree and its end in one dispatch (make_chained picks it when the tree finishes in a validity-tested
@@ -868,7 +878,7 @@ template <typename T, BodyFn<T> BODY> __device__ __noinline__ HState<T> h_chain_
     const U32x4 w = code[1];
     planes_apply<T, BODY>(st, lds0 + la, arg_imm<T>(w1, w23));
     const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * (uint64_t)(uint32_t)ldo);
-    FOR_PLANES *reinterpret_cast<__attribute__((address_space(1))) V *>(row + lds0 + (uint32_t)g * DE_PLANE_BYTES) = st.acc[g];
+    FOR_PLANES DE_OUT_STORE(V, row + lds0 + (uint32_t)g * DE_PLANE_BYTES, st.acc[g]);
     HTREE_END_TAIL(w, code_at(code, 2), code);
 }
 
@@ -1224,7 +1234,7 @@ template <int K, bool TB, int G> __device__ __forceinline__ void un_finish_plane
         const U32x4 wn = code[1];                                                                                           \
         const uint32_t tree = *reinterpret_cast<const DE_CONSTANT uint32_t *>(code); /* the end record's operand word */      \
         const GPtr row = reinterpret_cast<GPtr>(outp + (uint64_t)tree * (uint64_t)(uint32_t)ldo);                                               \
-        FOR_PLANES *reinterpret_cast<__attribute__((address_space(1))) VecOf<float>::type *>(row + lds0 + (uint32_t)g * DE_PLANE_BYTES) = st.acc[g]; \
+        FOR_PLANES DE_OUT_STORE(VecOf<float>::type, row + lds0 + (uint32_t)g * DE_PLANE_BYTES, st.acc[g]); \
         HTREE_END_TAIL(wn, code_at(code, 2), code);                                                                                     \
     }
 #define PLANE_ADDR(A, g) ((A) + (uint32_t)(g) * DE_PLANE_BYTES)

@@ -467,6 +467,10 @@ int lower_tree(const de_tape_node_t *tape, int64_t n, int64_t n_consts, const Lo
     for (int64_t k = 0; k < n_consts; k++) // (CSE tapes reference a subset of the slots)
         if (out->const_instr[(size_t)k] == -2) out->const_instr[(size_t)k] = -1;
     int root = stack[0];
+    // every shared definition must be READ somewhere: a DE_OP_SHARE whose subtree no DE_LEAF_SHARED names would give a
+    // persistent row without a reader, and the reverse sweep's `acc += adjoint of the row` (ROP_R_POPADD) would add a row nothing wrote
+    if (opt.cse && n_shared_defs > 0 && (L.nodes[(size_t)root].uses & ((1u << n_shared_defs) - 1u)) != ((1u << n_shared_defs) - 1u))
+        return fail(DE_ERR_BAD_TAPE, "DE_OP_SHARE definition that no DE_LEAF_SHARED references");
 
     if (opt.bumper) {
         L.annotate_bumper(root);

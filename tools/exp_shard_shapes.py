@@ -72,4 +72,34 @@ for name, popu, world in cases:
     row["us_per_complete_tree"] = 1e3 * row["ms_default"] / max(row["complete"], 1)
     res["shapes"].append(row)
     print(json.dumps(row), file=sys.stderr, flush=True)
+# ---- the exchange of a step, as far as one GPU can run it (round 5; UNMEASURED on a multi-GPU node) -------------------------------
+# (a) the pack + unpack launches of de_dist_gather_flags for a simulated world (de_dist_reorder_selftest: device time of ONE rank's
+#     share, no collective); (b) the world-size-1 gather through the C ABI, wall clock around call + synchronise (a device copy).
+import ctypes as C  # noqa: E402
+import time  # noqa: E402
+lib = api.library()
+ex = []
+for n_trees, world in ((1000, 2), (1000, 4), (1000, 8), (10000, 8)):
+    flags = (np.arange(n_trees) % 3 != 0).astype(np.uint8)
+    outf = np.zeros(n_trees, dtype=np.uint8)
+    ms = C.c_float(0)
+    best = 1e9
+    for _ in range(5):
+        ctx.check(lib.de_dist_reorder_selftest(ctx._h, flags.ctypes.data, n_trees, world, outf.ctypes.data, C.byref(ms)))
+        best = min(best, float(ms.value))
+    assert np.array_equal(outf, flags)
+    ex.append(dict(n_trees=n_trees, world=world, pack_plus_unpack_us=1e3 * best))
+comm = dedist.Comm(ctx, 0, 1, b"")
+okd = torch.ones(1000, device=dev, dtype=torch.uint8)
+for _ in range(3):
+    comm.gather_flags(okd, 1000)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50):
+    comm.gather_flags(okd, 1000)
+torch.cuda.synchronize()
+res["exchange"] = dict(note="pack + unpack = the library's own launches around ncclAllGather (3 stream operations per exchange since round 5, 11 before at 8 ranks); "
+                            "the collective itself (1000 bytes per rank, latency-bound over xGMI) is NOT in these numbers: no multi-GPU node",
+                       simulated_world=ex, world_size_1_gather_us_per_call=1e6 * (time.perf_counter() - t0) / 50)
+comm.close()
 print(json.dumps(res, indent=1))
