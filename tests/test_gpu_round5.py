@@ -183,3 +183,27 @@ def test_forward_grad_option_keeps_the_reference_forward_mode_flag_semantics(api
         assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
     for p in (pop_d, pop_f, pop_0):
         p.close()
+
+
+def test_tail_split_changes_nothing_but_the_order(api, monkeypatch):
+    """The last chunk of a small launch runs as four short sub-chunks (csrc/de_kernels.hip `tail_split`): which workgroup evaluates which
+    trees — rows and flags are bit for bit those of the unsplit launch, with and without the early exit, on a ragged last tile."""
+    import torch
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(200, seed=0x7A11)
+    N = 40_003
+    X = torch.from_numpy(np.ascontiguousarray(de.synth.random_X(5, N, seed=5).T)).cuda().t()
+    res = {}
+    for split in ("1", "4", "7"):
+        monkeypatch.setenv("DE_TAIL_SPLIT", split)
+        for full in (False, True):
+            pop = api.Population(trees, ops, np.float32, n_features=5, eval_context=api.EvalContext(full_eval=full))
+            out, ok = pop.eval(X)
+            torch.cuda.synchronize()
+            res[(split, full)] = (out.cpu().numpy(), ok.cpu().numpy())
+            pop.close()
+    ref_o, ref_k = res[("1", True)]
+    assert ref_k.any() and not ref_k.all()
+    for key, (o, k) in res.items():
+        assert np.array_equal(k, ref_k), key
+        assert np.array_equal(o[ref_k].view(np.uint32), ref_o[ref_k].view(np.uint32)), key
