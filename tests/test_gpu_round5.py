@@ -207,3 +207,23 @@ def test_tail_split_changes_nothing_but_the_order(api, monkeypatch):
     for key, (o, k) in res.items():
         assert np.array_equal(k, ref_k), key
         assert np.array_equal(o[ref_k].view(np.uint32), ref_o[ref_k].view(np.uint32)), key
+
+
+def test_sum_certificate_on_a_parametric_population_and_device_inputs(api):
+    """The certificate pass takes what de_eval takes: a ParametricExpression population (parameters staged as rows), X on the device, a ragged
+    sample count; its flags are de_eval's."""
+    import torch
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(80, seed=0xDE05, node_type=de.ParametricNode, nparams=8, dtype=np.float32)
+    g = np.random.Generator(np.random.PCG64(21))
+    N, C = 3001, 16
+    X = torch.from_numpy(np.ascontiguousarray(g.standard_normal((N, 5)).astype(np.float32))).cuda().t()
+    params = torch.from_numpy(np.ascontiguousarray(g.standard_normal((C, 8)).astype(np.float32))).cuda().t()
+    classes = torch.from_numpy(g.integers(1, C + 1, N).astype(np.int32)).cuda()
+    pop = api.Population(trees, ops, np.float32, n_features=5, n_params=8)
+    _, ok_eval = pop.eval(X, params, classes)
+    ok, cert, mx = pop.sum_certificate(X, params, classes)
+    torch.cuda.synchronize()
+    assert np.array_equal(ok, ok_eval.cpu().numpy().astype(bool))
+    assert cert[~ok].all() and cert.mean() > 0.9 and np.isfinite(mx[ok]).all()
+    pop.close()
