@@ -17,7 +17,7 @@ import fuzzlib as FZ
 pytestmark = pytest.mark.gpu
 
 # Caps = what was OBSERVED, with a factor of two, not a free allowance (round 5's run of the gate,
-# profiles/r5_pytest_gpu.log: the largest ill-conditioned share of any flavour is 1.13 % (mixed arity), and NO flag differs anywhere):
+# profiles/r5_pytest_gpu_8ulp.log: the largest ill-conditioned share of any flavour is 1.13 % (mixed arity), and NO flag differs anywhere):
 ILL_VALUE_CAP = {"hot": 0.015, "wide": 0.025}  # share of compared samples / entries the model may class as ill-conditioned (0.05 / 0.20 until round 4)
 ILL_FLAG_CAP_ABS = 2                           # trees whose FLAG differs through an ill-conditioned sample, per gate (3 % of the trees until round 4; observed: 0)
 

@@ -227,3 +227,29 @@ def test_sum_certificate_on_a_parametric_population_and_device_inputs(api):
     assert np.array_equal(ok, ok_eval.cpu().numpy().astype(bool))
     assert cert[~ok].all() and cert.mean() > 0.9 and np.isfinite(mx[ok]).all()
     pop.close()
+
+
+def test_a_share_definition_nobody_references_is_a_bad_tape(api):
+    """a DE_OP_SHARE whose subtree no DE_LEAF_SHARED names would leave a persistent row without a reader (the reverse sweep's
+    POPADD would add a row nothing wrote): the lowering refuses the tape; the same tape WITH its reference is accepted."""
+    import ctypes as C
+    from dynamicexpressions_jl_amd.node import TAPE_DTYPE, LEAF_FEATURE, LEAF_SHARED, OP_SHARE
+    lib, ctx = api.library(), api.Context(0)
+    cos = lib.de_opcode_by_name(b"cos", 1)
+    add = lib.de_opcode_by_name(b"+", 2)
+    expanded = np.array([(0, LEAF_FEATURE, 0), (1, cos, 0), (0, LEAF_FEATURE, 0), (1, cos, 0), (2, add, 0)], dtype=TAPE_DTYPE)  # cos(x1) + cos(x1)
+    good = np.array([(0, LEAF_FEATURE, 0), (1, cos, 0), (1, OP_SHARE, 0), (0, LEAF_SHARED, 0), (2, add, 0)], dtype=TAPE_DTYPE)
+    bad = np.array([(0, LEAF_FEATURE, 0), (1, cos, 0), (1, OP_SHARE, 0), (0, LEAF_FEATURE, 0), (1, cos, 0), (2, add, 0)], dtype=TAPE_DTYPE)  # defined, never read
+    noff = np.array([0, len(expanded)], dtype=np.int64)
+    coff = np.zeros(2, dtype=np.int64)
+    for cse, want_ok in ((good, True), (bad, False)):
+        cse_off = np.array([0, len(cse)], dtype=np.int64)
+        h = C.c_void_p()
+        rc = lib.de_program_create_cse(ctx._h, 0, expanded.ctypes.data, noff.ctypes.data, cse.ctypes.data, cse_off.ctypes.data, 1, None, coff.ctypes.data,
+                                       1, 0, 7, C.byref(h))
+        assert (rc == 0) == want_ok, (rc, lib.de_last_error(ctx._h))
+        if rc == 0:
+            lib.de_program_destroy(h)
+        else:
+            assert b"DE_OP_SHARE" in lib.de_last_error(ctx._h)
+    ctx.close()
