@@ -153,6 +153,7 @@ int de_dist_broadcast(de_comm_t *c, void *buf, size_t bytes, int root) {
     if (!c || (!buf && bytes) || root < 0 || root >= c->world) return DE_ERR_INVALID_ARG;
     if (c->world == 1 || bytes == 0) return DE_OK;
     hipStream_t stream = static_cast<hipStream_t>(de_ctx_stream(c->ctx));
+    if (hipSetDevice(de_ctx_device(c->ctx)) != hipSuccess) return dfail(c, DE_ERR_HIP, "de_dist_broadcast: cannot select the context's device");
     const int rc = g_rccl.Broadcast(buf, buf, bytes, kNcclUint8, root, c->comm, stream);
     if (rc != 0) return dfail(c, DE_ERR_RCCL, "ncclBroadcast: %s", g_rccl.GetErrorString(rc));
     return DE_OK;
@@ -169,6 +170,7 @@ int de_dist_gather_flags(de_comm_t *c, const uint8_t *ok_local, int64_t n_trees,
         hipError_t st_ = (expr);                                                                        \
         if (st_ != hipSuccess) return dfail(c, DE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(st_));  \
     } while (0)
+    HIPD(hipSetDevice(de_ctx_device(c->ctx))); // (the launches below go to the CURRENT device: make it the context's, as every de_eval* does)
     if (c->world == 1) {
         HIPD(hipMemcpyAsync(ok_global, ok_local, (size_t)n_trees, hipMemcpyDefault, stream));
         return DE_OK;
