@@ -637,6 +637,26 @@ def main():
         declared_res = dict(ms_per_step=1e3 * (time.perf_counter() - t0d) / args.steps, flags_equal=bool(torch.equal(ok, ok_main)))
         ctx.declare_dataset(None)
 
+    torchx_res = None
+    if (world == 1 and args.workload == "headline" and not args.no_complete_leg and not args.turbo
+            and os.environ.get("DE_BENCH_TORCH_X", "0") != "1"):
+        # THE SAME STEPS ON THE X OF ROUNDS 1-4 (torch.randn on the device, seed 1): the round-over-round comparable number.  That
+        # generator plants exact zeros (x / 0: more incomplete trees), so its headline is not this line's `value`; see config.X.
+        gx = torch.Generator(device=dev).manual_seed(1)
+        X_keep = X
+        X = torch.randn((N, 5), generator=gx, device=dev, dtype=torch.float32).t()
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0x = time.perf_counter()
+        for _ in range(args.steps):
+            fx = step()
+        barrier()
+        torchx_res = dict(ms_per_step=1e3 * (time.perf_counter() - t0x) / args.steps, complete_fraction=float(fx.float().mean().item()))
+        X = X_keep
+        del X_keep
+        ok.copy_(ok_main)  # (`flags` of the timed steps aliases this buffer at N = 1)
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_nodes * N * args.steps / elapsed
@@ -771,6 +791,11 @@ def main():
             res["dataset_declared"] = {"option": "de_ctx_declare_dataset(X) before the steps: the per-call pass over X (priority-tile keys) is done once per dataset",
                                        "ms_per_step": declared_res["ms_per_step"], "value": total_nodes * N / (declared_res["ms_per_step"] * 1e-3),
                                        "flags_equal_to_headline": declared_res["flags_equal"]}
+        if torchx_res is not None:
+            res["rounds_1_4_x"] = {"option": "the same steps on the X of rounds 1-4 (torch.randn on the device, seed 1; it plants exact zeros, profiles/r5_x_generators.txt): "
+                                             "compare THIS with BENCH_r01..r04's ms_per_step",
+                                   "ms_per_step": torchx_res["ms_per_step"], "value": total_nodes * N / (torchx_res["ms_per_step"] * 1e-3),
+                                   "complete_fraction": torchx_res["complete_fraction"]}
         if full_res is not None:
             res["full_evaluation"] = {"option": "DE_OPT_FULL_EVAL: no early exit, every tree evaluated on every sample (rounds 1-2 timed this)",
                                       "ms_per_step": full_res["ms_per_step"], "kernel_ms_last": full_res["kernel_ms"],
