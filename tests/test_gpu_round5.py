@@ -253,3 +253,32 @@ def test_a_share_definition_nobody_references_is_a_bad_tape(api):
         else:
             assert b"DE_OP_SHARE" in lib.de_last_error(ctx._h)
     ctx.close()
+
+
+def test_contexts_on_two_devices_with_the_other_device_current(api):
+    """ABI version 2 (d): one process may hold contexts on several GPUs; handler addresses belong to ONE device's copy of the code object.
+    Needs two devices (the round's boxes have one: skipped there) — verify, eval and gradient of a program on device d with device 1 - d
+    current."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one device visible")
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(40, seed=11)
+    Xh = de.synth.random_X(5, 3000, seed=2)
+    ref = None
+    for d in (0, 1):
+        ctx = api.Context(d)
+        pop = api.Population(trees, ops, np.float32, n_features=5, ctx=ctx)
+        torch.cuda.set_device(1 - d)
+        pop.verify()
+        out, ok = pop.eval(Xh)
+        _, grads, okg = pop.eval_grad(Xh, variable=True)
+        res = (np.asarray(out), np.asarray(ok), [np.asarray(g) for g in grads])
+        if ref is None:
+            ref = res
+        else:
+            assert np.array_equal(res[1], ref[1])
+            assert np.array_equal(res[0][ref[1]].view(np.uint32), ref[0][ref[1]].view(np.uint32))
+        pop.close()
+        ctx.close()
+    torch.cuda.set_device(0)
