@@ -162,3 +162,64 @@ def test_every_population_entry_point_takes_the_context_lock():
             before = body[:m.start()]
             locked = ("with_ctx(" in before or "with_pop(" in before or "trylock(" in before or fn.group(1) in ("check", "grad_widths"))
             assert locked, f"{fn.group(1)}: ccall(:{m.group(1)}) outside the context's lock"
+
+
+# ---- a block-balance check: what a parser would refuse first ------------------------------------------------------------------------
+OPENERS = {"function", "if", "for", "while", "try", "let", "begin", "struct", "module", "do", "quote", "macro"}
+
+
+def _julia_tokens(src):
+    """(token, bracket depth) of the identifiers / keywords outside strings, characters and comments; brackets tracked on the way."""
+    i, n, depth = 0, len(src), 0
+    while i < n:
+        ch = src[i]
+        if ch == "#":
+            if src.startswith("#=", i):
+                i = src.index("=#", i) + 2
+            else:
+                while i < n and src[i] != "\n":
+                    i += 1
+        elif src.startswith('"""', i):
+            i = src.index('"""', i + 3) + 3
+        elif ch == '"':
+            i += 1
+            while src[i] != '"':
+                i += 2 if src[i] == "\\" else 1
+            i += 1
+        elif ch == "'" and i + 2 < n and (src[i + 2] == "'" or (src[i + 1] == "\\" and src[i + 3] == "'")):
+            i += 3 if src[i + 2] == "'" else 4  # a character literal (not the adjoint operator)
+        elif ch in "([{":
+            depth += 1
+            i += 1
+        elif ch in ")]}":
+            depth -= 1
+            i += 1
+        elif ch.isalpha() or ch == "_" or ch == "@":
+            j = i + 1
+            while j < n and (src[j].isalnum() or src[j] in "_!"):
+                j += 1
+            yield src[i:j], depth, (src[i - 1] if i else "\n")
+            i = j
+        else:
+            i += 1
+    assert depth == 0, "unbalanced brackets"
+
+
+@pytest.mark.parametrize("path", [p for p in JULIA if not p.endswith("golden_cases.jl")], ids=lambda p: os.path.basename(p))
+def test_julia_blocks_balance(path):
+    """Every block opener outside brackets has its `end` (comprehensions / generators live inside brackets and have none; `a[end]` is an
+    index): the first thing a parser would refuse.  The build image has no Julia; this keeps an edit from leaving a block open."""
+    opened = closed = 0
+    stack = []
+    for tok, depth, prev in _julia_tokens(open(path).read()):
+        if depth:
+            continue
+        if tok in OPENERS and prev != ":" and prev != ".":  # (:if / x.begin are not keywords)
+            opened += 1
+            stack.append(tok)
+        elif tok == "end":
+            closed += 1
+            assert stack, f"{os.path.basename(path)}: `end` without an open block"
+            stack.pop()
+    assert not stack, f"{os.path.basename(path)}: unclosed block(s): {stack[-3:]}"
+    assert opened == closed and opened > 20
