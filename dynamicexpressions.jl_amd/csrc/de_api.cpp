@@ -7,10 +7,14 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <new>
 #include <string>
+#include <algorithm>
 #include <array>
 #include <atomic>
 #include <thread>
@@ -238,48 +242,106 @@ static const OpName kOps[] = {
 };
 
 // Host-side lowering is ~3 us per tree and per pass; populations of 10^4..10^5 trees are re-created every
-// generation by a search loop, so the per-tree passes run on a few host threads.
-template <class F> static void parallel_for_trees(int64_t n, F f) {
-    unsigned hw = std::thread::hardware_concurrency();
-    const char *env = getenv("DE_HOST_THREADS");
-    unsigned nt = env && *env ? (unsigned)atoi(env) : std::min(hw ? hw : 1u, 16u);
-    if ((int64_t)nt > n / 256) nt = (unsigned)(n / 256);
-    if (nt <= 1) {
-        for (int64_t i = 0; i < n; i++) f(i);
-        return;
+// generation by a search loop, so EVERY per-tree pass of de_program_create runs on a few host threads (round 5: the serial passes behind
+// the lowering — merge, bind, superinstructions, record chaining — were 80 % of a creation).  One persistent pool per process (spawning
+// 16 threads costs ~0.3 ms, a creation has ~10 parallel regions); one region at a time — a second context asking meanwhile runs its
+// ranges inline, in the same partition, so the result never depends on who ran it.  DE_HOST_THREADS=n caps the workers (1 = serial).
+namespace {
+struct HostPool {
+    std::mutex region;                 // held for the duration of a parallel region
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int)> *job = nullptr;
+    int n_jobs = 0, pending = 0;
+    uint64_t gen = 0;
+    bool failed = false;
+    int n_workers = 0;
+    void worker(int id) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)> *j = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return gen != seen; });
+                seen = gen;
+                if (id + 1 < n_jobs) j = job;
+            }
+            if (!j) continue;
+            bool bad = false;
+            try { (*j)(id + 1); } catch (...) { bad = true; }
+            {
+                const std::lock_guard<std::mutex> lk(m);
+                failed = failed || bad;
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
     }
-    std::vector<std::thread> th;
-    th.reserve(nt);
-    const int64_t per = (n + nt - 1) / nt;
-    for (unsigned k = 0; k < nt; k++) {
-        const int64_t b = (int64_t)k * per, e = std::min<int64_t>(n, b + per);
-        if (b >= e) break;
-        th.emplace_back([=] { for (int64_t i = b; i < e; i++) f(i); });
+    void ensure(int want) { // (under `region`)
+        while (n_workers < want) {
+            const int id = n_workers;
+            try { std::thread([this, id] { worker(id); }).detach(); } catch (...) { return; }
+            n_workers++;
+        }
     }
-    for (auto &t : th) t.join();
-}
-
-// The same split as parallel_for_trees, handing every worker its contiguous range [b, e) and its index k < 16:
-// for passes that append to a per-worker vector which is concatenated afterwards.
-template <class F> static void parallel_tree_ranges(int64_t n, F f) {
-    unsigned hw = std::thread::hardware_concurrency();
+    // job(k) for k = 0 .. n - 1, job(0) on the calling thread; false = the pool is busy or could not start threads: nothing was run
+    bool run(int n, const std::function<void(int)> &f) {
+        std::unique_lock<std::mutex> rl(region, std::try_to_lock);
+        if (!rl.owns_lock()) return false;
+        ensure(n - 1);
+        if (n_workers < n - 1) return false;
+        {
+            const std::lock_guard<std::mutex> lk(m);
+            job = &f;
+            n_jobs = n;
+            pending = n - 1;
+            failed = false;
+            gen++;
+        }
+        cv_work.notify_all();
+        bool bad = false;
+        try { f(0); } catch (...) { bad = true; }
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return pending == 0; });
+            job = nullptr;
+            n_jobs = 0;
+            bad = bad || failed;
+        }
+        if (bad) throw std::bad_alloc(); // (the passes only ever throw for memory)
+        return true;
+    }
+};
+HostPool &host_pool() { static HostPool *p = new HostPool(); return *p; } // (never destroyed: its threads are detached)
+unsigned host_threads_for(int64_t n) {
+    const unsigned hw = std::thread::hardware_concurrency();
     const char *env = getenv("DE_HOST_THREADS");
     unsigned nt = env && *env ? (unsigned)atoi(env) : std::min(hw ? hw : 1u, 16u);
     nt = std::min(nt, 16u);
-    if ((int64_t)nt > n / 256) nt = (unsigned)(n / 256);
+    static const int64_t min_trees = [] { const char *v = getenv("DE_HOST_MIN_TREES"); const int64_t m = v && *v ? atoll(v) : 32; return m < 1 ? 1 : m; }();
+    if ((int64_t)nt > n / min_trees) nt = (unsigned)(n / min_trees); // (a woken pool thread costs ~10 us, 32 trees are ~50 us of a pass: 10^3 trees 2.3 -> 1.4 ms against a floor of 256)
+    return nt;
+}
+} // namespace
+
+// The trees in contiguous ranges, one per worker: f(k, b, e) with k < 16 — for passes that append to a per-worker vector which is
+// concatenated afterwards, or that write disjoint slices of pre-sized vectors.  The partition depends on n and the thread count only.
+template <class F> static void parallel_tree_ranges(int64_t n, F f) {
+    const unsigned nt = host_threads_for(n);
     if (nt <= 1) {
         f(0, (int64_t)0, n);
         return;
     }
-    std::vector<std::thread> th;
-    th.reserve(nt);
     const int64_t per = (n + nt - 1) / nt;
-    for (unsigned k = 0; k < nt; k++) {
+    const int n_ranges = (int)((n + per - 1) / per);
+    const std::function<void(int)> job = [&](int k) {
         const int64_t b = (int64_t)k * per, e = std::min<int64_t>(n, b + per);
-        if (b >= e) break;
-        th.emplace_back([=] { f((int)k, b, e); });
-    }
-    for (auto &t : th) t.join();
+        if (b < e) f(k, b, e);
+    };
+    if (!host_pool().run(n_ranges, job))
+        for (int k = 0; k < n_ranges; k++) job(k);
+}
+template <class F> static void parallel_for_trees(int64_t n, F f) {
+    parallel_tree_ranges(n, [&](int, int64_t b, int64_t e) { for (int64_t i = b; i < e; i++) f(i); });
 }
 
 // Pair the constant-carrying instructions of a generic program with those of a derived (bound / fused)
@@ -288,19 +350,50 @@ template <class Derived, class Pred>
 static bool match_const_sites(const std::vector<Instr> &src, const std::vector<int32_t> &src_off, const std::vector<Derived> &dst,
                               const std::vector<int32_t> &dst_off, int64_t n_trees, Pred carries, std::vector<int32_t> *site) {
     site->assign(src.size(), -1);
-    for (int64_t t = 0; t < n_trees; t++) {
-        int32_t j = dst_off[(size_t)t];
-        const int32_t j1 = dst_off[(size_t)t + 1];
-        for (int32_t i = src_off[(size_t)t]; i < src_off[(size_t)t + 1]; i++) {
-            if (((src[(size_t)i].hdr >> H_SRC_SHIFT) & H_SRC_MASK) != SRC_CONST) continue;
+    std::atomic<bool> ok{true};
+    parallel_tree_ranges(n_trees, [&](int, int64_t tb, int64_t te) { // a tree writes its own instructions' entries only
+        for (int64_t t = tb; t < te && ok; t++) {
+            int32_t j = dst_off[(size_t)t];
+            const int32_t j1 = dst_off[(size_t)t + 1];
+            for (int32_t i = src_off[(size_t)t]; i < src_off[(size_t)t + 1]; i++) {
+                if (((src[(size_t)i].hdr >> H_SRC_SHIFT) & H_SRC_MASK) != SRC_CONST) continue;
+                while (j < j1 && !carries(dst[(size_t)j])) j++;
+                if (j >= j1) { ok = false; break; }
+                (*site)[(size_t)i] = j++;
+            }
             while (j < j1 && !carries(dst[(size_t)j])) j++;
-            if (j >= j1) { site->clear(); return false; }
-            (*site)[(size_t)i] = j++;
+            if (j != j1) ok = false;
         }
-        while (j < j1 && !carries(dst[(size_t)j])) j++;
-        if (j != j1) { site->clear(); return false; }
-    }
+    });
+    if (!ok) { site->clear(); return false; }
     return true;
+}
+
+// A per-tree pass that APPENDS records: every worker fills a vector of its own over its range of trees (emit(t, &out)), the pieces are
+// concatenated in tree order and off[t] .. off[t + 1] names tree t's records — the stream a serial loop over the trees would have built.
+template <class Rec, class Emit>
+static void build_stream_by_trees(int64_t n_trees, std::vector<Rec> *stream, std::vector<int32_t> *off, Emit emit) {
+    std::vector<Rec> parts[16];
+    int64_t first[16], last[16];
+    for (int k = 0; k < 16; k++) first[k] = last[k] = 0;
+    std::vector<int32_t> cnt((size_t)n_trees, 0);
+    parallel_tree_ranges(n_trees, [&](int k, int64_t tb, int64_t te) {
+        std::vector<Rec> &out = parts[k];
+        first[k] = tb;
+        last[k] = te;
+        for (int64_t t = tb; t < te; t++) {
+            const size_t before = out.size();
+            emit(t, &out);
+            cnt[(size_t)t] = (int32_t)(out.size() - before);
+        }
+    });
+    off->assign((size_t)n_trees + 1, 0);
+    for (int64_t t = 0; t < n_trees; t++) (*off)[(size_t)t + 1] = (*off)[(size_t)t] + cnt[(size_t)t];
+    stream->clear();
+    stream->resize((size_t)(*off)[(size_t)n_trees]);
+    for (int k = 0; k < 16; k++) // (a few MB: memcpy-bound, kept serial)
+        if (last[k] > first[k] && !parts[k].empty())
+            std::memcpy(static_cast<void *>(stream->data() + (*off)[(size_t)first[k]]), parts[k].data(), parts[k].size() * sizeof(Rec));
 }
 
 extern "C" {
@@ -522,26 +615,35 @@ static void rebind(de_program *p) {
     p->prows = p->uses_params && p->n_params > 0 && p->n_params <= 16 && param_rows_enabled() &&
                ((size_t)p->n_features + (size_t)p->n_slots + (size_t)p->n_params) * 257 * 16 <= 150 * 1024;
     const int prb = p->prows ? p->n_features + p->n_slots : -1;
-    p->bcode.clear();
-    p->bcode_off.assign((size_t)p->n_trees + 1, 0);
     const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
     const std::vector<int32_t> &off = p->folded ? p->fcode_off : p->code_off;
-    for (int64_t t = 0; t < p->n_trees; t++) {
+    const int nf = p->n_features;
+    build_stream_by_trees<BoundInstr>(p->n_trees, &p->bcode, &p->bcode_off, [&](int64_t t, std::vector<BoundInstr> *out) {
         const int32_t i0 = off[(size_t)t], i1 = off[(size_t)t + 1];
-        bind_tree(src.data() + i0, (size_t)(i1 - i0), ee, p->n_features, &p->bcode, prb);
-        p->bcode_off[(size_t)t + 1] = (int32_t)p->bcode.size();
-    }
+        bind_tree(src.data() + i0, (size_t)(i1 - i0), ee, nf, out, prb);
+    });
     match_const_sites(src, off, p->bcode, p->bcode_off, p->n_trees, [](const BoundInstr &b) { return bop_is_const_source(b.bop); }, &p->bsite);
     p->tsite.clear();
     p->site_gen++;
 }
-// (bind_tree / fuse_tree are ~0.3 us per tree: not worth threads)
+// (bind_tree / fuse_tree are ~0.3 us per tree — 3 ms each for 10^4 trees on one thread: build_stream_by_trees)
 
 // Threaded-code form of the bound program (de_kernels.hip, de_eval_threaded_kernel): word 0 =
 // handler address - handler_base, word 1 = LDS byte offset of the operand row | aux << 24.
+// DE_DEBUG_TIMING: microseconds since the previous lap of this thread, on stderr
+static void dbg_lap(const char *what);
+static void dbg_lap(const char *what) {
+    static const bool on = getenv("DE_DEBUG_TIMING") != nullptr;
+    if (!on) return;
+    static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    const auto now = std::chrono::steady_clock::now();
+    if (what) fprintf(stderr, "    [lap] %-40s %9.1f us\n", what, std::chrono::duration<double, std::micro>(now - last).count());
+    last = std::chrono::steady_clock::now();
+}
 static void make_chained(de_program *p);
 static int make_threaded(de_ctx *c, de_program *p) {
     p->threaded = false;
+    dbg_lap(nullptr);
     // the LDS-staged kernels need (n_features + n_slots) rows of 4112 B; wider X uses the direct variant
     p->direct = (size_t)eval_rows(p) * 257 * 16 > 150 * 1024; // (the flat-switch geometry decides)
     if (p->direct || !eval_uses_threaded()) return DE_OK;
@@ -549,6 +651,7 @@ static int make_threaded(de_ctx *c, de_program *p) {
     uint64_t table[TOPX_TABLE];
     hipError_t st = eval_handler_table(p->dtype, (p->options & DE_OPT_TURBO) != 0, table);
     if (st != hipSuccess) return fail(c, DE_ERR_HIP, "handler table: %s", hipGetErrorString(st));
+    dbg_lap("handler table");
     uint64_t base = table[0];
     for (int i = 0; i < (int)TOPX_TABLE; i++) base = std::min<uint64_t>(base, table[i]);
     for (int i = 0; i < (int)TOPX_TABLE; i++) {
@@ -561,16 +664,15 @@ static int make_threaded(de_ctx *c, de_program *p) {
     // superinstructions (de_bind.h): fewer dispatches for the same arithmetic
     const char *nf = getenv("DE_NO_FUSE");
     const bool fuse = !(nf && *nf == '1');
-    p->fbcode.clear();
-    p->tcode_off.assign((size_t)p->n_trees + 1, 0);
-    for (int64_t t = 0; t < p->n_trees; t++) {
+    build_stream_by_trees<BoundInstr>(p->n_trees, &p->fbcode, &p->tcode_off, [&](int64_t t, std::vector<BoundInstr> *out) {
         const int32_t b0 = p->bcode_off[(size_t)t], b1 = p->bcode_off[(size_t)t + 1];
-        if (fuse) fuse_tree(p->bcode.data() + b0, (size_t)(b1 - b0), &p->fbcode);
-        else p->fbcode.insert(p->fbcode.end(), p->bcode.begin() + b0, p->bcode.begin() + b1);
-        p->tcode_off[(size_t)t + 1] = (int32_t)p->fbcode.size();
-    }
+        if (fuse) fuse_tree(p->bcode.data() + b0, (size_t)(b1 - b0), out);
+        else out->insert(out->end(), p->bcode.begin() + b0, p->bcode.begin() + b1);
+    });
+    dbg_lap("fuse_tree");
     p->tcode.resize(p->fbcode.size());
-    for (size_t i = 0; i < p->fbcode.size(); i++) {
+    parallel_tree_ranges(p->n_trees, [&](int, int64_t tb, int64_t te) {
+    for (size_t i = (size_t)p->tcode_off[(size_t)tb]; i < (size_t)p->tcode_off[(size_t)te]; i++) {
         const BoundInstr &b = p->fbcode[i];
         BoundInstr t = b;
         t.bop = (uint32_t)(table[b.bop] - base);
@@ -595,16 +697,20 @@ static int make_threaded(de_ctx *c, de_program *p) {
         }
         p->tcode[i] = t;
     }
+    });
+    dbg_lap("threaded words");
     {
         const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
         const std::vector<int32_t> &off = p->folded ? p->fcode_off : p->code_off;
         match_const_sites(src, off, p->fbcode, p->tcode_off, p->n_trees, [](const BoundInstr &b) { return top_carries_const(b.bop); }, &p->tsite);
         p->site_gen++;
     }
+    dbg_lap("constant sites");
     p->handler_base = base;
     p->end_handler = table[TOPX_END];
     for (uint32_t k = 0; k < TOPX_ENDV_COUNT; k++) p->endv_handler[k] = table[TOPX_ENDV_BASE + k];
     make_chained(p);
+    dbg_lap("chained records");
     p->threaded = true;
     return DE_OK;
 }
@@ -628,31 +734,49 @@ static void make_chained(de_program *p) {
         if (f32) { r.lo = (uint32_t)handler; r.hi = (uint32_t)(handler >> 32); }
         else r.arg = (uint32_t)handler;
     };
-    const bool end_fuse = true; // (the DE_NO_END_FUSE switch of round 2 measured <= 1 % and is gone)
-    bool prev_fused = false; // the previous tree finishes in an end-fused handler: ITS last instruction names this tree's first handler
+    // (the DE_NO_END_FUSE switch of round 2 measured <= 1 % and is gone)
+    // a tree that finishes in a validity-tested hot operator runs that instruction and its end as ONE dispatch (h_chain_end);
+    // a one-instruction tree keeps the plain form (the kernel's first call cannot tell the two apart)
+    auto ev_of = [&](int64_t t) -> int {
+        const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1];
+        return i1 - i0 >= 2 ? topx_endv_of(p->fbcode[(size_t)i1 - 1].bop) : -1;
+    };
+    auto handler_of = [&](int32_t i, int32_t i1, int ev) -> uint64_t {
+        return (i == i1 - 1 && ev >= 0) ? p->endv_handler[ev] : p->handler_base + p->tcode[(size_t)i].bop;
+    };
+    // Pass A, on the host threads: the records a tree OWNS — its instruction records and its end record (h = one end record per
+    // preceding tree + the head record).  Pass B, serial (three writes per tree): what a tree writes into its PREDECESSOR's last two
+    // records — the handler of its first instruction, and the header words over the end record's.
+    parallel_tree_ranges(p->n_trees, [&](int, int64_t tb, int64_t te) {
+        for (int64_t t = tb; t < te; t++) {
+            const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1];
+            const size_t h = (size_t)i0 + (size_t)t + 1;
+            p->ccode_off[(size_t)t] = (int32_t)h;
+            const int ev = ev_of(t);
+            for (int32_t i = i0; i < i1; i++) {
+                const BoundInstr &s = p->tcode[(size_t)i];
+                put(p->ccode[h + (size_t)(i - i0)], s.arg, s.lo, s.hi);
+                if (i > i0) name_next(p->ccode[h + (size_t)(i - i0) - 1], handler_of(i, i1, ev)); // in the record in front
+            }
+            put(p->ccode[h + (size_t)(i1 - i0)], (uint32_t)t, 0u, 0u); // end record (operand word: the tree's index, informational)
+            if (i1 > i0) name_next(p->ccode[h + (size_t)(i1 - i0) - 1], p->end_handler);
+        }
+    });
     for (int64_t t = 0; t < p->n_trees; t++) {
         const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1];
-        const size_t h = (size_t)i0 + (size_t)t + 1; // one end record per preceding tree + the head record
-        p->ccode_off[(size_t)t] = (int32_t)h;
-        // a tree that finishes in a validity-tested hot operator runs that instruction and its end as ONE dispatch (h_chain_end);
-        // a one-instruction tree keeps the plain form (the kernel's first call cannot tell the two apart)
-        const int ev = (end_fuse && i1 - i0 >= 2) ? topx_endv_of(p->fbcode[(size_t)i1 - 1].bop) : -1;
-        const bool ev_ok = ev >= 0;
-        for (int32_t i = i0; i < i1; i++) {
-            const BoundInstr &s = p->tcode[(size_t)i];
-            put(p->ccode[h + (size_t)(i - i0)], s.arg, s.lo, s.hi);
-            const uint64_t handler = (i == i1 - 1 && ev_ok) ? p->endv_handler[ev] : p->handler_base + s.bop;
-            name_next(p->ccode[h + (size_t)(i - i0) - 1], handler); // in the record in front (head / previous end record / previous instruction)
-            if (i == i0 && prev_fused) name_next(p->ccode[h - 2], handler); // ... and in the previous tree's last instruction, which steps over its end record
-        }
-        put(p->ccode[h + (size_t)(i1 - i0)], (uint32_t)t, 0u, 0u); // end record (operand word: the tree's index, informational)
+        const size_t h = (size_t)p->ccode_off[(size_t)t];
+        const int ev = ev_of(t);
+        if (i1 > i0) {
+            const uint64_t first = handler_of(i0, i1, ev);
+            name_next(p->ccode[h - 1], first); // in the head record / the previous tree's end record
+            // the previous tree finishes in an end-fused handler: ITS last instruction names this tree's first handler, stepping over its end record
+            if (t > 0 && ev_of(t - 1) >= 0) name_next(p->ccode[h - 2], first);
+        } else name_next(p->ccode[h - 1], p->end_handler);
         // the record in front of the tree (head record / previous tree's end record) is its HEADER: its immediate = the number of
         // instruction records of the tree, which is what h_tree_skip needs to step over a tree that is not evaluated
         // bit 31 = the tree finishes in an end-fused handler (its last instruction record names the next tree's first handler too):
         // what de_compact_live_kernel (de_kernels.hip) needs to re-link a tree behind another one
-        put(p->ccode[h - 1], t == 0 ? 0u : (uint32_t)(t - 1), (uint32_t)(i1 - i0) | (ev_ok ? DE_HDR_FUSED_END : 0u), 0u);
-        name_next(p->ccode[h + (size_t)(i1 - i0) - 1], p->end_handler);
-        prev_fused = ev_ok;
+        put(p->ccode[h - 1], t == 0 ? 0u : (uint32_t)(t - 1), (uint32_t)(i1 - i0) | (ev >= 0 ? DE_HDR_FUSED_END : 0u), 0u);
     }
     if (p->n_trees > 0) name_next(p->ccode.back(), p->end_handler); // never followed: the last tree's end returns (left == 1)
     p->ccode_off[(size_t)p->n_trees] = (int32_t)p->ccode.size();
@@ -701,18 +825,23 @@ static int upload_ok_eval(de_ctx *c, de_program *p) {
 }
 
 // (Re-)evaluate the folded constant subtrees on the device and patch their values into fcode.
-static int refresh_folds(de_ctx *c, de_program *p) {
+// `aux_current`: the auxiliary program was created with the present constants this very moment (de_program_create: setting them
+// again cost 0.9 of the 1.1 ms this step took for 10^4 trees).
+static int refresh_folds(de_ctx *c, de_program *p, bool aux_current = false) {
     if (!p->folded || p->folds.empty()) return DE_OK; // (a CSE-only eval program has no constant subtrees to evaluate)
     const size_t es = p->dtype == DE_F32 ? 4 : 8;
     const size_t na = p->folds.size();
-    std::vector<unsigned char> ac(std::max<size_t>(p->aux_const_src.size(), 1) * es);
-    for (size_t k = 0; k < p->aux_const_src.size(); k++) {
-        const double v = p->consts[(size_t)p->aux_const_src[k]];
-        if (p->dtype == DE_F32) reinterpret_cast<float *>(ac.data())[k] = (float)v;
-        else reinterpret_cast<double *>(ac.data())[k] = v;
+    int rc = DE_OK;
+    if (!aux_current) {
+        std::vector<unsigned char> ac(std::max<size_t>(p->aux_const_src.size(), 1) * es);
+        for (size_t k = 0; k < p->aux_const_src.size(); k++) {
+            const double v = p->consts[(size_t)p->aux_const_src[k]];
+            if (p->dtype == DE_F32) reinterpret_cast<float *>(ac.data())[k] = (float)v;
+            else reinterpret_cast<double *>(ac.data())[k] = v;
+        }
+        rc = de_program_set_consts(p->aux, ac.data());
+        if (rc != DE_OK) return fail(c, rc, "constant folding: %s", p->aux->ctx->err.c_str());
     }
-    int rc = de_program_set_consts(p->aux, ac.data());
-    if (rc != DE_OK) return fail(c, rc, "constant folding: %s", p->aux->ctx->err.c_str());
     std::vector<unsigned char> X(std::max<size_t>((size_t)p->n_features, 1) * es, 0), out(na * es);
     p->fold_ok.assign(na, 0);
     rc = de_eval(c, p->aux, X.data(), 1, std::max<int64_t>(p->n_features, 1), nullptr, out.data(), 1, p->fold_ok.data());
@@ -762,6 +891,16 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
     if (n_trees > 0x7fffffff) return fail(ctx, DE_ERR_UNSUPPORTED, "too many trees");
     std::unique_ptr<de_program> p(new (std::nothrow) de_program());
     if (!p) return fail(ctx, DE_ERR_HIP, "out of host memory");
+    // DE_DEBUG_TIMING: microseconds per phase of the creation on stderr (tools/bench_create.py)
+    const bool timing = getenv("DE_DEBUG_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[de_program_create %lld trees%s] %-28s %9.1f us\n", (long long)n_trees, allow_fold ? "" : " (aux)", what,
+                std::chrono::duration<double, std::micro>(now - t_last).count());
+        t_last = std::chrono::steady_clock::now();
+    };
     try {
         p->ctx = ctx;
         p->dtype = dtype;
@@ -839,75 +978,127 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
             });
             if (oom) return fail(ctx, DE_ERR_HIP, "out of host memory");
         }
-        for (int64_t t = 0; t < n_trees; t++) {
-            const int64_t n0 = node_offsets[t], n1 = node_offsets[t + 1];
-            const int64_t c0 = const_offsets[t], c1 = const_offsets[t + 1];
-            TreeProgram &tp = low[(size_t)t].plain;
-            if (low[(size_t)t].rc != DE_OK) return fail(ctx, low[(size_t)t].rc, "tree %lld: %s", (long long)t, low[(size_t)t].why.c_str());
-            const int64_t cb = c0 - const_offsets[0];
-            p->const_off[(size_t)t] = cb;
-            p->const_off[(size_t)t + 1] = cb + (c1 - c0);
-            p->n_consts_tree[(size_t)t] = (int32_t)(c1 - c0);
-            const int32_t ib = (int32_t)p->code.size();
-            for (int64_t k = 0; k < c1 - c0; k++) {
-                const double v = dtype == DE_F32 ? (double)static_cast<const float *>(consts)[c0 + k]
-                                                 : static_cast<const double *>(consts)[c0 + k];
-                p->consts[(size_t)(cb + k)] = v;
-                // (a CSE lowering has no instruction for the later occurrences of a constant inside a shared subtree: -1)
-                p->const_instr[(size_t)(cb + k)] = tp.const_instr[(size_t)k] >= 0 ? ib + tp.const_instr[(size_t)k] : -1;
-                p->const_checks[(size_t)(cb + k)] = tp.const_checks[(size_t)k];
-                if (tp.const_instr[(size_t)k] >= 0) write_imm(tp.code[(size_t)tp.const_instr[(size_t)k]], dtype, v);
+        lap("lower (host threads)");
+        // merge: offsets by a serial prefix sum, the copies on the host threads (every tree writes slices of its own)
+        {
+            uint64_t total = 0;
+            for (int64_t t = 0; t < n_trees; t++) {
+                if (low[(size_t)t].rc != DE_OK) return fail(ctx, low[(size_t)t].rc, "tree %lld: %s", (long long)t, low[(size_t)t].why.c_str());
+                total += low[(size_t)t].plain.code.size();
+                if (total > 0x7fff0000u) return fail(ctx, DE_ERR_UNSUPPORTED, "program too large");
+                p->code_off[(size_t)t + 1] = (int32_t)total;
             }
-            p->code.insert(p->code.end(), tp.code.begin(), tp.code.end());
-            p->code_off[(size_t)t + 1] = (int32_t)p->code.size();
-            p->cse_generic = p->cse_generic || low[(size_t)t].cse_plain;
-            p->n_slots = std::max(p->n_slots, tp.n_slots);
-            p->uses_params = p->uses_params || tp.uses_params;
-            p->n_nodes += n1 - n0;
-            if (p->code.size() > 0x7fff0000u) return fail(ctx, DE_ERR_UNSUPPORTED, "program too large");
+            p->code.resize((size_t)total);
+            struct Part { int32_t n_slots = 0; bool cse = false, params = false; int64_t nodes = 0; } part[16];
+            parallel_tree_ranges(n_trees, [&](int wk, int64_t tb, int64_t te) {
+                Part &pt = part[wk];
+                for (int64_t t = tb; t < te; t++) {
+                    const int64_t n0 = node_offsets[t], n1 = node_offsets[t + 1];
+                    const int64_t c0 = const_offsets[t], c1 = const_offsets[t + 1];
+                    TreeProgram &tp = low[(size_t)t].plain;
+                    const int64_t cb = c0 - const_offsets[0];
+                    p->const_off[(size_t)t + 1] = cb + (c1 - c0); // (entry t is tree t - 1's, entry 0 stays 0)
+                    p->n_consts_tree[(size_t)t] = (int32_t)(c1 - c0);
+                    const int32_t ib = p->code_off[(size_t)t];
+                    for (int64_t k = 0; k < c1 - c0; k++) {
+                        const double v = dtype == DE_F32 ? (double)static_cast<const float *>(consts)[c0 + k]
+                                                         : static_cast<const double *>(consts)[c0 + k];
+                        p->consts[(size_t)(cb + k)] = v;
+                        // (a CSE lowering has no instruction for the later occurrences of a constant inside a shared subtree: -1)
+                        p->const_instr[(size_t)(cb + k)] = tp.const_instr[(size_t)k] >= 0 ? ib + tp.const_instr[(size_t)k] : -1;
+                        p->const_checks[(size_t)(cb + k)] = tp.const_checks[(size_t)k];
+                        if (tp.const_instr[(size_t)k] >= 0) write_imm(tp.code[(size_t)tp.const_instr[(size_t)k]], dtype, v);
+                    }
+                    std::copy(tp.code.begin(), tp.code.end(), p->code.begin() + ib);
+                    pt.cse = pt.cse || low[(size_t)t].cse_plain;
+                    pt.n_slots = std::max(pt.n_slots, tp.n_slots);
+                    pt.params = pt.params || tp.uses_params;
+                    pt.nodes += n1 - n0;
+                }
+            });
+            for (const Part &pt : part) {
+                p->cse_generic = p->cse_generic || pt.cse;
+                p->n_slots = std::max(p->n_slots, pt.n_slots);
+                p->uses_params = p->uses_params || pt.params;
+                p->n_nodes += pt.nodes;
+            }
         }
+        lap("merge plain");
         // ---- folded lowering of the eval program + the auxiliary population of constant subtrees
         if (allow_fold) {
             lo.fold = true;
             std::vector<de_tape_node_t> anodes;
-            std::vector<int64_t> anoff{0}, acoff{0};
+            std::vector<int64_t> anoff, acoff;
             bool any_cse = false;
             p->fcode_off.assign((size_t)n_trees + 1, 0);
             p->fconst_instr.assign((size_t)total_consts, -1);
-            for (int64_t t = 0; t < n_trees; t++) {
-                const int64_t n0 = node_offsets[t], n1 = node_offsets[t + 1];
-                const int64_t c0 = const_offsets[t], c1 = const_offsets[t + 1];
-                TreeProgram &tp = low[(size_t)t].folded;
-                if (low[(size_t)t].rcf != DE_OK)
-                    return fail(ctx, low[(size_t)t].rcf, "tree %lld (folded): %s", (long long)t, low[(size_t)t].why.c_str());
-                (void)n1;
-                const bool is_cse = low[(size_t)t].cse;
-                const de_tape_node_t *src_nodes = is_cse ? cse_nodes + cse_offsets[t] : nodes + n0; // the tape the fold spans index
-                any_cse = any_cse || is_cse;
-                p->n_slots = std::max(p->n_slots, tp.n_slots); // a CSE program keeps one persistent row per shared subtree
-                const int64_t cb = c0 - const_offsets[0];
-                const int32_t ib = (int32_t)p->fcode.size();
-                for (int64_t k = 0; k < c1 - c0; k++) {
-                    const int32_t ci = tp.const_instr[(size_t)k];
-                    if (ci < 0) continue; // constant lives inside a folded subtree
-                    p->fconst_instr[(size_t)(cb + k)] = ib + ci;
-                    write_imm(tp.code[(size_t)ci], dtype, p->consts[(size_t)(cb + k)]);
+            // offsets of every tree's instructions, folds, auxiliary tape nodes and auxiliary constants by a serial prefix sum ...
+            std::vector<int64_t> fold0((size_t)n_trees + 1, 0), anode0((size_t)n_trees + 1, 0), acs0((size_t)n_trees + 1, 0);
+            {
+                uint64_t total = 0;
+                for (int64_t t = 0; t < n_trees; t++) {
+                    const TreeProgram &tp = low[(size_t)t].folded;
+                    if (low[(size_t)t].rcf != DE_OK)
+                        return fail(ctx, low[(size_t)t].rcf, "tree %lld (folded): %s", (long long)t, low[(size_t)t].why.c_str());
+                    total += tp.code.size();
+                    if (total > 0x7fff0000u) return fail(ctx, DE_ERR_UNSUPPORTED, "program too large");
+                    p->fcode_off[(size_t)t + 1] = (int32_t)total;
+                    int64_t nn = 0, nc = 0;
+                    for (const FoldSpan &sp : tp.folds) { nn += sp.node_end - sp.node_begin; nc += sp.const_end - sp.const_begin; }
+                    fold0[(size_t)t + 1] = fold0[(size_t)t] + (int64_t)tp.folds.size();
+                    anode0[(size_t)t + 1] = anode0[(size_t)t] + nn;
+                    acs0[(size_t)t + 1] = acs0[(size_t)t] + nc;
                 }
-                for (size_t f = 0; f < tp.folds.size(); f++) {
-                    const FoldSpan &sp = tp.folds[f];
-                    p->folds.push_back({(int32_t)t, ib + tp.const_instr[(size_t)(c1 - c0) + f], sp.tested_always});
-                    for (int32_t q = sp.node_begin; q < sp.node_end; q++) {
-                        de_tape_node_t nd = src_nodes[q];
-                        if (nd.degree == 0 && nd.op == DE_LEAF_CONST) nd.arg = (uint16_t)(nd.arg - sp.const_begin);
-                        anodes.push_back(nd);
-                    }
-                    for (int32_t q = sp.const_begin; q < sp.const_end; q++) p->aux_const_src.push_back(cb + q);
-                    anoff.push_back((int64_t)anodes.size());
-                    acoff.push_back((int64_t)p->aux_const_src.size());
-                }
-                p->fcode.insert(p->fcode.end(), tp.code.begin(), tp.code.end());
-                p->fcode_off[(size_t)t + 1] = (int32_t)p->fcode.size();
+                p->fcode.resize((size_t)total);
             }
+            const size_t n_folds = (size_t)fold0[(size_t)n_trees];
+            p->folds.resize(n_folds);
+            anodes.resize((size_t)anode0[(size_t)n_trees]);
+            p->aux_const_src.resize((size_t)acs0[(size_t)n_trees]);
+            anoff.assign(n_folds + 1, 0);
+            acoff.assign(n_folds + 1, 0);
+            // ... the copies on the host threads
+            struct PartF { int32_t n_slots = 0; bool cse = false; } partf[16];
+            parallel_tree_ranges(n_trees, [&](int wk, int64_t tb, int64_t te) {
+                PartF &pt = partf[wk];
+                for (int64_t t = tb; t < te; t++) {
+                    const int64_t n0 = node_offsets[t];
+                    const int64_t c0 = const_offsets[t], c1 = const_offsets[t + 1];
+                    TreeProgram &tp = low[(size_t)t].folded;
+                    const bool is_cse = low[(size_t)t].cse;
+                    const de_tape_node_t *src_nodes = is_cse ? cse_nodes + cse_offsets[t] : nodes + n0; // the tape the fold spans index
+                    pt.cse = pt.cse || is_cse;
+                    pt.n_slots = std::max(pt.n_slots, tp.n_slots); // a CSE program keeps one persistent row per shared subtree
+                    const int64_t cb = c0 - const_offsets[0];
+                    const int32_t ib = p->fcode_off[(size_t)t];
+                    for (int64_t k = 0; k < c1 - c0; k++) {
+                        const int32_t ci = tp.const_instr[(size_t)k];
+                        if (ci < 0) continue; // constant lives inside a folded subtree
+                        p->fconst_instr[(size_t)(cb + k)] = ib + ci;
+                        write_imm(tp.code[(size_t)ci], dtype, p->consts[(size_t)(cb + k)]);
+                    }
+                    size_t an = (size_t)anode0[(size_t)t], ac = (size_t)acs0[(size_t)t];
+                    for (size_t f = 0; f < tp.folds.size(); f++) {
+                        const FoldSpan &sp = tp.folds[f];
+                        const size_t fi = (size_t)fold0[(size_t)t] + f;
+                        p->folds[fi] = {(int32_t)t, ib + tp.const_instr[(size_t)(c1 - c0) + f], sp.tested_always};
+                        for (int32_t q = sp.node_begin; q < sp.node_end; q++) {
+                            de_tape_node_t nd = src_nodes[q];
+                            if (nd.degree == 0 && nd.op == DE_LEAF_CONST) nd.arg = (uint16_t)(nd.arg - sp.const_begin);
+                            anodes[an++] = nd;
+                        }
+                        for (int32_t q = sp.const_begin; q < sp.const_end; q++) p->aux_const_src[ac++] = cb + q;
+                        anoff[fi + 1] = (int64_t)an;
+                        acoff[fi + 1] = (int64_t)ac;
+                    }
+                    std::copy(tp.code.begin(), tp.code.end(), p->fcode.begin() + ib);
+                }
+            });
+            for (const PartF &pt : partf) {
+                any_cse = any_cse || pt.cse;
+                p->n_slots = std::max(p->n_slots, pt.n_slots);
+            }
+            lap("merge folded");
             if (!p->folds.empty()) {
                 const size_t es = dtype == DE_F32 ? 4 : 8;
                 std::vector<unsigned char> ac(std::max<size_t>(p->aux_const_src.size(), 1) * es, 0);
@@ -920,8 +1111,10 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                                      acoff.data(), n_features, 0, options, false, &p->aux);
                 if (rc != DE_OK) return rc;
                 p->folded = true;
-                rc = refresh_folds(ctx, p.get());
+                lap("aux program (create)");
+                rc = refresh_folds(ctx, p.get(), true);
                 if (rc != DE_OK) return rc;
+                lap("aux program (evaluate)");
             } else if (any_cse) {
                 p->folded = true; // the eval program is the CSE lowering even without a constant subtree to fold
             } else {
@@ -929,8 +1122,12 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                 p->fcode_off.clear();
             }
         }
+        // the per-tree lowerings are ~16 small vectors each: released on the threads that allocated them (one thread took 5 ms for 10^4 trees)
+        parallel_for_trees(n_trees, [&](int64_t t) { Lowered done; std::swap(done, low[(size_t)t]); });
+        lap("release lowerings");
         recompute_host_ok(p.get());
         rebind(p.get());
+        lap("bind");
     } catch (const std::bad_alloc &) {
         return fail(ctx, DE_ERR_HIP, "out of host memory");
     }
@@ -940,6 +1137,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         try { rc = make_threaded(ctx, p.get()); } catch (const std::bad_alloc &) { rc = fail(ctx, DE_ERR_HIP, "out of host memory"); }
         if (rc != DE_OK) return rc;
     }
+    lap("threaded + chained records");
     // one trailing pad instruction: the flat-switch interpreter prefetches code[pc + 1]; the chained form of the
     // threaded kernel has one end record per tree and a head record (and the fused form is never longer than the bound one)
     const size_t cbytes = (p->bcode.size() + (size_t)p->n_trees + 2) * sizeof(BoundInstr); // + head record + one of padding
@@ -972,6 +1170,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
             }
         }
     }
+    lap("hipMalloc (stream, ints)");
     HIP_TRY(ctx, hipMemset(p->d_code, 0, cbytes));
     hipError_t st = hipMalloc(reinterpret_cast<void **>(&p->d_code_off), p->bcode_off.size() * sizeof(int32_t));
     if (st != hipSuccess) {
@@ -989,10 +1188,12 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         (void)hipFree(p->d_code_off);
         return fail(ctx, DE_ERR_HIP, "program upload failed: %s", hipGetErrorString(st));
     }
+    lap("memset + upload");
     {
         const int rc = upload_ok_eval(ctx, p.get());
         if (rc != DE_OK) return rc; // (~de_program is not run on this path: the process is out of device memory anyway)
     }
+    lap("flags upload");
     if (getenv("DE_VERIFY") && *getenv("DE_VERIFY") == '1') {
         const int rc = de_program_verify(p.get());
         if (rc != DE_OK) return rc;
@@ -1183,6 +1384,30 @@ int de_eval_plan(const de_program_t *p, int64_t N, int32_t *plan) {
     if (!p || !plan || N < 0) return DE_ERR_INVALID_ARG;
     eval_plan(p->dtype, p->n_trees, N, &plan[0], &plan[1], &plan[2]);
     return DE_OK;
+}
+
+// Test hook: one number over every HOST-side stream and table de_program_create built (generic, folded, bound, fused, threaded and chained
+// records, offsets, constant sites, fold list, flags, and the auxiliary program's) — the per-tree passes run on a pool of host threads
+// and must build what one thread builds (tests/test_gpu_round5.py: DE_HOST_THREADS=1 against the default).  FNV-1a, 64 bits.
+uint64_t de_program_stream_hash(const de_program_t *p) {
+    if (!p) return 0;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *data, size_t bytes) {
+        const unsigned char *b = static_cast<const unsigned char *>(data);
+        for (size_t i = 0; i < bytes; i++) { h ^= b[i]; h *= 1099511628211ull; }
+        const uint64_t n = bytes; // (the length too: an empty vector and a missing one differ from a shifted boundary)
+        for (int i = 0; i < 8; i++) { h ^= (n >> (8 * i)) & 0xFF; h *= 1099511628211ull; }
+    };
+    auto vec = [&](const auto &v) { mix(v.data(), v.size() * sizeof(v[0])); };
+    vec(p->code); vec(p->code_off); vec(p->fcode); vec(p->fcode_off); vec(p->bcode); vec(p->bcode_off);
+    vec(p->fbcode); vec(p->tcode); vec(p->tcode_off); vec(p->ccode); vec(p->ccode_off); vec(p->bsite); vec(p->tsite);
+    vec(p->consts); vec(p->const_off); vec(p->const_instr); vec(p->fconst_instr); vec(p->const_checks); vec(p->n_consts_tree);
+    vec(p->aux_const_src); vec(p->host_ok_eval); vec(p->host_ok_grad); vec(p->fold_ok);
+    for (const auto &f : p->folds) { const int32_t w[3] = {f.tree, f.instr, f.tested_always ? 1 : 0}; mix(w, sizeof w); }
+    const int64_t scal[6] = {p->n_trees, p->n_nodes, p->n_slots, p->uses_params ? 1 : 0, p->folded ? 1 : 0, p->threaded ? 1 : 0};
+    mix(scal, sizeof scal);
+    if (p->aux) { const uint64_t a = de_program_stream_hash(p->aux); mix(&a, sizeof a); }
+    return h;
 }
 
 // Program sanitizer (SURVEY.md §5 "sanitizer / bounds-checked debug"): the kernels trust the instruction streams —
@@ -1746,25 +1971,13 @@ static int ensure_generic_code(de_ctx *c, de_program *p) {
     if (p->gcode_stale || !p->d_gcode) {
         // gradients flow through constant subtrees, so this is the UNFOLDED program; every value the
         // reference tests is tested (ee binding) whatever the eval options were
-        p->gbcode.clear();
         p->gt_valid = false;
         p->rt_valid = false;
-        p->gbcode_off.assign((size_t)p->n_trees + 1, 0);
-        { // bound per worker into a vector of its own, then concatenated (10^4 trees: 3 ms on one thread)
-            std::vector<BoundInstr> parts[16];
-            std::vector<int32_t> cnt((size_t)p->n_trees, 0);
-            parallel_tree_ranges(p->n_trees, [&](int k, int64_t tb, int64_t te) {
-                for (int64_t t = tb; t < te; t++) {
-                    const int32_t i0 = p->code_off[(size_t)t], i1 = p->code_off[(size_t)t + 1];
-                    const size_t before = parts[k].size();
-                    bind_tree(p->code.data() + i0, (size_t)(i1 - i0), true, p->n_features, &parts[k]);
-                    cnt[(size_t)t] = (int32_t)(parts[k].size() - before);
-                }
-            });
-            for (int64_t t = 0; t < p->n_trees; t++) p->gbcode_off[(size_t)t + 1] = p->gbcode_off[(size_t)t] + cnt[(size_t)t];
-            p->gbcode.reserve((size_t)p->gbcode_off[(size_t)p->n_trees]);
-            for (int k = 0; k < 16; k++) p->gbcode.insert(p->gbcode.end(), parts[k].begin(), parts[k].end()); // ranges are in tree order
-        }
+        // bound per worker into a vector of its own, then concatenated (10^4 trees: 3 ms on one thread)
+        build_stream_by_trees<BoundInstr>(p->n_trees, &p->gbcode, &p->gbcode_off, [&](int64_t t, std::vector<BoundInstr> *out) {
+            const int32_t i0 = p->code_off[(size_t)t], i1 = p->code_off[(size_t)t + 1];
+            bind_tree(p->code.data() + i0, (size_t)(i1 - i0), true, p->n_features, out);
+        });
         match_const_sites(p->code, p->code_off, p->gbcode, p->gbcode_off, p->n_trees,
                           [](const BoundInstr &b) { return bop_is_const_source(b.bop); }, &p->gbsite);
         p->gtsite_of_gb.clear();
@@ -1811,6 +2024,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
     const char *envn = getenv("DE_GRAD_VS2_MIN_N");
     const bool wide = N >= (envn ? atoll(envn) : 65536);
     if (!(p->gt_valid && p->gt_mode == mode && p->gt_wide == wide)) {
+        dbg_lap(nullptr);
         // bucket of a tree: (width index 0..6 = single window of width 1,2,3,4,5,6,8; 7 = several windows of 8)
         // x (samples per lane - 1).  The two-sample modules exist for Float32 windows <= 6; their rows are
         // twice as long, so they only pay while a workgroup's LDS stays small: at most DE_GRAD_VS2_ROWS (15) rows per wave.
@@ -1821,7 +2035,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         const char *env2 = getenv("DE_GRAD_VS2_ROWS"); // most LDS rows per wave (X + parameters + slots) that still run two samples per lane
         const int vs2_rows = env2 ? atoi(env2) : 15;    // 15 rows x 512 B x 4 waves = 30.7 KB: 5 workgroups per CU
         std::vector<int32_t> tslots((size_t)p->n_trees, 0); // spill slots of each tree (rows >= F the code names)
-        for (int64_t t = 0; t < p->n_trees; t++) {
+        parallel_for_trees(p->n_trees, [&](int64_t t) {
             int32_t need = 0;
             for (int32_t i = p->gbcode_off[(size_t)t]; i < p->gbcode_off[(size_t)t + 1]; i++) {
                 const BoundInstr &b = p->gbcode[(size_t)i];
@@ -1833,7 +2047,8 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                 if (b.bop == BOP_TERN && b.lo >= (uint32_t)F) need = std::max(need, (int32_t)(b.lo - (uint32_t)F) + 1);
             }
             tslots[(size_t)t] = need;
-        }
+        });
+        dbg_lap("grad threaded: spill slots per tree");
         auto bucket_of = [&](int64_t t) {
             const int32_t G = ng[(size_t)t];
             int w;
@@ -1876,6 +2091,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                 if (tables[b][i] - base > 0xFFFFFFFFull) return DE_OK;
             bases[b] = base;
         }
+        dbg_lap("grad threaded: buckets, handler tables");
         auto leaf_seed = [&](uint32_t f) -> uint32_t { return mode != DE_GRAD_CONSTANT ? (uint32_t)P + f : 0xFFu; };
         auto const_seed = [&](uint32_t ord) -> uint32_t {
             return mode == DE_GRAD_CONSTANT ? ord : (mode == DE_GRAD_BOTH ? (uint32_t)(P + F) + ord : 0xFFu);
@@ -2037,25 +2253,36 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             tree_cnt[(size_t)t] = (int32_t)(out.size() - out_before);
         }
         });
+        dbg_lap("grad threaded: encode (host threads)");
         if (!ok) { p->gtsite_of_gb.clear(); p->site_gen++; return DE_OK; }
         for (int64_t t = 0; t < p->n_trees; t++) p->gtcode_off[(size_t)t + 1] = p->gtcode_off[(size_t)t] + tree_cnt[(size_t)t];
-        p->gtcode.reserve((size_t)p->gtcode_off[(size_t)p->n_trees]);
-        for (int k = 0; k < 16; k++) { // ranges are in tree order; sites move from worker-local to global positions
-            const int32_t base_k = (int32_t)p->gtcode.size();
-            p->gtcode.insert(p->gtcode.end(), parts[k].begin(), parts[k].end());
-            if (base_k != 0 && part_last[k] > part_first[k])
-                for (int32_t i = p->gbcode_off[(size_t)part_first[k]]; i < p->gbcode_off[(size_t)part_last[k]]; i++)
+        p->gtcode.resize((size_t)p->gtcode_off[(size_t)p->n_trees]);
+        // ranges are in tree order; sites move from worker-local to global positions (the same partition as the encoding pass: worker k
+        // copies the piece it encoded)
+        parallel_tree_ranges(p->n_trees, [&](int k, int64_t tb, int64_t te) {
+            if (part_first[k] != tb || part_last[k] != te) return; // (never: the partition depends on n_trees only)
+            const int32_t base_k = p->gtcode_off[(size_t)tb];
+            if (!parts[k].empty()) std::memcpy(static_cast<void *>(p->gtcode.data() + base_k), parts[k].data(), parts[k].size() * sizeof(BoundInstr));
+            if (base_k != 0)
+                for (int32_t i = p->gbcode_off[(size_t)tb]; i < p->gbcode_off[(size_t)te]; i++)
                     if (p->gtsite_of_gb[(size_t)i] >= 0) p->gtsite_of_gb[(size_t)i] += base_k;
+        });
+        {
+            size_t copied = 0;
+            for (int k = 0; k < 16; k++) copied += parts[k].size();
+            if (copied != p->gtcode.size()) { p->gtsite_of_gb.clear(); p->site_gen++; return fail(c, DE_ERR_HIP, "gradient program: the host threads' partitions disagree"); }
         }
+        dbg_lap("grad threaded: concatenate + sites");
         // the handler word of a record names the handler of the record BEHIND it, the end record names the tree's first handler
         // (de_grad_threaded.hip: a handler knows its successor at entry and jumps without waiting for the record it loads)
-        for (int64_t t = 0; t < p->n_trees; t++) {
+        parallel_for_trees(p->n_trees, [&](int64_t t) {
             const int32_t a0 = p->gtcode_off[(size_t)t], b0 = p->gtcode_off[(size_t)t + 1];
-            if (b0 - a0 < 2) continue;
+            if (b0 - a0 < 2) return;
             const uint32_t first = p->gtcode[(size_t)a0].bop;
             for (int32_t i = a0; i < b0 - 1; i++) p->gtcode[(size_t)i].bop = p->gtcode[(size_t)i + 1].bop;
             p->gtcode[(size_t)b0 - 1].bop = first;
-        }
+        });
+        dbg_lap("grad threaded: successor words");
         std::vector<int32_t> ids((size_t)p->n_trees);
         int32_t start[NB], run = 0;
         for (int b = 0; b < NB; b++) { start[b] = run; run += count[b]; }
@@ -2090,6 +2317,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode_off), p->gtcode_off.size() * sizeof(int32_t)));
             HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gt_ids), std::max<size_t>(ids.size(), 1) * sizeof(int32_t)));
         }
+        dbg_lap("grad threaded: ids, hipMalloc, memset");
         HIP_TRY(c, hipStreamSynchronize(c->stream)); // the previous form may be in use by queued work
         if (!p->gtcode.empty())
             HIP_TRY(c, hipMemcpy(p->d_gtcode, p->gtcode.data(), p->gtcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
@@ -2109,6 +2337,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             bk.handler_base = bases[b];
             bk.param_handler_off = (uint32_t)(tables[b][gop_param(WIDTH[b % NW])] - bases[b]);
         }
+        dbg_lap("grad threaded: upload");
         p->gt_mode = mode;
         p->gt_wide = wide;
         p->gt_valid = true;

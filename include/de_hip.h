@@ -247,6 +247,11 @@ int64_t de_program_dump(const de_program_t *prog, int64_t tree, uint32_t *words,
  * (samples past N are clamped to N - 1 and not stored). */
 int de_program_verify(const de_program_t *prog);
 
+/* Test hook: a 64-bit hash over every host-side stream and table de_program_create built for this program (and its auxiliary
+ * program of constant subtrees).  The per-tree passes of a creation run on a pool of host threads (DE_HOST_THREADS caps them,
+ * 1 = serial) and must build exactly what one thread builds: equal hashes, whatever the thread count.  0 for a null program. */
+uint64_t de_program_stream_hash(const de_program_t *prog);
+
 /* Host-only hook (makes no HIP call, works without a GPU): lower ONE tape and
  * return its instruction words (4 x uint32 each, csrc/de_program.h) in `words`
  * (capacity `cap` words).  meta[4] = {spill slots, host part of the eval flag,

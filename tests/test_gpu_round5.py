@@ -282,3 +282,49 @@ def test_contexts_on_two_devices_with_the_other_device_current(api):
         pop.close()
         ctx.close()
     torch.cuda.set_device(0)
+
+
+@pytest.mark.parametrize("kind", ["plain", "parametric", "graph"])
+def test_program_creation_on_host_threads_builds_what_one_thread_builds(api, monkeypatch, kind):
+    """de_program_create runs every per-tree pass (lowering, merge, bind, superinstructions, record chaining, constant sites) on a pool of
+    host threads: the streams must be those of DE_HOST_THREADS=1, byte for byte (de_program_stream_hash covers every host-side stream and
+    the auxiliary program of constant subtrees), and evaluate to the same bits."""
+    from dynamicexpressions_jl_amd.node import GraphNode
+    n = 3000  # 11 ranges of the pool (>= 256 trees per thread)
+    if kind == "parametric":
+        ops = de.synth.BENCH_OPERATORS
+        trees = de.synth.random_population(n, seed=0xDE05, node_type=de.ParametricNode, nparams=8)
+        kw = dict(n_features=5, n_params=8)
+    elif kind == "graph":
+        ops = de.synth.BENCH_OPERATORS
+        base = de.synth.random_population(n, seed=77, node_type=GraphNode)
+        trees = []
+        for i, t in enumerate(base):  # a shared subtree in every other tree: (t) op (t) with ONE object on both sides
+            trees.append(GraphNode(1 + i % 4, t, t) if i % 2 else t)
+        kw = dict(n_features=5)
+    else:
+        ops = de.OperatorEnum(binary_operators=("+", "-", "/", "*", "max"), unary_operators=("cos", "exp", "sin", "safe_log", "abs", "tanh"))
+        rng = de.synth.Xoshiro256ss(5)
+        trees = [de.synth.gen_random_tree_fixed_size(1 + i % 30, ops, 5, rng, np.float32) for i in range(n)]
+        kw = dict(n_features=5)
+    X = de.synth.random_X(5, 700, seed=3)
+    rng = np.random.default_rng(1)
+    params = rng.standard_normal((8, 4)).astype(np.float32) if kind == "parametric" else None
+    classes = rng.integers(1, 5, size=700).astype(np.int32) if kind == "parametric" else None
+    res = {}
+    for threads in ("1", None, "5"):
+        if threads is None:
+            monkeypatch.delenv("DE_HOST_THREADS", raising=False)
+        else:
+            monkeypatch.setenv("DE_HOST_THREADS", threads)
+        pop = api.Population(trees, ops, np.float32, **kw)
+        pop.verify()
+        out, ok = pop.eval(X, params, classes) if kind == "parametric" else pop.eval(X)
+        res[threads] = (pop.stream_hash(), np.asarray(out).copy(), np.asarray(ok).copy())
+        pop.close()
+    h1, o1, k1 = res["1"]
+    assert h1 != 0
+    for threads in (None, "5"):
+        h, o, k = res[threads]
+        assert h == h1, f"DE_HOST_THREADS={threads}: the streams differ from the serial build's"
+        assert np.array_equal(k, k1) and np.array_equal(o[k1].view(np.uint32), o1[k1].view(np.uint32))
