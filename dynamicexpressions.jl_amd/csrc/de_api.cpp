@@ -58,6 +58,16 @@ struct de_ctx {
     uint64_t ring_at = 0;
     std::string err;
     const char *last_kernel = "";
+    // Device buffers of destroyed programs, recycled (round 5): a search loop creates and destroys a program per generation, and hipFree
+    // of a multi-megabyte buffer takes 0.3 - 0.5 ms (10^4 trees: de_program_destroy 1.9 ms of a 10 ms generation).  Instruction streams
+    // of >= PROG_RECYCLE_MIN bytes are allocated in 1 MiB granules through prog_malloc and parked here by prog_free; at most
+    // PROG_RECYCLE_MAX of them / PROG_RECYCLE_BYTES in total, the rest is freed.  DE_NO_PROG_RECYCLE=1: plain hipMalloc / hipFree.
+    std::vector<std::pair<void *, size_t>> recycled;
+    std::map<void *, size_t> big_live; // granule-sized allocations in use (their sizes)
+    // ... and the HOST side of destroyed programs: `delete` of a 10^4-tree program is 1.5 ms of munmap (its ~40 vectors are tens of
+    // megabytes), and the next creation faults the same pages in again.  Up to four destroyed programs are parked with their vectors
+    // cleared; a creation takes the vectors' capacity over (park_program / adopt_parked).
+    std::vector<struct de_program *> parked;
     DevBuf sX, sOut, sGrad, sOk, sParams, sClasses, sOut2, sGoff, sNg, sY, sW, sLoss, sPartial, sSeg, sDloss, sColOff, sDoff, sPrio;
     DevBuf sCert; // de_eval_sum_certificate: per-tree maxima
     DevBuf sBcLoss, sBcDloss, sBcOk, sBcNg, sBcDoff, sBcOut, sBcTiles; // de_eval_loss_grad_by_class
@@ -396,6 +406,93 @@ static void build_stream_by_trees(int64_t n_trees, std::vector<Rec> *stream, std
             std::memcpy(static_cast<void *>(stream->data() + (*off)[(size_t)first[k]]), parts[k].data(), parts[k].size() * sizeof(Rec));
 }
 
+static void dbg_lap(const char *what);
+// ---- program buffers: recycled across de_program_destroy / de_program_create (see de_ctx::recycled) ----
+static constexpr size_t PROG_RECYCLE_MIN = 256u << 10, PROG_RECYCLE_BYTES = 256u << 20, PROG_RECYCLE_MAX = 12;
+static bool prog_recycle_enabled() {
+    static const bool on = [] { const char *v = getenv("DE_NO_PROG_RECYCLE"); return !(v && *v == '1'); }();
+    return on;
+}
+static hipError_t prog_malloc(de_ctx *c, void **out, size_t bytes) {
+    *out = nullptr;
+    if (bytes < PROG_RECYCLE_MIN || !prog_recycle_enabled()) return hipMalloc(out, bytes);
+    const size_t need = (bytes + 0xFFFFFu) & ~(size_t)0xFFFFFu;
+    int best = -1;
+    for (int i = 0; i < (int)c->recycled.size(); i++) {
+        const size_t sz = c->recycled[(size_t)i].second;
+        if (sz >= need && sz <= 2 * need && (best < 0 || sz < c->recycled[(size_t)best].second)) best = i;
+    }
+    if (best >= 0) {
+        *out = c->recycled[(size_t)best].first;
+        c->big_live[*out] = c->recycled[(size_t)best].second;
+        c->recycled.erase(c->recycled.begin() + best);
+        return hipSuccess;
+    }
+    const hipError_t st = hipMalloc(out, need);
+    if (st == hipSuccess) c->big_live[*out] = need;
+    return st;
+}
+// (the caller has synchronised the context's stream: nothing queued reads the buffer any more)
+static void prog_free(de_ctx *c, void *ptr) {
+    if (!ptr) return;
+    auto it = c->big_live.find(ptr);
+    if (it == c->big_live.end()) { (void)hipFree(ptr); return; }
+    const size_t sz = it->second;
+    c->big_live.erase(it);
+    size_t held = 0;
+    for (const auto &r : c->recycled) held += r.second;
+    if (c->recycled.size() >= PROG_RECYCLE_MAX || held + sz > PROG_RECYCLE_BYTES) {
+        // make room by dropping the oldest entry; a buffer larger than the whole budget is simply freed
+        if (sz > PROG_RECYCLE_BYTES) { (void)hipFree(ptr); return; }
+        while (!c->recycled.empty() && (c->recycled.size() >= PROG_RECYCLE_MAX || held + sz > PROG_RECYCLE_BYTES)) {
+            held -= c->recycled.front().second;
+            (void)hipFree(c->recycled.front().first);
+            c->recycled.erase(c->recycled.begin());
+        }
+    }
+    c->recycled.emplace_back(ptr, sz);
+}
+
+// The host vectors of a program that keep their capacity across a destroy / create pair.  A member missing here is merely allocated afresh.
+#define DE_PROGRAM_VECTORS(X) \
+    X(code) X(code_off) X(const_off) X(const_instr) X(const_checks) X(n_consts_tree) X(host_ok_eval) X(host_ok_grad) X(consts) X(fcode) \
+    X(fcode_off) X(fconst_instr) X(folds) X(aux_const_src) X(fold_ok) X(bcode) X(tcode) X(fbcode) X(tcode_off) X(ccode) X(ccode_off) \
+    X(bcode_off) X(gbcode) X(gbcode_off) X(gtcode) X(gtcode_off) X(bsite) X(tsite) X(gbsite) X(gtsite_of_gb) X(rtcode) X(rtcode_off) \
+    X(rtcode_mid) X(rtsite_of_gb)
+static constexpr size_t PARKED_MAX = 4, PARKED_BYTES = 512u << 20;
+static size_t program_host_bytes(const de_program *p) {
+    size_t b = 0;
+#define X(v) b += p->v.capacity() * sizeof(p->v[0]);
+    DE_PROGRAM_VECTORS(X)
+#undef X
+    return b;
+}
+// de_program_destroy's last step (device buffers are gone, `aux` is destroyed): park the shell or delete it
+static void park_program(de_ctx *c, de_program *p) {
+    size_t held = 0;
+    for (const de_program *q : c->parked) held += program_host_bytes(q);
+    if (!prog_recycle_enabled() || c->parked.size() >= PARKED_MAX || held + program_host_bytes(p) > PARKED_BYTES) { delete p; return; }
+#define X(v) p->v.clear();
+    DE_PROGRAM_VECTORS(X)
+#undef X
+    c->parked.push_back(p);
+}
+// a fresh (default-constructed) program takes over the vectors of the parked shell whose capacity is the largest
+static void adopt_parked(de_ctx *c, de_program *fresh) {
+    if (c->parked.empty()) return;
+    size_t best = 0, best_b = 0;
+    for (size_t i = 0; i < c->parked.size(); i++) {
+        const size_t b = program_host_bytes(c->parked[i]);
+        if (b >= best_b) { best = i; best_b = b; }
+    }
+    de_program *old = c->parked[best];
+    c->parked.erase(c->parked.begin() + (long)best);
+#define X(v) fresh->v.swap(old->v);
+    DE_PROGRAM_VECTORS(X)
+#undef X
+    delete old;
+}
+
 extern "C" {
 
 int de_abi_version(void) { return DE_HIP_ABI_VERSION; }
@@ -474,6 +571,10 @@ int de_ctx_destroy(de_ctx_t *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff, &c->sPrio, &c->sPrioDs, &c->sCert, &c->sBcLoss, &c->sBcDloss, &c->sBcOk, &c->sBcNg, &c->sBcDoff, &c->sBcOut, &c->sBcTiles}) b->release();
+    for (const auto &r : c->recycled) (void)hipFree(r.first);
+    c->recycled.clear();
+    for (de_program *q : c->parked) delete q;
+    c->parked.clear();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (hipEvent_t e : c->ring) (void)hipEventDestroy(e);
@@ -891,6 +992,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
     if (n_trees > 0x7fffffff) return fail(ctx, DE_ERR_UNSUPPORTED, "too many trees");
     std::unique_ptr<de_program> p(new (std::nothrow) de_program());
     if (!p) return fail(ctx, DE_ERR_HIP, "out of host memory");
+    adopt_parked(ctx, p.get());
     // DE_DEBUG_TIMING: microseconds per phase of the creation on stderr (tools/bench_create.py)
     const bool timing = getenv("DE_DEBUG_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -1150,14 +1252,14 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         hipError_t ast = hipSuccess;
         const size_t abytes = p->threaded ? 2 * cbytes : cbytes;
         for (;;) {
-            ast = hipMalloc(reinterpret_cast<void **>(&p->d_code), abytes);
+            ast = prog_malloc(ctx, reinterpret_cast<void **>(&p->d_code), abytes);
             if (ast != hipSuccess) break;
             const uint64_t a0 = (uint64_t)(uintptr_t)p->d_code, a1 = a0 + abytes - 1;
             if ((a0 >> 32) == (a1 >> 32) || n_rej == 4) break;
             rejected[n_rej++] = p->d_code;
             p->d_code = nullptr;
         }
-        for (int k = 0; k < n_rej; k++) (void)hipFree(rejected[k]);
+        for (int k = 0; k < n_rej; k++) prog_free(ctx, rejected[k]);
         if (ast != hipSuccess) return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(ast));
         const uint64_t a0 = (uint64_t)(uintptr_t)p->d_code;
         if ((a0 >> 32) != ((a0 + abytes - 1) >> 32)) return fail(ctx, DE_ERR_HIP, "instruction stream straddles a 4 GiB boundary");
@@ -1174,7 +1276,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
     HIP_TRY(ctx, hipMemset(p->d_code, 0, cbytes));
     hipError_t st = hipMalloc(reinterpret_cast<void **>(&p->d_code_off), p->bcode_off.size() * sizeof(int32_t));
     if (st != hipSuccess) {
-        (void)hipFree(p->d_code);
+        prog_free(ctx, p->d_code);
         return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(st));
     }
     if (!p->bcode.empty())
@@ -1184,7 +1286,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         st = hipMemcpy(p->d_code_off, (p->threaded ? p->ccode_off : p->bcode_off).data(), p->bcode_off.size() * sizeof(int32_t),
                        hipMemcpyHostToDevice);
     if (st != hipSuccess) {
-        (void)hipFree(p->d_code);
+        prog_free(ctx, p->d_code);
         (void)hipFree(p->d_code_off);
         return fail(ctx, DE_ERR_HIP, "program upload failed: %s", hipGetErrorString(st));
     }
@@ -1330,24 +1432,33 @@ static int set_consts_impl(de_program_t *p, const void *consts) {
 int de_program_destroy(de_program_t *p) {
     if (!p) return DE_OK;
     (void)hipSetDevice(p->ctx->device);
+    dbg_lap(nullptr);
     (void)hipStreamSynchronize(p->ctx->stream);
-    if (p->d_code) (void)hipFree(p->d_code);
+    de_ctx *c = p->ctx;
+    dbg_lap("destroy: stream sync");
+    prog_free(c, p->d_code);
     if (p->d_code_off) (void)hipFree(p->d_code_off);
     if (p->d_compact_ints) (void)hipFree(p->d_compact_ints);
     if (p->d_cert_code) (void)hipFree(p->d_cert_code);
     if (p->d_cert_off) (void)hipFree(p->d_cert_off);
+    dbg_lap("destroy: eval streams");
     if (p->aux) de_program_destroy(p->aux);
-    if (p->d_gcode) (void)hipFree(p->d_gcode);
+    dbg_lap(nullptr);
+    prog_free(c, p->d_gcode);
     if (p->d_gcode_off) (void)hipFree(p->d_gcode_off);
-    if (p->d_gtcode) (void)hipFree(p->d_gtcode);
+    prog_free(c, p->d_gtcode);
     if (p->d_gtcode_off) (void)hipFree(p->d_gtcode_off);
     if (p->d_gt_ids) (void)hipFree(p->d_gt_ids);
-    for (void *q : {(void *)p->d_rtcode, (void *)p->d_rtcode_off, (void *)p->d_rtcode_mid, (void *)p->d_rt_ids})
+    prog_free(c, p->d_rtcode);
+    for (void *q : {(void *)p->d_rtcode_off, (void *)p->d_rtcode_mid, (void *)p->d_rt_ids})
         if (q) (void)hipFree(q);
     if (p->d_ok_eval) (void)hipFree(p->d_ok_eval);
     for (void *q : {(void *)p->d_ok_grad, (void *)p->d_ng, (void *)p->d_goff})
         if (q) (void)hipFree(q);
-    delete p;
+    dbg_lap("destroy: gradient streams, flags");
+    p->aux = nullptr;
+    park_program(c, p);
+    dbg_lap("destroy: host vectors");
     return DE_OK;
 }
 
@@ -1984,7 +2095,7 @@ static int ensure_generic_code(de_ctx *c, de_program *p) {
         p->site_gen++;
     }
     if (!p->d_gcode) {
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gcode), (p->gbcode.size() + 1) * sizeof(BoundInstr)));
+        HIP_TRY(c, prog_malloc(c, reinterpret_cast<void **>(&p->d_gcode), (p->gbcode.size() + 1) * sizeof(BoundInstr)));
         HIP_TRY(c, hipMemset(p->d_gcode, 0, (p->gbcode.size() + 1) * sizeof(BoundInstr)));
         HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gcode_off), p->gbcode_off.size() * sizeof(int32_t)));
         HIP_TRY(c, hipMemcpy(p->d_gcode_off, p->gbcode_off.data(), p->gbcode_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -2301,14 +2412,14 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                 int n_rej = 0;
                 hipError_t ast = hipSuccess;
                 for (;;) {
-                    ast = hipMalloc(reinterpret_cast<void **>(&p->d_gtcode), gt_cap * sizeof(BoundInstr));
+                    ast = prog_malloc(c, reinterpret_cast<void **>(&p->d_gtcode), gt_cap * sizeof(BoundInstr));
                     if (ast != hipSuccess) break;
                     const uint64_t a0 = (uint64_t)(uintptr_t)p->d_gtcode, a1 = a0 + gt_cap * sizeof(BoundInstr) - 1;
                     if ((a0 >> 32) == (a1 >> 32) || n_rej == 4) break;
                     rejected[n_rej++] = p->d_gtcode;
                     p->d_gtcode = nullptr;
                 }
-                for (int k = 0; k < n_rej; k++) (void)hipFree(rejected[k]);
+                for (int k = 0; k < n_rej; k++) prog_free(c, rejected[k]);
                 if (ast != hipSuccess) return fail(c, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(ast));
                 const uint64_t a0 = (uint64_t)(uintptr_t)p->d_gtcode;
                 if ((a0 >> 32) != ((a0 + gt_cap * sizeof(BoundInstr) - 1) >> 32)) return fail(c, DE_ERR_HIP, "gradient instruction stream straddles a 4 GiB boundary");
@@ -2775,7 +2886,7 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream)); // the previous form may be in use by queued work
         if (p->d_rtcode) { // sizes depend on the mode
-            (void)hipFree(p->d_rtcode);
+            prog_free(c, p->d_rtcode);
             p->d_rtcode = nullptr;
         }
         { // (inside one 4 GiB window: the handlers bump the record pointer without a carry)
@@ -2784,14 +2895,14 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
             int n_rej = 0;
             hipError_t ast = hipSuccess;
             for (;;) {
-                ast = hipMalloc(reinterpret_cast<void **>(&p->d_rtcode), rbytes);
+                ast = prog_malloc(c, reinterpret_cast<void **>(&p->d_rtcode), rbytes);
                 if (ast != hipSuccess) break;
                 const uint64_t a0 = (uint64_t)(uintptr_t)p->d_rtcode;
                 if ((a0 >> 32) == ((a0 + rbytes - 1) >> 32) || n_rej == 4) break;
                 rejected[n_rej++] = p->d_rtcode;
                 p->d_rtcode = nullptr;
             }
-            for (int k = 0; k < n_rej; k++) (void)hipFree(rejected[k]);
+            for (int k = 0; k < n_rej; k++) prog_free(c, rejected[k]);
             if (ast != hipSuccess) return fail(c, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(ast));
             const uint64_t a0 = (uint64_t)(uintptr_t)p->d_rtcode;
             if ((a0 >> 32) != ((a0 + rbytes - 1) >> 32)) return fail(c, DE_ERR_HIP, "reverse instruction stream straddles a 4 GiB boundary");
