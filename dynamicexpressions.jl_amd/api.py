@@ -45,7 +45,7 @@ EXPORTS = [
     "de_opcode_degree", "de_status_string", "de_ctx_create", "de_ctx_destroy", "de_ctx_set_stream",
     "de_ctx_synchronize", "de_ctx_declare_dataset", "de_ctx_stream", "de_last_error", "de_program_create", "de_program_create_cse",
     "de_program_set_consts", "de_program_destroy", "de_program_n_trees", "de_program_n_nodes",
-    "de_program_n_grad", "de_program_dump", "de_program_verify", "de_program_stream_hash", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad", "de_eval_loss_grad_by_class",
+    "de_program_n_grad", "de_program_dump", "de_program_verify", "de_program_stream_hash", "de_host_pool_selftest", "de_lower_tape", "de_lower_tape_stage", "de_eval", "de_eval_grad", "de_eval_diff", "de_eval_loss", "de_eval_loss_grad", "de_eval_loss_grad_by_class",
     "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_prio_tiles_wanted", "de_program_last_live_trees", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size", "de_dist_world_size",
     "de_dist_broadcast", "de_dist_gather_flags", "de_dist_last_error", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
     "de_ctx_device", "de_ctx_timing_ring", "de_ctx_timing_read", "de_dist_reorder_selftest", "de_eval_sum_certificate",
@@ -114,6 +114,8 @@ def library() -> C.CDLL:
     lib.de_program_n_grad.restype = i64
     lib.de_program_n_grad.argtypes = [vp, i64, C.c_int]
     lib.de_program_verify.argtypes = [vp]
+    lib.de_host_pool_selftest.restype = C.c_int64
+    lib.de_host_pool_selftest.argtypes = [C.c_int64, C.POINTER(C.c_int32)]
     lib.de_program_stream_hash.restype = C.c_uint64
     lib.de_program_stream_hash.argtypes = [vp]
     lib.de_program_dump.restype = i64

@@ -1,6 +1,7 @@
 // de_api.cpp — the C ABI of libde_hip.so (include/de_hip.h): contexts, population
 // programs, evaluation entry points.  No exception leaves this file.
 #include <hip/hip_runtime.h>
+#include <pthread.h>
 
 #include <chrono>
 #include <cmath>
@@ -321,7 +322,17 @@ struct HostPool {
         return true;
     }
 };
-HostPool &host_pool() { static HostPool *p = new HostPool(); return *p; } // (never destroyed: its threads are detached)
+// (never destroyed: its threads are detached.  A fork()ed child has none of them: it starts with a pool of its own.)
+HostPool *g_host_pool = nullptr;
+HostPool &host_pool() {
+    static const bool once = [] {
+        g_host_pool = new HostPool();
+        (void)pthread_atfork(nullptr, nullptr, [] { g_host_pool = new HostPool(); });
+        return true;
+    }();
+    (void)once;
+    return *g_host_pool;
+}
 unsigned host_threads_for(int64_t n) {
     const unsigned hw = std::thread::hardware_concurrency();
     const char *env = getenv("DE_HOST_THREADS");
@@ -1495,6 +1506,24 @@ int de_eval_plan(const de_program_t *p, int64_t N, int32_t *plan) {
     if (!p || !plan || N < 0) return DE_ERR_INVALID_ARG;
     eval_plan(p->dtype, p->n_trees, N, &plan[0], &plan[1], &plan[2]);
     return DE_OK;
+}
+
+// Host-only test hook (no HIP call): n items over the pool of host threads that de_program_create's per-tree passes run on; returns how
+// many items were visited exactly once (n when all is well), *n_ranges = the ranges the items were split into (1 = ran inline).
+int64_t de_host_pool_selftest(int64_t n, int32_t *n_ranges) {
+    if (n < 0) return -1;
+    std::vector<uint8_t> hit((size_t)n, 0);
+    std::atomic<int32_t> ranges{0};
+    try {
+        parallel_tree_ranges(n, [&](int, int64_t b, int64_t e) {
+            ranges.fetch_add(1);
+            for (int64_t i = b; i < e; i++) hit[(size_t)i]++;
+        });
+    } catch (const std::bad_alloc &) { return -1; }
+    if (n_ranges) *n_ranges = ranges.load();
+    int64_t once = 0;
+    for (uint8_t h : hit) once += h == 1;
+    return once;
 }
 
 // Test hook: one number over every HOST-side stream and table de_program_create built (generic, folded, bound, fused, threaded and chained

@@ -252,6 +252,11 @@ int de_program_verify(const de_program_t *prog);
  * 1 = serial) and must build exactly what one thread builds: equal hashes, whatever the thread count.  0 for a null program. */
 uint64_t de_program_stream_hash(const de_program_t *prog);
 
+/* Host-only test hook (no HIP call): runs n items over the pool of host threads the per-tree passes of de_program_create use and
+ * returns how many were visited exactly once (== n); *n_ranges (may be NULL) = the ranges they were split into.  The pool is one per
+ * process, its threads are detached; a fork()ed child starts a pool of its own. */
+int64_t de_host_pool_selftest(int64_t n, int32_t *n_ranges);
+
 /* Host-only hook (makes no HIP call, works without a GPU): lower ONE tape and
  * return its instruction words (4 x uint32 each, csrc/de_program.h) in `words`
  * (capacity `cap` words).  meta[4] = {spill slots, host part of the eval flag,
