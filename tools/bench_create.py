@@ -13,13 +13,14 @@ lib = api.library()
 NROWS = 1000
 X = torch.from_numpy(np.ascontiguousarray(np.asarray(de.synth.random_X(5, NROWS, seed=1, dtype=np.float32)).T)).cuda()
 torch.cuda.synchronize()
-for nt in (1000, 10000):
+import os
+for nt in [int(float(v)) for v in os.environ.get('NTREES', '1e3,1e4').split(',')]:
     trees = de.synth.random_population(nt, seed=0xDE02)
     out = torch.empty((nt, NROWS), device="cuda", dtype=torch.float32)
     ok = torch.empty(nt, device="cuda", dtype=torch.uint8)
     yv = torch.randn(NROWS, device="cuda", dtype=torch.float32)
     lossv = torch.empty(nt, device="cuda", dtype=torch.float32)
-    dlossv = torch.empty(nt * 20, device="cuda", dtype=torch.float32)
+    dlossv = torch.empty(nt * 20 + 16, device="cuda", dtype=torch.float32)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tape, noff, consts, coff = de.flatten_population(trees, ops, np.float32)
