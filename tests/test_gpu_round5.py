@@ -369,3 +369,44 @@ def test_recycled_program_buffers_leave_no_trace(api):
             assert np.array_equal(got[3][want[5]].view(ui), want[3][want[5]].view(ui))
             assert np.array_equal(got[4].view(ui), want[4].view(ui))
     shared.close()
+
+
+def test_two_host_threads_create_programs_at_once(api):
+    """One context per calling thread (SURVEY §8b threading): two host threads create, evaluate and destroy populations at the same time —
+    one of them owns the pool of host threads, the other runs its per-tree passes inline in the same partition.  Every program must be the
+    one a quiet process builds (stream hash) and evaluate to the same bits."""
+    import threading
+    ops = de.synth.BENCH_OPERATORS
+    X = de.synth.random_X(5, 600, seed=9)
+    pops = [de.synth.random_population(1500 + 100 * k, seed=40 + k) for k in range(4)]
+    quiet = []
+    ctx0 = api.Context(0)
+    for trees in pops:
+        p = api.Population(trees, ops, np.float32, n_features=5, ctx=ctx0)
+        out, ok = p.eval(X)
+        quiet.append((p.stream_hash(), np.asarray(out).copy(), np.asarray(ok).copy()))
+        p.close()
+    ctx0.close()
+    errors = []
+
+    def worker(order):
+        try:
+            ctx = api.Context(0)
+            for rep in range(3):
+                for k in order:
+                    p = api.Population(pops[k], ops, np.float32, n_features=5, ctx=ctx)
+                    out, ok = p.eval(X)
+                    h, o, q = quiet[k]
+                    if p.stream_hash() != h or not np.array_equal(np.asarray(ok), q) or \
+                            not np.array_equal(np.asarray(out)[q].view(np.uint32), o[q].view(np.uint32)):
+                        errors.append((k, rep))
+                    p.close()
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    th = [threading.Thread(target=worker, args=(o,)) for o in ([0, 1, 2, 3], [3, 2, 1, 0], [1, 3, 0, 2])]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
