@@ -257,6 +257,7 @@ static const OpName kOps[] = {
 // the lowering — merge, bind, superinstructions, record chaining — were 80 % of a creation).  One persistent pool per process (spawning
 // 16 threads costs ~0.3 ms, a creation has ~10 parallel regions); one region at a time — a second context asking meanwhile runs its
 // ranges inline, in the same partition, so the result never depends on who ran it.  DE_HOST_THREADS=n caps the workers (1 = serial).
+constexpr int HOST_RANGES_MAX = 32; // ranges of one parallel pass (per-worker vectors are arrays of this size)
 namespace {
 struct HostPool {
     std::mutex region;                 // held for the duration of a parallel region
@@ -336,15 +337,16 @@ HostPool &host_pool() {
 unsigned host_threads_for(int64_t n) {
     const unsigned hw = std::thread::hardware_concurrency();
     const char *env = getenv("DE_HOST_THREADS");
-    unsigned nt = env && *env ? (unsigned)atoi(env) : std::min(hw ? hw : 1u, 16u);
-    nt = std::min(nt, 16u);
+    // 10^4 / 10^5 trees on a 256-core box: 8 threads 8.3 / 88 ms, 16: 7.0 / 68, 24: 5.2 / 53, 32: 5.3 / 50 (best of 6, shared host)
+    unsigned nt = env && *env ? (unsigned)atoi(env) : (hw >= 48 ? 24u : std::min(hw ? hw : 1u, 16u));
+    nt = std::min(nt, (unsigned)HOST_RANGES_MAX);
     static const int64_t min_trees = [] { const char *v = getenv("DE_HOST_MIN_TREES"); const int64_t m = v && *v ? atoll(v) : 32; return m < 1 ? 1 : m; }();
     if ((int64_t)nt > n / min_trees) nt = (unsigned)(n / min_trees); // (a woken pool thread costs ~10 us, 32 trees are ~50 us of a pass: 10^3 trees 2.3 -> 1.4 ms against a floor of 256)
     return nt;
 }
 } // namespace
 
-// The trees in contiguous ranges, one per worker: f(k, b, e) with k < 16 — for passes that append to a per-worker vector which is
+// The trees in contiguous ranges, one per worker: f(k, b, e) with k < HOST_RANGES_MAX — for passes that append to a per-worker vector which is
 // concatenated afterwards, or that write disjoint slices of pre-sized vectors.  The partition depends on n and the thread count only.
 template <class F> static void parallel_tree_ranges(int64_t n, F f) {
     const unsigned nt = host_threads_for(n);
@@ -394,9 +396,9 @@ static bool match_const_sites(const std::vector<Instr> &src, const std::vector<i
 // concatenated in tree order and off[t] .. off[t + 1] names tree t's records — the stream a serial loop over the trees would have built.
 template <class Rec, class Emit>
 static void build_stream_by_trees(int64_t n_trees, std::vector<Rec> *stream, std::vector<int32_t> *off, Emit emit) {
-    std::vector<Rec> parts[16];
-    int64_t first[16], last[16];
-    for (int k = 0; k < 16; k++) first[k] = last[k] = 0;
+    std::vector<Rec> parts[HOST_RANGES_MAX];
+    int64_t first[HOST_RANGES_MAX], last[HOST_RANGES_MAX];
+    for (int k = 0; k < HOST_RANGES_MAX; k++) first[k] = last[k] = 0;
     std::vector<int32_t> cnt((size_t)n_trees, 0);
     parallel_tree_ranges(n_trees, [&](int k, int64_t tb, int64_t te) {
         std::vector<Rec> &out = parts[k];
@@ -412,7 +414,7 @@ static void build_stream_by_trees(int64_t n_trees, std::vector<Rec> *stream, std
     for (int64_t t = 0; t < n_trees; t++) (*off)[(size_t)t + 1] = (*off)[(size_t)t] + cnt[(size_t)t];
     stream->clear();
     stream->resize((size_t)(*off)[(size_t)n_trees]);
-    for (int k = 0; k < 16; k++) // (a few MB: memcpy-bound, kept serial)
+    for (int k = 0; k < HOST_RANGES_MAX; k++) // (a few MB: memcpy-bound, kept serial)
         if (last[k] > first[k] && !parts[k].empty())
             std::memcpy(static_cast<void *>(stream->data() + (*off)[(size_t)first[k]]), parts[k].data(), parts[k].size() * sizeof(Rec));
 }
@@ -1102,7 +1104,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                 p->code_off[(size_t)t + 1] = (int32_t)total;
             }
             p->code.resize((size_t)total);
-            struct Part { int32_t n_slots = 0; bool cse = false, params = false; int64_t nodes = 0; } part[16];
+            struct Part { int32_t n_slots = 0; bool cse = false, params = false; int64_t nodes = 0; } part[HOST_RANGES_MAX];
             parallel_tree_ranges(n_trees, [&](int wk, int64_t tb, int64_t te) {
                 Part &pt = part[wk];
                 for (int64_t t = tb; t < te; t++) {
@@ -1171,7 +1173,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
             anoff.assign(n_folds + 1, 0);
             acoff.assign(n_folds + 1, 0);
             // ... the copies on the host threads
-            struct PartF { int32_t n_slots = 0; bool cse = false; } partf[16];
+            struct PartF { int32_t n_slots = 0; bool cse = false; } partf[HOST_RANGES_MAX];
             parallel_tree_ranges(n_trees, [&](int wk, int64_t tb, int64_t te) {
                 PartF &pt = partf[wk];
                 for (int64_t t = tb; t < te; t++) {
@@ -2242,10 +2244,10 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         p->site_gen++;
         std::atomic<bool> ok{true};
         // encoded per worker into a vector of its own (sites = positions in that vector), concatenated afterwards
-        std::vector<BoundInstr> parts[16];
+        std::vector<BoundInstr> parts[HOST_RANGES_MAX];
         std::vector<int32_t> tree_cnt((size_t)p->n_trees, 0);
-        int64_t part_first[16], part_last[16];
-        for (int k = 0; k < 16; k++) part_first[k] = part_last[k] = 0;
+        int64_t part_first[HOST_RANGES_MAX], part_last[HOST_RANGES_MAX];
+        for (int k = 0; k < HOST_RANGES_MAX; k++) part_first[k] = part_last[k] = 0;
         parallel_tree_ranges(p->n_trees, [&](int wk, int64_t tb, int64_t te) {
         std::vector<BoundInstr> &out = parts[wk];
         part_first[wk] = tb;
@@ -2409,7 +2411,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         });
         {
             size_t copied = 0;
-            for (int k = 0; k < 16; k++) copied += parts[k].size();
+            for (int k = 0; k < HOST_RANGES_MAX; k++) copied += parts[k].size();
             if (copied != p->gtcode.size()) { p->gtsite_of_gb.clear(); p->site_gen++; return fail(c, DE_ERR_HIP, "gradient program: the host threads' partitions disagree"); }
         }
         dbg_lap("grad threaded: concatenate + sites");
