@@ -259,6 +259,7 @@ static const OpName kOps[] = {
 // ranges inline, in the same partition, so the result never depends on who ran it.  DE_HOST_THREADS=n caps the workers (1 = serial).
 constexpr int HOST_RANGES_MAX = 32; // ranges of one parallel pass (per-worker vectors are arrays of this size)
 namespace {
+thread_local bool in_job = false;      // this thread is running a job of a parallel region
 struct HostPool {
     std::mutex region;                 // held for the duration of a parallel region
     std::mutex m;
@@ -280,7 +281,9 @@ struct HostPool {
             }
             if (!j) continue;
             bool bad = false;
+            in_job = true;
             try { (*j)(id + 1); } catch (...) { bad = true; }
+            in_job = false;
             {
                 const std::lock_guard<std::mutex> lk(m);
                 failed = failed || bad;
@@ -297,6 +300,7 @@ struct HostPool {
     }
     // job(k) for k = 0 .. n - 1, job(0) on the calling thread; false = the pool is busy or could not start threads: nothing was run
     bool run(int n, const std::function<void(int)> &f) {
+        if (in_job) return false; // a pass started from inside a job (never done today) runs inline instead of locking `region` twice
         std::unique_lock<std::mutex> rl(region, std::try_to_lock);
         if (!rl.owns_lock()) return false;
         ensure(n - 1);
@@ -311,7 +315,9 @@ struct HostPool {
         }
         cv_work.notify_all();
         bool bad = false;
+        in_job = true;
         try { f(0); } catch (...) { bad = true; }
+        in_job = false;
         {
             std::unique_lock<std::mutex> lk(m);
             cv_done.wait(lk, [&] { return pending == 0; });
@@ -505,6 +511,14 @@ static void adopt_parked(de_ctx *c, de_program *fresh) {
 #undef X
     delete old;
 }
+
+// No exception leaves this file: the gradient entry points build host vectors (and run passes on the host pool, which reports a worker's
+// failure as std::bad_alloc) — an allocation failure becomes a status like everywhere else.
+#define DE_NOTHROW(CTX, CALL)                                                                   \
+    do {                                                                                        \
+        try { return (CALL); }                                                                  \
+        catch (const std::bad_alloc &) { return fail((CTX), DE_ERR_HIP, "out of host memory"); } \
+    } while (0)
 
 extern "C" {
 
@@ -3188,7 +3202,7 @@ static int loss_grad_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N
 int de_eval_loss_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
                       int mode, const void *y, const void *w, int32_t loss_kind, void *loss, void *dloss,
                       const int64_t *dloss_offsets, uint8_t *ok) {
-    return loss_grad_impl(c, p, X, N, ldX, pa, mode, y, w, loss_kind, loss, dloss, dloss_offsets, ok, nullptr);
+    DE_NOTHROW(c, loss_grad_impl(c, p, X, N, ldX, pa, mode, y, w, loss_kind, loss, dloss, dloss_offsets, ok, nullptr));
 }
 static int loss_grad_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
                           int mode, const void *y, const void *w, int32_t loss_kind, void *loss, void *dloss,
@@ -3394,7 +3408,17 @@ static int loss_grad_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N
     return DE_OK;
 }
 
+static int by_class_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX,
+                               const de_param_args_t *pa, int mode, const void *y, const void *w, int32_t loss_kind,
+                               const int64_t *class_starts, void *loss, void *dloss, const int64_t *dloss_offsets,
+                               void *dparams, uint8_t *ok);
 int de_eval_loss_grad_by_class(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX,
+                               const de_param_args_t *pa, int mode, const void *y, const void *w, int32_t loss_kind,
+                               const int64_t *class_starts, void *loss, void *dloss, const int64_t *dloss_offsets,
+                               void *dparams, uint8_t *ok) {
+    DE_NOTHROW(c, by_class_impl(c, p, X, N, ldX, pa, mode, y, w, loss_kind, class_starts, loss, dloss, dloss_offsets, dparams, ok));
+}
+static int by_class_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX,
                                const de_param_args_t *pa, int mode, const void *y, const void *w, int32_t loss_kind,
                                const int64_t *class_starts, void *loss, void *dloss, const int64_t *dloss_offsets,
                                void *dparams, uint8_t *ok) {
@@ -3516,20 +3540,20 @@ int de_eval_loss_grad_by_class(de_ctx_t *c, de_program_t *p, const void *X, int6
 
 int de_eval_grad(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
                  int mode, void *out, int64_t ld_out, void *grad, const int64_t *grad_offsets, uint8_t *ok) {
-    return grad_impl(c, p, X, N, ldX, pa, mode, -1, out, ld_out, grad, grad_offsets, ok);
+    DE_NOTHROW(c, grad_impl(c, p, X, N, ldX, pa, mode, -1, out, ld_out, grad, grad_offsets, ok));
 }
 
 int de_eval_pullback_dX(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
                         const void *dY, void *dX, const int64_t *dX_offsets, uint8_t *ok) {
     if (c && N > 0 && !dY) return fail(c, DE_ERR_INVALID_ARG, "null cotangent dY");
-    return grad_impl(c, p, X, N, ldX, pa, DE_GRAD_VARIABLE, -1, nullptr, N, dX, dX_offsets, ok, dY);
+    DE_NOTHROW(c, grad_impl(c, p, X, N, ldX, pa, DE_GRAD_VARIABLE, -1, nullptr, N, dX, dX_offsets, ok, dY));
 }
 
 int de_eval_diff(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, int32_t direction, void *out,
                  void *dout, int64_t ld_out, uint8_t *ok) {
     if (direction < 0) return fail(c, DE_ERR_INVALID_ARG, "direction < 0");
     if (p && p->uses_params) return fail(c, DE_ERR_UNSUPPORTED, "eval_diff on parametric trees");
-    return grad_impl(c, p, X, N, ldX, nullptr, DE_GRAD_VARIABLE, direction, out, ld_out, dout, nullptr, ok);
+    DE_NOTHROW(c, grad_impl(c, p, X, N, ldX, nullptr, DE_GRAD_VARIABLE, direction, out, ld_out, dout, nullptr, ok));
 }
 
 } // extern "C"
