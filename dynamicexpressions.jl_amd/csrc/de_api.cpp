@@ -260,39 +260,58 @@ static const OpName kOps[] = {
 constexpr int HOST_RANGES_MAX = 32; // ranges of one parallel pass (per-worker vectors are arrays of this size)
 namespace {
 thread_local bool in_job = false;      // this thread is running a job of a parallel region
+static inline void cpu_relax() { __builtin_ia32_pause(); }
+// A creation is a BURST of ~12 short regions; a thread that sleeps on a condition variable between them wakes in 50 - 90 us on these
+// (shared, 256-core) hosts — the regions of a 10^3-tree creation take less.  Workers therefore spin for ~100 us after a region before
+// they go to sleep, and the caller spins for the stragglers (DE_HOST_SPIN=n: iterations; 0 = sleep at once).
 struct HostPool {
     std::mutex region;                 // held for the duration of a parallel region
     std::mutex m;
     std::condition_variable cv_work, cv_done;
-    const std::function<void(int)> *job = nullptr;
-    int n_jobs = 0, pending = 0;
-    uint64_t gen = 0;
-    bool failed = false;
+    const std::function<void(int)> *job = nullptr; // (job, n_jobs: written under m before `gen` moves, read after it was seen to move)
+    int n_jobs = 0;
+    std::atomic<int> pending{0};
+    std::atomic<uint64_t> gen{0};
+    std::atomic<bool> failed{false};
+    std::atomic<int> sleepers{0};      // workers blocked in cv_work (the publisher only notifies when there are any)
     int n_workers = 0;
+    const int spin = [] { const char *v = getenv("DE_HOST_SPIN"); const int n = v && *v ? atoi(v) : 4000; return n < 0 ? 0 : n; }();
     void worker(int id) {
         uint64_t seen = 0;
         for (;;) {
+            int spins = 0;
+            while (gen.load(std::memory_order_acquire) == seen) {
+                if (++spins <= spin) { cpu_relax(); continue; }
+                std::unique_lock<std::mutex> lk(m);
+                sleepers.fetch_add(1);
+                cv_work.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen; });
+                sleepers.fetch_sub(1);
+            }
             const std::function<void(int)> *j = nullptr;
             {
-                std::unique_lock<std::mutex> lk(m);
-                cv_work.wait(lk, [&] { return gen != seen; });
-                seen = gen;
+                // (the publisher moves `gen` under m after writing job / n_jobs: taking m orders this thread behind it, and a worker that
+                // overslept a whole region sees n_jobs == 0 or the NEXT region's job — never a dangling one)
+                const std::lock_guard<std::mutex> lk(m);
+                seen = gen.load(std::memory_order_acquire);
                 if (id + 1 < n_jobs) j = job;
+                if (j && claimed[id] == seen) j = nullptr; // (already ran this region's job)
+                if (j) claimed[id] = seen;
             }
             if (!j) continue;
             bool bad = false;
             in_job = true;
             try { (*j)(id + 1); } catch (...) { bad = true; }
             in_job = false;
-            {
+            if (bad) failed.store(true);
+            if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 const std::lock_guard<std::mutex> lk(m);
-                failed = failed || bad;
-                if (--pending == 0) cv_done.notify_one();
+                cv_done.notify_one();
             }
         }
     }
+    uint64_t claimed[HOST_RANGES_MAX] = {0};
     void ensure(int want) { // (under `region`)
-        while (n_workers < want) {
+        while (n_workers < want && n_workers < HOST_RANGES_MAX) {
             const int id = n_workers;
             try { std::thread([this, id] { worker(id); }).detach(); } catch (...) { return; }
             n_workers++;
@@ -309,21 +328,22 @@ struct HostPool {
             const std::lock_guard<std::mutex> lk(m);
             job = &f;
             n_jobs = n;
-            pending = n - 1;
-            failed = false;
-            gen++;
+            pending.store(n - 1);
+            failed.store(false);
+            gen.fetch_add(1, std::memory_order_release);
         }
-        cv_work.notify_all();
+        if (sleepers.load() > 0) cv_work.notify_all();
         bool bad = false;
         in_job = true;
         try { f(0); } catch (...) { bad = true; }
         in_job = false;
+        for (int spins = 0; pending.load(std::memory_order_acquire) != 0 && spins < spin; spins++) cpu_relax();
         {
             std::unique_lock<std::mutex> lk(m);
-            cv_done.wait(lk, [&] { return pending == 0; });
+            cv_done.wait(lk, [&] { return pending.load(std::memory_order_acquire) == 0; });
             job = nullptr;
             n_jobs = 0;
-            bad = bad || failed;
+            bad = bad || failed.load();
         }
         if (bad) throw std::bad_alloc(); // (the passes only ever throw for memory)
         return true;
@@ -340,22 +360,23 @@ HostPool &host_pool() {
     (void)once;
     return *g_host_pool;
 }
-unsigned host_threads_for(int64_t n) {
+unsigned host_threads_for(int64_t n, int64_t grain = 0) { // grain > 0: at least that many items per range (loops of a few ns per item)
     const unsigned hw = std::thread::hardware_concurrency();
     const char *env = getenv("DE_HOST_THREADS");
     // 10^4 / 10^5 trees on a 256-core box: 8 threads 8.3 / 88 ms, 16: 7.0 / 68, 24: 5.2 / 53, 32: 5.3 / 50 (best of 6, shared host)
     unsigned nt = env && *env ? (unsigned)atoi(env) : (hw >= 48 ? 24u : std::min(hw ? hw : 1u, 16u));
     nt = std::min(nt, (unsigned)HOST_RANGES_MAX);
     static const int64_t min_trees = [] { const char *v = getenv("DE_HOST_MIN_TREES"); const int64_t m = v && *v ? atoll(v) : 32; return m < 1 ? 1 : m; }();
-    if ((int64_t)nt > n / min_trees) nt = (unsigned)(n / min_trees); // (a woken pool thread costs ~10 us, 32 trees are ~50 us of a pass: 10^3 trees 2.3 -> 1.4 ms against a floor of 256)
+    const int64_t per_range = grain > min_trees ? grain : min_trees;
+    if ((int64_t)nt > n / per_range) nt = (unsigned)(n / per_range); // (a woken pool thread costs ~10 us, 32 trees are ~50 us of a pass: 10^3 trees 2.3 -> 1.4 ms against a floor of 256)
     return nt;
 }
 } // namespace
 
 // The trees in contiguous ranges, one per worker: f(k, b, e) with k < HOST_RANGES_MAX — for passes that append to a per-worker vector which is
 // concatenated afterwards, or that write disjoint slices of pre-sized vectors.  The partition depends on n and the thread count only.
-template <class F> static void parallel_tree_ranges(int64_t n, F f) {
-    const unsigned nt = host_threads_for(n);
+template <class F> static void parallel_tree_ranges(int64_t n, F f, int64_t grain = 0) {
+    const unsigned nt = host_threads_for(n, grain);
     if (nt <= 1) {
         f(0, (int64_t)0, n);
         return;
@@ -369,8 +390,8 @@ template <class F> static void parallel_tree_ranges(int64_t n, F f) {
     if (!host_pool().run(n_ranges, job))
         for (int k = 0; k < n_ranges; k++) job(k);
 }
-template <class F> static void parallel_for_trees(int64_t n, F f) {
-    parallel_tree_ranges(n, [&](int, int64_t b, int64_t e) { for (int64_t i = b; i < e; i++) f(i); });
+template <class F> static void parallel_for_trees(int64_t n, F f, int64_t grain = 0) {
+    parallel_tree_ranges(n, [&](int, int64_t b, int64_t e) { for (int64_t i = b; i < e; i++) f(i); }, grain);
 }
 
 // Pair the constant-carrying instructions of a generic program with those of a derived (bound / fused)
@@ -916,7 +937,7 @@ static inline void patch_chained_imm(de_program *p, int32_t c, uint32_t lo, uint
 
 static void recompute_host_ok(de_program *p) {
     const bool ee = (p->options & DE_OPT_EARLY_EXIT) != 0;
-    for (int64_t t = 0; t < p->n_trees; t++) {
+    parallel_for_trees(p->n_trees, [&](int64_t t) {
         bool ok_eval = true, ok_grad = true;
         for (int64_t k = p->const_off[t]; k < p->const_off[t + 1]; k++) {
             const bool fin = finite_in(p->dtype, p->consts[k]);
@@ -926,7 +947,7 @@ static void recompute_host_ok(de_program *p) {
         }
         p->host_ok_eval[t] = ok_eval;
         p->host_ok_grad[t] = ok_grad;
-    }
+    }, 1024);
     // a constant subtree that evaluates to a non-finite value clears the flag — with the flag
     // semantics of the program's own options (dispatch_constant_tree tests unconditionally,
     // the Bumper path only under early_exit): that is exactly what `aux` was lowered with
@@ -1332,8 +1353,12 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
 }
 
 static int set_consts_impl(de_program_t *p, const void *consts);
+static int set_consts_nothrow(de_program_t *p, const void *consts) {
+    if (!p) return DE_ERR_INVALID_ARG;
+    DE_NOTHROW(p->ctx, set_consts_impl(p, consts));
+}
 int de_program_set_consts(de_program_t *p, const void *consts) {
-    const int rc = set_consts_impl(p, consts);
+    const int rc = set_consts_nothrow(p, consts);
     if (rc == DE_OK && p && getenv("DE_VERIFY") && *getenv("DE_VERIFY") == '1') return de_program_verify(p);
     return rc;
 }
@@ -1345,13 +1370,18 @@ static int set_consts_impl(de_program_t *p, const void *consts) {
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
     const auto t0 = now();
-    for (size_t k = 0; k < p->consts.size(); k++) {
-        const double v = p->dtype == DE_F32 ? (double)static_cast<const float *>(consts)[k]
-                                            : static_cast<const double *>(consts)[k];
-        p->consts[k] = v;
-        if (p->const_instr[k] >= 0) write_imm(p->code[(size_t)p->const_instr[k]], p->dtype, v);
-        if (p->folded && p->fconst_instr[k] >= 0) write_imm(p->fcode[(size_t)p->fconst_instr[k]], p->dtype, v);
-    }
+    // (every loop of this function over constants, trees or sites writes slots of its own: on the host pool; 10^4 trees: 0.85 -> see DESIGN 9.1)
+    try {
+        parallel_tree_ranges((int64_t)p->consts.size(), [&](int, int64_t kb, int64_t ke) {
+            for (size_t k = (size_t)kb; k < (size_t)ke; k++) {
+                const double v = p->dtype == DE_F32 ? (double)static_cast<const float *>(consts)[k]
+                                                    : static_cast<const double *>(consts)[k];
+                p->consts[k] = v;
+                if (p->const_instr[k] >= 0) write_imm(p->code[(size_t)p->const_instr[k]], p->dtype, v);
+                if (p->folded && p->fconst_instr[k] >= 0) write_imm(p->fcode[(size_t)p->fconst_instr[k]], p->dtype, v);
+            }
+        }, 4096);
+    } catch (const std::bad_alloc &) { return fail(ctx, DE_ERR_HIP, "out of host memory"); }
     const auto t1 = now();
     if (p->folded) {
         int rc = DE_OK;
@@ -1393,28 +1423,37 @@ static int set_consts_impl(de_program_t *p, const void *consts) {
                 }
             p->lists_gen = p->site_gen;
         }
-        for (const de_program::EvalSite &e : p->eval_sites) {
-            const uint32_t lo = src[(size_t)e.src].imm.u32[0], hi = src[(size_t)e.src].imm.u32[1];
-            p->bcode[(size_t)e.b].lo = lo;
-            p->bcode[(size_t)e.b].hi = hi;
-            p->tcode[(size_t)e.t].lo = lo;
-            p->tcode[(size_t)e.t].hi = hi;
-            patch_chained_imm(p, e.c, lo, hi);
-        }
-        if (gpatch) {
-            for (const de_program::GradSite &g : p->grad_sites) {
-                const uint32_t lo = p->code[(size_t)g.src].imm.u32[0], hi = p->code[(size_t)g.src].imm.u32[1];
-                p->gbcode[(size_t)g.gb].lo = lo;
-                p->gbcode[(size_t)g.gb].hi = hi;
-                if (tpatch && g.gt >= 0) {
-                    p->gtcode[(size_t)g.gt].lo = lo;
-                    p->gtcode[(size_t)g.gt].hi = hi;
-                }
-                if (rpatch && g.rt >= 0) {
-                    p->rtcode[(size_t)g.rt].lo = lo;
-                    p->rtcode[(size_t)g.rt].hi = hi;
-                }
+        try {
+        parallel_tree_ranges((int64_t)p->eval_sites.size(), [&](int, int64_t sb, int64_t se) {
+            for (size_t q = (size_t)sb; q < (size_t)se; q++) {
+                const de_program::EvalSite &e = p->eval_sites[q];
+                const uint32_t lo = src[(size_t)e.src].imm.u32[0], hi = src[(size_t)e.src].imm.u32[1];
+                p->bcode[(size_t)e.b].lo = lo;
+                p->bcode[(size_t)e.b].hi = hi;
+                p->tcode[(size_t)e.t].lo = lo;
+                p->tcode[(size_t)e.t].hi = hi;
+                patch_chained_imm(p, e.c, lo, hi);
             }
+        }, 4096);
+        if (gpatch)
+            parallel_tree_ranges((int64_t)p->grad_sites.size(), [&](int, int64_t sb, int64_t se) {
+                for (size_t q = (size_t)sb; q < (size_t)se; q++) {
+                    const de_program::GradSite &g = p->grad_sites[q];
+                    const uint32_t lo = p->code[(size_t)g.src].imm.u32[0], hi = p->code[(size_t)g.src].imm.u32[1];
+                    p->gbcode[(size_t)g.gb].lo = lo;
+                    p->gbcode[(size_t)g.gb].hi = hi;
+                    if (tpatch && g.gt >= 0) {
+                        p->gtcode[(size_t)g.gt].lo = lo;
+                        p->gtcode[(size_t)g.gt].hi = hi;
+                    }
+                    if (rpatch && g.rt >= 0) {
+                        p->rtcode[(size_t)g.rt].lo = lo;
+                        p->rtcode[(size_t)g.rt].hi = hi;
+                    }
+                }
+            }, 4096);
+        } catch (const std::bad_alloc &) { return fail(ctx, DE_ERR_HIP, "out of host memory"); }
+        if (gpatch) {
             if (!tpatch) p->gt_valid = false;
             if (!rpatch) p->rt_valid = false;
         } else {
