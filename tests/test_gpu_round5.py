@@ -410,3 +410,41 @@ def test_two_host_threads_create_programs_at_once(api):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+def test_generations_do_not_leak(api):
+    """300 generations (create, evaluate, loss gradient every third, destroy) of populations of changing size on ONE context: the device
+    memory in use and the process's resident set settle (recycled buffers are bounded: 256 MB of device streams, 512 MB of host vectors
+    per context) instead of growing with the generations."""
+    import resource
+    import torch
+    ops = de.synth.BENCH_OPERATORS
+    X = de.synth.random_X(5, 256, seed=4)
+    y = np.cos(X[1]).astype(np.float32)
+    pool = de.synth.random_population(6000, seed=91)
+    ctx = api.Context(0)
+    rng = np.random.default_rng(3)
+
+    def generation(g):
+        n = int(rng.integers(50, 3000))
+        start = int(rng.integers(0, len(pool) - n))
+        pop = api.Population(pool[start:start + n], ops, np.float32, n_features=5, ctx=ctx)
+        pop.eval(X)
+        if g % 3 == 0:
+            pop.eval_loss_grad(X, y)
+        pop.close()
+
+    def used():
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info()
+        return total - free, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024
+
+    for g in range(60):  # warm: every buffer class has been allocated, parked and re-used
+        generation(g)
+    dev0, rss0 = used()
+    for g in range(60, 300):
+        generation(g)
+    dev1, rss1 = used()
+    ctx.close()
+    assert dev1 - dev0 < 96 << 20, f"device memory grew by {(dev1 - dev0) >> 20} MiB over 240 generations"
+    assert rss1 - rss0 < 192 << 20, f"resident set grew by {(rss1 - rss0) >> 20} MiB over 240 generations"
