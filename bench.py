@@ -280,6 +280,39 @@ def valu_measured(pm_entry):
                        "issue costs of profiles/r2_valu_rate.json; half-rate share from profiles/valu_static_mix.json")
 
 
+def search_generation_leg(ctx, lib, ops, X, n_trees=10000, rows=1000):
+    """de_program_create / de_eval / de_program_destroy of n_trees FRESH trees on `rows` samples through the C ABI."""
+    import ctypes as C
+    import dynamicexpressions_jl_amd as de
+    trees = de.synth.random_population(n_trees, seed=0xDE0D)
+    tape, noff, consts, coff = de.flatten_population(trees, ops, np.float32)
+    Xs = X[:, :rows].t().contiguous()  # [rows, 5] feature-fastest
+    out = torch.empty((n_trees, rows), device=X.device, dtype=torch.float32)
+    ok = torch.empty(n_trees, device=X.device, dtype=torch.uint8)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(4):
+        h = C.c_void_p()
+        t0 = time.perf_counter()
+        ctx.check(lib.de_program_create(ctx._h, 0, tape.ctypes.data, noff.ctypes.data, n_trees, consts.ctypes.data, coff.ctypes.data, 5, 0, 7, C.byref(h)))
+        t1 = time.perf_counter()
+        ctx.check(lib.de_eval(ctx._h, h, Xs.data_ptr(), rows, 5, None, out.data_ptr(), rows, ok.data_ptr()))
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        lib.de_program_destroy(h)
+        t3 = time.perf_counter()
+        cur = (1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2))
+        best = cur if best is None else tuple(min(a, b) for a, b in zip(best, cur))
+    nodes = sum(de.count_nodes(t) for t in trees)
+    total = sum(best)
+    return {"workload": f"{n_trees} fresh random 20-node trees x {rows} rows, Float32: de_program_create + de_eval (call + synchronise) + de_program_destroy, best of 4",
+            "create_ms": best[0], "eval_ms": best[1], "destroy_ms": best[2], "generation_ms": total, "us_per_tree": 1e3 * total / n_trees,
+            "value": nodes * rows / (total * 1e-3), "unit": "node-evals/s including the host side of the generation",
+            "complete_fraction": float(ok.float().mean().item()),
+            "note": "host lowering on the library's pool of host threads (DE_HOST_THREADS), device streams and host vectors recycled per context; "
+                    "Python-side flattening of the trees (test harness) is not included"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -801,6 +834,13 @@ def main():
                                       "ms_per_step": full_res["ms_per_step"], "kernel_ms_last": full_res["kernel_ms"],
                                       "value": total_nodes * N / (full_res["ms_per_step"] * 1e-3), "flags_equal_to_early_exit": full_res["flags_equal"],
                                       "roofline_frac": b_unit * units_all / (full_res["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if not args.no_cpu_baseline and world == 1 and args.workload == "headline" and not args.turbo:
+            # What a SEARCH LOOP pays per generation (new trees every call): the host side of this path, which the reference does not have
+            # (it evaluates the Node it is handed).  10^4 fresh trees: de_program_create, de_eval on 10^3 rows, de_program_destroy; best of 4.
+            try:
+                res["search_generation"] = search_generation_leg(ctx, lib, ops, X)
+            except Exception as e:  # noqa: BLE001  (a secondary leg must not cost the headline line)
+                res["search_generation"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1 and not is_param:  # reported at N=1 only (rank 0)
             Ns = min(N, 10**6)
             Xh = np.asfortranarray(X[:, :Ns].t().contiguous().cpu().numpy().T)
