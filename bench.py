@@ -64,8 +64,9 @@ WORKLOADS = {
     "C5": dict(n_trees=1000, N=10**6, parametric=True,
                desc="1000 random 20-node ParametricNode trees (8 parameters x 16 classes), 5 x 10^6 Float32: "
                     "eval_tree_array + eval_grad_tree_array(variable=false) per step"),
-    "C5pb": dict(n_trees=1000, N=10**6, parametric=True, by_class=True,
-                 desc="1000 random 20-node ParametricNode trees (8 parameters x 16 classes, samples grouped by class), "
+    "C5pb": dict(n_trees=1000, N=10**6, parametric=True, by_class=True, reverse_grad=True,
+                 desc="[EvalContext(reverse_grad=true) = DE_OPT_REVERSE_GRAD: reverse accumulation, an opt-in since ABI 3] "
+                      "1000 random 20-node ParametricNode trees (8 parameters x 16 classes, samples grouped by class), "
                       "5 x 10^6 Float32: eval_tree_array + the :both-mode pullback (dY = randn) with the parameter rows "
                       "reduced by class, fused (SURVEY.md §8d C5; src/ChainRules.jl:56-77, "
                       "test/test_parametric_expression.jl:326-372)"),
@@ -446,6 +447,8 @@ def main():
         total_nodes = sum(de.count_nodes(t) for t in all_trees)
 
         ec = api.EvalContext(turbo=True) if args.turbo else None
+        if wl.get("reverse_grad"):  # C5pb: the reverse-accumulation kernel is what the workload measures (default = forward duals: `forward_default` leg)
+            ec = api.EvalContext(turbo=bool(args.turbo), reverse_grad=True)
         # X: the in-repo stream SURVEY §8d specifies (synth.random_X: numpy PCG64 standard normals, seed 1 — the generator the parity tests
         # use), drawn on the host and uploaded ONCE, the same on every rank (replicated).  Rounds 1-4 drew it with torch.randn on the device:
         # `complete_fraction`, which decides half of the headline, then depended on torch's generator.  DE_BENCH_TORCH_X=1: that X.

@@ -29,7 +29,7 @@ def __getattr__(name):
         return importlib.import_module(f"{__name__}.{name}")
     _api_names = {
         "EvalContext", "eval_tree_array", "eval_grad_tree_array", "eval_diff_tree_array",
-        "Population", "ParametricExpression", "Expression", "library", "DeviceError",
+        "Population", "ParametricExpression", "Expression", "library", "DeviceError", "UncertifiedFlag",
     }
     if name in _api_names:
         from . import api

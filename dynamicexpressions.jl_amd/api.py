@@ -37,8 +37,8 @@ LIB_PATH = os.environ.get("DE_HIP_LIB") or os.path.join(_HERE, "csrc", "libde_hi
 
 DE_F32, DE_F64 = 0, 1
 GRAD_VARIABLE, GRAD_CONSTANT, GRAD_BOTH = 0, 1, 2
-ABI_VERSION = 2  # DE_HIP_ABI_VERSION of include/de_hip.h this module was written for
-OPT_EARLY_EXIT, OPT_FUSE_DEG1, OPT_FUSE_DEG2, OPT_BUMPER_CHECKS, OPT_TURBO, OPT_FULL_EVAL, OPT_FORWARD_GRAD = 1, 2, 4, 8, 16, 32, 64
+ABI_VERSION = 3  # DE_HIP_ABI_VERSION of include/de_hip.h this module was written for
+OPT_EARLY_EXIT, OPT_FUSE_DEG1, OPT_FUSE_DEG2, OPT_BUMPER_CHECKS, OPT_TURBO, OPT_FULL_EVAL, OPT_FORWARD_GRAD, OPT_REVERSE_GRAD = 1, 2, 4, 8, 16, 32, 64, 128
 
 EXPORTS = [
     "de_abi_version", "de_opcode_table_version", "de_opcode_by_name", "de_opcode_name",
@@ -49,11 +49,17 @@ EXPORTS = [
     "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_prio_tiles_wanted", "de_program_last_live_trees", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size", "de_dist_world_size",
     "de_dist_broadcast", "de_dist_gather_flags", "de_dist_last_error", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
     "de_ctx_device", "de_ctx_timing_ring", "de_ctx_timing_read", "de_dist_reorder_selftest", "de_eval_sum_certificate",
+    "de_dist_set_timeout",
 ]
 
 
 class DeviceError(RuntimeError):
     """The HIP library/GPU is unavailable or a de_* call failed.  Never swallowed."""
+
+
+class UncertifiedFlag(DeviceError):
+    """EvalContext(strict_flags=True): the device's element-wise validity flag of this tree is not PROVABLY the reference's
+    `isfinite(sum(x))` flag (a finite array whose sum may overflow): the caller keeps the CPU path for it."""
 
 
 class ParamArgs(C.Structure):
@@ -138,6 +144,7 @@ def library() -> C.CDLL:
     lib.de_dist_unique_id.argtypes = [vp]
     lib.de_dist_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     lib.de_dist_destroy.argtypes = [vp]
+    lib.de_dist_set_timeout.argtypes = [vp, i64]
     lib.de_dist_world_size.argtypes = [vp]
     lib.de_dist_shard_size.restype = i64
     lib.de_dist_shard_size.argtypes = [i64, C.c_int, C.c_int]
@@ -182,13 +189,21 @@ class EvalContext:
     buffer: object = None
     use_fused: bool = True
     full_eval: bool = False  # DE_OPT_FULL_EVAL: evaluate incomplete trees to the end as well (no early exit at tree granularity)
-    forward_grad: bool = False  # DE_OPT_FORWARD_GRAD: fused loss gradients always by forward duals (the reference's flag semantics exactly)
+    forward_grad: bool = False  # DE_OPT_FORWARD_GRAD: round 5's spelling of what is the default since ABI 3 (forward duals); wins over reverse_grad
+    # DE_OPT_REVERSE_GRAD: PERMISSION to run fused loss gradients by reverse accumulation (faster from 8 gradient rows per tree on; its
+    # products are associated leaf-wards: `ok` may differ from the reference's forward-mode flag in ~0.03 % of Float32 fuzz cases)
+    reverse_grad: bool = False
+    # strict_flags: after every Population.eval the certificate pass (de_eval_sum_certificate) runs as well and `Population.uncertified`
+    # lists the trees whose element-wise flag is NOT provably the reference's isfinite(sum(x)) flag (src/ValueInterface.jl:9) — the only
+    # trees a caller who needs the reference's bit has to re-derive on the CPU; the one-tree sugar raises UncertifiedFlag for such a tree
+    strict_flags: bool = False
 
     def option_bits(self, operators: OperatorEnum) -> int:
         f1, f2 = operators.fuse_flags(self.use_fused)
         return ((OPT_EARLY_EXIT if self.early_exit else 0) | (OPT_FUSE_DEG1 if f1 else 0) |
                 (OPT_FUSE_DEG2 if f2 else 0) | (OPT_BUMPER_CHECKS if self.bumper else 0) | (OPT_TURBO if self.turbo else 0) |
-                (OPT_FULL_EVAL if self.full_eval else 0) | (OPT_FORWARD_GRAD if self.forward_grad else 0))
+                (OPT_FULL_EVAL if self.full_eval else 0) | (OPT_FORWARD_GRAD if self.forward_grad else 0) |
+                (OPT_REVERSE_GRAD if self.reverse_grad else 0))
 
 
 class Context:
@@ -432,6 +447,7 @@ class Population:
                 consts.ctypes.data if len(consts) else None, coff.ctypes.data, self.n_features, self.n_params,
                 self.eval_context.option_bits(operators), C.byref(self._h)))
         self.n_nodes = int(lib.de_program_n_nodes(self._h))
+        self.uncertified = np.zeros(0, dtype=np.int64)  # EvalContext(strict_flags=True): set by every eval()
 
     # -- constants (optimiser inner loop, src/NodeUtils.jl:99-143) ------------------
     def set_constants(self, consts: np.ndarray) -> None:
@@ -585,12 +601,27 @@ class Population:
             ok = torch.empty(self.n_trees, dtype=torch.uint8, device=keep_x.device)
             self.ctx.check(lib.de_eval(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None,
                                        out.data_ptr(), N, ok.data_ptr()))
+            if self.eval_context.strict_flags:
+                self._certify(ptr, N, ldX, pa, ok.cpu().numpy())
             return out, ok.bool()
         out = np.empty((self.n_trees, N), dtype=self.dtype)
         ok = np.zeros(self.n_trees, dtype=np.uint8)
         self.ctx.check(lib.de_eval(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None,
                                    out.ctypes.data, N, ok.ctypes.data))
+        if self.eval_context.strict_flags:
+            self._certify(ptr, N, ldX, pa, ok)
         return out, ok.astype(bool)
+
+    def _certify(self, ptr, N, ldX, pa, ok_eval) -> None:
+        """strict_flags: the certificate pass behind an evaluation; `self.uncertified` = indices of the trees whose flag is not
+        provably the reference's (and the pass must reproduce the evaluation's flags: it runs the same tests)."""
+        ok = np.zeros(self.n_trees, dtype=np.uint8)
+        cert = np.zeros(self.n_trees, dtype=np.uint8)
+        self.ctx.check(library().de_eval_sum_certificate(self.ctx._h, self._h, ptr, N, ldX, C.byref(pa) if pa else None,
+                                                         ok.ctypes.data, cert.ctypes.data, None))
+        if not np.array_equal(ok.astype(bool), np.asarray(ok_eval).astype(bool)):
+            raise DeviceError("strict_flags: the certificate pass and the evaluation disagree on a flag")
+        self.uncertified = np.nonzero(cert == 0)[0]
 
     def sum_certificate(self, X, params=None, classes=None, class_base: int = 1):
         """``(ok, certified, max_abs)`` (numpy, per tree): the certificate of ``de_eval_sum_certificate`` — ``certified[t]`` says that the
@@ -927,6 +958,9 @@ def eval_tree_array(tree: Node, cX, operators: OperatorEnum, eval_context: Optio
     pop = Population([tree], operators, _x_dtype(cX), n_features=int(F), eval_context=eval_context, ctx=ctx)
     try:
         out, ok = pop.eval(cX)
+        if pop.eval_context.strict_flags and len(pop.uncertified):
+            raise UncertifiedFlag("strict_flags: the flag of this tree is not provably the reference's isfinite(sum(x)) flag on this X "
+                                  "(a finite tested array whose sum may overflow): keep the CPU path for it")
         return out[0], bool(ok[0])
     finally:
         pop.close()

@@ -64,6 +64,10 @@ struct de_ctx {
     // of >= PROG_RECYCLE_MIN bytes are allocated in 1 MiB granules through prog_malloc and parked here by prog_free; at most
     // PROG_RECYCLE_MAX of them / PROG_RECYCLE_BYTES in total, the rest is freed.  DE_NO_PROG_RECYCLE=1: plain hipMalloc / hipFree.
     std::vector<std::pair<void *, size_t>> recycled;
+    // ... and the SMALL ones (round 6): a one-tree program (de_eval_tree_array: the reference's own call shape) is a few hundred bytes, and
+    // its hipMalloc / hipFree pairs were a third of the call.  Power-of-two size classes from 512 B up to PROG_RECYCLE_MIN, at most
+    // SMALL_RECYCLE_MAX buffers parked per context.
+    std::vector<std::pair<void *, size_t>> small_free;
     std::map<void *, size_t> big_live; // granule-sized allocations in use (their sizes)
     // ... and the HOST side of destroyed programs: `delete` of a 10^4-tree program is 1.5 ms of munmap (its ~40 vectors are tens of
     // megabytes), and the next creation faults the same pages in again.  Up to four destroyed programs are parked with their vectors
@@ -109,9 +113,19 @@ struct de_program {
     std::vector<int32_t> fconst_instr;  // per constant: index into fcode, or < 0 if folded away
     struct Fold { int32_t tree, instr; bool tested_always; };
     std::vector<Fold> folds;            // aux tree j -> (owning tree, fcode instruction holding its value)
-    std::vector<int64_t> aux_const_src; // aux constant k = consts[aux_const_src[k]]
-    de_program *aux = nullptr;
+    std::vector<int64_t> aux_const_src; // constant k of the fold spans (all folds, concatenated) = consts[aux_const_src[k]]
+    de_program *aux = nullptr;          // the folds that are evaluated ON THE DEVICE (fold_host[j] == 0), as a population of their own
     std::vector<uint8_t> fold_ok;
+    // Round 6: a constant subtree made of IEEE-exact operators only (+ - * /) is folded ON THE HOST — the same bits by construction
+    // (the device's + - * / are correctly rounded, tests/test_gpu_eval.py::test_ieee_exact_operators_are_bit_identical, and every
+    // translation unit is built with -ffp-contract=off) — and never enters the auxiliary program: about half of the constant subtrees of the
+    // benchmark's operator set.  fold_nodes / fold_noff / fold_coff: every fold's tape slice (constant leaves numbered from the span's first
+    // slot) and its range in aux_const_src; aux_fold: auxiliary tree -> fold; aux_csrc: the auxiliary program's constants -> consts.
+    std::vector<uint8_t> fold_host;
+    std::vector<de_tape_node_t> fold_nodes;
+    std::vector<int64_t> fold_noff, fold_coff;
+    std::vector<int32_t> aux_fold;
+    std::vector<int64_t> aux_csrc;
     std::vector<BoundInstr> bcode;      // bound form of the eval program (handler ids)
     std::vector<BoundInstr> tcode;      // threaded form: handler address offsets + LDS byte offsets
     std::vector<BoundInstr> fbcode;     // fused (superinstruction) form the threaded code is made from
@@ -128,6 +142,7 @@ struct de_program {
     std::vector<int32_t> bcode_off;     // n_trees + 1
     BoundInstr *d_code = nullptr;
     int32_t *d_code_off = nullptr;
+    bool eval_arena = false;            // d_code_off / d_compact_ints / d_ok_eval point into d_code's allocation
     // compaction of the live trees (de_kernels.hip de_compact_live_kernel): the second half of the d_code allocation (same 4 GiB window) and
     // (n_trees + 1) + n_trees + 4 ints; null when the program is not threaded
     BoundInstr *d_compact_code = nullptr;
@@ -137,6 +152,8 @@ struct de_program {
     BoundInstr *d_cert_code = nullptr;
     int32_t *d_cert_off = nullptr;
     size_t cert_cap = 0;
+    uint64_t consts_gen = 0;       // bumped by every de_program_set_consts
+    uint64_t cert_gen = ~0ull;     // consts_gen the uploaded certificate program was built for (~0: none)
     std::vector<double> cert_cmax; // per tree: the largest |constant operand| (an array of N copies of it is summed by the reference)
     BoundInstr *d_gcode = nullptr;      // bound UNFOLDED program on the device (gradient kernels), lazily uploaded
     int32_t *d_gcode_off = nullptr;
@@ -260,7 +277,15 @@ static const OpName kOps[] = {
 constexpr int HOST_RANGES_MAX = 32; // ranges of one parallel pass (per-worker vectors are arrays of this size)
 namespace {
 thread_local bool in_job = false;      // this thread is running a job of a parallel region
-static inline void cpu_relax() { __builtin_ia32_pause(); }
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    std::this_thread::yield();
+#endif
+}
 // A creation is a BURST of ~12 short regions; a thread that sleeps on a condition variable between them wakes in 50 - 90 us on these
 // (shared, 256-core) hosts — the regions of a 10^3-tree creation take less.  Workers therefore spin for ~100 us after a region before
 // they go to sleep, and the caller spins for the stragglers (DE_HOST_SPIN=n: iterations; 0 = sleep at once).
@@ -273,6 +298,7 @@ struct HostPool {
     std::atomic<int> pending{0};
     std::atomic<uint64_t> gen{0};
     std::atomic<bool> failed{false};
+    std::exception_ptr first_error;    // (under m) what the first failing job of the region threw: rethrown on the caller's thread
     std::atomic<int> sleepers{0};      // workers blocked in cv_work (the publisher only notifies when there are any)
     int n_workers = 0;
     const int spin = [] { const char *v = getenv("DE_HOST_SPIN"); const int n = v && *v ? atoi(v) : 4000; return n < 0 ? 0 : n; }();
@@ -300,9 +326,14 @@ struct HostPool {
             if (!j) continue;
             bool bad = false;
             in_job = true;
-            try { (*j)(id + 1); } catch (...) { bad = true; }
+            std::exception_ptr err;
+            try { (*j)(id + 1); } catch (...) { bad = true; err = std::current_exception(); }
             in_job = false;
-            if (bad) failed.store(true);
+            if (bad) {
+                const std::lock_guard<std::mutex> lk(m);
+                if (!first_error) first_error = err;
+                failed.store(true);
+            }
             if (pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 const std::lock_guard<std::mutex> lk(m);
                 cv_done.notify_one();
@@ -330,22 +361,27 @@ struct HostPool {
             n_jobs = n;
             pending.store(n - 1);
             failed.store(false);
+            first_error = nullptr;
             gen.fetch_add(1, std::memory_order_release);
         }
         if (sleepers.load() > 0) cv_work.notify_all();
-        bool bad = false;
+        std::exception_ptr mine;
         in_job = true;
-        try { f(0); } catch (...) { bad = true; }
+        try { f(0); } catch (...) { mine = std::current_exception(); }
         in_job = false;
         for (int spins = 0; pending.load(std::memory_order_acquire) != 0 && spins < spin; spins++) cpu_relax();
+        std::exception_ptr theirs;
         {
             std::unique_lock<std::mutex> lk(m);
             cv_done.wait(lk, [&] { return pending.load(std::memory_order_acquire) == 0; });
             job = nullptr;
             n_jobs = 0;
-            bad = bad || failed.load();
+            if (failed.load()) theirs = first_error;
+            first_error = nullptr;
         }
-        if (bad) throw std::bad_alloc(); // (the passes only ever throw for memory)
+        // the caller sees what was actually thrown (everything used to become std::bad_alloc = "out of host memory")
+        if (mine) std::rethrow_exception(mine);
+        if (theirs) std::rethrow_exception(theirs);
         return true;
     }
 };
@@ -448,28 +484,61 @@ static void build_stream_by_trees(int64_t n_trees, std::vector<Rec> *stream, std
 
 static void dbg_lap(const char *what);
 // ---- program buffers: recycled across de_program_destroy / de_program_create (see de_ctx::recycled) ----
-static constexpr size_t PROG_RECYCLE_MIN = 256u << 10, PROG_RECYCLE_BYTES = 256u << 20, PROG_RECYCLE_MAX = 12;
+static constexpr size_t PROG_RECYCLE_MIN = 256u << 10, PROG_RECYCLE_BYTES = 256u << 20, PROG_RECYCLE_MAX = 12, SMALL_RECYCLE_MAX = 64;
 static bool prog_recycle_enabled() {
     static const bool on = [] { const char *v = getenv("DE_NO_PROG_RECYCLE"); return !(v && *v == '1'); }();
     return on;
 }
+// Instruction streams must lie inside ONE 4 GiB window (the handlers bump record pointers without a carry; the early-exit walk rebuilds
+// record addresses from their low 32 bits).  The property is established HERE, on the granule-rounded size, when a buffer is first
+// allocated, so a recycled buffer is safe for every request it can serve (the callers used to test the requested byte count — a
+// parked buffer that was fine for a smaller program could straddle for the next one, be rejected, re-parked and picked again forever).
+// A fresh allocation that straddles (once in ~10^4 for a 400 KB stream) is set aside, redone, and FREED — never parked.
+static inline bool in_one_window(const void *ptr, size_t bytes) {
+    const uint64_t a0 = (uint64_t)(uintptr_t)ptr;
+    return bytes == 0 || (a0 >> 32) == ((a0 + bytes - 1) >> 32);
+}
 static hipError_t prog_malloc(de_ctx *c, void **out, size_t bytes) {
     *out = nullptr;
-    if (bytes < PROG_RECYCLE_MIN || !prog_recycle_enabled()) return hipMalloc(out, bytes);
-    const size_t need = (bytes + 0xFFFFFu) & ~(size_t)0xFFFFFu;
-    int best = -1;
-    for (int i = 0; i < (int)c->recycled.size(); i++) {
-        const size_t sz = c->recycled[(size_t)i].second;
-        if (sz >= need && sz <= 2 * need && (best < 0 || sz < c->recycled[(size_t)best].second)) best = i;
+    const bool small = bytes < PROG_RECYCLE_MIN;
+    const bool pooled = prog_recycle_enabled();
+    size_t need = bytes;
+    if (pooled && small) { need = 512; while (need < bytes) need <<= 1; }
+    else if (pooled) need = (bytes + 0xFFFFFu) & ~(size_t)0xFFFFFu;
+    if (pooled && small) {
+        for (size_t i = c->small_free.size(); i-- > 0;)
+            if (c->small_free[i].second == need) {
+                *out = c->small_free[i].first;
+                c->big_live[*out] = need;
+                c->small_free.erase(c->small_free.begin() + (long)i);
+                return hipSuccess;
+            }
+    } else if (pooled) {
+        int best = -1;
+        for (int i = 0; i < (int)c->recycled.size(); i++) {
+            const size_t sz = c->recycled[(size_t)i].second;
+            if (sz >= need && sz <= 2 * need && (best < 0 || sz < c->recycled[(size_t)best].second)) best = i;
+        }
+        if (best >= 0) { // (every parked buffer passed the window test on its full size when it was allocated)
+            *out = c->recycled[(size_t)best].first;
+            c->big_live[*out] = c->recycled[(size_t)best].second;
+            c->recycled.erase(c->recycled.begin() + best);
+            return hipSuccess;
+        }
     }
-    if (best >= 0) {
-        *out = c->recycled[(size_t)best].first;
-        c->big_live[*out] = c->recycled[(size_t)best].second;
-        c->recycled.erase(c->recycled.begin() + best);
-        return hipSuccess;
+    void *rejected[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n_rej = 0;
+    hipError_t st = hipSuccess;
+    for (;;) {
+        st = hipMalloc(out, need);
+        if (st != hipSuccess) { *out = nullptr; break; }
+        if (need > 0xFFFFFFFFull || in_one_window(*out, need)) break;
+        if (n_rej == 4) { (void)hipFree(*out); *out = nullptr; st = hipErrorOutOfMemory; break; }
+        rejected[n_rej++] = *out;
+        *out = nullptr;
     }
-    const hipError_t st = hipMalloc(out, need);
-    if (st == hipSuccess) c->big_live[*out] = need;
+    for (int k = 0; k < n_rej; k++) (void)hipFree(rejected[k]);
+    if (st == hipSuccess && pooled) c->big_live[*out] = need;
     return st;
 }
 // (the caller has synchronised the context's stream: nothing queued reads the buffer any more)
@@ -479,6 +548,11 @@ static void prog_free(de_ctx *c, void *ptr) {
     if (it == c->big_live.end()) { (void)hipFree(ptr); return; }
     const size_t sz = it->second;
     c->big_live.erase(it);
+    if (sz < PROG_RECYCLE_MIN) {
+        if (c->small_free.size() >= SMALL_RECYCLE_MAX) { (void)hipFree(c->small_free.front().first); c->small_free.erase(c->small_free.begin()); }
+        c->small_free.emplace_back(ptr, sz);
+        return;
+    }
     size_t held = 0;
     for (const auto &r : c->recycled) held += r.second;
     if (c->recycled.size() >= PROG_RECYCLE_MAX || held + sz > PROG_RECYCLE_BYTES) {
@@ -498,7 +572,7 @@ static void prog_free(de_ctx *c, void *ptr) {
     X(code) X(code_off) X(const_off) X(const_instr) X(const_checks) X(n_consts_tree) X(host_ok_eval) X(host_ok_grad) X(consts) X(fcode) \
     X(fcode_off) X(fconst_instr) X(folds) X(aux_const_src) X(fold_ok) X(bcode) X(tcode) X(fbcode) X(tcode_off) X(ccode) X(ccode_off) \
     X(bcode_off) X(gbcode) X(gbcode_off) X(gtcode) X(gtcode_off) X(bsite) X(tsite) X(gbsite) X(gtsite_of_gb) X(rtcode) X(rtcode_off) \
-    X(rtcode_mid) X(rtsite_of_gb)
+    X(rtcode_mid) X(rtsite_of_gb) X(fold_host) X(fold_nodes) X(fold_noff) X(fold_coff) X(aux_fold) X(aux_csrc)
 static constexpr size_t PARKED_MAX = 4, PARKED_BYTES = 512u << 20;
 static size_t program_host_bytes(const de_program *p) {
     size_t b = 0;
@@ -512,10 +586,15 @@ static void park_program(de_ctx *c, de_program *p) {
     size_t held = 0;
     for (const de_program *q : c->parked) held += program_host_bytes(q);
     if (!prog_recycle_enabled() || c->parked.size() >= PARKED_MAX || held + program_host_bytes(p) > PARKED_BYTES) { delete p; return; }
-#define X(v) p->v.clear();
+    // only the LISTED vectors survive, in a fresh shell: everything else a program holds (site lists, certificate tables, gradient id
+    // tables ...) is released with `p`, so a parked shell pins exactly what program_host_bytes counts
+    de_program *shell = new (std::nothrow) de_program();
+    if (!shell) { delete p; return; }
+#define X(v) p->v.clear(); shell->v.swap(p->v);
     DE_PROGRAM_VECTORS(X)
 #undef X
-    c->parked.push_back(p);
+    delete p;
+    c->parked.push_back(shell);
 }
 // a fresh (default-constructed) program takes over the vectors of the parked shell whose capacity is the largest
 static void adopt_parked(de_ctx *c, de_program *fresh) {
@@ -533,12 +612,50 @@ static void adopt_parked(de_ctx *c, de_program *fresh) {
     delete old;
 }
 
+// A constant subtree of IEEE-exact operators, evaluated in the element type exactly as dispatch_constant_tree does
+// (src/Evaluate.jl:1002-1067: every node's output is validity-tested; the arithmetic goes on, IEEE propagates what it must).
+template <typename T>
+static bool host_fold_eval(const de_tape_node_t *nd, int64_t n, const double *consts, const int64_t *csrc, T *value) {
+    T stack_small[32];
+    std::vector<T> stack_big;
+    T *st = stack_small;
+    if (n > 32) { stack_big.resize((size_t)n); st = stack_big.data(); }
+    int sp = 0;
+    bool ok = true;
+    for (int64_t i = 0; i < n; i++) {
+        T v;
+        if (nd[i].degree == 0) v = (T)consts[csrc[nd[i].arg]];
+        else {
+            const T b = st[--sp], a = st[--sp];
+            switch (nd[i].op) {
+            case DE_B_ADD: v = a + b; break;
+            case DE_B_SUB: v = a - b; break;
+            case DE_B_MUL: v = a * b; break;
+            default: v = a / b; break; // DE_B_DIV (host_foldable admits nothing else)
+            }
+        }
+        ok = ok && std::isfinite(v);
+        st[sp++] = v;
+    }
+    *value = st[0];
+    return ok;
+}
+static bool host_foldable(const de_tape_node_t *nd, int64_t n) {
+    for (int64_t i = 0; i < n; i++) {
+        if (nd[i].degree == 0) { if (nd[i].op != DE_LEAF_CONST) return false; }
+        else if (nd[i].degree != 2 || nd[i].op < DE_B_ADD || nd[i].op > DE_B_DIV) return false;
+    }
+    return n > 0;
+}
+
 // No exception leaves this file: the gradient entry points build host vectors (and run passes on the host pool, which reports a worker's
 // failure as std::bad_alloc) — an allocation failure becomes a status like everywhere else.
 #define DE_NOTHROW(CTX, CALL)                                                                   \
     do {                                                                                        \
         try { return (CALL); }                                                                  \
         catch (const std::bad_alloc &) { return fail((CTX), DE_ERR_HIP, "out of host memory"); } \
+        catch (const std::exception &e) { return fail((CTX), DE_ERR_HIP, "internal error: %s", e.what()); } \
+        catch (...) { return fail((CTX), DE_ERR_HIP, "internal error (unknown exception)"); }  \
     } while (0)
 
 extern "C" {
@@ -620,6 +737,7 @@ int de_ctx_destroy(de_ctx_t *c) {
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff, &c->sPrio, &c->sPrioDs, &c->sCert, &c->sBcLoss, &c->sBcDloss, &c->sBcOk, &c->sBcNg, &c->sBcDoff, &c->sBcOut, &c->sBcTiles}) b->release();
     for (const auto &r : c->recycled) (void)hipFree(r.first);
+    for (const auto &r : c->small_free) (void)hipFree(r.first);
     c->recycled.clear();
     for (de_program *q : c->parked) delete q;
     c->parked.clear();
@@ -967,24 +1085,40 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
 static int upload_ok_eval(de_ctx *c, de_program *p) {
     p->tab_ok_stale = true; // host_ok_grad moves with the constants too
     if (p->n_trees == 0) return DE_OK;
-    if (!p->d_ok_eval) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_ok_eval), (size_t)p->n_trees));
+    if (!p->d_ok_eval) HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_ok_eval), (size_t)std::max<int64_t>(p->n_trees, 1))); // (never taken since round 6: the arena holds it)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(p->d_ok_eval, p->host_ok_eval.data(), (size_t)p->n_trees, hipMemcpyHostToDevice));
     return DE_OK;
 }
 
-// (Re-)evaluate the folded constant subtrees on the device and patch their values into fcode.
+// (Re-)evaluate the folded constant subtrees — the IEEE-exact ones on the host, the others on the device — and patch their
+// values into fcode.
 // `aux_current`: the auxiliary program was created with the present constants this very moment (de_program_create: setting them
 // again cost 0.9 of the 1.1 ms this step took for 10^4 trees).
 static int refresh_folds(de_ctx *c, de_program *p, bool aux_current = false) {
     if (!p->folded || p->folds.empty()) return DE_OK; // (a CSE-only eval program has no constant subtrees to evaluate)
     const size_t es = p->dtype == DE_F32 ? 4 : 8;
-    const size_t na = p->folds.size();
+    const size_t nf = p->folds.size();
+    p->fold_ok.assign(nf, 0);
+    parallel_for_trees((int64_t)nf, [&](int64_t j) {
+        if (!p->fold_host[(size_t)j]) return;
+        const de_tape_node_t *nd = p->fold_nodes.data() + p->fold_noff[(size_t)j];
+        const int64_t n = p->fold_noff[(size_t)j + 1] - p->fold_noff[(size_t)j];
+        const int64_t *csrc = p->aux_const_src.data() + p->fold_coff[(size_t)j];
+        double v;
+        bool ok;
+        if (p->dtype == DE_F32) { float f; ok = host_fold_eval<float>(nd, n, p->consts.data(), csrc, &f); v = (double)f; }
+        else ok = host_fold_eval<double>(nd, n, p->consts.data(), csrc, &v);
+        p->fold_ok[(size_t)j] = ok ? 1 : 0;
+        write_imm(p->fcode[(size_t)p->folds[(size_t)j].instr], p->dtype, v);
+    }, 256);
+    if (!p->aux) return DE_OK;
+    const size_t na = p->aux_fold.size();
     int rc = DE_OK;
     if (!aux_current) {
-        std::vector<unsigned char> ac(std::max<size_t>(p->aux_const_src.size(), 1) * es);
-        for (size_t k = 0; k < p->aux_const_src.size(); k++) {
-            const double v = p->consts[(size_t)p->aux_const_src[k]];
+        std::vector<unsigned char> ac(std::max<size_t>(p->aux_csrc.size(), 1) * es);
+        for (size_t k = 0; k < p->aux_csrc.size(); k++) {
+            const double v = p->consts[(size_t)p->aux_csrc[k]];
             if (p->dtype == DE_F32) reinterpret_cast<float *>(ac.data())[k] = (float)v;
             else reinterpret_cast<double *>(ac.data())[k] = v;
         }
@@ -992,12 +1126,14 @@ static int refresh_folds(de_ctx *c, de_program *p, bool aux_current = false) {
         if (rc != DE_OK) return fail(c, rc, "constant folding: %s", p->aux->ctx->err.c_str());
     }
     std::vector<unsigned char> X(std::max<size_t>((size_t)p->n_features, 1) * es, 0), out(na * es);
-    p->fold_ok.assign(na, 0);
-    rc = de_eval(c, p->aux, X.data(), 1, std::max<int64_t>(p->n_features, 1), nullptr, out.data(), 1, p->fold_ok.data());
+    std::vector<uint8_t> aok(na, 0);
+    rc = de_eval(c, p->aux, X.data(), 1, std::max<int64_t>(p->n_features, 1), nullptr, out.data(), 1, aok.data());
     if (rc != DE_OK) return rc;
-    for (size_t j = 0; j < na; j++) {
-        const double v = p->dtype == DE_F32 ? (double)reinterpret_cast<float *>(out.data())[j]
-                                            : reinterpret_cast<double *>(out.data())[j];
+    for (size_t a = 0; a < na; a++) {
+        const size_t j = (size_t)p->aux_fold[a];
+        const double v = p->dtype == DE_F32 ? (double)reinterpret_cast<float *>(out.data())[a]
+                                            : reinterpret_cast<double *>(out.data())[a];
+        p->fold_ok[j] = aok[a];
         write_imm(p->fcode[(size_t)p->folds[j].instr], p->dtype, v);
     }
     return DE_OK;
@@ -1008,8 +1144,9 @@ int de_program_create(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, con
                       int64_t n_trees, const void *consts, const int64_t *const_offsets,
                       int32_t n_features, int32_t n_params, uint32_t options, de_program_t **out_program) {
     const char *nf = getenv("DE_NO_FOLD");
-    return create_impl(ctx, dtype, nodes, node_offsets, n_trees, consts, const_offsets, n_features, n_params, options,
-                       !(nf && *nf == '1'), out_program);
+    if (!ctx) return DE_ERR_INVALID_ARG;
+    DE_NOTHROW(ctx, create_impl(ctx, dtype, nodes, node_offsets, n_trees, consts, const_offsets, n_features, n_params, options,
+                                !(nf && *nf == '1'), out_program));
 }
 
 int de_program_create_cse(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, const int64_t *node_offsets,
@@ -1018,9 +1155,10 @@ int de_program_create_cse(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes,
                           de_program_t **out_program) {
     const char *nf = getenv("DE_NO_FOLD"), *nc = getenv("DE_NO_CSE");
     const bool fold = !(nf && *nf == '1'), cse = !(nc && *nc == '1');
+    if (!ctx) return DE_ERR_INVALID_ARG;
     if (n_trees > 0 && cse_nodes && !cse_offsets) return fail(ctx, DE_ERR_INVALID_ARG, "cse_offsets is null");
-    return create_impl(ctx, dtype, nodes, node_offsets, n_trees, consts, const_offsets, n_features, n_params, options, fold, out_program,
-                       fold && cse ? cse_nodes : nullptr, cse_offsets);
+    DE_NOTHROW(ctx, create_impl(ctx, dtype, nodes, node_offsets, n_trees, consts, const_offsets, n_features, n_params, options, fold, out_program,
+                                fold && cse ? cse_nodes : nullptr, cse_offsets));
 }
 
 // The eval program of tree t is lowered from its CSE tape when the caller supplied one (a GraphNode tree: shared subtrees
@@ -1177,8 +1315,8 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         // ---- folded lowering of the eval program + the auxiliary population of constant subtrees
         if (allow_fold) {
             lo.fold = true;
-            std::vector<de_tape_node_t> anodes;
-            std::vector<int64_t> anoff, acoff;
+            std::vector<de_tape_node_t> &anodes = p->fold_nodes; // (retained: the host-folded subtrees are re-evaluated from them)
+            std::vector<int64_t> &anoff = p->fold_noff, &acoff = p->fold_coff;
             bool any_cse = false;
             p->fcode_off.assign((size_t)n_trees + 1, 0);
             p->fconst_instr.assign((size_t)total_consts, -1);
@@ -1251,20 +1389,45 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
             lap("merge folded");
             if (!p->folds.empty()) {
                 const size_t es = dtype == DE_F32 ? 4 : 8;
-                std::vector<unsigned char> ac(std::max<size_t>(p->aux_const_src.size(), 1) * es, 0);
-                for (size_t k = 0; k < p->aux_const_src.size(); k++) {
-                    const double v = p->consts[(size_t)p->aux_const_src[k]];
-                    if (dtype == DE_F32) reinterpret_cast<float *>(ac.data())[k] = (float)v;
-                    else reinterpret_cast<double *>(ac.data())[k] = v;
+                // which folds stay on the host: subtrees of + - * / only (the turbo division is not IEEE: such programs fold everything on
+                // the device, with the operators they evaluate with; DE_NO_HOST_FOLD=1: everything on the device, for A/B tests)
+                const char *nh = getenv("DE_NO_HOST_FOLD");
+                const bool host_fold = !(nh && *nh == '1') && !(options & DE_OPT_TURBO);
+                p->fold_host.assign(n_folds, 0);
+                if (host_fold)
+                    parallel_for_trees((int64_t)n_folds, [&](int64_t j) {
+                        p->fold_host[(size_t)j] = host_foldable(anodes.data() + anoff[(size_t)j], anoff[(size_t)j + 1] - anoff[(size_t)j]) ? 1 : 0;
+                    }, 512);
+                // the others form the auxiliary population (their tape slices and constants, concatenated in fold order)
+                std::vector<de_tape_node_t> xnodes;
+                std::vector<int64_t> xnoff{0}, xcoff{0};
+                p->aux_fold.clear();
+                p->aux_csrc.clear();
+                for (size_t j = 0; j < n_folds; j++) {
+                    if (p->fold_host[j]) continue;
+                    p->aux_fold.push_back((int32_t)j);
+                    xnodes.insert(xnodes.end(), anodes.begin() + anoff[j], anodes.begin() + anoff[j + 1]);
+                    p->aux_csrc.insert(p->aux_csrc.end(), p->aux_const_src.begin() + acoff[j], p->aux_const_src.begin() + acoff[j + 1]);
+                    xnoff.push_back((int64_t)xnodes.size());
+                    xcoff.push_back((int64_t)p->aux_csrc.size());
                 }
-                int rc = create_impl(ctx, dtype, anodes.data(), anoff.data(), (int64_t)p->folds.size(), ac.data(),
-                                     acoff.data(), n_features, 0, options, false, &p->aux);
-                if (rc != DE_OK) return rc;
                 p->folded = true;
-                lap("aux program (create)");
-                rc = refresh_folds(ctx, p.get(), true);
+                lap("host folds: classify, auxiliary tapes");
+                if (!p->aux_fold.empty()) {
+                    std::vector<unsigned char> ac(std::max<size_t>(p->aux_csrc.size(), 1) * es, 0);
+                    for (size_t k = 0; k < p->aux_csrc.size(); k++) {
+                        const double v = p->consts[(size_t)p->aux_csrc[k]];
+                        if (dtype == DE_F32) reinterpret_cast<float *>(ac.data())[k] = (float)v;
+                        else reinterpret_cast<double *>(ac.data())[k] = v;
+                    }
+                    int rc = create_impl(ctx, dtype, xnodes.data(), xnoff.data(), (int64_t)p->aux_fold.size(), ac.data(),
+                                         xcoff.data(), n_features, 0, options, false, &p->aux);
+                    if (rc != DE_OK) return rc;
+                    lap("aux program (create)");
+                }
+                int rc = refresh_folds(ctx, p.get(), true);
                 if (rc != DE_OK) return rc;
-                lap("aux program (evaluate)");
+                lap("folds (evaluate: host + aux)");
             } else if (any_cse) {
                 p->folded = true; // the eval program is the CSE lowering even without a constant subtree to fold
             } else {
@@ -1295,55 +1458,50 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         // the early-exit walk (h_tree_skip) rebuilds record addresses from their low 32 bits: the stream must lie inside one
         // 4 GiB window.  An allocation that straddles a boundary (once in ~10^4 for a 400 KB stream) is set aside and redone.
         // (a threaded program allocates the stream twice: the second half receives the re-linked stream of the live trees, de_compact_live_kernel)
-        void *rejected[4] = {nullptr, nullptr, nullptr, nullptr};
-        int n_rej = 0;
-        hipError_t ast = hipSuccess;
+        // ONE device arena per eval program (round 6): [record stream | its second half for the compacted live trees | tree offsets |
+        // compaction control ints | initial flags], one allocation from the context's pool; a small program (the one-tree call of
+        // de_eval_tree_array) goes up in ONE copy from a zero-filled host image, a large one in one memset + three copies.
         const size_t abytes = p->threaded ? 2 * cbytes : cbytes;
-        for (;;) {
-            ast = prog_malloc(ctx, reinterpret_cast<void **>(&p->d_code), abytes);
-            if (ast != hipSuccess) break;
-            const uint64_t a0 = (uint64_t)(uintptr_t)p->d_code, a1 = a0 + abytes - 1;
-            if ((a0 >> 32) == (a1 >> 32) || n_rej == 4) break;
-            rejected[n_rej++] = p->d_code;
-            p->d_code = nullptr;
-        }
-        for (int k = 0; k < n_rej; k++) prog_free(ctx, rejected[k]);
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t off_bytes = p->bcode_off.size() * sizeof(int32_t);
+        const size_t ints_bytes = p->threaded ? ((size_t)2 * (size_t)p->n_trees + 5) * sizeof(int32_t) : 0;
+        const size_t o_off = al(abytes), o_ints = o_off + al(off_bytes), o_ok = o_ints + al(ints_bytes);
+        const size_t total = o_ok + al((size_t)std::max<int64_t>(p->n_trees, 1));
+        const hipError_t ast = prog_malloc(ctx, reinterpret_cast<void **>(&p->d_code), total); // (one 4 GiB window: prog_malloc's contract)
         if (ast != hipSuccess) return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(ast));
-        const uint64_t a0 = (uint64_t)(uintptr_t)p->d_code;
-        if ((a0 >> 32) != ((a0 + abytes - 1) >> 32)) return fail(ctx, DE_ERR_HIP, "instruction stream straddles a 4 GiB boundary");
+        if (!in_one_window(p->d_code, abytes)) return fail(ctx, DE_ERR_HIP, "instruction stream straddles a 4 GiB boundary");
+        char *base = reinterpret_cast<char *>(p->d_code);
+        p->eval_arena = true; // (d_code_off, d_compact_ints, d_ok_eval live inside d_code's allocation: never freed on their own)
+        p->d_code_off = reinterpret_cast<int32_t *>(base + o_off);
+        p->d_ok_eval = reinterpret_cast<uint8_t *>(base + o_ok);
         if (p->threaded) {
             p->d_compact_code = p->d_code + cbytes / sizeof(BoundInstr);
-            if (hipMalloc(reinterpret_cast<void **>(&p->d_compact_ints), ((size_t)2 * (size_t)p->n_trees + 5) * sizeof(int32_t)) != hipSuccess) {
-                (void)hipGetLastError();
-                p->d_compact_ints = nullptr; // (the launch proper then walks past flagged trees as in round 3)
-                p->d_compact_code = nullptr;
-            }
+            p->d_compact_ints = reinterpret_cast<int32_t *>(base + o_ints);
+        }
+        lap("hipMalloc (arena)");
+        const std::vector<BoundInstr> &stream = p->threaded ? p->ccode : p->bcode;
+        const std::vector<int32_t> &offs = p->threaded ? p->ccode_off : p->bcode_off;
+        hipError_t st = hipSuccess;
+        if (total <= (size_t)(128u << 10)) {
+            // (the second half of a threaded stream needs no initial content: de_compact_live_kernel writes what the launch proper reads)
+            std::vector<unsigned char> img(total, 0);
+            if (!stream.empty()) std::memcpy(img.data(), stream.data(), stream.size() * sizeof(BoundInstr));
+            std::memcpy(img.data() + o_off, offs.data(), off_bytes);
+            if (p->n_trees > 0) std::memcpy(img.data() + o_ok, p->host_ok_eval.data(), (size_t)p->n_trees);
+            st = hipMemcpy(base, img.data(), total, hipMemcpyHostToDevice);
+        } else {
+            st = hipMemset(p->d_code, 0, cbytes);
+            if (st == hipSuccess && !stream.empty()) st = hipMemcpy(p->d_code, stream.data(), stream.size() * sizeof(BoundInstr), hipMemcpyHostToDevice);
+            if (st == hipSuccess) st = hipMemcpy(p->d_code_off, offs.data(), off_bytes, hipMemcpyHostToDevice);
+            if (st == hipSuccess && p->n_trees > 0) st = hipMemcpy(p->d_ok_eval, p->host_ok_eval.data(), (size_t)p->n_trees, hipMemcpyHostToDevice);
+        }
+        if (st != hipSuccess) {
+            prog_free(ctx, p->d_code);
+            p->d_code = nullptr;
+            return fail(ctx, DE_ERR_HIP, "program upload failed: %s", hipGetErrorString(st));
         }
     }
-    lap("hipMalloc (stream, ints)");
-    HIP_TRY(ctx, hipMemset(p->d_code, 0, cbytes));
-    hipError_t st = hipMalloc(reinterpret_cast<void **>(&p->d_code_off), p->bcode_off.size() * sizeof(int32_t));
-    if (st != hipSuccess) {
-        prog_free(ctx, p->d_code);
-        return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(st));
-    }
-    if (!p->bcode.empty())
-        st = hipMemcpy(p->d_code, (p->threaded ? p->ccode : p->bcode).data(),
-                       (p->threaded ? p->ccode : p->bcode).size() * sizeof(BoundInstr), hipMemcpyHostToDevice);
-    if (st == hipSuccess)
-        st = hipMemcpy(p->d_code_off, (p->threaded ? p->ccode_off : p->bcode_off).data(), p->bcode_off.size() * sizeof(int32_t),
-                       hipMemcpyHostToDevice);
-    if (st != hipSuccess) {
-        prog_free(ctx, p->d_code);
-        (void)hipFree(p->d_code_off);
-        return fail(ctx, DE_ERR_HIP, "program upload failed: %s", hipGetErrorString(st));
-    }
-    lap("memset + upload");
-    {
-        const int rc = upload_ok_eval(ctx, p.get());
-        if (rc != DE_OK) return rc; // (~de_program is not run on this path: the process is out of device memory anyway)
-    }
-    lap("flags upload");
+    lap("memset + upload (stream, offsets, flags)");
     if (getenv("DE_VERIFY") && *getenv("DE_VERIFY") == '1') {
         const int rc = de_program_verify(p.get());
         if (rc != DE_OK) return rc;
@@ -1366,6 +1524,7 @@ static int set_consts_impl(de_program_t *p, const void *consts) {
     if (!p) return DE_ERR_INVALID_ARG;
     de_ctx *ctx = p->ctx;
     if (!consts && !p->consts.empty()) return fail(ctx, DE_ERR_INVALID_ARG, "consts is null");
+    p->consts_gen++; // (the cached certificate program belongs to the old constants)
     const bool timing = getenv("DE_DEBUG_TIMING") != nullptr; // stderr: microseconds per phase
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
@@ -1503,8 +1662,10 @@ int de_program_destroy(de_program_t *p) {
     de_ctx *c = p->ctx;
     dbg_lap("destroy: stream sync");
     prog_free(c, p->d_code);
-    if (p->d_code_off) (void)hipFree(p->d_code_off);
-    if (p->d_compact_ints) (void)hipFree(p->d_compact_ints);
+    if (!p->eval_arena) {
+        if (p->d_code_off) (void)hipFree(p->d_code_off);
+        if (p->d_compact_ints) (void)hipFree(p->d_compact_ints);
+    }
     if (p->d_cert_code) (void)hipFree(p->d_cert_code);
     if (p->d_cert_off) (void)hipFree(p->d_cert_off);
     dbg_lap("destroy: eval streams");
@@ -1518,7 +1679,7 @@ int de_program_destroy(de_program_t *p) {
     prog_free(c, p->d_rtcode);
     for (void *q : {(void *)p->d_rtcode_off, (void *)p->d_rtcode_mid, (void *)p->d_rt_ids})
         if (q) (void)hipFree(q);
-    if (p->d_ok_eval) (void)hipFree(p->d_ok_eval);
+    if (p->d_ok_eval && !p->eval_arena) (void)hipFree(p->d_ok_eval);
     for (void *q : {(void *)p->d_ok_grad, (void *)p->d_ng, (void *)p->d_goff})
         if (q) (void)hipFree(q);
     dbg_lap("destroy: gradient streams, flags");
@@ -1574,7 +1735,7 @@ int64_t de_host_pool_selftest(int64_t n, int32_t *n_ranges) {
             ranges.fetch_add(1);
             for (int64_t i = b; i < e; i++) hit[(size_t)i]++;
         });
-    } catch (const std::bad_alloc &) { return -1; }
+    } catch (...) { return -1; }
     if (n_ranges) *n_ranges = ranges.load();
     int64_t once = 0;
     for (uint8_t h : hit) once += h == 1;
@@ -1598,6 +1759,8 @@ uint64_t de_program_stream_hash(const de_program_t *p) {
     vec(p->fbcode); vec(p->tcode); vec(p->tcode_off); vec(p->ccode); vec(p->ccode_off); vec(p->bsite); vec(p->tsite);
     vec(p->consts); vec(p->const_off); vec(p->const_instr); vec(p->fconst_instr); vec(p->const_checks); vec(p->n_consts_tree);
     vec(p->aux_const_src); vec(p->host_ok_eval); vec(p->host_ok_grad); vec(p->fold_ok);
+    vec(p->fold_host); vec(p->fold_noff); vec(p->fold_coff); vec(p->aux_fold); vec(p->aux_csrc);
+    mix(p->fold_nodes.data(), p->fold_nodes.size() * sizeof(de_tape_node_t));
     for (const auto &f : p->folds) { const int32_t w[3] = {f.tree, f.instr, f.tested_always ? 1 : 0}; mix(w, sizeof w); }
     const int64_t scal[6] = {p->n_trees, p->n_nodes, p->n_slots, p->uses_params ? 1 : 0, p->folded ? 1 : 0, p->threaded ? 1 : 0};
     mix(scal, sizeof scal);
@@ -1794,7 +1957,7 @@ int64_t de_lower_tape(int dtype, const de_tape_node_t *nodes, int64_t n_nodes, c
         if (!words || cap < nw) return nw;
         std::memcpy(words, tp.code.data(), (size_t)nw * 4);
         return nw;
-    } catch (const std::bad_alloc &) {
+    } catch (...) {
         return -DE_ERR_HIP;
     }
 }
@@ -1818,7 +1981,7 @@ int64_t de_lower_tape_stage(int dtype, const de_tape_node_t *nodes, int64_t n_no
         if (!words || cap < n) return n;
         std::memcpy(words, o.data(), (size_t)n * 4);
         return n;
-    } catch (const std::bad_alloc &) {
+    } catch (...) {
         return -DE_ERR_HIP;
     }
 }
@@ -1893,17 +2056,18 @@ static int ensure_cert_program(de_ctx *c, de_program *p);
 // keeps the FLAG exact but drops values the reference still sums — bound for the flat-switch kernel; plus, per tree, the largest
 // |constant operand| (deg0_eval of a constant is an array of N copies: the reference sums that too).  A superset of the arrays the
 // reference sums (the inner values of its fused 2/3-node kernels are never materialised there): sound, slightly conservative.
-// Rebuilt at every call (constants may have moved; ~1 us per tree).
+// Cached per constants generation (it used to be rebuilt serially, with a stream synchronisation and an upload, at EVERY call);
+// built on the pool of host threads like every other per-tree pass.
 static int ensure_cert_program(de_ctx *c, de_program *p) {
+    if (p->cert_gen == p->consts_gen && p->d_cert_code && p->d_cert_off) return DE_OK;
     const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
     const std::vector<int32_t> &off = p->folded ? p->fcode_off : p->code_off;
     const int prb = p->prows ? p->n_features + p->n_slots : -1;
     std::vector<BoundInstr> bc;
-    std::vector<int32_t> boff((size_t)p->n_trees + 1, 0);
-    std::vector<Instr> tmp;
+    std::vector<int32_t> boff;
     p->cert_cmax.assign((size_t)p->n_trees, 0.0);
-    for (int64_t t = 0; t < p->n_trees; t++) {
-        tmp.assign(src.begin() + off[(size_t)t], src.begin() + off[(size_t)t + 1]);
+    build_stream_by_trees(p->n_trees, &bc, &boff, [&](int64_t t, std::vector<BoundInstr> *out) {
+        std::vector<Instr> tmp(src.begin() + off[(size_t)t], src.begin() + off[(size_t)t + 1]);
         double cm = 0.0;
         for (Instr &ins : tmp) {
             if ((ins.hdr & H_OP_MASK) != DOP_LOAD) ins.hdr |= H_CHECK_OUT;
@@ -1913,9 +2077,8 @@ static int ensure_cert_program(de_ctx *c, de_program *p) {
             }
         }
         p->cert_cmax[(size_t)t] = cm;
-        bind_tree(tmp.data(), tmp.size(), true, p->n_features, &bc, prb);
-        boff[(size_t)t + 1] = (int32_t)bc.size();
-    }
+        bind_tree(tmp.data(), tmp.size(), true, p->n_features, out, prb);
+    });
     bc.push_back(BoundInstr{0u, 0u, 0u, 0u}); // (the kernel prefetches pc + 1)
     HIP_TRY(c, hipSetDevice(c->device));
     if (p->cert_cap < bc.size()) {
@@ -1929,6 +2092,7 @@ static int ensure_cert_program(de_ctx *c, de_program *p) {
     HIP_TRY(c, hipStreamSynchronize(c->stream)); // (an earlier certificate launch may still read the buffers)
     HIP_TRY(c, hipMemcpy(p->d_cert_code, bc.data(), bc.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(p->d_cert_off, boff.data(), boff.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    p->cert_gen = p->consts_gen;
     return DE_OK;
 }
 
@@ -1946,7 +2110,7 @@ int de_eval_sum_certificate(de_ctx_t *c, de_program_t *p, const void *X, int64_t
         return DE_OK;
     }
     const CertReq cr{certified, max_abs};
-    return eval_impl(c, p, X, N, ldX, pa, nullptr, N, ok, nullptr, &cr);
+    DE_NOTHROW(c, eval_impl(c, p, X, N, ldX, pa, nullptr, N, ok, nullptr, &cr)); // (builds host vectors: no exception may leave the C ABI)
 }
 
 int de_eval(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
@@ -1954,7 +2118,7 @@ int de_eval(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX,
     if (!c || !p) return DE_ERR_INVALID_ARG;
     if (N < 0 || !ok || (p->n_trees > 0 && N > 0 && (!X || !out))) return fail(c, DE_ERR_INVALID_ARG, "null buffer");
     if (ld_out < N) return fail(c, DE_ERR_INVALID_ARG, "ld_out < N");
-    return eval_impl(c, p, X, N, ldX, pa, out, ld_out, ok, nullptr);
+    DE_NOTHROW(c, eval_impl(c, p, X, N, ldX, pa, out, ld_out, ok, nullptr));
 }
 
 int de_eval_loss(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
@@ -1965,7 +2129,7 @@ int de_eval_loss(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t
     if (p->direct || !p->threaded)
         return fail(c, DE_ERR_UNSUPPORTED, "de_eval_loss needs the LDS-tiled kernel (feature matrix too wide for this build)");
     const LossReq lr{y, w, loss_kind, loss};
-    return eval_impl(c, p, X, N, ldX, pa, nullptr, N, ok, &lr);
+    DE_NOTHROW(c, eval_impl(c, p, X, N, ldX, pa, nullptr, N, ok, &lr));
 }
 
 static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t ldX, const de_param_args_t *pa,
@@ -2492,21 +2656,9 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             const size_t gt_cap = 2 * p->gbcode.size() + (size_t)p->n_trees + 1;
             // (inside one 4 GiB window: the handlers bump the record pointer without a carry; a straddling allocation is set aside and redone)
             {
-                void *rejected[4] = {nullptr, nullptr, nullptr, nullptr};
-                int n_rej = 0;
-                hipError_t ast = hipSuccess;
-                for (;;) {
-                    ast = prog_malloc(c, reinterpret_cast<void **>(&p->d_gtcode), gt_cap * sizeof(BoundInstr));
-                    if (ast != hipSuccess) break;
-                    const uint64_t a0 = (uint64_t)(uintptr_t)p->d_gtcode, a1 = a0 + gt_cap * sizeof(BoundInstr) - 1;
-                    if ((a0 >> 32) == (a1 >> 32) || n_rej == 4) break;
-                    rejected[n_rej++] = p->d_gtcode;
-                    p->d_gtcode = nullptr;
-                }
-                for (int k = 0; k < n_rej; k++) prog_free(c, rejected[k]);
+                const hipError_t ast = prog_malloc(c, reinterpret_cast<void **>(&p->d_gtcode), gt_cap * sizeof(BoundInstr));
                 if (ast != hipSuccess) return fail(c, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(ast));
-                const uint64_t a0 = (uint64_t)(uintptr_t)p->d_gtcode;
-                if ((a0 >> 32) != ((a0 + gt_cap * sizeof(BoundInstr) - 1) >> 32)) return fail(c, DE_ERR_HIP, "gradient instruction stream straddles a 4 GiB boundary");
+                if (!in_one_window(p->d_gtcode, gt_cap * sizeof(BoundInstr))) return fail(c, DE_ERR_HIP, "gradient instruction stream straddles a 4 GiB boundary");
             }
             HIP_TRY(c, hipMemset(p->d_gtcode, 0, gt_cap * sizeof(BoundInstr)));
             HIP_TRY(c, hipMalloc(reinterpret_cast<void **>(&p->d_gtcode_off), p->gtcode_off.size() * sizeof(int32_t)));
@@ -2558,6 +2710,9 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
     // DE_OPT_FORWARD_GRAD: the caller wants the reference's forward-mode flag semantics exactly (a product chain that overflows in one
     // association only flips `ok` in ~0.03 % of Float32 fuzz cases under reverse accumulation): forward duals whatever the width
     if (p->options & DE_OPT_FORWARD_GRAD) return DE_OK;
+    // ABI 3 (round 6): reverse accumulation is an OPT-IN (DE_OPT_REVERSE_GRAD, or DE_LOSS_GRAD_REVERSE=1 for the tests / experiments): the
+    // default keeps the reference's forward-mode flag semantics
+    if (!(p->options & DE_OPT_REVERSE_GRAD) && !(env && *env == '1')) return DE_OK;
     // a CSE program (GraphNode trees, §3.1) reads a persistent row from several consumers: the backward sweep ACCUMULATES their adjoints
     // into that row (round 4: `acc_use` below); DE_REV_NO_SHARED=1 restores round 3's fall-back to forward duals for such populations
     if (p->cse_generic && getenv("DE_REV_NO_SHARED")) return DE_OK;
@@ -2975,21 +3130,9 @@ static int ensure_rev_threaded(de_ctx *c, de_program *p, int mode, GradArgs *g) 
         }
         { // (inside one 4 GiB window: the handlers bump the record pointer without a carry)
             const size_t rbytes = (p->rtcode.size() + 1) * sizeof(BoundInstr);
-            void *rejected[4] = {nullptr, nullptr, nullptr, nullptr};
-            int n_rej = 0;
-            hipError_t ast = hipSuccess;
-            for (;;) {
-                ast = prog_malloc(c, reinterpret_cast<void **>(&p->d_rtcode), rbytes);
-                if (ast != hipSuccess) break;
-                const uint64_t a0 = (uint64_t)(uintptr_t)p->d_rtcode;
-                if ((a0 >> 32) == ((a0 + rbytes - 1) >> 32) || n_rej == 4) break;
-                rejected[n_rej++] = p->d_rtcode;
-                p->d_rtcode = nullptr;
-            }
-            for (int k = 0; k < n_rej; k++) prog_free(c, rejected[k]);
+            const hipError_t ast = prog_malloc(c, reinterpret_cast<void **>(&p->d_rtcode), rbytes);
             if (ast != hipSuccess) return fail(c, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(ast));
-            const uint64_t a0 = (uint64_t)(uintptr_t)p->d_rtcode;
-            if ((a0 >> 32) != ((a0 + rbytes - 1) >> 32)) return fail(c, DE_ERR_HIP, "reverse instruction stream straddles a 4 GiB boundary");
+            if (!in_one_window(p->d_rtcode, rbytes)) return fail(c, DE_ERR_HIP, "reverse instruction stream straddles a 4 GiB boundary");
         }
         HIP_TRY(c, hipMemset(p->d_rtcode, 0, (p->rtcode.size() + 1) * sizeof(BoundInstr)));
         if (!p->d_rtcode_off) {

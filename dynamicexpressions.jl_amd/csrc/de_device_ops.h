@@ -89,6 +89,22 @@ template <> struct M<float> {
     static __device__ __forceinline__ bool signbit(T x) { return __builtin_signbit(x); }
 };
 
+// ---- attribution (third party, NOT /root/reference) ------------------------------------------------------------------------------
+// de_atan_f64, de_tan_f64 (__kernel_tan + the Cody-Waite rem_pio2) and de_pow_f64 (the __ieee754_pow core) below restate the algorithms
+// of FreeBSD msun / fdlibm — s_atan.c, k_tan.c, e_rem_pio2.c, e_pow.c — the library Julia's Base ports: the same constants in the same
+// operation order, so that the device returns the reference's bits.  fdlibm's notice, which its licence requires to be preserved:
+//
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//   Copyright (C) 2004 by Sun Microsystems, Inc. All rights reserved.   (k_tan.c, e_pow.c)
+//
+//   Developed at SunSoft/SunPro, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
+//
+// (tools/fit/ holds the bit-exact Python prototypes that were checked against msun's hex words; the oracle calls glibc and restates none of it.)
 // Float64 atan: the algorithm Julia's Base.atan uses (the FreeBSD msun / fdlibm scheme: argument reduction at 7/16, 11/16, 19/16,
 // 39/16 to atan(0.5), atan(1), atan(1.5), atan(inf) in hi + lo parts, odd/even split of a degree-11 polynomial in x^2).  Same
 // constants, same operation order, no contraction (-ffp-contract=off): the reference's bits, 0.85 ulp worst case — OCML's atan

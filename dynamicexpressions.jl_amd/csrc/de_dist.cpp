@@ -8,10 +8,15 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <future>
+#include <memory>
 #include <string>
+#include <thread>
 
 #include "../../include/de_hip.h"
 #include "de_kernels.h"
@@ -28,6 +33,8 @@ struct Rccl {
     int (*AllGather)(const void *, void *, size_t, int, NcclComm, hipStream_t) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommAbort)(NcclComm) = nullptr;              // optional: a timed-out communicator is aborted, not destroyed (destroy would wait for the stuck collective)
+    int (*CommGetAsyncError)(NcclComm, int *) = nullptr; // optional
     std::string err;
     bool load() {
         if (lib) return true;
@@ -47,6 +54,8 @@ struct Rccl {
         SYM(Broadcast, "ncclBroadcast")
         SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+        CommAbort = reinterpret_cast<decltype(CommAbort)>(dlsym(lib, "ncclCommAbort"));
+        CommGetAsyncError = reinterpret_cast<decltype(CommGetAsyncError)>(dlsym(lib, "ncclCommGetAsyncError"));
         return true;
     }
 };
@@ -66,8 +75,19 @@ struct de_comm {
     uint8_t *send = nullptr, *recv = nullptr; // device staging: ceil(n / world) and world * ceil(n / world) bytes
     uint8_t *stage = nullptr;                 // device staging for HOST flag arrays: n bytes (local flags in, global flags out)
     size_t cap = 0, stage_cap = 0;
+    // Round 6: every collective is BOUNDED.  timeout_ms > 0: the call that queued a collective waits for it (polling the stream and the
+    // communicator's asynchronous error state) and gives up after timeout_ms with DE_ERR_RCCL and a message that says which rank waited
+    // for what — a peer that died or never entered the collective otherwise hangs every other rank for ever.  0 = the calls stay
+    // asynchronous (round 5's behaviour; the caller bounds its own synchronisation).  Default: DE_DIST_TIMEOUT_MS, else 0.
+    int64_t timeout_ms = 0;
+    bool dead = false; // a collective timed out: the communicator was aborted, every later call fails at once
     std::string err;
 };
+
+static int64_t env_ms(const char *name, int64_t dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoll(v) : dflt;
+}
 
 static int dfail(de_comm *c, int code, const char *fmt, ...) {
     char buf[512];
@@ -78,6 +98,35 @@ static int dfail(de_comm *c, int code, const char *fmt, ...) {
     if (c) c->err = buf;
     else g_rccl.err = buf;
     return code;
+}
+
+// Wait (bounded) for what was just queued on the context's stream; on timeout abort the communicator.
+static int bounded_wait(de_comm *c, hipStream_t stream, const char *what) {
+    if (c->timeout_ms <= 0) return DE_OK;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(c->timeout_ms);
+    for (int spins = 0;; spins++) {
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) return DE_OK;
+        if (q != hipErrorNotReady) return dfail(c, DE_ERR_HIP, "%s: %s", what, hipGetErrorString(q));
+        if (c->comm && g_rccl.CommGetAsyncError) {
+            int ae = 0;
+            if (g_rccl.CommGetAsyncError(c->comm, &ae) == 0 && ae != 0) {
+                c->dead = true;
+                if (g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm);
+                c->comm = nullptr;
+                return dfail(c, DE_ERR_RCCL, "%s: RCCL reported an asynchronous error on rank %d of %d: %s", what, c->rank, c->world, g_rccl.GetErrorString(ae));
+            }
+        }
+        if (std::chrono::steady_clock::now() > deadline) {
+            c->dead = true;
+            if (c->comm && g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm);
+            c->comm = nullptr;
+            return dfail(c, DE_ERR_RCCL, "%s timed out after %lld ms on rank %d of %d: a peer is down or did not enter the same collective "
+                         "(every rank must call it with the same sizes); the communicator was aborted", what, (long long)c->timeout_ms, c->rank, c->world);
+        }
+        if (spins < 2000) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
 }
 
 extern "C" {
@@ -114,7 +163,30 @@ int de_dist_init(de_ctx_t *ctx, int rank, int world, const void *id, de_comm_t *
             delete c;
             return DE_ERR_HIP;
         }
-        const int rc = g_rccl.CommInitRank(&c->comm, world, u, rank);
+        // ncclCommInitRank blocks until ALL `world` ranks have called it with this id: bounded too (DE_DIST_INIT_TIMEOUT_MS, default 120 s;
+        // 0 = wait for ever).  It runs on a helper thread (with the context's device current there); on timeout the thread is left behind —
+        // it is blocked inside RCCL and there is no call that cancels it — and the caller gets a status instead of a hang.
+        const int64_t init_ms = env_ms("DE_DIST_INIT_TIMEOUT_MS", 120000);
+        int rc = 0;
+        if (init_ms <= 0) rc = g_rccl.CommInitRank(&c->comm, world, u, rank);
+        else {
+            struct Slot { NcclComm comm = nullptr; std::promise<int> done; };
+            auto slot = std::make_shared<Slot>();
+            std::future<int> fut = slot->done.get_future();
+            std::thread([slot, world, u, rank, dev] {
+                (void)hipSetDevice(dev);
+                slot->done.set_value(g_rccl.CommInitRank(&slot->comm, world, u, rank));
+            }).detach();
+            if (fut.wait_for(std::chrono::milliseconds(init_ms)) != std::future_status::ready) {
+                if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+                dfail(nullptr, DE_ERR_RCCL, "ncclCommInitRank(rank %d of %d) timed out after %lld ms: not all %d ranks called de_dist_init with this "
+                      "unique id (DE_DIST_INIT_TIMEOUT_MS)", rank, world, (long long)init_ms, world);
+                delete c;
+                return DE_ERR_RCCL;
+            }
+            rc = fut.get();
+            c->comm = slot->comm;
+        }
         if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
         if (rc != 0) {
             dfail(nullptr, DE_ERR_RCCL, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(rc));
@@ -122,13 +194,20 @@ int de_dist_init(de_ctx_t *ctx, int rank, int world, const void *id, de_comm_t *
             return DE_ERR_RCCL;
         }
     }
+    c->timeout_ms = env_ms("DE_DIST_TIMEOUT_MS", 0);
     *out = c;
+    return DE_OK;
+}
+
+int de_dist_set_timeout(de_comm_t *c, int64_t timeout_ms) {
+    if (!c || timeout_ms < 0) return DE_ERR_INVALID_ARG;
+    c->timeout_ms = timeout_ms;
     return DE_OK;
 }
 
 int de_dist_destroy(de_comm_t *c) {
     if (!c) return DE_OK;
-    if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm); // (an aborted communicator is already gone: comm == nullptr)
     if (c->send) (void)hipFree(c->send);
     if (c->recv) (void)hipFree(c->recv);
     if (c->stage) (void)hipFree(c->stage);
@@ -152,16 +231,18 @@ int64_t de_dist_shard_size(int64_t n_trees, int rank, int world) { // trees {t :
 int de_dist_broadcast(de_comm_t *c, void *buf, size_t bytes, int root) {
     if (!c || (!buf && bytes) || root < 0 || root >= c->world) return DE_ERR_INVALID_ARG;
     if (c->world == 1 || bytes == 0) return DE_OK;
+    if (c->dead) return dfail(c, DE_ERR_RCCL, "de_dist_broadcast: the communicator was aborted by an earlier time-out");
     hipStream_t stream = static_cast<hipStream_t>(de_ctx_stream(c->ctx));
     if (hipSetDevice(de_ctx_device(c->ctx)) != hipSuccess) return dfail(c, DE_ERR_HIP, "de_dist_broadcast: cannot select the context's device");
     const int rc = g_rccl.Broadcast(buf, buf, bytes, kNcclUint8, root, c->comm, stream);
     if (rc != 0) return dfail(c, DE_ERR_RCCL, "ncclBroadcast: %s", g_rccl.GetErrorString(rc));
-    return DE_OK;
+    return bounded_wait(c, stream, "de_dist_broadcast (ncclBroadcast)");
 }
 
 int de_dist_gather_flags(de_comm_t *c, const uint8_t *ok_local, int64_t n_trees, uint8_t *ok_global) {
     if (!c || n_trees < 0 || (n_trees > 0 && (!ok_local || !ok_global))) return DE_ERR_INVALID_ARG;
     if (n_trees == 0) return DE_OK;
+    if (c->dead) return dfail(c, DE_ERR_RCCL, "de_dist_gather_flags: the communicator was aborted by an earlier time-out");
     hipStream_t stream = static_cast<hipStream_t>(de_ctx_stream(c->ctx));
     const int64_t mine = de_dist_shard_size(n_trees, c->rank, c->world);
     const size_t per = (size_t)((n_trees + c->world - 1) / c->world);
@@ -173,7 +254,7 @@ int de_dist_gather_flags(de_comm_t *c, const uint8_t *ok_local, int64_t n_trees,
     HIPD(hipSetDevice(de_ctx_device(c->ctx))); // (the launches below go to the CURRENT device: make it the context's, as every de_eval* does)
     if (c->world == 1) {
         HIPD(hipMemcpyAsync(ok_global, ok_local, (size_t)n_trees, hipMemcpyDefault, stream));
-        return DE_OK;
+        return bounded_wait(c, stream, "de_dist_gather_flags (one rank: a copy)");
     }
     if (c->cap < per) {
         if (c->send) (void)hipFree(c->send);
@@ -206,7 +287,7 @@ int de_dist_gather_flags(de_comm_t *c, const uint8_t *ok_local, int64_t n_trees,
     HIPD(de::launch_dist_unpack(glob_dev ? ok_global : c->stage, c->recv, (int64_t)per, c->world, n_trees, stream));
     if (!glob_dev) HIPD(hipMemcpyAsync(ok_global, c->stage, (size_t)n_trees, hipMemcpyDeviceToHost, stream));
 #undef HIPD
-    return DE_OK;
+    return bounded_wait(c, stream, "de_dist_gather_flags (ncclAllGather)");
 }
 
 // Test / measurement hook (no RCCL needed): the pack and unpack launches of de_dist_gather_flags for a SIMULATED world on one GPU — every

@@ -83,6 +83,11 @@ class Comm:
             from . import api
             raise api.DeviceError(f"{self._lib.de_status_string(rc).decode()}: {self._lib.de_dist_last_error(self._h).decode()}")
 
+    def set_timeout(self, timeout_ms: int) -> None:
+        """Bound every collective of this communicator: the calls then WAIT for what they queued and raise DeviceError (DE_ERR_RCCL, the
+        communicator aborted) after ``timeout_ms`` instead of hanging on a peer that is down; 0 = asynchronous calls (the default)."""
+        self._check(self._lib.de_dist_set_timeout(self._h, int(timeout_ms)))
+
     def world_size(self) -> int:
         """Ranks of the communicator as RCCL reports them (ncclCommCount)."""
         return int(self._lib.de_dist_world_size(self._h))

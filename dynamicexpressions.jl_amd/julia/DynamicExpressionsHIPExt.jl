@@ -32,12 +32,13 @@ const DE_ERR_UNSUPPORTED_OP = Cint(3)
 const DE_LEAF_CONST, DE_LEAF_FEATURE, DE_LEAF_PARAM, DE_LEAF_SHARED = UInt8(0), UInt8(1), UInt8(2), UInt8(3)
 const DE_OP_SHARE = UInt8(0xFE)   # include/de_opcodes.h: "the subtree just emitted is shared subtree `arg`"
 const DE_F32, DE_F64 = Cint(0), Cint(1)
-const DE_OPT_EARLY_EXIT, DE_OPT_FUSE_DEG1, DE_OPT_FUSE_DEG2, DE_OPT_BUMPER_CHECKS, DE_OPT_TURBO, DE_OPT_FULL_EVAL, DE_OPT_FORWARD_GRAD =
-    UInt32(1), UInt32(2), UInt32(4), UInt32(8), UInt32(16), UInt32(32), UInt32(64)
+const DE_OPT_EARLY_EXIT, DE_OPT_FUSE_DEG1, DE_OPT_FUSE_DEG2, DE_OPT_BUMPER_CHECKS, DE_OPT_TURBO, DE_OPT_FULL_EVAL, DE_OPT_FORWARD_GRAD, DE_OPT_REVERSE_GRAD =
+    UInt32(1), UInt32(2), UInt32(4), UInt32(8), UInt32(16), UInt32(32), UInt32(64), UInt32(128)
 # The ABI this file was written for (include/de_hip.h lists what changed between versions).  Version 2: the rows / gradients of a tree
 # with `complete == false` are NOT evaluated to the end (the reference's early exit, src/Evaluate.jl:26-32): with the host arrays this
 # shim passes, the library NaN-fills them; `full_eval=true` (DE_OPT_FULL_EVAL) evaluates every tree on every sample instead.
-const DE_HIP_ABI_VERSION = Cint(2)
+# Version 3: fused loss gradients run forward duals (the reference's flag semantics) unless `reverse_grad=true` (DE_OPT_REVERSE_GRAD).
+const DE_HIP_ABI_VERSION = Cint(3)
 function __init__()
     v = try
         ccall((:de_abi_version, LIBDE), Cint, ())
@@ -146,7 +147,7 @@ function opcode_table(operators::OperatorEnum)
 end
 
 """EvalContext knobs that change RESULTS -> de_options bits (src/Evaluate.jl:156-181,496,607)."""
-function option_bits(operators::OperatorEnum, ctx::EvalContext; full_eval::Bool=false, forward_grad::Bool=false)
+function option_bits(operators::OperatorEnum, ctx::EvalContext; full_eval::Bool=false, forward_grad::Bool=false, reverse_grad::Bool=false)
     nops(d) = d <= length(operators.ops) ? length(operators.ops[d]) : 0
     fused = ctx.use_fused isa Val{true}
     bits = UInt32(0)
@@ -156,7 +157,8 @@ function option_bits(operators::OperatorEnum, ctx::EvalContext; full_eval::Bool=
     ctx.bumper isa Val{true} && (bits |= DE_OPT_BUMPER_CHECKS)
     ctx.turbo isa Val{true} && (bits |= DE_OPT_TURBO)   # the LoopVectorization knob = the relaxed-accuracy device operators
     full_eval && (bits |= DE_OPT_FULL_EVAL)             # no early exit at tree granularity: rows of incomplete trees are fully evaluated
-    forward_grad && (bits |= DE_OPT_FORWARD_GRAD)       # fused loss gradients by forward duals whatever the width: the reference's flag semantics exactly
+    forward_grad && (bits |= DE_OPT_FORWARD_GRAD)       # ABI 2's spelling of what is the default since ABI 3: fused loss gradients by forward duals (the reference's flag semantics exactly)
+    reverse_grad && (bits |= DE_OPT_REVERSE_GRAD)       # permission for reverse accumulation (faster from 8 gradient rows per tree on; `ok` may differ in ~0.03 % of Float32 cases)
     return bits
 end
 
@@ -368,6 +370,7 @@ end
 function HIPPopulation(
     trees::AbstractVector{<:AbstractExpressionNode{T}}, operators::OperatorEnum, n_features::Integer;
     eval_context::EvalContext=EvalContext(), n_params::Integer=0, full_eval::Bool=false, forward_grad::Bool=false,
+    reverse_grad::Bool=false,
 ) where {T<:Union{Float32,Float64}}
     optable = opcode_table(operators)
     nodes, consts, cse = TapeNode[], T[], TapeNode[]
@@ -398,7 +401,7 @@ function HIPPopulation(
             (Ptr{Cvoid}, Cint, Ptr{TapeNode}, Ptr{Int64}, Ptr{TapeNode}, Ptr{Int64}, Int64, Ptr{Cvoid}, Ptr{Int64}, Int32, Int32,
              UInt32, Ref{Ptr{Cvoid}}),
             hc, dtype_code(T), nodes, node_off, isempty(cse) ? C_NULL : pointer(cse), cse_off, length(trees), consts,
-            const_off, n_features, n_params, option_bits(operators, eval_context; full_eval, forward_grad), h))
+            const_off, n_features, n_params, option_bits(operators, eval_context; full_eval, forward_grad, reverse_grad), h))
     end
     pop = HIPPopulation{T}(ctx, h[], length(trees), n_features, occ, n_slots, n_consts)
     finalizer(finalize_population, pop)
@@ -464,6 +467,20 @@ function population_sum_certificate(pop::HIPPopulation{T}, X::Matrix{T}) where {
             hc, hp, X, N, F, C_NULL, ok, cert, mx))
     end
     return ok .!= 0x00, cert .!= 0x00, mx
+end
+
+"""
+    eval_population_strict(pop, X) -> (out, ok, uncertified::Vector{Int})
+
+`eval_population` followed by the certificate pass: `uncertified` lists (1-based) the trees whose element-wise flag is NOT provably the
+reference's `isfinite(sum(x))` flag — for every other tree `ok[t]` IS `eval_tree_array`'s `complete`.  A caller who needs the
+reference's bit re-derives only those trees on the CPU (`strict_flags` of the Python twin).
+"""
+function eval_population_strict(pop::HIPPopulation{T}, X::Matrix{T}) where {T}
+    out, ok = eval_population(pop, X)
+    ok2, cert, _ = population_sum_certificate(pop, X)
+    ok2 == ok || error("strict flags: the certificate pass and the evaluation disagree on a flag")
+    return out, ok, findall(!, cert)
 end
 
 struct ParamArgs            # de_param_args_t
@@ -745,12 +762,25 @@ function gather_flags(comm::HIPComm, ok_local::Vector{Bool}, n_trees::Integer)
     loc = UInt8.(ok_local)
     out = Vector{UInt8}(undef, n_trees)
     with_ctx(comm.ctx) do hc
-        rc = GC.@preserve loc out ccall((:de_dist_gather_flags, LIBDE), Cint,
-            (Ptr{Cvoid}, Ptr{UInt8}, Int64, Ptr{UInt8}), comm.handle, loc, n_trees, out)
-        rc == DE_OK || error(unsafe_string(ccall((:de_dist_last_error, LIBDE), Cstring, (Ptr{Cvoid},), comm.handle)))
-        check(comm.ctx, ccall((:de_ctx_synchronize, LIBDE), Cint, (Ptr{Cvoid},), hc))
+        # the call only QUEUES its copies (host `loc` -> staging, gathered flags -> host `out`): both arrays must stay alive until
+        # the stream has drained, so the synchronisation sits inside the same GC.@preserve (ADVICE r5)
+        GC.@preserve loc out begin
+            rc = ccall((:de_dist_gather_flags, LIBDE), Cint,
+                (Ptr{Cvoid}, Ptr{UInt8}, Int64, Ptr{UInt8}), comm.handle, loc, n_trees, out)
+            rc == DE_OK || error(unsafe_string(ccall((:de_dist_last_error, LIBDE), Cstring, (Ptr{Cvoid},), comm.handle)))
+            check(comm.ctx, ccall((:de_ctx_synchronize, LIBDE), Cint, (Ptr{Cvoid},), hc))
+        end
     end
     return out .!= 0x00
+end
+"""Bound every collective of `comm` (`de_dist_set_timeout`): the calls then wait for what they queued and fail with a message naming
+the rank and the collective after `timeout_ms` instead of hanging on a peer that is down; 0 = asynchronous calls (the default)."""
+function set_comm_timeout!(comm::HIPComm, timeout_ms::Integer)
+    with_ctx(comm.ctx) do _
+        rc = ccall((:de_dist_set_timeout, LIBDE), Cint, (Ptr{Cvoid}, Int64), comm.handle, timeout_ms)
+        rc == DE_OK || error(unsafe_string(ccall((:de_dist_last_error, LIBDE), Cstring, (Ptr{Cvoid},), comm.handle)))
+    end
+    return nothing
 end
 close_comm(comm::HIPComm) = with_ctx(comm.ctx) do _
     comm.handle != C_NULL && ccall((:de_dist_destroy, LIBDE), Cint, (Ptr{Cvoid},), comm.handle)

@@ -36,3 +36,26 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---- the parity report: every "[label] ..." line a test prints — how many samples were bounded against the oracle,
+# which share of them the tolerance model declared ill-conditioned (compared on finiteness / flags only), how many flags differed, how
+# many trees a certificate covered — is collected from the captured output of PASSING tests too and printed at the end of the run, so
+# that it shows in `pytest -q` logs (GPUTEST records) and not only under `-s`.
+_PARITY_LINES = []
+
+
+def pytest_runtest_logreport(report):
+    if report.when != "call":
+        return
+    for line in (report.capstdout or "").splitlines():
+        if line.startswith("[") and "]" in line:
+            _PARITY_LINES.append((report.nodeid.split("::", 1)[-1], line.strip()))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not _PARITY_LINES:
+        return
+    terminalreporter.section("parity report (samples bounded / ill-conditioned share / flags, per test)")
+    for nodeid, line in _PARITY_LINES:
+        terminalreporter.write_line(f"{nodeid}: {line[:400]}")

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"libde_hip.so does not export {sym}"
     assert set(api.EXPORTS) <= declared
-    assert lib.de_abi_version() == 2 and lib.de_opcode_table_version() == 1
+    assert lib.de_abi_version() == 3 and lib.de_opcode_table_version() == 1
 
 
 def test_python_opcode_table_matches_c_table():

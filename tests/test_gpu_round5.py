@@ -154,35 +154,51 @@ def test_sum_certificate_is_sound_on_random_trees_near_the_overflow(api, scale):
     assert not ((el != sm) & cert).any()
 
 
-def test_forward_grad_option_keeps_the_reference_forward_mode_flag_semantics(api):
-    """DE_OPT_FORWARD_GRAD: a population wide enough for reverse accumulation (>= 8 gradient rows per tree) runs forward duals — the
-    kernel of de_eval_loss_grad is the forward one and the results are bit for bit what the default population gives when reverse
-    accumulation is switched off (reverse accumulation associates the products leaf-wards and may flip `ok` where a product
-    chain overflows in one association only; the reference is forward-mode)."""
+def test_forward_duals_are_the_default_and_reverse_accumulation_is_an_opt_in(api):
+    """ABI 3: a population wide enough for reverse accumulation (>= 8 gradient rows per tree) runs FORWARD duals by
+    default — the reference's flag semantics (src/EvaluateDerivative.jl:230-243,340-365) — bit for bit what DE_LOSS_GRAD_REVERSE=0 and
+    round 5's DE_OPT_FORWARD_GRAD give; EvalContext(reverse_grad=True) (DE_OPT_REVERSE_GRAD) is the permission to use reverse accumulation,
+    bit for bit what DE_LOSS_GRAD_REVERSE=1 gives (it associates the products leaf-wards and may flip `ok` where a product
+    chain overflows in one association only); DE_OPT_FORWARD_GRAD wins over DE_OPT_REVERSE_GRAD."""
     import os
     ops = de.synth.BENCH_OPERATORS
-    trees = de.synth.random_population(60, seed=0xF0, node_count=45, max_depth=40)  # ~11 constants per tree: reverse by default
+    trees = de.synth.random_population(60, seed=0xF0, node_count=45, max_depth=40)  # ~11 constants per tree: reverse where it is allowed
     g = np.random.Generator(np.random.PCG64(9))
     X = np.asfortranarray(g.standard_normal((5, 5000)).astype(np.float32))
     y = g.standard_normal(5000).astype(np.float32)
-    pop_d = api.Population(trees, ops, np.float32, n_features=5)
-    pop_d.eval_loss_grad(X, y)
-    assert pop_d.ctx.last_kernel_name() == "de_rev_threaded_kernel", pop_d.ctx.last_kernel_name()
-    pop_f = api.Population(trees, ops, np.float32, n_features=5, eval_context=api.EvalContext(forward_grad=True))
-    lf, df, okf = pop_f.eval_loss_grad(X, y)
-    assert pop_f.ctx.last_kernel_name() != "de_rev_threaded_kernel", pop_f.ctx.last_kernel_name()
-    os.environ["DE_LOSS_GRAD_REVERSE"] = "0"
-    try:
-        pop_0 = api.Population(trees, ops, np.float32, n_features=5)
-        l0, d0, ok0 = pop_0.eval_loss_grad(X, y)
-    finally:
-        del os.environ["DE_LOSS_GRAD_REVERSE"]
-    assert np.array_equal(np.asarray(okf), np.asarray(ok0))
-    assert np.array_equal(np.asarray(lf).view(np.uint32), np.asarray(l0).view(np.uint32))
-    for a, b in zip(df, d0):
-        assert np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
-    for p in (pop_d, pop_f, pop_0):
-        p.close()
+
+    def run(ec=None, env=None):
+        if env is not None:
+            os.environ["DE_LOSS_GRAD_REVERSE"] = env
+        try:
+            pop = api.Population(trees, ops, np.float32, n_features=5, eval_context=ec)
+            l, d, ok = pop.eval_loss_grad(X, y)
+            name = pop.ctx.last_kernel_name()
+            pop.close()
+        finally:
+            os.environ.pop("DE_LOSS_GRAD_REVERSE", None)
+        return np.asarray(l), [np.asarray(a) for a in d], np.asarray(ok), name
+
+    def same(a, b):
+        assert np.array_equal(a[2], b[2])
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+        for u, v in zip(a[1], b[1]):
+            assert np.array_equal(u.view(np.uint32), v.view(np.uint32))
+
+    dflt = run()
+    assert dflt[3] != "de_rev_threaded_kernel", dflt[3]
+    same(dflt, run(env="0"))
+    same(dflt, run(api.EvalContext(forward_grad=True)))
+    rev = run(api.EvalContext(reverse_grad=True))
+    assert rev[3] == "de_rev_threaded_kernel", rev[3]
+    same(rev, run(env="1"))
+    both = run(api.EvalContext(forward_grad=True, reverse_grad=True))
+    assert both[3] != "de_rev_threaded_kernel"
+    same(dflt, both)
+    # the two agree to rounding where both are complete (the tolerance tests of tests/test_gpu_loss.py bound them properly)
+    okb = dflt[2].astype(bool) & rev[2].astype(bool)
+    assert okb.sum() > 10
+    assert np.allclose(dflt[0][okb], rev[0][okb], rtol=1e-4)
 
 
 def test_tail_split_changes_nothing_but_the_order(api, monkeypatch):
