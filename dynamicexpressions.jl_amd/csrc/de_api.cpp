@@ -121,7 +121,13 @@ struct de_program {
     // translation unit is built with -ffp-contract=off) — and never enters the auxiliary program: about half of the constant subtrees of the
     // benchmark's operator set.  fold_nodes / fold_noff / fold_coff: every fold's tape slice (constant leaves numbered from the span's first
     // slot) and its range in aux_const_src; aux_fold: auxiliary tree -> fold; aux_csrc: the auxiliary program's constants -> consts.
-    std::vector<uint8_t> fold_host;
+    std::vector<uint8_t> fold_host;     // per fold: 1 = folded on the host, 2 = by de_fold_kernel (one thread per subtree), 0 = through `aux`
+    // the subtrees de_fold_kernel evaluates: kfold[k] = fold index; device image [tape slices | node offsets | constant offsets | constant
+    // values | values out | flags out] in ONE pooled allocation (uploaded once; the constant values again at every de_program_set_consts)
+    std::vector<int32_t> kfold;
+    std::vector<int64_t> kf_csrc;       // constant k of the kernel folds = consts[kf_csrc[k]]
+    char *d_kf = nullptr;
+    size_t kf_o_noff = 0, kf_o_coff = 0, kf_o_cvals = 0, kf_o_out = 0, kf_o_ok = 0, kf_bytes = 0;
     std::vector<de_tape_node_t> fold_nodes;
     std::vector<int64_t> fold_noff, fold_coff;
     std::vector<int32_t> aux_fold;
@@ -572,7 +578,7 @@ static void prog_free(de_ctx *c, void *ptr) {
     X(code) X(code_off) X(const_off) X(const_instr) X(const_checks) X(n_consts_tree) X(host_ok_eval) X(host_ok_grad) X(consts) X(fcode) \
     X(fcode_off) X(fconst_instr) X(folds) X(aux_const_src) X(fold_ok) X(bcode) X(tcode) X(fbcode) X(tcode_off) X(ccode) X(ccode_off) \
     X(bcode_off) X(gbcode) X(gbcode_off) X(gtcode) X(gtcode_off) X(bsite) X(tsite) X(gbsite) X(gtsite_of_gb) X(rtcode) X(rtcode_off) \
-    X(rtcode_mid) X(rtsite_of_gb) X(fold_host) X(fold_nodes) X(fold_noff) X(fold_coff) X(aux_fold) X(aux_csrc)
+    X(rtcode_mid) X(rtsite_of_gb) X(fold_host) X(fold_nodes) X(fold_noff) X(fold_coff) X(aux_fold) X(aux_csrc) X(kfold) X(kf_csrc)
 static constexpr size_t PARKED_MAX = 4, PARKED_BYTES = 512u << 20;
 static size_t program_host_bytes(const de_program *p) {
     size_t b = 0;
@@ -1101,7 +1107,7 @@ static int refresh_folds(de_ctx *c, de_program *p, bool aux_current = false) {
     const size_t nf = p->folds.size();
     p->fold_ok.assign(nf, 0);
     parallel_for_trees((int64_t)nf, [&](int64_t j) {
-        if (!p->fold_host[(size_t)j]) return;
+        if (p->fold_host[(size_t)j] != 1) return;
         const de_tape_node_t *nd = p->fold_nodes.data() + p->fold_noff[(size_t)j];
         const int64_t n = p->fold_noff[(size_t)j + 1] - p->fold_noff[(size_t)j];
         const int64_t *csrc = p->aux_const_src.data() + p->fold_coff[(size_t)j];
@@ -1112,6 +1118,34 @@ static int refresh_folds(de_ctx *c, de_program *p, bool aux_current = false) {
         p->fold_ok[(size_t)j] = ok ? 1 : 0;
         write_imm(p->fcode[(size_t)p->folds[(size_t)j].instr], p->dtype, v);
     }, 256);
+    if (!p->kfold.empty()) {
+        // the subtrees with other operators: one thread each on the device (de_fold_kernel), the operators' own device code.
+        // `aux_current`: the image uploaded at creation already holds these constants.
+        const size_t nk = p->kfold.size();
+        HIP_TRY(c, hipSetDevice(c->device));
+        if (!aux_current) {
+            std::vector<unsigned char> cv(std::max<size_t>(p->kf_csrc.size(), 1) * es);
+            for (size_t k = 0; k < p->kf_csrc.size(); k++) {
+                const double v = p->consts[(size_t)p->kf_csrc[k]];
+                if (p->dtype == DE_F32) reinterpret_cast<float *>(cv.data())[k] = (float)v;
+                else reinterpret_cast<double *>(cv.data())[k] = v;
+            }
+            HIP_TRY(c, hipStreamSynchronize(c->stream)); // (an earlier launch may still read the values)
+            if (!p->kf_csrc.empty()) HIP_TRY(c, hipMemcpy(p->d_kf + p->kf_o_cvals, cv.data(), p->kf_csrc.size() * es, hipMemcpyHostToDevice));
+        }
+        HIP_TRY(c, launch_fold(p->dtype, p->d_kf, reinterpret_cast<const int64_t *>(p->d_kf + p->kf_o_noff), reinterpret_cast<const int64_t *>(p->d_kf + p->kf_o_coff),
+                               p->d_kf + p->kf_o_cvals, (int64_t)nk, p->d_kf + p->kf_o_out, reinterpret_cast<uint8_t *>(p->d_kf + p->kf_o_ok), c->stream));
+        std::vector<unsigned char> res(p->kf_bytes - p->kf_o_out);
+        HIP_TRY(c, hipMemcpyAsync(res.data(), p->d_kf + p->kf_o_out, res.size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const unsigned char *okb = res.data() + (p->kf_o_ok - p->kf_o_out);
+        for (size_t k = 0; k < nk; k++) {
+            const size_t j = (size_t)p->kfold[k];
+            const double v = p->dtype == DE_F32 ? (double)reinterpret_cast<const float *>(res.data())[k] : reinterpret_cast<const double *>(res.data())[k];
+            p->fold_ok[j] = okb[k];
+            write_imm(p->fcode[(size_t)p->folds[j].instr], p->dtype, v);
+        }
+    }
     if (!p->aux) return DE_OK;
     const size_t na = p->aux_fold.size();
     int rc = DE_OK;
@@ -1393,11 +1427,58 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                 // the device, with the operators they evaluate with; DE_NO_HOST_FOLD=1: everything on the device, for A/B tests)
                 const char *nh = getenv("DE_NO_HOST_FOLD");
                 const bool host_fold = !(nh && *nh == '1') && !(options & DE_OPT_TURBO);
+                // ... and which go to de_fold_kernel (everything else whose evaluation stack fits; a turbo program evaluates with other
+                // operators than that kernel has: its subtrees stay with the auxiliary program; DE_NO_KERNEL_FOLD=1 for A/B tests)
+                const char *nk_env = getenv("DE_NO_KERNEL_FOLD");
+                const bool kernel_fold = !(nk_env && *nk_env == '1') && !(options & DE_OPT_TURBO);
                 p->fold_host.assign(n_folds, 0);
-                if (host_fold)
-                    parallel_for_trees((int64_t)n_folds, [&](int64_t j) {
-                        p->fold_host[(size_t)j] = host_foldable(anodes.data() + anoff[(size_t)j], anoff[(size_t)j + 1] - anoff[(size_t)j]) ? 1 : 0;
-                    }, 512);
+                parallel_for_trees((int64_t)n_folds, [&](int64_t j) {
+                    const de_tape_node_t *nd = anodes.data() + anoff[(size_t)j];
+                    const int64_t n = anoff[(size_t)j + 1] - anoff[(size_t)j];
+                    if (host_fold && host_foldable(nd, n)) { p->fold_host[(size_t)j] = 1; return; }
+                    if (!kernel_fold) return;
+                    int depth = 0, worst = 0;
+                    for (int64_t i = 0; i < n; i++) { depth += 1 - (int)nd[i].degree; worst = std::max(worst, depth); }
+                    if (worst <= DE_FOLD_STACK) p->fold_host[(size_t)j] = 2;
+                }, 512);
+                // the kernel's image: tape slices, offsets and constant sources of its subtrees, in fold order
+                p->kfold.clear();
+                p->kf_csrc.clear();
+                {
+                    std::vector<de_tape_node_t> knodes;
+                    std::vector<int64_t> knoff{0}, kcoff{0};
+                    for (size_t j = 0; j < n_folds; j++) {
+                        if (p->fold_host[j] != 2) continue;
+                        p->kfold.push_back((int32_t)j);
+                        knodes.insert(knodes.end(), anodes.begin() + anoff[j], anodes.begin() + anoff[j + 1]);
+                        p->kf_csrc.insert(p->kf_csrc.end(), p->aux_const_src.begin() + acoff[j], p->aux_const_src.begin() + acoff[j + 1]);
+                        knoff.push_back((int64_t)knodes.size());
+                        kcoff.push_back((int64_t)p->kf_csrc.size());
+                    }
+                    if (!p->kfold.empty()) {
+                        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+                        const size_t nk = p->kfold.size();
+                        p->kf_o_noff = al(knodes.size() * sizeof(de_tape_node_t));
+                        p->kf_o_coff = p->kf_o_noff + al(knoff.size() * sizeof(int64_t));
+                        p->kf_o_cvals = p->kf_o_coff + al(kcoff.size() * sizeof(int64_t));
+                        p->kf_o_out = p->kf_o_cvals + al(std::max<size_t>(p->kf_csrc.size(), 1) * es);
+                        p->kf_o_ok = p->kf_o_out + al(nk * es);
+                        p->kf_bytes = p->kf_o_ok + al(nk);
+                        std::vector<unsigned char> img(p->kf_o_out, 0);
+                        std::memcpy(img.data(), knodes.data(), knodes.size() * sizeof(de_tape_node_t));
+                        std::memcpy(img.data() + p->kf_o_noff, knoff.data(), knoff.size() * sizeof(int64_t));
+                        std::memcpy(img.data() + p->kf_o_coff, kcoff.data(), kcoff.size() * sizeof(int64_t));
+                        for (size_t k = 0; k < p->kf_csrc.size(); k++) {
+                            const double v = p->consts[(size_t)p->kf_csrc[k]];
+                            if (dtype == DE_F32) reinterpret_cast<float *>(img.data() + p->kf_o_cvals)[k] = (float)v;
+                            else reinterpret_cast<double *>(img.data() + p->kf_o_cvals)[k] = v;
+                        }
+                        HIP_TRY(ctx, hipSetDevice(ctx->device));
+                        const hipError_t kst = prog_malloc(ctx, reinterpret_cast<void **>(&p->d_kf), p->kf_bytes);
+                        if (kst != hipSuccess) return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(kst));
+                        HIP_TRY(ctx, hipMemcpy(p->d_kf, img.data(), img.size(), hipMemcpyHostToDevice));
+                    }
+                }
                 // the others form the auxiliary population (their tape slices and constants, concatenated in fold order)
                 std::vector<de_tape_node_t> xnodes;
                 std::vector<int64_t> xnoff{0}, xcoff{0};
@@ -1412,7 +1493,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                     xcoff.push_back((int64_t)p->aux_csrc.size());
                 }
                 p->folded = true;
-                lap("host folds: classify, auxiliary tapes");
+                lap("folds: classify, kernel image, auxiliary tapes");
                 if (!p->aux_fold.empty()) {
                     std::vector<unsigned char> ac(std::max<size_t>(p->aux_csrc.size(), 1) * es, 0);
                     for (size_t k = 0; k < p->aux_csrc.size(); k++) {
@@ -1427,7 +1508,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                 }
                 int rc = refresh_folds(ctx, p.get(), true);
                 if (rc != DE_OK) return rc;
-                lap("folds (evaluate: host + aux)");
+                lap("folds (evaluate: host + kernel + aux)");
             } else if (any_cse) {
                 p->folded = true; // the eval program is the CSE lowering even without a constant subtree to fold
             } else {
@@ -1670,6 +1751,8 @@ int de_program_destroy(de_program_t *p) {
     if (p->d_cert_off) (void)hipFree(p->d_cert_off);
     dbg_lap("destroy: eval streams");
     if (p->aux) de_program_destroy(p->aux);
+    prog_free(c, p->d_kf);
+    p->d_kf = nullptr;
     dbg_lap(nullptr);
     prog_free(c, p->d_gcode);
     if (p->d_gcode_off) (void)hipFree(p->d_gcode_off);
@@ -1759,7 +1842,7 @@ uint64_t de_program_stream_hash(const de_program_t *p) {
     vec(p->fbcode); vec(p->tcode); vec(p->tcode_off); vec(p->ccode); vec(p->ccode_off); vec(p->bsite); vec(p->tsite);
     vec(p->consts); vec(p->const_off); vec(p->const_instr); vec(p->fconst_instr); vec(p->const_checks); vec(p->n_consts_tree);
     vec(p->aux_const_src); vec(p->host_ok_eval); vec(p->host_ok_grad); vec(p->fold_ok);
-    vec(p->fold_host); vec(p->fold_noff); vec(p->fold_coff); vec(p->aux_fold); vec(p->aux_csrc);
+    vec(p->fold_host); vec(p->fold_noff); vec(p->fold_coff); vec(p->aux_fold); vec(p->aux_csrc); vec(p->kfold); vec(p->kf_csrc);
     mix(p->fold_nodes.data(), p->fold_nodes.size() * sizeof(de_tape_node_t));
     for (const auto &f : p->folds) { const int32_t w[3] = {f.tree, f.instr, f.tested_always ? 1 : 0}; mix(w, sizeof w); }
     const int64_t scal[6] = {p->n_trees, p->n_nodes, p->n_slots, p->uses_params ? 1 : 0, p->folded ? 1 : 0, p->threaded ? 1 : 0};

@@ -91,6 +91,10 @@ struct EvalArgs {
 constexpr int DE_PRIO_MAX_F = 8; // (the pre-pass keeps 6 registers per feature)
 constexpr int DE_PRIO_UNIT = 64;  // samples per unit of the keys' position field (every kernel's tile is a multiple)
 // multi-GPU flag exchange (de_dist.cpp): pack the local flags into the padded send block / scatter the gathered blocks to global tree order
+// constant subtrees (one thread each; de_kernels.hip de_fold_kernel): stack depth a subtree may need
+#define DE_FOLD_STACK 16
+hipError_t launch_fold(int dtype, const void *nodes, const int64_t *noff, const int64_t *coff, const void *cvals, int64_t n_folds, void *out,
+                       uint8_t *ok, hipStream_t stream);
 hipError_t launch_dist_pack(uint8_t *send, const uint8_t *ok_local_dev, int64_t mine, int64_t per, hipStream_t stream);
 hipError_t launch_dist_unpack(uint8_t *ok_global_dev, const uint8_t *recv, int64_t per, int32_t world, int64_t n_trees, hipStream_t stream);
 hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX, int F, void *keys, hipStream_t stream);

@@ -2501,6 +2501,90 @@ __global__ void __launch_bounds__(256) de_dist_unpack_kernel(uint8_t *__restrict
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t < n_trees) ok_global[t] = recv[(t % world) * per + t / world];
 }
+// ---- constant subtrees, evaluated once per set of constants (round 6) ------------------------------------------------------------
+// One thread per constant subtree ("fold"): a stack machine over the subtree's post-order tape slice, with the operator code of the
+// threaded kernel's handlers (un_apply for cos / exp / sin, IEEE + - * /, cold_op / cold_op3 for the rest: bit for bit what the eval kernel
+// computes for the same operator and argument), every node's output validity-tested as dispatch_constant_tree does
+// (src/Evaluate.jl:1002-1067).
+// Replaces the auxiliary PROGRAM of rounds 1-5 (a second population lowered, bound, threaded, uploaded and evaluated with N = 1: a
+// quarter of de_program_create) for every subtree whose evaluation stack fits DE_FOLD_STACK values.
+template <typename T>
+__global__ void __launch_bounds__(64) de_fold_kernel(const de_tape_node_t *__restrict__ nodes, const int64_t *__restrict__ noff,
+                                                     const int64_t *__restrict__ coff, const T *__restrict__ cvals, int64_t n_folds,
+                                                     T *__restrict__ out, uint8_t *__restrict__ ok) {
+    typedef typename VecOf<T>::type V;
+    constexpr int VW = VecOf<T>::W;
+    constexpr int G = 1;
+    const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (j >= n_folds) return;
+    V st[DE_FOLD_STACK];
+    uint32_t leaf_bits = 0; // bit k: stack entry k is a constant LEAF (not an operator's result)
+    int sp = 0;
+    bool good = true;
+    const int64_t c0 = coff[j];
+    for (int64_t i = noff[j]; i < noff[j + 1]; i++) {
+        const de_tape_node_t nd = nodes[i];
+        V acc[G];
+        if (nd.degree == 0) {
+            const T c = cvals[c0 + nd.arg];
+            FOR_I acc[0][i] = c;
+            leaf_bits |= 1u << sp;
+        } else if (nd.degree == 1) {
+            V x_[G];
+            x_[0] = st[--sp];
+            // cos / exp / sin OF A CONSTANT LEAF: the binder has no hot form for that operand kind (BOP_GEN_CONST -> cold_op -> the math
+            // library's function), so the eval kernel computes cos(c) with OCML's cosf and cos(x) with the fast polynomial — both within
+            // 2 ulp, not the same bits (cos(-0.456): ...d1 against ...d2).  A folded subtree carries what the eval kernel would compute.
+            const bool of_leaf = ((leaf_bits >> sp) & 1u) != 0;
+            leaf_bits &= ~(1u << sp);
+            const uint32_t op = nd.op;
+            // cos / exp / sin: the functions of the THREADED kernel's hot handlers (un_apply: the vectorised trig, the direct exp with its
+            // per-element select) — the flat-switch kernel's scalar forms differ from them in the last bit now and then
+            // (tests/test_gpu_round6.py found cos(-0.456...): 2 of 300 trees), and a folded subtree must carry the bits the eval kernel
+            // would have computed.  Everything else: cold_op, which the threaded kernel's generic handlers call too.
+            if (!of_leaf && op == DE_U_COS) acc[0] = un_apply<T, 0>(x_[0]);
+            else if (!of_leaf && op == DE_U_EXP) acc[0] = un_apply<T, 1>(x_[0]);
+            else if (!of_leaf && op == DE_U_SIN) acc[0] = un_apply<T, 2>(x_[0]);
+            else { acc[0] = x_[0]; COLD_CALL(x_) }
+        } else if (nd.degree == 2) {
+            V b[G];
+            b[0] = st[--sp];
+            acc[0] = st[--sp];
+            leaf_bits &= ~(3u << sp);
+            const uint32_t op = nd.op;
+            if (op == DE_B_ADD) { FOR_I acc[0][i] = acc[0][i] + b[0][i]; }
+            else if (op == DE_B_SUB) { FOR_I acc[0][i] = acc[0][i] - b[0][i]; }
+            else if (op == DE_B_MUL) { FOR_I acc[0][i] = acc[0][i] * b[0][i]; }
+            else if (op == DE_B_DIV) { FOR_I acc[0][i] = acc[0][i] / b[0][i]; }
+            else COLD_CALL(b)
+        } else {
+            VG<T, G> av, bv, cv;
+            av.v[0] = st[--sp]; // third argument
+            cv.v[0] = st[--sp];
+            bv.v[0] = st[--sp];
+            leaf_bits &= ~(7u << sp);
+            av = cold_op3<T, G>(nd.op, av, bv, cv);
+            acc[0] = av.v[0];
+        }
+        good = good && M<T>::isfinite(acc[0][0]);
+        st[sp++] = acc[0];
+    }
+    out[j] = st[0][0];
+    ok[j] = good ? 1 : 0;
+}
+hipError_t launch_fold(int dtype, const void *nodes, const int64_t *noff, const int64_t *coff, const void *cvals, int64_t n_folds, void *out,
+                       uint8_t *ok, hipStream_t stream) {
+    if (n_folds <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n_folds + 63) / 64)), block(64);
+    if (dtype == DE_F32)
+        hipLaunchKernelGGL(de_fold_kernel<float>, grid, block, 0, stream, static_cast<const de_tape_node_t *>(nodes), noff, coff,
+                           static_cast<const float *>(cvals), n_folds, static_cast<float *>(out), ok);
+    else
+        hipLaunchKernelGGL(de_fold_kernel<double>, grid, block, 0, stream, static_cast<const de_tape_node_t *>(nodes), noff, coff,
+                           static_cast<const double *>(cvals), n_folds, static_cast<double *>(out), ok);
+    return hipGetLastError();
+}
+
 hipError_t launch_dist_pack(uint8_t *send, const uint8_t *ok_local_dev, int64_t mine, int64_t per, hipStream_t stream) {
     if (per <= 0) return hipSuccess;
     hipLaunchKernelGGL(de_dist_pack_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream, send, ok_local_dev, mine, per);

@@ -147,23 +147,52 @@ print("HASH", h.hexdigest(), int(ok.sum()))
     assert 0 < int(hashes[0].split()[2]) < 300
 
 
+def _fold_routes(api, trees, ops, dtype, X, monkeypatch, consts=None):
+    """rows / flags / stream hash of the population under the three folding routes of constant subtrees: default (IEEE-exact subtrees on the
+    host, the others by de_fold_kernel), everything by de_fold_kernel, everything through the auxiliary program of rounds 1-5"""
+    res = {}
+    for name, env in (("default", {}), ("kernel", {"DE_NO_HOST_FOLD": "1"}), ("aux", {"DE_NO_HOST_FOLD": "1", "DE_NO_KERNEL_FOLD": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pop = api.Population(trees, ops, dtype, n_features=X.shape[0])
+        if consts is not None:
+            pop.set_constants(consts)
+        out, ok = pop.eval(X)
+        res[name] = (np.asarray(out), np.asarray(ok, dtype=bool), pop.stream_hash())
+        pop.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    return res
+
+
+def _same_bits(a, b, dtype, what):
+    u = np.uint32 if np.dtype(dtype) == np.float32 else np.uint64
+    assert np.array_equal(a[1], b[1]), f"{what}: flags"
+    fin = np.isfinite(a[0]) | np.isfinite(b[0])       # (NaN sign / payload is not compared: x86 0/0 = -NaN, gfx950 +NaN)
+    assert np.array_equal(a[0].view(u)[fin], b[0].view(u)[fin]), f"{what}: rows"
+    assert np.array_equal(np.isnan(a[0]), np.isnan(b[0])), f"{what}: NaN positions"
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_host_folded_constant_subtrees_have_the_bits_of_the_device_folded_ones(api, dtype, monkeypatch):
+def test_host_and_kernel_folded_constant_subtrees_have_the_bits_of_the_auxiliary_program(api, dtype, monkeypatch):
     """Round 6: constant subtrees made of + - * / only are folded ON THE HOST at de_program_create /
-    de_program_set_consts, the others through the auxiliary device program.  Same bits by construction — checked: rows, flags and the
-    lowered streams' immediates against DE_NO_HOST_FOLD=1 (everything on the device) on trees whose constant subtrees overflow, underflow
-    into subnormals, divide by zero and produce NaN; then again after new constants."""
+    de_program_set_consts, the others by de_fold_kernel (one thread per subtree, the operators' own device code) — the auxiliary PROGRAM
+    of rounds 1-5 (a second population lowered, bound, threaded and evaluated with N = 1) only remains for turbo programs.  Same bits by
+    construction — checked: rows and flags under the three routes on trees whose constant subtrees overflow, underflow into subnormals,
+    divide by zero and produce NaN; then again after new constants."""
     ops = de.synth.BENCH_OPERATORS
     rng = np.random.Generator(np.random.PCG64(17))
     add, sub, mul, div = (ops.index(s, 2) for s in "+-*/")
-    cos = ops.index("cos", 1)
+    cos, exp = ops.index("cos", 1), ops.index("exp", 1)
     tiny, huge = (1e-30, 1e30) if dtype == np.float32 else (1e-200, 1e200)
-    pool = [0.0, -0.0, 1.0, -2.5, 3.0, tiny, -tiny, huge, -huge, tiny * 1e-8, 0.1, 7.0, 1.0 / 3.0]
+    pool = [0.0, -0.0, 1.0, -2.5, 3.0, tiny, -tiny, huge, -huge, tiny * 1e-8, 0.1, 7.0, 1.0 / 3.0, 1e5, 88.0, -104.0]
 
-    def const_subtree(depth):
+    def const_subtree(depth, unary=False):
         if depth == 0 or rng.random() < 0.3:
             return de.Node(val=float(pool[rng.integers(len(pool))]) if rng.random() < 0.7 else float(rng.standard_normal()))
-        return de.Node([add, sub, mul, div][rng.integers(4)], const_subtree(depth - 1), const_subtree(depth - 1))
+        if unary and rng.random() < 0.4:
+            return de.Node([cos, exp][rng.integers(2)], const_subtree(depth - 1, unary))
+        return de.Node([add, sub, mul, div][rng.integers(4)], const_subtree(depth - 1, unary), const_subtree(depth - 1, unary))
 
     trees = []
     for k in range(300):
@@ -171,39 +200,56 @@ def test_host_folded_constant_subtrees_have_the_bits_of_the_device_folded_ones(a
         c = const_subtree(int(rng.integers(1, 4)))
         if c.degree == 0:
             c = de.Node(mul, c, de.Node(val=2.0))
-        inner = de.Node(cos, const_subtree(2)) if k % 5 == 0 else const_subtree(2)   # (a cos(...) subtree goes to the device)
+        inner = const_subtree(3, unary=True) if k % 2 == 0 else const_subtree(2)   # (a subtree with cos / exp cannot be folded on the host)
         trees.append(de.Node([add, mul, sub, div][k % 4], de.Node(add, x, inner), c))
     X = np.asfortranarray(rng.standard_normal((5, 700)).astype(dtype))
-
-    def run(consts=None):
-        pop = api.Population(trees, ops, dtype, n_features=5)
-        if consts is not None:
-            pop.set_constants(consts)
-        out, ok = pop.eval(X)
-        dumps = [pop.dump(t).copy() for t in range(0, len(trees), 7)]
-        h = pop.stream_hash()
-        pop.close()
-        return np.asarray(out), np.asarray(ok, dtype=bool), dumps, h
-
-    host = run()
-    monkeypatch.setenv("DE_NO_HOST_FOLD", "1")
-    dev = run()
-    monkeypatch.delenv("DE_NO_HOST_FOLD")
-    assert np.array_equal(host[1], dev[1]), "flags"
-    assert host[1].any() and not host[1].all()
-    u = np.uint32 if dtype == np.float32 else np.uint64
-    fin = np.isfinite(dev[0]) | np.isfinite(host[0])       # (NaN sign / payload is not compared: x86 0/0 = -NaN, gfx950 +NaN)
-    assert np.array_equal(host[0].view(u)[fin], dev[0].view(u)[fin]), "rows"
-    assert np.array_equal(np.isnan(host[0]), np.isnan(dev[0]))
-    assert host[3] != dev[3], "the two programs differ in WHERE they fold (the hash covers the host-fold tables)"
+    r = _fold_routes(api, trees, ops, dtype, X, monkeypatch)
+    assert r["default"][1].any() and not r["default"][1].all()
+    _same_bits(r["default"], r["aux"], dtype, "host + kernel against the auxiliary program")
+    _same_bits(r["kernel"], r["aux"], dtype, "kernel against the auxiliary program")
+    assert len({r[k][2] for k in r}) == 3, "the three programs differ in WHERE they fold (the hash covers the fold tables)"
     # ... and through de_program_set_consts
     consts = np.concatenate([de.flatten(t, ops, dtype)[1] for t in trees]).astype(dtype)
     c2 = (consts * dtype(1.5) + dtype(0.25)).astype(dtype)
-    host2 = run(c2)
-    monkeypatch.setenv("DE_NO_HOST_FOLD", "1")
-    dev2 = run(c2)
-    monkeypatch.delenv("DE_NO_HOST_FOLD")
-    assert np.array_equal(host2[1], dev2[1])
-    fin = np.isfinite(dev2[0]) | np.isfinite(host2[0])
-    assert np.array_equal(host2[0].view(u)[fin], dev2[0].view(u)[fin])
-    print(f"[host folds {np.dtype(dtype).name}] {int(host[1].sum())} of {len(trees)} trees complete; rows and flags bit-equal to the device-folded program, before and after set_constants")
+    r2 = _fold_routes(api, trees, ops, dtype, X, monkeypatch, consts=c2)
+    _same_bits(r2["default"], r2["aux"], dtype, "after set_constants: host + kernel against the auxiliary program")
+    _same_bits(r2["kernel"], r2["aux"], dtype, "after set_constants: kernel against the auxiliary program")
+    print(f"[constant folds {np.dtype(dtype).name}] {int(r['default'][1].sum())} of {len(trees)} trees complete; rows and flags bit-equal under host + kernel folding, "
+          "kernel folding and the auxiliary program, before and after set_constants")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_kernel_folded_subtrees_of_every_operator_have_the_bits_of_the_auxiliary_program(api, dtype, monkeypatch):
+    """de_fold_kernel evaluates EVERY operator of the table (hot ones through the flat-switch kernel's code, the others through cold_op /
+    cold_op3): constant subtrees over the wide operator set + the ternary operators, against the auxiliary program, bit for bit; a subtree
+    too deep for the kernel's stack (DE_FOLD_STACK = 16) stays with the auxiliary program and still evaluates."""
+    import fuzzlib as FZ
+    ops = de.OperatorEnum(binary_operators=FZ.OPS_WIDE.ops[1] + ("mod", "rem", "greater"), unary_operators=FZ.OPS_WIDE.ops[0] + ("sign", "round", "floor", "ceil", "inv", "sqrt", "cbrt", "exp2", "log", "log2", "log10", "log1p", "tan", "sinh", "cosh", "asin", "acos", "asinh", "acosh", "atanh", "safe_log2", "safe_log10", "safe_log1p", "safe_acosh", "gamma"),
+                          ternary_operators=("fma", "clamp", "+", "max"))
+    rng = de.synth.Xoshiro256ss(0xF01D)
+    g = np.random.Generator(np.random.PCG64(23))
+    trees = []
+    add = ops.index("+", 2)
+    for k in range(400):
+        sub = FZ.gen_mixed_arity_tree(rng, ops, 1, dtype, 3 + k % 3)
+        # make the subtree constant: every feature leaf becomes a constant
+        def constify(n):
+            if n.degree == 0:
+                return n if n.constant else de.Node(val=float(g.standard_normal() * (10.0 if k % 7 == 0 else 1.0)))
+            return de.Node(n.op, *[constify(c) for c in n.children])
+        trees.append(de.Node(add, de.Node(feature=1 + k % 3), constify(sub)))
+    # one subtree deeper than the kernel's stack: a right-leaning chain of 20 additions
+    deep = de.Node(val=1.0)
+    for i in range(20):
+        deep = de.Node(add, de.Node(val=float(i)), de.Node(ops.index("cos", 1), deep)) if i % 2 else de.Node(add, de.Node(val=float(i)), deep)
+    left = de.Node(val=0.5)
+    for i in range(19):   # left operands pile up: stack depth 20
+        left = de.Node(add, de.Node(ops.index("cos", 1), de.Node(val=float(i))), left)
+    trees.append(de.Node(add, de.Node(feature=1), deep))
+    trees.append(de.Node(add, de.Node(feature=2), left))
+    X = np.asfortranarray(g.standard_normal((3, 300)).astype(dtype))
+    r = _fold_routes(api, trees, ops, dtype, X, monkeypatch)
+    assert r["default"][1].sum() > 50
+    _same_bits(r["default"], r["aux"], dtype, "wide operator set: host + kernel against the auxiliary program")
+    _same_bits(r["kernel"], r["aux"], dtype, "wide operator set: kernel against the auxiliary program")
+    print(f"[constant folds, every operator, {np.dtype(dtype).name}] {int(r['default'][1].sum())} of {len(trees)} trees complete; bit-equal to the auxiliary program")
