@@ -20,6 +20,9 @@ build_obj() { # src obj extra...
 }
 build_obj de_lower.cpp $OBJ/de_lower.o &
 build_obj de_api.cpp $OBJ/de_api.o &
+build_obj de_api_program.cpp $OBJ/de_api_program.o &
+build_obj de_api_eval.cpp $OBJ/de_api_eval.o &
+build_obj de_api_grad.cpp $OBJ/de_api_grad.o &
 build_obj de_bind.cpp $OBJ/de_bind.o &
 build_obj de_dist.cpp $OBJ/de_dist.o &
 # de_kernels.hip goes through the same steps hipcc runs internally, with one extra pass over the optimised
@@ -105,6 +108,7 @@ for spec in f:float d:double; do  # the reverse-accumulation kernel: one module 
 done
 build_obj de_grad_kernels.hip $OBJ/de_grad_kernels.o &
 wait
-for o in $OBJ/de_lower.o $OBJ/de_bind.o $OBJ/de_dist.o $OBJ/de_api.o $OBJ/de_kernels.o $OBJ/de_grad_kernels.o $GT_OBJS; do [ -f $o ] || { echo "missing $o"; exit 1; }; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/de_lower.o $OBJ/de_bind.o $OBJ/de_dist.o $OBJ/de_api.o $OBJ/de_kernels.o $OBJ/de_grad_kernels.o $GT_OBJS -ldl
+API_OBJS="$OBJ/de_api.o $OBJ/de_api_program.o $OBJ/de_api_eval.o $OBJ/de_api_grad.o"
+for o in $OBJ/de_lower.o $OBJ/de_bind.o $OBJ/de_dist.o $API_OBJS $OBJ/de_kernels.o $OBJ/de_grad_kernels.o $GT_OBJS; do [ -f $o ] || { echo "missing $o"; exit 1; }; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/de_lower.o $OBJ/de_bind.o $OBJ/de_dist.o $API_OBJS $OBJ/de_kernels.o $OBJ/de_grad_kernels.o $GT_OBJS -ldl
 echo "built $(pwd)/$OUT"

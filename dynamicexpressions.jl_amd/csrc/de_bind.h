@@ -170,21 +170,21 @@ static_assert(gop_count(8) <= GOP_MAX, "GOP_MAX too small");
 
 // Handlers the threaded EVAL kernel has beyond the fused set: unary operators outside the binder's hot set
 // (GUN_K - 3 of them: neg .. relu, the list of gun_index) on a row or on the accumulator.  Chosen when the
-// threaded code is made (de_api.cpp make_threaded) instead of the generic handler; ids follow TOP_COUNT.
+// threaded code is made (de_api_program.cpp make_threaded) instead of the generic handler; ids follow TOP_COUNT.
 constexpr uint32_t TOPX_UN_BASE = TOP_COUNT;                 // + (k - 3) * 2 + (src == ACC)
 constexpr uint32_t TOPX_BIN_BASE = TOPX_UN_BASE + 2 * (GUN_K - 3); // max / min: + (k - 6) * 2 + (src == CONST)
 constexpr uint32_t TOPX_COUNT = TOPX_BIN_BASE + 4;
 // handler table of the threaded eval kernel: the ids above + the end-of-tree handler every chain finishes in
 constexpr uint32_t TOPX_END = TOPX_COUNT;
 // ... and "last instruction of a tree + its end" variants of the handlers most trees finish in (a validity-tested hot binary or
-// unary operator): the stream's end record is then skipped, one dispatch less per tree.  Chosen by make_chained (de_api.cpp).
+// unary operator): the stream's end record is then skipped, one dispatch less per tree.  Chosen by make_chained (de_api_program.cpp).
 constexpr uint32_t TOPX_ENDV_BASE = TOPX_END + 1;                 // + k * 2 + (operand is a constant), k < 6   | 12 + k, k < 3 (unary on acc)
 constexpr uint32_t TOPX_ENDV_COUNT = 15;
 // ... and two handlers no record names but every chain can reach (the out-of-line end of a tree, the early-exit walk over skipped
 // trees): in the table so that the host's address-window checks (32-bit offsets; Float64: one 4 GiB window) cover them too
 constexpr uint32_t TOPX_AUX_BASE = TOPX_ENDV_BASE + TOPX_ENDV_COUNT; // + 0: h_tree_end_slow, + 1: h_tree_skip
 constexpr uint32_t TOPX_TABLE = TOPX_AUX_BASE + 2;
-// chained stream (de_api.cpp make_chained): bit 31 of a tree header's length word = the tree finishes in an end-fused handler
+// chained stream (de_api_program.cpp make_chained): bit 31 of a tree header's length word = the tree finishes in an end-fused handler
 constexpr uint32_t DE_HDR_FUSED_END = 0x80000000u;
 // end variant of a fused / bound handler id, or -1
 constexpr int topx_endv_of(uint32_t id) {
@@ -226,7 +226,7 @@ bool top_is_const_source(uint32_t top);
 
 // Append the bound form of `code` (one tree) to `out`.
 // param_row_base >= 0: parameter operands are LDS rows param_row_base + p (the eval kernels stage the tile's parameter values like
-// features: de_api.cpp `prows`); < 0: BOP_GEN_PARAM, a gather per use
+// features: de_api_program.cpp `prows`); < 0: BOP_GEN_PARAM, a gather per use
 void bind_tree(const Instr *code, size_t n, bool early_exit, int n_features, std::vector<BoundInstr> *out, int param_row_base = -1);
 
 } // namespace de

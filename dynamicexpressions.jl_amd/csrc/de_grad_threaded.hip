@@ -11,7 +11,7 @@
 // SGPRs — knowing its successor since entry, without waiting for that load (round 4) —; the tree's end record (g_end) returns to
 // the kernel for the epilogue.  6 scalar + 1 vector instruction per dispatch against 14 + 2 for the call/return loop of round 1.
 //
-// Instruction word (16 B, built by de_api.cpp make_grad_threaded from the bound program):
+// Instruction word (16 B, built by de_api_grad.cpp ensure_grad_threaded from the bound program):
 //   x = handler address - handler base OF THE NEXT RECORD (end record: of the tree's first record); the base travels with the chain
 //       in SGPRs: one code object module per window width
 //   y = LDS byte offset of the operand (leaf row or spill slot base) | aux << 24
@@ -93,7 +93,7 @@ template <typename T, int GC> using GHandlerFn = GState<T, GC> (*)(GState<T, GC>
 template <typename T> __device__ __forceinline__ typename GImm<T>::type grec_imm(const U32x4 &w);
 template <> __device__ __forceinline__ uint32_t grec_imm<float>(const U32x4 &w) { return w.z; }
 template <> __device__ __forceinline__ uint64_t grec_imm<double>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
-// record address + 1 WITHOUT a carry into the high half (the stream lies inside one 4 GiB window: de_api.cpp checks the allocation)
+// record address + 1 WITHOUT a carry into the high half (the stream lies inside one 4 GiB window: prog_malloc in de_api.cpp guarantees it, the callers check the allocation)
 __device__ __forceinline__ ConstU4Ptr gcode_next(ConstU4Ptr c) {
     const uint64_t a = (uint64_t)(uintptr_t)c;
     return (ConstU4Ptr)(uintptr_t)((a & 0xFFFFFFFF00000000ull) | (uint64_t)((uint32_t)a + 16u));

@@ -1,4 +1,4 @@
-// de_kernels.h — launch interface between the C ABI (de_api.cpp) and the gfx950
+// de_kernels.h — launch interface between the C ABI (de_api*.cpp) and the gfx950
 // kernels (de_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>

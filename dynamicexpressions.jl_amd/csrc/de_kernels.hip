@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(BLK) de_eval_tape_kernel(const KArgs<T> a) {
 // tree and then structurizes it); an indirect call costs ~20, and each handler is compiled
 // as clean straight-line code.  Handler addresses are taken on the device
 // (de_fill_handlers), read back once per process, and bound into the instruction stream as
-// 32-bit offsets by the host (de_api.cpp).  G = 1, 256 threads per workgroup.
+// 32-bit offsets by the host (de_api_program.cpp).  G = 1, 256 threads per workgroup.
 // The validity poison is accumulated two lanes wide for Float32 so that one v_pk_fma_f32 tests two
 // samples (2 VALU per tested vector instead of 4).
 template <typename T> struct PoisonOf { typedef T type; };
@@ -703,7 +703,7 @@ template <typename T> struct RowOf { static constexpr uint32_t BYTES = (uint32_t
 #define HCHAIN_ARGS HState<T> st, HL_PARAMS_C uint32_t lds0, ConstU4Ptr code, uint64_t outp, uint32_t la, uint32_t w1, uint64_t w23, uint64_t okp, uint64_t ldo, uint64_t skip, uint32_t left, uint32_t flags
 #define HCHAIN_NEXT_AT(W, NEXT) [[clang::musttail]] return arg_next<T>(w1, w23)(st, HL_PASS_C lds0, NEXT, outp, (W).x, (W).y, ((uint64_t)(W).w << 32) | (W).z, okp, ldo, skip, left, flags)
 // record address + k records WITHOUT a carry into the high half: the stream lies inside one 4 GiB window (checked where it is allocated,
-// de_api.cpp), so the bump is ONE scalar instruction (s_add_u32) instead of the add / add-with-carry pair — the cheap handlers are bound
+// de_api.cpp prog_malloc), so the bump is ONE scalar instruction (s_add_u32) instead of the add / add-with-carry pair — the cheap handlers are bound
 // by their scalar instructions (tools/probe/issue_probe.py: one per ~4 cycles and SIMD; `acc * const` = 6 of them = 24 cycles)
 __device__ __forceinline__ ConstU4Ptr code_at(ConstU4Ptr c, int k) {
     const uint64_t a = (uint64_t)(uintptr_t)c;
@@ -2162,7 +2162,7 @@ template <typename T, bool TB> static hipError_t fetch_handlers(uint64_t *host_t
 
 // Handler addresses are baked into every record of the instruction streams and belong to ONE device's copy of the code object
 // (every device loads its own): the caches of the three handler tables (eval here, gradient and reverse in de_grad_kernels.hip) are
-// keyed by the CURRENT device — the device of the context that creates the program (de_api.cpp sets it before it asks).  A process may
+// keyed by the CURRENT device — the device of the context that creates the program (de_api_program.cpp sets it before it asks).  A process may
 // therefore hold contexts on several GPUs (round 3 refused every device but the first: ADVICE r3).
 hipError_t handler_device_slot(int *slot) {
     int dev = 0;

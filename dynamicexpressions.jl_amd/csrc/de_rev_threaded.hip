@@ -67,7 +67,7 @@ template <typename T> using RHandlerFn = GState<T> (*)(GState<T>, ConstU4Ptr, ui
 template <typename T> __device__ __forceinline__ typename RImm<T>::type rrec_imm(const U32x4 &w);
 template <> __device__ __forceinline__ uint64_t rrec_imm<float>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
 template <> __device__ __forceinline__ uint64_t rrec_imm<double>(const U32x4 &w) { return ((uint64_t)w.w << 32) | w.z; }
-// record address + 1 WITHOUT a carry into the high half (the stream lies inside one 4 GiB window: de_api.cpp checks the allocation)
+// record address + 1 WITHOUT a carry into the high half (the stream lies inside one 4 GiB window: prog_malloc in de_api.cpp guarantees it, the callers check the allocation)
 __device__ __forceinline__ ConstU4Ptr rcode_next(ConstU4Ptr c) {
     const uint64_t a = (uint64_t)(uintptr_t)c;
     return (ConstU4Ptr)(uintptr_t)((a & 0xFFFFFFFF00000000ull) | (uint64_t)((uint32_t)a + 16u));
@@ -295,7 +295,7 @@ template <typename T> __device__ __noinline__ GState<T> r_end(GState<T> st, Cons
 // One sample per lane makes this kernel dispatch-bound (VALU 40 % busy, as many scalar as vector instructions): every dispatch saved is
 // time saved.  The C5 pullback's streams (37.8 dispatches per tree) are full of fixed sequences — every PUSH is followed by the load (or the
 // unary function of a leaf) that starts the next subtree; backwards, every r_pop follows the r_leaf of that load, 1.9 r_leaf per tree follow
-// the r_un of a unary function of a leaf and 1.9 follow an r_bin whose operand is a tracked leaf.  The encoder (de_api.cpp
+// the r_un of a unary function of a leaf and 1.9 follow an r_bin whose operand is a tracked leaf.  The encoder (de_api_grad.cpp
 // ensure_rev_threaded) emits them as ONE record: la = two 16-bit LDS byte offsets relative to the lane's base (a wave's rows span < 64 KB:
 // checked there), imm = the column word(s).  Same arithmetic in the same order: the same bits as the unfused stream (DE_REV_NO_FUSE=1).
 template <typename T, int SRC> __device__ __noinline__ GState<T> rh_pushload(RCHAIN_ARGS) { // la = push slot | leaf row << 16 (CONST: imm = the constant)

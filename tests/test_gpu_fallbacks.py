@@ -195,3 +195,28 @@ def test_bench_two_ranks_on_one_gpu_strong_scaling_line(api):
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["config"]["rccl_world_size"] == 2 and d["config"]["trees_job"] == 64 and d["config"]["trees_this_rank"] == 32
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    # round 6: the line says how the flags were gathered and WHY, that every rank declared the dataset once (X is constant
+    # across the steps: the per-call pass over X does not shrink with the shard), and `value` is the executed rate beside the all-trees count
+    assert d["config"]["dataset_declared"] is True
+    assert "flag_gather_reason" in d["config"] and d["config"]["flag_gather"].startswith("torch.distributed")
+    assert 0 < d["value"] <= d["value_all_trees"] and d["value_executed"] == d["value"]
+
+
+def test_dist_timeout_is_accepted_and_a_one_rank_gather_still_works(api):
+    """de_dist_set_timeout (round 6): with a bound set, de_dist_gather_flags WAITS for what it queued (the one-rank path is a copy) and
+    returns the flags; a negative bound is refused; 0 puts the calls back to asynchronous."""
+    import torch
+    from dynamicexpressions_jl_amd import dist as dedist
+    ctx = api.Context(0)
+    comm = dedist.Comm(ctx, 0, 1)
+    flags = torch.tensor([1, 0, 1, 1, 0], dtype=torch.uint8, device="cuda")
+    comm.set_timeout(5000)
+    out = comm.gather_flags(flags, 5)
+    assert torch.equal(out.cpu(), flags.cpu())   # (no synchronisation needed: the bounded call waited)
+    with pytest.raises(api.DeviceError):
+        comm.set_timeout(-1)
+    comm.set_timeout(0)
+    out = comm.gather_flags(flags, 5)
+    ctx.synchronize()
+    assert torch.equal(out.cpu(), flags.cpu())
+    comm.close()

@@ -130,7 +130,7 @@ def test_fuzz_parametric_expressions(api, seed):
 
 @pytest.mark.parametrize("case", ["DE_NO_PARAM_ROWS", "20 parameters"])
 def test_fuzz_parametric_gather_fallback(api, case, monkeypatch):
-    """The eval kernels stage <= 16 parameters as LDS rows (csrc/de_api.cpp rebind); beyond that, or with DE_NO_PARAM_ROWS=1, every use
+    """The eval kernels stage <= 16 parameters as LDS rows (csrc/de_api_program.cpp rebind); beyond that, or with DE_NO_PARAM_ROWS=1, every use
     of a parameter gathers its samples' values (h_param, BOP_GEN_PARAM): the same differential run on that path."""
     if case == "DE_NO_PARAM_ROWS":
         monkeypatch.setenv("DE_NO_PARAM_ROWS", "1")

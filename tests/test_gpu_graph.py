@@ -230,7 +230,7 @@ def test_gradient_programs_share_subtrees_too(api, dtype):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_reverse_accumulation_over_shared_rows(api, dtype, monkeypatch):
     """Round 4 (VERDICT r3 missing 3): a CSE program keeps the reverse kernel.  A persistent row read by several consumers receives the SUM of
-    their adjoints in the backward sweep (the consumer that runs first stores, the others add: csrc/de_api.cpp `acc_use`), the definition's
+    their adjoints in the backward sweep (the consumer that runs first stores, the others add: csrc/de_api_grad.cpp `acc_use`), the definition's
     r_pop then continues with it.  Contract: the fused loss gradient of the EXPANDED tree — against the expanded population through the same
     reverse kernel and against the graph population through forward duals: flags identical, losses bit-identical, gradient rows equal to
     rounding (another order of the same additions; bound = the rows' path-absolute magnitude), constant rows summed per unique constant."""

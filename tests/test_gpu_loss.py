@@ -506,7 +506,7 @@ def test_fused_loss_grad_empty_and_error_paths(api):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_reverse_kernel_fused_records_give_the_same_bits(api, dtype, monkeypatch):
-    """The reverse-accumulation streams fuse fixed sequences into one record (csrc/de_api.cpp ensure_rev_threaded: PUSH + load / unary of
+    """The reverse-accumulation streams fuse fixed sequences into one record (csrc/de_api_grad.cpp ensure_rev_threaded: PUSH + load / unary of
     a leaf; [r_un] r_leaf [r_pop]; r_bin<column> r_leaf [r_pop]) — the same arithmetic in the same order: losses, gradients and flags
     are bit-identical to the unfused streams (DE_REV_NO_FUSE=1), for plain and parametric populations and the three modes."""
     import dynamicexpressions_jl_amd as de
