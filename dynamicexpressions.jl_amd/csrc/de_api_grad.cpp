@@ -69,7 +69,10 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         static const int WIDTH[10] = {1, 2, 3, 4, 5, 6, 8, 8, 5, 6};
         constexpr int NW = 10, NB = 2 * NW;
         const char *env2 = getenv("DE_GRAD_VS2_ROWS"); // most LDS rows per wave (X + parameters + slots) that still run two samples per lane
-        const int vs2_rows = env2 ? atoi(env2) : 15;    // 15 rows x 512 B x 4 waves = 30.7 KB: 5 workgroups per CU
+        // 15 rows x 512 B x 4 waves = 30.7 KB: 5 workgroups per CU.  Parametric populations (their P parameter rows come on top of X) take 18:
+        // measured in round 6 (tools/experiments/sweep_vs2_rows.sh, same box): C5 7.98 / 7.82 / 7.81 / 8.06 / 8.42 ms and C5Ng 7.30 / 7.06 / 7.14 /
+        // 7.40 / 7.66 ms at 15 / 18 / 20 / 22 / 24 rows — two samples per lane pay a little further out when most rows are shared inputs
+        const int vs2_rows = env2 ? atoi(env2) : (p->uses_params ? 18 : 15);
         std::vector<int32_t> tslots((size_t)p->n_trees, 0); // spill slots of each tree (rows >= F the code names)
         parallel_for_trees(p->n_trees, [&](int64_t t) {
             int32_t need = 0;

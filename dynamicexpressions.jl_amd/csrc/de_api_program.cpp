@@ -584,6 +584,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                         acoff[fi + 1] = (int64_t)ac;
                     }
                     std::copy(tp.code.begin(), tp.code.end(), p->fcode.begin() + ib);
+                    { Lowered done; std::swap(done, low[(size_t)t]); } // both lowerings of the tree are merged: released here, by the thread that is at it
                 }
             });
             for (const PartF &pt : partf) {
@@ -611,56 +612,62 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
                     for (int64_t i = 0; i < n; i++) { depth += 1 - (int)nd[i].degree; worst = std::max(worst, depth); }
                     if (worst <= DE_FOLD_STACK) p->fold_host[(size_t)j] = 2;
                 }, 512);
-                // the kernel's image: tape slices, offsets and constant sources of its subtrees, in fold order
-                p->kfold.clear();
-                p->kf_csrc.clear();
+                // the kernel's image and the auxiliary population: tape slices, offsets and constant sources of their subtrees, in fold order —
+                // positions by one serial prefix sum over the folds, the copies on the host threads
+                std::vector<de_tape_node_t> knodes, xnodes;
+                std::vector<int64_t> knoff{0}, kcoff{0}, xnoff{0}, xcoff{0};
                 {
-                    std::vector<de_tape_node_t> knodes;
-                    std::vector<int64_t> knoff{0}, kcoff{0};
+                    std::vector<int64_t> pos_n(n_folds), pos_c(n_folds);
+                    std::vector<int32_t> ord(n_folds);
+                    int64_t kn = 0, kc = 0, xn = 0, xc = 0;
+                    p->kfold.clear();
+                    p->aux_fold.clear();
                     for (size_t j = 0; j < n_folds; j++) {
-                        if (p->fold_host[j] != 2) continue;
-                        p->kfold.push_back((int32_t)j);
-                        knodes.insert(knodes.end(), anodes.begin() + anoff[j], anodes.begin() + anoff[j + 1]);
-                        p->kf_csrc.insert(p->kf_csrc.end(), p->aux_const_src.begin() + acoff[j], p->aux_const_src.begin() + acoff[j + 1]);
-                        knoff.push_back((int64_t)knodes.size());
-                        kcoff.push_back((int64_t)p->kf_csrc.size());
-                    }
-                    if (!p->kfold.empty()) {
-                        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-                        const size_t nk = p->kfold.size();
-                        p->kf_o_noff = al(knodes.size() * sizeof(de_tape_node_t));
-                        p->kf_o_coff = p->kf_o_noff + al(knoff.size() * sizeof(int64_t));
-                        p->kf_o_cvals = p->kf_o_coff + al(kcoff.size() * sizeof(int64_t));
-                        p->kf_o_out = p->kf_o_cvals + al(std::max<size_t>(p->kf_csrc.size(), 1) * es);
-                        p->kf_o_ok = p->kf_o_out + al(nk * es);
-                        p->kf_bytes = p->kf_o_ok + al(nk);
-                        std::vector<unsigned char> img(p->kf_o_out, 0);
-                        std::memcpy(img.data(), knodes.data(), knodes.size() * sizeof(de_tape_node_t));
-                        std::memcpy(img.data() + p->kf_o_noff, knoff.data(), knoff.size() * sizeof(int64_t));
-                        std::memcpy(img.data() + p->kf_o_coff, kcoff.data(), kcoff.size() * sizeof(int64_t));
-                        for (size_t k = 0; k < p->kf_csrc.size(); k++) {
-                            const double v = p->consts[(size_t)p->kf_csrc[k]];
-                            if (dtype == DE_F32) reinterpret_cast<float *>(img.data() + p->kf_o_cvals)[k] = (float)v;
-                            else reinterpret_cast<double *>(img.data() + p->kf_o_cvals)[k] = v;
+                        const int64_t nn = anoff[j + 1] - anoff[j], nc = acoff[j + 1] - acoff[j];
+                        if (p->fold_host[j] == 2) {
+                            ord[j] = (int32_t)p->kfold.size(); p->kfold.push_back((int32_t)j);
+                            pos_n[j] = kn; pos_c[j] = kc; kn += nn; kc += nc;
+                            knoff.push_back(kn); kcoff.push_back(kc);
+                        } else if (p->fold_host[j] == 0) {
+                            ord[j] = (int32_t)p->aux_fold.size(); p->aux_fold.push_back((int32_t)j);
+                            pos_n[j] = xn; pos_c[j] = xc; xn += nn; xc += nc;
+                            xnoff.push_back(xn); xcoff.push_back(xc);
                         }
-                        HIP_TRY(ctx, hipSetDevice(ctx->device));
-                        const hipError_t kst = prog_malloc(ctx, reinterpret_cast<void **>(&p->d_kf), p->kf_bytes);
-                        if (kst != hipSuccess) return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(kst));
-                        HIP_TRY(ctx, hipMemcpy(p->d_kf, img.data(), img.size(), hipMemcpyHostToDevice));
                     }
+                    knodes.resize((size_t)kn);
+                    xnodes.resize((size_t)xn);
+                    p->kf_csrc.resize((size_t)kc);
+                    p->aux_csrc.resize((size_t)xc);
+                    parallel_for_trees((int64_t)n_folds, [&](int64_t jj) {
+                        const size_t j = (size_t)jj;
+                        if (p->fold_host[j] == 1) return;
+                        const bool k = p->fold_host[j] == 2;
+                        std::copy(anodes.begin() + anoff[j], anodes.begin() + anoff[j + 1], (k ? knodes : xnodes).begin() + pos_n[j]);
+                        std::copy(p->aux_const_src.begin() + acoff[j], p->aux_const_src.begin() + acoff[j + 1], (k ? p->kf_csrc : p->aux_csrc).begin() + pos_c[j]);
+                    }, 512);
                 }
-                // the others form the auxiliary population (their tape slices and constants, concatenated in fold order)
-                std::vector<de_tape_node_t> xnodes;
-                std::vector<int64_t> xnoff{0}, xcoff{0};
-                p->aux_fold.clear();
-                p->aux_csrc.clear();
-                for (size_t j = 0; j < n_folds; j++) {
-                    if (p->fold_host[j]) continue;
-                    p->aux_fold.push_back((int32_t)j);
-                    xnodes.insert(xnodes.end(), anodes.begin() + anoff[j], anodes.begin() + anoff[j + 1]);
-                    p->aux_csrc.insert(p->aux_csrc.end(), p->aux_const_src.begin() + acoff[j], p->aux_const_src.begin() + acoff[j + 1]);
-                    xnoff.push_back((int64_t)xnodes.size());
-                    xcoff.push_back((int64_t)p->aux_csrc.size());
+                if (!p->kfold.empty()) {
+                    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+                    const size_t nk = p->kfold.size();
+                    p->kf_o_noff = al(knodes.size() * sizeof(de_tape_node_t));
+                    p->kf_o_coff = p->kf_o_noff + al(knoff.size() * sizeof(int64_t));
+                    p->kf_o_cvals = p->kf_o_coff + al(kcoff.size() * sizeof(int64_t));
+                    p->kf_o_out = p->kf_o_cvals + al(std::max<size_t>(p->kf_csrc.size(), 1) * es);
+                    p->kf_o_ok = p->kf_o_out + al(nk * es);
+                    p->kf_bytes = p->kf_o_ok + al(nk);
+                    std::vector<unsigned char> img(p->kf_o_out, 0);
+                    std::memcpy(img.data(), knodes.data(), knodes.size() * sizeof(de_tape_node_t));
+                    std::memcpy(img.data() + p->kf_o_noff, knoff.data(), knoff.size() * sizeof(int64_t));
+                    std::memcpy(img.data() + p->kf_o_coff, kcoff.data(), kcoff.size() * sizeof(int64_t));
+                    for (size_t k = 0; k < p->kf_csrc.size(); k++) {
+                        const double v = p->consts[(size_t)p->kf_csrc[k]];
+                        if (dtype == DE_F32) reinterpret_cast<float *>(img.data() + p->kf_o_cvals)[k] = (float)v;
+                        else reinterpret_cast<double *>(img.data() + p->kf_o_cvals)[k] = v;
+                    }
+                    HIP_TRY(ctx, hipSetDevice(ctx->device));
+                    const hipError_t kst = prog_malloc(ctx, reinterpret_cast<void **>(&p->d_kf), p->kf_bytes);
+                    if (kst != hipSuccess) return fail(ctx, DE_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(kst));
+                    HIP_TRY(ctx, hipMemcpy(p->d_kf, img.data(), img.size(), hipMemcpyHostToDevice));
                 }
                 p->folded = true;
                 lap("folds: classify, kernel image, auxiliary tapes");
@@ -687,7 +694,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
             }
         }
         // the per-tree lowerings are ~16 small vectors each: released on the threads that allocated them (one thread took 5 ms for 10^4 trees)
-        parallel_for_trees(n_trees, [&](int64_t t) { Lowered done; std::swap(done, low[(size_t)t]); });
+        if (!allow_fold) parallel_for_trees(n_trees, [&](int64_t t) { Lowered done; std::swap(done, low[(size_t)t]); }); // (with folding: released in the merge above)
         lap("release lowerings");
         recompute_host_ok(p.get());
         rebind(p.get());
