@@ -49,7 +49,7 @@ EXPORTS = [
     "de_eval_pullback_dX", "de_eval_tree_array", "de_eval_plan", "de_prio_tiles_wanted", "de_program_last_live_trees", "de_dist_unique_id", "de_dist_init", "de_dist_destroy", "de_dist_shard_size", "de_dist_world_size",
     "de_dist_broadcast", "de_dist_gather_flags", "de_dist_last_error", "de_ctx_last_kernel_ms", "de_ctx_last_kernel_name",
     "de_ctx_device", "de_ctx_timing_ring", "de_ctx_timing_read", "de_dist_reorder_selftest", "de_eval_sum_certificate",
-    "de_dist_set_timeout",
+    "de_dist_set_timeout", "de_ctx_trim",
 ]
 
 
@@ -259,6 +259,10 @@ class Context:
 
     def synchronize(self) -> None:
         self.check(library().de_ctx_synchronize(self._h))
+
+    def trim(self) -> None:
+        """Free what the context retains between programs (parked host vectors, recycled device buffers, staging scratch)."""
+        self.check(library().de_ctx_trim(self._h))
 
     def declare_dataset(self, X, dtype=None) -> None:
         """``X``: a device tensor ``[F, N]`` (feature index fastest, as ``eval`` takes it) that stays unchanged between calls — the

@@ -421,6 +421,7 @@ int de_ctx_destroy(de_ctx_t *c) {
     for (const auto &r : c->recycled) (void)hipFree(r.first);
     for (const auto &r : c->small_free) (void)hipFree(r.first);
     c->recycled.clear();
+    c->small_free.clear();
     for (de_program *q : c->parked) delete q;
     c->parked.clear();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -428,6 +429,23 @@ int de_ctx_destroy(de_ctx_t *c) {
     for (hipEvent_t e : c->ring) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return DE_OK;
+}
+
+// Give back what the context keeps for the NEXT program: the parked host vectors of destroyed programs (<= 4 shells / 512 MB), the recycled
+// device buffers (<= 12 / 256 MB + 64 small ones) and the staging scratch of host-pointer calls.  A context that is idle for long — a
+// Julia task per context multiplies the retention — calls this; the next de_program_create simply allocates afresh.
+int de_ctx_trim(de_ctx_t *c) {
+    if (!c) return DE_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (DevBuf *b : {&c->sX, &c->sOut, &c->sGrad, &c->sOk, &c->sParams, &c->sClasses, &c->sOut2, &c->sGoff, &c->sNg, &c->sY, &c->sW, &c->sLoss, &c->sPartial, &c->sSeg, &c->sDloss, &c->sColOff, &c->sDoff, &c->sCert, &c->sBcLoss, &c->sBcDloss, &c->sBcOk, &c->sBcNg, &c->sBcDoff, &c->sBcOut, &c->sBcTiles}) b->release();
+    for (const auto &r : c->recycled) (void)hipFree(r.first);
+    for (const auto &r : c->small_free) (void)hipFree(r.first);
+    c->recycled.clear();
+    c->small_free.clear();
+    for (de_program *q : c->parked) delete q;
+    c->parked.clear();
     return DE_OK;
 }
 

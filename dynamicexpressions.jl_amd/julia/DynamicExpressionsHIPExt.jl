@@ -285,6 +285,16 @@ function HIPContext(device::Integer=0)
 end
 """The calling task's context (task-local storage: tasks migrate between threads, `Threads.threadid()` is not a key)."""
 task_context() = get!(() -> HIPContext(0), task_local_storage(), :DynamicExpressionsHIPExt_context)::HIPContext
+"""Free what the context retains between populations (the parked host vectors and recycled device buffers of destroyed populations —
+up to 512 MB of host and 256 MB of device memory per context, i.e. per task — and the staging scratch of host arrays): `de_ctx_trim`.
+Call it from a task that goes idle; the next population simply allocates afresh."""
+function trim_context!(ctx::HIPContext=task_context())
+    with_ctx(ctx) do h
+        check(ctx, ccall((:de_ctx_trim, LIBDE), Cint, (Ptr{Cvoid},), h))
+    end
+    return nothing
+end
+
 function check(ctx::HIPContext, rc::Cint)
     rc == DE_OK && return true
     rc == DE_ERR_UNSUPPORTED_OP && throw(UnsupportedOperator(nothing, 0))

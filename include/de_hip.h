@@ -185,6 +185,11 @@ int de_ctx_destroy(de_ctx_t *ctx);
  * de_* call with the caller's current stream (torch.cuda.current_stream(), AMDGPU.stream()). */
 int de_ctx_set_stream(de_ctx_t *ctx, void *stream);
 int de_ctx_synchronize(de_ctx_t *ctx);
+/* Release what the context retains between programs (round 6): a destroyed program parks its host vectors (<= 4 shells, <= 512 MB) and its
+ * device streams (<= 12 buffers / 256 MB, + 64 small ones) with the context so that the next de_program_create of a search loop allocates
+ * nothing; host-pointer calls keep their staging scratch.  de_ctx_trim synchronises the stream and frees all of it (the context stays
+ * usable); de_ctx_destroy does the same.  DE_NO_PROG_RECYCLE=1 in the environment turns the retention off altogether. */
+int de_ctx_trim(de_ctx_t *ctx);
 /* Declare a DEVICE-resident feature matrix that does not change between calls (the X of a search: thousands of de_eval* calls on one
  * matrix): the library computes its per-dataset statistics — the 3 F priority-tile keys of large early-exit launches, one pass over
  * X — here, once, and every later call on this context with the same (X, N, ldX) skips its own pass.  The caller must re-declare (or

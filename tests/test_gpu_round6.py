@@ -253,3 +253,28 @@ def test_kernel_folded_subtrees_of_every_operator_have_the_bits_of_the_auxiliary
     _same_bits(r["default"], r["aux"], dtype, "wide operator set: host + kernel against the auxiliary program")
     _same_bits(r["kernel"], r["aux"], dtype, "wide operator set: kernel against the auxiliary program")
     print(f"[constant folds, every operator, {np.dtype(dtype).name}] {int(r['default'][1].sum())} of {len(trees)} trees complete; bit-equal to the auxiliary program")
+
+
+def test_ctx_trim_releases_the_retained_buffers_and_the_context_stays_usable(api):
+    """de_ctx_trim: the parked host vectors and recycled device buffers of destroyed programs are freed; programs created
+    afterwards build, byte for byte, what a fresh context builds."""
+    import torch
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(3000, seed=0x7219)
+    ctx = api.Context(0)
+    X = np.asfortranarray(de.synth.random_X(5, 500, seed=8))
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        pop = api.Population(trees, ops, np.float32, n_features=5, ctx=ctx)
+        out0, ok0 = pop.eval(X)
+        h0 = pop.stream_hash()
+        pop.close()
+    ctx.trim()
+    pop = api.Population(trees, ops, np.float32, n_features=5, ctx=ctx)
+    out1, ok1 = pop.eval(X)
+    assert pop.stream_hash() == h0 and np.array_equal(ok0, ok1)
+    assert np.array_equal(np.asarray(out0)[ok0].view(np.uint32), np.asarray(out1)[ok1].view(np.uint32))
+    pop.close()
+    ctx.trim()
+    ctx.close()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)

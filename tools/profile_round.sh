@@ -10,7 +10,7 @@ WLS=${*:-"headline turbo complete C2 C3 C4 C5 C5N C5Ng loss lossgrad C5pb"}
 R=$PWD; export TMPDIR=/tmp; O=$R/gpurun_out/profiles_$TAG; mkdir -p $O; cd /tmp
 for wl in $WLS; do
   args="--workload $wl"; [ $wl = turbo ] && args="--workload headline --turbo"
-  common="--no-cpu-baseline --no-turbo-leg --no-full-eval-leg --no-complete-leg"
+  common="--no-cpu-baseline --no-turbo-leg --no-full-eval-leg --no-complete-leg --no-configs"
   mkdir -p $O/$wl
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$wl/stats -o k -- python $R/bench.py $args --steps 5 --warmup 1 $common > $O/$wl/bench_under_rocprof.json 2>$O/$wl/stats.log
   for c in FETCH_SIZE WRITE_SIZE; do
