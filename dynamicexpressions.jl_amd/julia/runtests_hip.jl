@@ -233,3 +233,33 @@ end
     _, gm, _ = HIP._hip_eval_grad_tree_array(g, X, ops; variable=Val(false))
     @test size(gm, 1) == 1
 end
+
+@testset "round 6 / ABI 3: strict flags, the reverse-accumulation opt-in, trim" begin
+    # (a) eval_population_strict: outside `uncertified` the flag IS the reference's `complete` — including the isfinite(sum(x)) quirk
+    #     (src/ValueInterface.jl:9): ((x1 + 2.5) * big) / big has finite elements and an overflowing SUM
+    ops = OperatorEnum(1 => (cos, exp), 2 => (+, -, /, *))
+    x1 = Node{Float32}(; feature=1)
+    big = 3.0f34
+    quirk = ((x1 + 2.5f0) * big) / big
+    plain = x1 * cos(x1 - 3.2f0)
+    X = abs.(randn(Float32, 2, 4096)) .+ 0.5f0
+    pop = HIP.HIPPopulation([quirk, plain], ops, 2)
+    out, ok, uncertified = HIP.eval_population_strict(pop, X)
+    @test 1 in uncertified && !(2 in uncertified)
+    @test ok[2] == eval_tree_array(plain, X, ops)[2]
+    @test ok[1] && !eval_tree_array(quirk, X, ops)[2]      # the documented divergence, and why tree 1 is listed
+    # (b) forward duals are the default of the fused loss gradient; reverse_grad=true is the permission for reverse accumulation: same
+    #     values to rounding
+    wide = sum(Node{Float64}(; val=0.1 * k) * Node{Float64}(; feature=1 + k % 2) for k in 1:10)   # 10 constants: reverse where allowed
+    X64 = randn(Float64, 2, 2_000); y = randn(Float64, 2_000)
+    ops64 = OperatorEnum(1 => (cos, exp), 2 => (+, -, /, *))
+    pf = HIP.HIPPopulation([wide], ops64, 2)
+    pr = HIP.HIPPopulation([wide], ops64, 2; reverse_grad=true)
+    lf, df, okf = HIP.eval_population_loss_grad(pf, X64, y)
+    lr, dr, okr = HIP.eval_population_loss_grad(pr, X64, y)
+    @test okf == okr && isapprox(lf, lr; rtol=1e-12) && isapprox(df[1], dr[1]; rtol=1e-9)
+    # (c) trim_context! frees what the task's context retains; the next population simply allocates afresh
+    HIP.trim_context!()
+    out2, ok2 = HIP.eval_population(HIP.HIPPopulation([plain], ops, 2), X)
+    @test ok2[1] == ok[2] && agree(view(out2, :, 1), view(out, :, 2))
+end
