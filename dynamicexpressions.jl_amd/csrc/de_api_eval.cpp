@@ -213,8 +213,8 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
         sOk.dev = c->sOk.p;
         sOk.staged = true;
     }
-    if (p->d_ok_eval) HIP_TRY(c, hipMemcpyAsync(sOk.dev, p->d_ok_eval, (size_t)p->n_trees, hipMemcpyDeviceToDevice, c->stream));
-    else HIP_TRY(c, hipMemcpyAsync(sOk.dev, p->host_ok_eval.data(), (size_t)p->n_trees, hipMemcpyHostToDevice, c->stream));
+    // (the device copy of the initial flags goes in through the launch: EvalArgs.ok_init)
+    if (!p->d_ok_eval) HIP_TRY(c, hipMemcpyAsync(sOk.dev, p->host_ok_eval.data(), (size_t)p->n_trees, hipMemcpyHostToDevice, c->stream));
     if (p->uses_params) {
         rc = stage_in(c, c->sParams, pa->params, (size_t)pa->ld_params * (size_t)pa->n_classes * es, &sPar);
         if (rc) return rc;
@@ -237,6 +237,7 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
     a.out = sOut.dev;
     a.ld_out = ld_out;
     a.ok = static_cast<uint8_t *>(sOk.dev);
+    a.ok_init = p->d_ok_eval;
     if (p->uses_params) {
         a.params = sPar.dev;
         a.ld_params = pa->ld_params;

@@ -60,7 +60,9 @@ struct EvalArgs {
     int32_t F;
     void *out;                // device, [n_trees, ld_out]
     int64_t ld_out;
-    uint8_t *ok;              // device, n_trees bytes, pre-set to 1 by the caller
+    uint8_t *ok;              // device, n_trees bytes, pre-set by the caller — or by the launch when ok_init is given
+    const uint8_t *ok_init;   // device, n_trees bytes or null: the flags' initial values (the constant part of the flag); launch_eval puts them into
+                              // `ok` in front of its first kernel (round 6: inside the priority-tile pre-pass when that runs)
     // parametric
     const void *params;       // device [P, C]
     int64_t ld_params;
@@ -97,7 +99,9 @@ hipError_t launch_fold(int dtype, const void *nodes, const int64_t *noff, const 
                        uint8_t *ok, hipStream_t stream);
 hipError_t launch_dist_pack(uint8_t *send, const uint8_t *ok_local_dev, int64_t mine, int64_t per, hipStream_t stream);
 hipError_t launch_dist_unpack(uint8_t *ok_global_dev, const uint8_t *recv, int64_t per, int32_t world, int64_t n_trees, hipStream_t stream);
-hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX, int F, void *keys, hipStream_t stream);
+// (ok_init / ok / n_ok, optional: the kernel also copies the n_ok initial flag bytes into ok — the first kernel of an eval launch)
+hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX, int F, void *keys, hipStream_t stream, const uint8_t *ok_init = nullptr,
+                                uint8_t *ok = nullptr, int32_t n_ok = 0);
 bool prio_tiles_wanted(int64_t N, int F, int64_t n_trees);
 
 struct GradArgs {

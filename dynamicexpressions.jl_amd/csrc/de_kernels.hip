@@ -1621,7 +1621,10 @@ __device__ __forceinline__ uint32_t orderable_f32(float v) {
 // reduction per tile and feature — took 0.49 ms).
 template <typename T, int FMAX>
 __global__ void __launch_bounds__(256) de_tile_extremes_kernel(const T *__restrict__ X, int64_t N, int64_t ldX, int F, int tile_shift,
-                                                               unsigned long long *__restrict__ keys) {
+                                                               unsigned long long *__restrict__ keys, const uint8_t *__restrict__ ok_init,
+                                                               uint8_t *__restrict__ ok, int32_t n_ok) {
+    // (round 6) the launch's first kernel also sets the flags to their initial values: one stream operation less in front of a small launch
+    for (int32_t i = (int32_t)(blockIdx.x * 256 + threadIdx.x); i < n_ok; i += (int32_t)(gridDim.x * 256)) ok[i] = ok_init[i];
     const float inf = __builtin_inff();
     float v[3][FMAX];
     uint32_t at[3][FMAX];
@@ -2199,7 +2202,9 @@ bool eval_uses_threaded() { return env_int("DE_EVAL_THREADED", 1) != 0 && env_in
 // (0.118 ms for the headline's 200 MB, 2 % of the step).  F is a template parameter: element s * F + f of the group is a fixed register.
 // The <= 3 samples behind the last full group go through the scalar statistics of thread 0 of workgroup 0.
 template <int F>
-__global__ void __launch_bounds__(256) de_tile_extremes_vec_kernel(const float *__restrict__ X, int64_t N, int tile_shift, unsigned long long *__restrict__ keys) {
+__global__ void __launch_bounds__(256) de_tile_extremes_vec_kernel(const float *__restrict__ X, int64_t N, int tile_shift, unsigned long long *__restrict__ keys,
+                                                                   const uint8_t *__restrict__ ok_init, uint8_t *__restrict__ ok, int32_t n_ok) {
+    for (int32_t i = (int32_t)(blockIdx.x * 256 + threadIdx.x); i < n_ok; i += (int32_t)(gridDim.x * 256)) ok[i] = ok_init[i]; // (see de_tile_extremes_kernel)
     typedef float V4 __attribute__((ext_vector_type(4)));
     const float inf = __builtin_inff();
     float v[3][F];
@@ -2254,9 +2259,12 @@ __global__ void __launch_bounds__(256) de_tile_extremes_vec_kernel(const float *
 }
 
 // The pre-pass of the priority tiles (de_tile_extremes_kernel) for X[F, N]: keys[3 F] = orderable(value) << 32 | (sample / DE_PRIO_UNIT).
-hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX, int F, void *keys, hipStream_t stream) {
+hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX, int F, void *keys, hipStream_t stream, const uint8_t *ok_init, uint8_t *ok,
+                                int32_t n_ok) {
     if (!keys || F < 1 || F > DE_PRIO_MAX_F || N < 1) return hipErrorInvalidValue;
-    hipError_t st = hipMemsetAsync(keys, 0, (size_t)3 * F * sizeof(unsigned long long), stream);
+    if (!ok_init || !ok) n_ok = 0;
+    // (the whole key array, 192 bytes: a multiple of 16 is ONE fill kernel, 3 F x 8 = 120 bytes were two)
+    hipError_t st = hipMemsetAsync(keys, 0, (size_t)3 * DE_PRIO_MAX_F * sizeof(unsigned long long), stream);
     if (st != hipSuccess) return st;
     int shift = 0;
     while ((1 << shift) < DE_PRIO_UNIT) ++shift;
@@ -2268,7 +2276,7 @@ hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX
         unsigned long long *k = static_cast<unsigned long long *>(keys);
         const float *x = static_cast<const float *>(X);
         switch (F) {
-#define DE_TEV(FF) case FF: hipLaunchKernelGGL((de_tile_extremes_vec_kernel<FF>), gv, dim3(256), 0, stream, x, N, shift, k); break;
+#define DE_TEV(FF) case FF: hipLaunchKernelGGL((de_tile_extremes_vec_kernel<FF>), gv, dim3(256), 0, stream, x, N, shift, k, ok_init, ok, n_ok); break;
             DE_TEV(1) DE_TEV(2) DE_TEV(3) DE_TEV(4) DE_TEV(5) DE_TEV(6) DE_TEV(7) DE_TEV(8)
 #undef DE_TEV
             default: return hipErrorInvalidValue;
@@ -2277,10 +2285,10 @@ hipError_t launch_tile_extremes(int dtype, const void *X, int64_t N, int64_t ldX
     }
     if (dtype == DE_F32)
         hipLaunchKernelGGL((de_tile_extremes_kernel<float, DE_PRIO_MAX_F>), grid, dim3(256), 0, stream, static_cast<const float *>(X), N, ldX, F, shift,
-                           static_cast<unsigned long long *>(keys));
+                           static_cast<unsigned long long *>(keys), ok_init, ok, n_ok);
     else
         hipLaunchKernelGGL((de_tile_extremes_kernel<double, DE_PRIO_MAX_F>), grid, dim3(256), 0, stream, static_cast<const double *>(X), N, ldX, F, shift,
-                           static_cast<unsigned long long *>(keys));
+                           static_cast<unsigned long long *>(keys), ok_init, ok, n_ok);
     return hipGetLastError();
 }
 bool prio_tiles_wanted(int64_t N, int F, int64_t n_trees) {
@@ -2366,10 +2374,13 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     // first and once more in place.  The pre-pass: a memset, one read of X, a dependent launch (0.11 ms at 10^7 samples)
     a.prio = nullptr;
     a.n_prio_blocks = a.n_prio = 0;
+    bool ok_set = !e.ok_init; // e.ok_init: the flags' initial values, to be in e.ok before the first kernel reads them
     if (TBLK == 64 && a.skip_flagged && e.prio_keys && a.F >= 1 && prio_tiles_wanted(a.N, a.F, a.n_trees)) {
         const int np = 3 * a.F;
-        hipError_t ps = e.prio_keys_ready ? hipSuccess : launch_tile_extremes(sizeof(T) == 4 ? DE_F32 : DE_F64, a.X, a.N, a.ldX, a.F, e.prio_keys, stream);
+        hipError_t ps = e.prio_keys_ready ? hipSuccess
+                                          : launch_tile_extremes(sizeof(T) == 4 ? DE_F32 : DE_F64, a.X, a.N, a.ldX, a.F, e.prio_keys, stream, e.ok_init, e.ok, e.n_trees);
         if (ps != hipSuccess) return ps;
+        ok_set = !e.prio_keys_ready; // (the pre-pass, first kernel of the launch, has written the initial flags)
         const int tile_samples = TILE; // 512 / 128: a power of two
         a.prio_shift = 0;
         while ((DE_PRIO_UNIT << a.prio_shift) < tile_samples) ++a.prio_shift;
@@ -2382,6 +2393,10 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         }
         blocks += a.n_prio_blocks;
         if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    }
+    if (!ok_set) {
+        const hipError_t cs = hipMemcpyAsync(e.ok, e.ok_init, (size_t)e.n_trees, hipMemcpyDeviceToDevice, stream);
+        if (cs != hipSuccess) return cs;
     }
     // rows: X, spill slots, then (parametric) the class row [+ the table-pointer row for Float32] of h_param
     a.cls_row_off = (uint32_t)((size_t)(a.F + a.n_slots) * RowOf<T>::BYTES);
@@ -2597,6 +2612,10 @@ hipError_t launch_dist_unpack(uint8_t *ok_global_dev, const uint8_t *recv, int64
 }
 
 hipError_t launch_eval(int dtype, const EvalArgs &a, hipStream_t stream, const char **kernel_name) {
+    if (a.ok_init && !(a.threaded && !a.cert_max && !a.direct)) { // (the threaded launch sets the flags itself: fused into its pre-pass when that runs)
+        const hipError_t cs = hipMemcpyAsync(a.ok, a.ok_init, (size_t)a.n_trees, hipMemcpyDeviceToDevice, stream);
+        if (cs != hipSuccess) return cs;
+    }
     if (a.cert_max && !a.direct) return dtype == DE_F32 ? launch_eval_t<float, 1, 256>(a, stream, kernel_name) : launch_eval_t<double, 1, 256>(a, stream, kernel_name);
     if (a.direct) return dtype == DE_F32 ? launch_eval_t<float, 1, 256>(a, stream, kernel_name) : launch_eval_t<double, 1, 256>(a, stream, kernel_name);
     if (a.threaded) return dtype == DE_F32 ? launch_threaded_t<float>(a, stream, kernel_name) : launch_threaded_t<double>(a, stream, kernel_name);
