@@ -2,7 +2,7 @@
 # Command-line fuzz sweep with NEW seeds (round 4: 41, 42; after the chain / sentinel / side-stream changes: 51 — `bash tools/fuzz_sweep.sh 51`), default thresholds and with the exit path (priority tiles + compaction) forced on
 # every launch; one summary line per run -> gpurun_out/fuzz_sweep_r4.txt        gpurun --timeout 3000 -- 'bash tools/fuzz_sweep.sh'
 SEEDS=${*:-"41 42"}
-O=gpurun_out/fuzz_sweep_r4_$(echo $SEEDS | tr ' ' '_').txt; : > $O
+O=gpurun_out/fuzz_sweep_$(echo $SEEDS | tr ' ' '_').txt; : > $O
 run() { # label, env..., -- script seed
   local label=$1; shift
   local envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
