@@ -742,6 +742,27 @@ def main():
                                     complete_fraction=float(ok.float().mean().item()), nodes=sum(de.count_nodes(t) for t in chosen),
                                     candidates=n_cand, pop=pop_c, n=len(chosen))
 
+        fwd_res = None
+        if wl.get("reverse_grad") and is_param and by_class and world == 1:
+            # the same steps WITHOUT the permission: the library's default since ABI 3 — forward duals, the reference's flag semantics exactly
+            # (one fused pass per class instead of one reverse launch over all classes): what parity-first costs on this workload
+            pop_r = pop
+            pop = api.Population(trees, ops, np.float32, n_features=5, n_params=8, eval_context=api.EvalContext(turbo=bool(args.turbo)), ctx=ctx)
+            try:
+                for _ in range(2):
+                    step()
+                barrier()
+                t0w = time.perf_counter()
+                n_f = max(3, args.steps // 4)
+                for _ in range(n_f):
+                    step()
+                barrier()
+                fwd_res = dict(ms_per_step=1e3 * (time.perf_counter() - t0w) / n_f, steps=n_f, kernel=ctx.last_kernel_name(),
+                               flags_equal=bool(torch.equal(ok, ok_main)))
+            finally:
+                pop.close()
+                pop = pop_r
+            ok.copy_(ok_main)
         declared_res = None
         if world == 1 and not (is_param or is_grad or is_lossgrad or is_loss) and not args.no_complete_leg:
             # the same steps with the dataset DECLARED (de_ctx_declare_dataset: X does not change between the calls of a search, its
@@ -912,6 +933,9 @@ def main():
                                                      "frac": b_unit * cu / (ck * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b_unit * cu,
                                                      "valu": valu_ceiling(complete_res["pop"], complete_res["n"], cu, ck, turbo=bool(args.turbo))}}
                 complete_res["pop"].close()
+            if fwd_res is not None:
+                res["forward_default"] = {"option": "the same steps with the library's default (no DE_OPT_REVERSE_GRAD): forward duals, one fused pass per class — "
+                                                    "the reference's flag semantics exactly (ABI 3)", **fwd_res}
             if declared_res is not None:
                 res["dataset_declared"] = {"option": "de_ctx_declare_dataset(X) before the steps: the per-call pass over X (priority-tile keys) is done once per dataset",
                                            "ms_per_step": declared_res["ms_per_step"], "value": total_nodes * N / (declared_res["ms_per_step"] * 1e-3),
@@ -978,7 +1002,7 @@ def main():
                 c["roofline"]["valu_busy_est"] = rf["valu_measured"]["busy_est"]
             if rf.get("valu"):
                 c["roofline"]["valu_frac"] = rf["valu"].get("frac")
-            for kk in ("dataset_declared", "cpu_baseline"):
+            for kk in ("dataset_declared", "cpu_baseline", "forward_default"):
                 if kk in r:
                     c[kk] = r[kk]
             res["configs"][k] = c
