@@ -257,6 +257,9 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
     a.prio_keys_ready = !sX.staged && dataset_keys(c, p->dtype, X, N, ldX, p->n_features, &a.prio_keys);
     a.compact_code = p->d_compact_code;
     a.compact_ints = p->d_compact_ints;
+    a.waves = p->waves; // (wave groups: de_api_internal.h)
+    a.wave_slots = p->n_slots;
+    a.var_stride = p->var_stride;
     if (cr) { // the certificate pass: the un-elided program through the flat-switch kernel's CERT variant, nothing stored
         a.code = p->d_cert_code;
         a.code_off = p->d_cert_off;

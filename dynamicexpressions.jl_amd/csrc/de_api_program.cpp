@@ -84,6 +84,24 @@ static void rebind(de_program *p) {
 // handler address - handler_base, word 1 = LDS byte offset of the operand row | aux << 24.
 // DE_DEBUG_TIMING: microseconds since the previous lap of this thread, on stderr
 static void make_chained(de_program *p);
+// Waves per workgroup of the threaded eval kernel (de_api_internal.h `waves`): parametric programs with staged parameter rows only — the P
+// rows behind X and the slots cut a one-wave workgroup's occupancy to 2.5 waves per SIMD at P = 8 (15 rows; the kernel's registers allow 7);
+// W waves share X and the parameter rows.  The W (of 1, 2, 4) with the most resident waves per CU wins, the smaller on a tie.
+// DE_EVAL_WAVES = 1 | 2 | 4 overrides (1 = one-wave workgroups, the kernel of rounds 1-5).
+static int choose_waves(const de_program *p) {
+    if (!p->prows || !p->uses_params || TBLK != 64) return 1;
+    if (const char *e = getenv("DE_EVAL_WAVES")) { const int v = atoi(e); return (v == 2 || v == 4) ? v : 1; }
+    const size_t rb = trow_bytes(p->dtype), lds_cu = 160u << 10;
+    int best = 1;
+    size_t best_waves = 0;
+    for (int W : {1, 2, 4}) {
+        const size_t lds = ((size_t)p->n_features + (size_t)p->n_params + (size_t)W * (size_t)p->n_slots) * rb + (size_t)W * 256;
+        if (lds > 150u * 1024) continue;
+        const size_t waves = std::min<size_t>((lds_cu / lds) * (size_t)W, 28); // (28: 7 waves per SIMD by the kernel's vector registers)
+        if (waves > best_waves) { best = W; best_waves = waves; }
+    }
+    return best;
+}
 static int make_threaded(de_ctx *c, de_program *p) {
     p->threaded = false;
     dbg_lap(nullptr);
@@ -114,9 +132,8 @@ static int make_threaded(de_ctx *c, de_program *p) {
     });
     dbg_lap("fuse_tree");
     p->tcode.resize(p->fbcode.size());
-    parallel_tree_ranges(p->n_trees, [&](int, int64_t tb, int64_t te) {
-    for (size_t i = (size_t)p->tcode_off[(size_t)tb]; i < (size_t)p->tcode_off[(size_t)te]; i++) {
-        const BoundInstr &b = p->fbcode[i];
+    // fused instruction -> threaded words (also what make_wave_variants re-derives the operand words of the other waves' streams with)
+    auto threaded_words = [p, &table, base, hot_unary, row_bytes](const BoundInstr &b) {
         BoundInstr t = b;
         t.bop = (uint32_t)(table[b.bop] - base);
         if (hot_unary && (b.bop == BOP_GEN_ROW || b.bop == BOP_GEN_ACC)) {
@@ -138,8 +155,10 @@ static int make_threaded(de_ctx *c, de_program *p) {
             if (b.bop >= TOP_BIN2_BASE && b.bop < TOP_COUNT && !(((b.bop - TOP_BIN2_BASE) >> 2) & 1))
                 t.lo = (uint32_t)((int32_t)b.lo * (int32_t)row_bytes); // row-row: byte distance row A -> row B
         }
-        p->tcode[i] = t;
-    }
+        return t;
+    };
+    parallel_tree_ranges(p->n_trees, [&](int, int64_t tb, int64_t te) {
+        for (size_t i = (size_t)p->tcode_off[(size_t)tb]; i < (size_t)p->tcode_off[(size_t)te]; i++) p->tcode[i] = threaded_words(p->fbcode[i]);
     });
     dbg_lap("threaded words");
     {
@@ -155,6 +174,53 @@ static int make_threaded(de_ctx *c, de_program *p) {
     make_chained(p);
     dbg_lap("chained records");
     p->threaded = true;
+    // ---- wave groups: the stream variants of waves 1 .. W - 1 (de_api_internal.h `waves`)
+    p->waves = 1;
+    p->var_stride = 0;
+    p->ccode_w.clear();
+    const int W = choose_waves(p);
+    if (W > 1 && p->n_slots > 0 && fuse) {
+        const bool ee = (p->options & DE_OPT_EARLY_EXIT) != 0, f32 = p->dtype == DE_F32;
+        const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
+        const std::vector<int32_t> &off = p->folded ? p->fcode_off : p->code_off;
+        const int prb = p->n_features + p->n_slots;
+        const size_t n_rec = p->ccode.size();
+        p->ccode_w.resize(n_rec * (size_t)(W - 1));
+        std::atomic<bool> same{true};
+        for (int w = 1; w < W; w++) {
+            BoundInstr *cw = p->ccode_w.data() + n_rec * (size_t)(w - 1);
+            const int shift = p->n_params + w * p->n_slots; // [X | slots of wave 0 | parameter rows | slots of wave 1 | ...]: slot s of wave w = row F + S + P + (w - 1) S + s
+            parallel_tree_ranges(p->n_trees, [&](int, int64_t tb, int64_t te) {
+                std::vector<BoundInstr> b, f;
+                // (the records of trees tb .. te - 1 behind the header in front of tree tb, which is tree tb - 1's end record: disjoint ranges)
+                const size_t r0 = (size_t)p->ccode_off[(size_t)tb] - 1, r1 = te < p->n_trees ? (size_t)p->ccode_off[(size_t)te] - 1 : n_rec;
+                std::copy(p->ccode.begin() + (long)r0, p->ccode.begin() + (long)r1, cw + r0);
+                for (int64_t t = tb; t < te; t++) {
+                    b.clear();
+                    f.clear();
+                    bind_tree(src.data() + off[(size_t)t], (size_t)(off[(size_t)t + 1] - off[(size_t)t]), ee, p->n_features, &b, prb, shift);
+                    fuse_tree(b.data(), b.size(), &f);
+                    const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1];
+                    if ((int32_t)f.size() != i1 - i0) { same = false; return; }
+                    const size_t h = (size_t)p->ccode_off[(size_t)t];
+                    for (int32_t i = i0; i < i1; i++) {
+                        if (f[(size_t)(i - i0)].bop != p->fbcode[(size_t)i].bop) { same = false; return; }
+                        const BoundInstr tw = threaded_words(f[(size_t)(i - i0)]);
+                        BoundInstr &r = cw[h + (size_t)(i - i0)]; // (make_chained `put`: the operand words; the handler words stay)
+                        r.bop = tw.arg;
+                        if (f32) r.arg = tw.lo;
+                        else { r.lo = tw.lo; r.hi = tw.hi; }
+                    }
+                }
+            });
+        }
+        if (same) {
+            p->waves = W;
+            // (the device keeps a variant in cbytes = (bcode + trees + 2) records: de_program_create)
+            p->var_stride = (int64_t)(p->bcode.size() + (size_t)p->n_trees + 2);
+        } else p->ccode_w.clear(); // (a fusion decided differently with shifted rows: never seen — rows are < 128 apart — but then one wave)
+        dbg_lap("wave-group stream variants");
+    } else if (W > 1 && fuse) p->waves = W; // no slot: one stream for every wave
     return DE_OK;
 }
 
@@ -227,6 +293,20 @@ static void make_chained(de_program *p) {
 static inline void patch_chained_imm(de_program *p, int32_t c, uint32_t lo, uint32_t hi) {
     if (p->dtype == DE_F32) p->ccode[(size_t)c].arg = lo;
     else { p->ccode[(size_t)c].lo = lo; p->ccode[(size_t)c].hi = hi; }
+    for (size_t w = 0; w * p->ccode.size() < p->ccode_w.size(); w++) { // the other waves' variants of the record (wave groups)
+        BoundInstr &r = p->ccode_w[w * p->ccode.size() + (size_t)c];
+        if (p->dtype == DE_F32) r.arg = lo;
+        else { r.lo = lo; r.hi = hi; }
+    }
+}
+// the stream variants of waves 1 .. (wave groups) to their places behind variant 0
+static hipError_t upload_wave_variants(de_program *p) {
+    for (size_t w = 0; p->var_stride && w * p->ccode.size() < p->ccode_w.size(); w++) {
+        const hipError_t st = hipMemcpy(p->d_code + (w + 1) * (size_t)p->var_stride, p->ccode_w.data() + w * p->ccode.size(),
+                                        p->ccode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice);
+        if (st != hipSuccess) return st;
+    }
+    return hipSuccess;
 }
 
 static void recompute_host_ok(de_program *p) {
@@ -719,7 +799,9 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         // ONE device arena per eval program (round 6): [record stream | its second half for the compacted live trees | tree offsets |
         // compaction control ints | initial flags], one allocation from the context's pool; a small program (the one-tree call of
         // de_eval_tree_array) goes up in ONE copy from a zero-filled host image, a large one in one memset + three copies.
-        const size_t abytes = p->threaded ? 2 * cbytes : cbytes;
+        // (wave groups: `waves` variants of the stream var_stride = cbytes / 16 records apart, and as much room again for their compacted forms)
+        const size_t nvar = p->threaded && p->var_stride ? (size_t)p->waves : 1;
+        const size_t abytes = p->threaded ? 2 * nvar * cbytes : cbytes;
         auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
         const size_t off_bytes = p->bcode_off.size() * sizeof(int32_t);
         const size_t ints_bytes = p->threaded ? ((size_t)2 * (size_t)p->n_trees + 5) * sizeof(int32_t) : 0;
@@ -733,7 +815,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         p->d_code_off = reinterpret_cast<int32_t *>(base + o_off);
         p->d_ok_eval = reinterpret_cast<uint8_t *>(base + o_ok);
         if (p->threaded) {
-            p->d_compact_code = p->d_code + cbytes / sizeof(BoundInstr);
+            p->d_compact_code = p->d_code + nvar * cbytes / sizeof(BoundInstr);
             p->d_compact_ints = reinterpret_cast<int32_t *>(base + o_ints);
         }
         lap("hipMalloc (arena)");
@@ -744,12 +826,15 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
             // (the second half of a threaded stream needs no initial content: de_compact_live_kernel writes what the launch proper reads)
             std::vector<unsigned char> img(total, 0);
             if (!stream.empty()) std::memcpy(img.data(), stream.data(), stream.size() * sizeof(BoundInstr));
+            for (size_t w = 1; w < nvar; w++)
+                std::memcpy(img.data() + w * cbytes, p->ccode_w.data() + (w - 1) * p->ccode.size(), p->ccode.size() * sizeof(BoundInstr));
             std::memcpy(img.data() + o_off, offs.data(), off_bytes);
             if (p->n_trees > 0) std::memcpy(img.data() + o_ok, p->host_ok_eval.data(), (size_t)p->n_trees);
             st = hipMemcpy(base, img.data(), total, hipMemcpyHostToDevice);
         } else {
-            st = hipMemset(p->d_code, 0, cbytes);
+            st = hipMemset(p->d_code, 0, nvar * cbytes);
             if (st == hipSuccess && !stream.empty()) st = hipMemcpy(p->d_code, stream.data(), stream.size() * sizeof(BoundInstr), hipMemcpyHostToDevice);
+            if (st == hipSuccess) st = upload_wave_variants(p.get());
             if (st == hipSuccess) st = hipMemcpy(p->d_code_off, offs.data(), off_bytes, hipMemcpyHostToDevice);
             if (st == hipSuccess && p->n_trees > 0) st = hipMemcpy(p->d_ok_eval, p->host_ok_eval.data(), (size_t)p->n_trees, hipMemcpyHostToDevice);
         }
@@ -880,6 +965,7 @@ static int set_consts_impl(de_program_t *p, const void *consts) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // the program may be in use by work already queued
         if (!p->ccode.empty())
             HIP_TRY(ctx, hipMemcpy(p->d_code, p->ccode.data(), p->ccode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, upload_wave_variants(p));
         if (gpatch) {
             if (!p->gbcode.empty())
                 HIP_TRY(ctx, hipMemcpy(p->d_gcode, p->gbcode.data(), p->gbcode.size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
@@ -909,6 +995,7 @@ static int set_consts_impl(de_program_t *p, const void *consts) {
     if (!p->bcode.empty())
         HIP_TRY(ctx, hipMemcpy(p->d_code, (p->threaded ? p->ccode : p->bcode).data(),
                                (p->threaded ? p->ccode : p->bcode).size() * sizeof(BoundInstr), hipMemcpyHostToDevice));
+    if (p->threaded) HIP_TRY(ctx, upload_wave_variants(p)); // (same shapes: the variants the creation made room for)
     return DE_OK;
 }
 

@@ -36,7 +36,8 @@ BoundInstr mk(uint32_t bop, uint32_t arg, uint32_t lo = 0, uint32_t hi = 0) {
 
 } // namespace
 
-void bind_tree(const Instr *code, size_t n, bool ee, int n_features, std::vector<BoundInstr> *out, int param_row_base) {
+void bind_tree(const Instr *code, size_t n, bool ee, int n_features, std::vector<BoundInstr> *out, int param_row_base, int slot_shift) {
+    const uint32_t slot0 = (uint32_t)n_features + (uint32_t)slot_shift; // row of spill slot 0
     for (size_t i = 0; i < n; i++) {
         const Instr &ins = code[i];
         const uint32_t hdr = ins.hdr;
@@ -46,9 +47,9 @@ void bind_tree(const Instr *code, size_t n, bool ee, int n_features, std::vector
         if (src == SRC_PARAM && param_row_base >= 0) { // a parameter = one more staged row
             src = SRC_ROW;
             row += (uint32_t)param_row_base;
-        }
+        } else if (src == SRC_ROW && row >= (uint32_t)n_features) row += (uint32_t)slot_shift; // a popped / shared slot row
         const uint32_t lo = ins.imm.u32[0], hi = ins.imm.u32[1];
-        if (hdr & H_PUSH) out->push_back(mk(BOP_PUSH, (uint32_t)n_features + ((hdr >> H_PUSH_SHIFT) & H_SLOT_MASK)));
+        if (hdr & H_PUSH) out->push_back(mk(BOP_PUSH, slot0 + ((hdr >> H_PUSH_SHIFT) & H_SLOT_MASK)));
         const bool check_b = ee && (hdr & H_CHECK_B);
         if (check_b && src == SRC_ROW) out->push_back(mk(BOP_CHECK_ROW, row));
         const bool check_out = op != DOP_LOAD && (hdr & (ee ? H_CHECK_OUT : H_CHECK_ALWAYS));
@@ -59,7 +60,7 @@ void bind_tree(const Instr *code, size_t n, bool ee, int n_features, std::vector
             else if (src == SRC_CONST) out->push_back(mk(BOP_LOAD_CONST, ins.feat >> 16, lo, hi)); // arg = constant ordinal (gradient seed)
             else out->push_back(mk(BOP_GEN_PARAM, row | (check_b ? 1u << 23 : 0u) | (DOP_LOAD << 24)));
         } else if (op >= DE_T_FMA && op < DOP_LOAD) {
-            out->push_back(mk(BOP_TERN, row | (op << 24), (uint32_t)n_features + ((hdr >> H_POPC_SHIFT) & H_SLOT_MASK)));
+            out->push_back(mk(BOP_TERN, row | (op << 24), slot0 + ((hdr >> H_POPC_SHIFT) & H_SLOT_MASK)));
         } else if (inject && (src == SRC_ACC || src == SRC_ROW)) {
             out->push_back(mk(src == SRC_ACC ? BOP_INJ_ACC : BOP_INJ_ROW, row | (op << 24)));
         } else if (src == SRC_PARAM) {

@@ -227,6 +227,8 @@ bool top_is_const_source(uint32_t top);
 // Append the bound form of `code` (one tree) to `out`.
 // param_row_base >= 0: parameter operands are LDS rows param_row_base + p (the eval kernels stage the tile's parameter values like
 // features: de_api_program.cpp `prows`); < 0: BOP_GEN_PARAM, a gather per use
-void bind_tree(const Instr *code, size_t n, bool early_exit, int n_features, std::vector<BoundInstr> *out, int param_row_base = -1);
+// slot_shift: added to every SPILL-SLOT row (rows >= n_features of the lowering: pushes, popped operands, ternary operands, shared rows) —
+// the stream variant of wave w > 0 of a wave group keeps its slots behind the staged parameter rows (de_api_program.cpp make_wave_variants)
+void bind_tree(const Instr *code, size_t n, bool early_exit, int n_features, std::vector<BoundInstr> *out, int param_row_base = -1, int slot_shift = 0);
 
 } // namespace de

@@ -86,6 +86,11 @@ struct EvalArgs {
     void *compact_code;
     int32_t *compact_ints;
     bool *compacted; // out (may be null): this launch compacted its live trees
+    // wave groups (de_kernels.hip KArgs::var_stride): `code` (and the room behind compact_code) holds `waves` variants of the chained stream
+    // var_stride records apart (0: the trees use no spill slot, one stream serves every wave), each with wave_slots spill-slot rows of its own;
+    // 0 / 1 waves: one-wave workgroups
+    int32_t waves, wave_slots;
+    int64_t var_stride;
     // de_eval_sum_certificate: device array of n_trees zeroed words of the element type's size; non-null selects the CERT variant of the
     // flat-switch kernel (no output): the bits of the largest |validity-tested value| of every tree
     void *cert_max;

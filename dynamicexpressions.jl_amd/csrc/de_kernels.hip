@@ -88,6 +88,13 @@ template <typename T> struct KArgs {
     // threaded kernel: the LAST chunk of the plan runs as `tail_split` sub-chunks (1 = as it is): the workgroups that finish a launch are
     // short ones — the tail of a launch that fills the chip only a few times (10^6 samples: ~9 times, one 60-tree workgroup = 100 us of 900)
     int32_t tail_split;
+    // WAVE GROUPS (threaded kernel, template parameter WW > 1; round 6): a workgroup = WW waves on ONE sample tile — X and the staged parameter
+    // rows are shared, every wave runs a chunk of its own (chunk = group * WW + wave) with spill-slot rows of its own.  Slot rows are host
+    // data (the records carry LDS offsets), so the stream exists in WW variants, `var_stride` records apart (0: the trees use no slot),
+    // variant w = slots behind the parameter rows (de_api_program.cpp make_wave_variants); list_off = LDS byte address of wave 1's live-tree
+    // list (wave w: + (w - 1) * DE_SKIPLIST_BYTES; wave 0 keeps the list at 0), behind the rows.
+    int64_t var_stride;
+    uint32_t list_off;
 };
 
 // Chunk plan of a launch over n trees and n_tiles sample tiles (host: plan_chunks; device: de_compact_live_kernel for the live trees):
@@ -677,7 +684,10 @@ template <typename T> using BodyFn = BState<T> (*)(BState<T>, uint32_t, typename
 #define HL_TYPES_C(V) V, V, V, V,
 #endif
 template <typename T> using HandlerFn = HState<T> (*)(HState<T>, HL_TYPES_C(HL_T) uint32_t, ConstU4Ptr, uint64_t, uint32_t, uint32_t, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t);
-enum : uint32_t { HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0xFFFFFu,
+enum : uint32_t { HF_SLOW_STORE = 1u << 30, HF_NO_STORE = 1u << 29, HF_VALID_MASK = 0x3FFu, // (samples of the tile inside N: <= 512)
+                  // bits 10..24: LDS byte address >> 4 of this WAVE's live-tree list (h_tree_skip; 0 = the list in front of row 0 — every
+                  // one-wave workgroup, wave 0 of a wave group)
+                  HF_LIST_SHIFT = 10, HF_LIST_MASK = 0x7FFFu,
                   HF_SLOW = 1u << 31, // set with any of HF_SLOW_STORE / HF_NO_STORE / HF_LOSS: the out-of-line end of a tree (the sign bit: ONE scalar compare)
                   // plain flag stores (through the caches): always, except under flag protocol 1 (agent scope for every access, an
                   // experiment: skip_flag_load, de_device_ops.h)
@@ -765,7 +775,8 @@ template <typename T> __device__ __noinline__ HState<T> h_tree_skip(HCHAIN_ARGS)
     skip >>= n;
     left -= n;
     const uint32_t r = left - (uint32_t)__builtin_popcountll(skip >> 1); // live trees after the one the chain goes on with (the count holds the sentinel)
-    const uint32_t lo = *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(r * 4u)); // (wave-uniform address)
+    const uint32_t lb = (flags >> (HF_LIST_SHIFT - 4)) & (HF_LIST_MASK << 4); // this wave's list (0 unless the workgroup is a wave group)
+    const uint32_t lo = *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>((uintptr_t)(lb + r * 4u)); // (wave-uniform address)
     const uint64_t hdr = ((uint64_t)(uintptr_t)code & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
     const ConstU4Ptr nh = (ConstU4Ptr)(uintptr_t)hdr; // the tree's header record (the record in front of its first instruction)
     const U32x4 hn = nh[0], w = nh[1];
@@ -1688,7 +1699,12 @@ template <bool F32> __device__ __forceinline__ void rec_set_next(U32x4 &r, uint6
 template <bool F32>
 __global__ void __launch_bounds__(1024) de_compact_live_kernel(const U32x4 *__restrict__ code, const int32_t *__restrict__ code_off, const uint8_t *__restrict__ ok,
                                                               int32_t n_trees, U32x4 *__restrict__ ccode, int32_t *__restrict__ coff, int32_t *__restrict__ live_idx,
-                                                              int32_t *__restrict__ ctrl, int64_t n_tiles, int64_t want_blocks, int32_t tpc_max, const LossEnds le) {
+                                                              int32_t *__restrict__ ctrl, int64_t n_tiles, int64_t want_blocks, int32_t tpc_max, const LossEnds le,
+                                                              int64_t var_stride) {
+    // (a wave group's stream variants, KArgs::var_stride: workgroup v re-links variant v; the offsets, the tree list and the plan it writes
+    // are the same values in every workgroup, and each reads back only what it wrote itself)
+    code += (int64_t)blockIdx.x * var_stride;
+    ccode += (int64_t)blockIdx.x * var_stride;
     __shared__ int32_t wsum[2][16];
     __shared__ int32_t run[2]; // live trees / records placed so far
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1766,11 +1782,15 @@ __global__ void __launch_bounds__(1024) de_compact_live_kernel(const U32x4 *__re
     }
 }
 
-template <typename T, bool PARAMS, bool LOSS = false>
-__global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T> a) {
+// WW > 1: a WAVE GROUP (KArgs::var_stride) — WW waves of 64 lanes on one 64-lane tile; `tid` below is the lane's position in the TILE
+// (what addresses rows, samples and output), `stid` its position in the workgroup (what the cooperative staging loops stride by).
+template <typename T, bool PARAMS, bool LOSS = false, int WW = 1>
+__global__ void __launch_bounds__(DE_TBLK * WW) de_eval_threaded_kernel(const KArgs<T> a) {
     typedef typename VecOf<T>::type V;
     constexpr int VW = VecOf<T>::W;
     constexpr int BLK = DE_TBLK, G = TG<T>::G, PLANE = BLK * VW, TILE = PLANE * G, ROWV = BLK * G + 1; // (PLANE samples per plane, G planes per row)
+    static_assert(WW == 1 || DE_TBLK == 64, "a wave group shares one 64-lane tile");
+    constexpr int SBLK = BLK * WW; // threads that stage the tile
     extern __shared__ __align__(16) unsigned char smem_base[];
     unsigned char *const smem_raw = smem_base + DE_SKIPLIST_BYTES; // [0, DE_SKIPLIST_BYTES): the live-tree list of h_tree_skip; rows behind it
     T *__restrict__ rows = reinterpret_cast<T *>(smem_raw);
@@ -1786,22 +1806,28 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         tpc = ct[2];
         if (n_trees <= 0) return;
     }
+    // (a wave group maps GROUPS of WW chunks; the host launches it without a tail split)
+    const int32_t host_groups = WW > 1 ? (a.n_chunks + WW - 1) / WW : a.n_chunks, groups = WW > 1 ? (n_chunks + WW - 1) / WW : n_chunks + a.tail_split - 1;
     if (blockIdx.x < a.n_prio_blocks) { // a priority tile (see de_tile_extremes_kernel): its flags go straight to memory and come from there
-        const uint32_t k = blockIdx.x / (uint32_t)a.n_chunks;
+        const uint32_t k = blockIdx.x / (uint32_t)host_groups;
         if (k >= a.n_prio) return;
         tm.tile = (int64_t)((uint32_t)a.prio[k] >> a.prio_shift);
-        tm.chunk = (int32_t)(blockIdx.x % (uint32_t)a.n_chunks);
+        tm.chunk = (int32_t)(blockIdx.x % (uint32_t)host_groups);
         tm.valid = tm.tile < a.n_tiles;
         flag_protocol = 1;
-    } else tm = a.map_group > 0 ? map_block_grouped(blockIdx.x - a.n_prio_blocks, n_chunks + a.tail_split - 1, a.n_tiles, (uint32_t)a.map_group)
-                                : map_block(blockIdx.x - a.n_prio_blocks, n_chunks + a.tail_split - 1, a.n_tiles);
+    } else tm = a.map_group > 0 ? map_block_grouped(blockIdx.x - a.n_prio_blocks, groups, a.n_tiles, (uint32_t)a.map_group)
+                                : map_block(blockIdx.x - a.n_prio_blocks, groups, a.n_tiles);
     if (!tm.valid) return;
-    const int tid = threadIdx.x;
+    const int stid = threadIdx.x;
+    const int tid = WW > 1 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+    const int wave = WW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     const int64_t base = tm.tile * TILE;
     const int64_t last = a.N - 1;
-    int tA = tm.chunk * tpc; // this workgroup's trees: [tA, tB) (of the compact stream in a compacted launch)
+    if constexpr (WW > 1) tm.chunk = tm.chunk * WW + wave; // (a wave past the last chunk stages with the others and leaves behind the barrier)
+    int tA = tm.chunk * tpc; // this workgroup's (wave's) trees: [tA, tB) (of the compact stream in a compacted launch)
     int tB = (tA + tpc < n_trees) ? tA + tpc : n_trees;
-    if (a.tail_split > 1 && tm.chunk >= n_chunks - 1) { // the plan's last chunk in `tail_split` pieces (chunk-major order: the last workgroups of the launch)
+    if (WW > 1 && tm.chunk >= n_chunks) tA = tB = 0;
+    if (WW == 1 && a.tail_split > 1 && tm.chunk >= n_chunks - 1) { // the plan's last chunk in `tail_split` pieces (chunk-major order: the last workgroups of the launch)
         const int b0 = (n_chunks - 1) * tpc, rem = n_trees - b0;
         const int sub = (rem + a.tail_split - 1) / a.tail_split;
         tA = b0 + (tm.chunk - (n_chunks - 1)) * sub;
@@ -1812,7 +1838,7 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     // (wave 0 reads them for the whole workgroup: two waves reading at different moments could see different flags, and the
     // workgroup shares ONE live-tree list)
     uint8_t f_first = 1;
-    if (a.skip_flagged && tid < 64 && tA + tid < tB) f_first = skip_flag_load(a.ok + (a.live_idx ? a.live_idx[tA + tid] : tA + tid), flag_protocol, tm.tile);
+    if (a.skip_flagged && (WW > 1 || tid < 64) && tA + tid < tB) f_first = skip_flag_load(a.ok + (a.live_idx ? a.live_idx[tA + tid] : tA + tid), flag_protocol, tm.tile);
     // the 64-bit skip mask travels from wave 0 to the others through the padding vector of LDS row 0 (16 unused bytes behind the
     // DE_TBLK vectors of every row)
     uint64_t *const mask_slot = reinterpret_cast<uint64_t *>(smem_raw + (size_t)BLK * G * 16);
@@ -1830,6 +1856,26 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             // reciprocal instead of a run-time division.
             const V *__restrict__ src = reinterpret_cast<const V *>(a.X + base * (int64_t)F);
             const uint32_t GF = (uint32_t)G * F;
+            if constexpr (WW > 1) { // the same loop over the workgroup's SBLK threads (the tile has BLK * GF vectors)
+                const uint32_t nv = (uint32_t)BLK * GF;
+                for (uint32_t i0 = 0; i0 * SBLK < nv; i0 += 8) {
+                    V buf[8];
+                    DE_UNROLL for (uint32_t u = 0; u < 8; u++)
+                        if (stid + (i0 + u) * SBLK < nv) buf[u] = src[stid + (i0 + u) * SBLK];
+                    DE_UNROLL for (uint32_t u = 0; u < 8; u++) {
+                        if (stid + (i0 + u) * SBLK < nv) {
+                            const uint32_t e = (stid + (i0 + u) * SBLK) * VW;
+                            uint32_t j = a.f_magic ? __umulhi(e, a.f_magic) : e;
+                            uint32_t f = e - j * F;
+                            DE_UNROLL for (int c = 0; c < VW; c++) {
+                                rows[f * (ROWV * VW) + j] = buf[u][c];
+                                ++f;
+                                if (f == F) { f = 0; ++j; }
+                            }
+                        }
+                    }
+                }
+            } else
             for (uint32_t i0 = 0; i0 < GF; i0 += 8) {
                 V buf[8];
                 DE_UNROLL for (uint32_t u = 0; u < 8; u++)
@@ -1849,12 +1895,12 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             }
         } else if (a.ldX == (int64_t)F && base + TILE <= a.N) {
             const T *__restrict__ src = a.X + base * (int64_t)F;
-            for (uint32_t e = tid; e < total; e += BLK) {
+            for (uint32_t e = stid; e < total; e += SBLK) {
                 const uint32_t j = e / F, f = e - j * F;
                 rows[f * (ROWV * VW) + j] = src[e];
             }
         } else {
-            for (uint32_t e = tid; e < total; e += BLK) {
+            for (uint32_t e = stid; e < total; e += SBLK) {
                 const uint32_t j = e / F, f = e - j * F;
                 int64_t jj = base + j;
                 jj = jj < last ? jj : last;
@@ -1863,8 +1909,8 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         }
     }
     if (PARAMS && a.n_prows > 0) {
-        stage_param_rows<T>(a, rows, ROWV * VW, base, TILE, tid, BLK);
-    } else if (PARAMS) {
+        stage_param_rows<T>(a, rows, ROWV * VW, base, TILE, stid, SBLK);
+    } else if (PARAMS && WW == 1) { // (a wave group is only launched with staged parameter rows)
         // the class row: byte offsets of this thread's samples' parameter columns (the table has < 2^32 bytes: checked
         // on the host), and the table's address for h_param (see there)
         DE_UNROLL for (int g = 0; g < G; g++) {
@@ -1887,13 +1933,18 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             }
         }
     }
-    if (a.skip_flagged && tid < 64) { // (all 64 lanes of wave 0 take part in the ballot)
+    uint64_t m_first = 0ull; // (wave group: every wave has trees and flags of its own — its mask stays in registers)
+    if constexpr (WW > 1) {
+        if (a.skip_flagged) m_first = __ballot(f_first == 0);
+    } else if (a.skip_flagged && tid < 64) { // (all 64 lanes of wave 0 take part in the ballot)
         const uint64_t m0 = __ballot(f_first == 0);
         if (tid == 0) *mask_slot = m0;
     }
     __syncthreads();
 
-    const ConstU4Ptr code = (ConstU4Ptr)(uintptr_t)a.code;
+    const ConstU4Ptr code = (ConstU4Ptr)(uintptr_t)(a.code + (WW > 1 ? (int64_t)wave * a.var_stride : (int64_t)0));
+    // this wave's live-tree list (h_tree_skip): wave 0 / a one-wave workgroup at LDS address 0, wave w of a group behind the rows
+    const uint32_t list_at = (WW > 1 && wave > 0) ? a.list_off + (uint32_t)(wave - 1) * DE_SKIPLIST_BYTES : 0u;
     const ConstI32Ptr code_off = (ConstI32Ptr)(uintptr_t)a.code_off;
     const bool full = base + TILE <= a.N;
     // LDS byte address of this thread's vector in row 0 (the dynamic LDS segment starts at 0)
@@ -1925,6 +1976,11 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
     // (src/Evaluate.jl:26-32), this kernel stops at the next workgroup.  Agent scope: past this CU's vector cache.
     uint64_t skip = 0ull;
     if (a.skip_flagged) {
+        if constexpr (WW > 1) { // (one sub-chunk: a wave group's chunks hold <= 63 trees — launch_threaded_t)
+            if (t0 != tA) break;
+            skip = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m_first >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m_first);
+            skip &= (1ull << (t1 - t0)) - 1ull;
+        } else {
         if (t0 != tA) { // a later sub-chunk: wave 0 reads its flags once every wave is done with the previous list
             __syncthreads();
             if (tid < 64) {
@@ -1940,14 +1996,15 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
             skip = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
             skip &= (1ull << (t1 - t0)) - 1ull; // (the first mask holds the flags of 64 trees: the 64th belongs to the next sub-chunk)
         }
+        } // one-wave workgroup
         {
             // the live trees' header addresses, in reverse order (see h_tree_skip); every wave writes the whole list (same values):
             // a wave reads only what it wrote itself, no barrier
             const int i = t0 + (tid & 63);
             if (i < t1 && !((skip >> (tid & 63)) & 1ull)) {
                 const uint32_t r = (uint32_t)__builtin_popcountll((~skip & ((1ull << (t1 - t0)) - 1ull)) >> 1 >> (tid & 63));
-                const uint64_t hdr = (uint64_t)(uintptr_t)(a.code + (t0 == tA ? co_first : a.code_off[i]) - 1);
-                reinterpret_cast<uint32_t *>(smem_base)[r] = (uint32_t)hdr;
+                const uint64_t hdr = (uint64_t)(uintptr_t)(code + (t0 == tA ? co_first : a.code_off[i]) - 1);
+                reinterpret_cast<uint32_t *>(smem_base + list_at)[r] = (uint32_t)hdr;
             }
         }
     }
@@ -1968,11 +2025,11 @@ __global__ void __launch_bounds__(DE_TBLK) de_eval_threaded_kernel(const KArgs<T
         DE_UNROLL for (int g = 0; g < G; g++) DE_UNROLL for (int i = 0; i < VW; i++) st.acc[g][i] = T(0);
         st.poison = typename PoisonOf<T>::type{};
         const int64_t in_tile = a.N - base < (int64_t)TILE ? a.N - base : (int64_t)TILE;
-        uint32_t flags = flag_protocol == 1 ? 0u : HF_PLAIN_FLAG;
+        uint32_t flags = (flag_protocol == 1 ? 0u : HF_PLAIN_FLAG) | ((list_at >> 4) << HF_LIST_SHIFT);
         uint64_t outp, ldo_arg = ldo;
         if constexpr (LOSS) {
             flags |= HF_SLOW | HF_LOSS | (a.loss_kind == DE_LOSS_L1 ? (uint32_t)HF_LOSS_L1 : 0u) | ((full && !a.w) ? (uint32_t)HF_LOSS_PLAIN : 0u);
-            outp = (uint64_t)(uintptr_t)(a.partial + ((int64_t)tm.tile * a.n_trees) * TWAVES + __builtin_amdgcn_readfirstlane(tid >> 6)); // (wave-uniform: an SGPR argument)
+            outp = (uint64_t)(uintptr_t)(a.partial + ((int64_t)tm.tile * a.n_trees) * TWAVES + __builtin_amdgcn_readfirstlane(tid >> 6)); // (wave-uniform: an SGPR argument; a wave group: tid < 64)
             ldo_arg = (uint64_t)TWAVES * sizeof(T);
         } else {
             flags |= a.vec_store == 2 ? (HF_SLOW | HF_NO_STORE) : ((full && a.vec_store) ? 0u : (HF_SLOW | HF_SLOW_STORE | (uint32_t)in_tile));
@@ -2064,9 +2121,15 @@ static int cu_count() {
 // Tree chunking: chunks of ~64 trees keep workgroups short (fine-grained tail) while the
 // X-tile staging (one L2 read of the tile per chunk) stays a few percent of the work; with few
 // sample tiles, split further so the grid still covers the chip several times.
-static void plan_chunks(int64_t n_trees, int64_t n_tiles, int32_t *n_chunks_out, int32_t *tpc_out, int32_t *nc0_out = nullptr) {
+// (`waves` > 1: the chunks of a wave group — one per wave, 1 / waves of the trees each: a workgroup keeps the trees, and the record
+// footprint, of a one-wave workgroup)
+static int32_t plan_tpc_max(int waves) {
     const int64_t tpc_env = env_int("DE_EVAL_TPC", 63); // trees per chunk (experiments: X staging per tree against the tail of a short launch)
-    chunk_plan(n_trees, n_tiles, tpc_env, (int64_t)cu_count() * 4 * 8, n_chunks_out, tpc_out, nc0_out);
+    const int64_t t = (tpc_env < 1 ? 63 : (tpc_env > 63 && waves > 1 ? 63 : tpc_env)) / (waves > 1 ? waves : 1);
+    return (int32_t)(t < 1 ? 1 : t);
+}
+static void plan_chunks(int64_t n_trees, int64_t n_tiles, int32_t *n_chunks_out, int32_t *tpc_out, int32_t *nc0_out = nullptr, int waves = 1) {
+    chunk_plan(n_trees, n_tiles, plan_tpc_max(waves), (int64_t)cu_count() * 4 * 8, n_chunks_out, tpc_out, nc0_out);
     if (*n_chunks_out < 1) *n_chunks_out = 1;
 }
 
@@ -2330,8 +2393,11 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.f_magic = e.F > 1 ? (uint32_t)((0x100000000ull + (uint64_t)e.F - 1) / (uint64_t)e.F) : 0u;
     if (!env_int("DE_X_VEC", 1)) { a.x_vec = 0; a.f_magic = 0; } // scalar staging loop (A/B and the test of the vector path)
     if (env_int("DE_DEBUG_NO_STORE", 0)) a.vec_store = 2;
+    // wave groups (KArgs::var_stride): parametric programs with staged parameter rows whose stream exists in e.waves variants
+    const int WW = (TBLK == 64 && (e.waves == 2 || e.waves == 4) && e.uses_params && e.n_prows > 0) ? e.waves : 1;
+    a.var_stride = WW > 1 ? e.var_stride : 0;
     int32_t tpc, nch, nc0;
-    plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc, &nc0);
+    plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc, &nc0, WW);
     a.trees_per_chunk = tpc;
     a.n_chunks = nch;
     a.live_idx = a.ctrl = nullptr;
@@ -2351,7 +2417,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         // (tools/pmc_smem.sh), complete trees -2.5 %, fused loss -4 %, headline -1.2 % (tools/exp_map_group.sh; groups of 128 ... 2048 tiles
         // measured WORSE than either end) — and X is re-read from HBM once per chunk instead of once (+7 % traffic at F = 5, 16 chunks).
         // Wide X keeps the chunk-fastest order (its tile is re-served by the XCD's L2).
-        const int64_t g = env_int("DE_MAP_GROUP", (int64_t)a.F * 8 <= (int64_t)a.trees_per_chunk ? (int)(tiles8 > 0x3fffffff ? 0x3fffffff : tiles8) : 0);
+        const int64_t g = env_int("DE_MAP_GROUP", (int64_t)a.F * 8 <= (int64_t)a.trees_per_chunk * WW ? (int)(tiles8 > 0x3fffffff ? 0x3fffffff : tiles8) : 0);
         a.map_group = (int32_t)(g <= 0 ? 0 : (g > tiles8 ? tiles8 : g));
     }
     const int64_t tiles8g = a.map_group > 0 ? (tiles8 + a.map_group - 1) / a.map_group * a.map_group : tiles8;
@@ -2363,12 +2429,13 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     // chunk's X tiles staged four times) — so only launches of <= DE_TAIL_SPLIT_FILLS (24) fills of the chip split their last chunk.
     a.tail_split = 1;
     const int64_t fills = (a.n_tiles * (int64_t)a.n_chunks) / ((int64_t)(cu_count() > 0 ? cu_count() : 256) * 21);
-    if (TBLK == 64 && a.map_group > 0 && a.n_chunks > 1 && fills <= env_int("DE_TAIL_SPLIT_FILLS", 24)) {
+    if (TBLK == 64 && WW == 1 && a.map_group > 0 && a.n_chunks > 1 && fills <= env_int("DE_TAIL_SPLIT_FILLS", 24)) {
         const int ts = env_int("DE_TAIL_SPLIT", 4);
         const int most = tpc / 8; // (a sub-chunk keeps >= 8 trees when the chunk is full)
         a.tail_split = ts < 1 ? 1 : (ts > most ? (most < 1 ? 1 : most) : ts);
     }
-    int64_t blocks = tiles8g * 8 * ((int64_t)a.n_chunks + a.tail_split - 1);
+    auto groups_of = [&](int64_t chunks) { return WW > 1 ? (chunks + WW - 1) / WW : chunks + a.tail_split - 1; }; // workgroups per sample tile
+    int64_t blocks = tiles8g * 8 * groups_of(a.n_chunks);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     // priority tiles (de_tile_extremes_kernel): launches over >= 512 sample tiles and >= 96 trees with the early exit on; 3 F tiles, run
     // first and once more in place.  The pre-pass: a memset, one read of X, a dependent launch (0.11 ms at 10^7 samples)
@@ -2386,10 +2453,10 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         while ((DE_PRIO_UNIT << a.prio_shift) < tile_samples) ++a.prio_shift;
         a.prio = static_cast<const unsigned long long *>(e.prio_keys);
         a.n_prio = (uint32_t)np;
-        a.n_prio_blocks = (uint32_t)(((int64_t)np * a.n_chunks + 7) / 8 * 8);
+        a.n_prio_blocks = (uint32_t)(((int64_t)np * (WW > 1 ? groups_of(a.n_chunks) : (int64_t)a.n_chunks) + 7) / 8 * 8);
         if (!env_int("DE_PRIO_PROBE", 1)) { // (the priority tiles as the first workgroups of the ONE launch: they index the plain chunks)
-            blocks = tiles8g * 8 * (int64_t)a.n_chunks;
             a.tail_split = 1;
+            blocks = tiles8g * 8 * groups_of(a.n_chunks);
         }
         blocks += a.n_prio_blocks;
         if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -2402,14 +2469,22 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     a.cls_row_off = (uint32_t)((size_t)(a.F + a.n_slots) * RowOf<T>::BYTES);
     const int prm_rows = (e.uses_params && e.n_prows == 0) ? (sizeof(T) == 4 ? 2 : 1) : 0; // (the class row of h_param; staged parameter rows count as slots)
     if (e.uses_params && (uint64_t)e.ld_params * (uint64_t)e.n_classes * sizeof(T) > 0xFFFFFFFFull) return hipErrorInvalidValue; // 32-bit column offsets
-    const size_t lds = (size_t)(a.F + a.n_slots + prm_rows + env_int("DE_EXTRA_LDS_ROWS", 0)) * RowOf<T>::BYTES + DE_SKIPLIST_BYTES;
+    // (a wave group: the other waves' slot rows behind the parameter rows, then their live-tree lists)
+    const size_t row_bytes_all = (size_t)(a.F + a.n_slots + prm_rows + (WW - 1) * e.wave_slots + env_int("DE_EXTRA_LDS_ROWS", 0)) * RowOf<T>::BYTES;
+    a.list_off = (uint32_t)(DE_SKIPLIST_BYTES + row_bytes_all);
+    const size_t lds = row_bytes_all + (size_t)WW * DE_SKIPLIST_BYTES;
+    if (WW > 1 && (lds >> 4) > HF_LIST_MASK) return hipErrorInvalidValue;
     void (*kern)(const KArgs<T>) = e.uses_params ? de_eval_threaded_kernel<T, true> : de_eval_threaded_kernel<T, false>;
+    if (WW == 2) kern = de_eval_threaded_kernel<T, true, false, 2>;
+    if (WW == 4) kern = de_eval_threaded_kernel<T, true, false, 4>;
     a.y = a.w = nullptr;
     a.partial = nullptr;
     a.loss_kind = 0;
     if (e.loss && DE_NO_LOSS) return hipErrorInvalidValue; // (a build without the loss arguments)
     if (e.loss) {
         kern = e.uses_params ? de_eval_threaded_kernel<T, true, true> : de_eval_threaded_kernel<T, false, true>;
+        if (WW == 2) kern = de_eval_threaded_kernel<T, true, true, 2>;
+        if (WW == 4) kern = de_eval_threaded_kernel<T, true, true, 4>;
         a.y = static_cast<const T *>(e.loss->y);
         a.w = static_cast<const T *>(e.loss->w);
         a.partial = static_cast<T *>(e.loss->partial);
@@ -2428,8 +2503,8 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         pa.trees_per_chunk = env_int("DE_PRIO_PROBE_TPC", 8);
         pa.trees_per_chunk = pa.trees_per_chunk < 1 ? 1 : (pa.trees_per_chunk > 64 ? 64 : pa.trees_per_chunk); // (a divisor, and the skip mask has 64 bits)
         pa.n_chunks = (a.n_trees + pa.trees_per_chunk - 1) / pa.trees_per_chunk;
-        pa.n_prio_blocks = (uint32_t)(((int64_t)pa.n_prio * pa.n_chunks + 7) / 8 * 8);
-        hipLaunchKernelGGL(kern, dim3(pa.n_prio_blocks), dim3(TBLK), lds, stream, pa);
+        pa.n_prio_blocks = (uint32_t)(((int64_t)pa.n_prio * (WW > 1 ? ((int64_t)pa.n_chunks + WW - 1) / WW : (int64_t)pa.n_chunks) + 7) / 8 * 8);
+        hipLaunchKernelGGL(kern, dim3(pa.n_prio_blocks), dim3(TBLK * WW), lds, stream, pa);
         const hipError_t ps = hipGetLastError();
         if (ps != hipSuccess) return ps;
         blocks -= a.n_prio_blocks;
@@ -2440,7 +2515,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         if (e.compact_code && e.compact_ints && tpc <= 64 && env_int("DE_COMPACT", 1)) {
             int32_t *coff = e.compact_ints, *live_idx = coff + (size_t)e.n_trees + 1, *ctrl = live_idx + e.n_trees;
             const int64_t want_blocks = (int64_t)cu_count() * 4 * 8;
-            const int32_t tpc_max = env_int("DE_EVAL_TPC", 63);
+            const int32_t tpc_max = plan_tpc_max(WW);
             LossEnds le;
             std::memset(&le, 0, sizeof le);
             if (e.loss && env_int("DE_LOSS_PLAIN_ENDS", 1)) {
@@ -2455,11 +2530,11 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
                 }
             }
             if (sizeof(T) == 4)
-                hipLaunchKernelGGL(de_compact_live_kernel<true>, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const U32x4 *>(e.code), e.code_off, e.ok,
-                                   e.n_trees, reinterpret_cast<U32x4 *>(e.compact_code), coff, live_idx, ctrl, a.n_tiles, want_blocks, tpc_max, le);
+                hipLaunchKernelGGL(de_compact_live_kernel<true>, dim3(a.var_stride ? WW : 1), dim3(1024), 0, stream, reinterpret_cast<const U32x4 *>(e.code), e.code_off, e.ok,
+                                   e.n_trees, reinterpret_cast<U32x4 *>(e.compact_code), coff, live_idx, ctrl, a.n_tiles, want_blocks, tpc_max, le, a.var_stride);
             else
-                hipLaunchKernelGGL(de_compact_live_kernel<false>, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const U32x4 *>(e.code), e.code_off, e.ok,
-                                   e.n_trees, reinterpret_cast<U32x4 *>(e.compact_code), coff, live_idx, ctrl, a.n_tiles, want_blocks, tpc_max, le);
+                hipLaunchKernelGGL(de_compact_live_kernel<false>, dim3(a.var_stride ? WW : 1), dim3(1024), 0, stream, reinterpret_cast<const U32x4 *>(e.code), e.code_off, e.ok,
+                                   e.n_trees, reinterpret_cast<U32x4 *>(e.compact_code), coff, live_idx, ctrl, a.n_tiles, want_blocks, tpc_max, le, a.var_stride);
             const hipError_t cs = hipGetLastError();
             if (cs != hipSuccess) return cs;
             a.code = static_cast<const BoundInstr *>(e.compact_code);
@@ -2467,11 +2542,11 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
             a.live_idx = live_idx;
             a.ctrl = ctrl;
             if (e.compacted) *e.compacted = true;
-            blocks = tiles8g * 8 * ((int64_t)nc0 + a.tail_split - 1);
+            blocks = tiles8g * 8 * groups_of(nc0);
             if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TBLK), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TBLK * WW), lds, stream, a);
     hipError_t st = hipGetLastError();
     if (st != hipSuccess || !e.loss) return st;
     int32_t n_segs = 1;
