@@ -84,21 +84,27 @@ static void rebind(de_program *p) {
 // handler address - handler_base, word 1 = LDS byte offset of the operand row | aux << 24.
 // DE_DEBUG_TIMING: microseconds since the previous lap of this thread, on stderr
 static void make_chained(de_program *p);
-// Waves per workgroup of the threaded eval kernel (de_api_internal.h `waves`): parametric programs with staged parameter rows only — the P
-// rows behind X and the slots cut a one-wave workgroup's occupancy to 2.5 waves per SIMD at P = 8 (15 rows; the kernel's registers allow 7);
-// W waves share X and the parameter rows.  The W (of 1, 2, 4) with the most resident waves per CU wins, the smaller on a tie.
-// DE_EVAL_WAVES = 1 | 2 | 4 overrides (1 = one-wave workgroups, the kernel of rounds 1-5).
+// Waves per workgroup of the threaded eval kernel (de_api_internal.h `waves`).  A one-wave workgroup keeps F rows of X, S spill-slot rows
+// and (parametric) P staged parameter rows in LDS: at F = 5, S = 2 that is 21 resident waves per CU (5.25 per SIMD; the kernel's registers
+// allow 28) and more buys nothing (measured: W = 2 +1 %, W = 4 +6 % on the headline) — but 8 parameter rows leave 10 waves, 20 features 7, 30
+// features 4.  W waves share X and the parameter rows: W is doubled (1 -> 2 -> 4) while the workgroup is below 20 resident waves per CU and
+// the step raises them by half or more.  Measured, 10^6 samples x 1000 trees: 8 per-sample parameters 1.35 -> 0.92 ms, F = 12 1.29 -> 0.97,
+// F = 20 2.06 -> 1.08, F = 30 3.10 -> 1.22 (profiles/r6_wave_groups.txt).  DE_EVAL_WAVES = 1 | 2 | 4 overrides (1 = the kernel of rounds 1-5).
 static int choose_waves(const de_program *p) {
-    if (!p->prows || !p->uses_params || TBLK != 64) return 1;
+    if (TBLK != 64 || (p->uses_params && !p->prows)) return 1; // (gathered parameters: the class row is per wave)
     if (const char *e = getenv("DE_EVAL_WAVES")) { const int v = atoi(e); return (v == 2 || v == 4) ? v : 1; }
-    const size_t rb = trow_bytes(p->dtype), lds_cu = 160u << 10;
+    const size_t rb = trow_bytes(p->dtype), lds_cu = 160u << 10, shared = (size_t)p->n_features + (p->prows ? (size_t)p->n_params : 0);
+    auto resident = [&](int W) -> size_t {
+        const size_t lds = (shared + (size_t)W * (size_t)p->n_slots) * rb + (size_t)W * 256;
+        return lds > 150u * 1024 ? 0 : std::min<size_t>((lds_cu / lds) * (size_t)W, 28); // (28: 7 waves per SIMD by the kernel's vector registers)
+    };
     int best = 1;
-    size_t best_waves = 0;
-    for (int W : {1, 2, 4}) {
-        const size_t lds = ((size_t)p->n_features + (size_t)p->n_params + (size_t)W * (size_t)p->n_slots) * rb + (size_t)W * 256;
-        if (lds > 150u * 1024) continue;
-        const size_t waves = std::min<size_t>((lds_cu / lds) * (size_t)W, 28); // (28: 7 waves per SIMD by the kernel's vector registers)
-        if (waves > best_waves) { best = W; best_waves = waves; }
+    size_t have = resident(1);
+    for (int W : {2, 4}) {
+        const size_t w = resident(W);
+        if (have >= 20 || w * 2 < have * 3) break;
+        best = W;
+        have = w;
     }
     return best;
 }
@@ -183,13 +189,13 @@ static int make_threaded(de_ctx *c, de_program *p) {
         const bool ee = (p->options & DE_OPT_EARLY_EXIT) != 0, f32 = p->dtype == DE_F32;
         const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
         const std::vector<int32_t> &off = p->folded ? p->fcode_off : p->code_off;
-        const int prb = p->n_features + p->n_slots;
+        const int prb = p->prows ? p->n_features + p->n_slots : -1, n_prows = p->prows ? p->n_params : 0;
         const size_t n_rec = p->ccode.size();
         p->ccode_w.resize(n_rec * (size_t)(W - 1));
         std::atomic<bool> same{true};
         for (int w = 1; w < W; w++) {
             BoundInstr *cw = p->ccode_w.data() + n_rec * (size_t)(w - 1);
-            const int shift = p->n_params + w * p->n_slots; // [X | slots of wave 0 | parameter rows | slots of wave 1 | ...]: slot s of wave w = row F + S + P + (w - 1) S + s
+            const int shift = n_prows + w * p->n_slots; // [X | slots of wave 0 | parameter rows | slots of wave 1 | ...]: slot s of wave w = row F + S + P + (w - 1) S + s
             parallel_tree_ranges(p->n_trees, [&](int, int64_t tb, int64_t te) {
                 std::vector<BoundInstr> b, f;
                 // (the records of trees tb .. te - 1 behind the header in front of tree tb, which is tree tb - 1's end record: disjoint ranges)

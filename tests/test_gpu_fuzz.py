@@ -128,12 +128,15 @@ def test_fuzz_parametric_expressions(api, seed):
     gate(tot, "wide", f"ParametricExpression, seed {seed}")
 
 
-@pytest.mark.parametrize("case", ["DE_NO_PARAM_ROWS", "20 parameters"])
+@pytest.mark.parametrize("case", ["DE_NO_PARAM_ROWS", "20 parameters", "DE_EVAL_WAVES=1", "DE_EVAL_WAVES=2"])
 def test_fuzz_parametric_gather_fallback(api, case, monkeypatch):
     """The eval kernels stage <= 16 parameters as LDS rows (csrc/de_api_program.cpp rebind); beyond that, or with DE_NO_PARAM_ROWS=1, every use
-    of a parameter gathers its samples' values (h_param, BOP_GEN_PARAM): the same differential run on that path."""
+    of a parameter gathers its samples' values (h_param, BOP_GEN_PARAM): the same differential run on that path.  Staged rows run in wave
+    groups since round 6 (4 waves per workgroup by default here: the other fuzz tests): the one-wave and two-wave forms as well."""
     if case == "DE_NO_PARAM_ROWS":
         monkeypatch.setenv("DE_NO_PARAM_ROWS", "1")
+    if case.startswith("DE_EVAL_WAVES"):
+        monkeypatch.setenv("DE_EVAL_WAVES", case[-1])
     P = 20 if case == "20 parameters" else 5
     tot = FZ.Findings()
     rng = de.synth.Xoshiro256ss(4242)

@@ -278,3 +278,64 @@ def test_ctx_trim_releases_the_retained_buffers_and_the_context_stays_usable(api
     ctx.trim()
     ctx.close()
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+
+
+# ---- wave groups (csrc/de_api_program.cpp choose_waves, de_kernels.hip KArgs::var_stride) ----------------------------------------------------
+def _wave_case(kind, dtype, g):
+    """(trees, operators, X, params, classes, P): a population whose one-wave workgroup is short of resident waves."""
+    ops = de.synth.BENCH_OPERATORS
+    if kind == "parametric":
+        F, P, C = 5, 8, 11
+        trees = de.synth.random_population(330, seed=0x3A7E, dtype=dtype, node_type=de.ParametricNode, nparams=P)
+    else:  # a wide feature matrix
+        F, P, C = 20, 0, 0
+        trees = de.synth.random_population(330, seed=0x3A7F, dtype=dtype, nfeatures=F)
+    N = 150_001  # >= 512 sample tiles (priority tiles, probe launch, compaction of the live trees) and a ragged last tile
+    X = np.asfortranarray((g.standard_normal((F, N)) * 1.5).astype(dtype))
+    params = np.asfortranarray((g.standard_normal((P, C)) * 2).astype(dtype)) if P else None
+    classes = g.integers(1, C + 1, N).astype(np.int64) if P else None
+    return trees, ops, X, params, classes, P
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("kind", ["parametric", "wide X"])
+def test_wave_groups_have_the_bits_and_flags_of_one_wave_workgroups(api, kind, dtype, monkeypatch):
+    """A population with staged parameter rows, or with many features, runs 2 or 4 waves per workgroup on one sample tile (X and the parameter
+    rows staged once; a chunk, spill-slot rows, a live-tree list and a stream variant per wave).  Values, flags, fused losses: the bits of the
+    one-wave workgroups of rounds 1-5 (DE_EVAL_WAVES=1) — with the early exit's probe launch and compaction, and without (full evaluation);
+    and after de_program_set_consts (every variant of the stream carries the new immediates)."""
+    g = np.random.Generator(np.random.PCG64(99))
+    trees, ops, X, params, classes, P = _wave_case(kind, dtype, g)
+    y = g.standard_normal(X.shape[1]).astype(dtype)
+    kw = dict(params=params, classes=classes) if P else {}
+    results = {}
+    for waves in ("1", "2", "4", None):
+        if waves is None:
+            monkeypatch.delenv("DE_EVAL_WAVES", raising=False)
+        else:
+            monkeypatch.setenv("DE_EVAL_WAVES", waves)
+        got = []
+        for ec in (api.EvalContext(), api.EvalContext(early_exit=False)):
+            pop = api.Population(trees, ops, dtype, n_features=X.shape[0], n_params=P, eval_context=ec)
+            out, ok = pop.eval(X, **kw)
+            loss, ok_l = pop.eval_loss(X, y, **kw)
+            got.append((np.asarray(out), np.asarray(ok), np.asarray(loss), np.asarray(ok_l)))
+            if ec.early_exit:  # new constants: patched in place in every variant of the stream
+                consts = np.concatenate([de.flatten(t, ops, dtype)[1] for t in trees]).astype(dtype)
+                pop.set_constants(consts * dtype(1.25) - dtype(0.5))
+                out2, ok2 = pop.eval(X, **kw)
+                got.append((np.asarray(out2), np.asarray(ok2), None, None))
+            pop.close()
+        results[waves] = got
+    ref = results["1"]
+    assert ref[0][1].sum() > 100 and (ref[0][1] == 0).sum() > 30, "the case needs complete and incomplete trees"
+    for waves, got in results.items():
+        if waves == "1":
+            continue
+        assert len(got) == len(ref)
+        for (o, k, l, kl), (ro, rk, rl, rkl) in zip(got, ref):
+            assert np.array_equal(k, rk), f"waves {waves}: flags"
+            live = rk != 0
+            assert o[live].tobytes() == ro[live].tobytes(), f"waves {waves}: values of the complete trees"
+            if l is not None:
+                assert np.array_equal(kl, rkl) and l[rkl != 0].tobytes() == rl[rkl != 0].tobytes(), f"waves {waves}: fused loss"

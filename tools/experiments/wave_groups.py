@@ -20,21 +20,26 @@ ctx = api.Context(0)
 dev = "cuda"
 
 
+PLAIN = "plain" in sys.argv  # plain (non-parametric) programs
+ENV = "DE_EVAL_WAVES"
+
+
 def run(trees, ops, dtype, N, n_cls, per_sample, waves, steps=0, loss=False, P=8, F=5, seed=3):
     if waves is None:
-        os.environ.pop("DE_EVAL_WAVES", None)
+        os.environ.pop(ENV, None)
     else:
-        os.environ["DE_EVAL_WAVES"] = str(waves)
+        os.environ[ENV] = str(waves)
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     X = (torch.randn((N, F), generator=g, device=dev, dtype=tdt) * 1.5).t()  # [F, N] column-major
     params = torch.randn((n_cls, P), generator=g, device=dev, dtype=tdt)
     classes = torch.arange(1, N + 1, device=dev, dtype=torch.int32) if per_sample else torch.randint(1, n_cls + 1, (N,), generator=g, device=dev, dtype=torch.int32)
-    pop = api.Population(trees, ops, dtype, n_features=F, ctx=ctx, n_params=P)
+    pop = api.Population(trees, ops, dtype, n_features=F, ctx=ctx, n_params=0 if PLAIN else P)
     pa = api.ParamArgs()
     pa.params, pa.ld_params, pa.n_classes = params.data_ptr(), P, n_cls
     pa.classes, pa.classes_is_i64, pa.class_base = classes.data_ptr(), 0, 1
+    par = None if PLAIN else ctypes.byref(pa)
     out = torch.zeros((len(trees), N), device=dev, dtype=tdt)
     ok = torch.zeros(len(trees), device=dev, dtype=torch.uint8)
     y = torch.randn(N, generator=g, device=dev, dtype=tdt)
@@ -42,9 +47,9 @@ def run(trees, ops, dtype, N, n_cls, per_sample, waves, steps=0, loss=False, P=8
 
     def step():
         if loss:
-            ctx.check(lib.de_eval_loss(ctx._h, pop._h, X.data_ptr(), N, F, ctypes.byref(pa), y.data_ptr(), None, 0, lossv.data_ptr(), ok.data_ptr()))
+            ctx.check(lib.de_eval_loss(ctx._h, pop._h, X.data_ptr(), N, F, par, y.data_ptr(), None, 0, lossv.data_ptr(), ok.data_ptr()))
         else:
-            ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, F, ctypes.byref(pa), out.data_ptr(), N, ok.data_ptr()))
+            ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, F, par, out.data_ptr(), N, ok.data_ptr()))
     step()
     ctx.synchronize()
     ms = None
@@ -73,10 +78,10 @@ def same(a, b, okh):
 
 fails = 0
 ops = de.synth.BENCH_OPERATORS
-for dtype in (np.float32, np.float64):
+for dtype in (() if 'timeonly' in sys.argv else (np.float32, np.float64)):
     for (n_trees, N, n_cls, per_sample, P) in ((1000, 100_003, 16, False, 8), (300, 50_000, 50_000, True, 8), (7, 3_000, 5, False, 3), (1, 1_000_000, 16, False, 8),
                                                (2000, 300_000, 16, False, 16)):
-        trees = de.synth.random_population(n_trees, seed=0xC5 + n_trees, node_type=de.ParametricNode, nparams=P)
+        trees = de.synth.random_population(n_trees, seed=0xC5 + n_trees) if PLAIN else de.synth.random_population(n_trees, seed=0xC5 + n_trees, node_type=de.ParametricNode, nparams=P)
         for loss in (False, True):
             ok1, r1, _ = run(trees, ops, dtype, N, n_cls, per_sample, 1, loss=loss, P=P)
             for w in (2, 4, None):
@@ -88,6 +93,23 @@ for dtype in (np.float32, np.float64):
 print("FAILS", fails, flush=True)
 
 # timing: the C5N shape (1000 trees, 10^6 samples, 8 per-sample parameters) and 16 classes
+if PLAIN:  # the headline population at 10^6 and 10^7 samples
+    trees = de.synth.random_population(1000, seed=0xDE02)
+    for N in (10**6, 10**7):
+        for w in (1, 2, 4):
+            for loss in (False, True):
+                _, _, ms = run(trees, ops, np.float32, N, 16, False, w, steps=20, loss=loss)
+                print(f"TIME plain N {N} waves {w} loss {loss}: {ms:.3f} ms", flush=True)
+    # wide feature matrices: the X rows are what cuts the occupancy
+    for F in (12, 20, 30):
+        trees = de.synth.random_population(1000, seed=0xDE02 + F, nfeatures=F)
+        ref = None
+        for w in (1, 2, 4, None):
+            okh, res, ms = run(trees, ops, np.float32, 10**6, 16, False, w, steps=20, F=F)
+            if ref is None:
+                ref = (okh, res)
+            print(f"TIME plain F {F} N 1000000 waves {w}: {ms:.3f} ms; flags equal {(ref[0] == okh).all()}, complete rows bit-equal {same(ref[1], res, okh)}", flush=True)
+    raise SystemExit(0)
 trees = de.synth.random_population(1000, seed=0xDE05, node_type=de.ParametricNode, nparams=8)
 for (n_cls, per_sample) in ((10**6, True), (16, False)):
     for w in (1, 2, 4, None):
