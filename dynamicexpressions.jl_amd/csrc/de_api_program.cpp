@@ -1216,6 +1216,46 @@ int de_program_verify(const de_program_t *p) {
                 if (fb.bop == BOP_GEN_PARAM && (f32 ? r.arg : r.lo) != (uint32_t)rows * (uint32_t)trow_bytes(p->dtype)) return bad("class-row offset of a parameter operand", t, i - i0, r.arg);
             }
         }
+        // wave groups: variant w of the stream = variant 0 but for the slot rows, which lie `shift` rows further on (behind the staged
+        // parameter rows and the slots of the waves before): same handler words, every operand row inside the group's allocation, a row
+        // of variant 0's slot area moved by exactly the shift and every other row left where it is
+        if (p->waves > 1 && p->ccode_w.size() != (p->var_stride ? p->ccode.size() * (size_t)(p->waves - 1) : 0)) return bad("stream variants of the wave group", -1, p->waves, p->ccode_w.size());
+        const uint64_t rb = trow_bytes(p->dtype);
+        for (size_t w = 1; p->var_stride && w < (size_t)p->waves; w++) {
+            const BoundInstr *cw = p->ccode_w.data() + (w - 1) * p->ccode.size();
+            const int64_t shift = (p->prows ? p->n_params : 0) + (int64_t)w * p->n_slots, rows_all = rows + (int64_t)(p->waves - 1) * p->n_slots;
+            auto moved = [&](int64_t row0, int64_t roww) { return roww == (row0 >= p->n_features && row0 < spill_end ? row0 + shift : row0) && roww < rows_all; };
+            for (int64_t t = 0; t < p->n_trees; t++) {
+                const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1], h = p->ccode_off[(size_t)t];
+                for (int32_t i = i0 - 1; i <= i1; i++) { // the header in front, the instructions, the end record
+                    const BoundInstr &r0 = p->ccode[(size_t)(h + (i - i0))], &r = cw[(size_t)(h + (i - i0))];
+                    const bool same_next = f32 ? (r.lo == r0.lo && r.hi == r0.hi) : r.arg == r0.arg;
+                    if (!same_next) return bad("stream variant names another handler", t, i - i0, w);
+                    if (i < i0 || i == i1) { if (std::memcmp(&r, &r0, sizeof r)) return bad("stream variant: header / end record differs", t, i - i0, w); continue; }
+                    const BoundInstr &fb = p->fbcode[(size_t)i];
+                    const bool no_row = top_is_const_source(fb.bop) || fb.bop == BOP_CHECK_ACC || fb.bop == BOP_GEN_ACC || fb.bop == BOP_INJ_ACC ||
+                                        fb.bop == BOP_GEN_PARAM || (fb.bop >= BOP_UN_BASE && fb.bop < BOP_UN_END && !((fb.bop - BOP_UN_BASE) & 2)) ||
+                                        (fb.bop >= TOPX_UN_BASE && fb.bop < TOPX_BIN_BASE && ((fb.bop - TOPX_UN_BASE) & 1)) ||
+                                        (fb.bop >= TOPX_BIN_BASE && ((fb.bop - TOPX_BIN_BASE) & 1));
+                    if (no_row) { if (std::memcmp(&r, &r0, sizeof r)) return bad("stream variant: a record without a row operand differs", t, i - i0, w); continue; }
+                    const uint64_t off0 = r0.bop & 0xFFFFFFu, off = r.bop & 0xFFFFFFu;
+                    if (off % rb != 0 || !moved((int64_t)(off0 / rb), (int64_t)(off / rb))) return bad("stream variant: operand row", t, i - i0, r.bop);
+                    const bool pushes = (fb.bop >= TOP_LOADROW_BASE && fb.bop < TOP_LOADCONST_PUSH && ((fb.bop - TOP_LOADROW_BASE) & 2)) ||
+                                        (fb.bop >= TOP_UNROW_BASE && fb.bop < TOP_BINROWC_BASE && ((fb.bop - TOP_UNROW_BASE) & 2)) ||
+                                        (fb.bop >= TOP_BIN2_BASE && fb.bop < TOP_COUNT && ((fb.bop - TOP_BIN2_BASE) & 1));
+                    if (pushes && !moved((int64_t)(off0 / rb) + (int8_t)(r0.bop >> 24), (int64_t)(off / rb) + (int8_t)(r.bop >> 24)))
+                        return bad("stream variant: push row of a superinstruction", t, i - i0, r.bop);
+                    if (fb.bop >= TOP_BIN2_BASE && fb.bop < TOP_COUNT && !(((fb.bop - TOP_BIN2_BASE) >> 2) & 1)) { // row-row
+                        const int64_t s0 = (int64_t)off0 + (int32_t)(f32 ? r0.arg : r0.lo), s1 = (int64_t)off + (int32_t)(f32 ? r.arg : r.lo);
+                        if (s1 < 0 || s1 % (int64_t)rb != 0 || !moved(s0 / (int64_t)rb, s1 / (int64_t)rb)) return bad("stream variant: second operand row", t, i - i0, (uint64_t)s1);
+                    } else if (fb.bop == BOP_TERN) {
+                        const int64_t c0 = (int64_t)off0 + (int32_t)(f32 ? r0.arg : r0.lo), c1 = (int64_t)off + (int32_t)(f32 ? r.arg : r.lo);
+                        if (c1 < 0 || c1 % (int64_t)rb != 0 || !moved(c0 / (int64_t)rb, c1 / (int64_t)rb)) return bad("stream variant: third operand row", t, i - i0, (uint64_t)c1);
+                    } else if (top_carries_const(fb.bop) ? false : (f32 ? r.arg != r0.arg : (r.lo != r0.lo || r.hi != r0.hi)))
+                        return bad("stream variant: immediate differs", t, i - i0, w);
+                }
+            }
+        }
     }
     return DE_OK;
 }

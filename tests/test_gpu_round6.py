@@ -317,6 +317,7 @@ def test_wave_groups_have_the_bits_and_flags_of_one_wave_workgroups(api, kind, d
         got = []
         for ec in (api.EvalContext(), api.EvalContext(early_exit=False)):
             pop = api.Population(trees, ops, dtype, n_features=X.shape[0], n_params=P, eval_context=ec)
+            pop.verify()  # (the sanitizer walks every variant of the stream)
             out, ok = pop.eval(X, **kw)
             loss, ok_l = pop.eval_loss(X, y, **kw)
             got.append((np.asarray(out), np.asarray(ok), np.asarray(loss), np.asarray(ok_l)))
