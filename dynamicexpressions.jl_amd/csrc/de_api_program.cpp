@@ -1073,7 +1073,7 @@ int de_prio_tiles_wanted(int64_t N, int32_t n_features, int64_t n_trees) { retur
 
 int de_eval_plan(const de_program_t *p, int64_t N, int32_t *plan) {
     if (!p || !plan || N < 0) return DE_ERR_INVALID_ARG;
-    eval_plan(p->dtype, p->n_trees, N, &plan[0], &plan[1], &plan[2]);
+    eval_plan(p->dtype, p->n_trees, N, &plan[0], &plan[1], &plan[2], p->threaded ? p->waves : 1);
     return DE_OK;
 }
 

@@ -197,7 +197,7 @@ hipError_t eval_handler_table(int dtype, bool turbo, uint64_t *table);
 bool eval_uses_threaded();
 
 // Launch plan of the eval kernel for (n_trees, N): samples per workgroup tile, tree chunks.
-void eval_plan(int dtype, int64_t n_trees, int64_t N, int32_t *tile, int32_t *n_chunks, int32_t *trees_per_chunk);
+void eval_plan(int dtype, int64_t n_trees, int64_t N, int32_t *tile, int32_t *n_chunks, int32_t *trees_per_chunk, int waves = 1); // (waves: de_program::waves — wave groups)
 
 // Scratch the fused-loss reduction needs for (dtype, n_trees, N).
 void loss_scratch_bytes(int dtype, int64_t n_trees, int64_t N, size_t *partial_bytes, size_t *seg_bytes);

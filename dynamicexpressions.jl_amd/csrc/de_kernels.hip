@@ -2135,12 +2135,16 @@ static void plan_chunks(int64_t n_trees, int64_t n_tiles, int32_t *n_chunks_out,
     if (*n_chunks_out < 1) *n_chunks_out = 1;
 }
 
-void eval_plan(int dtype, int64_t n_trees, int64_t N, int32_t *tile, int32_t *n_chunks, int32_t *trees_per_chunk) {
+void eval_plan(int dtype, int64_t n_trees, int64_t N, int32_t *tile, int32_t *n_chunks, int32_t *trees_per_chunk, int waves) {
     int G, BLK;
     eval_geometry(dtype, &G, &BLK);
     if (eval_uses_threaded()) { G = tg_planes(dtype); BLK = TBLK; }
     *tile = BLK * G * (dtype == DE_F32 ? 4 : 2);
-    plan_chunks(n_trees, (N + *tile - 1) / *tile, n_chunks, trees_per_chunk);
+    plan_chunks(n_trees, (N + *tile - 1) / *tile, n_chunks, trees_per_chunk, nullptr, eval_uses_threaded() ? waves : 1);
+    if (eval_uses_threaded() && waves > 1) { // a wave group: the workgroups per sample tile, and the trees of one (they share its staged X tile)
+        *n_chunks = (*n_chunks + waves - 1) / waves;
+        *trees_per_chunk *= waves;
+    }
 }
 
 template <typename T, int G, int BLK>
@@ -2477,16 +2481,20 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     const size_t lds = row_bytes_all + (size_t)WW * DE_SKIPLIST_BYTES;
     if (WW > 1 && (lds >> 4) > HF_LIST_MASK) return hipErrorInvalidValue;
     void (*kern)(const KArgs<T>) = e.uses_params ? de_eval_threaded_kernel<T, true> : de_eval_threaded_kernel<T, false>;
-    if (WW == 2) kern = e.uses_params ? de_eval_threaded_kernel<T, true, false, 2> : de_eval_threaded_kernel<T, false, false, 2>;
-    if (WW == 4) kern = e.uses_params ? de_eval_threaded_kernel<T, true, false, 4> : de_eval_threaded_kernel<T, false, false, 4>;
+    if constexpr (TBLK == 64) { // (a build with wider tiles, -DDE_TBLK=128 for an A/B, has no wave groups: WW == 1 above)
+        if (WW == 2) kern = e.uses_params ? de_eval_threaded_kernel<T, true, false, 2> : de_eval_threaded_kernel<T, false, false, 2>;
+        if (WW == 4) kern = e.uses_params ? de_eval_threaded_kernel<T, true, false, 4> : de_eval_threaded_kernel<T, false, false, 4>;
+    }
     a.y = a.w = nullptr;
     a.partial = nullptr;
     a.loss_kind = 0;
     if (e.loss && DE_NO_LOSS) return hipErrorInvalidValue; // (a build without the loss arguments)
     if (e.loss) {
         kern = e.uses_params ? de_eval_threaded_kernel<T, true, true> : de_eval_threaded_kernel<T, false, true>;
-        if (WW == 2) kern = e.uses_params ? de_eval_threaded_kernel<T, true, true, 2> : de_eval_threaded_kernel<T, false, true, 2>;
-        if (WW == 4) kern = e.uses_params ? de_eval_threaded_kernel<T, true, true, 4> : de_eval_threaded_kernel<T, false, true, 4>;
+        if constexpr (TBLK == 64) {
+            if (WW == 2) kern = e.uses_params ? de_eval_threaded_kernel<T, true, true, 2> : de_eval_threaded_kernel<T, false, true, 2>;
+            if (WW == 4) kern = e.uses_params ? de_eval_threaded_kernel<T, true, true, 4> : de_eval_threaded_kernel<T, false, true, 4>;
+        }
         a.y = static_cast<const T *>(e.loss->y);
         a.w = static_cast<const T *>(e.loss->w);
         a.partial = static_cast<T *>(e.loss->partial);

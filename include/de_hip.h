@@ -438,7 +438,9 @@ int de_eval_tree_array(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, in
 /* ---- measurement hooks (bench.py) ------------------------------------------- */
 /* Launch plan de_eval would use for N samples: plan[0] = samples per workgroup tile,
  * plan[1] = tree chunks, plan[2] = trees per chunk (the trees that share one staged X
- * tile: the K_eff of the algorithmic-bytes formula). */
+ * tile: the K_eff of the algorithmic-bytes formula).  A program that runs
+ * in wave groups (several waves per workgroup on one tile, a chunk each): the workgroups
+ * per tile and the trees of one workgroup. */
 int de_eval_plan(const de_program_t *prog, int64_t N, int32_t *plan);
 /* 1 when an early-exit launch of n_trees trees over X[n_features, N] first runs the PRIORITY TILES (one pass over X, a probe
  * launch on the 3 F tiles with the features' extreme values, then the launch proper over the compacted live trees): the
