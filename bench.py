@@ -743,7 +743,7 @@ def main():
                                     candidates=n_cand, pop=pop_c, n=len(chosen))
 
         fwd_res = None
-        if wl.get("reverse_grad") and is_param and by_class and world == 1:
+        if wl.get("reverse_grad") and is_param and by_class and world == 1 and not args.no_complete_leg:  # (profiling runs pass --no-complete-leg: one kind of step under the profiler)
             # the same steps WITHOUT the permission: the library's default since ABI 3 — forward duals, the reference's flag semantics exactly
             # (one fused pass per class instead of one reverse launch over all classes): what parity-first costs on this workload
             pop_r = pop
