@@ -110,6 +110,9 @@ static int choose_waves(const de_program *p) {
 }
 static int make_threaded(de_ctx *c, de_program *p) {
     p->threaded = false;
+    p->waves = 1;
+    p->var_stride = 0;
+    p->ccode_w.clear();
     dbg_lap(nullptr);
     // the LDS-staged kernels need (n_features + n_slots) rows of 4112 B; wider X uses the direct variant
     p->direct = (size_t)eval_rows(p) * 257 * 16 > 150 * 1024; // (the flat-switch geometry decides)
@@ -1098,6 +1101,7 @@ uint64_t de_program_stream_hash(const de_program_t *p) {
     for (const auto &f : p->folds) { const int32_t w[3] = {f.tree, f.instr, f.tested_always ? 1 : 0}; mix(w, sizeof w); }
     const int64_t scal[6] = {p->n_trees, p->n_nodes, p->n_slots, p->uses_params ? 1 : 0, p->folded ? 1 : 0, p->threaded ? 1 : 0};
     mix(scal, sizeof scal);
+    if (!p->ccode_w.empty()) mix(p->ccode_w.data(), p->ccode_w.size() * sizeof(BoundInstr)); // the stream variants of a wave group
     if (p->aux) { const uint64_t a = de_program_stream_hash(p->aux); mix(&a, sizeof a); }
     return h;
 }
@@ -1233,25 +1237,22 @@ int de_program_verify(const de_program_t *p) {
                     if (!same_next) return bad("stream variant names another handler", t, i - i0, w);
                     if (i < i0 || i == i1) { if (std::memcmp(&r, &r0, sizeof r)) return bad("stream variant: header / end record differs", t, i - i0, w); continue; }
                     const BoundInstr &fb = p->fbcode[(size_t)i];
-                    const bool no_row = top_is_const_source(fb.bop) || fb.bop == BOP_CHECK_ACC || fb.bop == BOP_GEN_ACC || fb.bop == BOP_INJ_ACC ||
-                                        fb.bop == BOP_GEN_PARAM || (fb.bop >= BOP_UN_BASE && fb.bop < BOP_UN_END && !((fb.bop - BOP_UN_BASE) & 2)) ||
-                                        (fb.bop >= TOPX_UN_BASE && fb.bop < TOPX_BIN_BASE && ((fb.bop - TOPX_UN_BASE) & 1)) ||
-                                        (fb.bop >= TOPX_BIN_BASE && ((fb.bop - TOPX_BIN_BASE) & 1));
-                    if (no_row) { if (std::memcmp(&r, &r0, sizeof r)) return bad("stream variant: a record without a row operand differs", t, i - i0, w); continue; }
+                    if (fb.bop == BOP_GEN_PARAM) { if (std::memcmp(&r, &r0, sizeof r)) return bad("stream variant: a gathered-parameter record differs", t, i - i0, w); continue; }
+                    // the operand word: a row offset (a slot row moves by the shift, any other row stays; a record without an LDS operand
+                    // carries row 0 or no row offset at all: unchanged) | aux << 24
                     const uint64_t off0 = r0.bop & 0xFFFFFFu, off = r.bop & 0xFFFFFFu;
-                    if (off % rb != 0 || !moved((int64_t)(off0 / rb), (int64_t)(off / rb))) return bad("stream variant: operand row", t, i - i0, r.bop);
+                    if (off0 % rb != 0 || off % rb != 0) { if (off != off0) return bad("stream variant: operand word", t, i - i0, r.bop); }
+                    else if (!moved((int64_t)(off0 / rb), (int64_t)(off / rb))) return bad("stream variant: operand row", t, i - i0, r.bop);
                     const bool pushes = (fb.bop >= TOP_LOADROW_BASE && fb.bop < TOP_LOADCONST_PUSH && ((fb.bop - TOP_LOADROW_BASE) & 2)) ||
                                         (fb.bop >= TOP_UNROW_BASE && fb.bop < TOP_BINROWC_BASE && ((fb.bop - TOP_UNROW_BASE) & 2)) ||
                                         (fb.bop >= TOP_BIN2_BASE && fb.bop < TOP_COUNT && ((fb.bop - TOP_BIN2_BASE) & 1));
-                    if (pushes && !moved((int64_t)(off0 / rb) + (int8_t)(r0.bop >> 24), (int64_t)(off / rb) + (int8_t)(r.bop >> 24)))
-                        return bad("stream variant: push row of a superinstruction", t, i - i0, r.bop);
-                    if (fb.bop >= TOP_BIN2_BASE && fb.bop < TOP_COUNT && !(((fb.bop - TOP_BIN2_BASE) >> 2) & 1)) { // row-row
+                    if (pushes ? !moved((int64_t)(off0 / rb) + (int8_t)(r0.bop >> 24), (int64_t)(off / rb) + (int8_t)(r.bop >> 24)) : (r.bop >> 24) != (r0.bop >> 24))
+                        return bad("stream variant: push row / aux byte", t, i - i0, r.bop);
+                    const bool row_row = fb.bop >= TOP_BIN2_BASE && fb.bop < TOP_COUNT && !(((fb.bop - TOP_BIN2_BASE) >> 2) & 1);
+                    if (row_row || fb.bop == BOP_TERN) { // the immediate = byte distance to the second / third operand row
                         const int64_t s0 = (int64_t)off0 + (int32_t)(f32 ? r0.arg : r0.lo), s1 = (int64_t)off + (int32_t)(f32 ? r.arg : r.lo);
                         if (s1 < 0 || s1 % (int64_t)rb != 0 || !moved(s0 / (int64_t)rb, s1 / (int64_t)rb)) return bad("stream variant: second operand row", t, i - i0, (uint64_t)s1);
-                    } else if (fb.bop == BOP_TERN) {
-                        const int64_t c0 = (int64_t)off0 + (int32_t)(f32 ? r0.arg : r0.lo), c1 = (int64_t)off + (int32_t)(f32 ? r.arg : r.lo);
-                        if (c1 < 0 || c1 % (int64_t)rb != 0 || !moved(c0 / (int64_t)rb, c1 / (int64_t)rb)) return bad("stream variant: third operand row", t, i - i0, (uint64_t)c1);
-                    } else if (top_carries_const(fb.bop) ? false : (f32 ? r.arg != r0.arg : (r.lo != r0.lo || r.hi != r0.hi)))
+                    } else if (f32 ? r.arg != r0.arg : (r.lo != r0.lo || r.hi != r0.hi))
                         return bad("stream variant: immediate differs", t, i - i0, w);
                 }
             }
