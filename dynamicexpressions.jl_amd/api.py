@@ -527,9 +527,9 @@ class Population:
         return w[:int(got)].reshape(-1, 4)
 
     def meta(self, tree: int) -> dict:
-        w = np.zeros(4, dtype=np.uint32)
-        library().de_program_dump(self._h, tree, w.ctypes.data, 4, 1)
-        return dict(n_slots=int(w[0]), host_ok_eval=bool(w[1]), host_ok_grad=bool(w[2]), uses_params=bool(w[3]))
+        w = np.zeros(5, dtype=np.uint32)
+        library().de_program_dump(self._h, tree, w.ctypes.data, 5, 1)
+        return dict(n_slots=int(w[0]), host_ok_eval=bool(w[1]), host_ok_grad=bool(w[2]), uses_params=bool(w[3]), waves=int(w[4]))
 
     # -- evaluation -------------------------------------------------------------------
     def _param_args(self, params, classes, class_base, N, keep):

@@ -102,7 +102,11 @@ static int choose_waves(const de_program *p) {
     size_t have = resident(1);
     for (int W : {2, 4}) {
         const size_t w = resident(W);
-        if (have >= 20 || w * 2 < have * 3) break;
+        if (have >= 20) break;
+        if (w * 2 < have * 3) { // (many slot rows: two waves gain too little — four may still, when the workgroup is below 3 waves per SIMD)
+            if (W == 2 && have < 12) continue;
+            break;
+        }
         best = W;
         have = w;
     }
@@ -1269,7 +1273,9 @@ int64_t de_program_dump(const de_program_t *p, int64_t tree, uint32_t *words, in
         words[1] = p->host_ok_eval[(size_t)tree];
         words[2] = p->host_ok_grad[(size_t)tree];
         words[3] = p->uses_params;
-        return 4;
+        if (cap < 5) return 4;
+        words[4] = (uint32_t)(p->threaded ? p->waves : 1); // waves per workgroup of the eval kernel (wave groups: 2 / 4)
+        return 5;
     }
     if (which == 2) { // bound instructions (de_bind.h)
         const int32_t b0 = p->bcode_off[(size_t)tree], b1 = p->bcode_off[(size_t)tree + 1];

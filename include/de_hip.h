@@ -247,8 +247,10 @@ int64_t de_program_n_nodes(const de_program_t *prog);
 int64_t de_program_n_grad(const de_program_t *prog, int64_t tree, int mode);
 /* Debug/test hook: copy the lowered instruction words of tree t into `words`
  * (capacity `cap` 32-bit words); returns the number of words, or -status.
- * which: 0 generic program, 1 metadata, 2 bound program, 3 fused (superinstruction)
- * program of the threaded eval kernel (0 words when that kernel is not in use). */
+ * which: 0 generic program, 1 metadata (n_slots, host_ok_eval, host_ok_grad, uses_params and,
+ * with cap >= 5, the waves per workgroup the eval kernel runs this program with), 2 bound
+ * program, 3 fused (superinstruction) program of the threaded eval kernel (0 words when that
+ * kernel is not in use). */
 int64_t de_program_dump(const de_program_t *prog, int64_t tree, uint32_t *words, int64_t cap,
                         int which);
 

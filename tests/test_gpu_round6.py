@@ -318,6 +318,7 @@ def test_wave_groups_have_the_bits_and_flags_of_one_wave_workgroups(api, kind, d
         for ec in (api.EvalContext(), api.EvalContext(early_exit=False)):
             pop = api.Population(trees, ops, dtype, n_features=X.shape[0], n_params=P, eval_context=ec)
             pop.verify()  # (the sanitizer walks every variant of the stream)
+            assert pop.meta(0)["waves"] == (int(waves) if waves else 4)
             out, ok = pop.eval(X, **kw)
             loss, ok_l = pop.eval_loss(X, y, **kw)
             got.append((np.asarray(out), np.asarray(ok), np.asarray(loss), np.asarray(ok_l)))
@@ -340,3 +341,61 @@ def test_wave_groups_have_the_bits_and_flags_of_one_wave_workgroups(api, kind, d
             assert o[live].tobytes() == ro[live].tobytes(), f"waves {waves}: values of the complete trees"
             if l is not None:
                 assert np.array_equal(kl, rkl) and l[rkl != 0].tobytes() == rl[rkl != 0].tobytes(), f"waves {waves}: fused loss"
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("kind", ["graph", "ternary", "turbo"])
+def test_wave_groups_with_shared_rows_ternary_operators_and_turbo(api, kind, dtype, monkeypatch):
+    """The slot rows a stream variant moves are not only spill slots: a GraphNode's persistent rows (one evaluation of a shared subtree,
+    several readers), the two popped operands of a ternary operator; and `turbo` programs take the same route with their own handlers.
+    20 features make every one of these populations run four waves per workgroup: bits and flags of DE_EVAL_WAVES=1, and the oracle's
+    flags on the way."""
+    import fuzzlib as FZ
+    from test_lowering import random_graph
+    F, N = 20, 70_001
+    g = np.random.Generator(np.random.PCG64(321))
+    rng = de.synth.Xoshiro256ss(4711)
+    ec = api.EvalContext(turbo=True) if kind == "turbo" else api.EvalContext()
+    if kind == "turbo" and dtype == np.float64:
+        pytest.skip("turbo is a Float32 mode")
+    if kind == "graph":
+        ops = de.OperatorEnum(binary_operators=("+", "-", "*", "/"), unary_operators=("cos", "exp", "safe_log", "square"))
+        trees = [random_graph(rng, ops, 6 + i % 24, F, 1 + i % 4, dtype) for i in range(300)]
+        assert sum(de.flatten_graph(t, ops, dtype)[2] is not None for t in trees) > 100
+    elif kind == "ternary":
+        ops = de.OperatorEnum(unary_operators=("abs", "cos", "exp"), binary_operators=("+", "-", "*", "/"), ternary_operators=("fma", "clamp", "+", "max"))
+        trees = [FZ.gen_mixed_arity_tree(rng, ops, F, dtype, 12) for _ in range(400)]
+        trees = [t for t in trees if 3 <= de.count_nodes(t) <= 200][:300]
+        assert sum(1 for t in trees for n in de.node.postorder(t) if n.degree == 3) > 100
+    else:
+        ops = de.synth.BENCH_OPERATORS
+        trees = de.synth.random_population(300, seed=0x7B0, dtype=dtype, nfeatures=F)
+    X = np.asfortranarray((g.standard_normal((F, N)) * 1.2).astype(dtype))
+    got = {}
+    for waves in ("1", None):
+        if waves is None:
+            monkeypatch.delenv("DE_EVAL_WAVES", raising=False)
+        else:
+            monkeypatch.setenv("DE_EVAL_WAVES", waves)
+        pop = api.Population(trees, ops, dtype, n_features=F, eval_context=ec)
+        pop.verify()
+        out, ok = pop.eval(X)
+        got[waves] = (np.asarray(out), np.asarray(ok), pop.meta(0)["waves"])
+        pop.close()
+    (o1, k1, w1), (o4, k4, w4) = got["1"], got[None]
+    assert w1 == 1 and w4 in (2, 4), f"the population was meant to run in wave groups: {w1} {w4}"
+    print(f"[wave groups, {kind}] {w4} waves per workgroup")
+    assert np.array_equal(k1, k4)
+    live = k1 != 0
+    assert live.sum() > 50
+    assert o1[live].tobytes() == o4[live].tobytes()
+    if kind != "turbo":  # the flags are the oracle's (element-wise flavour) on a prefix the oracle finishes quickly
+        n = 4096
+        pop = api.Population(trees, ops, dtype, n_features=F, eval_context=ec)
+        _, kk = pop.eval(X[:, :n])
+        pop.close()
+        want = []
+        for t in trees:
+            tape, consts = de.flatten(de.break_sharing(t) if kind == "graph" else t, ops, dtype)
+            want.append(oracle.eval_tree_array(tape, consts, X[:, :n], 7, elementwise=True)[1])
+        assert np.array_equal(np.asarray(kk, dtype=bool), np.array(want, dtype=bool))
