@@ -153,6 +153,8 @@ struct de_program {
     // records as ccode but for the operand words that name a slot row), on the device `var_stride` records apart behind variant 0
     // (0: the trees use no slot — one stream serves every wave).  waves == 1: one-wave workgroups, nothing of this exists.
     int waves = 1;
+    int waves_choice = 0; // what choose_waves said when the program was created (0: not asked yet): a re-bind (de_program_set_consts under
+                          // DE_NO_CONST_PATCH) keeps it — the arena was sized for it
     int64_t var_stride = 0;
     std::vector<BoundInstr> ccode_w;
     uint64_t end_handler = 0;

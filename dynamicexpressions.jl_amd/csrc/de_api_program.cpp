@@ -191,7 +191,8 @@ static int make_threaded(de_ctx *c, de_program *p) {
     p->waves = 1;
     p->var_stride = 0;
     p->ccode_w.clear();
-    const int W = choose_waves(p);
+    if (p->waves_choice == 0) p->waves_choice = choose_waves(p);
+    const int W = p->waves_choice;
     if (W > 1 && p->n_slots > 0 && fuse) {
         const bool ee = (p->options & DE_OPT_EARLY_EXIT) != 0, f32 = p->dtype == DE_F32;
         const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
@@ -814,6 +815,7 @@ static int create_impl(de_ctx_t *ctx, int dtype, const de_tape_node_t *nodes, co
         // de_eval_tree_array) goes up in ONE copy from a zero-filled host image, a large one in one memset + three copies.
         // (wave groups: `waves` variants of the stream var_stride = cbytes / 16 records apart, and as much room again for their compacted forms)
         const size_t nvar = p->threaded && p->var_stride ? (size_t)p->waves : 1;
+        if (nvar > 1 && (size_t)p->var_stride * sizeof(BoundInstr) != cbytes) return fail(ctx, DE_ERR_HIP, "wave-group stream variants: stride and arena disagree");
         const size_t abytes = p->threaded ? 2 * nvar * cbytes : cbytes;
         auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
         const size_t off_bytes = p->bcode_off.size() * sizeof(int32_t);
