@@ -136,7 +136,7 @@ int de_eval_loss(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int64_t
     if (!c || !p) return DE_ERR_INVALID_ARG;
     if (N < 0 || !ok || (p->n_trees > 0 && (!loss || (N > 0 && (!X || !y))))) return fail(c, DE_ERR_INVALID_ARG, "null buffer");
     if (loss_kind != DE_LOSS_L2 && loss_kind != DE_LOSS_L1) return fail(c, DE_ERR_INVALID_ARG, "unknown loss_kind %d", loss_kind);
-    if (p->direct || !p->threaded)
+    if (!p->threaded)
         return fail(c, DE_ERR_UNSUPPORTED, "de_eval_loss needs the LDS-tiled kernel (feature matrix too wide for this build)");
     const LossReq lr{y, w, loss_kind, loss};
     DE_NOTHROW(c, eval_impl(c, p, X, N, ldX, pa, nullptr, N, ok, &lr));
@@ -169,7 +169,7 @@ static int eval_impl(de_ctx_t *c, de_program_t *p, const void *X, int64_t N, int
         }
         return DE_OK;
     }
-    const bool direct = p->direct;
+    const bool direct = p->direct && !(p->threaded && !cr); // (the threaded kernel stages a wider X than the flat-switch kernel can: de_api_program.cpp make_threaded)
 
     Staged sX, sOut, sOk, sPar, sCls, sY, sW, sLoss;
     LossArgs la;

@@ -119,8 +119,12 @@ static int make_threaded(de_ctx *c, de_program *p) {
     p->ccode_w.clear();
     dbg_lap(nullptr);
     // the LDS-staged kernels need (n_features + n_slots) rows of 4112 B; wider X uses the direct variant
-    p->direct = (size_t)eval_rows(p) * 257 * 16 > 150 * 1024; // (the flat-switch geometry decides)
-    if (p->direct || !eval_uses_threaded()) return DE_OK;
+    p->direct = (size_t)eval_rows(p) * 257 * 16 > 150 * 1024; // (the flat-switch kernel's geometry: 256 threads x 16 bytes per row; it gathers the features of a wider X from global memory)
+    // the threaded kernel's rows are a quarter of that (one wave's 64 vectors): it stages X up to ~140 rows — and shares them among the
+    // waves of a wave group (round 6: F = 36 ... 120 ran the gathering flat-switch kernel, 14 - 20 ms per 10^6 samples x 1000 trees)
+    // (a program the flat-switch kernel would gather for takes the threaded kernel while a group of FOUR waves fits: one wave per CU
+    // would be no better than the gathers)
+    if ((p->direct && ((size_t)eval_rows(p) + 3 * (size_t)p->n_slots) * trow_bytes(p->dtype) + 4 * 256 > 150 * 1024) || !eval_uses_threaded()) return DE_OK;
     if (eval_rows(p) > 4000) return DE_OK; // row offsets must fit 24 bits
     uint64_t table[TOPX_TABLE];
     hipError_t st = eval_handler_table(p->dtype, (p->options & DE_OPT_TURBO) != 0, table);

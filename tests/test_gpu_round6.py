@@ -399,3 +399,40 @@ def test_wave_groups_with_shared_rows_ternary_operators_and_turbo(api, kind, dty
             tape, consts = de.flatten(de.break_sharing(t) if kind == "graph" else t, ops, dtype)
             want.append(oracle.eval_tree_array(tape, consts, X[:, :n], 7, elementwise=True)[1])
         assert np.array_equal(np.asarray(kk, dtype=bool), np.array(want, dtype=bool))
+
+
+@pytest.mark.parametrize("F", [40, 60, 120])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_wide_feature_matrices_run_the_threaded_kernel_in_wave_groups(api, dtype, F):
+    """Up to round 6 a feature matrix of more than 35 rows went to the flat-switch kernel's `direct` variant (features gathered from global
+    memory: 14 - 20 ms per 10^6 samples x 1000 trees against 1.4 ms at 30 features).  The threaded kernel's rows are a quarter as long and a
+    wave group shares them: it stages X up to ~140 rows.  Parity with the oracle (values by the tolerance model, flags exactly), the fused
+    loss — refused for such programs before — against the values, and the same bits under DE_EVAL_WAVES=1."""
+    from test_gpu_eval import compare_population
+    ops = de.synth.BENCH_OPERATORS
+    trees = de.synth.random_population(120, seed=0xF00 + F, dtype=dtype, nfeatures=F)
+    g = np.random.Generator(np.random.PCG64(F))
+    X = np.asfortranarray((g.standard_normal((F, 2500)) * 1.3).astype(dtype))
+    for ec in (api.EvalContext(), api.EvalContext(early_exit=False)):
+        compare_population(api, trees, ops, X, dtype, eval_context=ec, min_ok=30, label=f"wide X, F = {F}, ee={ec.early_exit}")
+    pop = api.Population(trees, ops, dtype, n_features=F)
+    out, ok = pop.eval(X)
+    assert pop.ctx.last_kernel_name() == "de_eval_threaded_kernel" and pop.meta(0)["waves"] == 4, (pop.ctx.last_kernel_name(), pop.meta(0))
+    y = g.standard_normal(X.shape[1]).astype(dtype)
+    loss, ok_l = pop.eval_loss(X, y)
+    assert np.array_equal(np.asarray(ok_l), np.asarray(ok))
+    live = np.asarray(ok, dtype=bool)
+    want = ((np.asarray(out)[live].astype(np.float64) - y.astype(np.float64)) ** 2).sum(axis=1)
+    got = np.asarray(loss)[live].astype(np.float64)
+    inr = want < (1e36 if dtype == np.float32 else 1e300)  # (a square beyond the element type's range is Inf on the device, finite in this Float64 sum)
+    assert inr.sum() > 20
+    np.testing.assert_allclose(got[inr], want[inr], rtol=2e-4 if dtype == np.float32 else 1e-11)
+    pop.close()
+    os.environ["DE_EVAL_WAVES"] = "1"
+    try:
+        pop1 = api.Population(trees, ops, dtype, n_features=F)
+        out1, ok1 = pop1.eval(X)
+        pop1.close()
+    finally:
+        del os.environ["DE_EVAL_WAVES"]
+    assert np.array_equal(np.asarray(ok1), np.asarray(ok)) and np.asarray(out1)[live].tobytes() == np.asarray(out)[live].tobytes()
