@@ -87,20 +87,22 @@ static void make_chained(de_program *p);
 // Waves per workgroup of the threaded eval kernel (de_api_internal.h `waves`).  A one-wave workgroup keeps F rows of X, S spill-slot rows
 // and (parametric) P staged parameter rows in LDS: at F = 5, S = 2 that is 21 resident waves per CU (5.25 per SIMD; the kernel's registers
 // allow 28) and more buys nothing (measured: W = 2 +1 %, W = 4 +6 % on the headline) — but 8 parameter rows leave 10 waves, 20 features 7, 30
-// features 4.  W waves share X and the parameter rows: W is doubled (1 -> 2 -> 4) while the workgroup is below 20 resident waves per CU and
+// features 4.  W waves share X and the parameter rows: W is doubled (1 -> 2 -> 4 -> 8) while the workgroup is below 20 resident waves per CU and
 // the step raises them by half or more.  Measured, 10^6 samples x 1000 trees: 8 per-sample parameters 1.35 -> 0.92 ms, F = 12 1.29 -> 0.97,
-// F = 20 2.06 -> 1.08, F = 30 3.10 -> 1.22 (profiles/r6_wave_groups.txt).  DE_EVAL_WAVES = 1 | 2 | 4 overrides (1 = the kernel of rounds 1-5).
+// F = 20 2.06 -> 1.08, F = 30 3.10 -> 1.22 (profiles/r6_wave_groups.txt).  DE_EVAL_WAVES = 1 | 2 | 4 | 8 overrides (1 = the kernel of rounds 1-5).
 static int choose_waves(const de_program *p) {
     if (TBLK != 64 || (p->uses_params && !p->prows)) return 1; // (gathered parameters: the class row is per wave)
-    if (const char *e = getenv("DE_EVAL_WAVES")) { const int v = atoi(e); return (v == 2 || v == 4) ? v : 1; }
+    if (const char *e = getenv("DE_EVAL_WAVES")) { const int v = atoi(e); return (v == 2 || v == 4 || v == 8) ? v : 1; }
     const size_t rb = trow_bytes(p->dtype), lds_cu = 160u << 10, shared = (size_t)p->n_features + (p->prows ? (size_t)p->n_params : 0);
     auto resident = [&](int W) -> size_t {
         const size_t lds = (shared + (size_t)W * (size_t)p->n_slots) * rb + (size_t)W * 256;
-        return lds > 150u * 1024 ? 0 : std::min<size_t>((lds_cu / lds) * (size_t)W, 28); // (28: 7 waves per SIMD by the kernel's vector registers)
+        // (7 waves per SIMD by the kernel's vector registers; a group of W >= 4 waves puts W / 4 on every SIMD)
+        const size_t by_regs = W >= 4 ? 7 / ((size_t)W / 4) : 28 / (size_t)W;
+        return lds > 150u * 1024 ? 0 : std::min<size_t>(lds_cu / lds, by_regs) * (size_t)W;
     };
     int best = 1;
     size_t have = resident(1);
-    for (int W : {2, 4}) {
+    for (int W : {2, 4, 8}) {
         const size_t w = resident(W);
         if (have >= 20) break;
         if (w * 2 < have * 3) { // (many slot rows: two waves gain too little — four may still, when the workgroup is below 3 waves per SIMD)
@@ -142,9 +144,14 @@ static int make_threaded(de_ctx *c, de_program *p) {
     // superinstructions (de_bind.h): fewer dispatches for the same arithmetic
     const char *nf = getenv("DE_NO_FUSE");
     const bool fuse = !(nf && *nf == '1');
+    // wave groups (below): the waves per workgroup, and how far the last variant of the stream moves the slot rows — a fusion must fit all
+    if (p->waves_choice == 0) p->waves_choice = choose_waves(p);
+    const int W = fuse ? p->waves_choice : 1;
+    const int wave_prows = p->prows ? p->n_params : 0;
+    const FuseRows rows0{(uint32_t)p->n_features, (uint32_t)(p->n_features + p->n_slots), 0, W > 1 ? wave_prows + (W - 1) * p->n_slots : 0};
     build_stream_by_trees<BoundInstr>(p->n_trees, &p->fbcode, &p->tcode_off, [&](int64_t t, std::vector<BoundInstr> *out) {
         const int32_t b0 = p->bcode_off[(size_t)t], b1 = p->bcode_off[(size_t)t + 1];
-        if (fuse) fuse_tree(p->bcode.data() + b0, (size_t)(b1 - b0), out);
+        if (fuse) fuse_tree(p->bcode.data() + b0, (size_t)(b1 - b0), out, W > 1 && p->n_slots > 0 ? &rows0 : nullptr);
         else out->insert(out->end(), p->bcode.begin() + b0, p->bcode.begin() + b1);
     });
     dbg_lap("fuse_tree");
@@ -195,19 +202,18 @@ static int make_threaded(de_ctx *c, de_program *p) {
     p->waves = 1;
     p->var_stride = 0;
     p->ccode_w.clear();
-    if (p->waves_choice == 0) p->waves_choice = choose_waves(p);
-    const int W = p->waves_choice;
     if (W > 1 && p->n_slots > 0 && fuse) {
         const bool ee = (p->options & DE_OPT_EARLY_EXIT) != 0, f32 = p->dtype == DE_F32;
         const std::vector<Instr> &src = p->folded ? p->fcode : p->code;
         const std::vector<int32_t> &off = p->folded ? p->fcode_off : p->code_off;
-        const int prb = p->prows ? p->n_features + p->n_slots : -1, n_prows = p->prows ? p->n_params : 0;
+        const int prb = p->prows ? p->n_features + p->n_slots : -1, n_prows = wave_prows;
         const size_t n_rec = p->ccode.size();
         p->ccode_w.resize(n_rec * (size_t)(W - 1));
         std::atomic<bool> same{true};
         for (int w = 1; w < W; w++) {
             BoundInstr *cw = p->ccode_w.data() + n_rec * (size_t)(w - 1);
             const int shift = n_prows + w * p->n_slots; // [X | slots of wave 0 | parameter rows | slots of wave 1 | ...]: slot s of wave w = row F + S + P + (w - 1) S + s
+            const FuseRows rows_w{(uint32_t)(p->n_features + shift), (uint32_t)(p->n_features + shift + p->n_slots), shift, rows0.headroom};
             parallel_tree_ranges(p->n_trees, [&](int, int64_t tb, int64_t te) {
                 std::vector<BoundInstr> b, f;
                 // (the records of trees tb .. te - 1 behind the header in front of tree tb, which is tree tb - 1's end record: disjoint ranges)
@@ -217,7 +223,7 @@ static int make_threaded(de_ctx *c, de_program *p) {
                     b.clear();
                     f.clear();
                     bind_tree(src.data() + off[(size_t)t], (size_t)(off[(size_t)t + 1] - off[(size_t)t]), ee, p->n_features, &b, prb, shift);
-                    fuse_tree(b.data(), b.size(), &f);
+                    fuse_tree(b.data(), b.size(), &f, &rows_w);
                     const int32_t i0 = p->tcode_off[(size_t)t], i1 = p->tcode_off[(size_t)t + 1];
                     if ((int32_t)f.size() != i1 - i0) { same = false; return; }
                     const size_t h = (size_t)p->ccode_off[(size_t)t];

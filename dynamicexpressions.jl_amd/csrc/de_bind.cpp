@@ -107,9 +107,15 @@ int mirrored(int k) {
     default: return k; // ADD, MUL
     }
 }
-bool delta_ok(uint32_t a, uint32_t b) {
-    const int64_t d = (int64_t)b - (int64_t)a;
-    return d >= -127 && d <= 127;
+bool delta_ok(uint32_t a, uint32_t b, const FuseRows *fr = nullptr) {
+    int64_t d = (int64_t)b - (int64_t)a, lo = -127, hi = 127;
+    if (fr) { // the distance in variant 0, and the range every variant's distance stays in
+        const bool sa = a >= fr->slot_lo && a < fr->slot_hi, sb = b >= fr->slot_lo && b < fr->slot_hi;
+        d -= (int64_t)fr->shift * ((sb ? 1 : 0) - (sa ? 1 : 0));
+        if (sb && !sa) hi -= fr->headroom;
+        if (sa && !sb) lo += fr->headroom;
+    }
+    return d >= lo && d <= hi;
 }
 uint32_t with_delta(uint32_t rowA, bool push, uint32_t push_row) {
     const int32_t d = push ? (int32_t)push_row - (int32_t)rowA : 0;
@@ -122,7 +128,7 @@ bool top_is_const_source(uint32_t top) {
     return top == TOP_LOADCONST_PUSH; // TOP_BIN2 row-const keeps row A in arg
 }
 
-void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out) {
+void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out, const FuseRows *fr) {
     size_t i = 0;
     while (i < n) {
         size_t j = i;
@@ -134,8 +140,8 @@ void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out) {
             const BoundInstr &m = b[j];
             const uint32_t row = m.arg & 0xFFFFFFu;
             HotBin hb;
-            if (m.bop == BOP_LOAD_ROW && (!chk || chk_row == row) && (!push || delta_ok(row, push_row))) {
-                if (!chk && j + 1 < n && hot_bin_of(b[j + 1], &hb) && (hb.cst || delta_ok(row, b[j + 1].arg & 0xFFFFFFu))) {
+            if (m.bop == BOP_LOAD_ROW && (!chk || chk_row == row) && (!push || delta_ok(row, push_row, fr))) {
+                if (!chk && j + 1 < n && hot_bin_of(b[j + 1], &hb) && (hb.cst || delta_ok(row, b[j + 1].arg & 0xFFFFFFu, fr))) {
                     const BoundInstr &nb = b[j + 1];
                     BoundInstr f = nb;
                     f.bop = top_bin2(hb.k, hb.cst, hb.out, push);
@@ -153,7 +159,7 @@ void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out) {
                 continue;
             }
             if (m.bop == BOP_LOAD_CONST && push && !chk) {
-                if (j + 1 < n && hot_bin_of(b[j + 1], &hb) && !hb.cst && delta_ok(b[j + 1].arg & 0xFFFFFFu, push_row)) {
+                if (j + 1 < n && hot_bin_of(b[j + 1], &hb) && !hb.cst && delta_ok(b[j + 1].arg & 0xFFFFFFu, push_row, fr)) {
                     const uint32_t rowA = b[j + 1].arg & 0xFFFFFFu;
                     BoundInstr f = m; // keeps the constant's bits
                     f.bop = top_bin2(mirrored(hb.k), true, hb.out, true);
@@ -170,7 +176,7 @@ void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out) {
                 continue;
             }
             if (m.bop >= BOP_UN_BASE && m.bop < BOP_UN_END && ((m.bop - BOP_UN_BASE) & 2) && (!chk || chk_row == row) &&
-                (!push || delta_ok(row, push_row))) {
+                (!push || delta_ok(row, push_row, fr))) {
                 const uint32_t v = m.bop - BOP_UN_BASE;
                 BoundInstr f = m;
                 f.bop = top_unrow((int)(v >> 2), (v & 1) != 0, push, chk);
@@ -192,7 +198,7 @@ void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out) {
             HotBin hb;
             if (j + 1 < n && hot_bin_of(b[j + 1], &hb)) {
                 const BoundInstr &nb = b[j + 1];
-                if (m.bop == BOP_LOAD_ROW && (hb.cst || delta_ok(m.arg & 0xFFFFFFu, nb.arg & 0xFFFFFFu))) {
+                if (m.bop == BOP_LOAD_ROW && (hb.cst || delta_ok(m.arg & 0xFFFFFFu, nb.arg & 0xFFFFFFu, fr))) {
                     const uint32_t row = m.arg & 0xFFFFFFu;
                     BoundInstr f = nb;
                     f.bop = top_bin2(hb.k, hb.cst, hb.out, false);

@@ -220,7 +220,11 @@ inline bool top_carries_const(uint32_t top) {
 }
 
 // Fused form of one tree's bound instructions (appended to `out`).
-void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out);
+// `rows` (wave groups, de_api_program.cpp make_threaded): the tree's spill-slot rows are [slot_lo, slot_hi) in THIS stream variant, `shift`
+// rows behind their place in variant 0, and no variant moves them by more than `headroom` rows: a fusion whose int8 row distance would not
+// fit in EVERY variant is not made in any — the variants of a stream differ in operand words only.  Null: one stream, the plain +-127 rule.
+struct FuseRows { uint32_t slot_lo, slot_hi; int32_t shift, headroom; };
+void fuse_tree(const BoundInstr *b, size_t n, std::vector<BoundInstr> *out, const FuseRows *rows = nullptr);
 // True when the fused instruction's operand is an inline constant (arg carries no operand row).
 bool top_is_const_source(uint32_t top);
 

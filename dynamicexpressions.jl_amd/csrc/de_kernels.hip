@@ -2400,7 +2400,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     if (!env_int("DE_X_VEC", 1)) { a.x_vec = 0; a.f_magic = 0; } // scalar staging loop (A/B and the test of the vector path)
     if (env_int("DE_DEBUG_NO_STORE", 0)) a.vec_store = 2;
     // wave groups (KArgs::var_stride): parametric programs with staged parameter rows whose stream exists in e.waves variants
-    const int WW = (TBLK == 64 && (e.waves == 2 || e.waves == 4) && (!e.uses_params || e.n_prows > 0)) ? e.waves : 1;
+    const int WW = (TBLK == 64 && (e.waves == 2 || e.waves == 4 || e.waves == 8) && (!e.uses_params || e.n_prows > 0)) ? e.waves : 1;
     a.var_stride = WW > 1 ? e.var_stride : 0;
     int32_t tpc, nch, nc0;
     plan_chunks(e.n_trees, a.n_tiles, &nch, &tpc, &nc0, WW);
@@ -2484,6 +2484,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
     if constexpr (TBLK == 64) { // (a build with wider tiles, -DDE_TBLK=128 for an A/B, has no wave groups: WW == 1 above)
         if (WW == 2) kern = e.uses_params ? de_eval_threaded_kernel<T, true, false, 2> : de_eval_threaded_kernel<T, false, false, 2>;
         if (WW == 4) kern = e.uses_params ? de_eval_threaded_kernel<T, true, false, 4> : de_eval_threaded_kernel<T, false, false, 4>;
+        if (WW == 8) kern = e.uses_params ? de_eval_threaded_kernel<T, true, false, 8> : de_eval_threaded_kernel<T, false, false, 8>;
     }
     a.y = a.w = nullptr;
     a.partial = nullptr;
@@ -2494,6 +2495,7 @@ static hipError_t launch_threaded_t(const EvalArgs &e, hipStream_t stream, const
         if constexpr (TBLK == 64) {
             if (WW == 2) kern = e.uses_params ? de_eval_threaded_kernel<T, true, true, 2> : de_eval_threaded_kernel<T, false, true, 2>;
             if (WW == 4) kern = e.uses_params ? de_eval_threaded_kernel<T, true, true, 4> : de_eval_threaded_kernel<T, false, true, 4>;
+            if (WW == 8) kern = e.uses_params ? de_eval_threaded_kernel<T, true, true, 8> : de_eval_threaded_kernel<T, false, true, 8>;
         }
         a.y = static_cast<const T *>(e.loss->y);
         a.w = static_cast<const T *>(e.loss->w);
