@@ -147,7 +147,7 @@ struct de_program {
     std::vector<BoundInstr> ccode;
     std::vector<int32_t> ccode_off;     // n_trees + 1: first record of each tree
     // WAVE GROUPS (round 6; de_kernels.hip KArgs::var_stride; de_api_program.cpp choose_waves): a program whose one-wave workgroup is short of
-    // resident waves (staged parameter rows, many features) runs `waves` (2 / 4) waves per workgroup on one sample tile — X and the
+    // resident waves (staged parameter rows, many features) runs `waves` (2 / 4 / 8) waves per workgroup on one sample tile — X and the
     // parameter rows staged once, every wave a chunk and spill-slot rows of its own.  Slot rows
     // are host data, so the chained stream exists once per wave: ccode_w = variants 1 .. waves - 1 (each ccode.size() records; the same
     // records as ccode but for the operand words that name a slot row), on the device `var_stride` records apart behind variant 0

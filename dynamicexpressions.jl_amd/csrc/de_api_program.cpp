@@ -1286,7 +1286,7 @@ int64_t de_program_dump(const de_program_t *p, int64_t tree, uint32_t *words, in
         words[2] = p->host_ok_grad[(size_t)tree];
         words[3] = p->uses_params;
         if (cap < 5) return 4;
-        words[4] = (uint32_t)(p->threaded ? p->waves : 1); // waves per workgroup of the eval kernel (wave groups: 2 / 4)
+        words[4] = (uint32_t)(p->threaded ? p->waves : 1); // waves per workgroup of the eval kernel (wave groups: 2 / 4 / 8)
         return 5;
     }
     if (which == 2) { // bound instructions (de_bind.h)

@@ -7,7 +7,7 @@
 //  * grid  = sample tiles x tree chunks.  The threaded kernel (the default): a workgroup is ONE wave64 (DE_TBLK = 64) that owns
 //    TILE = 256 consecutive Float32 samples (4 per lane; 128 Float64) and runs a chunk of <= 63 trees as ONE chain of
 //    direct-threaded handlers — or, when LDS rows leave such a workgroup short of resident waves (staged parameter rows, many features),
-//    a WAVE GROUP of 2 / 4 waves on one tile that share the staged rows and run a chunk each (KArgs::var_stride, round 6);
+//    a WAVE GROUP of 2 / 4 / 8 waves on one tile that share the staged rows and run a chunk each (KArgs::var_stride, round 6);
 //    the flat-switch fall-back kernel uses 256 threads = 4 wave64 and G vectors per thread.
 //    Large early-exit launches are three launches: the priority tiles as a probe, the compaction of the live trees
 //    (de_compact_live_kernel), the launch proper over the re-linked stream.
