@@ -43,6 +43,8 @@ static int ensure_generic_code(de_ctx *c, de_program *p) {
 static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::vector<int32_t> &ng, int64_t N, GradArgs *g) {
     g->threaded_code = nullptr;
     g->n_buckets = 0;
+    g->gt_share = false;
+    g->gt_var_stride = 0;
     const char *env = getenv("DE_GRAD_THREADED");
     if (env && *env == '0') return DE_OK;
     const int F = p->n_features, P = p->n_params;
@@ -73,6 +75,13 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         // measured in round 6 (tools/experiments/sweep_vs2_rows.sh, same box): C5 7.98 / 7.82 / 7.81 / 8.06 / 8.42 ms and C5Ng 7.30 / 7.06 / 7.14 /
         // 7.40 / 7.66 ms at 15 / 18 / 20 / 22 / 24 rows — two samples per lane pay a little further out when most rows are shared inputs
         const int vs2_rows = env2 ? atoi(env2) : (p->uses_params ? 18 : 15);
+        // SHARED LEAF ROWS (GradArgs::gt_share): with many leaf rows most of a wave's LDS is a copy of inputs the other three waves could
+        // read as well — the four waves then take different trees on the same samples.  Measured (round 6, constant-mode Jacobians of 1000
+        // trees x 10^5 samples, tools/experiments/wide_x_grad.py): F = 5 0.80 -> 0.86 ms (worse: the staging is spread over fewer samples),
+        // F = 20 1.14 -> 1.03, F = 40 1.82 -> 1.05, F = 60 2.58 -> 1.18, F = 120 5.82 -> 1.91; 5 features + 8 parameter rows (C5): 7.42 -> 7.35 ms,
+        // nothing — those kernels are not short of resident waves.  From 16 leaf rows on; DE_GRAD_SHARE = 0 | 1 overrides.
+        const char *envs = getenv("DE_GRAD_SHARE"), *envf = getenv("DE_GRAD_SHARE_MIN_ROWS");
+        const bool share = envs ? *envs == '1' : FE >= (envf ? atoi(envf) : 16);
         std::vector<int32_t> tslots((size_t)p->n_trees, 0); // spill slots of each tree (rows >= F the code names)
         parallel_for_trees(p->n_trees, [&](int64_t t) {
             int32_t need = 0;
@@ -121,7 +130,8 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             const int GC = WIDTH[b % NW], VS = 1 + b / NW;
             const uint64_t RBb = 64ull * VS * es32; // one wave's row
             const uint64_t rows = (uint64_t)FE + std::max<uint64_t>((uint64_t)slots[b] * (1 + GC), (uint64_t)GC);
-            if (4 * rows * RBb > 160 * 1024) return DE_OK; // four waves' rows must fit the CU's LDS
+            const uint64_t srows = std::max<uint64_t>((uint64_t)slots[b] * (1 + GC), (uint64_t)GC);
+            if ((share ? ((uint64_t)FE + 4 * srows) : 4 * rows) * RBb > 160 * 1024) return DE_OK; // four waves' rows must fit the CU's LDS
             hipError_t st = grad_handler_table(p->dtype, GC, VS, tables[b].data());
             if (st != hipSuccess) return fail(c, DE_ERR_HIP, "gradient handler table: %s", hipGetErrorString(st));
             uint64_t base = tables[b][0];
@@ -142,11 +152,15 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         std::atomic<bool> ok{true};
         // encoded per worker into a vector of its own (sites = positions in that vector), concatenated afterwards
         std::vector<BoundInstr> parts[HOST_RANGES_MAX];
+        // ... and per record what a stream variant of the shared-leaf-row launch adds the wave's slot bytes to: 0 nothing, 1 the operand
+        // word (a slot operand, a push, the spilled operands of a ternary operator), 2 the immediate (push + load of a leaf: row -> slot distance)
+        std::vector<uint8_t> kparts[HOST_RANGES_MAX];
         std::vector<int32_t> tree_cnt((size_t)p->n_trees, 0);
         int64_t part_first[HOST_RANGES_MAX], part_last[HOST_RANGES_MAX];
         for (int k = 0; k < HOST_RANGES_MAX; k++) part_first[k] = part_last[k] = 0;
         parallel_tree_ranges(p->n_trees, [&](int wk, int64_t tb, int64_t te) {
         std::vector<BoundInstr> &out = parts[wk];
+        std::vector<uint8_t> &kout = kparts[wk];
         part_first[wk] = tb;
         part_last[wk] = te;
         for (int64_t t = tb; t < te && ok; t++) {
@@ -218,6 +232,7 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                     if (!ok) break;
                     o.bop = (uint32_t)(table[gop_pushload(GC, src, sv)] - base);
                     out.push_back(o);
+                    kout.push_back(b2.bop == BOP_LOAD_CONST ? 1 : 2);
                     i++; // the LOAD is part of this instruction
                     continue;
                 }
@@ -248,11 +263,13 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                     o.bop = (uint32_t)(table[gop_load(GC, src, sv)] - base);
                     p->gtsite_of_gb[(size_t)i] = (int32_t)out.size();
                     out.push_back(o);
+                    kout.push_back(0);
                     BoundInstr u = b;
                     u.arg = 0;
                     u.lo = u.hi = 0;
                     u.bop = (uint32_t)(table[gop_un(GC, gun_of(aux), GSRC_ACC, 0, false)] - base);
                     out.push_back(u);
+                    kout.push_back(0);
                     continue;
                 }
                 else if (b.bop == BOP_GEN_CONST) { const_operand(b.arg & 0xFFFFu, aux << 16, true); gop = gop_gen(GC, GSRC_CONST); }
@@ -286,9 +303,11 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
                 o.bop = (uint32_t)(table[gop] - base);
                 p->gtsite_of_gb[(size_t)i] = (int32_t)out.size();
                 out.push_back(o);
+                kout.push_back((src == GSRC_SLOT || b.bop == BOP_PUSH || b.bop == BOP_TERN) ? 1 : 0);
             }
             // the end record: every tree's chain finishes in g_end (the table slot of round 1's parameter handler)
             out.push_back(BoundInstr{(uint32_t)(table[gop_param(GC)] - base), 0u, 0u, 0u});
+            kout.push_back(0);
             tree_cnt[(size_t)t] = (int32_t)(out.size() - out_before);
         }
         });
@@ -322,6 +341,31 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             p->gtcode[(size_t)b0 - 1].bop = first;
         });
         dbg_lap("grad threaded: successor words");
+        p->gt_share = false;
+        p->gt_stride = 0;
+        if (share) { // the stream variants of waves 1 .. 3: the same records with the wave's slot bytes added where a record names a slot
+            const size_t n0 = p->gtcode.size();
+            std::vector<uint8_t> kinds(n0, 0);
+            parallel_tree_ranges(p->n_trees, [&](int k, int64_t tb, int64_t) {
+                if (!kparts[k].empty()) std::memcpy(kinds.data() + p->gtcode_off[(size_t)tb], kparts[k].data(), kparts[k].size());
+            });
+            p->gtcode.resize(4 * n0);
+            parallel_for_trees(p->n_trees, [&](int64_t t) {
+                const int bkt = bucket_of(t), GC = WIDTH[bkt % NW];
+                const uint32_t RB = 64u * (uint32_t)(1 + bkt / NW) * es32;
+                const uint32_t sbytes = (uint32_t)std::max<int64_t>((int64_t)slots[bkt] * (1 + GC), (int64_t)GC) * RB; // one wave's slot area
+                for (int32_t i = p->gtcode_off[(size_t)t]; i < p->gtcode_off[(size_t)t + 1]; i++)
+                    for (uint32_t w = 1; w < 4; w++) {
+                        BoundInstr r = p->gtcode[(size_t)i];
+                        if (kinds[(size_t)i] == 1) r.arg += w * sbytes; // (the low 24 bits: an LDS offset < 2^18)
+                        else if (kinds[(size_t)i] == 2) r.lo += w * sbytes;
+                        p->gtcode[(size_t)w * n0 + (size_t)i] = r;
+                    }
+            });
+            p->gt_share = true;
+            p->gt_stride = (int64_t)n0;
+            dbg_lap("grad threaded: stream variants (shared leaf rows)");
+        }
         std::vector<int32_t> ids((size_t)p->n_trees);
         int32_t start[NB], run = 0;
         for (int b = 0; b < NB; b++) { start[b] = run; run += count[b]; }
@@ -330,10 +374,18 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
             for (int b = 0; b < NB; b++) fill[b] = start[b];
             for (int64_t t = 0; t < p->n_trees; t++) ids[(size_t)fill[bucket_of(t)]++] = (int32_t)t;
         }
+        // a unary operator on a constant leaf becomes two instructions: at most twice the bound program
+        // ... plus one end record per tree and one of padding (every handler reads the record behind its own)
+        const size_t gt_cap = (2 * p->gbcode.size() + (size_t)p->n_trees + 1) * (share ? 4 : 1);
+        if (p->d_gtcode && p->gt_cap < gt_cap) { // (DE_GRAD_SHARE switched between two encodings of one program: tests)
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            prog_free(c, p->d_gtcode);
+            p->d_gtcode = nullptr;
+            if (p->d_gtcode_off) { (void)hipFree(p->d_gtcode_off); p->d_gtcode_off = nullptr; }
+            if (p->d_gt_ids) { (void)hipFree(p->d_gt_ids); p->d_gt_ids = nullptr; }
+        }
         if (!p->d_gtcode) {
-            // a unary operator on a constant leaf becomes two instructions: at most twice the bound program
-            // ... plus one end record per tree and one of padding (every handler reads the record behind its own)
-            const size_t gt_cap = 2 * p->gbcode.size() + (size_t)p->n_trees + 1;
+            p->gt_cap = gt_cap;
             // (inside one 4 GiB window: the handlers bump the record pointer without a carry; a straddling allocation is set aside and redone)
             {
                 const hipError_t ast = prog_malloc(c, reinterpret_cast<void **>(&p->d_gtcode), gt_cap * sizeof(BoundInstr));
@@ -370,6 +422,8 @@ static int ensure_grad_threaded(de_ctx *c, de_program *p, int mode, const std::v
         p->gt_valid = true;
     }
     g->threaded_code = p->d_gtcode;
+    g->gt_share = p->gt_share;
+    g->gt_var_stride = p->gt_stride;
     g->e.code_off = p->d_gtcode_off;
     g->n_buckets = p->gt_n_buckets;
     for (int b = 0; b < p->gt_n_buckets; b++) g->buckets[b] = p->gt_buckets[b];

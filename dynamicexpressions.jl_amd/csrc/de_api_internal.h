@@ -220,6 +220,9 @@ struct de_program {
     uint32_t rt_param_off = 0;
     int gt_mode = -1;
     bool gt_valid = false, gt_wide = false;
+    bool gt_share = false;        // the threaded gradient program exists in four variants (GradArgs::gt_share), gt_stride records apart in gtcode
+    int64_t gt_stride = 0;
+    size_t gt_cap = 0;            // records d_gtcode has room for
     int gt_n_buckets = 0;
     GradArgs::Bucket gt_buckets[24];
 };

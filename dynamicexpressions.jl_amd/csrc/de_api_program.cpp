@@ -970,8 +970,10 @@ static int set_consts_impl(de_program_t *p, const void *consts) {
                     p->gbcode[(size_t)g.gb].lo = lo;
                     p->gbcode[(size_t)g.gb].hi = hi;
                     if (tpatch && g.gt >= 0) {
-                        p->gtcode[(size_t)g.gt].lo = lo;
-                        p->gtcode[(size_t)g.gt].hi = hi;
+                        for (int64_t w = 0; w < (p->gt_share ? 4 : 1); w++) { // (every stream variant of a shared-leaf-row program)
+                            p->gtcode[(size_t)(g.gt + w * p->gt_stride)].lo = lo;
+                            p->gtcode[(size_t)(g.gt + w * p->gt_stride)].hi = hi;
+                        }
                     }
                     if (rpatch && g.rt >= 0) {
                         p->rtcode[(size_t)g.rt].lo = lo;

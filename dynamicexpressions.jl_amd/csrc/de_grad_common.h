@@ -55,6 +55,10 @@ template <typename T> struct GArgs {
     // (prio[k] & 0xFFFFFFFF) >> prio_shift first; null / 0: none
     const unsigned long long *prio;
     uint32_t n_prio, n_prio_blocks, prio_shift;
+    // de_grad_threaded.hip, SHARED LEAF ROWS (de_kernels.h GradArgs::gt_share): a workgroup = four waves on the same 64 x VS samples, wave w
+    // runs every fourth tree of the chunk through stream variant w (var_stride records apart); tiles are 64 x VS samples
+    int32_t share;
+    int64_t var_stride;
 };
 
 constexpr int GPTAB_MAX = 2048;

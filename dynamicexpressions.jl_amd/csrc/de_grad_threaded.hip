@@ -365,14 +365,14 @@ template <typename T, int GC> __global__ void de_grad_fill_handlers(uint64_t *t)
 // (taking the address of the kernel-argument struct would make every load from it look divergent): nothing
 // of the epilogue stays live in VGPRs across the handler calls of the interpreter loop.
 template <typename T, int GC>
-__device__ __noinline__ void g_epilogue_loss(GState<T, GC> st, const T *y, const T *w, T *pp, int64_t N, int loss_mode, int G, int g0, int64_t tile) {
-    constexpr int TILE = GBLK * VS;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t base = tile * TILE, last = N - 1;
+__device__ __noinline__ void g_epilogue_loss(GState<T, GC> st, const T *y, const T *w, T *pp, int64_t N, int loss_mode, int G, int g0, int64_t j0) {
+    // j0 = the first of this WAVE's 64 x VS samples; pp = this wave's entry of the partial sums of (tile, tree): [1 + n_grad][4 waves]
+    const int lane = threadIdx.x & 63;
+    const int64_t last = N - 1;
     T l = T(0);
     LV(T) lp, wv;
     DE_UNROLL for (int i = 0; i < VS; i++) {
-        const int64_t j = base + (int64_t)tid * VS + i;
+        const int64_t j = j0 + (int64_t)lane * VS + i;
         const int64_t jj = j < last ? j : last;
         const T yv = y[jj];
         wv[i] = j <= last ? (w ? w[jj] : T(1)) : T(0);
@@ -384,7 +384,6 @@ __device__ __noinline__ void g_epilogue_loss(GState<T, GC> st, const T *y, const
         if (wv[i] == T(0)) { li = T(0); lp[i] = T(0); } // weight 0 (and samples past N) really excludes the sample
         l += li;
     }
-    pp += wave; // pp = partial sums of this (tile, tree): [1 + n_grad][4 waves]
     if (g0 == 0) {
         const T s = wave_sum_to_lane63(l);
         if (lane == 63) pp[0] = s;
@@ -409,20 +408,20 @@ __device__ __noinline__ void g_epilogue_loss(GState<T, GC> st, const T *y, const
 #define DE_G_STORE(PTR, VAL) (*(PTR) = (VAL))
 #endif
 template <typename T, int GC>
-__device__ __noinline__ void g_epilogue_store(GState<T, GC> st, T *out_row, T *grad_tree, int64_t N, int G, int g0, int64_t tile, uint32_t stage0) {
-    constexpr int TILE = GBLK * VS, WSAMP = 64 * VS;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int64_t base = tile * TILE, last = N - 1;
+__device__ __noinline__ void g_epilogue_store(GState<T, GC> st, T *out_row, T *grad_tree, int64_t N, int G, int g0, int64_t j0, uint32_t stage0) {
+    // j0 = the first of this WAVE's 64 x VS samples; stage0 = LDS address of the wave's slot area
+    constexpr int WSAMP = 64 * VS;
+    const int lane = threadIdx.x & 63;
+    const int64_t last = N - 1;
     if (G <= GC) {
         // One window: the wave's gradient block — WSAMP samples x G rows, gradient index fastest
         // (src/EvaluateDerivative.jl:355-361) — is WSAMP*G contiguous elements in memory.  Transpose it
         // through the wave's (now idle) slot rows and write it with 16-byte stores; per-lane stores
         // would each touch 4 of every 4*G*VS bytes.
         DE_UNROLL for (int i = 0; i < VS; i++) {
-            const int64_t j = base + (int64_t)tid * VS + i;
+            const int64_t j = j0 + (int64_t)lane * VS + i;
             if (j <= last && out_row) DE_G_STORE(out_row + j, (T)st.x[i]);
         }
-        const int64_t j0 = base + (int64_t)wave * WSAMP;         // first sample of this wave
         const int64_t n_valid = N - j0 < WSAMP ? N - j0 : WSAMP; // samples of this wave inside N (may be <= 0)
         if (G > 0 && n_valid > 0) {
             DE_UNROLL for (int i = 0; i < VS; i++)
@@ -443,7 +442,7 @@ __device__ __noinline__ void g_epilogue_store(GState<T, GC> st, T *out_row, T *g
         }
     } else { // several windows: every window owns a few rows of the block — direct stores
         DE_UNROLL for (int i = 0; i < VS; i++) {
-            const int64_t j = base + (int64_t)tid * VS + i;
+            const int64_t j = j0 + (int64_t)lane * VS + i;
             if (j <= last) {
                 if (out_row && g0 == 0) out_row[j] = st.x[i];
                 T *__restrict__ gp = grad_tree + (int64_t)G * j + g0;
@@ -466,12 +465,35 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
     if (!tm.valid) return;
     const int flag_protocol = tm.prio ? 1 : a.skip_flagged;
     const int tid = threadIdx.x;
-    const int64_t base = tm.tile * TILE;
+    // SHARED LEAF ROWS (GArgs::share): the tile is one wave's 64 x VS samples, staged once for the four waves — rows [0, F) —, behind them
+    // every wave's slot rows; wave w runs trees t0 + w, t0 + w + 4, ... of the chunk through stream variant w
+    const bool share = a.share != 0;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t base = tm.tile * (share ? WSAMP : TILE);
     const int64_t last = a.N - 1;
     const int g0 = (int)blockIdx.y * GC; // first gradient component of this window
     const int F = a.F;
     const int slot_rows = a.n_slots * (1 + GC) > GC ? a.n_slots * (1 + GC) : GC;
     const int R = F + slot_rows; // rows per wave
+    if (share) {
+        const uint32_t Fu = (uint32_t)a.FX, total = (uint32_t)WSAMP * Fu;
+        for (uint32_t e = tid; e < total; e += GBLK) {
+            const uint32_t j = e / Fu, f = e - j * Fu;
+            int64_t jj = base + j;
+            jj = jj < last ? jj : last;
+            rows[f * WSAMP + j] = a.X[f + a.ldX * jj];
+        }
+        if (PARAMS) {
+            const uint32_t Pu = (uint32_t)(F - a.FX), totalp = (uint32_t)WSAMP * Pu;
+            for (uint32_t e = tid; e < totalp; e += GBLK) {
+                const uint32_t j = e / Pu, q = e - j * Pu;
+                int64_t jj = base + j;
+                jj = jj < last ? jj : last;
+                const int64_t cl = clamp_class((a.classes_is_i64 ? reinterpret_cast<const int64_t *>(a.classes)[jj] : (int64_t) reinterpret_cast<const int32_t *>(a.classes)[jj]) - a.class_base, a.n_classes);
+                rows[((uint32_t)a.FX + q) * WSAMP + j] = a.params[q + a.ld_params * cl];
+            }
+        }
+    } else {
     {
         const uint32_t Fu = (uint32_t)a.FX;
         const uint32_t total = (uint32_t)TILE * Fu;
@@ -492,22 +514,27 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
             rows[((j / WSAMP) * (uint32_t)R + (uint32_t)a.FX + q) * WSAMP + (j % WSAMP)] = a.params[q + a.ld_params * cl];
         }
     }
+    } // one copy of the leaf rows per wave
     __syncthreads();
 
-    const ConstU4Ptr code = (ConstU4Ptr)(uintptr_t)a.code;
+    const ConstU4Ptr code = (ConstU4Ptr)(uintptr_t)(a.code + (share ? (int64_t)wave * a.var_stride : (int64_t)0));
     const ConstI32Ptr code_off = (ConstI32Ptr)(uintptr_t)a.code_off;
     const ConstI64Ptr col_off = (ConstI64Ptr)(uintptr_t)a.col_off;
     const ConstI64Ptr grad_off = (ConstI64Ptr)(uintptr_t)a.grad_off;
     const ConstI32Ptr n_grad = (ConstI32Ptr)(uintptr_t)a.n_grad;
     const int t0 = tm.chunk * a.trees_per_chunk;
     const int t1 = (t0 + a.trees_per_chunk < a.n_trees) ? t0 + a.trees_per_chunk : a.n_trees;
-    const uint32_t wave_base = (uint32_t)(uintptr_t)gtsmem + (uint32_t)((tid >> 6) * R) * grow_bytes<T>();
+    const uint32_t wave_base = (uint32_t)(uintptr_t)gtsmem + (share ? 0u : (uint32_t)(wave * R) * grow_bytes<T>());
     const uint32_t lds0 = wave_base + (uint32_t)(tid & 63) * (uint32_t)(VS * sizeof(T));
-    const uint32_t stage0 = wave_base + (uint32_t)F * grow_bytes<T>(); // the wave's slot area, free between trees
+    const uint32_t stage0 = wave_base + (uint32_t)(F + (share ? wave * slot_rows : 0)) * grow_bytes<T>(); // the wave's slot area, free between trees
+    const int64_t j0 = share ? base : base + (int64_t)wave * WSAMP; // the first of this wave's samples
+    // this wave's entry of a (tile, tree) pair's partial sums [1 + n_grad][4 waves]: a shared-row tile is a quarter of a 4-wave tile
+    const int64_t ptile = share ? (int64_t)tm.tile >> 2 : (int64_t)tm.tile;
+    const int pwave = share ? (int)((int64_t)tm.tile & 3) : wave;
 
     const ConstI32Ptr tree_ids = (ConstI32Ptr)(uintptr_t)a.tree_ids;
     const uint64_t skip = gskip_mask(a.ok, tree_ids, t0, t1, flag_protocol, (int64_t)tm.tile);
-    for (int ti = t0; ti < t1; ++ti) {
+    for (int ti = share ? t0 + wave : t0; ti < t1; ti += share ? 4 : 1) {
         if ((skip >> (ti - t0)) & 1ull) continue; // already incomplete (early exit)
         const int tree = tree_ids[ti];
         const int G = n_grad[tree];
@@ -535,9 +562,9 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
         DE_UNROLL for (int k = 0; k < GC; k++) gpoison<T>(poison, g0 + k < G ? st.d[k] : lv_splat<T>(T(0)));
         if (a.loss_mode) {
             const int64_t n_cols = col_off[a.n_all_trees];
-            g_epilogue_loss<T, GC>(st, a.y, a.w, a.partial + ((int64_t)tm.tile * n_cols + col_off[tree]) * 4, a.N, a.loss_mode, G, g0, (int64_t)tm.tile);
+            g_epilogue_loss<T, GC>(st, a.y, a.w, a.partial + (ptile * n_cols + col_off[tree]) * 4 + pwave, a.N, a.loss_mode, G, g0, j0);
         } else {
-            g_epilogue_store<T, GC>(st, a.out ? a.out + (int64_t)tree * a.ld_out : nullptr, a.grad + grad_off[tree], a.N, G, g0, (int64_t)tm.tile, stage0);
+            g_epilogue_store<T, GC>(st, a.out ? a.out + (int64_t)tree * a.ld_out : nullptr, a.grad + grad_off[tree], a.N, G, g0, j0, stage0);
         }
         if (__ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree, flag_protocol == 1);
     }
@@ -580,7 +607,13 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStrea
     a.ldX = e.ldX;
     a.ld_out = e.ld_out;
     a.ld_params = e.ld_params;
-    a.n_tiles = (e.N + GBLK * VS - 1) / (GBLK * VS);
+    const bool share = ga.gt_share;
+    a.share = share ? 1 : 0;
+    a.var_stride = share ? ga.gt_var_stride : 0;
+    const int tile_samples = share ? 64 * VS : GBLK * VS;
+    // (shared rows: whole groups of four tiles — a fused-loss launch must write every (tile of 256 x VS samples, wave) entry of the partial
+    // sums, also the all-padding quarter tiles behind N, as the four-wave workgroup did)
+    a.n_tiles = share ? 4 * ((e.N + GBLK * VS - 1) / (GBLK * VS)) : (e.N + tile_samples - 1) / tile_samples;
     a.FX = e.F;
     a.F = e.F + (e.uses_params ? ga.P : 0); // leaf rows: X, then the parameters gathered by class
     a.P = ga.P;
@@ -628,10 +661,10 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStrea
     int64_t blocks = ((a.n_tiles + 7) / 8) * 8 * a.n_chunks;
     a.prio = nullptr;
     a.n_prio = a.n_prio_blocks = a.prio_shift = 0;
-    if (a.skip_flagged && ga.prio_ready) blocks += gprio_setup(a, e.prio_keys, e.F, GBLK * VS);
+    if (a.skip_flagged && ga.prio_ready) blocks += gprio_setup(a, e.prio_keys, e.F, tile_samples);
     if (blocks <= 0 || blocks > 0x7fffffffLL || windows > 65535) return hipErrorInvalidValue;
     const size_t slot_rows = std::max<size_t>((size_t)a.n_slots * (1 + GC), (size_t)GC);
-    const size_t lds = 4 * ((size_t)a.F + slot_rows) * 64 * VS * sizeof(T); // 4 waves x rows x one wave's samples
+    const size_t lds = (share ? (size_t)a.F + 4 * slot_rows : 4 * ((size_t)a.F + slot_rows)) * 64 * VS * sizeof(T); // 4 waves x rows x one wave's samples (shared leaf rows: once)
     void (*kern)(const GArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_grad_threaded_kernel<T, GC, true> : de_grad_threaded_kernel<T, GC, false>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return hipErrorInvalidValue;

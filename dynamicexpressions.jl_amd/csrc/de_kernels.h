@@ -141,6 +141,11 @@ struct GradArgs {
     uint64_t rev_handler_base;
     uint32_t rev_param_off;
     bool prio_ready;  // e.prio_keys holds this launch's priority tiles (launch_grad_threaded / launch_rev_threaded run the pre-pass)
+    // SHARED LEAF ROWS (round 6; de_grad_threaded.hip): the four waves of a workgroup run DIFFERENT trees on the SAME 64 x VS samples — X and
+    // the parameter rows are staged once per workgroup instead of once per wave; every wave keeps slot rows of its own, so the stream
+    // exists in four variants gt_var_stride records apart (variant w: slot offsets + w x the bucket's slot bytes)
+    bool gt_share;
+    int64_t gt_var_stride;
     int32_t n_buckets;
     struct Bucket {
         int32_t GC, VS;                // module: window width, samples per lane

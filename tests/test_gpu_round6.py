@@ -436,3 +436,53 @@ def test_wide_feature_matrices_run_the_threaded_kernel_in_wave_groups(api, dtype
     finally:
         del os.environ["DE_EVAL_WAVES"]
     assert np.array_equal(np.asarray(ok1), np.asarray(ok)) and np.asarray(out1)[live].tobytes() == np.asarray(out)[live].tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+def test_gradient_kernels_share_the_leaf_rows_of_a_wide_feature_matrix(api, dtype, monkeypatch):
+    """From 16 leaf rows on the four waves of a forward-dual workgroup run different trees on the SAME samples: X is staged once per workgroup
+    instead of once per wave, every wave keeps its own slot rows and reads the stream variant that names them (csrc/de_api_grad.cpp
+    ensure_grad_threaded, GradArgs::gt_share).  Jacobians, fused losses and loss gradients have the bits of one copy per wave
+    (DE_GRAD_SHARE=0) — one and two samples per lane, a ragged last tile, new constants —, the parametric case too when forced; and the
+    Jacobians stay inside the oracle's bounds."""
+    from test_gpu_grad import grad_compare
+    ops = de.synth.BENCH_OPERATORS
+    g = np.random.Generator(np.random.PCG64(2718))
+
+    def run(trees, F, P, N, share, new_consts=False):
+        monkeypatch.setenv("DE_GRAD_SHARE", share)
+        X = np.asfortranarray((np.random.Generator(np.random.PCG64(N)).standard_normal((F, N)) * 1.3).astype(dtype))
+        y = np.cos(np.arange(N)).astype(dtype)
+        gg = np.random.Generator(np.random.PCG64(N + 1))
+        kw = dict(params=np.asfortranarray((gg.standard_normal((P, 7)) * 2).astype(dtype)), classes=gg.integers(1, 8, N).astype(np.int64)) if P else {}
+        pop = api.Population(trees, ops, dtype, n_features=F, n_params=P)
+        res = []
+        for variable in ((False, "both") if P else (False, True)):
+            out, grads, ok = pop.eval_grad(X, variable=variable, **kw)
+            res.append((np.asarray(ok), [np.asarray(a) for a in grads], np.asarray(out)))
+            l, dl, okl = pop.eval_loss_grad(X, y, variable=variable, **kw)
+            res.append((np.asarray(okl), [np.asarray(a) for a in dl], np.asarray(l)))
+        if new_consts:  # (the immediates of every variant are patched in place)
+            consts = np.concatenate([de.flatten(t, ops, dtype)[1] for t in trees]).astype(dtype)
+            pop.set_constants(consts * dtype(0.75) + dtype(0.25))
+            l, dl, okl = pop.eval_loss_grad(X, y, variable=False, **kw)
+            res.append((np.asarray(okl), [np.asarray(a) for a in dl], np.asarray(l)))
+        pop.close()
+        return res
+
+    cases = [("wide X", de.synth.random_population(200, seed=0x51A, dtype=dtype, nfeatures=24), 24, 0),
+             ("parametric", de.synth.random_population(200, seed=0x51B, dtype=dtype, node_type=de.ParametricNode, nparams=8), 5, 8)]
+    for name, trees, F, P in cases:
+        for N in (70_001, 777):  # two samples per lane (Float32, >= 65536 samples) and one; ragged last tiles
+            a, b = run(trees, F, P, N, "0", new_consts=True), run(trees, F, P, N, "1", new_consts=True)
+            assert len(a) == len(b) == 5
+            for (k0, g0, o0), (k1, g1, o1) in zip(a, b):
+                assert np.array_equal(k0, k1), f"{name} N={N}: flags"
+                live = k0 != 0
+                assert live.sum() > 50
+                assert o0[live].tobytes() == o1[live].tobytes(), f"{name} N={N}: values / losses"
+                assert all(x.tobytes() == y_.tobytes() for x, y_, l in zip(g0, g1, live) if l), f"{name} N={N}: gradient rows"
+    monkeypatch.delenv("DE_GRAD_SHARE")  # the rule: 24 leaf rows share
+    X = np.asfortranarray((g.standard_normal((24, 1500)) * 1.2).astype(dtype))
+    for mode in ("constant", "variable"):
+        assert grad_compare(api, cases[0][1][:80], ops, X, dtype, mode) > 20
