@@ -364,15 +364,17 @@ template <typename T, int GC> __global__ void de_grad_fill_handlers(uint64_t *t)
 // End of a tree: store (or reduce) the wave's results.  Out of line on purpose, and fed with plain values
 // (taking the address of the kernel-argument struct would make every load from it look divergent): nothing
 // of the epilogue stays live in VGPRs across the handler calls of the interpreter loop.
-template <typename T, int GC>
-__device__ __noinline__ void g_epilogue_loss(GState<T, GC> st, const T *y, const T *w, T *pp, int64_t N, int loss_mode, int G, int g0, int64_t j0) {
-    // j0 = the first of this WAVE's 64 x VS samples; pp = this wave's entry of the partial sums of (tile, tree): [1 + n_grad][4 waves]
-    const int lane = threadIdx.x & 63;
-    const int64_t last = N - 1;
+template <typename T, int GC, bool SHARE>
+__device__ __noinline__ void g_epilogue_loss(GState<T, GC> st, const T *y, const T *w, T *pp, int64_t N, int loss_mode, int G, int g0, int64_t tile) {
+    // pp = the partial sums of the (tile of 256 x VS samples, tree) pair this wave's samples belong to: [1 + n_grad][4 waves]
+    // (shared leaf rows: `tile` counts 64 x VS samples — a quarter of such a tile, entry tile & 3 of its four)
+    constexpr int TILE = GBLK * VS, WSAMP = 64 * VS;
+    const int tid = threadIdx.x, wave = SHARE ? (int)(tile & 3) : tid >> 6, lane = tid & 63;
+    const int64_t jl = SHARE ? tile * WSAMP + (int64_t)lane * VS : tile * TILE + (int64_t)tid * VS, last = N - 1; // this lane's first sample
     T l = T(0);
     LV(T) lp, wv;
     DE_UNROLL for (int i = 0; i < VS; i++) {
-        const int64_t j = j0 + (int64_t)lane * VS + i;
+        const int64_t j = jl + i;
         const int64_t jj = j < last ? j : last;
         const T yv = y[jj];
         wv[i] = j <= last ? (w ? w[jj] : T(1)) : T(0);
@@ -384,6 +386,7 @@ __device__ __noinline__ void g_epilogue_loss(GState<T, GC> st, const T *y, const
         if (wv[i] == T(0)) { li = T(0); lp[i] = T(0); } // weight 0 (and samples past N) really excludes the sample
         l += li;
     }
+    pp += wave;
     if (g0 == 0) {
         const T s = wave_sum_to_lane63(l);
         if (lane == 63) pp[0] = s;
@@ -407,21 +410,22 @@ __device__ __noinline__ void g_epilogue_loss(GState<T, GC> st, const T *y, const
 #else
 #define DE_G_STORE(PTR, VAL) (*(PTR) = (VAL))
 #endif
-template <typename T, int GC>
-__device__ __noinline__ void g_epilogue_store(GState<T, GC> st, T *out_row, T *grad_tree, int64_t N, int G, int g0, int64_t j0, uint32_t stage0) {
-    // j0 = the first of this WAVE's 64 x VS samples; stage0 = LDS address of the wave's slot area
-    constexpr int WSAMP = 64 * VS;
-    const int lane = threadIdx.x & 63;
-    const int64_t last = N - 1;
+template <typename T, int GC, bool SHARE>
+__device__ __noinline__ void g_epilogue_store(GState<T, GC> st, T *out_row, T *grad_tree, int64_t N, int G, int g0, int64_t tile, uint32_t stage0) {
+    // stage0 = LDS address of the wave's slot area; `tile` counts 64 x VS samples under shared leaf rows, 256 x VS otherwise
+    constexpr int TILE = GBLK * VS, WSAMP = 64 * VS;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t jl = SHARE ? tile * WSAMP + (int64_t)lane * VS : tile * TILE + (int64_t)tid * VS, last = N - 1; // this lane's first sample
     if (G <= GC) {
         // One window: the wave's gradient block — WSAMP samples x G rows, gradient index fastest
         // (src/EvaluateDerivative.jl:355-361) — is WSAMP*G contiguous elements in memory.  Transpose it
         // through the wave's (now idle) slot rows and write it with 16-byte stores; per-lane stores
         // would each touch 4 of every 4*G*VS bytes.
         DE_UNROLL for (int i = 0; i < VS; i++) {
-            const int64_t j = j0 + (int64_t)lane * VS + i;
+            const int64_t j = jl + i;
             if (j <= last && out_row) DE_G_STORE(out_row + j, (T)st.x[i]);
         }
+        const int64_t j0 = SHARE ? tile * WSAMP : tile * TILE + (int64_t)wave * WSAMP; // first sample of this wave
         const int64_t n_valid = N - j0 < WSAMP ? N - j0 : WSAMP; // samples of this wave inside N (may be <= 0)
         if (G > 0 && n_valid > 0) {
             DE_UNROLL for (int i = 0; i < VS; i++)
@@ -442,7 +446,7 @@ __device__ __noinline__ void g_epilogue_store(GState<T, GC> st, T *out_row, T *g
         }
     } else { // several windows: every window owns a few rows of the block — direct stores
         DE_UNROLL for (int i = 0; i < VS; i++) {
-            const int64_t j = j0 + (int64_t)lane * VS + i;
+            const int64_t j = jl + i;
             if (j <= last) {
                 if (out_row && g0 == 0) out_row[j] = st.x[i];
                 T *__restrict__ gp = grad_tree + (int64_t)G * j + g0;
@@ -455,7 +459,7 @@ __device__ __noinline__ void g_epilogue_store(GState<T, GC> st, T *out_row, T *g
 
 // VS consecutive samples per thread; wave-major LDS: per wave, rows [0,F) = its slice of the X tile, then each
 // spill slot s owns 1+GC rows (x, d[0..GC)); at least GC rows follow the X rows (output staging).
-template <typename T, int GC, bool PARAMS>
+template <typename T, int GC, bool PARAMS, bool SHARE = false>
 __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a, const uint64_t hbase, const uint32_t param_off) {
     constexpr int TILE = GBLK * VS, WSAMP = 64 * VS; // samples per workgroup / per wave
     extern __shared__ __align__(16) unsigned char gtsmem[];
@@ -467,8 +471,8 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
     const int tid = threadIdx.x;
     // SHARED LEAF ROWS (GArgs::share): the tile is one wave's 64 x VS samples, staged once for the four waves — rows [0, F) —, behind them
     // every wave's slot rows; wave w runs trees t0 + w, t0 + w + 4, ... of the chunk through stream variant w
-    const bool share = a.share != 0;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr bool share = SHARE; // (a template parameter: the per-wave-copy kernel keeps the code it had)
+    const int wave = share ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int64_t base = tm.tile * (share ? WSAMP : TILE);
     const int64_t last = a.N - 1;
     const int g0 = (int)blockIdx.y * GC; // first gradient component of this window
@@ -527,10 +531,7 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
     const uint32_t wave_base = (uint32_t)(uintptr_t)gtsmem + (share ? 0u : (uint32_t)(wave * R) * grow_bytes<T>());
     const uint32_t lds0 = wave_base + (uint32_t)(tid & 63) * (uint32_t)(VS * sizeof(T));
     const uint32_t stage0 = wave_base + (uint32_t)(F + (share ? wave * slot_rows : 0)) * grow_bytes<T>(); // the wave's slot area, free between trees
-    const int64_t j0 = share ? base : base + (int64_t)wave * WSAMP; // the first of this wave's samples
-    // this wave's entry of a (tile, tree) pair's partial sums [1 + n_grad][4 waves]: a shared-row tile is a quarter of a 4-wave tile
-    const int64_t ptile = share ? (int64_t)tm.tile >> 2 : (int64_t)tm.tile;
-    const int pwave = share ? (int)((int64_t)tm.tile & 3) : wave;
+    const int64_t ptile = share ? (int64_t)tm.tile >> 2 : (int64_t)tm.tile; // (the tile of 256 x VS samples the partial sums are kept by)
 
     const ConstI32Ptr tree_ids = (ConstI32Ptr)(uintptr_t)a.tree_ids;
     const uint64_t skip = gskip_mask(a.ok, tree_ids, t0, t1, flag_protocol, (int64_t)tm.tile);
@@ -562,9 +563,9 @@ __global__ void __launch_bounds__(GBLK) de_grad_threaded_kernel(const GArgs<T> a
         DE_UNROLL for (int k = 0; k < GC; k++) gpoison<T>(poison, g0 + k < G ? st.d[k] : lv_splat<T>(T(0)));
         if (a.loss_mode) {
             const int64_t n_cols = col_off[a.n_all_trees];
-            g_epilogue_loss<T, GC>(st, a.y, a.w, a.partial + (ptile * n_cols + col_off[tree]) * 4 + pwave, a.N, a.loss_mode, G, g0, j0);
+            g_epilogue_loss<T, GC, SHARE>(st, a.y, a.w, a.partial + (ptile * n_cols + col_off[tree]) * 4, a.N, a.loss_mode, G, g0, (int64_t)tm.tile);
         } else {
-            g_epilogue_store<T, GC>(st, a.out ? a.out + (int64_t)tree * a.ld_out : nullptr, a.grad + grad_off[tree], a.N, G, g0, j0, stage0);
+            g_epilogue_store<T, GC, SHARE>(st, a.out ? a.out + (int64_t)tree * a.ld_out : nullptr, a.grad + grad_off[tree], a.N, G, g0, (int64_t)tm.tile, stage0);
         }
         if (__ballot(poison != poison) != 0ull) gflag_incomplete(a.ok + tree, flag_protocol == 1);
     }
@@ -666,6 +667,7 @@ hipError_t DE_GT_NAME(grad_thr_launch_)(const GradArgs &ga, int bucket, hipStrea
     const size_t slot_rows = std::max<size_t>((size_t)a.n_slots * (1 + GC), (size_t)GC);
     const size_t lds = (share ? (size_t)a.F + 4 * slot_rows : 4 * ((size_t)a.F + slot_rows)) * 64 * VS * sizeof(T); // 4 waves x rows x one wave's samples (shared leaf rows: once)
     void (*kern)(const GArgs<T>, uint64_t, uint32_t) = e.uses_params ? de_grad_threaded_kernel<T, GC, true> : de_grad_threaded_kernel<T, GC, false>;
+    if (share) kern = e.uses_params ? de_grad_threaded_kernel<T, GC, true, true> : de_grad_threaded_kernel<T, GC, false, true>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return hipErrorInvalidValue;
         hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
