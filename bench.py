@@ -313,6 +313,38 @@ def valu_measured(pm_entry):
                        "issue costs of profiles/r2_valu_rate.json; half-rate share from profiles/valu_static_mix.json")
 
 
+def wide_x_leg(ctx, lib, ops, device, F=60, n_trees=1000, N=10**6, steps=10):
+    """A feature matrix the flat-switch kernel could not stage (F = 60: its `direct` variant gathered the features from global memory, 14.3 ms
+    at this shape up to round 5): the threaded kernel in wave groups.  Not a BASELINE config: reported beside them."""
+    import dynamicexpressions_jl_amd as de
+    from dynamicexpressions_jl_amd import api
+    trees = de.synth.random_population(n_trees, seed=0xDE02 + F, nfeatures=F)
+    g = torch.Generator(device=device)
+    g.manual_seed(F)
+    X = (torch.randn((N, F), generator=g, device=device, dtype=torch.float32) * 1.2).t()  # [F, N] feature-fastest
+    out = torch.empty((n_trees, N), device=device, dtype=torch.float32)
+    ok = torch.empty(n_trees, device=device, dtype=torch.uint8)
+    pop = api.Population(trees, ops, np.float32, n_features=F, ctx=ctx)
+    t_end = time.perf_counter() + 0.08
+    while time.perf_counter() < t_end:  # steady clocks (see the `configs` legs)
+        ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, F, None, out.data_ptr(), N, ok.data_ptr()))
+        ctx.synchronize()
+    ctx.timing_ring(steps)
+    for _ in range(steps):
+        ctx.check(lib.de_eval(ctx._h, pop._h, X.data_ptr(), N, F, None, out.data_ptr(), N, ok.data_ptr()))
+    ctx.synchronize()
+    ms = float(np.mean([t for t in ctx.timing_read() if t is not None]))
+    ctx.timing_ring(0)
+    okh = ok.cpu().numpy().astype(bool)
+    nodes = np.array([de.count_nodes(t) for t in trees], dtype=np.int64)
+    res = {"workload": f"{n_trees} random 20-node trees over {F} features x {N} samples, Float32 (not a BASELINE config)", "ms_per_step": ms, "steps": steps,
+           "value": float(nodes[okh].sum()) * N / (ms * 1e-3), "value_all_trees": float(nodes.sum()) * N / (ms * 1e-3), "unit": "node-evals/s",
+           "complete_fraction": float(okh.mean()), "kernel": ctx.last_kernel_name(), "waves_per_workgroup": pop.meta(0)["waves"],
+           "rounds_1_5": "de_eval_tape_kernel<direct> (features gathered from global memory): 14.3 ms at this shape (DESIGN.md §4.1)"}
+    pop.close()
+    return res
+
+
 def search_generation_leg(ctx, lib, ops, X, n_trees=10000, rows=1000):
     """de_program_create / de_eval / de_program_destroy of n_trees FRESH trees on `rows` samples through the C ABI."""
     import ctypes as C
@@ -1006,6 +1038,15 @@ def main():
                 if kk in r:
                     c[kk] = r[kk]
             res["configs"][k] = c
+        # ... and one shape outside BASELINE.json that changed by an order of magnitude in round 6: a 60-feature dataset (last: it leaves the
+        # configs' memory and clocks alone)
+        x_cache.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            res["wide_x"] = wide_x_leg(ctx, api.library(), de.synth.BENCH_OPERATORS, "cuda")
+        except Exception as e:  # noqa: BLE001
+            res["wide_x"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
